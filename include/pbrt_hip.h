@@ -1,0 +1,173 @@
+/*
+ * pbrt_hip.h — C ABI of the MI355X-native (gfx950) wavefront path tracer that replaces the hot path of
+ * hackmad/pbrt-v3-rs:  SamplerIntegrator::render -> PathIntegrator::li -> BVHAccel::intersect/intersect_p ->
+ * Triangle::intersect/intersect_p.
+ *
+ * Every entry point below names the reference interface it replaces (path:line relative to the reference repo).
+ * Plain C types only: pointers + sizes, caller-allocated outputs, int status codes.  No callbacks, no C++ or
+ * torch types, no exceptions across the boundary.  A handle is NOT re-entrant (one in-flight call per handle);
+ * one handle drives exactly one GPU (one process per GPU; multi-GPU = one handle per rank + a film-tile gather
+ * done by the host with RCCL).
+ *
+ * Inputs are borrowed for the duration of the call and copied.  All floats are IEEE binary32 ("Float = f32",
+ * core/src/pbrt/common.rs:13).  Matrices are row-major float[16], m[r*4+c] (core/src/geometry/matrix4x4.rs:13).
+ */
+#ifndef PBRT_HIP_H
+#define PBRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PbrtHipScene PbrtHipScene;
+
+/* ---- status codes (reference behaviour on the same conditions is panic!/error!) ------------- */
+enum {
+    PBRT_HIP_OK = 0,
+    PBRT_HIP_ERR_INVALID_ARG = -1,  /* NULL handle, bad sizes, out-of-range ids                                  */
+    PBRT_HIP_ERR_STATE = -2,        /* call order violated (render before build_accel, no camera, ...)           */
+    PBRT_HIP_ERR_DEVICE = -3,       /* a HIP call failed; pbrt_hip_last_error() holds hipGetErrorString()        */
+    PBRT_HIP_ERR_NO_DEVICE = -4,    /* no gfx950 device visible: the product path never falls back to the CPU    */
+    PBRT_HIP_ERR_UNSUPPORTED = -5,  /* feature outside the hot-path scope (SURVEY §8 "next"/"out of scope")      */
+    PBRT_HIP_ERR_OOM = -6
+};
+
+/* 32-byte ray = core/src/geometry/ray.rs:10-28 without differentials/medium (dead on this path). */
+typedef struct PbrtHipRay {
+    float o[3];
+    float t_max;
+    float d[3];
+    float time;
+} PbrtHipRay;
+
+/* 32-byte closest-hit record: what Primitive::intersect (core/src/primitive.rs:22) hands back, reduced to the
+ * ray-dependent quantities of Triangle::intersect (shapes/src/triangle.rs:438-545): t, barycentrics and the
+ * primitive.  prim = index into the concatenation of all meshes' triangles in pbrt_hip_add_mesh order
+ * (= position in the reference's `primitives: &[ArcPrimitive]` before BVH reordering); 0xFFFFFFFF on a miss. */
+typedef struct PbrtHipHit {
+    float t;
+    uint32_t prim;
+    float b0, b1, b2;
+    uint32_t pad[3];
+} PbrtHipHit;
+
+/* Counters with the reference's own names (core/src/scene.rs:13-23, core/src/integrator/sampler_integrator.rs:19-23).
+ * Mrays/s := (regular_rays + shadow_rays) / render seconds. */
+typedef struct PbrtHipStats {
+    uint64_t camera_rays;        /* "Integrator/Camera rays traced"                         */
+    uint64_t regular_rays;       /* "Intersections/Regular ray intersection tests"          */
+    uint64_t shadow_rays;        /* "Intersections/Shadow ray intersection tests"           */
+    uint64_t paths_zero_radiance;/* "Integrator/Zero-radiance paths" numerator (path.rs:168) */
+    uint64_t paths_total;        /* its denominator (path.rs:164)                            */
+    double render_seconds;       /* device time of the render phase (HIP events)             */
+    double extend_seconds;       /* of which: closest-hit traversal kernels                  */
+    double shadow_seconds;       /* of which: any-hit traversal kernels                      */
+    double shade_seconds;        /* of which: raygen + shade + film kernels                  */
+} PbrtHipStats;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------- */
+int pbrt_hip_device_count(void);                          /* <0 on HIP failure */
+PbrtHipScene* pbrt_hip_scene_create(int device_ordinal);  /* NULL if no usable device */
+void pbrt_hip_scene_destroy(PbrtHipScene*);
+const char* pbrt_hip_last_error(const PbrtHipScene*);     /* NUL-terminated, owned by the library; NULL handle -> global */
+
+/* ---- scene capture (replaces the string factories, api/src/graphics_state.rs:254-720) -------------------- */
+
+/* MatteMaterial with constant textures (materials/src/matte.rs:47-92). sigma in degrees, clamped to [0,90]. */
+int pbrt_hip_add_material_matte(PbrtHipScene*, const float kd_rgb[3], float sigma_deg, uint32_t* out_id);
+
+/* TriangleMesh (shapes/src/triangle.rs:75-113): P/N/S must ALREADY be in world space exactly as TriangleMesh::new
+ * leaves them (:93-99).  N, S, UV may be NULL.  One GeometricPrimitive per triangle (api/src/lib.rs:783-812).
+ * first_area_light_id: -1, or the id returned by pbrt_hip_add_light_diffuse_area for the SAME n_tris (triangle k
+ * is bound to light id+k).  flags: bit0 reverse_orientation, bit1 transform_swaps_handedness
+ * (core/src/geometry/shape.rs:163-177).  alpha / shadowalpha: constant float textures only (triangle.rs:291-312);
+ * pass 1.0f,1.0f for the defaults. */
+int pbrt_hip_add_mesh(PbrtHipScene*, const float* P, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris,
+                      const float* N, const float* S, const float* UV, uint32_t material_id,
+                      int32_t first_area_light_id, uint32_t flags, float alpha, float shadow_alpha);
+
+/* Lights are numbered in call order = position in Scene::lights (core/src/scene.rs:50-75). */
+int pbrt_hip_add_light_infinite(PbrtHipScene*, const float L_rgb[3], const float light_to_world[16],
+                                const float world_to_light[16]);       /* lights/src/infinite.rs:63-107, constant L */
+int pbrt_hip_add_light_distant(PbrtHipScene*, const float L_rgb[3], const float w_light_world[3]); /* distant.rs:36-50: already transformed+normalized */
+int pbrt_hip_add_light_point(PbrtHipScene*, const float I_rgb[3], const float p_world[3]);         /* point.rs:36-55 */
+int pbrt_hip_add_light_diffuse_area(PbrtHipScene*, const float L_rgb[3], int two_sided, uint32_t n_tris,
+                                    uint32_t* out_first_id);           /* lights/src/diffuse.rs:46-82, one per triangle */
+
+/* PerspectiveCamera (cameras/src/perspective_camera.rs:47-95): the two transforms the ray generator uses. */
+int pbrt_hip_set_camera_perspective(PbrtHipScene*, const float raster_to_camera[16], const float camera_to_world[16],
+                                    float lens_radius, float focal_distance, float shutter_open, float shutter_close);
+
+/* Film (core/src/film/mod.rs:89-146).  cropped_pixel_bounds = {x0,y0,x1,y1}.  filter_table = the 16x16 table of
+ * Film::new (:117-129).  max_sample_luminance: INFINITY for none. */
+int pbrt_hip_set_film(PbrtHipScene*, int xres, int yres, const int cropped_pixel_bounds[4],
+                      const float filter_radius[2], const float filter_table_16x16[256], float scale,
+                      float max_sample_luminance);
+
+/* Sampler (samplers/src/halton.rs:61-100, sobol.rs:35-63). kind: 0 halton, 1 sobol. sample_bounds = Film::get_sample_bounds. */
+int pbrt_hip_set_sampler(PbrtHipScene*, int kind, uint32_t samples_per_pixel, const int sample_bounds[4],
+                         int sample_at_pixel_center);
+
+/* Optional: Sobol generator matrices (core/src/sobol_matrices.rs) as data: 1024*52 u32, then VdC 25x? tables.
+ * Required before rendering with kind==1; the library does not embed them. */
+int pbrt_hip_set_sobol_tables(PbrtHipScene*, const uint32_t* sobol_matrices32, size_t n32,
+                              const uint64_t* vdc_matrices, const uint64_t* vdc_matrices_inv, size_t n_vdc_each);
+
+/* BVHAccel::from (accelerators/src/bvh/mod.rs:339-360) = Integrator::preprocess time. split_method: 0 SAH. */
+int pbrt_hip_build_accel(PbrtHipScene*, int split_method, int max_prims_in_node);
+
+/* World bound of the built aggregate (BVHAccel::world_bound, bvh/mod.rs:161-167): {pmin[3], pmax[3]}. */
+int pbrt_hip_world_bound(const PbrtHipScene*, float out_bounds[6]);
+
+/* ---- the hot path ---------------------------------------------------------------------------------------- */
+
+/* Primitive::intersect on a batch (accelerators/src/bvh/mod.rs:173-226): host buffers, synchronous. */
+int pbrt_hip_intersect_batch(PbrtHipScene*, const PbrtHipRay* rays, PbrtHipHit* hits, uint64_t n);
+/* Primitive::intersect_p on a batch (bvh/mod.rs:231-283): out[i] = 1 if occluded. */
+int pbrt_hip_occluded_batch(PbrtHipScene*, const PbrtHipRay* rays, uint8_t* out_occluded, uint64_t n);
+
+/* Same, device-resident buffers on the handle's device; enqueued on the handle's stream and synchronised
+ * before returning unless sync==0.  kernel_ms (may be NULL) receives the HIP-event duration of the kernel alone. */
+int pbrt_hip_intersect_batch_device(PbrtHipScene*, const void* d_rays, void* d_hits, uint64_t n, float* kernel_ms);
+int pbrt_hip_occluded_batch_device(PbrtHipScene*, const void* d_rays, void* d_occluded, uint64_t n, float* kernel_ms);
+
+/* Integrator::render for PathIntegrator (core/src/integrator/sampler_integrator.rs:243-415 +
+ * integrators/src/path.rs:103-284).  Renders the 16x16 (tile_size) sample tiles whose index t satisfies
+ * t % tile_parts == tile_part (tile enumeration = sampler_integrator.rs:254-259,314-336), i.e. the whole frame for
+ * (0,1).  light_strategy: 0 uniform, 1 power (2 = spatial is "next": UNSUPPORTED unless the scene has one light,
+ * where the reference itself forces uniform, core/src/light_distrib/mod.rs:50-54).
+ *
+ * Output = the per-pixel state Film keeps (core/src/film/mod.rs:33-47): out_xyz[3*i..] = sum of rgb_to_xyz(tile
+ * contrib), out_weight[i] = filter weight sum, i indexing cropped_pixel_bounds row-major.  Film::write_image's
+ * normalisation (:356-417) is pbrt_hip_film_to_rgb. */
+int pbrt_hip_render_path(PbrtHipScene*, int max_depth, float rr_threshold, int light_strategy,
+                         const int pixel_bounds[4], int tile_size, int tile_part, int tile_parts,
+                         float* out_xyz, float* out_weight, PbrtHipStats* out_stats);
+
+/* Multi-GPU form: writes this rank's FilmTiles (contrib rgb + weight, 4 floats per tile pixel, tiles in
+ * increasing index order, each tile's pixel bounds as Film::get_film_tile computes them) into a DEVICE buffer
+ * the caller owns (e.g. a torch tensor) so the host can gather them with RCCL; then any rank calls
+ * pbrt_hip_merge_tiles on the gathered buffers.  Query sizes with pbrt_hip_tile_buffer_floats. */
+int pbrt_hip_tile_buffer_floats(PbrtHipScene*, int tile_size, int tile_part, int tile_parts, uint64_t* out_floats);
+int pbrt_hip_render_path_tiles_device(PbrtHipScene*, int max_depth, float rr_threshold, int light_strategy,
+                                      const int pixel_bounds[4], int tile_size, int tile_part, int tile_parts,
+                                      void* d_tile_buffer, PbrtHipStats* out_stats);
+/* Film::merge_film_tile (core/src/film/mod.rs:220-279) in increasing tile order over tile_parts device buffers. */
+int pbrt_hip_merge_tiles_device(PbrtHipScene*, int tile_size, int tile_parts, const void* const* d_tile_buffers,
+                                float* out_xyz, float* out_weight);
+
+/* Film::get_pixel_rgb (core/src/film/mod.rs:392-417) on the host: rgb[3*i..]. */
+int pbrt_hip_film_to_rgb(const PbrtHipScene*, const float* xyz, const float* weight, float* out_rgb);
+
+/* K1 alone, for parity tests of a-S/a-C: camera rays for sample index s of every pixel of pixel_bounds,
+ * row-major (get_camera_sample + generate_ray_differential, sampler/mod.rs:45-53, perspective_camera.rs:144-204). */
+int pbrt_hip_generate_camera_rays(PbrtHipScene*, const int pixel_bounds[4], uint32_t sample_index,
+                                  PbrtHipRay* out_rays, float* out_pfilm_xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBRT_HIP_H */

@@ -1,0 +1,338 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp header).
+// C API over the CPU restatement, mirroring include/pbrt_hip.h one-for-one with the prefix `oracle_` so the same
+// Python scene-description code can drive both the checker (this) and the product (libpbrt_hip.so).
+#include "oracle_render.hpp"
+#include <chrono>
+#include <cstdlib>
+
+using namespace orc;
+
+struct OracleScene {
+    Scene sc;
+    Renderer r;
+    std::string err;
+    bool built = false, have_camera = false, have_film = false, have_sampler = false;
+    std::vector<uint32_t> sobol32; std::vector<uint64_t> vdc, vdc_inv;
+    RayRecorder rec;
+    OracleScene() { r.sc = &sc; }
+};
+
+struct OracleRay { float o[3]; float t_max; float d[3]; float time; };
+struct OracleHit { float t; uint32_t prim; float b0, b1, b2; uint32_t pad[3]; };
+struct OracleStats {
+    uint64_t camera_rays, regular_rays, shadow_rays, paths_zero_radiance, paths_total;
+    double render_seconds, extend_seconds, shadow_seconds, shade_seconds;
+};
+struct OracleTraversalStats { uint64_t rays, nodes_visited, tri_tests; };
+
+static M4 m4_from(const float* a) { M4 m; std::memcpy(m.m, a, 64); return m; }
+
+extern "C" {
+
+int oracle_device_count(void) { return 0; }
+OracleScene* oracle_scene_create(int) { return new OracleScene(); }
+void oracle_scene_destroy(OracleScene* s) { delete s; }
+const char* oracle_last_error(const OracleScene* s) { return s ? s->err.c_str() : "null handle"; }
+
+int oracle_add_material_matte(OracleScene* s, const float kd[3], float sigma, uint32_t* out_id) {
+    if (!s || !kd) return -1;
+    Material m; m.kd = Spec(kd[0], kd[1], kd[2]); m.sigma = sigma;
+    s->sc.materials.push_back(m);
+    if (out_id) *out_id = (uint32_t)s->sc.materials.size() - 1;
+    return 0;
+}
+
+int oracle_add_mesh(OracleScene* s, const float* P, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, const float* N,
+                    const float* S, const float* UV, uint32_t material_id, int32_t first_area_light_id, uint32_t flags,
+                    float alpha, float shadow_alpha) {
+    if (!s || !P || !indices) return -1;
+    if (material_id >= s->sc.materials.size()) { s->err = "bad material id"; return -1; }
+    for (uint32_t i = 0; i < 3 * n_tris; i++) if (indices[i] >= n_verts) { s->err = "vertex index out of bounds"; return -1; }
+    Scene& sc = s->sc;
+    Mesh m;
+    m.vert_base = (uint32_t)sc.P.size(); m.tri_base = (uint32_t)sc.n_tris(); m.n_verts = n_verts; m.n_tris = n_tris;
+    m.has_n = N != nullptr; m.has_s = S != nullptr; m.has_uv = UV != nullptr;
+    m.material = material_id; m.first_light = first_area_light_id;
+    m.reverse_orientation = flags & 1; m.swaps_handedness = (flags >> 1) & 1;
+    m.alpha = alpha; m.shadow_alpha = shadow_alpha;
+    // P/N/S/UV arrays are kept index-aligned with P (zero-filled where a mesh lacks them)
+    for (uint32_t i = 0; i < n_verts; i++) {
+        sc.P.push_back(V3(P[3 * i], P[3 * i + 1], P[3 * i + 2]));
+        sc.N.push_back(N ? V3(N[3 * i], N[3 * i + 1], N[3 * i + 2]) : V3());
+        sc.S.push_back(S ? V3(S[3 * i], S[3 * i + 1], S[3 * i + 2]) : V3());
+        sc.UV.push_back(UV ? V2(UV[2 * i], UV[2 * i + 1]) : V2());
+    }
+    uint32_t mesh_id = (uint32_t)sc.meshes.size();
+    for (uint32_t i = 0; i < 3 * n_tris; i++) sc.idx.push_back(indices[i] + m.vert_base);
+    for (uint32_t i = 0; i < n_tris; i++) sc.tri_mesh.push_back(mesh_id);
+    sc.meshes.push_back(m);
+    if (first_area_light_id >= 0) {
+        if ((size_t)first_area_light_id + n_tris > sc.lights.size()) { s->err = "area light ids out of range"; return -1; }
+        for (uint32_t k = 0; k < n_tris; k++) {
+            Light& l = sc.lights[first_area_light_id + k];
+            if (l.type != L_AREA) { s->err = "light is not an area light"; return -1; }
+            uint32_t prim = m.tri_base + k;
+            l.prim = prim;
+            V3 p0 = sc.P[sc.idx[3 * prim]], p1 = sc.P[sc.idx[3 * prim + 1]], p2 = sc.P[sc.idx[3 * prim + 2]];
+            l.area = 0.5f * length(cross(p1 - p0, p2 - p0));  // Triangle::area (triangle.rs:906-911)
+        }
+    }
+    s->built = false;
+    return 0;
+}
+
+int oracle_add_light_infinite(OracleScene* s, const float L[3], const float l2w[16], const float w2l[16]) {
+    if (!s || !L || !l2w || !w2l) return -1;
+    Light l{}; l.type = L_INFINITE; l.L = Spec(L[0], L[1], L[2]); l.l2w = Transform(m4_from(l2w), m4_from(w2l));
+    infinite_light_setup(l);
+    s->sc.infinite_lights.push_back((int)s->sc.lights.size());
+    s->sc.lights.push_back(l);
+    return 0;
+}
+int oracle_add_light_distant(OracleScene* s, const float L[3], const float w[3]) {
+    if (!s || !L || !w) return -1;
+    Light l{}; l.type = L_DISTANT; l.L = Spec(L[0], L[1], L[2]); l.w_light = V3(w[0], w[1], w[2]);
+    s->sc.lights.push_back(l); return 0;
+}
+int oracle_add_light_point(OracleScene* s, const float I[3], const float p[3]) {
+    if (!s || !I || !p) return -1;
+    Light l{}; l.type = L_POINT; l.L = Spec(I[0], I[1], I[2]); l.p_light = V3(p[0], p[1], p[2]);
+    s->sc.lights.push_back(l); return 0;
+}
+int oracle_add_light_diffuse_area(OracleScene* s, const float L[3], int two_sided, uint32_t n_tris, uint32_t* out_first) {
+    if (!s || !L) return -1;
+    if (out_first) *out_first = (uint32_t)s->sc.lights.size();
+    for (uint32_t i = 0; i < n_tris; i++) {
+        Light l{}; l.type = L_AREA; l.L = Spec(L[0], L[1], L[2]); l.two_sided = two_sided; l.prim = 0xffffffffu; l.area = 0;
+        s->sc.lights.push_back(l);
+    }
+    return 0;
+}
+int oracle_set_camera_perspective(OracleScene* s, const float r2c[16], const float c2w[16], float lens_radius, float focal_distance,
+                                  float shutter_open, float shutter_close) {
+    if (!s || !r2c || !c2w) return -1;
+    s->r.cam.raster_to_camera = Transform(m4_from(r2c), M4::identity());  // only .m is used on the path
+    s->r.cam.camera_to_world = Transform(m4_from(c2w), M4::identity());
+    s->r.cam.lens_radius = lens_radius; s->r.cam.focal_distance = focal_distance;
+    s->r.cam.shutter_open = shutter_open; s->r.cam.shutter_close = shutter_close;
+    s->have_camera = true; return 0;
+}
+int oracle_set_film(OracleScene* s, int xres, int yres, const int crop[4], const float radius[2], const float table[256], float scale,
+                    float max_lum) {
+    if (!s || !crop || !radius || !table) return -1;
+    FilmCfg& f = s->r.film; f.xres = xres; f.yres = yres;
+    for (int i = 0; i < 4; i++) f.crop[i] = crop[i];
+    f.radius[0] = radius[0]; f.radius[1] = radius[1];
+    std::memcpy(f.table, table, sizeof(f.table)); f.scale = scale; f.max_lum = max_lum;
+    s->have_film = true; return 0;
+}
+int oracle_set_sampler(OracleScene* s, int kind, uint32_t spp, const int sb[4], int at_center) {
+    if (!s || !sb) return -1;
+    SamplerConfig& c = s->r.scfg; c.kind = kind; c.spp = spp; c.at_center = at_center != 0;
+    for (int i = 0; i < 4; i++) c.bounds[i] = sb[i];
+    s->have_sampler = true; return 0;
+}
+int oracle_set_sobol_tables(OracleScene* s, const uint32_t* m32, size_t n32, const uint64_t* vdc, const uint64_t* vdc_inv, size_t n_each) {
+    if (!s || !m32 || !vdc || !vdc_inv) return -1;
+    s->sobol32.assign(m32, m32 + n32); s->vdc.assign(vdc, vdc + n_each); s->vdc_inv.assign(vdc_inv, vdc_inv + n_each);
+    s->r.scfg.sobol.m32 = s->sobol32.data(); s->r.scfg.sobol.vdc = s->vdc.data(); s->r.scfg.sobol.vdc_inv = s->vdc_inv.data();
+    return 0;
+}
+int oracle_build_accel(OracleScene* s, int split_method, int max_prims) {
+    if (!s) return -1;
+    if (split_method == 1) { s->err = "HLBVH not in oracle scope yet"; return -5; }
+    s->sc.build_bvh(split_method, max_prims);
+    s->built = true; return 0;
+}
+int oracle_world_bound(const OracleScene* s, float out[6]) {
+    if (!s || !s->built) return -2;
+    const Bounds3& b = s->sc.world_bound;
+    out[0] = b.pmin.x; out[1] = b.pmin.y; out[2] = b.pmin.z; out[3] = b.pmax.x; out[4] = b.pmax.y; out[5] = b.pmax.z;
+    return 0;
+}
+
+static int batch_threads() { const char* e = std::getenv("ORACLE_THREADS"); int n = e ? std::atoi(e) : 0; if (n <= 0) n = (int)std::thread::hardware_concurrency(); return n > 0 ? n : 1; }
+
+int oracle_intersect_batch_stats(OracleScene* s, const OracleRay* rays, OracleHit* hits, uint64_t n, OracleTraversalStats* st, int n_threads) {
+    if (!s || (!rays && n) || (!hits && n)) return -1;
+    if (!s->built) { s->err = "build_accel first"; return -2; }
+    if (n_threads <= 0) n_threads = batch_threads();
+    std::vector<TraversalStats> ts(n_threads);
+    auto work = [&](int tid) {
+        for (uint64_t i = tid; i < n; i += n_threads) {
+            Ray r(V3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), V3(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].t_max, rays[i].time);
+            uint32_t prim = 0xffffffffu; TriHit h{0, 0, 0, 0};
+            bool found = s->sc.intersect(r, prim, h, st ? &ts[tid] : nullptr);
+            OracleHit& o = hits[i]; std::memset(&o, 0, sizeof(o));
+            if (found) { o.t = h.t; o.prim = prim; o.b0 = h.b0; o.b1 = h.b1; o.b2 = h.b2; }
+            else { o.t = rays[i].t_max; o.prim = 0xffffffffu; }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    if (st) { st->rays = st->nodes_visited = st->tri_tests = 0; for (auto& t : ts) { st->rays += t.rays; st->nodes_visited += t.nodes_visited; st->tri_tests += t.tri_tests; } }
+    return 0;
+}
+int oracle_intersect_batch(OracleScene* s, const OracleRay* rays, OracleHit* hits, uint64_t n) {
+    return oracle_intersect_batch_stats(s, rays, hits, n, nullptr, 0);
+}
+int oracle_occluded_batch_stats(OracleScene* s, const OracleRay* rays, uint8_t* out, uint64_t n, OracleTraversalStats* st, int n_threads) {
+    if (!s || (!rays && n) || (!out && n)) return -1;
+    if (!s->built) { s->err = "build_accel first"; return -2; }
+    if (n_threads <= 0) n_threads = batch_threads();
+    std::vector<TraversalStats> ts(n_threads);
+    auto work = [&](int tid) {
+        for (uint64_t i = tid; i < n; i += n_threads) {
+            Ray r(V3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), V3(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].t_max, rays[i].time);
+            out[i] = s->sc.intersect_p(r, st ? &ts[tid] : nullptr) ? 1 : 0;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    if (st) { st->rays = st->nodes_visited = st->tri_tests = 0; for (auto& t : ts) { st->rays += t.rays; st->nodes_visited += t.nodes_visited; st->tri_tests += t.tri_tests; } }
+    return 0;
+}
+int oracle_occluded_batch(OracleScene* s, const OracleRay* rays, uint8_t* out, uint64_t n) {
+    return oracle_occluded_batch_stats(s, rays, out, n, nullptr, 0);
+}
+
+// n_threads <= 0: all host cores.  record_cap > 0: also capture up to that many regular and shadow rays.
+int oracle_render_path_ex(OracleScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size,
+                          int tile_part, int tile_parts, float* out_xyz, float* out_weight, OracleStats* st, int n_threads,
+                          int count_traversal, uint64_t* out_nv_nt /*4: nv_reg, nt_reg, nv_sh, nt_sh*/) {
+    if (!s || !pixel_bounds || !out_xyz || !out_weight) return -1;
+    if (!s->built || !s->have_camera || !s->have_film || !s->have_sampler) { s->err = "scene incomplete"; return -2; }
+    if (s->r.scfg.kind == 1 && !s->r.scfg.sobol.m32) { s->err = "sobol tables not set"; return -2; }
+    if (light_strategy == 2 && s->sc.lights.size() != 1) { s->err = "spatial light distribution is out of scope"; return -5; }
+    Renderer& r = s->r;
+    r.max_depth = max_depth; r.rr_threshold = rr_threshold; r.light_strategy = light_strategy == 2 ? 0 : light_strategy;
+    for (int i = 0; i < 4; i++) r.pixel_bounds[i] = pixel_bounds[i];
+    r.stats.camera_rays = r.stats.regular_rays = r.stats.shadow_rays = r.stats.zero_paths = r.stats.total_paths = 0;
+    r.stats.nv_regular = r.stats.nt_regular = r.stats.nv_shadow = r.stats.nt_shadow = 0;
+    r.count_traversal = count_traversal != 0;
+    r.rec = s->rec.cap ? &s->rec : nullptr;
+    if (n_threads <= 0) n_threads = batch_threads();
+    auto t0 = std::chrono::steady_clock::now();
+    r.render(tile_size, tile_part, tile_parts, n_threads, out_xyz, out_weight);
+    auto t1 = std::chrono::steady_clock::now();
+    if (st) {
+        std::memset(st, 0, sizeof(*st));
+        st->camera_rays = r.stats.camera_rays; st->regular_rays = r.stats.regular_rays; st->shadow_rays = r.stats.shadow_rays;
+        st->paths_zero_radiance = r.stats.zero_paths; st->paths_total = r.stats.total_paths;
+        st->render_seconds = std::chrono::duration<double>(t1 - t0).count();
+    }
+    if (out_nv_nt) { out_nv_nt[0] = r.stats.nv_regular; out_nv_nt[1] = r.stats.nt_regular; out_nv_nt[2] = r.stats.nv_shadow; out_nv_nt[3] = r.stats.nt_shadow; }
+    return 0;
+}
+int oracle_render_path(OracleScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size,
+                       int tile_part, int tile_parts, float* out_xyz, float* out_weight, OracleStats* st) {
+    return oracle_render_path_ex(s, max_depth, rr_threshold, light_strategy, pixel_bounds, tile_size, tile_part, tile_parts, out_xyz, out_weight, st, 0, 0, nullptr);
+}
+int oracle_film_to_rgb(const OracleScene* s, const float* xyz, const float* weight, float* rgb) {
+    if (!s || !xyz || !weight || !rgb) return -1;
+    s->r.film_to_rgb(xyz, weight, rgb); return 0;
+}
+int oracle_generate_camera_rays(OracleScene* s, const int pb[4], uint32_t sample_index, OracleRay* out_rays, float* out_pfilm) {
+    if (!s || !pb || !out_rays) return -1;
+    if (!s->have_camera || !s->have_sampler) return -2;
+    size_t k = 0;
+    auto emit = [&](auto& sp) {
+        for (int y = pb[1]; y < pb[3]; y++)
+            for (int x = pb[0]; x < pb[2]; x++, k++) {
+                sp.start_pixel(x, y); sp.set_sample_number(sample_index);
+                V2 fs = sp.get_2d(); V2 pf((Float)x + fs.x, (Float)y + fs.y); Float tm = sp.get_1d(); V2 pl = sp.get_2d();
+                Ray r = s->r.generate_ray(pf, tm, pl);
+                OracleRay& o = out_rays[k];
+                o.o[0] = r.o.x; o.o[1] = r.o.y; o.o[2] = r.o.z; o.t_max = r.t_max; o.d[0] = r.d.x; o.d[1] = r.d.y; o.d[2] = r.d.z; o.time = r.time;
+                if (out_pfilm) { out_pfilm[2 * k] = pf.x; out_pfilm[2 * k + 1] = pf.y; }
+            }
+    };
+    if (s->r.scfg.kind == 0) { HaltonSampler sp(s->r.scfg); emit(sp); }
+    else { if (!s->r.scfg.sobol.m32) return -2; SobolSampler sp(s->r.scfg); emit(sp); }
+    return 0;
+}
+
+void oracle_set_libm_mode(int m) { g_libm_mode = m; }
+
+// ---- oracle-only extras -----------------------------------------------------------------------------------------------
+int oracle_record_rays(OracleScene* s, uint64_t cap) { if (!s) return -1; s->rec.cap = cap; s->rec.regular.clear(); s->rec.shadow.clear(); return 0; }
+uint64_t oracle_recorded_count(OracleScene* s, int shadow) { return s ? (shadow ? s->rec.shadow.size() : s->rec.regular.size()) : 0; }
+int oracle_recorded_rays(OracleScene* s, int shadow, OracleRay* out) {
+    if (!s || !out) return -1;
+    const std::vector<Ray>& v = shadow ? s->rec.shadow : s->rec.regular;
+    for (size_t i = 0; i < v.size(); i++) {
+        out[i].o[0] = v[i].o.x; out[i].o[1] = v[i].o.y; out[i].o[2] = v[i].o.z; out[i].t_max = v[i].t_max;
+        out[i].d[0] = v[i].d.x; out[i].d[1] = v[i].d.y; out[i].d[2] = v[i].d.z; out[i].time = v[i].time;
+    }
+    return 0;
+}
+uint64_t oracle_bvh_node_count(const OracleScene* s) { return s ? s->sc.nodes.size() : 0; }
+int oracle_bvh_nodes(const OracleScene* s, void* out32B) { if (!s) return -1; std::memcpy(out32B, s->sc.nodes.data(), s->sc.nodes.size() * 32); return 0; }
+int oracle_bvh_ordered_prims(const OracleScene* s, uint32_t* out) { if (!s) return -1; std::memcpy(out, s->sc.ordered_prims.data(), s->sc.ordered_prims.size() * 4); return 0; }
+
+// known-answer probes (tests/test_oracle_kat.py)
+void oracle_rng_u32(uint64_t seq, int use_default, uint32_t* out, int n) { RNG r = use_default ? RNG() : RNG(seq); for (int i = 0; i < n; i++) out[i] = r.uniform_u32(); }
+void oracle_halton_perm(int prime_index, uint16_t* out) { const auto& t = ld_tables(); std::memcpy(out, &t.perms[t.prime_sums[prime_index]], t.primes[prime_index] * 2); }
+uint32_t oracle_prime(int i) { return ld_tables().primes[i]; }
+uint32_t oracle_prime_sum(int i) { return ld_tables().prime_sums[i]; }
+float oracle_radical_inverse(int base_index, uint64_t a) { return radical_inverse(base_index, a); }
+float oracle_scrambled_radical_inverse(int base_index, uint64_t a) { const auto& t = ld_tables(); return scrambled_radical_inverse(base_index, a, &t.perms[t.prime_sums[base_index]]); }
+// Halton sample for (pixel, sample number, dimension) using the configured sampler
+float oracle_sampler_value(OracleScene* s, int x, int y, uint32_t sample, uint32_t dim) {
+    HaltonSampler sp(s->r.scfg); sp.start_pixel(x, y); sp.set_sample_number(sample);
+    return sp.sample_dimension(sp.interval_index, dim);
+}
+
+// geometry probes that replay the reference's proptests (core/src/geometry/*.rs #[cfg(test)])
+// op: 0 dot 1 cross 2 normalize 3 length 4 abs 5 min/max component 6 max_dimension 7 permute(xyz->a[3..6]) 8 ray.at
+//     9 coordinate_system 10 matrix inverse (16 in, 16 out) 11 face_forward 12 distance_squared 13 box test
+void oracle_geom_op(int op, const float* a, float* out) {
+    V3 u(a[0], a[1], a[2]), v(a[3], a[4], a[5]);
+    switch (op) {
+    case 0: out[0] = dot(u, v); break;
+    case 1: { V3 c = cross(u, v); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 2: { V3 c = normalize(u); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 3: out[0] = length(u); out[1] = length_squared(u); break;
+    case 4: { V3 c = vabs(u); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 5: out[0] = max_component(u); break;
+    case 6: out[0] = (float)max_dimension(u); break;
+    case 7: { V3 c = permute(u, (int)a[3], (int)a[4], (int)a[5]); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 8: { V3 c = u + v * a[6]; out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 9: { V3 b, c; coordinate_system(u, b, c); out[0] = b.x; out[1] = b.y; out[2] = b.z; out[3] = c.x; out[4] = c.y; out[5] = c.z; break; }
+    case 10: { M4 m = inverse(m4_from(a)); std::memcpy(out, m.m, 64); break; }
+    case 11: { V3 c = face_forward(u, v); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 12: out[0] = distance_squared(u, v); break;
+    case 13: {  // a: box pmin, pmax, ray o, d, t_max
+        Bounds3 b; b.pmin = u; b.pmax = v; Ray r(V3(a[6], a[7], a[8]), V3(a[9], a[10], a[11]), a[12], 0);
+        V3 inv(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z); int neg[3] = {inv.x < 0, inv.y < 0, inv.z < 0};
+        out[0] = Scene::box_hit(b, r, inv, neg) ? 1.0f : 0.0f; break;
+    }
+    }
+}
+// scene-construction helpers restating the reference's Transform factories (transform.rs) for host-side tests
+void oracle_look_at(const float pos[3], const float look[3], const float up[3], float out_m[16], float out_minv[16]) {
+    Transform t = t_look_at(V3(pos[0], pos[1], pos[2]), V3(look[0], look[1], look[2]), V3(up[0], up[1], up[2]));
+    std::memcpy(out_m, t.m.m, 64); std::memcpy(out_minv, t.m_inv.m, 64);
+}
+// raster_to_camera for a perspective camera (camera.rs:276-306 + perspective_camera.rs:47-66)
+void oracle_perspective_raster_to_camera(float fov, int xres, int yres, const float screen[4], float out_m[16]) {
+    Transform c2s = t_perspective(fov, 1e-2f, 1000.0f);
+    Transform s2r = t_scale((Float)xres, (Float)yres, 1.0f) * t_scale(1.0f / (screen[1] - screen[0]), 1.0f / (screen[2] - screen[3]), 1.0f) *
+                    t_translate(V3(-screen[0], -screen[3], 0.0f));
+    Transform r2s = s2r.inv();
+    Transform r2c = c2s.inv() * r2s;
+    std::memcpy(out_m, r2c.m.m, 64);
+}
+void oracle_transform_compose(int kind, const float* p, float out_m[16], float out_minv[16]) {  // 0 translate 1 scale 2 rotate(deg,axis)
+    Transform t;
+    if (kind == 0) t = t_translate(V3(p[0], p[1], p[2]));
+    else if (kind == 1) t = t_scale(p[0], p[1], p[2]);
+    else t = t_rotate_axis(p[0], V3(p[1], p[2], p[3]));
+    std::memcpy(out_m, t.m.m, 64); std::memcpy(out_minv, t.m_inv.m, 64);
+}
+
+}  // extern "C"

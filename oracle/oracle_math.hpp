@@ -1,0 +1,384 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of hackmad/pbrt-v3-rs for the north-star hot path.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, link or call this code.
+// The product (pbrt-v3-rs_amd/) never includes or links anything under oracle/.
+//
+// Parity pin status: the reference's own tests cover only core/src/geometry; those expression-order
+// pins are replayed in tests/test_oracle_geometry.py.  BVH/Triangle/sampler/path/film have NO reference tests or
+// golden vectors and the reference (Rust) cannot be built here, so for those parts parity is "unpinned" except
+// for the PCG32 / Halton-permutation KATs of SURVEY Appendix C (tests/golden/).
+//
+// Build: g++ -O2 -ffp-contract=off -fno-fast-math (Rust never contracts a*b+c).
+//
+// This file: scalar/vector math in the reference's exact f32 expression order.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+
+namespace orc {
+
+typedef float Float;
+
+// core/src/pbrt/common.rs:19-49
+static const Float INF = std::numeric_limits<float>::infinity();
+static const Float PI = 3.14159265358979323846f;  // std::f32::consts::PI
+static const Float INV_PI = 1.0f / PI;
+static const Float PI_OVER_TWO = PI * 0.5f;
+static const Float PI_OVER_FOUR = PI * 0.25f;
+static const Float TWO_PI = PI * 2.0f;
+static const Float INV_TWO_PI = 1.0f / TWO_PI;
+static const Float MACHINE_EPSILON = 5.9604644775390625e-08f;  // f32::EPSILON * 0.5 = 2^-24
+static const Float SHADOW_EPSILON = 0.0001f;
+static const Float ONE_MINUS_EPSILON = 0x1.fffffep-1f;  // core/src/rng.rs:7
+
+// Transcendentals (core/src/pbrt/common.rs:282-339 forward to f32::{sin,cos,acos,atan2} = platform libm).
+// mode 0: glibc f32 routines, i.e. what the reference links on linux-gnu.
+// mode 1: evaluate in f64 and round once to f32.  glibc's sinf/cosf/acosf/atan2f are NOT correctly rounded (they differ
+//         from the rounded f64 value for 1.3% / 1.3% / 7.8% / 16% of arguments), and a device libm differs again, so
+//         mode 1 is the platform-independent variant the GPU path can reproduce bit-for-bit; tests compare both.
+inline int g_libm_mode = 0;
+inline Float o_sin(Float x) { return g_libm_mode ? (Float)std::sin((double)x) : std::sin(x); }
+inline Float o_cos(Float x) { return g_libm_mode ? (Float)std::cos((double)x) : std::cos(x); }
+inline Float o_acos(Float x) { return g_libm_mode ? (Float)std::acos((double)x) : std::acos(x); }
+inline Float o_atan2(Float y, Float x) { return g_libm_mode ? (Float)std::atan2((double)y, (double)x) : std::atan2(y, x); }
+
+// core/src/pbrt/common.rs:66-107 — generic abs/min/max written with < and > (NaN and -0.0 behaviour matters)
+inline Float pabs(Float n) { return n < 0.0f ? -n : n; }
+template <class T> inline T pmin(T a, T b) { return a < b ? a : b; }
+template <class T> inline T pmax(T a, T b) { return a > b ? a : b; }
+// core/src/pbrt/clamp.rs:9-20
+template <class T> inline T pclamp(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// core/src/pbrt/common.rs:116-126
+template <class T> inline T prem(T a, T b) {
+    T r = a - (a / b) * b;
+    return r < 0 ? r + b : r;
+}
+// core/src/pbrt/common.rs:132-134
+inline Float gamma_n(int n) { return ((Float)n * MACHINE_EPSILON) / (1.0f - (Float)n * MACHINE_EPSILON); }
+// core/src/pbrt/common.rs:166-175
+inline Float lerp(Float t, Float a, Float b) { return (1.0f - t) * a + t * b; }
+
+inline uint32_t float_to_bits(Float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline Float bits_to_float(uint32_t u) { Float f; std::memcpy(&f, &u, 4); return f; }
+// core/src/pbrt/common.rs:205-243
+inline Float next_float_up(Float v) {
+    if (std::isinf(v) && v > 0.0f) return v;
+    Float nv = (v == -0.0f) ? 0.0f : v;
+    uint32_t ui = float_to_bits(nv);
+    if (nv >= 0.0f) ui += 1; else ui -= 1;
+    return bits_to_float(ui);
+}
+inline Float next_float_down(Float v) {
+    if (std::isinf(v) && v < 0.0f) return v;
+    Float nv = (v == 0.0f) ? -0.0f : v;
+    uint32_t ui = float_to_bits(nv);
+    if (nv > 0.0f) ui -= 1; else ui += 1;
+    return bits_to_float(ui);
+}
+// Rust `as usize` / `as i32` on floats saturate, NaN -> 0
+inline size_t f2usize(Float f) {
+    if (!(f > 0.0f)) return 0;  // NaN, negatives, zero
+    if (f >= 18446744073709551616.0f) return (size_t)-1;
+    return (size_t)f;
+}
+inline int32_t f2i32(Float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int32_t)(-2147483647 - 1);
+    return (int32_t)f;
+}
+// core/src/pbrt/common.rs:251-276
+template <class Pred> inline size_t find_interval(size_t size, Pred pred) {
+    size_t first = 0, len = size;
+    while (len > 0) {
+        size_t half = len >> 1, middle = first + half;
+        if (pred(middle)) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    if (first == 0) return 0;
+    return pclamp<size_t>(first - 1, 0, size - 2);
+}
+
+// Vector3f / Point3f / Normal3f share one POD here; the reference's three types have identical arithmetic
+// (core/src/geometry/{vector3,point3,normal}.rs).
+struct V3 {
+    Float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(Float a, Float b, Float c) : x(a), y(b), z(c) {}
+    Float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    Float& operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, Float f) { return V3(a.x * f, a.y * f, a.z * f); }
+inline V3 operator*(Float f, V3 a) { return V3(a.x * f, a.y * f, a.z * f); }
+// vector3.rs:406-418: Div multiplies by the reciprocal
+inline V3 operator/(V3 a, Float f) { Float inv = 1.0f / f; return V3(inv * a.x, inv * a.y, inv * a.z); }
+inline Float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                 // vector3.rs:151-157
+inline Float abs_dot(V3 a, V3 b) { return pabs(dot(a, b)); }
+inline V3 cross(V3 a, V3 b) {                                                                 // vector3.rs:169-178
+    return V3((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
+}
+inline Float length_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+inline Float length(V3 a) { return std::sqrt(length_squared(a)); }
+inline V3 normalize(V3 a) { return a / length(a); }                                          // vector3.rs:63-68
+inline V3 vabs(V3 a) { return V3(pabs(a.x), pabs(a.y), pabs(a.z)); }                         // vector3.rs:70-75
+inline Float max_component(V3 a) {                                                            // vector3.rs:93-107
+    if (a.x > a.y) return a.x > a.z ? a.x : a.z;
+    return a.y > a.z ? a.y : a.z;
+}
+inline int max_dimension(V3 a) {                                                              // vector3.rs:109-123
+    if (a.x > a.y) return a.x > a.z ? 0 : 2;
+    return a.y > a.z ? 1 : 2;
+}
+inline V3 permute(V3 a, int x, int y, int z) { return V3(a[x], a[y], a[z]); }
+inline V3 face_forward(V3 n, V3 v) { return dot(n, v) < 0.0f ? -n : n; }                     // geometry/common.rs:46-52
+inline Float distance_squared(V3 a, V3 b) { return length_squared(a - b); }
+inline Float distance(V3 a, V3 b) { return length(a - b); }
+inline V3 lerp(Float t, V3 a, V3 b) { return (1.0f - t) * a + t * b; }
+// core/src/geometry/coordinate_system.rs:12-20
+inline void coordinate_system(V3 v1, V3& v2, V3& v3) {
+    if (pabs(v1.x) > pabs(v1.y)) v2 = V3(-v1.z, 0.0f, v1.x) / std::sqrt(v1.x * v1.x + v1.z * v1.z);
+    else v2 = V3(0.0f, v1.z, -v1.y) / std::sqrt(v1.y * v1.y + v1.z * v1.z);
+    v3 = cross(v1, v2);
+}
+// core/src/geometry/util.rs:41-56
+inline Float spherical_theta(V3 v) { return o_acos(pclamp(v.z, -1.0f, 1.0f)); }
+inline Float spherical_phi(V3 v) { Float p = o_atan2(v.y, v.x); return p < 0.0f ? p + TWO_PI : p; }
+
+struct V2 { Float x, y; V2() : x(0), y(0) {} V2(Float a, Float b) : x(a), y(b) {} };
+
+// RGBSpectrum (core/src/spectrum/rgb_spectrum.rs)
+struct Spec {
+    Float c[3];
+    Spec() { c[0] = c[1] = c[2] = 0; }
+    explicit Spec(Float v) { c[0] = c[1] = c[2] = v; }
+    Spec(Float r, Float g, Float b) { c[0] = r; c[1] = g; c[2] = b; }
+    bool is_black() const { return c[0] == 0.0f && c[1] == 0.0f && c[2] == 0.0f; }          // spectrum/common.rs:102-109
+    Float y() const { return 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2]; }      // rgb_spectrum.rs:100-102
+    Float max_component_value() const { return pmax(pmax(c[0], c[1]), c[2]); }              // spectrum/common.rs:120-124
+    bool has_nans() const { return c[0] != c[0] || c[1] != c[1] || c[2] != c[2]; }
+};
+inline Spec operator+(Spec a, Spec b) { return Spec(a.c[0] + b.c[0], a.c[1] + b.c[1], a.c[2] + b.c[2]); }
+inline Spec operator*(Spec a, Spec b) { return Spec(a.c[0] * b.c[0], a.c[1] * b.c[1], a.c[2] * b.c[2]); }
+inline Spec operator*(Spec a, Float f) { return Spec(a.c[0] * f, a.c[1] * f, a.c[2] * f); }
+inline Spec operator*(Float f, Spec a) { return a * f; }
+inline Spec operator/(Spec a, Float f) { return a * (1.0f / f); }                            // rgb_spectrum.rs:255-263
+inline Spec& operator+=(Spec& a, Spec b) { a = a + b; return a; }
+inline Spec& operator*=(Spec& a, Spec b) { a = a * b; return a; }
+// core/src/spectrum/common.rs:337-355
+inline void xyz_to_rgb(const Float xyz[3], Float rgb[3]) {
+    rgb[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];
+    rgb[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+    rgb[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
+}
+inline void rgb_to_xyz(const Float rgb[3], Float xyz[3]) {
+    xyz[0] = 0.412453f * rgb[0] + 0.357580f * rgb[1] + 0.180423f * rgb[2];
+    xyz[1] = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];
+    xyz[2] = 0.019334f * rgb[0] + 0.119193f * rgb[1] + 0.950227f * rgb[2];
+}
+
+// core/src/geometry/bounds3.rs
+struct Bounds3 {
+    V3 pmin, pmax;
+    Bounds3() : pmin(std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()),
+                pmax(std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest()) {}  // EMPTY :23-30
+    Bounds3(V3 p) : pmin(p), pmax(p) {}
+    const V3& operator[](int i) const { return i == 0 ? pmin : pmax; }
+    Bounds3 union_p(V3 p) const {                                                             // :344-362
+        Bounds3 r;
+        r.pmin = V3(fmn(pmin.x, p.x), fmn(pmin.y, p.y), fmn(pmin.z, p.z));
+        r.pmax = V3(fmx(pmax.x, p.x), fmx(pmax.y, p.y), fmx(pmax.z, p.z));
+        return r;
+    }
+    Bounds3 union_b(const Bounds3& o) const {                                                 // :364-382
+        Bounds3 r;
+        r.pmin = V3(fmn(pmin.x, o.pmin.x), fmn(pmin.y, o.pmin.y), fmn(pmin.z, o.pmin.z));
+        r.pmax = V3(fmx(pmax.x, o.pmax.x), fmx(pmax.y, o.pmax.y), fmx(pmax.z, o.pmax.z));
+        return r;
+    }
+    bool is_empty() const { return pmax.x < pmin.x || pmax.y < pmin.y || pmax.z < pmin.z; }
+    V3 diagonal() const { return pmax - pmin; }
+    Float surface_area() const {                                                              // :95-107
+        if (is_empty()) return 0.0f;
+        V3 d = diagonal();
+        Float h = d.x * d.y + d.x * d.z + d.y * d.z;
+        return h + h;
+    }
+    int maximum_extent() const {                                                              // :122-134
+        V3 d = diagonal();
+        if (d.x > d.y && d.x > d.z) return 0;
+        if (d.y > d.z) return 1;
+        return 2;
+    }
+    V3 offset(V3 p) const {                                                                   // :152-168
+        V3 o = p - pmin;
+        if (pmax.x > pmin.x) o.x /= pmax.x - pmin.x;
+        if (pmax.y > pmin.y) o.y /= pmax.y - pmin.y;
+        if (pmax.z > pmin.z) o.z /= pmax.z - pmin.z;
+        return o;
+    }
+    bool contains(V3 p) const {
+        return (p.x >= pmin.x && p.x <= pmax.x) && (p.y >= pmin.y && p.y <= pmax.y) && (p.z >= pmin.z && p.z <= pmax.z);
+    }
+    void bounding_sphere(V3& center, Float& radius) const {                                   // :196-208
+        center = lerp(0.5f, pmin, pmax);
+        radius = contains(center) ? distance(center, pmax) : 0.0f;
+    }
+  private:
+    static Float fmn(Float a, Float b) { return a < b ? a : b; }
+    static Float fmx(Float a, Float b) { return a > b ? a : b; }
+};
+
+// 4x4 matrix + Transform (core/src/geometry/matrix4x4.rs, transform.rs)
+struct M4 {
+    Float m[4][4];
+    static M4 identity() { M4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = i == j ? 1.0f : 0.0f; return r; }
+    M4 transpose() const { M4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = m[j][i]; return r; }
+};
+inline M4 mul(const M4& a, const M4& b) {                                                     // matrix4x4.rs:181-201
+    M4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j] + a.m[i][3] * b.m[3][j];
+    return r;
+}
+inline M4 inverse(const M4& a) {                                                              // matrix4x4.rs:67-143 (Gauss-Jordan, full pivoting)
+    int indxc[4] = {0, 0, 0, 0}, indxr[4] = {0, 0, 0, 0}, ipiv[4] = {0, 0, 0, 0};
+    Float minv[4][4];
+    std::memcpy(minv, a.m, sizeof(minv));
+    for (int i = 0; i < 4; i++) {
+        int irow = 0, icol = 0;
+        Float big = 0.0f;
+        for (int j = 0; j < 4; j++) {
+            if (ipiv[j] != 1) {
+                for (int k = 0; k < 4; k++) {
+                    if (ipiv[k] == 0) {
+                        Float av = pabs(minv[j][k]);
+                        if (av >= big) { big = av; irow = j; icol = k; }
+                    }
+                }
+            }
+        }
+        ipiv[icol] += 1;
+        if (irow != icol)
+            for (int k = 0; k < 4; k++) { Float t = minv[irow][k]; minv[irow][k] = minv[icol][k]; minv[icol][k] = t; }
+        indxr[i] = irow; indxc[i] = icol;
+        Float pivinv = 1.0f / minv[icol][icol];
+        minv[icol][icol] = 1.0f;
+        for (int j = 0; j < 4; j++) minv[icol][j] *= pivinv;
+        for (int j = 0; j < 4; j++) {
+            if (j != icol) {
+                Float save = minv[j][icol];
+                minv[j][icol] = 0.0f;
+                for (int k = 0; k < 4; k++) minv[j][k] -= minv[icol][k] * save;
+            }
+        }
+    }
+    for (int j = 3; j >= 0; j--) {
+        if (indxr[j] != indxc[j])
+            for (int k = 0; k < 4; k++) { Float t = minv[k][indxr[j]]; minv[k][indxr[j]] = minv[k][indxc[j]]; minv[k][indxc[j]] = t; }
+    }
+    M4 r; std::memcpy(r.m, minv, sizeof(minv)); return r;
+}
+
+struct Transform {
+    M4 m, m_inv;
+    Transform() : m(M4::identity()), m_inv(M4::identity()) {}
+    Transform(const M4& a, const M4& b) : m(a), m_inv(b) {}
+    static Transform from_matrix(const M4& a) { return Transform(a, inverse(a)); }          // transform.rs:602-612
+    Transform inv() const { return Transform(m_inv, m); }
+    // transform.rs:288-302
+    V3 point(V3 p) const {
+        Float xp = m.m[0][0] * p.x + m.m[0][1] * p.y + m.m[0][2] * p.z + m.m[0][3];
+        Float yp = m.m[1][0] * p.x + m.m[1][1] * p.y + m.m[1][2] * p.z + m.m[1][3];
+        Float zp = m.m[2][0] * p.x + m.m[2][1] * p.y + m.m[2][2] * p.z + m.m[2][3];
+        Float wp = m.m[3][0] * p.x + m.m[3][1] * p.y + m.m[3][2] * p.z + m.m[3][3];
+        if (wp == 1.0f) return V3(xp, yp, zp);
+        return V3(xp, yp, zp) / wp;
+    }
+    // transform.rs:304-328
+    V3 point_with_error(V3 p, V3& err) const {
+        Float x = p.x, y = p.y, z = p.z;
+        Float xp = (m.m[0][0] * x + m.m[0][1] * y) + (m.m[0][2] * z + m.m[0][3]);
+        Float yp = (m.m[1][0] * x + m.m[1][1] * y) + (m.m[1][2] * z + m.m[1][3]);
+        Float zp = (m.m[2][0] * x + m.m[2][1] * y) + (m.m[2][2] * z + m.m[2][3]);
+        Float wp = (m.m[3][0] * x + m.m[3][1] * y) + (m.m[3][2] * z + m.m[3][3]);
+        Float xs = pabs(m.m[0][0] * x) + pabs(m.m[0][1] * y) + pabs(m.m[0][2] * z) + pabs(m.m[0][3]);
+        Float ys = pabs(m.m[1][0] * x) + pabs(m.m[1][1] * y) + pabs(m.m[1][2] * z) + pabs(m.m[1][3]);
+        Float zs = pabs(m.m[2][0] * x) + pabs(m.m[2][1] * y) + pabs(m.m[2][2] * z) + pabs(m.m[2][3]);
+        err = gamma_n(3) * V3(xs, ys, zs);
+        if (wp == 1.0f) return V3(xp, yp, zp);
+        return V3(xp, yp, zp) / wp;
+    }
+    V3 vector(V3 v) const {                                                                   // transform.rs:373-380
+        return V3(m.m[0][0] * v.x + m.m[0][1] * v.y + m.m[0][2] * v.z,
+                  m.m[1][0] * v.x + m.m[1][1] * v.y + m.m[1][2] * v.z,
+                  m.m[2][0] * v.x + m.m[2][1] * v.y + m.m[2][2] * v.z);
+    }
+    V3 normal(V3 n) const {                                                                   // transform.rs:441-448
+        return V3(m_inv.m[0][0] * n.x + m_inv.m[1][0] * n.y + m_inv.m[2][0] * n.z,
+                  m_inv.m[0][1] * n.x + m_inv.m[1][1] * n.y + m_inv.m[2][1] * n.z,
+                  m_inv.m[0][2] * n.x + m_inv.m[1][2] * n.y + m_inv.m[2][2] * n.z);
+    }
+    bool swaps_handedness() const {                                                           // transform.rs:593-599
+        Float det = m.m[0][0] * (m.m[1][1] * m.m[2][2] - m.m[1][2] * m.m[2][1]) -
+                    m.m[0][1] * (m.m[1][0] * m.m[2][2] - m.m[1][2] * m.m[2][0]) +
+                    m.m[0][2] * (m.m[1][0] * m.m[2][1] - m.m[1][1] * m.m[2][0]);
+        return det < 0.0f;
+    }
+};
+inline Transform operator*(const Transform& a, const Transform& b) {                          // transform.rs:644-656
+    return Transform(mul(a.m, b.m), mul(b.m_inv, a.m_inv));
+}
+inline M4 m4(Float a00, Float a01, Float a02, Float a03, Float a10, Float a11, Float a12, Float a13, Float a20, Float a21,
+             Float a22, Float a23, Float a30, Float a31, Float a32, Float a33) {
+    M4 r;
+    Float v[16] = {a00, a01, a02, a03, a10, a11, a12, a13, a20, a21, a22, a23, a30, a31, a32, a33};
+    std::memcpy(r.m, v, sizeof(v));
+    return r;
+}
+inline Transform t_translate(V3 d) {                                                          // transform.rs:49-66
+    return Transform(m4(1, 0, 0, d.x, 0, 1, 0, d.y, 0, 0, 1, d.z, 0, 0, 0, 1), m4(1, 0, 0, -d.x, 0, 1, 0, -d.y, 0, 0, 1, -d.z, 0, 0, 0, 1));
+}
+inline Transform t_scale(Float x, Float y, Float z) {                                         // transform.rs:68-85
+    return Transform(m4(x, 0, 0, 0, 0, y, 0, 0, 0, 0, z, 0, 0, 0, 0, 1),
+                     m4(1.0f / x, 0, 0, 0, 0, 1.0f / y, 0, 0, 0, 0, 1.0f / z, 0, 0, 0, 0, 1));
+}
+inline Float to_radians(Float deg) { return deg * (PI / 180.0f); }                            // f32::to_radians
+inline Transform t_rotate_axis(Float theta, V3 axis) {                                        // transform.rs:135-163
+    V3 a = normalize(axis);
+    Float r = to_radians(theta);
+    Float s = std::sin(r), c = std::cos(r);
+    M4 m = M4::identity();
+    m.m[0][0] = a.x * a.x + (1.0f - a.x * a.x) * c;
+    m.m[0][1] = a.x * a.y * (1.0f - c) - a.z * s;
+    m.m[0][2] = a.x * a.z * (1.0f - c) + a.y * s;
+    m.m[0][3] = 0.0f;
+    m.m[1][0] = a.x * a.y * (1.0f - c) + a.z * s;
+    m.m[1][1] = a.y * a.y + (1.0f - a.y * a.y) * c;
+    m.m[1][2] = a.y * a.z * (1.0f - c) - a.x * s;
+    m.m[1][3] = 0.0f;
+    m.m[2][0] = a.x * a.z * (1.0f - c) - a.y * s;
+    m.m[2][1] = a.y * a.z * (1.0f - c) + a.x * s;
+    m.m[2][2] = a.z * a.z + (1.0f - a.z * a.z) * c;
+    m.m[2][3] = 0.0f;
+    return Transform(m, m.transpose());
+}
+inline Transform t_look_at(V3 pos, V3 look, V3 up) {                                          // transform.rs:165-189
+    V3 dir = normalize(look - pos);
+    V3 right = cross(normalize(up), dir);
+    right = normalize(right);
+    V3 new_up = cross(dir, right);
+    M4 c2w = m4(right.x, new_up.x, dir.x, pos.x, right.y, new_up.y, dir.y, pos.y, right.z, new_up.z, dir.z, pos.z, 0, 0, 0, 1);
+    return Transform(inverse(c2w), c2w);
+}
+inline Transform t_perspective(Float fov, Float n, Float f) {                                 // transform.rs:197-210
+    M4 persp = m4(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, f / (f - n), -f * n / (f - n), 0, 0, 1, 0);
+    Float inv_tan_ang = 1.0f / std::tan(to_radians(fov) / 2.0f);
+    return t_scale(inv_tan_ang, inv_tan_ang, 1.0f) * Transform::from_matrix(persp);
+}
+
+}  // namespace orc

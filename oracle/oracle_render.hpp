@@ -1,0 +1,861 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp header).
+// Samplers, camera, lights, BSDF, PathIntegrator::li, Film, SamplerIntegrator::render.
+#pragma once
+#include "oracle_scene.hpp"
+#include <mutex>
+#include <thread>
+
+namespace orc {
+
+// =============================== RNG (core/src/rng.rs:20-120) =====================================================
+struct RNG {
+    uint64_t state, inc;
+    RNG() : state(0x853c49e6748fea9bULL), inc(0xda3e39cb94b95bdbULL) {}
+    explicit RNG(uint64_t seq) { set_sequence(seq); }
+    void set_sequence(uint64_t init_seq) {
+        state = 0; inc = (init_seq << 1) | 1;
+        uniform_u32();
+        state += 0x853c49e6748fea9bULL;
+        uniform_u32();
+    }
+    uint32_t uniform_u32() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
+        uint32_t rot = (uint32_t)(old >> 59);
+        return (xs >> rot) | (xs << ((~rot + 1) & 31));
+    }
+    uint32_t bounded_uniform_u32(uint32_t lo, uint32_t hi) {
+        uint32_t b = hi - lo, threshold = (~b + 1) % b;
+        for (;;) { uint32_t r = uniform_u32(); if (r >= threshold) return lo + r % b; }
+    }
+    Float uniform_float() { return pmin((Float)uniform_u32() * 0x1.0p-32f, ONE_MINUS_EPSILON); }
+};
+
+// =============================== low-discrepancy (core/src/low_discrepency.rs) ====================================
+static const int PRIME_TABLE_SIZE = 1000;
+struct LowDiscrepancyTables {
+    std::vector<uint32_t> primes, prime_sums;
+    std::vector<uint16_t> perms;  // compute_radical_inverse_permutations with RNG::default() (samplers/src/halton.rs:16-19)
+    LowDiscrepancyTables() {
+        for (uint32_t c = 2; primes.size() < (size_t)PRIME_TABLE_SIZE; c++) {
+            bool is_p = true;
+            for (uint32_t q : primes) { if (q * q > c) break; if (c % q == 0) { is_p = false; break; } }
+            if (is_p) primes.push_back(c);
+        }
+        uint32_t s = 0;
+        for (int i = 0; i < PRIME_TABLE_SIZE; i++) { prime_sums.push_back(s); s += primes[i]; }
+        perms.resize(s);
+        RNG rng; size_t p = 0;
+        for (int i = 0; i < PRIME_TABLE_SIZE; i++) {  // low_discrepency.rs:1512-1528 + RNG::shuffle (rng.rs:110-119)
+            uint32_t n = primes[i];
+            for (uint32_t j = 0; j < n; j++) perms[p + j] = (uint16_t)j;
+            for (uint32_t j = 0; j < n; j++) {
+                uint32_t other = j + rng.bounded_uniform_u32(0, n - j);
+                std::swap(perms[p + j], perms[p + other]);
+            }
+            p += n;
+        }
+    }
+};
+inline const LowDiscrepancyTables& ld_tables() { static LowDiscrepancyTables t; return t; }
+
+inline uint64_t reverse_bits_64(uint64_t n) {
+    n = ((n >> 1) & 0x5555555555555555ULL) | ((n & 0x5555555555555555ULL) << 1);
+    n = ((n >> 2) & 0x3333333333333333ULL) | ((n & 0x3333333333333333ULL) << 2);
+    n = ((n >> 4) & 0x0f0f0f0f0f0f0f0fULL) | ((n & 0x0f0f0f0f0f0f0f0fULL) << 4);
+    n = ((n >> 8) & 0x00ff00ff00ff00ffULL) | ((n & 0x00ff00ff00ff00ffULL) << 8);
+    n = ((n >> 16) & 0x0000ffff0000ffffULL) | ((n & 0x0000ffff0000ffffULL) << 16);
+    return (n >> 32) | (n << 32);
+}
+inline Float radical_inverse_specialized(uint32_t base_, uint64_t a) {  // :401-421
+    Float inv_base = 1.0f / (Float)base_;
+    uint64_t base = base_, reversed = 0;
+    Float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint64_t next = a / base, digit = a - next * base;
+        reversed = reversed * base + digit;
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return pmin((Float)reversed * inv_base_n, ONE_MINUS_EPSILON);
+}
+inline Float radical_inverse(int base_index, uint64_t a) {  // :454-464 (base 2: no clamp)
+    if (base_index == 0) return (Float)reverse_bits_64(a) * 0x1.0p-64f;
+    return radical_inverse_specialized(ld_tables().primes[base_index], a);
+}
+inline Float scrambled_radical_inverse(int base_index, uint64_t a, const uint16_t* perm) {  // :428-449
+    uint32_t base_ = ld_tables().primes[base_index];
+    Float inv_base = 1.0f / (Float)base_;
+    uint64_t base = base_, reversed = 0;
+    Float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint64_t next = a / base; size_t digit = (size_t)(a - next * base);
+        reversed = reversed * base + perm[digit];
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return pmin(inv_base_n * ((Float)reversed + inv_base * (Float)perm[0] / (1.0f - inv_base)), ONE_MINUS_EPSILON);
+}
+inline uint64_t inverse_radical_inverse(uint64_t base, uint64_t inverse, uint64_t n_digits) {  // :1535-1545
+    uint64_t index = 0;
+    for (uint64_t i = 0; i < n_digits; i++) { uint64_t digit = inverse % base; inverse /= base; index = index * base + digit; }
+    return index;
+}
+
+// =============================== Samplers =========================================================================
+struct SobolTables { const uint32_t* m32 = nullptr; const uint64_t* vdc = nullptr; const uint64_t* vdc_inv = nullptr; };
+
+struct SamplerConfig {
+    int kind = 0;  // 0 halton, 1 sobol, 2 random (CPU only)
+    uint32_t spp = 16;
+    int bounds[4] = {0, 0, 0, 0};  // sample_bounds x0,y0,x1,y1
+    bool at_center = false;
+    SobolTables sobol;
+};
+
+// HaltonSampler (samplers/src/halton.rs) as a per-tile object exactly like clone_sampler() produces
+struct HaltonSampler {
+    uint64_t base_scales[2], base_exponents[2], sample_stride;
+    int64_t mult_inverse[2];
+    bool at_center;
+    uint32_t spp;
+    int px = 0x7fffffff, py = 0x7fffffff;  // pixel_for_offset
+    int cur_x = 0, cur_y = 0;
+    uint64_t offset_for_pixel = 0, interval_index = 0;
+    uint32_t dimension = 0, sample_num = 0;
+    static void extended_gcd(uint64_t a, uint64_t b, int64_t& x, int64_t& y) {  // halton.rs:294-302
+        if (b == 0) { x = 1; y = 0; return; }
+        int64_t d = (int64_t)(a / b), xp, yp;
+        extended_gcd(b, a % b, xp, yp);
+        x = yp; y = xp - (d * yp);
+    }
+    static uint64_t multiplicative_inverse(int64_t a, int64_t n) { int64_t x, y; extended_gcd((uint64_t)a, (uint64_t)n, x, y); return (uint64_t)prem<int64_t>(x, n); }
+    HaltonSampler(const SamplerConfig& c) : at_center(c.at_center), spp(c.spp) {  // halton.rs:61-100
+        int res[2] = {c.bounds[2] - c.bounds[0], c.bounds[3] - c.bounds[1]};
+        for (int i = 0; i < 2; i++) {
+            uint64_t base = i == 0 ? 2 : 3, scale = 1, e = 0;
+            while ((int)scale < pmin(res[i], 128)) { scale *= base; e++; }
+            base_scales[i] = scale; base_exponents[i] = e;
+        }
+        sample_stride = base_scales[0] * base_scales[1];
+        mult_inverse[0] = (int64_t)multiplicative_inverse((int64_t)base_scales[1], (int64_t)base_scales[0]);
+        mult_inverse[1] = (int64_t)multiplicative_inverse((int64_t)base_scales[0], (int64_t)base_scales[1]);
+    }
+    uint64_t index_for_sample(uint64_t s) {  // halton.rs:118-144
+        if (cur_x != px || cur_y != py) {
+            offset_for_pixel = 0;
+            if (sample_stride > 1) {
+                int pm[2] = {prem(cur_x, 128), prem(cur_y, 128)};
+                for (int i = 0; i < 2; i++) {
+                    uint64_t dim_offset = inverse_radical_inverse(i == 0 ? 2 : 3, (uint64_t)pm[i], base_exponents[i]);
+                    offset_for_pixel += dim_offset * (sample_stride / base_scales[i]) * (uint64_t)mult_inverse[i];
+                }
+                offset_for_pixel %= sample_stride;
+            }
+            px = cur_x; py = cur_y;
+        }
+        return offset_for_pixel + s * sample_stride;
+    }
+    Float sample_dimension(uint64_t index, uint32_t dim) const {  // halton.rs:146-160
+        if (at_center && (dim == 0 || dim == 1)) return 0.5f;
+        if (dim == 0) return radical_inverse(0, index >> base_exponents[0]);
+        if (dim == 1) return radical_inverse(1, index / base_scales[1]);
+        // permutation_for_dimension asserts dim <= PRIME_TABLE_SIZE (halton.rs:106-110)
+        return scrambled_radical_inverse((int)dim, index, &ld_tables().perms[ld_tables().prime_sums[dim]]);
+    }
+    void start_pixel(int x, int y) { cur_x = x; cur_y = y; sample_num = 0; dimension = 0; interval_index = index_for_sample(0); }
+    bool start_next_sample() { dimension = 0; interval_index = index_for_sample(sample_num + 1); sample_num++; return sample_num < spp; }
+    void set_sample_number(uint32_t s) { dimension = 0; interval_index = index_for_sample(s); sample_num = s; }
+    Float get_1d() { Float p = sample_dimension(interval_index, dimension); dimension += 1; return p; }  // array dims: start=end=5, never fire
+    V2 get_2d() {
+        if (dimension + 1 >= 5 && dimension < 5) dimension = 5;  // halton.rs:238-240 with no arrays
+        V2 p(sample_dimension(interval_index, dimension), sample_dimension(interval_index, dimension + 1));
+        dimension += 2;
+        return p;
+    }
+};
+
+// SobolSampler (samplers/src/sobol.rs:35-93, core/src/low_discrepency.rs:1770-1848)
+struct SobolSampler {
+    SobolTables tb; uint32_t spp; int bounds[4]; int resolution, log2_res;
+    int cur_x = 0, cur_y = 0; uint64_t interval_index = 0; uint32_t dimension = 0, sample_num = 0;
+    static bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+    static uint32_t round_up_pow2(uint32_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
+    static int log2_int(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; }
+    SobolSampler(const SamplerConfig& c) : tb(c.sobol) {
+        spp = is_pow2(c.spp) ? c.spp : round_up_pow2(c.spp);  // sobol.rs:38-47 (round_up_pow2)
+        for (int i = 0; i < 4; i++) bounds[i] = c.bounds[i];
+        int dx = bounds[2] - bounds[0], dy = bounds[3] - bounds[1];
+        resolution = (int)round_up_pow2((uint32_t)pmax(dx, dy));
+        log2_res = log2_int((uint32_t)resolution);
+    }
+    uint64_t interval_to_index(uint32_t m, uint64_t frame, int px, int py) const {  // low_discrepency.rs:1770-1824
+        if (m == 0) return 0;
+        uint32_t m2 = m << 1;
+        uint64_t index = frame << m2;
+        uint64_t delta = 0;
+        for (int c = 0; frame != 0; frame >>= 1, c++)
+            if (frame & 1) delta ^= tb.vdc[(size_t)(m - 1) * 52 + c];
+        uint64_t b = (((uint64_t)(uint32_t)px << m) | (uint64_t)(uint32_t)py) ^ delta;
+        for (int c = 0; b != 0; b >>= 1, c++)
+            if (b & 1) index ^= tb.vdc_inv[(size_t)(m - 1) * 52 + c];
+        return index;
+    }
+    Float sobol_sample(uint64_t a, uint32_t dim) const {  // sobol_sample_f32, scramble = 0 (:1826-1848)
+        uint32_t v = 0;
+        for (size_t i = (size_t)dim * 52; a != 0; a >>= 1, i++) if (a & 1) v ^= tb.m32[i];
+        return pmin((Float)v * 0x1.0p-32f, ONE_MINUS_EPSILON);
+    }
+    uint64_t index_for_sample(uint64_t s) const { return interval_to_index((uint32_t)log2_res, s, cur_x - bounds[0], cur_y - bounds[1]); }
+    Float sample_dimension(uint64_t index, uint32_t dim) const {  // sobol.rs:77-93
+        Float s = sobol_sample(index, dim);
+        if (dim == 0 || dim == 1) {
+            s = s * (Float)resolution + (Float)bounds[dim];
+            s = pclamp(s - (Float)(dim == 0 ? cur_x : cur_y), 0.0f, ONE_MINUS_EPSILON);
+        }
+        return s;
+    }
+    void start_pixel(int x, int y) { cur_x = x; cur_y = y; sample_num = 0; dimension = 0; interval_index = index_for_sample(0); }
+    bool start_next_sample() { dimension = 0; interval_index = index_for_sample(sample_num + 1); sample_num++; return sample_num < spp; }
+    void set_sample_number(uint32_t s) { dimension = 0; interval_index = index_for_sample(s); sample_num = s; }
+    Float get_1d() { Float p = sample_dimension(interval_index, dimension); dimension += 1; return p; }
+    V2 get_2d() {
+        if (dimension + 1 >= 5 && dimension < 5) dimension = 5;
+        V2 p(sample_dimension(interval_index, dimension), sample_dimension(interval_index, dimension + 1));
+        dimension += 2;
+        return p;
+    }
+};
+
+// =============================== sampling routines (core/src/sampling/common.rs) ==================================
+inline V2 concentric_sample_disk(V2 u) {  // :138-155
+    V2 uo(2.0f * u.x - 1.0f, 2.0f * u.y - 1.0f);
+    if (uo.x == 0.0f && uo.y == 0.0f) return V2(0, 0);
+    Float r, theta;
+    if (pabs(uo.x) > pabs(uo.y)) { r = uo.x; theta = PI_OVER_FOUR * (uo.y / uo.x); }
+    else { r = uo.y; theta = PI_OVER_TWO - PI_OVER_FOUR * (uo.x / uo.y); }
+    return V2(r * o_cos(theta), r * o_sin(theta));
+}
+inline V3 cosine_sample_hemisphere(V2 u) {  // :207-211
+    V2 d = concentric_sample_disk(u);
+    Float z = std::sqrt(pmax(0.0f, 1.0f - d.x * d.x - d.y * d.y));
+    return V3(d.x, d.y, z);
+}
+inline V2 uniform_sample_triangle(V2 u) { Float su0 = std::sqrt(u.x); return V2(1.0f - su0, u.y * su0); }  // :198-201
+inline Float power_heuristic(int nf, Float fp, int ng, Float gp) {  // :239-243
+    Float f = (Float)nf * fp, g = (Float)ng * gp;
+    return (f * f) / (f * f + g * g);
+}
+
+// Distribution1D for small fixed sizes (core/src/sampling/distribution_1d.rs:22-95)
+struct Dist1D {
+    std::vector<Float> func, cdf; Float func_int = 0;
+    void init(const std::vector<Float>& f) {
+        func = f; size_t n = f.size(); cdf.assign(n + 1, 0.0f);
+        for (size_t i = 1; i < n + 1; i++) cdf[i] = cdf[i - 1] + f[i - 1] / (Float)n;
+        func_int = cdf[n];
+        if (func_int == 0.0f) for (size_t i = 1; i < n + 1; i++) cdf[i] = (Float)i / (Float)n;
+        else for (size_t i = 1; i < n + 1; i++) cdf[i] /= func_int;
+    }
+    size_t count() const { return func.size(); }
+    Float sample_continuous(Float u, Float& pdf, size_t& off) const {
+        size_t offset = find_interval(cdf.size(), [&](size_t i) { return cdf[i] <= u; });
+        Float du = u - cdf[offset];
+        if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
+        pdf = func_int > 0.0f ? func[offset] / func_int : 0.0f;
+        off = offset;
+        return ((Float)offset + du) / (Float)count();
+    }
+    size_t sample_discrete(Float u, Float& pdf) const {
+        size_t offset = find_interval(cdf.size(), [&](size_t i) { return cdf[i] <= u; });
+        pdf = func_int > 0.0f ? func[offset] / (func_int * (Float)count()) : 0.0f;
+        return offset;
+    }
+};
+
+// =============================== lights ===========================================================================
+// constant-L InfiniteAreaLight: 1x1 MIPMap::triangle (core/src/mipmap/mod.rs:293-311, texel :580-608)
+inline Spec infinite_lookup(const Spec& tx, V2 st) {
+    Float s = st.x * 1.0f - 0.5f, t = st.y * 1.0f - 0.5f;
+    Float s0 = std::floor(s), t0 = std::floor(t);  // `as isize` then back `as Float`: exact for these magnitudes
+    Float ds = s - s0, dt = t - t0;
+    return tx * (1.0f - ds) * (1.0f - dt) + tx * (1.0f - ds) * dt + tx * ds * (1.0f - dt) + tx * ds * dt;
+}
+inline void infinite_light_setup(Light& l) {  // lights/src/infinite.rs:63-107, 326-369
+    Float img[2][2];
+    for (int v = 0; v < 2; v++) {
+        Float vp = ((Float)v + 0.5f) / 2.0f;
+        Float sin_theta = std::sin(PI * ((Float)v + 0.5f) / 2.0f);
+        for (int u = 0; u < 2; u++) {
+            Float up = ((Float)u + 0.5f) / 2.0f;
+            img[v][u] = infinite_lookup(l.L, V2(up, vp)).y() * sin_theta;
+        }
+    }
+    Dist1D d; std::vector<Float> marg;
+    for (int v = 0; v < 2; v++) {
+        d.init({img[v][0], img[v][1]});
+        for (int i = 0; i < 2; i++) l.cond_func[v][i] = d.func[i];
+        for (int i = 0; i < 3; i++) l.cond_cdf[v][i] = d.cdf[i];
+        l.cond_int[v] = d.func_int; marg.push_back(d.func_int);
+    }
+    d.init(marg);
+    for (int i = 0; i < 2; i++) l.marg_func[i] = d.func[i];
+    for (int i = 0; i < 3; i++) l.marg_cdf[i] = d.cdf[i];
+    l.marg_int = d.func_int;
+}
+inline Float dist2_sample_continuous(const Float func[2], const Float cdf[3], Float func_int, Float u, Float& pdf, size_t& off) {
+    size_t offset = find_interval(3, [&](size_t i) { return cdf[i] <= u; });
+    Float du = u - cdf[offset];
+    if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
+    pdf = func_int > 0.0f ? func[offset] / func_int : 0.0f;
+    off = offset;
+    return ((Float)offset + du) / 2.0f;
+}
+
+struct SurfaceHit {  // the fields of Hit/SurfaceInteraction/Shading the path integrator consumes
+    V3 p, p_error, wo, n;   // Hit (core/src/interaction/mod.rs:107-125)
+    V3 ns, dpdu_s;          // shading.n, shading.dpdu
+    Float time;
+    uint32_t prim;
+};
+
+// Ray::offset_origin (core/src/geometry/ray.rs:107-127)
+inline V3 offset_origin(V3 p, V3 p_error, V3 n, V3 w) {
+    Float d = dot(vabs(n), p_error);
+    V3 offset = d * n;
+    if (dot(w, n) < 0.0f) offset = -offset;
+    V3 po = p + offset;
+    for (int a = 0; a < 3; a++) {
+        if (offset[a] > 0.0f) po[a] = next_float_up(po[a]);
+        else if (offset[a] < 0.0f) po[a] = next_float_down(po[a]);
+    }
+    return po;
+}
+inline Ray spawn_ray(const V3& p, const V3& p_error, const V3& n, Float time, V3 d) {  // interaction/mod.rs:189-192
+    return Ray(offset_origin(p, p_error, n, d), d, INF, time);
+}
+// Hit::spawn_ray_to_hit (interaction/mod.rs:212-223)
+inline Ray spawn_ray_to_hit(const V3& p, const V3& p_error, const V3& n, Float time, const V3& hp, const V3& hperr, const V3& hn) {
+    V3 origin = offset_origin(p, p_error, n, hp - p);
+    V3 target = offset_origin(hp, hperr, hn, origin - hp);
+    return Ray(origin, target - origin, 1.0f - SHADOW_EPSILON, time);
+}
+
+struct LiSample { V3 wi; Float pdf; Spec value; V3 vp, vperr, vn; bool valid; };  // Li + VisibilityTester.p1
+
+struct RenderStats {
+    std::atomic<uint64_t> camera_rays{0}, regular_rays{0}, shadow_rays{0}, zero_paths{0}, total_paths{0};
+    std::atomic<uint64_t> nv_regular{0}, nt_regular{0}, nv_shadow{0}, nt_shadow{0};
+};
+
+struct RayRecorder {  // optional capture of every ray handed to Scene::intersect / intersect_p
+    std::mutex mu; std::vector<Ray> regular, shadow; size_t cap = 0;
+    void add(std::vector<Ray>& v, const Ray& r) { std::lock_guard<std::mutex> g(mu); if (v.size() < cap) v.push_back(r); }
+};
+
+struct Camera {  // cameras/src/perspective_camera.rs
+    Transform raster_to_camera, camera_to_world;
+    Float lens_radius = 0, focal_distance = 1e6f, shutter_open = 0, shutter_close = 1;
+};
+struct FilmCfg {
+    int xres = 0, yres = 0; int crop[4] = {0, 0, 0, 0};
+    Float radius[2] = {0.5f, 0.5f}; Float table[256]; Float scale = 1.0f, max_lum = INF;
+};
+
+struct Renderer {
+    Scene* sc = nullptr;
+    Camera cam; FilmCfg film; SamplerConfig scfg;
+    int max_depth = 5; Float rr_threshold = 1.0f; int light_strategy = 0;
+    int pixel_bounds[4] = {0, 0, 0, 0};
+    Dist1D light_distrib;
+    RenderStats stats; RayRecorder* rec = nullptr; bool count_traversal = false;
+
+    // ---- Scene::intersect / intersect_p with the reference's counters (core/src/scene.rs:88-99)
+    bool scene_intersect(Ray& r, uint32_t& prim, TriHit& h) {
+        stats.regular_rays++;
+        if (rec) rec->add(rec->regular, r);
+        if (count_traversal) { TraversalStats ts; bool b = sc->intersect(r, prim, h, &ts); stats.nv_regular += ts.nodes_visited; stats.nt_regular += ts.tri_tests; return b; }
+        return sc->intersect(r, prim, h);
+    }
+    bool scene_intersect_p(const Ray& r) {
+        stats.shadow_rays++;
+        if (rec) rec->add(rec->shadow, r);
+        if (count_traversal) { TraversalStats ts; bool b = sc->intersect_p(r, &ts); stats.nv_shadow += ts.nodes_visited; stats.nt_shadow += ts.tri_tests; return b; }
+        return sc->intersect_p(r);
+    }
+
+    // ---- tail of Triangle::intersect (triangle.rs:547-724) + Hit::new (interaction/mod.rs:137-156)
+    SurfaceHit make_surface_hit(const Ray& r, uint32_t prim, const TriHit& h) const {
+        const Scene& s = *sc; const Mesh& m = s.mesh_of(prim);
+        uint32_t i0 = s.idx[3 * prim], i1 = s.idx[3 * prim + 1], i2 = s.idx[3 * prim + 2];
+        V3 p0 = s.P[i0], p1 = s.P[i1], p2 = s.P[i2];
+        Float b0 = h.b0, b1 = h.b1, b2 = h.b2;
+        SurfaceHit si; si.prim = prim; si.time = r.time;
+        V3 dpdu, dpdv; s.tri_dpdu_dpdv(prim, dpdu, dpdv);
+        V3 dp02 = p0 - p2, dp12 = p1 - p2;
+        Float xs = std::fabs(b0 * p0.x) + std::fabs(b1 * p1.x) + std::fabs(b2 * p2.x);
+        Float ys = std::fabs(b0 * p0.y) + std::fabs(b1 * p1.y) + std::fabs(b2 * p2.y);
+        Float zs = std::fabs(b0 * p0.z) + std::fabs(b1 * p1.z) + std::fabs(b2 * p2.z);
+        si.p_error = gamma_n(7) * V3(xs, ys, zs);
+        si.p = b0 * p0 + b1 * p1 + b2 * p2;
+        V3 wo = -r.d; Float l2 = length_squared(wo);
+        si.wo = (l2 == 0.0f) ? wo : wo / std::sqrt(l2);
+        si.n = normalize(cross(dp02, dp12));
+        if (m.reverse_orientation ^ m.swaps_handedness) si.n = -si.n;
+        si.ns = si.n; si.dpdu_s = dpdu;
+        if (m.has_n || m.has_s) {  // :631-721
+            V3 ns;
+            if (m.has_n) {
+                V3 ns2 = b0 * s.N[i0] + b1 * s.N[i1] + b2 * s.N[i2];
+                ns = length_squared(ns2) > 0.0f ? normalize(ns2) : si.n;
+            } else ns = si.n;
+            V3 ss;
+            if (m.has_s) {
+                V3 ss2 = b0 * s.S[i0] + b1 * s.S[i1] + b2 * s.S[i2];
+                ss = length_squared(ss2) > 0.0f ? normalize(ss2) : normalize(dpdu);
+            } else ss = normalize(dpdu);
+            V3 ts = cross(ss, ns);
+            if (length_squared(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
+            else coordinate_system(ns, ss, ts);
+            if (m.reverse_orientation) ts = -ts;
+            // set_shading_geometry(ss, ts, .., true) (surface_interaction.rs:152-173)
+            si.ns = normalize(cross(ss, ts));
+            si.n = face_forward(si.n, si.ns);
+            si.dpdu_s = ss;
+        }
+        return si;
+    }
+
+    // ---- lights ------------------------------------------------------------------------------------------------
+    Spec area_L(const Light& l, V3 n, V3 w) const { return (l.two_sided || dot(n, w) > 0.0f) ? l.L : Spec(0.0f); }  // diffuse.rs:220-226
+    Spec light_le(const Light& l, const Ray& ray) const {  // Light::le: infinite.rs:188-195; others Spectrum::ZERO
+        if (l.type != L_INFINITE) return Spec(0.0f);
+        V3 w = normalize(l.l2w.inv().vector(ray.d));
+        V2 st(spherical_phi(w) * INV_TWO_PI, spherical_theta(w) * INV_PI);
+        return infinite_lookup(l.L, st);
+    }
+    LiSample light_sample_li(const Light& l, const SurfaceHit& hit, V2 u) const {
+        LiSample r; r.valid = false; r.pdf = 0; r.vn = V3(); r.vperr = V3();
+        const Scene& s = *sc;
+        switch (l.type) {
+        case L_INFINITE: {  // infinite.rs:133-173
+            Float pdf1, pdf0; size_t v, dummy;
+            Float d1 = dist2_sample_continuous(l.marg_func, l.marg_cdf, l.marg_int, u.y, pdf1, v);
+            Float d0 = dist2_sample_continuous(l.cond_func[v], l.cond_cdf[v], l.cond_int[v], u.x, pdf0, dummy);
+            Float map_pdf = pdf0 * pdf1;
+            if (map_pdf == 0.0f) return r;
+            Float theta = d1 * PI, phi = d0 * TWO_PI;
+            Float cos_theta = o_cos(theta), sin_theta = o_sin(theta), sin_phi = o_sin(phi), cos_phi = o_cos(phi);
+            r.wi = l.l2w.vector(V3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
+            r.pdf = map_pdf / (TWO_PI * PI * sin_theta);
+            if (sin_theta == 0.0f) r.pdf = 0.0f;
+            r.vp = hit.p + r.wi * (2.0f * s.world_radius);
+            r.value = infinite_lookup(l.L, V2(d0, d1));
+            r.valid = true; return r;
+        }
+        case L_DISTANT:  // distant.rs:87-96
+            r.wi = l.w_light; r.pdf = 1.0f; r.vp = hit.p + l.w_light * (2.0f * s.world_radius); r.value = l.L; r.valid = true; return r;
+        case L_POINT:    // point.rs:83-93
+            r.wi = normalize(l.p_light - hit.p); r.pdf = 1.0f; r.vp = l.p_light;
+            r.value = l.L / distance_squared(l.p_light, hit.p); r.valid = true; return r;
+        case L_AREA: {   // diffuse.rs:114-129 -> Shape::sample_solid_angle (shape.rs:64-84) -> Triangle::sample (triangle.rs:918-949)
+            uint32_t prim = l.prim; const Mesh& m = s.mesh_of(prim);
+            uint32_t i0 = s.idx[3 * prim], i1 = s.idx[3 * prim + 1], i2 = s.idx[3 * prim + 2];
+            V3 p0 = s.P[i0], p1 = s.P[i1], p2 = s.P[i2];
+            V2 b = uniform_sample_triangle(u);
+            V3 p = b.x * p0 + b.y * p1 + (1.0f - b.x - b.y) * p2;
+            V3 n = normalize(cross(p1 - p0, p2 - p0));
+            if (m.has_n) {
+                V3 ns = b.x * s.N[i0] + b.y * s.N[i1] + (1.0f - b.x - b.y) * s.N[i2];
+                n = face_forward(n, ns);
+            } else if (m.reverse_orientation ^ m.swaps_handedness) n = n * -1.0f;
+            V3 a0 = vabs(b.x * p0), a1 = vabs(b.y * p1), a2 = vabs((1.0f - b.x - b.y) * p2);
+            V3 p_abs_sum = a0 + a1 + a2;
+            V3 p_error = gamma_n(6) * V3(p_abs_sum.x, p_abs_sum.y, p_abs_sum.z);
+            Float pdf = 1.0f / l.area;
+            V3 wi = p - hit.p;
+            if (length_squared(wi) == 0.0f) pdf = 0.0f;
+            else {
+                wi = normalize(wi);
+                pdf *= distance_squared(hit.p, p) / abs_dot(n, -wi);
+                if (std::isinf(pdf)) pdf = 0.0f;
+            }
+            V3 wi2 = p - hit.p; Float l2 = length_squared(wi2);
+            if (pdf == 0.0f || l2 == 0.0f) return r;
+            wi2 = wi2 / std::sqrt(l2);
+            r.wi = wi2; r.pdf = pdf; r.value = area_L(l, n, -wi2); r.vp = p; r.vperr = p_error; r.vn = n; r.valid = true; return r;
+        }
+        }
+        return r;
+    }
+    Float light_pdf_li(const Light& l, const SurfaceHit& hit, V3 wi) const {
+        const Scene& s = *sc;
+        if (l.type == L_INFINITE) {  // infinite.rs:201-211
+            V3 w = l.l2w.inv().vector(wi);
+            Float theta = spherical_theta(w), phi = spherical_phi(w), sin_theta = o_sin(theta);
+            if (sin_theta == 0.0f) return 0.0f;
+            V2 p(phi * INV_TWO_PI, theta * INV_PI);  // Distribution2D::pdf (distribution_2d.rs:51-65)
+            size_t iu = pclamp<size_t>(f2usize(p.x * 2.0f), 0, 1), iv = pclamp<size_t>(f2usize(p.y * 2.0f), 0, 1);
+            return (l.cond_func[iv][iu] / l.marg_int) / (TWO_PI * PI * sin_theta);
+        }
+        if (l.type == L_AREA) {  // Shape::pdf_solid_angle (shape.rs:86-107)
+            Ray ray = spawn_ray(hit.p, hit.p_error, hit.n, hit.time, wi);
+            TriHit h;
+            if (!s.tri_intersect(ray, l.prim, false, false, h)) return 0.0f;
+            SurfaceHit li = make_surface_hit(ray, l.prim, h);
+            Float pdf = distance_squared(hit.p, li.p) / (abs_dot(li.n, -wi) * l.area);
+            return std::isinf(pdf) ? 0.0f : pdf;
+        }
+        return 0.0f;
+    }
+    Spec light_power(const Light& l) const {
+        const Scene& s = *sc;
+        switch (l.type) {
+        case L_INFINITE: return PI * s.world_radius * s.world_radius * infinite_lookup(l.L, V2(0.5f, 0.5f));  // infinite.rs:176-183
+        case L_DISTANT: return l.L * PI * s.world_radius * s.world_radius;                                      // distant.rs:98-101
+        case L_POINT: return (4.0f * PI) * l.L;                                                                 // point.rs:95-97
+        default: return (l.two_sided ? 2.0f : 1.0f) * l.L * l.area * PI;                                        // diffuse.rs:131-134
+        }
+    }
+
+    // ---- BSDF for MatteMaterial (materials/src/matte.rs:47-76, core/src/reflection/bsdf.rs) ------------------------
+    struct BSDF {
+        V3 ns, ng, ss, ts; Spec r; bool has_bxdf; bool oren; Float a, b;
+        V3 w2l(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
+        V3 l2w(V3 v) const {
+            return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
+        }
+        static Float sin2(V3 w) { return pmax(0.0f, 1.0f - w.z * w.z); }
+        static Float sinth(V3 w) { return std::sqrt(sin2(w)); }
+        static Float cosphi(V3 w) { Float s = sinth(w); return s == 0.0f ? 1.0f : pclamp(w.x / s, -1.0f, 1.0f); }
+        static Float sinphi(V3 w) { Float s = sinth(w); return s == 0.0f ? 0.0f : pclamp(w.y / s, -1.0f, 1.0f); }
+        Spec bxdf_f(V3 wo, V3 wi) const {
+            if (!oren) return r * INV_PI;  // lambertian_reflection.rs:38-40
+            Float sin_i = sinth(wi), sin_o = sinth(wo), max_cos = 0.0f;  // oren_nayar.rs:46-72
+            if (sin_i > 1e-4f && sin_o > 1e-4f) {
+                Float d_cos = cosphi(wi) * cosphi(wo) + sinphi(wi) * sinphi(wo);
+                max_cos = pmax(0.0f, d_cos);
+            }
+            Float aco = pabs(wo.z), aci = pabs(wi.z), sin_alpha, tan_beta;
+            if (aci > aco) { sin_alpha = sin_o; tan_beta = sin_i / aci; }
+            else { sin_alpha = sin_i; tan_beta = sin_o / aco; }
+            return r * INV_PI * (a + b * max_cos * sin_alpha * tan_beta);
+        }
+        static Float bxdf_pdf(V3 wo, V3 wi) { return (wo.z * wi.z > 0.0f) ? pabs(wi.z) * INV_PI : 0.0f; }  // reflection/mod.rs:160-166
+        // BSDF::f (bsdf.rs:133-158); one REFLECTION|DIFFUSE lobe, flags = all or all & !SPECULAR (both match)
+        Spec f(V3 wo_w, V3 wi_w) const {
+            V3 wi = w2l(wi_w), wo = w2l(wo_w);
+            if (wo.z == 0.0f) return Spec(0.0f);
+            bool reflect = dot(wi_w, ng) * dot(wo_w, ng) > 0.0f;
+            Spec out(0.0f);
+            if (has_bxdf && reflect) out += bxdf_f(wo, wi);
+            return out;
+        }
+        Float pdf(V3 wo_w, V3 wi_w) const {  // bsdf.rs:331-356
+            if (!has_bxdf) return 0.0f;
+            V3 wo = w2l(wo_w), wi = w2l(wi_w);
+            if (wo.z == 0.0f) return 0.0f;
+            Float p = 0.0f; p += bxdf_pdf(wo, wi);
+            return p / 1.0f;
+        }
+        // BSDF::sample_f (bsdf.rs:194-292)
+        bool sample_f(V3 wo_w, V2 u, Spec& f_out, Float& pdf_out, V3& wi_out) const {
+            f_out = Spec(0.0f); pdf_out = 0.0f; wi_out = V3();
+            if (!has_bxdf) return false;
+            size_t comp = pmin<size_t>(f2usize(std::floor(u.x * 1.0f)), 0);
+            V2 ur(pmin(u.x * 1.0f - (Float)comp, ONE_MINUS_EPSILON), u.y);
+            V3 wo = w2l(wo_w);
+            if (wo.z == 0.0f) return false;
+            V3 wi = cosine_sample_hemisphere(ur);  // reflection/mod.rs:132-141
+            if (wo.z < 0.0f) wi.z *= -1.0f;
+            Float pdf = bxdf_pdf(wo, wi);
+            Spec fv = bxdf_f(wo, wi);
+            if (pdf == 0.0f) return false;
+            V3 wi_w = l2w(wi);
+            bool reflect = dot(wi_w, ng) * dot(wo_w, ng) > 0.0f;
+            fv = Spec(0.0f);
+            if (reflect) fv += bxdf_f(wo, wi);
+            f_out = fv; pdf_out = pdf; wi_out = wi_w;
+            return true;
+        }
+    };
+    BSDF make_bsdf(const SurfaceHit& si) const {
+        const Material& m = sc->materials[sc->mesh_of(si.prim).material];
+        BSDF b; b.ns = si.ns; b.ng = si.n; b.ss = normalize(si.dpdu_s); b.ts = cross(b.ns, b.ss);  // bsdf.rs:100-116
+        Spec r(pclamp(m.kd.c[0], 0.0f, INF), pclamp(m.kd.c[1], 0.0f, INF), pclamp(m.kd.c[2], 0.0f, INF));
+        Float sig = pclamp(m.sigma, 0.0f, 90.0f);
+        b.r = r; b.has_bxdf = !r.is_black(); b.oren = sig != 0.0f; b.a = b.b = 0;
+        if (b.oren) {  // oren_nayar.rs:28-39
+            Float s = to_radians(sig), s2 = s * s;
+            b.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
+            b.b = 0.45f * s2 / (s2 + 0.09f);
+        }
+        return b;
+    }
+
+    // ---- estimate_direct + uniform_sample_one_light (core/src/integrator/common.rs:89-299) -----------------------
+    template <class S> Spec uniform_sample_one_light(const SurfaceHit& hit, const BSDF& bsdf, S& sampler) {
+        const Scene& s = *sc;
+        size_t n_lights = s.lights.size();
+        if (n_lights == 0) return Spec(0.0f);
+        Float sample = sampler.get_1d(), light_pdf;
+        size_t light_num = light_distrib.sample_discrete(sample, light_pdf);  // lookup() always Some (uniform.rs / power.rs)
+        if (light_pdf == 0.0f) return Spec(0.0f);
+        const Light& light = s.lights[light_num];
+        V2 u_light = sampler.get_2d(), u_scattering = sampler.get_2d();
+        Spec est = estimate_direct(hit, bsdf, u_scattering, light, (int)light_num, u_light);
+        return est / light_pdf;
+    }
+    Spec estimate_direct(const SurfaceHit& hit, const BSDF& bsdf, V2 u_scattering, const Light& light, int light_num, V2 u_light) {
+        const Scene& s = *sc;
+        Spec ld(0.0f);
+        Float scattering_pdf = 0.0f;
+        LiSample ls = light_sample_li(light, hit, u_light);
+        V3 wi = ls.valid ? ls.wi : V3(); Float light_pdf = ls.valid ? ls.pdf : 0.0f; Spec li = ls.valid ? ls.value : Spec(0.0f);
+        bool is_delta = light.type == L_DISTANT || light.type == L_POINT;
+        if (light_pdf > 0.0f && !li.is_black()) {
+            Spec f = bsdf.f(hit.wo, wi) * abs_dot(wi, hit.ns);
+            scattering_pdf = bsdf.pdf(hit.wo, wi);
+            if (!f.is_black()) {
+                Ray sr = spawn_ray_to_hit(hit.p, hit.p_error, hit.n, hit.time, ls.vp, ls.vperr, ls.vn);
+                if (scene_intersect_p(sr)) li = Spec(0.0f);
+                if (!li.is_black()) {
+                    if (is_delta) ld += f * li / light_pdf;
+                    else { Float weight = power_heuristic(1, light_pdf, 1, scattering_pdf); ld += f * li * weight / light_pdf; }
+                }
+            }
+        }
+        if (!is_delta) {
+            Spec f1; Float scatter_pdf; V3 wi2;
+            bsdf.sample_f(hit.wo, u_scattering, f1, scatter_pdf, wi2);  // on failure: BxDFSample::default() = zeros
+            scattering_pdf = scatter_pdf; wi = wi2;
+            Spec f = f1 * abs_dot(wi, hit.ns);
+            if (!f.is_black() && scattering_pdf > 0.0f) {
+                Float lp = light_pdf_li(light, hit, wi);
+                if (lp == 0.0f) return ld;
+                Float weight = power_heuristic(1, scattering_pdf, 1, lp);
+                Ray ray = spawn_ray(hit.p, hit.p_error, hit.n, hit.time, wi);
+                uint32_t prim; TriHit h;
+                Spec li2(0.0f);
+                if (scene_intersect(ray, prim, h)) {
+                    const Mesh& m = s.mesh_of(prim);
+                    if (m.first_light >= 0 && (int)(m.first_light + (prim - m.tri_base)) == light_num) {
+                        SurfaceHit lh = make_surface_hit(ray, prim, h);
+                        li2 = area_L(light, lh.n, -wi);  // SurfaceInteraction::le (surface_interaction.rs:283-289)
+                    }
+                } else li2 = light_le(light, ray);
+                if (!li2.is_black()) ld += f * li2 * Spec(1.0f) * weight / scattering_pdf;
+            }
+        }
+        return ld;
+    }
+
+    // ---- PathIntegrator::li (integrators/src/path.rs:103-284) ------------------------------------------------------
+    template <class S> Spec li(Ray ray, S& sampler) {
+        const Scene& s = *sc;
+        Spec L(0.0f), beta(1.0f);
+        bool specular_bounce = false;
+        Float eta_scale = 1.0f;
+        int bounces = 0;
+        for (;;) {
+            uint32_t prim; TriHit h;
+            bool found = scene_intersect(ray, prim, h);
+            SurfaceHit isect;
+            if (found) isect = make_surface_hit(ray, prim, h);
+            if (bounces == 0 || specular_bounce) {
+                if (found) {
+                    const Mesh& m = s.mesh_of(prim);
+                    Spec le(0.0f);
+                    if (m.first_light >= 0) le = area_L(s.lights[m.first_light + (prim - m.tri_base)], isect.n, -ray.d);
+                    L += beta * le;
+                } else {
+                    for (int li_ : s.infinite_lights) L += beta * light_le(s.lights[li_], ray);
+                }
+            }
+            if (!found || bounces >= max_depth) break;
+            BSDF bsdf = make_bsdf(isect);  // materials always present in scope
+            V3 shading_n = isect.ns;
+            if (bsdf.has_bxdf) {  // num_components(all & !SPECULAR) > 0
+                stats.total_paths++;
+                Spec ld = beta * uniform_sample_one_light(isect, bsdf, sampler);
+                if (ld.is_black()) stats.zero_paths++;
+                L += ld;
+            }
+            V2 u = sampler.get_2d();
+            V3 wo = -ray.d, wi; Spec f; Float pdf;
+            bsdf.sample_f(wo, u, f, pdf, wi);
+            if (f.is_black() || pdf == 0.0f) break;
+            beta *= f * abs_dot(wi, shading_n) / pdf;
+            specular_bounce = false;
+            ray = spawn_ray(isect.p, isect.p_error, isect.n, isect.time, wi);
+            Spec rr_beta = beta * eta_scale;
+            if (rr_beta.max_component_value() < rr_threshold && bounces > 3) {
+                Float q = pmax(0.05f, 1.0f - rr_beta.max_component_value());
+                if (sampler.get_1d() < q) break;
+                beta = beta / (1.0f - q);
+            }
+            bounces++;
+        }
+        return L;
+    }
+
+    // ---- camera (perspective_camera.rs:144-204 + Transform::transform_ray transform.rs:451-476) ---------------------
+    Ray generate_ray(V2 p_film, Float time_s, V2 p_lens_s) const {
+        V3 p_camera = cam.raster_to_camera.point(V3(p_film.x, p_film.y, 0.0f));
+        Ray ray(V3(0, 0, 0), normalize(p_camera), INF, lerp(time_s, cam.shutter_open, cam.shutter_close));
+        if (cam.lens_radius > 0.0f) {
+            V2 cd = concentric_sample_disk(p_lens_s);
+            V2 p_lens(cam.lens_radius * cd.x, cam.lens_radius * cd.y);
+            Float ft = cam.focal_distance / ray.d.z;
+            V3 p_focus = ray.o + ray.d * ft;
+            ray.o = V3(p_lens.x, p_lens.y, 0.0f);
+            ray.d = normalize(p_focus - ray.o);
+        }
+        V3 o_err; V3 o = cam.camera_to_world.point_with_error(ray.o, o_err);
+        V3 d = cam.camera_to_world.vector(ray.d);
+        Float l2 = length_squared(d), t_max = ray.t_max;
+        if (l2 > 0.0f) { Float dt = dot(vabs(d), o_err) / l2; o = o + d * dt; t_max -= dt; }  // quirk B2
+        return Ray(o, d, t_max, ray.time);
+    }
+
+    // ---- Film ---------------------------------------------------------------------------------------------------
+    struct FilmTile { int b[4]; std::vector<Float> contrib, wsum; };  // contrib rgb
+    void sample_bounds(int out[4]) const {  // film/mod.rs:150-159
+        out[0] = f2i32(std::floor((Float)film.crop[0] + 0.5f - film.radius[0]));
+        out[1] = f2i32(std::floor((Float)film.crop[1] + 0.5f - film.radius[1]));
+        out[2] = f2i32(std::ceil((Float)film.crop[2] - 0.5f + film.radius[0]));
+        out[3] = f2i32(std::ceil((Float)film.crop[3] - 0.5f + film.radius[1]));
+    }
+    FilmTile get_film_tile(const int sb[4]) const {  // film/mod.rs:182-198
+        FilmTile t;
+        int p0x = f2i32(std::ceil((Float)sb[0] - 0.5f - film.radius[0])), p0y = f2i32(std::ceil((Float)sb[1] - 0.5f - film.radius[1]));
+        int p1x = f2i32(std::floor((Float)sb[2] - 0.5f + film.radius[0])) + 1, p1y = f2i32(std::floor((Float)sb[3] - 0.5f + film.radius[1])) + 1;
+        t.b[0] = pmax(p0x, film.crop[0]); t.b[1] = pmax(p0y, film.crop[1]);
+        t.b[2] = pmin(p1x, film.crop[2]); t.b[3] = pmin(p1y, film.crop[3]);
+        int w = t.b[2] - t.b[0], hgt = t.b[3] - t.b[1];
+        size_t n = (w > 0 && hgt > 0) ? (size_t)w * hgt : 0;
+        t.contrib.assign(3 * n, 0.0f); t.wsum.assign(n, 0.0f);
+        return t;
+    }
+    void add_sample(FilmTile& t, V2 p_film, Spec l, Float sample_weight) const {  // film_tile.rs:62-108
+        Float ly = l.y();
+        if (ly > film.max_lum) l = l * film.max_lum / ly;
+        V2 pd(p_film.x - 0.5f, p_film.y - 0.5f);
+        int p0x = f2i32(std::ceil(pd.x - film.radius[0])), p0y = f2i32(std::ceil(pd.y - film.radius[1]));
+        int p1x = f2i32(std::floor(pd.x + film.radius[0])) + 1, p1y = f2i32(std::floor(pd.y + film.radius[1])) + 1;
+        p0x = pmax(p0x, t.b[0]); p0y = pmax(p0y, t.b[1]); p1x = pmin(p1x, t.b[2]); p1y = pmin(p1y, t.b[3]);
+        Float inv_rx = 1.0f / film.radius[0], inv_ry = 1.0f / film.radius[1];
+        int w = t.b[2] - t.b[0];
+        for (int y = p0y; y < p1y; y++) {
+            Float fy = pabs(((Float)y - pd.y) * inv_ry * 16.0f);
+            size_t iy = f2usize(pmin(std::floor(fy), 15.0f));
+            for (int x = p0x; x < p1x; x++) {
+                Float fx = pabs(((Float)x - pd.x) * inv_rx * 16.0f);
+                size_t ix = f2usize(pmin(std::floor(fx), 15.0f));
+                Float fw = film.table[iy * 16 + ix];
+                size_t off = (size_t)(x - t.b[0]) + (size_t)(y - t.b[1]) * w;
+                Spec c = l * sample_weight * fw;
+                t.contrib[3 * off] += c.c[0]; t.contrib[3 * off + 1] += c.c[1]; t.contrib[3 * off + 2] += c.c[2];
+                t.wsum[off] += fw;
+            }
+        }
+    }
+
+    // ---- render_tile (sampler_integrator.rs:312-415) -----------------------------------------------------------------
+    template <class S> void render_tile_with(S& sampler, const int tb[4], FilmTile& ft) {
+        for (int y = tb[1]; y < tb[3]; y++)
+            for (int x = tb[0]; x < tb[2]; x++) {  // Bounds2i iteration: row-major (bounds2.rs:347-359)
+                sampler.start_pixel(x, y);
+                if (!(x >= pixel_bounds[0] && x < pixel_bounds[2] && y >= pixel_bounds[1] && y < pixel_bounds[3])) continue;
+                for (;;) {
+                    V2 fs = sampler.get_2d();
+                    V2 p_film((Float)x + fs.x, (Float)y + fs.y);
+                    Float time = sampler.get_1d();
+                    V2 p_lens = sampler.get_2d();
+                    Ray ray = generate_ray(p_film, time, p_lens);
+                    stats.camera_rays++;
+                    Spec L = li(ray, sampler);  // ray_weight is always 1.0 for the perspective camera
+                    if (L.has_nans()) L = Spec(0.0f);
+                    else if (L.y() < -1e-5f) L = Spec(0.0f);
+                    else if (std::isinf(L.y())) L = Spec(0.0f);
+                    add_sample(ft, p_film, L, 1.0f);
+                    if (!sampler.start_next_sample()) break;
+                }
+            }
+    }
+
+    void tile_bounds(int tile_idx, int ntx, const int sb[4], int tile_size, int tb[4]) const {
+        int tx = tile_idx % ntx, ty = tile_idx / ntx;
+        tb[0] = sb[0] + tx * tile_size; tb[2] = pmin(tb[0] + tile_size, sb[2]);
+        tb[1] = sb[1] + ty * tile_size; tb[3] = pmin(tb[1] + tile_size, sb[3]);
+    }
+
+    // SamplerIntegrator::render (sampler_integrator.rs:243-304).  Tiles are merged in increasing tile index
+    // (= the reference with --nthreads 1; with more threads the reference's merge order is completion order).
+    void render(int tile_size, int tile_part, int tile_parts, int n_threads, Float* out_xyz, Float* out_weight, std::vector<FilmTile>* keep_tiles = nullptr) {
+        // Integrator::preprocess: light distribution (path.rs:81-83, light_distrib/mod.rs:49-60)
+        const Scene& s = *sc;
+        std::vector<Float> lf;
+        int strat = s.lights.size() == 1 ? 0 : light_strategy;
+        for (const Light& l : s.lights) lf.push_back(strat == 0 ? 1.0f : light_power(l).y());
+        if (!lf.empty()) light_distrib.init(lf);
+        int sb[4]; sample_bounds(sb);
+        int ntx = (sb[2] - sb[0] + tile_size - 1) / tile_size, nty = (sb[3] - sb[1] + tile_size - 1) / tile_size;
+        int tile_count = ntx * nty;
+        std::vector<FilmTile> tiles(tile_count);
+        std::atomic<int> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                int t = next++;
+                if (t >= tile_count) break;
+                if (t % tile_parts != tile_part) continue;
+                int tb[4]; tile_bounds(t, ntx, sb, tile_size, tb);
+                tiles[t] = get_film_tile(tb);
+                if (scfg.kind == 0) { HaltonSampler sp(scfg); render_tile_with(sp, tb, tiles[t]); }
+                else { SobolSampler sp(scfg); render_tile_with(sp, tb, tiles[t]); }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_threads; i++) th.emplace_back(worker);
+        worker();
+        for (auto& t : th) t.join();
+        // Film::merge_film_tile (film/mod.rs:220-279)
+        int cw = film.crop[2] - film.crop[0], ch = film.crop[3] - film.crop[1];
+        size_t npx = (size_t)pmax(cw, 0) * pmax(ch, 0);
+        for (size_t i = 0; i < 3 * npx; i++) out_xyz[i] = 0.0f;
+        for (size_t i = 0; i < npx; i++) out_weight[i] = 0.0f;
+        for (int t = 0; t < tile_count; t++) {
+            if (t % tile_parts != tile_part) continue;
+            const FilmTile& ft = tiles[t];
+            int w = ft.b[2] - ft.b[0];
+            for (int y = ft.b[1]; y < ft.b[3]; y++)
+                for (int x = ft.b[0]; x < ft.b[2]; x++) {
+                    size_t to = (size_t)(x - ft.b[0]) + (size_t)(y - ft.b[1]) * w;
+                    size_t fo = (size_t)(x - film.crop[0]) + (size_t)(y - film.crop[1]) * cw;
+                    Float xyz[3]; rgb_to_xyz(&ft.contrib[3 * to], xyz);
+                    out_xyz[3 * fo] += xyz[0]; out_xyz[3 * fo + 1] += xyz[1]; out_xyz[3 * fo + 2] += xyz[2];
+                    out_weight[fo] += ft.wsum[to];
+                }
+        }
+        if (keep_tiles) *keep_tiles = std::move(tiles);
+    }
+    // Film::get_pixel_rgb (film/mod.rs:392-417), splat = 0
+    void film_to_rgb(const Float* xyz, const Float* weight, Float* rgb) const {
+        int cw = film.crop[2] - film.crop[0], ch = film.crop[3] - film.crop[1];
+        size_t npx = (size_t)pmax(cw, 0) * pmax(ch, 0);
+        for (size_t i = 0; i < npx; i++) {
+            Float c[3]; xyz_to_rgb(&xyz[3 * i], c);
+            Float zero[3] = {0, 0, 0}, srgb[3]; xyz_to_rgb(zero, srgb);
+            for (int k = 0; k < 3; k++) {
+                Float v = c[k];
+                if (weight[i] != 0.0f) { Float inv = 1.0f / weight[i]; v = pmax(0.0f, v * inv); }
+                v += 1.0f * srgb[0];  // quirk B3
+                v *= film.scale;
+                rgb[3 * i + k] = v;
+            }
+        }
+    }
+};
+
+}  // namespace orc

@@ -1,0 +1,377 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp header).
+// Scene data, BVH build + traversal, watertight triangle test.
+//   accelerators/src/bvh/{mod,common,sah}.rs, core/src/geometry/bounds3.rs, shapes/src/triangle.rs,
+//   core/src/primitives/geometric_primitive.rs
+// Third-party code on this path that is absent from /root/reference (Cargo.toml:33,36; no Cargo.lock):
+//   itertools = "0.13"  `partition` (sah.rs:229,354) — restated below from its published algorithm;
+//   order-stat = "0.1"  `kth_by`    (sah.rs:275)     — under SAH only ever called with 2 elements, where any
+//                                                       correct selection gives [smaller, larger].
+#pragma once
+#include "oracle_math.hpp"
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace orc {
+
+struct Ray {  // core/src/geometry/ray.rs:10-28 (differentials are dead for constant textures; medium out of scope)
+    V3 o, d;
+    Float t_max, time;
+    Ray() : t_max(INF), time(0) {}
+    Ray(V3 o_, V3 d_, Float tm, Float ti) : o(o_), d(d_), t_max(tm), time(ti) {}
+};
+
+struct Material { Spec kd; Float sigma; };  // materials/src/matte.rs with ConstantTexture
+
+enum LightType { L_INFINITE = 0, L_DISTANT = 1, L_POINT = 2, L_AREA = 3 };
+struct Light {
+    int type;
+    Spec L;             // infinite: lrgb; distant: emitted radiance; point: intensity; area: l_emit
+    Transform l2w;      // infinite only
+    V3 w_light;         // distant
+    V3 p_light;         // point
+    int two_sided;      // area
+    uint32_t prim;      // area: global triangle index bound to this light
+    Float area;         // area: Triangle::area()
+    // infinite: 2x2 scalar image distribution (lights/src/infinite.rs:326-369, sampling/distribution_2d.rs)
+    Float cond_func[2][2], cond_cdf[2][3], cond_int[2];
+    Float marg_func[2], marg_cdf[3], marg_int;
+};
+
+struct Mesh {
+    uint32_t vert_base, tri_base, n_verts, n_tris;
+    bool has_n, has_s, has_uv;
+    uint32_t material;
+    int32_t first_light;
+    bool reverse_orientation, swaps_handedness;
+    Float alpha, shadow_alpha;
+};
+
+struct LinearBVHNode {  // accelerators/src/bvh/common.rs:163-179 (32 bytes)
+    Bounds3 bounds;
+    uint32_t offset;
+    uint16_t n_primitives;
+    uint8_t axis, pad;
+};
+
+struct TriHit { Float t, b0, b1, b2; };
+
+struct TraversalStats { uint64_t nodes_visited = 0, tri_tests = 0, rays = 0; };
+
+struct Scene {
+    // geometry (all meshes concatenated)
+    std::vector<V3> P, N, S;
+    std::vector<V2> UV;
+    std::vector<uint32_t> idx;        // 3 per triangle, already offset by vert_base
+    std::vector<uint32_t> tri_mesh;   // mesh id per triangle
+    std::vector<Mesh> meshes;
+    std::vector<Material> materials;
+    std::vector<Light> lights;
+    std::vector<int> infinite_lights;
+    // BVH
+    std::vector<LinearBVHNode> nodes;
+    std::vector<uint32_t> ordered_prims;
+    int max_prims_in_node = 4;
+    Bounds3 world_bound;
+    V3 world_center;
+    Float world_radius = 1.0f;
+
+    size_t n_tris() const { return idx.size() / 3; }
+    const Mesh& mesh_of(uint32_t prim) const { return meshes[tri_mesh[prim]]; }
+
+    // ---- Triangle::world_bound (triangle.rs:427-431)
+    Bounds3 tri_bound(uint32_t prim) const {
+        return Bounds3(P[idx[3 * prim]]).union_p(P[idx[3 * prim + 1]]).union_p(P[idx[3 * prim + 2]]);
+    }
+    void tri_uvs(uint32_t prim, V2 uv[3]) const {  // triangle.rs:384-394
+        if (mesh_of(prim).has_uv) { uv[0] = UV[idx[3 * prim]]; uv[1] = UV[idx[3 * prim + 1]]; uv[2] = UV[idx[3 * prim + 2]]; }
+        else { uv[0] = V2(0, 0); uv[1] = V2(1, 0); uv[2] = V2(1, 1); }
+    }
+
+    // ---- Triangle::intersect up to the accept decision (triangle.rs:438-575 / 731-861).
+    // Returns true and fills `h` iff the reference would return Some(..)/true, given constant alpha textures.
+    // `test_alpha` mirrors test_alpha_texture; `shadow` selects intersect_p's extra shadow-alpha mask.
+    bool tri_intersect(const Ray& r, uint32_t prim, bool test_alpha, bool shadow, TriHit& h) const {
+        V3 p0 = P[idx[3 * prim]], p1 = P[idx[3 * prim + 1]], p2 = P[idx[3 * prim + 2]];
+        V3 p0t = p0 - r.o, p1t = p1 - r.o, p2t = p2 - r.o;
+        int kz = max_dimension(vabs(r.d));
+        int kx = kz + 1; if (kx == 3) kx = 0;   // core/src/pbrt/axis.rs:50-55
+        int ky = kx + 1; if (ky == 3) ky = 0;
+        V3 d = permute(r.d, kx, ky, kz);
+        p0t = permute(p0t, kx, ky, kz); p1t = permute(p1t, kx, ky, kz); p2t = permute(p2t, kx, ky, kz);
+        Float sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.0f / d.z;
+        p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
+        p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
+        p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+        Float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+        Float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+        Float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+        if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {  // f64 fallback :483-495
+            double a = (double)p2t.x * (double)p1t.y, b = (double)p2t.y * (double)p1t.x;
+            e0 = (Float)(b - a);
+            a = (double)p0t.x * (double)p2t.y; b = (double)p0t.y * (double)p2t.x;
+            e1 = (Float)(b - a);
+            a = (double)p1t.x * (double)p0t.y; b = (double)p1t.y * (double)p0t.x;
+            e2 = (Float)(b - a);
+        }
+        if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+        Float det = e0 + e1 + e2;
+        if (det == 0.0f) return false;
+        p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+        Float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+        if (det < 0.0f && (t_scaled >= 0.0f || t_scaled < r.t_max * det)) return false;
+        else if (det > 0.0f && (t_scaled <= 0.0f || t_scaled > r.t_max * det)) return false;
+        Float inv_det = 1.0f / det;
+        Float b0 = e0 * inv_det, b1 = e1 * inv_det, b2 = e2 * inv_det, t = t_scaled * inv_det;
+        Float max_z_t = max_component(vabs(V3(p0t.z, p1t.z, p2t.z)));
+        Float delta_z = gamma_n(3) * max_z_t;
+        Float max_x_t = max_component(vabs(V3(p0t.x, p1t.x, p2t.x)));
+        Float max_y_t = max_component(vabs(V3(p0t.y, p1t.y, p2t.y)));
+        Float delta_x = gamma_n(5) * (max_x_t + max_z_t);
+        Float delta_y = gamma_n(5) * (max_y_t + max_z_t);
+        Float delta_e = 2.0f * (gamma_n(2) * max_x_t * max_y_t + delta_y * max_x_t + delta_x * max_y_t);
+        Float max_e = max_component(vabs(V3(e0, e1, e2)));
+        Float delta_t = 3.0f * (gamma_n(3) * max_e * max_z_t + delta_e * max_z_t + delta_z * max_e) * std::fabs(inv_det);
+        if (t <= delta_t) return false;
+        // intersect(): dpdu/dpdv are always computed and a degenerate triangle rejects the hit (:548-574);
+        // intersect_p(): the same block runs only under `test_alpha && masks present` (:840-866) — the masks are
+        // always Some(ConstantTexture) (:291-312), so it runs whenever test_alpha is true.
+        const Mesh& m = mesh_of(prim);
+        if (!shadow || test_alpha) {
+            if (tri_is_bogus(prim)) return false;
+        }
+        if (test_alpha) {
+            if (m.alpha == 0.0f) return false;                    // mask.evaluate(..) == 0.0 (:603, :886)
+            if (shadow && m.shadow_alpha == 0.0f) return false;   // :891
+        }
+        h.t = t; h.b0 = b0; h.b1 = b1; h.b2 = b2;
+        return true;
+    }
+
+    // dpdu/dpdv of triangle.rs:548-574; returns false when "the intersection is bogus" (:567-570)
+    bool tri_dpdu_dpdv(uint32_t prim, V3& dpdu, V3& dpdv) const {
+        V3 p0 = P[idx[3 * prim]], p1 = P[idx[3 * prim + 1]], p2 = P[idx[3 * prim + 2]];
+        V2 uv[3]; tri_uvs(prim, uv);
+        V2 duv02(uv[0].x - uv[2].x, uv[0].y - uv[2].y), duv12(uv[1].x - uv[2].x, uv[1].y - uv[2].y);
+        V3 dp02 = p0 - p2, dp12 = p1 - p2;
+        Float determinant = duv02.x * duv12.y - duv02.y * duv12.x;
+        bool degenerate_uv = std::fabs(determinant) < 1e-8f;
+        dpdu = V3(); dpdv = V3();
+        if (!degenerate_uv) {
+            Float invdet = 1.0f / determinant;
+            dpdu = (duv12.y * dp02 - duv02.y * dp12) * invdet;
+            dpdv = (-duv12.x * dp02 + duv02.x * dp12) * invdet;
+        }
+        if (degenerate_uv || length_squared(cross(dpdu, dpdv)) == 0.0f) {
+            V3 ng = cross(p2 - p0, p1 - p0);
+            if (length_squared(ng) == 0.0f) return false;
+            coordinate_system(normalize(ng), dpdu, dpdv);
+        }
+        return true;
+    }
+    bool tri_is_bogus(uint32_t prim) const { V3 a, b; return !tri_dpdu_dpdv(prim, a, b); }
+
+    // ---- Bounds3::intersect_p_inv (bounds3.rs:292-325), incl. quirk B1 (z far plane not widened)
+    static bool box_hit(const Bounds3& b, const Ray& ray, V3 inv_dir, const int neg[3]) {
+        Float t_min = (b[neg[0]].x - ray.o.x) * inv_dir.x;
+        Float t_max = (b[1 - neg[0]].x - ray.o.x) * inv_dir.x;
+        Float t_y_min = (b[neg[1]].y - ray.o.y) * inv_dir.y;
+        Float t_y_max = (b[1 - neg[1]].y - ray.o.y) * inv_dir.y;
+        Float g3 = gamma_n(3);
+        t_max *= 1.0f + 2.0f * g3;
+        t_y_max *= 1.0f + 2.0f * g3;
+        if (t_min > t_y_max || t_y_min > t_max) return false;
+        if (t_y_min > t_min) t_min = t_y_min;
+        if (t_y_max < t_max) t_max = t_y_max;
+        Float t_z_min = (b[neg[2]].z - ray.o.z) * inv_dir.z;
+        Float t_z_max = (b[1 - neg[2]].z - ray.o.z) * inv_dir.z;
+        if (t_min > t_z_max || t_z_min > t_max) return false;
+        if (t_z_min > t_min) t_min = t_z_min;
+        if (t_z_max < t_max) t_max = t_z_max;
+        return t_min < ray.t_max && t_max > 0.0f;
+    }
+
+    // ---- BVHAccel::intersect (bvh/mod.rs:173-226) + GeometricPrimitive::intersect's r.t_max = t (:67-88)
+    bool intersect(Ray& r, uint32_t& prim_out, TriHit& hit_out, TraversalStats* st = nullptr) const {
+        bool any = false;
+        if (st) st->rays++;
+        if (nodes.empty()) return false;
+        V3 inv_dir(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+        int neg[3] = {inv_dir.x < 0.0f ? 1 : 0, inv_dir.y < 0.0f ? 1 : 0, inv_dir.z < 0.0f ? 1 : 0};
+        size_t to_visit = 0, cur = 0;
+        size_t stack[64];
+        for (;;) {
+            const LinearBVHNode& node = nodes[cur];
+            if (st) st->nodes_visited++;
+            if (box_hit(node.bounds, r, inv_dir, neg)) {
+                if (node.n_primitives > 0) {
+                    for (uint32_t i = 0; i < node.n_primitives; i++) {
+                        uint32_t prim = ordered_prims[node.offset + i];
+                        TriHit h;
+                        if (st) st->tri_tests++;
+                        if (tri_intersect(r, prim, true, false, h)) { r.t_max = h.t; prim_out = prim; hit_out = h; any = true; }
+                    }
+                    if (to_visit == 0) break;
+                    cur = stack[--to_visit];
+                } else {
+                    if (neg[node.axis] == 1) { stack[to_visit++] = cur + 1; cur = node.offset; }
+                    else { stack[to_visit++] = node.offset; cur = cur + 1; }
+                }
+            } else {
+                if (to_visit == 0) break;
+                cur = stack[--to_visit];
+            }
+        }
+        return any;
+    }
+    // ---- BVHAccel::intersect_p (bvh/mod.rs:231-283)
+    bool intersect_p(const Ray& r, TraversalStats* st = nullptr) const {
+        if (st) st->rays++;
+        if (nodes.empty()) return false;
+        V3 inv_dir(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+        int neg[3] = {inv_dir.x < 0.0f ? 1 : 0, inv_dir.y < 0.0f ? 1 : 0, inv_dir.z < 0.0f ? 1 : 0};
+        size_t to_visit = 0, cur = 0;
+        size_t stack[64];
+        for (;;) {
+            const LinearBVHNode& node = nodes[cur];
+            if (st) st->nodes_visited++;
+            if (box_hit(node.bounds, r, inv_dir, neg)) {
+                if (node.n_primitives > 0) {
+                    for (uint32_t i = 0; i < node.n_primitives; i++) {
+                        TriHit h;
+                        if (st) st->tri_tests++;
+                        if (tri_intersect(r, ordered_prims[node.offset + i], true, true, h)) return true;
+                    }
+                    if (to_visit == 0) break;
+                    cur = stack[--to_visit];
+                } else {
+                    if (neg[node.axis] == 1) { stack[to_visit++] = cur + 1; cur = node.offset; }
+                    else { stack[to_visit++] = node.offset; cur = cur + 1; }
+                }
+            } else {
+                if (to_visit == 0) break;
+                cur = stack[--to_visit];
+            }
+        }
+        return false;
+    }
+
+    // ================= BVH build: BVHAccel::new + sah::build (bvh/mod.rs:43-153, sah.rs:26-367) ================
+    struct PrimInfo { size_t number; Bounds3 bounds; V3 centroid; };
+
+    // itertools::partition (published algorithm, itertools 0.13 src/lib.rs `pub fn partition`)
+    template <class Pred> static size_t itertools_partition(PrimInfo* first, PrimInfo* last, Pred pred) {
+        size_t split = 0;
+        PrimInfo* front = first;
+        PrimInfo* back = last;
+        while (front != back) {
+            PrimInfo* f = front++;
+            if (!pred(*f)) {
+                bool found = false;
+                while (front != back) {
+                    PrimInfo* b = --back;
+                    if (pred(*b)) { std::swap(*f, *b); found = true; break; }
+                }
+                if (!found) return split;
+            }
+            split++;
+        }
+        return split;
+    }
+
+    static size_t sah_bucket(const Bounds3& cb, V3 c, int dim) {  // sah.rs:309-313
+        size_t b = f2usize(12.0f * cb.offset(c)[dim]);
+        if (b == 12) b = 11;
+        return b;
+    }
+
+    // returns node index; split_method: 0 SAH, 2 middle (quirk B6), 3 equal counts
+    uint32_t build_rec(std::vector<PrimInfo>& info, size_t start, size_t end, int split_method) {
+        uint32_t my = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        Bounds3 bounds;
+        for (size_t i = start; i < end; i++) bounds = bounds.union_b(info[i].bounds);
+        size_t n = end - start;
+        auto make_leaf = [&]() {
+            uint32_t first = (uint32_t)ordered_prims.size();
+            for (size_t i = start; i < end; i++) ordered_prims.push_back((uint32_t)info[i].number);
+            nodes[my].bounds = bounds; nodes[my].offset = first; nodes[my].n_primitives = (uint16_t)n; nodes[my].axis = 0; nodes[my].pad = 0;
+            return my;
+        };
+        if (n == 1) return make_leaf();
+        Bounds3 cb;
+        for (size_t i = start; i < end; i++) cb = cb.union_p(info[i].centroid);
+        int dim = cb.maximum_extent();
+        if (cb.pmax[dim] == cb.pmin[dim]) return make_leaf();
+        size_t mid = 0; bool have_mid = true;
+        auto equal_counts = [&]() {
+            size_t m = (start + end) / 2;
+            std::nth_element(info.begin() + start, info.begin() + m, info.begin() + end,
+                             [dim](const PrimInfo& a, const PrimInfo& b) { return a.centroid[dim] < b.centroid[dim]; });
+            return m;
+        };
+        if (split_method == 3) mid = equal_counts();
+        else if (split_method == 2) {  // sah.rs:61-76 incl. quirk B6
+            Float pmid = (cb.pmin[dim] + cb.pmax[dim]) / 2.0f;
+            size_t m = start + itertools_partition(&info[start], &info[start] + n, [&](const PrimInfo& pi) { return pi.centroid[dim] < pmid; });
+            if (m != start && m != end) m = equal_counts();
+            mid = m;
+        } else if (n <= 2) {
+            mid = (start + end) / 2;  // split_equal_counts on 2 elements: [smaller, larger]
+            if (info[start + 1].centroid[dim] < info[start].centroid[dim]) std::swap(info[start], info[start + 1]);
+        } else {
+            // split_sah (sah.rs:293-367)
+            size_t count[12] = {0}; Bounds3 bb[12];
+            for (size_t i = start; i < end; i++) {
+                size_t b = sah_bucket(cb, info[i].centroid, dim);
+                count[b]++; bb[b] = bb[b].union_b(info[i].bounds);
+            }
+            Float cost[11];
+            for (int i = 0; i < 11; i++) {
+                Bounds3 b0, b1; size_t c0 = 0, c1 = 0;
+                for (int j = 0; j <= i; j++) { b0 = b0.union_b(bb[j]); c0 += count[j]; }
+                for (int j = i + 1; j < 12; j++) { b1 = b1.union_b(bb[j]); c1 += count[j]; }
+                cost[i] = 1.0f + ((Float)c0 * b0.surface_area() + (Float)c1 * b1.surface_area()) / bounds.surface_area();
+            }
+            Float min_cost = cost[0]; size_t min_b = 0;
+            for (size_t i = 1; i < 11; i++) if (cost[i] < min_cost) { min_cost = cost[i]; min_b = i; }
+            Float leaf_cost = (Float)n;
+            if (n > (size_t)max_prims_in_node || min_cost < leaf_cost) {
+                mid = start + itertools_partition(&info[start], &info[start] + n,
+                                                  [&](const PrimInfo& pi) { return sah_bucket(cb, pi.centroid, dim) <= min_b; });
+            } else have_mid = false;
+        }
+        if (!have_mid) return make_leaf();
+        if (mid == start || mid == end) {
+            // the reference recurses with start==end and hits assert_ne! (sah.rs:37): a panic.  The oracle reports it.
+            std::fprintf(stderr, "oracle: BVH split produced an empty side (reference would panic, sah.rs:37)\n");
+            return make_leaf();
+        }
+        build_rec(info, start, mid, split_method);
+        uint32_t c1 = build_rec(info, mid, end, split_method);
+        // interior bounds = c0.bounds ∪ c1.bounds (common.rs:152-160); c0 sits at my+1 (mod.rs:126-153)
+        nodes[my].bounds = nodes[my + 1].bounds.union_b(nodes[c1].bounds);
+        nodes[my].offset = c1; nodes[my].n_primitives = 0; nodes[my].axis = (uint8_t)dim; nodes[my].pad = 0;
+        return my;
+    }
+
+    void build_bvh(int split_method, int max_prims) {
+        max_prims_in_node = max_prims & 0xff;  // quirk B8: `as u8`
+        nodes.clear(); ordered_prims.clear();
+        size_t n = n_tris();
+        if (n == 0) return;
+        std::vector<PrimInfo> info(n);
+        for (size_t i = 0; i < n; i++) {
+            info[i].number = i; info[i].bounds = tri_bound((uint32_t)i);
+            info[i].centroid = 0.5f * (info[i].bounds.pmin + info[i].bounds.pmax);  // common.rs:85-91
+        }
+        nodes.reserve(2 * n); ordered_prims.reserve(n);
+        build_rec(info, 0, n, split_method);
+        world_bound = nodes[0].bounds;
+        world_bound.bounding_sphere(world_center, world_radius);  // Light::preprocess (infinite.rs:113-117, distant.rs:54-58)
+    }
+};
+
+}  // namespace orc

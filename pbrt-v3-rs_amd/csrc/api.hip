@@ -1,0 +1,584 @@
+// C ABI of include/pbrt_hip.h: scene capture, BVH build, device upload, batch traversal entry points.
+// (The render entry points live in wavefront.hip.)  No CPU fallback exists anywhere in this library: without a
+// gfx950 device pbrt_hip_scene_create returns NULL and every compute entry point fails with PBRT_HIP_ERR_NO_DEVICE.
+#include "host_math.h"
+#include "scene_host.h"
+#include "traverse.h"
+#include <algorithm>
+#include <cstdio>
+#include <mutex>
+
+static std::string g_last_error;
+static std::mutex g_err_mu;
+
+namespace phost {
+
+int set_err(PbrtHipScene* s, int code, const std::string& msg) {
+    if (s) s->err = msg;
+    else { std::lock_guard<std::mutex> g(g_err_mu); g_last_error = msg; }
+    return code;
+}
+int hip_fail(PbrtHipScene* s, hipError_t e, const char* what) {
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return set_err(s, e == hipErrorOutOfMemory ? PBRT_HIP_ERR_OOM : PBRT_HIP_ERR_DEVICE, m);
+}
+int ensure_buf(PbrtHipScene* s, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return PBRT_HIP_OK;
+    if (b.p) { PH_CHECK(s, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    if (bytes == 0) bytes = 16;
+    PH_CHECK(s, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    if (bytes <= 4096) PH_CHECK(s, hipMemset(b.p, 0, bytes));  // flags / counters start cleared
+    return PBRT_HIP_OK;
+}
+
+template <class T> static int upload_vec(PbrtHipScene* s, const std::vector<T>& v, const T** out) {
+    *out = nullptr;
+    if (v.empty()) return PBRT_HIP_OK;
+    void* d = nullptr;
+    PH_CHECK(s, hipMalloc(&d, v.size() * sizeof(T)));
+    s->owned.push_back(d);
+    PH_CHECK(s, hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s->stream));
+    *out = reinterpret_cast<const T*>(d);
+    return PBRT_HIP_OK;
+}
+
+static void free_owned(PbrtHipScene* s) {
+    for (void* p : s->owned) (void)hipFree(p);
+    s->owned.clear();
+    s->uploaded = false;
+    s->light_strategy_uploaded = -1;
+}
+
+static hm::HaltonTables& halton_tables() {
+    static hm::HaltonTables t;
+    static std::once_flag once;
+    std::call_once(once, []() { t.build(); });
+    return t;
+}
+
+int upload_scene(PbrtHipScene* s) {
+    if (s->uploaded) return PBRT_HIP_OK;
+    free_owned(s);
+    DeviceScene& d = s->ds;
+    std::memset(&d, 0, sizeof(d));
+    int rc;
+    if ((rc = upload_vec(s, s->bvh.nodes, &d.nodes))) return rc;
+    if ((rc = upload_vec(s, s->bvh.tris, &d.tris))) return rc;
+    d.root_ref = s->bvh.root_ref;
+    d.n_tris = (uint32_t)(s->idx.size() / 3);
+    for (int k = 0; k < 3; k++) { d.root_lo[k] = s->bvh.root_lo[k]; d.root_hi[k] = s->bvh.root_hi[k]; d.world_center[k] = s->world_center[k]; }
+    d.world_radius = s->world_radius;
+    if ((rc = upload_vec(s, s->P, &d.P))) return rc;
+    if (s->any_n && (rc = upload_vec(s, s->N, &d.N))) return rc;
+    if (s->any_s && (rc = upload_vec(s, s->S, &d.S))) return rc;
+    if (s->any_uv && (rc = upload_vec(s, s->UV, &d.UV))) return rc;
+    if ((rc = upload_vec(s, s->idx, &d.idx))) return rc;
+    if ((rc = upload_vec(s, s->tri_mesh, &d.tri_mesh))) return rc;
+    if ((rc = upload_vec(s, s->meshes, &d.meshes))) return rc;
+    if ((rc = upload_vec(s, s->materials, &d.materials))) return rc;
+    if ((rc = upload_vec(s, s->lights, &d.lights))) return rc;
+    d.n_lights = (uint32_t)s->lights.size();
+    if ((rc = upload_vec(s, s->infinite_lights, &d.infinite_lights))) return rc;
+    d.n_infinite = (uint32_t)s->infinite_lights.size();
+    hm::HaltonTables& ht = halton_tables();
+    if ((rc = upload_vec(s, ht.perms, &d.halton_perms))) return rc;
+    if ((rc = upload_vec(s, ht.primes, &d.primes))) return rc;
+    if ((rc = upload_vec(s, ht.prime_sums, &d.prime_sums))) return rc;
+    if ((rc = upload_vec(s, s->sobol32, &d.sobol32))) return rc;
+    if ((rc = upload_vec(s, s->vdc, &d.vdc))) return rc;
+    if ((rc = upload_vec(s, s->vdc_inv, &d.vdc_inv))) return rc;
+    PH_CHECK(s, hipStreamSynchronize(s->stream));
+    s->uploaded = true;
+    return PBRT_HIP_OK;
+}
+
+// Light::power().y() per light -> Distribution1D (core/src/integrator/common.rs:304-311); uniform = all ones
+// (core/src/light_distrib/uniform.rs:24-31).  create_light_sample_distribution forces Uniform for a single light.
+int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
+    const size_t n = s->lights.size();
+    int strat = (n == 1) ? 0 : light_strategy;
+    if (s->light_strategy_uploaded == strat) return PBRT_HIP_OK;
+    std::vector<float> f(n, 1.0f), cdf;
+    float func_int = 0.0f;
+    if (strat == 1) {
+        const float wr = s->world_radius;
+        for (size_t i = 0; i < n; i++) {
+            const LightRec& l = s->lights[i];
+            float p[3];
+            for (int c = 0; c < 3; c++) {
+                switch (l.type) {
+                case PH_L_INFINITE: {  // infinite.rs:176-183: PI * r * r * lookup_triangle((.5,.5), .5)
+                    // 1x1 MIPMap::triangle at st=(0.5,0.5): s = 0, ds = 0 -> tx*1*1 + tx*1*0 + tx*0*1 + tx*0*0
+                    float tx = l.L[c];
+                    float v = tx * (1.0f - 0.0f) * (1.0f - 0.0f) + tx * (1.0f - 0.0f) * 0.0f + tx * 0.0f * (1.0f - 0.0f) + tx * 0.0f * 0.0f;
+                    p[c] = hm::kPi * wr * wr * v;
+                    break;
+                }
+                case PH_L_DISTANT: p[c] = l.L[c] * hm::kPi * wr * wr; break;                       // distant.rs:98-101
+                case PH_L_POINT: p[c] = (hm::kPi * 4.0f) * l.L[c]; break;                          // point.rs:95-97
+                default: p[c] = (l.two_sided ? 2.0f : 1.0f) * l.L[c] * l.area * hm::kPi; break;    // diffuse.rs:131-134
+                }
+            }
+            f[i] = 0.212671f * p[0] + 0.715160f * p[1] + 0.072169f * p[2];
+        }
+    }
+    if (n) hm::distribution1d(f, cdf, func_int);
+    int rc;
+    if ((rc = ensure_buf(s, s->d_ld_func, std::max<size_t>(n, 1) * 4))) return rc;
+    if ((rc = ensure_buf(s, s->d_ld_cdf, (n + 1) * 4))) return rc;
+    if (n) {
+        PH_CHECK(s, hipMemcpy(s->d_ld_func.p, f.data(), n * 4, hipMemcpyHostToDevice));
+        PH_CHECK(s, hipMemcpy(s->d_ld_cdf.p, cdf.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    }
+    s->ds.ld_func = (const float*)s->d_ld_func.p; s->ds.ld_cdf = (const float*)s->d_ld_cdf.p; s->ds.ld_func_int = func_int;
+    s->light_strategy_uploaded = strat;
+    return PBRT_HIP_OK;
+}
+
+int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_out, uint32_t n, float* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.0f;
+    if (n == 0) return PBRT_HIP_OK;
+    if (!s->trav_blocks) {
+        hipDeviceProp_t prop;
+        PH_CHECK(s, hipGetDeviceProperties(&prop, s->device));
+        int per_cu = 0;
+        PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false>, PH_TRAV_BLOCK, 0));
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        s->trav_blocks = (uint32_t)(prop.multiProcessorCount * per_cu);
+    }
+    // fewer rays than resident lanes: shrink the grid so idle waves exit immediately
+    uint32_t blocks = std::min<uint32_t>(s->trav_blocks, (n + PH_TRAV_BLOCK - 1) / PH_TRAV_BLOCK);
+    const uint32_t total_threads = s->trav_blocks * PH_TRAV_BLOCK;
+    int rc;
+    if ((rc = ensure_buf(s, s->d_counter, 64))) return rc;
+    if ((rc = ensure_buf(s, s->d_error, 64))) return rc;
+    if ((rc = ensure_buf(s, s->d_spill, (size_t)(PH_MAX_STACK - PH_LDS_DEPTH) * total_threads * sizeof(uint2)))) return rc;
+    PH_CHECK(s, hipMemsetAsync(s->d_counter.p, 0, 4, s->stream));
+    ph::TravParams p;
+    p.rays = (const ph::RayIn*)d_rays; p.out = d_out; p.n = n;
+    p.counter = (uint32_t*)s->d_counter.p; p.spill = (uint2*)s->d_spill.p; p.total_threads = total_threads;
+    p.error_flag = (uint32_t*)s->d_error.p;
+    if (kernel_ms) PH_CHECK(s, hipEventRecord(s->ev0, s->stream));
+    if (anyhit) hipLaunchKernelGGL(ph::traverse_kernel<true>, dim3(blocks), dim3(PH_TRAV_BLOCK), 0, s->stream, s->ds, p);
+    else hipLaunchKernelGGL(ph::traverse_kernel<false>, dim3(blocks), dim3(PH_TRAV_BLOCK), 0, s->stream, s->ds, p);
+    PH_CHECK(s, hipGetLastError());
+    if (kernel_ms) {
+        PH_CHECK(s, hipEventRecord(s->ev1, s->stream));
+        PH_CHECK(s, hipEventSynchronize(s->ev1));
+        PH_CHECK(s, hipEventElapsedTime(kernel_ms, s->ev0, s->ev1));
+    }
+    return PBRT_HIP_OK;
+}
+
+}  // namespace phost
+
+using namespace phost;
+
+namespace hm {
+M4 m4_inverse(const M4& a) {
+    int indxc[4] = {0, 0, 0, 0}, indxr[4] = {0, 0, 0, 0}, ipiv[4] = {0, 0, 0, 0};
+    float minv[4][4];
+    std::memcpy(minv, a.m, sizeof(minv));
+    for (int i = 0; i < 4; i++) {
+        int irow = 0, icol = 0;
+        float big = 0.0f;
+        for (int j = 0; j < 4; j++)
+            if (ipiv[j] != 1)
+                for (int k = 0; k < 4; k++)
+                    if (ipiv[k] == 0) { float av = fabs_p(minv[j][k]); if (av >= big) { big = av; irow = j; icol = k; } }
+        ipiv[icol] += 1;
+        if (irow != icol) for (int k = 0; k < 4; k++) std::swap(minv[irow][k], minv[icol][k]);
+        indxr[i] = irow; indxc[i] = icol;
+        float pivinv = 1.0f / minv[icol][icol];
+        minv[icol][icol] = 1.0f;
+        for (int j = 0; j < 4; j++) minv[icol][j] *= pivinv;
+        for (int j = 0; j < 4; j++)
+            if (j != icol) {
+                float save = minv[j][icol];
+                minv[j][icol] = 0.0f;
+                for (int k = 0; k < 4; k++) minv[j][k] -= minv[icol][k] * save;
+            }
+    }
+    for (int j = 3; j >= 0; j--)
+        if (indxr[j] != indxc[j]) for (int k = 0; k < 4; k++) std::swap(minv[k][indxr[j]], minv[k][indxc[j]]);
+    M4 r; std::memcpy(r.m, minv, sizeof(minv)); return r;
+}
+}  // namespace hm
+
+extern "C" {
+
+int pbrt_hip_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorNoDevice ? 0 : PBRT_HIP_ERR_DEVICE; }
+    return n;
+}
+
+PbrtHipScene* pbrt_hip_scene_create(int device_ordinal) {
+    int n = pbrt_hip_device_count();
+    if (n <= 0 || device_ordinal < 0 || device_ordinal >= n) {
+        set_err(nullptr, PBRT_HIP_ERR_NO_DEVICE, "pbrt_hip_scene_create: no usable HIP device (this library has no CPU path)");
+        return nullptr;
+    }
+    if (hipSetDevice(device_ordinal) != hipSuccess) { set_err(nullptr, PBRT_HIP_ERR_DEVICE, "hipSetDevice failed"); return nullptr; }
+    PbrtHipScene* s = new PbrtHipScene();
+    s->device = device_ordinal;
+    if (hipStreamCreate(&s->stream) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+        set_err(nullptr, PBRT_HIP_ERR_DEVICE, "stream/event creation failed");
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+void pbrt_hip_scene_destroy(PbrtHipScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    free_wavefront(s);
+    free_owned(s);
+    for (DevBuf* b : {&s->d_ld_func, &s->d_ld_cdf, &s->d_counter, &s->d_spill, &s->d_error, &s->d_rays_tmp, &s->d_out_tmp})
+        if (b->p) (void)hipFree(b->p);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+const char* pbrt_hip_last_error(const PbrtHipScene* s) {
+    if (s) return s->err.c_str();
+    std::lock_guard<std::mutex> g(g_err_mu);
+    return g_last_error.c_str();
+}
+
+int pbrt_hip_add_material_matte(PbrtHipScene* s, const float kd[3], float sigma_deg, uint32_t* out_id) {
+    if (!s || !kd) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_matte: null argument");
+    MaterialRec m{};
+    for (int c = 0; c < 3; c++) m.kd[c] = hm::clampf(kd[c], 0.0f, hm::kInf);  // clamp_default (matte.rs:63)
+    m.sigma = hm::clampf(sigma_deg, 0.0f, 90.0f);                              // matte.rs:64
+    m.has_bxdf = !(m.kd[0] == 0.0f && m.kd[1] == 0.0f && m.kd[2] == 0.0f);
+    if (m.sigma != 0.0f) {  // OrenNayar::new (oren_nayar.rs:28-39)
+        float sg = hm::to_radians(m.sigma), s2 = sg * sg;
+        m.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
+        m.b = 0.45f * s2 / (s2 + 0.09f);
+    }
+    s->materials.push_back(m);
+    if (out_id) *out_id = (uint32_t)s->materials.size() - 1;
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+
+// "the intersection is bogus" (triangle.rs:548-574): depends only on the triangle, so it is decided once here.
+static bool triangle_is_bogus(hm::V3 p0, hm::V3 p1, hm::V3 p2, const float* uv0, const float* uv1, const float* uv2) {
+    float u0[2] = {0, 0}, u1[2] = {1, 0}, u2[2] = {1, 1};  // default uvs (triangle.rs:384-394)
+    if (uv0) { u0[0] = uv0[0]; u0[1] = uv0[1]; u1[0] = uv1[0]; u1[1] = uv1[1]; u2[0] = uv2[0]; u2[1] = uv2[1]; }
+    float duv02[2] = {u0[0] - u2[0], u0[1] - u2[1]}, duv12[2] = {u1[0] - u2[0], u1[1] - u2[1]};
+    hm::V3 dp02 = hm::sub(p0, p2), dp12 = hm::sub(p1, p2);
+    float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+    bool degenerate_uv = std::fabs(determinant) < 1e-8f;
+    hm::V3 dpdu{0, 0, 0}, dpdv{0, 0, 0};
+    if (!degenerate_uv) {
+        float invdet = 1.0f / determinant;
+        dpdu = hm::mulf(hm::sub(hm::mulf(dp02, duv12[1]), hm::mulf(dp12, duv02[1])), invdet);
+        dpdv = hm::mulf(hm::add(hm::mulf(dp02, -duv12[0]), hm::mulf(dp12, duv02[0])), invdet);
+    }
+    if (degenerate_uv || hm::len2(hm::cross(dpdu, dpdv)) == 0.0f) {
+        hm::V3 ng = hm::cross(hm::sub(p2, p0), hm::sub(p1, p0));
+        if (hm::len2(ng) == 0.0f) return true;
+    }
+    return false;
+}
+
+int pbrt_hip_add_mesh(PbrtHipScene* s, const float* P, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, const float* N,
+                      const float* S, const float* UV, uint32_t material_id, int32_t first_area_light_id, uint32_t flags, float alpha,
+                      float shadow_alpha) {
+    if (!s || !P || !indices) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mesh: null argument");
+    if (material_id >= s->materials.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mesh: unknown material id");
+    for (uint32_t i = 0; i < 3 * n_tris; i++)
+        if (indices[i] >= n_verts) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mesh: vertex index out of bounds (triangle.rs:252-261)");
+    if (first_area_light_id >= 0) {
+        if ((size_t)first_area_light_id + n_tris > s->lights.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mesh: area light ids out of range");
+        for (uint32_t k = 0; k < n_tris; k++)
+            if (s->lights[first_area_light_id + k].type != PH_L_AREA || s->lights[first_area_light_id + k].prim != 0xFFFFFFFFu)
+                return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mesh: light is not an unbound diffuse area light");
+    }
+    MeshRec m{};
+    m.vert_base = (uint32_t)(s->P.size() / 3); m.tri_base = (uint32_t)(s->idx.size() / 3); m.n_tris = n_tris;
+    m.flags = (N ? PH_MESH_N : 0) | (S ? PH_MESH_S : 0) | (UV ? PH_MESH_UV : 0) | ((flags & 1) ? PH_MESH_REV : 0) | ((flags & 2) ? PH_MESH_SWAP : 0);
+    m.material = material_id; m.first_light = first_area_light_id;
+    const size_t v0 = s->P.size() / 3;
+    s->P.insert(s->P.end(), P, P + 3 * (size_t)n_verts);
+    // optional attributes stay vertex-aligned with P; arrays are materialised only once some mesh supplies them
+    auto grow_attr = [&](std::vector<float>& dst, bool& any, const float* src, int w) {
+        if (src && !any) { dst.assign(v0 * w, 0.0f); any = true; }
+        if (any) { if (src) dst.insert(dst.end(), src, src + (size_t)w * n_verts); else dst.insert(dst.end(), (size_t)w * n_verts, 0.0f); }
+    };
+    grow_attr(s->N, s->any_n, N, 3); grow_attr(s->S, s->any_s, S, 3); grow_attr(s->UV, s->any_uv, UV, 2);
+    const uint32_t mesh_id = (uint32_t)s->meshes.size();
+    for (uint32_t t = 0; t < n_tris; t++) {
+        uint32_t i0 = indices[3 * t], i1 = indices[3 * t + 1], i2 = indices[3 * t + 2];
+        s->idx.push_back(i0 + m.vert_base); s->idx.push_back(i1 + m.vert_base); s->idx.push_back(i2 + m.vert_base);
+        s->tri_mesh.push_back(mesh_id);
+        hm::V3 p0 = hm::ld(P + 3 * i0), p1 = hm::ld(P + 3 * i1), p2 = hm::ld(P + 3 * i2);
+        uint32_t tf = 0;
+        if (triangle_is_bogus(p0, p1, p2, UV ? UV + 2 * i0 : nullptr, UV ? UV + 2 * i1 : nullptr, UV ? UV + 2 * i2 : nullptr)) tf |= PH_TRI_BOGUS;
+        if (alpha == 0.0f) tf |= PH_TRI_ALPHA0;
+        if (shadow_alpha == 0.0f) tf |= PH_TRI_SALPHA0;
+        s->tri_flags.push_back(tf);
+        if (first_area_light_id >= 0) {
+            LightRec& l = s->lights[first_area_light_id + t];
+            l.prim = m.tri_base + t;
+            l.area = 0.5f * hm::len(hm::cross(hm::sub(p1, p0), hm::sub(p2, p0)));  // Triangle::area (triangle.rs:906-911)
+        }
+    }
+    s->meshes.push_back(m);
+    s->built = false; s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+
+// 1x1 MIPMap::triangle (core/src/mipmap/mod.rs:293-311) for a constant environment
+static float env_lookup(float tx, float s_, float t_) {
+    float s = s_ * 1.0f - 0.5f, t = t_ * 1.0f - 0.5f;
+    float s0 = std::floor(s), t0 = std::floor(t);
+    float ds = s - s0, dt = t - t0;
+    return tx * (1.0f - ds) * (1.0f - dt) + tx * (1.0f - ds) * dt + tx * ds * (1.0f - dt) + tx * ds * dt;
+}
+
+int pbrt_hip_add_light_infinite(PbrtHipScene* s, const float L[3], const float l2w[16], const float w2l[16]) {
+    if (!s || !L || !l2w || !w2l) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_infinite: null argument");
+    LightRec l{};
+    l.type = PH_L_INFINITE; l.prim = 0xFFFFFFFFu;
+    for (int c = 0; c < 3; c++) l.L[c] = L[c];
+    std::memcpy(l.l2w, l2w, 48); std::memcpy(l.w2l, w2l, 48);
+    // compute_scalar_image (infinite.rs:326-369): 2x2 image, fwidth 0.25 -> level < 0 -> triangle(0, st)
+    float img[2][2];
+    for (int v = 0; v < 2; v++) {
+        float vp = ((float)v + 0.5f) / 2.0f;
+        float sin_theta = std::sin(hm::kPi * ((float)v + 0.5f) / 2.0f);
+        for (int u = 0; u < 2; u++) {
+            float up = ((float)u + 0.5f) / 2.0f;
+            float y = 0.212671f * env_lookup(L[0], up, vp) + 0.715160f * env_lookup(L[1], up, vp) + 0.072169f * env_lookup(L[2], up, vp);
+            img[v][u] = y * sin_theta;
+        }
+    }
+    std::vector<float> marg, cdf;
+    for (int v = 0; v < 2; v++) {  // Distribution2D::new (distribution_2d.rs:21-29)
+        float fi;
+        hm::distribution1d({img[v][0], img[v][1]}, cdf, fi);
+        l.cond_func[2 * v] = img[v][0]; l.cond_func[2 * v + 1] = img[v][1];
+        for (int i = 0; i < 3; i++) l.cond_cdf[3 * v + i] = cdf[i];
+        l.cond_int[v] = fi; marg.push_back(fi);
+    }
+    float mi;
+    hm::distribution1d(marg, cdf, mi);
+    l.marg_func[0] = marg[0]; l.marg_func[1] = marg[1];
+    for (int i = 0; i < 3; i++) l.marg_cdf[i] = cdf[i];
+    l.marg_int = mi;
+    s->infinite_lights.push_back((uint32_t)s->lights.size());
+    s->lights.push_back(l);
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_add_light_distant(PbrtHipScene* s, const float L[3], const float w[3]) {
+    if (!s || !L || !w) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_distant: null argument");
+    LightRec l{}; l.type = PH_L_DISTANT; l.prim = 0xFFFFFFFFu;
+    for (int c = 0; c < 3; c++) { l.L[c] = L[c]; l.v[c] = w[c]; }
+    s->lights.push_back(l); s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_add_light_point(PbrtHipScene* s, const float I[3], const float p[3]) {
+    if (!s || !I || !p) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_point: null argument");
+    LightRec l{}; l.type = PH_L_POINT; l.prim = 0xFFFFFFFFu;
+    for (int c = 0; c < 3; c++) { l.L[c] = I[c]; l.v[c] = p[c]; }
+    s->lights.push_back(l); s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_add_light_diffuse_area(PbrtHipScene* s, const float L[3], int two_sided, uint32_t n_tris, uint32_t* out_first_id) {
+    if (!s || !L) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_diffuse_area: null argument");
+    if (out_first_id) *out_first_id = (uint32_t)s->lights.size();
+    for (uint32_t i = 0; i < n_tris; i++) {
+        LightRec l{}; l.type = PH_L_AREA; l.two_sided = two_sided ? 1 : 0; l.prim = 0xFFFFFFFFu;
+        for (int c = 0; c < 3; c++) l.L[c] = L[c];
+        s->lights.push_back(l);
+    }
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+
+int pbrt_hip_set_camera_perspective(PbrtHipScene* s, const float r2c[16], const float c2w[16], float lens_radius, float focal_distance,
+                                    float shutter_open, float shutter_close) {
+    if (!s || !r2c || !c2w) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_camera_perspective: null argument");
+    std::memcpy(s->cam.r2c, r2c, 64); std::memcpy(s->cam.c2w, c2w, 64);
+    s->cam.lens_radius = lens_radius; s->cam.focal_distance = focal_distance;
+    s->cam.shutter_open = shutter_open; s->cam.shutter_close = shutter_close;
+    s->have_camera = true;
+    return PBRT_HIP_OK;
+}
+
+int pbrt_hip_set_film(PbrtHipScene* s, int xres, int yres, const int crop[4], const float radius[2], const float table[256], float scale,
+                      float max_lum) {
+    if (!s || !crop || !radius || !table) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_film: null argument");
+    if (!(radius[0] > 0.0f) || !(radius[1] > 0.0f)) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_film: filter radius must be positive");
+    FilmRec& f = s->film;
+    f.xres = xres; f.yres = yres;
+    for (int i = 0; i < 4; i++) f.crop[i] = crop[i];
+    f.radius[0] = radius[0]; f.radius[1] = radius[1];
+    f.inv_radius[0] = 1.0f / radius[0]; f.inv_radius[1] = 1.0f / radius[1];  // film_tile.rs:50
+    f.scale = scale; f.max_lum = max_lum;
+    std::memcpy(f.table, table, sizeof(f.table));
+    s->have_film = true;
+    return PBRT_HIP_OK;
+}
+
+static void ext_gcd(uint64_t a, uint64_t b, int64_t& x, int64_t& y) {  // halton.rs:294-302
+    if (b == 0) { x = 1; y = 0; return; }
+    int64_t d = (int64_t)(a / b), xp, yp;
+    ext_gcd(b, a % b, xp, yp);
+    x = yp; y = xp - (d * yp);
+}
+static uint64_t mult_inverse(int64_t a, int64_t n) {  // halton.rs:304-311
+    int64_t x, y;
+    ext_gcd((uint64_t)a, (uint64_t)n, x, y);
+    int64_t r = x - (x / n) * n;
+    return (uint64_t)(r < 0 ? r + n : r);
+}
+
+int pbrt_hip_set_sampler(PbrtHipScene* s, int kind, uint32_t spp, const int sb[4], int at_center) {
+    if (!s || !sb) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_sampler: null argument");
+    if (kind != 0 && kind != 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_sampler: only halton (0) and sobol (1) are GPU-friendly (SURVEY §8a-S)");
+    if (spp == 0) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_sampler: spp must be > 0");
+    SamplerRec& r = s->sampler;
+    std::memset(&r, 0, sizeof(r));
+    r.kind = kind; r.spp = spp; r.at_center = at_center ? 1 : 0;
+    for (int i = 0; i < 4; i++) r.bounds[i] = sb[i];
+    if (kind == 0) {  // HaltonSampler::new (halton.rs:61-100)
+        int res[2] = {sb[2] - sb[0], sb[3] - sb[1]};
+        for (int i = 0; i < 2; i++) {
+            uint64_t base = i == 0 ? 2 : 3, scale = 1, e = 0;
+            while ((int)scale < std::min(res[i], 128)) { scale *= base; e++; }
+            r.base_scales[i] = (uint32_t)scale; r.base_exponents[i] = (uint32_t)e;
+        }
+        r.sample_stride = r.base_scales[0] * r.base_scales[1];
+        r.mult_inverse[0] = (uint32_t)mult_inverse(r.base_scales[1], r.base_scales[0]);
+        r.mult_inverse[1] = (uint32_t)mult_inverse(r.base_scales[0], r.base_scales[1]);
+        if (((uint64_t)spp + 1) * r.sample_stride >= (1ull << 32))
+            return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_sampler: halton index exceeds 32 bits at this spp/resolution");
+    } else {  // SobolSampler::new (sobol.rs:35-63)
+        auto pow2_up = [](uint32_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; };
+        if (spp & (spp - 1)) r.spp = pow2_up(spp);
+        int ext = std::max(sb[2] - sb[0], sb[3] - sb[1]);
+        r.resolution = (int)pow2_up((uint32_t)std::max(ext, 1));
+        int lg = 0; for (uint32_t v = (uint32_t)r.resolution; v >>= 1;) lg++;
+        r.log2_resolution = lg;
+    }
+    s->have_sampler = true;
+    return PBRT_HIP_OK;
+}
+
+int pbrt_hip_set_sobol_tables(PbrtHipScene* s, const uint32_t* m32, size_t n32, const uint64_t* vdc, const uint64_t* vdc_inv, size_t n_each) {
+    if (!s || !m32 || !vdc || !vdc_inv) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_sobol_tables: null argument");
+    s->sobol32.assign(m32, m32 + n32); s->vdc.assign(vdc, vdc + n_each); s->vdc_inv.assign(vdc_inv, vdc_inv + n_each);
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+
+int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_node) {
+    if (!s) return PBRT_HIP_ERR_INVALID_ARG;
+    if (split_method == 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: HLBVH is a 'next' row (SURVEY §8f)");
+    if (split_method == 2) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: splitmethod 'middle' panics in the reference (quirk B6, sah.rs:67-76)");
+    phost::BuildInput in;
+    in.P = s->P.data(); in.idx = s->idx.data(); in.n_tris = s->idx.size() / 3; in.tri_flags = s->tri_flags.data();
+    if (phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh) != 0) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: bad arguments");
+    // Light::preprocess: bounding sphere of the world bound (bounds3.rs:196-208; infinite.rs:113-117, distant.rs:54-58)
+    s->world_radius = 1.0f; s->world_center[0] = s->world_center[1] = s->world_center[2] = 0.0f;
+    if (in.n_tris) {
+        const float* lo = s->bvh.root_lo; const float* hi = s->bvh.root_hi;
+        float c[3];
+        for (int k = 0; k < 3; k++) c[k] = (1.0f - 0.5f) * lo[k] + 0.5f * hi[k];  // lerp(0.5, pmin, pmax) (common.rs:166-175)
+        bool inside = (c[0] >= lo[0] && c[0] <= hi[0]) && (c[1] >= lo[1] && c[1] <= hi[1]) && (c[2] >= lo[2] && c[2] <= hi[2]);
+        float dx = c[0] - hi[0], dy = c[1] - hi[1], dz = c[2] - hi[2];
+        s->world_radius = inside ? std::sqrt(dx * dx + dy * dy + dz * dz) : 0.0f;
+        for (int k = 0; k < 3; k++) s->world_center[k] = c[k];
+    }
+    s->built = true; s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+
+int pbrt_hip_world_bound(const PbrtHipScene* s, float out[6]) {
+    if (!s || !out) return PBRT_HIP_ERR_INVALID_ARG;
+    if (!s->built) return PBRT_HIP_ERR_STATE;
+    for (int k = 0; k < 3; k++) { out[k] = s->bvh.root_lo[k]; out[3 + k] = s->bvh.root_hi[k]; }
+    return PBRT_HIP_OK;
+}
+
+static int check_error_flag(PbrtHipScene* s) {
+    uint32_t flag = 0;
+    PH_CHECK(s, hipMemcpy(&flag, s->d_error.p, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        (void)hipMemset(s->d_error.p, 0, 4);
+        return set_err(s, PBRT_HIP_ERR_DEVICE, "traversal stack exceeded 64 entries (the reference panics here, bvh/mod.rs:185)");
+    }
+    return PBRT_HIP_OK;
+}
+
+static int batch_common(PbrtHipScene* s, bool anyhit, const void* rays, void* out, uint64_t n, bool device_ptrs, float* kernel_ms) {
+    if (!s) return PBRT_HIP_ERR_INVALID_ARG;
+    if (n && (!rays || !out)) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "batch: null buffer");
+    if (!s->built) return set_err(s, PBRT_HIP_ERR_STATE, "batch: call pbrt_hip_build_accel first");
+    if (n > 0xFFFF0000ull) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "batch: at most 2^32-65536 rays per call");
+    PH_CHECK(s, hipSetDevice(s->device));
+    int rc;
+    if ((rc = upload_scene(s))) return rc;
+    if (n == 0) return PBRT_HIP_OK;
+    const size_t out_bytes = anyhit ? (size_t)n : (size_t)n * sizeof(PbrtHipHit);
+    const void* d_rays = rays; void* d_out = out;
+    if (!device_ptrs) {
+        if ((rc = ensure_buf(s, s->d_rays_tmp, (size_t)n * sizeof(PbrtHipRay)))) return rc;
+        if ((rc = ensure_buf(s, s->d_out_tmp, out_bytes))) return rc;
+        PH_CHECK(s, hipMemcpyAsync(s->d_rays_tmp.p, rays, (size_t)n * sizeof(PbrtHipRay), hipMemcpyHostToDevice, s->stream));
+        d_rays = s->d_rays_tmp.p; d_out = s->d_out_tmp.p;
+    }
+    if ((rc = launch_traverse(s, anyhit, d_rays, d_out, (uint32_t)n, kernel_ms))) return rc;
+    if (!device_ptrs) PH_CHECK(s, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s->stream));
+    PH_CHECK(s, hipStreamSynchronize(s->stream));
+    return check_error_flag(s);
+}
+
+int pbrt_hip_intersect_batch(PbrtHipScene* s, const PbrtHipRay* rays, PbrtHipHit* hits, uint64_t n) { return batch_common(s, false, rays, hits, n, false, nullptr); }
+int pbrt_hip_occluded_batch(PbrtHipScene* s, const PbrtHipRay* rays, uint8_t* out, uint64_t n) { return batch_common(s, true, rays, out, n, false, nullptr); }
+int pbrt_hip_intersect_batch_device(PbrtHipScene* s, const void* d_rays, void* d_hits, uint64_t n, float* ms) { return batch_common(s, false, d_rays, d_hits, n, true, ms); }
+int pbrt_hip_occluded_batch_device(PbrtHipScene* s, const void* d_rays, void* d_occ, uint64_t n, float* ms) { return batch_common(s, true, d_rays, d_occ, n, true, ms); }
+
+// Film::get_pixel_rgb (core/src/film/mod.rs:392-417); splat is identically zero for the path integrator (quirk B3 kept)
+int pbrt_hip_film_to_rgb(const PbrtHipScene* s, const float* xyz, const float* weight, float* out_rgb) {
+    if (!s || !xyz || !weight || !out_rgb) return PBRT_HIP_ERR_INVALID_ARG;
+    if (!s->have_film) return PBRT_HIP_ERR_STATE;
+    const FilmRec& f = s->film;
+    const int w = f.crop[2] - f.crop[0], h = f.crop[3] - f.crop[1];
+    const size_t n = (size_t)std::max(w, 0) * (size_t)std::max(h, 0);
+    auto to_rgb = [](const float* x, float* r) {  // xyz_to_rgb (spectrum/common.rs:337-343)
+        r[0] = 3.240479f * x[0] - 1.537150f * x[1] - 0.498535f * x[2];
+        r[1] = -0.969256f * x[0] + 1.875991f * x[1] + 0.041556f * x[2];
+        r[2] = 0.055648f * x[0] - 0.204043f * x[1] + 1.057311f * x[2];
+    };
+    const float zero[3] = {0, 0, 0};
+    float splat_rgb[3];
+    to_rgb(zero, splat_rgb);
+    for (size_t i = 0; i < n; i++) {
+        float rgb[3];
+        to_rgb(xyz + 3 * i, rgb);
+        for (int c = 0; c < 3; c++) {
+            float v = rgb[c];
+            if (weight[i] != 0.0f) { float inv = 1.0f / weight[i]; float q = v * inv; v = 0.0f > q ? 0.0f : q; }
+            v += 1.0f * splat_rgb[0];
+            v *= f.scale;
+            out_rgb[3 * i + c] = v;
+        }
+    }
+    return PBRT_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+// See bvh_build.h.  Host C++ only (no device code).
+#include "bvh_build.h"
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+namespace phost {
+namespace {
+
+inline float fmn(float a, float b) { return a < b ? a : b; }  // core/src/pbrt/common.rs:81-92 (`<`-based)
+inline float fmx(float a, float b) { return a > b ? a : b; }
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {  // Bounds3f::EMPTY (bounds3.rs:23-30)
+        for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::max(); hi[k] = std::numeric_limits<float>::lowest(); }
+    }
+    void grow(const Box& o) { for (int k = 0; k < 3; k++) { lo[k] = fmn(lo[k], o.lo[k]); hi[k] = fmx(hi[k], o.hi[k]); } }
+    void grow_pt(const float* p) { for (int k = 0; k < 3; k++) { lo[k] = fmn(lo[k], p[k]); hi[k] = fmx(hi[k], p[k]); } }
+    float area() const {  // bounds3.rs:95-107
+        if (hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2]) return 0.0f;
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        float h = dx * dy + dx * dz + dy * dz;
+        return h + h;
+    }
+    int widest() const {  // bounds3.rs:122-134
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx > dy && dx > dz) return 0;
+        return dy > dz ? 1 : 2;
+    }
+};
+
+struct Prim { uint32_t id; Box b; float c[3]; };  // BVHPrimitiveInfo (bvh/common.rs:62-91)
+
+struct BNode {
+    Box b;
+    BNode* kid[2];
+    uint32_t first, count;  // leaf: range in the (final) prim array
+    int axis;
+};
+
+constexpr int kBuckets = 12;
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<BNode> pool;
+    std::atomic<size_t> pool_next{0};
+    std::atomic<int> spare_threads{0};
+    int split_method = 0, max_prims = 4;
+
+    BNode* alloc() { return &pool[pool_next.fetch_add(1)]; }
+
+    static uint32_t bucket_of(const Box& cb, const float* c, int dim) {  // sah.rs:309-313 (saturating `as usize`)
+        float o = c[dim] - cb.lo[dim];
+        if (cb.hi[dim] > cb.lo[dim]) o /= cb.hi[dim] - cb.lo[dim];
+        float f = (float)kBuckets * o;
+        uint32_t b = !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)f);
+        if (b == (uint32_t)kBuckets) b = kBuckets - 1;
+        return b;
+    }
+
+    // itertools::partition — the exact element order matters for leaf order
+    template <class Pred> size_t partition_like_itertools(size_t start, size_t end, Pred pred) {
+        size_t split = 0, front = start, back = end;
+        while (front != back) {
+            size_t f = front++;
+            if (!pred(prims[f])) {
+                bool swapped = false;
+                while (front != back) {
+                    size_t b = --back;
+                    if (pred(prims[b])) { std::swap(prims[f], prims[b]); swapped = true; break; }
+                }
+                if (!swapped) return split;
+            }
+            split++;
+        }
+        return split;
+    }
+
+    BNode* make_leaf(BNode* n, const Box& bounds, size_t start, size_t end) {
+        n->b = bounds; n->kid[0] = n->kid[1] = nullptr; n->first = (uint32_t)start; n->count = (uint32_t)(end - start); n->axis = 0;
+        return n;
+    }
+
+    BNode* build(size_t start, size_t end) {
+        BNode* node = alloc();
+        Box bounds; bounds.reset();
+        for (size_t i = start; i < end; i++) bounds.grow(prims[i].b);
+        const size_t n = end - start;
+        if (n == 1) return make_leaf(node, bounds, start, end);
+        Box cb; cb.reset();
+        for (size_t i = start; i < end; i++) cb.grow_pt(prims[i].c);
+        const int dim = cb.widest();
+        if (cb.hi[dim] == cb.lo[dim]) return make_leaf(node, bounds, start, end);  // sah.rs:61-63
+
+        size_t mid;
+        if (split_method == 3 || n <= 2) {
+            // split_equal_counts (sah.rs:240-254).  For n == 2 every correct selection yields [smaller, larger].
+            mid = (start + end) / 2;
+            if (n == 2) { if (prims[start + 1].c[dim] < prims[start].c[dim]) std::swap(prims[start], prims[start + 1]); }
+            else std::nth_element(prims.begin() + start, prims.begin() + mid, prims.begin() + end,
+                                  [dim](const Prim& a, const Prim& b) { return a.c[dim] < b.c[dim]; });
+        } else {
+            // split_sah (sah.rs:293-367)
+            size_t cnt[kBuckets]; Box bb[kBuckets];
+            for (int i = 0; i < kBuckets; i++) { cnt[i] = 0; bb[i].reset(); }
+            for (size_t i = start; i < end; i++) { uint32_t b = bucket_of(cb, prims[i].c, dim); cnt[b]++; bb[b].grow(prims[i].b); }
+            // suffix unions once; prefix grown on the fly (min/max are exact, so the grouping does not matter)
+            Box suf[kBuckets]; size_t sufc[kBuckets];
+            suf[kBuckets - 1] = bb[kBuckets - 1]; sufc[kBuckets - 1] = cnt[kBuckets - 1];
+            for (int i = kBuckets - 2; i >= 0; i--) { suf[i] = suf[i + 1]; suf[i].grow(bb[i]); sufc[i] = sufc[i + 1] + cnt[i]; }
+            Box pre; pre.reset(); size_t prec = 0;
+            const float inv_denominator_area = bounds.area();
+            float best = 0.0f; int best_b = 0;
+            for (int i = 0; i < kBuckets - 1; i++) {
+                pre.grow(bb[i]); prec += cnt[i];
+                float cost = 1.0f + ((float)prec * pre.area() + (float)sufc[i + 1] * suf[i + 1].area()) / inv_denominator_area;
+                if (i == 0 || cost < best) { best = cost; best_b = i; }
+            }
+            const float leaf_cost = (float)n;
+            if (n > (size_t)max_prims || best < leaf_cost) {
+                mid = start + partition_like_itertools(start, end, [&](const Prim& p) { return bucket_of(cb, p.c, dim) <= (uint32_t)best_b; });
+            } else return make_leaf(node, bounds, start, end);
+        }
+        if (mid == start || mid == end) return make_leaf(node, bounds, start, end);  // reference: assert_ne! panic (sah.rs:37)
+
+        node->axis = dim; node->first = 0; node->count = 0;
+        // fork the larger subtrees onto spare threads
+        if (n > 32768 && spare_threads.fetch_sub(1) > 0) {
+            BNode* left = nullptr;
+            std::thread t([&]() { left = build(start, mid); });
+            node->kid[1] = build(mid, end);
+            t.join();
+            node->kid[0] = left;
+            spare_threads.fetch_add(1);
+        } else {
+            if (n > 32768) spare_threads.fetch_add(1);
+            node->kid[0] = build(start, mid);
+            node->kid[1] = build(mid, end);
+        }
+        node->b = node->kid[0]->b; node->b.grow(node->kid[1]->b);  // bvh/common.rs:152-160
+        return node;
+    }
+};
+
+}  // namespace
+
+int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int n_threads, BuildOutput& out) {
+    if (split_method != 0 && split_method != 3) return -1;
+    out = BuildOutput();
+    const size_t n = in.n_tris;
+    if (n == 0) return 0;
+    if (n >= 0x7FFFFFFFu) return -1;
+    auto t0 = std::chrono::steady_clock::now();
+    Builder B;
+    B.split_method = split_method;
+    B.max_prims = max_prims_in_node & 0xff;  // bvh/mod.rs:357 `as u8`
+    B.prims.resize(n);
+    for (size_t i = 0; i < n; i++) {  // Triangle::world_bound (triangle.rs:427-431) + BVHPrimitiveInfo::new
+        Prim& p = B.prims[i];
+        p.id = (uint32_t)i;
+        const float* a = in.P + 3 * (size_t)in.idx[3 * i];
+        p.b.lo[0] = p.b.hi[0] = a[0]; p.b.lo[1] = p.b.hi[1] = a[1]; p.b.lo[2] = p.b.hi[2] = a[2];
+        p.b.grow_pt(in.P + 3 * (size_t)in.idx[3 * i + 1]);
+        p.b.grow_pt(in.P + 3 * (size_t)in.idx[3 * i + 2]);
+        for (int k = 0; k < 3; k++) p.c[k] = 0.5f * (p.b.lo[k] + p.b.hi[k]);
+    }
+    B.pool.resize(2 * n);
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    B.spare_threads = n_threads > 1 ? n_threads - 1 : 0;
+    BNode* root = B.build(0, n);
+
+    // ---- emit device layout: TriRecs in final prim-array order (= depth-first leaf order), Node64s in pre-order -------
+    out.tris.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t id = B.prims[i].id;
+        TriRec& t = out.tris[i];
+        const float* p0 = in.P + 3 * (size_t)in.idx[3 * (size_t)id];
+        const float* p1 = in.P + 3 * (size_t)in.idx[3 * (size_t)id + 1];
+        const float* p2 = in.P + 3 * (size_t)in.idx[3 * (size_t)id + 2];
+        std::memcpy(t.p0, p0, 12); std::memcpy(t.p1, p1, 12); std::memcpy(t.p2, p2, 12);
+        t.prim = id; t.flags = in.tri_flags ? (in.tri_flags[id] & ~PH_TRI_LAST) : 0u; t.pad = 0;
+    }
+    for (int k = 0; k < 3; k++) { out.root_lo[k] = root->b.lo[k]; out.root_hi[k] = root->b.hi[k]; }
+
+    auto ref_of_leaf = [&](const BNode* l) {
+        out.tris[l->first + l->count - 1].flags |= PH_TRI_LAST;
+        out.leaf_nodes++;
+        out.max_leaf_prims = std::max<size_t>(out.max_leaf_prims, l->count);
+        return PH_LEAF_BIT | l->first;
+    };
+    if (!root->kid[0]) {
+        out.root_ref = ref_of_leaf(root);
+    } else {
+        // iterative pre-order walk; an interior node's Node64 index is assigned when it is first reached
+        struct Item { const BNode* n; uint32_t self; int depth; };
+        std::vector<Item> stack;
+        out.nodes.reserve(n);
+        out.nodes.emplace_back();
+        out.root_ref = 0;
+        stack.push_back({root, 0u, 1});
+        while (!stack.empty()) {
+            Item it = stack.back(); stack.pop_back();
+            out.interior_nodes++;
+            out.max_depth = std::max(out.max_depth, it.depth);
+            uint32_t refs[2];
+            const BNode* kids[2] = {it.n->kid[0], it.n->kid[1]};
+            // reserve indices so that child 0's subtree follows its parent contiguously (reference pre-order)
+            for (int c = 0; c < 2; c++) {
+                if (kids[c]->kid[0]) { refs[c] = (uint32_t)out.nodes.size(); out.nodes.emplace_back(); }
+                else refs[c] = ref_of_leaf(kids[c]);
+            }
+            Node64& d = out.nodes[it.self];
+            d.x0[0] = kids[0]->b.lo[0]; d.x0[1] = kids[0]->b.hi[0]; d.y0[0] = kids[0]->b.lo[1]; d.y0[1] = kids[0]->b.hi[1];
+            d.z0[0] = kids[0]->b.lo[2]; d.z0[1] = kids[0]->b.hi[2];
+            d.x1[0] = kids[1]->b.lo[0]; d.x1[1] = kids[1]->b.hi[0]; d.y1[0] = kids[1]->b.lo[1]; d.y1[1] = kids[1]->b.hi[1];
+            d.z1[0] = kids[1]->b.lo[2]; d.z1[1] = kids[1]->b.hi[2];
+            d.c0 = refs[0]; d.c1 = refs[1]; d.axis = (uint32_t)it.n->axis; d.pad = 0;
+            if (kids[1]->kid[0]) stack.push_back({kids[1], refs[1], it.depth + 1});
+            if (kids[0]->kid[0]) stack.push_back({kids[0], refs[0], it.depth + 1});
+        }
+    }
+    out.total_nodes = out.interior_nodes + out.leaf_nodes;
+    out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+}  // namespace phost

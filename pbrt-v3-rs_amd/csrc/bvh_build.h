@@ -1,0 +1,39 @@
+// Host-side BVH construction for the device layout (Node64 + leaf-ordered TriRec).
+//
+// Topology contract: identical to BVHAccel::new with SplitMethod::SAH (accelerators/src/bvh/mod.rs:43-153,
+// sah.rs:26-367) — same bucketed SAH decisions, same partition order (itertools::partition's two-pointer swap), same
+// depth-first leaf order — so that closest-hit results agree with the reference even on exact-t ties and on the
+// rays the un-widened z slab (bounds3.rs:315-319) culls.  Only the in-memory encoding differs (scene_types.h).
+//
+// Unlike the reference's single-threaded recursion the build forks subtrees onto a thread pool; each node's
+// decision depends only on its own primitive range, so the result is independent of the schedule.
+#pragma once
+#include "scene_types.h"
+#include <cstddef>
+#include <vector>
+
+namespace phost {
+
+struct BuildInput {
+    const float* P;         // world-space vertices, 3 floats each
+    const uint32_t* idx;    // 3 per triangle
+    size_t n_tris;
+    const uint32_t* tri_flags;  // per-triangle PH_TRI_BOGUS/ALPHA0/SALPHA0 bits (LAST is set by the builder)
+};
+
+struct BuildOutput {
+    std::vector<Node64> nodes;
+    std::vector<TriRec> tris;        // leaf-contiguous order
+    uint32_t root_ref = PH_INVALID_REF;
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+    // statistics with the reference's names (bvh/common.rs:8-23)
+    size_t interior_nodes = 0, leaf_nodes = 0, total_nodes = 0, max_leaf_prims = 0;
+    int max_depth = 0;
+    double build_seconds = 0;
+};
+
+// split_method: 0 SAH, 3 EqualCounts.  (1 HLBVH and 2 Middle are not offered: see DESIGN.md.)
+// Returns 0 on success, <0 on invalid arguments.
+int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int n_threads, BuildOutput& out);
+
+}  // namespace phost

@@ -1,0 +1,180 @@
+// Host-side helpers that restate the reference's scene set-up arithmetic (the callers of the hot path), exported
+// with C linkage so any host (the C++ driver, a Rust shim, Python/ctypes) produces bit-identical camera/film inputs.
+//   Transform::{translate,scale,rotate_axis,look_at,perspective}  core/src/geometry/transform.rs:49-210
+//   ProjectiveCameraData::new                                      core/src/camera.rs:276-306
+//   PerspectiveCamera From<&ParamSet> screen window                cameras/src/perspective_camera.rs:365-407
+//   Film::new / get_sample_bounds                                  core/src/film/mod.rs:89-159
+#include "../../include/pbrt_hip_host.h"
+#include "host_math.h"
+#include <algorithm>
+
+using namespace hm;
+
+namespace {
+struct Xf { M4 m, mi; };
+Xf xf_mul(const Xf& a, const Xf& b) { return {m4_mul(a.m, b.m), m4_mul(b.mi, a.mi)}; }  // transform.rs:644-656
+M4 rows(float a00, float a01, float a02, float a03, float a10, float a11, float a12, float a13, float a20, float a21, float a22,
+        float a23, float a30, float a31, float a32, float a33) {
+    M4 r; float v[16] = {a00, a01, a02, a03, a10, a11, a12, a13, a20, a21, a22, a23, a30, a31, a32, a33};
+    std::memcpy(r.m, v, 64); return r;
+}
+Xf xf_translate(float x, float y, float z) { return {rows(1, 0, 0, x, 0, 1, 0, y, 0, 0, 1, z, 0, 0, 0, 1), rows(1, 0, 0, -x, 0, 1, 0, -y, 0, 0, 1, -z, 0, 0, 0, 1)}; }
+Xf xf_scale(float x, float y, float z) {
+    return {rows(x, 0, 0, 0, 0, y, 0, 0, 0, 0, z, 0, 0, 0, 0, 1), rows(1.0f / x, 0, 0, 0, 0, 1.0f / y, 0, 0, 0, 0, 1.0f / z, 0, 0, 0, 0, 1)};
+}
+Xf xf_rotate(float theta, V3 axis) {  // transform.rs:135-163
+    V3 a = normalize(axis);
+    float r = to_radians(theta), s = std::sin(r), c = std::cos(r);
+    M4 m = m4_identity();
+    m.m[0][0] = a.x * a.x + (1.0f - a.x * a.x) * c;
+    m.m[0][1] = a.x * a.y * (1.0f - c) - a.z * s;
+    m.m[0][2] = a.x * a.z * (1.0f - c) + a.y * s;
+    m.m[0][3] = 0.0f;
+    m.m[1][0] = a.x * a.y * (1.0f - c) + a.z * s;
+    m.m[1][1] = a.y * a.y + (1.0f - a.y * a.y) * c;
+    m.m[1][2] = a.y * a.z * (1.0f - c) - a.x * s;
+    m.m[1][3] = 0.0f;
+    m.m[2][0] = a.x * a.z * (1.0f - c) - a.y * s;
+    m.m[2][1] = a.y * a.z * (1.0f - c) + a.x * s;
+    m.m[2][2] = a.z * a.z + (1.0f - a.z * a.z) * c;
+    m.m[2][3] = 0.0f;
+    return {m, m4_transpose(m)};
+}
+void out16(const M4& m, float* o) { if (o) std::memcpy(o, m.m, 64); }
+M4 in16(const float* p) { M4 m; std::memcpy(m.m, p, 64); return m; }
+}  // namespace
+
+extern "C" {
+
+void pbrt_hip_host_translate(const float d[3], float out_m[16], float out_minv[16]) { Xf t = xf_translate(d[0], d[1], d[2]); out16(t.m, out_m); out16(t.mi, out_minv); }
+void pbrt_hip_host_scale(const float s[3], float out_m[16], float out_minv[16]) { Xf t = xf_scale(s[0], s[1], s[2]); out16(t.m, out_m); out16(t.mi, out_minv); }
+void pbrt_hip_host_rotate(float theta_deg, const float axis[3], float out_m[16], float out_minv[16]) {
+    Xf t = xf_rotate(theta_deg, {axis[0], axis[1], axis[2]}); out16(t.m, out_m); out16(t.mi, out_minv);
+}
+// Transform * Transform (transform.rs:644-656): out = a*b, out_inv = b_inv*a_inv
+void pbrt_hip_host_compose(const float a_m[16], const float a_minv[16], const float b_m[16], const float b_minv[16], float out_m[16], float out_minv[16]) {
+    Xf r = xf_mul({in16(a_m), in16(a_minv)}, {in16(b_m), in16(b_minv)}); out16(r.m, out_m); out16(r.mi, out_minv);
+}
+void pbrt_hip_host_invert(const float m[16], float out[16]) { out16(m4_inverse(in16(m)), out); }
+
+// Transform::look_at (transform.rs:165-189): out_m = world->camera, out_minv = camera->world.  Returns -1 when `up`
+// and the viewing direction are parallel (the reference panics).
+int pbrt_hip_host_look_at(const float pos[3], const float look[3], const float up[3], float out_m[16], float out_minv[16]) {
+    V3 p = ld(pos), dir = normalize(sub(ld(look), p));
+    V3 right = cross(normalize(ld(up)), dir);
+    if (len(right) == 0.0f) return -1;
+    right = normalize(right);
+    V3 new_up = cross(dir, right);
+    M4 c2w = rows(right.x, new_up.x, dir.x, p.x, right.y, new_up.y, dir.y, p.y, right.z, new_up.z, dir.z, p.z, 0, 0, 0, 1);
+    out16(m4_inverse(c2w), out_m); out16(c2w, out_minv);
+    return 0;
+}
+
+// Default screen window from the frame aspect ratio (perspective_camera.rs:381-389): {xmin, xmax, ymin, ymax}
+void pbrt_hip_host_screen_window(int xres, int yres, float out_screen[4]) {
+    float frame = (float)xres / (float)yres;
+    if (frame > 1.0f) { out_screen[0] = -frame; out_screen[1] = frame; out_screen[2] = -1.0f; out_screen[3] = 1.0f; }
+    else { out_screen[0] = -1.0f; out_screen[1] = 1.0f; out_screen[2] = -1.0f / frame; out_screen[3] = 1.0f / frame; }
+}
+
+// raster_to_camera of a PerspectiveCamera: Transform::perspective(fov, 1e-2, 1000) (perspective_camera.rs:60-66) and
+// ProjectiveCameraData::new (camera.rs:276-306)
+void pbrt_hip_host_perspective_raster_to_camera(float fov_deg, int xres, int yres, const float screen[4], float out_m[16]) {
+    const float n = 1e-2f, f = 1000.0f;
+    M4 persp = rows(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, f / (f - n), -f * n / (f - n), 0, 0, 1, 0);
+    float inv_tan_ang = 1.0f / std::tan(to_radians(fov_deg) / 2.0f);
+    Xf c2s = xf_mul(xf_scale(inv_tan_ang, inv_tan_ang, 1.0f), Xf{persp, m4_inverse(persp)});
+    Xf s2r = xf_mul(xf_mul(xf_scale((float)xres, (float)yres, 1.0f), xf_scale(1.0f / (screen[1] - screen[0]), 1.0f / (screen[2] - screen[3]), 1.0f)),
+                    xf_translate(-screen[0], -screen[3], 0.0f));
+    Xf r2s{s2r.mi, s2r.m};
+    Xf c2s_inv{c2s.mi, c2s.m};
+    out16(xf_mul(c2s_inv, r2s).m, out_m);
+}
+
+// Film::new crop bounds (film/mod.rs:101-111), the 16x16 filter table (:113-129) for a BOX filter
+// (filters/src/boxf.rs:31-47: evaluate == 1) and Film::get_sample_bounds (:150-159).
+void pbrt_hip_host_film_box(int xres, int yres, const float crop_window[4] /*x0 x1 y0 y1*/, const float radius[2], int out_cropped_bounds[4],
+                            float out_table[256], int out_sample_bounds[4]) {
+    auto sat = [](float v) { if (v != v) return 0; if (v >= 2147483648.0f) return 2147483647; if (v <= -2147483648.0f) return (int)0x80000000; return (int)v; };
+    out_cropped_bounds[0] = sat(std::ceil((float)xres * crop_window[0])); out_cropped_bounds[1] = sat(std::ceil((float)yres * crop_window[2]));
+    out_cropped_bounds[2] = sat(std::ceil((float)xres * crop_window[1])); out_cropped_bounds[3] = sat(std::ceil((float)yres * crop_window[3]));
+    for (int i = 0; i < 256; i++) out_table[i] = 1.0f;
+    out_sample_bounds[0] = sat(std::floor((float)out_cropped_bounds[0] + 0.5f - radius[0]));
+    out_sample_bounds[1] = sat(std::floor((float)out_cropped_bounds[1] + 0.5f - radius[1]));
+    out_sample_bounds[2] = sat(std::ceil((float)out_cropped_bounds[2] - 0.5f + radius[0]));
+    out_sample_bounds[3] = sat(std::ceil((float)out_cropped_bounds[3] - 0.5f + radius[1]));
+}
+
+// transform_point / transform_vector / transform_normal (transform.rs:288-302,373-380,441-448) for mesh vertices:
+// TriangleMesh::new moves P, N, S to world space once (triangle.rs:93-99).
+void pbrt_hip_host_transform_points(const float m[16], const float* in, float* out, size_t n) {
+    M4 a = in16(m);
+    for (size_t i = 0; i < n; i++) {
+        float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        float xp = a.m[0][0] * x + a.m[0][1] * y + a.m[0][2] * z + a.m[0][3];
+        float yp = a.m[1][0] * x + a.m[1][1] * y + a.m[1][2] * z + a.m[1][3];
+        float zp = a.m[2][0] * x + a.m[2][1] * y + a.m[2][2] * z + a.m[2][3];
+        float wp = a.m[3][0] * x + a.m[3][1] * y + a.m[3][2] * z + a.m[3][3];
+        if (wp == 1.0f) { out[3 * i] = xp; out[3 * i + 1] = yp; out[3 * i + 2] = zp; }
+        else { float inv = 1.0f / wp; out[3 * i] = inv * xp; out[3 * i + 1] = inv * yp; out[3 * i + 2] = inv * zp; }
+    }
+}
+void pbrt_hip_host_transform_vectors(const float m[16], const float* in, float* out, size_t n) {
+    M4 a = in16(m);
+    for (size_t i = 0; i < n; i++) {
+        float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        out[3 * i] = a.m[0][0] * x + a.m[0][1] * y + a.m[0][2] * z;
+        out[3 * i + 1] = a.m[1][0] * x + a.m[1][1] * y + a.m[1][2] * z;
+        out[3 * i + 2] = a.m[2][0] * x + a.m[2][1] * y + a.m[2][2] * z;
+    }
+}
+void pbrt_hip_host_transform_normals(const float m_inv[16], const float* in, float* out, size_t n) {
+    M4 a = in16(m_inv);
+    for (size_t i = 0; i < n; i++) {
+        float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        out[3 * i] = a.m[0][0] * x + a.m[1][0] * y + a.m[2][0] * z;
+        out[3 * i + 1] = a.m[0][1] * x + a.m[1][1] * y + a.m[2][1] * z;
+        out[3 * i + 2] = a.m[0][2] * x + a.m[1][2] * y + a.m[2][2] * z;
+    }
+}
+int pbrt_hip_host_swaps_handedness(const float m[16]) {  // transform.rs:593-599
+    M4 a = in16(m);
+    float det = a.m[0][0] * (a.m[1][1] * a.m[2][2] - a.m[1][2] * a.m[2][1]) - a.m[0][1] * (a.m[1][0] * a.m[2][2] - a.m[1][2] * a.m[2][0]) +
+                a.m[0][2] * (a.m[1][0] * a.m[2][1] - a.m[1][1] * a.m[2][0]);
+    return det < 0.0f ? 1 : 0;
+}
+// DistantLight::new: w_light = normalize(light_to_world(from - to)) (lights/src/distant.rs:36-50,147-157)
+void pbrt_hip_host_distant_direction(const float l2w[16], const float from[3], const float to[3], float out_w[3]) {
+    float d[3] = {from[0] - to[0], from[1] - to[1], from[2] - to[2]}, t[3];
+    pbrt_hip_host_transform_vectors(l2w, d, t, 1);
+    V3 w = normalize(ld(t));
+    out_w[0] = w.x; out_w[1] = w.y; out_w[2] = w.z;
+}
+// PointLight: p_light = (Translate(from) * light_to_world)(0,0,0) (lights/src/point.rs:36-55,150-158)
+void pbrt_hip_host_point_position(const float l2w[16], const float l2w_inv[16], const float from[3], float out_p[3]) {
+    Xf t = xf_mul(xf_translate(from[0], from[1], from[2]), Xf{in16(l2w), in16(l2w_inv)});
+    float z[3] = {0, 0, 0}, m[16];
+    out16(t.m, m);
+    pbrt_hip_host_transform_points(m, z, out_p, 1);
+}
+
+}  // extern "C"
+
+// ---- synthetic measurement scene (SURVEY §8d "gen_random_tris") ---------------------------------------------
+// PCG32 stream `seed` (RNG::new(seed), core/src/rng.rs:39-62).  Per triangle: centre c ~ U[-1,1)^3, then three vertices
+// c + s*U[-1,1)^3 with s = 1.5 * N^(-1/3) (constant expected density), U = 2*uniform_float()-1.  Unshared vertices
+// (3N positions, indices 0..3N-1).
+extern "C" void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, float* out_P /*9 per tri*/, uint32_t* out_idx /*3 per tri*/) {
+    Pcg32 rng;
+    rng.state = 0; rng.inc = (seed << 1) | 1;  // RNG::set_sequence
+    rng.next(); rng.state += 0x853c49e6748fea9bULL; rng.next();
+    auto uf = [&]() { float u = (float)rng.next() * 0x1.0p-32f; return u < 0x1.fffffep-1f ? u : 0x1.fffffep-1f; };  // uniform_float (rng.rs:98-103)
+    const float s = 1.5f * std::pow((float)n_tris, -1.0f / 3.0f);
+    for (uint64_t t = 0; t < n_tris; t++) {
+        float c[3];
+        for (int k = 0; k < 3; k++) c[k] = 2.0f * uf() - 1.0f;
+        for (int v = 0; v < 3; v++)
+            for (int k = 0; k < 3; k++) out_P[9 * t + 3 * v + k] = c[k] + s * (2.0f * uf() - 1.0f);
+        out_idx[3 * t] = (uint32_t)(3 * t); out_idx[3 * t + 1] = (uint32_t)(3 * t + 1); out_idx[3 * t + 2] = (uint32_t)(3 * t + 2);
+    }
+}

@@ -1,0 +1,69 @@
+// Host-side scene object behind the opaque PbrtHipScene handle (include/pbrt_hip.h).
+#pragma once
+#include "../../include/pbrt_hip.h"
+#include "bvh_build.h"
+#include "scene_types.h"
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct PbrtHipScene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- captured scene (host copies, add_mesh order) ----------------------------------------------------------------
+    std::vector<float> P, N, S, UV;  // N/S/UV are vertex-aligned with P when any mesh has them (zero-filled otherwise)
+    bool any_n = false, any_s = false, any_uv = false;
+    std::vector<uint32_t> idx, tri_mesh, tri_flags;
+    std::vector<MeshRec> meshes;
+    std::vector<MaterialRec> materials;
+    std::vector<LightRec> lights;
+    std::vector<uint32_t> infinite_lights;
+    CameraRec cam{};
+    FilmRec film{};
+    SamplerRec sampler{};
+    bool have_camera = false, have_film = false, have_sampler = false, built = false;
+    std::vector<uint32_t> sobol32;
+    std::vector<uint64_t> vdc, vdc_inv;
+
+    // ---- acceleration structure ---------------------------------------------------------------------------------------
+    phost::BuildOutput bvh;
+    float world_center[3] = {0, 0, 0}, world_radius = 1.0f;
+
+    // ---- device residency ---------------------------------------------------------------------------------------------
+    DeviceScene ds{};
+    std::vector<void*> owned;        // every hipMalloc of the scene, freed on destroy / rebuild
+    bool uploaded = false;
+    int light_strategy_uploaded = -1;
+    DevBuf d_ld_func, d_ld_cdf;
+
+    // traversal workspace
+    DevBuf d_counter, d_spill, d_error, d_rays_tmp, d_out_tmp;
+    uint32_t trav_blocks = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // wavefront workspace (allocated lazily by the renderer, see wavefront.hip)
+    struct Wavefront* wf = nullptr;
+};
+
+namespace phost {
+int set_err(PbrtHipScene* s, int code, const std::string& msg);
+int hip_fail(PbrtHipScene* s, hipError_t e, const char* what);
+int ensure_buf(PbrtHipScene* s, DevBuf& b, size_t bytes);
+int upload_scene(PbrtHipScene* s);
+int upload_light_distribution(PbrtHipScene* s, int light_strategy);
+int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_out, uint32_t n, float* kernel_ms);
+void free_wavefront(PbrtHipScene* s);
+}  // namespace phost
+
+#define PH_CHECK(s, call)                                              \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) return phost::hip_fail((s), e__, #call); \
+    } while (0)

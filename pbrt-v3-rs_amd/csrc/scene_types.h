@@ -1,0 +1,132 @@
+// Device-resident scene layout shared by host code and gfx950 kernels (plain PODs, no pointers to host memory).
+// Layout rationale is in DESIGN.md §3; reference counterparts are cited per struct.
+#pragma once
+#include <stdint.h>
+
+// ---- BVH ---------------------------------------------------------------------------------------------------------
+// The reference's 32-B LinearBVHNode (accelerators/src/bvh/common.rs:163-179) holds ONE box and is fetched, tested and
+// often rejected.  Here an interior node carries BOTH children's boxes (same numbers, same topology), so a rejected child
+// is never fetched: one 64-B line per interior visit, 4 x dwordx4 per lane.
+// Child reference: bit 31 set -> leaf, low 31 bits = offset of its first TriRec; else index of an interior Node64.
+#define PH_LEAF_BIT 0x80000000u
+#define PH_INVALID_REF 0xFFFFFFFFu
+struct alignas(64) Node64 {
+    // planes interleaved so that the dir_is_neg select touches one float2 per axis:
+    float x0[2], y0[2], z0[2];  // child 0: {min,max} per axis
+    float x1[2], y1[2], z1[2];  // child 1
+    uint32_t c0, c1;            // child references
+    uint32_t axis;              // split axis of THIS node (bvh/mod.rs:206: visit order = dir_is_neg[axis])
+    uint32_t pad;
+};
+
+// One triangle in BVH (leaf-contiguous) order: 48 B = the 3 indices + 3 positions a leaf test reads in the reference
+// (SURVEY §8d "48·n_t"), pre-gathered so the leaf loop has no index indirection.
+#define PH_TRI_LAST 1u   // last triangle of its leaf
+#define PH_TRI_BOGUS 2u  // degenerate: Triangle::intersect returns None after the t test (shapes/src/triangle.rs:567-570)
+#define PH_TRI_ALPHA0 4u   // mesh alpha texture == 0.0 (triangle.rs:603)
+#define PH_TRI_SALPHA0 8u  // mesh shadowalpha texture == 0.0 (triangle.rs:891)
+struct alignas(16) TriRec {
+    float p0[3]; uint32_t prim;   // prim = index in add_mesh order
+    float p1[3]; uint32_t flags;
+    float p2[3]; uint32_t pad;
+};
+
+// ---- shading-side geometry (indexed by prim, add_mesh order) ---------------------------------------------------------
+struct MeshRec {
+    uint32_t vert_base, tri_base, n_tris;
+    uint32_t flags;        // bit0 has N, bit1 has S, bit2 has UV, bit3 reverse_orientation, bit4 swaps_handedness
+    uint32_t material;
+    int32_t first_light;   // -1 none
+    uint32_t pad[2];
+};
+#define PH_MESH_N 1u
+#define PH_MESH_S 2u
+#define PH_MESH_UV 4u
+#define PH_MESH_REV 8u
+#define PH_MESH_SWAP 16u
+
+struct MaterialRec {  // MatteMaterial with constant textures (materials/src/matte.rs)
+    float kd[3];      // already clamp_default()'ed
+    float sigma;      // already clamped to [0,90]; 0 -> LambertianReflection
+    float a, b;       // OrenNayar A, B (core/src/reflection/oren_nayar.rs:28-39)
+    uint32_t has_bxdf; // !kd.is_black()
+    uint32_t pad;
+};
+
+enum { PH_L_INFINITE = 0, PH_L_DISTANT = 1, PH_L_POINT = 2, PH_L_AREA = 3 };
+struct LightRec {
+    int32_t type;
+    int32_t two_sided;
+    uint32_t prim;       // area: bound triangle
+    float area;          // area: Triangle::area()
+    float L[3];          // radiance / intensity
+    float pad0;
+    float v[3];          // distant: w_light; point: p_light
+    float pad1;
+    float l2w[12];       // infinite: rows 0..2 of light_to_world (3x4)
+    float w2l[12];       // infinite: rows 0..2 of world_to_light
+    // infinite: Distribution2D over the 2x2 scalar image (lights/src/infinite.rs:326-369)
+    float cond_func[4], cond_cdf[6], cond_int[2];
+    float marg_func[2], marg_cdf[3], marg_int;
+    float pad2[2];
+};
+
+struct CameraRec {  // cameras/src/perspective_camera.rs
+    float r2c[16];
+    float c2w[16];
+    float lens_radius, focal_distance, shutter_open, shutter_close;
+};
+
+struct FilmRec {  // core/src/film/mod.rs
+    int32_t xres, yres;
+    int32_t crop[4];
+    float radius[2], inv_radius[2];
+    float scale, max_lum;
+    float table[256];
+};
+
+struct SamplerRec {  // samplers/src/halton.rs:61-100
+    int32_t kind;  // 0 halton, 1 sobol
+    uint32_t spp;
+    int32_t bounds[4];
+    int32_t at_center;
+    // halton
+    uint32_t base_scales[2], base_exponents[2], sample_stride;
+    uint32_t mult_inverse[2];
+    // sobol
+    int32_t resolution, log2_resolution;
+};
+
+// Everything a kernel needs, passed by value (fits the 4 KB kernarg budget comfortably).
+struct DeviceScene {
+    const Node64* nodes;
+    const TriRec* tris;
+    uint32_t root_ref;        // PH_INVALID_REF when the scene is empty
+    uint32_t n_tris;
+    float root_lo[3], root_hi[3];
+    float world_center[3], world_radius;
+    // shading geometry
+    const float* P;           // 3 floats per vertex
+    const float* N;           // may be null
+    const float* S;
+    const float* UV;
+    const uint32_t* idx;      // 3 per triangle (global vertex ids)
+    const uint32_t* tri_mesh; // mesh id per triangle
+    const MeshRec* meshes;
+    const MaterialRec* materials;
+    const LightRec* lights;
+    uint32_t n_lights;
+    const uint32_t* infinite_lights;
+    uint32_t n_infinite;
+    // light-selection Distribution1D (core/src/sampling/distribution_1d.rs)
+    const float* ld_func;
+    const float* ld_cdf;      // n_lights + 1
+    float ld_func_int;
+    // sampler tables
+    const uint16_t* halton_perms;
+    const uint32_t* primes;       // 1000
+    const uint32_t* prime_sums;   // 1000
+    const uint32_t* sobol32;
+    const uint64_t* vdc;
+    const uint64_t* vdc_inv;
+};

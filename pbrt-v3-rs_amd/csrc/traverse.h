@@ -1,0 +1,262 @@
+// K2/K3/K5 — BVH traversal + watertight triangle test for gfx950 (wave64).
+//
+// Replaces BVHAccel::intersect / intersect_p (accelerators/src/bvh/mod.rs:173-283), Bounds3::intersect_p_inv
+// (core/src/geometry/bounds3.rs:292-325) and the accept/reject part of Triangle::intersect / intersect_p
+// (shapes/src/triangle.rs:438-545, 731-837), with GeometricPrimitive::intersect's `r.t_max = t`
+// (core/src/primitives/geometric_primitive.rs:67-88).
+//
+// Equivalence argument (why results are bit-identical to the reference, not merely "as good"):
+//  * same tree topology and leaf order (host builder restates sah.rs), same child visit order (dir_is_neg[axis]);
+//  * a child's box is tested when its PARENT is visited instead of when the child is popped.  The box test depends on
+//    the ray's t_max only through its last clause `t_min < ray.t_max`; the entry distance t_min is kept on the stack and
+//    that clause is re-evaluated with the current t_max when the entry is popped -> same visit/skip decision;
+//  * box and triangle arithmetic is the reference's expression order, compiled with -ffp-contract=off.
+//
+// Execution shape: persistent waves pull rays from a global counter (one atomic per refill, wave-aggregated with
+// ballot/popcount), per-lane replacement of finished rays, while-while traversal, traversal stack in LDS
+// ([depth][lane] so every push/pop is conflict-free) spilling to a per-lane global region beyond PH_LDS_DEPTH.
+#pragma once
+#include "dmath.h"
+#include "scene_types.h"
+
+namespace ph {
+
+struct alignas(16) RayIn { float ox, oy, oz, t_max, dx, dy, dz, time; };           // = PbrtHipRay
+struct alignas(16) HitOut { float t; uint32_t prim; float b0, b1, b2; uint32_t pad[3]; };  // = PbrtHipHit
+
+#ifndef PH_TRAV_BLOCK
+#define PH_TRAV_BLOCK 256
+#endif
+#ifndef PH_LDS_DEPTH
+#define PH_LDS_DEPTH 16
+#endif
+#define PH_MAX_STACK 64  // the reference's nodes_to_visit[64] (bvh/mod.rs:185)
+
+struct TravParams {
+    const RayIn* rays;
+    void* out;              // HitOut* (closest) or uint8_t* (any-hit)
+    uint32_t n;
+    uint32_t* counter;      // work-queue head, zeroed before launch
+    uint2* spill;           // [PH_MAX_STACK - PH_LDS_DEPTH][total_threads]
+    uint32_t total_threads;
+    uint32_t* error_flag;   // set to 1 on stack overflow (the reference would panic on index 64)
+};
+
+struct RayState {
+    float ox, oy, oz, dx, dy, dz, t_max;
+    float ix, iy, iz;       // 1/d (three IEEE divides, bvh/mod.rs:176)
+    int nx, ny, nz;         // dir_is_neg
+    int kx, ky, kz;         // triangle.rs:457-459
+    float sx, sy, sz;       // triangle.rs:467-469
+};
+
+PH_DEV void ray_setup(RayState& r, const RayIn& in) {
+    r.ox = in.ox; r.oy = in.oy; r.oz = in.oz; r.dx = in.dx; r.dy = in.dy; r.dz = in.dz; r.t_max = in.t_max;
+    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+    r.nx = r.ix < 0.0f ? 1 : 0; r.ny = r.iy < 0.0f ? 1 : 0; r.nz = r.iz < 0.0f ? 1 : 0;
+    f3 d = mk3(r.dx, r.dy, r.dz);
+    r.kz = max_dimension(vabs(d));
+    r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0;
+    r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0;
+    f3 dp = permute(d, r.kx, r.ky, r.kz);
+    r.sx = -dp.x / dp.z; r.sy = -dp.y / dp.z; r.sz = 1.0f / dp.z;
+}
+
+// Bounds3::intersect_p_inv without its final `t_min < ray.t_max` clause; returns t_min via reference.
+// Quirk B1 (z far plane not widened) is reproduced.
+PH_DEV bool box_test(const RayState& r, float xn, float xf, float yn, float yf, float zn, float zf, float& t_min_out) {
+    float t_min = (xn - r.ox) * r.ix;
+    float t_max = (xf - r.ox) * r.ix;
+    float t_y_min = (yn - r.oy) * r.iy;
+    float t_y_max = (yf - r.oy) * r.iy;
+    t_max *= kBoxScale;
+    t_y_max *= kBoxScale;
+    if (t_min > t_y_max || t_y_min > t_max) return false;
+    if (t_y_min > t_min) t_min = t_y_min;
+    if (t_y_max < t_max) t_max = t_y_max;
+    float t_z_min = (zn - r.oz) * r.iz;
+    float t_z_max = (zf - r.oz) * r.iz;
+    if (t_min > t_z_max || t_z_min > t_max) return false;
+    if (t_z_min > t_min) t_min = t_z_min;
+    if (t_z_max < t_max) t_max = t_z_max;
+    t_min_out = t_min;
+    return t_max > 0.0f;
+}
+
+// Triangle::intersect up to `if t <= delta_t` (triangle.rs:441-545).  Returns true when the reference proceeds past it.
+PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float& b0_out, float& b1_out, float& b2_out) {
+    f3 o = mk3(r.ox, r.oy, r.oz);
+    f3 p0t = permute(p0 - o, r.kx, r.ky, r.kz);
+    f3 p1t = permute(p1 - o, r.kx, r.ky, r.kz);
+    f3 p2t = permute(p2 - o, r.kx, r.ky, r.kz);
+    p0t.x += r.sx * p0t.z; p0t.y += r.sy * p0t.z;
+    p1t.x += r.sx * p1t.z; p1t.y += r.sy * p1t.z;
+    p2t.x += r.sx * p2t.z; p2t.y += r.sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {  // f64 fallback at edges (:483-495)
+        double a = (double)p2t.x * (double)p1t.y, b = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(b - a);
+        a = (double)p0t.x * (double)p2t.y; b = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(b - a);
+        a = (double)p1t.x * (double)p0t.y; b = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(b - a);
+    }
+    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0.0f) return false;
+    p0t.z *= r.sz; p1t.z *= r.sz; p2t.z *= r.sz;
+    float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0.0f && (t_scaled >= 0.0f || t_scaled < r.t_max * det)) return false;
+    else if (det > 0.0f && (t_scaled <= 0.0f || t_scaled > r.t_max * det)) return false;
+    float inv_det = 1.0f / det;
+    float b0 = e0 * inv_det, b1 = e1 * inv_det, b2 = e2 * inv_det, t = t_scaled * inv_det;
+    float max_z_t = max_component(vabs(mk3(p0t.z, p1t.z, p2t.z)));
+    float delta_z = kGamma3 * max_z_t;
+    float max_x_t = max_component(vabs(mk3(p0t.x, p1t.x, p2t.x)));
+    float max_y_t = max_component(vabs(mk3(p0t.y, p1t.y, p2t.y)));
+    float delta_x = kGamma5 * (max_x_t + max_z_t);
+    float delta_y = kGamma5 * (max_y_t + max_z_t);
+    float delta_e = 2.0f * (kGamma2 * max_x_t * max_y_t + delta_y * max_x_t + delta_x * max_y_t);
+    float max_e = max_component(vabs(mk3(e0, e1, e2)));
+    float delta_t = 3.0f * (kGamma3 * max_e * max_z_t + delta_e * max_z_t + delta_z * max_e) * fabsf(inv_det);
+    if (t <= delta_t) return false;
+    t_out = t; b0_out = b0; b1_out = b1; b2_out = b2;
+    return true;
+}
+
+template <bool ANYHIT>
+__global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc, TravParams p) {
+    __shared__ uint2 lds_stack[PH_LDS_DEPTH][PH_TRAV_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t gtid = blockIdx.x * PH_TRAV_BLOCK + tid;
+    const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    bool has_ray = false;
+    bool exhausted = false;  // wave-uniform
+    uint32_t ray_index = 0;
+    RayState r;
+    uint32_t cur = PH_INVALID_REF;
+    int sp = 0;
+    uint32_t hit_prim = 0xFFFFFFFFu;
+    float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
+    bool occluded = false;
+
+    auto push = [&](uint32_t ref, float tmin) {
+        uint2 e = make_uint2(ref, __float_as_uint(tmin));
+        if (sp < PH_LDS_DEPTH) lds_stack[sp][tid] = e;
+        else if (sp < PH_MAX_STACK) p.spill[(size_t)(sp - PH_LDS_DEPTH) * p.total_threads + gtid] = e;
+        else { *p.error_flag = 1u; return; }
+        sp++;
+    };
+    // pops entries until one survives `t_min < ray.t_max`; returns PH_INVALID_REF when the stack is empty
+    auto pop = [&]() -> uint32_t {
+        while (sp > 0) {
+            sp--;
+            uint2 e = (sp < PH_LDS_DEPTH) ? lds_stack[sp][tid] : p.spill[(size_t)(sp - PH_LDS_DEPTH) * p.total_threads + gtid];
+            if (__uint_as_float(e.y) < r.t_max) return e.x;
+        }
+        return PH_INVALID_REF;
+    };
+
+    for (;;) {
+        // ---- refill: idle lanes take the next rays of the queue (one atomic per wave) --------------------------------
+        if (!exhausted) {
+            const uint64_t idle = __ballot(!has_ray);
+            if (idle != 0ull) {
+                const uint32_t cnt = (uint32_t)__popcll(idle);
+                uint32_t base = 0;
+                if (lane == (uint32_t)(__ffsll((long long)idle) - 1)) base = atomicAdd(p.counter, cnt);
+                base = __shfl(base, __ffsll((long long)idle) - 1);
+                if (!has_ray) {
+                    const uint32_t my = base + (uint32_t)__popcll(idle & lane_lt);
+                    if (my < p.n) {
+                        ray_index = my;
+                        const float4* rp = reinterpret_cast<const float4*>(p.rays + my);
+                        const float4 a = rp[0], b = rp[1];
+                        RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = a.w; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
+                        ray_setup(r, in);
+                        has_ray = true; sp = 0; hit_prim = 0xFFFFFFFFu; hb0 = hb1 = hb2 = 0.0f; occluded = false;
+                        // root: the reference tests nodes[0].bounds first (bvh/mod.rs:189-190)
+                        cur = PH_INVALID_REF;
+                        if (sc.root_ref != PH_INVALID_REF) {
+                            float tmin;
+                            const bool h = box_test(r, r.nx ? sc.root_hi[0] : sc.root_lo[0], r.nx ? sc.root_lo[0] : sc.root_hi[0],
+                                                    r.ny ? sc.root_hi[1] : sc.root_lo[1], r.ny ? sc.root_lo[1] : sc.root_hi[1],
+                                                    r.nz ? sc.root_hi[2] : sc.root_lo[2], r.nz ? sc.root_lo[2] : sc.root_hi[2], tmin);
+                            if (h && tmin < r.t_max) cur = sc.root_ref;
+                        }
+                    }
+                }
+                if (base + cnt >= p.n) exhausted = true;
+            }
+        }
+        if (__ballot(has_ray) == 0ull) break;
+
+        // ---- traversal: while-while, bounded so that finished lanes get refilled ------------------------------------------
+        if (has_ray) {
+            int budget = 48;
+            while (cur != PH_INVALID_REF && budget > 0) {
+                // interior nodes
+                while (cur != PH_INVALID_REF && !(cur & PH_LEAF_BIT)) {
+                    const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+                    const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+                    const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
+                    // q0 = x0[0],x0[1],y0[0],y0[1]; q1 = z0[0],z0[1],x1[0],x1[1]; q2 = y1[0],y1[1],z1[0],z1[1]
+                    float t0, t1;
+                    bool h0 = box_test(r, r.nx ? q0.y : q0.x, r.nx ? q0.x : q0.y, r.ny ? q0.w : q0.z, r.ny ? q0.z : q0.w,
+                                       r.nz ? q1.y : q1.x, r.nz ? q1.x : q1.y, t0);
+                    bool h1 = box_test(r, r.nx ? q1.w : q1.z, r.nx ? q1.z : q1.w, r.ny ? q2.y : q2.x, r.ny ? q2.x : q2.y,
+                                       r.nz ? q2.w : q2.z, r.nz ? q2.z : q2.w, t1);
+                    h0 = h0 && (t0 < r.t_max);
+                    h1 = h1 && (t1 < r.t_max);
+                    const int neg_axis = q3.z == 0 ? r.nx : (q3.z == 1 ? r.ny : r.nz);
+                    // bvh/mod.rs:206-214: dir_is_neg[axis] -> second child first
+                    const uint32_t near_ref = neg_axis ? q3.y : q3.x, far_ref = neg_axis ? q3.x : q3.y;
+                    const bool near_hit = neg_axis ? h1 : h0, far_hit = neg_axis ? h0 : h1;
+                    const float far_t = neg_axis ? t0 : t1;
+                    if (near_hit) { cur = near_ref; if (far_hit) push(far_ref, far_t); }
+                    else if (far_hit) cur = far_ref;
+                    else cur = pop();
+                    budget--;
+                }
+                // leaf
+                if (cur != PH_INVALID_REF) {
+                    uint32_t ti = cur & ~PH_LEAF_BIT;
+                    bool last = false;
+                    while (!last) {
+                        const float4* tp = reinterpret_cast<const float4*>(sc.tris + ti);
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        const uint32_t flags = __float_as_uint(b.w);
+                        last = (flags & PH_TRI_LAST) != 0;
+                        float t, b0, b1, b2;
+                        if (tri_test(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), t, b0, b1, b2)) {
+                            // post-t rejections: degenerate triangle (triangle.rs:567-570 / 862-866), alpha == 0 (:603 / :886-893)
+                            const uint32_t reject = ANYHIT ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
+                            if (!(flags & reject)) {
+                                if (ANYHIT) { occluded = true; last = true; }
+                                else { r.t_max = t; hit_prim = __float_as_uint(a.w); hb0 = b0; hb1 = b1; hb2 = b2; }
+                            }
+                        }
+                        ti++;
+                    }
+                    cur = (ANYHIT && occluded) ? PH_INVALID_REF : pop();
+                    budget--;
+                }
+            }
+            if (cur == PH_INVALID_REF) {
+                if (ANYHIT) reinterpret_cast<uint8_t*>(p.out)[ray_index] = occluded ? 1 : 0;
+                else {
+                    float4* hp = reinterpret_cast<float4*>(reinterpret_cast<HitOut*>(p.out) + ray_index);
+                    hp[0] = make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1);
+                    hp[1] = make_float4(hb2, 0.0f, 0.0f, 0.0f);
+                }
+                has_ray = false;
+            }
+        }
+    }
+}
+
+}  // namespace ph

@@ -1,0 +1,393 @@
+"""pbrt_hip — thin ctypes host binding over libpbrt_hip.so (include/pbrt_hip.h).
+
+This is plumbing, not the product: every compute call goes straight through the C ABI into hand-written gfx950
+kernels.  The class layout mirrors the reference's plugin surface for the path: a `Scene` is captured
+with the same calls the reference's factories make (api/src/graphics_state.rs:254-720) and `render_path` stands in
+for `Integrator::render` (core/src/integrator/mod.rs:16-39).
+
+`Binding(lib, prefix)` is deliberately generic over the symbol prefix so that the TEST harness can drive the CPU
+oracle (liboracle.so, prefix ``oracle_``) through the identical Python code; nothing in this package imports or
+loads anything under oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libpbrt_hip.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_STATE, ERR_DEVICE, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = -1, -2, -3, -4, -5, -6
+
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("t_max", "<f4"), ("d", "<f4", 3), ("time", "<f4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<u4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"), ("pad", "<u4", 3)])
+assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 32
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("camera_rays", C.c_uint64), ("regular_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+        ("paths_zero_radiance", C.c_uint64), ("paths_total", C.c_uint64),
+        ("render_seconds", C.c_double), ("extend_seconds", C.c_double), ("shadow_seconds", C.c_double),
+        ("shade_seconds", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class PbrtHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pbrt_hip error {code}: {msg}")
+        self.code = code
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+class Binding:
+    """Loads a shared library exporting the include/pbrt_hip.h entry points under `prefix`."""
+
+    def __init__(self, path: str, prefix: str = "pbrt_hip_"):
+        if not os.path.exists(path):
+            raise PbrtHipError(ERR_NO_DEVICE, f"{path} not built — run __graft_entry__.build() (no CPU fallback exists)")
+        self.lib = C.CDLL(path)
+        self.prefix = prefix
+        self.path = path
+        f = self.fn
+        vp, fp, ip, u32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_uint32)
+        sig = {
+            "device_count": (C.c_int, []),
+            "scene_create": (vp, [C.c_int]),
+            "scene_destroy": (None, [vp]),
+            "last_error": (C.c_char_p, [vp]),
+            "add_material_matte": (C.c_int, [vp, fp, C.c_float, u32p]),
+            "add_mesh": (C.c_int, [vp, fp, C.c_uint32, u32p, C.c_uint32, fp, fp, fp, C.c_uint32, C.c_int32, C.c_uint32, C.c_float, C.c_float]),
+            "add_light_infinite": (C.c_int, [vp, fp, fp, fp]),
+            "add_light_distant": (C.c_int, [vp, fp, fp]),
+            "add_light_point": (C.c_int, [vp, fp, fp]),
+            "add_light_diffuse_area": (C.c_int, [vp, fp, C.c_int, C.c_uint32, u32p]),
+            "set_camera_perspective": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]),
+            "set_film": (C.c_int, [vp, C.c_int, C.c_int, ip, fp, fp, C.c_float, C.c_float]),
+            "set_sampler": (C.c_int, [vp, C.c_int, C.c_uint32, ip, C.c_int]),
+            "set_sobol_tables": (C.c_int, [vp, u32p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t]),
+            "build_accel": (C.c_int, [vp, C.c_int, C.c_int]),
+            "world_bound": (C.c_int, [vp, fp]),
+            "intersect_batch": (C.c_int, [vp, vp, vp, C.c_uint64]),
+            "occluded_batch": (C.c_int, [vp, vp, vp, C.c_uint64]),
+            "render_path": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, ip, C.c_int, C.c_int, C.c_int, fp, fp, C.POINTER(Stats)]),
+            "film_to_rgb": (C.c_int, [vp, fp, fp, fp]),
+            "generate_camera_rays": (C.c_int, [vp, ip, C.c_uint32, vp, fp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = f(name)
+            fn.restype, fn.argtypes = res, args
+        self._optional = {
+            "intersect_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, fp]),
+            "occluded_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, fp]),
+            "tile_buffer_floats": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+            "render_path_tiles_device": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, ip, C.c_int, C.c_int, C.c_int, vp, C.POINTER(Stats)]),
+            "merge_tiles_device": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp), fp, fp]),
+        }
+        for name, (res, args) in self._optional.items():
+            if hasattr(self.lib, prefix + name):
+                fn = f(name)
+                fn.restype, fn.argtypes = res, args
+
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def has(self, name):
+        return hasattr(self.lib, self.prefix + name)
+
+
+_default = None
+
+
+def default_binding() -> Binding:
+    """The product library.  Fails loudly when it has not been built."""
+    global _default
+    if _default is None:
+        _default = Binding(LIB_PATH, "pbrt_hip_")
+    return _default
+
+
+class Host:
+    """pbrt_hip_host_* helpers (include/pbrt_hip_host.h): the reference's scene set-up arithmetic, host side."""
+
+    def __init__(self, binding: Binding | None = None):
+        b = binding or default_binding()
+        self.lib = b.lib
+        fp = C.POINTER(C.c_float)
+        L = self.lib
+        L.pbrt_hip_host_look_at.restype = C.c_int
+        L.pbrt_hip_host_gen_random_tris.argtypes = [C.c_uint64, C.c_uint64, fp, C.POINTER(C.c_uint32)]
+        L.pbrt_hip_host_rotate.argtypes = [C.c_float, fp, fp, fp]
+        L.pbrt_hip_host_perspective_raster_to_camera.argtypes = [C.c_float, C.c_int, C.c_int, fp, fp]
+        L.pbrt_hip_host_transform_points.argtypes = [fp, fp, fp, C.c_size_t]
+        L.pbrt_hip_host_transform_vectors.argtypes = [fp, fp, fp, C.c_size_t]
+        L.pbrt_hip_host_transform_normals.argtypes = [fp, fp, fp, C.c_size_t]
+
+    @staticmethod
+    def _m():
+        return np.zeros(16, np.float32)
+
+    def look_at(self, pos, look, up):
+        m, mi = self._m(), self._m()
+        rc = self.lib.pbrt_hip_host_look_at(_ptr(_f32(pos), C.c_float), _ptr(_f32(look), C.c_float), _ptr(_f32(up), C.c_float), _ptr(m, C.c_float), _ptr(mi, C.c_float))
+        if rc != 0:
+            raise PbrtHipError(ERR_INVALID_ARG, "look_at: up vector and viewing direction are parallel")
+        return m, mi  # world->camera, camera->world
+
+    def translate(self, d):
+        m, mi = self._m(), self._m()
+        self.lib.pbrt_hip_host_translate(_ptr(_f32(d), C.c_float), _ptr(m, C.c_float), _ptr(mi, C.c_float))
+        return m, mi
+
+    def scale(self, s):
+        m, mi = self._m(), self._m()
+        self.lib.pbrt_hip_host_scale(_ptr(_f32(s), C.c_float), _ptr(m, C.c_float), _ptr(mi, C.c_float))
+        return m, mi
+
+    def rotate(self, theta_deg, axis):
+        m, mi = self._m(), self._m()
+        self.lib.pbrt_hip_host_rotate(C.c_float(theta_deg), _ptr(_f32(axis), C.c_float), _ptr(m, C.c_float), _ptr(mi, C.c_float))
+        return m, mi
+
+    def compose(self, a, b):
+        m, mi = self._m(), self._m()
+        self.lib.pbrt_hip_host_compose(_ptr(a[0], C.c_float), _ptr(a[1], C.c_float), _ptr(b[0], C.c_float), _ptr(b[1], C.c_float), _ptr(m, C.c_float), _ptr(mi, C.c_float))
+        return m, mi
+
+    def screen_window(self, xres, yres):
+        s = np.zeros(4, np.float32)
+        self.lib.pbrt_hip_host_screen_window(xres, yres, _ptr(s, C.c_float))
+        return s
+
+    def perspective_raster_to_camera(self, fov, xres, yres, screen=None):
+        if screen is None:
+            screen = self.screen_window(xres, yres)
+        m = self._m()
+        self.lib.pbrt_hip_host_perspective_raster_to_camera(C.c_float(fov), xres, yres, _ptr(_f32(screen), C.c_float), _ptr(m, C.c_float))
+        return m
+
+    def film_box(self, xres, yres, crop_window=(0.0, 1.0, 0.0, 1.0), radius=(0.5, 0.5)):
+        cb, sb, table = np.zeros(4, np.int32), np.zeros(4, np.int32), np.zeros(256, np.float32)
+        self.lib.pbrt_hip_host_film_box(xres, yres, _ptr(_f32(crop_window), C.c_float), _ptr(_f32(radius), C.c_float), _ptr(cb, C.c_int), _ptr(table, C.c_float), _ptr(sb, C.c_int))
+        return cb, table, sb
+
+    def transform_points(self, m, pts):
+        pts = _f32(pts, (-1, 3)); out = np.empty_like(pts)
+        self.lib.pbrt_hip_host_transform_points(_ptr(_f32(m), C.c_float), _ptr(pts, C.c_float), _ptr(out, C.c_float), len(pts))
+        return out
+
+    def gen_random_tris(self, n_tris, seed):
+        P = np.empty((3 * n_tris, 3), np.float32)
+        idx = np.empty(3 * n_tris, np.uint32)
+        self.lib.pbrt_hip_host_gen_random_tris(n_tris, seed, _ptr(P, C.c_float), _ptr(idx, C.c_uint32))
+        return P, idx
+
+
+IDENTITY = np.eye(4, dtype=np.float32).reshape(16)
+
+
+class Scene:
+    """One captured scene on one device (PbrtHipScene*).  Not re-entrant, like the C handle."""
+
+    def __init__(self, binding: Binding | None = None, device: int = 0):
+        self.b = binding or default_binding()
+        self.h = self.b.fn("scene_create")(device)
+        if not self.h:
+            msg = self.b.fn("last_error")(None)
+            raise PbrtHipError(ERR_NO_DEVICE, (msg or b"scene_create failed").decode())
+        self.film_shape = None
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.b.fn("scene_destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            msg = self.b.fn("last_error")(self.h)
+            raise PbrtHipError(rc, (msg or b"").decode())
+
+    # ---- capture -------------------------------------------------------------------------------------------------
+    def add_material_matte(self, kd=(0.5, 0.5, 0.5), sigma=0.0) -> int:
+        out = C.c_uint32(0)
+        self._chk(self.b.fn("add_material_matte")(self.h, _ptr(_f32(kd), C.c_float), C.c_float(sigma), C.byref(out)))
+        return out.value
+
+    def add_mesh(self, P, indices, material, N=None, S=None, UV=None, first_area_light=-1, reverse_orientation=False,
+                 swaps_handedness=False, alpha=1.0, shadow_alpha=1.0):
+        P = _f32(P, (-1, 3)); idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        N = _f32(N, (-1, 3)) if N is not None else None
+        S = _f32(S, (-1, 3)) if S is not None else None
+        UV = _f32(UV, (-1, 2)) if UV is not None else None
+        flags = (1 if reverse_orientation else 0) | (2 if swaps_handedness else 0)
+        self._chk(self.b.fn("add_mesh")(self.h, _ptr(P, C.c_float), len(P), _ptr(idx, C.c_uint32), len(idx) // 3, _ptr(N, C.c_float),
+                                        _ptr(S, C.c_float), _ptr(UV, C.c_float), material, first_area_light, flags, C.c_float(alpha), C.c_float(shadow_alpha)))
+
+    def add_light_infinite(self, L=(1, 1, 1), light_to_world=None, world_to_light=None):
+        l2w = _f32(light_to_world if light_to_world is not None else IDENTITY)
+        w2l = _f32(world_to_light if world_to_light is not None else IDENTITY)
+        self._chk(self.b.fn("add_light_infinite")(self.h, _ptr(_f32(L), C.c_float), _ptr(l2w, C.c_float), _ptr(w2l, C.c_float)))
+
+    def add_light_distant(self, L, w_light_world):
+        self._chk(self.b.fn("add_light_distant")(self.h, _ptr(_f32(L), C.c_float), _ptr(_f32(w_light_world), C.c_float)))
+
+    def add_light_point(self, I, p_world):
+        self._chk(self.b.fn("add_light_point")(self.h, _ptr(_f32(I), C.c_float), _ptr(_f32(p_world), C.c_float)))
+
+    def add_light_diffuse_area(self, L, n_tris, two_sided=False) -> int:
+        out = C.c_uint32(0)
+        self._chk(self.b.fn("add_light_diffuse_area")(self.h, _ptr(_f32(L), C.c_float), 1 if two_sided else 0, n_tris, C.byref(out)))
+        return out.value
+
+    def set_camera_perspective(self, raster_to_camera, camera_to_world, lens_radius=0.0, focal_distance=1e6, shutter_open=0.0, shutter_close=1.0):
+        self._chk(self.b.fn("set_camera_perspective")(self.h, _ptr(_f32(raster_to_camera), C.c_float), _ptr(_f32(camera_to_world), C.c_float),
+                                                      C.c_float(lens_radius), C.c_float(focal_distance), C.c_float(shutter_open), C.c_float(shutter_close)))
+
+    def set_film(self, xres, yres, cropped_bounds, radius, table, scale=1.0, max_sample_luminance=float("inf")):
+        cb = np.ascontiguousarray(cropped_bounds, dtype=np.int32)
+        self._chk(self.b.fn("set_film")(self.h, xres, yres, _ptr(cb, C.c_int), _ptr(_f32(radius), C.c_float), _ptr(_f32(table), C.c_float),
+                                        C.c_float(scale), C.c_float(max_sample_luminance)))
+        self.film_shape = (int(cb[3] - cb[1]), int(cb[2] - cb[0]))
+        self.cropped_bounds = cb
+
+    def set_sampler(self, kind, spp, sample_bounds, sample_at_pixel_center=False):
+        sb = np.ascontiguousarray(sample_bounds, dtype=np.int32)
+        self._chk(self.b.fn("set_sampler")(self.h, kind, spp, _ptr(sb, C.c_int), 1 if sample_at_pixel_center else 0))
+        self.sample_bounds = sb
+
+    def build_accel(self, split_method=0, max_prims_in_node=4):
+        self._chk(self.b.fn("build_accel")(self.h, split_method, max_prims_in_node))
+
+    def world_bound(self):
+        out = np.zeros(6, np.float32)
+        self._chk(self.b.fn("world_bound")(self.h, _ptr(out, C.c_float)))
+        return out
+
+    # ---- hot path ------------------------------------------------------------------------------------------------
+    def intersect_batch(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        self._chk(self.b.fn("intersect_batch")(self.h, rays.ctypes.data, hits.ctypes.data, len(rays)))
+        return hits
+
+    def occluded_batch(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        out = np.zeros(len(rays), np.uint8)
+        self._chk(self.b.fn("occluded_batch")(self.h, rays.ctypes.data, out.ctypes.data, len(rays)))
+        return out
+
+    def intersect_batch_device(self, d_rays_ptr, d_hits_ptr, n):
+        ms = C.c_float(0)
+        self._chk(self.b.fn("intersect_batch_device")(self.h, d_rays_ptr, d_hits_ptr, n, C.byref(ms)))
+        return ms.value
+
+    def occluded_batch_device(self, d_rays_ptr, d_out_ptr, n):
+        ms = C.c_float(0)
+        self._chk(self.b.fn("occluded_batch_device")(self.h, d_rays_ptr, d_out_ptr, n, C.byref(ms)))
+        return ms.value
+
+    def render_path(self, max_depth=5, rr_threshold=1.0, light_strategy=2, pixel_bounds=None, tile_size=16, tile_part=0, tile_parts=1):
+        h, w = self.film_shape
+        xyz = np.zeros((h, w, 3), np.float32); wt = np.zeros((h, w), np.float32)
+        pb = np.ascontiguousarray(pixel_bounds if pixel_bounds is not None else self.sample_bounds, dtype=np.int32)
+        st = Stats()
+        self._chk(self.b.fn("render_path")(self.h, max_depth, C.c_float(rr_threshold), light_strategy, _ptr(pb, C.c_int), tile_size, tile_part, tile_parts,
+                                           _ptr(xyz, C.c_float), _ptr(wt, C.c_float), C.byref(st)))
+        return xyz, wt, st
+
+    def film_to_rgb(self, xyz, weight):
+        rgb = np.zeros_like(xyz)
+        self._chk(self.b.fn("film_to_rgb")(self.h, _ptr(_f32(xyz), C.c_float), _ptr(_f32(weight), C.c_float), _ptr(rgb, C.c_float)))
+        return rgb
+
+    def generate_camera_rays(self, pixel_bounds, sample_index):
+        pb = np.ascontiguousarray(pixel_bounds, dtype=np.int32)
+        n = int((pb[2] - pb[0]) * (pb[3] - pb[1]))
+        rays = np.zeros(n, RAY_DTYPE); pf = np.zeros((n, 2), np.float32)
+        self._chk(self.b.fn("generate_camera_rays")(self.h, _ptr(pb, C.c_int), sample_index, rays.ctypes.data, _ptr(pf, C.c_float)))
+        return rays, pf
+
+    def tile_buffer_floats(self, tile_size, tile_part, tile_parts):
+        out = C.c_uint64(0)
+        self._chk(self.b.fn("tile_buffer_floats")(self.h, tile_size, tile_part, tile_parts, C.byref(out)))
+        return out.value
+
+    def render_path_tiles_device(self, d_tile_buffer_ptr, max_depth=5, rr_threshold=1.0, light_strategy=2, pixel_bounds=None, tile_size=16, tile_part=0, tile_parts=1):
+        pb = np.ascontiguousarray(pixel_bounds if pixel_bounds is not None else self.sample_bounds, dtype=np.int32)
+        st = Stats()
+        self._chk(self.b.fn("render_path_tiles_device")(self.h, max_depth, C.c_float(rr_threshold), light_strategy, _ptr(pb, C.c_int), tile_size, tile_part, tile_parts,
+                                                        d_tile_buffer_ptr, C.byref(st)))
+        return st
+
+    def merge_tiles_device(self, d_ptrs, tile_size=16):
+        h, w = self.film_shape
+        xyz = np.zeros((h, w, 3), np.float32); wt = np.zeros((h, w), np.float32)
+        arr = (C.c_void_p * len(d_ptrs))(*d_ptrs)
+        self._chk(self.b.fn("merge_tiles_device")(self.h, tile_size, len(d_ptrs), arr, _ptr(xyz, C.c_float), _ptr(wt, C.c_float)))
+        return xyz, wt
+
+
+@dataclass
+class SceneSpec:
+    """The synthetic measurement scene of BASELINE.md §3 / SURVEY §8d, as plain data, so that the same description can
+    be captured into any Binding (product or, in tests, the oracle)."""
+    n_tris: int = 1000
+    seed: int = 1
+    xres: int = 64
+    yres: int = 64
+    spp: int = 4
+    max_depth: int = 5
+    fov: float = 40.0
+    kd: tuple = (0.5, 0.5, 0.5)
+    sigma: float = 0.0
+    env_L: tuple = (1.0, 1.0, 1.0)
+    eye: tuple = (0.0, -4.0, 0.0)
+    look: tuple = (0.0, 0.0, 0.0)
+    up: tuple = (0.0, 0.0, 1.0)
+
+
+def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None):
+    """LookAt 0 -4 0  0 0 0  0 0 1 / perspective fov 40 / box filter / halton / matte 0.5 / infinite L=1."""
+    P, idx = geometry if geometry is not None else host.gen_random_tris(spec.n_tris, spec.seed)
+    mat = scene.add_material_matte(spec.kd, spec.sigma)
+    if spec.env_L is not None:
+        scene.add_light_infinite(spec.env_L)
+    scene.add_mesh(P, idx, mat)
+    w2c, c2w = host.look_at(spec.eye, spec.look, spec.up)
+    r2c = host.perspective_raster_to_camera(spec.fov, spec.xres, spec.yres)
+    scene.set_camera_perspective(r2c, c2w)
+    cb, table, sb = host.film_box(spec.xres, spec.yres)
+    scene.set_film(spec.xres, spec.yres, cb, (0.5, 0.5), table)
+    scene.set_sampler(0, spec.spp, sb)
+    scene.build_accel(0, 4)
+    return P, idx
