@@ -76,6 +76,7 @@ int upload_scene(PbrtHipScene* s) {
     if (s->any_uv && (rc = upload_vec(s, s->UV, &d.UV))) return rc;
     if ((rc = upload_vec(s, s->idx, &d.idx))) return rc;
     if ((rc = upload_vec(s, s->tri_mesh, &d.tri_mesh))) return rc;
+    if ((rc = upload_vec(s, s->tri_flags, &d.tri_flags))) return rc;
     if ((rc = upload_vec(s, s->meshes, &d.meshes))) return rc;
     if ((rc = upload_vec(s, s->materials, &d.materials))) return rc;
     if ((rc = upload_vec(s, s->lights, &d.lights))) return rc;
@@ -158,7 +159,7 @@ int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_ou
     if ((rc = ensure_buf(s, s->d_spill, (size_t)(PH_MAX_STACK - PH_LDS_DEPTH) * total_threads * sizeof(uint2)))) return rc;
     PH_CHECK(s, hipMemsetAsync(s->d_counter.p, 0, 4, s->stream));
     ph::TravParams p;
-    p.rays = (const ph::RayIn*)d_rays; p.out = d_out; p.n = n;
+    p.rays = (const ph::RayIn*)d_rays; p.out = d_out; p.n = n; p.n_ptr = nullptr;
     p.counter = (uint32_t*)s->d_counter.p; p.spill = (uint2*)s->d_spill.p; p.total_threads = total_threads;
     p.error_flag = (uint32_t*)s->d_error.p;
     if (kernel_ms) PH_CHECK(s, hipEventRecord(s->ev0, s->stream));

@@ -112,6 +112,7 @@ struct DeviceScene {
     const float* UV;
     const uint32_t* idx;      // 3 per triangle (global vertex ids)
     const uint32_t* tri_mesh; // mesh id per triangle
+    const uint32_t* tri_flags; // PH_TRI_BOGUS/ALPHA0/SALPHA0 per triangle (add_mesh order)
     const MeshRec* meshes;
     const MaterialRec* materials;
     const LightRec* lights;

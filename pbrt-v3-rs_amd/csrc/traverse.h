@@ -35,7 +35,8 @@ struct alignas(16) HitOut { float t; uint32_t prim; float b0, b1, b2; uint32_t p
 struct TravParams {
     const RayIn* rays;
     void* out;              // HitOut* (closest) or uint8_t* (any-hit)
-    uint32_t n;
+    uint32_t n;             // ray count, or (n_ptr != nullptr) read from device memory: no host sync between wavefront stages
+    const uint32_t* n_ptr;
     uint32_t* counter;      // work-queue head, zeroed before launch
     uint2* spill;           // [PH_MAX_STACK - PH_LDS_DEPTH][total_threads]
     uint32_t total_threads;
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * PH_TRAV_BLOCK + tid;
     const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t n_rays = p.n_ptr ? *p.n_ptr : p.n;
 
     bool has_ray = false;
     bool exhausted = false;  // wave-uniform
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                 base = __shfl(base, __ffsll((long long)idle) - 1);
                 if (!has_ray) {
                     const uint32_t my = base + (uint32_t)__popcll(idle & lane_lt);
-                    if (my < p.n) {
+                    if (my < n_rays) {
                         ray_index = my;
                         const float4* rp = reinterpret_cast<const float4*>(p.rays + my);
                         const float4 a = rp[0], b = rp[1];
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                         }
                     }
                 }
-                if (base + cnt >= p.n) exhausted = true;
+                if (base + cnt >= n_rays) exhausted = true;
             }
         }
         if (__ballot(has_ray) == 0ull) break;

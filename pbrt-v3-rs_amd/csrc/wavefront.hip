@@ -1,7 +1,779 @@
-// placeholder: the wavefront renderer lands next
+// Wavefront path tracer: SamplerIntegrator::render (core/src/integrator/sampler_integrator.rs:243-415) driving
+// PathIntegrator::li (integrators/src/path.rs:103-284) as a sequence of data-parallel stages over a pool of paths.
+//
+//   K1 raygen   get_camera_sample + generate_ray_differential                      (sampler/mod.rs:45-53, perspective_camera.rs:144-204)
+//   K2 extend   closest hit for extension rays AND the previous vertex's MIS rays     (traverse.h)
+//   K5 shadow   any hit for the previous vertex's shadow rays                       (traverse.h)
+//   K4 shade    resolve the previous vertex's direct lighting (K6), then li's loop body for the new vertex
+//   K7 film     FilmTile::add_sample in the reference's accumulation order, Film::merge_film_tile in tile order
+//
+// No host synchronisation inside a chunk: every stage reads its item count from device memory (queue counters written by
+// the previous stage with one wave-aggregated atomic per wave, __ballot/__popcll/__shfl), the traversal kernels are
+// persistent, and a chunk is one fixed launch sequence.
+//
+// Float accumulation order is the reference's: L gets Le, then each vertex's Ld in bounce order (the MIS/shadow results of
+// vertex k are folded in by the shade pass of iteration k+1 before anything of vertex k+1 is added); a pixel's FilmTile
+// sums run over its samples in (pixel row-major, sample index) order.
+#include "host_math.h"
+#include "pt_device.h"
 #include "scene_host.h"
-namespace phost { void free_wavefront(PbrtHipScene*) {} }
-extern "C" {
-int pbrt_hip_render_path(PbrtHipScene* s, int, float, int, const int*, int, int, int, float*, float*, PbrtHipStats*) { return phost::set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "not yet"); }
-int pbrt_hip_generate_camera_rays(PbrtHipScene* s, const int*, uint32_t, PbrtHipRay*, float*) { return phost::set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "not yet"); }
+#include <algorithm>
+#include <cstdlib>
+
+namespace ph {
+
+enum : uint32_t { F_EXT = 1u, F_PSH = 2u, F_PMIS = 4u };
+
+struct IterCounters {  // one per wavefront iteration, zeroed at chunk start
+    uint32_t n_cl, n_sh, n_live, head_cl, head_sh, pad[3];
+};
+struct DevStats { unsigned long long camera_rays, paths_total, paths_zero; };
+
+struct TileInfo {  // one per local tile (tiles with index % parts == part, increasing index)
+    int32_t tb[4];       // sample bounds of the tile (sampler_integrator.rs:331-336)
+    int32_t pb[4];       // FilmTile pixel bounds (film/mod.rs:182-198)
+    uint32_t px_off;     // first pixel of the tile in the rank's pixel list
+    uint32_t tile_index; // global tile index
+};
+
+struct WfParams {
+    // configuration
+    CameraRec cam; SamplerRec sp;
+    int32_t pixel_bounds[4];
+    int32_t max_depth; float rr_threshold;
+    uint32_t n_px;          // pixels in this rank's tiles
+    uint32_t chunk_spp, s0; // samples [s0, s0+chunk_spp) of every pixel in this chunk
+    uint32_t B;             // n_px * chunk_spp
+    // pixel list
+    const int2* px_xy;
+    // queues
+    RayIn* rays_cl[2]; HitOut* hits_cl; RayIn* rays_sh; uint8_t* occ; uint32_t* live[2];
+    IterCounters* ctr;
+    DevStats* stats;
+    // path state
+    float4* s_L; float4* s_beta; float4* s_A; float4* s_f2; float4* s_bold; uint4* s_idx;
+    // per-sample records of the whole render: {L.rgb, p_film.x} {p_film.y}
+    float4* rec_L; float* rec_py;
+};
+
+PH_DEV uint32_t wave_alloc(uint32_t* ctr, bool want) {
+    const uint64_t m = __ballot(want);
+    if (m == 0ull) return 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(ctr, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    return base + (uint32_t)__popcll(m & lt);
 }
+
+PH_DEV SamplerCursor cursor_for(const DeviceScene& sc, const SamplerRec& sp, int px, int py, uint32_t s, uint32_t dim) {
+    SamplerCursor c; c.px = px; c.py = py; c.dim = dim;
+    if (sp.kind == 0) c.index = (uint64_t)halton_pixel_offset(sp, px, py) + (uint64_t)s * sp.sample_stride;  // halton.rs:143
+    else c.index = sobol_interval_to_index(sc, (uint32_t)sp.log2_resolution, s, px - sp.bounds[0], py - sp.bounds[1]);
+    return c;
+}
+PH_DEV void store_ray(RayIn* dst, const RayIn& r) {
+    float4* p = reinterpret_cast<float4*>(dst);
+    p[0] = make_float4(r.ox, r.oy, r.oz, r.t_max); p[1] = make_float4(r.dx, r.dy, r.dz, r.time);
+}
+PH_DEV RayIn load_ray(const RayIn* src) {
+    const float4* p = reinterpret_cast<const float4*>(src);
+    float4 a = p[0], b = p[1];
+    RayIn r; r.ox = a.x; r.oy = a.y; r.oz = a.z; r.t_max = a.w; r.dx = b.x; r.dy = b.y; r.dz = b.z; r.time = b.w; return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// K1: one thread per (pixel, sample) of the chunk
+__global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w) {
+    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = pid < w.B;
+    RayIn ray;
+    if (active) {
+        const uint32_t pix = pid / w.chunk_spp, j = pid - pix * w.chunk_spp, s = w.s0 + j;
+        const int2 xy = w.px_xy[pix];
+        // pixels outside the integrator's pixel_bounds are skipped after start_pixel (sampler_integrator.rs:348-350)
+        active = xy.x >= w.pixel_bounds[0] && xy.x < w.pixel_bounds[2] && xy.y >= w.pixel_bounds[1] && xy.y < w.pixel_bounds[3];
+        const size_t gsi = (size_t)pix * w.sp.spp + s;
+        if (active) {
+            SamplerCursor c = cursor_for(sc, w.sp, xy.x, xy.y, s, 0);
+            f2 fs = get_2d(sc, w.sp, c);
+            f2 p_film = mk2((float)xy.x + fs.x, (float)xy.y + fs.y);
+            float time = get_1d(sc, w.sp, c);
+            f2 lens = get_2d(sc, w.sp, c);
+            generate_camera_ray(w.cam, p_film, time, lens, ray);
+            w.rec_L[gsi] = make_float4(0.0f, 0.0f, 0.0f, p_film.x);
+            w.rec_py[gsi] = p_film.y;
+            w.s_L[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            w.s_beta[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        } else {
+            w.rec_L[gsi] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0x7fc00000u));  // NaN p_film.x marks "no sample"
+            w.rec_py[gsi] = 0.0f;
+        }
+    }
+    const uint32_t slot = wave_alloc(&w.ctr[0].n_cl, active);
+    const uint32_t lslot = wave_alloc(&w.ctr[0].n_live, active);
+    if (active) {
+        store_ray(w.rays_cl[0] + slot, ray);
+        w.live[0][lslot] = pid;
+        w.s_idx[pid] = make_uint4(slot, 0u, 0u, F_EXT | (0u << 8) | (5u << 16));  // bounces 0, next sampler dimension 5
+        atomicAdd(&w.stats->camera_rays, 1ull);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// K4 (+K6): one thread per live path
+__global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, WfParams w, int it) {
+    const uint32_t n_live = w.ctr[it].n_live;
+    const RayIn* rays_in = w.rays_cl[it & 1];
+    RayIn* rays_out = w.rays_cl[(it + 1) & 1];
+    const uint32_t* live_in = w.live[it & 1];
+    uint32_t* live_out = w.live[(it + 1) & 1];
+    IterCounters* next = w.ctr + it + 1;
+
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n_live; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < n_live;
+        bool want_ext = false, want_mis = false, want_sh = false, still_live = false;
+        RayIn ray_ext, ray_mis, ray_sh;
+        uint32_t pid = 0, flags = 0, bounces = 0, dim = 0;
+        uint4 idx4 = make_uint4(0, 0, 0, 0);
+        spec L = mks1(0.0f), beta = mks1(1.0f);
+        float4 pA = make_float4(0, 0, 0, 0), pF2 = make_float4(0, 0, 0, 0), pBold = make_float4(0, 0, 0, 0);
+        float pick_pdf = 0.0f, w2 = 0.0f;
+        bool new_pending = false;
+
+        if (active) {
+            pid = live_in[i];
+            idx4 = w.s_idx[pid];
+            flags = idx4.w & 0xffu; bounces = (idx4.w >> 8) & 0xffu; dim = idx4.w >> 16;
+            const float4 L4 = w.s_L[pid], b4 = w.s_beta[pid];
+            L = mks(L4.x, L4.y, L4.z); beta = mks(b4.x, b4.y, b4.z);
+
+            // ---- K6: finish uniform_sample_one_light of the previous vertex (integrator/common.rs:196-221, 276-295, 132) ----
+            if (flags & (F_PSH | F_PMIS)) {
+                const float4 A4 = w.s_A[pid], F4 = w.s_f2[pid], O4 = w.s_bold[pid];
+                spec est = mks1(0.0f);
+                if (flags & F_PSH) {
+                    if (!w.occ[idx4.z]) est = est + mks(A4.x, A4.y, A4.z);
+                }
+                if (flags & F_PMIS) {
+                    const uint32_t light_num = __float_as_uint(F4.w);
+                    const LightRec light = sc.lights[light_num];
+                    const RayIn mr = load_ray(rays_in + idx4.y);
+                    const float4* hp = reinterpret_cast<const float4*>(w.hits_cl + idx4.y);
+                    const float4 h0 = hp[0], h1 = hp[1];
+                    const uint32_t hprim = __float_as_uint(h0.y);
+                    const f3 wi = mk3(mr.dx, mr.dy, mr.dz);
+                    spec li2 = mks1(0.0f);
+                    if (hprim != 0xFFFFFFFFu) {
+                        const MeshRec m = sc.meshes[sc.tri_mesh[hprim]];
+                        if (m.first_light >= 0 && (uint32_t)m.first_light + (hprim - m.tri_base) == light_num) {
+                            SurfHit lh = make_surface_hit(sc, wi, mr.time, hprim, h0.z, h0.w, h1.x);
+                            li2 = area_L(light, lh.n, -wi);  // SurfaceInteraction::le (surface_interaction.rs:283-289)
+                        }
+                    } else li2 = light_le(light, wi);
+                    if (!is_black(li2)) est = est + mks(F4.x, F4.y, F4.z) * li2 * mks1(1.0f) * A4.w / O4.w;  // f*li*tr*weight/scattering_pdf
+                }
+                const spec ldv = mks(O4.x, O4.y, O4.z) * (est / L4.w);  // beta * (estimate / light_pdf)  (path.rs:165)
+                if (is_black(ldv)) atomicAdd(&w.stats->paths_zero, 1ull);
+                L = L + ldv;
+                flags &= ~(F_PSH | F_PMIS);
+            }
+
+            // ---- the new vertex: body of li's loop (path.rs:116-279) -----------------------------------------------------
+            if (flags & F_EXT) {
+                flags &= ~F_EXT;
+                const RayIn ray = load_ray(rays_in + idx4.x);
+                const float4* hp = reinterpret_cast<const float4*>(w.hits_cl + idx4.x);
+                const float4 h0 = hp[0], h1 = hp[1];
+                const uint32_t hprim = __float_as_uint(h0.y);
+                const bool found = hprim != 0xFFFFFFFFu;
+                const f3 rd = mk3(ray.dx, ray.dy, ray.dz);
+                SurfHit si;
+                if (found) si = make_surface_hit(sc, rd, ray.time, hprim, h0.z, h0.w, h1.x);
+                if (bounces == 0) {  // `|| specular_bounce`: no specular lobes among matte materials
+                    if (found) {
+                        const MeshRec m = sc.meshes[sc.tri_mesh[hprim]];
+                        spec le = mks1(0.0f);
+                        if (m.first_light >= 0) le = area_L(sc.lights[(uint32_t)m.first_light + (hprim - m.tri_base)], si.n, -rd);
+                        L = L + beta * le;
+                    } else {
+                        for (uint32_t k = 0; k < sc.n_infinite; k++) L = L + beta * light_le(sc.lights[sc.infinite_lights[k]], rd);
+                    }
+                }
+                if (found && (int)bounces < w.max_depth) {
+                    const Bsdf bsdf = make_bsdf(sc, si);
+                    const int2 xy = w.px_xy[pid / w.chunk_spp];
+                    SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid % w.chunk_spp), dim);
+                    if (bsdf.has_bxdf) {  // num_components(all & !SPECULAR) > 0 (path.rs:161-172)
+                        atomicAdd(&w.stats->paths_total, 1ull);
+                        // uniform_sample_one_light (integrator/common.rs:89-133)
+                        if (sc.n_lights > 0) {
+                            const float sample = get_1d(sc, w.sp, cur);
+                            const uint32_t light_num = find_interval_cdf(sc.ld_cdf, sc.n_lights + 1, sample);  // sample_discrete
+                            pick_pdf = sc.ld_func_int > 0.0f ? sc.ld_func[light_num] / (sc.ld_func_int * (float)sc.n_lights) : 0.0f;
+                            if (pick_pdf != 0.0f) {
+                                const LightRec light = sc.lights[light_num];
+                                const f2 u_light = get_2d(sc, w.sp, cur), u_scatter = get_2d(sc, w.sp, cur);
+                                // estimate_direct (integrator/common.rs:146-299), specular = false, handle_media = false
+                                const LiSample ls = light_sample_li(sc, light, si, u_light);
+                                const bool is_delta = light.type == PH_L_DISTANT || light.type == PH_L_POINT;
+                                if (ls.valid && ls.pdf > 0.0f && !is_black(ls.value)) {
+                                    const spec f = bsdf_f(bsdf, si.wo, ls.wi) * abs_dot(ls.wi, si.ns);
+                                    const float scattering_pdf = bsdf_pdf(bsdf, si.wo, ls.wi);
+                                    if (!is_black(f)) {
+                                        ray_sh = spawn_ray_to_hit(si, ls.vp, ls.vperr, ls.vn);  // VisibilityTester::unoccluded
+                                        want_sh = true;
+                                        spec A;
+                                        if (is_delta) A = f * ls.value / ls.pdf;
+                                        else A = f * ls.value * power_heuristic1(ls.pdf, scattering_pdf) / ls.pdf;
+                                        pA.x = A.r; pA.y = A.g; pA.z = A.b;
+                                        flags |= F_PSH;
+                                    }
+                                }
+                                if (!is_delta) {
+                                    spec f1; float spdf; f3 wi2;
+                                    bsdf_sample_f(bsdf, si.wo, u_scatter, f1, spdf, wi2);
+                                    const spec f = f1 * abs_dot(wi2, si.ns);
+                                    if (!is_black(f) && spdf > 0.0f) {
+                                        const float lp = light_pdf_li(sc, light, si, wi2);
+                                        if (lp != 0.0f) {  // lp == 0 -> `return ld` with the light-sampling part only
+                                            w2 = power_heuristic1(spdf, lp);
+                                            ray_mis = spawn_ray(si, wi2);
+                                            want_mis = true;
+                                            pF2 = make_float4(f.r, f.g, f.b, __uint_as_float(light_num));
+                                            pBold.w = spdf;
+                                            flags |= F_PMIS;
+                                        }
+                                    }
+                                }
+                                if (flags & (F_PSH | F_PMIS)) { new_pending = true; pBold.x = beta.r; pBold.y = beta.g; pBold.z = beta.b; pA.w = w2; }
+                            }
+                        }
+                        if (!new_pending) atomicAdd(&w.stats->paths_zero, 1ull);  // ld is black
+                    }
+                    // sample the BSDF for the next direction (path.rs:174-206)
+                    const f2 u = get_2d(sc, w.sp, cur);
+                    spec f; float pdf; f3 wi;
+                    bsdf_sample_f(bsdf, -rd, u, f, pdf, wi);
+                    if (!(is_black(f) || pdf == 0.0f)) {
+                        beta = beta * (f * abs_dot(wi, si.ns) / pdf);
+                        ray_ext = spawn_ray(si, wi);
+                        bool cont = true;
+                        const spec rr_beta = beta * 1.0f;  // eta_scale stays 1 without specular transmission
+                        if (max_component_value(rr_beta) < w.rr_threshold && bounces > 3) {  // path.rs:264-276
+                            const float q = pmaxf(0.05f, 1.0f - max_component_value(rr_beta));
+                            if (get_1d(sc, w.sp, cur) < q) cont = false;
+                            else beta = beta / (1.0f - q);
+                        }
+                        if (cont) { bounces += 1; want_ext = true; flags |= F_EXT; }
+                    }
+                    dim = cur.dim;
+                }
+            }
+            still_live = (flags & (F_EXT | F_PSH | F_PMIS)) != 0;
+        }
+
+        // ---- queue appends: one atomic per wave and queue --------------------------------------------------------------------
+        const uint32_t n_cl = (want_ext ? 1u : 0u) + (want_mis ? 1u : 0u);
+        uint32_t cl_slot;
+        {   // two-slot allocation with a single atomic: exclusive prefix over lanes of n_cl
+            const uint64_t m1 = __ballot(want_ext), m2 = __ballot(want_mis);
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const uint32_t total = (uint32_t)(__popcll(m1) + __popcll(m2));
+            uint32_t b = 0;
+            if (total) {
+                if (lane == 0) b = atomicAdd(&next->n_cl, total);
+                b = __shfl(b, 0);
+            }
+            cl_slot = b + (uint32_t)(__popcll(m1 & lt) + __popcll(m2 & lt));
+        }
+        const uint32_t sh_slot = wave_alloc(&next->n_sh, want_sh);
+        const uint32_t lv_slot = wave_alloc(&next->n_live, still_live);
+        (void)n_cl;
+
+        if (active) {
+            uint32_t ext_slot = 0, mis_slot = 0;
+            if (want_ext) { ext_slot = cl_slot; store_ray(rays_out + ext_slot, ray_ext); }
+            if (want_mis) { mis_slot = cl_slot + (want_ext ? 1u : 0u); store_ray(rays_out + mis_slot, ray_mis); }
+            if (want_sh) store_ray(w.rays_sh + sh_slot, ray_sh);
+            if (still_live) {
+                live_out[lv_slot] = pid;
+                w.s_idx[pid] = make_uint4(ext_slot, mis_slot, sh_slot, flags | (bounces << 8) | (dim << 16));
+                w.s_L[pid] = make_float4(L.r, L.g, L.b, new_pending ? pick_pdf : 0.0f);
+                w.s_beta[pid] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                if (new_pending) { w.s_A[pid] = pA; w.s_f2[pid] = pF2; w.s_bold[pid] = pBold; }
+            } else {
+                // path finished: radiance sanitising of render_tile (sampler_integrator.rs:373-397)
+                if (has_nans(L)) L = mks1(0.0f);
+                else if (lum_y(L) < -1e-5f) L = mks1(0.0f);
+                else if (__builtin_isinf(lum_y(L))) L = mks1(0.0f);
+                const size_t gsi = (size_t)(pid / w.chunk_spp) * w.sp.spp + (w.s0 + pid % w.chunk_spp);
+                float4 rec = w.rec_L[gsi];
+                rec.x = L.r; rec.y = L.g; rec.z = L.b;
+                w.rec_L[gsi] = rec;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// K7a: FilmTile::add_sample (core/src/film/film_tile.rs:62-108), one thread per (tile, tile pixel).  The thread walks the
+// tile's samples that can reach its pixel in the reference's order (pixels row-major, then sample index) and accumulates
+// exactly the terms the reference adds, in the same order.
+struct FilmParams {
+    FilmRec film;
+    const TileInfo* tiles; uint32_t n_tiles;
+    uint32_t slot_w, slot_h;      // per-tile slot in the tile buffer: slot_w*slot_h float4 {contrib rgb, weight sum}
+    uint32_t spp;
+    const float4* rec_L; const float* rec_py;
+    float4* tile_buf;
+};
+__global__ __launch_bounds__(256) void film_tiles_kernel(FilmParams p) {
+    const uint32_t slot_px = p.slot_w * p.slot_h;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)p.n_tiles * slot_px) return;
+    const uint32_t lt = (uint32_t)(gid / slot_px), k = (uint32_t)(gid % slot_px);
+    const TileInfo t = p.tiles[lt];
+    const int pw = t.pb[2] - t.pb[0], phh = t.pb[3] - t.pb[1];
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int kx = (int)(k % p.slot_w), ky = (int)(k / p.slot_w);
+    if (kx < pw && ky < phh) {
+        const int x = t.pb[0] + kx, y = t.pb[1] + ky;
+        const float rx = p.film.radius[0], ry = p.film.radius[1];
+        // samples of pixel (sx,sy) land at p in [sx, sx+1): they can touch x only if ceil(p-.5-r) <= x <= floor(p-.5+r)
+        const int sx0 = pmaxi(f2i_sat(ceilf((float)x - 0.5f - rx)) - 1, t.tb[0]), sx1 = pmini(f2i_sat(floorf((float)x + 0.5f + rx)) + 1, t.tb[2] - 1);
+        const int sy0 = pmaxi(f2i_sat(ceilf((float)y - 0.5f - ry)) - 1, t.tb[1]), sy1 = pmini(f2i_sat(floorf((float)y + 0.5f + ry)) + 1, t.tb[3] - 1);
+        const int tw = t.tb[2] - t.tb[0];
+        for (int sy = sy0; sy <= sy1; sy++)
+            for (int sx = sx0; sx <= sx1; sx++) {
+                const size_t pix = (size_t)t.px_off + (size_t)(sy - t.tb[1]) * tw + (size_t)(sx - t.tb[0]);
+                for (uint32_t s = 0; s < p.spp; s++) {
+                    const float4 r = p.rec_L[pix * p.spp + s];
+                    if (r.w != r.w) continue;  // pixel outside pixel_bounds: no sample was taken
+                    const float pfx = r.w, pfy = p.rec_py[pix * p.spp + s];
+                    spec l = mks(r.x, r.y, r.z);
+                    const float ly = lum_y(l);
+                    if (ly > p.film.max_lum) l = l * p.film.max_lum / ly;
+                    const float pdx = pfx - 0.5f, pdy = pfy - 0.5f;
+                    int p0x = f2i_sat(ceilf(pdx - rx)), p0y = f2i_sat(ceilf(pdy - ry));
+                    int p1x = f2i_sat(floorf(pdx + rx)) + 1, p1y = f2i_sat(floorf(pdy + ry)) + 1;
+                    p0x = pmaxi(p0x, t.pb[0]); p0y = pmaxi(p0y, t.pb[1]); p1x = pmini(p1x, t.pb[2]); p1y = pmini(p1y, t.pb[3]);
+                    if (x < p0x || x >= p1x || y < p0y || y >= p1y) continue;
+                    const float fx = pabs(((float)x - pdx) * p.film.inv_radius[0] * 16.0f);
+                    const float fy = pabs(((float)y - pdy) * p.film.inv_radius[1] * 16.0f);
+                    const uint32_t ix = f2u_sat(pminf(floorf(fx), 15.0f)), iy = f2u_sat(pminf(floorf(fy), 15.0f));
+                    const float fw = p.film.table[iy * 16 + ix];
+                    const spec c = l * 1.0f * fw;  // l * sample_weight * filter_weight (ray weight is 1 for this camera)
+                    acc.x += c.r; acc.y += c.g; acc.z += c.b; acc.w += fw;
+                }
+            }
+    }
+    p.tile_buf[(size_t)lt * slot_px + k] = acc;
+}
+
+// K7b: Film::merge_film_tile (core/src/film/mod.rs:220-279) over all tiles in increasing tile index, one thread per film pixel
+struct MergeParams {
+    FilmRec film;
+    int32_t sb[4]; int32_t tile_size, ntx, nty, parts;
+    uint32_t slot_w, slot_h;
+    const float4* bufs[8];
+    float* out_xyz; float* out_w;
+};
+PH_DEV void tile_pixel_bounds(const FilmRec& f, const int tb[4], int pb[4]) {  // Film::get_film_tile (film/mod.rs:182-198)
+    const int p0x = f2i_sat(ceilf((float)tb[0] - 0.5f - f.radius[0])), p0y = f2i_sat(ceilf((float)tb[1] - 0.5f - f.radius[1]));
+    const int p1x = f2i_sat(floorf((float)tb[2] - 0.5f + f.radius[0])) + 1, p1y = f2i_sat(floorf((float)tb[3] - 0.5f + f.radius[1])) + 1;
+    pb[0] = pmaxi(p0x, f.crop[0]); pb[1] = pmaxi(p0y, f.crop[1]); pb[2] = pmini(p1x, f.crop[2]); pb[3] = pmini(p1y, f.crop[3]);
+}
+__global__ __launch_bounds__(256) void merge_kernel(MergeParams p) {
+    const int cw = p.film.crop[2] - p.film.crop[0], ch = p.film.crop[3] - p.film.crop[1];
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cw <= 0 || ch <= 0 || gid >= (uint64_t)cw * ch) return;
+    const int x = p.film.crop[0] + (int)(gid % cw), y = p.film.crop[1] + (int)(gid / cw);
+    const int ext_x = (int)ceilf(p.film.radius[0] + 0.5f) + 1, ext_y = (int)ceilf(p.film.radius[1] + 0.5f) + 1;
+    const int tx_lo = pmaxi((x - ext_x - p.sb[0]) / p.tile_size - 1, 0), tx_hi = pmini((x + ext_x - p.sb[0]) / p.tile_size + 1, p.ntx - 1);
+    const int ty_lo = pmaxi((y - ext_y - p.sb[1]) / p.tile_size - 1, 0), ty_hi = pmini((y + ext_y - p.sb[1]) / p.tile_size + 1, p.nty - 1);
+    float X = 0.0f, Y = 0.0f, Z = 0.0f, W = 0.0f;
+    const uint32_t slot_px = p.slot_w * p.slot_h;
+    for (int ty = ty_lo; ty <= ty_hi; ty++)
+        for (int tx = tx_lo; tx <= tx_hi; tx++) {
+            int tb[4], pb[4];
+            tb[0] = p.sb[0] + tx * p.tile_size; tb[2] = pmini(tb[0] + p.tile_size, p.sb[2]);
+            tb[1] = p.sb[1] + ty * p.tile_size; tb[3] = pmini(tb[1] + p.tile_size, p.sb[3]);
+            tile_pixel_bounds(p.film, tb, pb);
+            if (x < pb[0] || x >= pb[2] || y < pb[1] || y >= pb[3]) continue;
+            const uint32_t t = (uint32_t)(ty * p.ntx + tx);
+            const float4 c = p.bufs[t % p.parts][(size_t)(t / p.parts) * slot_px + (size_t)(y - pb[1]) * p.slot_w + (size_t)(x - pb[0])];
+            // contrib_sum.to_xyz() (spectrum/common.rs:349-355)
+            X += 0.412453f * c.x + 0.357580f * c.y + 0.180423f * c.z;
+            Y += 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z;
+            Z += 0.019334f * c.x + 0.119193f * c.y + 0.950227f * c.z;
+            W += c.w;
+        }
+    p.out_xyz[3 * gid] = X; p.out_xyz[3 * gid + 1] = Y; p.out_xyz[3 * gid + 2] = Z; p.out_w[gid] = W;
+}
+
+// camera rays only (parity harness for the sampler + camera rows of SURVEY §8a)
+__global__ void camera_rays_kernel(DeviceScene sc, CameraRec cam, SamplerRec sp, int x0, int y0, int x1, int y1, uint32_t s, RayIn* out, float* out_pf) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wdt = x1 - x0, hgt = y1 - y0;
+    if (wdt <= 0 || hgt <= 0 || gid >= (uint32_t)(wdt * hgt)) return;
+    const int x = x0 + (int)(gid % wdt), y = y0 + (int)(gid / wdt);
+    SamplerCursor c = cursor_for(sc, sp, x, y, s, 0);
+    f2 fs = get_2d(sc, sp, c);
+    f2 pf = mk2((float)x + fs.x, (float)y + fs.y);
+    float tm = get_1d(sc, sp, c);
+    f2 lens = get_2d(sc, sp, c);
+    RayIn r;
+    generate_camera_ray(cam, pf, tm, lens, r);
+    store_ray(out + gid, r);
+    if (out_pf) { out_pf[2 * gid] = pf.x; out_pf[2 * gid + 1] = pf.y; }
+}
+
+}  // namespace ph
+
+// =================================================================================================================================
+// host side
+// =================================================================================================================================
+struct Wavefront {
+    // geometry of the tile decomposition for the current (tile_size, part, parts, film, sampler)
+    std::vector<ph::TileInfo> tiles;
+    std::vector<int2> px_xy;
+    int sb[4] = {0, 0, 0, 0}, ntx = 0, nty = 0, tile_size = 0, part = 0, parts = 0;
+    uint32_t slot_w = 0, slot_h = 0;
+    DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats;
+    DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_recL, d_recpy, d_tilebuf, d_xyz, d_w;
+    std::vector<hipEvent_t> events;
+};
+
+namespace phost {
+
+void free_wavefront(PbrtHipScene* s) {
+    Wavefront* w = s->wf;
+    if (!w) return;
+    for (DevBuf* b : {&w->d_tiles, &w->d_px, &w->d_rays_cl[0], &w->d_rays_cl[1], &w->d_hits, &w->d_rays_sh, &w->d_occ, &w->d_live[0], &w->d_live[1], &w->d_ctr,
+                      &w->d_stats, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w})
+        if (b->p) (void)hipFree(b->p);
+    for (hipEvent_t e : w->events) (void)hipEventDestroy(e);
+    delete w;
+    s->wf = nullptr;
+}
+
+static int sat_i(float v) { if (v != v) return 0; if (v >= 2147483648.0f) return 2147483647; if (v <= -2147483648.0f) return (int)0x80000000; return (int)v; }
+
+// Tile decomposition exactly as SamplerIntegrator::render / render_tile enumerate it (sampler_integrator.rs:252-259, 314-336)
+static int setup_tiles(PbrtHipScene* s, int tile_size, int part, int parts) {
+    if (!s->wf) s->wf = new Wavefront();
+    Wavefront& w = *s->wf;
+    const FilmRec& f = s->film;
+    // Film::get_sample_bounds (film/mod.rs:150-159)
+    int sb[4] = {sat_i(std::floor((float)f.crop[0] + 0.5f - f.radius[0])), sat_i(std::floor((float)f.crop[1] + 0.5f - f.radius[1])),
+                 sat_i(std::ceil((float)f.crop[2] - 0.5f + f.radius[0])), sat_i(std::ceil((float)f.crop[3] - 0.5f + f.radius[1]))};
+    const int ntx = std::max((sb[2] - sb[0] + tile_size - 1) / tile_size, 0), nty = std::max((sb[3] - sb[1] + tile_size - 1) / tile_size, 0);
+    w.tiles.clear(); w.px_xy.clear();
+    std::memcpy(w.sb, sb, sizeof(sb)); w.ntx = ntx; w.nty = nty; w.tile_size = tile_size; w.part = part; w.parts = parts;
+    // slot big enough for any tile's FilmTile pixel bounds
+    const int e_lo_x = sat_i(std::floor(0.5f + f.radius[0])), e_hi_x = sat_i(std::floor(f.radius[0] - 0.5f)) + 1;
+    const int e_lo_y = sat_i(std::floor(0.5f + f.radius[1])), e_hi_y = sat_i(std::floor(f.radius[1] - 0.5f)) + 1;
+    w.slot_w = (uint32_t)std::max(tile_size + e_lo_x + e_hi_x, 1); w.slot_h = (uint32_t)std::max(tile_size + e_lo_y + e_hi_y, 1);
+    for (int t = part; t < ntx * nty; t += parts) {
+        ph::TileInfo ti{};
+        const int tx = t % ntx, ty = t / ntx;
+        ti.tb[0] = sb[0] + tx * tile_size; ti.tb[2] = std::min(ti.tb[0] + tile_size, sb[2]);
+        ti.tb[1] = sb[1] + ty * tile_size; ti.tb[3] = std::min(ti.tb[1] + tile_size, sb[3]);
+        const int p0x = sat_i(std::ceil((float)ti.tb[0] - 0.5f - f.radius[0])), p0y = sat_i(std::ceil((float)ti.tb[1] - 0.5f - f.radius[1]));
+        const int p1x = sat_i(std::floor((float)ti.tb[2] - 0.5f + f.radius[0])) + 1, p1y = sat_i(std::floor((float)ti.tb[3] - 0.5f + f.radius[1])) + 1;
+        ti.pb[0] = std::max(p0x, f.crop[0]); ti.pb[1] = std::max(p0y, f.crop[1]); ti.pb[2] = std::min(p1x, f.crop[2]); ti.pb[3] = std::min(p1y, f.crop[3]);
+        ti.px_off = (uint32_t)w.px_xy.size(); ti.tile_index = (uint32_t)t;
+        for (int y = ti.tb[1]; y < ti.tb[3]; y++)
+            for (int x = ti.tb[0]; x < ti.tb[2]; x++) w.px_xy.push_back(make_int2(x, y));  // Bounds2i iteration order (bounds2.rs:347-359)
+        w.tiles.push_back(ti);
+    }
+    int rc;
+    if ((rc = ensure_buf(s, w.d_tiles, std::max<size_t>(w.tiles.size(), 1) * sizeof(ph::TileInfo)))) return rc;
+    if ((rc = ensure_buf(s, w.d_px, std::max<size_t>(w.px_xy.size(), 1) * sizeof(int2)))) return rc;
+    if (!w.tiles.empty()) PH_CHECK(s, hipMemcpy(w.d_tiles.p, w.tiles.data(), w.tiles.size() * sizeof(ph::TileInfo), hipMemcpyHostToDevice));
+    if (!w.px_xy.empty()) PH_CHECK(s, hipMemcpy(w.d_px.p, w.px_xy.data(), w.px_xy.size() * sizeof(int2), hipMemcpyHostToDevice));
+    return PBRT_HIP_OK;
+}
+
+static size_t tile_buffer_floats_for(const PbrtHipScene* s, int tile_size, int part, int parts) {
+    const FilmRec& f = s->film;
+    int sb[4] = {sat_i(std::floor((float)f.crop[0] + 0.5f - f.radius[0])), sat_i(std::floor((float)f.crop[1] + 0.5f - f.radius[1])),
+                 sat_i(std::ceil((float)f.crop[2] - 0.5f + f.radius[0])), sat_i(std::ceil((float)f.crop[3] - 0.5f + f.radius[1]))};
+    const int ntx = std::max((sb[2] - sb[0] + tile_size - 1) / tile_size, 0), nty = std::max((sb[3] - sb[1] + tile_size - 1) / tile_size, 0);
+    const int n = ntx * nty;
+    const size_t local = n > part ? (size_t)(n - part + parts - 1) / parts : 0;
+    const int e_lo_x = sat_i(std::floor(0.5f + f.radius[0])), e_hi_x = sat_i(std::floor(f.radius[0] - 0.5f)) + 1;
+    const int e_lo_y = sat_i(std::floor(0.5f + f.radius[1])), e_hi_y = sat_i(std::floor(f.radius[1] - 0.5f)) + 1;
+    const size_t slot = (size_t)std::max(tile_size + e_lo_x + e_hi_x, 1) * (size_t)std::max(tile_size + e_lo_y + e_hi_y, 1);
+    return std::max<size_t>(local, 1) * slot * 4;
+}
+
+static hipEvent_t get_event(PbrtHipScene* s, size_t i) {
+    Wavefront& w = *s->wf;
+    while (w.events.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; w.events.push_back(e); }
+    return w.events[i];
+}
+
+static int check_render_args(PbrtHipScene* s, int max_depth, int light_strategy, const int* pixel_bounds, int tile_size, int part, int parts) {
+    if (!s || !pixel_bounds) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: null argument");
+    if (!s->built || !s->have_camera || !s->have_film || !s->have_sampler)
+        return set_err(s, PBRT_HIP_ERR_STATE, "render: camera, film, sampler and build_accel must be set first");
+    if (tile_size <= 0 || parts <= 0 || parts > 8 || part < 0 || part >= parts) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: bad tile partition");
+    if (max_depth < 0 || max_depth > 200) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: max_depth out of range");
+    if (light_strategy < 0 || light_strategy > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: bad light strategy");
+    if (light_strategy == 2 && s->lights.size() > 1)
+        return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: SpatialLightDistribution is a 'next' row (SURVEY §8f); use uniform (0) or power (1)");
+    if (s->sampler.kind == 1 && s->sobol32.empty()) return set_err(s, PBRT_HIP_ERR_STATE, "render: sobol tables not set (pbrt_hip_set_sobol_tables)");
+    // sampler dimension budget: 5 + per bounce (1+2+2) + 2 + 1; HaltonSampler asserts dim <= 1000 (halton.rs:106-110)
+    if (5 + 8 * (max_depth + 1) >= (s->sampler.kind == 0 ? 1000 : 1024)) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: path would exceed the sampler's dimension table");
+    return PBRT_HIP_OK;
+}
+
+// renders this rank's tiles into d_tile_buffer (device)
+static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size, int part,
+                        int parts, void* d_tile_buffer, PbrtHipStats* out_stats) {
+    int rc;
+    PH_CHECK(s, hipSetDevice(s->device));
+    if ((rc = upload_scene(s))) return rc;
+    if ((rc = upload_light_distribution(s, light_strategy == 2 ? 0 : light_strategy))) return rc;
+    if ((rc = setup_tiles(s, tile_size, part, parts))) return rc;
+    Wavefront& w = *s->wf;
+    const uint32_t n_px = (uint32_t)w.px_xy.size();
+    const uint32_t spp = s->sampler.spp;
+    if (out_stats) std::memset(out_stats, 0, sizeof(*out_stats));
+    const size_t tile_floats = tile_buffer_floats_for(s, tile_size, part, parts);
+    if (n_px == 0) { PH_CHECK(s, hipMemsetAsync(d_tile_buffer, 0, tile_floats * 4, s->stream)); PH_CHECK(s, hipStreamSynchronize(s->stream)); return PBRT_HIP_OK; }
+    if ((uint64_t)n_px * spp >= (1ull << 40)) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: too many samples");
+
+    // ---- chunking: B = n_px * chunk_spp paths in flight ----------------------------------------------------------------------
+    size_t max_paths = 8u << 20;
+    if (const char* e = std::getenv("PBRT_HIP_MAX_PATHS")) { long v = std::atol(e); if (v > 0) max_paths = (size_t)v; }
+    uint32_t chunk_spp = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, max_paths / std::max<uint32_t>(n_px, 1)));
+    const size_t B = (size_t)n_px * chunk_spp;
+    if (B >= 0x7FFF0000ull) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: tile range too large for one rank; use more tile_parts");
+    const int n_iter = max_depth + 1;
+
+    if ((rc = ensure_buf(s, w.d_rays_cl[0], 2 * B * sizeof(ph::RayIn)))) return rc;
+    if ((rc = ensure_buf(s, w.d_rays_cl[1], 2 * B * sizeof(ph::RayIn)))) return rc;
+    if ((rc = ensure_buf(s, w.d_hits, 2 * B * sizeof(ph::HitOut)))) return rc;
+    if ((rc = ensure_buf(s, w.d_rays_sh, B * sizeof(ph::RayIn)))) return rc;
+    if ((rc = ensure_buf(s, w.d_occ, B))) return rc;
+    if ((rc = ensure_buf(s, w.d_live[0], B * 4))) return rc;
+    if ((rc = ensure_buf(s, w.d_live[1], B * 4))) return rc;
+    if ((rc = ensure_buf(s, w.d_ctr, (size_t)(n_iter + 2) * sizeof(ph::IterCounters)))) return rc;
+    if ((rc = ensure_buf(s, w.d_stats, sizeof(ph::DevStats)))) return rc;
+    for (DevBuf* b : {&w.d_sL, &w.d_sbeta, &w.d_sA, &w.d_sf2, &w.d_sbold, &w.d_sidx})
+        if ((rc = ensure_buf(s, *b, B * 16))) return rc;
+    if ((rc = ensure_buf(s, w.d_recL, (size_t)n_px * spp * 16))) return rc;
+    if ((rc = ensure_buf(s, w.d_recpy, (size_t)n_px * spp * 4))) return rc;
+
+    // traversal launch geometry (shared with the batch entry points)
+    if (!s->trav_blocks) {
+        hipDeviceProp_t prop;
+        PH_CHECK(s, hipGetDeviceProperties(&prop, s->device));
+        int per_cu = 0;
+        PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false>, PH_TRAV_BLOCK, 0));
+        per_cu = std::min(std::max(per_cu, 1), 8);
+        s->trav_blocks = (uint32_t)(prop.multiProcessorCount * per_cu);
+    }
+    const uint32_t total_threads = s->trav_blocks * PH_TRAV_BLOCK;
+    if ((rc = ensure_buf(s, s->d_error, 64))) return rc;
+    if ((rc = ensure_buf(s, s->d_spill, (size_t)(PH_MAX_STACK - PH_LDS_DEPTH) * total_threads * sizeof(uint2)))) return rc;
+
+    ph::WfParams wp{};
+    wp.cam = s->cam; wp.sp = s->sampler;
+    for (int i = 0; i < 4; i++) wp.pixel_bounds[i] = pixel_bounds[i];
+    wp.max_depth = max_depth; wp.rr_threshold = rr_threshold;
+    wp.n_px = n_px; wp.px_xy = (const int2*)w.d_px.p;
+    wp.rays_cl[0] = (ph::RayIn*)w.d_rays_cl[0].p; wp.rays_cl[1] = (ph::RayIn*)w.d_rays_cl[1].p;
+    wp.hits_cl = (ph::HitOut*)w.d_hits.p; wp.rays_sh = (ph::RayIn*)w.d_rays_sh.p; wp.occ = (uint8_t*)w.d_occ.p;
+    wp.live[0] = (uint32_t*)w.d_live[0].p; wp.live[1] = (uint32_t*)w.d_live[1].p;
+    wp.ctr = (ph::IterCounters*)w.d_ctr.p; wp.stats = (ph::DevStats*)w.d_stats.p;
+    wp.s_L = (float4*)w.d_sL.p; wp.s_beta = (float4*)w.d_sbeta.p; wp.s_A = (float4*)w.d_sA.p; wp.s_f2 = (float4*)w.d_sf2.p;
+    wp.s_bold = (float4*)w.d_sbold.p; wp.s_idx = (uint4*)w.d_sidx.p;
+    wp.rec_L = (float4*)w.d_recL.p; wp.rec_py = (float*)w.d_recpy.p;
+
+    PH_CHECK(s, hipMemsetAsync(w.d_stats.p, 0, sizeof(ph::DevStats), s->stream));
+    size_t ev = 0;
+    hipEvent_t e_begin = get_event(s, ev++), e_end = get_event(s, ev++);
+    if (!e_begin || !e_end) return set_err(s, PBRT_HIP_ERR_DEVICE, "hipEventCreate failed");
+    struct Span { hipEvent_t a, b; int kind; };
+    std::vector<Span> spans;
+    auto timed = [&](int kind, auto&& launch) -> int {
+        hipEvent_t a = get_event(s, ev++), b = get_event(s, ev++);
+        if (!a || !b) return set_err(s, PBRT_HIP_ERR_DEVICE, "hipEventCreate failed");
+        PH_CHECK(s, hipEventRecord(a, s->stream));
+        launch();
+        PH_CHECK(s, hipGetLastError());
+        PH_CHECK(s, hipEventRecord(b, s->stream));
+        spans.push_back({a, b, kind});
+        return PBRT_HIP_OK;
+    };
+    PH_CHECK(s, hipEventRecord(e_begin, s->stream));
+    uint64_t regular = 0, shadow = 0;
+    std::vector<ph::IterCounters> hctr((size_t)n_iter + 2);
+    const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, 256 * 16);
+
+    for (uint32_t s0 = 0; s0 < spp; s0 += chunk_spp) {
+        const uint32_t cs = std::min(chunk_spp, spp - s0);
+        wp.chunk_spp = cs; wp.s0 = s0; wp.B = n_px * cs;
+        PH_CHECK(s, hipMemsetAsync(w.d_ctr.p, 0, (size_t)(n_iter + 2) * sizeof(ph::IterCounters), s->stream));
+        if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::raygen_kernel, dim3((wp.B + 255) / 256), dim3(256), 0, s->stream, s->ds, wp); }))) return rc;
+        for (int it = 0; it < n_iter; it++) {
+            ph::IterCounters* c = (ph::IterCounters*)w.d_ctr.p + it;
+            ph::TravParams tp{};
+            tp.spill = (uint2*)s->d_spill.p; tp.total_threads = total_threads; tp.error_flag = (uint32_t*)s->d_error.p;
+            tp.rays = wp.rays_cl[it & 1]; tp.out = wp.hits_cl; tp.n = 0; tp.n_ptr = &c->n_cl; tp.counter = &c->head_cl;
+            if ((rc = timed(0, [&]() { hipLaunchKernelGGL(ph::traverse_kernel<false>, dim3(s->trav_blocks), dim3(PH_TRAV_BLOCK), 0, s->stream, s->ds, tp); }))) return rc;
+            if (it > 0) {
+                tp.rays = wp.rays_sh; tp.out = wp.occ; tp.n_ptr = &c->n_sh; tp.counter = &c->head_sh;
+                if ((rc = timed(1, [&]() { hipLaunchKernelGGL(ph::traverse_kernel<true>, dim3(s->trav_blocks), dim3(PH_TRAV_BLOCK), 0, s->stream, s->ds, tp); }))) return rc;
+            }
+            if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::shade_kernel, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it); }))) return rc;
+        }
+        PH_CHECK(s, hipMemcpyAsync(hctr.data(), w.d_ctr.p, (size_t)(n_iter + 2) * sizeof(ph::IterCounters), hipMemcpyDeviceToHost, s->stream));
+        PH_CHECK(s, hipStreamSynchronize(s->stream));
+        for (int it = 0; it < n_iter; it++) { regular += hctr[it].n_cl; shadow += hctr[it].n_sh; }
+    }
+
+    // ---- film: per-tile accumulation in reference order ---------------------------------------------------------------------------
+    ph::FilmParams fp{};
+    fp.film = s->film; fp.tiles = (const ph::TileInfo*)w.d_tiles.p; fp.n_tiles = (uint32_t)w.tiles.size();
+    fp.slot_w = w.slot_w; fp.slot_h = w.slot_h; fp.spp = spp; fp.rec_L = wp.rec_L; fp.rec_py = wp.rec_py; fp.tile_buf = (float4*)d_tile_buffer;
+    const uint64_t film_threads = (uint64_t)fp.n_tiles * w.slot_w * w.slot_h;
+    if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::film_tiles_kernel, dim3((uint32_t)((film_threads + 255) / 256)), dim3(256), 0, s->stream, fp); }))) return rc;
+    PH_CHECK(s, hipEventRecord(e_end, s->stream));
+    PH_CHECK(s, hipStreamSynchronize(s->stream));
+
+    uint32_t flag = 0;
+    PH_CHECK(s, hipMemcpy(&flag, s->d_error.p, 4, hipMemcpyDeviceToHost));
+    if (flag) { (void)hipMemset(s->d_error.p, 0, 4); return set_err(s, PBRT_HIP_ERR_DEVICE, "traversal stack exceeded 64 entries (the reference panics here, bvh/mod.rs:185)"); }
+    if (out_stats) {
+        ph::DevStats ds;
+        PH_CHECK(s, hipMemcpy(&ds, w.d_stats.p, sizeof(ds), hipMemcpyDeviceToHost));
+        out_stats->camera_rays = ds.camera_rays; out_stats->regular_rays = regular; out_stats->shadow_rays = shadow;
+        out_stats->paths_total = ds.paths_total; out_stats->paths_zero_radiance = ds.paths_zero;
+        float ms = 0;
+        PH_CHECK(s, hipEventElapsedTime(&ms, e_begin, e_end));
+        out_stats->render_seconds = ms * 1e-3;
+        double acc[3] = {0, 0, 0};
+        for (const Span& sp : spans) { float m = 0; if (hipEventElapsedTime(&m, sp.a, sp.b) == hipSuccess) acc[sp.kind] += m * 1e-3; }
+        out_stats->extend_seconds = acc[0]; out_stats->shadow_seconds = acc[1]; out_stats->shade_seconds = acc[2];
+    }
+    return PBRT_HIP_OK;
+}
+
+static int merge_tiles(PbrtHipScene* s, int tile_size, int parts, const void* const* d_bufs, float* out_xyz, float* out_weight) {
+    Wavefront& w = *s->wf;
+    const FilmRec& f = s->film;
+    const int cw = f.crop[2] - f.crop[0], ch = f.crop[3] - f.crop[1];
+    const size_t npx = (size_t)std::max(cw, 0) * (size_t)std::max(ch, 0);
+    if (npx == 0) return PBRT_HIP_OK;
+    int rc;
+    if ((rc = ensure_buf(s, w.d_xyz, npx * 12))) return rc;
+    if ((rc = ensure_buf(s, w.d_w, npx * 4))) return rc;
+    ph::MergeParams mp{};
+    mp.film = f;
+    for (int i = 0; i < 4; i++) mp.sb[i] = w.sb[i];
+    mp.tile_size = tile_size; mp.ntx = w.ntx; mp.nty = w.nty; mp.parts = parts; mp.slot_w = w.slot_w; mp.slot_h = w.slot_h;
+    for (int i = 0; i < parts; i++) mp.bufs[i] = (const float4*)d_bufs[i];
+    mp.out_xyz = (float*)w.d_xyz.p; mp.out_w = (float*)w.d_w.p;
+    hipLaunchKernelGGL(ph::merge_kernel, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, s->stream, mp);
+    PH_CHECK(s, hipGetLastError());
+    PH_CHECK(s, hipMemcpyAsync(out_xyz, w.d_xyz.p, npx * 12, hipMemcpyDeviceToHost, s->stream));
+    PH_CHECK(s, hipMemcpyAsync(out_weight, w.d_w.p, npx * 4, hipMemcpyDeviceToHost, s->stream));
+    PH_CHECK(s, hipStreamSynchronize(s->stream));
+    return PBRT_HIP_OK;
+}
+
+}  // namespace phost
+
+using namespace phost;
+
+extern "C" {
+
+int pbrt_hip_tile_buffer_floats(PbrtHipScene* s, int tile_size, int tile_part, int tile_parts, uint64_t* out_floats) {
+    if (!s || !out_floats) return PBRT_HIP_ERR_INVALID_ARG;
+    if (!s->have_film) return set_err(s, PBRT_HIP_ERR_STATE, "tile_buffer_floats: set_film first");
+    if (tile_size <= 0 || tile_parts <= 0 || tile_part < 0 || tile_part >= tile_parts) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "tile_buffer_floats: bad partition");
+    *out_floats = tile_buffer_floats_for(s, tile_size, tile_part, tile_parts);
+    return PBRT_HIP_OK;
+}
+
+int pbrt_hip_render_path_tiles_device(PbrtHipScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size,
+                                      int tile_part, int tile_parts, void* d_tile_buffer, PbrtHipStats* out_stats) {
+    int rc = check_render_args(s, max_depth, light_strategy, pixel_bounds, tile_size, tile_part, tile_parts);
+    if (rc) return rc;
+    if (!d_tile_buffer) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: null tile buffer");
+    return render_tiles(s, max_depth, rr_threshold, light_strategy, pixel_bounds, tile_size, tile_part, tile_parts, d_tile_buffer, out_stats);
+}
+
+int pbrt_hip_merge_tiles_device(PbrtHipScene* s, int tile_size, int tile_parts, const void* const* d_tile_buffers, float* out_xyz, float* out_weight) {
+    if (!s || !d_tile_buffers || !out_xyz || !out_weight) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "merge: null argument");
+    if (!s->have_film) return set_err(s, PBRT_HIP_ERR_STATE, "merge: set_film first");
+    if (tile_size <= 0 || tile_parts <= 0 || tile_parts > 8) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "merge: bad partition");
+    PH_CHECK(s, hipSetDevice(s->device));
+    int rc;
+    if ((rc = setup_tiles(s, tile_size, 0, tile_parts))) return rc;
+    return merge_tiles(s, tile_size, tile_parts, d_tile_buffers, out_xyz, out_weight);
+}
+
+int pbrt_hip_render_path(PbrtHipScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size, int tile_part,
+                         int tile_parts, float* out_xyz, float* out_weight, PbrtHipStats* out_stats) {
+    int rc = check_render_args(s, max_depth, light_strategy, pixel_bounds, tile_size, tile_part, tile_parts);
+    if (rc) return rc;
+    if (!out_xyz || !out_weight) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: null output");
+    if (!s->wf) s->wf = new Wavefront();
+    const size_t floats = tile_buffer_floats_for(s, tile_size, tile_part, tile_parts);
+    if ((rc = ensure_buf(s, s->wf->d_tilebuf, floats * 4))) return rc;
+    if ((rc = render_tiles(s, max_depth, rr_threshold, light_strategy, pixel_bounds, tile_size, tile_part, tile_parts, s->wf->d_tilebuf.p, out_stats))) return rc;
+    // a single rank holds only its own tiles: the other parts contribute nothing (zero buffers are not needed: merge
+    // addresses only tiles t with t % parts == part when every other part's pointer aliases an all-zero slot)
+    if (tile_parts == 1) {
+        const void* bufs[1] = {s->wf->d_tilebuf.p};
+        return merge_tiles(s, tile_size, 1, bufs, out_xyz, out_weight);
+    }
+    // partial frame: merge this part against zeroed stand-ins for the missing ones
+    std::vector<DevBuf> zeros((size_t)tile_parts);
+    std::vector<const void*> bufs((size_t)tile_parts);
+    for (int i = 0; i < tile_parts; i++) {
+        if (i == tile_part) { bufs[i] = s->wf->d_tilebuf.p; continue; }
+        const size_t fl = tile_buffer_floats_for(s, tile_size, i, tile_parts);
+        if (hipMalloc(&zeros[i].p, fl * 4) != hipSuccess) { for (auto& z : zeros) if (z.p) (void)hipFree(z.p); return set_err(s, PBRT_HIP_ERR_OOM, "render: out of device memory"); }
+        (void)hipMemset(zeros[i].p, 0, fl * 4);
+        bufs[i] = zeros[i].p;
+    }
+    // setup_tiles(part) was used for rendering; merge needs the frame-wide tile grid only (sb/ntx/nty/slots are part-independent)
+    rc = merge_tiles(s, tile_size, tile_parts, bufs.data(), out_xyz, out_weight);
+    for (auto& z : zeros) if (z.p) (void)hipFree(z.p);
+    return rc;
+}
+
+int pbrt_hip_generate_camera_rays(PbrtHipScene* s, const int pb[4], uint32_t sample_index, PbrtHipRay* out_rays, float* out_pfilm) {
+    if (!s || !pb || !out_rays) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "generate_camera_rays: null argument");
+    if (!s->have_camera || !s->have_sampler) return set_err(s, PBRT_HIP_ERR_STATE, "generate_camera_rays: camera and sampler must be set");
+    if (s->sampler.kind == 1 && s->sobol32.empty()) return set_err(s, PBRT_HIP_ERR_STATE, "generate_camera_rays: sobol tables not set");
+    PH_CHECK(s, hipSetDevice(s->device));
+    const int wdt = pb[2] - pb[0], hgt = pb[3] - pb[1];
+    if (wdt <= 0 || hgt <= 0) return PBRT_HIP_OK;
+    const size_t n = (size_t)wdt * hgt;
+    int rc;
+    // camera rays need only the sampler tables; upload_scene copes with a scene whose BVH has not been built
+    if ((rc = upload_scene(s))) return rc;
+    if ((rc = ensure_buf(s, s->d_rays_tmp, n * sizeof(PbrtHipRay)))) return rc;
+    if ((rc = ensure_buf(s, s->d_out_tmp, n * 8))) return rc;
+    hipLaunchKernelGGL(ph::camera_rays_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s->stream, s->ds, s->cam, s->sampler, pb[0], pb[1], pb[2], pb[3],
+                       sample_index, (ph::RayIn*)s->d_rays_tmp.p, (float*)s->d_out_tmp.p);
+    PH_CHECK(s, hipGetLastError());
+    PH_CHECK(s, hipMemcpyAsync(out_rays, s->d_rays_tmp.p, n * sizeof(PbrtHipRay), hipMemcpyDeviceToHost, s->stream));
+    if (out_pfilm) PH_CHECK(s, hipMemcpyAsync(out_pfilm, s->d_out_tmp.p, n * 8, hipMemcpyDeviceToHost, s->stream));
+    PH_CHECK(s, hipStreamSynchronize(s->stream));
+    return PBRT_HIP_OK;
+}
+
+}  // extern "C"
