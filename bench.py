@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the MI355X wavefront path tracer on BASELINE.json's configs[1]
+("Synthetic 100k random triangles, single BVH, 512x512 @ 64 spp, 1x MI355X").
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one frame: SamplerIntegrator::render of the whole image (raygen -> [extend, shadow, shade] x (maxdepth+1) -> film).
+Scene, BVH and sampler tables are resident in HBM before the timed region.  With N ranks the frame's 16x16 tiles are dealt
+round-robin (tile t -> rank t % N, the reference's tile enumeration), every rank renders its tiles, the per-tile film buffers
+are gathered on rank 0 over RCCL and merged there in tile order: the same frame, so scaling is "strong".
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (closest-hit BVH traversal): achieved = algorithmic
+bytes (32 B per reference-format node visit + 48 B per triangle test + 64 B ray in / hit out) / its HIP-event time
+measured inside the timed steps.  `cpu_baseline` times the CPU oracle (oracle/, a port of the reference algorithm — the Rust
+reference cannot be built here) on a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pbrt-v3-rs_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def host_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota and by the box's per-GPU
+    CPU share (16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("PBRT_HIP_CPU_THREADS", "16"))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-tris", type=int, default=100_000)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--max-depth", type=int, default=5)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample (same scene, same resolution)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-count", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import pbrt_hip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    host = pbrt_hip.Host()
+    spec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=args.spp, max_depth=args.max_depth)
+    scene = pbrt_hip.Scene(device=local_rank)
+    t_setup = time.time()
+    geometry = pbrt_hip.capture_spec(spec, scene, host)
+    t_setup = time.time() - t_setup
+
+    tile_size = 16
+    floats = max(scene.tile_buffer_floats(tile_size, p, world) for p in range(world))
+    tile_buf = torch.zeros(floats, dtype=torch.float32, device=dev)
+    gather_list = [torch.zeros(floats, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        st = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=args.max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
+        film = None
+        if world > 1:
+            dist.gather(tile_buf, gather_list, dst=0)
+            if rank == 0:
+                torch.cuda.synchronize()
+                film = scene.merge_tiles_device([t.data_ptr() for t in gather_list], tile_size)
+        else:
+            film = scene.merge_tiles_device([tile_buf.data_ptr()], tile_size)
+        return st, film
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    rays = 0
+    ext_s = sh_s = shade_s = 0.0
+    reg = shd = 0
+    film = None
+    for _ in range(args.steps):
+        st, film = step()
+        rays += st.regular_rays + st.shadow_rays
+        reg += st.regular_rays; shd += st.shadow_rays
+        ext_s += st.extend_seconds; sh_s += st.shadow_seconds; shade_s += st.shade_seconds
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays, reg, shd], dtype=torch.int64, device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays, reg, shd = (int(v) for v in r.tolist())
+
+    out = None
+    if rank == 0:
+        mrays = rays / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {args.n_tris} random triangles (seed {args.seed}), single SAH BVH, {args.res}x{args.res} @ {args.spp} spp, "
+                                   f"PathIntegrator maxdepth {args.max_depth}, halton, box filter, constant infinite light, matte Kd 0.5",
+                       "tiles": "16x16, tile t on rank t % n_gpus, film tiles gathered on rank 0 (RCCL)" if world > 1 else "16x16, one rank",
+                       "rays_per_frame": rays // args.steps, "regular_rays_per_frame": reg // args.steps, "shadow_rays_per_frame": shd // args.steps,
+                       "scene_setup_seconds_host": round(t_setup, 3)},
+            "stage_ms_per_step_rank0": {"extend": round(ext_s / args.steps * 1e3, 3), "shadow": round(sh_s / args.steps * 1e3, 3),
+                                        "raygen_shade_film": round(shade_s / args.steps * 1e3, 3)},
+        }
+
+    # ---- roofline of the dominant kernel (closest-hit traversal), rank 0's share ------------------------------------------------
+    if rank == 0:
+        roof = {"bound": "hbm", "kernel": "ph::traverse_kernel<false,false> (closest hit)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": None, "traffic": None}
+        if not args.no_roofline_count:
+            C = pbrt_hip.C
+            lib = scene.b.lib
+            lib.pbrt_hip_set_traversal_counting.argtypes = [C.c_void_p, C.c_int]
+            lib.pbrt_hip_get_traversal_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+            lib.pbrt_hip_set_traversal_counting(scene.h, 1)
+            st_c = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=args.max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
+            cnt = (C.c_uint64 * 6)()
+            lib.pbrt_hip_get_traversal_counts(scene.h, cnt)
+            lib.pbrt_hip_set_traversal_counting(scene.h, 0)
+            nodes_passed, tri_tests, n_rays = int(cnt[0]), int(cnt[1]), int(cnt[2])
+            n_v = n_rays + 2 * nodes_passed  # reference-format node visits (traverse.h)
+            bytes_per_frame = 32 * n_v + 48 * tri_tests + 64 * n_rays
+            ext_per_frame = ext_s / args.steps
+            launches = int(st.extend_launches)
+            ach = bytes_per_frame / ext_per_frame / 1e9 if ext_per_frame > 0 else None
+            roof.update({"achieved": round(ach, 1) if ach else None, "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
+                         "algorithmic_bytes_per_launch": bytes_per_frame // max(launches, 1), "launches_per_step": launches,
+                         "avg_launch_ms": round(ext_per_frame / launches * 1e3, 4), "rays_per_step": n_rays,
+                         "ref_node_visits_per_ray": round(n_v / max(n_rays, 1), 2), "tri_tests_per_ray": round(tri_tests / max(n_rays, 1), 2),
+                         "bytes_per_ray": round(bytes_per_frame / max(n_rays, 1), 1),
+                         "kernel_Mrays_per_s": round(n_rays / ext_per_frame / 1e6, 1) if ext_per_frame > 0 else None,
+                         "note": "counts from an untimed counting pass of the same frame; time = HIP events around every closest-hit launch of the timed steps"})
+        out["roofline"] = roof
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores, bounded sample ------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_binding import OracleScene
+        cores = host_cores()
+        cspec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=args.cpu_spp, max_depth=args.max_depth)
+        orc = OracleScene()
+        tb = time.time()
+        pbrt_hip.capture_spec(cspec, orc, host, geometry=geometry)
+        tb = time.time() - tb
+        _, _, ost, _ = orc.render_path_ex(max_depth=args.max_depth, threads=cores)
+        crays = ost.regular_rays + ost.shadow_rays
+        out["cpu_baseline"] = {"value": round(crays / ost.render_seconds / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                               "sample": f"same scene and resolution at {args.cpu_spp} spp (the first {args.cpu_spp} Halton samples of every pixel): {crays} rays in "
+                                         f"{ost.render_seconds:.2f} s render phase; single-threaded SAH build {tb:.2f} s excluded",
+                               "gpu_over_cpu": round(out["value"] / (crays / ost.render_seconds / 1e6), 1)}
+        orc.close()
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,8 @@ typedef struct PbrtHipStats {
     double extend_seconds;       /* of which: closest-hit traversal kernels                  */
     double shadow_seconds;       /* of which: any-hit traversal kernels                      */
     double shade_seconds;        /* of which: raygen + shade + film kernels                  */
+    uint64_t extend_launches;    /* number of closest-hit traversal launches in this render  */
+    uint64_t shadow_launches;    /* number of any-hit traversal launches                     */
 } PbrtHipStats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------- */
@@ -133,6 +135,12 @@ int pbrt_hip_occluded_batch(PbrtHipScene*, const PbrtHipRay* rays, uint8_t* out_
  * before returning unless sync==0.  kernel_ms (may be NULL) receives the HIP-event duration of the kernel alone. */
 int pbrt_hip_intersect_batch_device(PbrtHipScene*, const void* d_rays, void* d_hits, uint64_t n, float* kernel_ms);
 int pbrt_hip_occluded_batch_device(PbrtHipScene*, const void* d_rays, void* d_occluded, uint64_t n, float* kernel_ms);
+
+/* Measurement aid (not a reference interface): with counting on, traversal launches also tally their work.
+ * out[0..2] closest-hit {interior nodes whose box test passed, triangle tests, rays}, out[3..5] the same for any-hit.
+ * Reference-format node visits of the closest-hit rays = out[2] + 2*out[0].  get resets the tallies.  Never timed. */
+int pbrt_hip_set_traversal_counting(PbrtHipScene*, int on);
+int pbrt_hip_get_traversal_counts(PbrtHipScene*, uint64_t out[6]);
 
 /* Integrator::render for PathIntegrator (core/src/integrator/sampler_integrator.rs:243-415 +
  * integrators/src/path.rs:103-284).  Renders the 16x16 (tile_size) sample tiles whose index t satisfies

@@ -22,6 +22,7 @@ struct OracleHit { float t; uint32_t prim; float b0, b1, b2; uint32_t pad[3]; };
 struct OracleStats {
     uint64_t camera_rays, regular_rays, shadow_rays, paths_zero_radiance, paths_total;
     double render_seconds, extend_seconds, shadow_seconds, shade_seconds;
+    uint64_t extend_launches, shadow_launches;
 };
 struct OracleTraversalStats { uint64_t rays, nodes_visited, tri_tests; };
 
@@ -211,8 +212,6 @@ int oracle_render_path_ex(OracleScene* s, int max_depth, float rr_threshold, int
     Renderer& r = s->r;
     r.max_depth = max_depth; r.rr_threshold = rr_threshold; r.light_strategy = light_strategy == 2 ? 0 : light_strategy;
     for (int i = 0; i < 4; i++) r.pixel_bounds[i] = pixel_bounds[i];
-    r.stats.camera_rays = r.stats.regular_rays = r.stats.shadow_rays = r.stats.zero_paths = r.stats.total_paths = 0;
-    r.stats.nv_regular = r.stats.nt_regular = r.stats.nv_shadow = r.stats.nt_shadow = 0;
     r.count_traversal = count_traversal != 0;
     r.rec = s->rec.cap ? &s->rec : nullptr;
     if (n_threads <= 0) n_threads = batch_threads();
@@ -221,11 +220,11 @@ int oracle_render_path_ex(OracleScene* s, int max_depth, float rr_threshold, int
     auto t1 = std::chrono::steady_clock::now();
     if (st) {
         std::memset(st, 0, sizeof(*st));
-        st->camera_rays = r.stats.camera_rays; st->regular_rays = r.stats.regular_rays; st->shadow_rays = r.stats.shadow_rays;
-        st->paths_zero_radiance = r.stats.zero_paths; st->paths_total = r.stats.total_paths;
+        st->camera_rays = r.total_stats.camera_rays; st->regular_rays = r.total_stats.regular_rays; st->shadow_rays = r.total_stats.shadow_rays;
+        st->paths_zero_radiance = r.total_stats.zero_paths; st->paths_total = r.total_stats.total_paths;
         st->render_seconds = std::chrono::duration<double>(t1 - t0).count();
     }
-    if (out_nv_nt) { out_nv_nt[0] = r.stats.nv_regular; out_nv_nt[1] = r.stats.nt_regular; out_nv_nt[2] = r.stats.nv_shadow; out_nv_nt[3] = r.stats.nt_shadow; }
+    if (out_nv_nt) { out_nv_nt[0] = r.total_stats.nv_regular; out_nv_nt[1] = r.total_stats.nt_regular; out_nv_nt[2] = r.total_stats.nv_shadow; out_nv_nt[3] = r.total_stats.nt_shadow; }
     return 0;
 }
 int oracle_render_path(OracleScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size,

@@ -344,10 +344,15 @@ inline Ray spawn_ray_to_hit(const V3& p, const V3& p_error, const V3& n, Float t
 
 struct LiSample { V3 wi; Float pdf; Spec value; V3 vp, vperr, vn; bool valid; };  // Li + VisibilityTester.p1
 
-struct RenderStats {
-    std::atomic<uint64_t> camera_rays{0}, regular_rays{0}, shadow_rays{0}, zero_paths{0}, total_paths{0};
-    std::atomic<uint64_t> nv_regular{0}, nt_regular{0}, nv_shadow{0}, nt_shadow{0};
+struct RenderStats {  // the reference keeps these per thread and merges at exit (core/src/stats/macros.rs:176-222)
+    uint64_t camera_rays = 0, regular_rays = 0, shadow_rays = 0, zero_paths = 0, total_paths = 0;
+    uint64_t nv_regular = 0, nt_regular = 0, nv_shadow = 0, nt_shadow = 0;
+    void add(const RenderStats& o) {
+        camera_rays += o.camera_rays; regular_rays += o.regular_rays; shadow_rays += o.shadow_rays; zero_paths += o.zero_paths; total_paths += o.total_paths;
+        nv_regular += o.nv_regular; nt_regular += o.nt_regular; nv_shadow += o.nv_shadow; nt_shadow += o.nt_shadow;
+    }
 };
+inline RenderStats& tls_stats() { static thread_local RenderStats s; return s; }
 
 struct RayRecorder {  // optional capture of every ray handed to Scene::intersect / intersect_p
     std::mutex mu; std::vector<Ray> regular, shadow; size_t cap = 0;
@@ -369,16 +374,18 @@ struct Renderer {
     int max_depth = 5; Float rr_threshold = 1.0f; int light_strategy = 0;
     int pixel_bounds[4] = {0, 0, 0, 0};
     Dist1D light_distrib;
-    RenderStats stats; RayRecorder* rec = nullptr; bool count_traversal = false;
+    RenderStats total_stats; std::mutex stats_mu; RayRecorder* rec = nullptr; bool count_traversal = false;
 
     // ---- Scene::intersect / intersect_p with the reference's counters (core/src/scene.rs:88-99)
     bool scene_intersect(Ray& r, uint32_t& prim, TriHit& h) {
+        RenderStats& stats = tls_stats();
         stats.regular_rays++;
         if (rec) rec->add(rec->regular, r);
         if (count_traversal) { TraversalStats ts; bool b = sc->intersect(r, prim, h, &ts); stats.nv_regular += ts.nodes_visited; stats.nt_regular += ts.tri_tests; return b; }
         return sc->intersect(r, prim, h);
     }
     bool scene_intersect_p(const Ray& r) {
+        RenderStats& stats = tls_stats();
         stats.shadow_rays++;
         if (rec) rec->add(rec->shadow, r);
         if (count_traversal) { TraversalStats ts; bool b = sc->intersect_p(r, &ts); stats.nv_shadow += ts.nodes_visited; stats.nt_shadow += ts.tri_tests; return b; }
@@ -677,9 +684,9 @@ struct Renderer {
             BSDF bsdf = make_bsdf(isect);  // materials always present in scope
             V3 shading_n = isect.ns;
             if (bsdf.has_bxdf) {  // num_components(all & !SPECULAR) > 0
-                stats.total_paths++;
+                tls_stats().total_paths++;
                 Spec ld = beta * uniform_sample_one_light(isect, bsdf, sampler);
-                if (ld.is_black()) stats.zero_paths++;
+                if (ld.is_black()) tls_stats().zero_paths++;
                 L += ld;
             }
             V2 u = sampler.get_2d();
@@ -774,7 +781,7 @@ struct Renderer {
                     Float time = sampler.get_1d();
                     V2 p_lens = sampler.get_2d();
                     Ray ray = generate_ray(p_film, time, p_lens);
-                    stats.camera_rays++;
+                    tls_stats().camera_rays++;
                     Spec L = li(ray, sampler);  // ray_weight is always 1.0 for the perspective camera
                     if (L.has_nans()) L = Spec(0.0f);
                     else if (L.y() < -1e-5f) L = Spec(0.0f);
@@ -805,10 +812,12 @@ struct Renderer {
         int tile_count = ntx * nty;
         std::vector<FilmTile> tiles(tile_count);
         std::atomic<int> next{0};
+        total_stats = RenderStats();
         auto worker = [&]() {
+            tls_stats() = RenderStats();
             for (;;) {
                 int t = next++;
-                if (t >= tile_count) break;
+                if (t >= tile_count) { std::lock_guard<std::mutex> g(stats_mu); total_stats.add(tls_stats()); break; }
                 if (t % tile_parts != tile_part) continue;
                 int tb[4]; tile_bounds(t, ntx, sb, tile_size, tb);
                 tiles[t] = get_film_tile(tb);

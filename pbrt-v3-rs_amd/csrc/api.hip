@@ -138,33 +138,51 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
     return PBRT_HIP_OK;
 }
 
-int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_out, uint32_t n, float* kernel_ms) {
-    if (kernel_ms) *kernel_ms = 0.0f;
-    if (n == 0) return PBRT_HIP_OK;
+int ensure_traversal_workspace(PbrtHipScene* s) {
     if (!s->trav_blocks) {
         hipDeviceProp_t prop;
         PH_CHECK(s, hipGetDeviceProperties(&prop, s->device));
         int per_cu = 0;
-        PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false>, PH_TRAV_BLOCK, 0));
-        if (per_cu < 1) per_cu = 1;
-        if (per_cu > 8) per_cu = 8;
+        PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false>, PH_TRAV_BLOCK, 0));
+        per_cu = std::min(std::max(per_cu, 1), 8);
         s->trav_blocks = (uint32_t)(prop.multiProcessorCount * per_cu);
     }
-    // fewer rays than resident lanes: shrink the grid so idle waves exit immediately
-    uint32_t blocks = std::min<uint32_t>(s->trav_blocks, (n + PH_TRAV_BLOCK - 1) / PH_TRAV_BLOCK);
     const uint32_t total_threads = s->trav_blocks * PH_TRAV_BLOCK;
     int rc;
     if ((rc = ensure_buf(s, s->d_counter, 64))) return rc;
     if ((rc = ensure_buf(s, s->d_error, 64))) return rc;
+    if ((rc = ensure_buf(s, s->d_counts, 64))) return rc;
     if ((rc = ensure_buf(s, s->d_spill, (size_t)(PH_MAX_STACK - PH_LDS_DEPTH) * total_threads * sizeof(uint2)))) return rc;
+    return PBRT_HIP_OK;
+}
+
+// p.spill / total_threads / error_flag / counts are filled here
+void launch_traverse_kernel(PbrtHipScene* s, bool anyhit, uint32_t blocks, const ph::TravParams& p_in) {
+    ph::TravParams p = p_in;
+    p.spill = (uint2*)s->d_spill.p; p.total_threads = s->trav_blocks * PH_TRAV_BLOCK; p.error_flag = (uint32_t*)s->d_error.p;
+    p.counts = (unsigned long long*)s->d_counts.p + (anyhit ? 3 : 0);
+    const dim3 g(blocks), b(PH_TRAV_BLOCK);
+    if (s->count_traversal) {
+        if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, true>), g, b, 0, s->stream, s->ds, p);
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, true>), g, b, 0, s->stream, s->ds, p);
+    } else {
+        if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, false>), g, b, 0, s->stream, s->ds, p);
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, false>), g, b, 0, s->stream, s->ds, p);
+    }
+}
+
+int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_out, uint32_t n, float* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.0f;
+    if (n == 0) return PBRT_HIP_OK;
+    int rc;
+    if ((rc = ensure_traversal_workspace(s))) return rc;
+    // fewer rays than resident lanes: shrink the grid so idle waves exit immediately
+    const uint32_t blocks = std::min<uint32_t>(s->trav_blocks, (n + PH_TRAV_BLOCK - 1) / PH_TRAV_BLOCK);
     PH_CHECK(s, hipMemsetAsync(s->d_counter.p, 0, 4, s->stream));
-    ph::TravParams p;
-    p.rays = (const ph::RayIn*)d_rays; p.out = d_out; p.n = n; p.n_ptr = nullptr;
-    p.counter = (uint32_t*)s->d_counter.p; p.spill = (uint2*)s->d_spill.p; p.total_threads = total_threads;
-    p.error_flag = (uint32_t*)s->d_error.p;
+    ph::TravParams p{};
+    p.rays = (const ph::RayIn*)d_rays; p.out = d_out; p.n = n; p.n_ptr = nullptr; p.counter = (uint32_t*)s->d_counter.p;
     if (kernel_ms) PH_CHECK(s, hipEventRecord(s->ev0, s->stream));
-    if (anyhit) hipLaunchKernelGGL(ph::traverse_kernel<true>, dim3(blocks), dim3(PH_TRAV_BLOCK), 0, s->stream, s->ds, p);
-    else hipLaunchKernelGGL(ph::traverse_kernel<false>, dim3(blocks), dim3(PH_TRAV_BLOCK), 0, s->stream, s->ds, p);
+    launch_traverse_kernel(s, anyhit, blocks, p);
     PH_CHECK(s, hipGetLastError());
     if (kernel_ms) {
         PH_CHECK(s, hipEventRecord(s->ev1, s->stream));
@@ -241,7 +259,7 @@ void pbrt_hip_scene_destroy(PbrtHipScene* s) {
     (void)hipStreamSynchronize(s->stream);
     free_wavefront(s);
     free_owned(s);
-    for (DevBuf* b : {&s->d_ld_func, &s->d_ld_cdf, &s->d_counter, &s->d_spill, &s->d_error, &s->d_rays_tmp, &s->d_out_tmp})
+    for (DevBuf* b : {&s->d_ld_func, &s->d_ld_cdf, &s->d_counter, &s->d_spill, &s->d_error, &s->d_counts, &s->d_rays_tmp, &s->d_out_tmp})
         if (b->p) (void)hipFree(b->p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -552,6 +570,28 @@ int pbrt_hip_intersect_batch(PbrtHipScene* s, const PbrtHipRay* rays, PbrtHipHit
 int pbrt_hip_occluded_batch(PbrtHipScene* s, const PbrtHipRay* rays, uint8_t* out, uint64_t n) { return batch_common(s, true, rays, out, n, false, nullptr); }
 int pbrt_hip_intersect_batch_device(PbrtHipScene* s, const void* d_rays, void* d_hits, uint64_t n, float* ms) { return batch_common(s, false, d_rays, d_hits, n, true, ms); }
 int pbrt_hip_occluded_batch_device(PbrtHipScene* s, const void* d_rays, void* d_occ, uint64_t n, float* ms) { return batch_common(s, true, d_rays, d_occ, n, true, ms); }
+
+// Roofline bookkeeping: with counting on, every traversal launch also accumulates the work it did.
+// out[0..2] closest-hit {interior nodes passed, triangle tests, rays}, out[3..5] any-hit.  Reference-format node visits of
+// the closest-hit rays = rays + 2*out[0] (see traverse.h).  Reading resets the counters.
+int pbrt_hip_set_traversal_counting(PbrtHipScene* s, int on) {
+    if (!s) return PBRT_HIP_ERR_INVALID_ARG;
+    PH_CHECK(s, hipSetDevice(s->device));
+    int rc;
+    if ((rc = ensure_traversal_workspace(s))) return rc;
+    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 48));
+    s->count_traversal = on != 0;
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_get_traversal_counts(PbrtHipScene* s, uint64_t out[6]) {
+    if (!s || !out) return PBRT_HIP_ERR_INVALID_ARG;
+    if (!s->d_counts.p) { for (int i = 0; i < 6; i++) out[i] = 0; return PBRT_HIP_OK; }
+    PH_CHECK(s, hipSetDevice(s->device));
+    PH_CHECK(s, hipStreamSynchronize(s->stream));
+    PH_CHECK(s, hipMemcpy(out, s->d_counts.p, 48, hipMemcpyDeviceToHost));
+    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 48));
+    return PBRT_HIP_OK;
+}
 
 // Film::get_pixel_rgb (core/src/film/mod.rs:392-417); splat is identically zero for the path integrator (quirk B3 kept)
 int pbrt_hip_film_to_rgb(const PbrtHipScene* s, const float* xyz, const float* weight, float* out_rgb) {

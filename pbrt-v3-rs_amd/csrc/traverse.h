@@ -41,6 +41,7 @@ struct TravParams {
     uint2* spill;           // [PH_MAX_STACK - PH_LDS_DEPTH][total_threads]
     uint32_t total_threads;
     uint32_t* error_flag;   // set to 1 on stack overflow (the reference would panic on index 64)
+    unsigned long long* counts;  // COUNT builds only: [0] interior nodes whose box test passed, [1] triangle tests, [2] rays
 };
 
 struct RayState {
@@ -127,7 +128,10 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
     return true;
 }
 
-template <bool ANYHIT>
+// COUNT = true adds per-ray work counters (roofline bookkeeping, never used in a timed run).  For closest-hit rays the
+// reference's "nodes visited" is exactly 1 + 2 * (interior nodes whose box test passed): it fetches and tests both children
+// of every such node (the far one when it is popped), and nothing else.
+template <bool ANYHIT, bool COUNT = false>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[PH_LDS_DEPTH][PH_TRAV_BLOCK];
     const uint32_t tid = threadIdx.x;
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
     uint32_t hit_prim = 0xFFFFFFFFu;
     float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     bool occluded = false;
+    uint32_t c_nodes = 0, c_tris = 0, c_rays = 0;
 
     auto push = [&](uint32_t ref, float tmin) {
         uint2 e = make_uint2(ref, __float_as_uint(tmin));
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                     const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
                     const float4 q0 = np[0], q1 = np[1], q2 = np[2];
                     const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
+                    if (COUNT) c_nodes++;
                     // q0 = x0[0],x0[1],y0[0],y0[1]; q1 = z0[0],z0[1],x1[0],x1[1]; q2 = y1[0],y1[1],z1[0],z1[1]
                     float t0, t1;
                     bool h0 = box_test(r, r.nx ? q0.y : q0.x, r.nx ? q0.x : q0.y, r.ny ? q0.w : q0.z, r.ny ? q0.z : q0.w,
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                         const uint32_t flags = __float_as_uint(b.w);
                         last = (flags & PH_TRI_LAST) != 0;
                         float t, b0, b1, b2;
+                        if (COUNT) c_tris++;
                         if (tri_test(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), t, b0, b1, b2)) {
                             // post-t rejections: degenerate triangle (triangle.rs:567-570 / 862-866), alpha == 0 (:603 / :886-893)
                             const uint32_t reject = ANYHIT ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
@@ -256,8 +263,14 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                     hp[1] = make_float4(hb2, 0.0f, 0.0f, 0.0f);
                 }
                 has_ray = false;
+                if (COUNT) c_rays++;
             }
         }
+    }
+    if (COUNT) {
+        atomicAdd(p.counts + 0, (unsigned long long)c_nodes);
+        atomicAdd(p.counts + 1, (unsigned long long)c_tris);
+        atomicAdd(p.counts + 2, (unsigned long long)c_rays);
     }
 }
 

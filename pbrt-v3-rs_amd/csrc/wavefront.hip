@@ -572,18 +572,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     if ((rc = ensure_buf(s, w.d_recL, (size_t)n_px * spp * 16))) return rc;
     if ((rc = ensure_buf(s, w.d_recpy, (size_t)n_px * spp * 4))) return rc;
 
-    // traversal launch geometry (shared with the batch entry points)
-    if (!s->trav_blocks) {
-        hipDeviceProp_t prop;
-        PH_CHECK(s, hipGetDeviceProperties(&prop, s->device));
-        int per_cu = 0;
-        PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false>, PH_TRAV_BLOCK, 0));
-        per_cu = std::min(std::max(per_cu, 1), 8);
-        s->trav_blocks = (uint32_t)(prop.multiProcessorCount * per_cu);
-    }
-    const uint32_t total_threads = s->trav_blocks * PH_TRAV_BLOCK;
-    if ((rc = ensure_buf(s, s->d_error, 64))) return rc;
-    if ((rc = ensure_buf(s, s->d_spill, (size_t)(PH_MAX_STACK - PH_LDS_DEPTH) * total_threads * sizeof(uint2)))) return rc;
+    if ((rc = ensure_traversal_workspace(s))) return rc;
 
     ph::WfParams wp{};
     wp.cam = s->cam; wp.sp = s->sampler;
@@ -627,12 +616,11 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
         for (int it = 0; it < n_iter; it++) {
             ph::IterCounters* c = (ph::IterCounters*)w.d_ctr.p + it;
             ph::TravParams tp{};
-            tp.spill = (uint2*)s->d_spill.p; tp.total_threads = total_threads; tp.error_flag = (uint32_t*)s->d_error.p;
             tp.rays = wp.rays_cl[it & 1]; tp.out = wp.hits_cl; tp.n = 0; tp.n_ptr = &c->n_cl; tp.counter = &c->head_cl;
-            if ((rc = timed(0, [&]() { hipLaunchKernelGGL(ph::traverse_kernel<false>, dim3(s->trav_blocks), dim3(PH_TRAV_BLOCK), 0, s->stream, s->ds, tp); }))) return rc;
+            if ((rc = timed(0, [&]() { launch_traverse_kernel(s, false, s->trav_blocks, tp); }))) return rc;
             if (it > 0) {
                 tp.rays = wp.rays_sh; tp.out = wp.occ; tp.n_ptr = &c->n_sh; tp.counter = &c->head_sh;
-                if ((rc = timed(1, [&]() { hipLaunchKernelGGL(ph::traverse_kernel<true>, dim3(s->trav_blocks), dim3(PH_TRAV_BLOCK), 0, s->stream, s->ds, tp); }))) return rc;
+                if ((rc = timed(1, [&]() { launch_traverse_kernel(s, true, s->trav_blocks, tp); }))) return rc;
             }
             if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::shade_kernel, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it); }))) return rc;
         }
@@ -664,6 +652,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
         double acc[3] = {0, 0, 0};
         for (const Span& sp : spans) { float m = 0; if (hipEventElapsedTime(&m, sp.a, sp.b) == hipSuccess) acc[sp.kind] += m * 1e-3; }
         out_stats->extend_seconds = acc[0]; out_stats->shadow_seconds = acc[1]; out_stats->shade_seconds = acc[2];
+        for (const Span& sp : spans) { if (sp.kind == 0) out_stats->extend_launches++; else if (sp.kind == 1) out_stats->shadow_launches++; }
     }
     return PBRT_HIP_OK;
 }
