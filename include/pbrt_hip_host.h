@@ -46,6 +46,14 @@ void pbrt_hip_host_point_position(const float l2w[16], const float l2w_inv[16], 
  * (core/src/rng.rs semantics). out_P: 9 floats per triangle, out_idx: 3 per triangle (unshared vertices). */
 void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, float* out_P, uint32_t* out_idx);
 
+/* Host-only run of the library's BVH builder (accelerators/src/bvh/{mod,sah}.rs topology contract), for inspection
+ * and tests; needs no GPU.  out_ordered_prims / out_leaf_last: n_tris entries in leaf order; out_nodes: room for
+ * n_tris-1 64-byte nodes or NULL; out_info[5] = {interior nodes, leaf nodes, max prims per leaf, max depth, root ref};
+ * out_root_bounds[6]. */
+int pbrt_hip_host_build_bvh(const float* P, const uint32_t* idx, uint64_t n_tris, int split_method, int max_prims_in_node,
+                            int n_threads, uint32_t* out_ordered_prims, uint32_t* out_leaf_last, void* out_nodes,
+                            uint64_t* out_info, float* out_root_bounds);
+
 #ifdef __cplusplus
 }
 #endif

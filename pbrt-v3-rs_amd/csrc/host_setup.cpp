@@ -178,3 +178,23 @@ extern "C" void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, fl
         out_idx[3 * t] = (uint32_t)(3 * t); out_idx[3 * t + 1] = (uint32_t)(3 * t + 1); out_idx[3 * t + 2] = (uint32_t)(3 * t + 2);
     }
 }
+
+// ---- host-only view of the BVH builder (no device needed): used by the CPU test-suite to pin the topology contract of
+// bvh_build.h against the oracle's restatement of BVHAccel::new.  out_ordered_prims: n_tris entries (leaf order);
+// out_nodes: up to n_tris-1 Node64 (may be NULL); out_info: {interior nodes, leaf nodes, max prims in a leaf, max depth, root_ref}.
+#include "bvh_build.h"
+extern "C" int pbrt_hip_host_build_bvh(const float* P, const uint32_t* idx, uint64_t n_tris, int split_method, int max_prims_in_node, int n_threads,
+                                       uint32_t* out_ordered_prims, uint32_t* out_leaf_last, void* out_nodes, uint64_t* out_info, float* out_root_bounds) {
+    phost::BuildInput in{P, idx, (size_t)n_tris, nullptr};
+    phost::BuildOutput out;
+    int rc = phost::build_bvh(in, split_method, max_prims_in_node, n_threads, out);
+    if (rc) return rc;
+    for (size_t i = 0; i < out.tris.size(); i++) {
+        if (out_ordered_prims) out_ordered_prims[i] = out.tris[i].prim;
+        if (out_leaf_last) out_leaf_last[i] = (out.tris[i].flags & PH_TRI_LAST) ? 1u : 0u;
+    }
+    if (out_nodes && !out.nodes.empty()) std::memcpy(out_nodes, out.nodes.data(), out.nodes.size() * sizeof(Node64));
+    if (out_info) { out_info[0] = out.interior_nodes; out_info[1] = out.leaf_nodes; out_info[2] = out.max_leaf_prims; out_info[3] = (uint64_t)out.max_depth; out_info[4] = out.root_ref; }
+    if (out_root_bounds) { for (int k = 0; k < 3; k++) { out_root_bounds[k] = out.root_lo[k]; out_root_bounds[3 + k] = out.root_hi[k]; } }
+    return 0;
+}

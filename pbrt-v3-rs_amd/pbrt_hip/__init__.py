@@ -5,9 +5,8 @@ kernels.  The class layout mirrors the reference's plugin surface for the path (
 with the same calls the reference's factories make (api/src/graphics_state.rs:254-720) and `render_path` stands in
 for `Integrator::render` (core/src/integrator/mod.rs:16-39).
 
-`Binding(lib, prefix)` is deliberately generic over the symbol prefix so that the TEST harness can drive the CPU
-oracle (liboracle.so, prefix ``oracle_``) through the identical Python code; nothing in this package imports or
-loads anything under oracle/.
+`Binding(lib, prefix)` is deliberately generic over the symbol prefix so that the TEST harness can drive its CPU
+checker through the identical Python code; nothing in this package imports, loads or links the checker.
 """
 from __future__ import annotations
 

@@ -1,0 +1,154 @@
+"""not gpu: the product's C-ABI library loads without a GPU and exports every symbol include/*.h declares; its host-side
+helpers and its BVH builder agree bit-for-bit with the oracle's independent restatement of the reference."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pbrt_hip
+from oracle_binding import OracleScene, oracle_binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pbrt_hip_\w+)\s*\(", src)))
+
+
+@pytest.mark.parametrize("header", ["pbrt_hip.h", "pbrt_hip_host.h"])
+def test_library_exports_every_declared_symbol(product, header):
+    names = _declared(header)
+    assert len(names) >= 15
+    missing = [n for n in names if not hasattr(product.lib, n)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback_without_a_gpu(product):
+    """Without a device the handle cannot even be created; nothing routes to the oracle or any CPU path."""
+    n = product.fn("device_count")()
+    if n > 0:
+        pytest.skip("a GPU is visible")
+    assert product.fn("scene_create")(0) is None
+    assert b"no usable HIP device" in product.fn("last_error")(None)
+    with pytest.raises(pbrt_hip.PbrtHipError) as e:
+        pbrt_hip.Scene(product)
+    assert e.value.code == pbrt_hip.ERR_NO_DEVICE
+
+
+def test_product_does_not_reference_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pbrt-v3-rs_amd")):
+        for f in files:
+            if f.endswith((".h", ".hip", ".cpp", ".py", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("liboracle", "oracle_capi", 'include "oracle', "oracle_binding", "import oracle", "oracle/"):
+                    assert needle not in txt, (needle, os.path.join(dirpath, f))
+
+
+def _m16():
+    return np.zeros(16, np.float32)
+
+
+def test_look_at_and_perspective_match_oracle(host):
+    ol = oracle_binding().lib
+    fp = C.POINTER(C.c_float)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        pos, look = rng.uniform(-5, 5, 3).astype(np.float32), rng.uniform(-1, 1, 3).astype(np.float32)
+        up = np.array([0.1, 0.2, 1.0], np.float32)
+        m, mi = host.look_at(pos, look, up)
+        om, omi = _m16(), _m16()
+        ol.oracle_look_at(pos.ctypes.data_as(fp), look.ctypes.data_as(fp), up.ctypes.data_as(fp), om.ctypes.data_as(fp), omi.ctypes.data_as(fp))
+        assert np.array_equal(m.view(np.uint32), om.view(np.uint32)) and np.array_equal(mi.view(np.uint32), omi.view(np.uint32))
+    for fov, xr, yr in ((40.0, 512, 512), (90.0, 1280, 720), (27.5, 300, 777)):
+        sw = host.screen_window(xr, yr)
+        r2c = host.perspective_raster_to_camera(fov, xr, yr, sw)
+        o = _m16()
+        ol.oracle_perspective_raster_to_camera(C.c_float(fov), xr, yr, sw.ctypes.data_as(fp), o.ctypes.data_as(fp))
+        assert np.array_equal(r2c.view(np.uint32), o.view(np.uint32))
+    with pytest.raises(pbrt_hip.PbrtHipError):
+        host.look_at([0, 0, 0], [0, 0, 1], [0, 0, 2])  # up parallel to the view direction: the reference panics
+
+
+def test_transform_factories_match_oracle(host):
+    ol = oracle_binding().lib
+    fp = C.POINTER(C.c_float)
+    for kind, params, fn in ((0, [1.5, -2.0, 0.25], lambda p: host.translate(p)), (1, [2.0, 0.5, -3.0], lambda p: host.scale(p)),
+                             (2, [33.0, 0.2, 1.0, -0.4], lambda p: host.rotate(p[0], p[1:]))):
+        p = np.array(params, np.float32)
+        m, mi = fn(p)
+        om, omi = _m16(), _m16()
+        ol.oracle_transform_compose(kind, p.ctypes.data_as(fp), om.ctypes.data_as(fp), omi.ctypes.data_as(fp))
+        assert np.array_equal(m.view(np.uint32), om.view(np.uint32)) and np.array_equal(mi.view(np.uint32), omi.view(np.uint32))
+
+
+def test_film_box_setup(host):
+    cb, table, sb = host.film_box(512, 512)
+    assert cb.tolist() == [0, 0, 512, 512] and sb.tolist() == [0, 0, 512, 512] and (table == 1.0).all()
+    cb, table, sb = host.film_box(100, 60, crop_window=(0.25, 0.75, 0.1, 0.9), radius=(2.0, 2.0))
+    assert cb.tolist() == [25, 6, 75, 54] and sb.tolist() == [23, 4, 77, 56]   # film/mod.rs:101-111,150-159
+
+
+def test_synthetic_scene_generator_is_deterministic_pcg32(host):
+    P1, i1 = host.gen_random_tris(1000, 1)
+    P2, _ = host.gen_random_tris(1000, 1)
+    P3, _ = host.gen_random_tris(1000, 2)
+    assert np.array_equal(P1, P2) and not np.array_equal(P1, P3)
+    assert i1.tolist() == list(range(3000))
+    # first centre comes straight from RNG::new(1): KAT 0x73c29fdb, 0xfbaa1ff7, 0xdb022af6
+    u = [np.float32(v) * np.float32(2.0 ** -32) for v in (0x73c29fdb, 0xfbaa1ff7, 0xdb022af6, 0x12d7398c)]
+    c0 = np.float32(2.0) * u[0] - np.float32(1.0)
+    s = np.float32(1.5) * np.float32(np.power(np.float32(1000.0), np.float32(-1.0 / 3.0)))
+    assert abs(float(P1[0, 0] - (c0 + s * (np.float32(2.0) * u[3] - np.float32(1.0))))) < 1e-6
+    assert np.abs(P1).max() < 1.3
+
+
+@pytest.mark.parametrize("n_tris,seed,max_prims", [(1, 1, 4), (2, 1, 4), (3, 5, 4), (17, 2, 4), (5000, 3, 4), (5000, 4, 1), (20000, 6, 8)])
+def test_bvh_topology_equals_oracle(host, product, n_tris, seed, max_prims):
+    """Same SAH decisions, same partition order: leaf order, leaf sizes and every child box equal the oracle's
+    (accelerators/src/bvh/sah.rs restated twice, independently)."""
+    P, idx = host.gen_random_tris(n_tris, seed)
+    orc = OracleScene()
+    m = orc.add_material_matte(); orc.add_mesh(P, idx, m); orc.build_accel(0, max_prims)
+    onodes = orc.bvh_nodes()
+    oprims = np.zeros(n_tris, np.uint32); orc.b.lib.oracle_bvh_ordered_prims(orc.h, oprims.ctypes.data)
+
+    order = np.zeros(n_tris, np.uint32); last = np.zeros(n_tris, np.uint32)
+    nodes = np.zeros((max(n_tris - 1, 1), 16), np.uint32); info = np.zeros(5, np.uint64); rb = np.zeros(6, np.float32)
+    lib = product.lib
+    lib.pbrt_hip_host_build_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for threads in (1, 4):
+        rc = lib.pbrt_hip_host_build_bvh(P.ctypes.data, idx.ctypes.data, n_tris, 0, max_prims, threads, order.ctypes.data, last.ctypes.data, nodes.ctypes.data,
+                                         info.ctypes.data, rb.ctypes.data)
+        assert rc == 0
+        assert np.array_equal(order, oprims), "leaf order differs"
+        leaves = onodes[onodes["n_primitives"] > 0]
+        assert int(info[1]) == len(leaves) and int(info[0]) == len(onodes) - len(leaves)
+        # leaf boundaries: cumulative leaf sizes in depth-first order
+        ends = np.cumsum(leaves[np.argsort(leaves["offset"])]["n_primitives"].astype(np.int64)) - 1
+        assert np.array_equal(np.flatnonzero(last), ends)
+        assert np.array_equal(rb[:3], onodes[0]["pmin"]) and np.array_equal(rb[3:], onodes[0]["pmax"])
+    # every interior Node64 carries exactly the two child boxes of the corresponding reference node
+    if int(info[0]) > 0:
+        f = nodes.view(np.float32)
+        boxes = set()
+        for k in range(int(info[0])):
+            for c in (0, 6):
+                boxes.add((f[k, c], f[k, c + 2], f[k, c + 4], f[k, c + 1], f[k, c + 3], f[k, c + 5]))
+        ref = {tuple(n["pmin"]) + tuple(n["pmax"]) for n in onodes[1:]}
+        assert boxes == ref
+
+
+def test_error_codes_and_state_machine_on_oracle_binding(host):
+    """The same Scene wrapper drives the oracle: argument validation mirrors the reference's error paths."""
+    s = OracleScene()
+    m = s.add_material_matte()
+    with pytest.raises(pbrt_hip.PbrtHipError):
+        s.add_mesh(np.zeros((3, 3), np.float32), [0, 1, 7], m)           # out-of-bounds index (triangle.rs:252-261)
+    with pytest.raises(pbrt_hip.PbrtHipError):
+        s.add_mesh(np.zeros((3, 3), np.float32), [0, 1, 2], m + 5)       # unknown material
+    with pytest.raises(pbrt_hip.PbrtHipError):
+        s.intersect_batch(np.zeros(1, pbrt_hip.RAY_DTYPE))               # before build_accel
