@@ -6,6 +6,7 @@
 #include "traverse.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 static std::string g_last_error;
@@ -87,6 +88,7 @@ int upload_scene(PbrtHipScene* s) {
     if ((rc = upload_vec(s, ht.perms, &d.halton_perms))) return rc;
     if ((rc = upload_vec(s, ht.primes, &d.primes))) return rc;
     if ((rc = upload_vec(s, ht.prime_sums, &d.prime_sums))) return rc;
+    if ((rc = upload_vec(s, ht.magic, &d.prime_magic))) return rc;
     if ((rc = upload_vec(s, s->sobol32, &d.sobol32))) return rc;
     if ((rc = upload_vec(s, s->vdc, &d.vdc))) return rc;
     if ((rc = upload_vec(s, s->vdc_inv, &d.vdc_inv))) return rc;
@@ -138,12 +140,33 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
     return PBRT_HIP_OK;
 }
 
+// Tuning variants of the traversal kernel, selectable at run time (PBRT_HIP_TRAV_VARIANT) so that one GPU session can
+// compare them on the same data.  {LEAF_MIN, REFILL_MIN, LDS_DEPTH}; variant 0 is the default.
+#define PH_VARIANTS(X) X(0, 20, 12, 12) X(1, 8, 8, 16) X(2, 24, 8, 16) X(3, 16, 4, 16) X(4, 16, 16, 16) X(5, 16, 8, 12) X(6, 16, 8, 8) X(7, 32, 8, 16) X(8, 12, 8, 12) X(9, 16, 8, 16)
+static int trav_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_VARIANT"); v = e ? std::atoi(e) : 0; if (v < 0 || v > 9) v = 0; }
+    return v;
+}
+static int variant_lds_depth(int v) {
+    switch (v) {
+#define X(id, lm, rm, ld) case id: return ld;
+        PH_VARIANTS(X)
+#undef X
+    }
+    return PH_LDS_DEPTH;
+}
+
 int ensure_traversal_workspace(PbrtHipScene* s) {
     if (!s->trav_blocks) {
         hipDeviceProp_t prop;
         PH_CHECK(s, hipGetDeviceProperties(&prop, s->device));
         int per_cu = 0;
-        PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false>, PH_TRAV_BLOCK, 0));
+        switch (trav_variant()) {
+#define X(id, lm, rm, ld) case id: PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false, lm, rm, ld>, PH_TRAV_BLOCK, 0)); break;
+            PH_VARIANTS(X)
+#undef X
+        }
         per_cu = std::min(std::max(per_cu, 1), 8);
         s->trav_blocks = (uint32_t)(prop.multiProcessorCount * per_cu);
     }
@@ -152,7 +175,7 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
     if ((rc = ensure_buf(s, s->d_counter, 64))) return rc;
     if ((rc = ensure_buf(s, s->d_error, 64))) return rc;
     if ((rc = ensure_buf(s, s->d_counts, 64))) return rc;
-    if ((rc = ensure_buf(s, s->d_spill, (size_t)(PH_MAX_STACK - PH_LDS_DEPTH) * total_threads * sizeof(uint2)))) return rc;
+    if ((rc = ensure_buf(s, s->d_spill, (size_t)(PH_MAX_STACK - variant_lds_depth(trav_variant())) * total_threads * sizeof(uint2)))) return rc;
     return PBRT_HIP_OK;
 }
 
@@ -161,13 +184,21 @@ void launch_traverse_kernel(PbrtHipScene* s, bool anyhit, uint32_t blocks, const
     ph::TravParams p = p_in;
     p.spill = (uint2*)s->d_spill.p; p.total_threads = s->trav_blocks * PH_TRAV_BLOCK; p.error_flag = (uint32_t*)s->d_error.p;
     p.counts = (unsigned long long*)s->d_counts.p + (anyhit ? 3 : 0);
+    { static int bt = -1; if (bt < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_BATCH"); bt = e ? std::atoi(e) : PH_BATCH; if (bt < 64) bt = 64; } p.batch = (uint32_t)bt; }
     const dim3 g(blocks), b(PH_TRAV_BLOCK);
     if (s->count_traversal) {
         if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, true>), g, b, 0, s->stream, s->ds, p);
         else hipLaunchKernelGGL((ph::traverse_kernel<false, true>), g, b, 0, s->stream, s->ds, p);
-    } else {
-        if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, false>), g, b, 0, s->stream, s->ds, p);
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, false>), g, b, 0, s->stream, s->ds, p);
+        return;
+    }
+    switch (trav_variant()) {
+#define X(id, lm, rm, ld)                                                                                                         \
+    case id:                                                                                                                      \
+        if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, false, lm, rm, ld>), g, b, 0, s->stream, s->ds, p);             \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, false, lm, rm, ld>), g, b, 0, s->stream, s->ds, p);                   \
+        break;
+        PH_VARIANTS(X)
+#undef X
     }
 }
 

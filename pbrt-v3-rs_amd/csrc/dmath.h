@@ -66,6 +66,7 @@ PH_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 // device routine can match it bit for bit; the rounded-f64 value is within 1 ulp of it and is reproducible on any host.
 PH_DEV float d_sin(float x) { return (float)sin((double)x); }
 PH_DEV float d_cos(float x) { return (float)cos((double)x); }
+PH_DEV void d_sincos(float x, float& s, float& c) { double ds, dc; sincos((double)x, &ds, &dc); s = (float)ds; c = (float)dc; }
 PH_DEV float d_acos(float x) { return (float)acos((double)x); }
 PH_DEV float d_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
 

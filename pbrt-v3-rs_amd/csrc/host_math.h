@@ -46,6 +46,7 @@ struct Pcg32 {
 struct HaltonTables {
     std::vector<uint32_t> primes, prime_sums;
     std::vector<uint16_t> perms;
+    std::vector<uint64_t> magic;  // ceil(2^64 / p): floor(a / p) == umul64hi(a, magic) for every a < 2^32
     void build() {
         primes.clear(); prime_sums.clear();
         for (uint32_t c = 2; primes.size() < 1000; c++) {
@@ -54,7 +55,8 @@ struct HaltonTables {
             if (is_p) primes.push_back(c);
         }
         uint32_t total = 0;
-        for (uint32_t p : primes) { prime_sums.push_back(total); total += p; }
+        magic.clear();
+        for (uint32_t p : primes) { prime_sums.push_back(total); total += p; magic.push_back((uint64_t)(((unsigned __int128)1 << 64) / p) + 1); }
         perms.assign(total, 0);
         Pcg32 rng; size_t at = 0;
         for (uint32_t p : primes) {

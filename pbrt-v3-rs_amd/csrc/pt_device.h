@@ -29,13 +29,14 @@ PH_DEV float radical_inverse_base(uint32_t base, uint32_t a) {
     }
     return pminf(__ull2float_rn(reversed) * inv_base_n, kOneMinusEps);
 }
-// scrambled_radical_inverse_specialized (:428-449)
-PH_DEV float scrambled_radical_inverse(uint32_t base, uint32_t a, const uint16_t* __restrict__ perm) {
+// scrambled_radical_inverse_specialized (:428-449).  `a / base` is the integer quotient; it is evaluated as
+// umul64hi(a, ceil(2^64/base)), which equals floor(a/base) for every a < 2^32 (integer arithmetic: no rounding involved).
+PH_DEV float scrambled_radical_inverse(uint32_t base, uint64_t magic, uint32_t a, const uint16_t* __restrict__ perm) {
     const float inv_base = 1.0f / (float)base;
     uint64_t reversed = 0;
     float inv_base_n = 1.0f;
     while (a != 0) {
-        uint32_t next = a / base, digit = a - next * base;
+        uint32_t next = (uint32_t)__umul64hi((uint64_t)a, magic), digit = a - next * base;
         reversed = reversed * base + perm[digit];
         inv_base_n *= inv_base;
         a = next;
@@ -68,7 +69,7 @@ PH_DEV float halton_sample(const DeviceScene& sc, const SamplerRec& sp, uint32_t
     if (sp.at_center && (dim == 0 || dim == 1)) return 0.5f;
     if (dim == 0) return radical_inverse_2((uint64_t)(index >> sp.base_exponents[0]));
     if (dim == 1) return radical_inverse_base(3u, index / sp.base_scales[1]);
-    return scrambled_radical_inverse(sc.primes[dim], index, sc.halton_perms + sc.prime_sums[dim]);
+    return scrambled_radical_inverse(sc.primes[dim], sc.prime_magic[dim], index, sc.halton_perms + sc.prime_sums[dim]);
 }
 
 // sobol_interval_to_index (core/src/low_discrepency.rs:1770-1810)
@@ -125,7 +126,9 @@ PH_DEV f2 concentric_sample_disk(f2 u) {  // :138-155
     float r, theta;
     if (pabs(uo.x) > pabs(uo.y)) { r = uo.x; theta = kPiOver4 * (uo.y / uo.x); }
     else { r = uo.y; theta = kPiOver2 - kPiOver4 * (uo.x / uo.y); }
-    return mk2(r * d_cos(theta), r * d_sin(theta));
+    float sn, cs;
+    d_sincos(theta, sn, cs);
+    return mk2(r * cs, r * sn);
 }
 PH_DEV f3 cosine_sample_hemisphere(f2 u) {  // :207-211
     f2 d = concentric_sample_disk(u);
@@ -409,7 +412,9 @@ PH_DEV LiSample light_sample_li(const DeviceScene& sc, const LightRec& l, const 
         float map_pdf = pdf0 * pdf1;
         if (map_pdf == 0.0f) return r;
         float theta = d1 * kPi, phi = d0 * kTwoPi;
-        float cos_theta = d_cos(theta), sin_theta = d_sin(theta), sin_phi_ = d_sin(phi), cos_phi_ = d_cos(phi);
+        float cos_theta, sin_theta, sin_phi_, cos_phi_;
+        d_sincos(theta, sin_theta, cos_theta);
+        d_sincos(phi, sin_phi_, cos_phi_);
         r.wi = xf_vec(l.l2w, mk3(sin_theta * cos_phi_, sin_theta * sin_phi_, cos_theta));
         r.pdf = map_pdf / (kTwoPi * kPi * sin_theta);
         if (sin_theta == 0.0f) r.pdf = 0.0f;

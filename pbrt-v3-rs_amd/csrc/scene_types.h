@@ -127,6 +127,7 @@ struct DeviceScene {
     const uint16_t* halton_perms;
     const uint32_t* primes;       // 1000
     const uint32_t* prime_sums;   // 1000
+    const uint64_t* prime_magic;  // 1000: ceil(2^64/p), exact u32 division by multiply-high
     const uint32_t* sobol32;
     const uint64_t* vdc;
     const uint64_t* vdc_inv;

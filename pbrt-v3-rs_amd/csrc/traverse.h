@@ -28,7 +28,7 @@ struct alignas(16) HitOut { float t; uint32_t prim; float b0, b1, b2; uint32_t p
 #define PH_TRAV_BLOCK 256
 #endif
 #ifndef PH_LDS_DEPTH
-#define PH_LDS_DEPTH 16
+#define PH_LDS_DEPTH 12
 #endif
 #define PH_MAX_STACK 64  // the reference's nodes_to_visit[64] (bvh/mod.rs:185)
 
@@ -41,6 +41,7 @@ struct TravParams {
     uint2* spill;           // [PH_MAX_STACK - PH_LDS_DEPTH][total_threads]
     uint32_t total_threads;
     uint32_t* error_flag;   // set to 1 on stack overflow (the reference would panic on index 64)
+    uint32_t batch;         // rays a wave claims per global atomic
     unsigned long long* counts;  // COUNT builds only: [0] interior nodes whose box test passed, [1] triangle tests, [2] rays
 };
 
@@ -131,9 +132,25 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
 // COUNT = true adds per-ray work counters (roofline bookkeeping, never used in a timed run).  For closest-hit rays the
 // reference's "nodes visited" is exactly 1 + 2 * (interior nodes whose box test passed): it fetches and tests both children
 // of every such node (the far one when it is popped), and nothing else.
-template <bool ANYHIT, bool COUNT = false>
+//
+// Loop shape (wave64): ONE loop, every lane advances its own ray by at most one interior-node step per iteration; lanes that
+// have reached a leaf wait until at least PH_LEAF_MIN lanes are at leaves (or no lane has node work left), then all of them
+// test ONE triangle each.  A nested "all lanes walk until everybody is at a leaf" (while-while) loop measured 15 % VALU lane
+// utilisation on incoherent rays at wave64 (profiles/r01_v1_*); this shape keeps the node code at >80 % and only runs the leaf
+// code when a quarter of the wave needs it.  Finished lanes are refilled from a wave-local batch of PH_BATCH consecutive rays
+// (one global atomic per batch, not per refill).
+#ifndef PH_LEAF_MIN
+#define PH_LEAF_MIN 20
+#endif
+#ifndef PH_REFILL_MIN
+#define PH_REFILL_MIN 12
+#endif
+#ifndef PH_BATCH
+#define PH_BATCH 64
+#endif
+template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc, TravParams p) {
-    __shared__ uint2 lds_stack[PH_LDS_DEPTH][PH_TRAV_BLOCK];
+    __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * PH_TRAV_BLOCK + tid;
@@ -141,10 +158,11 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
     const uint32_t n_rays = p.n_ptr ? *p.n_ptr : p.n;
 
     bool has_ray = false;
-    bool exhausted = false;  // wave-uniform
+    uint32_t batch_next = 0, batch_end = 0;  // wave-uniform
+    bool exhausted = false;                  // wave-uniform: the global queue has nothing left
     uint32_t ray_index = 0;
     RayState r;
-    uint32_t cur = PH_INVALID_REF;
+    uint32_t cur = PH_INVALID_REF;           // interior node index, or PH_LEAF_BIT | index of the NEXT TriRec to test
     int sp = 0;
     uint32_t hit_prim = 0xFFFFFFFFu;
     float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
@@ -153,8 +171,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
 
     auto push = [&](uint32_t ref, float tmin) {
         uint2 e = make_uint2(ref, __float_as_uint(tmin));
-        if (sp < PH_LDS_DEPTH) lds_stack[sp][tid] = e;
-        else if (sp < PH_MAX_STACK) p.spill[(size_t)(sp - PH_LDS_DEPTH) * p.total_threads + gtid] = e;
+        if (sp < LDS_DEPTH) lds_stack[sp][tid] = e;
+        else if (sp < PH_MAX_STACK) p.spill[(size_t)(sp - LDS_DEPTH) * p.total_threads + gtid] = e;
         else { *p.error_flag = 1u; return; }
         sp++;
     };
@@ -162,26 +180,31 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
             sp--;
-            uint2 e = (sp < PH_LDS_DEPTH) ? lds_stack[sp][tid] : p.spill[(size_t)(sp - PH_LDS_DEPTH) * p.total_threads + gtid];
+            uint2 e = (sp < LDS_DEPTH) ? lds_stack[sp][tid] : p.spill[(size_t)(sp - LDS_DEPTH) * p.total_threads + gtid];
             if (__uint_as_float(e.y) < r.t_max) return e.x;
         }
         return PH_INVALID_REF;
     };
 
     for (;;) {
-        // ---- refill: idle lanes take the next rays of the queue (one atomic per wave) --------------------------------
-        if (!exhausted) {
+        // ---- refill idle lanes from the wave's batch; grab a new batch with one atomic when it runs dry ---------------------------
+        {
             const uint64_t idle = __ballot(!has_ray);
-            if (idle != 0ull) {
-                const uint32_t cnt = (uint32_t)__popcll(idle);
-                uint32_t base = 0;
-                if (lane == (uint32_t)(__ffsll((long long)idle) - 1)) base = atomicAdd(p.counter, cnt);
-                base = __shfl(base, __ffsll((long long)idle) - 1);
-                if (!has_ray) {
-                    const uint32_t my = base + (uint32_t)__popcll(idle & lane_lt);
-                    if (my < n_rays) {
-                        ray_index = my;
-                        const float4* rp = reinterpret_cast<const float4*>(p.rays + my);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (n_idle >= (uint32_t)REFILL_MIN || n_idle == 64u || (n_idle && __ballot(has_ray && cur != PH_INVALID_REF) == 0ull)) {
+                if (batch_next == batch_end && !exhausted) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(p.counter, p.batch);
+                    b = __shfl(b, 0);
+                    if (b >= n_rays) exhausted = true;
+                    else { batch_next = b; batch_end = (b + p.batch < n_rays) ? b + p.batch : n_rays; }
+                }
+                const uint32_t avail = batch_end - batch_next;
+                if (avail) {
+                    const uint32_t rank = (uint32_t)__popcll(idle & lane_lt);
+                    if (!has_ray && rank < avail) {
+                        ray_index = batch_next + rank;
+                        const float4* rp = reinterpret_cast<const float4*>(p.rays + ray_index);
                         const float4 a = rp[0], b = rp[1];
                         RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = a.w; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
                         ray_setup(r, in);
@@ -196,75 +219,80 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                             if (h && tmin < r.t_max) cur = sc.root_ref;
                         }
                     }
+                    batch_next += (n_idle < avail) ? n_idle : avail;
                 }
-                if (base + cnt >= n_rays) exhausted = true;
             }
         }
-        if (__ballot(has_ray) == 0ull) break;
+        if (__ballot(has_ray) == 0ull) {
+            if (exhausted && batch_next == batch_end) break;
+            continue;
+        }
 
-        // ---- traversal: while-while, bounded so that finished lanes get refilled ------------------------------------------
-        if (has_ray) {
-            int budget = 48;
-            while (cur != PH_INVALID_REF && budget > 0) {
-                // interior nodes
-                while (cur != PH_INVALID_REF && !(cur & PH_LEAF_BIT)) {
-                    const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
-                    const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-                    const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
-                    if (COUNT) c_nodes++;
-                    // q0 = x0[0],x0[1],y0[0],y0[1]; q1 = z0[0],z0[1],x1[0],x1[1]; q2 = y1[0],y1[1],z1[0],z1[1]
-                    float t0, t1;
-                    bool h0 = box_test(r, r.nx ? q0.y : q0.x, r.nx ? q0.x : q0.y, r.ny ? q0.w : q0.z, r.ny ? q0.z : q0.w,
-                                       r.nz ? q1.y : q1.x, r.nz ? q1.x : q1.y, t0);
-                    bool h1 = box_test(r, r.nx ? q1.w : q1.z, r.nx ? q1.z : q1.w, r.ny ? q2.y : q2.x, r.ny ? q2.x : q2.y,
-                                       r.nz ? q2.w : q2.z, r.nz ? q2.z : q2.w, t1);
-                    h0 = h0 && (t0 < r.t_max);
-                    h1 = h1 && (t1 < r.t_max);
-                    const int neg_axis = q3.z == 0 ? r.nx : (q3.z == 1 ? r.ny : r.nz);
-                    // bvh/mod.rs:206-214: dir_is_neg[axis] -> second child first
-                    const uint32_t near_ref = neg_axis ? q3.y : q3.x, far_ref = neg_axis ? q3.x : q3.y;
-                    const bool near_hit = neg_axis ? h1 : h0, far_hit = neg_axis ? h0 : h1;
-                    const float far_t = neg_axis ? t0 : t1;
-                    if (near_hit) { cur = near_ref; if (far_hit) push(far_ref, far_t); }
-                    else if (far_hit) cur = far_ref;
-                    else cur = pop();
-                    budget--;
-                }
-                // leaf
-                if (cur != PH_INVALID_REF) {
-                    uint32_t ti = cur & ~PH_LEAF_BIT;
-                    bool last = false;
-                    while (!last) {
+        // ---- one interior-node step for every lane that is at an interior node -------------------------------------------------------
+        if (has_ray && cur != PH_INVALID_REF && !(cur & PH_LEAF_BIT)) {
+            const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+            const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
+            if (COUNT) c_nodes++;
+            // q0 = x0[0],x0[1],y0[0],y0[1]; q1 = z0[0],z0[1],x1[0],x1[1]; q2 = y1[0],y1[1],z1[0],z1[1]
+            float t0, t1;
+            bool h0 = box_test(r, r.nx ? q0.y : q0.x, r.nx ? q0.x : q0.y, r.ny ? q0.w : q0.z, r.ny ? q0.z : q0.w,
+                               r.nz ? q1.y : q1.x, r.nz ? q1.x : q1.y, t0);
+            bool h1 = box_test(r, r.nx ? q1.w : q1.z, r.nx ? q1.z : q1.w, r.ny ? q2.y : q2.x, r.ny ? q2.x : q2.y,
+                               r.nz ? q2.w : q2.z, r.nz ? q2.z : q2.w, t1);
+            h0 = h0 && (t0 < r.t_max);
+            h1 = h1 && (t1 < r.t_max);
+            const int neg_axis = q3.z == 0 ? r.nx : (q3.z == 1 ? r.ny : r.nz);
+            // bvh/mod.rs:206-214: dir_is_neg[axis] -> second child first
+            const uint32_t near_ref = neg_axis ? q3.y : q3.x, far_ref = neg_axis ? q3.x : q3.y;
+            const bool near_hit = neg_axis ? h1 : h0, far_hit = neg_axis ? h0 : h1;
+            const float far_t = neg_axis ? t0 : t1;
+            if (near_hit) { cur = near_ref; if (far_hit) push(far_ref, far_t); }
+            else if (far_hit) cur = far_ref;
+            else cur = pop();
+        }
+
+        // ---- leaf work: one triangle per lane, once enough lanes are waiting at leaves ----------------------------------------------------
+        {
+            const bool at_leaf = has_ray && cur != PH_INVALID_REF && (cur & PH_LEAF_BIT);
+            const uint64_t lm = __ballot(at_leaf);
+            if (lm != 0ull) {
+                const uint64_t nm = __ballot(has_ray && cur != PH_INVALID_REF && !(cur & PH_LEAF_BIT));
+                if ((uint32_t)__popcll(lm) >= (uint32_t)LEAF_MIN || nm == 0ull) {
+                    if (at_leaf) {
+                        const uint32_t ti = cur & ~PH_LEAF_BIT;
                         const float4* tp = reinterpret_cast<const float4*>(sc.tris + ti);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
                         const uint32_t flags = __float_as_uint(b.w);
-                        last = (flags & PH_TRI_LAST) != 0;
+                        bool last = (flags & PH_TRI_LAST) != 0;
                         float t, b0, b1, b2;
                         if (COUNT) c_tris++;
                         if (tri_test(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), t, b0, b1, b2)) {
                             // post-t rejections: degenerate triangle (triangle.rs:567-570 / 862-866), alpha == 0 (:603 / :886-893)
                             const uint32_t reject = ANYHIT ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
                             if (!(flags & reject)) {
-                                if (ANYHIT) { occluded = true; last = true; }
+                                if (ANYHIT) occluded = true;
                                 else { r.t_max = t; hit_prim = __float_as_uint(a.w); hb0 = b0; hb1 = b1; hb2 = b2; }
                             }
                         }
-                        ti++;
+                        if (ANYHIT && occluded) cur = PH_INVALID_REF;
+                        else if (last) cur = pop();
+                        else cur = cur + 1u;
                     }
-                    cur = (ANYHIT && occluded) ? PH_INVALID_REF : pop();
-                    budget--;
                 }
             }
-            if (cur == PH_INVALID_REF) {
-                if (ANYHIT) reinterpret_cast<uint8_t*>(p.out)[ray_index] = occluded ? 1 : 0;
-                else {
-                    float4* hp = reinterpret_cast<float4*>(reinterpret_cast<HitOut*>(p.out) + ray_index);
-                    hp[0] = make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1);
-                    hp[1] = make_float4(hb2, 0.0f, 0.0f, 0.0f);
-                }
-                has_ray = false;
-                if (COUNT) c_rays++;
+        }
+
+        // ---- retire finished rays --------------------------------------------------------------------------------------------------------
+        if (has_ray && cur == PH_INVALID_REF) {
+            if (ANYHIT) reinterpret_cast<uint8_t*>(p.out)[ray_index] = occluded ? 1 : 0;
+            else {
+                float4* hp = reinterpret_cast<float4*>(reinterpret_cast<HitOut*>(p.out) + ray_index);
+                hp[0] = make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1);
+                hp[1] = make_float4(hb2, 0.0f, 0.0f, 0.0f);
             }
+            has_ray = false;
+            if (COUNT) c_rays++;
         }
     }
     if (COUNT) {

@@ -44,6 +44,7 @@ struct WfParams {
     uint32_t n_px;          // pixels in this rank's tiles
     uint32_t chunk_spp, s0; // samples [s0, s0+chunk_spp) of every pixel in this chunk
     uint32_t B;             // n_px * chunk_spp
+    uint32_t identity_slots; // every pixel of the rank's tiles lies inside pixel_bounds
     // pixel list
     const int2* px_xy;
     // queues
@@ -112,68 +113,76 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
             w.rec_py[gsi] = 0.0f;
         }
     }
-    const uint32_t slot = wave_alloc(&w.ctr[0].n_cl, active);
-    const uint32_t lslot = wave_alloc(&w.ctr[0].n_live, active);
+    // common case (pixel_bounds covers the tiles): slot = pid, counters preset by the host -> no atomics at all
+    const uint32_t slot = w.identity_slots ? pid : wave_alloc(&w.ctr[0].n_cl, active);
+    const uint32_t lslot = w.identity_slots ? pid : wave_alloc(&w.ctr[0].n_live, active);
     if (active) {
         store_ray(w.rays_cl[0] + slot, ray);
         w.live[0][lslot] = pid;
         w.s_idx[pid] = make_uint4(slot, 0u, 0u, F_EXT | (0u << 8) | (5u << 16));  // bounces 0, next sampler dimension 5
-        atomicAdd(&w.stats->camera_rays, 1ull);
+        if (!w.identity_slots) atomicAdd(&w.stats->camera_rays, 1ull);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// K4 (+K6): one thread per live path
-__global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, WfParams w, int it) {
+// K4 (+K6): one thread per live path.
+// Queue appends are aggregated per BLOCK: rays are staged in LDS the moment they are known (which keeps them out of the
+// register file during the long vertex computation), then one thread per queue claims the block's slots with a single
+// atomic and every thread copies its rays to consecutive slots.  Per-wave atomics on the three queue counters were the
+// limiter of the first version (≈3 M returning atomics per frame on three addresses; one address sustains ≈88 per µs).
+#define PH_SHADE_BLOCK 256
+__global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, WfParams w, int it) {
+    __shared__ float4 stage[3][2][PH_SHADE_BLOCK];           // [ext, mis, shadow][ray halves][thread]
+    __shared__ uint32_t wave_cnt[3][PH_SHADE_BLOCK / 64];   // [cl, sh, live][wave]
+    __shared__ uint32_t q_base[3];
     const uint32_t n_live = w.ctr[it].n_live;
     const RayIn* rays_in = w.rays_cl[it & 1];
     RayIn* rays_out = w.rays_cl[(it + 1) & 1];
     const uint32_t* live_in = w.live[it & 1];
     uint32_t* live_out = w.live[(it + 1) & 1];
     IterCounters* next = w.ctr + it + 1;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     for (uint32_t base = blockIdx.x * blockDim.x; base < n_live; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + threadIdx.x;
+        const uint32_t i = base + tid;
         const bool active = i < n_live;
-        bool want_ext = false, want_mis = false, want_sh = false, still_live = false;
-        RayIn ray_ext, ray_mis, ray_sh;
         uint32_t pid = 0, flags = 0, bounces = 0, dim = 0;
-        uint4 idx4 = make_uint4(0, 0, 0, 0);
         spec L = mks1(0.0f), beta = mks1(1.0f);
-        float4 pA = make_float4(0, 0, 0, 0), pF2 = make_float4(0, 0, 0, 0), pBold = make_float4(0, 0, 0, 0);
-        float pick_pdf = 0.0f, w2 = 0.0f;
-        bool new_pending = false;
+        float pick_pdf = 0.0f;
+        bool want_ext = false, want_mis = false, want_sh = false;
 
         if (active) {
             pid = live_in[i];
-            idx4 = w.s_idx[pid];
+            const uint4 idx4 = w.s_idx[pid];
             flags = idx4.w & 0xffu; bounces = (idx4.w >> 8) & 0xffu; dim = idx4.w >> 16;
             const float4 L4 = w.s_L[pid], b4 = w.s_beta[pid];
             L = mks(L4.x, L4.y, L4.z); beta = mks(b4.x, b4.y, b4.z);
 
-            // ---- K6: finish uniform_sample_one_light of the previous vertex (integrator/common.rs:196-221, 276-295, 132) ----
+            // ---- K6: finish uniform_sample_one_light of the previous vertex (integrator/common.rs:196-221, 276-295, 132) --------
             if (flags & (F_PSH | F_PMIS)) {
-                const float4 A4 = w.s_A[pid], F4 = w.s_f2[pid], O4 = w.s_bold[pid];
+                const float4 A4 = w.s_A[pid], O4 = w.s_bold[pid];
                 spec est = mks1(0.0f);
                 if (flags & F_PSH) {
                     if (!w.occ[idx4.z]) est = est + mks(A4.x, A4.y, A4.z);
                 }
                 if (flags & F_PMIS) {
+                    const float4 F4 = w.s_f2[pid];
                     const uint32_t light_num = __float_as_uint(F4.w);
-                    const LightRec light = sc.lights[light_num];
                     const RayIn mr = load_ray(rays_in + idx4.y);
                     const float4* hp = reinterpret_cast<const float4*>(w.hits_cl + idx4.y);
-                    const float4 h0 = hp[0], h1 = hp[1];
+                    const float4 h0 = hp[0];
                     const uint32_t hprim = __float_as_uint(h0.y);
                     const f3 wi = mk3(mr.dx, mr.dy, mr.dz);
                     spec li2 = mks1(0.0f);
                     if (hprim != 0xFFFFFFFFu) {
                         const MeshRec m = sc.meshes[sc.tri_mesh[hprim]];
                         if (m.first_light >= 0 && (uint32_t)m.first_light + (hprim - m.tri_base) == light_num) {
+                            const float4 h1 = hp[1];
                             SurfHit lh = make_surface_hit(sc, wi, mr.time, hprim, h0.z, h0.w, h1.x);
-                            li2 = area_L(light, lh.n, -wi);  // SurfaceInteraction::le (surface_interaction.rs:283-289)
+                            li2 = area_L(sc.lights[light_num], lh.n, -wi);  // SurfaceInteraction::le (surface_interaction.rs:283-289)
                         }
-                    } else li2 = light_le(light, wi);
+                    } else li2 = light_le(sc.lights[light_num], wi);
                     if (!is_black(li2)) est = est + mks(F4.x, F4.y, F4.z) * li2 * mks1(1.0f) * A4.w / O4.w;  // f*li*tr*weight/scattering_pdf
                 }
                 const spec ldv = mks(O4.x, O4.y, O4.z) * (est / L4.w);  // beta * (estimate / light_pdf)  (path.rs:165)
@@ -182,130 +191,155 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, WfParams w, 
                 flags &= ~(F_PSH | F_PMIS);
             }
 
-            // ---- the new vertex: body of li's loop (path.rs:116-279) -----------------------------------------------------
+            // ---- the new vertex: body of li's loop (path.rs:116-279) ---------------------------------------------------------------
             if (flags & F_EXT) {
                 flags &= ~F_EXT;
                 const RayIn ray = load_ray(rays_in + idx4.x);
                 const float4* hp = reinterpret_cast<const float4*>(w.hits_cl + idx4.x);
-                const float4 h0 = hp[0], h1 = hp[1];
+                const float4 h0 = hp[0];
                 const uint32_t hprim = __float_as_uint(h0.y);
                 const bool found = hprim != 0xFFFFFFFFu;
                 const f3 rd = mk3(ray.dx, ray.dy, ray.dz);
-                SurfHit si;
-                if (found) si = make_surface_hit(sc, rd, ray.time, hprim, h0.z, h0.w, h1.x);
-                if (bounces == 0) {  // `|| specular_bounce`: no specular lobes among matte materials
-                    if (found) {
-                        const MeshRec m = sc.meshes[sc.tri_mesh[hprim]];
-                        spec le = mks1(0.0f);
-                        if (m.first_light >= 0) le = area_L(sc.lights[(uint32_t)m.first_light + (hprim - m.tri_base)], si.n, -rd);
-                        L = L + beta * le;
-                    } else {
+                if (!found) {
+                    if (bounces == 0)  // `|| specular_bounce`: no specular lobes among matte materials
                         for (uint32_t k = 0; k < sc.n_infinite; k++) L = L + beta * light_le(sc.lights[sc.infinite_lights[k]], rd);
+                } else {
+                    const float4 h1 = hp[1];
+                    const SurfHit si = make_surface_hit(sc, rd, ray.time, hprim, h0.z, h0.w, h1.x);
+                    if (bounces == 0) {
+                        const MeshRec m = sc.meshes[sc.tri_mesh[hprim]];
+                        if (m.first_light >= 0) L = L + beta * area_L(sc.lights[(uint32_t)m.first_light + (hprim - m.tri_base)], si.n, -rd);
+                        else L = L + beta * mks1(0.0f);
                     }
-                }
-                if (found && (int)bounces < w.max_depth) {
-                    const Bsdf bsdf = make_bsdf(sc, si);
-                    const int2 xy = w.px_xy[pid / w.chunk_spp];
-                    SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid % w.chunk_spp), dim);
-                    if (bsdf.has_bxdf) {  // num_components(all & !SPECULAR) > 0 (path.rs:161-172)
-                        atomicAdd(&w.stats->paths_total, 1ull);
-                        // uniform_sample_one_light (integrator/common.rs:89-133)
-                        if (sc.n_lights > 0) {
-                            const float sample = get_1d(sc, w.sp, cur);
-                            const uint32_t light_num = find_interval_cdf(sc.ld_cdf, sc.n_lights + 1, sample);  // sample_discrete
-                            pick_pdf = sc.ld_func_int > 0.0f ? sc.ld_func[light_num] / (sc.ld_func_int * (float)sc.n_lights) : 0.0f;
-                            if (pick_pdf != 0.0f) {
-                                const LightRec light = sc.lights[light_num];
-                                const f2 u_light = get_2d(sc, w.sp, cur), u_scatter = get_2d(sc, w.sp, cur);
-                                // estimate_direct (integrator/common.rs:146-299), specular = false, handle_media = false
-                                const LiSample ls = light_sample_li(sc, light, si, u_light);
-                                const bool is_delta = light.type == PH_L_DISTANT || light.type == PH_L_POINT;
-                                if (ls.valid && ls.pdf > 0.0f && !is_black(ls.value)) {
-                                    const spec f = bsdf_f(bsdf, si.wo, ls.wi) * abs_dot(ls.wi, si.ns);
-                                    const float scattering_pdf = bsdf_pdf(bsdf, si.wo, ls.wi);
-                                    if (!is_black(f)) {
-                                        ray_sh = spawn_ray_to_hit(si, ls.vp, ls.vperr, ls.vn);  // VisibilityTester::unoccluded
-                                        want_sh = true;
-                                        spec A;
-                                        if (is_delta) A = f * ls.value / ls.pdf;
-                                        else A = f * ls.value * power_heuristic1(ls.pdf, scattering_pdf) / ls.pdf;
-                                        pA.x = A.r; pA.y = A.g; pA.z = A.b;
-                                        flags |= F_PSH;
-                                    }
-                                }
-                                if (!is_delta) {
-                                    spec f1; float spdf; f3 wi2;
-                                    bsdf_sample_f(bsdf, si.wo, u_scatter, f1, spdf, wi2);
-                                    const spec f = f1 * abs_dot(wi2, si.ns);
-                                    if (!is_black(f) && spdf > 0.0f) {
-                                        const float lp = light_pdf_li(sc, light, si, wi2);
-                                        if (lp != 0.0f) {  // lp == 0 -> `return ld` with the light-sampling part only
-                                            w2 = power_heuristic1(spdf, lp);
-                                            ray_mis = spawn_ray(si, wi2);
-                                            want_mis = true;
-                                            pF2 = make_float4(f.r, f.g, f.b, __uint_as_float(light_num));
-                                            pBold.w = spdf;
-                                            flags |= F_PMIS;
+                    if ((int)bounces < w.max_depth) {
+                        const Bsdf bsdf = make_bsdf(sc, si);
+                        const int2 xy = w.px_xy[pid / w.chunk_spp];
+                        SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid % w.chunk_spp), dim);
+                        if (bsdf.has_bxdf) {  // num_components(all & !SPECULAR) > 0 (path.rs:161-172)
+                            atomicAdd(&w.stats->paths_total, 1ull);
+                            // uniform_sample_one_light (integrator/common.rs:89-133)
+                            if (sc.n_lights > 0) {
+                                const float sample = get_1d(sc, w.sp, cur);
+                                const uint32_t light_num = find_interval_cdf(sc.ld_cdf, sc.n_lights + 1, sample);  // sample_discrete
+                                pick_pdf = sc.ld_func_int > 0.0f ? sc.ld_func[light_num] / (sc.ld_func_int * (float)sc.n_lights) : 0.0f;
+                                if (pick_pdf != 0.0f) {
+                                    const LightRec& light = sc.lights[light_num];
+                                    const f2 u_light = get_2d(sc, w.sp, cur), u_scatter = get_2d(sc, w.sp, cur);
+                                    const bool is_delta = light.type == PH_L_DISTANT || light.type == PH_L_POINT;
+                                    float w2 = 0.0f, spdf_store = 0.0f;
+                                    spec A = mks1(0.0f);
+                                    // estimate_direct (integrator/common.rs:146-299), specular = false, handle_media = false
+                                    {
+                                        const LiSample ls = light_sample_li(sc, light, si, u_light);
+                                        if (ls.valid && ls.pdf > 0.0f && !is_black(ls.value)) {
+                                            const spec f = bsdf_f(bsdf, si.wo, ls.wi) * abs_dot(ls.wi, si.ns);
+                                            const float scattering_pdf = bsdf_pdf(bsdf, si.wo, ls.wi);
+                                            if (!is_black(f)) {
+                                                const RayIn rs = spawn_ray_to_hit(si, ls.vp, ls.vperr, ls.vn);  // VisibilityTester::unoccluded
+                                                stage[2][0][tid] = make_float4(rs.ox, rs.oy, rs.oz, rs.t_max);
+                                                stage[2][1][tid] = make_float4(rs.dx, rs.dy, rs.dz, rs.time);
+                                                want_sh = true;
+                                                if (is_delta) A = f * ls.value / ls.pdf;
+                                                else A = f * ls.value * power_heuristic1(ls.pdf, scattering_pdf) / ls.pdf;
+                                                flags |= F_PSH;
+                                            }
                                         }
                                     }
+                                    if (!is_delta) {
+                                        spec f1; float spdf; f3 wi2;
+                                        bsdf_sample_f(bsdf, si.wo, u_scatter, f1, spdf, wi2);
+                                        const spec f = f1 * abs_dot(wi2, si.ns);
+                                        if (!is_black(f) && spdf > 0.0f) {
+                                            const float lp = light_pdf_li(sc, light, si, wi2);
+                                            if (lp != 0.0f) {  // lp == 0 -> `return ld` with the light-sampling part only
+                                                w2 = power_heuristic1(spdf, lp);
+                                                spdf_store = spdf;
+                                                const RayIn rm = spawn_ray(si, wi2);
+                                                stage[1][0][tid] = make_float4(rm.ox, rm.oy, rm.oz, rm.t_max);
+                                                stage[1][1][tid] = make_float4(rm.dx, rm.dy, rm.dz, rm.time);
+                                                want_mis = true;
+                                                w.s_f2[pid] = make_float4(f.r, f.g, f.b, __uint_as_float(light_num));
+                                                flags |= F_PMIS;
+                                            }
+                                        }
+                                    }
+                                    if (flags & (F_PSH | F_PMIS)) {
+                                        w.s_A[pid] = make_float4(A.r, A.g, A.b, w2);
+                                        w.s_bold[pid] = make_float4(beta.r, beta.g, beta.b, spdf_store);
+                                    }
                                 }
-                                if (flags & (F_PSH | F_PMIS)) { new_pending = true; pBold.x = beta.r; pBold.y = beta.g; pBold.z = beta.b; pA.w = w2; }
+                            }
+                            if (!(flags & (F_PSH | F_PMIS))) atomicAdd(&w.stats->paths_zero, 1ull);  // ld is black
+                        }
+                        // sample the BSDF for the next direction (path.rs:174-206)
+                        const f2 u = get_2d(sc, w.sp, cur);
+                        spec f; float pdf; f3 wi;
+                        bsdf_sample_f(bsdf, -rd, u, f, pdf, wi);
+                        if (!(is_black(f) || pdf == 0.0f)) {
+                            beta = beta * (f * abs_dot(wi, si.ns) / pdf);
+                            const RayIn re = spawn_ray(si, wi);
+                            bool cont = true;
+                            const spec rr_beta = beta * 1.0f;  // eta_scale stays 1 without specular transmission
+                            if (max_component_value(rr_beta) < w.rr_threshold && bounces > 3) {  // path.rs:264-276
+                                const float q = pmaxf(0.05f, 1.0f - max_component_value(rr_beta));
+                                if (get_1d(sc, w.sp, cur) < q) cont = false;
+                                else beta = beta / (1.0f - q);
+                            }
+                            if (cont) {
+                                bounces += 1; flags |= F_EXT; want_ext = true;
+                                stage[0][0][tid] = make_float4(re.ox, re.oy, re.oz, re.t_max);
+                                stage[0][1][tid] = make_float4(re.dx, re.dy, re.dz, re.time);
                             }
                         }
-                        if (!new_pending) atomicAdd(&w.stats->paths_zero, 1ull);  // ld is black
+                        dim = cur.dim;
                     }
-                    // sample the BSDF for the next direction (path.rs:174-206)
-                    const f2 u = get_2d(sc, w.sp, cur);
-                    spec f; float pdf; f3 wi;
-                    bsdf_sample_f(bsdf, -rd, u, f, pdf, wi);
-                    if (!(is_black(f) || pdf == 0.0f)) {
-                        beta = beta * (f * abs_dot(wi, si.ns) / pdf);
-                        ray_ext = spawn_ray(si, wi);
-                        bool cont = true;
-                        const spec rr_beta = beta * 1.0f;  // eta_scale stays 1 without specular transmission
-                        if (max_component_value(rr_beta) < w.rr_threshold && bounces > 3) {  // path.rs:264-276
-                            const float q = pmaxf(0.05f, 1.0f - max_component_value(rr_beta));
-                            if (get_1d(sc, w.sp, cur) < q) cont = false;
-                            else beta = beta / (1.0f - q);
-                        }
-                        if (cont) { bounces += 1; want_ext = true; flags |= F_EXT; }
-                    }
-                    dim = cur.dim;
                 }
             }
-            still_live = (flags & (F_EXT | F_PSH | F_PMIS)) != 0;
         }
+        const bool still_live = active && (flags & (F_EXT | F_PSH | F_PMIS)) != 0;
 
-        // ---- queue appends: one atomic per wave and queue --------------------------------------------------------------------
-        const uint32_t n_cl = (want_ext ? 1u : 0u) + (want_mis ? 1u : 0u);
-        uint32_t cl_slot;
-        {   // two-slot allocation with a single atomic: exclusive prefix over lanes of n_cl
-            const uint64_t m1 = __ballot(want_ext), m2 = __ballot(want_mis);
-            const uint32_t lane = threadIdx.x & 63u;
-            const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            const uint32_t total = (uint32_t)(__popcll(m1) + __popcll(m2));
-            uint32_t b = 0;
-            if (total) {
-                if (lane == 0) b = atomicAdd(&next->n_cl, total);
-                b = __shfl(b, 0);
-            }
-            cl_slot = b + (uint32_t)(__popcll(m1 & lt) + __popcll(m2 & lt));
+        // ---- block-aggregated queue appends --------------------------------------------------------------------------------------------
+        const uint64_t m_ext = __ballot(want_ext), m_mis = __ballot(want_mis), m_sh = __ballot(want_sh), m_lv = __ballot(still_live);
+        if (lane == 0) {
+            wave_cnt[0][wid] = (uint32_t)(__popcll(m_ext) + __popcll(m_mis));
+            wave_cnt[1][wid] = (uint32_t)__popcll(m_sh);
+            wave_cnt[2][wid] = (uint32_t)__popcll(m_lv);
         }
-        const uint32_t sh_slot = wave_alloc(&next->n_sh, want_sh);
-        const uint32_t lv_slot = wave_alloc(&next->n_live, still_live);
-        (void)n_cl;
+        __syncthreads();
+        if (tid < 3) {
+            uint32_t tot = 0;
+            for (uint32_t k = 0; k < PH_SHADE_BLOCK / 64; k++) tot += wave_cnt[tid][k];
+            uint32_t* ctr = tid == 0 ? &next->n_cl : (tid == 1 ? &next->n_sh : &next->n_live);
+            q_base[tid] = tot ? atomicAdd(ctr, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t cl_slot = q_base[0], sh_slot = q_base[1], lv_slot = q_base[2];
+        for (uint32_t k = 0; k < wid; k++) { cl_slot += wave_cnt[0][k]; sh_slot += wave_cnt[1][k]; lv_slot += wave_cnt[2][k]; }
+        cl_slot += (uint32_t)(__popcll(m_ext & lane_lt) + __popcll(m_mis & lane_lt));
+        sh_slot += (uint32_t)__popcll(m_sh & lane_lt);
+        lv_slot += (uint32_t)__popcll(m_lv & lane_lt);
 
         if (active) {
             uint32_t ext_slot = 0, mis_slot = 0;
-            if (want_ext) { ext_slot = cl_slot; store_ray(rays_out + ext_slot, ray_ext); }
-            if (want_mis) { mis_slot = cl_slot + (want_ext ? 1u : 0u); store_ray(rays_out + mis_slot, ray_mis); }
-            if (want_sh) store_ray(w.rays_sh + sh_slot, ray_sh);
+            if (want_ext) {
+                ext_slot = cl_slot;
+                float4* d = reinterpret_cast<float4*>(rays_out + ext_slot);
+                d[0] = stage[0][0][tid]; d[1] = stage[0][1][tid];
+            }
+            if (want_mis) {
+                mis_slot = cl_slot + (want_ext ? 1u : 0u);
+                float4* d = reinterpret_cast<float4*>(rays_out + mis_slot);
+                d[0] = stage[1][0][tid]; d[1] = stage[1][1][tid];
+            }
+            if (want_sh) {
+                float4* d = reinterpret_cast<float4*>(w.rays_sh + sh_slot);
+                d[0] = stage[2][0][tid]; d[1] = stage[2][1][tid];
+            }
             if (still_live) {
                 live_out[lv_slot] = pid;
                 w.s_idx[pid] = make_uint4(ext_slot, mis_slot, sh_slot, flags | (bounces << 8) | (dim << 16));
-                w.s_L[pid] = make_float4(L.r, L.g, L.b, new_pending ? pick_pdf : 0.0f);
+                w.s_L[pid] = make_float4(L.r, L.g, L.b, pick_pdf);
                 w.s_beta[pid] = make_float4(beta.r, beta.g, beta.b, 0.0f);
-                if (new_pending) { w.s_A[pid] = pA; w.s_f2[pid] = pF2; w.s_bold[pid] = pBold; }
             } else {
                 // path finished: radiance sanitising of render_tile (sampler_integrator.rs:373-397)
                 if (has_nans(L)) L = mks1(0.0f);
@@ -317,6 +351,7 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, WfParams w, 
                 w.rec_L[gsi] = rec;
             }
         }
+        __syncthreads();  // stage / wave_cnt are reused by the next grid-stride round
     }
 }
 
@@ -344,9 +379,10 @@ __global__ __launch_bounds__(256) void film_tiles_kernel(FilmParams p) {
     if (kx < pw && ky < phh) {
         const int x = t.pb[0] + kx, y = t.pb[1] + ky;
         const float rx = p.film.radius[0], ry = p.film.radius[1];
-        // samples of pixel (sx,sy) land at p in [sx, sx+1): they can touch x only if ceil(p-.5-r) <= x <= floor(p-.5+r)
-        const int sx0 = pmaxi(f2i_sat(ceilf((float)x - 0.5f - rx)) - 1, t.tb[0]), sx1 = pmini(f2i_sat(floorf((float)x + 0.5f + rx)) + 1, t.tb[2] - 1);
-        const int sy0 = pmaxi(f2i_sat(ceilf((float)y - 0.5f - ry)) - 1, t.tb[1]), sy1 = pmini(f2i_sat(floorf((float)y + 0.5f + ry)) + 1, t.tb[3] - 1);
+        // a sample at film position p reaches pixel x iff ceil(p-.5-r) <= x <= floor(p-.5+r), i.e. p in [x+.5-r, x+.5+r]; samples of
+        // pixel sx have p in [sx, sx+1), so only sx in [floor(x+.5-r), floor(x+.5+r)] can contribute (evaluated in f64: exact).
+        const int sx0 = pmaxi((int)floor((double)x + 0.5 - (double)rx), t.tb[0]), sx1 = pmini((int)floor((double)x + 0.5 + (double)rx), t.tb[2] - 1);
+        const int sy0 = pmaxi((int)floor((double)y + 0.5 - (double)ry), t.tb[1]), sy1 = pmini((int)floor((double)y + 0.5 + (double)ry), t.tb[3] - 1);
         const int tw = t.tb[2] - t.tb[0];
         for (int sy = sy0; sy <= sy1; sy++)
             for (int sx = sx0; sx <= sx1; sx++) {
@@ -414,6 +450,11 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeParams p) {
             W += c.w;
         }
     p.out_xyz[3 * gid] = X; p.out_xyz[3 * gid + 1] = Y; p.out_xyz[3 * gid + 2] = Z; p.out_w[gid] = W;
+}
+
+__global__ void preset_counters_kernel(IterCounters* ctr, DevStats* stats, uint32_t n) {
+    ctr[0].n_cl = n; ctr[0].n_live = n;
+    stats->camera_rays += n;
 }
 
 // camera rays only (parity harness for the sampler + camera rows of SURVEY §8a)
@@ -588,6 +629,9 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     wp.rec_L = (float4*)w.d_recL.p; wp.rec_py = (float*)w.d_recpy.p;
 
     PH_CHECK(s, hipMemsetAsync(w.d_stats.p, 0, sizeof(ph::DevStats), s->stream));
+    bool identity = true;  // does pixel_bounds cover every pixel of this rank's tiles?
+    for (const ph::TileInfo& t : w.tiles)
+        if (t.tb[0] < pixel_bounds[0] || t.tb[1] < pixel_bounds[1] || t.tb[2] > pixel_bounds[2] || t.tb[3] > pixel_bounds[3]) { identity = false; break; }
     size_t ev = 0;
     hipEvent_t e_begin = get_event(s, ev++), e_end = get_event(s, ev++);
     if (!e_begin || !e_end) return set_err(s, PBRT_HIP_ERR_DEVICE, "hipEventCreate failed");
@@ -610,8 +654,9 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
 
     for (uint32_t s0 = 0; s0 < spp; s0 += chunk_spp) {
         const uint32_t cs = std::min(chunk_spp, spp - s0);
-        wp.chunk_spp = cs; wp.s0 = s0; wp.B = n_px * cs;
+        wp.chunk_spp = cs; wp.s0 = s0; wp.B = n_px * cs; wp.identity_slots = identity ? 1u : 0u;
         PH_CHECK(s, hipMemsetAsync(w.d_ctr.p, 0, (size_t)(n_iter + 2) * sizeof(ph::IterCounters), s->stream));
+        if (identity) hipLaunchKernelGGL(ph::preset_counters_kernel, dim3(1), dim3(1), 0, s->stream, wp.ctr, wp.stats, wp.B);
         if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::raygen_kernel, dim3((wp.B + 255) / 256), dim3(256), 0, s->stream, s->ds, wp); }))) return rc;
         for (int it = 0; it < n_iter; it++) {
             ph::IterCounters* c = (ph::IterCounters*)w.d_ctr.p + it;
