@@ -66,24 +66,26 @@ PH_DEV void ray_setup(RayState& r, const RayIn& in) {
 }
 
 // Bounds3::intersect_p_inv without its final `t_min < ray.t_max` clause; returns t_min via reference.
-// Quirk B1 (z far plane not widened) is reproduced.
+// Quirk B1 (z far plane not widened) is reproduced.  Written branch-free: the reference's early `return false`s only skip
+// arithmetic whose results are then unused, so evaluating everything and AND-ing the verdicts gives the same answer
+// (NaNs included: every comparison below is the reference's comparison, in the reference's direction).
 PH_DEV bool box_test(const RayState& r, float xn, float xf, float yn, float yf, float zn, float zf, float& t_min_out) {
     float t_min = (xn - r.ox) * r.ix;
     float t_max = (xf - r.ox) * r.ix;
-    float t_y_min = (yn - r.oy) * r.iy;
+    const float t_y_min = (yn - r.oy) * r.iy;
     float t_y_max = (yf - r.oy) * r.iy;
     t_max *= kBoxScale;
     t_y_max *= kBoxScale;
-    if (t_min > t_y_max || t_y_min > t_max) return false;
-    if (t_y_min > t_min) t_min = t_y_min;
-    if (t_y_max < t_max) t_max = t_y_max;
-    float t_z_min = (zn - r.oz) * r.iz;
-    float t_z_max = (zf - r.oz) * r.iz;
-    if (t_min > t_z_max || t_z_min > t_max) return false;
-    if (t_z_min > t_min) t_min = t_z_min;
-    if (t_z_max < t_max) t_max = t_z_max;
+    const bool miss_xy = (t_min > t_y_max) | (t_y_min > t_max);
+    t_min = (t_y_min > t_min) ? t_y_min : t_min;
+    t_max = (t_y_max < t_max) ? t_y_max : t_max;
+    const float t_z_min = (zn - r.oz) * r.iz;
+    const float t_z_max = (zf - r.oz) * r.iz;
+    const bool miss_z = (t_min > t_z_max) | (t_z_min > t_max);
+    t_min = (t_z_min > t_min) ? t_z_min : t_min;
+    t_max = (t_z_max < t_max) ? t_z_max : t_max;
     t_min_out = t_min;
-    return t_max > 0.0f;
+    return !miss_xy & !miss_z & (t_max > 0.0f);
 }
 
 // Triangle::intersect up to `if t <= delta_t` (triangle.rs:441-545).  Returns true when the reference proceeds past it.
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                                r.nz ? q1.y : q1.x, r.nz ? q1.x : q1.y, t0);
             bool h1 = box_test(r, r.nx ? q1.w : q1.z, r.nx ? q1.z : q1.w, r.ny ? q2.y : q2.x, r.ny ? q2.x : q2.y,
                                r.nz ? q2.w : q2.z, r.nz ? q2.z : q2.w, t1);
-            h0 = h0 && (t0 < r.t_max);
-            h1 = h1 && (t1 < r.t_max);
+            h0 = h0 & (t0 < r.t_max);
+            h1 = h1 & (t1 < r.t_max);
             const int neg_axis = q3.z == 0 ? r.nx : (q3.z == 1 ? r.ny : r.nz);
             // bvh/mod.rs:206-214: dir_is_neg[axis] -> second child first
             const uint32_t near_ref = neg_axis ? q3.y : q3.x, far_ref = neg_axis ? q3.x : q3.y;
