@@ -315,8 +315,13 @@ class Scene:
         self._chk(self.b.fn("occluded_batch_device")(self.h, d_rays_ptr, d_out_ptr, n, C.byref(ms)))
         return ms.value
 
+    def _film_hw(self):
+        if self.film_shape is None:
+            raise PbrtHipError(ERR_STATE, "set_film must be called before rendering")
+        return self.film_shape
+
     def render_path(self, max_depth=5, rr_threshold=1.0, light_strategy=2, pixel_bounds=None, tile_size=16, tile_part=0, tile_parts=1):
-        h, w = self.film_shape
+        h, w = self._film_hw()
         xyz = np.zeros((h, w, 3), np.float32); wt = np.zeros((h, w), np.float32)
         pb = np.ascontiguousarray(pixel_bounds if pixel_bounds is not None else self.sample_bounds, dtype=np.int32)
         st = Stats()
@@ -349,7 +354,7 @@ class Scene:
         return st
 
     def merge_tiles_device(self, d_ptrs, tile_size=16):
-        h, w = self.film_shape
+        h, w = self._film_hw()
         xyz = np.zeros((h, w, 3), np.float32); wt = np.zeros((h, w), np.float32)
         arr = (C.c_void_p * len(d_ptrs))(*d_ptrs)
         self._chk(self.b.fn("merge_tiles_device")(self.h, tile_size, len(d_ptrs), arr, _ptr(xyz, C.c_float), _ptr(wt, C.c_float)))

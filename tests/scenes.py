@@ -65,3 +65,46 @@ def hits_equal(a, b):
     for f in ("t", "b0", "b1", "b2"):
         ok &= (a[f].view(np.uint32) == b[f].view(np.uint32))
     return ok
+
+
+def cornell_like(host, with_normals=False, with_uv=False, two_sided=False, sigma=0.0, reverse=False):
+    """A closed-ish box with an emissive quad on the ceiling + a tilted inner quad: exercises DiffuseAreaLight sampling /
+    pdf_solid_angle / Le on hit, Oren-Nayar, optional per-vertex N / UV shading frames and reverse_orientation.
+    Returns a capture(scene) closure."""
+    def quad(a, b, c, d):
+        P = np.array([a, b, c, d], np.float32)
+        return P, np.array([0, 1, 2, 0, 2, 3], np.uint32)
+
+    walls = [
+        quad([-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1]),      # floor
+        quad([-1, -1, 1], [-1, 1, 1], [1, 1, 1], [1, -1, 1]),          # ceiling
+        quad([-1, 1, -1], [1, 1, -1], [1, 1, 1], [-1, 1, 1]),          # back
+        quad([-1, -1, -1], [-1, 1, -1], [-1, 1, 1], [-1, -1, 1]),      # left
+        quad([1, -1, -1], [1, -1, 1], [1, 1, 1], [1, 1, -1]),          # right
+    ]
+    light = quad([-0.3, -0.3, 0.98], [0.3, -0.3, 0.98], [0.3, 0.3, 0.98], [-0.3, 0.3, 0.98])
+    inner = quad([-0.5, 0.2, -0.6], [0.4, 0.0, -0.7], [0.5, 0.3, 0.1], [-0.4, 0.5, 0.2])
+
+    def capture(s):
+        white = s.add_material_matte((0.7, 0.7, 0.7), sigma)
+        red = s.add_material_matte((0.6, 0.1, 0.1), 0.0)
+        for k, (P, idx) in enumerate(walls):
+            s.add_mesh(P, idx, red if k == 3 else white)
+        lid = s.add_light_diffuse_area((8.0, 7.0, 6.0), 2, two_sided=two_sided)
+        # the light faces down (-z) only if its winding gives n = -z; flip with reverse_orientation otherwise
+        s.add_mesh(light[0], light[1], white, first_area_light=lid, reverse_orientation=True)
+        P, idx = inner
+        N = UV = None
+        if with_normals:
+            n = np.cross(P[1] - P[0], P[2] - P[0]); n /= np.linalg.norm(n)
+            N = np.tile(n, (4, 1)).astype(np.float32) + np.array([[0.1, 0, 0], [0, 0.1, 0], [-0.1, 0, 0], [0, -0.1, 0]], np.float32)
+        if with_uv:
+            UV = np.array([[0, 0], [2, 0.1], [2.2, 1.5], [0.1, 1.4]], np.float32)
+        s.add_mesh(P, idx, white, N=N, UV=UV, reverse_orientation=reverse)
+        w2c, c2w = host.look_at([0, -3.4, 0], [0, 0, 0], [0, 0, 1])
+        s.set_camera_perspective(host.perspective_raster_to_camera(40.0, 48, 48), c2w)
+        cb, table, sb = host.film_box(48, 48)
+        s.set_film(48, 48, cb, (0.5, 0.5), table)
+        s.set_sampler(0, 8, sb)
+        s.build_accel(0, 4)
+    return capture

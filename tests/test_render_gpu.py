@@ -89,3 +89,129 @@ def test_infinite_light_scene_film_bit_exact_and_l2(host, n_tris, res, spp, dept
     g2, o2, prod2, _ = _render_both(cap, 0, max_depth=depth)
     rel_rmse, outliers, mean_lum = _l2_report(prod2, g2, o2)
     assert rel_rmse <= TOL_RMSE and outliers <= TOL_OUTLIER_FRAC, (rel_rmse, outliers, mean_lum)
+
+
+def _assert_film_bit_exact(cap, **kw):
+    g, o, prod, orc = _render_both(cap, 1, **kw)
+    assert (g[2].regular_rays, g[2].shadow_rays, g[2].camera_rays) == (o[2].regular_rays, o[2].shadow_rays, o[2].camera_rays), (g[2].as_dict(), o[2].as_dict())
+    assert _bits_equal(g[1], o[1])
+    nb = int((g[0].view(np.uint32) != o[0].view(np.uint32)).any(axis=2).sum())
+    assert nb == 0, f"{nb} pixels differ"
+    assert float(o[0].max()) > 0.0
+    return g, o, prod
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(two_sided=True), dict(with_normals=True), dict(with_uv=True), dict(with_normals=True, with_uv=True, reverse=True),
+                                  dict(sigma=25.0)])
+def test_area_light_box_scene_bit_exact(host, opts):
+    """DiffuseAreaLight (sample_li via Triangle::sample, pdf_li via a single Triangle::intersect, Le on camera/MIS hits),
+    Oren-Nayar, vertex normals / UVs shading frames, reverse_orientation."""
+    cap = scenes.cornell_like(host, **opts)
+    for strategy in (0, 1):   # uniform and power light distributions (2 area lights + nothing else)
+        _assert_film_bit_exact(cap, max_depth=4, light_strategy=strategy)
+
+
+def test_point_and_distant_lights_bit_exact(host):
+    P, idx = host.gen_random_tris(3000, 11)
+
+    def cap(s):
+        m = s.add_material_matte((0.8, 0.6, 0.4), 0.0)
+        s.add_light_point((5.0, 5.0, 4.0), (0.5, -2.0, 1.5))
+        s.add_light_distant((1.0, 0.9, 0.8), (0.0, -0.6, 0.8))
+        s.add_light_infinite((0.2, 0.25, 0.3))
+        s.add_mesh(P, idx, m)
+        w2c, c2w = host.look_at([0, -4, 0.5], [0, 0, 0], [0, 0, 1])
+        s.set_camera_perspective(host.perspective_raster_to_camera(35.0, 64, 40), c2w)
+        cb, table, sb = host.film_box(64, 40)
+        s.set_film(64, 40, cb, (0.5, 0.5), table)
+        s.set_sampler(0, 4, sb)
+        s.build_accel(0, 4)
+    for strategy in (0, 1):
+        _assert_film_bit_exact(cap, max_depth=5, light_strategy=strategy)
+
+
+def test_rotated_infinite_light_and_rr(host):
+    """light_to_world != identity (pdf_li / le go through world_to_light), long paths so Russian roulette fires (bounces > 3)."""
+    P, idx = host.gen_random_tris(1500, 12)
+    l2w, w2l = host.rotate(37.0, (0.3, 1.0, 0.2))
+
+    def cap(s):
+        m = s.add_material_matte((0.9, 0.9, 0.9), 0.0)
+        s.add_light_infinite((1.0, 0.8, 0.6), l2w, w2l)
+        s.add_mesh(P, idx, m)
+        w2c, c2w = host.look_at([0, -4, 0], [0, 0, 0], [0, 0, 1])
+        s.set_camera_perspective(host.perspective_raster_to_camera(40.0, 40, 40), c2w)
+        cb, table, sb = host.film_box(40, 40)
+        s.set_film(40, 40, cb, (0.5, 0.5), table)
+        s.set_sampler(0, 8, sb)
+        s.build_accel(0, 4)
+    _assert_film_bit_exact(cap, max_depth=12, rr_threshold=1.0)
+    _assert_film_bit_exact(cap, max_depth=0)   # Le / environment only
+
+
+def test_crop_window_pixel_bounds_wide_radius_and_clamp(host):
+    """Film crop window, integrator pixelbounds (samples skipped after start_pixel), a box filter wider than a pixel (every
+    sample touches several pixels; tiles overlap by more than one row) and maxsampleluminance clamping."""
+    P, idx = host.gen_random_tris(800, 13)
+
+    def cap(s):
+        m = s.add_material_matte()
+        s.add_light_infinite((3.0, 3.0, 3.0))
+        s.add_mesh(P, idx, m)
+        w2c, c2w = host.look_at([0, -4, 0], [0, 0, 0], [0, 0, 1])
+        s.set_camera_perspective(host.perspective_raster_to_camera(40.0, 80, 60), c2w)
+        cb, table, sb = host.film_box(80, 60, crop_window=(0.1, 0.9, 0.2, 0.95), radius=(1.5, 1.25))
+        s.set_film(80, 60, cb, (1.5, 1.25), table, scale=2.0, max_sample_luminance=1.5)
+        s.set_sampler(0, 4, sb)
+        s.build_accel(0, 4)
+    g, o, prod = _assert_film_bit_exact(cap, max_depth=3)
+    assert float(g[1].max()) > 4.0  # several samples per pixel from neighbours
+    _assert_film_bit_exact(cap, max_depth=3, pixel_bounds=[20, 15, 50, 40])
+    rgb_g = prod.film_to_rgb(g[0], g[1])
+    from oracle_binding import OracleScene
+    orc = OracleScene(); cap(orc)
+    assert _bits_equal(rgb_g, orc.film_to_rgb(o[0], o[1]))
+
+
+def test_tile_parts_sum_to_the_full_frame(host):
+    spec = pbrt_hip.SceneSpec(n_tris=1000, seed=14, xres=70, yres=50, spp=4)
+    prod = pbrt_hip.Scene()
+    pbrt_hip.capture_spec(spec, prod, host)
+    full, wfull, st = prod.render_path()
+    acc = np.zeros_like(full); wacc = np.zeros_like(wfull); rays = 0
+    for p in range(3):
+        x, w, s = prod.render_path(tile_part=p, tile_parts=3)
+        acc += x; wacc += w; rays += s.regular_rays + s.shadow_rays
+    assert _bits_equal(acc, full) and _bits_equal(wacc, wfull)
+    assert rays == st.regular_rays + st.shadow_rays
+
+
+def test_chunked_render_equals_unchunked(host, monkeypatch):
+    """PBRT_HIP_MAX_PATHS forces several sample chunks per frame; the film must not depend on the chunking."""
+    spec = pbrt_hip.SceneSpec(n_tris=1000, seed=15, xres=64, yres=64, spp=8)
+    a = pbrt_hip.Scene(); pbrt_hip.capture_spec(spec, a, host)
+    x1, w1, s1 = a.render_path()
+    monkeypatch.setenv("PBRT_HIP_MAX_PATHS", str(64 * 64 * 3))
+    x2, w2, s2 = a.render_path()
+    assert s2.extend_launches > s1.extend_launches
+    assert _bits_equal(x1, x2) and _bits_equal(w1, w2)
+
+
+def test_unsupported_and_state_errors(host):
+    s = pbrt_hip.Scene()
+    spec = pbrt_hip.SceneSpec(n_tris=10, xres=16, yres=16, spp=1)
+    m = s.add_material_matte()
+    with pytest.raises(pbrt_hip.PbrtHipError) as e:
+        s.render_path()
+    assert e.value.code in (pbrt_hip.ERR_STATE, pbrt_hip.ERR_INVALID_ARG)
+    pbrt_hip.capture_spec(spec, s, host)
+    s.add_light_point((1, 1, 1), (0, 0, 3)); s.build_accel(0, 4)
+    with pytest.raises(pbrt_hip.PbrtHipError) as e:
+        s.render_path(light_strategy=2)       # spatial distribution with > 1 light: a "next" row
+    assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
+    with pytest.raises(pbrt_hip.PbrtHipError) as e:
+        s.build_accel(1, 4)                   # HLBVH
+    assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
+    with pytest.raises(pbrt_hip.PbrtHipError) as e:
+        s.set_sampler(2, 4, [0, 0, 16, 16])   # random sampler: per-tile sequential RNG, CPU only
+    assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
