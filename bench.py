@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample (same scene, same resolution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-count", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = functional rehearsal of the N>1 path on ONE GPU: all ranks share device 0 and film tiles travel through host memory")
     args = ap.parse_args()
 
     import numpy as np
@@ -71,11 +73,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
+    if args.backend == "gloo":
+        local_rank = 0  # rehearsal mode: every rank drives GPU 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -97,7 +104,14 @@ def main():
         st = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=args.max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
         film = None
         if world > 1:
-            dist.gather(tile_buf, gather_list, dst=0)
+            if args.backend == "nccl":
+                dist.gather(tile_buf, gather_list, dst=0)   # RCCL over xGMI, device buffers
+            else:
+                host_parts = [torch.zeros(floats) for _ in range(world)] if rank == 0 else None
+                dist.gather(tile_buf.cpu(), host_parts, dst=0)
+                if rank == 0:
+                    for g, h in zip(gather_list, host_parts):
+                        g.copy_(h)
             if rank == 0:
                 torch.cuda.synchronize()
                 film = scene.merge_tiles_device([t.data_ptr() for t in gather_list], tile_size)
@@ -110,6 +124,11 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def reduce_scalars(vals, op, dtype):
+        t = torch.tensor(vals, dtype=dtype, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=op)
+        return t.tolist()
 
     for _ in range(args.warmup):
         step()
@@ -128,12 +147,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([rays, reg, shd], dtype=torch.int64, device=dev)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays, reg, shd = (int(v) for v in r.tolist())
+        elapsed = float(reduce_scalars([elapsed], dist.ReduceOp.MAX, torch.float64)[0])
+        rays, reg, shd = (int(v) for v in reduce_scalars([rays, reg, shd], dist.ReduceOp.SUM, torch.int64))
 
     out = None
     if rank == 0:
@@ -147,6 +162,7 @@ def main():
                        "tiles": "16x16, tile t on rank t % n_gpus, film tiles gathered on rank 0 (RCCL)" if world > 1 else "16x16, one rank",
                        "rays_per_frame": rays // args.steps, "regular_rays_per_frame": reg // args.steps, "shadow_rays_per_frame": shd // args.steps,
                        "scene_setup_seconds_host": round(t_setup, 3)},
+            "film_sha256": __import__("hashlib").sha256(film[0].tobytes() + film[1].tobytes()).hexdigest(),
             "stage_ms_per_step_rank0": {"extend": round(ext_s / args.steps * 1e3, 3), "shadow": round(sh_s / args.steps * 1e3, 3),
                                         "raygen_shade_film": round(shade_s / args.steps * 1e3, 3)},
         }

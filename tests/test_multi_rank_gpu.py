@@ -1,0 +1,30 @@
+"""-m gpu: the N>1 device path (per-rank tile buffers -> gather -> merge_tiles_device) rehearsed with 2 ranks sharing the one
+GPU of the test box (gloo carries the tile buffers through host memory; on a multi-GPU node bench.py uses RCCL instead).
+The merged frame must be bit-identical to the 1-rank frame."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(out):
+    return json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+
+
+def test_two_ranks_one_gpu_film_identical():
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--spp", "4", "--res", "200", "--n-tris", "20000"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = _last_json(one.stdout), _last_json(two.stdout)
+    assert b["n_gpus"] == 2 and a["n_gpus"] == 1
+    assert a["film_sha256"] == b["film_sha256"]
+    assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
