@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample (same scene, same resolution)")
+    ap.add_argument("--cpu-spp", type=int, default=64, help="spp of the bounded CPU-baseline sample (same scene, same resolution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-count", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

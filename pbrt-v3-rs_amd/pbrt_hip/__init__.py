@@ -284,6 +284,12 @@ class Scene:
         self._chk(self.b.fn("set_sampler")(self.h, kind, spp, _ptr(sb, C.c_int), 1 if sample_at_pixel_center else 0))
         self.sample_bounds = sb
 
+    def set_sobol_tables(self, m32, vdc, vdc_inv):
+        """Generator matrices for the Sobol sampler (data tables the host owns; the library embeds none)."""
+        m32 = np.ascontiguousarray(m32, dtype=np.uint32); vdc = np.ascontiguousarray(vdc, dtype=np.uint64); vdci = np.ascontiguousarray(vdc_inv, dtype=np.uint64)
+        assert len(vdc) == len(vdci)
+        self._chk(self.b.fn("set_sobol_tables")(self.h, _ptr(m32, C.c_uint32), len(m32), _ptr(vdc, C.c_uint64), _ptr(vdci, C.c_uint64), len(vdc)))
+
     def build_accel(self, split_method=0, max_prims_in_node=4):
         self._chk(self.b.fn("build_accel")(self.h, split_method, max_prims_in_node))
 

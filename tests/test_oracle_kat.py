@@ -195,3 +195,43 @@ def test_tile_partition_is_exact(host):
         acc += x; wacc += w
     assert np.array_equal(wacc, wfull)
     assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+
+
+def _sobol_tables():
+    z = np.load(os.path.join(HERE, "golden", "sobol_subset.npz"))
+    return z["m32"], z["vdc"], z["vdc_inv"]
+
+
+def test_sobol_sampler_properties(host):
+    """SobolSampler (samplers/src/sobol.rs:35-93): per pixel, the first 16 samples' film offsets form a (0,2)-net — one sample in
+    each cell of the 4x4, 16x1 and 1x16 partitions of the pixel; every dimension stays in [0,1)."""
+    s = OracleScene()
+    spec = pbrt_hip.SceneSpec(n_tris=4, xres=100, yres=60, spp=16)
+    pbrt_hip.capture_spec(spec, s, host)
+    s.set_sobol_tables(*_sobol_tables())
+    s.set_sampler(1, 16, s.sample_bounds)
+    rays, pf = s.generate_camera_rays([0, 0, 100, 60], 0)
+    assert np.isfinite(rays["d"]).all()
+    offs = []
+    for k in range(16):
+        _, pf = s.generate_camera_rays([37, 21, 38, 22], k)
+        offs.append(pf[0] - np.array([37, 21], np.float32))
+    offs = np.array(offs)
+    assert (offs >= 0).all() and (offs < 1).all()
+    for nx, ny in ((4, 4), (16, 1), (1, 16), (2, 8), (8, 2)):
+        cells = {(int(o[0] * nx), int(o[1] * ny)) for o in offs}
+        assert len(cells) == 16, (nx, ny)
+    xyz, wt, st, _ = s.render_path_ex(max_depth=3)
+    assert st.camera_rays == 100 * 60 * 16 and float(s.film_to_rgb(xyz, wt).mean()) > 0.2
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "core/src/sobol_matrices.rs")), reason="reference tree not present")
+def test_sobol_fixture_matches_reference_tables():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(HERE, "golden", "make_sobol_fixture.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    src = open(mk.REF).read()
+    m32, vdc, vdci = _sobol_tables()
+    assert np.array_equal(m32, np.array(mk.table(src, "SOBOL_MATRICES_32")[: len(m32)], np.uint32))
+    assert np.array_equal(vdc, np.array(mk.table(src, "VD_C_SOBOL_MATRICES")[: len(vdc)], np.uint64))
+    assert np.array_equal(vdci, np.array(mk.table(src, "VD_C_SOBOL_MATRICES_INV")[: len(vdci)], np.uint64))

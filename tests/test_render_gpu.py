@@ -215,3 +215,26 @@ def test_unsupported_and_state_errors(host):
     with pytest.raises(pbrt_hip.PbrtHipError) as e:
         s.set_sampler(2, 4, [0, 0, 16, 16])   # random sampler: per-tile sequential RNG, CPU only
     assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
+
+
+def test_sobol_sampler_film_bit_exact(host):
+    """Sobol sampler on device (index via the VdC matrices, XOR of generator columns, pixel-relative remap of dims 0/1)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sobol_subset.npz"))
+    spec = pbrt_hip.SceneSpec(n_tris=2000, seed=21, xres=72, yres=50, spp=8, max_depth=4)
+
+    def cap(s):
+        pbrt_hip.capture_spec(spec, s, host)
+        s.set_sobol_tables(z["m32"], z["vdc"], z["vdc_inv"])
+        s.set_sampler(1, 8, s.sample_bounds)
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    cap(prod); cap(orc)
+    gr, gp = prod.generate_camera_rays([0, 0, 72, 50], 5)
+    orr, op = orc.generate_camera_rays([0, 0, 72, 50], 5)
+    assert _bits_equal(gp, op) and _bits_equal(np.ascontiguousarray(gr["d"]), np.ascontiguousarray(orr["d"]))
+    _assert_film_bit_exact(cap, max_depth=4)
+    # non power-of-two spp is rounded up (sobol.rs:38-47)
+    def cap6(s):
+        cap(s); s.set_sampler(1, 6, s.sample_bounds)
+    g, o, _ = _assert_film_bit_exact(cap6, max_depth=2)
+    assert g[2].camera_rays == 72 * 50 * 8
