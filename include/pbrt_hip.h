@@ -46,7 +46,8 @@ typedef struct PbrtHipRay {
 /* 32-byte closest-hit record: what Primitive::intersect (core/src/primitive.rs:22) hands back, reduced to the
  * ray-dependent quantities of Triangle::intersect (shapes/src/triangle.rs:438-545): t, barycentrics and the
  * primitive.  prim = index into the concatenation of all meshes' triangles in pbrt_hip_add_mesh order
- * (= position in the reference's `primitives: &[ArcPrimitive]` before BVH reordering); 0xFFFFFFFF on a miss. */
+ * (= position in the reference's `primitives: &[ArcPrimitive]` before BVH reordering); 0xFFFFFFFF on a miss.
+ * pad[0] carries the library's leaf-order index of the hit triangle (an internal shortcut for the shade stage); ignore it. */
 typedef struct PbrtHipHit {
     float t;
     uint32_t prim;

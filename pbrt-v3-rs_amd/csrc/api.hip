@@ -142,7 +142,7 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
 
 // Tuning variants of the traversal kernel, selectable at run time (PBRT_HIP_TRAV_VARIANT) so that one GPU session can
 // compare them on the same data.  {LEAF_MIN, REFILL_MIN, LDS_DEPTH}; variant 0 is the default.
-#define PH_VARIANTS(X) X(0, 20, 12, 12) X(1, 8, 8, 16) X(2, 24, 8, 16) X(3, 16, 4, 16) X(4, 16, 16, 16) X(5, 16, 8, 12) X(6, 16, 8, 8) X(7, 32, 8, 16) X(8, 12, 8, 12) X(9, 16, 8, 16)
+#define PH_VARIANTS(X) X(0, 20, 12, 12, 3) X(1, 20, 12, 12, 2) X(2, 20, 12, 12, 1) X(3, 24, 12, 12, 2) X(4, 16, 12, 12, 2) X(5, 28, 16, 12, 2) X(6, 20, 16, 12, 2) X(7, 20, 8, 12, 2) X(8, 24, 16, 10, 2) X(9, 24, 12, 12, 4)
 static int trav_variant() {
     static int v = -1;
     if (v < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_VARIANT"); v = e ? std::atoi(e) : 0; if (v < 0 || v > 9) v = 0; }
@@ -150,7 +150,7 @@ static int trav_variant() {
 }
 static int variant_lds_depth(int v) {
     switch (v) {
-#define X(id, lm, rm, ld) case id: return ld;
+#define X(id, lm, rm, ld, ns) case id: return ld;
         PH_VARIANTS(X)
 #undef X
     }
@@ -163,7 +163,7 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
         PH_CHECK(s, hipGetDeviceProperties(&prop, s->device));
         int per_cu = 0;
         switch (trav_variant()) {
-#define X(id, lm, rm, ld) case id: PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false, lm, rm, ld>, PH_TRAV_BLOCK, 0)); break;
+#define X(id, lm, rm, ld, ns) case id: PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false, lm, rm, ld, ns>, PH_TRAV_BLOCK, 0)); break;
             PH_VARIANTS(X)
 #undef X
         }
@@ -192,10 +192,10 @@ void launch_traverse_kernel(PbrtHipScene* s, bool anyhit, uint32_t blocks, const
         return;
     }
     switch (trav_variant()) {
-#define X(id, lm, rm, ld)                                                                                                         \
+#define X(id, lm, rm, ld, ns)                                                                                                     \
     case id:                                                                                                                      \
-        if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, false, lm, rm, ld>), g, b, 0, s->stream, s->ds, p);             \
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, false, lm, rm, ld>), g, b, 0, s->stream, s->ds, p);                   \
+        if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, false, lm, rm, ld, ns>), g, b, 0, s->stream, s->ds, p);         \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, false, lm, rm, ld, ns>), g, b, 0, s->stream, s->ds, p);               \
         break;
         PH_VARIANTS(X)
 #undef X
@@ -540,7 +540,7 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
     if (split_method == 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: HLBVH is a 'next' row (SURVEY §8f)");
     if (split_method == 2) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: splitmethod 'middle' panics in the reference (quirk B6, sah.rs:67-76)");
     phost::BuildInput in;
-    in.P = s->P.data(); in.idx = s->idx.data(); in.n_tris = s->idx.size() / 3; in.tri_flags = s->tri_flags.data();
+    in.P = s->P.data(); in.idx = s->idx.data(); in.n_tris = s->idx.size() / 3; in.tri_flags = s->tri_flags.data(); in.tri_mesh = s->tri_mesh.data();
     if (phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh) != 0) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: bad arguments");
     // Light::preprocess: bounding sphere of the world bound (bounds3.rs:196-208; infinite.rs:113-117, distant.rs:54-58)
     s->world_radius = 1.0f; s->world_center[0] = s->world_center[1] = s->world_center[2] = 0.0f;

@@ -182,7 +182,7 @@ int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int
         const float* p1 = in.P + 3 * (size_t)in.idx[3 * (size_t)id + 1];
         const float* p2 = in.P + 3 * (size_t)in.idx[3 * (size_t)id + 2];
         std::memcpy(t.p0, p0, 12); std::memcpy(t.p1, p1, 12); std::memcpy(t.p2, p2, 12);
-        t.prim = id; t.flags = in.tri_flags ? (in.tri_flags[id] & ~PH_TRI_LAST) : 0u; t.pad = 0;
+        t.prim = id; t.flags = in.tri_flags ? (in.tri_flags[id] & ~PH_TRI_LAST) : 0u; t.mesh = in.tri_mesh ? in.tri_mesh[id] : 0u;
     }
     for (int k = 0; k < 3; k++) { out.root_lo[k] = root->b.lo[k]; out.root_hi[k] = root->b.hi[k]; }
 

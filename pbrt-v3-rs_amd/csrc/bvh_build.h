@@ -19,6 +19,7 @@ struct BuildInput {
     const uint32_t* idx;    // 3 per triangle
     size_t n_tris;
     const uint32_t* tri_flags;  // per-triangle PH_TRI_BOGUS/ALPHA0/SALPHA0 bits (LAST is set by the builder)
+    const uint32_t* tri_mesh = nullptr;  // mesh id per triangle (copied into TriRec::mesh), may be null
 };
 
 struct BuildOutput {

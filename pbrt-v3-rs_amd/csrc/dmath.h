@@ -33,6 +33,18 @@ PH_DEV float pclampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi
 PH_DEV int pmini(int a, int b) { return a < b ? a : b; }
 PH_DEV int pmaxi(int a, int b) { return a > b ? a : b; }
 
+// Outlined IEEE divide / sqrt / f64 transcendentals for the big shade kernel (PH_OUTLINE_MATH): hipcc expands every correctly
+// rounded f32 divide into ~12 instructions and every f64 sin/cos into a few hundred; inlined at ~120 / ~10 sites they pushed the
+// shade kernel past the instruction cache (64 KB of code, ~37 cycles per issued instruction measured).  Arguments and results
+// travel in registers, so a call costs a handful of cycles.  The traversal kernels keep the inline forms.
+#ifdef PH_OUTLINE_MATH
+__device__ __noinline__ float ph_div(float a, float b) { return a / b; }
+__device__ __noinline__ float ph_sqrt(float a) { return sqrtf(a); }
+#else
+PH_DEV float ph_div(float a, float b) { return a / b; }
+PH_DEV float ph_sqrt(float a) { return sqrtf(a); }
+#endif
+
 struct f3 { float x, y, z; };
 PH_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PH_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -40,12 +52,12 @@ PH_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 PH_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 PH_DEV f3 operator*(f3 a, float f) { return mk3(a.x * f, a.y * f, a.z * f); }
 PH_DEV f3 operator*(float f, f3 a) { return mk3(a.x * f, a.y * f, a.z * f); }
-PH_DEV f3 operator/(f3 a, float f) { float inv = 1.0f / f; return mk3(inv * a.x, inv * a.y, inv * a.z); }  // vector3.rs:406-418
+PH_DEV f3 operator/(f3 a, float f) { float inv = ph_div(1.0f, f); return mk3(inv * a.x, inv * a.y, inv * a.z); }  // vector3.rs:406-418
 PH_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PH_DEV float abs_dot(f3 a, f3 b) { return pabs(dot(a, b)); }
 PH_DEV f3 cross(f3 a, f3 b) { return mk3((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)); }
 PH_DEV float length_squared(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-PH_DEV float length(f3 a) { return sqrtf(length_squared(a)); }
+PH_DEV float length(f3 a) { return ph_sqrt(length_squared(a)); }
 PH_DEV f3 normalize(f3 a) { return a / length(a); }
 PH_DEV f3 vabs(f3 a) { return mk3(pabs(a.x), pabs(a.y), pabs(a.z)); }
 PH_DEV float max_component(f3 a) { return a.x > a.y ? (a.x > a.z ? a.x : a.z) : (a.y > a.z ? a.y : a.z); }  // vector3.rs:93-107
@@ -55,8 +67,8 @@ PH_DEV f3 permute(f3 a, int kx, int ky, int kz) { return mk3(comp(a, kx), comp(a
 PH_DEV f3 face_forward(f3 n, f3 v) { return dot(n, v) < 0.0f ? -n : n; }
 PH_DEV float distance_squared(f3 a, f3 b) { return length_squared(a - b); }
 PH_DEV void coordinate_system(f3 v1, f3& v2, f3& v3) {  // core/src/geometry/coordinate_system.rs:12-20
-    if (pabs(v1.x) > pabs(v1.y)) v2 = mk3(-v1.z, 0.0f, v1.x) / sqrtf(v1.x * v1.x + v1.z * v1.z);
-    else v2 = mk3(0.0f, v1.z, -v1.y) / sqrtf(v1.y * v1.y + v1.z * v1.z);
+    if (pabs(v1.x) > pabs(v1.y)) v2 = mk3(-v1.z, 0.0f, v1.x) / ph_sqrt(v1.x * v1.x + v1.z * v1.z);
+    else v2 = mk3(0.0f, v1.z, -v1.y) / ph_sqrt(v1.y * v1.y + v1.z * v1.z);
     v3 = cross(v1, v2);
 }
 PH_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
@@ -64,11 +76,18 @@ PH_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 // Transcendentals: evaluated in f64 and rounded once.  The reference calls the platform's f32 libm, which is not
 // correctly rounded (glibc sinf differs from the rounded f64 value for ~1.3 % of arguments, atan2f for ~16 %), so no
 // device routine can match it bit for bit; the rounded-f64 value is within 1 ulp of it and is reproducible on any host.
-PH_DEV float d_sin(float x) { return (float)sin((double)x); }
-PH_DEV float d_cos(float x) { return (float)cos((double)x); }
-PH_DEV void d_sincos(float x, float& s, float& c) { double ds, dc; sincos((double)x, &ds, &dc); s = (float)ds; c = (float)dc; }
-PH_DEV float d_acos(float x) { return (float)acos((double)x); }
-PH_DEV float d_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+#ifdef PH_OUTLINE_MATH
+#define PH_TRIG __device__ __noinline__
+#else
+#define PH_TRIG PH_DEV
+#endif
+struct sc2 { float s, c; };
+PH_TRIG float d_sin(float x) { return (float)sin((double)x); }
+PH_TRIG float d_cos(float x) { return (float)cos((double)x); }
+PH_TRIG sc2 d_sincos2(float x) { double ds, dc; sincos((double)x, &ds, &dc); sc2 r; r.s = (float)ds; r.c = (float)dc; return r; }
+PH_DEV void d_sincos(float x, float& s, float& c) { sc2 r = d_sincos2(x); s = r.s; c = r.c; }
+PH_TRIG float d_acos(float x) { return (float)acos((double)x); }
+PH_TRIG float d_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
 
 PH_DEV float spherical_theta(f3 v) { return d_acos(pclampf(v.z, -1.0f, 1.0f)); }                    // geometry/util.rs:41-44
 PH_DEV float spherical_phi(f3 v) { float p = d_atan2(v.y, v.x); return p < 0.0f ? p + kTwoPi : p; }  // :46-56
@@ -108,7 +127,7 @@ PH_DEV spec operator+(spec a, spec b) { return mks(a.r + b.r, a.g + b.g, a.b + b
 PH_DEV spec operator*(spec a, spec b) { return mks(a.r * b.r, a.g * b.g, a.b * b.b); }
 PH_DEV spec operator*(spec a, float f) { return mks(a.r * f, a.g * f, a.b * f); }
 PH_DEV spec operator*(float f, spec a) { return a * f; }
-PH_DEV spec operator/(spec a, float f) { return a * (1.0f / f); }  // rgb_spectrum.rs:255-263
+PH_DEV spec operator/(spec a, float f) { return a * ph_div(1.0f, f); }  // rgb_spectrum.rs:255-263
 PH_DEV bool is_black(spec a) { return a.r == 0.0f && a.g == 0.0f && a.b == 0.0f; }
 PH_DEV float lum_y(spec a) { return 0.212671f * a.r + 0.715160f * a.g + 0.072169f * a.b; }
 PH_DEV float max_component_value(spec a) { return pmaxf(pmaxf(a.r, a.g), a.b); }

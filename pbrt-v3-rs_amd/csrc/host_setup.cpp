@@ -185,7 +185,7 @@ extern "C" void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, fl
 #include "bvh_build.h"
 extern "C" int pbrt_hip_host_build_bvh(const float* P, const uint32_t* idx, uint64_t n_tris, int split_method, int max_prims_in_node, int n_threads,
                                        uint32_t* out_ordered_prims, uint32_t* out_leaf_last, void* out_nodes, uint64_t* out_info, float* out_root_bounds) {
-    phost::BuildInput in{P, idx, (size_t)n_tris, nullptr};
+    phost::BuildInput in{P, idx, (size_t)n_tris, nullptr, nullptr};
     phost::BuildOutput out;
     int rc = phost::build_bvh(in, split_method, max_prims_in_node, n_threads, out);
     if (rc) return rc;

@@ -18,7 +18,7 @@ PH_DEV float radical_inverse_2(uint64_t a) {
 }
 // radical_inverse_specialized (:401-421)
 PH_DEV float radical_inverse_base(uint32_t base, uint32_t a) {
-    const float inv_base = 1.0f / (float)base;
+    const float inv_base = ph_div(1.0f, (float)base);
     uint64_t reversed = 0;
     float inv_base_n = 1.0f;
     while (a != 0) {
@@ -32,7 +32,7 @@ PH_DEV float radical_inverse_base(uint32_t base, uint32_t a) {
 // scrambled_radical_inverse_specialized (:428-449).  `a / base` is the integer quotient; it is evaluated as
 // umul64hi(a, ceil(2^64/base)), which equals floor(a/base) for every a < 2^32 (integer arithmetic: no rounding involved).
 PH_DEV float scrambled_radical_inverse(uint32_t base, uint64_t magic, uint32_t a, const uint16_t* __restrict__ perm) {
-    const float inv_base = 1.0f / (float)base;
+    const float inv_base = ph_div(1.0f, (float)base);
     uint64_t reversed = 0;
     float inv_base_n = 1.0f;
     while (a != 0) {
@@ -41,7 +41,7 @@ PH_DEV float scrambled_radical_inverse(uint32_t base, uint64_t magic, uint32_t a
         inv_base_n *= inv_base;
         a = next;
     }
-    return pminf(inv_base_n * (__ull2float_rn(reversed) + inv_base * (float)perm[0] / (1.0f - inv_base)), kOneMinusEps);
+    return pminf(inv_base_n * (__ull2float_rn(reversed) + ph_div(inv_base * (float)perm[0], 1.0f - inv_base)), kOneMinusEps);
 }
 // inverse_radical_inverse (:1535-1545)
 PH_DEV uint32_t inverse_radical_inverse(uint32_t base, uint32_t inverse, uint32_t n_digits) {
@@ -64,11 +64,41 @@ PH_DEV uint32_t halton_pixel_offset(const SamplerRec& sp, int px, int py) {
     }
     return (uint32_t)off;
 }
+// The first PH_LDS_DIMS dimensions' tables (17.8 KB of digit permutations + primes + magic numbers) can be staged in LDS:
+// a path vertex draws ~8 dimensions x ~7 digits, i.e. ~80 dependent table reads.  `lds` is null when a kernel does not stage them.
+#define PH_LDS_DIMS 64
+#define PH_LDS_PERMS 8893  // sum of the first 64 primes
+struct HaltonLds {
+    uint16_t perms[PH_LDS_PERMS + 3];
+    uint32_t primes[PH_LDS_DIMS], sums[PH_LDS_DIMS];
+    uint64_t magic[PH_LDS_DIMS];
+};
+PH_DEV void halton_lds_fill(HaltonLds* l, const DeviceScene& sc) {  // cooperative; caller synchronises
+    for (uint32_t i = threadIdx.x; i < PH_LDS_PERMS; i += blockDim.x) l->perms[i] = sc.halton_perms[i];
+    for (uint32_t i = threadIdx.x; i < PH_LDS_DIMS; i += blockDim.x) { l->primes[i] = sc.primes[i]; l->sums[i] = sc.prime_sums[i]; l->magic[i] = sc.prime_magic[i]; }
+}
+// scrambled radical inverse reading the permutation from LDS
+PH_DEV float scrambled_radical_inverse_lds(const HaltonLds* l, uint32_t dim, uint32_t a) {
+    const uint32_t base = l->primes[dim];
+    const uint64_t magic = l->magic[dim];
+    const uint16_t* perm = l->perms + l->sums[dim];
+    const float inv_base = ph_div(1.0f, (float)base);
+    uint64_t reversed = 0;
+    float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint32_t next = (uint32_t)__umul64hi((uint64_t)a, magic), digit = a - next * base;
+        reversed = reversed * base + perm[digit];
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return pminf(inv_base_n * (__ull2float_rn(reversed) + ph_div(inv_base * (float)perm[0], 1.0f - inv_base)), kOneMinusEps);
+}
 // HaltonSampler::sample_dimension (halton.rs:146-160)
-PH_DEV float halton_sample(const DeviceScene& sc, const SamplerRec& sp, uint32_t index, uint32_t dim) {
+PH_DEV float halton_sample(const DeviceScene& sc, const SamplerRec& sp, uint32_t index, uint32_t dim, const HaltonLds* lds = nullptr) {
     if (sp.at_center && (dim == 0 || dim == 1)) return 0.5f;
     if (dim == 0) return radical_inverse_2((uint64_t)(index >> sp.base_exponents[0]));
     if (dim == 1) return radical_inverse_base(3u, index / sp.base_scales[1]);
+    if (lds && dim < PH_LDS_DIMS) return scrambled_radical_inverse_lds(lds, dim, index);
     return scrambled_radical_inverse(sc.primes[dim], sc.prime_magic[dim], index, sc.halton_perms + sc.prime_sums[dim]);
 }
 
@@ -103,9 +133,10 @@ struct SamplerCursor {
     uint64_t index;
     uint32_t dim;
     int px, py;
+    const HaltonLds* lds;  // LDS-staged Halton tables, or null
 };
 PH_DEV float sampler_dim(const DeviceScene& sc, const SamplerRec& sp, const SamplerCursor& c, uint32_t dim) {
-    return sp.kind == 0 ? halton_sample(sc, sp, (uint32_t)c.index, dim) : sobol_sample(sc, sp, c.index, dim, c.px, c.py);
+    return sp.kind == 0 ? halton_sample(sc, sp, (uint32_t)c.index, dim, c.lds) : sobol_sample(sc, sp, c.index, dim, c.px, c.py);
 }
 PH_DEV float get_1d(const DeviceScene& sc, const SamplerRec& sp, SamplerCursor& c) {  // halton.rs:226-235 (no sample arrays on this path)
     float p = sampler_dim(sc, sp, c, c.dim);
@@ -124,21 +155,21 @@ PH_DEV f2 concentric_sample_disk(f2 u) {  // :138-155
     f2 uo = mk2(2.0f * u.x - 1.0f, 2.0f * u.y - 1.0f);
     if (uo.x == 0.0f && uo.y == 0.0f) return mk2(0.0f, 0.0f);
     float r, theta;
-    if (pabs(uo.x) > pabs(uo.y)) { r = uo.x; theta = kPiOver4 * (uo.y / uo.x); }
-    else { r = uo.y; theta = kPiOver2 - kPiOver4 * (uo.x / uo.y); }
+    if (pabs(uo.x) > pabs(uo.y)) { r = uo.x; theta = kPiOver4 * ph_div(uo.y, uo.x); }
+    else { r = uo.y; theta = kPiOver2 - kPiOver4 * ph_div(uo.x, uo.y); }
     float sn, cs;
     d_sincos(theta, sn, cs);
     return mk2(r * cs, r * sn);
 }
 PH_DEV f3 cosine_sample_hemisphere(f2 u) {  // :207-211
     f2 d = concentric_sample_disk(u);
-    float z = sqrtf(pmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
+    float z = ph_sqrt(pmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
     return mk3(d.x, d.y, z);
 }
-PH_DEV f2 uniform_sample_triangle(f2 u) { float su0 = sqrtf(u.x); return mk2(1.0f - su0, u.y * su0); }  // :198-201
+PH_DEV f2 uniform_sample_triangle(f2 u) { float su0 = ph_sqrt(u.x); return mk2(1.0f - su0, u.y * su0); }  // :198-201
 PH_DEV float power_heuristic1(float fp, float gp) {  // :239-243 with nf = ng = 1
     float f = 1.0f * fp, g = 1.0f * gp;
-    return (f * f) / (f * f + g * g);
+    return ph_div(f * f, f * f + g * g);
 }
 // find_interval (core/src/pbrt/common.rs:251-276) over cdf[i] <= u
 PH_DEV uint32_t find_interval_cdf(const float* cdf, uint32_t size, float u) {
@@ -169,7 +200,7 @@ PH_DEV void generate_camera_ray(const CameraRec& cam, f2 p_film, float time_s, f
     if (cam.lens_radius > 0.0f) {
         f2 cd = concentric_sample_disk(lens_s);
         f2 p_lens = mk2(cam.lens_radius * cd.x, cam.lens_radius * cd.y);
-        float ft = cam.focal_distance / d.z;
+        float ft = ph_div(cam.focal_distance, d.z);
         f3 p_focus = o + d * ft;
         o = mk3(p_lens.x, p_lens.y, 0.0f);
         d = normalize(p_focus - o);
@@ -188,7 +219,7 @@ PH_DEV void generate_camera_ray(const CameraRec& cam, f2 p_film, float time_s, f
     f3 dw = mk3(c[0] * d.x + c[1] * d.y + c[2] * d.z, c[4] * d.x + c[5] * d.y + c[6] * d.z, c[8] * d.x + c[9] * d.y + c[10] * d.z);
     float l2 = length_squared(dw), t_max = kInf;
     if (l2 > 0.0f) {
-        float dt = dot(vabs(dw), o_err) / l2;
+        float dt = ph_div(dot(vabs(dw), o_err), l2);
         ow3 = ow3 + dw * dt;
         t_max -= dt;
     }
@@ -223,7 +254,7 @@ PH_DEV void tri_dpdu(const DeviceScene& sc, const MeshRec& m, const TriVerts& t,
     bool degenerate_uv = fabsf(determinant) < 1e-8f;
     dpdu = mk3(0.0f, 0.0f, 0.0f); dpdv = mk3(0.0f, 0.0f, 0.0f);
     if (!degenerate_uv) {
-        float invdet = 1.0f / determinant;
+        float invdet = ph_div(1.0f, determinant);
         dpdu = (duv12.y * dp02 - duv02.y * dp12) * invdet;
         dpdv = (-duv12.x * dp02 + duv02.x * dp12) * invdet;
     }
@@ -234,9 +265,27 @@ PH_DEV void tri_dpdu(const DeviceScene& sc, const MeshRec& m, const TriVerts& t,
     }
 }
 // tail of Triangle::intersect (triangle.rs:576-724) + Hit::new (interaction/mod.rs:137-156)
+PH_DEV SurfHit make_surface_hit_tv(const DeviceScene& sc, const MeshRec& m, const TriVerts& t, f3 rd, float time, uint32_t prim, float b0, float b1, float b2);
 PH_DEV SurfHit make_surface_hit(const DeviceScene& sc, f3 rd, float time, uint32_t prim, float b0, float b1, float b2) {
     const MeshRec m = sc.meshes[sc.tri_mesh[prim]];
     const TriVerts t = load_tri(sc, prim);
+    return make_surface_hit_tv(sc, m, t, rd, time, prim, b0, b1, b2);
+}
+// Same, starting from the leaf-ordered TriRec the traversal kernel reported (hit.pad[0]): positions, primitive id and mesh id
+// arrive in ONE 48-byte fetch instead of the tri_mesh -> meshes and idx -> P dependent chains.
+PH_DEV SurfHit make_surface_hit_rec(const DeviceScene& sc, f3 rd, float time, uint32_t tri_index, float b0, float b1, float b2, MeshRec& m_out) {
+    const float4* tp = reinterpret_cast<const float4*>(sc.tris + tri_index);
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    const uint32_t prim = __float_as_uint(a.w);
+    const MeshRec m = sc.meshes[__float_as_uint(c.w)];
+    TriVerts t;
+    t.p0 = mk3(a.x, a.y, a.z); t.p1 = mk3(b.x, b.y, b.z); t.p2 = mk3(c.x, c.y, c.z);
+    t.i0 = t.i1 = t.i2 = 0;
+    if (m.flags & (PH_MESH_N | PH_MESH_S | PH_MESH_UV)) { t.i0 = sc.idx[3 * prim]; t.i1 = sc.idx[3 * prim + 1]; t.i2 = sc.idx[3 * prim + 2]; }
+    m_out = m;
+    return make_surface_hit_tv(sc, m, t, rd, time, prim, b0, b1, b2);
+}
+PH_DEV SurfHit make_surface_hit_tv(const DeviceScene& sc, const MeshRec& m, const TriVerts& t, f3 rd, float time, uint32_t prim, float b0, float b1, float b2) {
     SurfHit si;
     si.prim = prim; si.time = time;
     f3 dpdu, dpdv;
@@ -249,7 +298,7 @@ PH_DEV SurfHit make_surface_hit(const DeviceScene& sc, f3 rd, float time, uint32
     si.p = b0 * t.p0 + b1 * t.p1 + b2 * t.p2;
     f3 wo = -rd;
     float l2 = length_squared(wo);
-    si.wo = (l2 == 0.0f) ? wo : wo / sqrtf(l2);
+    si.wo = (l2 == 0.0f) ? wo : wo / ph_sqrt(l2);
     si.n = normalize(cross(dp02, dp12));
     const bool rev = (m.flags & PH_MESH_REV) != 0, swp = (m.flags & PH_MESH_SWAP) != 0;
     if (rev != swp) si.n = -si.n;
@@ -305,8 +354,8 @@ struct Bsdf {
     float a, b;
     bool has_bxdf, oren;
 };
-PH_DEV Bsdf make_bsdf(const DeviceScene& sc, const SurfHit& si) {
-    const MaterialRec m = sc.materials[sc.meshes[sc.tri_mesh[si.prim]].material];
+PH_DEV Bsdf make_bsdf(const DeviceScene& sc, const SurfHit& si, uint32_t material) {
+    const MaterialRec m = sc.materials[material];
     Bsdf b;
     b.ns = si.ns; b.ng = si.n; b.ss = normalize(si.dpdu_s); b.ts = cross(b.ns, b.ss);
     b.r = mks(m.kd[0], m.kd[1], m.kd[2]); b.has_bxdf = m.has_bxdf != 0; b.oren = m.sigma != 0.0f; b.a = m.a; b.b = m.b;
@@ -318,9 +367,9 @@ PH_DEV f3 l2w(const Bsdf& b, f3 v) {                                            
 }
 // core/src/reflection/common.rs
 PH_DEV float sin2_theta(f3 w) { return pmaxf(0.0f, 1.0f - w.z * w.z); }
-PH_DEV float sin_theta(f3 w) { return sqrtf(sin2_theta(w)); }
-PH_DEV float cos_phi(f3 w) { float s = sin_theta(w); return s == 0.0f ? 1.0f : pclampf(w.x / s, -1.0f, 1.0f); }
-PH_DEV float sin_phi(f3 w) { float s = sin_theta(w); return s == 0.0f ? 0.0f : pclampf(w.y / s, -1.0f, 1.0f); }
+PH_DEV float sin_theta(f3 w) { return ph_sqrt(sin2_theta(w)); }
+PH_DEV float cos_phi(f3 w) { float s = sin_theta(w); return s == 0.0f ? 1.0f : pclampf(ph_div(w.x, s), -1.0f, 1.0f); }
+PH_DEV float sin_phi(f3 w) { float s = sin_theta(w); return s == 0.0f ? 0.0f : pclampf(ph_div(w.y, s), -1.0f, 1.0f); }
 PH_DEV spec bxdf_f(const Bsdf& b, f3 wo, f3 wi) {
     if (!b.oren) return b.r * kInvPi;  // lambertian_reflection.rs:38-40
     float sin_i = sin_theta(wi), sin_o = sin_theta(wo), max_cos = 0.0f;  // oren_nayar.rs:46-72
@@ -329,8 +378,8 @@ PH_DEV spec bxdf_f(const Bsdf& b, f3 wo, f3 wi) {
         max_cos = pmaxf(0.0f, d_cos);
     }
     float aco = pabs(wo.z), aci = pabs(wi.z), sin_alpha, tan_beta;
-    if (aci > aco) { sin_alpha = sin_o; tan_beta = sin_i / aci; }
-    else { sin_alpha = sin_i; tan_beta = sin_o / aco; }
+    if (aci > aco) { sin_alpha = sin_o; tan_beta = ph_div(sin_i, aci); }
+    else { sin_alpha = sin_i; tan_beta = ph_div(sin_o, aco); }
     return b.r * kInvPi * (b.a + b.b * max_cos * sin_alpha * tan_beta);
 }
 PH_DEV float bxdf_pdf(f3 wo, f3 wi) { return (wo.z * wi.z > 0.0f) ? pabs(wi.z) * kInvPi : 0.0f; }  // reflection/mod.rs:160-166
@@ -348,7 +397,7 @@ PH_DEV float bsdf_pdf(const Bsdf& b, f3 wo_w, f3 wi_w) {  // bsdf.rs:331-356
     if (wo.z == 0.0f) return 0.0f;
     float pdf = 0.0f;
     pdf += bxdf_pdf(wo, wi);
-    return pdf / 1.0f;
+    return ph_div(pdf, 1.0f);
 }
 // BSDF::sample_f (bsdf.rs:194-292) for the single-lobe case; a failed sample is BxDFSample::default() (zeros)
 PH_DEV void bsdf_sample_f(const Bsdf& b, f3 wo_w, f2 u, spec& f_out, float& pdf_out, f3& wi_out) {
@@ -393,10 +442,10 @@ PH_DEV spec light_le(const LightRec& l, f3 ray_d) {  // Light::le: InfiniteAreaL
 PH_DEV float dist2_sample_continuous(const float* func, const float* cdf, float func_int, float u, float& pdf, uint32_t& off) {
     uint32_t offset = find_interval_cdf(cdf, 3, u);
     float du = u - cdf[offset];
-    if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
-    pdf = func_int > 0.0f ? func[offset] / func_int : 0.0f;
+    if (cdf[offset + 1] - cdf[offset] > 0.0f) du = ph_div(du, cdf[offset + 1] - cdf[offset]);
+    pdf = func_int > 0.0f ? ph_div(func[offset], func_int) : 0.0f;
     off = offset;
-    return ((float)offset + du) / 2.0f;
+    return ph_div((float)offset + du, 2.0f);
 }
 
 struct LiSample { f3 wi; float pdf; spec value; f3 vp, vperr, vn; bool valid; };
@@ -416,7 +465,7 @@ PH_DEV LiSample light_sample_li(const DeviceScene& sc, const LightRec& l, const 
         d_sincos(theta, sin_theta, cos_theta);
         d_sincos(phi, sin_phi_, cos_phi_);
         r.wi = xf_vec(l.l2w, mk3(sin_theta * cos_phi_, sin_theta * sin_phi_, cos_theta));
-        r.pdf = map_pdf / (kTwoPi * kPi * sin_theta);
+        r.pdf = ph_div(map_pdf, kTwoPi * kPi * sin_theta);
         if (sin_theta == 0.0f) r.pdf = 0.0f;
         r.vp = hit.p + r.wi * (2.0f * sc.world_radius);
         r.value = infinite_lookup(l, mk2(d0, d1));
@@ -440,18 +489,18 @@ PH_DEV LiSample light_sample_li(const DeviceScene& sc, const LightRec& l, const 
         } else if (((m.flags & PH_MESH_REV) != 0) != ((m.flags & PH_MESH_SWAP) != 0)) n = n * -1.0f;
         f3 p_abs_sum = vabs(b.x * t.p0) + vabs(b.y * t.p1) + vabs((1.0f - b.x - b.y) * t.p2);
         f3 p_error = kGamma6 * mk3(p_abs_sum.x, p_abs_sum.y, p_abs_sum.z);
-        float pdf = 1.0f / l.area;
+        float pdf = ph_div(1.0f, l.area);
         f3 wi = p - hit.p;
         if (length_squared(wi) == 0.0f) pdf = 0.0f;
         else {
             wi = normalize(wi);
-            pdf *= distance_squared(hit.p, p) / abs_dot(n, -wi);
+            pdf *= ph_div(distance_squared(hit.p, p), abs_dot(n, -wi));
             if (__builtin_isinf(pdf)) pdf = 0.0f;
         }
         f3 wi2 = p - hit.p;
         float l2 = length_squared(wi2);
         if (pdf == 0.0f || l2 == 0.0f) return r;
-        wi2 = wi2 / sqrtf(l2);
+        wi2 = wi2 / ph_sqrt(l2);
         r.wi = wi2; r.pdf = pdf; r.value = area_L(l, n, -wi2); r.vp = p; r.vperr = p_error; r.vn = n; r.valid = true;
     }
     return r;
@@ -464,7 +513,7 @@ PH_DEV float light_pdf_li(const DeviceScene& sc, const LightRec& l, const SurfHi
         uint32_t iu = f2u_sat(phi * kInvTwoPi * 2.0f), iv = f2u_sat(theta * kInvPi * 2.0f);
         if (iu > 1) iu = 1;
         if (iv > 1) iv = 1;
-        return (l.cond_func[2 * iv + iu] / l.marg_int) / (kTwoPi * kPi * sin_theta);
+        return ph_div(ph_div(l.cond_func[2 * iv + iu], l.marg_int), kTwoPi * kPi * sin_theta);
     }
     if (l.type == PH_L_AREA) {  // Shape::pdf_solid_angle (core/src/geometry/shape.rs:86-107): one Triangle::intersect, no BVH
         RayIn ray = spawn_ray(hit, wi);
@@ -475,7 +524,7 @@ PH_DEV float light_pdf_li(const DeviceScene& sc, const LightRec& l, const SurfHi
         if (!tri_test(rs, t.p0, t.p1, t.p2, tt, b0, b1, b2)) return 0.0f;
         if (sc.tri_flags[l.prim] & PH_TRI_BOGUS) return 0.0f;  // test_alpha = false: only the degenerate rejection applies
         SurfHit lh = make_surface_hit(sc, wi, hit.time, l.prim, b0, b1, b2);
-        float pdf = distance_squared(hit.p, lh.p) / (abs_dot(lh.n, -wi) * l.area);
+        float pdf = ph_div(distance_squared(hit.p, lh.p), abs_dot(lh.n, -wi) * l.area);
         return __builtin_isinf(pdf) ? 0.0f : pdf;
     }
     return 0.0f;

@@ -28,7 +28,7 @@ struct alignas(64) Node64 {
 struct alignas(16) TriRec {
     float p0[3]; uint32_t prim;   // prim = index in add_mesh order
     float p1[3]; uint32_t flags;
-    float p2[3]; uint32_t pad;
+    float p2[3]; uint32_t mesh;   // mesh id (shade-side shortcut)
 };
 
 // ---- shading-side geometry (indexed by prim, add_mesh order) ---------------------------------------------------------

@@ -150,7 +150,7 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
 #ifndef PH_BATCH
 #define PH_BATCH 64
 #endif
-template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH>
+template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
     const uint32_t tid = threadIdx.x;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
     RayState r;
     uint32_t cur = PH_INVALID_REF;           // interior node index, or PH_LEAF_BIT | index of the NEXT TriRec to test
     int sp = 0;
-    uint32_t hit_prim = 0xFFFFFFFFu;
+    uint32_t hit_prim = 0xFFFFFFFFu, hit_tri = 0u;
     float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     bool occluded = false;
     uint32_t c_nodes = 0, c_tris = 0, c_rays = 0;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                         const float4 a = rp[0], b = rp[1];
                         RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = a.w; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
                         ray_setup(r, in);
-                        has_ray = true; sp = 0; hit_prim = 0xFFFFFFFFu; hb0 = hb1 = hb2 = 0.0f; occluded = false;
+                        has_ray = true; sp = 0; hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hb0 = hb1 = hb2 = 0.0f; occluded = false;
                         // root: the reference tests nodes[0].bounds first (bvh/mod.rs:189-190)
                         cur = PH_INVALID_REF;
                         if (sc.root_ref != PH_INVALID_REF) {
@@ -230,7 +230,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
             continue;
         }
 
-        // ---- one interior-node step for every lane that is at an interior node -------------------------------------------------------
+        // ---- NODE_STEPS interior-node steps for every lane that is at an interior node ---------------------------------------------------
+#pragma unroll
+        for (int step = 0; step < NODE_STEPS; step++)
         if (has_ray && cur != PH_INVALID_REF && !(cur & PH_LEAF_BIT)) {
             const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
             const float4 q0 = np[0], q1 = np[1], q2 = np[2];
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                             const uint32_t reject = ANYHIT ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
                             if (!(flags & reject)) {
                                 if (ANYHIT) occluded = true;
-                                else { r.t_max = t; hit_prim = __float_as_uint(a.w); hb0 = b0; hb1 = b1; hb2 = b2; }
+                                else { r.t_max = t; hit_prim = __float_as_uint(a.w); hit_tri = ti; hb0 = b0; hb1 = b1; hb2 = b2; }
                             }
                         }
                         if (ANYHIT && occluded) cur = PH_INVALID_REF;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
             else {
                 float4* hp = reinterpret_cast<float4*>(reinterpret_cast<HitOut*>(p.out) + ray_index);
                 hp[0] = make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1);
-                hp[1] = make_float4(hb2, 0.0f, 0.0f, 0.0f);
+                hp[1] = make_float4(hb2, __uint_as_float(hit_tri), 0.0f, 0.0f);  // pad[0] = index of the hit's TriRec (leaf order)
             }
             has_ray = false;
             if (COUNT) c_rays++;

@@ -14,6 +14,7 @@
 // Float accumulation order is the reference's: L gets Le, then each vertex's Ld in bounce order (the MIS/shadow results of
 // vertex k are folded in by the shade pass of iteration k+1 before anything of vertex k+1 is added); a pixel's FilmTile
 // sums run over its samples in (pixel row-major, sample index) order.
+#define PH_OUTLINE_MATH 1
 #include "host_math.h"
 #include "pt_device.h"
 #include "scene_host.h"
@@ -69,8 +70,8 @@ PH_DEV uint32_t wave_alloc(uint32_t* ctr, bool want) {
     return base + (uint32_t)__popcll(m & lt);
 }
 
-PH_DEV SamplerCursor cursor_for(const DeviceScene& sc, const SamplerRec& sp, int px, int py, uint32_t s, uint32_t dim) {
-    SamplerCursor c; c.px = px; c.py = py; c.dim = dim;
+PH_DEV SamplerCursor cursor_for(const DeviceScene& sc, const SamplerRec& sp, int px, int py, uint32_t s, uint32_t dim, const HaltonLds* lds = nullptr) {
+    SamplerCursor c; c.px = px; c.py = py; c.dim = dim; c.lds = lds;
     if (sp.kind == 0) c.index = (uint64_t)halton_pixel_offset(sp, px, py) + (uint64_t)s * sp.sample_stride;  // halton.rs:143
     else c.index = sobol_interval_to_index(sc, (uint32_t)sp.log2_resolution, s, px - sp.bounds[0], py - sp.bounds[1]);
     return c;
@@ -135,7 +136,12 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
     __shared__ float4 stage[3][2][PH_SHADE_BLOCK];           // [ext, mis, shadow][ray halves][thread]
     __shared__ uint32_t wave_cnt[3][PH_SHADE_BLOCK / 64];   // [cl, sh, live][wave]
     __shared__ uint32_t q_base[3];
+    __shared__ HaltonLds halton_lds;
+    __shared__ float s_u[8][PH_SHADE_BLOCK];  // the (up to) 8 sampler dimensions a vertex can consume, drawn by ONE loop
     const uint32_t n_live = w.ctr[it].n_live;
+    const HaltonLds* hl = nullptr;
+    if (w.sp.kind == 0 && blockIdx.x * blockDim.x < n_live) { halton_lds_fill(&halton_lds, sc); hl = &halton_lds; }
+    __syncthreads();
     const RayIn* rays_in = w.rays_cl[it & 1];
     RayIn* rays_out = w.rays_cl[(it + 1) & 1];
     const uint32_t* live_in = w.live[it & 1];
@@ -143,6 +149,11 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
     IterCounters* next = w.ctr + it + 1;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // "Integrator/Zero-radiance paths" counters (path.rs:18-24): kept in registers and flushed once per block — a global
+    // atomic per vertex on one address costs more than the whole vertex (one address sustains ~88 atomics/us).
+    uint32_t n_paths_total = 0, n_paths_zero = 0;
+    __shared__ uint32_t blk_stats[2];
+    if (tid < 2) blk_stats[tid] = 0;
 
     for (uint32_t base = blockIdx.x * blockDim.x; base < n_live; base += gridDim.x * blockDim.x) {
         const uint32_t i = base + tid;
@@ -176,17 +187,18 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                     const f3 wi = mk3(mr.dx, mr.dy, mr.dz);
                     spec li2 = mks1(0.0f);
                     if (hprim != 0xFFFFFFFFu) {
-                        const MeshRec m = sc.meshes[sc.tri_mesh[hprim]];
-                        if (m.first_light >= 0 && (uint32_t)m.first_light + (hprim - m.tri_base) == light_num) {
+                        const LightRec& lt = sc.lights[light_num];
+                        if (lt.type == PH_L_AREA && lt.prim == hprim) {  // the hit primitive's area light IS the sampled light
                             const float4 h1 = hp[1];
-                            SurfHit lh = make_surface_hit(sc, wi, mr.time, hprim, h0.z, h0.w, h1.x);
-                            li2 = area_L(sc.lights[light_num], lh.n, -wi);  // SurfaceInteraction::le (surface_interaction.rs:283-289)
+                            MeshRec m;
+                            SurfHit lh = make_surface_hit_rec(sc, wi, mr.time, __float_as_uint(h1.y), h0.z, h0.w, h1.x, m);
+                            li2 = area_L(lt, lh.n, -wi);  // SurfaceInteraction::le (surface_interaction.rs:283-289)
                         }
                     } else li2 = light_le(sc.lights[light_num], wi);
                     if (!is_black(li2)) est = est + mks(F4.x, F4.y, F4.z) * li2 * mks1(1.0f) * A4.w / O4.w;  // f*li*tr*weight/scattering_pdf
                 }
                 const spec ldv = mks(O4.x, O4.y, O4.z) * (est / L4.w);  // beta * (estimate / light_pdf)  (path.rs:165)
-                if (is_black(ldv)) atomicAdd(&w.stats->paths_zero, 1ull);
+                if (is_black(ldv)) n_paths_zero++;
                 L = L + ldv;
                 flags &= ~(F_PSH | F_PMIS);
             }
@@ -205,26 +217,35 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                         for (uint32_t k = 0; k < sc.n_infinite; k++) L = L + beta * light_le(sc.lights[sc.infinite_lights[k]], rd);
                 } else {
                     const float4 h1 = hp[1];
-                    const SurfHit si = make_surface_hit(sc, rd, ray.time, hprim, h0.z, h0.w, h1.x);
+                    MeshRec m;
+                    const SurfHit si = make_surface_hit_rec(sc, rd, ray.time, __float_as_uint(h1.y), h0.z, h0.w, h1.x, m);
                     if (bounces == 0) {
-                        const MeshRec m = sc.meshes[sc.tri_mesh[hprim]];
                         if (m.first_light >= 0) L = L + beta * area_L(sc.lights[(uint32_t)m.first_light + (hprim - m.tri_base)], si.n, -rd);
                         else L = L + beta * mks1(0.0f);
                     }
                     if ((int)bounces < w.max_depth) {
-                        const Bsdf bsdf = make_bsdf(sc, si);
+                        const Bsdf bsdf = make_bsdf(sc, si, m.material);
                         const int2 xy = w.px_xy[pid / w.chunk_spp];
-                        SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid % w.chunk_spp), dim);
+                        SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid % w.chunk_spp), dim, hl);
+                        // Draw the next 8 dimensions in one (not unrolled) loop: light pick 1D, u_light 2D, u_scattering 2D, BSDF 2D,
+                        // Russian roulette 1D.  li consumes a prefix of them that depends on the vertex (A4 ledger); which VALUE lands in
+                        // which role is decided below exactly as get_1d/get_2d would, only the evaluation is hoisted (one copy of the
+                        // radical-inverse code instead of ten keeps the kernel inside the instruction cache).
+#pragma unroll 1
+                        for (uint32_t k = 0; k < 8; k++) s_u[k][tid] = sampler_dim(sc, w.sp, cur, dim + k);
+                        uint32_t c = 0;  // dimensions consumed so far at this vertex
                         if (bsdf.has_bxdf) {  // num_components(all & !SPECULAR) > 0 (path.rs:161-172)
-                            atomicAdd(&w.stats->paths_total, 1ull);
+                            n_paths_total++;
                             // uniform_sample_one_light (integrator/common.rs:89-133)
                             if (sc.n_lights > 0) {
-                                const float sample = get_1d(sc, w.sp, cur);
-                                const uint32_t light_num = find_interval_cdf(sc.ld_cdf, sc.n_lights + 1, sample);  // sample_discrete
-                                pick_pdf = sc.ld_func_int > 0.0f ? sc.ld_func[light_num] / (sc.ld_func_int * (float)sc.n_lights) : 0.0f;
+                                const float sample = s_u[0][tid]; c = 1;
+                                // sample_discrete; with a single light the CDF is {0, 1} and the answer is 0 for every sample in [0,1):
+                                // keeping that case wave-uniform lets the light record be fetched with scalar loads
+                                const uint32_t light_num = (sc.n_lights == 1) ? 0u : find_interval_cdf(sc.ld_cdf, sc.n_lights + 1, sample);
+                                pick_pdf = sc.ld_func_int > 0.0f ? ph_div(sc.ld_func[light_num], sc.ld_func_int * (float)sc.n_lights) : 0.0f;
                                 if (pick_pdf != 0.0f) {
                                     const LightRec& light = sc.lights[light_num];
-                                    const f2 u_light = get_2d(sc, w.sp, cur), u_scatter = get_2d(sc, w.sp, cur);
+                                    const f2 u_light = mk2(s_u[1][tid], s_u[2][tid]), u_scatter = mk2(s_u[3][tid], s_u[4][tid]); c = 5;
                                     const bool is_delta = light.type == PH_L_DISTANT || light.type == PH_L_POINT;
                                     float w2 = 0.0f, spdf_store = 0.0f;
                                     spec A = mks1(0.0f);
@@ -269,10 +290,10 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                                     }
                                 }
                             }
-                            if (!(flags & (F_PSH | F_PMIS))) atomicAdd(&w.stats->paths_zero, 1ull);  // ld is black
+                            if (!(flags & (F_PSH | F_PMIS))) n_paths_zero++;  // ld is black
                         }
                         // sample the BSDF for the next direction (path.rs:174-206)
-                        const f2 u = get_2d(sc, w.sp, cur);
+                        const f2 u = mk2(s_u[c][tid], s_u[c + 1][tid]); c += 2;
                         spec f; float pdf; f3 wi;
                         bsdf_sample_f(bsdf, -rd, u, f, pdf, wi);
                         if (!(is_black(f) || pdf == 0.0f)) {
@@ -282,7 +303,8 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                             const spec rr_beta = beta * 1.0f;  // eta_scale stays 1 without specular transmission
                             if (max_component_value(rr_beta) < w.rr_threshold && bounces > 3) {  // path.rs:264-276
                                 const float q = pmaxf(0.05f, 1.0f - max_component_value(rr_beta));
-                                if (get_1d(sc, w.sp, cur) < q) cont = false;
+                                const float rr = s_u[c][tid]; c += 1;
+                                if (rr < q) cont = false;
                                 else beta = beta / (1.0f - q);
                             }
                             if (cont) {
@@ -291,6 +313,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                                 stage[0][1][tid] = make_float4(re.dx, re.dy, re.dz, re.time);
                             }
                         }
+                        cur.dim = dim + c;
                         dim = cur.dim;
                     }
                 }
@@ -353,6 +376,11 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
         }
         __syncthreads();  // stage / wave_cnt are reused by the next grid-stride round
     }
+    for (int o = 32; o > 0; o >>= 1) { n_paths_total += __shfl_xor(n_paths_total, o); n_paths_zero += __shfl_xor(n_paths_zero, o); }
+    if (lane == 0) { atomicAdd(&blk_stats[0], n_paths_total); atomicAdd(&blk_stats[1], n_paths_zero); }
+    __syncthreads();
+    if (tid == 0 && blk_stats[0]) atomicAdd(&w.stats->paths_total, (unsigned long long)blk_stats[0]);
+    if (tid == 1 && blk_stats[1]) atomicAdd(&w.stats->paths_zero, (unsigned long long)blk_stats[1]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -592,7 +620,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     if ((uint64_t)n_px * spp >= (1ull << 40)) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: too many samples");
 
     // ---- chunking: B = n_px * chunk_spp paths in flight ----------------------------------------------------------------------
-    size_t max_paths = 8u << 20;
+    size_t max_paths = 32u << 20;
     if (const char* e = std::getenv("PBRT_HIP_MAX_PATHS")) { long v = std::atol(e); if (v > 0) max_paths = (size_t)v; }
     uint32_t chunk_spp = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, max_paths / std::max<uint32_t>(n_px, 1)));
     const size_t B = (size_t)n_px * chunk_spp;
