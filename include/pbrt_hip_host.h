@@ -33,6 +33,10 @@ void pbrt_hip_host_perspective_raster_to_camera(float fov_deg, int xres, int yre
 /* Film::new with a BoxFilter + Film::get_sample_bounds (core/src/film/mod.rs:89-159, filters/src/boxf.rs) */
 void pbrt_hip_host_film_box(int xres, int yres, const float crop_window[4], const float radius[2], int out_cropped_bounds[4],
                             float out_table[256], int out_sample_bounds[4]);
+/* Same for every filter of filters/src: kind 0 box, 1 gaussian {alpha}, 2 mitchell {B,C}, 3 sinc {tau}, 4 triangle
+ * (boxf.rs:31-47, gaussian.rs:33-62, mitchell.rs:36-80, sinc.rs:31-82, triangle.rs:28-45).  -1 on an unknown kind. */
+int pbrt_hip_host_film_filter(int kind, const float params[2], int xres, int yres, const float crop_window[4],
+                              const float radius[2], int out_cropped_bounds[4], float out_table[256], int out_sample_bounds[4]);
 /* Transform::transform_point / _vector / _normal (transform.rs:288-302,373-380,441-448), n elements of 3 floats */
 void pbrt_hip_host_transform_points(const float m[16], const float* in, float* out, size_t n);
 void pbrt_hip_host_transform_vectors(const float m[16], const float* in, float* out, size_t n);

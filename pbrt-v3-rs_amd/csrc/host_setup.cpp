@@ -105,6 +105,53 @@ void pbrt_hip_host_film_box(int xres, int yres, const float crop_window[4] /*x0 
     out_sample_bounds[3] = sat(std::ceil((float)out_cropped_bounds[3] - 0.5f + radius[1]));
 }
 
+// Film::new's 16x16 table (film/mod.rs:113-129) for every reconstruction filter the reference ships:
+//   kind 0 box (filters/src/boxf.rs:31-47)            params unused
+//   kind 1 gaussian (gaussian.rs:33-62)               params[0] = alpha
+//   kind 2 mitchell (mitchell.rs:36-80)               params = {B, C}; keeps the reference's constant term
+//                                                     (8*C + 24*C) of the |x|>1 branch as written there (:47)
+//   kind 3 sinc / Lanczos (sinc.rs:31-82)             params[0] = tau
+//   kind 4 triangle (triangle.rs:28-45)
+// Returns -1 for an unknown kind.  exp/sin are the host libm's f32 routines, as they are for the reference's host.
+int pbrt_hip_host_film_filter(int kind, const float params[2], int xres, int yres, const float crop_window[4], const float radius[2],
+                              int out_cropped_bounds[4], float out_table[256], int out_sample_bounds[4]) {
+    if (kind < 0 || kind > 4) return -1;
+    pbrt_hip_host_film_box(xres, yres, crop_window, radius, out_cropped_bounds, out_table, out_sample_bounds);
+    const float rx = radius[0], ry = radius[1];
+    const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;  // FilterData::new (core/src/filter.rs)
+    const float a = params ? params[0] : 0.0f, b = params ? params[1] : 0.0f;
+    auto fabs_ = [](float v) { return v < 0.0f ? -v : v; };
+    auto fmax_ = [](float x, float y) { return x > y ? x : y; };
+    auto gauss = [&](float d, float expv) { return fmax_(0.0f, std::exp(-a * d * d) - expv); };
+    auto mitchell = [&](float x0) {
+        const float B = a, Cc = b;
+        float x = fabs_(2.0f * x0);
+        if (x > 1.0f)
+            return ((-B - 6.0f * Cc) * x * x * x + (6.0f * B + 30.0f * Cc) * x * x + (-12.0f * B - 48.0f * Cc) * x + (8.0f * Cc + 24.0f * Cc)) * (1.0f / 6.0f);
+        return ((12.0f - 9.0f * B - 6.0f * Cc) * x * x * x + (-18.0f + 12.0f * B + 6.0f * Cc) * x * x + (6.0f - 2.0f * B)) * (1.0f / 6.0f);
+    };
+    const float PI_F = 3.14159265358979323846f;
+    auto sinc = [&](float x0) { float x = fabs_(x0); return x < 1e-5f ? 1.0f : std::sin(PI_F * x) / (PI_F * x); };
+    auto wsinc = [&](float x0, float r) { float x = fabs_(x0); if (x > r) return 0.0f; float l = sinc(x / a); return sinc(x) * l; };
+    const float exp_x = kind == 1 ? std::exp(-a * rx * rx) : 0.0f, exp_y = kind == 1 ? std::exp(-a * ry * ry) : 0.0f;
+    const float inv_w = 1.0f / 16.0f;  // INV_FILTER_TABLE_WIDTH
+    int o = 0;
+    for (int y = 0; y < 16; y++)
+        for (int x = 0; x < 16; x++, o++) {
+            const float px = ((float)x + 0.5f) * rx * inv_w, py = ((float)y + 0.5f) * ry * inv_w;
+            float v = 1.0f;
+            switch (kind) {
+                case 1: v = gauss(px, exp_x) * gauss(py, exp_y); break;
+                case 2: v = mitchell(px * inv_rx) * mitchell(py * inv_ry); break;
+                case 3: v = wsinc(px, rx) * wsinc(py, ry); break;
+                case 4: v = fmax_(0.0f, rx - fabs_(px)) * fmax_(0.0f, ry - fabs_(py)); break;
+                default: break;
+            }
+            out_table[o] = v;
+        }
+    return 0;
+}
+
 // transform_point / transform_vector / transform_normal (transform.rs:288-302,373-380,441-448) for mesh vertices:
 // TriangleMesh::new moves P, N, S to world space once (triangle.rs:93-99).
 void pbrt_hip_host_transform_points(const float m[16], const float* in, float* out, size_t n) {

@@ -1,0 +1,514 @@
+// Host-side scene API over the C ABI.  See pbrt_host.hpp for scope; reference: api/src/lib.rs, api/src/graphics_state.rs.
+#include "pbrt_host.hpp"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+
+namespace pbrt_host {
+
+// ------------------------------------------------------------------------------------------------ ParamSet
+float ParamSet::find_one_float(const std::string& n, float d) const {
+    auto it = floats.find(n);
+    return (it != floats.end() && it->second.size() == 1) ? it->second[0] : d;  // paramset: one-value lookups need exactly one
+}
+int ParamSet::find_one_int(const std::string& n, int d) const {
+    auto it = ints.find(n);
+    return (it != ints.end() && it->second.size() == 1) ? it->second[0] : d;
+}
+bool ParamSet::find_one_bool(const std::string& n, bool d) const {
+    auto it = bools.find(n);
+    return (it != bools.end() && it->second.size() == 1) ? it->second[0] : d;
+}
+std::string ParamSet::find_one_string(const std::string& n, const std::string& d) const {
+    auto it = strings.find(n);
+    return (it != strings.end() && it->second.size() == 1) ? it->second[0] : d;
+}
+std::string ParamSet::find_one_texture(const std::string& n) const {
+    auto it = textures.find(n);
+    return (it != textures.end() && it->second.size() == 1) ? it->second[0] : std::string();
+}
+const std::vector<float>* ParamSet::find_floats(const std::string& n) const {
+    auto it = floats.find(n);
+    return it == floats.end() ? nullptr : &it->second;
+}
+const std::vector<int>* ParamSet::find_ints(const std::string& n) const {
+    auto it = ints.find(n);
+    return it == ints.end() ? nullptr : &it->second;
+}
+std::array<float, 3> ParamSet::find_one_rgb(const std::string& n, std::array<float, 3> d) const {
+    auto it = floats.find(n);
+    if (it == floats.end() || it->second.size() != 3) return d;
+    return {it->second[0], it->second[1], it->second[2]};
+}
+
+// ------------------------------------------------------------------------------------------------ Api
+static Xform identity_xform() {
+    Xform x{};
+    for (int i = 0; i < 4; i++) x.m[i * 5] = x.mi[i * 5] = 1.0f;
+    return x;
+}
+
+// device < 0 = check mode: directives are parsed, validated and counted, nothing is sent to the library and nothing is
+// rendered (there is no CPU renderer to fall back to).
+#define ABI(call) (check_only_ ? (int)PBRT_HIP_OK : (call))
+
+Api::Api(int device) : check_only_(device < 0), ctm_(identity_xform()), camera_to_world_(identity_xform()) {
+    if (check_only_) return;
+    scene_ = pbrt_hip_scene_create(device);
+    if (!scene_) {
+        const char* e = pbrt_hip_last_error(nullptr);
+        error = std::string("no usable gfx950 device: ") + (e ? e : "");
+    }
+}
+Api::~Api() {
+    if (scene_) pbrt_hip_scene_destroy(scene_);
+}
+
+void Api::warn(const std::string& w) {
+    warnings.push_back(w);
+    if (!quiet) std::fprintf(stderr, "Warning: %s\n", w.c_str());
+}
+bool Api::check(int rc, const char* what) {
+    if (rc == PBRT_HIP_OK) return true;
+    if (error.empty()) {
+        const char* e = scene_ ? pbrt_hip_last_error(scene_) : nullptr;
+        error = std::string(what) + " failed (" + std::to_string(rc) + "): " + (e ? e : "");
+    }
+    return false;
+}
+// `ctm = ctm * t` for every active transform (api/src/lib.rs:140-152); the time-1 copy is dead on this path.
+void Api::concat(const Xform& t) {
+    Xform r;
+    pbrt_hip_host_compose(ctm_.m, ctm_.mi, t.m, t.mi, r.m, r.mi);
+    ctm_ = r;
+}
+
+void Api::pbrt_identity() { ctm_ = identity_xform(); }
+void Api::pbrt_translate(float dx, float dy, float dz) {
+    Xform t; const float d[3] = {dx, dy, dz};
+    pbrt_hip_host_translate(d, t.m, t.mi);
+    concat(t);
+}
+void Api::pbrt_rotate(float angle, float dx, float dy, float dz) {
+    Xform t; const float a[3] = {dx, dy, dz};
+    pbrt_hip_host_rotate(angle, a, t.m, t.mi);
+    concat(t);
+}
+void Api::pbrt_scale(float sx, float sy, float sz) {
+    Xform t; const float s[3] = {sx, sy, sz};
+    pbrt_hip_host_scale(s, t.m, t.mi);
+    concat(t);
+}
+void Api::pbrt_look_at(float ex, float ey, float ez, float lx, float ly, float lz, float ux, float uy, float uz) {
+    Xform t; const float e[3] = {ex, ey, ez}, l[3] = {lx, ly, lz}, u[3] = {ux, uy, uz};
+    if (pbrt_hip_host_look_at(e, l, u, t.m, t.mi) != 0) {
+        // transform.rs:173-181: "up" and the viewing direction are collinear -> identity with an error message
+        warn("LookAt: up vector and viewing direction are pointing in the same direction; using the identity transformation");
+        t = identity_xform();
+    }
+    concat(t);
+}
+// The file format hands matrices over column-major; Matrix4x4::new takes rows (api/src/lib.rs:208-262).
+static Xform from_column_major(const float tr[16]) {
+    Xform t;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) t.m[r * 4 + c] = tr[c * 4 + r];
+    pbrt_hip_host_invert(t.m, t.mi);
+    return t;
+}
+void Api::pbrt_concat_transform(const float tr[16]) { concat(from_column_major(tr)); }
+void Api::pbrt_transform(const float tr[16]) { ctm_ = from_column_major(tr); }
+void Api::pbrt_coordinate_system(const std::string& name) { named_cs_[name] = ctm_; }
+void Api::pbrt_coord_sys_transform(const std::string& name) {
+    auto it = named_cs_.find(name);
+    if (it != named_cs_.end()) ctm_ = it->second;
+    else warn("Couldn't find named coordinate system '" + name + "'");
+}
+
+// verify_options / verify_world (api/src/lib.rs:1003-1050): a directive in the wrong block is reported and ignored.
+bool Api::verify_options(const char* func) {
+    if (!world_block_) return true;
+    warn(std::string("Options cannot be set inside world block; '") + func + "' not allowed. Ignoring.");
+    return false;
+}
+bool Api::verify_world(const char* func) {
+    if (world_block_) return true;
+    warn(std::string("Scene description must be inside world block; '") + func + "' not allowed. Ignoring.");
+    return false;
+}
+
+void Api::pbrt_pixel_filter(const std::string& name, const ParamSet& p) { if (verify_options("PixelFilter")) { filter_name_ = name; filter_p_ = p; } }
+void Api::pbrt_film(const std::string& type, const ParamSet& p) { if (verify_options("Film")) { film_name_ = type; film_p_ = p; } }
+void Api::pbrt_sampler(const std::string& name, const ParamSet& p) { if (verify_options("Sampler")) { sampler_name_ = name; sampler_p_ = p; } }
+void Api::pbrt_accelerator(const std::string& name, const ParamSet& p) { if (verify_options("Accelerator")) { accel_name_ = name; accel_p_ = p; } }
+void Api::pbrt_integrator(const std::string& name, const ParamSet& p) { if (verify_options("Integrator")) { integrator_name_ = name; integrator_p_ = p; } }
+void Api::pbrt_camera(const std::string& name, const ParamSet& p) {
+    if (!verify_options("Camera")) return;
+    camera_name_ = name; camera_p_ = p;
+    // camera_to_world = inverse(ctm): swap m and m_inv (api/src/lib.rs:376-392)
+    std::memcpy(camera_to_world_.m, ctm_.mi, sizeof ctm_.mi);
+    std::memcpy(camera_to_world_.mi, ctm_.m, sizeof ctm_.m);
+    named_cs_["camera"] = camera_to_world_;
+}
+
+void Api::pbrt_world_begin() {
+    if (!verify_options("WorldBegin")) return;
+    world_block_ = true;
+    ctm_ = identity_xform();
+    named_cs_["world"] = ctm_;
+}
+void Api::pbrt_attribute_begin() { if (!verify_world("AttributeBegin")) return; gs_stack_.push_back(gs_); ctm_stack_.push_back(ctm_); }
+void Api::pbrt_attribute_end() {
+    if (!verify_world("AttributeEnd")) return;
+    if (gs_stack_.empty()) { warn("Unmatched AttributeEnd encountered. Ignoring it."); return; }
+    gs_ = gs_stack_.back(); gs_stack_.pop_back();
+    ctm_ = ctm_stack_.back(); ctm_stack_.pop_back();
+}
+void Api::pbrt_transform_begin() { if (!verify_world("TransformBegin")) return; ctm_stack_.push_back(ctm_); }
+void Api::pbrt_transform_end() {
+    if (!verify_world("TransformEnd")) return;
+    if (ctm_stack_.size() <= gs_stack_.size()) { warn("Unmatched TransformEnd encountered. Ignoring it."); return; }
+    ctm_ = ctm_stack_.back(); ctm_stack_.pop_back();
+}
+
+void Api::pbrt_texture(const std::string& name, const std::string& type, const std::string& tex_class, const ParamSet& p) {
+    if (!verify_world("Texture")) return;
+    const bool is_float = type == "float", is_spec = type == "color" || type == "spectrum";
+    if (!is_float && !is_spec) { warn("Texture type '" + type + "' unknown."); return; }
+    if (tex_class != "constant") {  // the device evaluates constant textures only (SURVEY §8f "next")
+        gs_.unsupported_textures[name] = tex_class;
+        gs_.float_textures.erase(name); gs_.spectrum_textures.erase(name);
+        return;
+    }
+    gs_.unsupported_textures.erase(name);
+    if (is_float) gs_.float_textures[name] = p.find_one_float("value", 1.0f);
+    else gs_.spectrum_textures[name] = p.find_one_rgb("value", {1.0f, 1.0f, 1.0f});
+}
+void Api::pbrt_material(const std::string& name, const ParamSet& p) { if (!verify_world("Material")) return; gs_.material.type = name; gs_.material.params = p; }
+void Api::pbrt_make_named_material(const std::string& name, const ParamSet& p) {
+    if (!verify_world("MakeNamedMaterial")) return;
+    MaterialDesc m; m.type = p.find_one_string("type", ""); m.params = p;
+    if (m.type.empty()) { warn("No parameter string \"type\" found in MakeNamedMaterial"); return; }
+    gs_.named_materials[name] = m;
+}
+void Api::pbrt_named_material(const std::string& name) {
+    if (!verify_world("NamedMaterial")) return;
+    auto it = gs_.named_materials.find(name);
+    if (it == gs_.named_materials.end()) { warn("NamedMaterial \"" + name + "\" unknown."); return; }
+    gs_.material = it->second;
+}
+void Api::pbrt_reverse_orientation() { if (!verify_world("ReverseOrientation")) return; gs_.reverse_orientation = !gs_.reverse_orientation; }
+
+static std::array<float, 3> mul3(std::array<float, 3> a, std::array<float, 3> b) { return {a[0] * b[0], a[1] * b[1], a[2] * b[2]}; }
+
+void Api::pbrt_light_source(const std::string& name, const ParamSet& p) {
+    if (!verify_world("LightSource") || !error.empty() || (!scene_ && !check_only_)) return;
+    for (auto& u : p.unsupported) { error = "LightSource \"" + name + "\": parameter '" + u + "' has a spectral type this host cannot evaluate"; return; }
+    const std::array<float, 3> one = {1.0f, 1.0f, 1.0f};
+    const std::array<float, 3> sc = p.find_one_rgb("scale", one);
+    if (name == "infinite" || name == "exinfinite") {
+        if (!p.find_one_string("mapname", "").empty()) { error = "LightSource \"infinite\": environment maps ('mapname') are outside the hot-path scope"; return; }
+        auto L = mul3(p.find_one_rgb("L", one), sc);
+        if (check(ABI(pbrt_hip_add_light_infinite(scene_, L.data(), ctm_.m, ctm_.mi)), "add_light_infinite")) n_lights_++;
+    } else if (name == "distant") {
+        auto L = mul3(p.find_one_rgb("L", one), sc);
+        auto from = p.find_one_rgb("from", {0.0f, 0.0f, 0.0f}), to = p.find_one_rgb("to", {0.0f, 0.0f, 1.0f});
+        float w[3];
+        pbrt_hip_host_distant_direction(ctm_.m, from.data(), to.data(), w);
+        if (check(ABI(pbrt_hip_add_light_distant(scene_, L.data(), w)), "add_light_distant")) n_lights_++;
+    } else if (name == "point") {
+        auto I = mul3(p.find_one_rgb("I", one), sc);
+        auto from = p.find_one_rgb("from", {0.0f, 0.0f, 0.0f});
+        float pw[3];
+        pbrt_hip_host_point_position(ctm_.m, ctm_.mi, from.data(), pw);
+        if (check(ABI(pbrt_hip_add_light_point(scene_, I.data(), pw)), "add_light_point")) n_lights_++;
+    } else {
+        error = "LightSource \"" + name + "\" is outside the hot-path scope (supported: infinite, distant, point, and diffuse area lights)";
+    }
+}
+void Api::pbrt_area_light_source(const std::string& name, const ParamSet& p) { if (!verify_world("AreaLightSource")) return; gs_.area_light = name; gs_.area_light_params = p; }
+
+// MatteMaterial From<&TextureParams> (materials/src/matte.rs:95-110) with TextureParams's lookup order: shape parameters
+// first, then the material's own (core/src/paramset/texture_params.rs).
+uint32_t Api::material_id_for(const MaterialDesc& m) {
+    char key[160];
+    std::array<float, 3> kd = {0.5f, 0.5f, 0.5f};
+    float sigma = 0.0f;
+    auto spectrum_tex = [&](const std::string& pname, std::array<float, 3> d) {
+        std::string tn = m.params.find_one_texture(pname);
+        if (!tn.empty()) {
+            auto it = gs_.spectrum_textures.find(tn);
+            if (it != gs_.spectrum_textures.end()) return it->second;
+            auto un = gs_.unsupported_textures.find(tn);
+            if (un != gs_.unsupported_textures.end() && error.empty())
+                error = "texture '" + tn + "' of class '" + un->second + "' is outside the hot-path scope (constant textures only)";
+            else if (error.empty()) warn("Couldn't find spectrum texture named '" + tn + "' for parameter '" + pname + "'");
+        }
+        return m.params.find_one_rgb(pname, d);
+    };
+    auto float_tex = [&](const std::string& pname, float d) {
+        std::string tn = m.params.find_one_texture(pname);
+        if (!tn.empty()) {
+            auto it = gs_.float_textures.find(tn);
+            if (it != gs_.float_textures.end()) return it->second;
+            auto un = gs_.unsupported_textures.find(tn);
+            if (un != gs_.unsupported_textures.end() && error.empty())
+                error = "texture '" + tn + "' of class '" + un->second + "' is outside the hot-path scope (constant textures only)";
+            else if (error.empty()) warn("Couldn't find float texture named '" + tn + "' for parameter '" + pname + "'");
+        }
+        return m.params.find_one_float(pname, d);
+    };
+    kd = spectrum_tex("Kd", kd);
+    sigma = float_tex("sigma", sigma);
+    if (!m.params.find_one_texture("bumpmap").empty() && error.empty()) error = "matte 'bumpmap' is outside the hot-path scope";
+    uint32_t kb[4]; std::memcpy(kb, kd.data(), 12); std::memcpy(&kb[3], &sigma, 4);
+    std::snprintf(key, sizeof key, "matte:%08x:%08x:%08x:%08x", kb[0], kb[1], kb[2], kb[3]);
+    auto it = material_cache_.find(key);
+    if (it != material_cache_.end()) return it->second;
+    uint32_t id = 0;
+    if (!check(ABI(pbrt_hip_add_material_matte(scene_, kd.data(), sigma, &id)), "add_material_matte")) return 0;
+    material_cache_[key] = id;
+    return id;
+}
+
+void Api::pbrt_shape(const std::string& name, const ParamSet& p, const std::string& scene_dir) {
+    if (!verify_world("Shape") || !error.empty() || (!scene_ && !check_only_)) return;
+    std::vector<float> P, N, S, UV;
+    std::vector<uint32_t> idx;
+    if (name == "trianglemesh") {  // shapes/src/triangle.rs:184-330
+        const std::vector<int>* vi = p.find_ints("indices");
+        const std::vector<float>* pp = p.find_floats("P");
+        if (!vi || vi->empty()) { warn("Vertex indices 'indices' not provided with triangle mesh shape"); return; }
+        if (!pp || pp->empty()) { warn("Vertex positions 'P' not provided with triangle mesh shape"); return; }
+        const size_t npi = pp->size() / 3;
+        P.assign(pp->begin(), pp->begin() + npi * 3);
+        const std::vector<float>* uv = p.find_floats("uv");
+        if (!uv || uv->empty()) uv = p.find_floats("st");
+        if (uv && !uv->empty()) {
+            const size_t nuv = uv->size() / 2;
+            if (nuv < npi) warn("Not enough of 'uv' for triangle mesh. Discarding.");
+            else { if (nuv > npi) warn("More 'uv' provided than will be used for triangle mesh."); UV.assign(uv->begin(), uv->begin() + npi * 2); }
+        }
+        if (const std::vector<float>* s = p.find_floats("S")) {
+            if (s->size() / 3 != npi) warn("Number of 'S' for triangle mesh must match 'P'."); else S = *s;
+        }
+        if (const std::vector<float>* n = p.find_floats("N")) {
+            if (n->size() / 3 != npi) warn("Number of 'N' for triangle mesh must match 'P'."); else N = *n;
+        }
+        for (int v : *vi)
+            if (v < 0 || (size_t)v >= npi) { warn("trianglemesh has out-of-bounds vertex index " + std::to_string(v)); return; }
+        idx.assign(vi->begin(), vi->end());
+        idx.resize(idx.size() / 3 * 3);
+    } else if (name == "plymesh") {  // shapes/src/plymesh.rs:21-141
+        std::string fn = p.find_one_string("filename", "");
+        if (fn.empty()) { error = "plymesh: no 'filename' parameter"; return; }
+        if (fn[0] != '/' && !scene_dir.empty()) fn = scene_dir + "/" + fn;
+        PlyMesh mesh; std::string err;
+        if (!read_ply(fn, mesh, err)) { error = "Unable to parse PLY file '" + fn + "'. " + err; return; }
+        if (mesh.P.empty() || mesh.indices.empty()) { warn("PLY file '" + fn + "' is invalid! No face/vertex elements found!"); return; }
+        P.swap(mesh.P); N.swap(mesh.N); UV.swap(mesh.UV); idx.swap(mesh.indices);
+    } else {
+        error = "Shape \"" + name + "\" is outside the hot-path scope (supported: trianglemesh, plymesh)";
+        return;
+    }
+    // alpha / shadowalpha: constant float textures only (triangle.rs:278-312)
+    auto alpha_of = [&](const char* pname) {
+        std::string tn = p.find_one_texture(pname);
+        if (!tn.empty()) {
+            auto it = gs_.float_textures.find(tn);
+            if (it != gs_.float_textures.end()) return it->second;
+            auto un = gs_.unsupported_textures.find(tn);
+            if (un != gs_.unsupported_textures.end()) { if (error.empty()) error = std::string("'") + pname + "' texture '" + tn + "' of class '" + un->second + "' is outside the hot-path scope"; }
+            else warn("Couldn't find float texture '" + tn + "' for '" + pname + "' parameter. Using float parameter instead.");
+        }
+        return p.find_one_float(pname, 1.0f);
+    };
+    const float alpha = alpha_of("alpha"), shadow_alpha = alpha_of("shadowalpha");
+    if (!error.empty()) return;
+
+    // material: shape parameters override the material's (graphics_state.rs:147-165)
+    if (gs_.material.type != "matte") {
+        error = "Material \"" + gs_.material.type + "\" is outside the hot-path scope (supported: matte)";
+        return;
+    }
+    MaterialDesc eff = gs_.material;
+    for (auto& kv : p.floats) if (kv.first == "Kd" || kv.first == "sigma") eff.params.floats[kv.first] = kv.second;
+    for (auto& kv : p.textures) if (kv.first == "Kd" || kv.first == "sigma" || kv.first == "bumpmap") eff.params.textures[kv.first] = kv.second;
+    for (auto& kv : p.textures) if (kv.first == "Kd" || kv.first == "sigma") eff.params.floats.erase(kv.first);
+    const uint32_t mat = material_id_for(eff);
+    if (!error.empty()) return;
+
+    // TriangleMesh::new moves the vertices to world space once (triangle.rs:93-99)
+    const size_t nv = P.size() / 3;
+    std::vector<float> Pw(P.size());
+    pbrt_hip_host_transform_points(ctm_.m, P.data(), Pw.data(), nv);
+    if (!N.empty()) { std::vector<float> t(N.size()); pbrt_hip_host_transform_normals(ctm_.mi, N.data(), t.data(), nv); N.swap(t); }
+    if (!S.empty()) { std::vector<float> t(S.size()); pbrt_hip_host_transform_vectors(ctm_.m, S.data(), t.data(), nv); S.swap(t); }
+    const uint32_t n_tris = (uint32_t)(idx.size() / 3);
+    const uint32_t flags = (gs_.reverse_orientation ? 1u : 0u) | (pbrt_hip_host_swaps_handedness(ctm_.m) ? 2u : 0u);
+
+    int32_t first_light = -1;
+    if (!gs_.area_light.empty()) {  // one DiffuseAreaLight per triangle, numbered where the Shape directive stands (lib.rs:783-812)
+        if (gs_.area_light != "diffuse" && gs_.area_light != "area") { error = "AreaLightSource \"" + gs_.area_light + "\" unknown"; return; }
+        const ParamSet& ap = gs_.area_light_params;
+        for (auto& u : ap.unsupported) { error = "AreaLightSource: parameter '" + u + "' has a spectral type this host cannot evaluate"; return; }
+        auto L = mul3(ap.find_one_rgb("L", {1.0f, 1.0f, 1.0f}), ap.find_one_rgb("scale", {1.0f, 1.0f, 1.0f}));
+        uint32_t id = 0;
+        if (!check(ABI(pbrt_hip_add_light_diffuse_area(scene_, L.data(), ap.find_one_bool("twosided", false) ? 1 : 0, n_tris, &id)), "add_light_diffuse_area")) return;
+        first_light = (int32_t)id;
+        n_lights_ += n_tris;
+    }
+    if (!check(ABI(pbrt_hip_add_mesh(scene_, Pw.data(), (uint32_t)nv, idx.data(), n_tris, N.empty() ? nullptr : N.data(), S.empty() ? nullptr : S.data(),
+                                 UV.empty() ? nullptr : UV.data(), mat, first_light, flags, alpha, shadow_alpha)), "add_mesh")) return;
+    n_tris_ += n_tris;
+}
+
+static bool ends_with(const std::string& s, const std::string& suf) { return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0; }
+
+int Api::pbrt_world_end(RenderReport& rep) {
+    using clk = std::chrono::steady_clock;
+    if (!scene_ && !check_only_) return PBRT_HIP_ERR_NO_DEVICE;
+    if (!error.empty()) return PBRT_HIP_ERR_UNSUPPORTED;
+    if (!verify_world("WorldEnd")) { error = "WorldEnd outside a world block"; return PBRT_HIP_ERR_STATE; }
+    while (!gs_stack_.empty()) { warn("Missing end to AttributeBegin"); pbrt_attribute_end(); }
+    while (!ctm_stack_.empty()) { warn("Missing end to TransformBegin"); ctm_stack_.pop_back(); }
+
+    // ---- filter + film (make_filter / make_film, graphics_state.rs:600-690; film/mod.rs:420-487)
+    int fkind = -1; float rad[2] = {0.5f, 0.5f}, fparams[2] = {0.0f, 0.0f};
+    if (filter_name_ == "box") { fkind = 0; rad[0] = filter_p_.find_one_float("xwidth", 0.5f); rad[1] = filter_p_.find_one_float("ywidth", 0.5f); }
+    else if (filter_name_ == "gaussian") { fkind = 1; rad[0] = filter_p_.find_one_float("xwidth", 2.0f); rad[1] = filter_p_.find_one_float("ywidth", 2.0f); fparams[0] = filter_p_.find_one_float("alpha", 2.0f); }
+    else if (filter_name_ == "mitchell") { fkind = 2; rad[0] = filter_p_.find_one_float("xwidth", 2.0f); rad[1] = filter_p_.find_one_float("ywidth", 2.0f); fparams[0] = filter_p_.find_one_float("B", 1.0f / 3.0f); fparams[1] = filter_p_.find_one_float("C", 1.0f / 3.0f); }
+    else if (filter_name_ == "sinc") { fkind = 3; rad[0] = filter_p_.find_one_float("xwidth", 4.0f); rad[1] = filter_p_.find_one_float("ywidth", 4.0f); fparams[0] = filter_p_.find_one_float("tau", 3.0f); }
+    else if (filter_name_ == "triangle") { fkind = 4; rad[0] = filter_p_.find_one_float("xwidth", 2.0f); rad[1] = filter_p_.find_one_float("ywidth", 2.0f); }
+    else { error = "Filter \"" + filter_name_ + "\" unknown."; return PBRT_HIP_ERR_UNSUPPORTED; }
+    if (film_name_ != "image") { error = "Film \"" + film_name_ + "\" unknown."; return PBRT_HIP_ERR_UNSUPPORTED; }
+    const int xres = film_p_.find_one_int("xresolution", 1280), yres = film_p_.find_one_int("yresolution", 720);
+    float crop[4] = {0.0f, 1.0f, 0.0f, 1.0f};
+    auto clamp01 = [](float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); };
+    if (const std::vector<float>* cr = film_p_.find_floats("cropwindow")) {
+        if (cr->size() != 4) { error = std::to_string(cr->size()) + " values supplied for 'cropwindow'. Expected 4."; return PBRT_HIP_ERR_INVALID_ARG; }
+        const float* c = cr->data();
+        crop[0] = clamp01(c[0] < c[1] ? c[0] : c[1]); crop[1] = clamp01(c[0] > c[1] ? c[0] : c[1]);
+        crop[2] = clamp01(c[2] < c[3] ? c[2] : c[3]); crop[3] = clamp01(c[2] > c[3] ? c[2] : c[3]);
+    } else if (has_crop_override) {
+        for (int i = 0; i < 4; i++) crop[i] = clamp01(crop_override[i]);
+    }
+    std::string filename = film_p_.find_one_string("filename", "pbrt.exr");
+    if (!override_outfile.empty()) {
+        if (film_p_.strings.count("filename")) warn("Output filename supplied on command line, '" + override_outfile + "' is overriding filename provided in scene description file, '" + filename + "'.");
+        filename = override_outfile;
+    }
+    if (!ends_with(filename, ".pfm")) {  // this host writes PFM only (image_io.rs:336-374); EXR/PNG/TGA encoders are out of scope
+        size_t dot = filename.find_last_of('.'), slash = filename.find_last_of('/');
+        std::string stem = (dot != std::string::npos && (slash == std::string::npos || dot > slash)) ? filename.substr(0, dot) : filename;
+        warn("Image format of '" + filename + "' is not written by this host; writing '" + stem + ".pfm' instead.");
+        filename = stem + ".pfm";
+    }
+    const float film_scale = film_p_.find_one_float("scale", 1.0f);
+    const float max_lum = film_p_.find_one_float("maxsampleluminance", std::numeric_limits<float>::infinity());
+    int cb[4], sb[4]; float table[256];
+    if (pbrt_hip_host_film_filter(fkind, fparams, xres, yres, crop, rad, cb, table, sb) != 0) { error = "film filter set-up failed"; return PBRT_HIP_ERR_INVALID_ARG; }
+    if (!check(ABI(pbrt_hip_set_film(scene_, xres, yres, cb, rad, table, film_scale, max_lum)), "set_film")) return PBRT_HIP_ERR_INVALID_ARG;
+
+    // ---- camera (perspective_camera.rs:358-419)
+    if (camera_name_ != "perspective") { error = "Camera \"" + camera_name_ + "\" is outside the hot-path scope (supported: perspective)"; return PBRT_HIP_ERR_UNSUPPORTED; }
+    float shutter_open = camera_p_.find_one_float("shutteropen", 0.0f), shutter_close = camera_p_.find_one_float("shutterclose", 1.0f);
+    if (shutter_close < shutter_open) { warn("Shutter close time < shutter open. Swapping them."); std::swap(shutter_open, shutter_close); }
+    const float lens_radius = camera_p_.find_one_float("lensradius", 0.0f), focal_distance = camera_p_.find_one_float("focaldistance", 1e6f);
+    const float frame = camera_p_.find_one_float("frameaspectratio", (float)xres / (float)yres);
+    float screen[4];
+    if (frame > 1.0f) { screen[0] = -frame; screen[1] = frame; screen[2] = -1.0f; screen[3] = 1.0f; }
+    else { screen[0] = -1.0f; screen[1] = 1.0f; screen[2] = -1.0f / frame; screen[3] = 1.0f / frame; }
+    if (const std::vector<float>* sw = camera_p_.find_floats("screenwindow")) {
+        if (sw->size() == 4) for (int i = 0; i < 4; i++) screen[i] = (*sw)[i];
+        else warn("'screenwindow' should have four values");
+    }
+    float fov = camera_p_.find_one_float("fov", 90.0f);
+    const float half_fov = camera_p_.find_one_float("halffov", -1.0f);
+    if (half_fov > 0.0f) fov = 2.0f * half_fov;
+    float r2c[16];
+    pbrt_hip_host_perspective_raster_to_camera(fov, xres, yres, screen, r2c);
+    if (!check(ABI(pbrt_hip_set_camera_perspective(scene_, r2c, camera_to_world_.m, lens_radius, focal_distance, shutter_open, shutter_close)), "set_camera_perspective")) return PBRT_HIP_ERR_INVALID_ARG;
+
+    // ---- sampler (halton.rs:272-290, sobol.rs:201-214)
+    int skind;
+    if (sampler_name_ == "halton") skind = 0;
+    else if (sampler_name_ == "sobol") skind = 1;
+    else { error = "Sampler \"" + sampler_name_ + "\" is outside the hot-path scope (supported: halton, sobol)"; return PBRT_HIP_ERR_UNSUPPORTED; }
+    const int spp = sampler_p_.find_one_int("pixelsamples", 16);
+    if (spp <= 0) { error = "pixelsamples must be positive"; return PBRT_HIP_ERR_INVALID_ARG; }
+    if (!check(ABI(pbrt_hip_set_sampler(scene_, skind, (uint32_t)spp, sb, sampler_p_.find_one_bool("samplepixelcenter", false) ? 1 : 0)), "set_sampler")) return PBRT_HIP_ERR_INVALID_ARG;
+    if (skind == 1) {
+        if (sobol_tables_file.empty()) { error = "Sampler \"sobol\" needs --sobol-tables FILE (the generator matrices are data the library does not embed)"; return PBRT_HIP_ERR_STATE; }
+        std::ifstream f(sobol_tables_file, std::ios::binary);
+        const size_t n32 = 1024 * 52, nv = 25 * 52, nvi = 26 * 52;
+        std::vector<uint32_t> m32(n32); std::vector<uint64_t> vdc(nvi), vdci(nvi);
+        if (!f || !f.read((char*)m32.data(), n32 * 4) || !f.read((char*)vdc.data(), nv * 8) || !f.read((char*)vdci.data(), nvi * 8)) {
+            error = "cannot read Sobol tables from '" + sobol_tables_file + "'"; return PBRT_HIP_ERR_INVALID_ARG;
+        }
+        if (!check(ABI(pbrt_hip_set_sobol_tables(scene_, m32.data(), n32, vdc.data(), vdci.data(), nvi)), "set_sobol_tables")) return PBRT_HIP_ERR_INVALID_ARG;
+    }
+
+    // ---- accelerator (bvh/mod.rs:339-360)
+    int split = 0;
+    if (accel_name_ == "bvh") {
+        const std::string sm = accel_p_.find_one_string("splitmethod", "sah");
+        if (sm == "sah") split = 0;
+        else if (sm == "equal") split = 3;
+        else if (sm == "middle" || sm == "hlbvh") { error = "BVH splitmethod \"" + sm + "\" is outside the hot-path scope (supported: sah, equal)"; return PBRT_HIP_ERR_UNSUPPORTED; }
+        else { warn("BVH split method \"" + sm + "\" unknown.  Using \"sah\"."); split = 0; }
+    } else { error = "Accelerator \"" + accel_name_ + "\" is outside the hot-path scope (supported: bvh)"; return PBRT_HIP_ERR_UNSUPPORTED; }
+    const int max_prims = accel_p_.find_one_int("maxnodeprims", 4);
+    if (n_lights_ == 0) warn("No light sources defined in scene; rendering a black image.");
+    auto t0 = clk::now();
+    if (!check(ABI(pbrt_hip_build_accel(scene_, split, max_prims)), "build_accel")) return PBRT_HIP_ERR_DEVICE;
+    rep.build_seconds = std::chrono::duration<double>(clk::now() - t0).count();
+
+    // ---- integrator (path.rs:287-327)
+    if (integrator_name_ != "path") { error = "Integrator \"" + integrator_name_ + "\" is outside the hot-path scope (supported: path)"; return PBRT_HIP_ERR_UNSUPPORTED; }
+    const int max_depth = integrator_p_.find_one_int("maxdepth", 5);
+    int pb[4] = {sb[0], sb[1], sb[2], sb[3]};
+    if (const std::vector<int>* v = integrator_p_.find_ints("pixelbounds")) {
+        if (v->size() != 4) warn("Expected 4 values for 'pixelbounds' parameter.");
+        else {
+            pb[0] = std::max(pb[0], (*v)[0]); pb[1] = std::max(pb[1], (*v)[1]);
+            pb[2] = std::min(pb[2], (*v)[2]); pb[3] = std::min(pb[3], (*v)[3]);
+            if (pb[2] <= pb[0] || pb[3] <= pb[1]) { warn("Degenerate 'pixelbounds' specified."); pb[2] = pb[0]; pb[3] = pb[1]; }
+        }
+    }
+    const float rr = integrator_p_.find_one_float("rrthreshold", 1.0f);
+    const std::string lss = integrator_p_.find_one_string("lightsamplestrategy", "spatial");
+    int strategy = 2;
+    if (lss == "uniform") strategy = 0; else if (lss == "power") strategy = 1; else if (lss == "spatial") strategy = 2;
+    else { warn("Light sample distribution type \"" + lss + "\" unknown. Using \"spatial\"."); strategy = 2; }
+
+    rep.xres = xres; rep.yres = yres; std::memcpy(rep.crop, cb, sizeof cb);
+    rep.n_triangles = n_tris_; rep.n_lights = n_lights_; rep.warnings = warnings;
+    rep.spp = spp; rep.max_depth = max_depth; rep.light_strategy = strategy; std::memcpy(rep.pixel_bounds, pb, sizeof pb);
+    if (check_only_) { rep.out_file = filename; return PBRT_HIP_OK; }
+    const size_t npix = (size_t)std::max(0, cb[2] - cb[0]) * (size_t)std::max(0, cb[3] - cb[1]);
+    std::vector<float> xyz(npix * 3), wt(npix), rgb(npix * 3);
+    int rc = pbrt_hip_render_path(scene_, max_depth, rr, strategy, pb, tile_size, 0, 1, xyz.data(), wt.data(), &rep.stats);
+    if (!check(rc, "render_path")) return rc;
+    if (!check(pbrt_hip_film_to_rgb(scene_, xyz.data(), wt.data(), rgb.data()), "film_to_rgb")) return PBRT_HIP_ERR_DEVICE;
+    std::string err;
+    if (!write_pfm(filename, rgb.data(), cb[2] - cb[0], cb[3] - cb[1], err)) { error = err; return PBRT_HIP_ERR_INVALID_ARG; }
+    rep.out_file = filename; rep.warnings = warnings;
+    return PBRT_HIP_OK;
+}
+
+// core/src/image_io.rs:336-374: "PF", width height, scale -1 (little endian), scanlines bottom-to-top, f32 RGB.
+bool write_pfm(const std::string& path, const float* rgb, int w, int h, std::string& err) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) { err = "Unable to open output PFM file '" + path + "'"; return false; }
+    std::fprintf(f, "PF\n%d %d\n-1\n", w, h);
+    for (int y = h - 1; y >= 0; y--)
+        if (std::fwrite(rgb + (size_t)y * w * 3, sizeof(float), (size_t)w * 3, f) != (size_t)w * 3) { err = "Error writing PFM file '" + path + "'"; std::fclose(f); return false; }
+    std::fclose(f);
+    return true;
+}
+
+}  // namespace pbrt_host

@@ -138,6 +138,11 @@ class Host:
         L.pbrt_hip_host_transform_points.argtypes = [fp, fp, fp, C.c_size_t]
         L.pbrt_hip_host_transform_vectors.argtypes = [fp, fp, fp, C.c_size_t]
         L.pbrt_hip_host_transform_normals.argtypes = [fp, fp, fp, C.c_size_t]
+        ip = C.POINTER(C.c_int)
+        L.pbrt_hip_host_film_filter.argtypes = [C.c_int, fp, C.c_int, C.c_int, fp, fp, ip, fp, ip]
+        L.pbrt_hip_host_film_filter.restype = C.c_int
+        L.pbrt_hip_host_swaps_handedness.argtypes = [fp]
+        L.pbrt_hip_host_swaps_handedness.restype = C.c_int
 
     @staticmethod
     def _m():
@@ -186,6 +191,46 @@ class Host:
         cb, sb, table = np.zeros(4, np.int32), np.zeros(4, np.int32), np.zeros(256, np.float32)
         self.lib.pbrt_hip_host_film_box(xres, yres, _ptr(_f32(crop_window), C.c_float), _ptr(_f32(radius), C.c_float), _ptr(cb, C.c_int), _ptr(table, C.c_float), _ptr(sb, C.c_int))
         return cb, table, sb
+
+    FILTER_KINDS = {"box": 0, "gaussian": 1, "mitchell": 2, "sinc": 3, "triangle": 4}
+
+    def film_filter(self, kind, xres, yres, radius, params=(0.0, 0.0), crop_window=(0.0, 1.0, 0.0, 1.0)):
+        """Film::new for any filter of filters/src (kind: name or 0..4) -> (cropped bounds, 16x16 table, sample bounds)."""
+        k = self.FILTER_KINDS[kind] if isinstance(kind, str) else int(kind)
+        cb, sb, table = np.zeros(4, np.int32), np.zeros(4, np.int32), np.zeros(256, np.float32)
+        rc = self.lib.pbrt_hip_host_film_filter(k, _ptr(_f32(params), C.c_float), xres, yres, _ptr(_f32(crop_window), C.c_float), _ptr(_f32(radius), C.c_float),
+                                                _ptr(cb, C.c_int), _ptr(table, C.c_float), _ptr(sb, C.c_int))
+        if rc != 0:
+            raise PbrtHipError(ERR_INVALID_ARG, f"film_filter: unknown filter kind {kind}")
+        return cb, table, sb
+
+    def invert(self, m):
+        out = self._m()
+        self.lib.pbrt_hip_host_invert(_ptr(_f32(m), C.c_float), _ptr(out, C.c_float))
+        return out
+
+    def transform_vectors(self, m, v):
+        v = _f32(v, (-1, 3)); out = np.empty_like(v)
+        self.lib.pbrt_hip_host_transform_vectors(_ptr(_f32(m), C.c_float), _ptr(v, C.c_float), _ptr(out, C.c_float), len(v))
+        return out
+
+    def transform_normals(self, m_inv, n):
+        n = _f32(n, (-1, 3)); out = np.empty_like(n)
+        self.lib.pbrt_hip_host_transform_normals(_ptr(_f32(m_inv), C.c_float), _ptr(n, C.c_float), _ptr(out, C.c_float), len(n))
+        return out
+
+    def swaps_handedness(self, m):
+        return bool(self.lib.pbrt_hip_host_swaps_handedness(_ptr(_f32(m), C.c_float)))
+
+    def distant_direction(self, l2w, frm, to):
+        w = np.zeros(3, np.float32)
+        self.lib.pbrt_hip_host_distant_direction(_ptr(_f32(l2w), C.c_float), _ptr(_f32(frm), C.c_float), _ptr(_f32(to), C.c_float), _ptr(w, C.c_float))
+        return w
+
+    def point_position(self, l2w, l2w_inv, frm):
+        p = np.zeros(3, np.float32)
+        self.lib.pbrt_hip_host_point_position(_ptr(_f32(l2w), C.c_float), _ptr(_f32(l2w_inv), C.c_float), _ptr(_f32(frm), C.c_float), _ptr(p, C.c_float))
+        return p
 
     def transform_points(self, m, pts):
         pts = _f32(pts, (-1, 3)); out = np.empty_like(pts)
