@@ -69,6 +69,7 @@ typedef struct PbrtHipStats {
     double shade_seconds;        /* of which: raygen + shade + film kernels                  */
     uint64_t extend_launches;    /* number of closest-hit traversal launches in this render  */
     uint64_t shadow_launches;    /* number of any-hit traversal launches                     */
+    uint64_t light_distributions_created; /* "SpatialLightDistribution/Distributions created" (light_distrib/spatial.rs:17-21) */
 } PbrtHipStats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------- */
@@ -146,8 +147,8 @@ int pbrt_hip_get_traversal_counts(PbrtHipScene*, uint64_t out[6]);
 /* Integrator::render for PathIntegrator (core/src/integrator/sampler_integrator.rs:243-415 +
  * integrators/src/path.rs:103-284).  Renders the 16x16 (tile_size) sample tiles whose index t satisfies
  * t % tile_parts == tile_part (tile enumeration = sampler_integrator.rs:254-259,314-336), i.e. the whole frame for
- * (0,1).  light_strategy: 0 uniform, 1 power (2 = spatial is "next": UNSUPPORTED unless the scene has one light,
- * where the reference itself forces uniform, core/src/light_distrib/mod.rs:50-54).
+ * (0,1).  light_strategy: 0 uniform, 1 power, 2 spatial (the reference's default, core/src/light_distrib/spatial.rs;
+ * with one light the reference itself forces uniform, light_distrib/mod.rs:59-64).
  *
  * Output = the per-pixel state Film keeps (core/src/film/mod.rs:33-47): out_xyz[3*i..] = sum of rgb_to_xyz(tile
  * contrib), out_weight[i] = filter weight sum, i indexing cropped_pixel_bounds row-major.  Film::write_image's

@@ -22,7 +22,7 @@ struct OracleHit { float t; uint32_t prim; float b0, b1, b2; uint32_t pad[3]; };
 struct OracleStats {
     uint64_t camera_rays, regular_rays, shadow_rays, paths_zero_radiance, paths_total;
     double render_seconds, extend_seconds, shadow_seconds, shade_seconds;
-    uint64_t extend_launches, shadow_launches;
+    uint64_t extend_launches, shadow_launches, light_distributions_created;
 };
 struct OracleTraversalStats { uint64_t rays, nodes_visited, tri_tests; };
 
@@ -208,9 +208,8 @@ int oracle_render_path_ex(OracleScene* s, int max_depth, float rr_threshold, int
     if (!s || !pixel_bounds || !out_xyz || !out_weight) return -1;
     if (!s->built || !s->have_camera || !s->have_film || !s->have_sampler) { s->err = "scene incomplete"; return -2; }
     if (s->r.scfg.kind == 1 && !s->r.scfg.sobol.m32) { s->err = "sobol tables not set"; return -2; }
-    if (light_strategy == 2 && s->sc.lights.size() != 1) { s->err = "spatial light distribution is out of scope"; return -5; }
     Renderer& r = s->r;
-    r.max_depth = max_depth; r.rr_threshold = rr_threshold; r.light_strategy = light_strategy == 2 ? 0 : light_strategy;
+    r.max_depth = max_depth; r.rr_threshold = rr_threshold; r.light_strategy = light_strategy;
     for (int i = 0; i < 4; i++) r.pixel_bounds[i] = pixel_bounds[i];
     r.count_traversal = count_traversal != 0;
     r.rec = s->rec.cap ? &s->rec : nullptr;
@@ -223,8 +222,28 @@ int oracle_render_path_ex(OracleScene* s, int max_depth, float rr_threshold, int
         st->camera_rays = r.total_stats.camera_rays; st->regular_rays = r.total_stats.regular_rays; st->shadow_rays = r.total_stats.shadow_rays;
         st->paths_zero_radiance = r.total_stats.zero_paths; st->paths_total = r.total_stats.total_paths;
         st->render_seconds = std::chrono::duration<double>(t1 - t0).count();
+        st->light_distributions_created = r.spatial ? r.spatial_created : 0;
     }
     if (out_nv_nt) { out_nv_nt[0] = r.total_stats.nv_regular; out_nv_nt[1] = r.total_stats.nt_regular; out_nv_nt[2] = r.total_stats.nv_shadow; out_nv_nt[3] = r.total_stats.nt_shadow; }
+    return 0;
+}
+// SpatialLightDistribution of the last render: out[0..2] voxel resolution, out[3] distributions created
+// ("SpatialLightDistribution/Distributions created", spatial.rs:17-21).
+int oracle_spatial_stats(OracleScene* s, uint64_t out[4]) {
+    if (!s || !out) return -1;
+    for (int i = 0; i < 3; i++) out[i] = (uint64_t)s->r.n_voxels[i];
+    out[3] = s->r.spatial_created;
+    return 0;
+}
+// One voxel's distribution, computed directly (compute_distribution, spatial.rs:90-160): func[n_lights], cdf[n_lights+1].
+int oracle_spatial_voxel(OracleScene* s, const int pi[3], float* out_func, float* out_cdf, float* out_func_int) {
+    if (!s || !pi || !s->built) return -1;
+    Renderer& r = s->r;
+    r.spatial_init(64);
+    Dist1D d; r.spatial_compute(pi, d);
+    for (size_t i = 0; i < d.func.size(); i++) out_func[i] = d.func[i];
+    for (size_t i = 0; i < d.cdf.size(); i++) out_cdf[i] = d.cdf[i];
+    *out_func_int = d.func_int;
     return 0;
 }
 int oracle_render_path(OracleScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size,

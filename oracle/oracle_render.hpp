@@ -2,6 +2,7 @@
 // Samplers, camera, lights, BSDF, PathIntegrator::li, Film, SamplerIntegrator::render.
 #pragma once
 #include "oracle_scene.hpp"
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -374,6 +375,14 @@ struct Renderer {
     int max_depth = 5; Float rr_threshold = 1.0f; int light_strategy = 0;
     int pixel_bounds[4] = {0, 0, 0, 0};
     Dist1D light_distrib;
+    // SpatialLightDistribution (core/src/light_distrib/spatial.rs): the reference keeps voxel distributions in a lock-free
+    // hash table; a voxel's distribution is a pure function of the voxel, so the table is only a cache and is restated
+    // here as a dense array filled on first use.  (With several threads the reference's lookup can return None while
+    // another thread is still computing the entry, :213-216, and the caller then samples uniformly — a data race; this
+    // restatement is the race-free, --nthreads 1 behaviour.)
+    bool spatial = false; int n_voxels[3] = {1, 1, 1}; Float wb_lo[3], wb_hi[3];
+    std::vector<std::unique_ptr<Dist1D>> voxel_dist; std::vector<std::once_flag> voxel_once;
+    uint64_t spatial_created = 0; std::mutex spatial_mu;
     RenderStats total_stats; std::mutex stats_mu; RayRecorder* rec = nullptr; bool count_traversal = false;
 
     // ---- Scene::intersect / intersect_p with the reference's counters (core/src/scene.rs:88-99)
@@ -601,13 +610,80 @@ struct Renderer {
         return b;
     }
 
+    // ---- SpatialLightDistribution::new / lookup / compute_distribution (light_distrib/spatial.rs:57-245) ------------------
+    void spatial_init(int max_voxels) {
+        const Scene& s = *sc;
+        const V3 blo = s.world_bound.pmin, bhi = s.world_bound.pmax;
+        wb_lo[0] = blo.x; wb_lo[1] = blo.y; wb_lo[2] = blo.z; wb_hi[0] = bhi.x; wb_hi[1] = bhi.y; wb_hi[2] = bhi.z;
+        Float diag[3] = {wb_hi[0] - wb_lo[0], wb_hi[1] - wb_lo[1], wb_hi[2] - wb_lo[2]};
+        int ext = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);  // bounds3.rs:122-134
+        Float bmax = diag[ext];
+        for (int i = 0; i < 3; i++) {
+            Float r = std::round(diag[i] / bmax * (Float)max_voxels);
+            long long v = (r != r) ? 0 : (r <= 0.0f ? 0 : (r >= 9.2e18f ? (long long)9.2e18 : (long long)r));  // `as usize` saturates, NaN -> 0
+            n_voxels[i] = (int)(v < 1 ? 1 : (v > (1 << 20) - 1 ? (1 << 20) - 1 : v));
+        }
+        size_t nv = (size_t)n_voxels[0] * n_voxels[1] * n_voxels[2];
+        voxel_dist.clear(); voxel_dist.resize(nv);
+        voxel_once = std::vector<std::once_flag>(nv);
+        spatial_created = 0;
+    }
+    static Float lerp1(Float t, Float a, Float b) { return (1.0f - t) * a + t * b; }  // pbrt/common.rs:167-173
+    void spatial_compute(const int pi[3], Dist1D& out) const {
+        const Scene& s = *sc;
+        Float lo[3], hi[3];
+        for (int i = 0; i < 3; i++) {
+            Float p0 = (Float)pi[i] / (Float)n_voxels[i], p1 = (Float)(pi[i] + 1) / (Float)n_voxels[i];
+            Float a = lerp1(p0, wb_lo[i], wb_hi[i]), b = lerp1(p1, wb_lo[i], wb_hi[i]);
+            lo[i] = pmin(a, b); hi[i] = pmax(a, b);  // Bounds3f::new
+        }
+        const size_t n_samples = 128, n_lights = s.lights.size();
+        std::vector<Float> contrib(n_lights, 0.0f);
+        for (size_t i = 0; i < n_samples; i++) {
+            SurfaceHit intr{};
+            intr.p = V3(lerp1(radical_inverse(0, i), lo[0], hi[0]), lerp1(radical_inverse(1, i), lo[1], hi[1]), lerp1(radical_inverse(2, i), lo[2], hi[2]));
+            intr.time = 0.0f;
+            V2 u(radical_inverse(3, i), radical_inverse(4, i));
+            for (size_t j = 0; j < n_lights; j++) {
+                LiSample li = light_sample_li(s.lights[j], intr, u);
+                if (li.valid && li.pdf > 0.0f) contrib[j] += li.value.y() / li.pdf;
+            }
+        }
+        Float sum = 0.0f;
+        for (Float c : contrib) sum += c;
+        Float avg = sum / (Float)(n_samples * n_lights);
+        Float min_contrib = avg > 0.0f ? 0.001f * avg : 1.0f;
+        for (Float& c : contrib) c = pmax(c, min_contrib);
+        out.init(contrib);
+    }
+    void spatial_voxel_of(V3 p, int pi[3]) const {  // lookup's first half (:170-181); Bounds3::offset (bounds3.rs:153-168)
+        Float o[3] = {p.x - wb_lo[0], p.y - wb_lo[1], p.z - wb_lo[2]};
+        for (int i = 0; i < 3; i++) {
+            if (wb_hi[i] > wb_lo[i]) o[i] /= wb_hi[i] - wb_lo[i];
+            int v = f2i32(o[i] * (Float)n_voxels[i]);
+            pi[i] = pclamp(v, 0, n_voxels[i] - 1);
+        }
+    }
+    const Dist1D& spatial_lookup(V3 p) {
+        int pi[3]; spatial_voxel_of(p, pi);
+        size_t idx = ((size_t)pi[0] * n_voxels[1] + pi[1]) * n_voxels[2] + pi[2];
+        std::call_once(voxel_once[idx], [&] {
+            std::unique_ptr<Dist1D> d(new Dist1D());
+            spatial_compute(pi, *d);
+            voxel_dist[idx] = std::move(d);
+            std::lock_guard<std::mutex> g(spatial_mu); spatial_created++;
+        });
+        return *voxel_dist[idx];
+    }
+
     // ---- estimate_direct + uniform_sample_one_light (core/src/integrator/common.rs:89-299) -----------------------
     template <class S> Spec uniform_sample_one_light(const SurfaceHit& hit, const BSDF& bsdf, S& sampler) {
         const Scene& s = *sc;
         size_t n_lights = s.lights.size();
         if (n_lights == 0) return Spec(0.0f);
         Float sample = sampler.get_1d(), light_pdf;
-        size_t light_num = light_distrib.sample_discrete(sample, light_pdf);  // lookup() always Some (uniform.rs / power.rs)
+        const Dist1D& distrib = spatial ? spatial_lookup(hit.p) : light_distrib;  // LightDistribution::lookup(&isect.hit.p) (path.rs:156-157)
+        size_t light_num = distrib.sample_discrete(sample, light_pdf);
         if (light_pdf == 0.0f) return Spec(0.0f);
         const Light& light = s.lights[light_num];
         V2 u_light = sampler.get_2d(), u_scattering = sampler.get_2d();
@@ -805,8 +881,10 @@ struct Renderer {
         const Scene& s = *sc;
         std::vector<Float> lf;
         int strat = s.lights.size() == 1 ? 0 : light_strategy;
-        for (const Light& l : s.lights) lf.push_back(strat == 0 ? 1.0f : light_power(l).y());
+        for (const Light& l : s.lights) lf.push_back(strat == 1 ? light_power(l).y() : 1.0f);
         if (!lf.empty()) light_distrib.init(lf);
+        spatial = strat == 2;
+        if (spatial) spatial_init(64);  // create_light_sample_distribution (light_distrib/mod.rs:59-69)
         int sb[4]; sample_bounds(sb);
         int ntx = (sb[2] - sb[0] + tile_size - 1) / tile_size, nty = (sb[3] - sb[1] + tile_size - 1) / tile_size;
         int tile_count = ntx * nty;

@@ -41,6 +41,30 @@ struct Pcg32 {
     }
 };
 
+// radical_inverse (core/src/low_discrepency.rs:401-421, 454-464): base 2 by bit reversal, other bases digit by digit
+inline float radical_inverse(uint32_t base, uint64_t a) {
+    if (base == 2) {
+        uint64_t n = a;
+        n = ((n >> 1) & 0x5555555555555555ULL) | ((n & 0x5555555555555555ULL) << 1);
+        n = ((n >> 2) & 0x3333333333333333ULL) | ((n & 0x3333333333333333ULL) << 2);
+        n = ((n >> 4) & 0x0f0f0f0f0f0f0f0fULL) | ((n & 0x0f0f0f0f0f0f0f0fULL) << 4);
+        n = ((n >> 8) & 0x00ff00ff00ff00ffULL) | ((n & 0x00ff00ff00ff00ffULL) << 8);
+        n = ((n >> 16) & 0x0000ffff0000ffffULL) | ((n & 0x0000ffff0000ffffULL) << 16);
+        n = (n >> 32) | (n << 32);
+        return (float)n * 0x1.0p-64f;
+    }
+    const float inv_base = 1.0f / (float)base;
+    uint64_t reversed = 0; float inv_base_n = 1.0f;
+    while (a != 0) {
+        const uint64_t next = a / base, digit = a - next * base;
+        reversed = reversed * base + digit;
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    const float v = (float)reversed * inv_base_n;
+    return v < 0x1.fffffep-1f ? v : 0x1.fffffep-1f;
+}
+
 // PRIMES / PRIME_SUMS (core/src/low_discrepency.rs:13,102) and the Halton digit permutations
 // (compute_radical_inverse_permutations :1512-1528 seeded with RNG::default(), samplers/src/halton.rs:16-19)
 struct HaltonTables {

@@ -18,6 +18,7 @@
 #include "host_math.h"
 #include "pt_device.h"
 #include "scene_host.h"
+#include "spatial.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -56,6 +57,8 @@ struct WfParams {
     float4* s_L; float4* s_beta; float4* s_A; float4* s_f2; float4* s_bold; uint4* s_idx;
     // per-sample records of the whole render: {L.rgb, p_film.x} {p_film.y}
     float4* rec_L; float* rec_py;
+    // light sampling: SpatialLightDistribution tables when enabled, else the scene-wide Distribution1D of DeviceScene
+    SpatialRec spatial;
 };
 
 PH_DEV uint32_t wave_alloc(uint32_t* ctr, bool want) {
@@ -122,6 +125,34 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
         w.live[0][lslot] = pid;
         w.s_idx[pid] = make_uint4(slot, 0u, 0u, F_EXT | (0u << 8) | (5u << 16));  // bounces 0, next sampler dimension 5
         if (!w.identity_slots) atomicAdd(&w.stats->camera_rays, 1ull);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// SpatialLightDistribution::lookup, first half (spatial.rs:166-236): every path that is about to sample a light at a new
+// vertex names its voxel; the first path to touch a voxel claims a pool slot for it (spatial_compute_kernel fills it).
+__global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfParams w, int it) {
+    const uint32_t n_live = w.ctr[it].n_live;
+    const uint32_t* live_in = w.live[it & 1];
+    const SpatialRec& sr = w.spatial;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_live; i += gridDim.x * blockDim.x) {
+        const uint32_t pid = live_in[i];
+        const uint4 idx4 = w.s_idx[pid];
+        const uint32_t flags = idx4.w & 0xffu, bounces = (idx4.w >> 8) & 0xffu;
+        if (!(flags & F_EXT) || (int)bounces >= w.max_depth) continue;
+        const float4* hp = reinterpret_cast<const float4*>(w.hits_cl + idx4.x);
+        const float4 h0 = hp[0];
+        if (__float_as_uint(h0.y) == 0xFFFFFFFFu) continue;
+        const float4 h1 = hp[1];
+        const float4* tp = reinterpret_cast<const float4*>(sc.tris + __float_as_uint(h1.y));
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        const f3 p = h0.z * mk3(a.x, a.y, a.z) + h0.w * mk3(b.x, b.y, b.z) + h1.x * mk3(c.x, c.y, c.z);  // = SurfHit::p (make_surface_hit_tv)
+        const uint32_t v = spatial_voxel_of(sr, p);
+        if (sr.vox_slot[v] == -1 && atomicCAS(&sr.vox_slot[v], -1, -2) == -1) {
+            const uint32_t slot = atomicAdd(&sr.counters[SP_CLAIMED], 1u);
+            if (slot < sr.capacity) sr.new_list[slot] = v;
+            else sr.counters[SP_OVERFLOW] = 1u;
+        }
     }
 }
 
@@ -241,8 +272,16 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                                 const float sample = s_u[0][tid]; c = 1;
                                 // sample_discrete; with a single light the CDF is {0, 1} and the answer is 0 for every sample in [0,1):
                                 // keeping that case wave-uniform lets the light record be fetched with scalar loads
-                                const uint32_t light_num = (sc.n_lights == 1) ? 0u : find_interval_cdf(sc.ld_cdf, sc.n_lights + 1, sample);
-                                pick_pdf = sc.ld_func_int > 0.0f ? ph_div(sc.ld_func[light_num], sc.ld_func_int * (float)sc.n_lights) : 0.0f;
+                                const float* ld_func = sc.ld_func; const float* ld_cdf = sc.ld_cdf; float ld_func_int = sc.ld_func_int;
+                                if (w.spatial.enabled) {  // light_distribution.lookup(&isect.hit.p) (path.rs:156-157)
+                                    const int32_t slot = w.spatial.vox_slot[spatial_voxel_of(w.spatial, si.p)];
+                                    if (slot >= 0) {
+                                        ld_func = w.spatial.pool + (size_t)slot * w.spatial.stride;
+                                        ld_cdf = ld_func + sc.n_lights; ld_func_int = ld_cdf[sc.n_lights + 1];
+                                    } else ld_func_int = 0.0f;  // pool exhausted: the render call fails (ERR_OOM), nothing is returned
+                                }
+                                const uint32_t light_num = (sc.n_lights == 1) ? 0u : find_interval_cdf(ld_cdf, sc.n_lights + 1, sample);
+                                pick_pdf = ld_func_int > 0.0f ? ph_div(ld_func[light_num], ld_func_int * (float)sc.n_lights) : 0.0f;
                                 if (pick_pdf != 0.0f) {
                                     const LightRec& light = sc.lights[light_num];
                                     const f2 u_light = mk2(s_u[1][tid], s_u[2][tid]), u_scatter = mk2(s_u[3][tid], s_u[4][tid]); c = 5;
@@ -515,6 +554,7 @@ struct Wavefront {
     uint32_t slot_w = 0, slot_h = 0;
     DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats;
     DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_recL, d_recpy, d_tilebuf, d_xyz, d_w;
+    DevBuf d_vox_slot, d_sp_pool, d_sp_list, d_sp_ctr, d_sp_halton;  // SpatialLightDistribution tables (spatial.h)
     std::vector<hipEvent_t> events;
 };
 
@@ -524,7 +564,8 @@ void free_wavefront(PbrtHipScene* s) {
     Wavefront* w = s->wf;
     if (!w) return;
     for (DevBuf* b : {&w->d_tiles, &w->d_px, &w->d_rays_cl[0], &w->d_rays_cl[1], &w->d_hits, &w->d_rays_sh, &w->d_occ, &w->d_live[0], &w->d_live[1], &w->d_ctr,
-                      &w->d_stats, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w})
+                      &w->d_stats, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
+                      &w->d_vox_slot, &w->d_sp_pool, &w->d_sp_list, &w->d_sp_ctr, &w->d_sp_halton})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : w->events) (void)hipEventDestroy(e);
     delete w;
@@ -595,11 +636,56 @@ static int check_render_args(PbrtHipScene* s, int max_depth, int light_strategy,
     if (tile_size <= 0 || parts <= 0 || parts > 8 || part < 0 || part >= parts) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: bad tile partition");
     if (max_depth < 0 || max_depth > 200) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: max_depth out of range");
     if (light_strategy < 0 || light_strategy > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: bad light strategy");
-    if (light_strategy == 2 && s->lights.size() > 1)
-        return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: SpatialLightDistribution is a 'next' row (SURVEY §8f); use uniform (0) or power (1)");
     if (s->sampler.kind == 1 && s->sobol32.empty()) return set_err(s, PBRT_HIP_ERR_STATE, "render: sobol tables not set (pbrt_hip_set_sobol_tables)");
     // sampler dimension budget: 5 + per bounce (1+2+2) + 2 + 1; HaltonSampler asserts dim <= 1000 (halton.rs:106-110)
     if (5 + 8 * (max_depth + 1) >= (s->sampler.kind == 0 ? 1000 : 1024)) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: path would exceed the sampler's dimension table");
+    return PBRT_HIP_OK;
+}
+
+// SpatialLightDistribution::new (spatial.rs:57-88): voxel resolution from the scene bounds, tables reset for this render
+// (the reference builds the distribution in Integrator::preprocess and fills it lazily while rendering, so the cost of the
+// voxel distributions is inside the timed render here too).
+static int setup_spatial(PbrtHipScene* s, ph::SpatialRec& sr) {
+    Wavefront& w = *s->wf;
+    const size_t n_lights = s->lights.size();
+    float diag[3];
+    for (int i = 0; i < 3; i++) { sr.lo[i] = s->bvh.root_lo[i]; sr.hi[i] = s->bvh.root_hi[i]; diag[i] = sr.hi[i] - sr.lo[i]; }
+    const int ext = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);  // Bounds3::maximum_extent
+    const float bmax = diag[ext];
+    size_t nvox = 1;
+    for (int i = 0; i < 3; i++) {
+        const float r = std::round(diag[i] / bmax * 64.0f);  // f32::round: half away from zero; `as usize` saturates, NaN -> 0
+        long long v = (r != r) ? 0 : (r <= 0.0f ? 0 : (r >= 1048575.0f ? 1048575 : (long long)r));
+        sr.nv[i] = (int32_t)std::max<long long>(1, v);
+        nvox *= (size_t)sr.nv[i];
+    }
+    sr.stride = (uint32_t)(2 * n_lights + 2);
+    size_t free_b = 0, total_b = 0;
+    PH_CHECK(s, hipMemGetInfo(&free_b, &total_b));
+    const size_t slot_bytes = (size_t)sr.stride * 4;
+    size_t budget = free_b / 2 + w.d_sp_pool.bytes;  // the pool may take half of what is free (plus what it already holds)
+    if (const char* e = std::getenv("PBRT_HIP_SPATIAL_POOL_BYTES")) { long long v = std::atoll(e); if (v > 0) budget = (size_t)v; }
+    const size_t cap = std::min(nvox, budget / slot_bytes);
+    if (cap == 0) return set_err(s, PBRT_HIP_ERR_OOM, "render: no memory for the SpatialLightDistribution pool");
+    sr.capacity = (uint32_t)cap;
+    int rc;
+    if ((rc = ensure_buf(s, w.d_vox_slot, nvox * 4))) return rc;
+    if ((rc = ensure_buf(s, w.d_sp_list, cap * 4))) return rc;
+    if ((rc = ensure_buf(s, w.d_sp_ctr, 64))) return rc;
+    if ((rc = ensure_buf(s, w.d_sp_pool, cap * slot_bytes))) return rc;
+    if (!w.d_sp_halton.p) {
+        if ((rc = ensure_buf(s, w.d_sp_halton, 128 * 5 * 4))) return rc;
+        static const uint32_t bases[5] = {2, 3, 5, 7, 11};
+        float h[128 * 5];
+        for (uint64_t i = 0; i < 128; i++)
+            for (int d = 0; d < 5; d++) h[5 * i + d] = hm::radical_inverse(bases[d], i);
+        PH_CHECK(s, hipMemcpy(w.d_sp_halton.p, h, sizeof h, hipMemcpyHostToDevice));
+    }
+    PH_CHECK(s, hipMemsetAsync(w.d_vox_slot.p, 0xFF, nvox * 4, s->stream));
+    PH_CHECK(s, hipMemsetAsync(w.d_sp_ctr.p, 0, 64, s->stream));
+    sr.enabled = 1;
+    sr.vox_slot = (int32_t*)w.d_vox_slot.p; sr.pool = (float*)w.d_sp_pool.p; sr.new_list = (uint32_t*)w.d_sp_list.p;
+    sr.counters = (uint32_t*)w.d_sp_ctr.p; sr.halton = (const float*)w.d_sp_halton.p;
     return PBRT_HIP_OK;
 }
 
@@ -609,6 +695,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     int rc;
     PH_CHECK(s, hipSetDevice(s->device));
     if ((rc = upload_scene(s))) return rc;
+    const bool spatial = light_strategy == 2 && s->lights.size() > 1;  // one light -> uniform (light_distrib/mod.rs:59-64)
     if ((rc = upload_light_distribution(s, light_strategy == 2 ? 0 : light_strategy))) return rc;
     if ((rc = setup_tiles(s, tile_size, part, parts))) return rc;
     Wavefront& w = *s->wf;
@@ -656,6 +743,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     wp.s_bold = (float4*)w.d_sbold.p; wp.s_idx = (uint4*)w.d_sidx.p;
     wp.rec_L = (float4*)w.d_recL.p; wp.rec_py = (float*)w.d_recpy.p;
 
+    if (spatial) { if ((rc = setup_spatial(s, wp.spatial))) return rc; }
     PH_CHECK(s, hipMemsetAsync(w.d_stats.p, 0, sizeof(ph::DevStats), s->stream));
     bool identity = true;  // does pixel_bounds cover every pixel of this rank's tiles?
     for (const ph::TileInfo& t : w.tiles)
@@ -695,6 +783,12 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
                 tp.rays = wp.rays_sh; tp.out = wp.occ; tp.n_ptr = &c->n_sh; tp.counter = &c->head_sh;
                 if ((rc = timed(1, [&]() { launch_traverse_kernel(s, true, s->trav_blocks, tp); }))) return rc;
             }
+            if (spatial && it < max_depth) {  // vertices reached at bounce == max_depth sample no light (path.rs:136-139)
+                if ((rc = timed(2, [&]() {
+                        hipLaunchKernelGGL(ph::spatial_mark_kernel, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        hipLaunchKernelGGL(ph::spatial_compute_kernel, dim3(1024), dim3(PH_SPATIAL_BLOCK), 0, s->stream, s->ds, wp.spatial);
+                    }))) return rc;
+            }
             if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::shade_kernel, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it); }))) return rc;
         }
         PH_CHECK(s, hipMemcpyAsync(hctr.data(), w.d_ctr.p, (size_t)(n_iter + 2) * sizeof(ph::IterCounters), hipMemcpyDeviceToHost, s->stream));
@@ -714,7 +808,15 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     uint32_t flag = 0;
     PH_CHECK(s, hipMemcpy(&flag, s->d_error.p, 4, hipMemcpyDeviceToHost));
     if (flag) { (void)hipMemset(s->d_error.p, 0, 4); return set_err(s, PBRT_HIP_ERR_DEVICE, "traversal stack exceeded 64 entries (the reference panics here, bvh/mod.rs:185)"); }
+    uint32_t sp_ctr[4] = {0, 0, 0, 0};
+    if (spatial) {
+        PH_CHECK(s, hipMemcpy(sp_ctr, w.d_sp_ctr.p, sizeof sp_ctr, hipMemcpyDeviceToHost));
+        if (sp_ctr[ph::SP_OVERFLOW])
+            return set_err(s, PBRT_HIP_ERR_OOM, "render: SpatialLightDistribution pool exhausted (" + std::to_string(sp_ctr[ph::SP_CLAIMED]) + " voxels x " +
+                                                std::to_string(s->lights.size()) + " lights); use lightsamplestrategy power/uniform or a larger GPU memory budget");
+    }
     if (out_stats) {
+        out_stats->light_distributions_created = sp_ctr[ph::SP_DONE];
         ph::DevStats ds;
         PH_CHECK(s, hipMemcpy(&ds, w.d_stats.p, sizeof(ds), hipMemcpyDeviceToHost));
         out_stats->camera_rays = ds.camera_rays; out_stats->regular_rays = regular; out_stats->shadow_rays = shadow;

@@ -33,6 +33,7 @@ class Stats(C.Structure):
         ("paths_zero_radiance", C.c_uint64), ("paths_total", C.c_uint64),
         ("render_seconds", C.c_double), ("extend_seconds", C.c_double), ("shadow_seconds", C.c_double),
         ("shade_seconds", C.c_double), ("extend_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
+        ("light_distributions_created", C.c_uint64),
     ]
 
     def as_dict(self):

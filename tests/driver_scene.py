@@ -45,6 +45,7 @@ def write_files(d, filter_line='PixelFilter "gaussian" "float xwidth" 1.5 "float
         fh.write('AttributeBegin\n  Rotate 30 0 0 1\n  Translate 0.2 0 0\n'
                  '  Shape "plymesh" "string filename" "mesh.ply" "rgb Kd" [0.8 0.1 0.1]\nAttributeEnd\n')
     crop_s = f'"float cropwindow" [{fl(crop)}]' if crop is not None else ""
+    strategy_s = f'"string lightsamplestrategy" "{strategy}"' if strategy else ""
     text = f"""# host-driver parity scene
 Scale -1 1 1   # handedness flip, as most exported scenes have
 LookAt 0.5 -5 2.5  0 0 0.5  0 0 1
@@ -52,7 +53,7 @@ Camera "perspective" "float fov" [38] "float lensradius" 0.02 "float focaldistan
 Film "image" "integer xresolution" [{XRES}] "integer yresolution" {YRES} "string filename" "scene.pfm" {crop_s}
 Sampler "halton" "integer pixelsamples" {SPP}
 {filter_line}
-Integrator "path" "integer maxdepth" {MAXDEPTH} "string lightsamplestrategy" "{strategy}"
+Integrator "path" "integer maxdepth" {MAXDEPTH} {strategy_s}
 Accelerator "bvh" "integer maxnodeprims" 2
 WorldBegin
 AttributeBegin

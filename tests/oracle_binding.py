@@ -57,6 +57,8 @@ def oracle_binding():
         L.oracle_halton_perm.argtypes = [C.c_int, vp]
         L.oracle_geom_op.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.oracle_set_libm_mode.argtypes = [C.c_int]
+        L.oracle_spatial_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.oracle_spatial_voxel.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _binding = b
     return _binding
 
@@ -91,6 +93,20 @@ class OracleScene(pbrt_hip.Scene):
                                                   tile_part, tile_parts, xyz.ctypes.data_as(C.POINTER(C.c_float)), wt.ctypes.data_as(C.POINTER(C.c_float)),
                                                   C.byref(st), threads, 1 if count_traversal else 0, nvnt))
         return xyz, wt, st, list(nvnt)
+
+    def spatial_stats(self):
+        """(voxel resolution xyz, distributions created) of the last spatial render."""
+        out = (C.c_uint64 * 4)()
+        self._chk(self.b.lib.oracle_spatial_stats(self.h, out))
+        return tuple(out[:3]), int(out[3])
+
+    def spatial_voxel(self, pi, n_lights):
+        """compute_distribution for voxel pi: (func[n], cdf[n+1], func_int)."""
+        func = np.zeros(n_lights, np.float32); cdf = np.zeros(n_lights + 1, np.float32); fi = C.c_float()
+        pi = np.ascontiguousarray(pi, dtype=np.int32)
+        self._chk(self.b.lib.oracle_spatial_voxel(self.h, pi.ctypes.data_as(C.POINTER(C.c_int)), func.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 cdf.ctypes.data_as(C.POINTER(C.c_float)), C.byref(fi)))
+        return func, cdf, fi.value
 
     def record_rays(self, cap):
         self.b.lib.oracle_record_rays(self.h, cap)

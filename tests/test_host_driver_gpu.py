@@ -62,7 +62,12 @@ def test_python_capture_matches_driver(tmp_path, host):
     assert (img.view(np.uint32) == rgb.view(np.uint32)).all()
 
 
-def test_spatial_strategy_with_many_lights_is_refused(tmp_path):
-    path = ds.write_files(str(tmp_path), strategy="spatial")
+def test_default_light_strategy_is_spatial(tmp_path, host):
+    """No lightsamplestrategy parameter = "spatial" (path.rs:314), 5 lights: the voxel distributions are built on the GPU."""
+    path = ds.write_files(str(tmp_path), strategy=None, filter_line=ds.FILTERS["box"][0])
     r = subprocess.run([ds.RENDER_BIN, "--quiet", path], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 1 and "render_path failed" in r.stderr
+    assert r.returncode == 0, r.stderr
+    img = ds.read_pfm(str(tmp_path / "scene.pfm"))
+    ref, st = oracle_image(host, "box", 2)
+    assert st.light_distributions_created > 100
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()

@@ -207,9 +207,6 @@ def test_unsupported_and_state_errors(host):
     pbrt_hip.capture_spec(spec, s, host)
     s.add_light_point((1, 1, 1), (0, 0, 3)); s.build_accel(0, 4)
     with pytest.raises(pbrt_hip.PbrtHipError) as e:
-        s.render_path(light_strategy=2)       # spatial distribution with > 1 light: a "next" row
-    assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
-    with pytest.raises(pbrt_hip.PbrtHipError) as e:
         s.build_accel(1, 4)                   # HLBVH
     assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
     with pytest.raises(pbrt_hip.PbrtHipError) as e:
