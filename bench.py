@@ -8,7 +8,10 @@
 A step = one frame: SamplerIntegrator::render of the whole image (raygen -> [extend, shadow, shade] x (maxdepth+1) -> film).
 Scene, BVH and sampler tables are resident in HBM before the timed region.  With N ranks the frame's 16x16 tiles are dealt
 round-robin (tile t -> rank t % N, the reference's tile enumeration), every rank renders its tiles, the per-tile film buffers
-are gathered on rank 0 over RCCL and merged there in tile order: the same frame, so scaling is "strong".
+are gathered on rank 0 over RCCL (the path's one exchange step) and merged there in tile order.
+Scaling (N > 1): "weak" by default — the frame is rendered at N x the samples per pixel, so every rank traces as many paths as
+the single GPU does at N = 1 and the job is N frames' worth of work; `--scaling strong` renders the identical N = 1 frame
+instead (same film bits as one rank, tests/test_multi_rank_gpu.py).
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (closest-hit BVH traversal): achieved = algorithmic
 bytes (32 B per reference-format node visit + 48 B per triangle test + 64 B ray in / hit out) / its HIP-event time
@@ -58,6 +61,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=64, help="spp of the bounded CPU-baseline sample (same scene, same resolution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-count", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = spp x N (per-GPU work fixed), strong = the N=1 frame split over N ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = functional rehearsal of the N>1 path on ONE GPU: all ranks share device 0 and film tiles travel through host memory")
     args = ap.parse_args()
@@ -89,7 +94,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     host = pbrt_hip.Host()
-    spec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=args.spp, max_depth=args.max_depth)
+    frame_spp = args.spp * (world if args.scaling == "weak" else 1)
+    spec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=frame_spp, max_depth=args.max_depth)
     scene = pbrt_hip.Scene(device=local_rank)
     t_setup = time.time()
     geometry = pbrt_hip.capture_spec(spec, scene, host)
@@ -151,13 +157,14 @@ def main():
         rays, reg, shd = (int(v) for v in reduce_scalars([rays, reg, shd], dist.ReduceOp.SUM, torch.int64))
 
     out = None
+    spp_note = f" (= {args.spp} x {world} ranks)" if frame_spp != args.spp else ""
     if rank == 0:
         mrays = rays / elapsed / 1e6
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {args.n_tris} random triangles (seed {args.seed}), single SAH BVH, {args.res}x{args.res} @ {args.spp} spp, "
+            "config": {"workload": f"configs[1]: {args.n_tris} random triangles (seed {args.seed}), single SAH BVH, {args.res}x{args.res} @ {frame_spp} spp{spp_note}, "
                                    f"PathIntegrator maxdepth {args.max_depth}, halton, box filter, constant infinite light, matte Kd 0.5",
                        "tiles": "16x16, tile t on rank t % n_gpus, film tiles gathered on rank 0 (RCCL)" if world > 1 else "16x16, one rank",
                        "rays_per_frame": rays // args.steps, "regular_rays_per_frame": reg // args.steps, "shadow_rays_per_frame": shd // args.steps,
@@ -201,7 +208,7 @@ def main():
         if os.path.exists(tpath) and roof.get("achieved"):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == [args.n_tris, args.res, args.spp, args.max_depth, args.seed]:
+                if tj.get("workload") == [args.n_tris, args.res, args.spp, args.max_depth, args.seed] and world == 1:
                     k = tj["closest_hit"]
                     per_launch = (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"]
                     roof["traffic"] = int(per_launch)

@@ -22,9 +22,24 @@ def test_two_ranks_one_gpu_film_identical():
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common, capture_output=True, text=True, env=env, timeout=900)
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", "strong"] + common, capture_output=True, text=True, env=env, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     a, b = _last_json(one.stdout), _last_json(two.stdout)
     assert b["n_gpus"] == 2 and a["n_gpus"] == 1
     assert a["film_sha256"] == b["film_sha256"]
     assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+
+
+def test_two_ranks_weak_scaling_doubles_the_samples():
+    """Default N>1 mode: spp x N, so per-rank work equals the one-rank frame; the merged 2-rank frame equals a one-rank render of
+    the same 2x-spp frame."""
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--res", "128", "--n-tris", "5000"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spp", "8"] + common, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29534",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--spp", "4"] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = _last_json(one.stdout), _last_json(two.stdout)
+    assert b["scaling"] == "weak" and b["n_gpus"] == 2
+    assert a["film_sha256"] == b["film_sha256"] and a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
