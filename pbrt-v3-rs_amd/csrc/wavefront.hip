@@ -96,11 +96,11 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
     bool active = pid < w.B;
     RayIn ray;
     if (active) {
-        const uint32_t pix = pid / w.chunk_spp, j = pid - pix * w.chunk_spp, s = w.s0 + j;
+        const uint32_t pix = pid / w.chunk_spp, j = pid - pix * w.chunk_spp, s = w.s0 + j;  // a wave = consecutive samples of one pixel (coherent rays)
         const int2 xy = w.px_xy[pix];
         // pixels outside the integrator's pixel_bounds are skipped after start_pixel (sampler_integrator.rs:348-350)
         active = xy.x >= w.pixel_bounds[0] && xy.x < w.pixel_bounds[2] && xy.y >= w.pixel_bounds[1] && xy.y < w.pixel_bounds[3];
-        const size_t gsi = (size_t)pix * w.sp.spp + s;
+        const size_t gsi = (size_t)s * w.n_px + pix;  // sample records are [sample][pixel]: film_tiles_kernel reads them coalesced
         if (active) {
             SamplerCursor c = cursor_for(sc, w.sp, xy.x, xy.y, s, 0);
             f2 fs = get_2d(sc, w.sp, c);
@@ -256,8 +256,9 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                     }
                     if ((int)bounces < w.max_depth) {
                         const Bsdf bsdf = make_bsdf(sc, si, m.material);
-                        const int2 xy = w.px_xy[pid / w.chunk_spp];
-                        SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid % w.chunk_spp), dim, hl);
+                        const uint32_t ppix = pid / w.chunk_spp;
+                        const int2 xy = w.px_xy[ppix];
+                        SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid - ppix * w.chunk_spp), dim, hl);
                         // Draw the next 8 dimensions in one (not unrolled) loop: light pick 1D, u_light 2D, u_scattering 2D, BSDF 2D,
                         // Russian roulette 1D.  li consumes a prefix of them that depends on the vertex (A4 ledger); which VALUE lands in
                         // which role is decided below exactly as get_1d/get_2d would, only the evaluation is hoisted (one copy of the
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                 if (has_nans(L)) L = mks1(0.0f);
                 else if (lum_y(L) < -1e-5f) L = mks1(0.0f);
                 else if (__builtin_isinf(lum_y(L))) L = mks1(0.0f);
-                const size_t gsi = (size_t)(pid / w.chunk_spp) * w.sp.spp + (w.s0 + pid % w.chunk_spp);
+                const uint32_t ppix = pid / w.chunk_spp;
+                const size_t gsi = (size_t)(w.s0 + (pid - ppix * w.chunk_spp)) * w.n_px + ppix;
                 float4 rec = w.rec_L[gsi];
                 rec.x = L.r; rec.y = L.g; rec.z = L.b;
                 w.rec_L[gsi] = rec;
@@ -430,8 +432,8 @@ struct FilmParams {
     FilmRec film;
     const TileInfo* tiles; uint32_t n_tiles;
     uint32_t slot_w, slot_h;      // per-tile slot in the tile buffer: slot_w*slot_h float4 {contrib rgb, weight sum}
-    uint32_t spp;
-    const float4* rec_L; const float* rec_py;
+    uint32_t spp, n_px;
+    const float4* rec_L; const float* rec_py;   // [sample][pixel of the rank's pixel list]
     float4* tile_buf;
 };
 __global__ __launch_bounds__(256) void film_tiles_kernel(FilmParams p) {
@@ -455,9 +457,9 @@ __global__ __launch_bounds__(256) void film_tiles_kernel(FilmParams p) {
             for (int sx = sx0; sx <= sx1; sx++) {
                 const size_t pix = (size_t)t.px_off + (size_t)(sy - t.tb[1]) * tw + (size_t)(sx - t.tb[0]);
                 for (uint32_t s = 0; s < p.spp; s++) {
-                    const float4 r = p.rec_L[pix * p.spp + s];
+                    const float4 r = p.rec_L[(size_t)s * p.n_px + pix];
                     if (r.w != r.w) continue;  // pixel outside pixel_bounds: no sample was taken
-                    const float pfx = r.w, pfy = p.rec_py[pix * p.spp + s];
+                    const float pfx = r.w, pfy = p.rec_py[(size_t)s * p.n_px + pix];
                     spec l = mks(r.x, r.y, r.z);
                     const float ly = lum_y(l);
                     if (ly > p.film.max_lum) l = l * p.film.max_lum / ly;
@@ -799,7 +801,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     // ---- film: per-tile accumulation in reference order ---------------------------------------------------------------------------
     ph::FilmParams fp{};
     fp.film = s->film; fp.tiles = (const ph::TileInfo*)w.d_tiles.p; fp.n_tiles = (uint32_t)w.tiles.size();
-    fp.slot_w = w.slot_w; fp.slot_h = w.slot_h; fp.spp = spp; fp.rec_L = wp.rec_L; fp.rec_py = wp.rec_py; fp.tile_buf = (float4*)d_tile_buffer;
+    fp.slot_w = w.slot_w; fp.slot_h = w.slot_h; fp.spp = spp; fp.n_px = n_px; fp.rec_L = wp.rec_L; fp.rec_py = wp.rec_py; fp.tile_buf = (float4*)d_tile_buffer;
     const uint64_t film_threads = (uint64_t)fp.n_tiles * w.slot_w * w.slot_h;
     if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::film_tiles_kernel, dim3((uint32_t)((film_threads + 255) / 256)), dim3(256), 0, s->stream, fp); }))) return rc;
     PH_CHECK(s, hipEventRecord(e_end, s->stream));
