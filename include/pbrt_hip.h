@@ -120,7 +120,9 @@ int pbrt_hip_set_sampler(PbrtHipScene*, int kind, uint32_t samples_per_pixel, co
 int pbrt_hip_set_sobol_tables(PbrtHipScene*, const uint32_t* sobol_matrices32, size_t n32,
                               const uint64_t* vdc_matrices, const uint64_t* vdc_matrices_inv, size_t n_vdc_each);
 
-/* BVHAccel::from (accelerators/src/bvh/mod.rs:339-360) = Integrator::preprocess time. split_method: 0 SAH. */
+/* BVHAccel::from (accelerators/src/bvh/mod.rs:339-360) = Integrator::preprocess time.  split_method: 0 SAH (sah.rs),
+ * 1 HLBVH (hlbvh.rs, the reference's tree incl. its Morton-code quirk), 3 EqualCounts; 2 (Middle) panics in the reference
+ * and returns UNSUPPORTED. */
 int pbrt_hip_build_accel(PbrtHipScene*, int split_method, int max_prims_in_node);
 
 /* World bound of the built aggregate (BVHAccel::world_bound, bvh/mod.rs:161-167): {pmin[3], pmax[3]}. */

@@ -141,8 +141,8 @@ int oracle_set_sobol_tables(OracleScene* s, const uint32_t* m32, size_t n32, con
 }
 int oracle_build_accel(OracleScene* s, int split_method, int max_prims) {
     if (!s) return -1;
-    if (split_method == 1) { s->err = "HLBVH not in oracle scope yet"; return -5; }
     s->sc.build_bvh(split_method, max_prims);
+    if (split_method == 1 && s->sc.hlbvh_panic) { s->err = "HLBVH build hit one of the reference's assertions (hlbvh.rs:338/356/418, mod.rs:128)"; return -1; }
     s->built = true; return 0;
 }
 int oracle_world_bound(const OracleScene* s, float out[6]) {

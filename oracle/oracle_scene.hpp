@@ -357,6 +357,164 @@ struct Scene {
         return my;
     }
 
+    // ================= HLBVH: hlbvh::build (bvh/hlbvh.rs:33-449) + morton.rs ====================================
+    // Restated as written, including quirk B10: encode_morton_3 feeds left_shift_3 the IEEE BIT PATTERN of the scaled
+    // centroid offset (`float_to_bits`, morton.rs:33-39), not its integer value, so the "Morton" order is an order on
+    // mantissa bits.  The tree is valid (every primitive lands in exactly one leaf) but not spatially coherent.
+    // ordered_prims offsets are handed out in the single-thread order (treelet by treelet, depth first); with several
+    // threads the reference assigns them in completion order, which changes nothing a ray can observe.
+    struct MortonPrim { size_t primitive_index; uint32_t morton_code; };
+    struct HNode { Bounds3 bounds; int kid[2]; uint32_t first, n; int axis; };
+    std::vector<HNode> hpool;
+    bool hlbvh_panic = false;
+
+    static uint32_t left_shift_3(uint32_t x) {  // morton.rs:101-118 (wrapping shifts on u32)
+        uint32_t x1 = (x == (1u << 10)) ? x - 1 : x;
+        x1 = (x1 | (x1 << 16)) & 0x030000FFu;
+        x1 = (x1 | (x1 << 8)) & 0x0300F00Fu;
+        x1 = (x1 | (x1 << 4)) & 0x030C30C3u;
+        x1 = (x1 | (x1 << 2)) & 0x09249249u;
+        return x1;
+    }
+    static uint32_t encode_morton_3(V3 v) {
+        return (left_shift_3(float_to_bits(v.z)) << 2) | (left_shift_3(float_to_bits(v.y)) << 1) | left_shift_3(float_to_bits(v.x));
+    }
+    static void radix_sort(std::vector<MortonPrim>& v) {  // morton.rs:50-98: 5 stable passes of 6 bits
+        std::vector<MortonPrim> tmp(v.size());
+        for (int pass = 0; pass < 5; pass++) {
+            int low_bit = pass * 6;
+            std::vector<MortonPrim>& in = (pass & 1) ? tmp : v;
+            std::vector<MortonPrim>& out = (pass & 1) ? v : tmp;
+            size_t count[64] = {0}, out_index[64];
+            for (const MortonPrim& mp : in) count[(mp.morton_code >> low_bit) & 63]++;
+            out_index[0] = 0;
+            for (int i = 1; i < 64; i++) out_index[i] = out_index[i - 1] + count[i - 1];
+            for (const MortonPrim& mp : in) out[out_index[(mp.morton_code >> low_bit) & 63]++] = mp;
+        }
+        v.swap(tmp);  // N_PASSES is odd: the result sits in the temporary
+    }
+    int emit_lbvh(const std::vector<PrimInfo>& info, const MortonPrim* mp, size_t n, int bit_index) {  // hlbvh.rs:199-294
+        if (bit_index == -1 || n < (size_t)max_prims_in_node) {
+            HNode h; h.kid[0] = h.kid[1] = -1; h.axis = 0; h.n = (uint32_t)n;
+            h.first = (uint32_t)ordered_prims.size();
+            for (size_t i = 0; i < n; i++) {
+                ordered_prims.push_back((uint32_t)mp[i].primitive_index);
+                h.bounds = h.bounds.union_b(info[mp[i].primitive_index].bounds);
+            }
+            hpool.push_back(h);
+            return (int)hpool.size() - 1;
+        }
+        uint32_t mask = 1u << bit_index;
+        if ((mp[0].morton_code & mask) == (mp[n - 1].morton_code & mask)) return emit_lbvh(info, mp, n, bit_index - 1);
+        size_t search_start = 0, search_end = n - 1;
+        while (search_start + 1 != search_end) {
+            size_t mid = (search_start + search_end) / 2;
+            if ((mp[search_start].morton_code & mask) == (mp[mid].morton_code & mask)) search_start = mid;
+            else search_end = mid;
+        }
+        size_t split = search_end;
+        int c0 = emit_lbvh(info, mp, split, bit_index - 1);
+        int c1 = emit_lbvh(info, mp + split, n - split, bit_index - 1);
+        HNode h; h.kid[0] = c0; h.kid[1] = c1; h.first = 0; h.n = 0; h.axis = bit_index % 3;
+        h.bounds = hpool[c0].bounds.union_b(hpool[c1].bounds);
+        hpool.push_back(h);
+        return (int)hpool.size() - 1;
+    }
+    static size_t hl_bucket(Float centroid, Float lo, Float hi) {  // hlbvh.rs:349-355
+        size_t b = f2usize(12.0f * ((centroid - lo) / (hi - lo)));
+        if (b == 12) b = 11;
+        return b;
+    }
+    int build_upper_sah(std::vector<int>& roots, size_t start, size_t end) {  // hlbvh.rs:296-432
+        size_t n_nodes = end - start;
+        if (n_nodes == 1) return roots[start];
+        Bounds3 bounds, cb;
+        for (size_t i = start; i < end; i++) bounds = bounds.union_b(hpool[roots[i]].bounds);
+        for (size_t i = start; i < end; i++) cb = cb.union_p((hpool[roots[i]].bounds.pmin + hpool[roots[i]].bounds.pmax) * 0.5f);
+        int dim = cb.maximum_extent();
+        if (cb.pmax[dim] == cb.pmin[dim]) { hlbvh_panic = true; return roots[start]; }  // assert_ne! (:338)
+        size_t count[12] = {0}; Bounds3 bb[12];
+        for (size_t i = start; i < end; i++) {
+            const Bounds3& nb = hpool[roots[i]].bounds;
+            Float c = (nb.pmin[dim] + nb.pmax[dim]) * 0.5f;
+            size_t b = hl_bucket(c, cb.pmin[dim], cb.pmax[dim]);
+            if (b >= 12) { hlbvh_panic = true; return roots[start]; }  // assert!(b < N_BUCKETS)
+            count[b]++; bb[b] = bb[b].union_b(nb);
+        }
+        Float cost[11];
+        for (int i = 0; i < 11; i++) {
+            Bounds3 b0, b1; size_t c0 = 0, c1 = 0;
+            for (int j = 0; j <= i; j++) { b0 = b0.union_b(bb[j]); c0 += count[j]; }
+            for (int j = i + 1; j < 12; j++) { b1 = b1.union_b(bb[j]); c1 += count[j]; }
+            cost[i] = 0.125f + ((Float)c0 * b0.surface_area() + (Float)c1 * b1.surface_area()) / bounds.surface_area();
+        }
+        Float min_cost = cost[0]; size_t min_b = 0;
+        for (size_t i = 1; i < 11; i++) if (cost[i] < min_cost) { min_cost = cost[i]; min_b = i; }
+        // itertools::partition over the treelet roots
+        size_t split = 0;
+        {
+            size_t front = start, back = end;
+            auto pred = [&](int r) {
+                const Bounds3& nb = hpool[r].bounds;
+                Float c = (nb.pmin[dim] + nb.pmax[dim]) * 0.5f;
+                return hl_bucket(c, cb.pmin[dim], cb.pmax[dim]) <= min_b;
+            };
+            while (front != back) {
+                size_t f = front++;
+                if (!pred(roots[f])) {
+                    bool found = false;
+                    while (front != back) { size_t b = --back; if (pred(roots[b])) { std::swap(roots[f], roots[b]); found = true; break; } }
+                    if (!found) break;
+                }
+                split++;
+            }
+        }
+        size_t mid = start + split;
+        if (!(mid > start) || !(mid < end)) { hlbvh_panic = true; return roots[start]; }  // assert! (:418-419)
+        int c0 = build_upper_sah(roots, start, mid);
+        int c1 = build_upper_sah(roots, mid, end);
+        HNode h; h.kid[0] = c0; h.kid[1] = c1; h.first = 0; h.n = 0; h.axis = dim;
+        h.bounds = hpool[c0].bounds.union_b(hpool[c1].bounds);
+        hpool.push_back(h);
+        return (int)hpool.size() - 1;
+    }
+    uint32_t flatten_h(int node) {  // flatten_bvh_tree (bvh/mod.rs:118-150)
+        uint32_t my = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        const HNode h = hpool[node];
+        if (h.n > 0) {
+            nodes[my].bounds = h.bounds; nodes[my].offset = h.first; nodes[my].n_primitives = (uint16_t)h.n; nodes[my].axis = 0; nodes[my].pad = 0;
+            if (h.n >= 65536) hlbvh_panic = true;  // assert!(node.n_primitives < 65536)
+        } else {
+            flatten_h(h.kid[0]);
+            uint32_t c1 = flatten_h(h.kid[1]);
+            nodes[my].bounds = h.bounds; nodes[my].offset = c1; nodes[my].n_primitives = 0; nodes[my].axis = (uint8_t)h.axis; nodes[my].pad = 0;
+        }
+        return my;
+    }
+    void build_hlbvh(std::vector<PrimInfo>& info) {
+        Bounds3 bounds;
+        for (const PrimInfo& pi : info) bounds = bounds.union_b(pi.bounds);
+        std::vector<MortonPrim> mp(info.size());
+        for (size_t i = 0; i < info.size(); i++) {
+            V3 v = bounds.offset(info[i].centroid) * 1024.0f;  // MORTON_SCALE = 1 << 10
+            mp[i].primitive_index = info[i].number; mp[i].morton_code = encode_morton_3(v);
+        }
+        radix_sort(mp);
+        hpool.clear(); hlbvh_panic = false;
+        std::vector<int> roots;
+        const uint32_t MASK = 0x3FFC0000u;
+        size_t start = 0;
+        for (size_t end = 1; end <= mp.size(); end++) {
+            if (end == mp.size() || ((mp[start].morton_code & MASK) != (mp[end].morton_code & MASK))) {
+                roots.push_back(emit_lbvh(info, &mp[start], end - start, 29 - 12));  // FIRST_BIT_INDEX = N_BITS - 1 - N_BUCKETS
+                start = end;
+            }
+        }
+        int root = build_upper_sah(roots, 0, roots.size());
+        flatten_h(root);
+    }
+
     void build_bvh(int split_method, int max_prims) {
         max_prims_in_node = max_prims & 0xff;  // quirk B8: `as u8`
         nodes.clear(); ordered_prims.clear();
@@ -368,7 +526,8 @@ struct Scene {
             info[i].centroid = 0.5f * (info[i].bounds.pmin + info[i].bounds.pmax);  // common.rs:85-91
         }
         nodes.reserve(2 * n); ordered_prims.reserve(n);
-        build_rec(info, 0, n, split_method);
+        if (split_method == 1) build_hlbvh(info);
+        else build_rec(info, 0, n, split_method);
         world_bound = nodes[0].bounds;
         world_bound.bounding_sphere(world_center, world_radius);  // Light::preprocess (infinite.rs:113-117, distant.rs:54-58)
     }

@@ -537,11 +537,12 @@ int pbrt_hip_set_sobol_tables(PbrtHipScene* s, const uint32_t* m32, size_t n32, 
 
 int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_node) {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
-    if (split_method == 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: HLBVH is a 'next' row (SURVEY §8f)");
     if (split_method == 2) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: splitmethod 'middle' panics in the reference (quirk B6, sah.rs:67-76)");
     phost::BuildInput in;
     in.P = s->P.data(); in.idx = s->idx.data(); in.n_tris = s->idx.size() / 3; in.tri_flags = s->tri_flags.data(); in.tri_mesh = s->tri_mesh.data();
-    if (phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh) != 0) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: bad arguments");
+    const int brc = phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh);
+    if (brc == -2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: the reference's HLBVH build asserts on this input (hlbvh.rs:338/356/418)");
+    if (brc != 0) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: bad arguments");
     // Light::preprocess: bounding sphere of the world bound (bounds3.rs:196-208; infinite.rs:113-117, distant.rs:54-58)
     s->world_radius = 1.0f; s->world_center[0] = s->world_center[1] = s->world_center[2] = 0.0f;
     if (in.n_tris) {

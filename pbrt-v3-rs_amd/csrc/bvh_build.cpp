@@ -144,12 +144,169 @@ struct Builder {
         node->b = node->kid[0]->b; node->b.grow(node->kid[1]->b);  // bvh/common.rs:152-160
         return node;
     }
+
+    // ================= HLBVH (accelerators/src/bvh/hlbvh.rs:33-449, morton.rs) =========================================
+    // Same tree as the reference builds, including its Morton quirk: encode_morton_3 interleaves the low bits of the IEEE
+    // bit pattern of the scaled centroid offset (morton.rs:33-39 `float_to_bits`), so the order is not spatial and the
+    // tree is valid but slow to traverse.  Treelets are independent and built by a thread pool; the reference hands out
+    // ordered_prims offsets in completion order, here leaves are laid out depth first afterwards (nothing a ray can
+    // observe depends on it).
+    struct MP { uint32_t id, code; };
+    std::vector<MP> mp;
+    std::atomic<bool> panic{false};
+
+    static uint32_t left_shift_3(uint32_t x) {  // morton.rs:101-118
+        uint32_t v = (x == (1u << 10)) ? x - 1 : x;
+        v = (v | (v << 16)) & 0x030000FFu;
+        v = (v | (v << 8)) & 0x0300F00Fu;
+        v = (v | (v << 4)) & 0x030C30C3u;
+        v = (v | (v << 2)) & 0x09249249u;
+        return v;
+    }
+    static uint32_t bits_of(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+    BNode* emit_lbvh(size_t first, size_t n, int bit) {  // hlbvh.rs:199-294; leaves refer to [first, first+n) of `mp`
+        for (;;) {
+            if (bit == -1 || n < (size_t)max_prims) {
+                BNode* leaf = alloc();
+                leaf->b.reset();
+                for (size_t i = 0; i < n; i++) leaf->b.grow(prims[mp[first + i].id].b);
+                leaf->kid[0] = leaf->kid[1] = nullptr; leaf->first = (uint32_t)first; leaf->count = (uint32_t)n; leaf->axis = 0;
+                return leaf;
+            }
+            const uint32_t mask = 1u << bit;
+            if ((mp[first].code & mask) != (mp[first + n - 1].code & mask)) break;
+            bit--;  // no split on this bit
+        }
+        const uint32_t mask = 1u << bit;
+        size_t lo = 0, hi = n - 1;
+        while (lo + 1 != hi) {
+            const size_t mid = (lo + hi) / 2;
+            if ((mp[first + lo].code & mask) == (mp[first + mid].code & mask)) lo = mid; else hi = mid;
+        }
+        BNode* node = alloc();
+        node->kid[0] = emit_lbvh(first, hi, bit - 1);
+        node->kid[1] = emit_lbvh(first + hi, n - hi, bit - 1);
+        node->axis = bit % 3; node->first = 0; node->count = 0;
+        node->b = node->kid[0]->b; node->b.grow(node->kid[1]->b);
+        return node;
+    }
+    static uint32_t hl_bucket(float c, float lo, float hi) {  // hlbvh.rs:349-355 (saturating `as usize`)
+        const float f = (float)kBuckets * ((c - lo) / (hi - lo));
+        uint32_t b = !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)f);
+        if (b == (uint32_t)kBuckets) b = kBuckets - 1;
+        return b;
+    }
+    BNode* upper_sah(std::vector<BNode*>& roots, size_t start, size_t end) {  // hlbvh.rs:296-432
+        if (end - start == 1) return roots[start];
+        Box bounds, cb; bounds.reset(); cb.reset();
+        for (size_t i = start; i < end; i++) bounds.grow(roots[i]->b);
+        for (size_t i = start; i < end; i++) {
+            float c[3];
+            for (int k = 0; k < 3; k++) c[k] = (roots[i]->b.lo[k] + roots[i]->b.hi[k]) * 0.5f;
+            cb.grow_pt(c);
+        }
+        const int dim = cb.widest();
+        if (cb.hi[dim] == cb.lo[dim]) { panic = true; return roots[start]; }  // assert_ne! (:338)
+        size_t cnt[kBuckets]; Box bb[kBuckets];
+        for (int i = 0; i < kBuckets; i++) { cnt[i] = 0; bb[i].reset(); }
+        auto bucket = [&](const BNode* r) { return hl_bucket((r->b.lo[dim] + r->b.hi[dim]) * 0.5f, cb.lo[dim], cb.hi[dim]); };
+        for (size_t i = start; i < end; i++) {
+            const uint32_t b = bucket(roots[i]);
+            if (b >= (uint32_t)kBuckets) { panic = true; return roots[start]; }
+            cnt[b]++; bb[b].grow(roots[i]->b);
+        }
+        float best = 0.0f; int best_b = 0;
+        for (int i = 0; i < kBuckets - 1; i++) {
+            Box b0, b1; b0.reset(); b1.reset(); size_t c0 = 0, c1 = 0;
+            for (int j = 0; j <= i; j++) { b0.grow(bb[j]); c0 += cnt[j]; }
+            for (int j = i + 1; j < kBuckets; j++) { b1.grow(bb[j]); c1 += cnt[j]; }
+            const float cost = 0.125f + ((float)c0 * b0.area() + (float)c1 * b1.area()) / bounds.area();
+            if (i == 0 || cost < best) { best = cost; best_b = i; }
+        }
+        size_t split = 0, front = start, back = end;  // itertools::partition
+        while (front != back) {
+            const size_t f = front++;
+            if (!(bucket(roots[f]) <= (uint32_t)best_b)) {
+                bool swapped = false;
+                while (front != back) {
+                    const size_t b = --back;
+                    if (bucket(roots[b]) <= (uint32_t)best_b) { std::swap(roots[f], roots[b]); swapped = true; break; }
+                }
+                if (!swapped) break;
+            }
+            split++;
+        }
+        const size_t mid = start + split;
+        if (!(mid > start) || !(mid < end)) { panic = true; return roots[start]; }  // assert! (:418-419)
+        BNode* node = alloc();
+        node->kid[0] = upper_sah(roots, start, mid);
+        node->kid[1] = upper_sah(roots, mid, end);
+        node->axis = dim; node->first = 0; node->count = 0;
+        node->b = node->kid[0]->b; node->b.grow(node->kid[1]->b);
+        return node;
+    }
+    BNode* build_hlbvh(int n_threads) {
+        const size_t n = prims.size();
+        Box bounds; bounds.reset();
+        for (const Prim& p : prims) bounds.grow(p.b);
+        mp.resize(n);
+        for (size_t i = 0; i < n; i++) {  // compute_morton_primitives (:97-135): Bounds3::offset * 1024, then the BITS of each float
+            uint32_t c[3];
+            for (int k = 0; k < 3; k++) {
+                float o = prims[i].c[k] - bounds.lo[k];
+                if (bounds.hi[k] > bounds.lo[k]) o /= bounds.hi[k] - bounds.lo[k];
+                c[k] = left_shift_3(bits_of(o * 1024.0f));
+            }
+            mp[i].id = (uint32_t)i; mp[i].code = (c[2] << 2) | (c[1] << 1) | c[0];
+        }
+        {  // radix_sort (morton.rs:50-98): five stable 6-bit passes
+            std::vector<MP> tmp(n);
+            for (int pass = 0; pass < 5; pass++) {
+                const int low = pass * 6;
+                std::vector<MP>& in = (pass & 1) ? tmp : mp;
+                std::vector<MP>& out = (pass & 1) ? mp : tmp;
+                size_t count[64] = {0}, at[64];
+                for (const MP& m : in) count[(m.code >> low) & 63]++;
+                at[0] = 0;
+                for (int i = 1; i < 64; i++) at[i] = at[i - 1] + count[i - 1];
+                for (const MP& m : in) out[at[(m.code >> low) & 63]++] = m;
+            }
+            mp.swap(tmp);
+        }
+        struct Span { size_t first, n; };
+        std::vector<Span> spans;
+        const uint32_t MASK = 0x3FFC0000u;
+        for (size_t start = 0, end = 1; end <= n; end++)
+            if (end == n || ((mp[start].code & MASK) != (mp[end].code & MASK))) { spans.push_back({start, end - start}); start = end; }
+        std::vector<BNode*> roots(spans.size());
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < spans.size();) roots[i] = emit_lbvh(spans[i].first, spans[i].n, 29 - 12); };
+        std::vector<std::thread> pool_threads;
+        for (int t = 1; t < n_threads && (size_t)t < spans.size(); t++) pool_threads.emplace_back(work);
+        work();
+        for (std::thread& t : pool_threads) t.join();
+        BNode* root = upper_sah(roots, 0, roots.size());
+        // lay the leaves out depth first: prims[] becomes the final primitive order, leaf ranges point into it
+        std::vector<Prim> ordered; ordered.reserve(n);
+        std::vector<BNode*> stack{root};
+        while (!stack.empty()) {
+            BNode* nd = stack.back(); stack.pop_back();
+            if (!nd->kid[0]) {
+                const uint32_t first = (uint32_t)ordered.size();
+                for (uint32_t i = 0; i < nd->count; i++) ordered.push_back(prims[mp[nd->first + i].id]);
+                nd->first = first;
+            } else { stack.push_back(nd->kid[1]); stack.push_back(nd->kid[0]); }
+        }
+        prims.swap(ordered);
+        return root;
+    }
 };
 
 }  // namespace
 
 int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int n_threads, BuildOutput& out) {
-    if (split_method != 0 && split_method != 3) return -1;
+    if (split_method != 0 && split_method != 1 && split_method != 3) return -1;
     out = BuildOutput();
     const size_t n = in.n_tris;
     if (n == 0) return 0;
@@ -171,7 +328,8 @@ int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int
     B.pool.resize(2 * n);
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     B.spare_threads = n_threads > 1 ? n_threads - 1 : 0;
-    BNode* root = B.build(0, n);
+    BNode* root = split_method == 1 ? B.build_hlbvh(std::max(n_threads, 1)) : B.build(0, n);
+    if (B.panic) return -2;  // one of the reference's assertions fired (hlbvh.rs:338/356/418)
 
     // ---- emit device layout: TriRecs in final prim-array order (= depth-first leaf order), Node64s in pre-order -------
     out.tris.resize(n);

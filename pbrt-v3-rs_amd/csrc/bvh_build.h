@@ -33,8 +33,8 @@ struct BuildOutput {
     double build_seconds = 0;
 };
 
-// split_method: 0 SAH, 3 EqualCounts.  (1 HLBVH and 2 Middle are not offered: see DESIGN.md.)
-// Returns 0 on success, <0 on invalid arguments.
+// split_method: 0 SAH, 1 HLBVH, 3 EqualCounts.  (2 Middle is not offered: it panics in the reference, DESIGN.md.)
+// Returns 0 on success, -1 on invalid arguments, -2 where the reference's HLBVH build would hit an assertion.
 int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int n_threads, BuildOutput& out);
 
 }  // namespace phost

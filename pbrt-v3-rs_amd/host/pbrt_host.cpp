@@ -458,7 +458,8 @@ int Api::pbrt_world_end(RenderReport& rep) {
         const std::string sm = accel_p_.find_one_string("splitmethod", "sah");
         if (sm == "sah") split = 0;
         else if (sm == "equal") split = 3;
-        else if (sm == "middle" || sm == "hlbvh") { error = "BVH splitmethod \"" + sm + "\" is outside the hot-path scope (supported: sah, equal)"; return PBRT_HIP_ERR_UNSUPPORTED; }
+        else if (sm == "hlbvh") split = 1;
+        else if (sm == "middle") { error = "BVH splitmethod \"middle\" panics in the reference (sah.rs:67-76) and is not offered (supported: sah, hlbvh, equal)"; return PBRT_HIP_ERR_UNSUPPORTED; }
         else { warn("BVH split method \"" + sm + "\" unknown.  Using \"sah\"."); split = 0; }
     } else { error = "Accelerator \"" + accel_name_ + "\" is outside the hot-path scope (supported: bvh)"; return PBRT_HIP_ERR_UNSUPPORTED; }
     const int max_prims = accel_p_.find_one_int("maxnodeprims", 4);

@@ -207,7 +207,7 @@ def test_unsupported_and_state_errors(host):
     pbrt_hip.capture_spec(spec, s, host)
     s.add_light_point((1, 1, 1), (0, 0, 3)); s.build_accel(0, 4)
     with pytest.raises(pbrt_hip.PbrtHipError) as e:
-        s.build_accel(1, 4)                   # HLBVH
+        s.build_accel(2, 4)                   # Middle: panics in the reference (quirk B6)
     assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
     with pytest.raises(pbrt_hip.PbrtHipError) as e:
         s.set_sampler(2, 4, [0, 0, 16, 16])   # random sampler: per-tile sequential RNG, CPU only
@@ -235,3 +235,18 @@ def test_sobol_sampler_film_bit_exact(host):
         cap(s); s.set_sampler(1, 6, s.sample_bounds)
     g, o, _ = _assert_film_bit_exact(cap6, max_depth=2)
     assert g[2].camera_rays == 72 * 50 * 8
+
+
+def test_hlbvh_scene_renders_the_sah_image(host):
+    """`Accelerator "bvh" "string splitmethod" "hlbvh"`: a different tree, the same radiance — bit-exact against the oracle using
+    its own HLBVH, and equal to the SAH render wherever no equal-t tie is involved (random triangles: everywhere)."""
+    spec = pbrt_hip.SceneSpec(n_tris=1500, seed=4, xres=32, yres=32, spp=2, max_depth=3)
+
+    def cap(split):
+        def f(s):
+            pbrt_hip.capture_spec(spec, s, host)
+            s.build_accel(split, 4)
+        return f
+    g1, o1, _ = _assert_film_bit_exact(cap(1), max_depth=3)
+    g0, o0, _ = _assert_film_bit_exact(cap(0), max_depth=3)
+    assert _bits_equal(g0[0], g1[0])

@@ -120,3 +120,30 @@ def test_empty_and_error_paths(host):
     assert len(s.intersect_batch(np.zeros(0, pbrt_hip.RAY_DTYPE))) == 0
     with pytest.raises(pbrt_hip.PbrtHipError):
         s.add_mesh(np.zeros((3, 3), np.float32), [0, 1, 5], m)  # out-of-bounds index (triangle.rs:252-261)
+
+
+@pytest.mark.parametrize("split_method,max_prims", [(1, 4), (1, 1), (3, 4)])
+def test_other_split_methods_bit_exact(host, split_method, max_prims):
+    """HLBVH (hlbvh.rs, incl. its Morton-bit-pattern quirk) and EqualCounts trees on the device: same closest hits and occlusion
+    flags as the oracle traversing the oracle's own tree of that kind; the grid mesh puts equal-t ties on shared edges, which
+    resolve by traversal order and therefore test the topology."""
+    Pg, ig = scenes.grid_mesh(6, z=0.1, size=0.9)
+    P, idx = host.gen_random_tris(3000, 21)
+
+    def capture(s):
+        m = s.add_material_matte()
+        s.add_mesh(P, idx, m)
+        s.add_mesh(Pg, ig, m)
+        s.build_accel(split_method, max_prims)
+    prod, orc = scenes.build_pair(capture, OracleScene)
+    n = len(Pg)
+    edge = np.zeros(n, pbrt_hip.RAY_DTYPE)
+    edge["t_max"] = np.inf; edge["o"] = Pg + np.array([0, 0, 2], np.float32); edge["d"] = [0, 0, -1]
+    rays = np.concatenate([scenes.random_rays(30000, 77), scenes.axis_rays(), edge])
+    got = prod.intersect_batch(rays)
+    want, st = orc.intersect_batch_stats(rays)
+    eq = scenes.hits_equal(got, want)
+    assert eq.all(), f"{(~eq).sum()} of {len(rays)} rays differ"
+    assert np.array_equal(prod.occluded_batch(rays), orc.occluded_batch_stats(rays)[0])
+    if split_method == 1:
+        assert st.nodes_visited / st.rays > 300   # the reference's HLBVH is not spatially coherent (DESIGN quirk B10)
