@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=64, help="spp of the bounded CPU-baseline sample (same scene, same resolution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-count", action="store_true")
+    ap.add_argument("--instances", type=int, default=0,
+                    help="K > 0: the triangles become one object instanced K times (two-level BVH, TransformedPrimitive path); not the headline workload")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = spp x N (per-GPU work fixed), strong = the N=1 frame split over N ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -98,7 +100,7 @@ def main():
     spec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=frame_spp, max_depth=args.max_depth)
     scene = pbrt_hip.Scene(device=local_rank)
     t_setup = time.time()
-    geometry = pbrt_hip.capture_spec(spec, scene, host)
+    geometry = pbrt_hip.capture_spec(spec, scene, host, instances=args.instances)
     t_setup = time.time() - t_setup
 
     tile_size = 16
@@ -164,7 +166,8 @@ def main():
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {args.n_tris} random triangles (seed {args.seed}), single SAH BVH, {args.res}x{args.res} @ {frame_spp} spp{spp_note}, "
+            "config": {"workload": ("" if not args.instances else f"INSTANCED x{args.instances} (one object, two-level BVH) — ") +
+                                   f"configs[1]: {args.n_tris} random triangles (seed {args.seed}), single SAH BVH, {args.res}x{args.res} @ {frame_spp} spp{spp_note}, "
                                    f"PathIntegrator maxdepth {args.max_depth}, halton, box filter, constant infinite light, matte Kd 0.5",
                        "tiles": "16x16, tile t on rank t % n_gpus, film tiles gathered on rank 0 (RCCL)" if world > 1 else "16x16, one rank",
                        "rays_per_frame": rays // args.steps, "regular_rays_per_frame": reg // args.steps, "shadow_rays_per_frame": shd // args.steps,
@@ -226,7 +229,7 @@ def main():
         cspec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=args.cpu_spp, max_depth=args.max_depth)
         orc = OracleScene()
         tb = time.time()
-        pbrt_hip.capture_spec(cspec, orc, host, geometry=geometry)
+        pbrt_hip.capture_spec(cspec, orc, host, geometry=geometry, instances=args.instances)
         tb = time.time() - tb
         _, _, ost, _ = orc.render_path_ex(max_depth=args.max_depth, threads=cores)
         crays = ost.regular_rays + ost.shadow_rays

@@ -47,6 +47,9 @@ typedef struct PbrtHipRay {
  * ray-dependent quantities of Triangle::intersect (shapes/src/triangle.rs:438-545): t, barycentrics and the
  * primitive.  prim = index into the concatenation of all meshes' triangles in pbrt_hip_add_mesh order
  * (= position in the reference's `primitives: &[ArcPrimitive]` before BVH reordering); 0xFFFFFFFF on a miss.
+ * For a hit inside an object instance prim is the triangle's number in add_mesh order (object meshes included) and pad[1] =
+ * instance number + 1 (add_instance call order); t, b0..b2 are those of the instance-space ray, as TransformedPrimitive::intersect
+ * leaves them in `r.t_max` (transformed_primitive.rs:56).  pad[1] = 0 otherwise.
  * pad[0] carries the library's leaf-order index of the hit triangle (an internal shortcut for the shade stage); ignore it. */
 typedef struct PbrtHipHit {
     float t;
@@ -92,6 +95,16 @@ int pbrt_hip_add_material_matte(PbrtHipScene*, const float kd_rgb[3], float sigm
 int pbrt_hip_add_mesh(PbrtHipScene*, const float* P, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris,
                       const float* N, const float* S, const float* UV, uint32_t material_id,
                       int32_t first_area_light_id, uint32_t flags, float alpha, float shadow_alpha);
+
+/* Object instancing (api/src/lib.rs:911-1000, core/src/primitives/transformed_primitive.rs:33-73).  Meshes added between
+ * object_begin and object_end belong to the object, not to the scene (ObjectBegin/ObjectEnd); add_instance places one
+ * TransformedPrimitive(object aggregate, instance_to_world) in the scene's primitive list (ObjectInstance) — nothing if the
+ * object is empty.  The object's aggregate uses the split method of pbrt_hip_build_accel; an object with exactly one
+ * primitive is used directly (lib.rs:953-971).  Area lights inside objects are refused (the reference drops them with a
+ * warning, lib.rs:877-881).  Transforms are static (AnimatedTransform with equal end points). */
+int pbrt_hip_object_begin(PbrtHipScene*, uint32_t* out_object_id);
+int pbrt_hip_object_end(PbrtHipScene*);
+int pbrt_hip_add_instance(PbrtHipScene*, uint32_t object_id, const float instance_to_world[16], const float world_to_instance[16]);
 
 /* Lights are numbered in call order = position in Scene::lights (core/src/scene.rs:50-75). */
 int pbrt_hip_add_light_infinite(PbrtHipScene*, const float L_rgb[3], const float light_to_world[16],

@@ -50,6 +50,7 @@ int oracle_add_mesh(OracleScene* s, const float* P, uint32_t n_verts, const uint
     if (material_id >= s->sc.materials.size()) { s->err = "bad material id"; return -1; }
     for (uint32_t i = 0; i < 3 * n_tris; i++) if (indices[i] >= n_verts) { s->err = "vertex index out of bounds"; return -1; }
     Scene& sc = s->sc;
+    if (sc.open_object >= 0 && first_area_light_id >= 0) { s->err = "area lights are not supported inside an object instance (lib.rs:877-881)"; return -5; }
     Mesh m;
     m.vert_base = (uint32_t)sc.P.size(); m.tri_base = (uint32_t)sc.n_tris(); m.n_verts = n_verts; m.n_tris = n_tris;
     m.has_n = N != nullptr; m.has_s = S != nullptr; m.has_uv = UV != nullptr;
@@ -78,6 +79,40 @@ int oracle_add_mesh(OracleScene* s, const float* P, uint32_t n_verts, const uint
             l.area = 0.5f * length(cross(p1 - p0, p2 - p0));  // Triangle::area (triangle.rs:906-911)
         }
     }
+    if (sc.open_object >= 0) sc.objects[sc.open_object].tri1 = m.tri_base + n_tris;
+    else for (uint32_t k = 0; k < n_tris; k++) sc.top_items.push_back(m.tri_base + k);
+    s->built = false;
+    return 0;
+}
+
+// ObjectBegin / ObjectEnd / ObjectInstance (api/src/lib.rs:911-1000)
+int oracle_object_begin(OracleScene* s, uint32_t* out_id) {
+    if (!s || !out_id) return -1;
+    Scene& sc = s->sc;
+    if (sc.open_object >= 0) { s->err = "ObjectBegin called inside of an instance definition"; return -2; }
+    Object ob; ob.tri0 = ob.tri1 = (uint32_t)sc.n_tris();
+    sc.objects.push_back(ob);
+    sc.open_object = (int)sc.objects.size() - 1;
+    *out_id = (uint32_t)sc.open_object;
+    return 0;
+}
+int oracle_object_end(OracleScene* s) {
+    if (!s) return -1;
+    if (s->sc.open_object < 0) { s->err = "ObjectEnd called outside of instance definition"; return -2; }
+    s->sc.open_object = -1;
+    return 0;
+}
+int oracle_add_instance(OracleScene* s, uint32_t object_id, const float i2w[16], const float w2i[16]) {
+    if (!s || !i2w || !w2i) return -1;
+    Scene& sc = s->sc;
+    if (sc.open_object >= 0) { s->err = "ObjectInstance can't be called inside of instance definition"; return -2; }
+    if (object_id >= sc.objects.size()) { s->err = "unknown object"; return -1; }
+    if (sc.objects[object_id].tri1 == sc.objects[object_id].tri0) return 0;  // empty object: nothing is added (lib.rs:949-951)
+    Instance in; in.object = object_id;
+    M4 a, b; std::memcpy(a.m, i2w, 64); std::memcpy(b.m, w2i, 64);
+    in.i2w = Transform(a, b);
+    sc.instances.push_back(in);
+    sc.top_items.push_back(ORC_INST_BIT | (uint32_t)(sc.instances.size() - 1));
     s->built = false;
     return 0;
 }
@@ -165,7 +200,7 @@ int oracle_intersect_batch_stats(OracleScene* s, const OracleRay* rays, OracleHi
             uint32_t prim = 0xffffffffu; TriHit h{0, 0, 0, 0};
             bool found = s->sc.intersect(r, prim, h, st ? &ts[tid] : nullptr);
             OracleHit& o = hits[i]; std::memset(&o, 0, sizeof(o));
-            if (found) { o.t = h.t; o.prim = prim; o.b0 = h.b0; o.b1 = h.b1; o.b2 = h.b2; }
+            if (found) { o.t = h.t; o.prim = prim; o.b0 = h.b0; o.b1 = h.b1; o.b2 = h.b2; o.pad[1] = h.inst; }
             else { o.t = rays[i].t_max; o.prim = 0xffffffffu; }
         }
     };

@@ -323,6 +323,27 @@ struct Transform {
                   m_inv.m[0][1] * n.x + m_inv.m[1][1] * n.y + m_inv.m[2][1] * n.z,
                   m_inv.m[0][2] * n.x + m_inv.m[1][2] * n.y + m_inv.m[2][2] * n.z);
     }
+    // transform.rs:338-370
+    V3 point_with_abs_error(V3 p, V3 pe, V3& err) const {
+        Float x = p.x, y = p.y, z = p.z;
+        Float xp = (m.m[0][0] * x + m.m[0][1] * y) + (m.m[0][2] * z + m.m[0][3]);
+        Float yp = (m.m[1][0] * x + m.m[1][1] * y) + (m.m[1][2] * z + m.m[1][3]);
+        Float zp = (m.m[2][0] * x + m.m[2][1] * y) + (m.m[2][2] * z + m.m[2][3]);
+        Float wp = (m.m[3][0] * x + m.m[3][1] * y) + (m.m[3][2] * z + m.m[3][3]);
+        Float g3 = gamma_n(3);
+        err = V3((g3 + 1.0f) * (pabs(m.m[0][0]) * pe.x + pabs(m.m[0][1]) * pe.y + pabs(m.m[0][2]) * pe.z) +
+                     g3 * (pabs(m.m[0][0] * x) + pabs(m.m[0][1] * y) + pabs(m.m[0][2] * z) + pabs(m.m[0][3])),
+                 (g3 + 1.0f) * (pabs(m.m[1][0]) * pe.x + pabs(m.m[1][1]) * pe.y + pabs(m.m[1][2]) * pe.z) +
+                     g3 * (pabs(m.m[1][0] * x) + pabs(m.m[1][1] * y) + pabs(m.m[1][2] * z) + pabs(m.m[1][3])),
+                 (g3 + 1.0f) * (pabs(m.m[2][0]) * pe.x + pabs(m.m[2][1]) * pe.y + pabs(m.m[2][2]) * pe.z) +
+                     g3 * (pabs(m.m[2][0] * x) + pabs(m.m[2][1] * y) + pabs(m.m[2][2] * z) + pabs(m.m[2][3])));
+        if (wp == 1.0f) return V3(xp, yp, zp);
+        return V3(xp, yp, zp) / wp;
+    }
+    bool is_identity() const {                                                                // transform.rs:265-267
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (m.m[i][j] != (i == j ? 1.0f : 0.0f)) return false;
+        return true;
+    }
     bool swaps_handedness() const {                                                           // transform.rs:593-599
         Float det = m.m[0][0] * (m.m[1][1] * m.m[2][2] - m.m[1][2] * m.m[2][1]) -
                     m.m[0][1] * (m.m[1][0] * m.m[2][2] - m.m[1][2] * m.m[2][0]) +

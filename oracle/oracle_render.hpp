@@ -402,7 +402,24 @@ struct Renderer {
     }
 
     // ---- tail of Triangle::intersect (triangle.rs:547-724) + Hit::new (interaction/mod.rs:137-156)
-    SurfaceHit make_surface_hit(const Ray& r, uint32_t prim, const TriHit& h) const {
+    SurfaceHit make_surface_hit(const Ray& r_world, uint32_t prim, const TriHit& h) const {
+        if (h.inst == 0) return make_surface_hit_local(r_world, prim, h);
+        // TransformedPrimitive::intersect (transformed_primitive.rs:51-73): the triangle was met by the instance-space ray, its
+        // interaction is then carried to world space by transform_surface_interaction (transform.rs:566-590)
+        const Instance& in = sc->instances[h.inst - 1];
+        Ray ray = transform_ray(in.i2w.inv(), r_world);
+        SurfaceHit si = make_surface_hit_local(ray, prim, h);
+        if (in.i2w.is_identity()) return si;
+        const Transform& t = in.i2w;
+        V3 pe; si.p = t.point_with_abs_error(si.p, si.p_error, pe); si.p_error = pe;
+        si.wo = normalize(t.vector(si.wo));
+        si.n = normalize(t.normal(si.n));
+        si.ns = normalize(t.normal(si.ns));
+        si.ns = face_forward(si.ns, si.n);
+        si.dpdu_s = t.vector(si.dpdu_s);
+        return si;
+    }
+    SurfaceHit make_surface_hit_local(const Ray& r, uint32_t prim, const TriHit& h) const {
         const Scene& s = *sc; const Mesh& m = s.mesh_of(prim);
         uint32_t i0 = s.idx[3 * prim], i1 = s.idx[3 * prim + 1], i2 = s.idx[3 * prim + 2];
         V3 p0 = s.P[i0], p1 = s.P[i1], p2 = s.P[i2];

@@ -56,7 +56,35 @@ struct LinearBVHNode {  // accelerators/src/bvh/common.rs:163-179 (32 bytes)
     uint8_t axis, pad;
 };
 
-struct TriHit { Float t, b0, b1, b2; };
+struct TriHit { Float t, b0, b1, b2; uint32_t inst = 0; };  // inst = instance number + 1 when the hit lies inside an ObjectInstance
+
+// Object instancing (api/src/lib.rs:911-1000, core/src/primitives/transformed_primitive.rs).  An object is a contiguous range
+// of the scene's triangles; when it is instanced the reference wraps its primitives in one aggregate (the BVH the Accelerator
+// directive names) unless there is exactly one, which is used directly (lib.rs:953-971).
+#define ORC_INST_BIT 0x80000000u
+struct Object {
+    uint32_t tri0 = 0, tri1 = 0;
+    bool built = false;
+    std::vector<LinearBVHNode> nodes; std::vector<uint32_t> ordered_prims;
+    Bounds3 bound;
+};
+struct Instance { uint32_t object; Transform i2w; };
+
+// Transform::transform_ray (core/src/geometry/transform.rs:451-476) incl. quirk B2 (t_max -= dt)
+inline Ray transform_ray(const Transform& t, const Ray& r) {
+    V3 o_error; V3 o = t.point_with_error(r.o, o_error);
+    V3 d = t.vector(r.d);
+    Float l2 = length_squared(d), t_max = r.t_max;
+    if (l2 > 0.0f) { Float dt = dot(vabs(d), o_error) / l2; o = o + d * dt; t_max -= dt; }
+    return Ray(o, d, t_max, r.time);
+}
+inline Bounds3 transform_bounds(const Transform& t, const Bounds3& b) {  // transform.rs:552-561
+    return Bounds3(t.point(V3(b.pmin.x, b.pmin.y, b.pmin.z)))
+        .union_p(t.point(V3(b.pmax.x, b.pmin.y, b.pmin.z))).union_p(t.point(V3(b.pmin.x, b.pmax.y, b.pmin.z)))
+        .union_p(t.point(V3(b.pmin.x, b.pmin.y, b.pmax.z))).union_p(t.point(V3(b.pmin.x, b.pmax.y, b.pmax.z)))
+        .union_p(t.point(V3(b.pmax.x, b.pmax.y, b.pmin.z))).union_p(t.point(V3(b.pmax.x, b.pmin.y, b.pmax.z)))
+        .union_p(t.point(V3(b.pmax.x, b.pmax.y, b.pmax.z)));
+}
 
 struct TraversalStats { uint64_t nodes_visited = 0, tri_tests = 0, rays = 0; };
 
@@ -70,6 +98,11 @@ struct Scene {
     std::vector<Material> materials;
     std::vector<Light> lights;
     std::vector<int> infinite_lights;
+    // objects / instances; top_items = the scene's primitive list in directive order (triangle id, or ORC_INST_BIT | instance)
+    std::vector<Object> objects;
+    std::vector<Instance> instances;
+    std::vector<uint32_t> top_items;
+    int open_object = -1;
     // BVH
     std::vector<LinearBVHNode> nodes;
     std::vector<uint32_t> ordered_prims;
@@ -193,10 +226,38 @@ struct Scene {
         return t_min < ray.t_max && t_max > 0.0f;
     }
 
-    // ---- BVHAccel::intersect (bvh/mod.rs:173-226) + GeometricPrimitive::intersect's r.t_max = t (:67-88)
-    bool intersect(Ray& r, uint32_t& prim_out, TriHit& hit_out, TraversalStats* st = nullptr) const {
+    // ---- one primitive of an aggregate: a triangle (GeometricPrimitive::intersect, :67-88, `r.t_max = t`) or a
+    //      TransformedPrimitive (transformed_primitive.rs:51-73)
+    bool prim_intersect(Ray& r, uint32_t ref, uint32_t& prim_out, TriHit& hit_out, TraversalStats* st) const {
+        if (!(ref & ORC_INST_BIT)) {
+            TriHit h;
+            if (st) st->tri_tests++;
+            if (tri_intersect(r, ref, true, false, h)) { r.t_max = h.t; prim_out = ref; hit_out = h; return true; }
+            return false;
+        }
+        const uint32_t ii = ref & ~ORC_INST_BIT;
+        const Instance& in = instances[ii]; const Object& ob = objects[in.object];
+        Ray ray = transform_ray(in.i2w.inv(), r);
+        bool hit;
+        if (ob.tri1 - ob.tri0 == 1) hit = prim_intersect(ray, ob.tri0, prim_out, hit_out, st);
+        else hit = intersect_in(ob.nodes, ob.ordered_prims, ray, prim_out, hit_out, st);
+        if (!hit) return false;
+        r.t_max = ray.t_max;
+        hit_out.inst = ii + 1;
+        return true;
+    }
+    bool prim_intersect_p(const Ray& r, uint32_t ref, TraversalStats* st) const {
+        if (!(ref & ORC_INST_BIT)) { TriHit h; if (st) st->tri_tests++; return tri_intersect(r, ref, true, true, h); }
+        const Instance& in = instances[ref & ~ORC_INST_BIT]; const Object& ob = objects[in.object];
+        Ray ray = transform_ray(in.i2w.inv(), r);
+        if (ob.tri1 - ob.tri0 == 1) return prim_intersect_p(ray, ob.tri0, st);
+        return intersect_p_in(ob.nodes, ob.ordered_prims, ray, st);
+    }
+
+    // ---- BVHAccel::intersect (bvh/mod.rs:173-226)
+    bool intersect_in(const std::vector<LinearBVHNode>& nodes, const std::vector<uint32_t>& ordered_prims, Ray& r, uint32_t& prim_out, TriHit& hit_out,
+                      TraversalStats* st) const {
         bool any = false;
-        if (st) st->rays++;
         if (nodes.empty()) return false;
         V3 inv_dir(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
         int neg[3] = {inv_dir.x < 0.0f ? 1 : 0, inv_dir.y < 0.0f ? 1 : 0, inv_dir.z < 0.0f ? 1 : 0};
@@ -207,12 +268,8 @@ struct Scene {
             if (st) st->nodes_visited++;
             if (box_hit(node.bounds, r, inv_dir, neg)) {
                 if (node.n_primitives > 0) {
-                    for (uint32_t i = 0; i < node.n_primitives; i++) {
-                        uint32_t prim = ordered_prims[node.offset + i];
-                        TriHit h;
-                        if (st) st->tri_tests++;
-                        if (tri_intersect(r, prim, true, false, h)) { r.t_max = h.t; prim_out = prim; hit_out = h; any = true; }
-                    }
+                    for (uint32_t i = 0; i < node.n_primitives; i++)
+                        if (prim_intersect(r, ordered_prims[node.offset + i], prim_out, hit_out, st)) any = true;
                     if (to_visit == 0) break;
                     cur = stack[--to_visit];
                 } else {
@@ -226,9 +283,13 @@ struct Scene {
         }
         return any;
     }
-    // ---- BVHAccel::intersect_p (bvh/mod.rs:231-283)
-    bool intersect_p(const Ray& r, TraversalStats* st = nullptr) const {
+    bool intersect(Ray& r, uint32_t& prim_out, TriHit& hit_out, TraversalStats* st = nullptr) const {
         if (st) st->rays++;
+        hit_out.inst = 0;
+        return intersect_in(nodes, ordered_prims, r, prim_out, hit_out, st);
+    }
+    // ---- BVHAccel::intersect_p (bvh/mod.rs:231-283)
+    bool intersect_p_in(const std::vector<LinearBVHNode>& nodes, const std::vector<uint32_t>& ordered_prims, const Ray& r, TraversalStats* st) const {
         if (nodes.empty()) return false;
         V3 inv_dir(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
         int neg[3] = {inv_dir.x < 0.0f ? 1 : 0, inv_dir.y < 0.0f ? 1 : 0, inv_dir.z < 0.0f ? 1 : 0};
@@ -239,11 +300,8 @@ struct Scene {
             if (st) st->nodes_visited++;
             if (box_hit(node.bounds, r, inv_dir, neg)) {
                 if (node.n_primitives > 0) {
-                    for (uint32_t i = 0; i < node.n_primitives; i++) {
-                        TriHit h;
-                        if (st) st->tri_tests++;
-                        if (tri_intersect(r, ordered_prims[node.offset + i], true, true, h)) return true;
-                    }
+                    for (uint32_t i = 0; i < node.n_primitives; i++)
+                        if (prim_intersect_p(r, ordered_prims[node.offset + i], st)) return true;
                     if (to_visit == 0) break;
                     cur = stack[--to_visit];
                 } else {
@@ -256,6 +314,10 @@ struct Scene {
             }
         }
         return false;
+    }
+    bool intersect_p(const Ray& r, TraversalStats* st = nullptr) const {
+        if (st) st->rays++;
+        return intersect_p_in(nodes, ordered_prims, r, st);
     }
 
     // ================= BVH build: BVHAccel::new + sah::build (bvh/mod.rs:43-153, sah.rs:26-367) ================
@@ -398,7 +460,7 @@ struct Scene {
             HNode h; h.kid[0] = h.kid[1] = -1; h.axis = 0; h.n = (uint32_t)n;
             h.first = (uint32_t)ordered_prims.size();
             for (size_t i = 0; i < n; i++) {
-                ordered_prims.push_back((uint32_t)mp[i].primitive_index);
+                ordered_prims.push_back((uint32_t)info[mp[i].primitive_index].number);
                 h.bounds = h.bounds.union_b(info[mp[i].primitive_index].bounds);
             }
             hpool.push_back(h);
@@ -498,7 +560,7 @@ struct Scene {
         std::vector<MortonPrim> mp(info.size());
         for (size_t i = 0; i < info.size(); i++) {
             V3 v = bounds.offset(info[i].centroid) * 1024.0f;  // MORTON_SCALE = 1 << 10
-            mp[i].primitive_index = info[i].number; mp[i].morton_code = encode_morton_3(v);
+            mp[i].primitive_index = i; mp[i].morton_code = encode_morton_3(v);  // primitive_number == position in the aggregate's list
         }
         radix_sort(mp);
         hpool.clear(); hlbvh_panic = false;
@@ -515,19 +577,42 @@ struct Scene {
         flatten_h(root);
     }
 
+    // builds over `info` into the members nodes / ordered_prims
+    void build_over(std::vector<PrimInfo>& info, int split_method) {
+        nodes.clear(); ordered_prims.clear();
+        if (info.empty()) return;
+        nodes.reserve(2 * info.size()); ordered_prims.reserve(info.size());
+        if (split_method == 1) build_hlbvh(info);
+        else build_rec(info, 0, info.size(), split_method);
+    }
+    PrimInfo info_of(size_t number, const Bounds3& b) const {
+        PrimInfo pi; pi.number = number; pi.bounds = b; pi.centroid = 0.5f * (b.pmin + b.pmax);  // common.rs:85-91
+        return pi;
+    }
     void build_bvh(int split_method, int max_prims) {
         max_prims_in_node = max_prims & 0xff;  // quirk B8: `as u8`
-        nodes.clear(); ordered_prims.clear();
-        size_t n = n_tris();
-        if (n == 0) return;
-        std::vector<PrimInfo> info(n);
-        for (size_t i = 0; i < n; i++) {
-            info[i].number = i; info[i].bounds = tri_bound((uint32_t)i);
-            info[i].centroid = 0.5f * (info[i].bounds.pmin + info[i].bounds.pmax);  // common.rs:85-91
+        // aggregates of the instanced objects first (make_accelerator at ObjectInstance time, lib.rs:953-971)
+        for (const Instance& in : instances) {
+            Object& ob = objects[in.object];
+            if (ob.built) continue;
+            ob.built = true;
+            const uint32_t n = ob.tri1 - ob.tri0;
+            if (n == 1) { ob.bound = tri_bound(ob.tri0); continue; }
+            std::vector<PrimInfo> info;
+            for (uint32_t t = ob.tri0; t < ob.tri1; t++) info.push_back(info_of(t, tri_bound(t)));
+            build_over(info, split_method);
+            ob.nodes.swap(nodes); ob.ordered_prims.swap(ordered_prims);
+            ob.bound = ob.nodes.empty() ? Bounds3() : ob.nodes[0].bounds;  // BVHAccel::world_bound (bvh/mod.rs:161-167)
         }
-        nodes.reserve(2 * n); ordered_prims.reserve(n);
-        if (split_method == 1) build_hlbvh(info);
-        else build_rec(info, 0, n, split_method);
+        // the scene aggregate over triangles and TransformedPrimitives (world_bound = motion_bounds = transform_bounds when static)
+        std::vector<PrimInfo> info;
+        if (objects.empty()) for (size_t i = 0; i < n_tris(); i++) info.push_back(info_of(i, tri_bound((uint32_t)i)));
+        else for (uint32_t it : top_items) {
+            if (it & ORC_INST_BIT) { const Instance& in = instances[it & ~ORC_INST_BIT]; info.push_back(info_of(it, transform_bounds(in.i2w, objects[in.object].bound))); }
+            else info.push_back(info_of(it, tri_bound(it)));
+        }
+        build_over(info, split_method);
+        if (nodes.empty()) return;
         world_bound = nodes[0].bounds;
         world_bound.bounding_sphere(world_center, world_radius);  // Light::preprocess (infinite.rs:113-117, distant.rs:54-58)
     }

@@ -84,6 +84,8 @@ int upload_scene(PbrtHipScene* s) {
     d.n_lights = (uint32_t)s->lights.size();
     if ((rc = upload_vec(s, s->infinite_lights, &d.infinite_lights))) return rc;
     d.n_infinite = (uint32_t)s->infinite_lights.size();
+    if ((rc = upload_vec(s, s->inst_recs, &d.instances))) return rc;
+    d.n_instances = (uint32_t)s->inst_recs.size();
     hm::HaltonTables& ht = halton_tables();
     if ((rc = upload_vec(s, ht.perms, &d.halton_perms))) return rc;
     if ((rc = upload_vec(s, ht.primes, &d.primes))) return rc;
@@ -175,7 +177,9 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
     if ((rc = ensure_buf(s, s->d_counter, 64))) return rc;
     if ((rc = ensure_buf(s, s->d_error, 64))) return rc;
     if ((rc = ensure_buf(s, s->d_counts, 64))) return rc;
-    if ((rc = ensure_buf(s, s->d_spill, (size_t)(PH_MAX_STACK - variant_lds_depth(trav_variant())) * total_threads * sizeof(uint2)))) return rc;
+    const int stack_cap = s->inst_recs.empty() ? PH_MAX_STACK : 2 * PH_MAX_STACK;  // with instances the scene-level and object-level entries share one stack
+    const int lds_depth = s->inst_recs.empty() ? variant_lds_depth(trav_variant()) : PH_LDS_DEPTH;
+    if ((rc = ensure_buf(s, s->d_spill, (size_t)(stack_cap - lds_depth) * total_threads * sizeof(uint2)))) return rc;
     return PBRT_HIP_OK;
 }
 
@@ -186,6 +190,16 @@ void launch_traverse_kernel(PbrtHipScene* s, bool anyhit, uint32_t blocks, const
     p.counts = (unsigned long long*)s->d_counts.p + (anyhit ? 3 : 0);
     { static int bt = -1; if (bt < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_BATCH"); bt = e ? std::atoi(e) : PH_BATCH; if (bt < 64) bt = 64; } p.batch = (uint32_t)bt; }
     const dim3 g(blocks), b(PH_TRAV_BLOCK);
+    if (!s->inst_recs.empty()) {  // scenes with object instances: the TransformedPrimitive-aware kernels
+        if (s->count_traversal) {
+            if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true>), g, b, 0, s->stream, s->ds, p);
+            else hipLaunchKernelGGL((ph::traverse_kernel<false, true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true>), g, b, 0, s->stream, s->ds, p);
+        } else {
+            if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true>), g, b, 0, s->stream, s->ds, p);
+            else hipLaunchKernelGGL((ph::traverse_kernel<false, false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true>), g, b, 0, s->stream, s->ds, p);
+        }
+        return;
+    }
     if (s->count_traversal) {
         if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, true>), g, b, 0, s->stream, s->ds, p);
         else hipLaunchKernelGGL((ph::traverse_kernel<false, true>), g, b, 0, s->stream, s->ds, p);
@@ -355,6 +369,8 @@ int pbrt_hip_add_mesh(PbrtHipScene* s, const float* P, uint32_t n_verts, const u
             if (s->lights[first_area_light_id + k].type != PH_L_AREA || s->lights[first_area_light_id + k].prim != 0xFFFFFFFFu)
                 return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mesh: light is not an unbound diffuse area light");
     }
+    if (s->open_object >= 0 && first_area_light_id >= 0)
+        return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_mesh: area lights are not supported inside an object instance (the reference warns and drops them, api/src/lib.rs:877-881)");
     MeshRec m{};
     m.vert_base = (uint32_t)(s->P.size() / 3); m.tri_base = (uint32_t)(s->idx.size() / 3); m.n_tris = n_tris;
     m.flags = (N ? PH_MESH_N : 0) | (S ? PH_MESH_S : 0) | (UV ? PH_MESH_UV : 0) | ((flags & 1) ? PH_MESH_REV : 0) | ((flags & 2) ? PH_MESH_SWAP : 0);
@@ -385,6 +401,37 @@ int pbrt_hip_add_mesh(PbrtHipScene* s, const float* P, uint32_t n_verts, const u
         }
     }
     s->meshes.push_back(m);
+    if (s->open_object >= 0) s->objects[s->open_object].tri1 = m.tri_base + n_tris;
+    else for (uint32_t t = 0; t < n_tris; t++) s->top_items.push_back(m.tri_base + t);
+    s->built = false; s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+
+// ObjectBegin / ObjectEnd / ObjectInstance (api/src/lib.rs:911-1000)
+int pbrt_hip_object_begin(PbrtHipScene* s, uint32_t* out_object_id) {
+    if (!s || !out_object_id) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "object_begin: null argument");
+    if (s->open_object >= 0) return set_err(s, PBRT_HIP_ERR_STATE, "object_begin: ObjectBegin called inside of an instance definition");
+    PbrtHipScene::ObjectHost ob; ob.tri0 = ob.tri1 = (uint32_t)(s->idx.size() / 3);
+    s->objects.push_back(ob);
+    s->open_object = (int)s->objects.size() - 1;
+    *out_object_id = (uint32_t)s->open_object;
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_object_end(PbrtHipScene* s) {
+    if (!s) return PBRT_HIP_ERR_INVALID_ARG;
+    if (s->open_object < 0) return set_err(s, PBRT_HIP_ERR_STATE, "object_end: ObjectEnd called outside of instance definition");
+    s->open_object = -1;
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_add_instance(PbrtHipScene* s, uint32_t object_id, const float i2w[16], const float w2i[16]) {
+    if (!s || !i2w || !w2i) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_instance: null argument");
+    if (s->open_object >= 0) return set_err(s, PBRT_HIP_ERR_STATE, "add_instance: ObjectInstance can't be called inside of instance definition");
+    if (object_id >= s->objects.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_instance: unknown object");
+    if (s->objects[object_id].tri1 == s->objects[object_id].tri0) return PBRT_HIP_OK;  // empty object: nothing is added (lib.rs:949-951)
+    PbrtHipScene::InstanceHost in; in.object = object_id;
+    std::memcpy(in.i2w, i2w, 64); std::memcpy(in.w2i, w2i, 64);
+    s->instances.push_back(in);
+    s->top_items.push_back(PH_ITEM_INST | (uint32_t)(s->instances.size() - 1));
     s->built = false; s->uploaded = false;
     return PBRT_HIP_OK;
 }
@@ -540,12 +587,83 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
     if (split_method == 2) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: splitmethod 'middle' panics in the reference (quirk B6, sah.rs:67-76)");
     phost::BuildInput in;
     in.P = s->P.data(); in.idx = s->idx.data(); in.n_tris = s->idx.size() / 3; in.tri_flags = s->tri_flags.data(); in.tri_mesh = s->tri_mesh.data();
-    const int brc = phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh);
-    if (brc == -2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: the reference's HLBVH build asserts on this input (hlbvh.rs:338/356/418)");
-    if (brc != 0) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: bad arguments");
+    auto fail = [&](int brc) {
+        if (brc == -2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: the reference's HLBVH build asserts on this input (hlbvh.rs:338/356/418)");
+        return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: bad arguments");
+    };
+    s->inst_recs.clear();
+    if (s->objects.empty()) {
+        const int brc = phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh);
+        if (brc != 0) return fail(brc);
+    } else {
+        if (s->open_object >= 0) return set_err(s, PBRT_HIP_ERR_STATE, "build_accel: an object definition is still open (missing ObjectEnd)");
+        // 1. one aggregate per instanced object (make_accelerator at ObjectInstance time, lib.rs:953-971), appended to shared arrays
+        struct Built { bool done = false; uint32_t root_ref = PH_INVALID_REF; float lo[3], hi[3]; bool single = false; };
+        std::vector<Built> built(s->objects.size());
+        std::vector<Node64> obj_nodes; std::vector<TriRec> obj_tris;
+        for (const PbrtHipScene::InstanceHost& ih : s->instances) {
+            Built& b = built[ih.object];
+            if (b.done) continue;
+            b.done = true;
+            const PbrtHipScene::ObjectHost& ob = s->objects[ih.object];
+            std::vector<uint32_t> items(ob.tri1 - ob.tri0);
+            for (uint32_t t = ob.tri0; t < ob.tri1; t++) items[t - ob.tri0] = t;
+            phost::BuildInput oi = in; oi.items = items.data(); oi.n_items = items.size();
+            phost::BuildOutput bo;
+            const int brc = phost::build_bvh(oi, split_method, max_prims_in_node, 0, bo);
+            if (brc != 0) return fail(brc);
+            const uint32_t node_off = (uint32_t)obj_nodes.size(), tri_off = (uint32_t)obj_tris.size();
+            auto fix = [&](uint32_t ref) { return (ref & PH_LEAF_BIT) ? (PH_LEAF_BIT | ((ref & ~PH_LEAF_BIT) + tri_off)) : ref + node_off; };
+            for (Node64 nd : bo.nodes) { nd.c0 = fix(nd.c0); nd.c1 = fix(nd.c1); obj_nodes.push_back(nd); }
+            obj_tris.insert(obj_tris.end(), bo.tris.begin(), bo.tris.end());
+            b.root_ref = fix(bo.root_ref); b.single = items.size() == 1;
+            for (int k = 0; k < 3; k++) { b.lo[k] = bo.root_lo[k]; b.hi[k] = bo.root_hi[k]; }
+        }
+        // 2. TransformedPrimitive::world_bound = Transform::transform_bounds of the aggregate's bound (transform.rs:552-561): the 8 corners
+        //    in the reference's order, each through transform_point (:288-302)
+        std::vector<float> ibounds(6 * s->instances.size());
+        for (size_t k = 0; k < s->instances.size(); k++) {
+            const PbrtHipScene::InstanceHost& ih = s->instances[k];
+            const Built& b = built[ih.object];
+            const float* m = ih.i2w;
+            auto xf = [&](float x, float y, float z, float* o) {
+                const float xp = m[0] * x + m[1] * y + m[2] * z + m[3], yp = m[4] * x + m[5] * y + m[6] * z + m[7];
+                const float zp = m[8] * x + m[9] * y + m[10] * z + m[11], wp = m[12] * x + m[13] * y + m[14] * z + m[15];
+                if (wp == 1.0f) { o[0] = xp; o[1] = yp; o[2] = zp; } else { const float inv = 1.0f / wp; o[0] = inv * xp; o[1] = inv * yp; o[2] = inv * zp; }
+            };
+            const float* lo = b.lo; const float* hi = b.hi;
+            const float corners[8][3] = {{lo[0], lo[1], lo[2]}, {hi[0], lo[1], lo[2]}, {lo[0], hi[1], lo[2]}, {lo[0], lo[1], hi[2]},
+                                         {lo[0], hi[1], hi[2]}, {hi[0], hi[1], lo[2]}, {hi[0], lo[1], hi[2]}, {hi[0], hi[1], hi[2]}};
+            float* ob = &ibounds[6 * k];
+            for (int c = 0; c < 8; c++) {
+                float q[3]; xf(corners[c][0], corners[c][1], corners[c][2], q);
+                for (int a = 0; a < 3; a++) {
+                    if (c == 0) { ob[a] = ob[3 + a] = q[a]; }
+                    else { ob[a] = ob[a] < q[a] ? ob[a] : q[a]; ob[3 + a] = ob[3 + a] > q[a] ? ob[3 + a] : q[a]; }
+                }
+            }
+            InstRec r{};
+            std::memcpy(r.w2i, ih.w2i, 64); std::memcpy(r.i2w, ih.i2w, 64);
+            for (int a = 0; a < 3; a++) { r.lo[a] = b.lo[a]; r.hi[a] = b.hi[a]; }
+            r.root_ref = b.root_ref; r.flags = b.single ? PH_INST_SINGLE : 0u;
+            bool ident = true;
+            for (int a = 0; a < 16; a++) if (ih.i2w[a] != ((a % 5 == 0) ? 1.0f : 0.0f)) ident = false;
+            if (ident) r.flags |= PH_INST_IDENTITY;
+            s->inst_recs.push_back(r);
+        }
+        // 3. the scene aggregate over triangles and instances, then one node / TriRec array: [scene | objects]
+        phost::BuildInput ti = in; ti.items = s->top_items.data(); ti.n_items = s->top_items.size(); ti.inst_bounds = ibounds.data();
+        const int brc = phost::build_bvh(ti, split_method, max_prims_in_node, 0, s->bvh);
+        if (brc != 0) return fail(brc);
+        const uint32_t node_off = (uint32_t)s->bvh.nodes.size(), tri_off = (uint32_t)s->bvh.tris.size();
+        auto fix = [&](uint32_t ref) { return (ref & PH_LEAF_BIT) ? (PH_LEAF_BIT | ((ref & ~PH_LEAF_BIT) + tri_off)) : ref + node_off; };
+        for (Node64 nd : obj_nodes) { nd.c0 = fix(nd.c0); nd.c1 = fix(nd.c1); s->bvh.nodes.push_back(nd); }
+        s->bvh.tris.insert(s->bvh.tris.end(), obj_tris.begin(), obj_tris.end());
+        for (InstRec& r : s->inst_recs) r.root_ref = fix(r.root_ref);
+    }
     // Light::preprocess: bounding sphere of the world bound (bounds3.rs:196-208; infinite.rs:113-117, distant.rs:54-58)
     s->world_radius = 1.0f; s->world_center[0] = s->world_center[1] = s->world_center[2] = 0.0f;
-    if (in.n_tris) {
+    if (s->bvh.root_ref != PH_INVALID_REF) {
         const float* lo = s->bvh.root_lo; const float* hi = s->bvh.root_hi;
         float c[3];
         for (int k = 0; k < 3; k++) c[k] = (1.0f - 0.5f) * lo[k] + 0.5f * hi[k];  // lerp(0.5, pmin, pmax) (common.rs:166-175)

@@ -308,7 +308,7 @@ struct Builder {
 int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int n_threads, BuildOutput& out) {
     if (split_method != 0 && split_method != 1 && split_method != 3) return -1;
     out = BuildOutput();
-    const size_t n = in.n_tris;
+    const size_t n = in.items ? in.n_items : in.n_tris;
     if (n == 0) return 0;
     if (n >= 0x7FFFFFFFu) return -1;
     auto t0 = std::chrono::steady_clock::now();
@@ -318,11 +318,17 @@ int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int
     B.prims.resize(n);
     for (size_t i = 0; i < n; i++) {  // Triangle::world_bound (triangle.rs:427-431) + BVHPrimitiveInfo::new
         Prim& p = B.prims[i];
-        p.id = (uint32_t)i;
-        const float* a = in.P + 3 * (size_t)in.idx[3 * i];
-        p.b.lo[0] = p.b.hi[0] = a[0]; p.b.lo[1] = p.b.hi[1] = a[1]; p.b.lo[2] = p.b.hi[2] = a[2];
-        p.b.grow_pt(in.P + 3 * (size_t)in.idx[3 * i + 1]);
-        p.b.grow_pt(in.P + 3 * (size_t)in.idx[3 * i + 2]);
+        p.id = in.items ? in.items[i] : (uint32_t)i;
+        if (p.id & PH_ITEM_INST) {  // TransformedPrimitive::world_bound, computed by the caller
+            const float* bb = in.inst_bounds + 6 * (size_t)(p.id & ~PH_ITEM_INST);
+            for (int k = 0; k < 3; k++) { p.b.lo[k] = bb[k]; p.b.hi[k] = bb[3 + k]; }
+        } else {
+            const size_t t = p.id;
+            const float* a = in.P + 3 * (size_t)in.idx[3 * t];
+            p.b.lo[0] = p.b.hi[0] = a[0]; p.b.lo[1] = p.b.hi[1] = a[1]; p.b.lo[2] = p.b.hi[2] = a[2];
+            p.b.grow_pt(in.P + 3 * (size_t)in.idx[3 * t + 1]);
+            p.b.grow_pt(in.P + 3 * (size_t)in.idx[3 * t + 2]);
+        }
         for (int k = 0; k < 3; k++) p.c[k] = 0.5f * (p.b.lo[k] + p.b.hi[k]);
     }
     B.pool.resize(2 * n);
@@ -336,6 +342,7 @@ int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int
     for (size_t i = 0; i < n; i++) {
         const uint32_t id = B.prims[i].id;
         TriRec& t = out.tris[i];
+        if (id & PH_ITEM_INST) { std::memset(&t, 0, sizeof t); t.prim = id & ~PH_ITEM_INST; t.flags = PH_TRI_INSTANCE; continue; }
         const float* p0 = in.P + 3 * (size_t)in.idx[3 * (size_t)id];
         const float* p1 = in.P + 3 * (size_t)in.idx[3 * (size_t)id + 1];
         const float* p2 = in.P + 3 * (size_t)in.idx[3 * (size_t)id + 2];

@@ -20,7 +20,13 @@ struct BuildInput {
     size_t n_tris;
     const uint32_t* tri_flags;  // per-triangle PH_TRI_BOGUS/ALPHA0/SALPHA0 bits (LAST is set by the builder)
     const uint32_t* tri_mesh = nullptr;  // mesh id per triangle (copied into TriRec::mesh), may be null
+    // Optional primitive list (default: triangles 0..n_tris-1): entry = triangle id, or PH_ITEM_INST | k for a
+    // TransformedPrimitive whose world bound is inst_bounds[6k..6k+5] = {lo xyz, hi xyz}.
+    const uint32_t* items = nullptr;
+    size_t n_items = 0;
+    const float* inst_bounds = nullptr;
 };
+#define PH_ITEM_INST 0x80000000u
 
 struct BuildOutput {
     std::vector<Node64> nodes;

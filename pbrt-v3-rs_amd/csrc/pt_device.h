@@ -430,6 +430,39 @@ PH_DEV spec infinite_lookup(const LightRec& l, f2 st) {
 PH_DEV f3 xf_vec(const float* m, f3 v) {  // transform_vector (transform.rs:373-380) on a 3x4 row-major block
     return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
+// ---- object instances: Transform::transform_surface_interaction (core/src/geometry/transform.rs:566-590) ------------------------
+PH_DEV f3 xf_normal(const float* m_inv, f3 n) {  // transform_normal (transform.rs:441-448): transpose of the inverse
+    return mk3(m_inv[0] * n.x + m_inv[4] * n.y + m_inv[8] * n.z, m_inv[1] * n.x + m_inv[5] * n.y + m_inv[9] * n.z, m_inv[2] * n.x + m_inv[6] * n.y + m_inv[10] * n.z);
+}
+// transform_point_with_abs_error (transform.rs:338-370); returns the point, writes the new absolute error
+PH_DEV f3 xf_point_abs_err(const float* m, f3 p, f3 pe, f3& err) {
+    const float x = p.x, y = p.y, z = p.z;
+    const float xp = (m[0] * x + m[1] * y) + (m[2] * z + m[3]);
+    const float yp = (m[4] * x + m[5] * y) + (m[6] * z + m[7]);
+    const float zp = (m[8] * x + m[9] * y) + (m[10] * z + m[11]);
+    const float wp = (m[12] * x + m[13] * y) + (m[14] * z + m[15]);
+    const float g3 = kGamma3;
+    err = mk3((g3 + 1.0f) * (pabs(m[0]) * pe.x + pabs(m[1]) * pe.y + pabs(m[2]) * pe.z) + g3 * (pabs(m[0] * x) + pabs(m[1] * y) + pabs(m[2] * z) + pabs(m[3])),
+              (g3 + 1.0f) * (pabs(m[4]) * pe.x + pabs(m[5]) * pe.y + pabs(m[6]) * pe.z) + g3 * (pabs(m[4] * x) + pabs(m[5] * y) + pabs(m[6] * z) + pabs(m[7])),
+              (g3 + 1.0f) * (pabs(m[8]) * pe.x + pabs(m[9]) * pe.y + pabs(m[10]) * pe.z) + g3 * (pabs(m[8] * x) + pabs(m[9] * y) + pabs(m[10] * z) + pabs(m[11])));
+    return (wp == 1.0f) ? mk3(xp, yp, zp) : mk3(xp, yp, zp) / wp;
+}
+// The interaction TransformedPrimitive::intersect hands back (transformed_primitive.rs:51-73): the triangle met the instance-space
+// ray, then everything the integrator reads is carried to world space.  inst = instance number + 1 (HitOut pad[1]), 0 = none.
+PH_DEV SurfHit make_surface_hit_any(const DeviceScene& sc, f3 rd_world, float time, uint32_t tri_index, uint32_t inst, float b0, float b1, float b2, MeshRec& m_out) {
+    if (inst == 0u) return make_surface_hit_rec(sc, rd_world, time, tri_index, b0, b1, b2, m_out);
+    const InstRec& I = sc.instances[inst - 1u];
+    SurfHit si = make_surface_hit_rec(sc, xf_vec(I.w2i, rd_world), time, tri_index, b0, b1, b2, m_out);
+    if (I.flags & PH_INST_IDENTITY) return si;
+    f3 pe;
+    si.p = xf_point_abs_err(I.i2w, si.p, si.p_error, pe); si.p_error = pe;
+    si.wo = normalize(xf_vec(I.i2w, si.wo));
+    si.n = normalize(xf_normal(I.w2i, si.n));
+    si.ns = normalize(xf_normal(I.w2i, si.ns));
+    si.ns = face_forward(si.ns, si.n);
+    si.dpdu_s = xf_vec(I.i2w, si.dpdu_s);
+    return si;
+}
 PH_DEV spec area_L(const LightRec& l, f3 n, f3 w) {  // DiffuseAreaLight::l (lights/src/diffuse.rs:220-226)
     return (l.two_sided || dot(n, w) > 0.0f) ? mks(l.L[0], l.L[1], l.L[2]) : mks1(0.0f);
 }

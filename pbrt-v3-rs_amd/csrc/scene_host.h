@@ -26,6 +26,15 @@ struct PbrtHipScene {
     std::vector<MaterialRec> materials;
     std::vector<LightRec> lights;
     std::vector<uint32_t> infinite_lights;
+    // object instancing (api/src/lib.rs:911-1000): an object is a contiguous triangle range; top_items is the scene's primitive
+    // list in directive order (triangle id, or PH_ITEM_INST | instance index)
+    struct ObjectHost { uint32_t tri0 = 0, tri1 = 0; };
+    struct InstanceHost { uint32_t object; float i2w[16], w2i[16]; };
+    std::vector<ObjectHost> objects;
+    std::vector<InstanceHost> instances;
+    std::vector<uint32_t> top_items;
+    int open_object = -1;
+    std::vector<InstRec> inst_recs;  // built by build_accel
     CameraRec cam{};
     FilmRec film{};
     SamplerRec sampler{};

@@ -25,10 +25,21 @@ struct alignas(64) Node64 {
 #define PH_TRI_BOGUS 2u  // degenerate: Triangle::intersect returns None after the t test (shapes/src/triangle.rs:567-570)
 #define PH_TRI_ALPHA0 4u   // mesh alpha texture == 0.0 (triangle.rs:603)
 #define PH_TRI_SALPHA0 8u  // mesh shadowalpha texture == 0.0 (triangle.rs:891)
+#define PH_TRI_INSTANCE 16u  // not a triangle: a TransformedPrimitive (object instance); `prim` = index into DeviceScene::instances
 struct alignas(16) TriRec {
     float p0[3]; uint32_t prim;   // prim = index in add_mesh order
     float p1[3]; uint32_t flags;
     float p2[3]; uint32_t mesh;   // mesh id (shade-side shortcut)
+};
+
+// One ObjectInstance = TransformedPrimitive (core/src/primitives/transformed_primitive.rs): the object's aggregate lives in the
+// same node / TriRec arrays as the scene's; a ray entering it is carried to instance space by transform_ray (transform.rs:451-476).
+#define PH_INST_SINGLE 1u    // the object holds exactly one primitive: it is used directly, no aggregate and no root box test (lib.rs:953-971)
+#define PH_INST_IDENTITY 2u  // instance_to_world is the identity: transform_surface_interaction is skipped (transformed_primitive.rs:58)
+struct InstRec {
+    float w2i[16], i2w[16];   // row-major 4x4
+    float lo[3], hi[3];       // object aggregate's root bounds (instance space)
+    uint32_t root_ref, flags;
 };
 
 // ---- shading-side geometry (indexed by prim, add_mesh order) ---------------------------------------------------------
@@ -119,6 +130,8 @@ struct DeviceScene {
     uint32_t n_lights;
     const uint32_t* infinite_lights;
     uint32_t n_infinite;
+    const InstRec* instances;
+    uint32_t n_instances;
     // light-selection Distribution1D (core/src/sampling/distribution_1d.rs)
     const float* ld_func;
     const float* ld_cdf;      // n_lights + 1

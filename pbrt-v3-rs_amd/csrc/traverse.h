@@ -65,6 +65,32 @@ PH_DEV void ray_setup(RayState& r, const RayIn& in) {
     r.sx = -dp.x / dp.z; r.sy = -dp.y / dp.z; r.sz = 1.0f / dp.z;
 }
 
+// Transform::transform_ray (core/src/geometry/transform.rs:451-476) by a row-major 4x4 `c`: transform_point_with_error on the
+// origin (:304-328), transform_vector on the direction, origin pushed to the edge of its error box and t_max shortened by the
+// same dt (quirk B2).  Used when a ray enters an object instance (transformed_primitive.rs:51-53).
+PH_DEV RayIn xf_ray(const float* c, const RayState& r, float time) {
+    const float x = r.ox, y = r.oy, z = r.oz;
+    const float ox = (c[0] * x + c[1] * y) + (c[2] * z + c[3]);
+    const float oy = (c[4] * x + c[5] * y) + (c[6] * z + c[7]);
+    const float oz = (c[8] * x + c[9] * y) + (c[10] * z + c[11]);
+    const float ow = (c[12] * x + c[13] * y) + (c[14] * z + c[15]);
+    const float xs = pabs(c[0] * x) + pabs(c[1] * y) + pabs(c[2] * z) + pabs(c[3]);
+    const float ys = pabs(c[4] * x) + pabs(c[5] * y) + pabs(c[6] * z) + pabs(c[7]);
+    const float zs = pabs(c[8] * x) + pabs(c[9] * y) + pabs(c[10] * z) + pabs(c[11]);
+    const f3 o_err = kGamma3 * mk3(xs, ys, zs);
+    f3 o = (ow == 1.0f) ? mk3(ox, oy, oz) : mk3(ox, oy, oz) / ow;
+    const f3 d = mk3(c[0] * r.dx + c[1] * r.dy + c[2] * r.dz, c[4] * r.dx + c[5] * r.dy + c[6] * r.dz, c[8] * r.dx + c[9] * r.dy + c[10] * r.dz);
+    const float l2 = length_squared(d);
+    float t_max = r.t_max;
+    if (l2 > 0.0f) {
+        const float dt = ph_div(dot(vabs(d), o_err), l2);
+        o = o + d * dt;
+        t_max -= dt;
+    }
+    RayIn out; out.ox = o.x; out.oy = o.y; out.oz = o.z; out.t_max = t_max; out.dx = d.x; out.dy = d.y; out.dz = d.z; out.time = time;
+    return out;
+}
+
 // Bounds3::intersect_p_inv without its final `t_min < ray.t_max` clause; returns t_min via reference.
 // Quirk B1 (z far plane not widened) is reproduced.  Written branch-free: the reference's early `return false`s only skip
 // arithmetic whose results are then unused, so evaluating everything and AND-ing the verdicts gives the same answer
@@ -150,7 +176,11 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
 #ifndef PH_BATCH
 #define PH_BATCH 64
 #endif
-template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1>
+// INST = true adds object instancing (TransformedPrimitive): a leaf record may name an instance; the lane then carries its ray
+// into instance space, walks the object's aggregate above its current stack height and returns to the scene-level leaf where it
+// left it (same order of primitive tests as the reference's recursion).  Compiled separately so scenes without instances keep
+// the leaner kernel.
+template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1, bool INST = false>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
     const uint32_t tid = threadIdx.x;
@@ -170,17 +200,25 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
     float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     bool occluded = false;
     uint32_t c_nodes = 0, c_tris = 0, c_rays = 0;
+    // instancing state (INST only)
+    uint32_t in_inst = 0;                 // instance number + 1 while inside an object's aggregate
+    int inst_sp = 0;                      // stack height at entry: the object's entries live above it
+    float world_tmax = 0.0f;              // the scene-level ray's t_max at entry
+    uint32_t cont_ref = PH_INVALID_REF;   // next record of the scene-level leaf, or PH_INVALID_REF = pop
+    bool inst_hit = false;                // a primitive of the current instance was accepted
+    uint32_t hit_inst = 0;
 
     auto push = [&](uint32_t ref, float tmin) {
         uint2 e = make_uint2(ref, __float_as_uint(tmin));
         if (sp < LDS_DEPTH) lds_stack[sp][tid] = e;
-        else if (sp < PH_MAX_STACK) p.spill[(size_t)(sp - LDS_DEPTH) * p.total_threads + gtid] = e;
+        else if (sp < (INST ? 2 * PH_MAX_STACK : PH_MAX_STACK)) p.spill[(size_t)(sp - LDS_DEPTH) * p.total_threads + gtid] = e;  // INST: scene + object entries share the stack
         else { *p.error_flag = 1u; return; }
         sp++;
     };
     // pops entries until one survives `t_min < ray.t_max`; returns PH_INVALID_REF when the stack is empty
     auto pop = [&]() -> uint32_t {
-        while (sp > 0) {
+        const int floor_sp = (INST && in_inst) ? inst_sp : 0;
+        while (sp > floor_sp) {
             sp--;
             uint2 e = (sp < LDS_DEPTH) ? lds_stack[sp][tid] : p.spill[(size_t)(sp - LDS_DEPTH) * p.total_threads + gtid];
             if (__uint_as_float(e.y) < r.t_max) return e.x;
@@ -211,6 +249,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                         RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = a.w; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
                         ray_setup(r, in);
                         has_ray = true; sp = 0; hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hb0 = hb1 = hb2 = 0.0f; occluded = false;
+                        if (INST) { in_inst = 0; hit_inst = 0; }
                         // root: the reference tests nodes[0].bounds first (bvh/mod.rs:189-190)
                         cur = PH_INVALID_REF;
                         if (sc.root_ref != PH_INVALID_REF) {
@@ -270,21 +309,54 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                         const uint32_t flags = __float_as_uint(b.w);
                         bool last = (flags & PH_TRI_LAST) != 0;
                         float t, b0, b1, b2;
+                        if (INST && (flags & PH_TRI_INSTANCE)) {
+                            // TransformedPrimitive::intersect / intersect_p (transformed_primitive.rs:51-73)
+                            const InstRec& I = sc.instances[__float_as_uint(a.w)];
+                            world_tmax = r.t_max; cont_ref = last ? PH_INVALID_REF : cur + 1u;
+                            in_inst = __float_as_uint(a.w) + 1u; inst_sp = sp; inst_hit = false;
+                            const RayIn in = xf_ray(I.w2i, r, 0.0f);
+                            ray_setup(r, in);
+                            cur = PH_INVALID_REF;
+                            if (I.flags & PH_INST_SINGLE) cur = I.root_ref;  // the lone primitive itself, no aggregate
+                            else {
+                                float tmin;
+                                const bool h = box_test(r, r.nx ? I.hi[0] : I.lo[0], r.nx ? I.lo[0] : I.hi[0], r.ny ? I.hi[1] : I.lo[1], r.ny ? I.lo[1] : I.hi[1],
+                                                        r.nz ? I.hi[2] : I.lo[2], r.nz ? I.lo[2] : I.hi[2], tmin);
+                                if (h && tmin < r.t_max) cur = I.root_ref;
+                            }
+                        } else {
                         if (COUNT) c_tris++;
                         if (tri_test(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), t, b0, b1, b2)) {
                             // post-t rejections: degenerate triangle (triangle.rs:567-570 / 862-866), alpha == 0 (:603 / :886-893)
                             const uint32_t reject = ANYHIT ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
                             if (!(flags & reject)) {
                                 if (ANYHIT) occluded = true;
-                                else { r.t_max = t; hit_prim = __float_as_uint(a.w); hit_tri = ti; hb0 = b0; hb1 = b1; hb2 = b2; }
+                                else {
+                                    r.t_max = t; hit_prim = __float_as_uint(a.w); hit_tri = ti; hb0 = b0; hb1 = b1; hb2 = b2;
+                                    if (INST) { hit_inst = in_inst; inst_hit = true; }
+                                }
                             }
                         }
                         if (ANYHIT && occluded) cur = PH_INVALID_REF;
                         else if (last) cur = pop();
                         else cur = cur + 1u;
+                        }
                     }
                 }
             }
+        }
+
+        // ---- leave an exhausted instance: back to the scene-level ray, `r.t_max = ray.t_max` only if something was hit inside ----------
+        if (INST && has_ray && in_inst && cur == PH_INVALID_REF) {
+            if (!(ANYHIT && occluded)) {
+                const float t_new = inst_hit ? r.t_max : world_tmax;
+                const float4* rp = reinterpret_cast<const float4*>(p.rays + ray_index);
+                const float4 a = rp[0], b = rp[1];
+                RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = t_new; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
+                ray_setup(r, in);
+                in_inst = 0;
+                cur = (cont_ref != PH_INVALID_REF) ? cont_ref : pop();
+            } else in_inst = 0;
         }
 
         // ---- retire finished rays --------------------------------------------------------------------------------------------------------
@@ -293,7 +365,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
             else {
                 float4* hp = reinterpret_cast<float4*>(reinterpret_cast<HitOut*>(p.out) + ray_index);
                 hp[0] = make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1);
-                hp[1] = make_float4(hb2, __uint_as_float(hit_tri), 0.0f, 0.0f);  // pad[0] = index of the hit's TriRec (leaf order)
+                hp[1] = make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), 0.0f);  // pad[0] = the hit's TriRec, pad[1] = instance + 1
             }
             has_ray = false;
             if (COUNT) c_rays++;

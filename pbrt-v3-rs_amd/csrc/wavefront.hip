@@ -146,7 +146,11 @@ __global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfPar
         const float4 h1 = hp[1];
         const float4* tp = reinterpret_cast<const float4*>(sc.tris + __float_as_uint(h1.y));
         const float4 a = tp[0], b = tp[1], c = tp[2];
-        const f3 p = h0.z * mk3(a.x, a.y, a.z) + h0.w * mk3(b.x, b.y, b.z) + h1.x * mk3(c.x, c.y, c.z);  // = SurfHit::p (make_surface_hit_tv)
+        f3 p = h0.z * mk3(a.x, a.y, a.z) + h0.w * mk3(b.x, b.y, b.z) + h1.x * mk3(c.x, c.y, c.z);  // = SurfHit::p (make_surface_hit_tv)
+        const uint32_t inst = __float_as_uint(h1.z);
+        if (inst != 0u && !(sc.instances[inst - 1u].flags & PH_INST_IDENTITY)) {  // world-space p of an instanced hit (make_surface_hit_any)
+            f3 pe; p = xf_point_abs_err(sc.instances[inst - 1u].i2w, p, mk3(0.0f, 0.0f, 0.0f), pe);
+        }
         const uint32_t v = spatial_voxel_of(sr, p);
         if (sr.vox_slot[v] == -1 && atomicCAS(&sr.vox_slot[v], -1, -2) == -1) {
             const uint32_t slot = atomicAdd(&sr.counters[SP_CLAIMED], 1u);
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                         if (lt.type == PH_L_AREA && lt.prim == hprim) {  // the hit primitive's area light IS the sampled light
                             const float4 h1 = hp[1];
                             MeshRec m;
-                            SurfHit lh = make_surface_hit_rec(sc, wi, mr.time, __float_as_uint(h1.y), h0.z, h0.w, h1.x, m);
+                            SurfHit lh = make_surface_hit_any(sc, wi, mr.time, __float_as_uint(h1.y), __float_as_uint(h1.z), h0.z, h0.w, h1.x, m);
                             li2 = area_L(lt, lh.n, -wi);  // SurfaceInteraction::le (surface_interaction.rs:283-289)
                         }
                     } else li2 = light_le(sc.lights[light_num], wi);
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                 } else {
                     const float4 h1 = hp[1];
                     MeshRec m;
-                    const SurfHit si = make_surface_hit_rec(sc, rd, ray.time, __float_as_uint(h1.y), h0.z, h0.w, h1.x, m);
+                    const SurfHit si = make_surface_hit_any(sc, rd, ray.time, __float_as_uint(h1.y), __float_as_uint(h1.z), h0.z, h0.w, h1.x, m);
                     if (bounces == 0) {
                         if (m.first_light >= 0) L = L + beta * area_L(sc.lights[(uint32_t)m.first_light + (hprim - m.tri_base)], si.n, -rd);
                         else L = L + beta * mks1(0.0f);

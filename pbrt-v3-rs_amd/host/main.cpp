@@ -43,9 +43,9 @@ int main(int argc, char** argv) {
         pbrt_host::RenderReport rep;
         if (!pbrt_host::parse_file(fn, api, &rep)) { std::fprintf(stderr, "Error: %s: %s\n", fn.c_str(), api.error.c_str()); return 1; }
         if (check) {
-            std::printf("{\"file\": \"%s\", \"triangles\": %llu, \"lights\": %llu, \"xres\": %d, \"yres\": %d, \"crop\": [%d, %d, %d, %d], \"spp\": %d, \"max_depth\": %d, "
+            std::printf("{\"file\": \"%s\", \"triangles\": %llu, \"lights\": %llu, \"instances\": %llu, \"xres\": %d, \"yres\": %d, \"crop\": [%d, %d, %d, %d], \"spp\": %d, \"max_depth\": %d, "
                         "\"light_strategy\": %d, \"pixel_bounds\": [%d, %d, %d, %d], \"out_file\": \"%s\", \"warnings\": %zu}\n",
-                        fn.c_str(), (unsigned long long)rep.n_triangles, (unsigned long long)rep.n_lights, rep.xres, rep.yres, rep.crop[0], rep.crop[1], rep.crop[2], rep.crop[3],
+                        fn.c_str(), (unsigned long long)rep.n_triangles, (unsigned long long)rep.n_lights, (unsigned long long)rep.n_instances, rep.xres, rep.yres, rep.crop[0], rep.crop[1], rep.crop[2], rep.crop[3],
                         rep.spp, rep.max_depth, rep.light_strategy, rep.pixel_bounds[0], rep.pixel_bounds[1], rep.pixel_bounds[2], rep.pixel_bounds[3], rep.out_file.c_str(), rep.warnings.size());
             continue;
         }

@@ -188,6 +188,9 @@ struct Parser {
             else if (d == "LightSource") { if (!name_and_params(name, ps)) return false; api.pbrt_light_source(name, ps); }
             else if (d == "AreaLightSource") { if (!name_and_params(name, ps)) return false; api.pbrt_area_light_source(name, ps); }
             else if (d == "Shape") { if (!name_and_params(name, ps)) return false; api.pbrt_shape(name, ps, scene_dir); }
+            else if (d == "ObjectBegin") { if (!quoted(name)) return false; api.pbrt_object_begin(name); }
+            else if (d == "ObjectEnd") api.pbrt_object_end();
+            else if (d == "ObjectInstance") { if (!quoted(name)) return false; api.pbrt_object_instance(name); }
             else if (d == "Include") {
                 if (!quoted(name)) return false;
                 if (depth > 32) return fail("Include nesting too deep");
@@ -205,8 +208,7 @@ struct Parser {
                 const int rc = api.pbrt_world_end(rep);
                 if (rc != 0) return fail(api.error.empty() ? ("WorldEnd failed with status " + std::to_string(rc)) : api.error);
             }
-            else if (d == "ObjectBegin" || d == "ObjectEnd" || d == "ObjectInstance" || d == "MakeNamedMedium" || d == "MediumInterface" ||
-                     d == "ActiveTransform" || d == "TransformTimes")
+            else if (d == "MakeNamedMedium" || d == "MediumInterface" || d == "ActiveTransform" || d == "TransformTimes")
                 return fail("directive '" + d + "' is outside the hot-path scope of this host (SURVEY §8f)");
             else return fail("unknown directive '" + d + "'");
             if (!api.error.empty()) return fail(api.error);

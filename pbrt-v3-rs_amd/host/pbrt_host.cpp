@@ -200,6 +200,31 @@ void Api::pbrt_named_material(const std::string& name) {
     if (it == gs_.named_materials.end()) { warn("NamedMaterial \"" + name + "\" unknown."); return; }
     gs_.material = it->second;
 }
+// ObjectBegin / ObjectEnd / ObjectInstance (api/src/lib.rs:911-1000)
+void Api::pbrt_object_begin(const std::string& name) {
+    if (!verify_world("ObjectBegin")) return;
+    pbrt_attribute_begin();
+    if (!current_object_.empty()) { warn("ObjectBegin called inside of an instance definition."); return; }
+    uint32_t id = (uint32_t)objects_.size();
+    if (!check(ABI(pbrt_hip_object_begin(scene_, &id)), "object_begin")) return;
+    objects_[name] = id; object_tris_[name] = 0;
+    current_object_ = name;
+}
+void Api::pbrt_object_end() {
+    if (!verify_world("ObjectEnd")) return;
+    if (current_object_.empty()) warn("ObjectEnd called outside of instance definition.");
+    else { check(ABI(pbrt_hip_object_end(scene_)), "object_end"); current_object_.clear(); }
+    pbrt_attribute_end();
+}
+void Api::pbrt_object_instance(const std::string& name) {
+    if (!verify_world("ObjectInstance") || !error.empty()) return;
+    if (!current_object_.empty()) { warn("ObjectInstance can't be called inside of instance definition."); return; }
+    auto it = objects_.find(name);
+    if (it == objects_.end()) { warn("Unable to find object instance named '" + name + "'"); return; }
+    if (object_tris_[name] == 0) return;  // empty object: nothing is added (lib.rs:949-951)
+    if (!check(ABI(pbrt_hip_add_instance(scene_, it->second, ctm_.m, ctm_.mi)), "add_instance")) return;
+    n_instances_++; n_tris_ += object_tris_[name];
+}
 void Api::pbrt_reverse_orientation() { if (!verify_world("ReverseOrientation")) return; gs_.reverse_orientation = !gs_.reverse_orientation; }
 
 static std::array<float, 3> mul3(std::array<float, 3> a, std::array<float, 3> b) { return {a[0] * b[0], a[1] * b[1], a[2] * b[2]}; }
@@ -351,6 +376,10 @@ void Api::pbrt_shape(const std::string& name, const ParamSet& p, const std::stri
     const uint32_t flags = (gs_.reverse_orientation ? 1u : 0u) | (pbrt_hip_host_swaps_handedness(ctm_.m) ? 2u : 0u);
 
     int32_t first_light = -1;
+    if (!gs_.area_light.empty() && !current_object_.empty()) {
+        error = "AreaLightSource inside ObjectBegin/ObjectEnd: the reference keeps the emission but drops the light (lib.rs:877-881); not offered";
+        return;
+    }
     if (!gs_.area_light.empty()) {  // one DiffuseAreaLight per triangle, numbered where the Shape directive stands (lib.rs:783-812)
         if (gs_.area_light != "diffuse" && gs_.area_light != "area") { error = "AreaLightSource \"" + gs_.area_light + "\" unknown"; return; }
         const ParamSet& ap = gs_.area_light_params;
@@ -363,7 +392,7 @@ void Api::pbrt_shape(const std::string& name, const ParamSet& p, const std::stri
     }
     if (!check(ABI(pbrt_hip_add_mesh(scene_, Pw.data(), (uint32_t)nv, idx.data(), n_tris, N.empty() ? nullptr : N.data(), S.empty() ? nullptr : S.data(),
                                  UV.empty() ? nullptr : UV.data(), mat, first_light, flags, alpha, shadow_alpha)), "add_mesh")) return;
-    n_tris_ += n_tris;
+    if (current_object_.empty()) n_tris_ += n_tris; else object_tris_[current_object_] += n_tris;
 }
 
 static bool ends_with(const std::string& s, const std::string& suf) { return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0; }
@@ -487,7 +516,7 @@ int Api::pbrt_world_end(RenderReport& rep) {
     else { warn("Light sample distribution type \"" + lss + "\" unknown. Using \"spatial\"."); strategy = 2; }
 
     rep.xres = xres; rep.yres = yres; std::memcpy(rep.crop, cb, sizeof cb);
-    rep.n_triangles = n_tris_; rep.n_lights = n_lights_; rep.warnings = warnings;
+    rep.n_triangles = n_tris_; rep.n_lights = n_lights_; rep.n_instances = n_instances_; rep.warnings = warnings;
     rep.spp = spp; rep.max_depth = max_depth; rep.light_strategy = strategy; std::memcpy(rep.pixel_bounds, pb, sizeof pb);
     if (check_only_) { rep.out_file = filename; return PBRT_HIP_OK; }
     const size_t npix = (size_t)std::max(0, cb[2] - cb[0]) * (size_t)std::max(0, cb[3] - cb[1]);

@@ -50,7 +50,7 @@ struct RenderReport {
     int xres = 0, yres = 0, crop[4] = {0, 0, 0, 0};
     std::string out_file;
     double build_seconds = 0, load_seconds = 0;
-    uint64_t n_triangles = 0, n_lights = 0;
+    uint64_t n_triangles = 0, n_lights = 0, n_instances = 0;  // n_triangles counts instanced triangles once per instance
     int spp = 0, max_depth = 0, light_strategy = 0, pixel_bounds[4] = {0, 0, 0, 0};
     std::vector<std::string> warnings;
 };
@@ -90,6 +90,9 @@ class Api {
     void pbrt_area_light_source(const std::string& name, const ParamSet& p);
     void pbrt_shape(const std::string& name, const ParamSet& p, const std::string& scene_dir);
     void pbrt_reverse_orientation();
+    void pbrt_object_begin(const std::string& name);
+    void pbrt_object_end();
+    void pbrt_object_instance(const std::string& name);
     // builds the accelerator, renders, writes the image; returns 0 or a PBRT_HIP_ERR_* code
     int pbrt_world_end(RenderReport& report);
 
@@ -118,6 +121,10 @@ class Api {
     Xform camera_to_world_;
     uint64_t n_tris_ = 0, n_lights_ = 0;
     std::map<std::string, uint32_t> material_cache_;
+    std::map<std::string, uint32_t> objects_;   // named object instances (render_options.instances)
+    std::map<std::string, uint64_t> object_tris_;
+    std::string current_object_;                // "" outside ObjectBegin/ObjectEnd
+    uint64_t n_instances_ = 0;
     void warn(const std::string& w);
     bool verify_options(const char* func);
     bool verify_world(const char* func);

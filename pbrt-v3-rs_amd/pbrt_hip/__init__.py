@@ -100,6 +100,9 @@ class Binding:
             "tile_buffer_floats": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
             "render_path_tiles_device": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, ip, C.c_int, C.c_int, C.c_int, vp, C.POINTER(Stats)]),
             "merge_tiles_device": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp), fp, fp]),
+            "object_begin": (C.c_int, [vp, u32p]),
+            "object_end": (C.c_int, [vp]),
+            "add_instance": (C.c_int, [vp, C.c_uint32, fp, fp]),
         }
         for name, (res, args) in self._optional.items():
             if hasattr(self.lib, prefix + name):
@@ -298,6 +301,19 @@ class Scene:
         self._chk(self.b.fn("add_mesh")(self.h, _ptr(P, C.c_float), len(P), _ptr(idx, C.c_uint32), len(idx) // 3, _ptr(N, C.c_float),
                                         _ptr(S, C.c_float), _ptr(UV, C.c_float), material, first_area_light, flags, C.c_float(alpha), C.c_float(shadow_alpha)))
 
+    def object_begin(self) -> int:
+        """ObjectBegin (api/src/lib.rs:911-925): meshes added until object_end() belong to the returned object."""
+        oid = C.c_uint32()
+        self._chk(self.b.fn("object_begin")(self.h, C.byref(oid)))
+        return oid.value
+
+    def object_end(self):
+        self._chk(self.b.fn("object_end")(self.h))
+
+    def add_instance(self, object_id, instance_to_world, world_to_instance):
+        """ObjectInstance (lib.rs:942-1000): one TransformedPrimitive in the scene's primitive list."""
+        self._chk(self.b.fn("add_instance")(self.h, object_id, _ptr(_f32(instance_to_world), C.c_float), _ptr(_f32(world_to_instance), C.c_float)))
+
     def add_light_infinite(self, L=(1, 1, 1), light_to_world=None, world_to_light=None):
         l2w = _f32(light_to_world if light_to_world is not None else IDENTITY)
         w2l = _f32(world_to_light if world_to_light is not None else IDENTITY)
@@ -432,13 +448,28 @@ class SceneSpec:
     up: tuple = (0.0, 0.0, 1.0)
 
 
-def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None):
-    """LookAt 0 -4 0  0 0 0  0 0 1 / perspective fov 40 / box filter / halton / matte 0.5 / infinite L=1."""
+def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None, instances: int = 0):
+    """LookAt 0 -4 0  0 0 0  0 0 1 / perspective fov 40 / box filter / halton / matte 0.5 / infinite L=1.
+    instances = K > 0: the triangles form ONE object placed K times (ObjectInstance) on a jittered lattice inside the unit
+    cube, each copy scaled by K^(-1/3) and rotated — K x n_tris instanced triangles behind a two-level BVH."""
     P, idx = geometry if geometry is not None else host.gen_random_tris(spec.n_tris, spec.seed)
     mat = scene.add_material_matte(spec.kd, spec.sigma)
     if spec.env_L is not None:
         scene.add_light_infinite(spec.env_L)
-    scene.add_mesh(P, idx, mat)
+    if instances > 0:
+        ob = scene.object_begin(); scene.add_mesh(P, idx, mat); scene.object_end()
+        side = int(np.ceil(instances ** (1.0 / 3.0)))
+        rng = np.random.default_rng(spec.seed + 1000)
+        ident = (IDENTITY, IDENTITY)
+        sc = 1.0 / side
+        for k in range(instances):
+            i, j, l = k % side, (k // side) % side, k // (side * side)
+            c = (np.array([i, j, l], np.float64) + 0.5) / side * 2.0 - 1.0 + rng.uniform(-0.2, 0.2, 3) / side
+            t = host.compose(host.compose(host.compose(ident, host.translate(c)), host.rotate(float(rng.uniform(0, 360)), rng.normal(size=3) + 1e-3)),
+                             host.scale([sc, sc, sc]))
+            scene.add_instance(ob, t[0], t[1])
+    else:
+        scene.add_mesh(P, idx, mat)
     w2c, c2w = host.look_at(spec.eye, spec.look, spec.up)
     r2c = host.perspective_raster_to_camera(spec.fov, spec.xres, spec.yres)
     scene.set_camera_perspective(r2c, c2w)

@@ -61,7 +61,7 @@ def build_pair(capture, oracle_scene_cls):
 
 def hits_equal(a, b):
     """Bit-exact comparison of (t, prim, b0, b1, b2)."""
-    ok = (a["prim"] == b["prim"])
+    ok = (a["prim"] == b["prim"]) & (a["pad"][:, 1] == b["pad"][:, 1])   # pad[1]: instance number + 1
     for f in ("t", "b0", "b1", "b2"):
         ok &= (a[f].view(np.uint32) == b[f].view(np.uint32))
     return ok

@@ -46,7 +46,9 @@ def test_check_mode_crop_and_outfile(tmp_path):
 @pytest.mark.parametrize("text,needle", [
     ('WorldBegin\nShape "sphere" "float radius" 1\nWorldEnd\n', 'Shape "sphere" is outside the hot-path scope'),
     ('WorldBegin\nMaterial "glass"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', 'Material "glass"'),
-    ('WorldBegin\nObjectBegin "a"\nObjectEnd\nWorldEnd\n', "directive 'ObjectBegin'"),
+    ('WorldBegin\nMakeNamedMedium "fog" "string type" "homogeneous"\nWorldEnd\n', "directive 'MakeNamedMedium'"),
+    ('WorldBegin\nObjectBegin "a"\nAreaLightSource "diffuse"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nObjectEnd\nWorldEnd\n',
+     "AreaLightSource inside ObjectBegin"),
     ('WorldBegin\nLightSource "spot"\nWorldEnd\n', 'LightSource "spot"'),
     ('Camera "orthographic"\nWorldBegin\nWorldEnd\n', 'Camera "orthographic"'),
     ('Integrator "bdpt"\nWorldBegin\nWorldEnd\n', 'Integrator "bdpt"'),
@@ -77,6 +79,20 @@ def test_wrong_block_directives_are_ignored_with_a_warning(tmp_path):
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["triangles"] == 0 and info["xres"] == 8 and info["lights"] == 1
     assert "must be inside world block" in r.stderr and "cannot be set inside world block" in r.stderr and "Unmatched AttributeEnd" in r.stderr
+
+
+def test_object_instancing_directives(tmp_path):
+    p = tmp_path / "s.pbrt"
+    p.write_text('WorldBegin\nLightSource "infinite"\n'
+                 'ObjectBegin "pair"\n  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [0 0 0 1 0 0 1 1 0 0 1 0]\nObjectEnd\n'
+                 'ObjectBegin "nothing"\nObjectEnd\n'
+                 'AttributeBegin\n  Translate 2 0 0\n  ObjectInstance "pair"\nAttributeEnd\n'
+                 'ObjectInstance "pair"\nObjectInstance "nothing"\nObjectInstance "unknown"\nObjectEnd\nWorldEnd\n')
+    r = run(["--check", str(p)])
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["instances"] == 2 and info["triangles"] == 4      # two instances of a two-triangle object; the empty one adds nothing
+    assert "Unable to find object instance named 'unknown'" in r.stderr and "ObjectEnd called outside" in r.stderr
 
 
 def test_ascii_ply_and_bad_ply(tmp_path):

@@ -71,3 +71,76 @@ def test_default_light_strategy_is_spatial(tmp_path, host):
     ref, st = oracle_image(host, "box", 2)
     assert st.light_distributions_created > 100
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def test_object_instances_in_a_scene_file(tmp_path, host):
+    """ObjectBegin / ObjectInstance through the parser and Api: same bits as the oracle fed the same instances call by call."""
+    import scenes
+    Pq = np.array([[-0.5, -0.5, 0], [0.5, -0.5, 0], [0.5, 0.5, 0.3], [-0.5, 0.5, 0.3]], np.float32)
+    text = f"""LookAt 0 -6 2.5  0 0 0.3  0 0 1
+Camera "perspective" "float fov" 45
+Film "image" "integer xresolution" 40 "integer yresolution" 32 "string filename" "i.pfm"
+Sampler "halton" "integer pixelsamples" 4
+Integrator "path" "integer maxdepth" 3
+WorldBegin
+LightSource "infinite" "rgb L" [0.7 0.8 0.9]
+LightSource "point" "point from" [0 -1 3] "rgb I" [20 20 20]
+Material "matte" "rgb Kd" [0.5 0.5 0.5]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-3 -3 -0.5 3 -3 -0.5 3 3 -0.5 -3 3 -0.5]
+ObjectBegin "tile"
+  Material "matte" "rgb Kd" [0.8 0.3 0.2] "float sigma" 20
+  Rotate 20 1 0 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [{ds.fl(Pq)}]
+ObjectEnd
+ObjectBegin "single"
+  Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 0.6 0 0.2 0 0.6 0.4]
+ObjectEnd
+AttributeBegin
+  Translate -1.5 0 0.2
+  ObjectInstance "tile"
+  Translate 1.5 0.5 0.4
+  Scale 1.5 1 -1
+  ObjectInstance "tile"
+  ObjectInstance "single"
+AttributeEnd
+ObjectInstance "single"
+WorldEnd
+"""
+    (tmp_path / "i.pbrt").write_text(text)
+    r = subprocess.run([ds.RENDER_BIN, "--quiet", str(tmp_path / "i.pbrt")], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    img = ds.read_pfm(str(tmp_path / "i.pfm"))
+
+    I = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+    mul = host.compose
+    set_libm_mode(1)
+    try:
+        with OracleScene() as o:
+            w2c = mul(I, host.look_at([0, -6, 2.5], [0, 0, 0.3], [0, 0, 1]))
+            o.add_light_infinite((0.7, 0.8, 0.9))
+            o.add_light_point(np.float32([20, 20, 20]), host.point_position(I[0], I[1], [0, -1, 3]))
+            grey = o.add_material_matte((0.5, 0.5, 0.5), 0.0)
+            o.add_mesh(np.float32([[-3, -3, -0.5], [3, -3, -0.5], [3, 3, -0.5], [-3, 3, -0.5]]), [0, 1, 2, 0, 2, 3], grey)
+            tile = o.object_begin()
+            red = o.add_material_matte((0.8, 0.3, 0.2), 20.0)
+            t = mul(I, host.rotate(20, [1, 0, 0]))
+            o.add_mesh(host.transform_points(t[0], Pq), [0, 1, 2, 0, 2, 3], red, swaps_handedness=host.swaps_handedness(t[0]))
+            o.object_end()
+            single = o.object_begin()
+            o.add_mesh(np.float32([[0, 0, 0], [0.6, 0, 0.2], [0, 0.6, 0.4]]), [0, 1, 2], grey)   # Material reverts at ObjectEnd (attribute pop)
+            o.object_end()
+            a = mul(I, host.translate([-1.5, 0, 0.2]))
+            o.add_instance(tile, a[0], a[1])
+            b = mul(mul(a, host.translate([1.5, 0.5, 0.4])), host.scale([1.5, 1, -1]))
+            o.add_instance(tile, b[0], b[1]); o.add_instance(single, b[0], b[1])
+            o.add_instance(single, I[0], I[1])
+            o.set_camera_perspective(host.perspective_raster_to_camera(45.0, 40, 32), w2c[1])
+            cb, table, sb = host.film_box(40, 32)
+            o.set_film(40, 32, cb, (0.5, 0.5), table)
+            o.set_sampler(0, 4, sb)
+            o.build_accel(0, 4)
+            xyz, wt, st = o.render_path(max_depth=3, light_strategy=2, pixel_bounds=sb)
+            ref = o.film_to_rgb(xyz, wt).reshape(32, 40, 3)
+    finally:
+        set_libm_mode(0)
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), f"{(img != ref).sum()} values differ"

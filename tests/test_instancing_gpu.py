@@ -1,0 +1,108 @@
+"""-m gpu: object instancing (ObjectBegin / ObjectInstance -> TransformedPrimitive, core/src/primitives/transformed_primitive.rs)
+on the device against the oracle: closest hits incl. instance ids, occlusion, and rendered film bit-exact."""
+import numpy as np
+import pytest
+
+import pbrt_hip
+import scenes
+from oracle_binding import OracleScene, set_libm_mode
+
+pytestmark = pytest.mark.gpu
+I4 = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+
+
+def _transforms(host):
+    mul = host.compose
+    return [mul(mul(I4, host.translate([2.5, 0.3, -0.2])), host.rotate(40, [0.2, 1, 0.3])),
+            mul(mul(I4, host.translate([-2.0, 0.5, 0.4])), host.scale([0.7, 1.3, 0.9])),
+            mul(mul(I4, host.translate([0.2, -2.2, 0.1])), host.scale([-1.0, 1.0, 1.0])),   # handedness flip
+            I4]
+
+
+def _instanced_scene(host, split=0, n_obj_tris=300, with_normals=False):
+    P, idx = host.gen_random_tris(n_obj_tris, 5)
+    N = None
+    if with_normals:
+        rng = np.random.default_rng(1)
+        N = rng.normal(size=P.shape).astype(np.float32)
+    Pg, ig = scenes.grid_mesh(4, z=-1.2, size=3.0)
+    if split == 1:  # the regular grid makes hlbvh.rs assert (equal treelet centroids, :338) in the reference itself
+        Pg, ig = host.gen_random_tris(40, 9)
+        Pg = Pg * np.float32(2.5) + np.float32([0, 0, -1.5])
+    T = _transforms(host)
+
+    def capture(s):
+        m = s.add_material_matte((0.6, 0.5, 0.4), 15.0)
+        m2 = s.add_material_matte((0.2, 0.6, 0.8), 0.0)
+        s.add_mesh(Pg, ig, m)                                               # scene-level triangles before ...
+        ob = s.object_begin(); s.add_mesh(P, idx, m2, N=N); s.object_end()
+        one = s.object_begin(); s.add_mesh(P[:3] * np.float32(2.0), [0, 1, 2], m); s.object_end()   # single primitive: used directly
+        empty = s.object_begin(); s.object_end()
+        s.add_instance(ob, *T[0]); s.add_instance(ob, *T[1]); s.add_instance(one, *T[0]); s.add_instance(empty, *T[1])
+        s.add_mesh(Pg + np.float32([0, 0, 3.5]), ig, m)                     # ... between ...
+        s.add_instance(ob, *T[2]); s.add_instance(ob, *T[3]); s.add_instance(one, *T[3])
+        s.build_accel(split, 4)
+    return capture
+
+
+@pytest.mark.parametrize("split", [0, 1, 3])
+def test_instanced_hits_bit_exact(host, split):
+    prod, orc = scenes.build_pair(_instanced_scene(host, split), OracleScene)
+    rays = np.concatenate([scenes.random_rays(60000, 3, bound=3.0), scenes.axis_rays()])
+    got = prod.intersect_batch(rays)
+    want, _ = orc.intersect_batch_stats(rays)
+    eq = scenes.hits_equal(got, want)
+    assert eq.all(), f"{(~eq).sum()} of {len(rays)} differ; first {np.flatnonzero(~eq)[:5]}: {got[~eq][:3]} vs {want[~eq][:3]}"
+    insts = np.bincount(want["pad"][:, 1][want["prim"] != 0xFFFFFFFF], minlength=7)
+    assert (insts[:7] > 0).sum() >= 6, insts     # scene-level hits and most instances are represented
+    assert np.array_equal(prod.occluded_batch(rays), orc.occluded_batch_stats(rays)[0])
+    assert np.array_equal(prod.world_bound(), orc.world_bound())
+
+
+def test_instanced_scene_film_bit_exact(host):
+    base = _instanced_scene(host, 0, with_normals=True)
+
+    def cap(s):
+        s.add_light_infinite((0.5, 0.6, 0.7))
+        s.add_light_point((30, 28, 25), (0.5, -1.0, 2.5))
+        base(s)
+        w2c, c2w = host.look_at([0.5, -7.5, 2.0], [0, 0, 0.5], [0, 0, 1])
+        s.set_camera_perspective(host.perspective_raster_to_camera(50.0, 48, 40), c2w)
+        cb, table, sb = host.film_box(48, 40)
+        s.set_film(48, 40, cb, (0.5, 0.5), table)
+        s.set_sampler(0, 4, sb)
+        s.build_accel(0, 4)
+    for strategy in (0, 2):   # uniform, and spatial (voxel of the WORLD-space hit point)
+        prod = pbrt_hip.Scene(); orc = OracleScene()
+        cap(prod); cap(orc)
+        set_libm_mode(1)
+        try:
+            oxyz, owt, ost, _ = orc.render_path_ex(max_depth=4, light_strategy=strategy)
+        finally:
+            set_libm_mode(0)
+        gxyz, gwt, gst = prod.render_path(max_depth=4, light_strategy=strategy)
+        assert (gst.regular_rays, gst.shadow_rays) == (ost.regular_rays, ost.shadow_rays)
+        assert gst.light_distributions_created == ost.light_distributions_created
+        assert np.array_equal(gwt.view(np.uint32), owt.view(np.uint32))
+        nb = int((gxyz.view(np.uint32) != oxyz.view(np.uint32)).any(axis=2).sum())
+        assert nb == 0, f"{nb} pixels differ (strategy {strategy})"
+        assert float(oxyz.max()) > 0
+
+
+def test_instancing_errors(host):
+    with pbrt_hip.Scene() as s:
+        m = s.add_material_matte()
+        ob = s.object_begin()
+        with pytest.raises(pbrt_hip.PbrtHipError):
+            s.object_begin()                                   # nested definition
+        lid = s.add_light_diffuse_area((1, 1, 1), 1)
+        with pytest.raises(pbrt_hip.PbrtHipError) as e:
+            s.add_mesh(np.eye(3, dtype=np.float32), [0, 1, 2], m, first_area_light=lid)   # area light inside an object
+        assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
+        with pytest.raises(pbrt_hip.PbrtHipError):
+            s.add_instance(ob, *I4)                            # ObjectInstance inside a definition
+        s.object_end()
+        with pytest.raises(pbrt_hip.PbrtHipError):
+            s.object_end()
+        with pytest.raises(pbrt_hip.PbrtHipError):
+            s.add_instance(99, *I4)
