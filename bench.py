@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=64, help="spp of the bounded CPU-baseline sample (same scene, same resolution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-count", action="store_true")
+    ap.add_argument("--material", default="matte", choices=["matte", "plastic", "glass", "metal", "uber"],
+                    help="material of every triangle; anything but matte runs the general-BSDF shade kernel (not the headline workload)")
     ap.add_argument("--instances", type=int, default=0,
                     help="K > 0: the triangles become one object instanced K times (two-level BVH, TransformedPrimitive path); not the headline workload")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -97,7 +99,7 @@ def main():
 
     host = pbrt_hip.Host()
     frame_spp = args.spp * (world if args.scaling == "weak" else 1)
-    spec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=frame_spp, max_depth=args.max_depth)
+    spec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=frame_spp, max_depth=args.max_depth, material=args.material)
     scene = pbrt_hip.Scene(device=local_rank)
     t_setup = time.time()
     geometry = pbrt_hip.capture_spec(spec, scene, host, instances=args.instances)
@@ -168,7 +170,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("" if not args.instances else f"INSTANCED x{args.instances} (one object, two-level BVH) — ") +
                                    f"configs[1]: {args.n_tris} random triangles (seed {args.seed}), single SAH BVH, {args.res}x{args.res} @ {frame_spp} spp{spp_note}, "
-                                   f"PathIntegrator maxdepth {args.max_depth}, halton, box filter, constant infinite light, matte Kd 0.5",
+                                   f"PathIntegrator maxdepth {args.max_depth}, halton, box filter, constant infinite light, " + ("matte Kd 0.5" if args.material == "matte" else f"material {args.material}"),
                        "tiles": "16x16, tile t on rank t % n_gpus, film tiles gathered on rank 0 (RCCL)" if world > 1 else "16x16, one rank",
                        "rays_per_frame": rays // args.steps, "regular_rays_per_frame": reg // args.steps, "shadow_rays_per_frame": shd // args.steps,
                        "scene_setup_seconds_host": round(t_setup, 3)},
@@ -226,7 +228,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle_binding import OracleScene
         cores = host_cores()
-        cspec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=args.cpu_spp, max_depth=args.max_depth)
+        cspec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=args.cpu_spp, max_depth=args.max_depth, material=args.material)
         orc = OracleScene()
         tb = time.time()
         pbrt_hip.capture_spec(cspec, orc, host, geometry=geometry, instances=args.instances)

@@ -86,6 +86,27 @@ const char* pbrt_hip_last_error(const PbrtHipScene*);     /* NUL-terminated, own
 /* MatteMaterial with constant textures (materials/src/matte.rs:47-92). sigma in degrees, clamped to [0,90]. */
 int pbrt_hip_add_material_matte(PbrtHipScene*, const float kd_rgb[3], float sigma_deg, uint32_t* out_id);
 
+/* More materials, all with constant textures: the library builds the BxDF list their compute_scattering_functions would
+ * (allow_multiple_lobes = true, TransportMode::Radiance, as PathIntegrator calls it, integrators/src/path.rs:143).  Roughness is
+ * remapped by TrowbridgeReitzDistribution::roughness_to_alpha when remap_roughness != 0 (the scene-file default).
+ *   mirror   materials/src/mirror.rs:40-62     SpecularReflection(Kr, FresnelNoOp)
+ *   plastic  materials/src/plastic.rs:50-82    LambertianReflection(Kd) + MicrofacetReflection(Ks, TR(rough), Dielectric(1.5, 1))
+ *   glass    materials/src/glass.rs:62-118     FresnelSpecular(Kr, Kt, 1, eta) if both roughnesses are 0, else MicrofacetReflection +
+ *                                              MicrofacetTransmission over TR(urough, vrough)
+ *   metal    materials/src/metal.rs:62-98      MicrofacetReflection(1, TR(urough, vrough), Conductor(1, eta, k)); eta/k as RGB (the
+ *                                              reference's copper default needs its spectral tables: pass them explicitly)
+ *   uber     materials/src/uber.rs:116-186     opacity pass-through + Lambert(Kd) + Microfacet(Ks) + SpecularReflection(Kr) +
+ *                                              SpecularTransmission(Kt); pass urough = vrough = roughness when the file gives one value
+ * Bump maps are outside the scope (constant textures have no gradient: Material::bump is the identity for them). */
+int pbrt_hip_add_material_mirror(PbrtHipScene*, const float kr_rgb[3], uint32_t* out_id);
+int pbrt_hip_add_material_plastic(PbrtHipScene*, const float kd_rgb[3], const float ks_rgb[3], float roughness, int remap_roughness, uint32_t* out_id);
+int pbrt_hip_add_material_glass(PbrtHipScene*, const float kr_rgb[3], const float kt_rgb[3], float uroughness, float vroughness, float eta,
+                                int remap_roughness, uint32_t* out_id);
+int pbrt_hip_add_material_metal(PbrtHipScene*, const float eta_rgb[3], const float k_rgb[3], float uroughness, float vroughness, int remap_roughness,
+                                uint32_t* out_id);
+int pbrt_hip_add_material_uber(PbrtHipScene*, const float kd_rgb[3], const float ks_rgb[3], const float kr_rgb[3], const float kt_rgb[3],
+                               const float opacity_rgb[3], float uroughness, float vroughness, float eta, int remap_roughness, uint32_t* out_id);
+
 /* TriangleMesh (shapes/src/triangle.rs:75-113): P/N/S must ALREADY be in world space exactly as TriangleMesh::new
  * leaves them (:93-99).  N, S, UV may be NULL.  One GeometricPrimitive per triangle (api/src/lib.rs:783-812).
  * first_area_light_id: -1, or the id returned by pbrt_hip_add_light_diffuse_area for the SAME n_tris (triangle k

@@ -35,12 +35,108 @@ OracleScene* oracle_scene_create(int) { return new OracleScene(); }
 void oracle_scene_destroy(OracleScene* s) { delete s; }
 const char* oracle_last_error(const OracleScene* s) { return s ? s->err.c_str() : "null handle"; }
 
-int oracle_add_material_matte(OracleScene* s, const float kd[3], float sigma, uint32_t* out_id) {
-    if (!s || !kd) return -1;
-    Material m; m.kd = Spec(kd[0], kd[1], kd[2]); m.sigma = sigma;
+// ---- materials: the BxDF list compute_scattering_functions builds, for constant textures (materials/src/*.rs) -------------
+static Float roughness_to_alpha(Float roughness) {  // microfacet/trowbridge_reitz.rs:31-40
+    roughness = pmax(roughness, 1e-3f);
+    Float x = std::log(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+static void set_tr(Lobe& l, Float ax, Float ay) { l.ax = pmax(0.001f, ax); l.ay = pmax(0.001f, ay); }  // TrowbridgeReitzDistribution::new (:21-28)
+static Spec spec3(const float v[3]) { return Spec(v[0], v[1], v[2]); }
+static int push_material(OracleScene* s, Material& m, uint32_t* out_id) {
     s->sc.materials.push_back(m);
     if (out_id) *out_id = (uint32_t)s->sc.materials.size() - 1;
     return 0;
+}
+int oracle_add_material_matte(OracleScene* s, const float kd[3], float sigma, uint32_t* out_id) {  // matte.rs:47-76
+    if (!s || !kd) return -1;
+    Material m; m.kd = spec3(kd); m.sigma = sigma;
+    Spec r = spec_clamp0(m.kd);
+    Float sig = pclamp(sigma, 0.0f, 90.0f);
+    if (!r.is_black()) {
+        Lobe l; l.r = r; l.type = BX_REFL | BX_DIFF;
+        if (sig == 0.0f) l.kind = LK_LAMBERT;
+        else {  // oren_nayar.rs:28-39
+            l.kind = LK_OREN;
+            Float sg = to_radians(sig), s2 = sg * sg;
+            l.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
+            l.b = 0.45f * s2 / (s2 + 0.09f);
+        }
+        m.lobes.push_back(l);
+    }
+    return push_material(s, m, out_id);
+}
+int oracle_add_material_mirror(OracleScene* s, const float kr[3], uint32_t* out_id) {  // mirror.rs:40-62
+    if (!s || !kr) return -1;
+    Material m; m.general = true;
+    Spec r = spec_clamp0(spec3(kr));
+    if (!r.is_black()) { Lobe l; l.kind = LK_SPEC_R; l.type = BX_REFL | BX_SPEC; l.fresnel = FR_NOOP; l.r = r; m.lobes.push_back(l); }
+    return push_material(s, m, out_id);
+}
+int oracle_add_material_plastic(OracleScene* s, const float kd[3], const float ks[3], float roughness, int remap, uint32_t* out_id) {  // plastic.rs:50-82
+    if (!s || !kd || !ks) return -1;
+    Material m; m.general = true;
+    Spec d = spec_clamp0(spec3(kd)), sp = spec_clamp0(spec3(ks));
+    if (!d.is_black()) { Lobe l; l.kind = LK_LAMBERT; l.type = BX_REFL | BX_DIFF; l.r = d; m.lobes.push_back(l); }
+    if (!sp.is_black()) {
+        Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.5f; l.eta_b = 1.0f; l.r = sp;
+        Float rough = remap ? roughness_to_alpha(roughness) : roughness;
+        set_tr(l, rough, rough);
+        m.lobes.push_back(l);
+    }
+    return push_material(s, m, out_id);
+}
+int oracle_add_material_glass(OracleScene* s, const float kr[3], const float kt[3], float urough, float vrough, float eta, int remap, uint32_t* out_id) {  // glass.rs:62-118
+    if (!s || !kr || !kt) return -1;
+    Material m; m.general = true;  // BSDF::new(.., None): eta stays 1 (glass.rs:82)
+    Spec r = spec_clamp0(spec3(kr)), t = spec_clamp0(spec3(kt));
+    if (!(r.is_black() && t.is_black())) {
+        bool is_specular = urough == 0.0f && vrough == 0.0f;
+        if (is_specular) {  // allow_multiple_lobes is true on this path (path.rs:143)
+            Lobe l; l.kind = LK_FRESNEL_SPEC; l.type = BX_REFL | BX_TRANS | BX_SPEC; l.r = r; l.t = t; l.eta_a = 1.0f; l.eta_b = eta; m.lobes.push_back(l);
+        } else {
+            if (remap) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
+            if (!r.is_black()) { Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; l.r = r; set_tr(l, urough, vrough); m.lobes.push_back(l); }
+            if (!t.is_black()) { Lobe l; l.kind = LK_MICRO_T; l.type = BX_TRANS | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; l.t = t; set_tr(l, urough, vrough); m.lobes.push_back(l); }
+        }
+    }
+    return push_material(s, m, out_id);
+}
+int oracle_add_material_metal(OracleScene* s, const float eta[3], const float k[3], float urough, float vrough, int remap, uint32_t* out_id) {  // metal.rs:62-98
+    if (!s || !eta || !k) return -1;
+    Material m; m.general = true;
+    if (remap) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
+    Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_COND; l.r = Spec(1.0f);
+    l.c_eta_i = Spec(1.0f); l.c_eta_t = spec3(eta); l.c_k = spec3(k);
+    set_tr(l, urough, vrough);
+    m.lobes.push_back(l);
+    return push_material(s, m, out_id);
+}
+int oracle_add_material_uber(OracleScene* s, const float kd[3], const float ks[3], const float kr[3], const float kt[3], const float opacity[3], float urough,
+                             float vrough, float eta, int remap, uint32_t* out_id) {  // uber.rs:116-186
+    if (!s || !kd || !ks || !kr || !kt || !opacity) return -1;
+    Material m; m.general = true;
+    Float e = eta;
+    Spec op = spec_clamp0(spec3(opacity));
+    Spec t = spec_clamp0(-op + Spec(1.0f));
+    if (!t.is_black()) {
+        m.bsdf_eta = 1.0f;
+        Lobe l; l.kind = LK_SPEC_T; l.type = BX_TRANS | BX_SPEC; l.fresnel = FR_DIEL; l.t = t; l.eta_a = 1.0f; l.eta_b = 1.0f; m.lobes.push_back(l);
+    } else m.bsdf_eta = e;
+    Spec d = op * spec_clamp0(spec3(kd));
+    if (!d.is_black()) { Lobe l; l.kind = LK_LAMBERT; l.type = BX_REFL | BX_DIFF; l.r = d; m.lobes.push_back(l); }
+    Spec sp = op * spec_clamp0(spec3(ks));
+    if (!sp.is_black()) {
+        Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.r = sp;
+        if (remap) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
+        set_tr(l, urough, vrough);
+        m.lobes.push_back(l);
+    }
+    Spec r = op * spec_clamp0(spec3(kr));
+    if (!r.is_black()) { Lobe l; l.kind = LK_SPEC_R; l.type = BX_REFL | BX_SPEC; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.r = r; m.lobes.push_back(l); }
+    Spec tt = op * spec_clamp0(spec3(kt));
+    if (!tt.is_black()) { Lobe l; l.kind = LK_SPEC_T; l.type = BX_TRANS | BX_SPEC; l.fresnel = FR_DIEL; l.t = tt; l.eta_a = 1.0f; l.eta_b = e; m.lobes.push_back(l); }
+    return push_material(s, m, out_id);
 }
 
 int oracle_add_mesh(OracleScene* s, const float* P, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, const float* N,
@@ -262,6 +358,29 @@ int oracle_render_path_ex(OracleScene* s, int max_depth, float rr_threshold, int
     if (out_nv_nt) { out_nv_nt[0] = r.total_stats.nv_regular; out_nv_nt[1] = r.total_stats.nt_regular; out_nv_nt[2] = r.total_stats.nv_shadow; out_nv_nt[3] = r.total_stats.nt_shadow; }
     return 0;
 }
+// BSDF probe for pinning tests: the material's BSDF in the canonical frame (ns = ng = +z, ss = +x).
+//   op 0: out[0..2] = f(wo, wi, flags), out[3] = pdf(wo, wi, flags)
+//   op 1: sample_f(wo, u, flags): out[0..2] = f, out[3] = pdf, out[4..6] = wi, out[7] = sampled BxDFType
+//   op 2: out[0] = num_components(flags), out[1] = number of lobes, out[2] = bsdf.eta
+int oracle_bsdf_probe(OracleScene* s, uint32_t material, int op, const float wo[3], const float wi[3], const float u[2], int flags, float out[8]) {
+    if (!s || material >= s->sc.materials.size() || !out) return -1;
+    const Material& m = s->sc.materials[material];
+    Renderer::BSDF b; b.ns = b.ng = V3(0, 0, 1); b.ss = V3(1, 0, 0); b.ts = cross(b.ns, b.ss);
+    b.lobes = m.lobes.data(); b.n = (int)m.lobes.size(); b.eta = m.bsdf_eta;
+    for (int i = 0; i < 8; i++) out[i] = 0.0f;
+    if (op == 0) {
+        Spec f = b.f(V3(wo[0], wo[1], wo[2]), V3(wi[0], wi[1], wi[2]), flags);
+        out[0] = f.c[0]; out[1] = f.c[1]; out[2] = f.c[2]; out[3] = b.pdf(V3(wo[0], wo[1], wo[2]), V3(wi[0], wi[1], wi[2]), flags);
+    } else if (op == 1) {
+        Spec f; Float pdf; V3 w; int st = 0;
+        b.sample_f(V3(wo[0], wo[1], wo[2]), V2(u[0], u[1]), f, pdf, w, flags, &st);
+        out[0] = f.c[0]; out[1] = f.c[1]; out[2] = f.c[2]; out[3] = pdf; out[4] = w.x; out[5] = w.y; out[6] = w.z; out[7] = (float)st;
+    } else {
+        out[0] = (float)b.num_components(flags); out[1] = (float)b.n; out[2] = b.eta;
+    }
+    return 0;
+}
+
 // SpatialLightDistribution of the last render: out[0..2] voxel resolution, out[3] distributions created
 // ("SpatialLightDistribution/Distributions created", spatial.rs:17-21).
 int oracle_spatial_stats(OracleScene* s, uint64_t out[4]) {

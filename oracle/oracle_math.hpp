@@ -166,6 +166,11 @@ inline Spec operator*(Spec a, Spec b) { return Spec(a.c[0] * b.c[0], a.c[1] * b.
 inline Spec operator*(Spec a, Float f) { return Spec(a.c[0] * f, a.c[1] * f, a.c[2] * f); }
 inline Spec operator*(Float f, Spec a) { return a * f; }
 inline Spec operator/(Spec a, Float f) { return a * (1.0f / f); }                            // rgb_spectrum.rs:255-263
+inline Spec operator-(Spec a, Spec b) { return Spec(a.c[0] - b.c[0], a.c[1] - b.c[1], a.c[2] - b.c[2]); }
+inline Spec operator/(Spec a, Spec b) { return Spec(a.c[0] / b.c[0], a.c[1] / b.c[1], a.c[2] / b.c[2]); }   // rgb_spectrum.rs:316-327
+inline Spec operator-(Spec a) { return a * -1.0f; }                                           // rgb_spectrum.rs:360-367
+inline Spec spec_sqrt(Spec a) { return Spec(std::sqrt(a.c[0]), std::sqrt(a.c[1]), std::sqrt(a.c[2])); }
+inline Spec spec_clamp0(Spec a) { return Spec(pclamp(a.c[0], 0.0f, INF), pclamp(a.c[1], 0.0f, INF), pclamp(a.c[2], 0.0f, INF)); }  // clamp_default
 inline Spec& operator+=(Spec& a, Spec b) { a = a + b; return a; }
 inline Spec& operator*=(Spec& a, Spec b) { a = a * b; return a; }
 // core/src/spectrum/common.rs:337-355

@@ -552,78 +552,307 @@ struct Renderer {
         }
     }
 
-    // ---- BSDF for MatteMaterial (materials/src/matte.rs:47-76, core/src/reflection/bsdf.rs) ------------------------
+    // ---- BSDF (core/src/reflection/bsdf.rs) over the lobes of a material ------------------------------------------------
     struct BSDF {
-        V3 ns, ng, ss, ts; Spec r; bool has_bxdf; bool oren; Float a, b;
+        V3 ns, ng, ss, ts; const Lobe* lobes = nullptr; int n = 0; Float eta = 1.0f;
         V3 w2l(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
         V3 l2w(V3 v) const {
             return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
         }
-        static Float sin2(V3 w) { return pmax(0.0f, 1.0f - w.z * w.z); }
+        // reflection/common.rs
+        static Float cos2(V3 w) { return w.z * w.z; }
+        static Float sin2(V3 w) { return pmax(0.0f, 1.0f - cos2(w)); }
         static Float sinth(V3 w) { return std::sqrt(sin2(w)); }
+        static Float tanth(V3 w) { return sinth(w) / w.z; }
+        static Float tan2(V3 w) { return sin2(w) / cos2(w); }
         static Float cosphi(V3 w) { Float s = sinth(w); return s == 0.0f ? 1.0f : pclamp(w.x / s, -1.0f, 1.0f); }
         static Float sinphi(V3 w) { Float s = sinth(w); return s == 0.0f ? 0.0f : pclamp(w.y / s, -1.0f, 1.0f); }
-        Spec bxdf_f(V3 wo, V3 wi) const {
-            if (!oren) return r * INV_PI;  // lambertian_reflection.rs:38-40
-            Float sin_i = sinth(wi), sin_o = sinth(wo), max_cos = 0.0f;  // oren_nayar.rs:46-72
-            if (sin_i > 1e-4f && sin_o > 1e-4f) {
-                Float d_cos = cosphi(wi) * cosphi(wo) + sinphi(wi) * sinphi(wo);
-                max_cos = pmax(0.0f, d_cos);
-            }
-            Float aco = pabs(wo.z), aci = pabs(wi.z), sin_alpha, tan_beta;
-            if (aci > aco) { sin_alpha = sin_o; tan_beta = sin_i / aci; }
-            else { sin_alpha = sin_i; tan_beta = sin_o / aco; }
-            return r * INV_PI * (a + b * max_cos * sin_alpha * tan_beta);
+        static Float cos2phi(V3 w) { Float c = cosphi(w); return c * c; }
+        static Float sin2phi(V3 w) { Float c = sinphi(w); return c * c; }
+        static bool same_hemisphere(V3 a, V3 b) { return a.z * b.z > 0.0f; }
+        static V3 reflect(V3 wo, V3 n) { return -wo + 2.0f * dot(wo, n) * n; }
+        static bool refract(V3 wi, V3 n, Float eta, V3& wt) {  // common.rs:103-118
+            Float cos_i = dot(n, wi);
+            Float sin2_i = pmax(0.0f, 1.0f - cos_i * cos_i);
+            Float sin2_t = eta * eta * sin2_i;
+            if (sin2_t >= 1.0f) return false;
+            Float cos_t = std::sqrt(1.0f - sin2_t);
+            wt = eta * -wi + (eta * cos_i - cos_t) * n;
+            return true;
         }
-        static Float bxdf_pdf(V3 wo, V3 wi) { return (wo.z * wi.z > 0.0f) ? pabs(wi.z) * INV_PI : 0.0f; }  // reflection/mod.rs:160-166
-        // BSDF::f (bsdf.rs:133-158); one REFLECTION|DIFFUSE lobe, flags = all or all & !SPECULAR (both match)
-        Spec f(V3 wo_w, V3 wi_w) const {
+        // fresnel.rs:135-170 (f32::max keeps the non-NaN operand; the operands here are never NaN)
+        static Float fr_dielectric(Float cos_i, Float eta_i, Float eta_t) {
+            cos_i = pclamp(cos_i, -1.0f, 1.0f);
+            if (!(cos_i > 0.0f)) { std::swap(eta_i, eta_t); cos_i = pabs(cos_i); }
+            Float sin_i = std::sqrt(std::fmax(0.0f, 1.0f - cos_i * cos_i));
+            Float sin_t = eta_i / eta_t * sin_i;
+            if (sin_t >= 1.0f) return 1.0f;
+            Float cos_t = std::sqrt(std::fmax(0.0f, 1.0f - sin_t * sin_t));
+            Float r_parl = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+            Float r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+            return (r_parl * r_parl + r_perp * r_perp) / 2.0f;
+        }
+        // fresnel.rs:172-196 — as written there: `sin_theta_i_2 = 1.0 - cos_theta_i` (not 1 - cos^2), quirk B11
+        static Spec fr_conductor(Float cos_i, Spec eta_i, Spec eta_t, Spec k) {
+            cos_i = pclamp(cos_i, -1.0f, 1.0f);
+            Spec eta = eta_t / eta_i, eta_k = k / eta_i;
+            Float cos2_i = cos_i * cos_i, sin2_i = 1.0f - cos_i;
+            Spec eta_2 = eta * eta, eta_k_2 = eta_k * eta_k;
+            Spec t0 = eta_2 - eta_k_2 - Spec(sin2_i);
+            Spec a2_plus_b2 = spec_sqrt(t0 * t0 + 4.0f * eta_2 * eta_k_2);
+            Spec t1 = a2_plus_b2 + Spec(cos2_i);
+            Spec a = spec_sqrt(0.5f * (a2_plus_b2 + t0));
+            Spec t2 = 2.0f * cos_i * a;
+            Spec rs = (t1 - t2) / (t1 + t2);
+            Spec t3 = cos2_i * a2_plus_b2 + Spec(sin2_i * sin2_i);
+            Spec t4 = t2 * sin2_i;
+            Spec rp = rs * (t3 - t4) / (t3 + t4);
+            return 0.5f * (rp + rs);
+        }
+        static Spec fresnel_eval(const Lobe& l, Float cos_i) {
+            if (l.fresnel == FR_DIEL) return Spec(fr_dielectric(cos_i, l.eta_a, l.eta_b));
+            if (l.fresnel == FR_COND) return fr_conductor(pabs(cos_i), l.c_eta_i, l.c_eta_t, l.c_k);
+            return Spec(1.0f);
+        }
+        // microfacet/trowbridge_reitz.rs
+        static Float tr_d(const Lobe& l, V3 wh) {
+            Float t2 = tan2(wh);
+            if (std::isinf(t2)) return 0.0f;
+            Float cos4 = cos2(wh) * cos2(wh);
+            Float e = (cos2phi(wh) / (l.ax * l.ax) + sin2phi(wh) / (l.ay * l.ay)) * t2;
+            return 1.0f / (PI * l.ax * l.ay * cos4 * (1.0f + e) * (1.0f + e));
+        }
+        static Float tr_lambda(const Lobe& l, V3 w) {
+            Float att = pabs(tanth(w));
+            if (std::isinf(att)) return 0.0f;
+            Float alpha = std::sqrt(cos2phi(w) * l.ax * l.ax + sin2phi(w) * l.ay * l.ay);
+            Float a2t2 = (alpha * att) * (alpha * att);
+            return (-1.0f + std::sqrt(1.0f + a2t2)) / 2.0f;
+        }
+        static Float tr_g1(const Lobe& l, V3 w) { return 1.0f / (1.0f + tr_lambda(l, w)); }
+        static Float tr_g(const Lobe& l, V3 wo, V3 wi) { return 1.0f / (1.0f + tr_lambda(l, wo) + tr_lambda(l, wi)); }
+        static Float tr_pdf(const Lobe& l, V3 wo, V3 wh) { return tr_d(l, wh) * tr_g1(l, wo) * abs_dot(wo, wh) / pabs(wo.z); }  // sample_visible_area = true
+        static void tr_sample_11(Float cos_theta, Float u1, Float u2, Float& slope_x, Float& slope_y) {
+            if (cos_theta > 0.9999f) {
+                Float r = std::sqrt(u1 / (1.0f - u1));
+                Float phi = TWO_PI * u2;
+                slope_x = r * o_cos(phi); slope_y = r * o_sin(phi);
+                return;
+            }
+            Float sin_theta = std::sqrt(pmax(0.0f, 1.0f - cos_theta * cos_theta));
+            Float tan_theta = sin_theta / cos_theta;
+            Float a = 1.0f / tan_theta;
+            Float g1 = 2.0f / (1.0f + std::sqrt(1.0f + 1.0f / (a * a)));
+            a = 2.0f * u1 / g1 - 1.0f;
+            Float tmp = 1.0f / (a * a - 1.0f);
+            if (tmp > 1e10f) tmp = 1e10f;
+            Float b = tan_theta;
+            Float d = std::sqrt(pmax(b * b * tmp * tmp - (a * a - b * b) * tmp, 0.0f));
+            Float sx1 = b * tmp - d, sx2 = b * tmp + d;
+            slope_x = (a < 0.0f || sx2 > 1.0f / tan_theta) ? sx1 : sx2;
+            Float sgn;
+            if (u2 > 0.5f) { sgn = 1.0f; u2 = 2.0f * (u2 - 0.5f); } else { sgn = -1.0f; u2 = 2.0f * (0.5f - u2); }
+            Float z = (u2 * (u2 * (u2 * 0.27385f - 0.73369f) + 0.46341f)) / (u2 * (u2 * (u2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+            slope_y = sgn * z * std::sqrt(1.0f + slope_x * slope_x);
+        }
+        static V3 tr_sample_wh(const Lobe& l, V3 wo, V2 u) {
+            bool flip = wo.z < 0.0f;
+            V3 wi = flip ? -wo : wo;
+            V3 ws = normalize(V3(l.ax * wi.x, l.ay * wi.y, wi.z));
+            Float sx, sy; tr_sample_11(ws.z, u.x, u.y, sx, sy);
+            Float tmp = cosphi(ws) * sx - sinphi(ws) * sy;
+            sy = sinphi(ws) * sx + cosphi(ws) * sy;
+            sx = tmp;
+            sx *= l.ax; sy *= l.ay;
+            V3 wh = normalize(V3(-sx, -sy, 1.0f));
+            return flip ? -wh : wh;
+        }
+        // ---- per-lobe f / pdf / sample_f ----------------------------------------------------------------------------------
+        static Spec lobe_f(const Lobe& l, V3 wo, V3 wi) {
+            switch (l.kind) {
+            case LK_LAMBERT: return l.r * INV_PI;  // lambertian_reflection.rs:38-40
+            case LK_OREN: {  // oren_nayar.rs:46-72
+                Float sin_i = sinth(wi), sin_o = sinth(wo), max_cos = 0.0f;
+                if (sin_i > 1e-4f && sin_o > 1e-4f) {
+                    Float d_cos = cosphi(wi) * cosphi(wo) + sinphi(wi) * sinphi(wo);
+                    max_cos = pmax(0.0f, d_cos);
+                }
+                Float aco = pabs(wo.z), aci = pabs(wi.z), sin_alpha, tan_beta;
+                if (aci > aco) { sin_alpha = sin_o; tan_beta = sin_i / aci; }
+                else { sin_alpha = sin_i; tan_beta = sin_o / aco; }
+                return l.r * INV_PI * (l.a + l.b * max_cos * sin_alpha * tan_beta);
+            }
+            case LK_MICRO_R: {  // microfacet_reflection.rs:34-52
+                Float cos_o = pabs(wo.z), cos_i = pabs(wi.z);
+                V3 wh = wi + wo;
+                if ((cos_i == 0.0f || cos_o == 0.0f) || (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f)) return Spec(0.0f);
+                wh = normalize(wh);
+                Spec f = fresnel_eval(l, dot(wi, face_forward(wh, V3(0.0f, 0.0f, 1.0f))));
+                return l.r * tr_d(l, wh) * tr_g(l, wo, wi) * f / (4.0f * cos_i * cos_o);
+            }
+            case LK_MICRO_T: {  // microfacet_transmission.rs:46-95
+                if (same_hemisphere(wo, wi)) return Spec(0.0f);
+                Float cos_o = wo.z, cos_i = wi.z;
+                if (cos_i == 0.0f || cos_o == 0.0f) return Spec(0.0f);
+                Float eta = wo.z > 0.0f ? l.eta_b / l.eta_a : l.eta_a / l.eta_b;
+                V3 wh = normalize(wo + wi * eta);
+                if (wh.z < 0.0f) wh = -wh;
+                if (dot(wo, wh) * dot(wi, wh) > 0.0f) return Spec(0.0f);
+                Spec f(fr_dielectric(dot(wo, wh), l.eta_a, l.eta_b));
+                Float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+                Float factor = 1.0f / eta;  // TransportMode::Radiance
+                return (Spec(1.0f) - f) * l.t *
+                       pabs(tr_d(l, wh) * tr_g(l, wo, wi) * eta * eta * abs_dot(wi, wh) * abs_dot(wo, wh) * factor * factor / (cos_i * cos_o * sqrt_denom * sqrt_denom));
+            }
+            default: return Spec(0.0f);  // specular lobes scatter nothing outside their delta direction
+            }
+        }
+        static Float lobe_pdf(const Lobe& l, V3 wo, V3 wi) {
+            switch (l.kind) {
+            case LK_LAMBERT: case LK_OREN: return same_hemisphere(wo, wi) ? pabs(wi.z) * INV_PI : 0.0f;  // reflection/mod.rs:160-166
+            case LK_MICRO_R: {
+                if (!same_hemisphere(wo, wi)) return 0.0f;
+                V3 wh = normalize(wo + wi);
+                return tr_pdf(l, wo, wh) / (4.0f * dot(wo, wh));
+            }
+            case LK_MICRO_T: {
+                if (same_hemisphere(wo, wi)) return 0.0f;
+                Float eta = wo.z > 0.0f ? l.eta_b / l.eta_a : l.eta_a / l.eta_b;
+                V3 wh = normalize(wo + wi * eta);
+                if (dot(wo, wh) * dot(wi, wh) > 0.0f) return 0.0f;
+                Float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+                Float dwh_dwi = pabs((eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom));
+                return tr_pdf(l, wo, wh) * dwh_dwi;
+            }
+            default: return 0.0f;
+            }
+        }
+        // returns the sampled BxDFType; f/pdf/wi zero where the reference returns BxDFSample::from(type)
+        static int lobe_sample_f(const Lobe& l, V3 wo, V2 u, Spec& f, Float& pdf, V3& wi) {
+            f = Spec(0.0f); pdf = 0.0f; wi = V3();
+            switch (l.kind) {
+            case LK_LAMBERT: case LK_OREN: {  // reflection/mod.rs:132-141
+                wi = cosine_sample_hemisphere(u);
+                if (wo.z < 0.0f) wi.z *= -1.0f;
+                pdf = lobe_pdf(l, wo, wi); f = lobe_f(l, wo, wi);
+                return l.type;
+            }
+            case LK_SPEC_R: {  // specular_reflection.rs:38-44
+                wi = V3(-wo.x, -wo.y, wo.z); pdf = 1.0f;
+                f = fresnel_eval(l, wi.z) * l.r / pabs(wi.z);
+                return l.type;
+            }
+            case LK_SPEC_T: {  // specular_transmission.rs:45-64
+                bool entering = wo.z > 0.0f;
+                Float eta_i = entering ? l.eta_a : l.eta_b, eta_t = entering ? l.eta_b : l.eta_a;
+                V3 wt;
+                if (!refract(wo, face_forward(V3(0.0f, 0.0f, 1.0f), wo), eta_i / eta_t, wt)) return l.type;
+                wi = wt; pdf = 1.0f;
+                Spec ft = l.t * (Spec(1.0f) - Spec(fr_dielectric(wi.z, l.eta_a, l.eta_b)));
+                ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));  // TransportMode::Radiance
+                f = ft / pabs(wi.z);
+                return l.type;
+            }
+            case LK_FRESNEL_SPEC: {  // fresnel_specular.rs:42-79
+                Float fr = fr_dielectric(wo.z, l.eta_a, l.eta_b);
+                if (u.x < fr) {
+                    wi = V3(-wo.x, -wo.y, wo.z); pdf = fr;
+                    f = fr * l.r / pabs(wi.z);
+                    return BX_SPEC | BX_REFL;
+                }
+                bool entering = wo.z > 0.0f;
+                Float eta_i = entering ? l.eta_a : l.eta_b, eta_t = entering ? l.eta_b : l.eta_a;
+                V3 wt;
+                if (!refract(wo, face_forward(V3(0.0f, 0.0f, 1.0f), wo), eta_i / eta_t, wt)) return BX_SPEC | BX_TRANS;
+                wi = wt;
+                Spec ft = l.t * (1.0f - fr);
+                ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+                pdf = 1.0f - fr;
+                f = ft / pabs(wi.z);
+                return BX_SPEC | BX_TRANS;
+            }
+            case LK_MICRO_R: {  // microfacet_reflection.rs:54-76
+                if (wo.z == 0.0f) return l.type;
+                V3 wh = tr_sample_wh(l, wo, u);
+                if (dot(wo, wh) < 0.0f) return l.type;
+                wi = reflect(wo, wh);
+                if (!same_hemisphere(wo, wi)) return l.type;  // f = 0, pdf = 0, wi kept
+                pdf = tr_pdf(l, wo, wh) / (4.0f * dot(wo, wh));
+                f = lobe_f(l, wo, wi);
+                return l.type;
+            }
+            case LK_MICRO_T: {  // microfacet_transmission.rs:97-120
+                if (wo.z == 0.0f) return l.type;
+                V3 wh = tr_sample_wh(l, wo, u);
+                if (dot(wo, wh) < 0.0f) return l.type;
+                Float eta = wo.z > 0.0f ? l.eta_a / l.eta_b : l.eta_b / l.eta_a;
+                V3 wt;
+                if (!refract(wo, wh, eta, wt)) return l.type;
+                wi = wt;
+                pdf = lobe_pdf(l, wo, wi); f = lobe_f(l, wo, wi);
+                return l.type;
+            }
+            }
+            return l.type;
+        }
+        static bool matches(const Lobe& l, int flags) { return (l.type & flags) == l.type; }
+        int num_components(int flags) const { int c = 0; for (int i = 0; i < n; i++) if (matches(lobes[i], flags)) c++; return c; }
+        // BSDF::f (bsdf.rs:133-158)
+        Spec f(V3 wo_w, V3 wi_w, int flags = BX_ALL) const {
             V3 wi = w2l(wi_w), wo = w2l(wo_w);
             if (wo.z == 0.0f) return Spec(0.0f);
             bool reflect = dot(wi_w, ng) * dot(wo_w, ng) > 0.0f;
             Spec out(0.0f);
-            if (has_bxdf && reflect) out += bxdf_f(wo, wi);
+            for (int i = 0; i < n; i++) {
+                const Lobe& l = lobes[i];
+                if (matches(l, flags) && ((reflect && (l.type & BX_REFL)) || (!reflect && (l.type & BX_TRANS)))) out += lobe_f(l, wo, wi);
+            }
             return out;
         }
-        Float pdf(V3 wo_w, V3 wi_w) const {  // bsdf.rs:331-356
-            if (!has_bxdf) return 0.0f;
+        Float pdf(V3 wo_w, V3 wi_w, int flags = BX_ALL) const {  // bsdf.rs:331-356
+            if (n == 0) return 0.0f;
             V3 wo = w2l(wo_w), wi = w2l(wi_w);
             if (wo.z == 0.0f) return 0.0f;
-            Float p = 0.0f; p += bxdf_pdf(wo, wi);
-            return p / 1.0f;
+            int matching = 0; Float p = 0.0f;
+            for (int i = 0; i < n; i++) if (matches(lobes[i], flags)) { matching++; p += lobe_pdf(lobes[i], wo, wi); }
+            return matching > 0 ? p / (Float)matching : 0.0f;
         }
-        // BSDF::sample_f (bsdf.rs:194-292)
-        bool sample_f(V3 wo_w, V2 u, Spec& f_out, Float& pdf_out, V3& wi_out) const {
+        // BSDF::sample_f (bsdf.rs:160-292); returns false where the reference returns BxDFSample::default()
+        bool sample_f(V3 wo_w, V2 u, Spec& f_out, Float& pdf_out, V3& wi_out, int flags = BX_ALL, int* sampled_type = nullptr) const {
             f_out = Spec(0.0f); pdf_out = 0.0f; wi_out = V3();
-            if (!has_bxdf) return false;
-            size_t comp = pmin<size_t>(f2usize(std::floor(u.x * 1.0f)), 0);
-            V2 ur(pmin(u.x * 1.0f - (Float)comp, ONE_MINUS_EPSILON), u.y);
+            if (sampled_type) *sampled_type = 0;
+            int matching = num_components(flags);
+            if (matching == 0) return false;
+            size_t comp = pmin<size_t>(f2usize(std::floor(u.x * (Float)matching)), (size_t)matching - 1);
+            int idx = -1; size_t count = comp;
+            for (int i = 0; i < n; i++) if (matches(lobes[i], flags)) { if (count == 0) { idx = i; break; } count--; }
+            V2 ur(pmin(u.x * (Float)matching - (Float)comp, ONE_MINUS_EPSILON), u.y);
             V3 wo = w2l(wo_w);
             if (wo.z == 0.0f) return false;
-            V3 wi = cosine_sample_hemisphere(ur);  // reflection/mod.rs:132-141
-            if (wo.z < 0.0f) wi.z *= -1.0f;
-            Float pdf = bxdf_pdf(wo, wi);
-            Spec fv = bxdf_f(wo, wi);
+            Spec fv; Float pdf; V3 wi;
+            int st = lobe_sample_f(lobes[idx], wo, ur, fv, pdf, wi);
             if (pdf == 0.0f) return false;
             V3 wi_w = l2w(wi);
-            bool reflect = dot(wi_w, ng) * dot(wo_w, ng) > 0.0f;
-            fv = Spec(0.0f);
-            if (reflect) fv += bxdf_f(wo, wi);
+            if (!(st & BX_SPEC) && matching > 1)
+                for (int i = 0; i < n; i++) if (i != idx && matches(lobes[i], flags)) pdf += lobe_pdf(lobes[i], wo, wi);
+            if (matching > 1) pdf /= (Float)matching;
+            if (!(st & BX_SPEC)) {
+                bool reflect = dot(wi_w, ng) * dot(wo_w, ng) > 0.0f;
+                fv = Spec(0.0f);
+                for (int i = 0; i < n; i++) {
+                    const Lobe& l = lobes[i];
+                    if (matches(l, flags) && ((reflect && (l.type & BX_REFL)) || (!reflect && (l.type & BX_TRANS)))) fv += lobe_f(l, wo, wi);
+                }
+            }
             f_out = fv; pdf_out = pdf; wi_out = wi_w;
+            if (sampled_type) *sampled_type = st;
             return true;
         }
     };
     BSDF make_bsdf(const SurfaceHit& si) const {
         const Material& m = sc->materials[sc->mesh_of(si.prim).material];
         BSDF b; b.ns = si.ns; b.ng = si.n; b.ss = normalize(si.dpdu_s); b.ts = cross(b.ns, b.ss);  // bsdf.rs:100-116
-        Spec r(pclamp(m.kd.c[0], 0.0f, INF), pclamp(m.kd.c[1], 0.0f, INF), pclamp(m.kd.c[2], 0.0f, INF));
-        Float sig = pclamp(m.sigma, 0.0f, 90.0f);
-        b.r = r; b.has_bxdf = !r.is_black(); b.oren = sig != 0.0f; b.a = b.b = 0;
-        if (b.oren) {  // oren_nayar.rs:28-39
-            Float s = to_radians(sig), s2 = s * s;
-            b.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
-            b.b = 0.45f * s2 / (s2 + 0.09f);
-        }
+        b.lobes = m.lobes.data(); b.n = (int)m.lobes.size(); b.eta = m.bsdf_eta;
         return b;
     }
 
@@ -715,8 +944,8 @@ struct Renderer {
         V3 wi = ls.valid ? ls.wi : V3(); Float light_pdf = ls.valid ? ls.pdf : 0.0f; Spec li = ls.valid ? ls.value : Spec(0.0f);
         bool is_delta = light.type == L_DISTANT || light.type == L_POINT;
         if (light_pdf > 0.0f && !li.is_black()) {
-            Spec f = bsdf.f(hit.wo, wi) * abs_dot(wi, hit.ns);
-            scattering_pdf = bsdf.pdf(hit.wo, wi);
+            Spec f = bsdf.f(hit.wo, wi, BX_ALL & ~BX_SPEC) * abs_dot(wi, hit.ns);  // bsdf_flags: specular = false (common.rs:157-161)
+            scattering_pdf = bsdf.pdf(hit.wo, wi, BX_ALL & ~BX_SPEC);
             if (!f.is_black()) {
                 Ray sr = spawn_ray_to_hit(hit.p, hit.p_error, hit.n, hit.time, ls.vp, ls.vperr, ls.vn);
                 if (scene_intersect_p(sr)) li = Spec(0.0f);
@@ -728,13 +957,18 @@ struct Renderer {
         }
         if (!is_delta) {
             Spec f1; Float scatter_pdf; V3 wi2;
-            bsdf.sample_f(hit.wo, u_scattering, f1, scatter_pdf, wi2);  // on failure: BxDFSample::default() = zeros
+            int sampled_type = 0;
+            bsdf.sample_f(hit.wo, u_scattering, f1, scatter_pdf, wi2, BX_ALL & ~BX_SPEC, &sampled_type);  // on failure: BxDFSample::default() = zeros
             scattering_pdf = scatter_pdf; wi = wi2;
             Spec f = f1 * abs_dot(wi, hit.ns);
+            bool sampled_specular = (sampled_type & BX_SPEC) != 0;
             if (!f.is_black() && scattering_pdf > 0.0f) {
-                Float lp = light_pdf_li(light, hit, wi);
-                if (lp == 0.0f) return ld;
-                Float weight = power_heuristic(1, scattering_pdf, 1, lp);
+                Float weight = 1.0f;
+                if (!sampled_specular) {
+                    Float lp = light_pdf_li(light, hit, wi);
+                    if (lp == 0.0f) return ld;
+                    weight = power_heuristic(1, scattering_pdf, 1, lp);
+                }
                 Ray ray = spawn_ray(hit.p, hit.p_error, hit.n, hit.time, wi);
                 uint32_t prim; TriHit h;
                 Spec li2(0.0f);
@@ -776,18 +1010,22 @@ struct Renderer {
             if (!found || bounces >= max_depth) break;
             BSDF bsdf = make_bsdf(isect);  // materials always present in scope
             V3 shading_n = isect.ns;
-            if (bsdf.has_bxdf) {  // num_components(all & !SPECULAR) > 0
+            if (bsdf.num_components(BX_ALL & ~BX_SPEC) > 0) {
                 tls_stats().total_paths++;
                 Spec ld = beta * uniform_sample_one_light(isect, bsdf, sampler);
                 if (ld.is_black()) tls_stats().zero_paths++;
                 L += ld;
             }
             V2 u = sampler.get_2d();
-            V3 wo = -ray.d, wi; Spec f; Float pdf;
-            bsdf.sample_f(wo, u, f, pdf, wi);
+            V3 wo = -ray.d, wi; Spec f; Float pdf; int flags = 0;
+            bsdf.sample_f(wo, u, f, pdf, wi, BX_ALL, &flags);
             if (f.is_black() || pdf == 0.0f) break;
             beta *= f * abs_dot(wi, shading_n) / pdf;
-            specular_bounce = false;
+            specular_bounce = (flags & BX_SPEC) != 0;
+            if ((flags & BX_SPEC) && (flags & BX_TRANS)) {  // path.rs:192-203
+                Float eta = bsdf.eta;
+                eta_scale *= dot(wo, isect.n) > 0.0f ? eta * eta : 1.0f / (eta * eta);
+            }
             ray = spawn_ray(isect.p, isect.p_error, isect.n, isect.time, wi);
             Spec rr_beta = beta * eta_scale;
             if (rr_beta.max_component_value() < rr_threshold && bounces > 3) {

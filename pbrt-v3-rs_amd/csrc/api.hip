@@ -80,6 +80,7 @@ int upload_scene(PbrtHipScene* s) {
     if ((rc = upload_vec(s, s->tri_flags, &d.tri_flags))) return rc;
     if ((rc = upload_vec(s, s->meshes, &d.meshes))) return rc;
     if ((rc = upload_vec(s, s->materials, &d.materials))) return rc;
+    if ((rc = upload_vec(s, s->lobes, &d.lobes))) return rc;
     if ((rc = upload_vec(s, s->lights, &d.lights))) return rc;
     d.n_lights = (uint32_t)s->lights.size();
     if ((rc = upload_vec(s, s->infinite_lights, &d.infinite_lights))) return rc;
@@ -318,21 +319,129 @@ const char* pbrt_hip_last_error(const PbrtHipScene* s) {
     return g_last_error.c_str();
 }
 
+// ---- materials: the BxDF list compute_scattering_functions builds for constant textures (materials/src/*.rs) ------------------
+namespace {
+float roughness_to_alpha(float roughness) {  // TrowbridgeReitzDistribution::roughness_to_alpha (microfacet/trowbridge_reitz.rs:31-40); host libm logf as for the reference
+    roughness = roughness > 1e-3f ? roughness : 1e-3f;
+    const float x = std::log(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+bool clamp3(const float in[3], float out[3]) {  // clamp_default(); returns !is_black()
+    for (int c = 0; c < 3; c++) out[c] = hm::clampf(in[c], 0.0f, hm::kInf);
+    return !(out[0] == 0.0f && out[1] == 0.0f && out[2] == 0.0f);
+}
+LobeRec lobe(uint32_t kind, uint32_t type) { LobeRec l{}; l.kind = kind; l.type = type; l.eta_a = l.eta_b = 1.0f; return l; }
+void set_tr(LobeRec& l, float ax, float ay) { l.ax = 0.001f > ax ? 0.001f : ax; l.ay = 0.001f > ay ? 0.001f : ay; }  // TrowbridgeReitzDistribution::new: max(0.001, alpha)
+enum : uint32_t { T_REFL = 1, T_TRANS = 2, T_DIFF = 4, T_GLOSSY = 8, T_SPEC = 16 };
+int push_material(PbrtHipScene* s, MaterialRec& m, const std::vector<LobeRec>& lobes, bool general, uint32_t* out_id) {
+    m.lobe_base = (uint32_t)s->lobes.size(); m.n_lobes = (uint32_t)lobes.size();
+    s->lobes.insert(s->lobes.end(), lobes.begin(), lobes.end());
+    s->materials.push_back(m);
+    if (general) s->general_materials = true;
+    if (out_id) *out_id = (uint32_t)s->materials.size() - 1;
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+}  // namespace
+
 int pbrt_hip_add_material_matte(PbrtHipScene* s, const float kd[3], float sigma_deg, uint32_t* out_id) {
     if (!s || !kd) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_matte: null argument");
     MaterialRec m{};
     for (int c = 0; c < 3; c++) m.kd[c] = hm::clampf(kd[c], 0.0f, hm::kInf);  // clamp_default (matte.rs:63)
     m.sigma = hm::clampf(sigma_deg, 0.0f, 90.0f);                              // matte.rs:64
     m.has_bxdf = !(m.kd[0] == 0.0f && m.kd[1] == 0.0f && m.kd[2] == 0.0f);
+    m.bsdf_eta = 1.0f;
     if (m.sigma != 0.0f) {  // OrenNayar::new (oren_nayar.rs:28-39)
         float sg = hm::to_radians(m.sigma), s2 = sg * sg;
         m.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
         m.b = 0.45f * s2 / (s2 + 0.09f);
     }
-    s->materials.push_back(m);
-    if (out_id) *out_id = (uint32_t)s->materials.size() - 1;
-    s->uploaded = false;
-    return PBRT_HIP_OK;
+    std::vector<LobeRec> lobes;
+    if (m.has_bxdf) {
+        LobeRec l = lobe(m.sigma != 0.0f ? PH_LK_OREN : PH_LK_LAMBERT, T_REFL | T_DIFF);
+        std::memcpy(l.r, m.kd, 12); l.a = m.a; l.b = m.b;
+        lobes.push_back(l);
+    }
+    return push_material(s, m, lobes, false, out_id);
+}
+int pbrt_hip_add_material_mirror(PbrtHipScene* s, const float kr[3], uint32_t* out_id) {  // mirror.rs:40-62
+    if (!s || !kr) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mirror: null argument");
+    MaterialRec m{}; m.bsdf_eta = 1.0f;
+    std::vector<LobeRec> lobes;
+    float r[3];
+    if (clamp3(kr, r)) { LobeRec l = lobe(PH_LK_SPEC_R, T_REFL | T_SPEC); l.fresnel = PH_FR_NOOP; std::memcpy(l.r, r, 12); lobes.push_back(l); }
+    return push_material(s, m, lobes, true, out_id);
+}
+int pbrt_hip_add_material_plastic(PbrtHipScene* s, const float kd[3], const float ks[3], float roughness, int remap_roughness, uint32_t* out_id) {  // plastic.rs:50-82
+    if (!s || !kd || !ks) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_plastic: null argument");
+    MaterialRec m{}; m.bsdf_eta = 1.0f;
+    std::vector<LobeRec> lobes;
+    float d[3], sp[3];
+    if (clamp3(kd, d)) { LobeRec l = lobe(PH_LK_LAMBERT, T_REFL | T_DIFF); std::memcpy(l.r, d, 12); lobes.push_back(l); }
+    if (clamp3(ks, sp)) {
+        LobeRec l = lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.5f; l.eta_b = 1.0f; std::memcpy(l.r, sp, 12);
+        const float rough = remap_roughness ? roughness_to_alpha(roughness) : roughness;
+        set_tr(l, rough, rough);
+        lobes.push_back(l);
+    }
+    return push_material(s, m, lobes, true, out_id);
+}
+int pbrt_hip_add_material_glass(PbrtHipScene* s, const float kr[3], const float kt[3], float urough, float vrough, float eta, int remap_roughness,
+                                uint32_t* out_id) {  // glass.rs:62-118 with allow_multiple_lobes = true (path.rs:143)
+    if (!s || !kr || !kt) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_glass: null argument");
+    MaterialRec m{}; m.bsdf_eta = 1.0f;  // BSDF::new(.., None) (glass.rs:82)
+    std::vector<LobeRec> lobes;
+    float r[3], t[3];
+    const bool rb = clamp3(kr, r), tb = clamp3(kt, t);
+    if (rb || tb) {
+        if (urough == 0.0f && vrough == 0.0f) {
+            LobeRec l = lobe(PH_LK_FRESNEL_SPEC, T_REFL | T_TRANS | T_SPEC); std::memcpy(l.r, r, 12); std::memcpy(l.t, t, 12); l.eta_a = 1.0f; l.eta_b = eta;
+            lobes.push_back(l);
+        } else {
+            if (remap_roughness) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
+            if (rb) { LobeRec l = lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; std::memcpy(l.r, r, 12); set_tr(l, urough, vrough); lobes.push_back(l); }
+            if (tb) { LobeRec l = lobe(PH_LK_MICRO_T, T_TRANS | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; std::memcpy(l.t, t, 12); set_tr(l, urough, vrough); lobes.push_back(l); }
+        }
+    }
+    return push_material(s, m, lobes, true, out_id);
+}
+int pbrt_hip_add_material_metal(PbrtHipScene* s, const float eta[3], const float k[3], float urough, float vrough, int remap_roughness, uint32_t* out_id) {  // metal.rs:62-98
+    if (!s || !eta || !k) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_metal: null argument");
+    MaterialRec m{}; m.bsdf_eta = 1.0f;
+    if (remap_roughness) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
+    LobeRec l = lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY); l.fresnel = PH_FR_COND;
+    l.r[0] = l.r[1] = l.r[2] = 1.0f; std::memcpy(l.c_eta_t, eta, 12); std::memcpy(l.c_k, k, 12);
+    set_tr(l, urough, vrough);
+    return push_material(s, m, {l}, true, out_id);
+}
+int pbrt_hip_add_material_uber(PbrtHipScene* s, const float kd[3], const float ks[3], const float kr[3], const float kt[3], const float opacity[3], float urough,
+                               float vrough, float eta, int remap_roughness, uint32_t* out_id) {  // uber.rs:116-186
+    if (!s || !kd || !ks || !kr || !kt || !opacity) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_uber: null argument");
+    MaterialRec m{};
+    std::vector<LobeRec> lobes;
+    float op[3], t[3], tmp[3];
+    clamp3(opacity, op);
+    for (int c = 0; c < 3; c++) tmp[c] = op[c] * -1.0f + 1.0f;  // (-op + Spectrum::ONE)
+    if (clamp3(tmp, t)) {
+        m.bsdf_eta = 1.0f;
+        LobeRec l = lobe(PH_LK_SPEC_T, T_TRANS | T_SPEC); l.fresnel = PH_FR_DIEL; std::memcpy(l.t, t, 12); l.eta_a = 1.0f; l.eta_b = 1.0f; lobes.push_back(l);
+    } else m.bsdf_eta = eta;
+    auto scaled = [&](const float in[3], float out[3]) {  // op * k.clamp_default()
+        float c[3]; clamp3(in, c);
+        for (int i = 0; i < 3; i++) out[i] = op[i] * c[i];
+        return !(out[0] == 0.0f && out[1] == 0.0f && out[2] == 0.0f);
+    };
+    float v[3];
+    if (scaled(kd, v)) { LobeRec l = lobe(PH_LK_LAMBERT, T_REFL | T_DIFF); std::memcpy(l.r, v, 12); lobes.push_back(l); }
+    if (scaled(ks, v)) {
+        LobeRec l = lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; std::memcpy(l.r, v, 12);
+        if (remap_roughness) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
+        set_tr(l, urough, vrough);
+        lobes.push_back(l);
+    }
+    if (scaled(kr, v)) { LobeRec l = lobe(PH_LK_SPEC_R, T_REFL | T_SPEC); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; std::memcpy(l.r, v, 12); lobes.push_back(l); }
+    if (scaled(kt, v)) { LobeRec l = lobe(PH_LK_SPEC_T, T_TRANS | T_SPEC); l.fresnel = PH_FR_DIEL; std::memcpy(l.t, v, 12); l.eta_a = 1.0f; l.eta_b = eta; lobes.push_back(l); }
+    return push_material(s, m, lobes, true, out_id);
 }
 
 // "the intersection is bogus" (triangle.rs:548-574): depends only on the triangle, so it is decided once here.

@@ -1,0 +1,334 @@
+// General BSDF (core/src/reflection/bsdf.rs) over a material's lobe list, for scenes that use more than MatteMaterial.
+//
+// With constant textures compute_scattering_functions (materials/src/{matte,mirror,plastic,glass,metal,uber}.rs) produces the
+// same BxDF list at every hit, so the host builds it once per material (api.hip) and the device only walks it:
+//   LambertianReflection, OrenNayar, SpecularReflection, SpecularTransmission, FresnelSpecular (core/src/reflection/*.rs),
+//   MicrofacetReflection / MicrofacetTransmission over TrowbridgeReitzDistribution with visible-area sampling
+//   (core/src/microfacet/trowbridge_reitz.rs), Fresnel NoOp / Dielectric / Conductor (core/src/reflection/fresnel.rs).
+// Expression order is the reference's; TransportMode is Radiance on this path.
+#pragma once
+#include "pt_device.h"
+
+namespace ph {
+
+enum : uint32_t { BX_REFL = 1u, BX_TRANS = 2u, BX_DIFF = 4u, BX_GLOSSY = 8u, BX_SPEC = 16u, BX_ALL = 31u };  // BxDFType (bsdf.rs:10-20)
+
+struct GBsdf {
+    f3 ns, ng, ss, ts;
+    const LobeRec* lobes;
+    uint32_t n;
+    float eta;
+};
+PH_DEV GBsdf make_gbsdf(const DeviceScene& sc, const SurfHit& si, uint32_t material) {
+    const MaterialRec& m = sc.materials[material];
+    GBsdf b;
+    b.ns = si.ns; b.ng = si.n; b.ss = normalize(si.dpdu_s); b.ts = cross(b.ns, b.ss);  // bsdf.rs:100-116
+    b.lobes = sc.lobes + m.lobe_base; b.n = m.n_lobes; b.eta = m.bsdf_eta;
+    return b;
+}
+PH_DEV f3 w2l(const GBsdf& b, f3 v) { return mk3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
+PH_DEV f3 l2w(const GBsdf& b, f3 v) {
+    return mk3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z, b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
+}
+
+// reflection/common.rs
+PH_DEV float g_cos2(f3 w) { return w.z * w.z; }
+PH_DEV float g_tan(f3 w) { return ph_div(sin_theta(w), w.z); }
+PH_DEV float g_tan2(f3 w) { return ph_div(sin2_theta(w), g_cos2(w)); }
+PH_DEV float g_cos2phi(f3 w) { const float c = cos_phi(w); return c * c; }
+PH_DEV float g_sin2phi(f3 w) { const float c = sin_phi(w); return c * c; }
+PH_DEV bool g_same_hemi(f3 a, f3 b) { return a.z * b.z > 0.0f; }
+PH_DEV f3 g_reflect(f3 wo, f3 n) { return -wo + 2.0f * dot(wo, n) * n; }
+PH_DEV bool g_refract(f3 wi, f3 n, float eta, f3& wt) {  // common.rs:103-118
+    const float cos_i = dot(n, wi);
+    const float sin2_i = pmaxf(0.0f, 1.0f - cos_i * cos_i);
+    const float sin2_t = eta * eta * sin2_i;
+    if (sin2_t >= 1.0f) return false;
+    const float cos_t = ph_sqrt(1.0f - sin2_t);
+    wt = eta * -wi + (eta * cos_i - cos_t) * n;
+    return true;
+}
+PH_DEV spec sp3(const float* v) { return mks(v[0], v[1], v[2]); }
+PH_DEV spec spec_div(spec a, spec b) { return mks(ph_div(a.r, b.r), ph_div(a.g, b.g), ph_div(a.b, b.b)); }  // rgb_spectrum.rs:316-327
+PH_DEV spec spec_sub(spec a, spec b) { return mks(a.r - b.r, a.g - b.g, a.b - b.b); }
+PH_DEV spec spec_sqrt(spec a) { return mks(ph_sqrt(a.r), ph_sqrt(a.g), ph_sqrt(a.b)); }
+
+// fresnel.rs:135-170
+PH_DEV float fr_dielectric(float cos_i, float eta_i, float eta_t) {
+    cos_i = pclampf(cos_i, -1.0f, 1.0f);
+    if (!(cos_i > 0.0f)) { const float t = eta_i; eta_i = eta_t; eta_t = t; cos_i = pabs(cos_i); }
+    const float sin_i = ph_sqrt(__builtin_fmaxf(0.0f, 1.0f - cos_i * cos_i));
+    const float sin_t = ph_div(eta_i, eta_t) * sin_i;
+    if (sin_t >= 1.0f) return 1.0f;
+    const float cos_t = ph_sqrt(__builtin_fmaxf(0.0f, 1.0f - sin_t * sin_t));
+    const float r_parl = ph_div((eta_t * cos_i) - (eta_i * cos_t), (eta_t * cos_i) + (eta_i * cos_t));
+    const float r_perp = ph_div((eta_i * cos_i) - (eta_t * cos_t), (eta_i * cos_i) + (eta_t * cos_t));
+    return ph_div(r_parl * r_parl + r_perp * r_perp, 2.0f);
+}
+// fresnel.rs:172-196 as written: `sin_theta_i_2 = 1.0 - cos_theta_i` (quirk B11); eta_i is Spectrum::ONE for every conductor made on
+// this path (metal.rs:84-88), and x / 1.0 == x
+PH_DEV spec fr_conductor(float cos_i, spec eta_t, spec k) {
+    cos_i = pclampf(cos_i, -1.0f, 1.0f);
+    const spec eta = eta_t, eta_k = k;
+    const float cos2_i = cos_i * cos_i, sin2_i = 1.0f - cos_i;
+    const spec eta_2 = eta * eta, eta_k_2 = eta_k * eta_k;
+    const spec t0 = spec_sub(spec_sub(eta_2, eta_k_2), mks1(sin2_i));
+    const spec a2_plus_b2 = spec_sqrt(t0 * t0 + 4.0f * eta_2 * eta_k_2);
+    const spec t1 = a2_plus_b2 + mks1(cos2_i);
+    const spec a = spec_sqrt(0.5f * (a2_plus_b2 + t0));
+    const spec t2 = (2.0f * cos_i) * a;
+    const spec rs = spec_div(spec_sub(t1, t2), t1 + t2);
+    const spec t3 = cos2_i * a2_plus_b2 + mks1(sin2_i * sin2_i);
+    const spec t4 = t2 * sin2_i;
+    const spec rp = spec_div(rs * spec_sub(t3, t4), t3 + t4);
+    return 0.5f * (rp + rs);
+}
+PH_DEV spec fresnel_eval(const LobeRec& l, float cos_i) {
+    if (l.fresnel == PH_FR_DIEL) return mks1(fr_dielectric(cos_i, l.eta_a, l.eta_b));
+    if (l.fresnel == PH_FR_COND) return fr_conductor(pabs(cos_i), sp3(l.c_eta_t), sp3(l.c_k));
+    return mks1(1.0f);
+}
+
+// microfacet/trowbridge_reitz.rs + microfacet/mod.rs (sample_visible_area = true)
+PH_DEV float tr_d(const LobeRec& l, f3 wh) {
+    const float t2 = g_tan2(wh);
+    if (__builtin_isinf(t2)) return 0.0f;
+    const float cos4 = g_cos2(wh) * g_cos2(wh);
+    const float e = (ph_div(g_cos2phi(wh), l.ax * l.ax) + ph_div(g_sin2phi(wh), l.ay * l.ay)) * t2;
+    return ph_div(1.0f, kPi * l.ax * l.ay * cos4 * (1.0f + e) * (1.0f + e));
+}
+PH_DEV float tr_lambda(const LobeRec& l, f3 w) {
+    const float att = pabs(g_tan(w));
+    if (__builtin_isinf(att)) return 0.0f;
+    const float alpha = ph_sqrt(g_cos2phi(w) * l.ax * l.ax + g_sin2phi(w) * l.ay * l.ay);
+    const float a2t2 = (alpha * att) * (alpha * att);
+    return ph_div(-1.0f + ph_sqrt(1.0f + a2t2), 2.0f);
+}
+PH_DEV float tr_g1(const LobeRec& l, f3 w) { return ph_div(1.0f, 1.0f + tr_lambda(l, w)); }
+PH_DEV float tr_g(const LobeRec& l, f3 wo, f3 wi) { return ph_div(1.0f, 1.0f + tr_lambda(l, wo) + tr_lambda(l, wi)); }
+PH_DEV float tr_pdf(const LobeRec& l, f3 wo, f3 wh) { return ph_div(tr_d(l, wh) * tr_g1(l, wo) * abs_dot(wo, wh), pabs(wo.z)); }
+PH_DEV void tr_sample_11(float cos_theta, float u1, float u2, float& slope_x, float& slope_y) {
+    if (cos_theta > 0.9999f) {
+        const float r = ph_sqrt(ph_div(u1, 1.0f - u1));
+        const float phi = kTwoPi * u2;
+        float sn, cs; d_sincos(phi, sn, cs);
+        slope_x = r * cs; slope_y = r * sn;
+        return;
+    }
+    const float sin_theta_ = ph_sqrt(pmaxf(0.0f, 1.0f - cos_theta * cos_theta));
+    const float tan_theta_ = ph_div(sin_theta_, cos_theta);
+    float a = ph_div(1.0f, tan_theta_);
+    const float g1 = ph_div(2.0f, 1.0f + ph_sqrt(1.0f + ph_div(1.0f, a * a)));
+    a = ph_div(2.0f * u1, g1) - 1.0f;
+    float tmp = ph_div(1.0f, a * a - 1.0f);
+    if (tmp > 1e10f) tmp = 1e10f;
+    const float b = tan_theta_;
+    const float d = ph_sqrt(pmaxf(b * b * tmp * tmp - (a * a - b * b) * tmp, 0.0f));
+    const float sx1 = b * tmp - d, sx2 = b * tmp + d;
+    slope_x = (a < 0.0f || sx2 > ph_div(1.0f, tan_theta_)) ? sx1 : sx2;
+    float sgn;
+    if (u2 > 0.5f) { sgn = 1.0f; u2 = 2.0f * (u2 - 0.5f); } else { sgn = -1.0f; u2 = 2.0f * (0.5f - u2); }
+    const float z = ph_div(u2 * (u2 * (u2 * 0.27385f - 0.73369f) + 0.46341f), u2 * (u2 * (u2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+    slope_y = sgn * z * ph_sqrt(1.0f + slope_x * slope_x);
+}
+PH_DEV f3 tr_sample_wh(const LobeRec& l, f3 wo, f2 u) {
+    const bool flip = wo.z < 0.0f;
+    const f3 wi = flip ? -wo : wo;
+    const f3 ws = normalize(mk3(l.ax * wi.x, l.ay * wi.y, wi.z));
+    float sx, sy;
+    tr_sample_11(ws.z, u.x, u.y, sx, sy);
+    const float tmp = cos_phi(ws) * sx - sin_phi(ws) * sy;
+    sy = sin_phi(ws) * sx + cos_phi(ws) * sy;
+    sx = tmp;
+    sx *= l.ax; sy *= l.ay;
+    const f3 wh = normalize(mk3(-sx, -sy, 1.0f));
+    return flip ? -wh : wh;
+}
+
+// ---- per-lobe f / pdf / sample_f ------------------------------------------------------------------------------------------------
+PH_DEV spec lobe_f(const LobeRec& l, f3 wo, f3 wi) {
+    switch (l.kind) {
+    case PH_LK_LAMBERT: return sp3(l.r) * kInvPi;  // lambertian_reflection.rs:38-40
+    case PH_LK_OREN: {  // oren_nayar.rs:46-72
+        const float sin_i = sin_theta(wi), sin_o = sin_theta(wo);
+        float max_cos = 0.0f;
+        if (sin_i > 1e-4f && sin_o > 1e-4f) {
+            const float d_cos = cos_phi(wi) * cos_phi(wo) + sin_phi(wi) * sin_phi(wo);
+            max_cos = pmaxf(0.0f, d_cos);
+        }
+        const float aco = pabs(wo.z), aci = pabs(wi.z);
+        float sin_alpha, tan_beta;
+        if (aci > aco) { sin_alpha = sin_o; tan_beta = ph_div(sin_i, aci); }
+        else { sin_alpha = sin_i; tan_beta = ph_div(sin_o, aco); }
+        return sp3(l.r) * kInvPi * (l.a + l.b * max_cos * sin_alpha * tan_beta);
+    }
+    case PH_LK_MICRO_R: {  // microfacet_reflection.rs:34-52
+        const float cos_o = pabs(wo.z), cos_i = pabs(wi.z);
+        f3 wh = wi + wo;
+        if ((cos_i == 0.0f || cos_o == 0.0f) || (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f)) return mks1(0.0f);
+        wh = normalize(wh);
+        const spec f = fresnel_eval(l, dot(wi, face_forward(wh, mk3(0.0f, 0.0f, 1.0f))));
+        return sp3(l.r) * tr_d(l, wh) * tr_g(l, wo, wi) * f / (4.0f * cos_i * cos_o);
+    }
+    case PH_LK_MICRO_T: {  // microfacet_transmission.rs:46-95
+        if (g_same_hemi(wo, wi)) return mks1(0.0f);
+        const float cos_o = wo.z, cos_i = wi.z;
+        if (cos_i == 0.0f || cos_o == 0.0f) return mks1(0.0f);
+        const float eta = wo.z > 0.0f ? ph_div(l.eta_b, l.eta_a) : ph_div(l.eta_a, l.eta_b);
+        f3 wh = normalize(wo + wi * eta);
+        if (wh.z < 0.0f) wh = -wh;
+        if (dot(wo, wh) * dot(wi, wh) > 0.0f) return mks1(0.0f);
+        const spec f = mks1(fr_dielectric(dot(wo, wh), l.eta_a, l.eta_b));
+        const float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+        const float factor = ph_div(1.0f, eta);
+        return spec_sub(mks1(1.0f), f) * sp3(l.t) *
+               pabs(ph_div(tr_d(l, wh) * tr_g(l, wo, wi) * eta * eta * abs_dot(wi, wh) * abs_dot(wo, wh) * factor * factor, cos_i * cos_o * sqrt_denom * sqrt_denom));
+    }
+    default: return mks1(0.0f);
+    }
+}
+PH_DEV float lobe_pdf(const LobeRec& l, f3 wo, f3 wi) {
+    switch (l.kind) {
+    case PH_LK_LAMBERT: case PH_LK_OREN: return g_same_hemi(wo, wi) ? pabs(wi.z) * kInvPi : 0.0f;  // reflection/mod.rs:160-166
+    case PH_LK_MICRO_R: {
+        if (!g_same_hemi(wo, wi)) return 0.0f;
+        const f3 wh = normalize(wo + wi);
+        return ph_div(tr_pdf(l, wo, wh), 4.0f * dot(wo, wh));
+    }
+    case PH_LK_MICRO_T: {
+        if (g_same_hemi(wo, wi)) return 0.0f;
+        const float eta = wo.z > 0.0f ? ph_div(l.eta_b, l.eta_a) : ph_div(l.eta_a, l.eta_b);
+        const f3 wh = normalize(wo + wi * eta);
+        if (dot(wo, wh) * dot(wi, wh) > 0.0f) return 0.0f;
+        const float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+        const float dwh_dwi = pabs(ph_div(eta * eta * dot(wi, wh), sqrt_denom * sqrt_denom));
+        return tr_pdf(l, wo, wh) * dwh_dwi;
+    }
+    default: return 0.0f;
+    }
+}
+// returns the sampled BxDFType; f / pdf / wi are zero where the reference returns BxDFSample::from(type)
+PH_DEV uint32_t lobe_sample_f(const LobeRec& l, f3 wo, f2 u, spec& f, float& pdf, f3& wi) {
+    f = mks1(0.0f); pdf = 0.0f; wi = mk3(0.0f, 0.0f, 0.0f);
+    switch (l.kind) {
+    case PH_LK_LAMBERT: case PH_LK_OREN: {  // reflection/mod.rs:132-141
+        wi = cosine_sample_hemisphere(u);
+        if (wo.z < 0.0f) wi.z *= -1.0f;
+        pdf = lobe_pdf(l, wo, wi); f = lobe_f(l, wo, wi);
+        return l.type;
+    }
+    case PH_LK_SPEC_R: {  // specular_reflection.rs:38-44
+        wi = mk3(-wo.x, -wo.y, wo.z); pdf = 1.0f;
+        f = fresnel_eval(l, wi.z) * sp3(l.r) / pabs(wi.z);
+        return l.type;
+    }
+    case PH_LK_SPEC_T: {  // specular_transmission.rs:45-64
+        const bool entering = wo.z > 0.0f;
+        const float eta_i = entering ? l.eta_a : l.eta_b, eta_t = entering ? l.eta_b : l.eta_a;
+        f3 wt;
+        if (!g_refract(wo, face_forward(mk3(0.0f, 0.0f, 1.0f), wo), ph_div(eta_i, eta_t), wt)) return l.type;
+        wi = wt; pdf = 1.0f;
+        spec ft = sp3(l.t) * spec_sub(mks1(1.0f), mks1(fr_dielectric(wi.z, l.eta_a, l.eta_b)));
+        ft = ft * ph_div(eta_i * eta_i, eta_t * eta_t);
+        f = ft / pabs(wi.z);
+        return l.type;
+    }
+    case PH_LK_FRESNEL_SPEC: {  // fresnel_specular.rs:42-79
+        const float fr = fr_dielectric(wo.z, l.eta_a, l.eta_b);
+        if (u.x < fr) {
+            wi = mk3(-wo.x, -wo.y, wo.z); pdf = fr;
+            f = fr * sp3(l.r) / pabs(wi.z);
+            return BX_SPEC | BX_REFL;
+        }
+        const bool entering = wo.z > 0.0f;
+        const float eta_i = entering ? l.eta_a : l.eta_b, eta_t = entering ? l.eta_b : l.eta_a;
+        f3 wt;
+        if (!g_refract(wo, face_forward(mk3(0.0f, 0.0f, 1.0f), wo), ph_div(eta_i, eta_t), wt)) return BX_SPEC | BX_TRANS;
+        wi = wt;
+        spec ft = sp3(l.t) * (1.0f - fr);
+        ft = ft * ph_div(eta_i * eta_i, eta_t * eta_t);
+        pdf = 1.0f - fr;
+        f = ft / pabs(wi.z);
+        return BX_SPEC | BX_TRANS;
+    }
+    case PH_LK_MICRO_R: {  // microfacet_reflection.rs:54-76
+        if (wo.z == 0.0f) return l.type;
+        const f3 wh = tr_sample_wh(l, wo, u);
+        if (dot(wo, wh) < 0.0f) return l.type;
+        wi = g_reflect(wo, wh);
+        if (!g_same_hemi(wo, wi)) return l.type;
+        pdf = ph_div(tr_pdf(l, wo, wh), 4.0f * dot(wo, wh));
+        f = lobe_f(l, wo, wi);
+        return l.type;
+    }
+    case PH_LK_MICRO_T: {  // microfacet_transmission.rs:97-120
+        if (wo.z == 0.0f) return l.type;
+        const f3 wh = tr_sample_wh(l, wo, u);
+        if (dot(wo, wh) < 0.0f) return l.type;
+        const float eta = wo.z > 0.0f ? ph_div(l.eta_a, l.eta_b) : ph_div(l.eta_b, l.eta_a);
+        f3 wt;
+        if (!g_refract(wo, wh, eta, wt)) return l.type;
+        wi = wt;
+        pdf = lobe_pdf(l, wo, wi); f = lobe_f(l, wo, wi);
+        return l.type;
+    }
+    default: return l.type;
+    }
+}
+
+PH_DEV bool lobe_matches(const LobeRec& l, uint32_t flags) { return (l.type & flags) == l.type; }
+PH_DEV uint32_t bsdf_num_components(const GBsdf& b, uint32_t flags) {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < b.n; i++) if (lobe_matches(b.lobes[i], flags)) c++;
+    return c;
+}
+PH_DEV spec bsdf_f(const GBsdf& b, f3 wo_w, f3 wi_w, uint32_t flags) {  // bsdf.rs:133-158
+    const f3 wi = w2l(b, wi_w), wo = w2l(b, wo_w);
+    if (wo.z == 0.0f) return mks1(0.0f);
+    const bool reflect = dot(wi_w, b.ng) * dot(wo_w, b.ng) > 0.0f;
+    spec f = mks1(0.0f);
+    for (uint32_t i = 0; i < b.n; i++) {
+        const LobeRec& l = b.lobes[i];
+        if (lobe_matches(l, flags) && ((reflect && (l.type & BX_REFL)) || (!reflect && (l.type & BX_TRANS)))) f = f + lobe_f(l, wo, wi);
+    }
+    return f;
+}
+PH_DEV float bsdf_pdf(const GBsdf& b, f3 wo_w, f3 wi_w, uint32_t flags) {  // bsdf.rs:331-356
+    if (b.n == 0) return 0.0f;
+    const f3 wo = w2l(b, wo_w), wi = w2l(b, wi_w);
+    if (wo.z == 0.0f) return 0.0f;
+    uint32_t matching = 0; float pdf = 0.0f;
+    for (uint32_t i = 0; i < b.n; i++) if (lobe_matches(b.lobes[i], flags)) { matching++; pdf += lobe_pdf(b.lobes[i], wo, wi); }
+    return matching > 0 ? ph_div(pdf, (float)matching) : 0.0f;
+}
+// BSDF::sample_f (bsdf.rs:160-292); a failed sample is BxDFSample::default(): zeros and type NONE
+PH_DEV void bsdf_sample_f(const GBsdf& b, f3 wo_w, f2 u, uint32_t flags, spec& f_out, float& pdf_out, f3& wi_out, uint32_t& type_out) {
+    f_out = mks1(0.0f); pdf_out = 0.0f; wi_out = mk3(0.0f, 0.0f, 0.0f); type_out = 0u;
+    const uint32_t matching = bsdf_num_components(b, flags);
+    if (matching == 0u) return;
+    uint32_t comp = f2u_sat(floorf(u.x * (float)matching));
+    if (comp > matching - 1u) comp = matching - 1u;
+    uint32_t idx = 0, count = comp;
+    for (uint32_t i = 0; i < b.n; i++) if (lobe_matches(b.lobes[i], flags)) { if (count == 0u) { idx = i; break; } count--; }
+    const f2 ur = mk2(pminf(u.x * (float)matching - (float)comp, kOneMinusEps), u.y);
+    const f3 wo = w2l(b, wo_w);
+    if (wo.z == 0.0f) return;
+    spec f; float pdf; f3 wi;
+    const uint32_t st = lobe_sample_f(b.lobes[idx], wo, ur, f, pdf, wi);
+    if (pdf == 0.0f) return;
+    const f3 wi_w = l2w(b, wi);
+    if (!(st & BX_SPEC) && matching > 1u)
+        for (uint32_t i = 0; i < b.n; i++) if (i != idx && lobe_matches(b.lobes[i], flags)) pdf += lobe_pdf(b.lobes[i], wo, wi);
+    if (matching > 1u) pdf = ph_div(pdf, (float)matching);
+    if (!(st & BX_SPEC)) {
+        const bool reflect = dot(wi_w, b.ng) * dot(wo_w, b.ng) > 0.0f;
+        f = mks1(0.0f);
+        for (uint32_t i = 0; i < b.n; i++) {
+            const LobeRec& l = b.lobes[i];
+            if (lobe_matches(l, flags) && ((reflect && (l.type & BX_REFL)) || (!reflect && (l.type & BX_TRANS)))) f = f + lobe_f(l, wo, wi);
+        }
+    }
+    f_out = f; pdf_out = pdf; wi_out = wi_w; type_out = st;
+}
+
+}  // namespace ph

@@ -24,6 +24,8 @@ struct PbrtHipScene {
     std::vector<uint32_t> idx, tri_mesh, tri_flags;
     std::vector<MeshRec> meshes;
     std::vector<MaterialRec> materials;
+    std::vector<LobeRec> lobes;
+    bool general_materials = false;  // some material is not matte: the renderer uses the general BSDF kernel
     std::vector<LightRec> lights;
     std::vector<uint32_t> infinite_lights;
     // object instancing (api/src/lib.rs:911-1000): an object is a contiguous triangle range; top_items is the scene's primitive

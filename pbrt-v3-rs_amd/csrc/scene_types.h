@@ -56,12 +56,28 @@ struct MeshRec {
 #define PH_MESH_REV 8u
 #define PH_MESH_SWAP 16u
 
-struct MaterialRec {  // MatteMaterial with constant textures (materials/src/matte.rs)
+// One BxDF of a material's BSDF (core/src/reflection/*.rs).  Constant textures make the list a property of the material, so the
+// host builds it (api.hip) and the device walks it (bsdf_general.h).
+enum { PH_LK_LAMBERT = 0, PH_LK_OREN = 1, PH_LK_SPEC_R = 2, PH_LK_SPEC_T = 3, PH_LK_FRESNEL_SPEC = 4, PH_LK_MICRO_R = 5, PH_LK_MICRO_T = 6 };
+enum { PH_FR_NOOP = 0, PH_FR_DIEL = 1, PH_FR_COND = 2 };
+struct alignas(16) LobeRec {
+    uint32_t kind, type, fresnel, pad0;   // type = BxDFType bits (bsdf.rs:10-20)
+    float a, b;                           // Oren-Nayar A, B
+    float ax, ay;                         // Trowbridge-Reitz alpha_x, alpha_y (already max(0.001, .))
+    float eta_a, eta_b, pad1[2];          // dielectric Fresnel (eta_i, eta_t) / transmission lobes (etaA, etaB)
+    float r[3], pad2;
+    float t[3], pad3;
+    float c_eta_t[3], pad4;               // conductor Fresnel: eta_t and k (eta_i is ONE, metal.rs:84-88)
+    float c_k[3], pad5;
+};
+
+struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant textures) + the general lobe list
     float kd[3];      // already clamp_default()'ed
     float sigma;      // already clamped to [0,90]; 0 -> LambertianReflection
     float a, b;       // OrenNayar A, B (core/src/reflection/oren_nayar.rs:28-39)
     uint32_t has_bxdf; // !kd.is_black()
-    uint32_t pad;
+    uint32_t lobe_base, n_lobes;  // DeviceScene::lobes[lobe_base .. lobe_base + n_lobes)
+    float bsdf_eta;    // BSDF::eta (bsdf.rs:101): 1 unless the material passes one (uber.rs:131-138)
 };
 
 enum { PH_L_INFINITE = 0, PH_L_DISTANT = 1, PH_L_POINT = 2, PH_L_AREA = 3 };
@@ -126,6 +142,7 @@ struct DeviceScene {
     const uint32_t* tri_flags; // PH_TRI_BOGUS/ALPHA0/SALPHA0 per triangle (add_mesh order)
     const MeshRec* meshes;
     const MaterialRec* materials;
+    const LobeRec* lobes;
     const LightRec* lights;
     uint32_t n_lights;
     const uint32_t* infinite_lights;

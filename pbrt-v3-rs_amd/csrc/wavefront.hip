@@ -19,12 +19,13 @@
 #include "pt_device.h"
 #include "scene_host.h"
 #include "spatial.h"
+#include "bsdf_general.h"
 #include <algorithm>
 #include <cstdlib>
 
 namespace ph {
 
-enum : uint32_t { F_EXT = 1u, F_PSH = 2u, F_PMIS = 4u };
+enum : uint32_t { F_EXT = 1u, F_PSH = 2u, F_PMIS = 4u, F_SPEC = 8u };  // F_SPEC: the previous bounce sampled a specular lobe (path.rs:190)
 
 struct IterCounters {  // one per wavefront iteration, zeroed at chunk start
     uint32_t n_cl, n_sh, n_live, head_cl, head_sh, pad[3];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
             w.rec_L[gsi] = make_float4(0.0f, 0.0f, 0.0f, p_film.x);
             w.rec_py[gsi] = p_film.y;
             w.s_L[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            w.s_beta[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            w.s_beta[pid] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // beta, eta_scale
         } else {
             w.rec_L[gsi] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0x7fc00000u));  // NaN p_film.x marks "no sample"
             w.rec_py[gsi] = 0.0f;
@@ -166,8 +167,34 @@ __global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfPar
 // register file during the long vertex computation), then one thread per queue claims the block's slots with a single
 // atomic and every thread copies its rays to consecutive slots.  Per-wave atomics on the three queue counters were the
 // limiter of the first version (≈3 M returning atomics per frame on three addresses; one address sustains ≈88 per µs).
+// BSDF front ends of the two shade_kernel instantiations: GEN = false keeps the one-lobe matte code (pt_device.h) for scenes made
+// of MatteMaterial only — the headline workload —, GEN = true walks the general lobe list (bsdf_general.h).
+template <bool GEN> struct BsdfOps;
+template <> struct BsdfOps<false> {
+    using T = Bsdf;
+    static PH_DEV T make(const DeviceScene& sc, const SurfHit& si, uint32_t mat) { return make_bsdf(sc, si, mat); }
+    static PH_DEV bool has_non_specular(const T& b) { return b.has_bxdf; }
+    static PH_DEV spec f_ns(const T& b, f3 wo, f3 wi) { return bsdf_f(b, wo, wi); }
+    static PH_DEV float pdf_ns(const T& b, f3 wo, f3 wi) { return bsdf_pdf(b, wo, wi); }
+    static PH_DEV void sample_ns(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi) { bsdf_sample_f(b, wo, u, f, pdf, wi); }
+    static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, f, pdf, wi); type = BX_REFL | BX_DIFF; }
+    static PH_DEV float eta(const T&) { return 1.0f; }
+};
+template <> struct BsdfOps<true> {
+    using T = GBsdf;
+    static PH_DEV T make(const DeviceScene& sc, const SurfHit& si, uint32_t mat) { return make_gbsdf(sc, si, mat); }
+    static PH_DEV bool has_non_specular(const T& b) { return bsdf_num_components(b, BX_ALL & ~BX_SPEC) > 0u; }
+    static PH_DEV spec f_ns(const T& b, f3 wo, f3 wi) { return bsdf_f(b, wo, wi, BX_ALL & ~BX_SPEC); }   // estimate_direct: specular = false (common.rs:157-161)
+    static PH_DEV float pdf_ns(const T& b, f3 wo, f3 wi) { return bsdf_pdf(b, wo, wi, BX_ALL & ~BX_SPEC); }
+    static PH_DEV void sample_ns(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi) { uint32_t t; bsdf_sample_f(b, wo, u, BX_ALL & ~BX_SPEC, f, pdf, wi, t); }
+    static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, BX_ALL, f, pdf, wi, type); }
+    static PH_DEV float eta(const T& b) { return b.eta; }
+};
+
 #define PH_SHADE_BLOCK 256
+template <bool GEN>
 __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, WfParams w, int it) {
+    using BO = BsdfOps<GEN>;
     __shared__ float4 stage[3][2][PH_SHADE_BLOCK];           // [ext, mis, shadow][ray halves][thread]
     __shared__ uint32_t wave_cnt[3][PH_SHADE_BLOCK / 64];   // [cl, sh, live][wave]
     __shared__ uint32_t q_base[3];
@@ -195,7 +222,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
         const bool active = i < n_live;
         uint32_t pid = 0, flags = 0, bounces = 0, dim = 0;
         spec L = mks1(0.0f), beta = mks1(1.0f);
-        float pick_pdf = 0.0f;
+        float pick_pdf = 0.0f, eta_scale = 1.0f;
         bool want_ext = false, want_mis = false, want_sh = false;
 
         if (active) {
@@ -204,6 +231,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
             flags = idx4.w & 0xffu; bounces = (idx4.w >> 8) & 0xffu; dim = idx4.w >> 16;
             const float4 L4 = w.s_L[pid], b4 = w.s_beta[pid];
             L = mks(L4.x, L4.y, L4.z); beta = mks(b4.x, b4.y, b4.z);
+            if (GEN) eta_scale = b4.w;
 
             // ---- K6: finish uniform_sample_one_light of the previous vertex (integrator/common.rs:196-221, 276-295, 132) --------
             if (flags & (F_PSH | F_PMIS)) {
@@ -247,19 +275,20 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                 const uint32_t hprim = __float_as_uint(h0.y);
                 const bool found = hprim != 0xFFFFFFFFu;
                 const f3 rd = mk3(ray.dx, ray.dy, ray.dz);
+                const bool emit = bounces == 0 || (GEN && (flags & F_SPEC));  // `bounces == 0 || specular_bounce` (path.rs:116)
                 if (!found) {
-                    if (bounces == 0)  // `|| specular_bounce`: no specular lobes among matte materials
+                    if (emit)
                         for (uint32_t k = 0; k < sc.n_infinite; k++) L = L + beta * light_le(sc.lights[sc.infinite_lights[k]], rd);
                 } else {
                     const float4 h1 = hp[1];
                     MeshRec m;
                     const SurfHit si = make_surface_hit_any(sc, rd, ray.time, __float_as_uint(h1.y), __float_as_uint(h1.z), h0.z, h0.w, h1.x, m);
-                    if (bounces == 0) {
+                    if (emit) {
                         if (m.first_light >= 0) L = L + beta * area_L(sc.lights[(uint32_t)m.first_light + (hprim - m.tri_base)], si.n, -rd);
                         else L = L + beta * mks1(0.0f);
                     }
                     if ((int)bounces < w.max_depth) {
-                        const Bsdf bsdf = make_bsdf(sc, si, m.material);
+                        const typename BO::T bsdf = BO::make(sc, si, m.material);
                         const uint32_t ppix = pid / w.chunk_spp;
                         const int2 xy = w.px_xy[ppix];
                         SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid - ppix * w.chunk_spp), dim, hl);
@@ -270,7 +299,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
 #pragma unroll 1
                         for (uint32_t k = 0; k < 8; k++) s_u[k][tid] = sampler_dim(sc, w.sp, cur, dim + k);
                         uint32_t c = 0;  // dimensions consumed so far at this vertex
-                        if (bsdf.has_bxdf) {  // num_components(all & !SPECULAR) > 0 (path.rs:161-172)
+                        if (BO::has_non_specular(bsdf)) {  // num_components(all & !SPECULAR) > 0 (path.rs:161-172)
                             n_paths_total++;
                             // uniform_sample_one_light (integrator/common.rs:89-133)
                             if (sc.n_lights > 0) {
@@ -297,8 +326,8 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                                     {
                                         const LiSample ls = light_sample_li(sc, light, si, u_light);
                                         if (ls.valid && ls.pdf > 0.0f && !is_black(ls.value)) {
-                                            const spec f = bsdf_f(bsdf, si.wo, ls.wi) * abs_dot(ls.wi, si.ns);
-                                            const float scattering_pdf = bsdf_pdf(bsdf, si.wo, ls.wi);
+                                            const spec f = BO::f_ns(bsdf, si.wo, ls.wi) * abs_dot(ls.wi, si.ns);
+                                            const float scattering_pdf = BO::pdf_ns(bsdf, si.wo, ls.wi);
                                             if (!is_black(f)) {
                                                 const RayIn rs = spawn_ray_to_hit(si, ls.vp, ls.vperr, ls.vn);  // VisibilityTester::unoccluded
                                                 stage[2][0][tid] = make_float4(rs.ox, rs.oy, rs.oz, rs.t_max);
@@ -312,7 +341,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                                     }
                                     if (!is_delta) {
                                         spec f1; float spdf; f3 wi2;
-                                        bsdf_sample_f(bsdf, si.wo, u_scatter, f1, spdf, wi2);
+                                        BO::sample_ns(bsdf, si.wo, u_scatter, f1, spdf, wi2);  // never specular with these flags: sampled_specular = false
                                         const spec f = f1 * abs_dot(wi2, si.ns);
                                         if (!is_black(f) && spdf > 0.0f) {
                                             const float lp = light_pdf_li(sc, light, si, wi2);
@@ -338,13 +367,21 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                         }
                         // sample the BSDF for the next direction (path.rs:174-206)
                         const f2 u = mk2(s_u[c][tid], s_u[c + 1][tid]); c += 2;
-                        spec f; float pdf; f3 wi;
-                        bsdf_sample_f(bsdf, -rd, u, f, pdf, wi);
+                        spec f; float pdf; f3 wi; uint32_t stype;
+                        BO::sample_all(bsdf, -rd, u, f, pdf, wi, stype);
+                        flags &= ~F_SPEC;
                         if (!(is_black(f) || pdf == 0.0f)) {
                             beta = beta * (f * abs_dot(wi, si.ns) / pdf);
+                            if (GEN) {
+                                if (stype & BX_SPEC) flags |= F_SPEC;  // specular_bounce (path.rs:190)
+                                if ((stype & BX_SPEC) && (stype & BX_TRANS)) {  // radiance scaling across a refraction (path.rs:192-203)
+                                    const float eta = BO::eta(bsdf);
+                                    eta_scale *= dot(-rd, si.n) > 0.0f ? eta * eta : ph_div(1.0f, eta * eta);
+                                }
+                            }
                             const RayIn re = spawn_ray(si, wi);
                             bool cont = true;
-                            const spec rr_beta = beta * 1.0f;  // eta_scale stays 1 without specular transmission
+                            const spec rr_beta = beta * eta_scale;  // eta_scale stays 1 without specular transmission
                             if (max_component_value(rr_beta) < w.rr_threshold && bounces > 3) {  // path.rs:264-276
                                 const float q = pmaxf(0.05f, 1.0f - max_component_value(rr_beta));
                                 const float rr = s_u[c][tid]; c += 1;
@@ -406,7 +443,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                 live_out[lv_slot] = pid;
                 w.s_idx[pid] = make_uint4(ext_slot, mis_slot, sh_slot, flags | (bounces << 8) | (dim << 16));
                 w.s_L[pid] = make_float4(L.r, L.g, L.b, pick_pdf);
-                w.s_beta[pid] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                w.s_beta[pid] = make_float4(beta.r, beta.g, beta.b, eta_scale);
             } else {
                 // path finished: radiance sanitising of render_tile (sampler_integrator.rs:373-397)
                 if (has_nans(L)) L = mks1(0.0f);
@@ -795,7 +832,10 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
                         hipLaunchKernelGGL(ph::spatial_compute_kernel, dim3(1024), dim3(PH_SPATIAL_BLOCK), 0, s->stream, s->ds, wp.spatial);
                     }))) return rc;
             }
-            if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::shade_kernel, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it); }))) return rc;
+            if ((rc = timed(2, [&]() {
+                    if (s->general_materials) hipLaunchKernelGGL(ph::shade_kernel<true>, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                    else hipLaunchKernelGGL(ph::shade_kernel<false>, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                }))) return rc;
         }
         PH_CHECK(s, hipMemcpyAsync(hctr.data(), w.d_ctr.p, (size_t)(n_iter + 2) * sizeof(ph::IterCounters), hipMemcpyDeviceToHost, s->stream));
         PH_CHECK(s, hipStreamSynchronize(s->stream));

@@ -259,7 +259,6 @@ void Api::pbrt_area_light_source(const std::string& name, const ParamSet& p) { i
 // MatteMaterial From<&TextureParams> (materials/src/matte.rs:95-110) with TextureParams's lookup order: shape parameters
 // first, then the material's own (core/src/paramset/texture_params.rs).
 uint32_t Api::material_id_for(const MaterialDesc& m) {
-    char key[160];
     std::array<float, 3> kd = {0.5f, 0.5f, 0.5f};
     float sigma = 0.0f;
     auto spectrum_tex = [&](const std::string& pname, std::array<float, 3> d) {
@@ -286,15 +285,58 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
         }
         return m.params.find_one_float(pname, d);
     };
-    kd = spectrum_tex("Kd", kd);
-    sigma = float_tex("sigma", sigma);
-    if (!m.params.find_one_texture("bumpmap").empty() && error.empty()) error = "matte 'bumpmap' is outside the hot-path scope";
-    uint32_t kb[4]; std::memcpy(kb, kd.data(), 12); std::memcpy(&kb[3], &sigma, 4);
-    std::snprintf(key, sizeof key, "matte:%08x:%08x:%08x:%08x", kb[0], kb[1], kb[2], kb[3]);
+    if (!m.params.find_one_texture("bumpmap").empty() && error.empty()) error = "'bumpmap' is outside the hot-path scope";
+    const bool remap = m.params.find_one_bool("remaproughness", true);
+    // every float that defines the material, in order, is the cache key
+    std::vector<float> kv;
+    auto put3 = [&](const std::array<float, 3>& a) { kv.insert(kv.end(), a.begin(), a.end()); };
+    const std::array<float, 3> zero = {0.0f, 0.0f, 0.0f}, one = {1.0f, 1.0f, 1.0f}, quarter = {0.25f, 0.25f, 0.25f};
+    std::array<float, 3> a3 = zero, b3 = zero, c3 = zero, d3 = zero, e3 = zero;
+    float f0 = 0, f1 = 0, f2 = 0;
+    const std::string& t = m.type;
+    auto eta_of = [&]() {  // `eta`, else `index`, else 1.5 (glass.rs:124-127, uber.rs:201-204)
+        if (m.params.floats.count("eta") || !m.params.find_one_texture("eta").empty()) return float_tex("eta", 1.5f);
+        return float_tex("index", 1.5f);
+    };
+    auto uv_rough = [&](float dflt, float& u, float& v) {  // `uroughness` / `vroughness` fall back to `roughness` (metal.rs:69-76, uber.rs:148-155)
+        const float r = float_tex("roughness", dflt);
+        const bool hu = m.params.floats.count("uroughness") || !m.params.find_one_texture("uroughness").empty();
+        const bool hv = m.params.floats.count("vroughness") || !m.params.find_one_texture("vroughness").empty();
+        u = hu ? float_tex("uroughness", r) : r; v = hv ? float_tex("vroughness", r) : r;
+    };
+    if (t == "matte") { a3 = spectrum_tex("Kd", kd); f0 = float_tex("sigma", sigma); put3(a3); kv.push_back(f0); }
+    else if (t == "mirror") { a3 = spectrum_tex("Kr", {0.9f, 0.9f, 0.9f}); put3(a3); }
+    else if (t == "plastic") { a3 = spectrum_tex("Kd", quarter); b3 = spectrum_tex("Ks", quarter); f0 = float_tex("roughness", 0.1f); put3(a3); put3(b3); kv.push_back(f0); }
+    else if (t == "glass") {
+        a3 = spectrum_tex("Kr", one); b3 = spectrum_tex("Kt", one); f0 = float_tex("uroughness", 0.0f); f1 = float_tex("vroughness", 0.0f); f2 = eta_of();
+        put3(a3); put3(b3); kv.push_back(f0); kv.push_back(f1); kv.push_back(f2);
+    } else if (t == "metal") {
+        if (!(m.params.floats.count("eta") && m.params.floats.count("k")) && error.empty())
+            error = "Material \"metal\": give 'rgb eta' and 'rgb k' (the reference's copper default and named spectra need its spectral tables, which this host does not carry)";
+        a3 = m.params.find_one_rgb("eta", one); b3 = m.params.find_one_rgb("k", one); uv_rough(0.01f, f0, f1);
+        put3(a3); put3(b3); kv.push_back(f0); kv.push_back(f1);
+    } else if (t == "uber") {
+        a3 = spectrum_tex("Kd", quarter); b3 = spectrum_tex("Ks", quarter); c3 = spectrum_tex("Kr", zero); d3 = spectrum_tex("Kt", zero); e3 = spectrum_tex("opacity", one);
+        uv_rough(0.1f, f0, f1); f2 = eta_of();
+        put3(a3); put3(b3); put3(c3); put3(d3); put3(e3); kv.push_back(f0); kv.push_back(f1); kv.push_back(f2);
+    } else {
+        if (error.empty()) error = "Material \"" + t + "\" is outside the hot-path scope (supported: matte, mirror, plastic, glass, metal, uber)";
+        return 0;
+    }
+    if (!error.empty()) return 0;
+    std::string key = t + (remap ? ":r" : ":n");
+    for (float v : kv) { uint32_t u; std::memcpy(&u, &v, 4); char b[12]; std::snprintf(b, sizeof b, ":%08x", u); key += b; }
     auto it = material_cache_.find(key);
     if (it != material_cache_.end()) return it->second;
     uint32_t id = 0;
-    if (!check(ABI(pbrt_hip_add_material_matte(scene_, kd.data(), sigma, &id)), "add_material_matte")) return 0;
+    int rc;
+    if (t == "matte") rc = ABI(pbrt_hip_add_material_matte(scene_, a3.data(), f0, &id));
+    else if (t == "mirror") rc = ABI(pbrt_hip_add_material_mirror(scene_, a3.data(), &id));
+    else if (t == "plastic") rc = ABI(pbrt_hip_add_material_plastic(scene_, a3.data(), b3.data(), f0, remap ? 1 : 0, &id));
+    else if (t == "glass") rc = ABI(pbrt_hip_add_material_glass(scene_, a3.data(), b3.data(), f0, f1, f2, remap ? 1 : 0, &id));
+    else if (t == "metal") rc = ABI(pbrt_hip_add_material_metal(scene_, a3.data(), b3.data(), f0, f1, remap ? 1 : 0, &id));
+    else rc = ABI(pbrt_hip_add_material_uber(scene_, a3.data(), b3.data(), c3.data(), d3.data(), e3.data(), f0, f1, f2, remap ? 1 : 0, &id));
+    if (!check(rc, "add_material")) return 0;
     material_cache_[key] = id;
     return id;
 }
@@ -354,15 +396,15 @@ void Api::pbrt_shape(const std::string& name, const ParamSet& p, const std::stri
     const float alpha = alpha_of("alpha"), shadow_alpha = alpha_of("shadowalpha");
     if (!error.empty()) return;
 
-    // material: shape parameters override the material's (graphics_state.rs:147-165)
-    if (gs_.material.type != "matte") {
-        error = "Material \"" + gs_.material.type + "\" is outside the hot-path scope (supported: matte)";
-        return;
-    }
+    // material: shape parameters override the material's (TextureParams looks in the shape's set first, graphics_state.rs:147-165)
     MaterialDesc eff = gs_.material;
-    for (auto& kv : p.floats) if (kv.first == "Kd" || kv.first == "sigma") eff.params.floats[kv.first] = kv.second;
-    for (auto& kv : p.textures) if (kv.first == "Kd" || kv.first == "sigma" || kv.first == "bumpmap") eff.params.textures[kv.first] = kv.second;
-    for (auto& kv : p.textures) if (kv.first == "Kd" || kv.first == "sigma") eff.params.floats.erase(kv.first);
+    static const char* kMatParams[] = {"Kd", "Ks", "Kr", "Kt", "sigma", "roughness", "uroughness", "vroughness", "eta", "index", "k", "opacity", "bumpmap"};
+    for (const char* name : kMatParams) {
+        auto f = p.floats.find(name); auto tx = p.textures.find(name);
+        if (tx != p.textures.end()) { eff.params.textures[name] = tx->second; eff.params.floats.erase(name); }
+        else if (f != p.floats.end()) { eff.params.floats[name] = f->second; eff.params.textures.erase(name); }
+    }
+    { auto b = p.bools.find("remaproughness"); if (b != p.bools.end()) eff.params.bools["remaproughness"] = b->second; }
     const uint32_t mat = material_id_for(eff);
     if (!error.empty()) return;
 

@@ -100,6 +100,11 @@ class Binding:
             "tile_buffer_floats": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
             "render_path_tiles_device": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, ip, C.c_int, C.c_int, C.c_int, vp, C.POINTER(Stats)]),
             "merge_tiles_device": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp), fp, fp]),
+            "add_material_mirror": (C.c_int, [vp, fp, u32p]),
+            "add_material_plastic": (C.c_int, [vp, fp, fp, C.c_float, C.c_int, u32p]),
+            "add_material_glass": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, u32p]),
+            "add_material_metal": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_int, u32p]),
+            "add_material_uber": (C.c_int, [vp, fp, fp, fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, u32p]),
             "object_begin": (C.c_int, [vp, u32p]),
             "object_end": (C.c_int, [vp]),
             "add_instance": (C.c_int, [vp, C.c_uint32, fp, fp]),
@@ -291,6 +296,32 @@ class Scene:
         self._chk(self.b.fn("add_material_matte")(self.h, _ptr(_f32(kd), C.c_float), C.c_float(sigma), C.byref(out)))
         return out.value
 
+    def _mat(self, name, *args):
+        mid = C.c_uint32()
+        self._chk(self.b.fn(name)(self.h, *args, C.byref(mid)))
+        return mid.value
+
+    @staticmethod
+    def _rgb(v):
+        return _ptr(_f32(v), C.c_float)
+
+    def add_material_mirror(self, kr=(0.9, 0.9, 0.9)) -> int:
+        return self._mat("add_material_mirror", self._rgb(kr))
+
+    def add_material_plastic(self, kd=(0.25, 0.25, 0.25), ks=(0.25, 0.25, 0.25), roughness=0.1, remap_roughness=True) -> int:
+        return self._mat("add_material_plastic", self._rgb(kd), self._rgb(ks), C.c_float(roughness), int(remap_roughness))
+
+    def add_material_glass(self, kr=(1, 1, 1), kt=(1, 1, 1), uroughness=0.0, vroughness=0.0, eta=1.5, remap_roughness=True) -> int:
+        return self._mat("add_material_glass", self._rgb(kr), self._rgb(kt), C.c_float(uroughness), C.c_float(vroughness), C.c_float(eta), int(remap_roughness))
+
+    def add_material_metal(self, eta, k, uroughness=0.01, vroughness=0.01, remap_roughness=True) -> int:
+        return self._mat("add_material_metal", self._rgb(eta), self._rgb(k), C.c_float(uroughness), C.c_float(vroughness), int(remap_roughness))
+
+    def add_material_uber(self, kd=(0.25, 0.25, 0.25), ks=(0.25, 0.25, 0.25), kr=(0, 0, 0), kt=(0, 0, 0), opacity=(1, 1, 1), uroughness=0.1, vroughness=0.1,
+                          eta=1.5, remap_roughness=True) -> int:
+        return self._mat("add_material_uber", self._rgb(kd), self._rgb(ks), self._rgb(kr), self._rgb(kt), self._rgb(opacity), C.c_float(uroughness),
+                         C.c_float(vroughness), C.c_float(eta), int(remap_roughness))
+
     def add_mesh(self, P, indices, material, N=None, S=None, UV=None, first_area_light=-1, reverse_orientation=False,
                  swaps_handedness=False, alpha=1.0, shadow_alpha=1.0):
         P = _f32(P, (-1, 3)); idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
@@ -443,6 +474,7 @@ class SceneSpec:
     kd: tuple = (0.5, 0.5, 0.5)
     sigma: float = 0.0
     env_L: tuple = (1.0, 1.0, 1.0)
+    material: str = "matte"   # matte | plastic | glass | metal | uber: the material of every triangle (headline workload: matte)
     eye: tuple = (0.0, -4.0, 0.0)
     look: tuple = (0.0, 0.0, 0.0)
     up: tuple = (0.0, 0.0, 1.0)
@@ -453,7 +485,18 @@ def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None, insta
     instances = K > 0: the triangles form ONE object placed K times (ObjectInstance) on a jittered lattice inside the unit
     cube, each copy scaled by K^(-1/3) and rotated — K x n_tris instanced triangles behind a two-level BVH."""
     P, idx = geometry if geometry is not None else host.gen_random_tris(spec.n_tris, spec.seed)
-    mat = scene.add_material_matte(spec.kd, spec.sigma)
+    if spec.material == "matte":
+        mat = scene.add_material_matte(spec.kd, spec.sigma)
+    elif spec.material == "plastic":
+        mat = scene.add_material_plastic(spec.kd, (0.25, 0.25, 0.25), 0.1, True)
+    elif spec.material == "glass":
+        mat = scene.add_material_glass((1, 1, 1), (1, 1, 1), 0.0, 0.0, 1.5, True)
+    elif spec.material == "metal":
+        mat = scene.add_material_metal((0.2, 0.92, 1.1), (3.9, 2.45, 2.14), 0.05, 0.05, True)
+    elif spec.material == "uber":
+        mat = scene.add_material_uber(spec.kd, (0.25, 0.25, 0.25), (0.1, 0.1, 0.1), (0.1, 0.1, 0.1), (0.9, 0.9, 0.9), 0.1, 0.1, 1.5, True)
+    else:
+        raise ValueError(spec.material)
     if spec.env_L is not None:
         scene.add_light_infinite(spec.env_L)
     if instances > 0:

@@ -57,6 +57,8 @@ def oracle_binding():
         L.oracle_halton_perm.argtypes = [C.c_int, vp]
         L.oracle_geom_op.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.oracle_set_libm_mode.argtypes = [C.c_int]
+        fp = C.POINTER(C.c_float)
+        L.oracle_bsdf_probe.argtypes = [vp, C.c_uint32, C.c_int, fp, fp, fp, C.c_int, fp]
         L.oracle_spatial_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.oracle_spatial_voxel.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _binding = b
@@ -93,6 +95,13 @@ class OracleScene(pbrt_hip.Scene):
                                                   tile_part, tile_parts, xyz.ctypes.data_as(C.POINTER(C.c_float)), wt.ctypes.data_as(C.POINTER(C.c_float)),
                                                   C.byref(st), threads, 1 if count_traversal else 0, nvnt))
         return xyz, wt, st, list(nvnt)
+
+    def bsdf_probe(self, material, op, wo=(0, 0, 1), wi=(0, 0, 1), u=(0.5, 0.5), flags=31):
+        """BSDF of `material` in the canonical frame: op 0 -> (f rgb, pdf), op 1 -> sample_f (f rgb, pdf, wi xyz, type), op 2 -> counts."""
+        out = np.zeros(8, np.float32)
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.POINTER(C.c_float))
+        self._chk(self.b.lib.oracle_bsdf_probe(self.h, material, op, f(wo), f(wi), f(u), flags, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def spatial_stats(self):
         """(voxel resolution xyz, distributions created) of the last spatial render."""

@@ -144,3 +144,89 @@ WorldEnd
     finally:
         set_libm_mode(0)
     assert (img.view(np.uint32) == ref.view(np.uint32)).all(), f"{(img != ref).sum()} values differ"
+
+
+def test_materials_in_a_scene_file(tmp_path, host):
+    """Material / MakeNamedMaterial directives for mirror, plastic, glass, metal, uber with shape-level overrides: same bits as the
+    oracle given the same constructor arguments."""
+    quad = "[-1 -1 0 1 -1 0 1 1 0 -1 1 0]"
+    text = f"""LookAt 0 -5 2  0 0 0.4  0 0 1
+Camera "perspective" "float fov" 50
+Film "image" "integer xresolution" 36 "integer yresolution" 28 "string filename" "m.pfm"
+Sampler "halton" "integer pixelsamples" 8
+Integrator "path" "integer maxdepth" 6
+WorldBegin
+LightSource "infinite" "rgb L" [0.8 0.9 1.0]
+LightSource "distant" "point from" [1 -1 2] "point to" [0 0 0] "rgb L" [2 2 2]
+MakeNamedMaterial "gold" "string type" "metal" "rgb eta" [0.14 0.37 1.44] "rgb k" [3.98 2.38 1.6] "float roughness" 0.1
+MakeNamedMaterial "wet" "string type" "uber" "rgb Kd" [0.2 0.3 0.2] "rgb Ks" [0.3 0.3 0.3] "rgb Kr" [0.1 0.1 0.1] "float index" 1.33 "rgb opacity" [0.8 0.8 0.8]
+AttributeBegin
+  Material "plastic" "rgb Kd" [0.4 0.4 0.5] "float roughness" 0.2
+  Scale 2.5 2.5 1
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" {quad}
+AttributeEnd
+AttributeBegin
+  NamedMaterial "gold"
+  Translate -1.2 0.3 0.6
+  Rotate 60 1 0 0
+  Scale 0.6 0.6 0.6
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" {quad}
+AttributeEnd
+AttributeBegin
+  Material "glass" "float eta" 1.4
+  Translate 0 -0.4 0.7
+  Rotate 75 1 0 0
+  Scale 0.5 0.5 0.5
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" {quad}
+  Translate 0 0 -0.6
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" {quad} "float uroughness" 0.2 "float vroughness" 0.2
+AttributeEnd
+AttributeBegin
+  NamedMaterial "wet"
+  Translate 1.3 0.2 0.5
+  Rotate 80 1 0.2 0
+  Scale 0.6 0.6 0.6
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" {quad}
+  Material "mirror"
+  Translate 0 0 -0.8
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" {quad} "rgb Kr" [0.5 0.6 0.7]
+AttributeEnd
+WorldEnd
+"""
+    (tmp_path / "m.pbrt").write_text(text)
+    r = subprocess.run([ds.RENDER_BIN, "--quiet", str(tmp_path / "m.pbrt")], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    img = ds.read_pfm(str(tmp_path / "m.pfm"))
+    Q = np.float32([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]]); QI = [0, 1, 2, 0, 2, 3]
+    I = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+    mul = host.compose
+
+    def put(o, t, mat):
+        o.add_mesh(host.transform_points(t[0], Q), QI, mat, swaps_handedness=host.swaps_handedness(t[0]))
+    set_libm_mode(1)
+    try:
+        with OracleScene() as o:
+            w2c = mul(I, host.look_at([0, -5, 2], [0, 0, 0.4], [0, 0, 1]))
+            o.add_light_infinite((0.8, 0.9, 1.0))
+            o.add_light_distant(np.float32([2, 2, 2]), host.distant_direction(I[0], [1, -1, 2], [0, 0, 0]))
+            put(o, mul(I, host.scale([2.5, 2.5, 1])), o.add_material_plastic((0.4, 0.4, 0.5), (0.25, 0.25, 0.25), 0.2, True))
+            t = mul(mul(mul(I, host.translate([-1.2, 0.3, 0.6])), host.rotate(60, [1, 0, 0])), host.scale([0.6, 0.6, 0.6]))
+            put(o, t, o.add_material_metal((0.14, 0.37, 1.44), (3.98, 2.38, 1.6), 0.1, 0.1, True))
+            t = mul(mul(mul(I, host.translate([0, -0.4, 0.7])), host.rotate(75, [1, 0, 0])), host.scale([0.5, 0.5, 0.5]))
+            put(o, t, o.add_material_glass((1, 1, 1), (1, 1, 1), 0.0, 0.0, 1.4, True))
+            t = mul(t, host.translate([0, 0, -0.6]))
+            put(o, t, o.add_material_glass((1, 1, 1), (1, 1, 1), 0.2, 0.2, 1.4, True))
+            t = mul(mul(mul(I, host.translate([1.3, 0.2, 0.5])), host.rotate(80, [1, 0.2, 0])), host.scale([0.6, 0.6, 0.6]))
+            put(o, t, o.add_material_uber((0.2, 0.3, 0.2), (0.3, 0.3, 0.3), (0.1, 0.1, 0.1), (0, 0, 0), (0.8, 0.8, 0.8), 0.1, 0.1, 1.33, True))
+            t = mul(t, host.translate([0, 0, -0.8]))
+            put(o, t, o.add_material_mirror((0.5, 0.6, 0.7)))
+            o.set_camera_perspective(host.perspective_raster_to_camera(50.0, 36, 28), w2c[1])
+            cb, table, sb = host.film_box(36, 28)
+            o.set_film(36, 28, cb, (0.5, 0.5), table)
+            o.set_sampler(0, 8, sb)
+            o.build_accel(0, 4)
+            xyz, wt, st = o.render_path(max_depth=6, light_strategy=2, pixel_bounds=sb)
+            ref = o.film_to_rgb(xyz, wt).reshape(28, 36, 3)
+    finally:
+        set_libm_mode(0)
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), f"{(img != ref).sum()} values differ"
