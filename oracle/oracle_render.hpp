@@ -1010,6 +1010,7 @@ struct Renderer {
             if (!found || bounces >= max_depth) break;
             BSDF bsdf = make_bsdf(isect);  // materials always present in scope
             V3 shading_n = isect.ns;
+            if (spatial) (void)spatial_lookup(isect.p);  // light_distribution.lookup(&isect.hit.p) happens for every vertex (path.rs:156-157)
             if (bsdf.num_components(BX_ALL & ~BX_SPEC) > 0) {
                 tls_stats().total_paths++;
                 Spec ld = beta * uniform_sample_one_light(isect, bsdf, sampler);
