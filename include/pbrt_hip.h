@@ -132,6 +132,8 @@ int pbrt_hip_add_light_infinite(PbrtHipScene*, const float L_rgb[3], const float
                                 const float world_to_light[16]);       /* lights/src/infinite.rs:63-107, constant L */
 int pbrt_hip_add_light_distant(PbrtHipScene*, const float L_rgb[3], const float w_light_world[3]); /* distant.rs:36-50: already transformed+normalized */
 int pbrt_hip_add_light_point(PbrtHipScene*, const float I_rgb[3], const float p_world[3]);         /* point.rs:36-55 */
+int pbrt_hip_add_light_spot(PbrtHipScene*, const float I_rgb[3], const float light_to_world[16], const float world_to_light[16],
+                            float cos_total_width, float cos_falloff_start);                       /* lights/src/spot.rs:27-90 */
 int pbrt_hip_add_light_diffuse_area(PbrtHipScene*, const float L_rgb[3], int two_sided, uint32_t n_tris,
                                     uint32_t* out_first_id);           /* lights/src/diffuse.rs:46-82, one per triangle */
 

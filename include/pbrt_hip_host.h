@@ -46,6 +46,11 @@ int pbrt_hip_host_swaps_handedness(const float m[16]); /* transform.rs:593-599 *
 void pbrt_hip_host_distant_direction(const float l2w[16], const float from[3], const float to[3], float out_w[3]);
 void pbrt_hip_host_point_position(const float l2w[16], const float l2w_inv[16], const float from[3], float out_p[3]);
 
+/* SpotLight From<ParamSet> (lights/src/spot.rs:150-190): light_to_world / world_to_light from the CTM, `from`, `to`; out_cos =
+ * {cos_total_width, cos_falloff_start} from coneangle / conedeltaangle (degrees). */
+void pbrt_hip_host_spot(const float ctm_m[16], const float ctm_minv[16], const float from[3], const float to[3], float cone_angle,
+                        float cone_delta, float out_l2w[16], float out_w2l[16], float out_cos[2]);
+
 /* Synthetic measurement scene of BASELINE.md §3: n_tris random triangles from PCG32 stream `seed`
  * (core/src/rng.rs semantics). out_P: 9 floats per triangle, out_idx: 3 per triangle (unshared vertices). */
 void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, float* out_P, uint32_t* out_idx);

@@ -231,6 +231,16 @@ int oracle_add_light_point(OracleScene* s, const float I[3], const float p[3]) {
     Light l{}; l.type = L_POINT; l.L = Spec(I[0], I[1], I[2]); l.p_light = V3(p[0], p[1], p[2]);
     s->sc.lights.push_back(l); return 0;
 }
+int oracle_add_light_spot(OracleScene* s, const float I[3], const float l2w[16], const float w2l[16], float cos_total_width, float cos_falloff_start) {  // spot.rs:27-50
+    if (!s || !I || !l2w || !w2l) return -1;
+    Light l{}; l.type = L_SPOT; l.L = Spec(I[0], I[1], I[2]);
+    M4 a, b; std::memcpy(a.m, l2w, 64); std::memcpy(b.m, w2l, 64);
+    l.l2w = Transform(a, b);
+    l.p_light = l.l2w.point(V3(0, 0, 0));
+    l.cos_total_width = cos_total_width; l.cos_falloff_start = cos_falloff_start;
+    s->sc.lights.push_back(l);
+    return 0;
+}
 int oracle_add_light_diffuse_area(OracleScene* s, const float L[3], int two_sided, uint32_t n_tris, uint32_t* out_first) {
     if (!s || !L) return -1;
     if (out_first) *out_first = (uint32_t)s->sc.lights.size();

@@ -489,6 +489,15 @@ struct Renderer {
         }
         case L_DISTANT:  // distant.rs:87-96
             r.wi = l.w_light; r.pdf = 1.0f; r.vp = hit.p + l.w_light * (2.0f * s.world_radius); r.value = l.L; r.valid = true; return r;
+        case L_SPOT: {   // spot.rs:75-84 with falloff (:52-66)
+            r.wi = normalize(l.p_light - hit.p); r.pdf = 1.0f; r.vp = l.p_light;
+            V3 wl = normalize(l.l2w.inv().vector(-r.wi));
+            Float cos_theta = wl.z, fall;
+            if (cos_theta < l.cos_total_width) fall = 0.0f;
+            else if (cos_theta >= l.cos_falloff_start) fall = 1.0f;
+            else { Float delta = (cos_theta - l.cos_total_width) / (l.cos_falloff_start - l.cos_total_width); fall = (delta * delta) * (delta * delta); }
+            r.value = l.L * fall / distance_squared(l.p_light, hit.p); r.valid = true; return r;
+        }
         case L_POINT:    // point.rs:83-93
             r.wi = normalize(l.p_light - hit.p); r.pdf = 1.0f; r.vp = l.p_light;
             r.value = l.L / distance_squared(l.p_light, hit.p); r.valid = true; return r;
@@ -547,6 +556,7 @@ struct Renderer {
         switch (l.type) {
         case L_INFINITE: return PI * s.world_radius * s.world_radius * infinite_lookup(l.L, V2(0.5f, 0.5f));  // infinite.rs:176-183
         case L_DISTANT: return l.L * PI * s.world_radius * s.world_radius;                                      // distant.rs:98-101
+        case L_SPOT: return l.L * TWO_PI * (1.0f - 0.5f * (l.cos_falloff_start + l.cos_total_width));                    // spot.rs:86-88
         case L_POINT: return (4.0f * PI) * l.L;                                                                 // point.rs:95-97
         default: return (l.two_sided ? 2.0f : 1.0f) * l.L * l.area * PI;                                        // diffuse.rs:131-134
         }
@@ -942,7 +952,7 @@ struct Renderer {
         Float scattering_pdf = 0.0f;
         LiSample ls = light_sample_li(light, hit, u_light);
         V3 wi = ls.valid ? ls.wi : V3(); Float light_pdf = ls.valid ? ls.pdf : 0.0f; Spec li = ls.valid ? ls.value : Spec(0.0f);
-        bool is_delta = light.type == L_DISTANT || light.type == L_POINT;
+        bool is_delta = light.type == L_DISTANT || light.type == L_POINT || light.type == L_SPOT;
         if (light_pdf > 0.0f && !li.is_black()) {
             Spec f = bsdf.f(hit.wo, wi, BX_ALL & ~BX_SPEC) * abs_dot(wi, hit.ns);  // bsdf_flags: specular = false (common.rs:157-161)
             scattering_pdf = bsdf.pdf(hit.wo, wi, BX_ALL & ~BX_SPEC);

@@ -38,13 +38,14 @@ struct Lobe {
 };
 struct Material { Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; };
 
-enum LightType { L_INFINITE = 0, L_DISTANT = 1, L_POINT = 2, L_AREA = 3 };
+enum LightType { L_INFINITE = 0, L_DISTANT = 1, L_POINT = 2, L_AREA = 3, L_SPOT = 4 };
 struct Light {
     int type;
     Spec L;             // infinite: lrgb; distant: emitted radiance; point: intensity; area: l_emit
     Transform l2w;      // infinite only
     V3 w_light;         // distant
-    V3 p_light;         // point
+    V3 p_light;         // point, spot
+    Float cos_total_width = 0, cos_falloff_start = 0;  // spot (lights/src/spot.rs:24-25); l2w holds its light_to_world
     int two_sided;      // area
     uint32_t prim;      // area: global triangle index bound to this light
     Float area;         // area: Triangle::area()

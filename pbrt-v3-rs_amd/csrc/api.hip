@@ -124,6 +124,7 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
                 }
                 case PH_L_DISTANT: p[c] = l.L[c] * hm::kPi * wr * wr; break;                       // distant.rs:98-101
                 case PH_L_POINT: p[c] = (hm::kPi * 4.0f) * l.L[c]; break;                          // point.rs:95-97
+                case PH_L_SPOT: p[c] = l.L[c] * (2.0f * hm::kPi) * (1.0f - 0.5f * (l.cos_falloff_start + l.cos_total_width)); break;  // spot.rs:86-88
                 default: p[c] = (l.two_sided ? 2.0f : 1.0f) * l.L[c] * l.area * hm::kPi; break;    // diffuse.rs:131-134
                 }
             }
@@ -599,6 +600,19 @@ int pbrt_hip_add_light_point(PbrtHipScene* s, const float I[3], const float p[3]
     if (!s || !I || !p) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_point: null argument");
     LightRec l{}; l.type = PH_L_POINT; l.prim = 0xFFFFFFFFu;
     for (int c = 0; c < 3; c++) { l.L[c] = I[c]; l.v[c] = p[c]; }
+    s->lights.push_back(l); s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_add_light_spot(PbrtHipScene* s, const float I[3], const float l2w[16], const float w2l[16], float cos_total_width, float cos_falloff_start) {  // spot.rs:27-50
+    if (!s || !I || !l2w || !w2l) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_spot: null argument");
+    LightRec l{}; l.type = PH_L_SPOT; l.prim = 0xFFFFFFFFu;
+    for (int c = 0; c < 3; c++) l.L[c] = I[c];
+    std::memcpy(l.l2w, l2w, 48); std::memcpy(l.w2l, w2l, 48);
+    // p_light = light_to_world.transform_point(Point3f::ZERO) (transform.rs:288-302)
+    const float xp = l2w[0] * 0.0f + l2w[1] * 0.0f + l2w[2] * 0.0f + l2w[3], yp = l2w[4] * 0.0f + l2w[5] * 0.0f + l2w[6] * 0.0f + l2w[7];
+    const float zp = l2w[8] * 0.0f + l2w[9] * 0.0f + l2w[10] * 0.0f + l2w[11], wp = l2w[12] * 0.0f + l2w[13] * 0.0f + l2w[14] * 0.0f + l2w[15];
+    if (wp == 1.0f) { l.v[0] = xp; l.v[1] = yp; l.v[2] = zp; } else { const float inv = 1.0f / wp; l.v[0] = inv * xp; l.v[1] = inv * yp; l.v[2] = inv * zp; }
+    l.cos_total_width = cos_total_width; l.cos_falloff_start = cos_falloff_start;
     s->lights.push_back(l); s->uploaded = false;
     return PBRT_HIP_OK;
 }

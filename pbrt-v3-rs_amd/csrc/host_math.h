@@ -24,6 +24,11 @@ inline V3 cross(V3 a, V3 b) { return {(a.y * b.z) - (a.z * b.y), (a.z * b.x) - (
 inline float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 inline float len(V3 a) { return std::sqrt(len2(a)); }
 inline V3 normalize(V3 a) { return divf(a, len(a)); }
+inline void coordinate_system(V3 v1, V3& v2, V3& v3) {  // core/src/geometry/coordinate_system.rs:12-20
+    if (std::fabs(v1.x) > std::fabs(v1.y)) v2 = divf({-v1.z, 0.0f, v1.x}, std::sqrt(v1.x * v1.x + v1.z * v1.z));
+    else v2 = divf({0.0f, v1.z, -v1.y}, std::sqrt(v1.y * v1.y + v1.z * v1.z));
+    v3 = cross(v1, v2);
+}
 inline V3 ld(const float* p) { return {p[0], p[1], p[2]}; }
 
 // PCG32 (core/src/rng.rs:20-120)

@@ -211,7 +211,23 @@ void pbrt_hip_host_point_position(const float l2w[16], const float l2w_inv[16], 
 // PCG32 stream `seed` (RNG::new(seed), core/src/rng.rs:39-62).  Per triangle: centre c ~ U[-1,1)^3, then three vertices
 // c + s*U[-1,1)^3 with s = 1.5 * N^(-1/3) (constant expected density), U = 2*uniform_float()-1.  Unshared vertices
 // (3N positions, indices 0..3N-1).
-extern "C" void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, float* out_P /*9 per tri*/, uint32_t* out_idx /*3 per tri*/) {
+extern "C" // SpotLight From<ParamSet> (lights/src/spot.rs:150-190): light_to_world = ctm * translate(from) * inverse(dir_to_z) with dir_to_z rows
+// (du, dv, dir) from coordinate_system(normalize(to - from)); cos_total_width = cos(radians(coneangle)), cos_falloff_start =
+// cos(radians(coneangle - conedeltaangle)) (:42-43, host libm cosf as for the reference).
+void pbrt_hip_host_spot(const float ctm_m[16], const float ctm_minv[16], const float from[3], const float to[3], float cone_angle, float cone_delta,
+                        float out_l2w[16], float out_w2l[16], float out_cos[2]) {
+    V3 dir = normalize(sub({to[0], to[1], to[2]}, {from[0], from[1], from[2]}));
+    V3 du, dv;
+    coordinate_system(dir, du, dv);
+    Xf d2z; d2z.m = rows(du.x, du.y, du.z, 0, dv.x, dv.y, dv.z, 0, dir.x, dir.y, dir.z, 0, 0, 0, 0, 1); d2z.mi = m4_inverse(d2z.m);
+    Xf inv_d2z = {d2z.mi, d2z.m};
+    Xf r = xf_mul(xf_mul({in16(ctm_m), in16(ctm_minv)}, xf_translate(from[0], from[1], from[2])), inv_d2z);
+    out16(r.m, out_l2w); out16(r.mi, out_w2l);
+    out_cos[0] = std::cos(to_radians(cone_angle));
+    out_cos[1] = std::cos(to_radians(cone_angle - cone_delta));
+}
+
+void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, float* out_P /*9 per tri*/, uint32_t* out_idx /*3 per tri*/) {
     Pcg32 rng;
     rng.state = 0; rng.inc = (seed << 1) | 1;  // RNG::set_sequence
     rng.next(); rng.state += 0x853c49e6748fea9bULL; rng.next();

@@ -506,6 +506,16 @@ PH_DEV LiSample light_sample_li(const DeviceScene& sc, const LightRec& l, const 
     } else if (l.type == PH_L_DISTANT) {  // distant.rs:87-96
         f3 w = mk3(l.v[0], l.v[1], l.v[2]);
         r.wi = w; r.pdf = 1.0f; r.vp = hit.p + w * (2.0f * sc.world_radius); r.value = mks(l.L[0], l.L[1], l.L[2]); r.valid = true;
+    } else if (l.type == PH_L_SPOT) {  // spot.rs:75-84, falloff :52-66
+        f3 pl = mk3(l.v[0], l.v[1], l.v[2]);
+        r.wi = normalize(pl - hit.p); r.pdf = 1.0f; r.vp = pl;
+        const f3 wl = normalize(xf_vec(l.w2l, -r.wi));
+        const float cos_theta = wl.z;
+        float fall;
+        if (cos_theta < l.cos_total_width) fall = 0.0f;
+        else if (cos_theta >= l.cos_falloff_start) fall = 1.0f;
+        else { const float delta = ph_div(cos_theta - l.cos_total_width, l.cos_falloff_start - l.cos_total_width); fall = (delta * delta) * (delta * delta); }
+        r.value = mks(l.L[0], l.L[1], l.L[2]) * fall / distance_squared(pl, hit.p); r.valid = true;
     } else if (l.type == PH_L_POINT) {  // point.rs:83-93
         f3 pl = mk3(l.v[0], l.v[1], l.v[2]);
         r.wi = normalize(pl - hit.p); r.pdf = 1.0f; r.vp = pl;

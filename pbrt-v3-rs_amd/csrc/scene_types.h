@@ -80,7 +80,7 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     float bsdf_eta;    // BSDF::eta (bsdf.rs:101): 1 unless the material passes one (uber.rs:131-138)
 };
 
-enum { PH_L_INFINITE = 0, PH_L_DISTANT = 1, PH_L_POINT = 2, PH_L_AREA = 3 };
+enum { PH_L_INFINITE = 0, PH_L_DISTANT = 1, PH_L_POINT = 2, PH_L_AREA = 3, PH_L_SPOT = 4 };
 struct LightRec {
     int32_t type;
     int32_t two_sided;
@@ -88,14 +88,14 @@ struct LightRec {
     float area;          // area: Triangle::area()
     float L[3];          // radiance / intensity
     float pad0;
-    float v[3];          // distant: w_light; point: p_light
+    float v[3];          // distant: w_light; point / spot: p_light
     float pad1;
     float l2w[12];       // infinite: rows 0..2 of light_to_world (3x4)
     float w2l[12];       // infinite: rows 0..2 of world_to_light
     // infinite: Distribution2D over the 2x2 scalar image (lights/src/infinite.rs:326-369)
     float cond_func[4], cond_cdf[6], cond_int[2];
     float marg_func[2], marg_cdf[3], marg_int;
-    float pad2[2];
+    float cos_total_width, cos_falloff_start;  // spot (lights/src/spot.rs:24-25); w2l holds its world_to_light, v its position
 };
 
 struct CameraRec {  // cameras/src/perspective_camera.rs

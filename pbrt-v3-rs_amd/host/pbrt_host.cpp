@@ -250,8 +250,14 @@ void Api::pbrt_light_source(const std::string& name, const ParamSet& p) {
         float pw[3];
         pbrt_hip_host_point_position(ctm_.m, ctm_.mi, from.data(), pw);
         if (check(ABI(pbrt_hip_add_light_point(scene_, I.data(), pw)), "add_light_point")) n_lights_++;
+    } else if (name == "spot") {
+        auto I = mul3(p.find_one_rgb("I", one), sc);
+        auto from = p.find_one_rgb("from", {0.0f, 0.0f, 0.0f}), to = p.find_one_rgb("to", {0.0f, 0.0f, 1.0f});
+        float l2w[16], w2l[16], cs[2];
+        pbrt_hip_host_spot(ctm_.m, ctm_.mi, from.data(), to.data(), p.find_one_float("coneangle", 30.0f), p.find_one_float("conedeltaangle", 5.0f), l2w, w2l, cs);
+        if (check(ABI(pbrt_hip_add_light_spot(scene_, I.data(), l2w, w2l, cs[0], cs[1])), "add_light_spot")) n_lights_++;
     } else {
-        error = "LightSource \"" + name + "\" is outside the hot-path scope (supported: infinite, distant, point, and diffuse area lights)";
+        error = "LightSource \"" + name + "\" is outside the hot-path scope (supported: infinite, distant, point, spot, and diffuse area lights)";
     }
 }
 void Api::pbrt_area_light_source(const std::string& name, const ParamSet& p) { if (!verify_world("AreaLightSource")) return; gs_.area_light = name; gs_.area_light_params = p; }

@@ -78,6 +78,7 @@ class Binding:
             "add_light_infinite": (C.c_int, [vp, fp, fp, fp]),
             "add_light_distant": (C.c_int, [vp, fp, fp]),
             "add_light_point": (C.c_int, [vp, fp, fp]),
+            "add_light_spot": (C.c_int, [vp, fp, fp, fp, C.c_float, C.c_float]),
             "add_light_diffuse_area": (C.c_int, [vp, fp, C.c_int, C.c_uint32, u32p]),
             "set_camera_perspective": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]),
             "set_film": (C.c_int, [vp, C.c_int, C.c_int, ip, fp, fp, C.c_float, C.c_float]),
@@ -150,6 +151,7 @@ class Host:
         ip = C.POINTER(C.c_int)
         L.pbrt_hip_host_film_filter.argtypes = [C.c_int, fp, C.c_int, C.c_int, fp, fp, ip, fp, ip]
         L.pbrt_hip_host_film_filter.restype = C.c_int
+        L.pbrt_hip_host_spot.argtypes = [fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, fp]
         L.pbrt_hip_host_swaps_handedness.argtypes = [fp]
         L.pbrt_hip_host_swaps_handedness.restype = C.c_int
 
@@ -235,6 +237,13 @@ class Host:
         w = np.zeros(3, np.float32)
         self.lib.pbrt_hip_host_distant_direction(_ptr(_f32(l2w), C.c_float), _ptr(_f32(frm), C.c_float), _ptr(_f32(to), C.c_float), _ptr(w, C.c_float))
         return w
+
+    def spot(self, ctm, frm, to, cone_angle=30.0, cone_delta=5.0):
+        """SpotLight parameters -> (light_to_world, world_to_light, cos_total_width, cos_falloff_start)."""
+        l2w, w2l, c = self._m(), self._m(), np.zeros(2, np.float32)
+        self.lib.pbrt_hip_host_spot(_ptr(_f32(ctm[0]), C.c_float), _ptr(_f32(ctm[1]), C.c_float), _ptr(_f32(frm), C.c_float), _ptr(_f32(to), C.c_float),
+                                    C.c_float(cone_angle), C.c_float(cone_delta), _ptr(l2w, C.c_float), _ptr(w2l, C.c_float), _ptr(c, C.c_float))
+        return l2w, w2l, float(c[0]), float(c[1])
 
     def point_position(self, l2w, l2w_inv, frm):
         p = np.zeros(3, np.float32)
@@ -355,6 +364,10 @@ class Scene:
 
     def add_light_point(self, I, p_world):
         self._chk(self.b.fn("add_light_point")(self.h, _ptr(_f32(I), C.c_float), _ptr(_f32(p_world), C.c_float)))
+
+    def add_light_spot(self, I, light_to_world, world_to_light, cos_total_width, cos_falloff_start):
+        self._chk(self.b.fn("add_light_spot")(self.h, _ptr(_f32(I), C.c_float), _ptr(_f32(light_to_world), C.c_float), _ptr(_f32(world_to_light), C.c_float),
+                                              C.c_float(cos_total_width), C.c_float(cos_falloff_start)))
 
     def add_light_diffuse_area(self, L, n_tris, two_sided=False) -> int:
         out = C.c_uint32(0)

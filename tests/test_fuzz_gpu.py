@@ -62,9 +62,13 @@ def build_case(host, seed):
             t = random_transform(host, lr)
             s.add_light_infinite(tuple(lr.uniform(0.1, 0.8, 3)), t[0], t[1])
         for _ in range(n_lights):
-            k = lr.integers(0, 2)
+            k = lr.integers(0, 3)
             if k == 0:
                 s.add_light_point(tuple(lr.uniform(2, 12, 3)), lr.uniform(-1.5, 1.5, 3).astype(np.float32))
+            elif k == 2:
+                t = random_transform(host, lr, 0.5)
+                l2w, w2l, ctw, cfs = host.spot(t, lr.uniform(-1, 1, 3) + np.array([0, 0, 1.5]), lr.uniform(-0.5, 0.5, 3), float(lr.uniform(15, 70)), float(lr.uniform(1, 14)))
+                s.add_light_spot(tuple(lr.uniform(5, 30, 3)), l2w, w2l, ctw, cfs)
             else:
                 w = lr.normal(size=3); w /= np.linalg.norm(w)
                 s.add_light_distant(tuple(lr.uniform(0.3, 2, 3)), np.float32(w))

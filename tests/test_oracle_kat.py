@@ -235,3 +235,45 @@ def test_sobol_fixture_matches_reference_tables():
     assert np.array_equal(m32, np.array(mk.table(src, "SOBOL_MATRICES_32")[: len(m32)], np.uint32))
     assert np.array_equal(vdc, np.array(mk.table(src, "VD_C_SOBOL_MATRICES")[: len(vdc)], np.uint64))
     assert np.array_equal(vdci, np.array(mk.table(src, "VD_C_SOBOL_MATRICES_INV")[: len(vdci)], np.uint64))
+
+
+def test_spot_light_closed_form(host):
+    """SpotLight (lights/src/spot.rs): a Lambertian floor lit by one spot, max_depth 1, one centred sample per pixel.  Every pixel must
+    equal Kd/pi * I * falloff(cos) / d^2 * cos_surface evaluated in float64 at the camera ray's hit point."""
+    import pbrt_hip
+    from oracle_binding import OracleScene
+    I4 = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+    Iv, kd, cone, delta = np.array([20.0, 15.0, 10.0]), np.array([0.6, 0.5, 0.4]), 35.0, 12.0
+    res = 48
+    with OracleScene() as o:
+        l2w, w2l, c_tw, c_fs = host.spot(I4, [0.3, -0.2, 2.0], [0.5, 0.1, 0.0], cone, delta)
+        assert c_tw == pytest.approx(np.cos(np.radians(cone)), rel=1e-6) and c_fs == pytest.approx(np.cos(np.radians(cone - delta)), rel=1e-6)
+        o.add_light_spot(Iv, l2w, w2l, c_tw, c_fs)
+        m = o.add_material_matte(kd, 0.0)
+        o.add_mesh(np.float32([[-4, -4, 0], [4, -4, 0], [4, 4, 0], [-4, 4, 0]]), [0, 1, 2, 0, 2, 3], m)
+        w2c, c2w = host.look_at([0, -3, 4], [0.2, 0, 0], [0, 0, 1])
+        o.set_camera_perspective(host.perspective_raster_to_camera(50.0, res, res), c2w)
+        cb, table, sb = host.film_box(res, res)
+        o.set_film(res, res, cb, (0.5, 0.5), table)
+        o.set_sampler(0, 1, sb, sample_at_pixel_center=True)
+        o.build_accel(0, 4)
+        xyz, wt, st = o.render_path(max_depth=1, light_strategy=0)
+        rgb = o.film_to_rgb(xyz, wt).reshape(res, res, 3).astype(np.float64)
+        rays, pfilm = o.generate_camera_rays([0, 0, res, res], 0)
+    ro = rays["o"].astype(np.float64); rd = rays["d"].astype(np.float64)
+    t = -ro[:, 2] / rd[:, 2]
+    P = ro + rd * t[:, None]
+    pl = np.array([0.3, -0.2, 2.0]); axis = np.array([0.5, 0.1, 0.0]) - pl; axis /= np.linalg.norm(axis)
+    w = P - pl; d2 = (w ** 2).sum(1); wn = w / np.sqrt(d2)[:, None]
+    cos_l = wn @ axis
+    ctw, cfs = np.cos(np.radians(cone)), np.cos(np.radians(cone - delta))
+    dl = np.clip((cos_l - ctw) / (cfs - ctw), 0.0, 1.0)
+    fall = np.where(cos_l < ctw, 0.0, np.where(cos_l >= cfs, 1.0, dl ** 4))
+    cos_s = np.abs(wn[:, 2])
+    expect = (kd / np.pi)[None, :] * Iv[None, :] * (fall / d2 * cos_s)[:, None]
+    got = rgb.reshape(-1, 3)
+    lit = fall > 1e-3
+    assert lit.sum() > 100 and (~lit).sum() > 100
+    # XYZ round trip of the film (rgb -> xyz -> rgb) costs ~1e-6 relative; the falloff edge amplifies f32 rounding of cos
+    assert np.allclose(got[lit], expect[lit], rtol=2e-3, atol=1e-6)
+    assert np.abs(got[fall == 0]).max() < 1e-7

@@ -250,3 +250,19 @@ def test_hlbvh_scene_renders_the_sah_image(host):
     g1, o1, _ = _assert_film_bit_exact(cap(1), max_depth=3)
     g0, o0, _ = _assert_film_bit_exact(cap(0), max_depth=3)
     assert _bits_equal(g0[0], g1[0])
+
+
+def test_spot_lights_bit_exact(host):
+    """SpotLight::sample_li / falloff / power (lights/src/spot.rs) under the uniform, power and spatial strategies."""
+    I4 = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+    base = scenes.cornell_like(host, sigma=10.0)
+
+    def cap(s):
+        t = host.compose(I4, host.rotate(15, [0, 1, 0]))
+        a = host.spot(t, [0.5, -0.6, 0.9], [-0.2, 0.2, -1.0], 40.0, 10.0)
+        b = host.spot(I4, [-0.8, -0.8, 0.0], [0.5, 0.5, -0.5], 25.0, 25.0)
+        s.add_light_spot((6, 5, 4), *a)
+        s.add_light_spot((1, 3, 6), *b)
+        base(s)
+    for strategy in (0, 1, 2):
+        _assert_film_bit_exact(cap, max_depth=4, light_strategy=strategy)
