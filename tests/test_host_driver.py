@@ -51,7 +51,7 @@ def test_check_mode_crop_and_outfile(tmp_path):
     ('WorldBegin\nMakeNamedMedium "fog" "string type" "homogeneous"\nWorldEnd\n', "directive 'MakeNamedMedium'"),
     ('WorldBegin\nObjectBegin "a"\nAreaLightSource "diffuse"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nObjectEnd\nWorldEnd\n',
      "AreaLightSource inside ObjectBegin"),
-    ('WorldBegin\nLightSource "spot"\nWorldEnd\n', 'LightSource "spot"'),
+    ('WorldBegin\nLightSource "goniometric"\nWorldEnd\n', 'LightSource "goniometric"'),
     ('Camera "orthographic"\nWorldBegin\nWorldEnd\n', 'Camera "orthographic"'),
     ('Integrator "bdpt"\nWorldBegin\nWorldEnd\n', 'Integrator "bdpt"'),
     ('Sampler "random"\nWorldBegin\nWorldEnd\n', 'Sampler "random"'),
