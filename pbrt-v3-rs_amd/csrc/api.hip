@@ -708,8 +708,23 @@ int pbrt_hip_set_sobol_tables(PbrtHipScene* s, const uint32_t* m32, size_t n32, 
 int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_node) {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
     if (split_method == 2) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: splitmethod 'middle' panics in the reference (quirk B6, sah.rs:67-76)");
+    // material classes (shade-side sorting key): materials with the same sequence of lobe kinds share a class; at most 7 classes
+    {
+        std::vector<uint64_t> sigs;
+        for (MaterialRec& m : s->materials) {
+            uint64_t sig = 1;
+            for (uint32_t k = 0; k < m.n_lobes; k++) sig = sig * 8 + (s->lobes[m.lobe_base + k].kind + 1);
+            size_t c = 0;
+            while (c < sigs.size() && sigs[c] != sig) c++;
+            if (c == sigs.size()) sigs.push_back(sig);
+            static const bool no_sort = std::getenv("PBRT_HIP_NO_MATERIAL_SORT") != nullptr;  // measurement aid: every material in one class
+            m.sort_class = no_sort ? 0u : (uint32_t)std::min<size_t>(c, 6);
+        }
+    }
+    std::vector<uint32_t> build_flags(s->tri_flags);
+    for (size_t t = 0; t < build_flags.size(); t++) build_flags[t] |= s->materials[s->meshes[s->tri_mesh[t]].material].sort_class << PH_TRI_CLASS_SHIFT;
     phost::BuildInput in;
-    in.P = s->P.data(); in.idx = s->idx.data(); in.n_tris = s->idx.size() / 3; in.tri_flags = s->tri_flags.data(); in.tri_mesh = s->tri_mesh.data();
+    in.P = s->P.data(); in.idx = s->idx.data(); in.n_tris = s->idx.size() / 3; in.tri_flags = build_flags.data(); in.tri_mesh = s->tri_mesh.data();
     auto fail = [&](int brc) {
         if (brc == -2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: the reference's HLBVH build asserts on this input (hlbvh.rs:338/356/418)");
         return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "build_accel: bad arguments");

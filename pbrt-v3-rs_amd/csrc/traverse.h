@@ -196,7 +196,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
     RayState r;
     uint32_t cur = PH_INVALID_REF;           // interior node index, or PH_LEAF_BIT | index of the NEXT TriRec to test
     int sp = 0;
-    uint32_t hit_prim = 0xFFFFFFFFu, hit_tri = 0u;
+    uint32_t hit_prim = 0xFFFFFFFFu, hit_tri = 0u, hit_cls = 0u;
     float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     bool occluded = false;
     uint32_t c_nodes = 0, c_tris = 0, c_rays = 0;
@@ -333,6 +333,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                                 if (ANYHIT) occluded = true;
                                 else {
                                     r.t_max = t; hit_prim = __float_as_uint(a.w); hit_tri = ti; hb0 = b0; hb1 = b1; hb2 = b2;
+                                    hit_cls = (flags >> PH_TRI_CLASS_SHIFT) & 7u;
                                     if (INST) { hit_inst = in_inst; inst_hit = true; }
                                 }
                             }
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
             else {
                 float4* hp = reinterpret_cast<float4*>(reinterpret_cast<HitOut*>(p.out) + ray_index);
                 hp[0] = make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1);
-                hp[1] = make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), 0.0f);  // pad[0] = the hit's TriRec, pad[1] = instance + 1
+                hp[1] = make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), __uint_as_float(hit_cls));  // pad[0] = the hit's TriRec, pad[1] = instance + 1, pad[2] = material class
             }
             has_ray = false;
             if (COUNT) c_rays++;

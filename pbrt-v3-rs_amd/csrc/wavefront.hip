@@ -200,6 +200,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
     __shared__ uint32_t q_base[3];
     __shared__ HaltonLds halton_lds;
     __shared__ float s_u[8][PH_SHADE_BLOCK];  // the (up to) 8 sampler dimensions a vertex can consume, drawn by ONE loop
+    __shared__ uint32_t sort_cnt[9], sort_pid[GEN ? PH_SHADE_BLOCK : 1];   // GEN: block-local material sorting
     const uint32_t n_live = w.ctr[it].n_live;
     const HaltonLds* hl = nullptr;
     if (w.sp.kind == 0 && blockIdx.x * blockDim.x < n_live) { halton_lds_fill(&halton_lds, sc); hl = &halton_lds; }
@@ -225,8 +226,35 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
         float pick_pdf = 0.0f, eta_scale = 1.0f;
         bool want_ext = false, want_mis = false, want_sh = false;
 
+        if (GEN) {
+            // ---- block-local material sorting: the 256 paths of this round are regrouped by the material class of the surface they hit
+            // (class = distinct lobe-kind signature, recorded by the traversal kernel in HitOut.pad[2]), so that a wave walks one kind of
+            // lobe list.  Paths with nothing to shade (miss / only pending shadow + MIS results) form the last group.  Which thread
+            // handles which path is free: paths are independent and the film is accumulated by sample index.
+            uint32_t cls = 8u, cand = 0u;
+            if (active) {
+                cand = live_in[i];
+                const uint4 c4 = w.s_idx[cand];
+                cls = 7u;
+                if (c4.w & F_EXT) {
+                    const float4 ch = reinterpret_cast<const float4*>(w.hits_cl + c4.x)[1];
+                    const float4 c0 = reinterpret_cast<const float4*>(w.hits_cl + c4.x)[0];
+                    if (__float_as_uint(c0.y) != 0xFFFFFFFFu) cls = __float_as_uint(ch.w) & 7u;
+                    if (cls == 7u) cls = 6u;
+                }
+            }
+            __syncthreads();
+            if (tid < 9) sort_cnt[tid] = 0u;
+            __syncthreads();
+            const uint32_t my_rank = atomicAdd(&sort_cnt[cls], 1u);   // LDS atomic; order inside a class is irrelevant
+            __syncthreads();
+            uint32_t off = 0;
+            for (uint32_t k = 0; k < cls; k++) off += sort_cnt[k];
+            sort_pid[off + my_rank] = cand;
+            __syncthreads();
+        }
         if (active) {
-            pid = live_in[i];
+            pid = GEN ? sort_pid[tid] : live_in[i];
             const uint4 idx4 = w.s_idx[pid];
             flags = idx4.w & 0xffu; bounces = (idx4.w >> 8) & 0xffu; dim = idx4.w >> 16;
             const float4 L4 = w.s_L[pid], b4 = w.s_beta[pid];

@@ -508,11 +508,21 @@ def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None, insta
         mat = scene.add_material_metal((0.2, 0.92, 1.1), (3.9, 2.45, 2.14), 0.05, 0.05, True)
     elif spec.material == "uber":
         mat = scene.add_material_uber(spec.kd, (0.25, 0.25, 0.25), (0.1, 0.1, 0.1), (0.1, 0.1, 0.1), (0.9, 0.9, 0.9), 0.1, 0.1, 1.5, True)
+    elif spec.material == "mixed":
+        mat = None
     else:
         raise ValueError(spec.material)
     if spec.env_L is not None:
         scene.add_light_infinite(spec.env_L)
-    if instances > 0:
+    if mat is None:  # five materials over five equal slices of the triangle list (spatially interleaved: the triangles are random)
+        mats = [scene.add_material_matte(spec.kd, spec.sigma), scene.add_material_plastic(spec.kd, (0.25, 0.25, 0.25), 0.1, True),
+                scene.add_material_glass((1, 1, 1), (1, 1, 1), 0.0, 0.0, 1.5, True), scene.add_material_metal((0.2, 0.92, 1.1), (3.9, 2.45, 2.14), 0.05, 0.05, True),
+                scene.add_material_uber(spec.kd, (0.25, 0.25, 0.25), (0.1, 0.1, 0.1), (0.1, 0.1, 0.1), (0.9, 0.9, 0.9), 0.1, 0.1, 1.5, True)]
+        nt = len(idx) // 3
+        for k, m in enumerate(mats):
+            t0, t1 = nt * k // 5, nt * (k + 1) // 5
+            scene.add_mesh(P[3 * t0:3 * t1], idx[3 * t0:3 * t1] - 3 * t0, m)
+    elif instances > 0:
         ob = scene.object_begin(); scene.add_mesh(P, idx, mat); scene.object_end()
         side = int(np.ceil(instances ** (1.0 / 3.0)))
         rng = np.random.default_rng(spec.seed + 1000)
