@@ -97,6 +97,11 @@ int pbrt_hip_add_material_matte(PbrtHipScene*, const float kd_rgb[3], float sigm
  *                                              reference's copper default needs its spectral tables: pass them explicitly)
  *   uber     materials/src/uber.rs:116-186     opacity pass-through + Lambert(Kd) + Microfacet(Ks) + SpecularReflection(Kr) +
  *                                              SpecularTransmission(Kt); pass urough = vrough = roughness when the file gives one value
+ *   substrate   materials/src/substrate.rs:55-84   FresnelBlend(Kd, Ks, TR(urough, vrough))
+ *   translucent materials/src/translucent.rs:57-112 Lambertian R/T (reflect*Kd, transmit*Kd) + Microfacet R/T (reflect*Ks, transmit*Ks), eta 1.5;
+ *                                               reflect = transmit = 0 is refused (the reference leaves the BSDF unset there)
+ *   mix         materials/src/mix.rs:51-88        the two materials' lobes as ScaledBxDF(amount) / ScaledBxDF(1 - amount); at most 8 lobes,
+ *                                               mixes of mixes up to two levels
  * Bump maps are outside the scope (constant textures have no gradient: Material::bump is the identity for them). */
 int pbrt_hip_add_material_mirror(PbrtHipScene*, const float kr_rgb[3], uint32_t* out_id);
 int pbrt_hip_add_material_plastic(PbrtHipScene*, const float kd_rgb[3], const float ks_rgb[3], float roughness, int remap_roughness, uint32_t* out_id);
@@ -106,6 +111,12 @@ int pbrt_hip_add_material_metal(PbrtHipScene*, const float eta_rgb[3], const flo
                                 uint32_t* out_id);
 int pbrt_hip_add_material_uber(PbrtHipScene*, const float kd_rgb[3], const float ks_rgb[3], const float kr_rgb[3], const float kt_rgb[3],
                                const float opacity_rgb[3], float uroughness, float vroughness, float eta, int remap_roughness, uint32_t* out_id);
+
+int pbrt_hip_add_material_substrate(PbrtHipScene*, const float kd_rgb[3], const float ks_rgb[3], float uroughness, float vroughness, int remap_roughness,
+                                    uint32_t* out_id);
+int pbrt_hip_add_material_translucent(PbrtHipScene*, const float kd_rgb[3], const float ks_rgb[3], const float reflect_rgb[3], const float transmit_rgb[3],
+                                      float roughness, int remap_roughness, uint32_t* out_id);
+int pbrt_hip_add_material_mix(PbrtHipScene*, uint32_t material1, uint32_t material2, const float amount_rgb[3], uint32_t* out_id);
 
 /* TriangleMesh (shapes/src/triangle.rs:75-113): P/N/S must ALREADY be in world space exactly as TriangleMesh::new
  * leaves them (:93-99).  N, S, UV may be NULL.  One GeometricPrimitive per triangle (api/src/lib.rs:783-812).

@@ -368,6 +368,48 @@ int oracle_render_path_ex(OracleScene* s, int max_depth, float rr_threshold, int
     if (out_nv_nt) { out_nv_nt[0] = r.total_stats.nv_regular; out_nv_nt[1] = r.total_stats.nt_regular; out_nv_nt[2] = r.total_stats.nv_shadow; out_nv_nt[3] = r.total_stats.nt_shadow; }
     return 0;
 }
+int oracle_add_material_substrate(OracleScene* s, const float kd[3], const float ks[3], float urough, float vrough, int remap, uint32_t* out_id) {  // substrate.rs:55-84
+    if (!s || !kd || !ks) return -1;
+    Material m; m.general = true;
+    Spec d = spec_clamp0(spec3(kd)), sp = spec_clamp0(spec3(ks));
+    if (!d.is_black() || !sp.is_black()) {
+        if (remap) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
+        Lobe l; l.kind = LK_FRESNEL_BLEND; l.type = BX_REFL | BX_GLOSSY; l.r = d; l.t = sp; set_tr(l, urough, vrough);
+        m.lobes.push_back(l);
+    }
+    return push_material(s, m, out_id);
+}
+int oracle_add_material_translucent(OracleScene* s, const float kd[3], const float ks[3], const float reflect[3], const float transmit[3], float roughness, int remap,
+                                    uint32_t* out_id) {  // translucent.rs:57-112
+    if (!s || !kd || !ks || !reflect || !transmit) return -1;
+    Material m; m.general = true; m.bsdf_eta = 1.5f;
+    Spec r = spec_clamp0(spec3(reflect)), t = spec_clamp0(spec3(transmit));
+    if (r.is_black() && t.is_black()) { s->err = "translucent with reflect = transmit = 0 leaves the BSDF unset (translucent.rs:73-75): null-BSDF skipping is out of scope"; return -5; }
+    Spec d = spec_clamp0(spec3(kd));
+    if (!d.is_black()) {
+        if (!r.is_black()) { Lobe l; l.kind = LK_LAMBERT; l.type = BX_REFL | BX_DIFF; l.r = r * d; m.lobes.push_back(l); }
+        if (!t.is_black()) { Lobe l; l.kind = LK_LAMBERT_T; l.type = BX_TRANS | BX_DIFF; l.t = t * d; m.lobes.push_back(l); }
+    }
+    Spec sp = spec_clamp0(spec3(ks));
+    if (!sp.is_black() && (!r.is_black() || !t.is_black())) {
+        Float rough = remap ? roughness_to_alpha(roughness) : roughness;
+        if (!r.is_black()) { Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; l.r = r * sp; set_tr(l, rough, rough); m.lobes.push_back(l); }
+        if (!t.is_black()) { Lobe l; l.kind = LK_MICRO_T; l.type = BX_TRANS | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; l.t = t * sp; set_tr(l, rough, rough); m.lobes.push_back(l); }
+    }
+    return push_material(s, m, out_id);
+}
+int oracle_add_material_mix(OracleScene* s, uint32_t m1, uint32_t m2, const float amount[3], uint32_t* out_id) {  // mix.rs:51-88
+    if (!s || !amount || m1 >= s->sc.materials.size() || m2 >= s->sc.materials.size()) return -1;
+    Material m; m.general = true;
+    Spec s1 = spec_clamp0(spec3(amount));
+    Spec s2 = spec_clamp0(Spec(1.0f) - s1);
+    const Material a = s->sc.materials[m1], b = s->sc.materials[m2];
+    if (a.lobes.size() + b.lobes.size() > 8) { s->err = "mix: more than MAX_BXDFS = 8 lobes (bsdf.rs:119-125 asserts)"; return -1; }
+    for (Lobe l : a.lobes) { if (l.n_scale >= 2) { s->err = "mix nested deeper than two levels"; return -5; } l.scale[l.n_scale++] = s1; m.lobes.push_back(l); }
+    for (Lobe l : b.lobes) { if (l.n_scale >= 2) { s->err = "mix nested deeper than two levels"; return -5; } l.scale[l.n_scale++] = s2; m.lobes.push_back(l); }
+    return push_material(s, m, out_id);
+}
+
 // BSDF probe for pinning tests: the material's BSDF in the canonical frame (ns = ng = +z, ss = +x).
 //   op 0: out[0..2] = f(wo, wi, flags), out[3] = pdf(wo, wi, flags)
 //   op 1: sample_f(wo, u, flags): out[0..2] = f, out[3] = pdf, out[4..6] = wi, out[7] = sampled BxDFType

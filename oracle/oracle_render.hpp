@@ -678,9 +678,25 @@ struct Renderer {
             return flip ? -wh : wh;
         }
         // ---- per-lobe f / pdf / sample_f ----------------------------------------------------------------------------------
-        static Spec lobe_f(const Lobe& l, V3 wo, V3 wi) {
+        static Float pow5(Float v) { return (v * v) * (v * v) * v; }  // pbrt/common.rs:345-347
+        static Spec lobe_f(const Lobe& l, V3 wo, V3 wi) {  // ScaledBxDF::f (scaled_bxdf.rs:27-29), innermost wrapper first
+            Spec f = lobe_f_raw(l, wo, wi);
+            for (int k = 0; k < l.n_scale; k++) f = l.scale[k] * f;
+            return f;
+        }
+        static Spec lobe_f_raw(const Lobe& l, V3 wo, V3 wi) {
             switch (l.kind) {
             case LK_LAMBERT: return l.r * INV_PI;  // lambertian_reflection.rs:38-40
+            case LK_LAMBERT_T: return l.t * INV_PI;  // lambertian_transmission.rs:24-26
+            case LK_FRESNEL_BLEND: {  // fresnel_blend.rs:32-50 (rd = l.r, rs = l.t)
+                Spec diffuse = (28.0f / (23.0f * PI)) * l.r * (Spec(1.0f) - l.t) * (1.0f - pow5(1.0f - 0.5f * pabs(wi.z))) * (1.0f - pow5(1.0f - 0.5f * pabs(wo.z)));
+                V3 wh = wi + wo;
+                if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return Spec(0.0f);
+                wh = normalize(wh);
+                Spec schlick = l.t + (Spec(1.0f) - l.t) * pow5(1.0f - dot(wi, wh));
+                Spec specular = tr_d(l, wh) / (4.0f * abs_dot(wi, wh) * pmax(pabs(wi.z), pabs(wo.z))) * schlick;
+                return diffuse + specular;
+            }
             case LK_OREN: {  // oren_nayar.rs:46-72
                 Float sin_i = sinth(wi), sin_o = sinth(wo), max_cos = 0.0f;
                 if (sin_i > 1e-4f && sin_o > 1e-4f) {
@@ -720,6 +736,13 @@ struct Renderer {
         static Float lobe_pdf(const Lobe& l, V3 wo, V3 wi) {
             switch (l.kind) {
             case LK_LAMBERT: case LK_OREN: return same_hemisphere(wo, wi) ? pabs(wi.z) * INV_PI : 0.0f;  // reflection/mod.rs:160-166
+            case LK_LAMBERT_T: return !same_hemisphere(wo, wi) ? pabs(wi.z) * INV_PI : 0.0f;           // lambertian_transmission.rs:36-42
+            case LK_FRESNEL_BLEND: {  // fresnel_blend.rs:77-85
+                if (!same_hemisphere(wo, wi)) return 0.0f;
+                V3 wh = normalize(wo + wi);
+                Float pdf_wh = tr_pdf(l, wo, wh);
+                return 0.5f * (pabs(wi.z) * INV_PI + pdf_wh / (4.0f * dot(wo, wh)));
+            }
             case LK_MICRO_R: {
                 if (!same_hemisphere(wo, wi)) return 0.0f;
                 V3 wh = normalize(wo + wi);
@@ -738,13 +761,38 @@ struct Renderer {
             }
         }
         // returns the sampled BxDFType; f/pdf/wi zero where the reference returns BxDFSample::from(type)
-        static int lobe_sample_f(const Lobe& l, V3 wo, V2 u, Spec& f, Float& pdf, V3& wi) {
+        static int lobe_sample_f(const Lobe& l, V3 wo, V2 u, Spec& f, Float& pdf, V3& wi) {  // ScaledBxDF::sample_f (scaled_bxdf.rs:31-35)
+            int st = lobe_sample_f_raw(l, wo, u, f, pdf, wi);
+            for (int k = 0; k < l.n_scale; k++) f = l.scale[k] * f;
+            return st;
+        }
+        static int lobe_sample_f_raw(const Lobe& l, V3 wo, V2 u, Spec& f, Float& pdf, V3& wi) {
             f = Spec(0.0f); pdf = 0.0f; wi = V3();
             switch (l.kind) {
+            case LK_LAMBERT_T: {  // lambertian_transmission.rs:28-35
+                wi = cosine_sample_hemisphere(u);
+                if (wo.z > 0.0f) wi.z *= -1.0f;
+                pdf = lobe_pdf(l, wo, wi); f = lobe_f_raw(l, wo, wi);
+                return l.type;
+            }
+            case LK_FRESNEL_BLEND: {  // fresnel_blend.rs:52-75
+                if (u.x < 0.5f) {
+                    u.x = pmin(2.0f * u.x, ONE_MINUS_EPSILON);
+                    wi = cosine_sample_hemisphere(u);
+                    if (wo.z < 0.0f) wi.z *= -1.0f;
+                } else {
+                    u.x = pmin(2.0f * (u.x - 0.5f), ONE_MINUS_EPSILON);
+                    V3 wh = tr_sample_wh(l, wo, u);
+                    wi = reflect(wo, wh);
+                    if (!same_hemisphere(wo, wi)) return l.type;  // f = 0, pdf = 0
+                }
+                pdf = lobe_pdf(l, wo, wi); f = lobe_f_raw(l, wo, wi);
+                return l.type;
+            }
             case LK_LAMBERT: case LK_OREN: {  // reflection/mod.rs:132-141
                 wi = cosine_sample_hemisphere(u);
                 if (wo.z < 0.0f) wi.z *= -1.0f;
-                pdf = lobe_pdf(l, wo, wi); f = lobe_f(l, wo, wi);
+                pdf = lobe_pdf(l, wo, wi); f = lobe_f_raw(l, wo, wi);
                 return l.type;
             }
             case LK_SPEC_R: {  // specular_reflection.rs:38-44
@@ -788,7 +836,7 @@ struct Renderer {
                 wi = reflect(wo, wh);
                 if (!same_hemisphere(wo, wi)) return l.type;  // f = 0, pdf = 0, wi kept
                 pdf = tr_pdf(l, wo, wh) / (4.0f * dot(wo, wh));
-                f = lobe_f(l, wo, wi);
+                f = lobe_f_raw(l, wo, wi);
                 return l.type;
             }
             case LK_MICRO_T: {  // microfacet_transmission.rs:97-120
@@ -799,7 +847,7 @@ struct Renderer {
                 V3 wt;
                 if (!refract(wo, wh, eta, wt)) return l.type;
                 wi = wt;
-                pdf = lobe_pdf(l, wo, wi); f = lobe_f(l, wo, wi);
+                pdf = lobe_pdf(l, wo, wi); f = lobe_f_raw(l, wo, wi);
                 return l.type;
             }
             }

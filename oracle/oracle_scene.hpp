@@ -26,7 +26,7 @@ struct Ray {  // core/src/geometry/ray.rs:10-28 (differentials are dead for cons
 // A material with constant textures always produces the same list of BxDFs (compute_scattering_functions only evaluates
 // textures), so the list is made once when the material is created.  core/src/reflection/*, materials/src/*.rs
 enum { BX_REFL = 1, BX_TRANS = 2, BX_DIFF = 4, BX_GLOSSY = 8, BX_SPEC = 16, BX_ALL = 31 };  // BxDFType (bsdf.rs:10-20)
-enum LobeKind { LK_LAMBERT = 0, LK_OREN = 1, LK_SPEC_R = 2, LK_SPEC_T = 3, LK_FRESNEL_SPEC = 4, LK_MICRO_R = 5, LK_MICRO_T = 6 };
+enum LobeKind { LK_LAMBERT = 0, LK_OREN = 1, LK_SPEC_R = 2, LK_SPEC_T = 3, LK_FRESNEL_SPEC = 4, LK_MICRO_R = 5, LK_MICRO_T = 6, LK_FRESNEL_BLEND = 7, LK_LAMBERT_T = 8 };
 enum FresnelKind { FR_NOOP = 0, FR_DIEL = 1, FR_COND = 2 };
 struct Lobe {
     int kind = LK_LAMBERT, type = BX_REFL | BX_DIFF, fresnel = FR_NOOP;
@@ -35,6 +35,7 @@ struct Lobe {
     Float ax = 0, ay = 0;      // Trowbridge-Reitz alpha (already max(0.001, .))
     Float eta_a = 1, eta_b = 1;  // dielectric indices (Fresnel eta_i/eta_t, or etaA/etaB of the transmission lobes)
     Spec c_eta_i, c_eta_t, c_k;  // conductor Fresnel
+    int n_scale = 0; Spec scale[2];  // ScaledBxDF wrappers of MixMaterial, innermost first (scaled_bxdf.rs)
 };
 struct Material { Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; };
 

@@ -445,6 +445,64 @@ int pbrt_hip_add_material_uber(PbrtHipScene* s, const float kd[3], const float k
     return push_material(s, m, lobes, true, out_id);
 }
 
+int pbrt_hip_add_material_substrate(PbrtHipScene* s, const float kd[3], const float ks[3], float urough, float vrough, int remap_roughness, uint32_t* out_id) {  // substrate.rs:55-84
+    if (!s || !kd || !ks) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_substrate: null argument");
+    MaterialRec m{}; m.bsdf_eta = 1.0f;
+    std::vector<LobeRec> lobes;
+    float d[3], sp[3];
+    const bool db = clamp3(kd, d), sb = clamp3(ks, sp);
+    if (db || sb) {
+        if (remap_roughness) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
+        LobeRec l = lobe(PH_LK_FRESNEL_BLEND, T_REFL | T_GLOSSY); std::memcpy(l.r, d, 12); std::memcpy(l.t, sp, 12); set_tr(l, urough, vrough);
+        lobes.push_back(l);
+    }
+    return push_material(s, m, lobes, true, out_id);
+}
+int pbrt_hip_add_material_translucent(PbrtHipScene* s, const float kd[3], const float ks[3], const float reflect[3], const float transmit[3], float roughness,
+                                      int remap_roughness, uint32_t* out_id) {  // translucent.rs:57-112
+    if (!s || !kd || !ks || !reflect || !transmit) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_translucent: null argument");
+    MaterialRec m{}; m.bsdf_eta = 1.5f;
+    std::vector<LobeRec> lobes;
+    float r[3], t[3], d[3], sp[3], v[3];
+    const bool rb = clamp3(reflect, r), tb = clamp3(transmit, t);
+    if (!rb && !tb)
+        return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_translucent: reflect = transmit = 0 leaves the BSDF unset in the reference (translucent.rs:73-75); null-BSDF skipping is out of scope");
+    auto prod = [&](const float a[3], const float b[3]) { for (int c = 0; c < 3; c++) v[c] = a[c] * b[c]; };
+    if (clamp3(kd, d)) {
+        if (rb) { LobeRec l = lobe(PH_LK_LAMBERT, T_REFL | T_DIFF); prod(r, d); std::memcpy(l.r, v, 12); lobes.push_back(l); }
+        if (tb) { LobeRec l = lobe(PH_LK_LAMBERT_T, T_TRANS | T_DIFF); prod(t, d); std::memcpy(l.t, v, 12); lobes.push_back(l); }
+    }
+    if (clamp3(ks, sp)) {
+        const float rough = remap_roughness ? roughness_to_alpha(roughness) : roughness;
+        if (rb) { LobeRec l = lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; prod(r, sp); std::memcpy(l.r, v, 12); set_tr(l, rough, rough); lobes.push_back(l); }
+        if (tb) { LobeRec l = lobe(PH_LK_MICRO_T, T_TRANS | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; prod(t, sp); std::memcpy(l.t, v, 12); set_tr(l, rough, rough); lobes.push_back(l); }
+    }
+    return push_material(s, m, lobes, true, out_id);
+}
+int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t material2, const float amount[3], uint32_t* out_id) {  // mix.rs:51-88
+    if (!s || !amount) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: null argument");
+    if (material1 >= s->materials.size() || material2 >= s->materials.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: unknown material id");
+    MaterialRec m{}; m.bsdf_eta = 1.0f;
+    float s1[3], s2[3], tmp[3];
+    clamp3(amount, s1);
+    for (int c = 0; c < 3; c++) tmp[c] = 1.0f - s1[c];
+    clamp3(tmp, s2);
+    const MaterialRec a = s->materials[material1], b = s->materials[material2];
+    if (a.n_lobes + b.n_lobes > 8) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: more than MAX_BXDFS = 8 lobes (BSDF::add asserts, bsdf.rs:119-125)");
+    std::vector<LobeRec> lobes;
+    auto take = [&](const MaterialRec& src, const float sc[3]) {
+        for (uint32_t k = 0; k < src.n_lobes; k++) {
+            LobeRec l = s->lobes[src.lobe_base + k];
+            if (l.n_scale >= 2) return false;
+            std::memcpy(l.n_scale == 0 ? l.scale0 : l.scale1, sc, 12); l.n_scale++;
+            lobes.push_back(l);
+        }
+        return true;
+    };
+    if (!take(a, s1) || !take(b, s2)) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: mix nested deeper than two levels");
+    return push_material(s, m, lobes, true, out_id);
+}
+
 // "the intersection is bogus" (triangle.rs:548-574): depends only on the triangle, so it is decided once here.
 static bool triangle_is_bogus(hm::V3 p0, hm::V3 p1, hm::V3 p2, const float* uv0, const float* uv1, const float* uv2) {
     float u0[2] = {0, 0}, u1[2] = {1, 0}, u2[2] = {1, 1};  // default uvs (triangle.rs:384-394)

@@ -146,8 +146,27 @@ PH_DEV f3 tr_sample_wh(const LobeRec& l, f3 wo, f2 u) {
 }
 
 // ---- per-lobe f / pdf / sample_f ------------------------------------------------------------------------------------------------
-PH_DEV spec lobe_f(const LobeRec& l, f3 wo, f3 wi) {
+PH_DEV float pow5(float v) { return (v * v) * (v * v) * v; }  // pbrt/common.rs:345-347
+PH_DEV spec lobe_f_raw(const LobeRec& l, f3 wo, f3 wi);
+PH_DEV spec apply_scales(const LobeRec& l, spec f) {  // ScaledBxDF (scaled_bxdf.rs:27-35), innermost wrapper first
+    if (l.n_scale > 0u) f = sp3(l.scale0) * f;
+    if (l.n_scale > 1u) f = sp3(l.scale1) * f;
+    return f;
+}
+PH_DEV spec lobe_f(const LobeRec& l, f3 wo, f3 wi) { return apply_scales(l, lobe_f_raw(l, wo, wi)); }
+PH_DEV spec lobe_f_raw(const LobeRec& l, f3 wo, f3 wi) {
     switch (l.kind) {
+    case PH_LK_LAMBERT_T: return sp3(l.t) * kInvPi;  // lambertian_transmission.rs:24-26
+    case PH_LK_FRESNEL_BLEND: {  // fresnel_blend.rs:32-50 (Rd = l.r, Rs = l.t)
+        const spec rd = sp3(l.r), rs = sp3(l.t);
+        const spec diffuse = ph_div(28.0f, 23.0f * kPi) * rd * spec_sub(mks1(1.0f), rs) * (1.0f - pow5(1.0f - 0.5f * pabs(wi.z))) * (1.0f - pow5(1.0f - 0.5f * pabs(wo.z)));
+        f3 wh = wi + wo;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mks1(0.0f);
+        wh = normalize(wh);
+        const spec schlick = rs + spec_sub(mks1(1.0f), rs) * pow5(1.0f - dot(wi, wh));
+        const spec specular = ph_div(tr_d(l, wh), 4.0f * abs_dot(wi, wh) * pmaxf(pabs(wi.z), pabs(wo.z))) * schlick;
+        return diffuse + specular;
+    }
     case PH_LK_LAMBERT: return sp3(l.r) * kInvPi;  // lambertian_reflection.rs:38-40
     case PH_LK_OREN: {  // oren_nayar.rs:46-72
         const float sin_i = sin_theta(wi), sin_o = sin_theta(wo);
@@ -190,6 +209,13 @@ PH_DEV spec lobe_f(const LobeRec& l, f3 wo, f3 wi) {
 PH_DEV float lobe_pdf(const LobeRec& l, f3 wo, f3 wi) {
     switch (l.kind) {
     case PH_LK_LAMBERT: case PH_LK_OREN: return g_same_hemi(wo, wi) ? pabs(wi.z) * kInvPi : 0.0f;  // reflection/mod.rs:160-166
+    case PH_LK_LAMBERT_T: return !g_same_hemi(wo, wi) ? pabs(wi.z) * kInvPi : 0.0f;            // lambertian_transmission.rs:36-42
+    case PH_LK_FRESNEL_BLEND: {  // fresnel_blend.rs:77-85
+        if (!g_same_hemi(wo, wi)) return 0.0f;
+        const f3 wh = normalize(wo + wi);
+        const float pdf_wh = tr_pdf(l, wo, wh);
+        return 0.5f * (pabs(wi.z) * kInvPi + ph_div(pdf_wh, 4.0f * dot(wo, wh)));
+    }
     case PH_LK_MICRO_R: {
         if (!g_same_hemi(wo, wi)) return 0.0f;
         const f3 wh = normalize(wo + wi);
@@ -208,13 +234,39 @@ PH_DEV float lobe_pdf(const LobeRec& l, f3 wo, f3 wi) {
     }
 }
 // returns the sampled BxDFType; f / pdf / wi are zero where the reference returns BxDFSample::from(type)
+PH_DEV uint32_t lobe_sample_f_raw(const LobeRec& l, f3 wo, f2 u, spec& f, float& pdf, f3& wi);
 PH_DEV uint32_t lobe_sample_f(const LobeRec& l, f3 wo, f2 u, spec& f, float& pdf, f3& wi) {
+    const uint32_t st = lobe_sample_f_raw(l, wo, u, f, pdf, wi);
+    f = apply_scales(l, f);
+    return st;
+}
+PH_DEV uint32_t lobe_sample_f_raw(const LobeRec& l, f3 wo, f2 u, spec& f, float& pdf, f3& wi) {
     f = mks1(0.0f); pdf = 0.0f; wi = mk3(0.0f, 0.0f, 0.0f);
     switch (l.kind) {
+    case PH_LK_LAMBERT_T: {  // lambertian_transmission.rs:28-35
+        wi = cosine_sample_hemisphere(u);
+        if (wo.z > 0.0f) wi.z *= -1.0f;
+        pdf = lobe_pdf(l, wo, wi); f = lobe_f_raw(l, wo, wi);
+        return l.type;
+    }
+    case PH_LK_FRESNEL_BLEND: {  // fresnel_blend.rs:52-75
+        if (u.x < 0.5f) {
+            u.x = pminf(2.0f * u.x, kOneMinusEps);
+            wi = cosine_sample_hemisphere(u);
+            if (wo.z < 0.0f) wi.z *= -1.0f;
+        } else {
+            u.x = pminf(2.0f * (u.x - 0.5f), kOneMinusEps);
+            const f3 wh = tr_sample_wh(l, wo, u);
+            wi = g_reflect(wo, wh);
+            if (!g_same_hemi(wo, wi)) return l.type;
+        }
+        pdf = lobe_pdf(l, wo, wi); f = lobe_f_raw(l, wo, wi);
+        return l.type;
+    }
     case PH_LK_LAMBERT: case PH_LK_OREN: {  // reflection/mod.rs:132-141
         wi = cosine_sample_hemisphere(u);
         if (wo.z < 0.0f) wi.z *= -1.0f;
-        pdf = lobe_pdf(l, wo, wi); f = lobe_f(l, wo, wi);
+        pdf = lobe_pdf(l, wo, wi); f = lobe_f_raw(l, wo, wi);
         return l.type;
     }
     case PH_LK_SPEC_R: {  // specular_reflection.rs:38-44
@@ -258,7 +310,7 @@ PH_DEV uint32_t lobe_sample_f(const LobeRec& l, f3 wo, f2 u, spec& f, float& pdf
         wi = g_reflect(wo, wh);
         if (!g_same_hemi(wo, wi)) return l.type;
         pdf = ph_div(tr_pdf(l, wo, wh), 4.0f * dot(wo, wh));
-        f = lobe_f(l, wo, wi);
+        f = lobe_f_raw(l, wo, wi);
         return l.type;
     }
     case PH_LK_MICRO_T: {  // microfacet_transmission.rs:97-120
@@ -269,7 +321,7 @@ PH_DEV uint32_t lobe_sample_f(const LobeRec& l, f3 wo, f2 u, spec& f, float& pdf
         f3 wt;
         if (!g_refract(wo, wh, eta, wt)) return l.type;
         wi = wt;
-        pdf = lobe_pdf(l, wo, wi); f = lobe_f(l, wo, wi);
+        pdf = lobe_pdf(l, wo, wi); f = lobe_f_raw(l, wo, wi);
         return l.type;
     }
     default: return l.type;

@@ -59,10 +59,11 @@ struct MeshRec {
 
 // One BxDF of a material's BSDF (core/src/reflection/*.rs).  Constant textures make the list a property of the material, so the
 // host builds it (api.hip) and the device walks it (bsdf_general.h).
-enum { PH_LK_LAMBERT = 0, PH_LK_OREN = 1, PH_LK_SPEC_R = 2, PH_LK_SPEC_T = 3, PH_LK_FRESNEL_SPEC = 4, PH_LK_MICRO_R = 5, PH_LK_MICRO_T = 6 };
+enum { PH_LK_LAMBERT = 0, PH_LK_OREN = 1, PH_LK_SPEC_R = 2, PH_LK_SPEC_T = 3, PH_LK_FRESNEL_SPEC = 4, PH_LK_MICRO_R = 5, PH_LK_MICRO_T = 6,
+       PH_LK_FRESNEL_BLEND = 7 /* r = Rd, t = Rs */, PH_LK_LAMBERT_T = 8 };
 enum { PH_FR_NOOP = 0, PH_FR_DIEL = 1, PH_FR_COND = 2 };
 struct alignas(16) LobeRec {
-    uint32_t kind, type, fresnel, pad0;   // type = BxDFType bits (bsdf.rs:10-20)
+    uint32_t kind, type, fresnel, n_scale; // type = BxDFType bits (bsdf.rs:10-20); n_scale = ScaledBxDF wrappers around the lobe (mix.rs)
     float a, b;                           // Oren-Nayar A, B
     float ax, ay;                         // Trowbridge-Reitz alpha_x, alpha_y (already max(0.001, .))
     float eta_a, eta_b, pad1[2];          // dielectric Fresnel (eta_i, eta_t) / transmission lobes (etaA, etaB)
@@ -70,6 +71,8 @@ struct alignas(16) LobeRec {
     float t[3], pad3;
     float c_eta_t[3], pad4;               // conductor Fresnel: eta_t and k (eta_i is ONE, metal.rs:84-88)
     float c_k[3], pad5;
+    float scale0[3], pad6;                // innermost ScaledBxDF scale
+    float scale1[3], pad7;
 };
 
 struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant textures) + the general lobe list

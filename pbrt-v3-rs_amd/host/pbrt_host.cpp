@@ -178,6 +178,31 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
     if (!verify_world("Texture")) return;
     const bool is_float = type == "float", is_spec = type == "color" || type == "spectrum";
     if (!is_float && !is_spec) { warn("Texture type '" + type + "' unknown."); return; }
+    // "scale" and "mix" of constant textures are constant: fold them (textures/src/scale.rs:38-40 tex1 * tex2; mix.rs:44-49 (1 - amt) * t1 + amt * t2)
+    if (tex_class == "scale" || tex_class == "mix") {
+        bool ok = true;
+        auto fget = [&](const char* n, float d) {
+            std::string tn = p.find_one_texture(n);
+            if (!tn.empty()) { auto it = gs_.float_textures.find(tn); if (it != gs_.float_textures.end()) return it->second; ok = false; }
+            return p.find_one_float(n, d);
+        };
+        auto sget = [&](const char* n, std::array<float, 3> d) {
+            std::string tn = p.find_one_texture(n);
+            if (!tn.empty()) { auto it = gs_.spectrum_textures.find(tn); if (it != gs_.spectrum_textures.end()) return it->second; ok = false; }
+            return p.find_one_rgb(n, d);
+        };
+        if (is_float) {
+            const float t1 = fget("tex1", tex_class == "scale" ? 1.0f : 0.0f), t2 = fget("tex2", 1.0f);
+            const float v = tex_class == "scale" ? t1 * t2 : ((1.0f - fget("amount", 0.5f)) * t1 + fget("amount", 0.5f) * t2);
+            if (ok) { gs_.unsupported_textures.erase(name); gs_.float_textures[name] = v; return; }
+        } else {
+            const std::array<float, 3> t1 = sget("tex1", tex_class == "scale" ? std::array<float, 3>{1, 1, 1} : std::array<float, 3>{0, 0, 0}), t2 = sget("tex2", {1, 1, 1});
+            std::array<float, 3> v;
+            const float amt = fget("amount", 0.5f);
+            for (int c = 0; c < 3; c++) v[c] = tex_class == "scale" ? t1[c] * t2[c] : ((1.0f - amt) * t1[c] + amt * t2[c]);
+            if (ok) { gs_.unsupported_textures.erase(name); gs_.spectrum_textures[name] = v; return; }
+        }
+    }
     if (tex_class != "constant") {  // the device evaluates constant textures only (SURVEY §8f "next")
         gs_.unsupported_textures[name] = tex_class;
         gs_.float_textures.erase(name); gs_.spectrum_textures.erase(name);
@@ -325,8 +350,30 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
         a3 = spectrum_tex("Kd", quarter); b3 = spectrum_tex("Ks", quarter); c3 = spectrum_tex("Kr", zero); d3 = spectrum_tex("Kt", zero); e3 = spectrum_tex("opacity", one);
         uv_rough(0.1f, f0, f1); f2 = eta_of();
         put3(a3); put3(b3); put3(c3); put3(d3); put3(e3); kv.push_back(f0); kv.push_back(f1); kv.push_back(f2);
+    } else if (t == "substrate") {
+        a3 = spectrum_tex("Kd", {0.5f, 0.5f, 0.5f}); b3 = spectrum_tex("Ks", {0.5f, 0.5f, 0.5f}); f0 = float_tex("uroughness", 0.1f); f1 = float_tex("vroughness", 0.1f);
+        put3(a3); put3(b3); kv.push_back(f0); kv.push_back(f1);
+    } else if (t == "translucent") {
+        a3 = spectrum_tex("Kd", quarter); b3 = spectrum_tex("Ks", quarter); c3 = spectrum_tex("reflect", {0.5f, 0.5f, 0.5f}); d3 = spectrum_tex("transmit", {0.5f, 0.5f, 0.5f});
+        f0 = float_tex("roughness", 0.1f);
+        put3(a3); put3(b3); put3(c3); put3(d3); kv.push_back(f0);
+    } else if (t == "mix") {  // graphics_state.rs:310-330: two named materials, an unknown name falls back to matte made from the same parameters
+        a3 = spectrum_tex("amount", {0.5f, 0.5f, 0.5f}); put3(a3);
+        uint32_t sub[2];
+        const char* pn[2] = {"namedmaterial1", "namedmaterial2"};
+        for (int k = 0; k < 2; k++) {
+            const std::string nm = m.params.find_one_string(pn[k], "");
+            auto it = gs_.named_materials.find(nm);
+            MaterialDesc md;
+            if (it != gs_.named_materials.end()) md = it->second;
+            else { warn("Named material '" + nm + "' undefined. Using 'matte'."); md.type = "matte"; md.params = m.params; }
+            sub[k] = material_id_for(md);
+            if (!error.empty()) return 0;
+            kv.push_back((float)sub[k]);
+        }
+        f0 = (float)sub[0]; f1 = (float)sub[1];
     } else {
-        if (error.empty()) error = "Material \"" + t + "\" is outside the hot-path scope (supported: matte, mirror, plastic, glass, metal, uber)";
+        if (error.empty()) error = "Material \"" + t + "\" is outside the hot-path scope (supported: matte, mirror, plastic, glass, metal, uber, substrate, translucent, mix)";
         return 0;
     }
     if (!error.empty()) return 0;
@@ -341,6 +388,9 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     else if (t == "plastic") rc = ABI(pbrt_hip_add_material_plastic(scene_, a3.data(), b3.data(), f0, remap ? 1 : 0, &id));
     else if (t == "glass") rc = ABI(pbrt_hip_add_material_glass(scene_, a3.data(), b3.data(), f0, f1, f2, remap ? 1 : 0, &id));
     else if (t == "metal") rc = ABI(pbrt_hip_add_material_metal(scene_, a3.data(), b3.data(), f0, f1, remap ? 1 : 0, &id));
+    else if (t == "substrate") rc = ABI(pbrt_hip_add_material_substrate(scene_, a3.data(), b3.data(), f0, f1, remap ? 1 : 0, &id));
+    else if (t == "translucent") rc = ABI(pbrt_hip_add_material_translucent(scene_, a3.data(), b3.data(), c3.data(), d3.data(), f0, remap ? 1 : 0, &id));
+    else if (t == "mix") rc = ABI(pbrt_hip_add_material_mix(scene_, (uint32_t)f0, (uint32_t)f1, a3.data(), &id));
     else rc = ABI(pbrt_hip_add_material_uber(scene_, a3.data(), b3.data(), c3.data(), d3.data(), e3.data(), f0, f1, f2, remap ? 1 : 0, &id));
     if (!check(rc, "add_material")) return 0;
     material_cache_[key] = id;
@@ -404,7 +454,7 @@ void Api::pbrt_shape(const std::string& name, const ParamSet& p, const std::stri
 
     // material: shape parameters override the material's (TextureParams looks in the shape's set first, graphics_state.rs:147-165)
     MaterialDesc eff = gs_.material;
-    static const char* kMatParams[] = {"Kd", "Ks", "Kr", "Kt", "sigma", "roughness", "uroughness", "vroughness", "eta", "index", "k", "opacity", "bumpmap"};
+    static const char* kMatParams[] = {"Kd", "Ks", "Kr", "Kt", "sigma", "roughness", "uroughness", "vroughness", "eta", "index", "k", "opacity", "bumpmap", "reflect", "transmit", "amount"};
     for (const char* name : kMatParams) {
         auto f = p.floats.find(name); auto tx = p.textures.find(name);
         if (tx != p.textures.end()) { eff.params.textures[name] = tx->second; eff.params.floats.erase(name); }

@@ -106,6 +106,9 @@ class Binding:
             "add_material_glass": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, u32p]),
             "add_material_metal": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_int, u32p]),
             "add_material_uber": (C.c_int, [vp, fp, fp, fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, u32p]),
+            "add_material_substrate": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_int, u32p]),
+            "add_material_translucent": (C.c_int, [vp, fp, fp, fp, fp, C.c_float, C.c_int, u32p]),
+            "add_material_mix": (C.c_int, [vp, C.c_uint32, C.c_uint32, fp, u32p]),
             "object_begin": (C.c_int, [vp, u32p]),
             "object_end": (C.c_int, [vp]),
             "add_instance": (C.c_int, [vp, C.c_uint32, fp, fp]),
@@ -330,6 +333,15 @@ class Scene:
                           eta=1.5, remap_roughness=True) -> int:
         return self._mat("add_material_uber", self._rgb(kd), self._rgb(ks), self._rgb(kr), self._rgb(kt), self._rgb(opacity), C.c_float(uroughness),
                          C.c_float(vroughness), C.c_float(eta), int(remap_roughness))
+
+    def add_material_substrate(self, kd=(0.5, 0.5, 0.5), ks=(0.5, 0.5, 0.5), uroughness=0.1, vroughness=0.1, remap_roughness=True) -> int:
+        return self._mat("add_material_substrate", self._rgb(kd), self._rgb(ks), C.c_float(uroughness), C.c_float(vroughness), int(remap_roughness))
+
+    def add_material_translucent(self, kd=(0.25,) * 3, ks=(0.25,) * 3, reflect=(0.5,) * 3, transmit=(0.5,) * 3, roughness=0.1, remap_roughness=True) -> int:
+        return self._mat("add_material_translucent", self._rgb(kd), self._rgb(ks), self._rgb(reflect), self._rgb(transmit), C.c_float(roughness), int(remap_roughness))
+
+    def add_material_mix(self, material1, material2, amount=(0.5, 0.5, 0.5)) -> int:
+        return self._mat("add_material_mix", int(material1), int(material2), self._rgb(amount))
 
     def add_mesh(self, P, indices, material, N=None, S=None, UV=None, first_area_light=-1, reverse_orientation=False,
                  swaps_handedness=False, alpha=1.0, shadow_alpha=1.0):

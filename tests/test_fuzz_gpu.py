@@ -14,7 +14,7 @@ I4 = (np.eye(4, dtype=np.float32).reshape(16),) * 2
 
 
 def random_material(s, rng):
-    k = rng.integers(0, 7)
+    k = rng.integers(0, 10)
     c = lambda lo=0.05, hi=0.95: tuple(rng.uniform(lo, hi, 3).astype(np.float32))
     if k == 0:
         return s.add_material_matte(c(), float(rng.choice([0.0, rng.uniform(1, 60)])))
@@ -30,6 +30,14 @@ def random_material(s, rng):
     if k == 5:
         op = float(rng.choice([1.0, rng.uniform(0.3, 0.9)]))
         return s.add_material_uber(c(), c(0.05, 0.4), c(0, 0.3), c(0, 0.3), (op, op, op), float(rng.uniform(0.02, 0.3)), float(rng.uniform(0.02, 0.3)), float(rng.uniform(1.1, 1.7)), True)
+    if k == 6:
+        return s.add_material_substrate(c(), c(0.05, 0.6), float(rng.uniform(0.02, 0.4)), float(rng.uniform(0.02, 0.4)), bool(rng.integers(0, 2)))
+    if k == 7:
+        return s.add_material_translucent(c(), c(0, 0.5), c(0.1, 0.9), c(0, 0.9), float(rng.uniform(0.02, 0.3)), True)
+    if k == 8:
+        a = s.add_material_plastic(c(), c(0.05, 0.5), float(rng.uniform(0.01, 0.4)), True)
+        b = s.add_material_mirror(c(0.3, 1.0)) if rng.integers(0, 2) else s.add_material_glass(c(0.5, 1), c(0.5, 1), 0.0, 0.0, 1.5, True)
+        return s.add_material_mix(a, b, c(0.1, 0.9))
     return s.add_material_matte((0, 0, 0), 0.0)   # black: no BxDF at all (matte.rs:66)
 
 

@@ -230,3 +230,79 @@ WorldEnd
     finally:
         set_libm_mode(0)
     assert (img.view(np.uint32) == ref.view(np.uint32)).all(), f"{(img != ref).sum()} values differ"
+
+
+def test_mix_substrate_translucent_and_folded_textures_in_a_scene_file(tmp_path, host):
+    quad = "[-1 -1 0 1 -1 0 1 1 0 -1 1 0]"
+    text = f"""LookAt 0 -5 2  0 0 0.4  0 0 1
+Camera "perspective" "float fov" 50
+Film "image" "integer xresolution" 32 "integer yresolution" 24 "string filename" "x.pfm"
+Sampler "halton" "integer pixelsamples" 8
+Integrator "path" "integer maxdepth" 5
+WorldBegin
+LightSource "infinite" "rgb L" [0.8 0.9 1.0]
+LightSource "spot" "point from" [0 -2 3] "point to" [0 0 0] "rgb I" [30 30 30] "float coneangle" 40 "float conedeltaangle" 15
+Texture "a" "color" "constant" "rgb value" [0.8 0.6 0.4]
+Texture "b" "color" "constant" "rgb value" [0.5 0.5 1.0]
+Texture "ab" "color" "scale" "texture tex1" "a" "texture tex2" "b"
+Texture "half" "float" "constant" "float value" 0.25
+Texture "blend" "color" "mix" "texture tex1" "a" "rgb tex2" [0.1 0.9 0.1] "texture amount" "half"
+MakeNamedMaterial "base" "string type" "matte" "texture Kd" "ab"
+MakeNamedMaterial "coat" "string type" "mirror" "rgb Kr" [0.8 0.8 0.8]
+MakeNamedMaterial "both" "string type" "mix" "string namedmaterial1" "base" "string namedmaterial2" "coat" "rgb amount" [0.6 0.6 0.6]
+AttributeBegin
+  Material "substrate" "texture Kd" "blend" "rgb Ks" [0.2 0.2 0.2] "float uroughness" 0.05
+  Scale 2.5 2.5 1
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" {quad}
+AttributeEnd
+AttributeBegin
+  NamedMaterial "both"
+  Translate -1.0 0.3 0.7
+  Rotate 70 1 0 0
+  Scale 0.7 0.7 0.7
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" {quad}
+AttributeEnd
+AttributeBegin
+  Material "translucent" "rgb Kd" [0.5 0.5 0.3] "rgb transmit" [0.7 0.7 0.7]
+  Translate 1.0 0 0.8
+  Rotate 85 1 0 0.3
+  Scale 0.7 0.7 0.7
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" {quad}
+AttributeEnd
+WorldEnd
+"""
+    (tmp_path / "x.pbrt").write_text(text)
+    r = subprocess.run([ds.RENDER_BIN, "--quiet", str(tmp_path / "x.pbrt")], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    img = ds.read_pfm(str(tmp_path / "x.pfm"))
+    Q = np.float32([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]]); QI = [0, 1, 2, 0, 2, 3]
+    I = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+    mul = host.compose
+    f32 = np.float32
+
+    def put(o, t, mat):
+        o.add_mesh(host.transform_points(t[0], Q), QI, mat, swaps_handedness=host.swaps_handedness(t[0]))
+    set_libm_mode(1)
+    try:
+        with OracleScene() as o:
+            w2c = mul(I, host.look_at([0, -5, 2], [0, 0, 0.4], [0, 0, 1]))
+            o.add_light_infinite((0.8, 0.9, 1.0))
+            o.add_light_spot(f32([30, 30, 30]), *host.spot(I, [0, -2, 3], [0, 0, 0], 40.0, 15.0))
+            a, b = f32([0.8, 0.6, 0.4]), f32([0.5, 0.5, 1.0])
+            ab = a * b
+            blend = (f32(1.0) - f32(0.25)) * a + f32(0.25) * f32([0.1, 0.9, 0.1])
+            put(o, mul(I, host.scale([2.5, 2.5, 1])), o.add_material_substrate(blend, (0.2, 0.2, 0.2), 0.05, 0.1, True))
+            t = mul(mul(mul(I, host.translate([-1.0, 0.3, 0.7])), host.rotate(70, [1, 0, 0])), host.scale([0.7, 0.7, 0.7]))
+            put(o, t, o.add_material_mix(o.add_material_matte(ab, 0.0), o.add_material_mirror((0.8, 0.8, 0.8)), (0.6, 0.6, 0.6)))
+            t = mul(mul(mul(I, host.translate([1.0, 0, 0.8])), host.rotate(85, [1, 0, 0.3])), host.scale([0.7, 0.7, 0.7]))
+            put(o, t, o.add_material_translucent((0.5, 0.5, 0.3), (0.25,) * 3, (0.5,) * 3, (0.7, 0.7, 0.7), 0.1, True))
+            o.set_camera_perspective(host.perspective_raster_to_camera(50.0, 32, 24), w2c[1])
+            cb, table, sb = host.film_box(32, 24)
+            o.set_film(32, 24, cb, (0.5, 0.5), table)
+            o.set_sampler(0, 8, sb)
+            o.build_accel(0, 4)
+            xyz, wt, st = o.render_path(max_depth=5, light_strategy=2, pixel_bounds=sb)
+            ref = o.film_to_rgb(xyz, wt).reshape(24, 32, 3)
+    finally:
+        set_libm_mode(0)
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), f"{(img != ref).sum()} values differ"

@@ -76,6 +76,12 @@ MATERIAL_SETS = {
                                    s.add_material_matte((0.5, 0.6, 0.5), 0.0), s.add_material_glass((1, 1, 1), (1, 1, 1), 0.1, 0.25, 1.5, True),
                                    s.add_material_uber((0.3, 0.1, 0.1), (0.3, 0.3, 0.3), (0.2, 0.2, 0.2), (0.4, 0.4, 0.4), (0.7, 0.6, 0.5), 0.05, 0.2, 1.3, True),
                                    s.add_material_glass((1, 1, 1), (0.8, 0.9, 1.0), 0.3, 0.3, 1.6, False)),
+    "substrate_translucent_mix": lambda s: (s.add_material_substrate((0.5, 0.4, 0.3), (0.3, 0.3, 0.3), 0.15, 0.05, True),
+                                            s.add_material_mix(s.add_material_matte((0.7, 0.2, 0.2), 0.0), s.add_material_mirror((0.9, 0.9, 0.9)), (0.7, 0.6, 0.5)),
+                                            s.add_material_translucent((0.4, 0.5, 0.4), (0.3, 0.3, 0.3), (0.5, 0.5, 0.5), (0.6, 0.5, 0.4), 0.1, True),
+                                            s.add_material_mix(s.add_material_mix(s.add_material_plastic(), s.add_material_glass(), (0.5, 0.5, 0.5)),
+                                                               s.add_material_substrate(), (0.3, 0.6, 0.9)),
+                                            s.add_material_translucent((0.25,) * 3, (0, 0, 0), (0, 0, 0), (0.9, 0.9, 0.9), 0.1, False)),
 }
 
 

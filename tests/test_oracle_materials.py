@@ -144,3 +144,48 @@ def test_conductor_fresnel_quirk_b11():
         G = 1.0 / (1.0 + 2 * ((-1 + np.sqrt(1 + (0.3 * np.tan(th)) ** 2)) / 2))
         D = 1.0 / (np.pi * 0.09)
         assert f == pytest.approx(D * G * F / (4 * c * c), rel=2e-4)
+
+
+def test_substrate_translucent_mix():
+    rng = np.random.default_rng(7)
+    with OracleScene() as o:
+        sub = o.add_material_substrate((0.4, 0.3, 0.2), (0.1, 0.2, 0.3), 0.2, 0.1, False)
+        tl = o.add_material_translucent((0.3,) * 3, (0.2,) * 3, (0.6,) * 3, (0.4,) * 3, 0.15, True)
+        matte = o.add_material_matte((0.5, 0.4, 0.3), 0.0)
+        mirror = o.add_material_mirror((0.9, 0.9, 0.9))
+        mix = o.add_material_mix(matte, mirror, (0.25, 0.5, 0.75))
+        mix2 = o.add_material_mix(mix, sub, (0.5, 0.5, 0.5))
+        n = lambda m, fl=ALL: tuple(o.bsdf_probe(m, 2, flags=fl)[:3])
+        assert n(sub)[:2] == (1, 1) and n(tl) == (4, 4, 1.5) and n(mix)[:2] == (2, 2) and n(mix, ALL & ~SPEC)[0] == 1 and n(mix2)[:2] == (3, 3)
+        # FresnelBlend at wo = wi = +z: diffuse = 28/(23 pi) Rd (1 - Rs) (1 - (1/2)^5)^2, specular = D / (4 * 1 * 1) * Rs, D = 1/(pi ax ay)
+        rd, rs = np.array([0.4, 0.3, 0.2]), np.array([0.1, 0.2, 0.3])
+        f = o.bsdf_probe(sub, 0, wo=(0, 0, 1), wi=(0, 0, 1))
+        expect = 28 / (23 * np.pi) * rd * (1 - rs) * (1 - 0.5 ** 5) ** 2 + 1 / (np.pi * 0.2 * 0.1) / 4 * rs
+        assert f[:3] == pytest.approx(expect, rel=1e-5)
+        for _ in range(30):   # reciprocity of the blend and pdf consistency of its two sampling branches
+            wo = sph(rng.uniform(0.05, 1.4), rng.uniform(0, 2 * np.pi)); wi = sph(rng.uniform(0.05, 1.4), rng.uniform(0, 2 * np.pi))
+            a = o.bsdf_probe(sub, 0, wo=wo, wi=wi); b = o.bsdf_probe(sub, 0, wo=wi, wi=wo)
+            # Ashikhmin-Shirley's specular term divides by max(cos_i, cos_o) but uses (wi . wh): reciprocal because wi.wh = wo.wh
+            assert a[0] == pytest.approx(b[0], rel=3e-4)
+            sm = o.bsdf_probe(sub, 1, wo=wo, u=rng.uniform(0.01, 0.99, 2))
+            if sm[3] > 0:
+                e = o.bsdf_probe(sub, 0, wo=wo, wi=sm[4:7])
+                assert e[3] == pytest.approx(sm[3], rel=2e-3) and e[0] == pytest.approx(sm[0], rel=2e-3)
+        # translucent: LambertianTransmission sends wi to the other side with pdf |cos|/pi and f = transmit*Kd/pi
+        wo = sph(0.5, 1.0)
+        got = set()
+        for u0 in np.linspace(0.01, 0.99, 40):
+            sm = o.bsdf_probe(tl, 1, wo=wo, u=(u0, 0.37))
+            if sm[3] > 0:
+                got.add((int(sm[7]), bool(sm[6] * wo[2] > 0)))
+        assert (TRANS | DIFF, False) in got and (REFL | DIFF, True) in got and (REFL | GLOSSY, True) in got
+        ft = o.bsdf_probe(tl, 0, wo=wo, wi=-wo, flags=TRANS | DIFF)
+        assert ft[0] == pytest.approx(0.4 * 0.3 / np.pi, rel=1e-5) and ft[3] == pytest.approx(abs(wo[2]) / np.pi, rel=1e-5)
+        # mix: f = amount * f(matte) (the mirror lobe contributes nothing to f); the mirror branch of sample_f carries (1 - amount)
+        wi = sph(0.9, 2.0)
+        fm = o.bsdf_probe(mix, 0, wo=wo, wi=wi)
+        assert fm[:3] == pytest.approx(np.array([0.25, 0.5, 0.75]) * np.array([0.5, 0.4, 0.3]) / np.pi, rel=1e-5)
+        sm = o.bsdf_probe(mix, 1, wo=wo, u=(0.75, 0.5))       # second of two components: the mirror
+        assert sm[7] == SPEC | REFL and sm[:3] == pytest.approx(np.array([0.75, 0.5, 0.25]) * 0.9 / wo[2], rel=1e-5) and sm[3] == pytest.approx(0.5)
+        with pytest.raises(Exception):
+            o.add_material_translucent((0.3,) * 3, (0.2,) * 3, (0, 0, 0), (0, 0, 0), 0.1, True)
