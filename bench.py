@@ -207,18 +207,21 @@ def main():
                          "kernel_Mrays_per_s": round(n_rays / ext_per_frame / 1e6, 1) if ext_per_frame > 0 else None,
                          "note": "counts from an untimed counting pass of the same frame; time = HIP events around every closest-hit launch of the timed steps"})
         # HBM-side traffic of the same kernel from rocprofv3 PMC passes (separate runs of this script under `rocprofv3 --pmc`,
-        # scripts/pmc_profile.sh; summary committed under profiles/): FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
-        # for gfx950 16-B/lane reads, WRITE_SIZE taken as is.  Only used when it was collected on this exact workload.
+        # scripts/pmc_profile.sh; summary committed under profiles/).  MI355X_MICROARCH.md prescribes doubling FETCH_SIZE for wide coalesced
+        # streaming reads; this kernel's reads are random 64-B lines (4 x dwordx4 per lane), for which a calibration run on a known byte count
+        # (scripts/calib/fetch_calib.hip, profiles/r01_fetch_calibration.txt) shows FETCH_SIZE to be exact — so it is used unscaled.
+        # Only used when it was collected on this exact workload.
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath) and roof.get("achieved"):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == [args.n_tris, args.res, args.spp, args.max_depth, args.seed] and world == 1:
+                if tj.get("workload") == [args.n_tris, args.res, args.spp, args.max_depth, args.seed] and world == 1 and args.material == "matte" and not args.instances:
                     k = tj["closest_hit"]
-                    per_launch = (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"]
+                    per_launch = (float(tj.get("fetch_scale", 1.0)) * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"]
                     roof["traffic"] = int(per_launch)
-                    roof["traffic_note"] = ("HBM-side bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, " + tj.get("source", "profiles/") +
-                                            "); algorithmic bytes are counted in the reference's 32-B-node format, most of them are served by L2/MALL")
+                    roof["traffic_note"] = ("HBM-side bytes per launch from rocprofv3 PMC (FETCH_SIZE + WRITE_SIZE, " + tj.get("source", "profiles/") + "; FETCH_SIZE calibrated exact "
+                                            "for this access pattern, " + tj.get("calibration", "") + "); algorithmic bytes are counted in the reference's 32-B-node format, "
+                                            "most of them are served by L2/MALL (L2 hit %.3f)" % (k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"])))
             except Exception:
                 pass
         out["roofline"] = roof
