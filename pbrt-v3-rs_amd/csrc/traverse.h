@@ -176,6 +176,9 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
 #ifndef PH_BATCH
 #define PH_BATCH 64
 #endif
+#ifndef PH_LEAF_STEPS
+#define PH_LEAF_STEPS 1   // triangles a lane may test per leaf step (a leaf holds up to max_prims_in_node of them)
+#endif
 // INST = true adds object instancing (TransformedPrimitive): a leaf record may name an instance; the lane then carries its ray
 // into instance space, walks the object's aggregate above its current stack height and returns to the scene-level leaf where it
 // left it (same order of primitive tests as the reference's recursion).  Compiled separately so scenes without instances keep
@@ -302,7 +305,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
             if (lm != 0ull) {
                 const uint64_t nm = __ballot(has_ray && cur != PH_INVALID_REF && !(cur & PH_LEAF_BIT));
                 if ((uint32_t)__popcll(lm) >= (uint32_t)LEAF_MIN || nm == 0ull) {
-                    if (at_leaf) {
+#pragma unroll
+                    for (int ls = 0; ls < PH_LEAF_STEPS; ls++)
+                    if (has_ray && cur != PH_INVALID_REF && (cur & PH_LEAF_BIT)) {
                         const uint32_t ti = cur & ~PH_LEAF_BIT;
                         const float4* tp = reinterpret_cast<const float4*>(sc.tris + ti);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
