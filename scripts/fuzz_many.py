@@ -6,9 +6,10 @@ from oracle_binding import OracleScene, set_libm_mode
 import test_fuzz_gpu as T
 host = pbrt_hip.Host()
 first, last = int(sys.argv[1]), int(sys.argv[2])
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 bad = []
 for seed in range(first, last):
-    cap, kw = T.build_case(host, seed)
+    cap, kw = T.build_case(host, seed, big)
     prod = pbrt_hip.Scene(); orc = OracleScene()
     try:
         cb = cap(prod); cap(orc)

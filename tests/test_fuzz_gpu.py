@@ -48,10 +48,13 @@ def random_transform(host, rng, spread=1.5):
     return host.compose(t, host.scale(sc))
 
 
-def build_case(host, seed):
+def build_case(host, seed, big=False):
+    """big: a few hundred thousand paths over thousands of triangles (many shade blocks, several traversal batches per wave)."""
     rng = np.random.default_rng(seed)
     res = (int(rng.integers(17, 41)), int(rng.integers(13, 37)))
     spp = int(rng.choice([1, 2, 3, 5, 8]))
+    if big:
+        res = (int(rng.integers(120, 200)), int(rng.integers(90, 160))); spp = int(rng.choice([4, 8, 12]))
     split = int(rng.choice([0, 0, 0, 3]))
     fkind = str(rng.choice(["box", "gaussian", "mitchell", "triangle", "sinc"]))
     radius = {"box": (0.5, 0.5), "gaussian": (1.5, 2.0), "mitchell": (2.0, 2.0), "triangle": (1.0, 2.0), "sinc": (3.0, 2.5)}[fkind]
@@ -87,7 +90,7 @@ def build_case(host, seed):
         s.add_mesh(P * np.float32(0.4) + np.float32([0, 0, 1.3]), idx, mats[0], first_area_light=lid, reverse_orientation=bool(g.integers(0, 2)))
         # scene-level meshes with optional N / UV / alpha
         for k in range(int(g.integers(1, 4))):
-            P, idx = host.gen_random_tris(int(g.integers(5, 120)), int(g.integers(1, 1000)))
+            P, idx = host.gen_random_tris(int(g.integers(5, 120)) * (60 if big else 1), int(g.integers(1, 1000)))
             N = g.normal(size=P.shape).astype(np.float32) if g.integers(0, 2) else None
             UV = g.uniform(0, 1, (len(P), 2)).astype(np.float32) if g.integers(0, 2) else None
             s.add_mesh(P, idx, mats[k % 4], N=N, UV=UV, reverse_orientation=bool(g.integers(0, 2)), swaps_handedness=bool(g.integers(0, 2)),
@@ -131,3 +134,22 @@ def test_random_scene_film_bit_exact(host, seed):
     assert np.array_equal(gwt.view(np.uint32), owt.view(np.uint32)), seed
     nb = int((gxyz.view(np.uint32) != oxyz.view(np.uint32)).any(axis=2).sum())
     assert nb == 0, f"seed {seed} {kw}: {nb} pixels differ, max abs {np.abs(gxyz - oxyz).max()}"
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_random_scene_medium_size(host, seed):
+    """The same generator at a few hundred thousand paths: many shade blocks per launch, sample chunks, block-local sorting across blocks."""
+    cap, kw = build_case(host, seed, big=True)
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    cb = cap(prod); cap(orc)
+    if (cb[2] - cb[0]) * (cb[3] - cb[1]) <= 0:
+        pytest.skip("empty crop window")
+    set_libm_mode(1)
+    try:
+        oxyz, owt, ost, _ = orc.render_path_ex(**kw)
+    finally:
+        set_libm_mode(0)
+    gxyz, gwt, gst = prod.render_path(**kw)
+    assert (gst.regular_rays, gst.shadow_rays, gst.paths_total, gst.paths_zero_radiance, gst.light_distributions_created) == \
+           (ost.regular_rays, ost.shadow_rays, ost.paths_total, ost.paths_zero_radiance, ost.light_distributions_created), (seed, kw)
+    assert np.array_equal(gwt.view(np.uint32), owt.view(np.uint32)) and np.array_equal(gxyz.view(np.uint32), oxyz.view(np.uint32)), seed
