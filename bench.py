@@ -109,6 +109,7 @@ def main():
     floats = max(scene.tile_buffer_floats(tile_size, p, world) for p in range(world))
     tile_buf = torch.zeros(floats, dtype=torch.float32, device=dev)
     gather_list = [torch.zeros(floats, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()  # the library writes tile_buf on its own stream: torch's fill kernels must have finished
 
     def step():
         st = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=args.max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
