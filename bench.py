@@ -123,8 +123,8 @@ def main():
                 if rank == 0:
                     for g, h in zip(gather_list, host_parts):
                         g.copy_(h)
+            torch.cuda.synchronize()  # the collective runs on torch's stream: finish it before the library reads (rank 0) or rewrites (all) the buffers
             if rank == 0:
-                torch.cuda.synchronize()
                 film = scene.merge_tiles_device([t.data_ptr() for t in gather_list], tile_size)
         else:
             film = scene.merge_tiles_device([tile_buf.data_ptr()], tile_size)
