@@ -103,6 +103,8 @@ int pbrt_hip_add_material_matte(PbrtHipScene*, const float kd_rgb[3], float sigm
  *   mix         materials/src/mix.rs:51-88        the two materials' lobes as ScaledBxDF(amount) / ScaledBxDF(1 - amount); at most 8 lobes,
  *                                               mixes of mixes up to two levels
  * Bump maps are outside the scope (constant textures have no gradient: Material::bump is the identity for them). */
+int pbrt_hip_add_material_none(PbrtHipScene*, uint32_t* out_id);   /* Material "none" / "": no BSDF; PathIntegrator::li passes through the surface without
+                                                                       counting a bounce (integrators/src/path.rs:142-150) */
 int pbrt_hip_add_material_mirror(PbrtHipScene*, const float kr_rgb[3], uint32_t* out_id);
 int pbrt_hip_add_material_plastic(PbrtHipScene*, const float kd_rgb[3], const float ks_rgb[3], float roughness, int remap_roughness, uint32_t* out_id);
 int pbrt_hip_add_material_glass(PbrtHipScene*, const float kr_rgb[3], const float kt_rgb[3], float uroughness, float vroughness, float eta,

@@ -66,6 +66,11 @@ int oracle_add_material_matte(OracleScene* s, const float kd[3], float sigma, ui
     }
     return push_material(s, m, out_id);
 }
+int oracle_add_material_none(OracleScene* s, uint32_t* out_id) {  // Material "none" / "": GeometricPrimitive without a material (geometric_primitive.rs:112-134)
+    if (!s) return -1;
+    Material m; m.none = true;
+    return push_material(s, m, out_id);
+}
 int oracle_add_material_mirror(OracleScene* s, const float kr[3], uint32_t* out_id) {  // mirror.rs:40-62
     if (!s || !kr) return -1;
     Material m; m.general = true;

@@ -1066,7 +1066,11 @@ struct Renderer {
                 }
             }
             if (!found || bounces >= max_depth) break;
-            BSDF bsdf = make_bsdf(isect);  // materials always present in scope
+            if (s.materials[s.mesh_of(isect.prim).material].none) {  // null BSDF: the surface is skipped, bounces does not advance (path.rs:142-150)
+                ray = spawn_ray(isect.p, isect.p_error, isect.n, isect.time, ray.d);
+                continue;
+            }
+            BSDF bsdf = make_bsdf(isect);
             V3 shading_n = isect.ns;
             if (spatial) (void)spatial_lookup(isect.p);  // light_distribution.lookup(&isect.hit.p) happens for every vertex (path.rs:156-157)
             if (bsdf.num_components(BX_ALL & ~BX_SPEC) > 0) {

@@ -37,7 +37,7 @@ struct Lobe {
     Spec c_eta_i, c_eta_t, c_k;  // conductor Fresnel
     int n_scale = 0; Spec scale[2];  // ScaledBxDF wrappers of MixMaterial, innermost first (scaled_bxdf.rs)
 };
-struct Material { Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; };
+struct Material { Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; bool none = false; };  // none: Material "none" / "" -> no BSDF at all
 
 enum LightType { L_INFINITE = 0, L_DISTANT = 1, L_POINT = 2, L_AREA = 3, L_SPOT = 4 };
 struct Light {

@@ -365,6 +365,12 @@ int pbrt_hip_add_material_matte(PbrtHipScene* s, const float kd[3], float sigma_
     }
     return push_material(s, m, lobes, false, out_id);
 }
+int pbrt_hip_add_material_none(PbrtHipScene* s, uint32_t* out_id) {  // Material "none" / "" (graphics_state.rs make_material -> None)
+    if (!s) return PBRT_HIP_ERR_INVALID_ARG;
+    MaterialRec m{}; m.bsdf_eta = 1.0f; m.none = 1u;
+    s->has_none_material = true;
+    return push_material(s, m, {}, false, out_id);
+}
 int pbrt_hip_add_material_mirror(PbrtHipScene* s, const float kr[3], uint32_t* out_id) {  // mirror.rs:40-62
     if (!s || !kr) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mirror: null argument");
     MaterialRec m{}; m.bsdf_eta = 1.0f;
@@ -777,6 +783,7 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
             if (c == sigs.size()) sigs.push_back(sig);
             static const bool no_sort = std::getenv("PBRT_HIP_NO_MATERIAL_SORT") != nullptr;  // measurement aid: every material in one class
             m.sort_class = no_sort ? 0u : (uint32_t)std::min<size_t>(c, 6);
+            if (m.none) m.sort_class = 7u;
         }
     }
     std::vector<uint32_t> build_flags(s->tri_flags);

@@ -25,6 +25,7 @@ struct PbrtHipScene {
     std::vector<MeshRec> meshes;
     std::vector<MaterialRec> materials;
     std::vector<LobeRec> lobes;
+    bool has_none_material = false;  // some material is "none": paths may need more wavefront iterations than max_depth + 1
     bool general_materials = false;  // some material is not matte: the renderer uses the general BSDF kernel
     std::vector<LightRec> lights;
     std::vector<uint32_t> infinite_lights;

@@ -25,7 +25,7 @@ struct alignas(64) Node64 {
 #define PH_TRI_BOGUS 2u  // degenerate: Triangle::intersect returns None after the t test (shapes/src/triangle.rs:567-570)
 #define PH_TRI_ALPHA0 4u   // mesh alpha texture == 0.0 (triangle.rs:603)
 #define PH_TRI_SALPHA0 8u  // mesh shadowalpha texture == 0.0 (triangle.rs:891)
-#define PH_TRI_CLASS_SHIFT 8  // bits 8..10: material class of the triangle (shade-side sorting key), set at build time
+#define PH_TRI_CLASS_SHIFT 8  // bits 8..10: material class of the triangle (shade-side sorting key; 7 = Material "none"), set at build time
 #define PH_TRI_INSTANCE 16u  // not a triangle: a TransformedPrimitive (object instance); `prim` = index into DeviceScene::instances
 struct alignas(16) TriRec {
     float p0[3]; uint32_t prim;   // prim = index in add_mesh order
@@ -83,6 +83,7 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     uint32_t lobe_base, n_lobes;  // DeviceScene::lobes[lobe_base .. lobe_base + n_lobes)
     uint32_t sort_class;  // 0..6: index of this material's lobe-kind signature among the scene's materials (block-local sorting key)
     float bsdf_eta;    // BSDF::eta (bsdf.rs:101): 1 unless the material passes one (uber.rs:131-138)
+    uint32_t none;     // Material "none": no BSDF, the path integrator skips the surface (path.rs:142-150)
 };
 
 enum { PH_L_INFINITE = 0, PH_L_DISTANT = 1, PH_L_POINT = 2, PH_L_AREA = 3, PH_L_SPOT = 4 };

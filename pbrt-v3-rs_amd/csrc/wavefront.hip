@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfPar
         const float4 h0 = hp[0];
         if (__float_as_uint(h0.y) == 0xFFFFFFFFu) continue;
         const float4 h1 = hp[1];
+        if ((__float_as_uint(h1.w) & 7u) == 7u) continue;  // Material "none": the surface is skipped before the lookup (path.rs:146-150)
         const float4* tp = reinterpret_cast<const float4*>(sc.tris + __float_as_uint(h1.y));
         const float4 a = tp[0], b = tp[1], c = tp[2];
         f3 p = h0.z * mk3(a.x, a.y, a.z) + h0.w * mk3(b.x, b.y, b.z) + h1.x * mk3(c.x, c.y, c.z);  // = SurfHit::p (make_surface_hit_tv)
@@ -315,7 +316,14 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, W
                         if (m.first_light >= 0) L = L + beta * area_L(sc.lights[(uint32_t)m.first_light + (hprim - m.tri_base)], si.n, -rd);
                         else L = L + beta * mks1(0.0f);
                     }
-                    if ((int)bounces < w.max_depth) {
+                    if ((int)bounces < w.max_depth && sc.materials[m.material].none) {
+                        // null BSDF (Material "none"): `*ray = isect.spawn_ray(&ray.d); continue;` — bounces, the sampler dimension and the
+                        // specular flag stay as they are (path.rs:142-150)
+                        const RayIn re = spawn_ray(si, rd);
+                        flags |= F_EXT; want_ext = true;
+                        stage[0][0][tid] = make_float4(re.ox, re.oy, re.oz, re.t_max);
+                        stage[0][1][tid] = make_float4(re.dx, re.dy, re.dz, re.time);
+                    } else if ((int)bounces < w.max_depth) {
                         const typename BO::T bsdf = BO::make(sc, si, m.material);
                         const uint32_t ppix = pid / w.chunk_spp;
                         const int2 xy = w.px_xy[ppix];
@@ -784,6 +792,10 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     const size_t B = (size_t)n_px * chunk_spp;
     if (B >= 0x7FFF0000ull) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: tile range too large for one rank; use more tile_parts");
     const int n_iter = max_depth + 1;
+    // Material "none" surfaces are passed through without counting a bounce, so a path may need more rounds than max_depth + 1: those are
+    // run one at a time while paths remain (host reads the live count), up to kMaxNullSkips more.
+    const int kMaxNullSkips = 1024;
+    const int n_iter_cap = s->has_none_material ? n_iter + kMaxNullSkips : n_iter;
 
     if ((rc = ensure_buf(s, w.d_rays_cl[0], 2 * B * sizeof(ph::RayIn)))) return rc;
     if ((rc = ensure_buf(s, w.d_rays_cl[1], 2 * B * sizeof(ph::RayIn)))) return rc;
@@ -792,7 +804,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     if ((rc = ensure_buf(s, w.d_occ, B))) return rc;
     if ((rc = ensure_buf(s, w.d_live[0], B * 4))) return rc;
     if ((rc = ensure_buf(s, w.d_live[1], B * 4))) return rc;
-    if ((rc = ensure_buf(s, w.d_ctr, (size_t)(n_iter + 2) * sizeof(ph::IterCounters)))) return rc;
+    if ((rc = ensure_buf(s, w.d_ctr, (size_t)(n_iter_cap + 2) * sizeof(ph::IterCounters)))) return rc;
     if ((rc = ensure_buf(s, w.d_stats, sizeof(ph::DevStats)))) return rc;
     for (DevBuf* b : {&w.d_sL, &w.d_sbeta, &w.d_sA, &w.d_sf2, &w.d_sbold, &w.d_sidx})
         if ((rc = ensure_buf(s, *b, B * 16))) return rc;
@@ -836,17 +848,26 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     };
     PH_CHECK(s, hipEventRecord(e_begin, s->stream));
     uint64_t regular = 0, shadow = 0;
-    std::vector<ph::IterCounters> hctr((size_t)n_iter + 2);
+    std::vector<ph::IterCounters> hctr((size_t)n_iter_cap + 2);
     const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, 256 * 16);
 
     for (uint32_t s0 = 0; s0 < spp; s0 += chunk_spp) {
         const uint32_t cs = std::min(chunk_spp, spp - s0);
         wp.chunk_spp = cs; wp.s0 = s0; wp.B = n_px * cs; wp.identity_slots = identity ? 1u : 0u;
-        PH_CHECK(s, hipMemsetAsync(w.d_ctr.p, 0, (size_t)(n_iter + 2) * sizeof(ph::IterCounters), s->stream));
+        PH_CHECK(s, hipMemsetAsync(w.d_ctr.p, 0, (size_t)(n_iter_cap + 2) * sizeof(ph::IterCounters), s->stream));
         if (identity) hipLaunchKernelGGL(ph::preset_counters_kernel, dim3(1), dim3(1), 0, s->stream, wp.ctr, wp.stats, wp.B);
         if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::raygen_kernel, dim3((wp.B + 255) / 256), dim3(256), 0, s->stream, s->ds, wp); }))) return rc;
-        for (int it = 0; it < n_iter; it++) {
+        int iters_run = 0;
+        for (int it = 0; it < n_iter_cap; it++) {
             ph::IterCounters* c = (ph::IterCounters*)w.d_ctr.p + it;
+            if (it >= n_iter) {  // only with "none" materials: go on while some path is still alive
+                uint32_t live = 0;
+                PH_CHECK(s, hipMemcpyAsync(&live, &c->n_live, 4, hipMemcpyDeviceToHost, s->stream));
+                PH_CHECK(s, hipStreamSynchronize(s->stream));
+                if (live == 0) break;
+                if (it == n_iter_cap - 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: a path crossed more than 1024 'none' surfaces");
+            }
+            iters_run = it + 1;
             ph::TravParams tp{};
             tp.rays = wp.rays_cl[it & 1]; tp.out = wp.hits_cl; tp.n = 0; tp.n_ptr = &c->n_cl; tp.counter = &c->head_cl;
             if ((rc = timed(0, [&]() { launch_traverse_kernel(s, false, s->trav_blocks, tp); }))) return rc;
@@ -854,7 +875,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
                 tp.rays = wp.rays_sh; tp.out = wp.occ; tp.n_ptr = &c->n_sh; tp.counter = &c->head_sh;
                 if ((rc = timed(1, [&]() { launch_traverse_kernel(s, true, s->trav_blocks, tp); }))) return rc;
             }
-            if (spatial && it < max_depth) {  // vertices reached at bounce == max_depth sample no light (path.rs:136-139)
+            if (spatial && (it < max_depth || s->has_none_material)) {  // vertices reached at bounce == max_depth sample no light (path.rs:136-139)
                 if ((rc = timed(2, [&]() {
                         hipLaunchKernelGGL(ph::spatial_mark_kernel, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         hipLaunchKernelGGL(ph::spatial_compute_kernel, dim3(1024), dim3(PH_SPATIAL_BLOCK), 0, s->stream, s->ds, wp.spatial);
@@ -865,9 +886,9 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
                     else hipLaunchKernelGGL(ph::shade_kernel<false>, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                 }))) return rc;
         }
-        PH_CHECK(s, hipMemcpyAsync(hctr.data(), w.d_ctr.p, (size_t)(n_iter + 2) * sizeof(ph::IterCounters), hipMemcpyDeviceToHost, s->stream));
+        PH_CHECK(s, hipMemcpyAsync(hctr.data(), w.d_ctr.p, (size_t)(iters_run + 1) * sizeof(ph::IterCounters), hipMemcpyDeviceToHost, s->stream));
         PH_CHECK(s, hipStreamSynchronize(s->stream));
-        for (int it = 0; it < n_iter; it++) { regular += hctr[it].n_cl; shadow += hctr[it].n_sh; }
+        for (int it = 0; it < iters_run; it++) { regular += hctr[it].n_cl; shadow += hctr[it].n_sh; }
     }
 
     // ---- film: per-tile accumulation in reference order ---------------------------------------------------------------------------

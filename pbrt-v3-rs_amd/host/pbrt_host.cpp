@@ -335,7 +335,8 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
         const bool hv = m.params.floats.count("vroughness") || !m.params.find_one_texture("vroughness").empty();
         u = hu ? float_tex("uroughness", r) : r; v = hv ? float_tex("vroughness", r) : r;
     };
-    if (t == "matte") { a3 = spectrum_tex("Kd", kd); f0 = float_tex("sigma", sigma); put3(a3); kv.push_back(f0); }
+    if (t == "none" || t.empty()) { /* no BSDF: graphics_state.rs make_material returns None */ }
+    else if (t == "matte") { a3 = spectrum_tex("Kd", kd); f0 = float_tex("sigma", sigma); put3(a3); kv.push_back(f0); }
     else if (t == "mirror") { a3 = spectrum_tex("Kr", {0.9f, 0.9f, 0.9f}); put3(a3); }
     else if (t == "plastic") { a3 = spectrum_tex("Kd", quarter); b3 = spectrum_tex("Ks", quarter); f0 = float_tex("roughness", 0.1f); put3(a3); put3(b3); kv.push_back(f0); }
     else if (t == "glass") {
@@ -383,7 +384,8 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     if (it != material_cache_.end()) return it->second;
     uint32_t id = 0;
     int rc;
-    if (t == "matte") rc = ABI(pbrt_hip_add_material_matte(scene_, a3.data(), f0, &id));
+    if (t == "none" || t.empty()) rc = ABI(pbrt_hip_add_material_none(scene_, &id));
+    else if (t == "matte") rc = ABI(pbrt_hip_add_material_matte(scene_, a3.data(), f0, &id));
     else if (t == "mirror") rc = ABI(pbrt_hip_add_material_mirror(scene_, a3.data(), &id));
     else if (t == "plastic") rc = ABI(pbrt_hip_add_material_plastic(scene_, a3.data(), b3.data(), f0, remap ? 1 : 0, &id));
     else if (t == "glass") rc = ABI(pbrt_hip_add_material_glass(scene_, a3.data(), b3.data(), f0, f1, f2, remap ? 1 : 0, &id));

@@ -101,6 +101,7 @@ class Binding:
             "tile_buffer_floats": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
             "render_path_tiles_device": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, ip, C.c_int, C.c_int, C.c_int, vp, C.POINTER(Stats)]),
             "merge_tiles_device": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp), fp, fp]),
+            "add_material_none": (C.c_int, [vp, u32p]),
             "add_material_mirror": (C.c_int, [vp, fp, u32p]),
             "add_material_plastic": (C.c_int, [vp, fp, fp, C.c_float, C.c_int, u32p]),
             "add_material_glass": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, u32p]),
@@ -316,6 +317,9 @@ class Scene:
     @staticmethod
     def _rgb(v):
         return _ptr(_f32(v), C.c_float)
+
+    def add_material_none(self) -> int:
+        return self._mat("add_material_none")
 
     def add_material_mirror(self, kr=(0.9, 0.9, 0.9)) -> int:
         return self._mat("add_material_mirror", self._rgb(kr))

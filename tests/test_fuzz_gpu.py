@@ -14,7 +14,7 @@ I4 = (np.eye(4, dtype=np.float32).reshape(16),) * 2
 
 
 def random_material(s, rng):
-    k = rng.integers(0, 10)
+    k = rng.integers(0, 11)
     c = lambda lo=0.05, hi=0.95: tuple(rng.uniform(lo, hi, 3).astype(np.float32))
     if k == 0:
         return s.add_material_matte(c(), float(rng.choice([0.0, rng.uniform(1, 60)])))
@@ -38,6 +38,8 @@ def random_material(s, rng):
         a = s.add_material_plastic(c(), c(0.05, 0.5), float(rng.uniform(0.01, 0.4)), True)
         b = s.add_material_mirror(c(0.3, 1.0)) if rng.integers(0, 2) else s.add_material_glass(c(0.5, 1), c(0.5, 1), 0.0, 0.0, 1.5, True)
         return s.add_material_mix(a, b, c(0.1, 0.9))
+    if k == 9:
+        return s.add_material_none()              # null BSDF: surfaces are passed through (path.rs:142-150)
     return s.add_material_matte((0, 0, 0), 0.0)   # black: no BxDF at all (matte.rs:66)
 
 

@@ -125,3 +125,18 @@ def test_material_sets_within_tolerance_of_glibc_libm(host, name):
     assert np.sqrt((d ** 2).mean()) / mean <= 2e-3
     assert float((np.abs(d).max(axis=2) > 1e-2 * mean).mean()) <= 2e-3
     assert abs(int(gst.regular_rays) - int(ost.regular_rays)) <= 1e-4 * ost.regular_rays
+
+
+def test_none_material_veils_bit_exact(host):
+    """Material "none" (null BSDF, path.rs:142-150) in front of and inside the material scene: paths need more wavefront rounds than
+    max_depth + 1; film and counters still equal the oracle's, with the spatial strategy too (no voxel lookup at skipped surfaces)."""
+    base = material_scene(host, MATERIAL_SETS["plastic_metal"], res=32, spp=4)
+
+    def cap(s):
+        none = s.add_material_none()
+        for y in (-2.6, -2.3, -1.5):
+            P, idx = quad([-0.9, y, -0.9], [0.9, y, -0.9], [0.9, y, 0.9], [-0.9, y, 0.9]); s.add_mesh(P, idx, none)
+        P, idx = quad([-0.9, -0.9, -0.2], [0.9, -0.9, -0.2], [0.9, 0.9, -0.2], [-0.9, 0.9, -0.2]); s.add_mesh(P, idx, none)
+        base(s)
+    for strategy, depth in ((0, 3), (2, 5), (1, 1)):
+        _check(cap, strategy=strategy, max_depth=depth)

@@ -189,3 +189,33 @@ def test_substrate_translucent_mix():
         assert sm[7] == SPEC | REFL and sm[:3] == pytest.approx(np.array([0.75, 0.5, 0.25]) * 0.9 / wo[2], rel=1e-5) and sm[3] == pytest.approx(0.5)
         with pytest.raises(Exception):
             o.add_material_translucent((0.3,) * 3, (0.2,) * 3, (0, 0, 0), (0, 0, 0), 0.1, True)
+
+
+def test_none_material_is_passed_through(host):
+    """Material "none": PathIntegrator::li respawns the ray behind the surface without counting a bounce (path.rs:142-150), so an emitter seen
+    through veils of such triangles still shows its Le (added only while bounces == 0) — at max_depth >= 1; at max_depth 0 the `bounces >=
+    max_depth` break comes first and the veil ends the path.  Shadow rays are NOT let through (intersect_p knows nothing about materials)."""
+    def build(n_veils, max_depth):
+        o = OracleScene()
+        black = o.add_material_matte((0, 0, 0), 0.0)
+        lid = o.add_light_diffuse_area((3.0, 2.0, 1.0), 2, two_sided=True)
+        o.add_mesh(np.float32([[-9, 1, -9], [9, 1, -9], [9, 1, 9], [-9, 1, 9]]), [0, 1, 2, 0, 2, 3], black, first_area_light=lid)
+        none = o.add_material_none()
+        for k in range(n_veils):
+            y = -2.5 + 0.3 * k
+            o.add_mesh(np.float32([[-9, y, -9], [9, y, -9], [9, y, 9], [-9, y, 9]]), [0, 1, 2, 0, 2, 3], none)
+        w2c, c2w = host.look_at([0, -4, 0.2], [0, 0, 0], [0, 0, 1])
+        o.set_camera_perspective(host.perspective_raster_to_camera(40.0, 16, 16), c2w)
+        cb, table, sb = host.film_box(16, 16)
+        o.set_film(16, 16, cb, (0.5, 0.5), table); o.set_sampler(0, 2, sb); o.build_accel(0, 4)
+        xyz, wt, st = o.render_path(max_depth=max_depth, light_strategy=0)
+        img = o.film_to_rgb(xyz, wt).reshape(16, 16, 3); o.close()
+        return img, st
+    ref, s0 = build(0, 2)
+    assert np.allclose(ref, [3.0, 2.0, 1.0], rtol=1e-5)
+    for veils in (1, 3):
+        img, st = build(veils, 2)
+        assert np.array_equal(img, ref)                                        # Le seen through the veils, bounces still 0
+        assert st.regular_rays == s0.regular_rays + veils * s0.camera_rays     # one more regular ray per crossing
+    img, _ = build(2, 0)
+    assert (img == 0).all()                                                    # max_depth 0: the first veil ends every path
