@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -51,7 +53,37 @@ struct Builder {
     std::atomic<int> spare_threads{0};
     int split_method = 0, max_prims = 4;
 
-    BNode* alloc() { return &pool[pool_next.fetch_add(1)]; }
+    // Nodes come from per-thread chunks of the pool: one shared atomic per 1024 nodes instead of one per node.
+    static constexpr size_t kArenaChunk = 1024;
+    static uint64_t next_serial() { static std::atomic<uint64_t> g{1}; return g.fetch_add(1); }
+    const uint64_t serial = next_serial();
+    BNode* alloc() {
+        thread_local BNode* cur = nullptr; thread_local BNode* lim = nullptr; thread_local uint64_t owner = 0;
+        if (owner != serial || cur == lim) {  // `serial` is unique per Builder: a later Builder at the same address must not reuse the chunk
+            const size_t at = pool_next.fetch_add(kArenaChunk);
+            cur = pool.data() + at; lim = cur + kArenaChunk; owner = serial;
+        }
+        return cur++;
+    }
+
+    // Helper threads for the data-parallel passes over one large range (taken from the same budget as the forked subtrees).
+    static constexpr size_t kParallelRange = 1u << 18;
+    int grab_helpers() {
+        int got = 0;
+        while (got < 7) { if (spare_threads.fetch_sub(1) > 0) got++; else { spare_threads.fetch_add(1); break; } }
+        return got;
+    }
+    void release_helpers(int n) { if (n > 0) spare_threads.fetch_add(n); }
+    template <class F> static void parallel_chunks(size_t start, size_t end, int helpers, F f) {
+        const size_t n = end - start, parts = (size_t)helpers + 1, step = (n + parts - 1) / parts;
+        std::vector<std::thread> th;
+        for (int t = 1; t <= helpers; t++) {
+            const size_t a = std::min(end, start + (size_t)t * step), b = std::min(end, a + step);
+            th.emplace_back([=]() { f(t, a, b); });
+        }
+        f(0, start, std::min(end, start + step));
+        for (std::thread& x : th) x.join();
+    }
 
     static uint32_t bucket_of(const Box& cb, const float* c, int dim) {  // sah.rs:309-313 (saturating `as usize`)
         float o = c[dim] - cb.lo[dim];
@@ -87,14 +119,25 @@ struct Builder {
 
     BNode* build(size_t start, size_t end) {
         BNode* node = alloc();
-        Box bounds; bounds.reset();
-        for (size_t i = start; i < end; i++) bounds.grow(prims[i].b);
+        Box bounds, cb; bounds.reset(); cb.reset();
         const size_t n = end - start;
-        if (n == 1) return make_leaf(node, bounds, start, end);
-        Box cb; cb.reset();
-        for (size_t i = start; i < end; i++) cb.grow_pt(prims[i].c);
+        // one pass for the node bound and the centroid bound; min/max are exact, so any grouping of the unions gives the reference's boxes.
+        // Large ranges (the top of the tree, where nothing else runs in parallel yet) are reduced by several threads.
+        const int helpers = n >= kParallelRange ? grab_helpers() : 0;
+        if (helpers > 0) {
+            std::vector<Box> pb(helpers + 1), pc(helpers + 1);
+            parallel_chunks(start, end, helpers, [&](int t, size_t a, size_t b) {
+                Box bb, cc; bb.reset(); cc.reset();
+                for (size_t i = a; i < b; i++) { bb.grow(prims[i].b); cc.grow_pt(prims[i].c); }
+                pb[t] = bb; pc[t] = cc;
+            });
+            for (int t = 0; t <= helpers; t++) { bounds.grow(pb[t]); cb.grow(pc[t]); }
+        } else {
+            for (size_t i = start; i < end; i++) { bounds.grow(prims[i].b); cb.grow_pt(prims[i].c); }
+        }
+        if (n == 1) { release_helpers(helpers); return make_leaf(node, bounds, start, end); }
         const int dim = cb.widest();
-        if (cb.hi[dim] == cb.lo[dim]) return make_leaf(node, bounds, start, end);  // sah.rs:61-63
+        if (cb.hi[dim] == cb.lo[dim]) { release_helpers(helpers); return make_leaf(node, bounds, start, end); }  // sah.rs:61-63
 
         size_t mid;
         if (split_method == 3 || n <= 2) {
@@ -107,6 +150,16 @@ struct Builder {
             // split_sah (sah.rs:293-367)
             size_t cnt[kBuckets]; Box bb[kBuckets];
             for (int i = 0; i < kBuckets; i++) { cnt[i] = 0; bb[i].reset(); }
+            if (helpers > 0) {
+                struct Part { size_t cnt[kBuckets]; Box bb[kBuckets]; };
+                std::vector<Part> parts(helpers + 1);
+                parallel_chunks(start, end, helpers, [&](int t, size_t a, size_t b2) {
+                    Part& q = parts[t];
+                    for (int i = 0; i < kBuckets; i++) { q.cnt[i] = 0; q.bb[i].reset(); }
+                    for (size_t i = a; i < b2; i++) { uint32_t b = bucket_of(cb, prims[i].c, dim); q.cnt[b]++; q.bb[b].grow(prims[i].b); }
+                });
+                for (int t = 0; t <= helpers; t++) for (int i = 0; i < kBuckets; i++) { cnt[i] += parts[t].cnt[i]; bb[i].grow(parts[t].bb[i]); }
+            } else
             for (size_t i = start; i < end; i++) { uint32_t b = bucket_of(cb, prims[i].c, dim); cnt[b]++; bb[b].grow(prims[i].b); }
             // suffix unions once; prefix grown on the fly (min/max are exact, so the grouping does not matter)
             Box suf[kBuckets]; size_t sufc[kBuckets];
@@ -123,8 +176,9 @@ struct Builder {
             const float leaf_cost = (float)n;
             if (n > (size_t)max_prims || best < leaf_cost) {
                 mid = start + partition_like_itertools(start, end, [&](const Prim& p) { return bucket_of(cb, p.c, dim) <= (uint32_t)best_b; });
-            } else return make_leaf(node, bounds, start, end);
+            } else { release_helpers(helpers); return make_leaf(node, bounds, start, end); }
         }
+        release_helpers(helpers);
         if (mid == start || mid == end) return make_leaf(node, bounds, start, end);  // reference: assert_ne! panic (sah.rs:37)
 
         node->axis = dim; node->first = 0; node->count = 0;
@@ -331,15 +385,19 @@ int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int
         }
         for (int k = 0; k < 3; k++) p.c[k] = 0.5f * (p.b.lo[k] + p.b.hi[k]);
     }
-    B.pool.resize(2 * n);
+    const bool prof = std::getenv("PBRT_HIP_BUILD_PROFILE") != nullptr;
+    auto t_prims = std::chrono::steady_clock::now();
+    B.pool.resize(2 * n + 4096 * Builder::kArenaChunk);  // room for the partly used chunks of every thread the build may start
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     B.spare_threads = n_threads > 1 ? n_threads - 1 : 0;
     BNode* root = split_method == 1 ? B.build_hlbvh(std::max(n_threads, 1)) : B.build(0, n);
     if (B.panic) return -2;  // one of the reference's assertions fired (hlbvh.rs:338/356/418)
+    auto t_built = std::chrono::steady_clock::now();
 
     // ---- emit device layout: TriRecs in final prim-array order (= depth-first leaf order), Node64s in pre-order -------
     out.tris.resize(n);
-    for (size_t i = 0; i < n; i++) {
+    auto fill = [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++) {
         const uint32_t id = B.prims[i].id;
         TriRec& t = out.tris[i];
         if (id & PH_ITEM_INST) { std::memset(&t, 0, sizeof t); t.prim = id & ~PH_ITEM_INST; t.flags = PH_TRI_INSTANCE; continue; }
@@ -348,6 +406,15 @@ int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int
         const float* p2 = in.P + 3 * (size_t)in.idx[3 * (size_t)id + 2];
         std::memcpy(t.p0, p0, 12); std::memcpy(t.p1, p1, 12); std::memcpy(t.p2, p2, 12);
         t.prim = id; t.flags = in.tri_flags ? (in.tri_flags[id] & ~PH_TRI_LAST) : 0u; t.mesh = in.tri_mesh ? in.tri_mesh[id] : 0u;
+    }
+    };
+    {  // the gather of vertex positions is a random walk over P: spread it over the threads
+        const int nt = (n >= (1u << 16)) ? std::max(n_threads, 1) : 1;
+        std::vector<std::thread> th;
+        const size_t step = (n + nt - 1) / nt;
+        for (int t = 1; t < nt; t++) th.emplace_back(fill, std::min(n, (size_t)t * step), std::min(n, (size_t)(t + 1) * step));
+        fill(0, std::min(n, step));
+        for (std::thread& x : th) x.join();
     }
     for (int k = 0; k < 3; k++) { out.root_lo[k] = root->b.lo[k]; out.root_hi[k] = root->b.hi[k]; }
 
@@ -387,6 +454,11 @@ int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int
             if (kids[1]->kid[0]) stack.push_back({kids[1], refs[1], it.depth + 1});
             if (kids[0]->kid[0]) stack.push_back({kids[0], refs[0], it.depth + 1});
         }
+    }
+    if (prof) {
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "build_bvh n=%zu: prims %.3f s, tree %.3f s, emit %.3f s\n", n, std::chrono::duration<double>(t_prims - t0).count(),
+                     std::chrono::duration<double>(t_built - t_prims).count(), std::chrono::duration<double>(now - t_built).count());
     }
     out.total_nodes = out.interior_nodes + out.leaf_nodes;
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
