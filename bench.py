@@ -13,9 +13,9 @@ Scaling (N > 1): "weak" by default — the frame is rendered at N x the samples 
 the single GPU does at N = 1 and the job is N frames' worth of work; `--scaling strong` renders the identical N = 1 frame
 instead (same film bits as one rank, tests/test_multi_rank_gpu.py).
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (closest-hit BVH traversal): achieved = algorithmic
-bytes (32 B per reference-format node visit + 48 B per triangle test + 64 B ray in / hit out) / its HIP-event time
-measured inside the timed steps.  `cpu_baseline` times the CPU oracle (oracle/, a port of the reference algorithm — the Rust
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (BVH traversal; one launch per wavefront round serves that round's closest-hit
+and any-hit rays): achieved = algorithmic bytes (32 B per reference-format node visit + 48 B per triangle test + 64 B ray in / hit
+out, 33 B for any-hit rays) / its HIP-event time measured inside the timed steps.  `cpu_baseline` times the CPU oracle (oracle/, a port of the reference algorithm — the Rust
 reference cannot be built here) on a bounded sample of the same workload on this box's host cores.
 """
 import argparse
@@ -180,33 +180,34 @@ def main():
                                         "raygen_shade_film": round(shade_s / args.steps * 1e3, 3)},
         }
 
-    # ---- roofline of the dominant kernel (closest-hit traversal), rank 0's share ------------------------------------------------
+    # ---- roofline of the dominant kernel (BVH traversal, both ray kinds), rank 0's share ------------------------------------------------
     if rank == 0:
-        roof = {"bound": "hbm", "kernel": "ph::traverse_kernel<false,false> (closest hit)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": "ph::traverse_kernel (BVH traversal + triangle tests; one launch per wavefront round serves the round's closest-hit and any-hit rays)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": None, "traffic": None}
         if not args.no_roofline_count:
-            C = pbrt_hip.C
-            lib = scene.b.lib
-            lib.pbrt_hip_set_traversal_counting.argtypes = [C.c_void_p, C.c_int]
-            lib.pbrt_hip_get_traversal_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-            lib.pbrt_hip_set_traversal_counting(scene.h, 1)
+            scene.set_traversal_counting(True)
             st_c = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=args.max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
-            cnt = (C.c_uint64 * 6)()
-            lib.pbrt_hip_get_traversal_counts(scene.h, cnt)
-            lib.pbrt_hip_set_traversal_counting(scene.h, 0)
-            nodes_passed, tri_tests, n_rays = int(cnt[0]), int(cnt[1]), int(cnt[2])
-            n_v = n_rays + 2 * nodes_passed  # reference-format node visits (traverse.h)
-            bytes_per_frame = 32 * n_v + 48 * tri_tests + 64 * n_rays
-            ext_per_frame = ext_s / args.steps
-            launches = int(st.extend_launches)
-            ach = bytes_per_frame / ext_per_frame / 1e9 if ext_per_frame > 0 else None
+            cnt = scene.traversal_counts()
+            scene.set_traversal_counting(False)
+            cl, ah = cnt["closest"], cnt["any_hit"]
+            # 32 B per reference-format node visit + 48 B per triangle test + ray in / result out (32 + 32 closest hit, 32 + 1 any hit)
+            bytes_cl = 32 * cl["ref_node_visits"] + 48 * cl["tri_tests"] + 64 * cl["rays"]
+            bytes_ah = 32 * ah["ref_node_visits"] + 48 * ah["tri_tests"] + 33 * ah["rays"]
+            bytes_per_frame = bytes_cl + bytes_ah
+            n_rays = cl["rays"] + ah["rays"]
+            trav_per_frame = (ext_s + sh_s) / args.steps
+            launches = int(st.extend_launches + st.shadow_launches)
+            ach = bytes_per_frame / trav_per_frame / 1e9 if trav_per_frame > 0 else None
             roof.update({"achieved": round(ach, 1) if ach else None, "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
                          "algorithmic_bytes_per_launch": bytes_per_frame // max(launches, 1), "launches_per_step": launches,
-                         "avg_launch_ms": round(ext_per_frame / launches * 1e3, 4), "rays_per_step": n_rays,
-                         "ref_node_visits_per_ray": round(n_v / max(n_rays, 1), 2), "tri_tests_per_ray": round(tri_tests / max(n_rays, 1), 2),
-                         "bytes_per_ray": round(bytes_per_frame / max(n_rays, 1), 1),
-                         "kernel_Mrays_per_s": round(n_rays / ext_per_frame / 1e6, 1) if ext_per_frame > 0 else None,
-                         "note": "counts from an untimed counting pass of the same frame; time = HIP events around every closest-hit launch of the timed steps"})
+                         "avg_launch_ms": round(trav_per_frame / launches * 1e3, 4), "rays_per_step": n_rays,
+                         "closest_hit": {"rays": cl["rays"], "ref_node_visits_per_ray": round(cl["ref_node_visits"] / max(cl["rays"], 1), 2),
+                                         "tri_tests_per_ray": round(cl["tri_tests"] / max(cl["rays"], 1), 2), "bytes_per_ray": round(bytes_cl / max(cl["rays"], 1), 1)},
+                         "any_hit": {"rays": ah["rays"], "ref_node_visits_per_ray": round(ah["ref_node_visits"] / max(ah["rays"], 1), 2),
+                                     "tri_tests_per_ray": round(ah["tri_tests"] / max(ah["rays"], 1), 2), "bytes_per_ray": round(bytes_ah / max(ah["rays"], 1), 1)},
+                         "kernel_Mrays_per_s": round(n_rays / trav_per_frame / 1e6, 1) if trav_per_frame > 0 else None,
+                         "note": "counts from an untimed counting pass of the same frame (node visits and triangle tests the reference's traversal makes for these rays); "
+                                 "time = HIP events around every traversal launch of the timed steps"})
         # HBM-side traffic of the same kernel from rocprofv3 PMC passes (separate runs of this script under `rocprofv3 --pmc`,
         # scripts/pmc_profile.sh; summary committed under profiles/).  MI355X_MICROARCH.md prescribes doubling FETCH_SIZE for wide coalesced
         # streaming reads; this kernel's reads are random 64-B lines (4 x dwordx4 per lane), for which a calibration run on a known byte count
@@ -217,7 +218,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == [args.n_tris, args.res, args.spp, args.max_depth, args.seed] and world == 1 and args.material == "matte" and not args.instances:
-                    k = tj["closest_hit"]
+                    k = tj["traversal"]
                     per_launch = (float(tj.get("fetch_scale", 1.0)) * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"]
                     roof["traffic"] = int(per_launch)
                     roof["traffic_note"] = ("HBM-side bytes per launch from rocprofv3 PMC (FETCH_SIZE + WRITE_SIZE, " + tj.get("source", "profiles/") + "; FETCH_SIZE calibrated exact "

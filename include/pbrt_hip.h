@@ -191,9 +191,10 @@ int pbrt_hip_occluded_batch_device(PbrtHipScene*, const void* d_rays, void* d_oc
 
 /* Measurement aid (not a reference interface): with counting on, traversal launches also tally their work.
  * out[0..2] closest-hit {interior nodes whose box test passed, triangle tests, rays}, out[3..5] the same for any-hit.
- * Reference-format node visits of the closest-hit rays = out[2] + 2*out[0].  get resets the tallies.  Never timed. */
+ * Reference-format node visits of the closest-hit rays = out[2] + 2*out[0]; of the any-hit rays (which stop early) = out[6],
+ * counted as they happen.  out[7] is spare.  get resets the tallies.  Never timed. */
 int pbrt_hip_set_traversal_counting(PbrtHipScene*, int on);
-int pbrt_hip_get_traversal_counts(PbrtHipScene*, uint64_t out[6]);
+int pbrt_hip_get_traversal_counts(PbrtHipScene*, uint64_t out[8]);
 
 /* Integrator::render for PathIntegrator (core/src/integrator/sampler_integrator.rs:243-415 +
  * integrators/src/path.rs:103-284).  Renders the 16x16 (tile_size) sample tiles whose index t satisfies

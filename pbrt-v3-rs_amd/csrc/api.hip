@@ -172,6 +172,7 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
 #undef X
         }
         per_cu = std::min(std::max(per_cu, 1), 8);
+        if (const char* e = std::getenv("PBRT_HIP_TRAV_BLOCKS_PER_CU")) per_cu = std::min(std::max(std::atoi(e), 1), per_cu);  // measurement aid
         s->trav_blocks = (uint32_t)(prop.multiProcessorCount * per_cu);
     }
     const uint32_t total_threads = s->trav_blocks * PH_TRAV_BLOCK;
@@ -185,37 +186,31 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
     return PBRT_HIP_OK;
 }
 
-// p.spill / total_threads / error_flag / counts are filled here
-void launch_traverse_kernel(PbrtHipScene* s, bool anyhit, uint32_t blocks, const ph::TravParams& p_in) {
+// p.spill / total_threads / error_flag / counts are filled here.  mode: 0 closest hit, 1 any hit, 2 both queues in one launch (MIXED)
+void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph::TravParams& p_in) {
     ph::TravParams p = p_in;
     p.spill = (uint2*)s->d_spill.p; p.total_threads = s->trav_blocks * PH_TRAV_BLOCK; p.error_flag = (uint32_t*)s->d_error.p;
-    p.counts = (unsigned long long*)s->d_counts.p + (anyhit ? 3 : 0);
+    p.counts = (unsigned long long*)s->d_counts.p;
     { static int bt = -1; if (bt < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_BATCH"); bt = e ? std::atoi(e) : PH_BATCH; if (bt < 64) bt = 64; } p.batch = (uint32_t)bt; }
     const dim3 g(blocks), b(PH_TRAV_BLOCK);
+#define PH_LAUNCH3(cnt, lm, rm, ld, ns, inst)                                                                                          \
+    do {                                                                                                                              \
+        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, true>), g, b, 0, s->stream, s->ds, p); \
+        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst>), g, b, 0, s->stream, s->ds, p);   \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst>), g, b, 0, s->stream, s->ds, p);                 \
+    } while (0)
     if (!s->inst_recs.empty()) {  // scenes with object instances: the TransformedPrimitive-aware kernels
-        if (s->count_traversal) {
-            if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true>), g, b, 0, s->stream, s->ds, p);
-            else hipLaunchKernelGGL((ph::traverse_kernel<false, true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true>), g, b, 0, s->stream, s->ds, p);
-        } else {
-            if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true>), g, b, 0, s->stream, s->ds, p);
-            else hipLaunchKernelGGL((ph::traverse_kernel<false, false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true>), g, b, 0, s->stream, s->ds, p);
-        }
+        if (s->count_traversal) PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true);
+        else PH_LAUNCH3(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true);
         return;
     }
-    if (s->count_traversal) {
-        if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, true>), g, b, 0, s->stream, s->ds, p);
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, true>), g, b, 0, s->stream, s->ds, p);
-        return;
-    }
+    if (s->count_traversal) { PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false); return; }
     switch (trav_variant()) {
-#define X(id, lm, rm, ld, ns)                                                                                                     \
-    case id:                                                                                                                      \
-        if (anyhit) hipLaunchKernelGGL((ph::traverse_kernel<true, false, lm, rm, ld, ns>), g, b, 0, s->stream, s->ds, p);         \
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, false, lm, rm, ld, ns>), g, b, 0, s->stream, s->ds, p);               \
-        break;
+#define X(id, lm, rm, ld, ns) case id: PH_LAUNCH3(false, lm, rm, ld, ns, false); break;
         PH_VARIANTS(X)
 #undef X
     }
+#undef PH_LAUNCH3
 }
 
 int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_out, uint32_t n, float* kernel_ms) {
@@ -229,7 +224,7 @@ int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_ou
     ph::TravParams p{};
     p.rays = (const ph::RayIn*)d_rays; p.out = d_out; p.n = n; p.n_ptr = nullptr; p.counter = (uint32_t*)s->d_counter.p;
     if (kernel_ms) PH_CHECK(s, hipEventRecord(s->ev0, s->stream));
-    launch_traverse_kernel(s, anyhit, blocks, p);
+    launch_traverse_kernel(s, anyhit ? 1 : 0, blocks, p);
     PH_CHECK(s, hipGetLastError());
     if (kernel_ms) {
         PH_CHECK(s, hipEventRecord(s->ev1, s->stream));
@@ -932,17 +927,17 @@ int pbrt_hip_set_traversal_counting(PbrtHipScene* s, int on) {
     PH_CHECK(s, hipSetDevice(s->device));
     int rc;
     if ((rc = ensure_traversal_workspace(s))) return rc;
-    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 48));
+    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 64));
     s->count_traversal = on != 0;
     return PBRT_HIP_OK;
 }
-int pbrt_hip_get_traversal_counts(PbrtHipScene* s, uint64_t out[6]) {
+int pbrt_hip_get_traversal_counts(PbrtHipScene* s, uint64_t out[8]) {
     if (!s || !out) return PBRT_HIP_ERR_INVALID_ARG;
-    if (!s->d_counts.p) { for (int i = 0; i < 6; i++) out[i] = 0; return PBRT_HIP_OK; }
+    if (!s->d_counts.p) { for (int i = 0; i < 8; i++) out[i] = 0; return PBRT_HIP_OK; }
     PH_CHECK(s, hipSetDevice(s->device));
     PH_CHECK(s, hipStreamSynchronize(s->stream));
-    PH_CHECK(s, hipMemcpy(out, s->d_counts.p, 48, hipMemcpyDeviceToHost));
-    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 48));
+    PH_CHECK(s, hipMemcpy(out, s->d_counts.p, 64, hipMemcpyDeviceToHost));
+    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 64));
     return PBRT_HIP_OK;
 }
 

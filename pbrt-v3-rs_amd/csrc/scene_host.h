@@ -60,7 +60,7 @@ struct PbrtHipScene {
     DevBuf d_counter, d_spill, d_error, d_rays_tmp, d_out_tmp;
     uint32_t trav_blocks = 0;
     bool count_traversal = false;    // roofline bookkeeping mode (pbrt_hip_set_traversal_counting)
-    DevBuf d_counts;                 // 2 x 3 u64: closest-hit {nodes, tris, rays}, any-hit {nodes, tris, rays}
+    DevBuf d_counts;                 // 8 u64: closest-hit {nodes, tris, rays}, any-hit {nodes, tris, rays}, any-hit reference node visits, spare
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // wavefront workspace (allocated lazily by the renderer, see wavefront.hip)
@@ -74,7 +74,7 @@ int ensure_buf(PbrtHipScene* s, DevBuf& b, size_t bytes);
 int upload_scene(PbrtHipScene* s);
 int upload_light_distribution(PbrtHipScene* s, int light_strategy);
 int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_out, uint32_t n, float* kernel_ms);
-void launch_traverse_kernel(PbrtHipScene* s, bool anyhit, uint32_t blocks, const ph::TravParams& p);
+void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph::TravParams& p);  // 0 closest, 1 any hit, 2 both (MIXED)
 int ensure_traversal_workspace(PbrtHipScene* s);
 void free_wavefront(PbrtHipScene* s);
 }  // namespace phost

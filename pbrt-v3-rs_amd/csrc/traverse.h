@@ -43,6 +43,8 @@ struct TravParams {
     uint32_t* error_flag;   // set to 1 on stack overflow (the reference would panic on index 64)
     uint32_t batch;         // rays a wave claims per global atomic
     unsigned long long* counts;  // COUNT builds only: [0] interior nodes whose box test passed, [1] triangle tests, [2] rays
+    // MIXED kernels only: one launch walks the closest-hit queue (rays/out/n_ptr) and then the any-hit queue below
+    const RayIn* rays2; uint8_t* out2; const uint32_t* n2_ptr;
 };
 
 struct RayState {
@@ -183,14 +185,19 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
 // into instance space, walks the object's aggregate above its current stack height and returns to the scene-level leaf where it
 // left it (same order of primitive tests as the reference's recursion).  Compiled separately so scenes without instances keep
 // the leaner kernel.
-template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1, bool INST = false>
+// MIXED = true serves both ray kinds of one wavefront round from ONE launch: indices [0, n_cl) are closest-hit rays, [n_cl, n_cl + n_sh)
+// any-hit rays (each lane knows its kind).  Every launch ends with a latency-bound tail (the last rays' dependent loads, ~0.4 ms
+// whatever the launch size), so one launch per round instead of two removes one tail per bounce.
+template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1, bool INST = false, bool MIXED = false>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * PH_TRAV_BLOCK + tid;
     const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const uint32_t n_rays = p.n_ptr ? *p.n_ptr : p.n;
+    const uint32_t n_first = p.n_ptr ? *p.n_ptr : p.n;
+    const uint32_t n_rays = MIXED ? n_first + *p.n2_ptr : n_first;
+    bool ah = ANYHIT;                        // this lane's ray kind (MIXED: per ray, else the template's)
 
     bool has_ray = false;
     uint32_t batch_next = 0, batch_end = 0;  // wave-uniform
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
     uint32_t hit_prim = 0xFFFFFFFFu, hit_tri = 0u, hit_cls = 0u;
     float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     bool occluded = false;
-    uint32_t c_nodes = 0, c_tris = 0, c_rays = 0;
+    uint32_t c_nodes[2] = {0, 0}, c_tris[2] = {0, 0}, c_rays[2] = {0, 0}, c_visits = 0;  // COUNT: [0] this launch's first kind, [1] MIXED any-hit
     // instancing state (INST only)
     uint32_t in_inst = 0;                 // instance number + 1 while inside an object's aggregate
     int inst_sp = 0;                      // stack height at entry: the object's entries live above it
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
         while (sp > floor_sp) {
             sp--;
             uint2 e = (sp < LDS_DEPTH) ? lds_stack[sp][tid] : p.spill[(size_t)(sp - LDS_DEPTH) * p.total_threads + gtid];
+            if (COUNT && ah) c_visits++;  // the reference fetches and box-tests every node it pops
             if (__uint_as_float(e.y) < r.t_max) return e.x;
         }
         return PH_INVALID_REF;
@@ -247,7 +255,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                     const uint32_t rank = (uint32_t)__popcll(idle & lane_lt);
                     if (!has_ray && rank < avail) {
                         ray_index = batch_next + rank;
-                        const float4* rp = reinterpret_cast<const float4*>(p.rays + ray_index);
+                        if (MIXED) ah = ray_index >= n_first;
+                        const float4* rp = reinterpret_cast<const float4*>((MIXED && ah) ? p.rays2 + (ray_index - n_first) : p.rays + ray_index);
                         const float4 a = rp[0], b = rp[1];
                         RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = a.w; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
                         ray_setup(r, in);
@@ -255,6 +264,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                         if (INST) { in_inst = 0; hit_inst = 0; }
                         // root: the reference tests nodes[0].bounds first (bvh/mod.rs:189-190)
                         cur = PH_INVALID_REF;
+                        if (COUNT && ah) c_visits++;
                         if (sc.root_ref != PH_INVALID_REF) {
                             float tmin;
                             const bool h = box_test(r, r.nx ? sc.root_hi[0] : sc.root_lo[0], r.nx ? sc.root_lo[0] : sc.root_hi[0],
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
             const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
             const float4 q0 = np[0], q1 = np[1], q2 = np[2];
             const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
-            if (COUNT) c_nodes++;
+            if (COUNT) c_nodes[(MIXED && ah) ? 1 : 0]++;
             // q0 = x0[0],x0[1],y0[0],y0[1]; q1 = z0[0],z0[1],x1[0],x1[1]; q2 = y1[0],y1[1],z1[0],z1[1]
             float t0, t1;
             bool h0 = box_test(r, r.nx ? q0.y : q0.x, r.nx ? q0.x : q0.y, r.ny ? q0.w : q0.z, r.ny ? q0.z : q0.w,
@@ -293,6 +303,12 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
             const uint32_t near_ref = neg_axis ? q3.y : q3.x, far_ref = neg_axis ? q3.x : q3.y;
             const bool near_hit = neg_axis ? h1 : h0, far_hit = neg_axis ? h0 : h1;
             const float far_t = neg_axis ? t0 : t1;
+            if (COUNT && ah) {
+                // any-hit rays stop early, so "nodes the reference visits" is counted as it goes: the near child always, the far child when
+                // it is popped — also when its box test fails, hence the NaN-keyed entry (pop() counts it and skips it)
+                if (near_hit) { c_visits++; if (!far_hit) push(far_ref, __builtin_nanf("")); }
+                else c_visits += 2;
+            }
             if (near_hit) { cur = near_ref; if (far_hit) push(far_ref, far_t); }
             else if (far_hit) cur = far_ref;
             else cur = pop();
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
             const uint64_t lm = __ballot(at_leaf);
             if (lm != 0ull) {
                 const uint64_t nm = __ballot(has_ray && cur != PH_INVALID_REF && !(cur & PH_LEAF_BIT));
-                if ((uint32_t)__popcll(lm) >= (uint32_t)LEAF_MIN || nm == 0ull) {
+                if ((uint32_t)__popcll(lm) >= (uint32_t)LEAF_MIN || nm == 0ull || exhausted) {  // queue drained: no throughput left to protect, only the tail's latency
 #pragma unroll
                     for (int ls = 0; ls < PH_LEAF_STEPS; ls++)
                     if (has_ray && cur != PH_INVALID_REF && (cur & PH_LEAF_BIT)) {
@@ -330,12 +346,12 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                                 if (h && tmin < r.t_max) cur = I.root_ref;
                             }
                         } else {
-                        if (COUNT) c_tris++;
+                        if (COUNT) c_tris[(MIXED && ah) ? 1 : 0]++;
                         if (tri_test(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), t, b0, b1, b2)) {
                             // post-t rejections: degenerate triangle (triangle.rs:567-570 / 862-866), alpha == 0 (:603 / :886-893)
-                            const uint32_t reject = ANYHIT ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
+                            const uint32_t reject = ah ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
                             if (!(flags & reject)) {
-                                if (ANYHIT) occluded = true;
+                                if (ah) occluded = true;
                                 else {
                                     r.t_max = t; hit_prim = __float_as_uint(a.w); hit_tri = ti; hb0 = b0; hb1 = b1; hb2 = b2;
                                     hit_cls = (flags >> PH_TRI_CLASS_SHIFT) & 7u;
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                                 }
                             }
                         }
-                        if (ANYHIT && occluded) cur = PH_INVALID_REF;
+                        if (ah && occluded) cur = PH_INVALID_REF;
                         else if (last) cur = pop();
                         else cur = cur + 1u;
                         }
@@ -354,9 +370,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
 
         // ---- leave an exhausted instance: back to the scene-level ray, `r.t_max = ray.t_max` only if something was hit inside ----------
         if (INST && has_ray && in_inst && cur == PH_INVALID_REF) {
-            if (!(ANYHIT && occluded)) {
+            if (!(ah && occluded)) {
                 const float t_new = inst_hit ? r.t_max : world_tmax;
-                const float4* rp = reinterpret_cast<const float4*>(p.rays + ray_index);
+                const float4* rp = reinterpret_cast<const float4*>((MIXED && ah) ? p.rays2 + (ray_index - n_first) : p.rays + ray_index);
                 const float4 a = rp[0], b = rp[1];
                 RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = t_new; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
                 ray_setup(r, in);
@@ -367,20 +383,29 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
 
         // ---- retire finished rays --------------------------------------------------------------------------------------------------------
         if (has_ray && cur == PH_INVALID_REF) {
-            if (ANYHIT) reinterpret_cast<uint8_t*>(p.out)[ray_index] = occluded ? 1 : 0;
+            if (MIXED && ah) p.out2[ray_index - n_first] = occluded ? 1 : 0;
+            else if (!MIXED && ANYHIT) reinterpret_cast<uint8_t*>(p.out)[ray_index] = occluded ? 1 : 0;
             else {
                 float4* hp = reinterpret_cast<float4*>(reinterpret_cast<HitOut*>(p.out) + ray_index);
                 hp[0] = make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1);
                 hp[1] = make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), __uint_as_float(hit_cls));  // pad[0] = the hit's TriRec, pad[1] = instance + 1, pad[2] = material class
             }
             has_ray = false;
-            if (COUNT) c_rays++;
+            if (COUNT) c_rays[(MIXED && ah) ? 1 : 0]++;
         }
     }
     if (COUNT) {
-        atomicAdd(p.counts + 0, (unsigned long long)c_nodes);
-        atomicAdd(p.counts + 1, (unsigned long long)c_tris);
-        atomicAdd(p.counts + 2, (unsigned long long)c_rays);
+        // p.counts: closest-hit {nodes, tris, rays} any-hit {nodes, tris, rays} any-hit reference node visits
+        const int k0 = (!MIXED && ANYHIT) ? 3 : 0;
+        atomicAdd(p.counts + k0 + 0, (unsigned long long)c_nodes[0]);
+        atomicAdd(p.counts + k0 + 1, (unsigned long long)c_tris[0]);
+        atomicAdd(p.counts + k0 + 2, (unsigned long long)c_rays[0]);
+        if (MIXED) {
+            atomicAdd(p.counts + 3, (unsigned long long)c_nodes[1]);
+            atomicAdd(p.counts + 4, (unsigned long long)c_tris[1]);
+            atomicAdd(p.counts + 5, (unsigned long long)c_rays[1]);
+        }
+        atomicAdd(p.counts + 6, (unsigned long long)c_visits);
     }
 }
 

@@ -847,6 +847,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
         return PBRT_HIP_OK;
     };
     PH_CHECK(s, hipEventRecord(e_begin, s->stream));
+    static const bool split_traversal = std::getenv("PBRT_HIP_SPLIT_TRAVERSAL") != nullptr;  // measurement aid: one launch per ray kind
     uint64_t regular = 0, shadow = 0;
     std::vector<ph::IterCounters> hctr((size_t)n_iter_cap + 2);
     const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, 256 * 16);
@@ -870,10 +871,15 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
             iters_run = it + 1;
             ph::TravParams tp{};
             tp.rays = wp.rays_cl[it & 1]; tp.out = wp.hits_cl; tp.n = 0; tp.n_ptr = &c->n_cl; tp.counter = &c->head_cl;
-            if ((rc = timed(0, [&]() { launch_traverse_kernel(s, false, s->trav_blocks, tp); }))) return rc;
-            if (it > 0) {
-                tp.rays = wp.rays_sh; tp.out = wp.occ; tp.n_ptr = &c->n_sh; tp.counter = &c->head_sh;
-                if ((rc = timed(1, [&]() { launch_traverse_kernel(s, true, s->trav_blocks, tp); }))) return rc;
+            if (it > 0 && !split_traversal) {  // this round's extension rays and the shadow rays of the previous vertices: one launch, one tail
+                tp.rays2 = wp.rays_sh; tp.out2 = wp.occ; tp.n2_ptr = &c->n_sh;
+                if ((rc = timed(0, [&]() { launch_traverse_kernel(s, 2, s->trav_blocks, tp); }))) return rc;
+            } else {
+                if ((rc = timed(0, [&]() { launch_traverse_kernel(s, 0, s->trav_blocks, tp); }))) return rc;
+                if (it > 0) {
+                    tp.rays = wp.rays_sh; tp.out = wp.occ; tp.n_ptr = &c->n_sh; tp.counter = &c->head_sh;
+                    if ((rc = timed(1, [&]() { launch_traverse_kernel(s, 1, s->trav_blocks, tp); }))) return rc;
+                }
             }
             if (spatial && (it < max_depth || s->has_none_material)) {  // vertices reached at bounce == max_depth sample no light (path.rs:136-139)
                 if ((rc = timed(2, [&]() {

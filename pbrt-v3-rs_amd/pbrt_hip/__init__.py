@@ -113,6 +113,8 @@ class Binding:
             "object_begin": (C.c_int, [vp, u32p]),
             "object_end": (C.c_int, [vp]),
             "add_instance": (C.c_int, [vp, C.c_uint32, fp, fp]),
+            "set_traversal_counting": (C.c_int, [vp, C.c_int]),
+            "get_traversal_counts": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         }
         for name, (res, args) in self._optional.items():
             if hasattr(self.lib, prefix + name):
@@ -442,6 +444,17 @@ class Scene:
         ms = C.c_float(0)
         self._chk(self.b.fn("occluded_batch_device")(self.h, d_rays_ptr, d_out_ptr, n, C.byref(ms)))
         return ms.value
+
+    def set_traversal_counting(self, on):
+        """Measurement aid (include/pbrt_hip.h): traversal launches also tally nodes / triangle tests / rays.  Never timed."""
+        self._chk(self.b.fn("set_traversal_counting")(self.h, 1 if on else 0))
+
+    def traversal_counts(self):
+        """{closest: nodes_passed, tri_tests, rays, ref_node_visits; any_hit: the same} since the last call (resets the tallies)."""
+        c = (C.c_uint64 * 8)()
+        self._chk(self.b.fn("get_traversal_counts")(self.h, c))
+        return {"closest": {"nodes_passed": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2]), "ref_node_visits": int(c[2]) + 2 * int(c[0])},
+                "any_hit": {"nodes_passed": int(c[3]), "tri_tests": int(c[4]), "rays": int(c[5]), "ref_node_visits": int(c[6])}}
 
     def _film_hw(self):
         if self.film_shape is None:

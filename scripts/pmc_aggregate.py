@@ -42,5 +42,11 @@ for k in agg:
         n = max(calls[k].values())
         out_json[k.strip()] = {"dispatches": n, "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c.get("WRITE_SIZE", 0.0),
                                "TCC_HIT": c.get("TCC_HIT_sum"), "TCC_MISS": c.get("TCC_MISS_sum")}
+# all traversal launches of the frame together (round 0 = closest-hit only kernel, later rounds = the MIXED kernel)
+tk = [k for k in out_json if "traverse_kernel" in k]
+if tk:
+    out_json["traversal"] = {"kernels": tk, "dispatches": sum(out_json[k]["dispatches"] for k in tk),
+                             "FETCH_SIZE_KB": sum(out_json[k]["FETCH_SIZE_KB"] for k in tk), "WRITE_SIZE_KB": sum(out_json[k]["WRITE_SIZE_KB"] for k in tk),
+                             "TCC_HIT": sum(out_json[k]["TCC_HIT"] or 0 for k in tk), "TCC_MISS": sum(out_json[k]["TCC_MISS"] or 0 for k in tk)}
 with open(os.path.join(out, "traffic.json"), "w") as f:
     json.dump(out_json, f, indent=1)

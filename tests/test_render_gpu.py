@@ -266,3 +266,33 @@ def test_spot_lights_bit_exact(host):
         base(s)
     for strategy in (0, 1, 2):
         _assert_film_bit_exact(cap, max_depth=4, light_strategy=strategy)
+
+
+@pytest.mark.parametrize("instances", [0, 3])
+def test_traversal_work_counters_equal_the_oracles(host, instances):
+    """The roofline's algorithmic bytes are built from node visits and triangle tests of the REFERENCE's traversal:
+    the device's counting pass must report, for both ray kinds, exactly what the oracle's instrumented
+    BVHAccel::intersect / intersect_p count for the same frame."""
+    spec = pbrt_hip.SceneSpec(n_tris=3000, xres=48, yres=40, spp=4, max_depth=4)
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    pbrt_hip.capture_spec(spec, prod, host, instances=instances); pbrt_hip.capture_spec(spec, orc, host, instances=instances)
+    set_libm_mode(1)
+    try:
+        oxyz, owt, ost, nvnt = orc.render_path_ex(max_depth=4, count_traversal=True)
+    finally:
+        set_libm_mode(0)
+    prod.set_traversal_counting(True)
+    gxyz, gwt, gst = prod.render_path(max_depth=4)
+    cnt = prod.traversal_counts()
+    prod.set_traversal_counting(False)
+    assert _bits_equal(gxyz, oxyz)
+    assert cnt["closest"]["rays"] == ost.regular_rays and cnt["any_hit"]["rays"] == ost.shadow_rays
+    assert cnt["closest"]["tri_tests"] == nvnt[1] and cnt["any_hit"]["tri_tests"] == nvnt[3]
+    if not instances:  # the oracle also counts the nodes of the objects' own BVHs' roots; the device's tally leaves instance roots out
+        assert cnt["closest"]["ref_node_visits"] == nvnt[0]
+        assert cnt["any_hit"]["ref_node_visits"] == nvnt[2]
+    else:
+        assert 0 < cnt["closest"]["ref_node_visits"] <= nvnt[0] and 0 < cnt["any_hit"]["ref_node_visits"] <= nvnt[2]
+    # counting must not change the image, and the counters reset on read
+    again = prod.traversal_counts()
+    assert again["closest"]["rays"] == 0 and again["any_hit"]["rays"] == 0
