@@ -67,11 +67,12 @@ typedef struct PbrtHipStats {
     uint64_t paths_zero_radiance;/* "Integrator/Zero-radiance paths" numerator (path.rs:168) */
     uint64_t paths_total;        /* its denominator (path.rs:164)                            */
     double render_seconds;       /* device time of the render phase (HIP events)             */
-    double extend_seconds;       /* of which: closest-hit traversal kernels                  */
-    double shadow_seconds;       /* of which: any-hit traversal kernels                      */
+    double extend_seconds;       /* of which: traversal launches that carry closest-hit rays (from the second wavefront round on they also
+                                    carry that round's shadow rays: one launch per round) */
+    double shadow_seconds;       /* of which: any-hit-only traversal launches (0 unless PBRT_HIP_SPLIT_TRAVERSAL is set) */
     double shade_seconds;        /* of which: raygen + shade + film kernels                  */
-    uint64_t extend_launches;    /* number of closest-hit traversal launches in this render  */
-    uint64_t shadow_launches;    /* number of any-hit traversal launches                     */
+    uint64_t extend_launches;    /* number of launches counted in extend_seconds             */
+    uint64_t shadow_launches;    /* number of launches counted in shadow_seconds             */
     uint64_t light_distributions_created; /* "SpatialLightDistribution/Distributions created" (light_distrib/spatial.rs:17-21) */
 } PbrtHipStats;
 
