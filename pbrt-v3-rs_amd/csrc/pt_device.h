@@ -64,24 +64,26 @@ PH_DEV uint32_t halton_pixel_offset(const SamplerRec& sp, int px, int py) {
     }
     return (uint32_t)off;
 }
-// The first PH_LDS_DIMS dimensions' tables (17.8 KB of digit permutations + primes + magic numbers) can be staged in LDS:
+// The first PH_LDS_DIMS dimensions' tables (6.7 KB of digit permutations + primes + magic numbers) can be staged in LDS:
 // a path vertex draws ~8 dimensions x ~7 digits, i.e. ~80 dependent table reads.  `lds` is null when a kernel does not stage them.
-#define PH_LDS_DIMS 64
-#define PH_LDS_PERMS 8893  // sum of the first 64 primes
+// 54 dimensions = every prime below 256, so a permutation entry fits a byte (maxdepth 5 uses dimensions 0..52; deeper paths read
+// the later dimensions from the global tables).  LDS per block decides how many shade blocks a CU holds.
+#define PH_LDS_DIMS 54
+#define PH_LDS_PERMS 6081  // sum of the first 54 primes
 struct HaltonLds {
-    uint16_t perms[PH_LDS_PERMS + 3];
+    uint8_t perms[PH_LDS_PERMS + 2];
     uint32_t primes[PH_LDS_DIMS], sums[PH_LDS_DIMS];
     uint64_t magic[PH_LDS_DIMS];
 };
 PH_DEV void halton_lds_fill(HaltonLds* l, const DeviceScene& sc) {  // cooperative; caller synchronises
-    for (uint32_t i = threadIdx.x; i < PH_LDS_PERMS; i += blockDim.x) l->perms[i] = sc.halton_perms[i];
+    for (uint32_t i = threadIdx.x; i < PH_LDS_PERMS; i += blockDim.x) l->perms[i] = (uint8_t)sc.halton_perms[i];
     for (uint32_t i = threadIdx.x; i < PH_LDS_DIMS; i += blockDim.x) { l->primes[i] = sc.primes[i]; l->sums[i] = sc.prime_sums[i]; l->magic[i] = sc.prime_magic[i]; }
 }
 // scrambled radical inverse reading the permutation from LDS
 PH_DEV float scrambled_radical_inverse_lds(const HaltonLds* l, uint32_t dim, uint32_t a) {
     const uint32_t base = l->primes[dim];
     const uint64_t magic = l->magic[dim];
-    const uint16_t* perm = l->perms + l->sums[dim];
+    const uint8_t* perm = l->perms + l->sums[dim];
     const float inv_base = ph_div(1.0f, (float)base);
     uint64_t reversed = 0;
     float inv_base_n = 1.0f;

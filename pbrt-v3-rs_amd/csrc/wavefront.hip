@@ -193,8 +193,11 @@ template <> struct BsdfOps<true> {
 };
 
 #define PH_SHADE_BLOCK 256
+// Waves per SIMD the shade kernels are compiled for.  40 KB of LDS per block allow 4 blocks per CU; the one-lobe kernel fits 128 VGPRs with
+// 51 spilled registers and gains 6 % from the fourth wave, the general-BSDF kernel would spill 181 and loses, so it stays at 3.
+#define PH_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(GEN ? 3 : 4, GEN ? 3 : 4)))
 template <bool GEN>
-__global__ __launch_bounds__(PH_SHADE_BLOCK) void shade_kernel(DeviceScene sc, WfParams w, int it) {
+__global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(DeviceScene sc, WfParams w, int it) {
     using BO = BsdfOps<GEN>;
     __shared__ float4 stage[3][2][PH_SHADE_BLOCK];           // [ext, mis, shadow][ray halves][thread]
     __shared__ uint32_t wave_cnt[3][PH_SHADE_BLOCK / 64];   // [cl, sh, live][wave]
