@@ -141,6 +141,29 @@ int pbrt_hip_object_begin(PbrtHipScene*, uint32_t* out_object_id);
 int pbrt_hip_object_end(PbrtHipScene*);
 int pbrt_hip_add_instance(PbrtHipScene*, uint32_t object_id, const float instance_to_world[16], const float world_to_instance[16]);
 
+/* ---- textures (textures/src/{constant,scale,mix,imagemap}.rs, core/src/mipmap/mod.rs) -------------------------------
+ * Float- and spectrum-valued textures share one id space; a float texture is a spectrum texture whose channels are equal.
+ * add_mipmap is generate_mipmap + MIPMap::new (core/src/mipmap/cache.rs:74-120, mod.rs:115-189): `rgb` is width*height
+ * texels as the reference's read_image returns them (row 0 = top of the image); the library flips them, applies
+ * `scale * (gamma ? inv_gamma_correct(x) : x)` (as_float: to the texel's luminance, ImageTexture<Float>), resamples to powers of two and
+ * builds the pyramid.  filtering: 0 trilinear, 1 EWA.  wrap: 0 repeat, 1 black, 2 clamp.  Image file decoding is the host's job.
+ * imagemap uses UVMapping2D (su, sv, du, dv) (core/src/texture/mapping/uv_2d.rs); other mappings are not provided yet.
+ * mix: (1 - amount) * tex1 + amount * tex2 with `amount` a float texture.  Trees deeper than 4 live values are refused. */
+int pbrt_hip_add_mipmap(PbrtHipScene*, int width, int height, const float* rgb, int as_float, float scale, int gamma, int filtering, int wrap,
+                        float max_anisotropy, uint32_t* out_mipmap);
+int pbrt_hip_add_texture_constant(PbrtHipScene*, const float value[3], uint32_t* out_texture);
+int pbrt_hip_add_texture_scale(PbrtHipScene*, uint32_t tex1, uint32_t tex2, uint32_t* out_texture);
+int pbrt_hip_add_texture_mix(PbrtHipScene*, uint32_t tex1, uint32_t tex2, uint32_t amount, uint32_t* out_texture);
+int pbrt_hip_add_texture_imagemap(PbrtHipScene*, uint32_t mipmap, float su, float sv, float du, float dv, uint32_t* out_texture);
+/* MatteMaterial whose Kd is a texture (materials/src/matte.rs:58-71): evaluated at every hit, with the ray differentials of camera rays
+ * (SurfaceInteraction::compute_differentials) driving the MIPMap filter.  sigma stays a constant. */
+int pbrt_hip_add_material_matte_tex(PbrtHipScene*, uint32_t kd_texture, float sigma_degrees, uint32_t* out_material);
+/* Test aids: evaluate a texture on the device at explicit (u, v, du/dx, dv/dx, du/dy, dv/dy) tuples; read back the pyramid the host built. */
+int pbrt_hip_texture_eval_batch(PbrtHipScene*, uint32_t texture, uint64_t n, const float* uv_and_derivatives /*6 per point*/, float* out_rgb /*3 per point*/);
+int pbrt_hip_mipmap_levels(PbrtHipScene*, uint32_t mipmap, int* out_levels, int* out_width_height /*2 per level, <= 16 levels*/);
+int pbrt_hip_mipmap_level_texels(PbrtHipScene*, uint32_t mipmap, int level, float* out_rgb);
+
+
 /* Lights are numbered in call order = position in Scene::lights (core/src/scene.rs:50-75). */
 int pbrt_hip_add_light_infinite(PbrtHipScene*, const float L_rgb[3], const float light_to_world[16],
                                 const float world_to_light[16]);       /* lights/src/infinite.rs:63-107, constant L */

@@ -262,7 +262,79 @@ int oracle_set_camera_perspective(OracleScene* s, const float r2c[16], const flo
     s->r.cam.camera_to_world = Transform(m4_from(c2w), M4::identity());
     s->r.cam.lens_radius = lens_radius; s->r.cam.focal_distance = focal_distance;
     s->r.cam.shutter_open = shutter_open; s->r.cam.shutter_close = shutter_close;
+    const Transform& rc = s->r.cam.raster_to_camera;  // perspective_camera.rs:70-74
+    s->r.cam.dx_camera = rc.point(V3(1, 0, 0)) - rc.point(V3(0, 0, 0));
+    s->r.cam.dy_camera = rc.point(V3(0, 1, 0)) - rc.point(V3(0, 0, 0));
     s->have_camera = true; return 0;
+}
+
+// ---- textures (oracle_texture.hpp).  One id space for float and spectrum textures; float ones carry three equal channels.
+int oracle_add_mipmap(OracleScene* s, int width, int height, const float* rgb, int as_float, float scale, int gamma, int filtering, int wrap,
+                      float max_anisotropy, uint32_t* out_id) {
+    if (!s || !rgb || width <= 0 || height <= 0) return -1;
+    MipMap m; m.build(rgb, (size_t)width, (size_t)height, as_float != 0, scale, gamma != 0, filtering, wrap, max_anisotropy);
+    s->sc.mipmaps.push_back(std::move(m));
+    if (out_id) *out_id = (uint32_t)s->sc.mipmaps.size() - 1;
+    return 0;
+}
+static int push_texture(OracleScene* s, const Texture& t, uint32_t* out_id) {
+    s->sc.textures.push_back(t);
+    if (out_id) *out_id = (uint32_t)s->sc.textures.size() - 1;
+    return 0;
+}
+int oracle_add_texture_constant(OracleScene* s, const float v[3], uint32_t* out_id) {
+    if (!s || !v) return -1;
+    Texture t; t.kind = TK_CONST; t.c = spec3(v); return push_texture(s, t, out_id);
+}
+int oracle_add_texture_scale(OracleScene* s, uint32_t t1, uint32_t t2, uint32_t* out_id) {
+    if (!s || t1 >= s->sc.textures.size() || t2 >= s->sc.textures.size()) return -1;
+    Texture t; t.kind = TK_SCALE; t.t1 = (int)t1; t.t2 = (int)t2; return push_texture(s, t, out_id);
+}
+int oracle_add_texture_mix(OracleScene* s, uint32_t t1, uint32_t t2, uint32_t amount, uint32_t* out_id) {
+    if (!s || t1 >= s->sc.textures.size() || t2 >= s->sc.textures.size() || amount >= s->sc.textures.size()) return -1;
+    Texture t; t.kind = TK_MIX; t.t1 = (int)t1; t.t2 = (int)t2; t.amount = (int)amount; return push_texture(s, t, out_id);
+}
+int oracle_add_texture_imagemap(OracleScene* s, uint32_t mipmap, float su, float sv, float du, float dv, uint32_t* out_id) {
+    if (!s || mipmap >= s->sc.mipmaps.size()) return -1;
+    Texture t; t.kind = TK_IMAGE; t.mip = (int)mipmap; t.su = su; t.sv = sv; t.du = du; t.dv = dv; return push_texture(s, t, out_id);
+}
+// probes for the pinning tests
+int oracle_texture_eval_batch(OracleScene* s, uint32_t tex, uint64_t n, const float* in /*6 per point: u v dudx dvdx dudy dvdy*/, float* out_rgb) {
+    if (!s || tex >= s->sc.textures.size()) return -1;
+    for (uint64_t i = 0; i < n; i++) {
+        TexCtx c; c.uv = V2(in[6 * i], in[6 * i + 1]); c.dudx = in[6 * i + 2]; c.dvdx = in[6 * i + 3]; c.dudy = in[6 * i + 4]; c.dvdy = in[6 * i + 5];
+        Spec v = tex_eval(s->sc.textures, s->sc.mipmaps, (int)tex, c);
+        out_rgb[3 * i] = v.c[0]; out_rgb[3 * i + 1] = v.c[1]; out_rgb[3 * i + 2] = v.c[2];
+    }
+    return 0;
+}
+int oracle_mipmap_levels(OracleScene* s, uint32_t mip, int* out_levels, int* out_wh /*2 per level, up to 32 levels*/) {
+    if (!s || mip >= s->sc.mipmaps.size()) return -1;
+    const MipMap& m = s->sc.mipmaps[mip];
+    *out_levels = (int)m.pyr.size();
+    for (size_t i = 0; i < m.pyr.size() && i < 32; i++) { out_wh[2 * i] = (int)m.pyr[i].w; out_wh[2 * i + 1] = (int)m.pyr[i].h; }
+    return 0;
+}
+int oracle_mipmap_level_texels(OracleScene* s, uint32_t mip, int level, float* out_rgb) {
+    if (!s || mip >= s->sc.mipmaps.size() || level < 0 || (size_t)level >= s->sc.mipmaps[mip].pyr.size()) return -1;
+    const MipMap::Level& l = s->sc.mipmaps[mip].pyr[(size_t)level];
+    for (size_t i = 0; i < l.t.size(); i++) { out_rgb[3 * i] = l.t[i].c[0]; out_rgb[3 * i + 1] = l.t[i].c[1]; out_rgb[3 * i + 2] = l.t[i].c[2]; }
+    return 0;
+}
+int oracle_add_material_matte_tex(OracleScene* s, uint32_t kd_tex, float sigma, uint32_t* out_id) {  // matte.rs:47-76 with a texture for Kd
+    if (!s || kd_tex >= s->sc.textures.size()) return -1;
+    Material m; m.kd = Spec(0.0f); m.sigma = sigma; m.kd_tex = (int)kd_tex;
+    Float sig = pclamp(sigma, 0.0f, 90.0f);
+    Lobe l; l.type = BX_REFL | BX_DIFF;
+    if (sig == 0.0f) l.kind = LK_LAMBERT;
+    else {
+        l.kind = LK_OREN;
+        Float sg = to_radians(sig), s2 = sg * sg;
+        l.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
+        l.b = 0.45f * s2 / (s2 + 0.09f);
+    }
+    m.lobes.push_back(l);
+    return push_material(s, m, out_id);
 }
 int oracle_set_film(OracleScene* s, int xres, int yres, const int crop[4], const float radius[2], const float table[256], float scale,
                     float max_lum) {

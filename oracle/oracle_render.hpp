@@ -319,6 +319,8 @@ struct SurfaceHit {  // the fields of Hit/SurfaceInteraction/Shading the path in
     V3 ns, dpdu_s;          // shading.n, shading.dpdu
     Float time;
     uint32_t prim;
+    V2 uv; V3 dpdu, dpdv;   // SurfaceInteraction.uv, der.dpdu / der.dpdv (geometric)
+    Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;  // der, filled by compute_differentials
 };
 
 // Ray::offset_origin (core/src/geometry/ray.rs:107-127)
@@ -363,6 +365,7 @@ struct RayRecorder {  // optional capture of every ray handed to Scene::intersec
 struct Camera {  // cameras/src/perspective_camera.rs
     Transform raster_to_camera, camera_to_world;
     Float lens_radius = 0, focal_distance = 1e6f, shutter_open = 0, shutter_close = 1;
+    V3 dx_camera, dy_camera;  // perspective_camera.rs:70-74, set with the camera
 };
 struct FilmCfg {
     int xres = 0, yres = 0; int crop[4] = {0, 0, 0, 0};
@@ -417,6 +420,7 @@ struct Renderer {
         si.ns = normalize(t.normal(si.ns));
         si.ns = face_forward(si.ns, si.n);
         si.dpdu_s = t.vector(si.dpdu_s);
+        si.dpdu = t.vector(si.dpdu); si.dpdv = t.vector(si.dpdv);  // transform.rs:566-590
         return si;
     }
     SurfaceHit make_surface_hit_local(const Ray& r, uint32_t prim, const TriHit& h) const {
@@ -437,6 +441,8 @@ struct Renderer {
         si.n = normalize(cross(dp02, dp12));
         if (m.reverse_orientation ^ m.swaps_handedness) si.n = -si.n;
         si.ns = si.n; si.dpdu_s = dpdu;
+        si.dpdu = dpdu; si.dpdv = dpdv;
+        { V2 uv[3]; s.tri_uvs(prim, uv); si.uv = V2((b0 * uv[0].x + b1 * uv[1].x) + b2 * uv[2].x, (b0 * uv[0].y + b1 * uv[1].y) + b2 * uv[2].y); }  // triangle.rs:584
         if (m.has_n || m.has_s) {  // :631-721
             V3 ns;
             if (m.has_n) {
@@ -907,10 +913,17 @@ struct Renderer {
             return true;
         }
     };
-    BSDF make_bsdf(const SurfaceHit& si) const {
+    // `local` receives the per-hit lobe of a textured material; the returned BSDF points at it, so it must outlive the BSDF
+    BSDF make_bsdf(const SurfaceHit& si, Lobe& local) const {
         const Material& m = sc->materials[sc->mesh_of(si.prim).material];
         BSDF b; b.ns = si.ns; b.ng = si.n; b.ss = normalize(si.dpdu_s); b.ts = cross(b.ns, b.ss);  // bsdf.rs:100-116
         b.lobes = m.lobes.data(); b.n = (int)m.lobes.size(); b.eta = m.bsdf_eta;
+        if (m.kd_tex >= 0) {  // MatteMaterial::compute_scattering_functions with a texture (matte.rs:58-68)
+            TexCtx c; c.uv = si.uv; c.dudx = si.dudx; c.dvdx = si.dvdx; c.dudy = si.dudy; c.dvdy = si.dvdy;
+            Spec r = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, m.kd_tex, c));
+            if (r.is_black()) { b.lobes = nullptr; b.n = 0; }
+            else { local = m.lobes[0]; local.r = r; b.lobes = &local; b.n = 1; }
+        }
         return b;
     }
 
@@ -1070,7 +1083,9 @@ struct Renderer {
                 ray = spawn_ray(isect.p, isect.p_error, isect.n, isect.time, ray.d);
                 continue;
             }
-            BSDF bsdf = make_bsdf(isect);
+            compute_differentials(isect, ray);  // SurfaceInteraction::compute_scattering_functions (surface_interaction.rs:176-195)
+            Lobe hit_lobe;
+            BSDF bsdf = make_bsdf(isect, hit_lobe);
             V3 shading_n = isect.ns;
             if (spatial) (void)spatial_lookup(isect.p);  // light_distribution.lookup(&isect.hit.p) happens for every vertex (path.rs:156-157)
             if (bsdf.num_components(BX_ALL & ~BX_SPEC) > 0) {
@@ -1113,11 +1128,68 @@ struct Renderer {
             ray.o = V3(p_lens.x, p_lens.y, 0.0f);
             ray.d = normalize(p_focus - ray.o);
         }
+        // ray differentials (perspective_camera.rs:173-200), carried to world space by transform_ray (transform.rs:464-472)
+        V3 rx_o, ry_o, rx_d, ry_d;
+        if (cam.lens_radius > 0.0f) {
+            V2 cd = concentric_sample_disk(p_lens_s);
+            V2 p_lens(cam.lens_radius * cd.x, cam.lens_radius * cd.y);
+            V3 dx = normalize(p_camera + cam.dx_camera);
+            Float ft = cam.focal_distance / dx.z;
+            V3 p_focus = V3(0, 0, 0) + (ft * dx);
+            rx_o = V3(p_lens.x, p_lens.y, 0.0f); rx_d = normalize(p_focus - rx_o);
+            V3 dy = normalize(p_camera + cam.dy_camera);
+            ft = cam.focal_distance / dy.z;
+            p_focus = V3(0, 0, 0) + (ft * dy);
+            ry_o = V3(p_lens.x, p_lens.y, 0.0f); ry_d = normalize(p_focus - ry_o);
+        } else {
+            rx_o = ray.o; ry_o = ray.o;
+            rx_d = normalize(p_camera + cam.dx_camera); ry_d = normalize(p_camera + cam.dy_camera);
+        }
         V3 o_err; V3 o = cam.camera_to_world.point_with_error(ray.o, o_err);
         V3 d = cam.camera_to_world.vector(ray.d);
         Float l2 = length_squared(d), t_max = ray.t_max;
         if (l2 > 0.0f) { Float dt = dot(vabs(d), o_err) / l2; o = o + d * dt; t_max -= dt; }  // quirk B2
-        return Ray(o, d, t_max, ray.time);
+        Ray out(o, d, t_max, ray.time);
+        out.has_diff = true;
+        out.rx_o = cam.camera_to_world.point(rx_o); out.ry_o = cam.camera_to_world.point(ry_o);
+        out.rx_d = cam.camera_to_world.vector(rx_d); out.ry_d = cam.camera_to_world.vector(ry_d);
+        return out;
+    }
+    static void scale_differentials(Ray& r, Float sc) {  // ray.rs:90-99
+        if (!r.has_diff) return;
+        r.rx_o = r.o + (r.rx_o - r.o) * sc; r.ry_o = r.o + (r.ry_o - r.o) * sc;
+        r.rx_d = r.d + (r.rx_d - r.d) * sc; r.ry_d = r.d + (r.ry_d - r.d) * sc;
+    }
+    // SurfaceInteraction::compute_differentials (surface_interaction.rs:203-278)
+    static void compute_differentials(SurfaceHit& si, const Ray& ray) {
+        si.dudx = si.dvdx = si.dudy = si.dvdy = 0.0f;
+        if (!ray.has_diff) return;
+        V3 n = si.n, p = si.p;
+        Float d = dot(n, p);
+        Float tx = -(dot(n, ray.rx_o) - d) / dot(n, ray.rx_d);
+        if (std::isinf(tx) || tx != tx) return;
+        V3 px = ray.rx_o + tx * ray.rx_d;
+        Float ty = -(dot(n, ray.ry_o) - d) / dot(n, ray.ry_d);
+        if (std::isinf(ty) || ty != ty) return;
+        V3 py = ray.ry_o + ty * ray.ry_d;
+        int dim[2];
+        if (std::fabs(n.x) > std::fabs(n.y) && std::fabs(n.x) > std::fabs(n.z)) { dim[0] = 1; dim[1] = 2; }
+        else if (std::fabs(n.y) > std::fabs(n.z)) { dim[0] = 0; dim[1] = 2; }
+        else { dim[0] = 0; dim[1] = 1; }
+        auto comp = [](V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); };
+        Float a[2][2] = {{comp(si.dpdu, dim[0]), comp(si.dpdv, dim[0])}, {comp(si.dpdu, dim[1]), comp(si.dpdv, dim[1])}};
+        Float bx[2] = {comp(px, dim[0]) - comp(p, dim[0]), comp(px, dim[1]) - comp(p, dim[1])};
+        Float by[2] = {comp(py, dim[0]) - comp(p, dim[0]), comp(py, dim[1]) - comp(p, dim[1])};
+        auto solve = [&](const Float b[2], Float& x0, Float& x1) {  // matrix4x4.rs:305-318
+            Float det = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+            if (std::fabs(det) < 1e-10f) return false;
+            x0 = (a[1][1] * b[0] - a[0][1] * b[1]) / det;
+            x1 = (a[0][0] * b[1] - a[1][0] * b[0]) / det;
+            return !(x0 != x0 || x1 != x1);
+        };
+        Float u0, u1;
+        if (solve(bx, u0, u1)) { si.dudx = u0; si.dvdx = u1; }
+        if (solve(by, u0, u1)) { si.dudy = u0; si.dvdy = u1; }
     }
 
     // ---- Film ---------------------------------------------------------------------------------------------------
@@ -1175,6 +1247,7 @@ struct Renderer {
                     Float time = sampler.get_1d();
                     V2 p_lens = sampler.get_2d();
                     Ray ray = generate_ray(p_film, time, p_lens);
+                    scale_differentials(ray, 1.0f / std::sqrt((Float)sampler.spp));  // sampler_integrator.rs:358
                     tls_stats().camera_rays++;
                     Spec L = li(ray, sampler);  // ray_weight is always 1.0 for the perspective camera
                     if (L.has_nans()) L = Spec(0.0f);

@@ -13,12 +13,15 @@
 #include <cstdio>
 #include <string>
 #include <vector>
+#include "oracle_texture.hpp"
 
 namespace orc {
 
-struct Ray {  // core/src/geometry/ray.rs:10-28 (differentials are dead for constant textures; medium out of scope)
+struct Ray {  // core/src/geometry/ray.rs:10-28 (medium out of scope)
     V3 o, d;
     Float t_max, time;
+    bool has_diff = false;          // ray.differentials: Some only for camera rays (spawn_ray never sets them)
+    V3 rx_o, ry_o, rx_d, ry_d;
     Ray() : t_max(INF), time(0) {}
     Ray(V3 o_, V3 d_, Float tm, Float ti) : o(o_), d(d_), t_max(tm), time(ti) {}
 };
@@ -37,7 +40,10 @@ struct Lobe {
     Spec c_eta_i, c_eta_t, c_k;  // conductor Fresnel
     int n_scale = 0; Spec scale[2];  // ScaledBxDF wrappers of MixMaterial, innermost first (scaled_bxdf.rs)
 };
-struct Material { Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; bool none = false; };  // none: Material "none" / "" -> no BSDF at all
+struct Material {
+    Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; bool none = false;  // none: Material "none" / "" -> no BSDF at all
+    int kd_tex = -1;  // MatteMaterial with a non-constant Kd: the lobe is made per hit (matte.rs:58-68); `lobes` then holds its template (r unset)
+};
 
 enum LightType { L_INFINITE = 0, L_DISTANT = 1, L_POINT = 2, L_AREA = 3, L_SPOT = 4 };
 struct Light {
@@ -111,6 +117,8 @@ struct Scene {
     std::vector<uint32_t> tri_mesh;   // mesh id per triangle
     std::vector<Mesh> meshes;
     std::vector<Material> materials;
+    std::vector<Texture> textures;    // float and spectrum textures share one id space
+    std::vector<MipMap> mipmaps;
     std::vector<Light> lights;
     std::vector<int> infinite_lights;
     // objects / instances; top_items = the scene's primitive list in directive order (triangle id, or ORC_INST_BIT | instance)

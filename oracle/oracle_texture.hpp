@@ -1,0 +1,237 @@
+// TEST INFRASTRUCTURE ONLY (see oracle_math.hpp).  CPU restatement of the reference's image textures:
+//   MIPMap<T>::new / lookup / triangle / ewa / resample_image / resample_weights / texel   core/src/mipmap/mod.rs:115-608
+//   generate_mipmap (y flip + convert_in)                                                  core/src/mipmap/cache.rs:74-120, convert_in.rs:20-47
+//   ImageTexture / ScaleTexture / MixTexture / ConstantTexture evaluate                    textures/src/{imagemap,scale,mix,constant}.rs
+//   UVMapping2D::map                                                                       core/src/texture/mapping/uv_2d.rs:52-60
+//   lanczos                                                                                core/src/texture/common.rs:216-228
+// Float-valued textures (ImageTexture<Float>, ...) are carried as Spec with three equal channels: every operation the reference applies
+// to them is applied per channel here, except `sum / sum_wts` in ewa(), a true division for Float and a multiply by the reciprocal for
+// RGBSpectrum (rgb_spectrum.rs:255-263) — `is_float` selects it.
+#pragma once
+#include "oracle_math.hpp"
+#include <vector>
+
+namespace orc {
+
+inline Float o_log2(Float x) { return g_libm_mode ? (Float)std::log2((double)x) : std::log2(x); }
+
+enum { TEX_WRAP_REPEAT = 0, TEX_WRAP_BLACK = 1, TEX_WRAP_CLAMP = 2 };
+enum { TEX_FILTER_TRILINEAR = 0, TEX_FILTER_EWA = 1 };
+static const int WEIGHT_LUT_SIZE = 128;  // mipmap/mod.rs:24
+
+inline int64_t rem_i(int64_t a, int64_t b) { int64_t r = a - (a / b) * b; return r < 0 ? r + b : r; }  // pbrt/common.rs:116-126
+inline int64_t f2isize(Float f) {  // `as isize`: saturating, NaN -> 0
+    if (f != f) return 0;
+    if (f >= 9223372036854775808.0f) return INT64_MAX;
+    if (f <= -9223372036854775808.0f) return INT64_MIN;
+    return (int64_t)f;
+}
+inline Float lanczos(Float x, Float tau) {  // texture/common.rs:216-228 (host-side f32 sin: libm's, like the reference's)
+    x = std::fabs(x);
+    if (x < 1e-5f) return 1.0f;
+    if (x > 1.0f) return 0.0f;
+    x *= PI;
+    Float s = std::sin(x * tau) / (x * tau);
+    Float l = std::sin(x) / x;
+    return s * l;
+}
+inline Float inv_gamma_correct(Float v) {  // pbrt/common.rs:152-158
+    if (v <= 0.04045f) return v * 1.0f / 12.92f;
+    return std::pow((v + 0.055f) * 1.0f / 1.055f, 2.4f);
+}
+
+struct ResampleWeight { size_t first_texel; Float weight[4]; };
+inline std::vector<ResampleWeight> resample_weights(size_t old_res, size_t new_res) {  // mipmap/mod.rs:535-560
+    std::vector<ResampleWeight> wt(new_res);
+    const Float filterwidth = 2.0f;
+    for (size_t i = 0; i < new_res; i++) {
+        Float center = ((Float)i + 0.5f) * (Float)old_res / (Float)new_res;
+        wt[i].first_texel = f2usize(std::floor((center - filterwidth) + 0.5f));  // `as usize`: negative saturates to 0 (a quirk: C++ pbrt keeps the sign)
+        for (int j = 0; j < 4; j++) {
+            Float pos = (Float)wt[i].first_texel + (Float)j + 0.5f;
+            wt[i].weight[j] = lanczos((pos - center) / filterwidth, 2.0f);
+        }
+        Float inv_sum = 1.0f / (wt[i].weight[0] + wt[i].weight[1] + wt[i].weight[2] + wt[i].weight[3]);
+        for (int j = 0; j < 4; j++) wt[i].weight[j] *= inv_sum;
+    }
+    return wt;
+}
+
+struct MipMap {
+    int filtering = TEX_FILTER_EWA, wrap = TEX_WRAP_REPEAT;
+    Float max_anisotropy = 8.0f;
+    bool is_float = false;
+    struct Level { int64_t w, h; std::vector<Spec> t; };
+    std::vector<Level> pyr;
+    Float weight_lut[WEIGHT_LUT_SIZE];
+
+    Spec texel(size_t level, int64_t s, int64_t t) const {  // mipmap/mod.rs:569-608
+        const Level& l = pyr[level];
+        switch (wrap) {
+            case TEX_WRAP_REPEAT: s = rem_i(s, l.w); t = rem_i(t, l.h); break;
+            case TEX_WRAP_CLAMP: s = pclamp<int64_t>(s, 0, l.w - 1); t = pclamp<int64_t>(t, 0, l.h - 1); break;
+            default: if (s < 0 || s >= l.w || t < 0 || t >= l.h) return Spec(0.0f);
+        }
+        return l.t[(size_t)t * (size_t)l.w + (size_t)s];
+    }
+
+    // `rgb`: w*h texels as read_image returns them (top row first).  generate_mipmap: flip in y, convert_in, MIPMap::new.
+    void build(const Float* rgb, size_t w, size_t h, bool as_float, Float scale, bool gamma, int filtering_, int wrap_, Float max_aniso) {
+        filtering = filtering_; wrap = wrap_; max_anisotropy = max_aniso; is_float = as_float;
+        std::vector<Spec> img(w * h);
+        for (size_t y = 0; y < h; y++)
+            for (size_t x = 0; x < w; x++) {
+                const Float* px = rgb + 3 * ((h - 1 - y) * w + x);
+                Spec in(px[0], px[1], px[2]);
+                if (as_float) { Float yv = in.y(); img[y * w + x] = Spec(scale * (gamma ? inv_gamma_correct(yv) : yv)); }
+                else img[y * w + x] = Spec(scale * (gamma ? inv_gamma_correct(in.c[0]) : in.c[0]), scale * (gamma ? inv_gamma_correct(in.c[1]) : in.c[1]),
+                                           scale * (gamma ? inv_gamma_correct(in.c[2]) : in.c[2]));
+            }
+        size_t rw = w, rh = h;
+        auto pow2 = [](size_t v) { return v && !(v & (v - 1)); };
+        if (!pow2(w) || !pow2(h)) {  // resample_image (mipmap/mod.rs:383-529)
+            auto next_pow2 = [](size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; };
+            rw = next_pow2(w); rh = next_pow2(h);
+            std::vector<Spec> r(rw * rh, Spec(0.0f));
+            std::vector<ResampleWeight> sw = resample_weights(w, rw);
+            for (size_t t = 0; t < h; t++)
+                for (size_t s = 0; s < rw; s++) {
+                    Spec pixel(0.0f);
+                    for (int j = 0; j < 4; j++) {
+                        size_t os = sw[s].first_texel + j;
+                        if (wrap == TEX_WRAP_REPEAT) os = os % w;
+                        else if (wrap == TEX_WRAP_CLAMP) os = pclamp<size_t>(os, 0, w - 1);
+                        if (os < w) pixel += img[t * w + os] * sw[s].weight[j];
+                    }
+                    r[t * rw + s] += pixel;
+                }
+            std::vector<ResampleWeight> tw = resample_weights(h, rh);
+            std::vector<Spec> work(rh);
+            for (size_t s = 0; s < rw; s++) {
+                for (size_t t = 0; t < rh; t++) {
+                    work[t] = Spec(0.0f);
+                    for (int j = 0; j < 4; j++) {
+                        size_t off = tw[t].first_texel + j;
+                        if (wrap == TEX_WRAP_REPEAT) off = off % h;
+                        else if (wrap == TEX_WRAP_CLAMP) off = pclamp<size_t>(off, 0, h - 1);
+                        if (off < h) work[t] += r[off * rw + s] * tw[t].weight[j];
+                    }
+                }
+                for (size_t t = 0; t < rh; t++) r[t * rw + s] = spec_clamp0(work[t]);
+            }
+            img.swap(r);
+        }
+        size_t m = rw > rh ? rw : rh, n_levels = 1;
+        while ((m >>= 1)) n_levels++;  // 1 + log2int(max(w, h))
+        pyr.clear(); pyr.reserve(n_levels);
+        pyr.push_back(Level{(int64_t)rw, (int64_t)rh, img});
+        for (size_t i = 1; i < n_levels; i++) {
+            int64_t sr = pmax<int64_t>(1, pyr[i - 1].w / 2), tr = pmax<int64_t>(1, pyr[i - 1].h / 2);
+            Level l{sr, tr, std::vector<Spec>((size_t)(sr * tr))};
+            for (int64_t t = 0; t < tr; t++)
+                for (int64_t s = 0; s < sr; s++)
+                    l.t[(size_t)(t * sr + s)] = (texel(i - 1, 2 * s, 2 * t) + texel(i - 1, 2 * s + 1, 2 * t) + texel(i - 1, 2 * s, 2 * t + 1) + texel(i - 1, 2 * s + 1, 2 * t + 1)) * 0.25f;
+            pyr.push_back(std::move(l));
+        }
+        for (int i = 0; i < WEIGHT_LUT_SIZE; i++) {
+            Float r2 = (Float)i / (Float)(WEIGHT_LUT_SIZE - 1);
+            weight_lut[i] = std::exp(-2.0f * r2) - std::exp(-2.0f);
+        }
+    }
+
+    Spec triangle(size_t level, V2 st) const {  // mipmap/mod.rs:293-312
+        level = pclamp<size_t>(level, 0, pyr.size() - 1);
+        Float s = st.x * (Float)pyr[level].w - 0.5f, t = st.y * (Float)pyr[level].h - 0.5f;
+        int64_t s0 = f2isize(std::floor(s)), t0 = f2isize(std::floor(t));
+        Float ds = s - (Float)s0, dt = t - (Float)t0;
+        return texel(level, s0, t0) * (1.0f - ds) * (1.0f - dt) + texel(level, s0, t0 + 1) * (1.0f - ds) * dt + texel(level, s0 + 1, t0) * ds * (1.0f - dt) +
+               texel(level, s0 + 1, t0 + 1) * ds * dt;
+    }
+    Spec ewa(size_t level, V2 st, V2 dst0, V2 dst1) const {  // mipmap/mod.rs:320-371
+        if (level >= pyr.size()) return texel(pyr.size() - 1, 0, 0);
+        Float us = (Float)pyr[level].w, vs = (Float)pyr[level].h;
+        Float s = st.x * us - 0.5f, t = st.y * vs - 0.5f;
+        Float d0x = dst0.x * us, d0y = dst0.y * vs, d1x = dst1.x * us, d1y = dst1.y * vs;
+        Float a = d0y * d0y + d1y * d1y + 1.0f;
+        Float b = -2.0f * (d0x * d0y + d1x * d1y);
+        Float c = d0x * d0x + d1x * d1x + 1.0f;
+        Float inv_f = 1.0f / (a * c - b * b * 0.25f);
+        a *= inv_f; b *= inv_f; c *= inv_f;
+        Float det = -b * b + 4.0f * a * c;
+        Float inv_det = 1.0f / det;
+        Float u_sqrt = std::sqrt(det * c), v_sqrt = std::sqrt(a * det);
+        int64_t s0 = f2isize(std::ceil(s - 2.0f * inv_det * u_sqrt)), s1 = f2isize(std::floor(s + 2.0f * inv_det * u_sqrt));
+        int64_t t0 = f2isize(std::ceil(t - 2.0f * inv_det * v_sqrt)), t1 = f2isize(std::floor(t + 2.0f * inv_det * v_sqrt));
+        Spec sum(0.0f); Float sum_wts = 0.0f;
+        for (int64_t it = t0; it <= t1; it++) {
+            Float tt = (Float)it - t;
+            for (int64_t is = s0; is <= s1; is++) {
+                Float ss = (Float)is - s;
+                Float r2 = a * ss * ss + b * ss * tt + c * tt * tt;
+                if (r2 < 1.0f) {
+                    size_t index = pmin<size_t>(f2usize(r2 * (Float)WEIGHT_LUT_SIZE), WEIGHT_LUT_SIZE - 1);
+                    Float weight = weight_lut[index];
+                    sum += texel(level, is, it) * weight;
+                    sum_wts += weight;
+                }
+            }
+        }
+        if (is_float) return Spec(sum.c[0] / sum_wts);
+        return sum / sum_wts;
+    }
+    Spec lookup(V2 st, V2 dst0, V2 dst1) const {  // mipmap/mod.rs:205-290
+        const size_t levels = pyr.size();
+        if (filtering == TEX_FILTER_TRILINEAR) {
+            Float width = pmax(pmax(pabs(dst0.x), pabs(dst0.y)), pmax(pabs(dst1.x), pabs(dst1.y)));
+            Float level = (Float)levels - 1.0f + o_log2(pmax(width, 1e-8f));
+            if (level < 0.0f) return triangle(0, st);
+            if (level >= (Float)(levels - 1)) return texel(levels - 1, 0, 0);
+            size_t il = f2usize(std::floor(level));
+            Float delta = level - (Float)il;
+            return triangle(il, st) * (1.0f - delta) + triangle(il + 1, st) * delta;
+        }
+        if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) { V2 tmp = dst0; dst0 = dst1; dst1 = tmp; }
+        Float major_length = std::sqrt(dst0.x * dst0.x + dst0.y * dst0.y);
+        Float minor_length = std::sqrt(dst1.x * dst1.x + dst1.y * dst1.y);
+        Float adjusted = minor_length * max_anisotropy;
+        if (adjusted < major_length && minor_length > 0.0f) {
+            Float sc = major_length / adjusted;
+            dst1.x *= sc; dst1.y *= sc;
+            minor_length *= sc;
+        }
+        if (minor_length == 0.0f) return triangle(0, st);
+        Float lod = pmax(0.0f, (Float)levels - 1.0f + o_log2(minor_length));
+        size_t il = f2usize(std::floor(lod));
+        Float t = lod - (Float)il;
+        return ewa(il, st, dst0, dst1) * (1.0f - t) + ewa(il + 1, st, dst0, dst1) * t;
+    }
+};
+
+enum { TK_CONST = 0, TK_SCALE = 1, TK_MIX = 2, TK_IMAGE = 3 };
+struct Texture {
+    int kind = TK_CONST;
+    Spec c;                       // TK_CONST (float textures: three equal channels)
+    int t1 = -1, t2 = -1, amount = -1;
+    int mip = -1; Float su = 1, sv = 1, du = 0, dv = 0;  // TK_IMAGE + UVMapping2D
+};
+struct TexCtx { V2 uv; Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0; };
+
+inline Spec tex_eval(const std::vector<Texture>& tex, const std::vector<MipMap>& mips, int id, const TexCtx& c) {
+    const Texture& t = tex[(size_t)id];
+    switch (t.kind) {
+        case TK_SCALE: return tex_eval(tex, mips, t.t1, c) * tex_eval(tex, mips, t.t2, c);
+        case TK_MIX: {
+            Spec a = tex_eval(tex, mips, t.t1, c), b = tex_eval(tex, mips, t.t2, c);
+            Float amt = tex_eval(tex, mips, t.amount, c).c[0];
+            return (1.0f - amt) * a + amt * b;
+        }
+        case TK_IMAGE: {
+            V2 dstdx(t.su * c.dudx, t.sv * c.dvdx), dstdy(t.su * c.dudy, t.sv * c.dvdy);
+            V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+            return mips[(size_t)t.mip].lookup(st, dstdx, dstdy);
+        }
+        default: return t.c;
+    }
+}
+
+}  // namespace orc

@@ -4,6 +4,7 @@
 #include "host_math.h"
 #include "scene_host.h"
 #include "traverse.h"
+#include "texture.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +82,23 @@ int upload_scene(PbrtHipScene* s) {
     if ((rc = upload_vec(s, s->meshes, &d.meshes))) return rc;
     if ((rc = upload_vec(s, s->materials, &d.materials))) return rc;
     if ((rc = upload_vec(s, s->lobes, &d.lobes))) return rc;
+    if (!s->textures.empty()) {
+        std::vector<TexRec> recs; std::vector<TexOp> ops;
+        for (const PbrtHipScene::TextureHost& t : s->textures) {
+            recs.push_back(TexRec{(uint32_t)ops.size(), (uint32_t)t.prog.size()});
+            ops.insert(ops.end(), t.prog.begin(), t.prog.end());
+        }
+        std::vector<float> lut(PH_EWA_LUT_SIZE);
+        for (int i = 0; i < PH_EWA_LUT_SIZE; i++) {  // mipmap/mod.rs:168-174 (host expf, as in the reference)
+            const float r2 = (float)i / (float)(PH_EWA_LUT_SIZE - 1);
+            lut[(size_t)i] = std::exp(-2.0f * r2) - std::exp(-2.0f);
+        }
+        if ((rc = upload_vec(s, recs, &d.textures))) return rc;
+        if ((rc = upload_vec(s, ops, &d.tex_ops))) return rc;
+        if ((rc = upload_vec(s, s->mipmaps, &d.mipmaps))) return rc;
+        if ((rc = upload_vec(s, s->texels, &d.texels))) return rc;
+        if ((rc = upload_vec(s, lut, &d.ewa_lut))) return rc;
+    }
     if ((rc = upload_vec(s, s->lights, &d.lights))) return rc;
     d.n_lights = (uint32_t)s->lights.size();
     if ((rc = upload_vec(s, s->infinite_lights, &d.infinite_lights))) return rc;
@@ -95,6 +113,13 @@ int upload_scene(PbrtHipScene* s) {
     if ((rc = upload_vec(s, s->sobol32, &d.sobol32))) return rc;
     if ((rc = upload_vec(s, s->vdc, &d.vdc))) return rc;
     if ((rc = upload_vec(s, s->vdc_inv, &d.vdc_inv))) return rc;
+    {   // device-resident copy of the struct itself (DeviceScene::self), for out-of-line device functions
+        void* dself = nullptr;
+        PH_CHECK(s, hipMalloc(&dself, sizeof(DeviceScene)));
+        s->owned.push_back(dself);
+        d.self = reinterpret_cast<const DeviceScene*>(dself);
+        PH_CHECK(s, hipMemcpyAsync(dself, &d, sizeof(DeviceScene), hipMemcpyHostToDevice, s->stream));
+    }
     PH_CHECK(s, hipStreamSynchronize(s->stream));
     s->uploaded = true;
     return PBRT_HIP_OK;
@@ -359,6 +384,215 @@ int pbrt_hip_add_material_matte(PbrtHipScene* s, const float kd[3], float sigma_
         lobes.push_back(l);
     }
     return push_material(s, m, lobes, false, out_id);
+}
+// ---- textures --------------------------------------------------------------------------------------------------------------------
+namespace {
+inline float inv_gamma_correct(float v) {  // pbrt/common.rs:152-158 (host powf, as in the reference)
+    if (v <= 0.04045f) return v * 1.0f / 12.92f;
+    return std::pow((v + 0.055f) * 1.0f / 1.055f, 2.4f);
+}
+inline float lanczos2(float x) {  // texture/common.rs:216-228 with tau = 2
+    x = std::fabs(x);
+    if (x < 1e-5f) return 1.0f;
+    if (x > 1.0f) return 0.0f;
+    x *= hm::kPi;
+    const float s = std::sin(x * 2.0f) / (x * 2.0f);
+    const float l = std::sin(x) / x;
+    return s * l;
+}
+struct RsWeight { size_t first; float w[4]; };
+// resample_weights (mipmap/mod.rs:535-560).  `first` is a usize in the reference: a negative start saturates to 0.
+void resample_weights(size_t old_res, size_t new_res, std::vector<RsWeight>& wt) {
+    wt.resize(new_res);
+    for (size_t i = 0; i < new_res; i++) {
+        const float center = ((float)i + 0.5f) * (float)old_res / (float)new_res;
+        const float f = std::floor((center - 2.0f) + 0.5f);
+        wt[i].first = f > 0.0f ? (size_t)f : 0;
+        for (int j = 0; j < 4; j++) wt[i].w[j] = lanczos2((((float)wt[i].first + (float)j + 0.5f) - center) / 2.0f);
+        const float inv = 1.0f / (wt[i].w[0] + wt[i].w[1] + wt[i].w[2] + wt[i].w[3]);
+        for (int j = 0; j < 4; j++) wt[i].w[j] *= inv;
+    }
+}
+inline size_t wrap_index(size_t i, size_t n, int wrap) { return wrap == 0 ? i % n : (wrap == 2 ? (i > n - 1 ? n - 1 : i) : i); }
+int push_texture(PbrtHipScene* s, PbrtHipScene::TextureHost&& t, uint32_t* out_id) {
+    if (t.stack_need > PH_TEX_STACK) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "texture: scale / mix nesting needs more than 4 live values");
+    s->textures.push_back(std::move(t));
+    if (out_id) *out_id = (uint32_t)s->textures.size() - 1;
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+}  // namespace
+
+// generate_mipmap + MIPMap::new (mipmap/cache.rs:74-120, mipmap/mod.rs:115-189): flip in y, convert texels, resample to powers of
+// two, box-filter the pyramid.  Texels are kept as three floats per texel while building.
+int pbrt_hip_add_mipmap(PbrtHipScene* s, int width, int height, const float* rgb, int as_float, float scale, int gamma, int filtering, int wrap,
+                        float max_anisotropy, uint32_t* out_id) {
+    if (!s || !rgb) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: null argument");
+    if (width <= 0 || height <= 0 || width > 32768 || height > 32768) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: resolution must be within 1..32768");
+    if (filtering < 0 || filtering > 1 || wrap < 0 || wrap > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: unknown filtering / wrap mode");
+    size_t w = (size_t)width, h = (size_t)height;
+    std::vector<float> img(3 * w * h);
+    for (size_t y = 0; y < h; y++)
+        for (size_t x = 0; x < w; x++) {
+            const float* px = rgb + 3 * ((h - 1 - y) * w + x);  // texture space has (0,0) at the lower left
+            float* o = &img[3 * (y * w + x)];
+            if (as_float) {  // ConvertIn<Float> for RGBSpectrum (convert_in.rs:37-47)
+                const float lum = 0.212671f * px[0] + 0.715160f * px[1] + 0.072169f * px[2];
+                o[0] = o[1] = o[2] = scale * (gamma ? inv_gamma_correct(lum) : lum);
+            } else for (int c = 0; c < 3; c++) o[c] = scale * (gamma ? inv_gamma_correct(px[c]) : px[c]);
+        }
+    auto is_pow2 = [](size_t v) { return (v & (v - 1)) == 0; };
+    if (!is_pow2(w) || !is_pow2(h)) {  // resample_image (mipmap/mod.rs:383-529)
+        size_t rw = 1, rh = 1;
+        while (rw < w) rw <<= 1;
+        while (rh < h) rh <<= 1;
+        std::vector<float> r(3 * rw * rh, 0.0f);
+        std::vector<RsWeight> sw, tw;
+        resample_weights(w, rw, sw);
+        for (size_t t = 0; t < h; t++)
+            for (size_t x = 0; x < rw; x++) {
+                float px[3] = {0.0f, 0.0f, 0.0f};
+                for (int j = 0; j < 4; j++) {
+                    const size_t o = wrap_index(sw[x].first + (size_t)j, w, wrap);
+                    if (o < w) for (int c = 0; c < 3; c++) px[c] += img[3 * (t * w + o) + c] * sw[x].w[j];
+                }
+                for (int c = 0; c < 3; c++) r[3 * (t * rw + x) + c] += px[c];
+            }
+        resample_weights(h, rh, tw);
+        std::vector<float> col(3 * rh);
+        for (size_t x = 0; x < rw; x++) {
+            for (size_t t = 0; t < rh; t++) {
+                float px[3] = {0.0f, 0.0f, 0.0f};
+                for (int j = 0; j < 4; j++) {
+                    const size_t o = wrap_index(tw[t].first + (size_t)j, h, wrap);
+                    if (o < h) for (int c = 0; c < 3; c++) px[c] += r[3 * (o * rw + x) + c] * tw[t].w[j];
+                }
+                for (int c = 0; c < 3; c++) col[3 * t + c] = px[c];
+            }
+            for (size_t t = 0; t < rh; t++)
+                for (int c = 0; c < 3; c++) r[3 * (t * rw + x) + c] = hm::clampf(col[3 * t + c], 0.0f, hm::kInf);  // clamp_default
+        }
+        img.swap(r); w = rw; h = rh;
+    }
+    MipRec m{};
+    m.filtering = (uint32_t)filtering; m.wrap = (uint32_t)wrap; m.is_float = as_float ? 1u : 0u; m.max_anisotropy = max_anisotropy;
+    size_t lw = w, lh = h;
+    std::vector<float> cur = std::move(img);
+    for (;;) {
+        if (m.n_levels >= PH_MIP_MAX_LEVELS) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: too many pyramid levels");
+        const uint32_t L = m.n_levels++;
+        if (s->texels.size() + lw * lh > 0xFFFFFFFFull) return set_err(s, PBRT_HIP_ERR_OOM, "add_mipmap: texel pool exceeds 2^32 texels");
+        m.level_off[L] = (uint32_t)s->texels.size(); m.level_w[L] = (uint32_t)lw; m.level_h[L] = (uint32_t)lh;
+        for (size_t i = 0; i < lw * lh; i++) s->texels.push_back(Texel{cur[3 * i], cur[3 * i + 1], cur[3 * i + 2], 0.0f});
+        if (lw == 1 && lh == 1) break;
+        // next level: four texels of this one, fetched through the wrap mode like MIPMap::texel (mod.rs:150-164)
+        const size_t nw = lw / 2 > 1 ? lw / 2 : 1, nh = lh / 2 > 1 ? lh / 2 : 1;
+        std::vector<float> nxt(3 * nw * nh);
+        auto tex = [&](long long x, long long y, int c) -> float {
+            const long long W = (long long)lw, H = (long long)lh;
+            if (wrap == 0) { x %= W; y %= H; }            // indices are non-negative here
+            else if (wrap == 2) { x = x > W - 1 ? W - 1 : x; y = y > H - 1 ? H - 1 : y; }
+            else if (x >= W || y >= H) return 0.0f;
+            return cur[3 * ((size_t)y * lw + (size_t)x) + (size_t)c];
+        };
+        for (size_t t = 0; t < nh; t++)
+            for (size_t x = 0; x < nw; x++)
+                for (int c = 0; c < 3; c++) {
+                    const long long X = 2 * (long long)x, Y = 2 * (long long)t;
+                    nxt[3 * (t * nw + x) + c] = (((tex(X, Y, c) + tex(X + 1, Y, c)) + tex(X, Y + 1, c)) + tex(X + 1, Y + 1, c)) * 0.25f;
+                }
+        cur.swap(nxt); lw = nw; lh = nh;
+    }
+    s->mipmaps.push_back(m);
+    if (out_id) *out_id = (uint32_t)s->mipmaps.size() - 1;
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_add_texture_constant(PbrtHipScene* s, const float v[3], uint32_t* out_id) {
+    if (!s || !v) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_constant: null argument");
+    PbrtHipScene::TextureHost t; TexOp op{}; op.op = PH_TOP_CONST; std::memcpy(op.c, v, 12); t.prog.push_back(op);
+    return push_texture(s, std::move(t), out_id);
+}
+int pbrt_hip_add_texture_imagemap(PbrtHipScene* s, uint32_t mipmap, float su, float sv, float du, float dv, uint32_t* out_id) {
+    if (!s || mipmap >= s->mipmaps.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_imagemap: unknown mipmap");
+    PbrtHipScene::TextureHost t; TexOp op{}; op.op = PH_TOP_IMAGE; op.mip = mipmap; op.su = su; op.sv = sv; op.du = du; op.dv = dv; t.prog.push_back(op);
+    return push_texture(s, std::move(t), out_id);
+}
+int pbrt_hip_add_texture_scale(PbrtHipScene* s, uint32_t t1, uint32_t t2, uint32_t* out_id) {
+    if (!s || t1 >= s->textures.size() || t2 >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_scale: unknown texture");
+    PbrtHipScene::TextureHost t; const PbrtHipScene::TextureHost &a = s->textures[t1], &b = s->textures[t2];
+    t.prog = a.prog; t.prog.insert(t.prog.end(), b.prog.begin(), b.prog.end());
+    TexOp op{}; op.op = PH_TOP_MUL; t.prog.push_back(op);
+    t.stack_need = std::max(a.stack_need, 1 + b.stack_need);
+    return push_texture(s, std::move(t), out_id);
+}
+int pbrt_hip_add_texture_mix(PbrtHipScene* s, uint32_t t1, uint32_t t2, uint32_t amount, uint32_t* out_id) {
+    if (!s || t1 >= s->textures.size() || t2 >= s->textures.size() || amount >= s->textures.size())
+        return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_mix: unknown texture");
+    PbrtHipScene::TextureHost t; const PbrtHipScene::TextureHost &a = s->textures[t1], &b = s->textures[t2], &c = s->textures[amount];
+    t.prog = a.prog; t.prog.insert(t.prog.end(), b.prog.begin(), b.prog.end()); t.prog.insert(t.prog.end(), c.prog.begin(), c.prog.end());
+    TexOp op{}; op.op = PH_TOP_MIX; t.prog.push_back(op);
+    t.stack_need = std::max(a.stack_need, std::max(1 + b.stack_need, 2 + c.stack_need));
+    return push_texture(s, std::move(t), out_id);
+}
+int pbrt_hip_add_material_matte_tex(PbrtHipScene* s, uint32_t kd_tex, float sigma_deg, uint32_t* out_id) {  // matte.rs:47-76, Kd a texture
+    if (!s || kd_tex >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_matte_tex: unknown texture");
+    MaterialRec m{};
+    m.kd_tex1 = kd_tex + 1u; m.has_bxdf = 1u;  // decided per hit
+    m.sigma = hm::clampf(sigma_deg, 0.0f, 90.0f);
+    m.bsdf_eta = 1.0f;
+    if (m.sigma != 0.0f) {
+        float sg = hm::to_radians(m.sigma), s2 = sg * sg;
+        m.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
+        m.b = 0.45f * s2 / (s2 + 0.09f);
+    }
+    LobeRec l = lobe(m.sigma != 0.0f ? PH_LK_OREN : PH_LK_LAMBERT, T_REFL | T_DIFF);  // template: r is filled per hit
+    l.a = m.a; l.b = m.b;
+    s->textured_materials = true;
+    return push_material(s, m, std::vector<LobeRec>{l}, false, out_id);
+}
+// ---- texture probes (test aids: the device's texture evaluation on explicit inputs, and the pyramid the host built) ----------------
+namespace ph {
+__global__ void texture_eval_kernel(DeviceScene sc, uint32_t tex, uint32_t n, const float* in, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    TexCtx c; c.uv = mk2(in[6 * i], in[6 * i + 1]); c.dudx = in[6 * i + 2]; c.dvdx = in[6 * i + 3]; c.dudy = in[6 * i + 4]; c.dvdy = in[6 * i + 5];
+    const spec v = tex_eval(sc.self, tex, c);
+    out[3 * i] = v.r; out[3 * i + 1] = v.g; out[3 * i + 2] = v.b;
+}
+}  // namespace ph
+int pbrt_hip_texture_eval_batch(PbrtHipScene* s, uint32_t tex, uint64_t n, const float* uv_and_derivatives, float* out_rgb) {
+    if (!s || (n && (!uv_and_derivatives || !out_rgb))) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "texture_eval_batch: null argument");
+    if (tex >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "texture_eval_batch: unknown texture");
+    if (n == 0) return PBRT_HIP_OK;
+    if (n > 0xFFFFFFFFull) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "texture_eval_batch: too many points");
+    PH_CHECK(s, hipSetDevice(s->device));
+    // textures do not need the accelerator: upload what exists (an empty BVH is fine)
+    int rc;
+    if ((rc = upload_scene(s))) return rc;
+    if ((rc = ensure_buf(s, s->d_rays_tmp, n * 24))) return rc;
+    if ((rc = ensure_buf(s, s->d_out_tmp, n * 12))) return rc;
+    PH_CHECK(s, hipMemcpyAsync(s->d_rays_tmp.p, uv_and_derivatives, n * 24, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(ph::texture_eval_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s->stream, s->ds, tex, (uint32_t)n, (const float*)s->d_rays_tmp.p, (float*)s->d_out_tmp.p);
+    PH_CHECK(s, hipGetLastError());
+    PH_CHECK(s, hipMemcpyAsync(out_rgb, s->d_out_tmp.p, n * 12, hipMemcpyDeviceToHost, s->stream));
+    PH_CHECK(s, hipStreamSynchronize(s->stream));
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_mipmap_levels(PbrtHipScene* s, uint32_t mip, int* out_levels, int* out_wh) {
+    if (!s || !out_levels || !out_wh || mip >= s->mipmaps.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "mipmap_levels: bad argument");
+    const MipRec& m = s->mipmaps[mip];
+    *out_levels = (int)m.n_levels;
+    for (uint32_t i = 0; i < m.n_levels; i++) { out_wh[2 * i] = (int)m.level_w[i]; out_wh[2 * i + 1] = (int)m.level_h[i]; }
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_mipmap_level_texels(PbrtHipScene* s, uint32_t mip, int level, float* out_rgb) {
+    if (!s || !out_rgb || mip >= s->mipmaps.size() || level < 0 || (uint32_t)level >= s->mipmaps[mip].n_levels)
+        return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "mipmap_level_texels: bad argument");
+    const MipRec& m = s->mipmaps[mip];
+    const size_t n = (size_t)m.level_w[level] * m.level_h[level];
+    for (size_t i = 0; i < n; i++) { const Texel& t = s->texels[m.level_off[level] + i]; out_rgb[3 * i] = t.r; out_rgb[3 * i + 1] = t.g; out_rgb[3 * i + 2] = t.b; }
+    return PBRT_HIP_OK;
 }
 int pbrt_hip_add_material_none(PbrtHipScene* s, uint32_t* out_id) {  // Material "none" / "" (graphics_state.rs make_material -> None)
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
@@ -693,6 +927,18 @@ int pbrt_hip_set_camera_perspective(PbrtHipScene* s, const float r2c[16], const 
     std::memcpy(s->cam.r2c, r2c, 64); std::memcpy(s->cam.c2w, c2w, 64);
     s->cam.lens_radius = lens_radius; s->cam.focal_distance = focal_distance;
     s->cam.shutter_open = shutter_open; s->cam.shutter_close = shutter_close;
+    {   // dx_camera / dy_camera (perspective_camera.rs:70-74): raster_to_camera(1,0,0) - raster_to_camera(0,0,0), same for y
+        auto pt = [&](float x, float y, float out[3]) {  // Transform::transform_point (transform.rs:288-302)
+            const float* m = r2c;
+            const float xp = m[0] * x + m[1] * y + m[2] * 0.0f + m[3], yp = m[4] * x + m[5] * y + m[6] * 0.0f + m[7];
+            const float zp = m[8] * x + m[9] * y + m[10] * 0.0f + m[11], wp = m[12] * x + m[13] * y + m[14] * 0.0f + m[15];
+            if (wp == 1.0f) { out[0] = xp; out[1] = yp; out[2] = zp; }
+            else { const float inv = 1.0f / wp; out[0] = inv * xp; out[1] = inv * yp; out[2] = inv * zp; }  // Point3 / f (point3.rs: times the reciprocal)
+        };
+        float p0[3], px[3], py[3];
+        pt(0.0f, 0.0f, p0); pt(1.0f, 0.0f, px); pt(0.0f, 1.0f, py);
+        for (int k = 0; k < 3; k++) { s->cam.dx_camera[k] = px[k] - p0[k]; s->cam.dy_camera[k] = py[k] - p0[k]; }
+    }
     s->have_camera = true;
     return PBRT_HIP_OK;
 }

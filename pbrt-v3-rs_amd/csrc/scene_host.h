@@ -25,6 +25,12 @@ struct PbrtHipScene {
     std::vector<MeshRec> meshes;
     std::vector<MaterialRec> materials;
     std::vector<LobeRec> lobes;
+    // textures: every texture id owns a flattened postfix program (its children's programs followed by its own op)
+    struct TextureHost { std::vector<TexOp> prog; int stack_need = 1; };
+    std::vector<TextureHost> textures;
+    std::vector<MipRec> mipmaps;
+    std::vector<Texel> texels;
+    bool textured_materials = false;  // some material evaluates a texture per hit
     bool has_none_material = false;  // some material is "none": paths may need more wavefront iterations than max_depth + 1
     bool general_materials = false;  // some material is not matte: the renderer uses the general BSDF kernel
     std::vector<LightRec> lights;

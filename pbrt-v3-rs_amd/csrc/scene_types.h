@@ -84,7 +84,32 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     uint32_t sort_class;  // 0..6: index of this material's lobe-kind signature among the scene's materials (block-local sorting key)
     float bsdf_eta;    // BSDF::eta (bsdf.rs:101): 1 unless the material passes one (uber.rs:131-138)
     uint32_t none;     // Material "none": no BSDF, the path integrator skips the surface (path.rs:142-150)
+    uint32_t kd_tex1;  // 0, or 1 + the texture MatteMaterial evaluates for Kd at every hit (matte.rs:63): kd / has_bxdf are then per hit
 };
+
+// ---- textures (textures/src/*.rs, core/src/mipmap/mod.rs).  A texture is a postfix program over a small value stack: the host
+// flattens the scale / mix tree once (api.hip), the device runs it per hit (texture.h).  Float-valued textures are carried as three equal
+// channels; the one place the reference treats them differently (the final division of MIPMap::ewa) is selected by MipRec::is_float.
+enum { PH_TOP_CONST = 0, PH_TOP_IMAGE = 1, PH_TOP_MUL = 2, PH_TOP_MIX = 3 };
+#define PH_TEX_STACK 4
+struct TexOp {
+    uint32_t op;
+    uint32_t mip;          // PH_TOP_IMAGE: index into DeviceScene::mipmaps
+    float c[3];            // PH_TOP_CONST
+    float su, sv, du, dv;  // PH_TOP_IMAGE: UVMapping2D (texture/mapping/uv_2d.rs)
+    uint32_t pad[3];
+};
+struct TexRec { uint32_t first_op, n_ops; };  // DeviceScene::tex_ops[first_op .. first_op + n_ops)
+struct Texel { float r, g, b, pad; };  // one 16-byte load per texel
+#define PH_MIP_MAX_LEVELS 16
+struct MipRec {  // MIPMap<T> (core/src/mipmap/mod.rs:76-96): pyramid levels in one pool of float4 texels (rgb + pad), row-major [t][s]
+    uint32_t n_levels, filtering /*0 trilinear 1 EWA*/, wrap /*0 repeat 1 black 2 clamp*/, is_float;
+    float max_anisotropy;
+    uint32_t pad[3];
+    uint32_t level_off[PH_MIP_MAX_LEVELS];  // first texel of each level in DeviceScene::texels
+    uint32_t level_w[PH_MIP_MAX_LEVELS], level_h[PH_MIP_MAX_LEVELS];
+};
+#define PH_EWA_LUT_SIZE 128
 
 enum { PH_L_INFINITE = 0, PH_L_DISTANT = 1, PH_L_POINT = 2, PH_L_AREA = 3, PH_L_SPOT = 4 };
 struct LightRec {
@@ -108,6 +133,8 @@ struct CameraRec {  // cameras/src/perspective_camera.rs
     float r2c[16];
     float c2w[16];
     float lens_radius, focal_distance, shutter_open, shutter_close;
+    float dx_camera[3], dy_camera[3];  // :70-74, for the ray differentials texture filtering needs
+    float pad[2];
 };
 
 struct FilmRec {  // core/src/film/mod.rs
@@ -149,6 +176,12 @@ struct DeviceScene {
     const MeshRec* meshes;
     const MaterialRec* materials;
     const LobeRec* lobes;
+    const TexRec* textures;
+    const TexOp* tex_ops;
+    const MipRec* mipmaps;
+    const Texel* texels;
+    const float* ewa_lut;     // PH_EWA_LUT_SIZE Gaussian weights (mipmap/mod.rs:168-174), made on the host with its expf
+    const DeviceScene* self;  // device-resident copy of this struct: out-of-line device functions take it instead of the by-value kernel argument
     const LightRec* lights;
     uint32_t n_lights;
     const uint32_t* infinite_lights;

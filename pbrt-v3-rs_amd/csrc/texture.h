@@ -1,0 +1,229 @@
+// Device side of the image textures: MIPMap<T>::lookup / triangle / ewa / texel (core/src/mipmap/mod.rs:205-371, 569-608), the texture
+// programs the host flattens from ScaleTexture / MixTexture / ImageTexture / ConstantTexture trees (textures/src/*.rs), UVMapping2D
+// (core/src/texture/mapping/uv_2d.rs:52-60), SurfaceInteraction::compute_differentials (core/src/interaction/surface_interaction.rs:203-278)
+// and the camera-ray differentials it consumes (cameras/src/perspective_camera.rs:173-200, ray.rs:90-99, transform.rs:464-472).
+// f32 throughout, in the reference's order; log2 is evaluated in f64 and rounded (glibc's f32 log2f is not reproducible on the device,
+// same policy as the trigonometric functions: DESIGN.md section 2).
+#pragma once
+#include "pt_device.h"
+
+namespace ph {
+
+struct TexCtx { f2 uv; float dudx, dvdx, dudy, dvdy; };
+
+PH_DEV float d_log2(float x) { return (float)log2((double)x); }
+PH_DEV long long f2ll_sat(float f) {  // `as isize`
+    if (f != f) return 0;
+    if (f >= 9223372036854775808.0f) return 0x7FFFFFFFFFFFFFFFll;
+    if (f <= -9223372036854775808.0f) return (long long)0x8000000000000000ull;
+    return (long long)f;
+}
+PH_DEV long long rem_ll(long long a, long long b) { long long r = a - (a / b) * b; return r < 0 ? r + b : r; }  // pbrt/common.rs:116-126
+
+PH_DEV spec mip_texel(const DeviceScene& sc, const MipRec& m, uint32_t level, long long s, long long t) {
+    const long long w = (long long)m.level_w[level], h = (long long)m.level_h[level];
+    if (m.wrap == 0u) { s = rem_ll(s, w); t = rem_ll(t, h); }
+    else if (m.wrap == 2u) { s = s < 0 ? 0 : (s > w - 1 ? w - 1 : s); t = t < 0 ? 0 : (t > h - 1 ? h - 1 : t); }
+    else if (s < 0 || s >= w || t < 0 || t >= h) return mks1(0.0f);
+    const float4 v = *reinterpret_cast<const float4*>(sc.texels + ((size_t)m.level_off[level] + (size_t)t * (size_t)w + (size_t)s));
+    return mks(v.x, v.y, v.z);
+}
+PH_DEV spec mip_triangle(const DeviceScene& sc, const MipRec& m, uint32_t level, f2 st) {
+    if (level > m.n_levels - 1u) level = m.n_levels - 1u;
+    const float s = st.x * (float)m.level_w[level] - 0.5f, t = st.y * (float)m.level_h[level] - 0.5f;
+    const long long s0 = f2ll_sat(floorf(s)), t0 = f2ll_sat(floorf(t));
+    const float ds = s - (float)s0, dt = t - (float)t0;
+    return mip_texel(sc, m, level, s0, t0) * (1.0f - ds) * (1.0f - dt) + mip_texel(sc, m, level, s0, t0 + 1) * (1.0f - ds) * dt +
+           mip_texel(sc, m, level, s0 + 1, t0) * ds * (1.0f - dt) + mip_texel(sc, m, level, s0 + 1, t0 + 1) * ds * dt;
+}
+PH_DEV spec mip_ewa(const DeviceScene& sc, const MipRec& m, uint32_t level, f2 st, f2 dst0, f2 dst1) {
+    if (level >= m.n_levels) return mip_texel(sc, m, m.n_levels - 1u, 0, 0);
+    const float us = (float)m.level_w[level], vs = (float)m.level_h[level];
+    const float s = st.x * us - 0.5f, t = st.y * vs - 0.5f;
+    const float d0x = dst0.x * us, d0y = dst0.y * vs, d1x = dst1.x * us, d1y = dst1.y * vs;
+    float a = d0y * d0y + d1y * d1y + 1.0f;
+    float b = -2.0f * (d0x * d0y + d1x * d1y);
+    float c = d0x * d0x + d1x * d1x + 1.0f;
+    const float inv_f = ph_div(1.0f, a * c - b * b * 0.25f);
+    a *= inv_f; b *= inv_f; c *= inv_f;
+    const float det = -b * b + 4.0f * a * c;
+    const float inv_det = ph_div(1.0f, det);
+    const float u_sqrt = ph_sqrt(det * c), v_sqrt = ph_sqrt(a * det);
+    const long long s0 = f2ll_sat(ceilf(s - 2.0f * inv_det * u_sqrt)), s1 = f2ll_sat(floorf(s + 2.0f * inv_det * u_sqrt));
+    const long long t0 = f2ll_sat(ceilf(t - 2.0f * inv_det * v_sqrt)), t1 = f2ll_sat(floorf(t + 2.0f * inv_det * v_sqrt));
+    spec sum = mks1(0.0f);
+    float sum_wts = 0.0f;
+    for (long long it = t0; it <= t1; it++) {
+        const float tt = (float)it - t;
+        for (long long is = s0; is <= s1; is++) {
+            const float ss = (float)is - s;
+            const float r2 = a * ss * ss + b * ss * tt + c * tt * tt;
+            if (r2 < 1.0f) {
+                uint32_t index = f2u_sat(r2 * (float)PH_EWA_LUT_SIZE);
+                if (index > PH_EWA_LUT_SIZE - 1u) index = PH_EWA_LUT_SIZE - 1u;
+                const float weight = sc.ewa_lut[index];
+                sum = sum + mip_texel(sc, m, level, is, it) * weight;
+                sum_wts += weight;
+            }
+        }
+    }
+    if (m.is_float) return mks1(ph_div(sum.r, sum_wts));  // Float: a true division; RGBSpectrum: times the reciprocal (rgb_spectrum.rs:255-263)
+    return sum / sum_wts;
+}
+PH_DEV spec mip_lookup(const DeviceScene& sc, const MipRec& m, f2 st, f2 dst0, f2 dst1) {
+    const uint32_t levels = m.n_levels;
+    if (m.filtering == 0u) {
+        const float width = pmaxf(pmaxf(pabs(dst0.x), pabs(dst0.y)), pmaxf(pabs(dst1.x), pabs(dst1.y)));
+        const float level = (float)levels - 1.0f + d_log2(pmaxf(width, 1e-8f));
+        if (level < 0.0f) return mip_triangle(sc, m, 0u, st);
+        if (level >= (float)(levels - 1u)) return mip_texel(sc, m, levels - 1u, 0, 0);
+        const uint32_t il = f2u_sat(floorf(level));
+        const float delta = level - (float)il;
+        return mip_triangle(sc, m, il, st) * (1.0f - delta) + mip_triangle(sc, m, il + 1u, st) * delta;
+    }
+    if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) { const f2 tmp = dst0; dst0 = dst1; dst1 = tmp; }
+    const float major_length = ph_sqrt(dst0.x * dst0.x + dst0.y * dst0.y);
+    float minor_length = ph_sqrt(dst1.x * dst1.x + dst1.y * dst1.y);
+    const float adjusted = minor_length * m.max_anisotropy;
+    if (adjusted < major_length && minor_length > 0.0f) {
+        const float scl = ph_div(major_length, adjusted);
+        dst1.x *= scl; dst1.y *= scl;
+        minor_length *= scl;
+    }
+    if (minor_length == 0.0f) return mip_triangle(sc, m, 0u, st);
+    const float lod = pmaxf(0.0f, (float)levels - 1.0f + d_log2(minor_length));
+    const uint32_t il = f2u_sat(floorf(lod));
+    const float t = lod - (float)il;
+    return mip_ewa(sc, m, il, st, dst0, dst1) * (1.0f - t) + mip_ewa(sc, m, il + 1u, st, dst0, dst1) * t;
+}
+
+// Runs texture `id`'s postfix program.  Kept out of line: the shade kernels call it only for materials that carry a texture.
+// `dsc` = DeviceScene::self (the by-value kernel argument must not have its address taken: it would be copied to scratch).
+static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id, TexCtx c) {
+    const DeviceScene& sc = *dsc;
+    const TexRec tr = sc.textures[id];
+    spec st[PH_TEX_STACK];
+    int sp = 0;
+    for (uint32_t k = 0; k < tr.n_ops; k++) {
+        const TexOp& op = sc.tex_ops[tr.first_op + k];
+        switch (op.op) {
+        case PH_TOP_CONST: st[sp++] = mks(op.c[0], op.c[1], op.c[2]); break;
+        case PH_TOP_IMAGE: {
+            const f2 dstdx = mk2(op.su * c.dudx, op.sv * c.dvdx), dstdy = mk2(op.su * c.dudy, op.sv * c.dvdy);
+            const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+            st[sp++] = mip_lookup(sc, sc.mipmaps[op.mip], p, dstdx, dstdy);
+            break;
+        }
+        case PH_TOP_MUL: { sp--; st[sp - 1] = st[sp - 1] * st[sp]; break; }                          // scale.rs:33
+        default: {  // PH_TOP_MIX: (1 - amt) * t1 + amt * t2 (mix.rs:36-41); stack = t1, t2, amount
+            sp -= 2;
+            const float amt = st[sp + 1].r;
+            st[sp - 1] = (1.0f - amt) * st[sp - 1] + amt * st[sp];
+            break;
+        }
+        }
+    }
+    return st[0];
+}
+
+// ---- ray differentials of a camera ray, in world space, scaled as render_tile does (sampler_integrator.rs:358) --------------
+struct RayDiff { f3 rx_o, ry_o, rx_d, ry_d; };
+PH_DEV f3 xf_point_plain(const float* m, f3 p) {  // Transform::transform_point (transform.rs:288-302)
+    const float x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    const float y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    const float z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    const float w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    return (w == 1.0f) ? mk3(x, y, z) : mk3(x, y, z) / w;
+}
+PH_DEV RayDiff camera_ray_differentials(const CameraRec& cam, f2 p_film, f2 lens_s, f3 o_world, f3 d_world, uint32_t spp) {
+    const f3 p_camera = xf_point_plain(cam.r2c, mk3(p_film.x, p_film.y, 0.0f));
+    const f3 dxc = mk3(cam.dx_camera[0], cam.dx_camera[1], cam.dx_camera[2]), dyc = mk3(cam.dy_camera[0], cam.dy_camera[1], cam.dy_camera[2]);
+    f3 rx_o, ry_o, rx_d, ry_d;
+    if (cam.lens_radius > 0.0f) {
+        const f2 cd = concentric_sample_disk(lens_s);
+        const f2 p_lens = mk2(cam.lens_radius * cd.x, cam.lens_radius * cd.y);
+        const f3 dx = normalize(p_camera + dxc);
+        float ft = ph_div(cam.focal_distance, dx.z);
+        f3 p_focus = mk3(0.0f, 0.0f, 0.0f) + (ft * dx);
+        rx_o = mk3(p_lens.x, p_lens.y, 0.0f); rx_d = normalize(p_focus - rx_o);
+        const f3 dy = normalize(p_camera + dyc);
+        ft = ph_div(cam.focal_distance, dy.z);
+        p_focus = mk3(0.0f, 0.0f, 0.0f) + (ft * dy);
+        ry_o = mk3(p_lens.x, p_lens.y, 0.0f); ry_d = normalize(p_focus - ry_o);
+    } else {
+        rx_o = mk3(0.0f, 0.0f, 0.0f); ry_o = rx_o;
+        rx_d = normalize(p_camera + dxc); ry_d = normalize(p_camera + dyc);
+    }
+    RayDiff r;
+    r.rx_o = xf_point_plain(cam.c2w, rx_o); r.ry_o = xf_point_plain(cam.c2w, ry_o);
+    r.rx_d = xf_vec(cam.c2w, rx_d); r.ry_d = xf_vec(cam.c2w, ry_d);
+    const float sc = ph_div(1.0f, ph_sqrt((float)spp));
+    r.rx_o = o_world + (r.rx_o - o_world) * sc; r.ry_o = o_world + (r.ry_o - o_world) * sc;
+    r.rx_d = d_world + (r.rx_d - d_world) * sc; r.ry_d = d_world + (r.ry_d - d_world) * sc;
+    return r;
+}
+PH_DEV float comp3(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+// `dpdu`, `dpdv`: SurfaceInteraction.der (geometric); returns der.du/dv d x/y (zeros where the reference leaves zeros)
+PH_DEV void compute_differentials(f3 p, f3 n, f3 dpdu, f3 dpdv, const RayDiff& rd, TexCtx& c) {
+    c.dudx = c.dvdx = c.dudy = c.dvdy = 0.0f;
+    const float d = dot(n, p);
+    const float tx = ph_div(-(dot(n, rd.rx_o) - d), dot(n, rd.rx_d));
+    if (__builtin_isinf(tx) || tx != tx) return;
+    const f3 px = rd.rx_o + tx * rd.rx_d;
+    const float ty = ph_div(-(dot(n, rd.ry_o) - d), dot(n, rd.ry_d));
+    if (__builtin_isinf(ty) || ty != ty) return;
+    const f3 py = rd.ry_o + ty * rd.ry_d;
+    int d0, d1;
+    if (pabs(n.x) > pabs(n.y) && pabs(n.x) > pabs(n.z)) { d0 = 1; d1 = 2; }
+    else if (pabs(n.y) > pabs(n.z)) { d0 = 0; d1 = 2; }
+    else { d0 = 0; d1 = 1; }
+    const float a00 = comp3(dpdu, d0), a01 = comp3(dpdv, d0), a10 = comp3(dpdu, d1), a11 = comp3(dpdv, d1);
+    const float bx0 = comp3(px, d0) - comp3(p, d0), bx1 = comp3(px, d1) - comp3(p, d1);
+    const float by0 = comp3(py, d0) - comp3(p, d0), by1 = comp3(py, d1) - comp3(p, d1);
+    const float det = a00 * a11 - a01 * a10;  // solve_linear_system_2x2 (matrix4x4.rs:305-318)
+    if (pabs(det) < 1e-10f) return;
+    float x0 = ph_div(a11 * bx0 - a01 * bx1, det), x1 = ph_div(a00 * bx1 - a10 * bx0, det);
+    if (!(x0 != x0 || x1 != x1)) { c.dudx = x0; c.dvdx = x1; }
+    x0 = ph_div(a11 * by0 - a01 * by1, det); x1 = ph_div(a00 * by1 - a10 * by0, det);
+    if (!(x0 != x0 || x1 != x1)) { c.dudy = x0; c.dvdy = x1; }
+}
+
+// MatteMaterial's `kd.evaluate(..).clamp_default()` for a hit (matte.rs:63), out of line.  Everything texture evaluation needs beyond
+// what the integrator carries is rebuilt here from the TriRec the traversal reported: uv (triangle.rs:584), the geometric dp/du, dp/dv
+// (:548-574, carried to world space for an instance: transform.rs:566-590) and — for camera rays only — du/dv d x/y.
+static __device__ __noinline__ spec textured_kd(const DeviceScene* dsc, const CameraRec* cam, uint32_t spp, uint32_t tex, uint32_t tri_index, uint32_t inst,
+                                                f3 bary, f3 p, f3 n, f3 ro, f3 rd, f2 p_film, f2 lens, uint32_t camera_ray) {
+    const DeviceScene& sc = *dsc;
+    const float4* tp = reinterpret_cast<const float4*>(sc.tris + tri_index);
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    const uint32_t prim = __float_as_uint(a.w);
+    const MeshRec m = sc.meshes[__float_as_uint(c.w)];
+    TriVerts t;
+    t.p0 = mk3(a.x, a.y, a.z); t.p1 = mk3(b.x, b.y, b.z); t.p2 = mk3(c.x, c.y, c.z);
+    t.i0 = t.i1 = t.i2 = 0;
+    f2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);
+    if (m.flags & PH_MESH_UV) {
+        t.i0 = sc.idx[3 * prim]; t.i1 = sc.idx[3 * prim + 1]; t.i2 = sc.idx[3 * prim + 2];
+        uv0 = mk2(sc.UV[2 * (size_t)t.i0], sc.UV[2 * (size_t)t.i0 + 1]);
+        uv1 = mk2(sc.UV[2 * (size_t)t.i1], sc.UV[2 * (size_t)t.i1 + 1]);
+        uv2 = mk2(sc.UV[2 * (size_t)t.i2], sc.UV[2 * (size_t)t.i2 + 1]);
+    }
+    f3 dpdu, dpdv;
+    tri_dpdu(sc, m, t, dpdu, dpdv);
+    if (inst != 0u) {
+        const InstRec& I = sc.instances[inst - 1u];
+        if (!(I.flags & PH_INST_IDENTITY)) { dpdu = xf_vec(I.i2w, dpdu); dpdv = xf_vec(I.i2w, dpdv); }
+    }
+    TexCtx ctx;
+    ctx.uv = mk2((bary.x * uv0.x + bary.y * uv1.x) + bary.z * uv2.x, (bary.x * uv0.y + bary.y * uv1.y) + bary.z * uv2.y);
+    ctx.dudx = ctx.dvdx = ctx.dudy = ctx.dvdy = 0.0f;
+    if (camera_ray) {
+        const CameraRec cm = *cam;
+        const RayDiff rdf = camera_ray_differentials(cm, p_film, lens, ro, rd, spp);
+        compute_differentials(p, n, dpdu, dpdv, rdf, ctx);
+    }
+    const spec v = tex_eval(dsc, tex, ctx);
+    return mks(pclampf(v.r, 0.0f, kInf), pclampf(v.g, 0.0f, kInf), pclampf(v.b, 0.0f, kInf));
+}
+
+}  // namespace ph

@@ -20,12 +20,13 @@
 #include "scene_host.h"
 #include "spatial.h"
 #include "bsdf_general.h"
+#include "texture.h"
 #include <algorithm>
 #include <cstdlib>
 
 namespace ph {
 
-enum : uint32_t { F_EXT = 1u, F_PSH = 2u, F_PMIS = 4u, F_SPEC = 8u };  // F_SPEC: the previous bounce sampled a specular lobe (path.rs:190)
+enum : uint32_t { F_EXT = 1u, F_PSH = 2u, F_PMIS = 4u, F_SPEC = 8u, F_NODIFF = 16u };  // F_NODIFF: the ray was respawned at a "none" surface and has no differentials  // F_SPEC: the previous bounce sampled a specular lobe (path.rs:190)
 
 struct IterCounters {  // one per wavefront iteration, zeroed at chunk start
     uint32_t n_cl, n_sh, n_live, head_cl, head_sh, pad[3];
@@ -60,6 +61,9 @@ struct WfParams {
     float4* rec_L; float* rec_py;
     // light sampling: SpatialLightDistribution tables when enabled, else the scene-wide Distribution1D of DeviceScene
     SpatialRec spatial;
+    // materials that evaluate a texture per hit (texture.h): device copy of `cam` for the out-of-line evaluation
+    const CameraRec* cam_dev; uint32_t textured;
+    LobeRec* hit_lobes;  // general-BSDF kernel only: one slot per thread of the grid
 };
 
 PH_DEV uint32_t wave_alloc(uint32_t* ctr, bool want) {
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
             w.rec_py[gsi] = p_film.y;
             w.s_L[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             w.s_beta[pid] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // beta, eta_scale
+            if (w.textured && w.cam.lens_radius > 0.0f) w.s_A[pid] = make_float4(lens.x, lens.y, 0.0f, 0.0f);  // for the first hit's ray differentials (s_A is idle until then)
         } else {
             w.rec_L[gsi] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0x7fc00000u));  // NaN p_film.x marks "no sample"
             w.rec_py[gsi] = 0.0f;
@@ -180,6 +185,7 @@ template <> struct BsdfOps<false> {
     static PH_DEV void sample_ns(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi) { bsdf_sample_f(b, wo, u, f, pdf, wi); }
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, f, pdf, wi); type = BX_REFL | BX_DIFF; }
     static PH_DEV float eta(const T&) { return 1.0f; }
+    static PH_DEV void set_kd(T& b, spec kd, LobeRec*) { b.r = kd; b.has_bxdf = !is_black(kd); }
 };
 template <> struct BsdfOps<true> {
     using T = GBsdf;
@@ -190,13 +196,20 @@ template <> struct BsdfOps<true> {
     static PH_DEV void sample_ns(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi) { uint32_t t; bsdf_sample_f(b, wo, u, BX_ALL & ~BX_SPEC, f, pdf, wi, t); }
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, BX_ALL, f, pdf, wi, type); }
     static PH_DEV float eta(const T& b) { return b.eta; }
+    // the hit's own lobe (the material's template with this hit's reflectance) goes to the thread's slot of WfParams::hit_lobes
+    static PH_DEV void set_kd(T& b, spec kd, LobeRec* slot) {
+        if (is_black(kd)) { b.n = 0u; return; }
+        LobeRec l = b.lobes[0];
+        l.r[0] = kd.r; l.r[1] = kd.g; l.r[2] = kd.b;
+        *slot = l; b.lobes = slot;
+    }
 };
 
 #define PH_SHADE_BLOCK 256
 // Waves per SIMD the shade kernels are compiled for.  40 KB of LDS per block allow 4 blocks per CU; the one-lobe kernel fits 128 VGPRs with
 // 51 spilled registers and gains 6 % from the fourth wave, the general-BSDF kernel would spill 181 and loses, so it stays at 3.
 #define PH_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(GEN ? 3 : 4, GEN ? 3 : 4)))
-template <bool GEN>
+template <bool GEN, bool TEX = false>
 __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(DeviceScene sc, WfParams w, int it) {
     using BO = BsdfOps<GEN>;
     __shared__ float4 stage[3][2][PH_SHADE_BLOCK];           // [ext, mis, shadow][ray halves][thread]
@@ -323,13 +336,28 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         // null BSDF (Material "none"): `*ray = isect.spawn_ray(&ray.d); continue;` — bounces, the sampler dimension and the
                         // specular flag stay as they are (path.rs:142-150)
                         const RayIn re = spawn_ray(si, rd);
-                        flags |= F_EXT; want_ext = true;
+                        flags |= F_EXT | F_NODIFF; want_ext = true;
                         stage[0][0][tid] = make_float4(re.ox, re.oy, re.oz, re.t_max);
                         stage[0][1][tid] = make_float4(re.dx, re.dy, re.dz, re.time);
                     } else if ((int)bounces < w.max_depth) {
-                        const typename BO::T bsdf = BO::make(sc, si, m.material);
+                        typename BO::T bsdf = BO::make(sc, si, m.material);
                         const uint32_t ppix = pid / w.chunk_spp;
                         const int2 xy = w.px_xy[ppix];
+                        if (TEX) {  // compiled into separate instantiations: the out-of-line call would cost the texture-free kernels registers
+                            const uint32_t kd_tex1 = sc.materials[m.material].kd_tex1;
+                            if (kd_tex1) {  // MatteMaterial with a texture for Kd: the lobe's reflectance is this hit's (matte.rs:63-71)
+                                const uint32_t camera_ray = (bounces == 0u && !(flags & F_NODIFF)) ? 1u : 0u;  // only camera rays carry differentials
+                                f2 p_film = mk2(0.0f, 0.0f), lens = mk2(0.0f, 0.0f);
+                                if (camera_ray) {
+                                    const size_t gsi = (size_t)(w.s0 + (pid - ppix * w.chunk_spp)) * w.n_px + ppix;
+                                    p_film = mk2(w.rec_L[gsi].w, w.rec_py[gsi]);
+                                    if (w.cam.lens_radius > 0.0f) { const float4 la = w.s_A[pid]; lens = mk2(la.x, la.y); }
+                                }
+                                const spec kd = textured_kd(sc.self, w.cam_dev, w.sp.spp, kd_tex1 - 1u, __float_as_uint(h1.y), __float_as_uint(h1.z), mk3(h0.z, h0.w, h1.x),
+                                                            si.p, si.n, mk3(ray.ox, ray.oy, ray.oz), rd, p_film, lens, camera_ray);
+                                BO::set_kd(bsdf, kd, w.hit_lobes ? w.hit_lobes + (size_t)blockIdx.x * PH_SHADE_BLOCK + tid : nullptr);
+                            }
+                        }
                         SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid - ppix * w.chunk_spp), dim, hl);
                         // Draw the next 8 dimensions in one (not unrolled) loop: light pick 1D, u_light 2D, u_scattering 2D, BSDF 2D,
                         // Russian roulette 1D.  li consumes a prefix of them that depends on the vertex (A4 ledger); which VALUE lands in
@@ -634,7 +662,7 @@ struct Wavefront {
     std::vector<int2> px_xy;
     int sb[4] = {0, 0, 0, 0}, ntx = 0, nty = 0, tile_size = 0, part = 0, parts = 0;
     uint32_t slot_w = 0, slot_h = 0;
-    DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats;
+    DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats, d_cam, d_hit_lobes;
     DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_recL, d_recpy, d_tilebuf, d_xyz, d_w;
     DevBuf d_vox_slot, d_sp_pool, d_sp_list, d_sp_ctr, d_sp_halton;  // SpatialLightDistribution tables (spatial.h)
     std::vector<hipEvent_t> events;
@@ -646,7 +674,7 @@ void free_wavefront(PbrtHipScene* s) {
     Wavefront* w = s->wf;
     if (!w) return;
     for (DevBuf* b : {&w->d_tiles, &w->d_px, &w->d_rays_cl[0], &w->d_rays_cl[1], &w->d_hits, &w->d_rays_sh, &w->d_occ, &w->d_live[0], &w->d_live[1], &w->d_ctr,
-                      &w->d_stats, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
+                      &w->d_stats, &w->d_cam, &w->d_hit_lobes, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
                       &w->d_vox_slot, &w->d_sp_pool, &w->d_sp_list, &w->d_sp_ctr, &w->d_sp_halton})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : w->events) (void)hipEventDestroy(e);
@@ -818,6 +846,12 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
 
     ph::WfParams wp{};
     wp.cam = s->cam; wp.sp = s->sampler;
+    wp.textured = s->textured_materials ? 1u : 0u; wp.cam_dev = nullptr;
+    if (s->textured_materials) {
+        if ((rc = ensure_buf(s, w.d_cam, sizeof(CameraRec)))) return rc;
+        PH_CHECK(s, hipMemcpyAsync(w.d_cam.p, &s->cam, sizeof(CameraRec), hipMemcpyHostToDevice, s->stream));
+        wp.cam_dev = (const CameraRec*)w.d_cam.p;
+    }
     for (int i = 0; i < 4; i++) wp.pixel_bounds[i] = pixel_bounds[i];
     wp.max_depth = max_depth; wp.rr_threshold = rr_threshold;
     wp.n_px = n_px; wp.px_xy = (const int2*)w.d_px.p;
@@ -854,6 +888,11 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     uint64_t regular = 0, shadow = 0;
     std::vector<ph::IterCounters> hctr((size_t)n_iter_cap + 2);
     const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, 256 * 16);
+    wp.hit_lobes = nullptr;
+    if (s->textured_materials && s->general_materials) {
+        if ((rc = ensure_buf(s, w.d_hit_lobes, (size_t)shade_blocks * PH_SHADE_BLOCK * sizeof(LobeRec)))) return rc;
+        wp.hit_lobes = (LobeRec*)w.d_hit_lobes.p;
+    }
 
     for (uint32_t s0 = 0; s0 < spp; s0 += chunk_spp) {
         const uint32_t cs = std::min(chunk_spp, spp - s0);
@@ -891,7 +930,10 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
                     }))) return rc;
             }
             if ((rc = timed(2, [&]() {
-                    if (s->general_materials) hipLaunchKernelGGL(ph::shade_kernel<true>, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                    if (s->textured_materials) {
+                        if (s->general_materials) hipLaunchKernelGGL((ph::shade_kernel<true, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        else hipLaunchKernelGGL((ph::shade_kernel<false, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                    } else if (s->general_materials) hipLaunchKernelGGL(ph::shade_kernel<true>, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                     else hipLaunchKernelGGL(ph::shade_kernel<false>, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                 }))) return rc;
         }

@@ -113,6 +113,15 @@ class Binding:
             "object_begin": (C.c_int, [vp, u32p]),
             "object_end": (C.c_int, [vp]),
             "add_instance": (C.c_int, [vp, C.c_uint32, fp, fp]),
+            "add_mipmap": (C.c_int, [vp, C.c_int, C.c_int, fp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, u32p]),
+            "add_texture_constant": (C.c_int, [vp, fp, u32p]),
+            "add_texture_scale": (C.c_int, [vp, C.c_uint32, C.c_uint32, u32p]),
+            "add_texture_mix": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
+            "add_texture_imagemap": (C.c_int, [vp, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
+            "add_material_matte_tex": (C.c_int, [vp, C.c_uint32, C.c_float, u32p]),
+            "texture_eval_batch": (C.c_int, [vp, C.c_uint32, C.c_uint64, fp, fp]),
+            "mipmap_levels": (C.c_int, [vp, C.c_uint32, ip, ip]),
+            "mipmap_level_texels": (C.c_int, [vp, C.c_uint32, C.c_int, fp]),
             "set_traversal_counting": (C.c_int, [vp, C.c_int]),
             "get_traversal_counts": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         }
@@ -444,6 +453,55 @@ class Scene:
         ms = C.c_float(0)
         self._chk(self.b.fn("occluded_batch_device")(self.h, d_rays_ptr, d_out_ptr, n, C.byref(ms)))
         return ms.value
+
+    # ---- textures (include/pbrt_hip.h "textures") ------------------------------------------------------------------------------
+    WRAP = {"repeat": 0, "black": 1, "clamp": 2}
+
+    def add_mipmap(self, image, as_float=False, scale=1.0, gamma=False, trilinear=False, wrap="repeat", max_anisotropy=8.0):
+        """image: (H, W, 3) float32 as an image reader returns it (top row first).  Returns the mipmap id."""
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        assert img.ndim == 3 and img.shape[2] == 3
+        out = C.c_uint32(0)
+        self._chk(self.b.fn("add_mipmap")(self.h, img.shape[1], img.shape[0], _ptr(img, C.c_float), 1 if as_float else 0, C.c_float(scale), 1 if gamma else 0,
+                                          0 if trilinear else 1, self.WRAP[wrap], C.c_float(max_anisotropy), C.byref(out)))
+        return out.value
+
+    def add_texture_constant(self, value):
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(value, np.float32), (3,)), dtype=np.float32)
+        out = C.c_uint32(0); self._chk(self.b.fn("add_texture_constant")(self.h, _ptr(v, C.c_float), C.byref(out))); return out.value
+
+    def add_texture_scale(self, t1, t2):
+        out = C.c_uint32(0); self._chk(self.b.fn("add_texture_scale")(self.h, t1, t2, C.byref(out))); return out.value
+
+    def add_texture_mix(self, t1, t2, amount):
+        out = C.c_uint32(0); self._chk(self.b.fn("add_texture_mix")(self.h, t1, t2, amount, C.byref(out))); return out.value
+
+    def add_texture_imagemap(self, mipmap, su=1.0, sv=1.0, du=0.0, dv=0.0):
+        out = C.c_uint32(0)
+        self._chk(self.b.fn("add_texture_imagemap")(self.h, mipmap, C.c_float(su), C.c_float(sv), C.c_float(du), C.c_float(dv), C.byref(out))); return out.value
+
+    def add_material_matte_tex(self, kd_texture, sigma=0.0):
+        out = C.c_uint32(0); self._chk(self.b.fn("add_material_matte_tex")(self.h, kd_texture, C.c_float(sigma), C.byref(out))); return out.value
+
+    def texture_eval(self, texture, uv, derivs=None):
+        """Evaluates `texture` at uv (n,2) with (du/dx, dv/dx, du/dy, dv/dy) (n,4); returns (n,3).  A probe for the parity tests."""
+        uv = np.asarray(uv, np.float32).reshape(-1, 2)
+        d = np.zeros((len(uv), 4), np.float32) if derivs is None else np.asarray(derivs, np.float32).reshape(-1, 4)
+        inp = np.ascontiguousarray(np.concatenate([uv, d], axis=1), dtype=np.float32)
+        out = np.zeros((len(uv), 3), np.float32)
+        self._chk(self.b.fn("texture_eval_batch")(self.h, texture, len(uv), _ptr(inp, C.c_float), _ptr(out, C.c_float)))
+        return out
+
+    def mipmap_pyramid(self, mipmap):
+        """The pyramid the host built: list of (h, w, 3) float32 arrays, finest first (row 0 = t 0 = the image's bottom row)."""
+        n = C.c_int(0); wh = (C.c_int * 64)()
+        self._chk(self.b.fn("mipmap_levels")(self.h, mipmap, C.byref(n), wh))
+        levels = []
+        for i in range(n.value):
+            a = np.zeros((wh[2 * i + 1], wh[2 * i], 3), np.float32)
+            self._chk(self.b.fn("mipmap_level_texels")(self.h, mipmap, i, _ptr(a, C.c_float)))
+            levels.append(a)
+        return levels
 
     def set_traversal_counting(self, on):
         """Measurement aid (include/pbrt_hip.h): traversal launches also tally nodes / triangle tests / rays.  Never timed."""

@@ -1,0 +1,163 @@
+"""CPU: pins for the oracle's restatement of the image textures (oracle/oracle_texture.hpp) by closed forms and by values
+re-derived independently in numpy from the formulas of core/src/mipmap/mod.rs.  The reference holds no golden vectors for
+MIPMap (its tests cover only TexInfo hashing), so these closed forms are the pin."""
+import numpy as np
+import pytest
+
+from oracle_binding import OracleScene
+from texture_scenes import make_image, probe_points
+
+f32 = np.float32
+
+
+def test_pow2_pyramid_is_flipped_image_then_box_averages():
+    img = make_image(8, 4, seed=3)
+    s = OracleScene(); mp = s.add_mipmap(img)
+    pyr = s.mipmap_pyramid(mp)
+    assert [p.shape[:2] for p in pyr] == [(4, 8), (2, 4), (1, 2), (1, 1)]   # 1 + log2(max(w, h)) levels, each dimension halved, never below 1
+    assert np.array_equal(pyr[0], img[::-1])                                # texture space has (0,0) at the lower left (cache.rs:97-104)
+    l1 = ((pyr[0][0::2, 0::2] + pyr[0][0::2, 1::2]) + pyr[0][1::2, 0::2] + pyr[0][1::2, 1::2]) * f32(0.25)
+    assert np.array_equal(pyr[1], l1.astype(np.float32))
+    # 1 x 2 level from a 2 x 4 one: rows are halved, the single row is fetched twice through the wrap mode (repeat: row 1 -> row... 2t+1 = 1)
+    l2 = ((pyr[1][0::2, 0::2] + pyr[1][0::2, 1::2]) + pyr[1][1::2, 0::2] + pyr[1][1::2, 1::2]) * f32(0.25)
+    assert np.array_equal(pyr[2], l2.astype(np.float32))
+
+
+def test_scale_gamma_and_float_conversion():
+    img = make_image(4, 4, seed=5)
+    s = OracleScene()
+    lin = s.mipmap_pyramid(s.add_mipmap(img, scale=0.5))[0]
+    assert np.array_equal(lin, (f32(0.5) * img[::-1]).astype(np.float32))
+    g = s.mipmap_pyramid(s.add_mipmap(img, gamma=True))[0]
+    x = img[::-1].astype(np.float64)
+    want = np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+    assert np.allclose(g, want, rtol=3e-6, atol=1e-7)                       # inv_gamma_correct (pbrt/common.rs:152-158), f32 powf
+    fl = s.mipmap_pyramid(s.add_mipmap(img, as_float=True))[0]
+    y = (f32(0.212671) * img[..., 0] + f32(0.715160) * img[..., 1]) + f32(0.072169) * img[..., 2]
+    assert np.array_equal(fl[..., 0], y[::-1].astype(np.float32)) and np.array_equal(fl[..., 0], fl[..., 2])
+
+
+def _lanczos(x, tau=2.0):
+    x = abs(f32(x))
+    if x < f32(1e-5): return f32(1.0)
+    if x > f32(1.0): return f32(0.0)
+    x = f32(x * f32(np.pi))
+    return f32(f32(np.sin(f32(x * f32(tau)), dtype=f32) / f32(x * f32(tau))) * f32(np.sin(x, dtype=f32) / x))
+
+
+def _resample_weights(old, new):
+    out = []
+    for i in range(new):
+        center = f32(f32(f32(i) + f32(0.5)) * f32(old)) / f32(new)
+        first = max(int(np.floor(f32(f32(center - f32(2.0)) + f32(0.5)))), 0)   # `as usize` saturates: never negative
+        w = [_lanczos(f32(f32(f32(f32(first) + f32(j)) + f32(0.5)) - center) / f32(2.0)) for j in range(4)]
+        inv = f32(1.0) / f32(f32(f32(w[0] + w[1]) + w[2]) + w[3])
+        out.append((first, [f32(x * inv) for x in w]))
+    return out
+
+
+@pytest.mark.parametrize("wrap", ["repeat", "clamp", "black"])
+def test_npot_resampling_matches_the_formulas(wrap):
+    """3 x 5 -> 4 x 8: s pass then t pass with Lanczos weights, first_texel saturated at 0 (mipmap/mod.rs:383-560)."""
+    w, h = 3, 5
+    img = make_image(w, h, seed=7)
+    s = OracleScene()
+    got = s.mipmap_pyramid(s.add_mipmap(img, wrap=wrap))[0]
+    assert got.shape[:2] == (8, 4)
+    src = img[::-1].astype(np.float32)
+    sw = _resample_weights(w, 4)
+    mid = np.zeros((h, 4, 3), np.float32)
+
+    def wrapi(i, n):
+        return i % n if wrap == "repeat" else (min(i, n - 1) if wrap == "clamp" else i)
+    for t in range(h):
+        for x in range(4):
+            px = np.zeros(3, np.float32)
+            for j in range(4):
+                o = wrapi(sw[x][0] + j, w)
+                if o < w: px = (px + src[t, o] * sw[x][1][j]).astype(np.float32)
+            mid[t, x] = px
+    tw = _resample_weights(h, 8)
+    want = np.zeros((8, 4, 3), np.float32)
+    for x in range(4):
+        for t in range(8):
+            px = np.zeros(3, np.float32)
+            for j in range(4):
+                o = wrapi(tw[t][0] + j, h)
+                if o < h: px = (px + mid[o, x] * tw[t][1][j]).astype(np.float32)
+            want[t, x] = np.maximum(px, 0.0)                                  # clamp_default
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-7)                        # sinf may differ by an ulp between numpy and libm
+
+
+def test_bilinear_lookup_closed_forms_and_wrap_modes():
+    img = np.zeros((2, 2, 3), np.float32)
+    img[0, 0] = (1, 0, 0); img[0, 1] = (0, 1, 0); img[1, 0] = (0, 0, 1); img[1, 1] = (1, 1, 1)   # top row first
+    s = OracleScene()
+    tex = {w: s.add_texture_imagemap(s.add_mipmap(img, trilinear=True, wrap=w)) for w in ("repeat", "clamp", "black")}
+    # texel centres of level 0 (zero footprint -> MIPMap::triangle(0, st)): (0.25, 0.25) is texel (0,0) of the FLIPPED image = img[1,0]
+    c = s.texture_eval(tex["clamp"], [[0.25, 0.25], [0.75, 0.25], [0.25, 0.75], [0.75, 0.75], [0.5, 0.5]])
+    assert np.array_equal(c[0], img[1, 0]) and np.array_equal(c[1], img[1, 1]) and np.array_equal(c[2], img[0, 0]) and np.array_equal(c[3], img[0, 1])
+    assert np.allclose(c[4], img.reshape(4, 3).mean(0))
+    # outside [0,1]: clamp repeats the edge texel, black fades to zero, repeat wraps
+    out = [[-0.25, 0.25]]
+    assert np.array_equal(s.texture_eval(tex["clamp"], out)[0], img[1, 0])
+    assert np.array_equal(s.texture_eval(tex["black"], out)[0], np.zeros(3, np.float32))
+    assert np.array_equal(s.texture_eval(tex["repeat"], out)[0], s.texture_eval(tex["repeat"], [[0.75, 0.25]])[0])
+    assert np.allclose(s.texture_eval(tex["repeat"], [[1.3, 2.6]])[0], s.texture_eval(tex["repeat"], [[0.3, 0.6]])[0], atol=2e-6)
+
+
+@pytest.mark.parametrize("trilinear", [True, False])
+def test_constant_image_is_constant_under_every_filter(trilinear):
+    img = np.full((8, 16, 3), (0.2, 0.5, 0.7), np.float32)
+    s = OracleScene()
+    tex = s.add_texture_imagemap(s.add_mipmap(img, trilinear=trilinear))
+    uv, d = probe_points(500, 1)
+    out = s.texture_eval(tex, uv, d)
+    assert np.allclose(out, (0.2, 0.5, 0.7), rtol=3e-6)
+
+
+def test_level_selection_of_the_trilinear_filter():
+    """A 1-texel checkerboard averages to 0.5 from level 1 on: width 2^-k selects level levels-1-k (mod.rs:222-238)."""
+    img = make_image(16, 16, kind="checker")
+    s = OracleScene()
+    tex = s.add_texture_imagemap(s.add_mipmap(img, trilinear=True))
+    uv = np.array([[0.4, 0.6]], np.float32)
+    fine = s.texture_eval(tex, uv, [[0, 0, 0, 0]])[0]           # level < 0 -> bilinear on level 0: not grey at a generic point
+    assert abs(fine[0] - 0.5) > 0.01
+    for width in (2.0 ** -3, 2.0 ** -2, 0.5, 1.0, 4.0):       # levels 1, 2, 3, 4 (coarsest) and beyond
+        assert np.allclose(s.texture_eval(tex, uv, [[width, 0, 0, 0]])[0], 0.5, atol=1e-6)
+    half = s.texture_eval(tex, uv, [[2.0 ** -3.5, 0, 0, 0]])[0]  # between levels 0 and 1: lerp(0.5) of the two
+    l0 = s.texture_eval(tex, uv, [[2.0 ** -4, 0, 0, 0]])[0]      # exactly level 0 with delta 0 -> triangle(0)
+    assert np.allclose(l0, fine, atol=1e-6)
+    assert np.allclose(half, 0.5 * l0 + 0.25, atol=1e-5)
+
+
+def test_ewa_degenerate_cases_fall_back_to_bilinear_and_clamp_anisotropy():
+    img = make_image(32, 32, seed=11)
+    s = OracleScene()
+    ewa = s.add_texture_imagemap(s.add_mipmap(img))
+    tri = s.add_texture_imagemap(s.add_mipmap(img, trilinear=True))
+    uv, _ = probe_points(50, 2)
+    d = np.zeros((50, 4), np.float32); d[:, 0] = 0.05                     # one axis of length 0 -> minor_length == 0 -> triangle(0, st)
+    assert np.array_equal(s.texture_eval(ewa, uv, d), s.texture_eval(tri, uv, np.zeros((50, 4), np.float32)))
+    # a footprint far beyond the image: both EWA levels are past the pyramid -> the single coarsest texel
+    coarse = s.mipmap_pyramid(0)[-1][0, 0]
+    big = np.tile(np.array([[40.0, 0.0, 0.0, 40.0]], np.float32), (50, 1))
+    assert np.allclose(s.texture_eval(ewa, uv, big), coarse, rtol=1e-6)
+
+
+def test_scale_and_mix_textures():
+    s = OracleScene()
+    a = s.add_texture_constant((0.2, 0.4, 0.8)); b = s.add_texture_constant((0.5, 0.25, 2.0)); amt = s.add_texture_constant(0.25)
+    sc = s.add_texture_scale(a, b); mx = s.add_texture_mix(a, b, amt)
+    assert np.array_equal(s.texture_eval(sc, [[0, 0]])[0], (np.array([0.2, 0.4, 0.8], np.float32) * np.array([0.5, 0.25, 2.0], np.float32)))
+    want = f32(0.75) * np.array([0.2, 0.4, 0.8], np.float32) + f32(0.25) * np.array([0.5, 0.25, 2.0], np.float32)
+    assert np.array_equal(s.texture_eval(mx, [[0, 0]])[0], want.astype(np.float32))
+    img = make_image(4, 4, seed=1)
+    im = s.add_texture_imagemap(s.add_mipmap(img), su=2.0, sv=0.5, du=0.125, dv=0.25)
+    plain = s.add_texture_imagemap(0)
+    uv = np.array([[0.3, 0.7]], np.float32)
+    st = np.array([[f32(2.0) * f32(0.3) + f32(0.125), f32(0.5) * f32(0.7) + f32(0.25)]], np.float32)   # UVMapping2D (uv_2d.rs:52-60)
+    assert np.array_equal(s.texture_eval(im, uv)[0], s.texture_eval(plain, st)[0])
+    nested = s.add_texture_scale(s.add_texture_mix(im, a, amt), sc)
+    assert np.allclose(s.texture_eval(nested, uv)[0], (0.75 * s.texture_eval(im, uv)[0] + 0.25 * np.array([0.2, 0.4, 0.8])) * s.texture_eval(sc, uv)[0], rtol=1e-6)

@@ -1,0 +1,126 @@
+"""-m gpu: image textures (MIPMap build on the host side of the library, lookups + ray differentials on the device) against the oracle.
+Bit-exact with the oracle in libm mode 1 (log2 / trig evaluated in f64 and rounded, as the device does); the glibc-mode comparison
+uses the film tolerance of tests/test_render_gpu.py."""
+import numpy as np
+import pytest
+
+import pbrt_hip
+from oracle_binding import OracleScene, set_libm_mode
+from texture_scenes import make_image, probe_points, textured_quad_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h", [(16, 8), (5, 3), (33, 20), (1, 7)])
+@pytest.mark.parametrize("wrap", ["repeat", "clamp", "black"])
+def test_pyramid_equals_the_oracles(w, h, wrap):
+    img = make_image(w, h, seed=w * 100 + h)
+    for kw in (dict(), dict(as_float=True, gamma=True, scale=0.7), dict(gamma=True)):
+        prod = pbrt_hip.Scene(); orc = OracleScene()
+        pp = prod.mipmap_pyramid(prod.add_mipmap(img, wrap=wrap, **kw)); po = orc.mipmap_pyramid(orc.add_mipmap(img, wrap=wrap, **kw))
+        assert len(pp) == len(po)
+        for a, b in zip(pp, po):
+            assert a.shape == b.shape and _bits_equal(a, b)
+
+
+@pytest.mark.parametrize("trilinear", [True, False])
+@pytest.mark.parametrize("wrap", ["repeat", "clamp", "black"])
+@pytest.mark.parametrize("as_float", [False, True])
+def test_lookups_bit_exact(trilinear, wrap, as_float):
+    img = make_image(37, 24, seed=9)
+    uv, d = probe_points(4000, 5)
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    outs = []
+    for sc in (prod, orc):
+        mp = sc.add_mipmap(img, as_float=as_float, trilinear=trilinear, wrap=wrap, max_anisotropy=8.0 if not trilinear else 0.0)
+        t = sc.add_texture_imagemap(mp, su=1.5, sv=0.75, du=0.1, dv=-0.2)
+        k = sc.add_texture_constant((0.9, 0.5, 0.3)); amt = sc.add_texture_imagemap(sc.add_mipmap(make_image(8, 8, seed=2), as_float=True, trilinear=True))
+        tex = sc.add_texture_mix(sc.add_texture_scale(t, k), t, amt)
+        if sc is orc: set_libm_mode(1)
+        try:
+            outs.append((sc.texture_eval(t, uv, d), sc.texture_eval(tex, uv, d)))
+        finally:
+            set_libm_mode(0)
+    assert _bits_equal(outs[0][0], outs[1][0])
+    assert _bits_equal(outs[0][1], outs[1][1])
+    assert np.isfinite(outs[0][0]).all()
+
+
+def _render_pair(builder, **kw):
+    host = pbrt_hip.Host()
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    textured_quad_scene(prod, host, builder, **kw); textured_quad_scene(orc, host, builder, **kw)
+    return prod, orc
+
+
+def _tex(kind="noise", w=64, h=64, **mip_kw):
+    def build(sc):
+        return sc.add_texture_imagemap(sc.add_mipmap(make_image(w, h, seed=4, kind=kind), **mip_kw))
+    return build
+
+
+CASES = {
+    "ewa": dict(builder=_tex()),
+    "trilinear": dict(builder=_tex(trilinear=True)),
+    "npot_clamp_gamma": dict(builder=_tex(w=50, h=37, wrap="clamp", gamma=True)),
+    "black_wrap_top_view": dict(builder=_tex(wrap="black"), tilt=False),
+    "thin_lens": dict(builder=_tex(), lens_radius=0.05),
+    "instanced": dict(builder=_tex(kind="ramp"), instance=True),
+    "oren_nayar": dict(builder=_tex(), sigma=20.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_textured_matte_film_bit_exact(name):
+    kw = dict(CASES[name]); builder = kw.pop("builder")
+    prod, orc = _render_pair(builder, **kw)
+    set_libm_mode(1)
+    try:
+        oxyz, owt, ost, _ = orc.render_path_ex(max_depth=3)
+    finally:
+        set_libm_mode(0)
+    gxyz, gwt, gst = prod.render_path(max_depth=3)
+    assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
+    assert gst.regular_rays == ost.regular_rays and gst.shadow_rays == ost.shadow_rays
+    assert float(gxyz.mean()) > 0.0
+
+
+def test_textured_matte_with_general_materials_and_none_veil():
+    """The general-BSDF kernel with a textured matte among glass / plastic, seen through a 'none' veil: rays respawned at the veil carry no
+    differentials (path.rs:146-150), so the texture behind it is filtered with a zero footprint."""
+    def extra(sc):
+        gl = sc.add_material_glass((1, 1, 1), (1, 1, 1), 0.0, 0.0, 1.5, True)
+        pl = sc.add_material_plastic((0.3, 0.5, 0.2), (0.3, 0.3, 0.3), 0.1, True)
+        no = sc.add_material_none()
+        S = np.array([[-1.5, -1, 0.1], [-0.8, -1, 0.1], [-1.15, -1, 0.9], [0.8, -1, 0.1], [1.5, -1, 0.1], [1.15, -1, 0.9]], np.float32)
+        sc.add_mesh(S[:3], np.array([0, 1, 2], np.uint32), gl)
+        sc.add_mesh(S[3:], np.array([0, 1, 2], np.uint32), pl)
+        V = np.array([[-0.6, -3, 0.0], [0.6, -3, 0.0], [0.6, -3, 1.0], [-0.6, -3, 1.0]], np.float32)
+        sc.add_mesh(V, np.array([0, 1, 2, 0, 2, 3], np.uint32), no)
+    prod, orc = _render_pair(_tex(kind="checker", w=128, h=128), extra=extra, res=48)
+    set_libm_mode(1)
+    try:
+        oxyz, owt, ost, _ = orc.render_path_ex(max_depth=4)
+    finally:
+        set_libm_mode(0)
+    gxyz, gwt, gst = prod.render_path(max_depth=4)
+    assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
+
+
+def test_filtering_removes_the_moire_and_glibc_mode_is_within_tolerance():
+    """A one-texel checkerboard tiled to the horizon: with EWA the far field converges to grey; and against the oracle with glibc's own
+    log2f / trig (what the Rust reference links) the film stays within the stated tolerance."""
+    prod, orc = _render_pair(_tex(kind="checker", w=256, h=256), res=64, spp=8)
+    oxyz, owt, _, _ = orc.render_path_ex(max_depth=1)
+    gxyz, gwt, _ = prod.render_path(max_depth=1)
+    g = prod.film_to_rgb(gxyz, gwt); o = prod.film_to_rgb(oxyz, owt)
+    mean = float(o.mean())
+    rmse = float(np.sqrt(((g - o) ** 2).mean()))
+    assert rmse <= 1e-3 * mean
+    assert float((np.abs(g - o).max(axis=2) > 1e-2 * mean).mean()) <= 1e-3
+    far = g[31:34, 8:56, 1]    # just below the horizon of the tilted view: many checker periods per pixel -> filtered to grey
+    assert far.std() < 0.25 * far.mean() and 0.35 < float(far.mean()) < 0.65   # 0/1 texels under a white sky: about one half
