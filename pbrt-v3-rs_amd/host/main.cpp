@@ -14,6 +14,7 @@ static void usage() {
                  "  --tile-size N          sample tile edge (default 16, as the reference)\n"
                  "  --sobol-tables FILE    raw Sobol generator matrices (needed for Sampler \"sobol\")\n"
                  "  --check                parse and validate only: no GPU is touched and nothing is rendered\n"
+                 "  --convert-image IN OUT.pfm   decode a texture file (PFM, TGA, PNG) the way ImageTexture would see it and write it as PFM\n"
                  "  --quiet                no warnings / statistics\n");
 }
 
@@ -30,6 +31,13 @@ int main(int argc, char** argv) {
         else if (a == "--sobol-tables") { need(1); sobol = argv[++i]; }
         else if (a == "--quiet") quiet = true;
         else if (a == "--check") check = true;
+        else if (a == "--convert-image") {
+            need(2);
+            std::vector<float> rgb; int w = 0, h = 0; std::string err;
+            if (!pbrt_host::read_image(argv[i + 1], rgb, w, h, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            if (!pbrt_host::write_pfm(argv[i + 2], rgb.data(), w, h, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            return 0;
+        }
         else if (a == "--help" || a == "-h") { usage(); return 0; }
         else if (a.size() > 1 && a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 2; }
         else files.push_back(a);

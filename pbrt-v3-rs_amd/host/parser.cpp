@@ -183,7 +183,7 @@ struct Parser {
             else if (d == "Texture") {
                 std::string type, cls;
                 if (!quoted(name) || !quoted(type) || !quoted(cls) || !param_list(ps)) return false;
-                api.pbrt_texture(name, type, cls, ps);
+                api.pbrt_texture(name, type, cls, ps, scene_dir);
             }
             else if (d == "LightSource") { if (!name_and_params(name, ps)) return false; api.pbrt_light_source(name, ps); }
             else if (d == "AreaLightSource") { if (!name_and_params(name, ps)) return false; api.pbrt_area_light_source(name, ps); }

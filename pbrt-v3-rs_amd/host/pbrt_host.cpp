@@ -174,7 +174,7 @@ void Api::pbrt_transform_end() {
     ctm_ = ctm_stack_.back(); ctm_stack_.pop_back();
 }
 
-void Api::pbrt_texture(const std::string& name, const std::string& type, const std::string& tex_class, const ParamSet& p) {
+void Api::pbrt_texture(const std::string& name, const std::string& type, const std::string& tex_class, const ParamSet& p, const std::string& scene_dir) {
     if (!verify_world("Texture")) return;
     const bool is_float = type == "float", is_spec = type == "color" || type == "spectrum";
     if (!is_float && !is_spec) { warn("Texture type '" + type + "' unknown."); return; }
@@ -194,21 +194,78 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
         if (is_float) {
             const float t1 = fget("tex1", tex_class == "scale" ? 1.0f : 0.0f), t2 = fget("tex2", 1.0f);
             const float v = tex_class == "scale" ? t1 * t2 : ((1.0f - fget("amount", 0.5f)) * t1 + fget("amount", 0.5f) * t2);
-            if (ok) { gs_.unsupported_textures.erase(name); gs_.float_textures[name] = v; return; }
+            if (ok) { gs_.unsupported_textures.erase(name); gs_.device_textures.erase(name); gs_.float_textures[name] = v; return; }
         } else {
             const std::array<float, 3> t1 = sget("tex1", tex_class == "scale" ? std::array<float, 3>{1, 1, 1} : std::array<float, 3>{0, 0, 0}), t2 = sget("tex2", {1, 1, 1});
             std::array<float, 3> v;
             const float amt = fget("amount", 0.5f);
             for (int c = 0; c < 3; c++) v[c] = tex_class == "scale" ? t1[c] * t2[c] : ((1.0f - amt) * t1[c] + amt * t2[c]);
-            if (ok) { gs_.unsupported_textures.erase(name); gs_.spectrum_textures[name] = v; return; }
+            if (ok) { gs_.unsupported_textures.erase(name); gs_.device_textures.erase(name); gs_.spectrum_textures[name] = v; return; }
         }
     }
-    if (tex_class != "constant") {  // the device evaluates constant textures only (SURVEY §8f "next")
-        gs_.unsupported_textures[name] = tex_class;
-        gs_.float_textures.erase(name); gs_.spectrum_textures.erase(name);
+    auto forget = [&]() { gs_.unsupported_textures.erase(name); gs_.float_textures.erase(name); gs_.spectrum_textures.erase(name); gs_.device_textures.erase(name); };
+    if (tex_class == "imagemap") {  // ImageTexture::from (textures/src/imagemap.rs:117-160)
+        forget();
+        const std::string mapping = p.find_one_string("mapping", "uv");
+        if (mapping != "uv") { gs_.unsupported_textures[name] = "imagemap with mapping '" + mapping + "'"; return; }
+        std::string file = p.find_one_string("filename", "");
+        if (file.empty()) { if (error.empty()) error = "imagemap path not specified."; return; }
+        if (file[0] != '/' && !scene_dir.empty()) file = scene_dir + "/" + file;
+        const bool trilinear = p.find_one_bool("trilinear", false);
+        const float max_aniso = p.find_one_float("maxanisotropy", 8.0f), scale = p.find_one_float("scale", 1.0f);
+        const std::string wrap_s = p.find_one_string("wrap", "repeat");
+        const int wrap = wrap_s == "black" ? 1 : (wrap_s == "clamp" ? 2 : 0);
+        auto ends = [&](const char* e) { const size_t n = std::strlen(e); return file.size() >= n && file.compare(file.size() - n, n, e) == 0; };
+        const bool gamma = p.find_one_bool("gamma", ends(".tga") || ends(".png"));
+        char key[64];
+        std::snprintf(key, sizeof key, "|%d|%d|%d|%a|%d|%a", is_float ? 1 : 0, trilinear ? 0 : 1, wrap, (double)scale, gamma ? 1 : 0, (double)max_aniso);
+        const std::string ck = file + key;
+        uint32_t mip = 0;
+        auto it = mipmap_cache_.find(ck);
+        if (it != mipmap_cache_.end()) mip = it->second;
+        else {
+            std::vector<float> rgb; int w = 0, h = 0; std::string err;
+            if (!read_image(file, rgb, w, h, err)) { if (error.empty()) error = "Unable to load MIPMap: Error reading texture " + file + ", " + err; return; }
+            if (!check(ABI(pbrt_hip_add_mipmap(scene_, w, h, rgb.data(), is_float ? 1 : 0, scale, gamma ? 1 : 0, trilinear ? 0 : 1, wrap, max_aniso, &mip)), "add_mipmap")) return;
+            mipmap_cache_[ck] = mip;
+        }
+        uint32_t id = 0;
+        if (!check(ABI(pbrt_hip_add_texture_imagemap(scene_, mip, p.find_one_float("uscale", 1.0f), p.find_one_float("vscale", 1.0f), p.find_one_float("udelta", 0.0f),
+                                                     p.find_one_float("vdelta", 0.0f), &id)), "add_texture_imagemap")) return;
+        gs_.device_textures[name] = GraphicsState::DeviceTexture{is_float, id};
         return;
     }
-    gs_.unsupported_textures.erase(name);
+    if (tex_class == "scale" || tex_class == "mix") {  // an operand is evaluated per hit: the whole tree goes to the library
+        bool ok = true;
+        auto operand = [&](const char* pn, bool want_float, std::array<float, 3> dflt) -> uint32_t {
+            const std::string tn = p.find_one_texture(pn);
+            if (!tn.empty()) {
+                auto dt = gs_.device_textures.find(tn);
+                if (dt != gs_.device_textures.end() && dt->second.is_float == want_float) return dt->second.id;
+                std::array<float, 3> v = dflt; bool found = false;
+                if (want_float) { auto f = gs_.float_textures.find(tn); if (f != gs_.float_textures.end()) { v = {f->second, f->second, f->second}; found = true; } }
+                else { auto sp = gs_.spectrum_textures.find(tn); if (sp != gs_.spectrum_textures.end()) { v = sp->second; found = true; } }
+                if (!found) { ok = false; return 0u; }
+                dflt = v;
+            } else if (want_float) { const float f = p.find_one_float(pn, dflt[0]); dflt = {f, f, f}; }
+            else dflt = p.find_one_rgb(pn, dflt);
+            uint32_t id = 0;
+            if (!check(ABI(pbrt_hip_add_texture_constant(scene_, dflt.data(), &id)), "add_texture_constant")) ok = false;
+            return id;
+        };
+        const float d1 = tex_class == "scale" ? 1.0f : 0.0f;
+        const uint32_t t1 = operand("tex1", is_float, {d1, d1, d1}), t2 = operand("tex2", is_float, {1.0f, 1.0f, 1.0f});
+        uint32_t id = 0;
+        if (ok && tex_class == "scale") ok = check(ABI(pbrt_hip_add_texture_scale(scene_, t1, t2, &id)), "add_texture_scale");
+        else if (ok) { const uint32_t amt = operand("amount", true, {0.5f, 0.5f, 0.5f}); if (ok) ok = check(ABI(pbrt_hip_add_texture_mix(scene_, t1, t2, amt, &id)), "add_texture_mix"); }
+        if (ok) { forget(); gs_.device_textures[name] = GraphicsState::DeviceTexture{is_float, id}; return; }
+    }
+    if (tex_class != "constant") {  // bilerp / checkerboard / dots / fbm / marble / uv / windy / wrinkled / ptex: not evaluated by the library yet
+        forget();
+        gs_.unsupported_textures[name] = tex_class;
+        return;
+    }
+    forget();
     if (is_float) gs_.float_textures[name] = p.find_one_float("value", 1.0f);
     else gs_.spectrum_textures[name] = p.find_one_rgb("value", {1.0f, 1.0f, 1.0f});
 }
@@ -292,14 +349,19 @@ void Api::pbrt_area_light_source(const std::string& name, const ParamSet& p) { i
 uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::array<float, 3> kd = {0.5f, 0.5f, 0.5f};
     float sigma = 0.0f;
+    int64_t kd_tex = -1;  // matte: Kd names a texture the library evaluates per hit
     auto spectrum_tex = [&](const std::string& pname, std::array<float, 3> d) {
         std::string tn = m.params.find_one_texture(pname);
         if (!tn.empty()) {
+            if (gs_.device_textures.count(tn)) {
+                if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit textures are wired to MatteMaterial's Kd only so far";
+                return m.params.find_one_rgb(pname, d);
+            }
             auto it = gs_.spectrum_textures.find(tn);
             if (it != gs_.spectrum_textures.end()) return it->second;
             auto un = gs_.unsupported_textures.find(tn);
             if (un != gs_.unsupported_textures.end() && error.empty())
-                error = "texture '" + tn + "' of class '" + un->second + "' is outside the hot-path scope (constant textures only)";
+                error = "texture '" + tn + "' of class '" + un->second + "' is not evaluated by the library yet (constant, scale, mix and imagemap are)";
             else if (error.empty()) warn("Couldn't find spectrum texture named '" + tn + "' for parameter '" + pname + "'");
         }
         return m.params.find_one_rgb(pname, d);
@@ -307,11 +369,15 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     auto float_tex = [&](const std::string& pname, float d) {
         std::string tn = m.params.find_one_texture(pname);
         if (!tn.empty()) {
+            if (gs_.device_textures.count(tn)) {
+                if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit textures are wired to MatteMaterial's Kd only so far";
+                return m.params.find_one_float(pname, d);
+            }
             auto it = gs_.float_textures.find(tn);
             if (it != gs_.float_textures.end()) return it->second;
             auto un = gs_.unsupported_textures.find(tn);
             if (un != gs_.unsupported_textures.end() && error.empty())
-                error = "texture '" + tn + "' of class '" + un->second + "' is outside the hot-path scope (constant textures only)";
+                error = "texture '" + tn + "' of class '" + un->second + "' is not evaluated by the library yet (constant, scale, mix and imagemap are)";
             else if (error.empty()) warn("Couldn't find float texture named '" + tn + "' for parameter '" + pname + "'");
         }
         return m.params.find_one_float(pname, d);
@@ -336,7 +402,13 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
         u = hu ? float_tex("uroughness", r) : r; v = hv ? float_tex("vroughness", r) : r;
     };
     if (t == "none" || t.empty()) { /* no BSDF: graphics_state.rs make_material returns None */ }
-    else if (t == "matte") { a3 = spectrum_tex("Kd", kd); f0 = float_tex("sigma", sigma); put3(a3); kv.push_back(f0); }
+    else if (t == "matte") {
+        const std::string kd_name = m.params.find_one_texture("Kd");
+        auto dt = kd_name.empty() ? gs_.device_textures.end() : gs_.device_textures.find(kd_name);
+        if (dt != gs_.device_textures.end() && !dt->second.is_float) { kd_tex = (int64_t)dt->second.id; kv.push_back((float)dt->second.id); kv.push_back(-1.0f); }
+        else a3 = spectrum_tex("Kd", kd);
+        f0 = float_tex("sigma", sigma); put3(a3); kv.push_back(f0);
+    }
     else if (t == "mirror") { a3 = spectrum_tex("Kr", {0.9f, 0.9f, 0.9f}); put3(a3); }
     else if (t == "plastic") { a3 = spectrum_tex("Kd", quarter); b3 = spectrum_tex("Ks", quarter); f0 = float_tex("roughness", 0.1f); put3(a3); put3(b3); kv.push_back(f0); }
     else if (t == "glass") {
@@ -385,6 +457,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     uint32_t id = 0;
     int rc;
     if (t == "none" || t.empty()) rc = ABI(pbrt_hip_add_material_none(scene_, &id));
+    else if (t == "matte" && kd_tex >= 0) rc = ABI(pbrt_hip_add_material_matte_tex(scene_, (uint32_t)kd_tex, f0, &id));
     else if (t == "matte") rc = ABI(pbrt_hip_add_material_matte(scene_, a3.data(), f0, &id));
     else if (t == "mirror") rc = ABI(pbrt_hip_add_material_mirror(scene_, a3.data(), &id));
     else if (t == "plastic") rc = ABI(pbrt_hip_add_material_plastic(scene_, a3.data(), b3.data(), f0, remap ? 1 : 0, &id));

@@ -43,6 +43,8 @@ struct GraphicsState {  // api/src/graphics_state.rs:60-130
     std::map<std::string, std::array<float, 3>> spectrum_textures;  // constant textures only
     std::map<std::string, float> float_textures;
     std::map<std::string, std::string> unsupported_textures;       // name -> class, reported only if something uses them
+    struct DeviceTexture { bool is_float; uint32_t id; };          // imagemap, or scale / mix over one: evaluated by the library per hit
+    std::map<std::string, DeviceTexture> device_textures;
 };
 
 struct RenderReport {
@@ -82,7 +84,7 @@ class Api {
     void pbrt_attribute_end();
     void pbrt_transform_begin();
     void pbrt_transform_end();
-    void pbrt_texture(const std::string& name, const std::string& type, const std::string& tex_class, const ParamSet& p);
+    void pbrt_texture(const std::string& name, const std::string& type, const std::string& tex_class, const ParamSet& p, const std::string& scene_dir = "");
     void pbrt_material(const std::string& name, const ParamSet& p);
     void pbrt_make_named_material(const std::string& name, const ParamSet& p);
     void pbrt_named_material(const std::string& name);
@@ -121,6 +123,7 @@ class Api {
     Xform camera_to_world_;
     uint64_t n_tris_ = 0, n_lights_ = 0;
     std::map<std::string, uint32_t> material_cache_;
+    std::map<std::string, uint32_t> mipmap_cache_;  // MIPMapCache (core/src/mipmap/cache.rs:28-60), keyed by TexInfo + texel type
     std::map<std::string, uint32_t> objects_;   // named object instances (render_options.instances)
     std::map<std::string, uint64_t> object_tris_;
     std::string current_object_;                // "" outside ObjectBegin/ObjectEnd
@@ -140,6 +143,9 @@ bool parse_string(const std::string& text, const std::string& scene_dir, Api& ap
 // shapes/src/plymesh.rs:165-249 — vertices (x y z [nx ny nz] [u v | s t]) and faces of 3 or 4 vertex_indices
 struct PlyMesh { std::vector<float> P, N, UV; std::vector<uint32_t> indices; };
 bool read_ply(const std::string& path, PlyMesh& out, std::string& err);
+
+// core/src/image_io.rs:42-50 (PFM, TGA, PNG): width*height RGB floats, top row first
+bool read_image(const std::string& path, std::vector<float>& rgb, int& w, int& h, std::string& err);
 
 // core/src/image_io.rs:336-374
 bool write_pfm(const std::string& path, const float* rgb, int w, int h, std::string& err);

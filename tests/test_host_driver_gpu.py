@@ -306,3 +306,77 @@ WorldEnd
     finally:
         set_libm_mode(0)
     assert (img.view(np.uint32) == ref.view(np.uint32)).all(), f"{(img != ref).sum()} values differ"
+
+
+def test_textured_pbrt_file_renders_the_oracle_image(tmp_path, host):
+    """Texture "imagemap" (PNG with its default gamma, trilinear TGA float map, scaled PFM with black wrap and uv scale), "scale" and
+    "mix" textures over them, MatteMaterial "texture Kd": the C++ front end decodes the files and feeds the library; the oracle gets the
+    same texels from this test.  Images must be equal bit for bit."""
+    import image_files as imf
+    rng = np.random.default_rng(12)
+    a8 = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)                     # NPOT
+    m8 = (np.indices((16, 16)).sum(0) * 8 % 256).astype(np.uint8)             # grey ramp
+    hdr = rng.uniform(0.0, 2.0, (8, 8, 3)).astype(np.float32)
+    imf.write_png(str(tmp_path / "a.png"), a8)
+    imf.write_tga(str(tmp_path / "m.tga"), m8, grey=True, rle=True)
+    imf.write_pfm(str(tmp_path / "h.pfm"), hdr)
+    Q = np.array([[-4, -4, 0], [4, -4, 0], [4, 4, 0], [-4, 4, 0]], np.float32)
+    UVQ = np.array([[0, 0], [2, 0], [2, 2], [0, 2]], np.float32)
+    W = np.array([[-2, 3, 0], [2, 3, 0], [2, 3, 2.5], [-2, 3, 2.5]], np.float32)
+    UVW = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    res, spp, depth = 48, 4, 3
+    text = f"""LookAt 0 -6 1.5  0 0 0.5  0 0 1
+Camera "perspective" "float fov" [40]
+Film "image" "integer xresolution" [{res}] "integer yresolution" [{res}] "string filename" "tex.pfm"
+Sampler "halton" "integer pixelsamples" {spp}
+PixelFilter "box"
+Integrator "path" "integer maxdepth" {depth} "string lightsamplestrategy" "uniform"
+WorldBegin
+LightSource "infinite" "rgb L" [1 1 1]
+Texture "wood" "color" "imagemap" "string filename" "a.png"
+Texture "tint" "color" "scale" "texture tex1" "wood" "rgb tex2" [0.9 0.6 0.4]
+Texture "amt" "float" "imagemap" "string filename" "m.tga" "bool trilinear" "true" "string wrap" "clamp" "bool gamma" "false"
+Texture "blend" "color" "mix" "texture tex1" "tint" "rgb tex2" [0.1 0.2 0.8] "texture amount" "amt"
+Texture "hdr" "color" "imagemap" "string filename" "h.pfm" "float scale" 0.5 "float uscale" 2 "float vscale" 2 "string wrap" "black"
+Material "matte" "texture Kd" "blend"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [{ds.fl(Q)}] "float uv" [{ds.fl(UVQ)}]
+Material "matte" "texture Kd" "hdr" "float sigma" 20
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [{ds.fl(W)}] "float st" [{ds.fl(UVW)}]
+WorldEnd
+"""
+    (tmp_path / "tex.pbrt").write_text(text)
+    r = subprocess.run([ds.RENDER_BIN, "--quiet", str(tmp_path / "tex.pbrt")], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    img = ds.read_pfm(str(tmp_path / "tex.pfm"))
+
+    def capture(s):
+        wood = s.add_texture_imagemap(s.add_mipmap(a8.astype(np.float32) / np.float32(255.0), gamma=True))
+        tint = s.add_texture_scale(wood, s.add_texture_constant((0.9, 0.6, 0.4)))
+        grey = np.repeat(m8[..., None], 3, axis=2).astype(np.float32) / np.float32(255.0)
+        amt = s.add_texture_imagemap(s.add_mipmap(grey, as_float=True, trilinear=True, wrap="clamp", gamma=False))
+        blend = s.add_texture_mix(tint, s.add_texture_constant((0.1, 0.2, 0.8)), amt)
+        hd = s.add_texture_imagemap(s.add_mipmap(hdr, scale=0.5, wrap="black"), su=2.0, sv=2.0)
+        s.add_light_infinite((1.0, 1.0, 1.0))
+        s.add_mesh(Q, [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(blend, 0.0), UV=UVQ)
+        s.add_mesh(W, [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(hd, 20.0), UV=UVW)
+        w2c, c2w = host.look_at((0, -6, 1.5), (0, 0, 0.5), (0, 0, 1))
+        s.set_camera_perspective(host.perspective_raster_to_camera(40.0, res, res), c2w)
+        cb, table, sb = host.film_box(res, res)
+        s.set_film(res, res, cb, (0.5, 0.5), table)
+        s.set_sampler(0, spp, sb)
+        s.build_accel(0, 4)
+        return sb
+    set_libm_mode(1)
+    try:
+        with OracleScene() as o:
+            sb = capture(o)
+            xyz, wt, _ = o.render_path(max_depth=depth, light_strategy=0, pixel_bounds=sb)
+            ref = o.film_to_rgb(xyz, wt).reshape(res, res, 3)
+    finally:
+        set_libm_mode(0)
+    assert img.shape == ref.shape and float(img.mean()) > 0.05
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), f"{(img != ref).sum()} differing values, max {np.abs(img - ref).max()}"
+    with pbrt_hip.Scene() as s:   # and the Python wrapper over the same ABI
+        sb = capture(s)
+        xyz, wt, _ = s.render_path(max_depth=depth, light_strategy=0, pixel_bounds=sb)
+        assert (s.film_to_rgb(xyz, wt).reshape(res, res, 3).view(np.uint32) == ref.view(np.uint32)).all()

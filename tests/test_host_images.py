@@ -1,0 +1,72 @@
+"""CPU: the host front end's texture-file decoders (pbrt-v3-rs_amd/host/image_io.cpp, the read_image of core/src/image_io.rs:42-50)
+through `pbrt_hip_render --convert-image`: every decoded texel must be the value the reference's read_image would hand to the MIPMap
+(PFM: the float times |scale|; 8-bit formats: u8 / 255)."""
+import subprocess
+
+import numpy as np
+import pytest
+
+import driver_scene as ds
+import image_files as imf
+
+
+def _convert(tmp_path, name):
+    out = tmp_path / (name + ".out.pfm")
+    r = subprocess.run([ds.RENDER_BIN, "--convert-image", str(tmp_path / name), str(out)], capture_output=True, text=True, timeout=60)
+    return r, (ds.read_pfm(str(out)) if r.returncode == 0 else None)
+
+
+def _u8(h, w, seed):
+    return np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def test_pfm_both_endians_scale_and_grey(tmp_path):
+    img = np.random.default_rng(1).uniform(-2, 5, (5, 7, 3)).astype(np.float32)
+    imf.write_pfm(str(tmp_path / "a.pfm"), img, little=True)
+    imf.write_pfm(str(tmp_path / "b.pfm"), img, little=False, scale=2.0)
+    imf.write_pfm(str(tmp_path / "c.pfm"), img[..., 0], little=True)
+    r, a = _convert(tmp_path, "a.pfm"); assert r.returncode == 0, r.stderr
+    assert np.array_equal(a, img)
+    r, b = _convert(tmp_path, "b.pfm"); assert r.returncode == 0, r.stderr
+    assert np.array_equal(b, (img * np.float32(2.0)).astype(np.float32))
+    r, c = _convert(tmp_path, "c.pfm"); assert r.returncode == 0, r.stderr
+    assert np.array_equal(c, np.repeat(img[..., :1], 3, axis=2))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(rle=True), dict(top_origin=True), dict(rle=True, alpha=True), dict(grey=True), dict(grey=True, rle=True, top_origin=True)])
+def test_tga_variants(tmp_path, kw):
+    img = _u8(9, 13, 3)
+    img[2:5, 3:9] = img[2, 3]   # runs for the RLE packets
+    src = img[..., 0] if kw.get("grey") else img
+    imf.write_tga(str(tmp_path / "t.tga"), src, **kw)
+    r, got = _convert(tmp_path, "t.tga"); assert r.returncode == 0, r.stderr
+    want = (np.repeat(src[..., None], 3, axis=2) if kw.get("grey") else src).astype(np.float32) / np.float32(255.0)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ct", [0, 2, 3, 4, 6])
+def test_png_colour_types_and_row_filters(tmp_path, ct):
+    rgb = _u8(11, 6, 5)
+    if ct == 2: src, want = rgb, rgb
+    elif ct == 6: src = np.concatenate([rgb, _u8(11, 6, 6)[..., :1]], axis=2); want = rgb
+    elif ct == 0: src = rgb[..., 0]; want = np.repeat(rgb[..., :1], 3, axis=2)
+    elif ct == 4: src = rgb[..., :2]; want = np.repeat(rgb[..., :1], 3, axis=2)
+    else:
+        pal = _u8(1, 17, 7)[0]; src = np.random.default_rng(8).integers(0, 17, (11, 6), dtype=np.uint8); want = pal[src]
+    imf.write_png(str(tmp_path / "p.png"), src, color_type=ct, palette=pal if ct == 3 else None)
+    r, got = _convert(tmp_path, "p.png"); assert r.returncode == 0, r.stderr
+    assert np.array_equal(got, want.astype(np.float32) / np.float32(255.0))
+
+
+def test_undecodable_files_are_errors_not_black_textures(tmp_path):
+    (tmp_path / "x.exr").write_bytes(b"v/1\x01")
+    (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\nnonsense")
+    (tmp_path / "short.tga").write_bytes(b"\0" * 10)
+    for name, msg in (("x.exr", "not decoded"), ("bad.png", "PNG"), ("short.tga", "TGA"), ("missing.pfm", "cannot open")):
+        r, _ = _convert(tmp_path, name)
+        assert r.returncode != 0 and msg in r.stderr
+    # and a scene that names an undecodable map fails to load, also in --check mode (no GPU involved)
+    (tmp_path / "s.pbrt").write_text('Film "image" "integer xresolution" 8 "integer yresolution" 8\nWorldBegin\n'
+                                     'Texture "t" "color" "imagemap" "string filename" "x.exr"\nWorldEnd\n')
+    r = subprocess.run([ds.RENDER_BIN, "--check", str(tmp_path / "s.pbrt")], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "x.exr" in (r.stderr + r.stdout)
