@@ -155,8 +155,15 @@ int pbrt_hip_add_texture_constant(PbrtHipScene*, const float value[3], uint32_t*
 int pbrt_hip_add_texture_scale(PbrtHipScene*, uint32_t tex1, uint32_t tex2, uint32_t* out_texture);
 int pbrt_hip_add_texture_mix(PbrtHipScene*, uint32_t tex1, uint32_t tex2, uint32_t amount, uint32_t* out_texture);
 int pbrt_hip_add_texture_imagemap(PbrtHipScene*, uint32_t mipmap, float su, float sv, float du, float dv, uint32_t* out_texture);
-/* MatteMaterial whose Kd is a texture (materials/src/matte.rs:58-71): evaluated at every hit, with the ray differentials of camera rays
- * (SurfaceInteraction::compute_differentials) driving the MIPMap filter.  sigma stays a constant. */
+/* Replaces a colour parameter of an existing material by a texture evaluated at every hit (`self.kd.evaluate(..).clamp_default()` in
+ * compute_scattering_functions: materials/src/matte.rs:63, plastic.rs:62-70, mirror.rs:53-55, substrate.rs:60-62), with the ray
+ * differentials of camera rays (SurfaceInteraction::compute_differentials) driving the MIPMap filter.  Which lobes a hit gets follows the
+ * reference's `is_black` tests on the value at that hit.  Texturable so far: matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks;
+ * the material must have been created with a non-black constant for that parameter.  Scalar parameters (sigma, roughness, ...) stay constants;
+ * materials with per-hit textures cannot be children of a mix yet. */
+enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2 };
+int pbrt_hip_set_material_texture(PbrtHipScene*, uint32_t material, int param, uint32_t texture);
+/* = add_material_matte((1,1,1), sigma) + set_material_texture(KD) */
 int pbrt_hip_add_material_matte_tex(PbrtHipScene*, uint32_t kd_texture, float sigma_degrees, uint32_t* out_material);
 /* Test aids: evaluate a texture on the device at explicit (u, v, du/dx, dv/dx, du/dy, dv/dy) tuples; read back the pyramid the host built. */
 int pbrt_hip_texture_eval_batch(PbrtHipScene*, uint32_t texture, uint64_t n, const float* uv_and_derivatives /*6 per point*/, float* out_rgb /*3 per point*/);

@@ -63,6 +63,7 @@ int oracle_add_material_matte(OracleScene* s, const float kd[3], float sigma, ui
             l.b = 0.45f * s2 / (s2 + 0.09f);
         }
         m.lobes.push_back(l);
+        m.param_lobe[0] = 0;
     }
     return push_material(s, m, out_id);
 }
@@ -75,15 +76,16 @@ int oracle_add_material_mirror(OracleScene* s, const float kr[3], uint32_t* out_
     if (!s || !kr) return -1;
     Material m; m.general = true;
     Spec r = spec_clamp0(spec3(kr));
-    if (!r.is_black()) { Lobe l; l.kind = LK_SPEC_R; l.type = BX_REFL | BX_SPEC; l.fresnel = FR_NOOP; l.r = r; m.lobes.push_back(l); }
+    if (!r.is_black()) { Lobe l; l.kind = LK_SPEC_R; l.type = BX_REFL | BX_SPEC; l.fresnel = FR_NOOP; l.r = r; m.lobes.push_back(l); m.param_lobe[2] = 0; }
     return push_material(s, m, out_id);
 }
 int oracle_add_material_plastic(OracleScene* s, const float kd[3], const float ks[3], float roughness, int remap, uint32_t* out_id) {  // plastic.rs:50-82
     if (!s || !kd || !ks) return -1;
     Material m; m.general = true;
     Spec d = spec_clamp0(spec3(kd)), sp = spec_clamp0(spec3(ks));
-    if (!d.is_black()) { Lobe l; l.kind = LK_LAMBERT; l.type = BX_REFL | BX_DIFF; l.r = d; m.lobes.push_back(l); }
+    if (!d.is_black()) { Lobe l; l.kind = LK_LAMBERT; l.type = BX_REFL | BX_DIFF; l.r = d; m.lobes.push_back(l); m.param_lobe[0] = 0; }
     if (!sp.is_black()) {
+        m.param_lobe[1] = (int)m.lobes.size();
         Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.5f; l.eta_b = 1.0f; l.r = sp;
         Float rough = remap ? roughness_to_alpha(roughness) : roughness;
         set_tr(l, rough, rough);
@@ -321,20 +323,22 @@ int oracle_mipmap_level_texels(OracleScene* s, uint32_t mip, int level, float* o
     for (size_t i = 0; i < l.t.size(); i++) { out_rgb[3 * i] = l.t[i].c[0]; out_rgb[3 * i + 1] = l.t[i].c[1]; out_rgb[3 * i + 2] = l.t[i].c[2]; }
     return 0;
 }
+int oracle_set_material_texture(OracleScene* s, uint32_t material, int param, uint32_t texture) {
+    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || param < 0 || param > 2) return -1;
+    Material& m = s->sc.materials[material];
+    if (m.param_lobe[param] < 0) return -6;
+    Lobe& l = m.lobes[(size_t)m.param_lobe[param]];
+    if (m.param_field[param] == 0) l.r_tex = (int)texture; else l.t_tex = (int)texture;
+    m.textured = true;
+    return 0;
+}
 int oracle_add_material_matte_tex(OracleScene* s, uint32_t kd_tex, float sigma, uint32_t* out_id) {  // matte.rs:47-76 with a texture for Kd
-    if (!s || kd_tex >= s->sc.textures.size()) return -1;
-    Material m; m.kd = Spec(0.0f); m.sigma = sigma; m.kd_tex = (int)kd_tex;
-    Float sig = pclamp(sigma, 0.0f, 90.0f);
-    Lobe l; l.type = BX_REFL | BX_DIFF;
-    if (sig == 0.0f) l.kind = LK_LAMBERT;
-    else {
-        l.kind = LK_OREN;
-        Float sg = to_radians(sig), s2 = sg * sg;
-        l.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
-        l.b = 0.45f * s2 / (s2 + 0.09f);
-    }
-    m.lobes.push_back(l);
-    return push_material(s, m, out_id);
+    const float one[3] = {1.0f, 1.0f, 1.0f};
+    uint32_t id = 0;
+    int rc = oracle_add_material_matte(s, one, sigma, &id);
+    if (rc == 0) rc = oracle_set_material_texture(s, id, 0, kd_tex);
+    if (rc == 0 && out_id) *out_id = id;
+    return rc;
 }
 int oracle_set_film(OracleScene* s, int xres, int yres, const int crop[4], const float radius[2], const float table[256], float scale,
                     float max_lum) {
@@ -453,6 +457,7 @@ int oracle_add_material_substrate(OracleScene* s, const float kd[3], const float
         if (remap) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
         Lobe l; l.kind = LK_FRESNEL_BLEND; l.type = BX_REFL | BX_GLOSSY; l.r = d; l.t = sp; set_tr(l, urough, vrough);
         m.lobes.push_back(l);
+        m.param_lobe[0] = 0; m.param_field[0] = 0; m.param_lobe[1] = 0; m.param_field[1] = 1;
     }
     return push_material(s, m, out_id);
 }

@@ -913,16 +913,22 @@ struct Renderer {
             return true;
         }
     };
-    // `local` receives the per-hit lobe of a textured material; the returned BSDF points at it, so it must outlive the BSDF
-    BSDF make_bsdf(const SurfaceHit& si, Lobe& local) const {
+    // `local` receives the per-hit lobe list of a textured material; the returned BSDF points at it, so it must outlive the BSDF
+    BSDF make_bsdf(const SurfaceHit& si, Lobe* local) const {
         const Material& m = sc->materials[sc->mesh_of(si.prim).material];
         BSDF b; b.ns = si.ns; b.ng = si.n; b.ss = normalize(si.dpdu_s); b.ts = cross(b.ns, b.ss);  // bsdf.rs:100-116
         b.lobes = m.lobes.data(); b.n = (int)m.lobes.size(); b.eta = m.bsdf_eta;
-        if (m.kd_tex >= 0) {  // MatteMaterial::compute_scattering_functions with a texture (matte.rs:58-68)
+        if (m.textured) {  // compute_scattering_functions evaluates the textures at this hit (matte.rs:63-71, plastic.rs:62-81, mirror.rs:53-57, substrate.rs:60-80)
             TexCtx c; c.uv = si.uv; c.dudx = si.dudx; c.dvdx = si.dvdx; c.dudy = si.dudy; c.dvdy = si.dvdy;
-            Spec r = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, m.kd_tex, c));
-            if (r.is_black()) { b.lobes = nullptr; b.n = 0; }
-            else { local = m.lobes[0]; local.r = r; b.lobes = &local; b.n = 1; }
+            int k = 0;
+            for (const Lobe& tl : m.lobes) {
+                Lobe l = tl;
+                if (l.r_tex >= 0) l.r = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.r_tex, c));
+                if (l.t_tex >= 0) l.t = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.t_tex, c));
+                const bool keep = l.kind == LK_FRESNEL_BLEND ? !(l.r.is_black() && l.t.is_black()) : !l.r.is_black();
+                if (keep) local[k++] = l;
+            }
+            b.lobes = local; b.n = k;
         }
         return b;
     }
@@ -1084,8 +1090,8 @@ struct Renderer {
                 continue;
             }
             compute_differentials(isect, ray);  // SurfaceInteraction::compute_scattering_functions (surface_interaction.rs:176-195)
-            Lobe hit_lobe;
-            BSDF bsdf = make_bsdf(isect, hit_lobe);
+            Lobe hit_lobes[8];
+            BSDF bsdf = make_bsdf(isect, hit_lobes);
             V3 shading_n = isect.ns;
             if (spatial) (void)spatial_lookup(isect.p);  // light_distribution.lookup(&isect.hit.p) happens for every vertex (path.rs:156-157)
             if (bsdf.num_components(BX_ALL & ~BX_SPEC) > 0) {

@@ -39,10 +39,12 @@ struct Lobe {
     Float eta_a = 1, eta_b = 1;  // dielectric indices (Fresnel eta_i/eta_t, or etaA/etaB of the transmission lobes)
     Spec c_eta_i, c_eta_t, c_k;  // conductor Fresnel
     int n_scale = 0; Spec scale[2];  // ScaledBxDF wrappers of MixMaterial, innermost first (scaled_bxdf.rs)
+    int r_tex = -1, t_tex = -1;      // this colour is a texture evaluated per hit (set_material_texture)
 };
 struct Material {
     Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; bool none = false;  // none: Material "none" / "" -> no BSDF at all
-    int kd_tex = -1;  // MatteMaterial with a non-constant Kd: the lobe is made per hit (matte.rs:58-68); `lobes` then holds its template (r unset)
+    bool textured = false;  // some lobe colour is a texture: the BSDF's lobe list is made per hit (compute_scattering_functions evaluates the textures there)
+    int param_lobe[3] = {-1, -1, -1}, param_field[3] = {0, 0, 0};  // [Kd, Ks, Kr] -> lobe index / 0 = r, 1 = t
 };
 
 enum LightType { L_INFINITE = 0, L_DISTANT = 1, L_POINT = 2, L_AREA = 3, L_SPOT = 4 };

@@ -358,6 +358,7 @@ int push_material(PbrtHipScene* s, MaterialRec& m, const std::vector<LobeRec>& l
     m.lobe_base = (uint32_t)s->lobes.size(); m.n_lobes = (uint32_t)lobes.size();
     s->lobes.insert(s->lobes.end(), lobes.begin(), lobes.end());
     s->materials.push_back(m);
+    s->material_params.resize(s->materials.size());
     if (general) s->general_materials = true;
     if (out_id) *out_id = (uint32_t)s->materials.size() - 1;
     s->uploaded = false;
@@ -383,7 +384,9 @@ int pbrt_hip_add_material_matte(PbrtHipScene* s, const float kd[3], float sigma_
         std::memcpy(l.r, m.kd, 12); l.a = m.a; l.b = m.b;
         lobes.push_back(l);
     }
-    return push_material(s, m, lobes, false, out_id);
+    const int rc = push_material(s, m, lobes, false, out_id);
+    if (rc == PBRT_HIP_OK && m.has_bxdf) s->material_params.back().lobe[0] = 0;
+    return rc;
 }
 // ---- textures --------------------------------------------------------------------------------------------------------------------
 namespace {
@@ -535,21 +538,33 @@ int pbrt_hip_add_texture_mix(PbrtHipScene* s, uint32_t t1, uint32_t t2, uint32_t
     t.stack_need = std::max(a.stack_need, std::max(1 + b.stack_need, 2 + c.stack_need));
     return push_texture(s, std::move(t), out_id);
 }
+// Replaces a material's constant colour parameter by a texture evaluated at every hit.  The material must have been created with a non-black
+// constant for that parameter (so that its lobe exists); which lobes a hit finally gets follows the reference's `is_black` tests on the
+// texture's value at that hit.
+int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param, uint32_t texture) {
+    if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: unknown material or texture");
+    if (param < 0 || param > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: param must be PBRT_HIP_PARAM_KD / KS / KR");
+    const PbrtHipScene::MaterialParams& mp = s->material_params[material];
+    if (mp.lobe[param] < 0)
+        return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: this material has no lobe fed by that parameter (matte Kd, plastic Kd / Ks, mirror Kr and substrate Kd / Ks "
+                                                   "take textures; create the material with a non-black placeholder for the parameter)");
+    MaterialRec& m = s->materials[material];
+    LobeRec& l = s->lobes[m.lobe_base + (uint32_t)mp.lobe[param]];
+    if (mp.field[param] == 0) l.r_tex1 = texture + 1u; else l.t_tex1 = texture + 1u;
+    m.textured = 1u;
+    if (l.kind == PH_LK_LAMBERT || l.kind == PH_LK_OREN) { if (m.n_lobes == 1u) m.kd_tex1 = texture + 1u; }  // MatteMaterial: the one-lobe kernel reads kd_tex1
+    s->textured_materials = true;
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
 int pbrt_hip_add_material_matte_tex(PbrtHipScene* s, uint32_t kd_tex, float sigma_deg, uint32_t* out_id) {  // matte.rs:47-76, Kd a texture
     if (!s || kd_tex >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_matte_tex: unknown texture");
-    MaterialRec m{};
-    m.kd_tex1 = kd_tex + 1u; m.has_bxdf = 1u;  // decided per hit
-    m.sigma = hm::clampf(sigma_deg, 0.0f, 90.0f);
-    m.bsdf_eta = 1.0f;
-    if (m.sigma != 0.0f) {
-        float sg = hm::to_radians(m.sigma), s2 = sg * sg;
-        m.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
-        m.b = 0.45f * s2 / (s2 + 0.09f);
-    }
-    LobeRec l = lobe(m.sigma != 0.0f ? PH_LK_OREN : PH_LK_LAMBERT, T_REFL | T_DIFF);  // template: r is filled per hit
-    l.a = m.a; l.b = m.b;
-    s->textured_materials = true;
-    return push_material(s, m, std::vector<LobeRec>{l}, false, out_id);
+    const float one[3] = {1.0f, 1.0f, 1.0f};
+    uint32_t id = 0;
+    int rc = pbrt_hip_add_material_matte(s, one, sigma_deg, &id);
+    if (rc == PBRT_HIP_OK) rc = pbrt_hip_set_material_texture(s, id, 0, kd_tex);
+    if (rc == PBRT_HIP_OK && out_id) *out_id = id;
+    return rc;
 }
 // ---- texture probes (test aids: the device's texture evaluation on explicit inputs, and the pyramid the host built) ----------------
 namespace ph {
@@ -606,7 +621,9 @@ int pbrt_hip_add_material_mirror(PbrtHipScene* s, const float kr[3], uint32_t* o
     std::vector<LobeRec> lobes;
     float r[3];
     if (clamp3(kr, r)) { LobeRec l = lobe(PH_LK_SPEC_R, T_REFL | T_SPEC); l.fresnel = PH_FR_NOOP; std::memcpy(l.r, r, 12); lobes.push_back(l); }
-    return push_material(s, m, lobes, true, out_id);
+    const int rc = push_material(s, m, lobes, true, out_id);
+    if (rc == PBRT_HIP_OK && !lobes.empty()) s->material_params.back().lobe[2] = 0;
+    return rc;
 }
 int pbrt_hip_add_material_plastic(PbrtHipScene* s, const float kd[3], const float ks[3], float roughness, int remap_roughness, uint32_t* out_id) {  // plastic.rs:50-82
     if (!s || !kd || !ks) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_plastic: null argument");
@@ -620,7 +637,10 @@ int pbrt_hip_add_material_plastic(PbrtHipScene* s, const float kd[3], const floa
         set_tr(l, rough, rough);
         lobes.push_back(l);
     }
-    return push_material(s, m, lobes, true, out_id);
+    const int kd_lobe = (!lobes.empty() && lobes[0].kind == PH_LK_LAMBERT) ? 0 : -1, ks_lobe = (!lobes.empty() && lobes.back().kind == PH_LK_MICRO_R) ? (int)lobes.size() - 1 : -1;
+    const int rc = push_material(s, m, lobes, true, out_id);
+    if (rc == PBRT_HIP_OK) { s->material_params.back().lobe[0] = kd_lobe; s->material_params.back().lobe[1] = ks_lobe; }
+    return rc;
 }
 int pbrt_hip_add_material_glass(PbrtHipScene* s, const float kr[3], const float kt[3], float urough, float vrough, float eta, int remap_roughness,
                                 uint32_t* out_id) {  // glass.rs:62-118 with allow_multiple_lobes = true (path.rs:143)
@@ -691,7 +711,9 @@ int pbrt_hip_add_material_substrate(PbrtHipScene* s, const float kd[3], const fl
         LobeRec l = lobe(PH_LK_FRESNEL_BLEND, T_REFL | T_GLOSSY); std::memcpy(l.r, d, 12); std::memcpy(l.t, sp, 12); set_tr(l, urough, vrough);
         lobes.push_back(l);
     }
-    return push_material(s, m, lobes, true, out_id);
+    const int rc = push_material(s, m, lobes, true, out_id);
+    if (rc == PBRT_HIP_OK && !lobes.empty()) { PbrtHipScene::MaterialParams& mp = s->material_params.back(); mp.lobe[0] = 0; mp.field[0] = 0; mp.lobe[1] = 0; mp.field[1] = 1; }
+    return rc;
 }
 int pbrt_hip_add_material_translucent(PbrtHipScene* s, const float kd[3], const float ks[3], const float reflect[3], const float transmit[3], float roughness,
                                       int remap_roughness, uint32_t* out_id) {  // translucent.rs:57-112
@@ -723,6 +745,7 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
     for (int c = 0; c < 3; c++) tmp[c] = 1.0f - s1[c];
     clamp3(tmp, s2);
     const MaterialRec a = s->materials[material1], b = s->materials[material2];
+    if (a.textured || b.textured) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a mix of materials with per-hit textures is not supported yet");
     if (a.n_lobes + b.n_lobes > 8) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: more than MAX_BXDFS = 8 lobes (BSDF::add asserts, bsdf.rs:119-125)");
     std::vector<LobeRec> lobes;
     auto take = [&](const MaterialRec& src, const float sc[3]) {

@@ -30,6 +30,9 @@ struct PbrtHipScene {
     std::vector<TextureHost> textures;
     std::vector<MipRec> mipmaps;
     std::vector<Texel> texels;
+    // which lobe and which of its two colours each texturable parameter of a material feeds (set_material_texture); -1 = that lobe was not made
+    struct MaterialParams { int lobe[3] = {-1, -1, -1}; int field[3] = {0, 0, 0}; };  // [Kd, Ks, Kr]; field 0 = r, 1 = t
+    std::vector<MaterialParams> material_params;
     bool textured_materials = false;  // some material evaluates a texture per hit
     bool has_none_material = false;  // some material is "none": paths may need more wavefront iterations than max_depth + 1
     bool general_materials = false;  // some material is not matte: the renderer uses the general BSDF kernel

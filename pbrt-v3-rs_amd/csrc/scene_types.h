@@ -67,8 +67,8 @@ struct alignas(16) LobeRec {
     float a, b;                           // Oren-Nayar A, B
     float ax, ay;                         // Trowbridge-Reitz alpha_x, alpha_y (already max(0.001, .))
     float eta_a, eta_b, pad1[2];          // dielectric Fresnel (eta_i, eta_t) / transmission lobes (etaA, etaB)
-    float r[3], pad2;
-    float t[3], pad3;
+    float r[3]; uint32_t r_tex1;          // r_tex1 / t_tex1: 0, or 1 + the texture that supplies this colour at every hit (set_material_texture)
+    float t[3]; uint32_t t_tex1;
     float c_eta_t[3], pad4;               // conductor Fresnel: eta_t and k (eta_i is ONE, metal.rs:84-88)
     float c_k[3], pad5;
     float scale0[3], pad6;                // innermost ScaledBxDF scale
@@ -85,7 +85,10 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     float bsdf_eta;    // BSDF::eta (bsdf.rs:101): 1 unless the material passes one (uber.rs:131-138)
     uint32_t none;     // Material "none": no BSDF, the path integrator skips the surface (path.rs:142-150)
     uint32_t kd_tex1;  // 0, or 1 + the texture MatteMaterial evaluates for Kd at every hit (matte.rs:63): kd / has_bxdf are then per hit
+    uint32_t textured; // some lobe of the list takes a colour from a texture: the general-BSDF kernel builds the hit's own list
+    uint32_t pad[3];
 };
+#define PH_HIT_LOBES 2   // per-thread slots for the per-hit lobe list of a textured material (matte, mirror: 1; plastic: 2; substrate: 1)
 
 // ---- textures (textures/src/*.rs, core/src/mipmap/mod.rs).  A texture is a postfix program over a small value stack: the host
 // flattens the scale / mix tree once (api.hip), the device runs it per hit (texture.h).  Float-valued textures are carried as three equal

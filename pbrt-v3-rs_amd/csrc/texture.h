@@ -188,11 +188,11 @@ PH_DEV void compute_differentials(f3 p, f3 n, f3 dpdu, f3 dpdv, const RayDiff& r
     if (!(x0 != x0 || x1 != x1)) { c.dudy = x0; c.dvdy = x1; }
 }
 
-// MatteMaterial's `kd.evaluate(..).clamp_default()` for a hit (matte.rs:63), out of line.  Everything texture evaluation needs beyond
-// what the integrator carries is rebuilt here from the TriRec the traversal reported: uv (triangle.rs:584), the geometric dp/du, dp/dv
-// (:548-574, carried to world space for an instance: transform.rs:566-590) and — for camera rays only — du/dv d x/y.
-static __device__ __noinline__ spec textured_kd(const DeviceScene* dsc, const CameraRec* cam, uint32_t spp, uint32_t tex, uint32_t tri_index, uint32_t inst,
-                                                f3 bary, f3 p, f3 n, f3 ro, f3 rd, f2 p_film, f2 lens, uint32_t camera_ray) {
+// The texture-evaluation context of a hit, out of line.  Everything texture evaluation needs beyond what the integrator carries is rebuilt
+// here from the TriRec the traversal reported: uv (triangle.rs:584), the geometric dp/du, dp/dv (:548-574, carried to world space for an
+// instance: transform.rs:566-590) and — for camera rays only — du/dv d x/y.
+static __device__ __noinline__ TexCtx hit_tex_ctx(const DeviceScene* dsc, const CameraRec* cam, uint32_t spp, uint32_t tri_index, uint32_t inst,
+                                                  f3 bary, f3 p, f3 n, f3 ro, f3 rd, f2 p_film, f2 lens, uint32_t camera_ray) {
     const DeviceScene& sc = *dsc;
     const float4* tp = reinterpret_cast<const float4*>(sc.tris + tri_index);
     const float4 a = tp[0], b = tp[1], c = tp[2];
@@ -222,8 +222,26 @@ static __device__ __noinline__ spec textured_kd(const DeviceScene* dsc, const Ca
         const RayDiff rdf = camera_ray_differentials(cm, p_film, lens, ro, rd, spp);
         compute_differentials(p, n, dpdu, dpdv, rdf, ctx);
     }
+    return ctx;
+}
+// `tex.evaluate(..).clamp_default()` (matte.rs:63, plastic.rs:62-70, mirror.rs:53, substrate.rs:60-61)
+PH_DEV spec tex_eval_clamped(const DeviceScene* dsc, uint32_t tex, const TexCtx& ctx) {
     const spec v = tex_eval(dsc, tex, ctx);
     return mks(pclampf(v.r, 0.0f, kInf), pclampf(v.g, 0.0f, kInf), pclampf(v.b, 0.0f, kInf));
+}
+// The hit's own lobe list of a textured material: the template lobes with their textured colours filled in, a lobe dropped where the reference
+// would not add it (`if !kd.is_black()`, plastic.rs:63 / :70, mirror.rs:55, matte.rs:66; FresnelBlend unless both are black, substrate.rs:62).
+PH_DEV uint32_t build_hit_lobes(const DeviceScene* dsc, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, LobeRec* out) {
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < n && k < PH_HIT_LOBES; i++) {
+        LobeRec l = tmpl[i];
+        if (l.r_tex1) { const spec c = tex_eval_clamped(dsc, l.r_tex1 - 1u, ctx); l.r[0] = c.r; l.r[1] = c.g; l.r[2] = c.b; }
+        if (l.t_tex1) { const spec c = tex_eval_clamped(dsc, l.t_tex1 - 1u, ctx); l.t[0] = c.r; l.t[1] = c.g; l.t[2] = c.b; }
+        const bool r_black = l.r[0] == 0.0f && l.r[1] == 0.0f && l.r[2] == 0.0f, t_black = l.t[0] == 0.0f && l.t[1] == 0.0f && l.t[2] == 0.0f;
+        const bool keep = l.kind == PH_LK_FRESNEL_BLEND ? !(r_black && t_black) : !r_black;
+        if (keep) out[k++] = l;
+    }
+    return k;
 }
 
 }  // namespace ph

@@ -185,7 +185,10 @@ template <> struct BsdfOps<false> {
     static PH_DEV void sample_ns(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi) { bsdf_sample_f(b, wo, u, f, pdf, wi); }
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, f, pdf, wi); type = BX_REFL | BX_DIFF; }
     static PH_DEV float eta(const T&) { return 1.0f; }
-    static PH_DEV void set_kd(T& b, spec kd, LobeRec*) { b.r = kd; b.has_bxdf = !is_black(kd); }
+    static PH_DEV void apply_textures(const DeviceScene& sc, T& b, const MaterialRec& mr, const TexCtx& ctx, LobeRec*) {
+        const spec kd = tex_eval_clamped(sc.self, mr.kd_tex1 - 1u, ctx);
+        b.r = kd; b.has_bxdf = !is_black(kd);
+    }
 };
 template <> struct BsdfOps<true> {
     using T = GBsdf;
@@ -196,12 +199,10 @@ template <> struct BsdfOps<true> {
     static PH_DEV void sample_ns(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi) { uint32_t t; bsdf_sample_f(b, wo, u, BX_ALL & ~BX_SPEC, f, pdf, wi, t); }
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, BX_ALL, f, pdf, wi, type); }
     static PH_DEV float eta(const T& b) { return b.eta; }
-    // the hit's own lobe (the material's template with this hit's reflectance) goes to the thread's slot of WfParams::hit_lobes
-    static PH_DEV void set_kd(T& b, spec kd, LobeRec* slot) {
-        if (is_black(kd)) { b.n = 0u; return; }
-        LobeRec l = b.lobes[0];
-        l.r[0] = kd.r; l.r[1] = kd.g; l.r[2] = kd.b;
-        *slot = l; b.lobes = slot;
+    // the hit's own lobe list goes to the thread's slots of WfParams::hit_lobes
+    static PH_DEV void apply_textures(const DeviceScene& sc, T& b, const MaterialRec&, const TexCtx& ctx, LobeRec* slots) {
+        b.n = build_hit_lobes(sc.self, b.lobes, b.n, ctx, slots);
+        b.lobes = slots;
     }
 };
 
@@ -343,9 +344,9 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         typename BO::T bsdf = BO::make(sc, si, m.material);
                         const uint32_t ppix = pid / w.chunk_spp;
                         const int2 xy = w.px_xy[ppix];
-                        if (TEX) {  // compiled into separate instantiations: the out-of-line call would cost the texture-free kernels registers
-                            const uint32_t kd_tex1 = sc.materials[m.material].kd_tex1;
-                            if (kd_tex1) {  // MatteMaterial with a texture for Kd: the lobe's reflectance is this hit's (matte.rs:63-71)
+                        if (TEX) {  // compiled into separate instantiations: the out-of-line calls would cost the texture-free kernels registers
+                            const MaterialRec& mr = sc.materials[m.material];
+                            if (GEN ? mr.textured != 0u : mr.kd_tex1 != 0u) {  // some colour of this material is this hit's (matte.rs:63, plastic.rs:62-70, ...)
                                 const uint32_t camera_ray = (bounces == 0u && !(flags & F_NODIFF)) ? 1u : 0u;  // only camera rays carry differentials
                                 f2 p_film = mk2(0.0f, 0.0f), lens = mk2(0.0f, 0.0f);
                                 if (camera_ray) {
@@ -353,9 +354,9 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                     p_film = mk2(w.rec_L[gsi].w, w.rec_py[gsi]);
                                     if (w.cam.lens_radius > 0.0f) { const float4 la = w.s_A[pid]; lens = mk2(la.x, la.y); }
                                 }
-                                const spec kd = textured_kd(sc.self, w.cam_dev, w.sp.spp, kd_tex1 - 1u, __float_as_uint(h1.y), __float_as_uint(h1.z), mk3(h0.z, h0.w, h1.x),
-                                                            si.p, si.n, mk3(ray.ox, ray.oy, ray.oz), rd, p_film, lens, camera_ray);
-                                BO::set_kd(bsdf, kd, w.hit_lobes ? w.hit_lobes + (size_t)blockIdx.x * PH_SHADE_BLOCK + tid : nullptr);
+                                const TexCtx ctx = hit_tex_ctx(sc.self, w.cam_dev, w.sp.spp, __float_as_uint(h1.y), __float_as_uint(h1.z), mk3(h0.z, h0.w, h1.x),
+                                                               si.p, si.n, mk3(ray.ox, ray.oy, ray.oz), rd, p_film, lens, camera_ray);
+                                BO::apply_textures(sc, bsdf, mr, ctx, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr);
                             }
                         }
                         SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid - ppix * w.chunk_spp), dim, hl);
@@ -890,7 +891,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, 256 * 16);
     wp.hit_lobes = nullptr;
     if (s->textured_materials && s->general_materials) {
-        if ((rc = ensure_buf(s, w.d_hit_lobes, (size_t)shade_blocks * PH_SHADE_BLOCK * sizeof(LobeRec)))) return rc;
+        if ((rc = ensure_buf(s, w.d_hit_lobes, (size_t)shade_blocks * PH_SHADE_BLOCK * PH_HIT_LOBES * sizeof(LobeRec)))) return rc;
         wp.hit_lobes = (LobeRec*)w.d_hit_lobes.p;
     }
 

@@ -349,13 +349,21 @@ void Api::pbrt_area_light_source(const std::string& name, const ParamSet& p) { i
 uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::array<float, 3> kd = {0.5f, 0.5f, 0.5f};
     float sigma = 0.0f;
-    int64_t kd_tex = -1;  // matte: Kd names a texture the library evaluates per hit
+    int64_t tex_param[3] = {-1, -1, -1};  // [Kd, Ks, Kr]: the parameter names a texture the library evaluates per hit
     auto spectrum_tex = [&](const std::string& pname, std::array<float, 3> d) {
         std::string tn = m.params.find_one_texture(pname);
         if (!tn.empty()) {
-            if (gs_.device_textures.count(tn)) {
-                if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit textures are wired to MatteMaterial's Kd only so far";
-                return m.params.find_one_rgb(pname, d);
+            auto dt = gs_.device_textures.find(tn);
+            if (dt != gs_.device_textures.end()) {
+                // a texture the library evaluates per hit: the material is created with a white placeholder and the texture attached afterwards
+                const int param = pname == "Kd" ? 0 : (pname == "Ks" ? 1 : (pname == "Kr" ? 2 : -1));
+                const bool takes = (m.type == "matte" && param == 0) || ((m.type == "plastic" || m.type == "substrate") && (param == 0 || param == 1)) || (m.type == "mirror" && param == 2);
+                if (!takes || dt->second.is_float) {
+                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": image-based textures are wired to matte Kd, plastic Kd / Ks, mirror Kr and substrate Kd / Ks so far";
+                    return m.params.find_one_rgb(pname, d);
+                }
+                tex_param[param] = (int64_t)dt->second.id;
+                return std::array<float, 3>{1.0f, 1.0f, 1.0f};
             }
             auto it = gs_.spectrum_textures.find(tn);
             if (it != gs_.spectrum_textures.end()) return it->second;
@@ -370,7 +378,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
         std::string tn = m.params.find_one_texture(pname);
         if (!tn.empty()) {
             if (gs_.device_textures.count(tn)) {
-                if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit textures are wired to MatteMaterial's Kd only so far";
+                if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": image-based textures feed colour parameters only (matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks); scalar parameters stay constants";
                 return m.params.find_one_float(pname, d);
             }
             auto it = gs_.float_textures.find(tn);
@@ -403,11 +411,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     };
     if (t == "none" || t.empty()) { /* no BSDF: graphics_state.rs make_material returns None */ }
     else if (t == "matte") {
-        const std::string kd_name = m.params.find_one_texture("Kd");
-        auto dt = kd_name.empty() ? gs_.device_textures.end() : gs_.device_textures.find(kd_name);
-        if (dt != gs_.device_textures.end() && !dt->second.is_float) { kd_tex = (int64_t)dt->second.id; kv.push_back((float)dt->second.id); kv.push_back(-1.0f); }
-        else a3 = spectrum_tex("Kd", kd);
-        f0 = float_tex("sigma", sigma); put3(a3); kv.push_back(f0);
+        a3 = spectrum_tex("Kd", kd); f0 = float_tex("sigma", sigma); put3(a3); kv.push_back(f0);
     }
     else if (t == "mirror") { a3 = spectrum_tex("Kr", {0.9f, 0.9f, 0.9f}); put3(a3); }
     else if (t == "plastic") { a3 = spectrum_tex("Kd", quarter); b3 = spectrum_tex("Ks", quarter); f0 = float_tex("roughness", 0.1f); put3(a3); put3(b3); kv.push_back(f0); }
@@ -452,12 +456,12 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     if (!error.empty()) return 0;
     std::string key = t + (remap ? ":r" : ":n");
     for (float v : kv) { uint32_t u; std::memcpy(&u, &v, 4); char b[12]; std::snprintf(b, sizeof b, ":%08x", u); key += b; }
+    for (int k = 0; k < 3; k++) if (tex_param[k] >= 0) key += "|tex" + std::to_string(k) + "=" + std::to_string(tex_param[k]);
     auto it = material_cache_.find(key);
     if (it != material_cache_.end()) return it->second;
     uint32_t id = 0;
     int rc;
     if (t == "none" || t.empty()) rc = ABI(pbrt_hip_add_material_none(scene_, &id));
-    else if (t == "matte" && kd_tex >= 0) rc = ABI(pbrt_hip_add_material_matte_tex(scene_, (uint32_t)kd_tex, f0, &id));
     else if (t == "matte") rc = ABI(pbrt_hip_add_material_matte(scene_, a3.data(), f0, &id));
     else if (t == "mirror") rc = ABI(pbrt_hip_add_material_mirror(scene_, a3.data(), &id));
     else if (t == "plastic") rc = ABI(pbrt_hip_add_material_plastic(scene_, a3.data(), b3.data(), f0, remap ? 1 : 0, &id));
@@ -468,6 +472,8 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     else if (t == "mix") rc = ABI(pbrt_hip_add_material_mix(scene_, (uint32_t)f0, (uint32_t)f1, a3.data(), &id));
     else rc = ABI(pbrt_hip_add_material_uber(scene_, a3.data(), b3.data(), c3.data(), d3.data(), e3.data(), f0, f1, f2, remap ? 1 : 0, &id));
     if (!check(rc, "add_material")) return 0;
+    for (int k = 0; k < 3; k++)
+        if (tex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_texture(scene_, id, k, (uint32_t)tex_param[k])), "set_material_texture")) return 0;
     material_cache_[key] = id;
     return id;
 }

@@ -119,6 +119,7 @@ class Binding:
             "add_texture_mix": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
             "add_texture_imagemap": (C.c_int, [vp, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
             "add_material_matte_tex": (C.c_int, [vp, C.c_uint32, C.c_float, u32p]),
+            "set_material_texture": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32]),
             "texture_eval_batch": (C.c_int, [vp, C.c_uint32, C.c_uint64, fp, fp]),
             "mipmap_levels": (C.c_int, [vp, C.c_uint32, ip, ip]),
             "mipmap_level_texels": (C.c_int, [vp, C.c_uint32, C.c_int, fp]),
@@ -482,6 +483,12 @@ class Scene:
 
     def add_material_matte_tex(self, kd_texture, sigma=0.0):
         out = C.c_uint32(0); self._chk(self.b.fn("add_material_matte_tex")(self.h, kd_texture, C.c_float(sigma), C.byref(out))); return out.value
+
+    PARAM = {"Kd": 0, "Ks": 1, "Kr": 2}
+
+    def set_material_texture(self, material, param, texture):
+        """param: "Kd" | "Ks" | "Kr" — that colour of `material` becomes `texture`, evaluated per hit."""
+        self._chk(self.b.fn("set_material_texture")(self.h, material, self.PARAM[param], texture))
 
     def texture_eval(self, texture, uv, derivs=None):
         """Evaluates `texture` at uv (n,2) with (du/dx, dv/dx, du/dy, dv/dy) (n,4); returns (n,3).  A probe for the parity tests."""

@@ -161,3 +161,40 @@ def test_scale_and_mix_textures():
     assert np.array_equal(s.texture_eval(im, uv)[0], s.texture_eval(plain, st)[0])
     nested = s.add_texture_scale(s.add_texture_mix(im, a, amt), sc)
     assert np.allclose(s.texture_eval(nested, uv)[0], (0.75 * s.texture_eval(im, uv)[0] + 0.25 * np.array([0.2, 0.4, 0.8])) * s.texture_eval(sc, uv)[0], rtol=1e-6)
+
+
+def test_a_constant_texture_is_the_constant_parameter():
+    """set_material_texture with a ConstantTexture must be indistinguishable from passing the constant: same lobes, same film (the
+    per-hit lobe list degenerates to the material's own list)."""
+    import pbrt_hip
+    from texture_scenes import textured_quad_scene
+    host = pbrt_hip.Host()
+
+    def film(material):
+        s = OracleScene()
+        textured_quad_scene(s, host, lambda sc: sc.add_texture_constant((0.3, 0.6, 0.2)), res=24, spp=2, material=material)
+        xyz, wt, st, _ = s.render_path_ex(max_depth=3)
+        return xyz
+
+    def plastic_tex(sc, tex):
+        m = sc.add_material_plastic((1, 1, 1), (1, 1, 1), 0.1, True)
+        sc.set_material_texture(m, "Kd", tex); sc.set_material_texture(m, "Ks", tex); return m
+    assert np.array_equal(film(plastic_tex), film(lambda sc, tex: sc.add_material_plastic((0.3, 0.6, 0.2), (0.3, 0.6, 0.2), 0.1, True)))
+
+    def substrate_tex(sc, tex):
+        m = sc.add_material_substrate((1, 1, 1), (1, 1, 1), 0.2, 0.1, True)
+        sc.set_material_texture(m, "Kd", tex); sc.set_material_texture(m, "Ks", tex); return m
+    assert np.array_equal(film(substrate_tex), film(lambda sc, tex: sc.add_material_substrate((0.3, 0.6, 0.2), (0.3, 0.6, 0.2), 0.2, 0.1, True)))
+
+    def mirror_tex(sc, tex):
+        m = sc.add_material_mirror((1, 1, 1)); sc.set_material_texture(m, "Kr", tex); return m
+    assert np.array_equal(film(mirror_tex), film(lambda sc, tex: sc.add_material_mirror((0.3, 0.6, 0.2))))
+    assert np.array_equal(film(lambda sc, tex: sc.add_material_matte_tex(tex, 15.0)), film(lambda sc, tex: sc.add_material_matte((0.3, 0.6, 0.2), 15.0)))
+    # a black constant texture removes the lobe exactly as a black constant does
+    def black(material):
+        s = OracleScene()
+        textured_quad_scene(s, host, lambda sc: sc.add_texture_constant((0.0, 0.0, 0.0)), res=24, spp=2, material=material)
+        return s.render_path_ex(max_depth=3)[0]
+    def plastic_kd_black(sc, tex):
+        m = sc.add_material_plastic((1, 1, 1), (0.2, 0.2, 0.2), 0.1, True); sc.set_material_texture(m, "Kd", tex); return m
+    assert np.array_equal(black(plastic_kd_black), black(lambda sc, tex: sc.add_material_plastic((0, 0, 0), (0.2, 0.2, 0.2), 0.1, True)))

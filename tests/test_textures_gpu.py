@@ -124,3 +124,63 @@ def test_filtering_removes_the_moire_and_glibc_mode_is_within_tolerance():
     assert float((np.abs(g - o).max(axis=2) > 1e-2 * mean).mean()) <= 1e-3
     far = g[31:34, 8:56, 1]    # just below the horizon of the tilted view: many checker periods per pixel -> filtered to grey
     assert far.std() < 0.25 * far.mean() and 0.35 < float(far.mean()) < 0.65   # 0/1 texels under a white sky: about one half
+
+
+def _plastic(kd=True, ks=True):
+    def make(sc, tex):
+        m = sc.add_material_plastic((1, 1, 1) if kd else (0.3, 0.2, 0.1), (1, 1, 1) if ks else (0.25, 0.25, 0.25), 0.1, True)
+        if kd: sc.set_material_texture(m, "Kd", tex)
+        if ks: sc.set_material_texture(m, "Ks", sc.add_texture_scale(tex, sc.add_texture_constant((0.5, 0.5, 0.5))))
+        return m
+    return make
+
+
+def _mirror(sc, tex):
+    m = sc.add_material_mirror((1, 1, 1)); sc.set_material_texture(m, "Kr", tex); return m
+
+
+def _substrate(sc, tex):
+    m = sc.add_material_substrate((1, 1, 1), (1, 1, 1), 0.2, 0.1, True)
+    sc.set_material_texture(m, "Kd", tex)
+    sc.set_material_texture(m, "Ks", sc.add_texture_mix(tex, sc.add_texture_constant((0.04, 0.04, 0.04)), sc.add_texture_constant(0.5)))
+    return m
+
+
+MATERIAL_CASES = {
+    "plastic_kd_ks": (_plastic(), _tex()),
+    "plastic_kd_checker_with_black_texels": (_plastic(ks=False), _tex(kind="checker", w=16, h=16)),   # Lambert lobe absent on the black squares
+    "plastic_ks_only": (_plastic(kd=False), _tex(kind="checker", w=8, h=8, trilinear=True)),         # microfacet lobe absent there
+    "mirror_kr": (_mirror, _tex(kind="checker", w=8, h=8)),                                          # no BSDF lobe at all on black squares
+    "substrate": (_substrate, _tex(w=50, h=30)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MATERIAL_CASES))
+def test_textured_general_materials_film_bit_exact(name):
+    material, builder = MATERIAL_CASES[name]
+    prod, orc = _render_pair(builder, material=material, res=48)
+    set_libm_mode(1)
+    try:
+        oxyz, owt, ost, _ = orc.render_path_ex(max_depth=4)
+    finally:
+        set_libm_mode(0)
+    gxyz, gwt, gst = prod.render_path(max_depth=4)
+    assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
+    assert gst.regular_rays == ost.regular_rays and gst.shadow_rays == ost.shadow_rays and gst.paths_zero_radiance == ost.paths_zero_radiance
+    assert float(gxyz.mean()) > 0.0
+
+
+def test_set_material_texture_errors():
+    s = pbrt_hip.Scene()
+    t = s.add_texture_constant((0.5, 0.5, 0.5))
+    glass = s.add_material_glass((1, 1, 1), (1, 1, 1), 0.0, 0.0, 1.5, True)
+    with pytest.raises(pbrt_hip.PbrtHipError, match="no lobe fed by that parameter"):
+        s.set_material_texture(glass, "Kr", t)
+    black = s.add_material_plastic((0, 0, 0), (0.2, 0.2, 0.2), 0.1, True)     # Kd black: the Lambert lobe was never made
+    with pytest.raises(pbrt_hip.PbrtHipError, match="non-black placeholder"):
+        s.set_material_texture(black, "Kd", t)
+    pl = s.add_material_plastic((1, 1, 1), (0.2, 0.2, 0.2), 0.1, True); s.set_material_texture(pl, "Kd", t)
+    with pytest.raises(pbrt_hip.PbrtHipError, match="mix of materials with per-hit textures"):
+        s.add_material_mix(pl, glass, (0.5, 0.5, 0.5))
+    with pytest.raises(pbrt_hip.PbrtHipError):
+        s.set_material_texture(pl, "Kd", 999)

@@ -32,12 +32,13 @@ def probe_points(n, seed):
     return uv, d
 
 
-def textured_quad_scene(scene, host, tex_builder, res=64, spp=4, sigma=0.0, lens_radius=0.0, tilt=True, instance=False, extra=None):
+def textured_quad_scene(scene, host, tex_builder, res=64, spp=4, sigma=0.0, lens_radius=0.0, tilt=True, instance=False, extra=None, material=None):
     """A ground quad with UVs tiled 3 x 3 under a matte material whose Kd is the texture `tex_builder(scene)` returns, seen at a
     grazing angle (strongly anisotropic footprints near the horizon) and lit by a white environment; a small mirror-free matte
-    block above it gives the bounce rays something to shadow.  instance=True places the quad through an ObjectInstance."""
+    block above it gives the bounce rays something to shadow.  instance=True places the quad through an ObjectInstance.
+    material(scene, tex) -> material id replaces the textured matte."""
     tex = tex_builder(scene)
-    mat = scene.add_material_matte_tex(tex, sigma)
+    mat = material(scene, tex) if material is not None else scene.add_material_matte_tex(tex, sigma)
     grey = scene.add_material_matte((0.6, 0.6, 0.6), 0.0)
     P = np.array([[-4, -4, 0], [4, -4, 0], [4, 4, 0], [-4, 4, 0]], np.float32)
     UV = np.array([[0, 0], [3, 0], [3, 3], [0, 3]], np.float32)
