@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=64, help="spp of the bounded CPU-baseline sample (same scene, same resolution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-count", action="store_true")
-    ap.add_argument("--material", default="matte", choices=["matte", "plastic", "glass", "metal", "uber", "mixed"],
+    ap.add_argument("--material", default="matte", choices=["matte", "plastic", "glass", "metal", "uber", "mixed", "textured"],
                     help="material of every triangle; anything but matte runs the general-BSDF shade kernel (not the headline workload)")
     ap.add_argument("--instances", type=int, default=0,
                     help="K > 0: the triangles become one object instanced K times (two-level BVH, TransformedPrimitive path); not the headline workload")

@@ -208,8 +208,9 @@ template <> struct BsdfOps<true> {
 
 #define PH_SHADE_BLOCK 256
 // Waves per SIMD the shade kernels are compiled for.  40 KB of LDS per block allow 4 blocks per CU; the one-lobe kernel fits 128 VGPRs with
-// 51 spilled registers and gains 6 % from the fourth wave, the general-BSDF kernel would spill 181 and loses, so it stays at 3.
-#define PH_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(GEN ? 3 : 4, GEN ? 3 : 4)))
+// 51 spilled registers and gains 6 % from the fourth wave, the general-BSDF kernel would spill 181 and loses, so it stays at 3; so do the
+// texture variants, whose out-of-line calls keep many values live (textured matte: 279 spilled registers at 4 waves, 45 at 3; 19.5 -> 15.9 ms).
+#define PH_SHADE_ATTR __attribute__((amdgpu_waves_per_eu((GEN || TEX) ? 3 : 4, (GEN || TEX) ? 3 : 4)))
 template <bool GEN, bool TEX = false>
 __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(DeviceScene sc, WfParams w, int it) {
     using BO = BsdfOps<GEN>;

@@ -602,6 +602,9 @@ def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None, insta
         mat = scene.add_material_metal((0.2, 0.92, 1.1), (3.9, 2.45, 2.14), 0.05, 0.05, True)
     elif spec.material == "uber":
         mat = scene.add_material_uber(spec.kd, (0.25, 0.25, 0.25), (0.1, 0.1, 0.1), (0.1, 0.1, 0.1), (0.9, 0.9, 0.9), 0.1, 0.1, 1.5, True)
+    elif spec.material == "textured":  # MatteMaterial whose Kd is a 1024 x 1024 image map (EWA, repeat); triangles use the default uv (0,0) (1,0) (1,1)
+        img = np.random.default_rng(spec.seed + 7).uniform(0.1, 0.9, (1024, 1024, 3)).astype(np.float32)
+        mat = scene.add_material_matte_tex(scene.add_texture_imagemap(scene.add_mipmap(img)), spec.sigma)
     elif spec.material == "mixed":
         mat = None
     else:
