@@ -148,13 +148,20 @@ int pbrt_hip_add_instance(PbrtHipScene*, uint32_t object_id, const float instanc
  * `scale * (gamma ? inv_gamma_correct(x) : x)` (as_float: to the texel's luminance, ImageTexture<Float>), resamples to powers of two and
  * builds the pyramid.  filtering: 0 trilinear, 1 EWA.  wrap: 0 repeat, 1 black, 2 clamp.  Image file decoding is the host's job.
  * imagemap uses UVMapping2D (su, sv, du, dv) (core/src/texture/mapping/uv_2d.rs); other mappings are not provided yet.
- * mix: (1 - amount) * tex1 + amount * tex2 with `amount` a float texture.  Trees deeper than 4 live values are refused. */
+ * mix: (1 - amount) * tex1 + amount * tex2 with `amount` a float texture.  Trees that need more than 6 live values are refused. */
 int pbrt_hip_add_mipmap(PbrtHipScene*, int width, int height, const float* rgb, int as_float, float scale, int gamma, int filtering, int wrap,
                         float max_anisotropy, uint32_t* out_mipmap);
 int pbrt_hip_add_texture_constant(PbrtHipScene*, const float value[3], uint32_t* out_texture);
 int pbrt_hip_add_texture_scale(PbrtHipScene*, uint32_t tex1, uint32_t tex2, uint32_t* out_texture);
 int pbrt_hip_add_texture_mix(PbrtHipScene*, uint32_t tex1, uint32_t tex2, uint32_t amount, uint32_t* out_texture);
 int pbrt_hip_add_texture_imagemap(PbrtHipScene*, uint32_t mipmap, float su, float sv, float du, float dv, uint32_t* out_texture);
+/* Procedural 2D textures over the same uv mapping: CheckerboardTexture2D (textures/src/checkerboard_2d.rs; aa_mode 0 "none", 1 "closedform"),
+ * UVTexture (uv.rs), BilerpTexture (bilerp.rs; four constant corner values), DotsTexture (dots.rs; Perlin noise of core/src/texture/common.rs). */
+int pbrt_hip_add_texture_checkerboard(PbrtHipScene*, uint32_t tex1, uint32_t tex2, float su, float sv, float du, float dv, int aa_mode, uint32_t* out_texture);
+int pbrt_hip_add_texture_uv(PbrtHipScene*, float su, float sv, float du, float dv, uint32_t* out_texture);
+int pbrt_hip_add_texture_bilerp(PbrtHipScene*, const float v00[3], const float v01[3], const float v10[3], const float v11[3], float su, float sv, float du, float dv,
+                                uint32_t* out_texture);
+int pbrt_hip_add_texture_dots(PbrtHipScene*, uint32_t inside, uint32_t outside, float su, float sv, float du, float dv, uint32_t* out_texture);
 /* Replaces a colour parameter of an existing material by a texture evaluated at every hit (`self.kd.evaluate(..).clamp_default()` in
  * compute_scattering_functions: materials/src/matte.rs:63, plastic.rs:62-70, mirror.rs:53-55, substrate.rs:60-62), with the ray
  * differentials of camera rays (SurfaceInteraction::compute_differentials) driving the MIPMap filter.  Which lobes a hit gets follows the

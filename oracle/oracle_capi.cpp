@@ -300,6 +300,24 @@ int oracle_add_texture_imagemap(OracleScene* s, uint32_t mipmap, float su, float
     if (!s || mipmap >= s->sc.mipmaps.size()) return -1;
     Texture t; t.kind = TK_IMAGE; t.mip = (int)mipmap; t.su = su; t.sv = sv; t.du = du; t.dv = dv; return push_texture(s, t, out_id);
 }
+int oracle_add_texture_checkerboard(OracleScene* s, uint32_t t1, uint32_t t2, float su, float sv, float du, float dv, int aa_mode, uint32_t* out_id) {
+    if (!s || t1 >= s->sc.textures.size() || t2 >= s->sc.textures.size()) return -1;
+    Texture t; t.kind = TK_CHECKER; t.t1 = (int)t1; t.t2 = (int)t2; t.su = su; t.sv = sv; t.du = du; t.dv = dv; t.aa = aa_mode; return push_texture(s, t, out_id);
+}
+int oracle_add_texture_uv(OracleScene* s, float su, float sv, float du, float dv, uint32_t* out_id) {
+    if (!s) return -1;
+    Texture t; t.kind = TK_UV; t.su = su; t.sv = sv; t.du = du; t.dv = dv; return push_texture(s, t, out_id);
+}
+int oracle_add_texture_bilerp(OracleScene* s, const float v00[3], const float v01[3], const float v10[3], const float v11[3], float su, float sv, float du, float dv,
+                              uint32_t* out_id) {
+    if (!s || !v00 || !v01 || !v10 || !v11) return -1;
+    Texture t; t.kind = TK_BILERP; t.v[0] = spec3(v00); t.v[1] = spec3(v01); t.v[2] = spec3(v10); t.v[3] = spec3(v11); t.su = su; t.sv = sv; t.du = du; t.dv = dv;
+    return push_texture(s, t, out_id);
+}
+int oracle_add_texture_dots(OracleScene* s, uint32_t inside, uint32_t outside, float su, float sv, float du, float dv, uint32_t* out_id) {
+    if (!s || inside >= s->sc.textures.size() || outside >= s->sc.textures.size()) return -1;
+    Texture t; t.kind = TK_DOTS; t.t1 = (int)inside; t.t2 = (int)outside; t.su = su; t.sv = sv; t.du = du; t.dv = dv; return push_texture(s, t, out_id);
+}
 // probes for the pinning tests
 int oracle_texture_eval_batch(OracleScene* s, uint32_t tex, uint64_t n, const float* in /*6 per point: u v dudx dvdx dudy dvdy*/, float* out_rgb) {
     if (!s || tex >= s->sc.textures.size()) return -1;

@@ -207,12 +207,56 @@ struct MipMap {
     }
 };
 
-enum { TK_CONST = 0, TK_SCALE = 1, TK_MIX = 2, TK_IMAGE = 3 };
+// ---- Perlin noise (core/src/texture/common.rs:9-117).  The permutation is Ken Perlin's reference table, duplicated so that indices up to 511 work.
+static const uint8_t NOISE_PERM[512] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148, 247, 120, 234, 75, 0, 26,
+    197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146,
+    158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89,
+    18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207,
+    206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98,
+    108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107,
+    49, 192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66,
+    215, 61, 156, 180,
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148, 247, 120, 234, 75, 0, 26,
+    197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146,
+    158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89,
+    18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207,
+    206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98,
+    108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107,
+    49, 192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66,
+    215, 61, 156, 180};
+inline Float noise_grad(int64_t x, int64_t y, int64_t z, Float dx, Float dy, Float dz) {
+    int h = NOISE_PERM[NOISE_PERM[NOISE_PERM[x] + y] + z] & 15;
+    Float u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+    Float v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+    return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+}
+inline Float noise_weight(Float t) { Float t3 = t * t * t, t4 = t3 * t; return 6.0f * t4 * t - 15.0f * t4 + 10.0f * t3; }
+inline Float noise_3d(Float x, Float y, Float z) {
+    int64_t ix = f2isize(std::floor(x)), iy = f2isize(std::floor(y)), iz = f2isize(std::floor(z));
+    Float dx = x - (Float)ix, dy = y - (Float)iy, dz = z - (Float)iz;
+    ix &= 255; iy &= 255; iz &= 255;
+    Float w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+    Float w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0f, dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+    Float w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0f), w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+    Float w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+    Float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+    auto lerpf = [](Float t, Float a, Float b) { return (1.0f - t) * a + t * b; };
+    Float x00 = lerpf(wx, w000, w100), x10 = lerpf(wx, w010, w110), x01 = lerpf(wx, w001, w101), x11 = lerpf(wx, w011, w111);
+    Float y0 = lerpf(wy, x00, x10), y1 = lerpf(wy, x01, x11);
+    return lerpf(wz, y0, y1);
+}
+inline Float noise_2d(Float x, Float y) { return noise_3d(x, y, 0.5f); }
+inline Float bump_int(Float x) { return std::floor(x / 2.0f) + 2.0f * pmax((x / 2.0f) - std::floor(x / 2.0f) - 0.5f, 0.0f); }  // checkerboard_2d.rs:108-110
+
+enum { TK_CONST = 0, TK_SCALE = 1, TK_MIX = 2, TK_IMAGE = 3, TK_CHECKER = 4, TK_UV = 5, TK_BILERP = 6, TK_DOTS = 7 };
 struct Texture {
     int kind = TK_CONST;
     Spec c;                       // TK_CONST (float textures: three equal channels)
     int t1 = -1, t2 = -1, amount = -1;
-    int mip = -1; Float su = 1, sv = 1, du = 0, dv = 0;  // TK_IMAGE + UVMapping2D
+    int mip = -1; Float su = 1, sv = 1, du = 0, dv = 0;  // TK_IMAGE + UVMapping2D (also the mapping of the 2D procedural textures)
+    int aa = 1;                   // TK_CHECKER: 0 none, 1 closedform
+    Spec v[4];                    // TK_BILERP: v00 v01 v10 v11
 };
 struct TexCtx { V2 uv; Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0; };
 
@@ -229,6 +273,40 @@ inline Spec tex_eval(const std::vector<Texture>& tex, const std::vector<MipMap>&
             V2 dstdx(t.su * c.dudx, t.sv * c.dvdx), dstdy(t.su * c.dudy, t.sv * c.dvdy);
             V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
             return mips[(size_t)t.mip].lookup(st, dstdx, dstdy);
+        }
+        case TK_CHECKER: {  // checkerboard_2d.rs:60-104
+            V2 dstdx(t.su * c.dudx, t.sv * c.dvdx), dstdy(t.su * c.dudy, t.sv * c.dvdy);
+            V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+            Spec a = tex_eval(tex, mips, t.t1, c), b = tex_eval(tex, mips, t.t2, c);
+            auto point = [&]() { return ((int32_t)((uint32_t)f2i32(std::floor(st.x)) + (uint32_t)f2i32(std::floor(st.y))) % 2 == 0) ? a : b; };
+            if (t.aa == 0) return point();
+            Float ds = pmax(pabs(dstdx.x), pabs(dstdy.x)), dt = pmax(pabs(dstdx.y), pabs(dstdy.y));
+            Float s0 = st.x - ds, s1 = st.x + ds, t0 = st.y - dt, t1 = st.y + dt;
+            if (std::floor(s0) == std::floor(s1) && std::floor(t0) == std::floor(t1)) return point();
+            Float sint = (bump_int(s1) - bump_int(s0)) / (2.0f * ds), tint = (bump_int(t1) - bump_int(t0)) / (2.0f * dt);
+            Float area2 = (ds > 1.0f || dt > 1.0f) ? 0.5f : sint + tint - 2.0f * sint * tint;
+            return a * (1.0f - area2) + b * area2;
+        }
+        case TK_UV: {  // uv.rs:33-38
+            V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+            return Spec(st.x - std::floor(st.x), st.y - std::floor(st.y), 0.0f);
+        }
+        case TK_BILERP: {  // bilerp.rs:58-71
+            V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+            Float s00 = (1.0f - st.x) * (1.0f - st.y), s01 = (1.0f - st.x) * st.y, s10 = st.x * (1.0f - st.y), s11 = st.x * st.y;
+            return (t.v[0] * s00) + (t.v[1] * s01) + (t.v[2] * s10) + (t.v[3] * s11);
+        }
+        case TK_DOTS: {  // dots.rs:48-69
+            V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+            Float s_cell = std::floor(st.x + 0.5f), t_cell = std::floor(st.y + 0.5f);
+            if (noise_2d(s_cell + 0.5f, t_cell + 0.5f) > 0.0f) {
+                const Float radius = 0.35f, max_shift = 0.5f - radius;
+                Float s_center = s_cell + max_shift * noise_2d(s_cell + 1.5f, t_cell + 2.8f);
+                Float t_center = t_cell + max_shift * noise_2d(s_cell + 4.5f, t_cell + 9.8f);
+                Float ddx = st.x - s_center, ddy = st.y - t_center;
+                if (ddx * ddx + ddy * ddy < radius * radius) return tex_eval(tex, mips, t.t1, c);
+            }
+            return tex_eval(tex, mips, t.t2, c);
         }
         default: return t.c;
     }

@@ -418,7 +418,7 @@ void resample_weights(size_t old_res, size_t new_res, std::vector<RsWeight>& wt)
 }
 inline size_t wrap_index(size_t i, size_t n, int wrap) { return wrap == 0 ? i % n : (wrap == 2 ? (i > n - 1 ? n - 1 : i) : i); }
 int push_texture(PbrtHipScene* s, PbrtHipScene::TextureHost&& t, uint32_t* out_id) {
-    if (t.stack_need > PH_TEX_STACK) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "texture: scale / mix nesting needs more than 4 live values");
+    if (t.stack_need > PH_TEX_STACK) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "texture: the tree needs more than 6 live values");
     s->textures.push_back(std::move(t));
     if (out_id) *out_id = (uint32_t)s->textures.size() - 1;
     s->uploaded = false;
@@ -536,6 +536,36 @@ int pbrt_hip_add_texture_mix(PbrtHipScene* s, uint32_t t1, uint32_t t2, uint32_t
     t.prog = a.prog; t.prog.insert(t.prog.end(), b.prog.begin(), b.prog.end()); t.prog.insert(t.prog.end(), c.prog.begin(), c.prog.end());
     TexOp op{}; op.op = PH_TOP_MIX; t.prog.push_back(op);
     t.stack_need = std::max(a.stack_need, std::max(1 + b.stack_need, 2 + c.stack_need));
+    return push_texture(s, std::move(t), out_id);
+}
+int pbrt_hip_add_texture_checkerboard(PbrtHipScene* s, uint32_t t1, uint32_t t2, float su, float sv, float du, float dv, int aa_mode, uint32_t* out_id) {
+    if (!s || t1 >= s->textures.size() || t2 >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_checkerboard: unknown texture");
+    PbrtHipScene::TextureHost t; const PbrtHipScene::TextureHost &a = s->textures[t1], &b = s->textures[t2];
+    t.prog = a.prog; t.prog.insert(t.prog.end(), b.prog.begin(), b.prog.end());
+    TexOp op{}; op.op = PH_TOP_CHECKER; op.mip = aa_mode ? 1u : 0u; op.su = su; op.sv = sv; op.du = du; op.dv = dv; t.prog.push_back(op);
+    t.stack_need = std::max(a.stack_need, 1 + b.stack_need);
+    return push_texture(s, std::move(t), out_id);
+}
+int pbrt_hip_add_texture_uv(PbrtHipScene* s, float su, float sv, float du, float dv, uint32_t* out_id) {
+    if (!s) return PBRT_HIP_ERR_INVALID_ARG;
+    PbrtHipScene::TextureHost t; TexOp op{}; op.op = PH_TOP_UV; op.su = su; op.sv = sv; op.du = du; op.dv = dv; t.prog.push_back(op);
+    return push_texture(s, std::move(t), out_id);
+}
+int pbrt_hip_add_texture_bilerp(PbrtHipScene* s, const float v00[3], const float v01[3], const float v10[3], const float v11[3], float su, float sv, float du, float dv,
+                                uint32_t* out_id) {
+    if (!s || !v00 || !v01 || !v10 || !v11) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_bilerp: null argument");
+    PbrtHipScene::TextureHost t;
+    for (const float* v : {v00, v01, v10, v11}) { TexOp c{}; c.op = PH_TOP_CONST; std::memcpy(c.c, v, 12); t.prog.push_back(c); }
+    TexOp op{}; op.op = PH_TOP_BILERP; op.su = su; op.sv = sv; op.du = du; op.dv = dv; t.prog.push_back(op);
+    t.stack_need = 4;
+    return push_texture(s, std::move(t), out_id);
+}
+int pbrt_hip_add_texture_dots(PbrtHipScene* s, uint32_t inside, uint32_t outside, float su, float sv, float du, float dv, uint32_t* out_id) {
+    if (!s || inside >= s->textures.size() || outside >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_dots: unknown texture");
+    PbrtHipScene::TextureHost t; const PbrtHipScene::TextureHost &a = s->textures[inside], &b = s->textures[outside];
+    t.prog = a.prog; t.prog.insert(t.prog.end(), b.prog.begin(), b.prog.end());
+    TexOp op{}; op.op = PH_TOP_DOTS; op.su = su; op.sv = sv; op.du = du; op.dv = dv; t.prog.push_back(op);
+    t.stack_need = std::max(a.stack_need, 1 + b.stack_need);
     return push_texture(s, std::move(t), out_id);
 }
 // Replaces a material's constant colour parameter by a texture evaluated at every hit.  The material must have been created with a non-black

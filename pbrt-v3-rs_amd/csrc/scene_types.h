@@ -93,8 +93,9 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
 // ---- textures (textures/src/*.rs, core/src/mipmap/mod.rs).  A texture is a postfix program over a small value stack: the host
 // flattens the scale / mix tree once (api.hip), the device runs it per hit (texture.h).  Float-valued textures are carried as three equal
 // channels; the one place the reference treats them differently (the final division of MIPMap::ewa) is selected by MipRec::is_float.
-enum { PH_TOP_CONST = 0, PH_TOP_IMAGE = 1, PH_TOP_MUL = 2, PH_TOP_MIX = 3 };
-#define PH_TEX_STACK 4
+enum { PH_TOP_CONST = 0, PH_TOP_IMAGE = 1, PH_TOP_MUL = 2, PH_TOP_MIX = 3, PH_TOP_CHECKER = 4 /* pops tex1, tex2; mip = aa mode */, PH_TOP_UV = 5,
+       PH_TOP_BILERP = 6 /* pops v00 v01 v10 v11 */, PH_TOP_DOTS = 7 /* pops inside, outside */ };
+#define PH_TEX_STACK 6
 struct TexOp {
     uint32_t op;
     uint32_t mip;          // PH_TOP_IMAGE: index into DeviceScene::mipmaps

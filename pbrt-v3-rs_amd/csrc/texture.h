@@ -97,6 +97,47 @@ PH_DEV spec mip_lookup(const DeviceScene& sc, const MipRec& m, f2 st, f2 dst0, f
     return mip_ewa(sc, m, il, st, dst0, dst1) * (1.0f - t) + mip_ewa(sc, m, il + 1u, st, dst0, dst1) * t;
 }
 
+// ---- Perlin noise (core/src/texture/common.rs:9-117); the permutation is Ken Perlin's reference table, twice
+static __device__ const uint8_t kNoisePerm[512] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148, 247, 120, 234, 75, 0, 26,
+    197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146,
+    158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89,
+    18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207,
+    206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98,
+    108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107,
+    49, 192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66,
+    215, 61, 156, 180,
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148, 247, 120, 234, 75, 0, 26,
+    197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146,
+    158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89,
+    18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207,
+    206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98,
+    108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107,
+    49, 192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66,
+    215, 61, 156, 180};
+PH_DEV float noise_grad(long long x, long long y, long long z, float dx, float dy, float dz) {
+    const int h = kNoisePerm[kNoisePerm[kNoisePerm[x] + y] + z] & 15;
+    const float u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+    const float v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+    return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+}
+PH_DEV float noise_weight(float t) { const float t3 = t * t * t, t4 = t3 * t; return 6.0f * t4 * t - 15.0f * t4 + 10.0f * t3; }
+PH_DEV float lerpf(float t, float a, float b) { return (1.0f - t) * a + t * b; }
+PH_DEV float noise_3d(float x, float y, float z) {
+    long long ix = f2ll_sat(floorf(x)), iy = f2ll_sat(floorf(y)), iz = f2ll_sat(floorf(z));
+    const float dx = x - (float)ix, dy = y - (float)iy, dz = z - (float)iz;
+    ix &= 255; iy &= 255; iz &= 255;
+    const float w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+    const float w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0f, dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+    const float w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0f), w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+    const float w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+    const float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+    const float x00 = lerpf(wx, w000, w100), x10 = lerpf(wx, w010, w110), x01 = lerpf(wx, w001, w101), x11 = lerpf(wx, w011, w111);
+    return lerpf(wz, lerpf(wy, x00, x10), lerpf(wy, x01, x11));
+}
+PH_DEV float noise_2d(float x, float y) { return noise_3d(x, y, 0.5f); }
+PH_DEV float bump_int(float x) { return floorf(ph_div(x, 2.0f)) + 2.0f * pmaxf(ph_div(x, 2.0f) - floorf(ph_div(x, 2.0f)) - 0.5f, 0.0f); }  // checkerboard_2d.rs:108-110
+
 // Runs texture `id`'s postfix program.  Kept out of line: the shade kernels call it only for materials that carry a texture.
 // `dsc` = DeviceScene::self (the by-value kernel argument must not have its address taken: it would be copied to scratch).
 static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id, TexCtx c) {
@@ -115,6 +156,52 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
             break;
         }
         case PH_TOP_MUL: { sp--; st[sp - 1] = st[sp - 1] * st[sp]; break; }                          // scale.rs:33
+        case PH_TOP_CHECKER: {  // checkerboard_2d.rs:60-104; stack = tex1, tex2 (both are evaluated: they have no side effects)
+            sp--;
+            const spec a = st[sp - 1], b = st[sp];
+            const f2 dstdx = mk2(op.su * c.dudx, op.sv * c.dvdx), dstdy = mk2(op.su * c.dudy, op.sv * c.dvdy);
+            const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+            const bool even = (int)((uint32_t)f2i_sat(floorf(p.x)) + (uint32_t)f2i_sat(floorf(p.y))) % 2 == 0;
+            spec r = even ? a : b;
+            if (op.mip != 0u) {
+                const float ds = pmaxf(pabs(dstdx.x), pabs(dstdy.x)), dt = pmaxf(pabs(dstdx.y), pabs(dstdy.y));
+                const float s0 = p.x - ds, s1 = p.x + ds, t0 = p.y - dt, t1 = p.y + dt;
+                if (!(floorf(s0) == floorf(s1) && floorf(t0) == floorf(t1))) {
+                    const float sint = ph_div(bump_int(s1) - bump_int(s0), 2.0f * ds), tint = ph_div(bump_int(t1) - bump_int(t0), 2.0f * dt);
+                    const float area2 = (ds > 1.0f || dt > 1.0f) ? 0.5f : sint + tint - 2.0f * sint * tint;
+                    r = a * (1.0f - area2) + b * area2;
+                }
+            }
+            st[sp - 1] = r;
+            break;
+        }
+        case PH_TOP_UV: {  // uv.rs:33-38
+            const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+            st[sp++] = mks(p.x - floorf(p.x), p.y - floorf(p.y), 0.0f);
+            break;
+        }
+        case PH_TOP_BILERP: {  // bilerp.rs:58-71; stack = v00, v01, v10, v11
+            sp -= 3;
+            const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+            const float s00 = (1.0f - p.x) * (1.0f - p.y), s01 = (1.0f - p.x) * p.y, s10 = p.x * (1.0f - p.y), s11 = p.x * p.y;
+            st[sp - 1] = (st[sp - 1] * s00) + (st[sp] * s01) + (st[sp + 1] * s10) + (st[sp + 2] * s11);
+            break;
+        }
+        case PH_TOP_DOTS: {  // dots.rs:48-69; stack = inside, outside
+            sp--;
+            const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+            const float s_cell = floorf(p.x + 0.5f), t_cell = floorf(p.y + 0.5f);
+            bool inside = false;
+            if (noise_2d(s_cell + 0.5f, t_cell + 0.5f) > 0.0f) {
+                const float radius = 0.35f, max_shift = 0.5f - radius;
+                const float s_center = s_cell + max_shift * noise_2d(s_cell + 1.5f, t_cell + 2.8f);
+                const float t_center = t_cell + max_shift * noise_2d(s_cell + 4.5f, t_cell + 9.8f);
+                const float ddx = p.x - s_center, ddy = p.y - t_center;
+                inside = ddx * ddx + ddy * ddy < radius * radius;
+            }
+            st[sp - 1] = inside ? st[sp - 1] : st[sp];
+            break;
+        }
         default: {  // PH_TOP_MIX: (1 - amt) * t1 + amt * t2 (mix.rs:36-41); stack = t1, t2, amount
             sp -= 2;
             const float amt = st[sp + 1].r;

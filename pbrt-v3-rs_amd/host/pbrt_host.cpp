@@ -260,7 +260,48 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
         else if (ok) { const uint32_t amt = operand("amount", true, {0.5f, 0.5f, 0.5f}); if (ok) ok = check(ABI(pbrt_hip_add_texture_mix(scene_, t1, t2, amt, &id)), "add_texture_mix"); }
         if (ok) { forget(); gs_.device_textures[name] = GraphicsState::DeviceTexture{is_float, id}; return; }
     }
-    if (tex_class != "constant") {  // bilerp / checkerboard / dots / fbm / marble / uv / windy / wrinkled / ptex: not evaluated by the library yet
+    if (tex_class == "checkerboard" || tex_class == "uv" || tex_class == "bilerp" || tex_class == "dots") {  // 2D procedural textures (textures/src/*.rs)
+        const std::string mapping = p.find_one_string("mapping", "uv");
+        if (mapping != "uv") { forget(); gs_.unsupported_textures[name] = tex_class + " with mapping '" + mapping + "'"; return; }
+        if (tex_class == "checkerboard" && p.find_one_int("dimension", 2) != 2) { forget(); gs_.unsupported_textures[name] = "checkerboard with dimension 3"; return; }
+        if (tex_class == "uv" && is_float) { warn("Unable to create float texture 'uv'."); return; }   // textures/src/lib.rs: only a spectrum variant exists
+        const float su = p.find_one_float("uscale", 1.0f), sv = p.find_one_float("vscale", 1.0f), du = p.find_one_float("udelta", 0.0f), dv = p.find_one_float("vdelta", 0.0f);
+        bool ok = true;
+        auto operand = [&](const char* pn, float dflt) -> uint32_t {  // a texture reference of this texture's own type, or a constant
+            std::array<float, 3> v = {dflt, dflt, dflt};
+            const std::string tn = p.find_one_texture(pn);
+            if (!tn.empty()) {
+                auto dt = gs_.device_textures.find(tn);
+                if (dt != gs_.device_textures.end() && dt->second.is_float == is_float) return dt->second.id;
+                bool found = false;
+                if (is_float) { auto f = gs_.float_textures.find(tn); if (f != gs_.float_textures.end()) { v = {f->second, f->second, f->second}; found = true; } }
+                else { auto sp = gs_.spectrum_textures.find(tn); if (sp != gs_.spectrum_textures.end()) { v = sp->second; found = true; } }
+                if (!found) { ok = false; if (error.empty()) error = "Texture \"" + name + "\": operand '" + tn + "' is not a texture the library evaluates"; return 0u; }
+            } else if (is_float) { const float f = p.find_one_float(pn, dflt); v = {f, f, f}; }
+            else v = p.find_one_rgb(pn, v);
+            uint32_t id = 0;
+            if (!check(ABI(pbrt_hip_add_texture_constant(scene_, v.data(), &id)), "add_texture_constant")) ok = false;
+            return id;
+        };
+        uint32_t id = 0;
+        if (tex_class == "checkerboard") {
+            const uint32_t t1 = operand("tex1", 1.0f), t2 = operand("tex2", 0.0f);
+            std::string aa = p.find_one_string("aamode", "closedform");
+            if (aa != "none" && aa != "closedform") { warn("Antialiasing mode '" + aa + "' not understood by Checkerboard2DTexture; using 'closedform'"); aa = "closedform"; }
+            if (ok) ok = check(ABI(pbrt_hip_add_texture_checkerboard(scene_, t1, t2, su, sv, du, dv, aa == "none" ? 0 : 1, &id)), "add_texture_checkerboard");
+        } else if (tex_class == "dots") {
+            const uint32_t in = operand("inside", 1.0f), out = operand("outside", 0.0f);
+            if (ok) ok = check(ABI(pbrt_hip_add_texture_dots(scene_, in, out, su, sv, du, dv, &id)), "add_texture_dots");
+        } else if (tex_class == "uv") ok = check(ABI(pbrt_hip_add_texture_uv(scene_, su, sv, du, dv, &id)), "add_texture_uv");
+        else {
+            auto corner = [&](const char* pn, float d) { std::array<float, 3> v = {d, d, d}; if (is_float) { const float f = p.find_one_float(pn, d); v = {f, f, f}; } else v = p.find_one_rgb(pn, v); return v; };
+            const std::array<float, 3> v00 = corner("v00", 0.0f), v01 = corner("v01", 1.0f), v10 = corner("v10", 0.0f), v11 = corner("v11", 1.0f);
+            ok = check(ABI(pbrt_hip_add_texture_bilerp(scene_, v00.data(), v01.data(), v10.data(), v11.data(), su, sv, du, dv, &id)), "add_texture_bilerp");
+        }
+        if (ok) { forget(); gs_.device_textures[name] = GraphicsState::DeviceTexture{is_float, id}; }
+        return;
+    }
+    if (tex_class != "constant") {  // fbm / marble / windy / wrinkled / 3D checkerboard / ptex: not evaluated by the library yet
         forget();
         gs_.unsupported_textures[name] = tex_class;
         return;

@@ -118,6 +118,10 @@ class Binding:
             "add_texture_scale": (C.c_int, [vp, C.c_uint32, C.c_uint32, u32p]),
             "add_texture_mix": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
             "add_texture_imagemap": (C.c_int, [vp, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
+            "add_texture_checkerboard": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, u32p]),
+            "add_texture_uv": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
+            "add_texture_bilerp": (C.c_int, [vp, fp, fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
+            "add_texture_dots": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
             "add_material_matte_tex": (C.c_int, [vp, C.c_uint32, C.c_float, u32p]),
             "set_material_texture": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32]),
             "texture_eval_batch": (C.c_int, [vp, C.c_uint32, C.c_uint64, fp, fp]),
@@ -480,6 +484,24 @@ class Scene:
     def add_texture_imagemap(self, mipmap, su=1.0, sv=1.0, du=0.0, dv=0.0):
         out = C.c_uint32(0)
         self._chk(self.b.fn("add_texture_imagemap")(self.h, mipmap, C.c_float(su), C.c_float(sv), C.c_float(du), C.c_float(dv), C.byref(out))); return out.value
+
+    def add_texture_checkerboard(self, t1, t2, su=1.0, sv=1.0, du=0.0, dv=0.0, aa="closedform"):
+        out = C.c_uint32(0)
+        self._chk(self.b.fn("add_texture_checkerboard")(self.h, t1, t2, C.c_float(su), C.c_float(sv), C.c_float(du), C.c_float(dv), 0 if aa == "none" else 1, C.byref(out)))
+        return out.value
+
+    def add_texture_uv(self, su=1.0, sv=1.0, du=0.0, dv=0.0):
+        out = C.c_uint32(0); self._chk(self.b.fn("add_texture_uv")(self.h, C.c_float(su), C.c_float(sv), C.c_float(du), C.c_float(dv), C.byref(out))); return out.value
+
+    def add_texture_bilerp(self, v00, v01, v10, v11, su=1.0, sv=1.0, du=0.0, dv=0.0):
+        vs = [np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32), (3,)), dtype=np.float32) for v in (v00, v01, v10, v11)]
+        out = C.c_uint32(0)
+        self._chk(self.b.fn("add_texture_bilerp")(self.h, *[_ptr(v, C.c_float) for v in vs], C.c_float(su), C.c_float(sv), C.c_float(du), C.c_float(dv), C.byref(out)))
+        return out.value
+
+    def add_texture_dots(self, inside, outside, su=1.0, sv=1.0, du=0.0, dv=0.0):
+        out = C.c_uint32(0)
+        self._chk(self.b.fn("add_texture_dots")(self.h, inside, outside, C.c_float(su), C.c_float(sv), C.c_float(du), C.c_float(dv), C.byref(out))); return out.value
 
     def add_material_matte_tex(self, kd_texture, sigma=0.0):
         out = C.c_uint32(0); self._chk(self.b.fn("add_material_matte_tex")(self.h, kd_texture, C.c_float(sigma), C.byref(out))); return out.value

@@ -349,6 +349,10 @@ NamedMaterial "glossy"
 Shape "trianglemesh" "integer indices" [0 1 2] "point P" [1 1 0.01  3 1 0.01  2 2.5 1.5] "float uv" [0 0 1 0 0.5 1]
 Material "mirror" "texture Kr" "wood"
 Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-1 -1 0.01  1 -1 0.01  0 0 1.2]
+Texture "checks" "color" "checkerboard" "float uscale" 6 "float vscale" 6 "texture tex1" "wood" "rgb tex2" [0.1 0.1 0.1]
+Texture "spots" "color" "dots" "float uscale" 3 "float vscale" 3 "texture inside" "checks" "rgb outside" [0.7 0.2 0.2]
+Material "matte" "texture Kd" "spots"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 -4 0.005  -2 -4 0.005  -2 -2 0.005  -4 -2 0.005] "float uv" [0 0 1 0 1 1 0 1]
 WorldEnd
 """
     (tmp_path / "tex.pbrt").write_text(text)
@@ -373,6 +377,10 @@ WorldEnd
         s.add_mesh(np.array([[1, 1, 0.01], [3, 1, 0.01], [2, 2.5, 1.5]], np.float32), [0, 1, 2], sb_, UV=tri_uv)
         mi = s.add_material_mirror((1, 1, 1)); s.set_material_texture(mi, "Kr", wood)
         s.add_mesh(np.array([[-1, -1, 0.01], [1, -1, 0.01], [0, 0, 1.2]], np.float32), [0, 1, 2], mi)
+        checks = s.add_texture_checkerboard(wood, s.add_texture_constant((0.1, 0.1, 0.1)), su=6.0, sv=6.0)
+        spots = s.add_texture_dots(checks, s.add_texture_constant((0.7, 0.2, 0.2)), su=3.0, sv=3.0)
+        s.add_mesh(np.array([[-4, -4, 0.005], [-2, -4, 0.005], [-2, -2, 0.005], [-4, -2, 0.005]], np.float32), [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(spots, 0.0),
+                   UV=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32))
         w2c, c2w = host.look_at((0, -6, 1.5), (0, 0, 0.5), (0, 0, 1))
         s.set_camera_perspective(host.perspective_raster_to_camera(40.0, res, res), c2w)
         cb, table, sb = host.film_box(res, res)

@@ -198,3 +198,54 @@ def test_a_constant_texture_is_the_constant_parameter():
     def plastic_kd_black(sc, tex):
         m = sc.add_material_plastic((1, 1, 1), (0.2, 0.2, 0.2), 0.1, True); sc.set_material_texture(m, "Kd", tex); return m
     assert np.array_equal(black(plastic_kd_black), black(lambda sc, tex: sc.add_material_plastic((0, 0, 0), (0.2, 0.2, 0.2), 0.1, True)))
+
+
+def test_procedural_2d_textures_closed_forms():
+    s = OracleScene()
+    a = s.add_texture_constant((1.0, 0.5, 0.25)); b = s.add_texture_constant((0.0, 0.2, 0.4))
+    # checkerboard, point sampled: (floor(s) + floor(t)) % 2 == 0 -> tex1; Rust's % keeps the sign, so (-1 + 0) % 2 = -1 selects tex2
+    ck = s.add_texture_checkerboard(a, b, su=4.0, sv=4.0, aa="none")
+    uv = np.array([[0.1, 0.1], [0.3, 0.1], [0.3, 0.3], [-0.1, 0.1], [-0.1, -0.1], [-0.3, 0.1]], np.float32)
+    got = s.texture_eval(ck, uv)
+    want = [(1.0, 0.5, 0.25), (0.0, 0.2, 0.4), (1.0, 0.5, 0.25), (0.0, 0.2, 0.4), (1.0, 0.5, 0.25), (1.0, 0.5, 0.25)]
+    assert np.array_equal(got, np.array(want, np.float32))
+    # closed form: a filter much wider than a check (ds > 1) averages to one half; one inside a check is the point sample
+    cf = s.add_texture_checkerboard(a, b, su=4.0, sv=4.0)
+    wide = s.texture_eval(cf, [[0.37, 0.41]], [[0.6, 0, 0, 0.6]])[0]            # ds = dt = 2.4 > 1
+    assert np.allclose(wide, 0.5 * (np.array(want[0]) + np.array(want[1])), rtol=1e-6)
+    assert np.array_equal(s.texture_eval(cf, [[0.1, 0.1]], [[0.001, 0, 0, 0.001]])[0], np.array(want[0], np.float32))
+    # box filter centred on a vertical check edge (s = 1), well inside the row: exactly half of each
+    edge = s.texture_eval(cf, [[0.25, 0.125]], [[0.05, 0, 0, 0.01]])[0]         # st = (1.0, 0.5), ds = 0.2, dt = 0.04
+    assert np.allclose(edge, 0.5 * (np.array(want[0]) + np.array(want[1])), atol=2e-6)
+    # uv texture and bilerp
+    uvt = s.add_texture_uv(su=2.0, sv=3.0, du=0.25, dv=0.5)
+    g = s.texture_eval(uvt, [[0.7, 0.9]])[0]
+    st = (np.float32(2.0) * np.float32(0.7) + np.float32(0.25), np.float32(3.0) * np.float32(0.9) + np.float32(0.5))
+    assert np.array_equal(g, np.array([st[0] - np.floor(st[0]), st[1] - np.floor(st[1]), 0.0], np.float32))
+    bl = s.add_texture_bilerp((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1))
+    assert np.array_equal(s.texture_eval(bl, [[0, 0], [0, 1], [1, 0], [1, 1]]), np.array([(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)], np.float32))
+    assert np.allclose(s.texture_eval(bl, [[0.5, 0.5]])[0], (0.5, 0.5, 0.5))
+
+
+def test_noise_table_and_dots():
+    """The permutation behind DotsTexture must be the reference's (compared with its text when the tree is present); Perlin noise vanishes
+    on the integer lattice and is bounded; dots: every value is one of the two operands and both occur."""
+    import os, re
+    here = os.path.dirname(os.path.abspath(__file__))
+    mine = open(os.path.join(here, "..", "oracle", "oracle_texture.hpp")).read()
+    tab = [int(x) for x in re.findall(r"\d+", mine[mine.index("NOISE_PERM[512] = {"):].split("};")[0].split("{", 1)[1])]
+    assert len(tab) == 512 and tab[:256] == tab[256:] and sorted(tab[:256]) == list(range(256))
+    dev = open(os.path.join(here, "..", "pbrt-v3-rs_amd", "csrc", "texture.h")).read()
+    dtab = [int(x) for x in re.findall(r"\d+", dev[dev.index("kNoisePerm[512] = {"):].split("};")[0].split("{", 1)[1])]
+    assert dtab == tab
+    ref = "/root/reference/core/src/texture/common.rs"
+    if os.path.exists(ref):
+        txt = open(ref).read()
+        rtab = [int(x) for x in re.findall(r"\d+", txt[txt.index("NOISE_PERM: [usize; 2 * NOISE_PERM_SIZE] = ["):].split("];")[0].split("= [", 1)[1])]
+        assert rtab == tab
+    s = OracleScene()
+    a = s.add_texture_constant((1.0, 1.0, 1.0)); b = s.add_texture_constant((0.0, 0.0, 0.0))
+    dots = s.add_texture_dots(a, b, su=10.0, sv=10.0)
+    rng = np.random.default_rng(3)
+    v = s.texture_eval(dots, rng.uniform(0, 1, (4000, 2)).astype(np.float32))[:, 0]
+    assert set(np.unique(v)) == {0.0, 1.0} and 0.05 < v.mean() < 0.5

@@ -184,3 +184,40 @@ def test_set_material_texture_errors():
         s.add_material_mix(pl, glass, (0.5, 0.5, 0.5))
     with pytest.raises(pbrt_hip.PbrtHipError):
         s.set_material_texture(pl, "Kd", 999)
+
+
+def test_procedural_2d_lookups_bit_exact():
+    uv, d = probe_points(4000, 8)
+    uv = (uv * np.float32(3.0)).astype(np.float32)
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    outs = []
+    for sc in (prod, orc):
+        img = sc.add_texture_imagemap(sc.add_mipmap(make_image(16, 16, seed=6)))
+        k = sc.add_texture_constant((0.2, 0.4, 0.6))
+        texs = [sc.add_texture_checkerboard(img, k, su=3.0, sv=2.0, du=0.1, dv=0.2),
+                sc.add_texture_checkerboard(k, img, su=5.0, sv=5.0, aa="none"),
+                sc.add_texture_uv(su=1.5, sv=2.5, du=-0.3, dv=0.7),
+                sc.add_texture_bilerp((1, 0, 0), (0.2, 1, 0), (0, 0.3, 1), (1, 1, 0.5), su=0.5, sv=0.5),
+                sc.add_texture_dots(img, k, su=7.0, sv=7.0)]
+        texs.append(sc.add_texture_mix(texs[0], texs[4], sc.add_texture_bilerp(0.0, 1.0, 0.25, 0.75)))
+        if sc is orc: set_libm_mode(1)
+        try:
+            outs.append([sc.texture_eval(t, uv, d) for t in texs])
+        finally:
+            set_libm_mode(0)
+    for a, b in zip(*outs):
+        assert _bits_equal(a, b)
+
+
+def test_checkerboard_and_dots_scene_film_bit_exact():
+    def builder(sc):
+        a = sc.add_texture_constant((0.8, 0.7, 0.1)); b = sc.add_texture_imagemap(sc.add_mipmap(make_image(32, 32, seed=2)))
+        return sc.add_texture_dots(sc.add_texture_uv(su=4.0, sv=4.0), sc.add_texture_checkerboard(a, b, su=6.0, sv=6.0), su=5.0, sv=5.0)
+    prod, orc = _render_pair(builder, res=48)
+    set_libm_mode(1)
+    try:
+        oxyz, owt, _, _ = orc.render_path_ex(max_depth=3)
+    finally:
+        set_libm_mode(0)
+    gxyz, gwt, _ = prod.render_path(max_depth=3)
+    assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
