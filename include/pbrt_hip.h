@@ -162,6 +162,15 @@ int pbrt_hip_add_texture_uv(PbrtHipScene*, float su, float sv, float du, float d
 int pbrt_hip_add_texture_bilerp(PbrtHipScene*, const float v00[3], const float v01[3], const float v10[3], const float v11[3], float su, float sv, float du, float dv,
                                 uint32_t* out_texture);
 int pbrt_hip_add_texture_dots(PbrtHipScene*, uint32_t inside, uint32_t outside, float su, float sv, float du, float dv, uint32_t* out_texture);
+/* 3D procedural textures over IdentityMapping3D (core/src/texture/mapping/identity_3d.rs): `m` is the row-major 4x4 matrix the mapping applies to the
+ * hit point and to dp/dx, dp/dy — the reference hands it the Texture directive's CTM (tex2world, textures/src/fbm.rs:65), so pass that.
+ * FBmTexture, WrinkledTexture (fbm.rs, wrinkled.rs; omega = "roughness", octaves), WindyTexture (windy.rs), MarbleTexture (marble.rs; scale, variation),
+ * CheckerboardTexture3D (checkerboard_3d.rs).  fbm / wrinkled / windy are float-valued (three equal channels). */
+int pbrt_hip_add_texture_fbm(PbrtHipScene*, const float m[16], float omega, int octaves, uint32_t* out_texture);
+int pbrt_hip_add_texture_wrinkled(PbrtHipScene*, const float m[16], float omega, int octaves, uint32_t* out_texture);
+int pbrt_hip_add_texture_windy(PbrtHipScene*, const float m[16], uint32_t* out_texture);
+int pbrt_hip_add_texture_marble(PbrtHipScene*, const float m[16], float omega, int octaves, float scale, float variation, uint32_t* out_texture);
+int pbrt_hip_add_texture_checkerboard3d(PbrtHipScene*, uint32_t tex1, uint32_t tex2, const float m[16], uint32_t* out_texture);
 /* Replaces a colour parameter of an existing material by a texture evaluated at every hit (`self.kd.evaluate(..).clamp_default()` in
  * compute_scattering_functions: materials/src/matte.rs:63, plastic.rs:62-70, mirror.rs:53-55, substrate.rs:60-62), with the ray
  * differentials of camera rays (SurfaceInteraction::compute_differentials) driving the MIPMap filter.  Which lobes a hit gets follows the
@@ -172,8 +181,8 @@ enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2 };
 int pbrt_hip_set_material_texture(PbrtHipScene*, uint32_t material, int param, uint32_t texture);
 /* = add_material_matte((1,1,1), sigma) + set_material_texture(KD) */
 int pbrt_hip_add_material_matte_tex(PbrtHipScene*, uint32_t kd_texture, float sigma_degrees, uint32_t* out_material);
-/* Test aids: evaluate a texture on the device at explicit (u, v, du/dx, dv/dx, du/dy, dv/dy) tuples; read back the pyramid the host built. */
-int pbrt_hip_texture_eval_batch(PbrtHipScene*, uint32_t texture, uint64_t n, const float* uv_and_derivatives /*6 per point*/, float* out_rgb /*3 per point*/);
+/* Test aids: evaluate a texture on the device at explicit contexts (u, v, du/dx, dv/dx, du/dy, dv/dy, p[3], dp/dx[3], dp/dy[3]); read back the pyramid the host built. */
+int pbrt_hip_texture_eval_batch(PbrtHipScene*, uint32_t texture, uint64_t n, const float* contexts /*15 per point*/, float* out_rgb /*3 per point*/);
 int pbrt_hip_mipmap_levels(PbrtHipScene*, uint32_t mipmap, int* out_levels, int* out_width_height /*2 per level, <= 16 levels*/);
 int pbrt_hip_mipmap_level_texels(PbrtHipScene*, uint32_t mipmap, int level, float* out_rgb);
 

@@ -319,10 +319,27 @@ int oracle_add_texture_dots(OracleScene* s, uint32_t inside, uint32_t outside, f
     Texture t; t.kind = TK_DOTS; t.t1 = (int)inside; t.t2 = (int)outside; t.su = su; t.sv = sv; t.du = du; t.dv = dv; return push_texture(s, t, out_id);
 }
 // probes for the pinning tests
-int oracle_texture_eval_batch(OracleScene* s, uint32_t tex, uint64_t n, const float* in /*6 per point: u v dudx dvdx dudy dvdy*/, float* out_rgb) {
+static int push_texture3d(OracleScene* s, int kind, const float m[16], float omega, int octaves, float scale, float variation, uint32_t t1, uint32_t t2, uint32_t* out_id) {
+    if (!s || !m) return -1;
+    Texture t; t.kind = kind; t.w2t = m4_from(m); t.omega = omega; t.octaves = octaves; t.scale = scale; t.variation = variation; t.t1 = (int)t1; t.t2 = (int)t2;
+    return push_texture(s, t, out_id);
+}
+int oracle_add_texture_fbm(OracleScene* s, const float m[16], float omega, int octaves, uint32_t* out_id) { return push_texture3d(s, TK_FBM, m, omega, octaves, 1, 0, 0, 0, out_id); }
+int oracle_add_texture_wrinkled(OracleScene* s, const float m[16], float omega, int octaves, uint32_t* out_id) { return push_texture3d(s, TK_WRINKLED, m, omega, octaves, 1, 0, 0, 0, out_id); }
+int oracle_add_texture_windy(OracleScene* s, const float m[16], uint32_t* out_id) { return push_texture3d(s, TK_WINDY, m, 0.5f, 0, 1, 0, 0, 0, out_id); }
+int oracle_add_texture_marble(OracleScene* s, const float m[16], float omega, int octaves, float scale, float variation, uint32_t* out_id) {
+    return push_texture3d(s, TK_MARBLE, m, omega, octaves, scale, variation, 0, 0, out_id);
+}
+int oracle_add_texture_checkerboard3d(OracleScene* s, uint32_t t1, uint32_t t2, const float m[16], uint32_t* out_id) {
+    if (!s || t1 >= s->sc.textures.size() || t2 >= s->sc.textures.size()) return -1;
+    return push_texture3d(s, TK_CHECKER3D, m, 0, 0, 1, 0, t1, t2, out_id);
+}
+int oracle_texture_eval_batch(OracleScene* s, uint32_t tex, uint64_t n, const float* in /*15 per point: u v dudx dvdx dudy dvdy p[3] dpdx[3] dpdy[3]*/, float* out_rgb) {
     if (!s || tex >= s->sc.textures.size()) return -1;
     for (uint64_t i = 0; i < n; i++) {
-        TexCtx c; c.uv = V2(in[6 * i], in[6 * i + 1]); c.dudx = in[6 * i + 2]; c.dvdx = in[6 * i + 3]; c.dudy = in[6 * i + 4]; c.dvdy = in[6 * i + 5];
+        const float* q = in + 15 * i;
+        TexCtx c; c.uv = V2(q[0], q[1]); c.dudx = q[2]; c.dvdx = q[3]; c.dudy = q[4]; c.dvdy = q[5];
+        c.p = V3(q[6], q[7], q[8]); c.dpdx = V3(q[9], q[10], q[11]); c.dpdy = V3(q[12], q[13], q[14]);
         Spec v = tex_eval(s->sc.textures, s->sc.mipmaps, (int)tex, c);
         out_rgb[3 * i] = v.c[0]; out_rgb[3 * i + 1] = v.c[1]; out_rgb[3 * i + 2] = v.c[2];
     }

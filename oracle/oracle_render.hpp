@@ -321,6 +321,7 @@ struct SurfaceHit {  // the fields of Hit/SurfaceInteraction/Shading the path in
     uint32_t prim;
     V2 uv; V3 dpdu, dpdv;   // SurfaceInteraction.uv, der.dpdu / der.dpdv (geometric)
     Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;  // der, filled by compute_differentials
+    V3 dpdx, dpdy;
 };
 
 // Ray::offset_origin (core/src/geometry/ray.rs:107-127)
@@ -919,7 +920,7 @@ struct Renderer {
         BSDF b; b.ns = si.ns; b.ng = si.n; b.ss = normalize(si.dpdu_s); b.ts = cross(b.ns, b.ss);  // bsdf.rs:100-116
         b.lobes = m.lobes.data(); b.n = (int)m.lobes.size(); b.eta = m.bsdf_eta;
         if (m.textured) {  // compute_scattering_functions evaluates the textures at this hit (matte.rs:63-71, plastic.rs:62-81, mirror.rs:53-57, substrate.rs:60-80)
-            TexCtx c; c.uv = si.uv; c.dudx = si.dudx; c.dvdx = si.dvdx; c.dudy = si.dudy; c.dvdy = si.dvdy;
+            TexCtx c; c.uv = si.uv; c.dudx = si.dudx; c.dvdx = si.dvdx; c.dudy = si.dudy; c.dvdy = si.dvdy; c.p = si.p; c.dpdx = si.dpdx; c.dpdy = si.dpdy;
             int k = 0;
             for (const Lobe& tl : m.lobes) {
                 Lobe l = tl;
@@ -1168,7 +1169,7 @@ struct Renderer {
     }
     // SurfaceInteraction::compute_differentials (surface_interaction.rs:203-278)
     static void compute_differentials(SurfaceHit& si, const Ray& ray) {
-        si.dudx = si.dvdx = si.dudy = si.dvdy = 0.0f;
+        si.dudx = si.dvdx = si.dudy = si.dvdy = 0.0f; si.dpdx = V3(0, 0, 0); si.dpdy = V3(0, 0, 0);
         if (!ray.has_diff) return;
         V3 n = si.n, p = si.p;
         Float d = dot(n, p);
@@ -1178,6 +1179,7 @@ struct Renderer {
         Float ty = -(dot(n, ray.ry_o) - d) / dot(n, ray.ry_d);
         if (std::isinf(ty) || ty != ty) return;
         V3 py = ray.ry_o + ty * ray.ry_d;
+        si.dpdx = px - p; si.dpdy = py - p;
         int dim[2];
         if (std::fabs(n.x) > std::fabs(n.y) && std::fabs(n.x) > std::fabs(n.z)) { dim[0] = 1; dim[1] = 2; }
         else if (std::fabs(n.y) > std::fabs(n.z)) { dim[0] = 0; dim[1] = 2; }

@@ -249,7 +249,43 @@ inline Float noise_3d(Float x, Float y, Float z) {
 inline Float noise_2d(Float x, Float y) { return noise_3d(x, y, 0.5f); }
 inline Float bump_int(Float x) { return std::floor(x / 2.0f) + 2.0f * pmax((x / 2.0f) - std::floor(x / 2.0f) - 0.5f, 0.0f); }  // checkerboard_2d.rs:108-110
 
-enum { TK_CONST = 0, TK_SCALE = 1, TK_MIX = 2, TK_IMAGE = 3, TK_CHECKER = 4, TK_UV = 5, TK_BILERP = 6, TK_DOTS = 7 };
+// ---- fbm / turbulence (core/src/texture/common.rs:119-214) over IdentityMapping3D (mapping/identity_3d.rs)
+inline Float smooth_step(Float mn, Float mx, Float value) { Float v = pclamp((value - mn) / (mx - mn), 0.0f, 1.0f); return v * v * (-2.0f * v + 3.0f); }
+inline Float fbm(V3 p, V3 dpdx, V3 dpdy, Float omega, int max_octaves) {
+    Float len2 = pmax(length_squared(dpdx), length_squared(dpdy));
+    Float n = pclamp(-1.0f - 0.5f * o_log2(len2), 0.0f, (Float)max_octaves);
+    size_t n_int = f2usize(std::floor(n));
+    Float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (size_t i = 0; i < n_int; i++) { sum += o * noise_3d(lambda * p.x, lambda * p.y, lambda * p.z); lambda *= 1.99f; o *= omega; }
+    Float n_partial = n - (Float)n_int;
+    sum += o * smooth_step(0.3f, 0.7f, n_partial) * noise_3d(lambda * p.x, lambda * p.y, lambda * p.z);
+    return sum;
+}
+inline Float turbulence(V3 p, V3 dpdx, V3 dpdy, Float omega, int max_octaves) {
+    Float len2 = pmax(length_squared(dpdx), length_squared(dpdy));
+    Float n = pclamp(-1.0f - 0.5f * o_log2(len2), 0.0f, (Float)max_octaves);
+    size_t n_int = f2usize(std::floor(n));
+    Float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (size_t i = 0; i < n_int; i++) { sum += o * pabs(noise_3d(lambda * p.x, lambda * p.y, lambda * p.z)); lambda *= 1.99f; o *= omega; }
+    Float n_partial = n - (Float)n_int;
+    Float ss = smooth_step(0.3f, 0.7f, n_partial);
+    sum += o * ((1.0f - ss) * 0.2f + ss * pabs(noise_3d(lambda * p.x, lambda * p.y, lambda * p.z)));  // lerp(ss, 0.2, |noise|)
+    for (size_t i = n_int; i < (size_t)max_octaves; i++) { sum += o * 0.2f; o *= omega; }
+    return sum;
+}
+inline V3 m4_point(const M4& m, V3 p) {  // Transform::transform_point (transform.rs:288-302)
+    Float x = m.m[0][0] * p.x + m.m[0][1] * p.y + m.m[0][2] * p.z + m.m[0][3], y = m.m[1][0] * p.x + m.m[1][1] * p.y + m.m[1][2] * p.z + m.m[1][3];
+    Float z = m.m[2][0] * p.x + m.m[2][1] * p.y + m.m[2][2] * p.z + m.m[2][3], w = m.m[3][0] * p.x + m.m[3][1] * p.y + m.m[3][2] * p.z + m.m[3][3];
+    return w == 1.0f ? V3(x, y, z) : V3(x, y, z) / w;
+}
+inline V3 m4_vector(const M4& m, V3 v) {  // transform_vector (:373-380)
+    return V3(m.m[0][0] * v.x + m.m[0][1] * v.y + m.m[0][2] * v.z, m.m[1][0] * v.x + m.m[1][1] * v.y + m.m[1][2] * v.z, m.m[2][0] * v.x + m.m[2][1] * v.y + m.m[2][2] * v.z);
+}
+static const Float MARBLE_C[9][3] = {{0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.5f, 0.5f, 0.5f}, {0.6f, 0.59f, 0.58f},
+                                     {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.2f, 0.2f, 0.33f}, {0.58f, 0.58f, 0.6f}};  // marble.rs:104-114
+
+enum { TK_CONST = 0, TK_SCALE = 1, TK_MIX = 2, TK_IMAGE = 3, TK_CHECKER = 4, TK_UV = 5, TK_BILERP = 6, TK_DOTS = 7, TK_FBM = 8, TK_WRINKLED = 9, TK_WINDY = 10,
+       TK_MARBLE = 11, TK_CHECKER3D = 12 };
 struct Texture {
     int kind = TK_CONST;
     Spec c;                       // TK_CONST (float textures: three equal channels)
@@ -257,8 +293,10 @@ struct Texture {
     int mip = -1; Float su = 1, sv = 1, du = 0, dv = 0;  // TK_IMAGE + UVMapping2D (also the mapping of the 2D procedural textures)
     int aa = 1;                   // TK_CHECKER: 0 none, 1 closedform
     Spec v[4];                    // TK_BILERP: v00 v01 v10 v11
+    M4 w2t = M4::identity();      // 3D textures: IdentityMapping3D's matrix (the reference hands it tex2world, fbm.rs:65 — kept)
+    Float omega = 0.5f, scale = 1.0f, variation = 0.2f; int octaves = 8;
 };
-struct TexCtx { V2 uv; Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0; };
+struct TexCtx { V2 uv; Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0; V3 p, dpdx, dpdy; };
 
 inline Spec tex_eval(const std::vector<Texture>& tex, const std::vector<MipMap>& mips, int id, const TexCtx& c) {
     const Texture& t = tex[(size_t)id];
@@ -307,6 +345,30 @@ inline Spec tex_eval(const std::vector<Texture>& tex, const std::vector<MipMap>&
                 if (ddx * ddx + ddy * ddy < radius * radius) return tex_eval(tex, mips, t.t1, c);
             }
             return tex_eval(tex, mips, t.t2, c);
+        }
+        case TK_FBM: case TK_WRINKLED: case TK_WINDY: case TK_MARBLE: case TK_CHECKER3D: {
+            V3 dpdx = m4_vector(t.w2t, c.dpdx), dpdy = m4_vector(t.w2t, c.dpdy), p = m4_point(t.w2t, c.p);
+            if (t.kind == TK_FBM) return Spec(fbm(p, dpdx, dpdy, t.omega, t.octaves));                    // fbm.rs:45-50
+            if (t.kind == TK_WRINKLED) return Spec(turbulence(p, dpdx, dpdy, t.omega, t.octaves));        // wrinkled.rs:45-50
+            if (t.kind == TK_WINDY) {                                                                      // windy.rs:36-44
+                Float wind = fbm(0.1f * p, 0.1f * dpdx, 0.1f * dpdy, 0.5f, 3), wave = fbm(p, dpdx, dpdy, 0.5f, 6);
+                return Spec(pabs(wind) * wave);
+            }
+            if (t.kind == TK_CHECKER3D) {                                                                  // checkerboard_3d.rs:44-53
+                Spec a = tex_eval(tex, mips, t.t1, c), b = tex_eval(tex, mips, t.t2, c);
+                uint32_t sum = (uint32_t)f2i32(std::floor(p.x)) + (uint32_t)f2i32(std::floor(p.y)) + (uint32_t)f2i32(std::floor(p.z));
+                return ((int32_t)sum % 2 == 0) ? a : b;
+            }
+            p = p * t.scale;                                                                               // marble.rs:54-85
+            Float marble = p.y + t.variation * fbm(p, t.scale * dpdx, t.scale * dpdy, t.omega, t.octaves);
+            Float tt = 0.5f + 0.5f * o_sin(marble);
+            size_t first = pmin<size_t>(1, f2usize(std::floor(tt * 6.0f)));   // `min(1, ..)` as in the reference (and in C++ pbrt)
+            tt = tt * 6.0f - (Float)first;
+            Spec c0(MARBLE_C[first][0], MARBLE_C[first][1], MARBLE_C[first][2]), c1(MARBLE_C[first + 1][0], MARBLE_C[first + 1][1], MARBLE_C[first + 1][2]);
+            Spec c2(MARBLE_C[first + 2][0], MARBLE_C[first + 2][1], MARBLE_C[first + 2][2]), c3(MARBLE_C[first + 3][0], MARBLE_C[first + 3][1], MARBLE_C[first + 3][2]);
+            Spec s0 = (1.0f - tt) * c0 + tt * c1, s1 = (1.0f - tt) * c1 + tt * c2, s2 = (1.0f - tt) * c2 + tt * c3;
+            s0 = (1.0f - tt) * s0 + tt * s1; s1 = (1.0f - tt) * s1 + tt * s2;
+            return 1.5f * ((1.0f - tt) * s0 + tt * s1);
         }
         default: return t.c;
     }

@@ -568,6 +568,29 @@ int pbrt_hip_add_texture_dots(PbrtHipScene* s, uint32_t inside, uint32_t outside
     t.stack_need = std::max(a.stack_need, 1 + b.stack_need);
     return push_texture(s, std::move(t), out_id);
 }
+namespace {
+int push_texture3d(PbrtHipScene* s, uint32_t opc, const float m[16], float omega, int octaves, float scale, float variation, const char* what, uint32_t* out_id,
+                   const PbrtHipScene::TextureHost* a = nullptr, const PbrtHipScene::TextureHost* b = nullptr) {
+    if (!s || !m) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, std::string(what) + ": null argument");
+    if (octaves < 0 || octaves > 64) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, std::string(what) + ": octaves must be within 0..64");
+    PbrtHipScene::TextureHost t;
+    if (a) { t.prog = a->prog; t.prog.insert(t.prog.end(), b->prog.begin(), b->prog.end()); t.stack_need = std::max(a->stack_need, 1 + b->stack_need); }
+    TexOp op{}; op.op = opc; op.octaves = (uint32_t)octaves; op.omega = omega; op.scale = scale; op.variation = variation; std::memcpy(op.m, m, 64);
+    t.prog.push_back(op);
+    return push_texture(s, std::move(t), out_id);
+}
+}  // namespace
+int pbrt_hip_add_texture_fbm(PbrtHipScene* s, const float m[16], float omega, int octaves, uint32_t* out_id) { return push_texture3d(s, PH_TOP_FBM, m, omega, octaves, 1.0f, 0.0f, "add_texture_fbm", out_id); }
+int pbrt_hip_add_texture_wrinkled(PbrtHipScene* s, const float m[16], float omega, int octaves, uint32_t* out_id) { return push_texture3d(s, PH_TOP_WRINKLED, m, omega, octaves, 1.0f, 0.0f, "add_texture_wrinkled", out_id); }
+int pbrt_hip_add_texture_windy(PbrtHipScene* s, const float m[16], uint32_t* out_id) { return push_texture3d(s, PH_TOP_WINDY, m, 0.5f, 0, 1.0f, 0.0f, "add_texture_windy", out_id); }
+int pbrt_hip_add_texture_marble(PbrtHipScene* s, const float m[16], float omega, int octaves, float scale, float variation, uint32_t* out_id) {
+    return push_texture3d(s, PH_TOP_MARBLE, m, omega, octaves, scale, variation, "add_texture_marble", out_id);
+}
+int pbrt_hip_add_texture_checkerboard3d(PbrtHipScene* s, uint32_t t1, uint32_t t2, const float m[16], uint32_t* out_id) {
+    if (!s || t1 >= s->textures.size() || t2 >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_checkerboard3d: unknown texture");
+    const PbrtHipScene::TextureHost a = s->textures[t1], b = s->textures[t2];
+    return push_texture3d(s, PH_TOP_CHECKER3D, m, 0.0f, 0, 1.0f, 0.0f, "add_texture_checkerboard3d", out_id, &a, &b);
+}
 // Replaces a material's constant colour parameter by a texture evaluated at every hit.  The material must have been created with a non-black
 // constant for that parameter (so that its lobe exists); which lobes a hit finally gets follows the reference's `is_black` tests on the
 // texture's value at that hit.
@@ -601,7 +624,9 @@ namespace ph {
 __global__ void texture_eval_kernel(DeviceScene sc, uint32_t tex, uint32_t n, const float* in, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    TexCtx c; c.uv = mk2(in[6 * i], in[6 * i + 1]); c.dudx = in[6 * i + 2]; c.dvdx = in[6 * i + 3]; c.dudy = in[6 * i + 4]; c.dvdy = in[6 * i + 5];
+    const float* q = in + 15 * (size_t)i;
+    TexCtx c; c.uv = mk2(q[0], q[1]); c.dudx = q[2]; c.dvdx = q[3]; c.dudy = q[4]; c.dvdy = q[5];
+    c.p = mk3(q[6], q[7], q[8]); c.dpdx = mk3(q[9], q[10], q[11]); c.dpdy = mk3(q[12], q[13], q[14]);
     const spec v = tex_eval(sc.self, tex, c);
     out[3 * i] = v.r; out[3 * i + 1] = v.g; out[3 * i + 2] = v.b;
 }
@@ -615,9 +640,9 @@ int pbrt_hip_texture_eval_batch(PbrtHipScene* s, uint32_t tex, uint64_t n, const
     // textures do not need the accelerator: upload what exists (an empty BVH is fine)
     int rc;
     if ((rc = upload_scene(s))) return rc;
-    if ((rc = ensure_buf(s, s->d_rays_tmp, n * 24))) return rc;
+    if ((rc = ensure_buf(s, s->d_rays_tmp, n * 60))) return rc;
     if ((rc = ensure_buf(s, s->d_out_tmp, n * 12))) return rc;
-    PH_CHECK(s, hipMemcpyAsync(s->d_rays_tmp.p, uv_and_derivatives, n * 24, hipMemcpyHostToDevice, s->stream));
+    PH_CHECK(s, hipMemcpyAsync(s->d_rays_tmp.p, uv_and_derivatives, n * 60, hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(ph::texture_eval_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s->stream, s->ds, tex, (uint32_t)n, (const float*)s->d_rays_tmp.p, (float*)s->d_out_tmp.p);
     PH_CHECK(s, hipGetLastError());
     PH_CHECK(s, hipMemcpyAsync(out_rgb, s->d_out_tmp.p, n * 12, hipMemcpyDeviceToHost, s->stream));

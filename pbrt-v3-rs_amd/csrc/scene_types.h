@@ -94,14 +94,17 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
 // flattens the scale / mix tree once (api.hip), the device runs it per hit (texture.h).  Float-valued textures are carried as three equal
 // channels; the one place the reference treats them differently (the final division of MIPMap::ewa) is selected by MipRec::is_float.
 enum { PH_TOP_CONST = 0, PH_TOP_IMAGE = 1, PH_TOP_MUL = 2, PH_TOP_MIX = 3, PH_TOP_CHECKER = 4 /* pops tex1, tex2; mip = aa mode */, PH_TOP_UV = 5,
-       PH_TOP_BILERP = 6 /* pops v00 v01 v10 v11 */, PH_TOP_DOTS = 7 /* pops inside, outside */ };
+       PH_TOP_BILERP = 6 /* pops v00 v01 v10 v11 */, PH_TOP_DOTS = 7 /* pops inside, outside */, PH_TOP_FBM = 8, PH_TOP_WRINKLED = 9, PH_TOP_WINDY = 10, PH_TOP_MARBLE = 11,
+       PH_TOP_CHECKER3D = 12 /* pops tex1, tex2 */ };
 #define PH_TEX_STACK 6
 struct TexOp {
     uint32_t op;
     uint32_t mip;          // PH_TOP_IMAGE: index into DeviceScene::mipmaps
     float c[3];            // PH_TOP_CONST
-    float su, sv, du, dv;  // PH_TOP_IMAGE: UVMapping2D (texture/mapping/uv_2d.rs)
-    uint32_t pad[3];
+    float su, sv, du, dv;  // 2D textures: UVMapping2D (texture/mapping/uv_2d.rs)
+    uint32_t octaves;      // fbm / wrinkled / marble
+    float omega, scale, variation;
+    float m[16];           // 3D textures: IdentityMapping3D's matrix (texture/mapping/identity_3d.rs)
 };
 struct TexRec { uint32_t first_op, n_ops; };  // DeviceScene::tex_ops[first_op .. first_op + n_ops)
 struct Texel { float r, g, b, pad; };  // one 16-byte load per texel

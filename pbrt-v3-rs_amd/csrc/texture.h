@@ -9,7 +9,7 @@
 
 namespace ph {
 
-struct TexCtx { f2 uv; float dudx, dvdx, dudy, dvdy; };
+struct TexCtx { f2 uv; float dudx, dvdx, dudy, dvdy; f3 p, dpdx, dpdy; };
 
 PH_DEV float d_log2(float x) { return (float)log2((double)x); }
 PH_DEV long long f2ll_sat(float f) {  // `as isize`
@@ -138,6 +138,33 @@ PH_DEV float noise_3d(float x, float y, float z) {
 PH_DEV float noise_2d(float x, float y) { return noise_3d(x, y, 0.5f); }
 PH_DEV float bump_int(float x) { return floorf(ph_div(x, 2.0f)) + 2.0f * pmaxf(ph_div(x, 2.0f) - floorf(ph_div(x, 2.0f)) - 0.5f, 0.0f); }  // checkerboard_2d.rs:108-110
 
+// ---- fbm / turbulence (core/src/texture/common.rs:119-214)
+PH_DEV float smooth_step(float mn, float mx, float value) { const float v = pclampf(ph_div(value - mn, mx - mn), 0.0f, 1.0f); return v * v * (-2.0f * v + 3.0f); }
+PH_DEV float tex_fbm(f3 p, f3 dpdx, f3 dpdy, float omega, uint32_t max_octaves, bool turbulence) {
+    const float len2 = pmaxf(length_squared(dpdx), length_squared(dpdy));
+    const float n = pclampf(-1.0f - 0.5f * d_log2(len2), 0.0f, (float)max_octaves);
+    const uint32_t n_int = f2u_sat(floorf(n));
+    float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (uint32_t i = 0; i < n_int; i++) {
+        const float nz = noise_3d(lambda * p.x, lambda * p.y, lambda * p.z);
+        sum += o * (turbulence ? pabs(nz) : nz);
+        lambda *= 1.99f; o *= omega;
+    }
+    const float n_partial = n - (float)n_int;
+    const float ss = smooth_step(0.3f, 0.7f, n_partial), nz = noise_3d(lambda * p.x, lambda * p.y, lambda * p.z);
+    if (!turbulence) return sum + o * ss * nz;
+    sum += o * ((1.0f - ss) * 0.2f + ss * pabs(nz));
+    for (uint32_t i = n_int; i < max_octaves; i++) { sum += o * 0.2f; o *= omega; }
+    return sum;
+}
+static __device__ const float kMarbleC[9][3] = {{0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.5f, 0.5f, 0.5f}, {0.6f, 0.59f, 0.58f},
+                                                {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.2f, 0.2f, 0.33f}, {0.58f, 0.58f, 0.6f}};  // marble.rs:104-114
+PH_DEV f3 xf_point16(const float* m, f3 p) {  // Transform::transform_point (transform.rs:288-302)
+    const float x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    const float z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11], w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    return (w == 1.0f) ? mk3(x, y, z) : mk3(x, y, z) / w;
+}
+
 // Runs texture `id`'s postfix program.  Kept out of line: the shade kernels call it only for materials that carry a texture.
 // `dsc` = DeviceScene::self (the by-value kernel argument must not have its address taken: it would be copied to scratch).
 static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id, TexCtx c) {
@@ -185,6 +212,34 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
             const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
             const float s00 = (1.0f - p.x) * (1.0f - p.y), s01 = (1.0f - p.x) * p.y, s10 = p.x * (1.0f - p.y), s11 = p.x * p.y;
             st[sp - 1] = (st[sp - 1] * s00) + (st[sp] * s01) + (st[sp + 1] * s10) + (st[sp + 2] * s11);
+            break;
+        }
+        case PH_TOP_FBM: case PH_TOP_WRINKLED: case PH_TOP_WINDY: case PH_TOP_MARBLE: case PH_TOP_CHECKER3D: {  // IdentityMapping3D::map (identity_3d.rs)
+            const f3 dpdx = xf_vec(op.m, c.dpdx), dpdy = xf_vec(op.m, c.dpdy);
+            f3 p = xf_point16(op.m, c.p);
+            if (op.op == PH_TOP_FBM) st[sp++] = mks1(tex_fbm(p, dpdx, dpdy, op.omega, op.octaves, false));            // fbm.rs:45-50
+            else if (op.op == PH_TOP_WRINKLED) st[sp++] = mks1(tex_fbm(p, dpdx, dpdy, op.omega, op.octaves, true));   // wrinkled.rs:45-50
+            else if (op.op == PH_TOP_WINDY) {                                                                          // windy.rs:36-44
+                const float wind = tex_fbm(0.1f * p, 0.1f * dpdx, 0.1f * dpdy, 0.5f, 3u, false), wave = tex_fbm(p, dpdx, dpdy, 0.5f, 6u, false);
+                st[sp++] = mks1(pabs(wind) * wave);
+            } else if (op.op == PH_TOP_CHECKER3D) {                                                                    // checkerboard_3d.rs:44-53
+                sp--;
+                const uint32_t sum = (uint32_t)f2i_sat(floorf(p.x)) + (uint32_t)f2i_sat(floorf(p.y)) + (uint32_t)f2i_sat(floorf(p.z));
+                st[sp - 1] = ((int)sum % 2 == 0) ? st[sp - 1] : st[sp];
+            } else {                                                                                                   // marble.rs:54-85
+                p = p * op.scale;
+                const float marble = p.y + op.variation * tex_fbm(p, op.scale * dpdx, op.scale * dpdy, op.omega, op.octaves, false);
+                float tt = 0.5f + 0.5f * d_sin(marble);
+                uint32_t first = f2u_sat(floorf(tt * 6.0f));
+                if (first > 1u) first = 1u;   // `min(1, ..)`, as in the reference
+                tt = tt * 6.0f - (float)first;
+                const spec c0 = mks(kMarbleC[first][0], kMarbleC[first][1], kMarbleC[first][2]), c1 = mks(kMarbleC[first + 1][0], kMarbleC[first + 1][1], kMarbleC[first + 1][2]);
+                const spec c2 = mks(kMarbleC[first + 2][0], kMarbleC[first + 2][1], kMarbleC[first + 2][2]), c3 = mks(kMarbleC[first + 3][0], kMarbleC[first + 3][1], kMarbleC[first + 3][2]);
+                spec s0 = (1.0f - tt) * c0 + tt * c1, s1 = (1.0f - tt) * c1 + tt * c2;
+                const spec s2 = (1.0f - tt) * c2 + tt * c3;
+                s0 = (1.0f - tt) * s0 + tt * s1; s1 = (1.0f - tt) * s1 + tt * s2;
+                st[sp++] = 1.5f * ((1.0f - tt) * s0 + tt * s1);
+            }
             break;
         }
         case PH_TOP_DOTS: {  // dots.rs:48-69; stack = inside, outside
@@ -253,6 +308,7 @@ PH_DEV float comp3(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 // `dpdu`, `dpdv`: SurfaceInteraction.der (geometric); returns der.du/dv d x/y (zeros where the reference leaves zeros)
 PH_DEV void compute_differentials(f3 p, f3 n, f3 dpdu, f3 dpdv, const RayDiff& rd, TexCtx& c) {
     c.dudx = c.dvdx = c.dudy = c.dvdy = 0.0f;
+    c.dpdx = mk3(0.0f, 0.0f, 0.0f); c.dpdy = c.dpdx;
     const float d = dot(n, p);
     const float tx = ph_div(-(dot(n, rd.rx_o) - d), dot(n, rd.rx_d));
     if (__builtin_isinf(tx) || tx != tx) return;
@@ -260,6 +316,7 @@ PH_DEV void compute_differentials(f3 p, f3 n, f3 dpdu, f3 dpdv, const RayDiff& r
     const float ty = ph_div(-(dot(n, rd.ry_o) - d), dot(n, rd.ry_d));
     if (__builtin_isinf(ty) || ty != ty) return;
     const f3 py = rd.ry_o + ty * rd.ry_d;
+    c.dpdx = px - p; c.dpdy = py - p;
     int d0, d1;
     if (pabs(n.x) > pabs(n.y) && pabs(n.x) > pabs(n.z)) { d0 = 1; d1 = 2; }
     else if (pabs(n.y) > pabs(n.z)) { d0 = 0; d1 = 2; }
@@ -304,6 +361,7 @@ static __device__ __noinline__ TexCtx hit_tex_ctx(const DeviceScene* dsc, const 
     TexCtx ctx;
     ctx.uv = mk2((bary.x * uv0.x + bary.y * uv1.x) + bary.z * uv2.x, (bary.x * uv0.y + bary.y * uv1.y) + bary.z * uv2.y);
     ctx.dudx = ctx.dvdx = ctx.dudy = ctx.dvdy = 0.0f;
+    ctx.p = p; ctx.dpdx = mk3(0.0f, 0.0f, 0.0f); ctx.dpdy = ctx.dpdx;
     if (camera_ray) {
         const CameraRec cm = *cam;
         const RayDiff rdf = camera_ray_differentials(cm, p_film, lens, ro, rd, spp);

@@ -260,10 +260,13 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
         else if (ok) { const uint32_t amt = operand("amount", true, {0.5f, 0.5f, 0.5f}); if (ok) ok = check(ABI(pbrt_hip_add_texture_mix(scene_, t1, t2, amt, &id)), "add_texture_mix"); }
         if (ok) { forget(); gs_.device_textures[name] = GraphicsState::DeviceTexture{is_float, id}; return; }
     }
-    if (tex_class == "checkerboard" || tex_class == "uv" || tex_class == "bilerp" || tex_class == "dots") {  // 2D procedural textures (textures/src/*.rs)
+    if ((tex_class == "checkerboard" && p.find_one_int("dimension", 2) != 3) || tex_class == "uv" || tex_class == "bilerp" || tex_class == "dots") {  // 2D procedural textures (textures/src/*.rs)
         const std::string mapping = p.find_one_string("mapping", "uv");
         if (mapping != "uv") { forget(); gs_.unsupported_textures[name] = tex_class + " with mapping '" + mapping + "'"; return; }
-        if (tex_class == "checkerboard" && p.find_one_int("dimension", 2) != 2) { forget(); gs_.unsupported_textures[name] = "checkerboard with dimension 3"; return; }
+        if (tex_class == "checkerboard" && p.find_one_int("dimension", 2) != 2 && p.find_one_int("dimension", 2) != 3) {
+            if (error.empty()) error = "Texture \"" + name + "\": " + std::to_string(p.find_one_int("dimension", 2)) + " dimensional checkerboard texture not supported";
+            return;
+        }
         if (tex_class == "uv" && is_float) { warn("Unable to create float texture 'uv'."); return; }   // textures/src/lib.rs: only a spectrum variant exists
         const float su = p.find_one_float("uscale", 1.0f), sv = p.find_one_float("vscale", 1.0f), du = p.find_one_float("udelta", 0.0f), dv = p.find_one_float("vdelta", 0.0f);
         bool ok = true;
@@ -301,7 +304,40 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
         if (ok) { forget(); gs_.device_textures[name] = GraphicsState::DeviceTexture{is_float, id}; }
         return;
     }
-    if (tex_class != "constant") {  // fbm / marble / windy / wrinkled / 3D checkerboard / ptex: not evaluated by the library yet
+    const bool checker3d = tex_class == "checkerboard" && p.find_one_int("dimension", 2) == 3;
+    if (tex_class == "fbm" || tex_class == "wrinkled" || tex_class == "windy" || tex_class == "marble" || checker3d) {  // 3D procedural textures over IdentityMapping3D
+        // the reference builds IdentityMapping3D from tex2world = the CTM at the Texture directive (textures/src/fbm.rs:63-65) and applies it as is
+        if (tex_class == "marble" && is_float) { warn("Unable to create float texture 'marble'."); return; }
+        const float omega = p.find_one_float("roughness", 0.5f); const int octaves = p.find_one_int("octaves", 8);
+        uint32_t id = 0; bool ok = true;
+        if (tex_class == "fbm") ok = check(ABI(pbrt_hip_add_texture_fbm(scene_, ctm_.m, omega, octaves, &id)), "add_texture_fbm");
+        else if (tex_class == "wrinkled") ok = check(ABI(pbrt_hip_add_texture_wrinkled(scene_, ctm_.m, omega, octaves, &id)), "add_texture_wrinkled");
+        else if (tex_class == "windy") ok = check(ABI(pbrt_hip_add_texture_windy(scene_, ctm_.m, &id)), "add_texture_windy");
+        else if (tex_class == "marble") ok = check(ABI(pbrt_hip_add_texture_marble(scene_, ctm_.m, omega, octaves, p.find_one_float("scale", 1.0f), p.find_one_float("variation", 0.2f), &id)), "add_texture_marble");
+        else {
+            auto operand = [&](const char* pn, float dflt) -> uint32_t {
+                std::array<float, 3> v = {dflt, dflt, dflt};
+                const std::string tn = p.find_one_texture(pn);
+                if (!tn.empty()) {
+                    auto dt = gs_.device_textures.find(tn);
+                    if (dt != gs_.device_textures.end() && dt->second.is_float == is_float) return dt->second.id;
+                    bool found = false;
+                    if (is_float) { auto f = gs_.float_textures.find(tn); if (f != gs_.float_textures.end()) { v = {f->second, f->second, f->second}; found = true; } }
+                    else { auto sp = gs_.spectrum_textures.find(tn); if (sp != gs_.spectrum_textures.end()) { v = sp->second; found = true; } }
+                    if (!found) { ok = false; if (error.empty()) error = "Texture \"" + name + "\": operand '" + tn + "' is not a texture the library evaluates"; return 0u; }
+                } else if (is_float) { const float f = p.find_one_float(pn, dflt); v = {f, f, f}; }
+                else v = p.find_one_rgb(pn, v);
+                uint32_t cid = 0;
+                if (!check(ABI(pbrt_hip_add_texture_constant(scene_, v.data(), &cid)), "add_texture_constant")) ok = false;
+                return cid;
+            };
+            const uint32_t t1 = operand("tex1", 1.0f), t2 = operand("tex2", 0.0f);
+            if (ok) ok = check(ABI(pbrt_hip_add_texture_checkerboard3d(scene_, t1, t2, ctm_.m, &id)), "add_texture_checkerboard3d");
+        }
+        if (ok) { forget(); gs_.device_textures[name] = GraphicsState::DeviceTexture{is_float, id}; }
+        return;
+    }
+    if (tex_class != "constant") {  // ptex: not evaluated by the library
         forget();
         gs_.unsupported_textures[name] = tex_class;
         return;

@@ -122,6 +122,11 @@ class Binding:
             "add_texture_uv": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
             "add_texture_bilerp": (C.c_int, [vp, fp, fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
             "add_texture_dots": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
+            "add_texture_fbm": (C.c_int, [vp, fp, C.c_float, C.c_int, u32p]),
+            "add_texture_wrinkled": (C.c_int, [vp, fp, C.c_float, C.c_int, u32p]),
+            "add_texture_windy": (C.c_int, [vp, fp, u32p]),
+            "add_texture_marble": (C.c_int, [vp, fp, C.c_float, C.c_int, C.c_float, C.c_float, u32p]),
+            "add_texture_checkerboard3d": (C.c_int, [vp, C.c_uint32, C.c_uint32, fp, u32p]),
             "add_material_matte_tex": (C.c_int, [vp, C.c_uint32, C.c_float, u32p]),
             "set_material_texture": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32]),
             "texture_eval_batch": (C.c_int, [vp, C.c_uint32, C.c_uint64, fp, fp]),
@@ -503,6 +508,20 @@ class Scene:
         out = C.c_uint32(0)
         self._chk(self.b.fn("add_texture_dots")(self.h, inside, outside, C.c_float(su), C.c_float(sv), C.c_float(du), C.c_float(dv), C.byref(out))); return out.value
 
+    def add_texture_fbm(self, m=IDENTITY, omega=0.5, octaves=8, wrinkled=False):
+        out = C.c_uint32(0)
+        self._chk(self.b.fn("add_texture_wrinkled" if wrinkled else "add_texture_fbm")(self.h, _ptr(_f32(m), C.c_float), C.c_float(omega), octaves, C.byref(out))); return out.value
+
+    def add_texture_windy(self, m=IDENTITY):
+        out = C.c_uint32(0); self._chk(self.b.fn("add_texture_windy")(self.h, _ptr(_f32(m), C.c_float), C.byref(out))); return out.value
+
+    def add_texture_marble(self, m=IDENTITY, omega=0.5, octaves=8, scale=1.0, variation=0.2):
+        out = C.c_uint32(0)
+        self._chk(self.b.fn("add_texture_marble")(self.h, _ptr(_f32(m), C.c_float), C.c_float(omega), octaves, C.c_float(scale), C.c_float(variation), C.byref(out))); return out.value
+
+    def add_texture_checkerboard3d(self, t1, t2, m=IDENTITY):
+        out = C.c_uint32(0); self._chk(self.b.fn("add_texture_checkerboard3d")(self.h, t1, t2, _ptr(_f32(m), C.c_float), C.byref(out))); return out.value
+
     def add_material_matte_tex(self, kd_texture, sigma=0.0):
         out = C.c_uint32(0); self._chk(self.b.fn("add_material_matte_tex")(self.h, kd_texture, C.c_float(sigma), C.byref(out))); return out.value
 
@@ -512,11 +531,14 @@ class Scene:
         """param: "Kd" | "Ks" | "Kr" — that colour of `material` becomes `texture`, evaluated per hit."""
         self._chk(self.b.fn("set_material_texture")(self.h, material, self.PARAM[param], texture))
 
-    def texture_eval(self, texture, uv, derivs=None):
-        """Evaluates `texture` at uv (n,2) with (du/dx, dv/dx, du/dy, dv/dy) (n,4); returns (n,3).  A probe for the parity tests."""
+    def texture_eval(self, texture, uv, derivs=None, p=None, dpdx=None, dpdy=None):
+        """Evaluates `texture` at uv (n,2) with (du/dx, dv/dx, du/dy, dv/dy) (n,4) and, for the 3D textures, the hit point p (n,3) with dp/dx, dp/dy;
+        returns (n,3).  A probe for the parity tests."""
         uv = np.asarray(uv, np.float32).reshape(-1, 2)
+        z3 = np.zeros((len(uv), 3), np.float32)
         d = np.zeros((len(uv), 4), np.float32) if derivs is None else np.asarray(derivs, np.float32).reshape(-1, 4)
-        inp = np.ascontiguousarray(np.concatenate([uv, d], axis=1), dtype=np.float32)
+        cols = [uv, d] + [z3 if a is None else np.asarray(a, np.float32).reshape(-1, 3) for a in (p, dpdx, dpdy)]
+        inp = np.ascontiguousarray(np.concatenate(cols, axis=1), dtype=np.float32)
         out = np.zeros((len(uv), 3), np.float32)
         self._chk(self.b.fn("texture_eval_batch")(self.h, texture, len(uv), _ptr(inp, C.c_float), _ptr(out, C.c_float)))
         return out

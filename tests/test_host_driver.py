@@ -56,8 +56,8 @@ def test_check_mode_crop_and_outfile(tmp_path):
     ('Integrator "bdpt"\nWorldBegin\nWorldEnd\n', 'Integrator "bdpt"'),
     ('Sampler "random"\nWorldBegin\nWorldEnd\n', 'Sampler "random"'),
     ('WorldBegin\nLightSource "infinite" "string mapname" "sky.exr"\nWorldEnd\n', "mapname"),
-    ('WorldBegin\nTexture "c" "color" "marble"\nMaterial "matte" "texture Kd" "c"\n'
-     'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "marble"),
+    ('WorldBegin\nTexture "c" "color" "ptex"\nMaterial "matte" "texture Kd" "c"\n'
+     'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "ptex"),
     ('WorldBegin\nLightSource "point" "blackbody I" [6500 1]\nWorldEnd\n', "spectral type"),
     ('Frobnicate 1 2 3\n', "unknown directive"),
     ('Translate 1 2\nWorldBegin\n', "expected a number"),

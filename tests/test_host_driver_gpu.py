@@ -353,6 +353,14 @@ Texture "checks" "color" "checkerboard" "float uscale" 6 "float vscale" 6 "textu
 Texture "spots" "color" "dots" "float uscale" 3 "float vscale" 3 "texture inside" "checks" "rgb outside" [0.7 0.2 0.2]
 Material "matte" "texture Kd" "spots"
 Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 -4 0.005  -2 -4 0.005  -2 -2 0.005  -4 -2 0.005] "float uv" [0 0 1 0 1 1 0 1]
+TransformBegin
+  Scale 2 2 2
+  Rotate 20 0 0 1
+  Texture "stone" "color" "marble" "float scale" 2 "float variation" 0.3 "integer octaves" 6
+  Texture "cells" "color" "checkerboard" "integer dimension" 3 "texture tex1" "stone" "rgb tex2" [0.05 0.3 0.05]
+TransformEnd
+Material "matte" "texture Kd" "cells"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [2 -4 0.005  4 -4 0.005  4 -2 0.005  2 -2 0.005]
 WorldEnd
 """
     (tmp_path / "tex.pbrt").write_text(text)
@@ -381,6 +389,11 @@ WorldEnd
         spots = s.add_texture_dots(checks, s.add_texture_constant((0.7, 0.2, 0.2)), su=3.0, sv=3.0)
         s.add_mesh(np.array([[-4, -4, 0.005], [-2, -4, 0.005], [-2, -2, 0.005], [-4, -2, 0.005]], np.float32), [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(spots, 0.0),
                    UV=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32))
+        ident = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+        ctm = host.compose(host.compose(ident, host.scale([2, 2, 2])), host.rotate(20, [0, 0, 1]))[0]   # the CTM at the Texture directive = "tex2world"
+        stone = s.add_texture_marble(ctm, 0.5, 6, 2.0, 0.3)
+        cells = s.add_texture_checkerboard3d(stone, s.add_texture_constant((0.05, 0.3, 0.05)), ctm)
+        s.add_mesh(np.array([[2, -4, 0.005], [4, -4, 0.005], [4, -2, 0.005], [2, -2, 0.005]], np.float32), [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(cells, 0.0))
         w2c, c2w = host.look_at((0, -6, 1.5), (0, 0, 0.5), (0, 0, 1))
         s.set_camera_perspective(host.perspective_raster_to_camera(40.0, res, res), c2w)
         cb, table, sb = host.film_box(res, res)

@@ -249,3 +249,90 @@ def test_noise_table_and_dots():
     rng = np.random.default_rng(3)
     v = s.texture_eval(dots, rng.uniform(0, 1, (4000, 2)).astype(np.float32))[:, 0]
     assert set(np.unique(v)) == {0.0, 1.0} and 0.05 < v.mean() < 0.5
+
+
+def _perm():
+    import os, re
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "oracle_texture.hpp")).read()
+    return [int(x) for x in re.findall(r"\d+", src[src.index("NOISE_PERM[512] = {"):].split("};")[0].split("{", 1)[1])]
+
+
+def _noise3(x, y, z, P):
+    """Perlin noise of core/src/texture/common.rs:37-117 in numpy float32 scalars (an independent second implementation)."""
+    x, y, z = f32(x), f32(y), f32(z)
+    ix, iy, iz = int(np.floor(x)), int(np.floor(y)), int(np.floor(z))
+    dx, dy, dz = f32(x - f32(ix)), f32(y - f32(iy)), f32(z - f32(iz))
+    ix &= 255; iy &= 255; iz &= 255
+
+    def grad(a, b, c, u_, v_, w_):
+        h = P[P[P[a] + b] + c] & 15
+        u = u_ if (h < 8 or h in (12, 13)) else v_
+        v = v_ if (h < 4 or h in (12, 13)) else w_
+        return f32((-u if h & 1 else u) + (-v if h & 2 else v))
+
+    def wgt(t):
+        t3 = f32(f32(t * t) * t); t4 = f32(t3 * t)
+        return f32(f32(f32(f32(6.0) * t4) * t - f32(f32(15.0) * t4)) + f32(f32(10.0) * t3))
+
+    def lerp(t, a, b):
+        return f32(f32(f32(f32(1.0) - t) * a) + f32(t * b))
+    one = f32(1.0)
+    w = [[[grad(ix + i, iy + j, iz + k, f32(dx - i * one) if i else dx, f32(dy - j * one) if j else dy, f32(dz - k * one) if k else dz) for k in (0, 1)] for j in (0, 1)] for i in (0, 1)]
+    wx, wy, wz = wgt(dx), wgt(dy), wgt(dz)
+    x00, x10, x01, x11 = lerp(wx, w[0][0][0], w[1][0][0]), lerp(wx, w[0][1][0], w[1][1][0]), lerp(wx, w[0][0][1], w[1][0][1]), lerp(wx, w[0][1][1], w[1][1][1])
+    return lerp(wz, lerp(wy, x00, x10), lerp(wy, x01, x11))
+
+
+def test_fbm_turbulence_windy_marble_against_a_second_implementation():
+    P = _perm()
+    s = OracleScene()
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-3, 3, (12, 3)).astype(np.float32)
+    big = np.tile(np.array([[10.0, 0, 0]], np.float32), (12, 1))      # |dp/dx|^2 = 100 -> n = clamp(-1 - 0.5 log2(100)) = 0: only the partial octave, weight smooth_step(0) = 0
+    fbm = s.add_texture_fbm(omega=0.6, octaves=5); wr = s.add_texture_fbm(omega=0.6, octaves=5, wrinkled=True)
+    uv0 = np.zeros((12, 2), np.float32)
+    assert np.array_equal(s.texture_eval(fbm, uv0, p=pts, dpdx=big, dpdy=big)[:, 0], np.zeros(12, np.float32))
+    # zero footprint: log2(0) = -inf -> n = octaves: the full sum, and the partial term has weight smooth_step(0.3, 0.7, 0) = 0
+    got_f = s.texture_eval(fbm, uv0, p=pts)[:, 0]; got_w = s.texture_eval(wr, uv0, p=pts)[:, 0]
+    for q, gf, gw in zip(pts, got_f, got_w):
+        sf = sw = f32(0.0); lam = o = f32(1.0)
+        for _ in range(5):
+            nz = _noise3(lam * q[0], lam * q[1], lam * q[2], P)
+            sf = f32(sf + f32(o * nz)); sw = f32(sw + f32(o * abs(nz)))
+            lam = f32(lam * f32(1.99)); o = f32(o * f32(0.6))
+        nz = _noise3(lam * q[0], lam * q[1], lam * q[2], P)
+        sf = f32(sf + f32(f32(o * f32(0.0)) * nz))
+        sw = f32(sw + f32(o * f32(f32(f32(1.0) * f32(0.2)) + f32(f32(0.0) * abs(nz)))))   # lerp(0, 0.2, |noise|)
+        assert gf == sf and gw == sw
+    # noise vanishes on the integer lattice (one octave, lambda = 1)
+    lattice = np.array([[1, 2, 3], [-4, 0, 7], [255, 256, -256]], np.float32)
+    one = s.add_texture_fbm(omega=0.5, octaves=1)
+    assert np.array_equal(s.texture_eval(one, np.zeros((3, 2), np.float32), p=lattice)[:, 0], np.zeros(3, np.float32))
+    # the mapping matrix is applied as given: scaling the point by 2 through the matrix equals evaluating at 2p
+    m = np.diag([2.0, 2.0, 2.0, 1.0]).astype(np.float32).reshape(16)
+    scaled = s.add_texture_fbm(m=m, omega=0.6, octaves=5)
+    assert np.array_equal(s.texture_eval(scaled, uv0, p=pts)[:, 0], s.texture_eval(fbm, uv0, p=(pts * np.float32(2.0)).astype(np.float32))[:, 0])
+    # windy = |fbm(0.1 p, 0.5, 3)| * fbm(p, 0.5, 6); marble stays inside its spline's hull (x 1.5)
+    windy = s.add_texture_windy()
+    f3_ = s.add_texture_fbm(omega=0.5, octaves=3); f6 = s.add_texture_fbm(omega=0.5, octaves=6)
+    w_ = s.texture_eval(windy, uv0, p=pts)[:, 0]
+    a = s.texture_eval(f3_, uv0, p=(np.float32(0.1) * pts).astype(np.float32))[:, 0]; b = s.texture_eval(f6, uv0, p=pts)[:, 0]
+    assert np.array_equal(w_, (np.abs(a) * b).astype(np.float32))
+    # marble: t = 0.5 + 0.5 sin(scale p.y + variation fbm(scale p)), then the Bezier spline with `first = min(1, floor(6 t))` — the reference's (and
+    # C++ pbrt's) clamp, which lets the local parameter run up to 5 and the spline extrapolate; recomputed here in float64 from the oracle's own fbm
+    mar = s.texture_eval(s.add_texture_marble(omega=0.5, octaves=8, scale=3.0, variation=0.4), uv0, p=pts)
+    f8 = s.texture_eval(s.add_texture_fbm(m=np.diag([3.0, 3.0, 3.0, 1.0]).astype(np.float32).reshape(16), omega=0.5, octaves=8), uv0, p=pts)[:, 0]
+    C = np.array([[0.58, 0.58, 0.6], [0.58, 0.58, 0.6], [0.58, 0.58, 0.6], [0.5, 0.5, 0.5], [0.6, 0.59, 0.58], [0.58, 0.58, 0.6], [0.58, 0.58, 0.6], [0.2, 0.2, 0.33], [0.58, 0.58, 0.6]])
+    for q, fb, got in zip(pts.astype(np.float64), f8.astype(np.float64), mar):
+        t = 0.5 + 0.5 * np.sin(3.0 * q[1] + 0.4 * fb)
+        first = min(1, int(np.floor(t * 6)))
+        t = t * 6 - first
+        c = [C[first + k] for k in range(4)]
+        s0, s1, s2 = (1 - t) * c[0] + t * c[1], (1 - t) * c[1] + t * c[2], (1 - t) * c[2] + t * c[3]
+        s0, s1 = (1 - t) * s0 + t * s1, (1 - t) * s1 + t * s2
+        assert np.allclose(got, 1.5 * ((1 - t) * s0 + t * s1), rtol=2e-4, atol=1e-4)
+    # 3D checkerboard: parity of floor(x) + floor(y) + floor(z), Rust's % keeping the sign
+    a_ = s.add_texture_constant(1.0); b_ = s.add_texture_constant(0.0)
+    c3 = s.add_texture_checkerboard3d(a_, b_)
+    cp = np.array([[0.5, 0.5, 0.5], [1.5, 0.5, 0.5], [1.5, 1.5, 0.5], [-0.5, 0.5, 0.5], [-0.5, -0.5, 0.5]], np.float32)
+    assert list(s.texture_eval(c3, np.zeros((5, 2), np.float32), p=cp)[:, 0]) == [1.0, 0.0, 1.0, 0.0, 1.0]

@@ -221,3 +221,41 @@ def test_checkerboard_and_dots_scene_film_bit_exact():
         set_libm_mode(0)
     gxyz, gwt, _ = prod.render_path(max_depth=3)
     assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
+
+
+def test_procedural_3d_lookups_and_scene_bit_exact():
+    rng = np.random.default_rng(9)
+    n = 3000
+    pts = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    dx = (rng.normal(size=(n, 3)) * rng.choice([0.0, 1e-3, 0.05, 2.0], size=(n, 1))).astype(np.float32)
+    dy = (rng.normal(size=(n, 3)) * rng.choice([0.0, 1e-3, 0.05, 2.0], size=(n, 1))).astype(np.float32)
+    uv = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    host = pbrt_hip.Host()
+    m = host.compose(host.rotate(30.0, [1, 2, 3]), host.scale([1.5, 0.7, 2.0]))[0]
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    outs = []
+    for sc in (prod, orc):
+        k1 = sc.add_texture_constant((0.9, 0.1, 0.2)); k2 = sc.add_texture_constant((0.1, 0.3, 0.9))
+        texs = [sc.add_texture_fbm(m, 0.55, 6), sc.add_texture_fbm(m, 0.45, 7, wrinkled=True), sc.add_texture_windy(m), sc.add_texture_marble(m, 0.5, 8, 2.0, 0.3),
+                sc.add_texture_checkerboard3d(k1, k2, m)]
+        texs.append(sc.add_texture_mix(texs[3], texs[4], texs[1]))
+        if sc is orc: set_libm_mode(1)
+        try:
+            outs.append([sc.texture_eval(t, uv, p=pts, dpdx=dx, dpdy=dy) for t in texs])
+        finally:
+            set_libm_mode(0)
+    for a, b in zip(*outs):
+        assert _bits_equal(a, b)
+
+    def builder(sc):
+        return sc.add_texture_mix(sc.add_texture_marble(m, 0.5, 8, 2.0, 0.3), sc.add_texture_checkerboard3d(sc.add_texture_constant((0.9, 0.1, 0.2)), sc.add_texture_constant((0.1, 0.3, 0.9)), m),
+                                  sc.add_texture_fbm(m, 0.5, 4, wrinkled=True))
+    for kw in (dict(), dict(instance=True)):
+        prod, orc = _render_pair(builder, res=40, **kw)
+        set_libm_mode(1)
+        try:
+            oxyz, owt, _, _ = orc.render_path_ex(max_depth=3)
+        finally:
+            set_libm_mode(0)
+        gxyz, gwt, _ = prod.render_path(max_depth=3)
+        assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
