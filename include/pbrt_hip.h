@@ -162,6 +162,10 @@ int pbrt_hip_add_texture_uv(PbrtHipScene*, float su, float sv, float du, float d
 int pbrt_hip_add_texture_bilerp(PbrtHipScene*, const float v00[3], const float v01[3], const float v10[3], const float v11[3], float su, float sv, float du, float dv,
                                 uint32_t* out_texture);
 int pbrt_hip_add_texture_dots(PbrtHipScene*, uint32_t inside, uint32_t outside, float su, float sv, float du, float dv, uint32_t* out_texture);
+/* The other TextureMapping2D kinds for a 2D texture (imagemap, checkerboard, uv, bilerp, dots; core/src/texture/mapping/): kind 1 SphericalMapping2D and
+ * 2 CylindericalMapping2D take params = the row-major 4x4 world_to_texture matrix (the reference passes tex2world.inverse(), textures/src/lib.rs:54-55),
+ * 3 PlanarMapping2D takes params = v1[3], v2[3], udelta, vdelta.  Set it before the texture is used as an operand of another texture. */
+int pbrt_hip_set_texture_mapping(PbrtHipScene*, uint32_t texture, int kind, const float* params);
 /* 3D procedural textures over IdentityMapping3D (core/src/texture/mapping/identity_3d.rs): `m` is the row-major 4x4 matrix the mapping applies to the
  * hit point and to dp/dx, dp/dy — the reference hands it the Texture directive's CTM (tex2world, textures/src/fbm.rs:65), so pass that.
  * FBmTexture, WrinkledTexture (fbm.rs, wrinkled.rs; omega = "roughness", octaves), WindyTexture (windy.rs), MarbleTexture (marble.rs; scale, variation),

@@ -318,6 +318,15 @@ int oracle_add_texture_dots(OracleScene* s, uint32_t inside, uint32_t outside, f
     if (!s || inside >= s->sc.textures.size() || outside >= s->sc.textures.size()) return -1;
     Texture t; t.kind = TK_DOTS; t.t1 = (int)inside; t.t2 = (int)outside; t.su = su; t.sv = sv; t.du = du; t.dv = dv; return push_texture(s, t, out_id);
 }
+int oracle_set_texture_mapping(OracleScene* s, uint32_t tex, int kind, const float* prm) {
+    if (!s || tex >= s->sc.textures.size() || kind < 1 || kind > 3 || !prm) return -1;
+    Texture& t = s->sc.textures[tex];
+    if (!(t.kind == TK_IMAGE || t.kind == TK_CHECKER || t.kind == TK_UV || t.kind == TK_BILERP || t.kind == TK_DOTS)) return -6;
+    t.mapping = kind;
+    if (kind == 3) { t.vs = V3(prm[0], prm[1], prm[2]); t.vt = V3(prm[3], prm[4], prm[5]); t.du = prm[6]; t.dv = prm[7]; }
+    else t.w2t = m4_from(prm);
+    return 0;
+}
 // probes for the pinning tests
 static int push_texture3d(OracleScene* s, int kind, const float m[16], float omega, int octaves, float scale, float variation, uint32_t t1, uint32_t t2, uint32_t* out_id) {
     if (!s || !m) return -1;

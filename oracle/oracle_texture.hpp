@@ -284,6 +284,19 @@ inline V3 m4_vector(const M4& m, V3 v) {  // transform_vector (:373-380)
 static const Float MARBLE_C[9][3] = {{0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.5f, 0.5f, 0.5f}, {0.6f, 0.59f, 0.58f},
                                      {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.2f, 0.2f, 0.33f}, {0.58f, 0.58f, 0.6f}};  // marble.rs:104-114
 
+// TextureMapping2D::map of the four 2D mappings (core/src/texture/mapping/{uv_2d,spherical_2d,cylinderical_2d,planar_2d}.rs)
+inline V2 map_sphere(const M4& w2t, V3 p) {
+    V3 vec = normalize(m4_point(w2t, p) - V3(0, 0, 0));
+    return V2(spherical_theta(vec) * INV_PI, spherical_phi(vec) * INV_TWO_PI);
+}
+inline V2 map_cylinder(const M4& w2t, V3 p) {
+    V3 vec = normalize(m4_point(w2t, p) - V3(0, 0, 0));
+    return V2((PI + o_atan2(vec.y, vec.x)) * INV_TWO_PI, vec.z);
+}
+struct Texture;
+struct TexCtx;
+inline void fix_wrap(Float& d) { if (d > 0.5f) d = 1.0f - d; else if (d < -0.5f) d = -(d + 1.0f); }
+
 enum { TK_CONST = 0, TK_SCALE = 1, TK_MIX = 2, TK_IMAGE = 3, TK_CHECKER = 4, TK_UV = 5, TK_BILERP = 6, TK_DOTS = 7, TK_FBM = 8, TK_WRINKLED = 9, TK_WINDY = 10,
        TK_MARBLE = 11, TK_CHECKER3D = 12 };
 struct Texture {
@@ -293,10 +306,31 @@ struct Texture {
     int mip = -1; Float su = 1, sv = 1, du = 0, dv = 0;  // TK_IMAGE + UVMapping2D (also the mapping of the 2D procedural textures)
     int aa = 1;                   // TK_CHECKER: 0 none, 1 closedform
     Spec v[4];                    // TK_BILERP: v00 v01 v10 v11
+    int mapping = 0;              // 2D textures: 0 uv, 1 spherical, 2 cylindrical (w2t), 3 planar (vs, vt, du = ds, dv = dt)
+    V3 vs, vt;
     M4 w2t = M4::identity();      // 3D textures: IdentityMapping3D's matrix (the reference hands it tex2world, fbm.rs:65 — kept)
     Float omega = 0.5f, scale = 1.0f, variation = 0.2f; int octaves = 8;
 };
 struct TexCtx { V2 uv; Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0; V3 p, dpdx, dpdy; };
+
+inline void map_2d(const Texture& t, const TexCtx& c, V2& st, V2& dstdx, V2& dstdy) {
+    if (t.mapping == 0) {
+        dstdx = V2(t.su * c.dudx, t.sv * c.dvdx); dstdy = V2(t.su * c.dudy, t.sv * c.dvdy);
+        st = V2(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+    } else if (t.mapping == 3) {
+        dstdx = V2(dot(c.dpdx, t.vs), dot(c.dpdx, t.vt)); dstdy = V2(dot(c.dpdy, t.vs), dot(c.dpdy, t.vt));
+        st = V2(t.du + dot(c.p, t.vs), t.dv + dot(c.p, t.vt));
+    } else {
+        const bool sph = t.mapping == 1;
+        const Float delta = sph ? 0.1f : 0.01f;
+        st = sph ? map_sphere(t.w2t, c.p) : map_cylinder(t.w2t, c.p);
+        V2 sx = sph ? map_sphere(t.w2t, c.p + delta * c.dpdx) : map_cylinder(t.w2t, c.p + delta * c.dpdx);
+        V2 sy = sph ? map_sphere(t.w2t, c.p + delta * c.dpdy) : map_cylinder(t.w2t, c.p + delta * c.dpdy);
+        Float inv = 1.0f / delta;                                  // Vector2 / f multiplies by the reciprocal (vector2.rs:298-310)
+        dstdx = V2(inv * (sx.x - st.x), inv * (sx.y - st.y)); dstdy = V2(inv * (sy.x - st.x), inv * (sy.y - st.y));
+        fix_wrap(dstdx.y); fix_wrap(dstdy.y);
+    }
+}
 
 inline Spec tex_eval(const std::vector<Texture>& tex, const std::vector<MipMap>& mips, int id, const TexCtx& c) {
     const Texture& t = tex[(size_t)id];
@@ -308,13 +342,11 @@ inline Spec tex_eval(const std::vector<Texture>& tex, const std::vector<MipMap>&
             return (1.0f - amt) * a + amt * b;
         }
         case TK_IMAGE: {
-            V2 dstdx(t.su * c.dudx, t.sv * c.dvdx), dstdy(t.su * c.dudy, t.sv * c.dvdy);
-            V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+            V2 st, dstdx, dstdy; map_2d(t, c, st, dstdx, dstdy);
             return mips[(size_t)t.mip].lookup(st, dstdx, dstdy);
         }
         case TK_CHECKER: {  // checkerboard_2d.rs:60-104
-            V2 dstdx(t.su * c.dudx, t.sv * c.dvdx), dstdy(t.su * c.dudy, t.sv * c.dvdy);
-            V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+            V2 st, dstdx, dstdy; map_2d(t, c, st, dstdx, dstdy);
             Spec a = tex_eval(tex, mips, t.t1, c), b = tex_eval(tex, mips, t.t2, c);
             auto point = [&]() { return ((int32_t)((uint32_t)f2i32(std::floor(st.x)) + (uint32_t)f2i32(std::floor(st.y))) % 2 == 0) ? a : b; };
             if (t.aa == 0) return point();
@@ -326,16 +358,16 @@ inline Spec tex_eval(const std::vector<Texture>& tex, const std::vector<MipMap>&
             return a * (1.0f - area2) + b * area2;
         }
         case TK_UV: {  // uv.rs:33-38
-            V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+            V2 st, dstdx_, dstdy_; map_2d(t, c, st, dstdx_, dstdy_);
             return Spec(st.x - std::floor(st.x), st.y - std::floor(st.y), 0.0f);
         }
         case TK_BILERP: {  // bilerp.rs:58-71
-            V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+            V2 st, dstdx_, dstdy_; map_2d(t, c, st, dstdx_, dstdy_);
             Float s00 = (1.0f - st.x) * (1.0f - st.y), s01 = (1.0f - st.x) * st.y, s10 = st.x * (1.0f - st.y), s11 = st.x * st.y;
             return (t.v[0] * s00) + (t.v[1] * s01) + (t.v[2] * s10) + (t.v[3] * s11);
         }
         case TK_DOTS: {  // dots.rs:48-69
-            V2 st(t.su * c.uv.x + t.du, t.sv * c.uv.y + t.dv);
+            V2 st, dstdx_, dstdy_; map_2d(t, c, st, dstdx_, dstdy_);
             Float s_cell = std::floor(st.x + 0.5f), t_cell = std::floor(st.y + 0.5f);
             if (noise_2d(s_cell + 0.5f, t_cell + 0.5f) > 0.0f) {
                 const Float radius = 0.35f, max_shift = 0.5f - radius;

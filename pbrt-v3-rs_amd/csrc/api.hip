@@ -591,6 +591,20 @@ int pbrt_hip_add_texture_checkerboard3d(PbrtHipScene* s, uint32_t t1, uint32_t t
     const PbrtHipScene::TextureHost a = s->textures[t1], b = s->textures[t2];
     return push_texture3d(s, PH_TOP_CHECKER3D, m, 0.0f, 0, 1.0f, 0.0f, "add_texture_checkerboard3d", out_id, &a, &b);
 }
+// TextureMapping2D other than uv for a 2D texture (imagemap, checkerboard, uv, bilerp, dots).  Programs are copied into their parents when those
+// are created, so the mapping has to be set before the texture is used as an operand.
+int pbrt_hip_set_texture_mapping(PbrtHipScene* s, uint32_t texture, int kind, const float* params) {
+    if (!s || texture >= s->textures.size() || !params) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_texture_mapping: bad argument");
+    if (kind < 1 || kind > 3) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_texture_mapping: kind must be 1 spherical, 2 cylindrical or 3 planar");
+    TexOp& op = s->textures[texture].prog.back();
+    if (!(op.op == PH_TOP_IMAGE || op.op == PH_TOP_CHECKER || op.op == PH_TOP_UV || op.op == PH_TOP_BILERP || op.op == PH_TOP_DOTS))
+        return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_texture_mapping: only imagemap, checkerboard (2D), uv, bilerp and dots textures take a 2D mapping");
+    op.mapping = (uint32_t)kind;
+    if (kind == 3) { std::memcpy(op.m, params, 24); op.du = params[6]; op.dv = params[7]; }
+    else std::memcpy(op.m, params, 64);
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
 // Replaces a material's constant colour parameter by a texture evaluated at every hit.  The material must have been created with a non-black
 // constant for that parameter (so that its lobe exists); which lobes a hit finally gets follows the reference's `is_black` tests on the
 // texture's value at that hit.

@@ -104,7 +104,9 @@ struct TexOp {
     float su, sv, du, dv;  // 2D textures: UVMapping2D (texture/mapping/uv_2d.rs)
     uint32_t octaves;      // fbm / wrinkled / marble
     float omega, scale, variation;
-    float m[16];           // 3D textures: IdentityMapping3D's matrix (texture/mapping/identity_3d.rs)
+    float m[16];           // 3D textures: IdentityMapping3D's matrix (texture/mapping/identity_3d.rs); 2D textures with mapping 1 / 2: world_to_texture; 3: vs, vt
+    uint32_t mapping;      // 2D textures: 0 uv, 1 spherical, 2 cylindrical, 3 planar (du, dv = ds, dt)
+    uint32_t pad_[3];
 };
 struct TexRec { uint32_t first_op, n_ops; };  // DeviceScene::tex_ops[first_op .. first_op + n_ops)
 struct Texel { float r, g, b, pad; };  // one 16-byte load per texel

@@ -165,6 +165,35 @@ PH_DEV f3 xf_point16(const float* m, f3 p) {  // Transform::transform_point (tra
     return (w == 1.0f) ? mk3(x, y, z) : mk3(x, y, z) / w;
 }
 
+// TextureMapping2D::map of the four 2D mappings (core/src/texture/mapping/{uv_2d,spherical_2d,cylinderical_2d,planar_2d}.rs)
+PH_DEV f2 map_sphere(const float* m, f3 p) {
+    const f3 v = normalize(xf_point16(m, p) - mk3(0.0f, 0.0f, 0.0f));
+    return mk2(spherical_theta(v) * kInvPi, spherical_phi(v) * kInvTwoPi);
+}
+PH_DEV f2 map_cylinder(const float* m, f3 p) {
+    const f3 v = normalize(xf_point16(m, p) - mk3(0.0f, 0.0f, 0.0f));
+    return mk2((kPi + d_atan2(v.y, v.x)) * kInvTwoPi, v.z);
+}
+PH_DEV float fix_wrap(float d) { return d > 0.5f ? 1.0f - d : (d < -0.5f ? -(d + 1.0f) : d); }
+PH_DEV void map_2d(const TexOp& op, const TexCtx& c, f2& st, f2& dstdx, f2& dstdy) {
+    if (op.mapping == 0u) {
+        dstdx = mk2(op.su * c.dudx, op.sv * c.dvdx); dstdy = mk2(op.su * c.dudy, op.sv * c.dvdy);
+        st = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+    } else if (op.mapping == 3u) {
+        const f3 vs = mk3(op.m[0], op.m[1], op.m[2]), vt = mk3(op.m[3], op.m[4], op.m[5]);
+        dstdx = mk2(dot(c.dpdx, vs), dot(c.dpdx, vt)); dstdy = mk2(dot(c.dpdy, vs), dot(c.dpdy, vt));
+        st = mk2(op.du + dot(c.p, vs), op.dv + dot(c.p, vt));
+    } else {
+        const bool sph = op.mapping == 1u;
+        const float delta = sph ? 0.1f : 0.01f;
+        st = sph ? map_sphere(op.m, c.p) : map_cylinder(op.m, c.p);
+        const f2 sx = sph ? map_sphere(op.m, c.p + delta * c.dpdx) : map_cylinder(op.m, c.p + delta * c.dpdx);
+        const f2 sy = sph ? map_sphere(op.m, c.p + delta * c.dpdy) : map_cylinder(op.m, c.p + delta * c.dpdy);
+        const float inv = ph_div(1.0f, delta);
+        dstdx = mk2(inv * (sx.x - st.x), fix_wrap(inv * (sx.y - st.y))); dstdy = mk2(inv * (sy.x - st.x), fix_wrap(inv * (sy.y - st.y)));
+    }
+}
+
 // Runs texture `id`'s postfix program.  Kept out of line: the shade kernels call it only for materials that carry a texture.
 // `dsc` = DeviceScene::self (the by-value kernel argument must not have its address taken: it would be copied to scratch).
 static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id, TexCtx c) {
@@ -177,8 +206,7 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
         switch (op.op) {
         case PH_TOP_CONST: st[sp++] = mks(op.c[0], op.c[1], op.c[2]); break;
         case PH_TOP_IMAGE: {
-            const f2 dstdx = mk2(op.su * c.dudx, op.sv * c.dvdx), dstdy = mk2(op.su * c.dudy, op.sv * c.dvdy);
-            const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+            f2 p, dstdx, dstdy; map_2d(op, c, p, dstdx, dstdy);
             st[sp++] = mip_lookup(sc, sc.mipmaps[op.mip], p, dstdx, dstdy);
             break;
         }
@@ -186,8 +214,7 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
         case PH_TOP_CHECKER: {  // checkerboard_2d.rs:60-104; stack = tex1, tex2 (both are evaluated: they have no side effects)
             sp--;
             const spec a = st[sp - 1], b = st[sp];
-            const f2 dstdx = mk2(op.su * c.dudx, op.sv * c.dvdx), dstdy = mk2(op.su * c.dudy, op.sv * c.dvdy);
-            const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+            f2 p, dstdx, dstdy; map_2d(op, c, p, dstdx, dstdy);
             const bool even = (int)((uint32_t)f2i_sat(floorf(p.x)) + (uint32_t)f2i_sat(floorf(p.y))) % 2 == 0;
             spec r = even ? a : b;
             if (op.mip != 0u) {
@@ -203,13 +230,13 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
             break;
         }
         case PH_TOP_UV: {  // uv.rs:33-38
-            const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+            f2 p, dx_, dy_; map_2d(op, c, p, dx_, dy_);
             st[sp++] = mks(p.x - floorf(p.x), p.y - floorf(p.y), 0.0f);
             break;
         }
         case PH_TOP_BILERP: {  // bilerp.rs:58-71; stack = v00, v01, v10, v11
             sp -= 3;
-            const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+            f2 p, dx_, dy_; map_2d(op, c, p, dx_, dy_);
             const float s00 = (1.0f - p.x) * (1.0f - p.y), s01 = (1.0f - p.x) * p.y, s10 = p.x * (1.0f - p.y), s11 = p.x * p.y;
             st[sp - 1] = (st[sp - 1] * s00) + (st[sp] * s01) + (st[sp + 1] * s10) + (st[sp + 2] * s11);
             break;
@@ -244,7 +271,7 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
         }
         case PH_TOP_DOTS: {  // dots.rs:48-69; stack = inside, outside
             sp--;
-            const f2 p = mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+            f2 p, dx_, dy_; map_2d(op, c, p, dx_, dy_);
             const float s_cell = floorf(p.x + 0.5f), t_cell = floorf(p.y + 0.5f);
             bool inside = false;
             if (noise_2d(s_cell + 0.5f, t_cell + 0.5f) > 0.0f) {

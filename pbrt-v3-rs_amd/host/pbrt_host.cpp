@@ -203,11 +203,24 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
             if (ok) { gs_.unsupported_textures.erase(name); gs_.device_textures.erase(name); gs_.spectrum_textures[name] = v; return; }
         }
     }
+    // get_texture_mapping (textures/src/lib.rs:44-67): "uv" travels in the texture's own parameters, the other three are attached afterwards
+    auto mapping_ok = [&](const std::string& mp) { return mp == "uv" || mp == "spherical" || mp == "cylindrical" || mp == "planar"; };
+    auto attach_mapping = [&](uint32_t id) -> bool {
+        const std::string mp = p.find_one_string("mapping", "uv");
+        if (mp == "uv" || !mapping_ok(mp)) return true;   // unknown names fall back to uv with a warning (issued by the caller)
+        if (mp == "planar") {
+            float prm[8] = {1, 0, 0, 0, 1, 0, p.find_one_float("udelta", 0.0f), p.find_one_float("vdelta", 0.0f)};
+            if (const std::vector<float>* v = p.find_floats("v1")) if (v->size() >= 3) for (int k = 0; k < 3; k++) prm[k] = (*v)[(size_t)k];
+            if (const std::vector<float>* v = p.find_floats("v2")) if (v->size() >= 3) for (int k = 0; k < 3; k++) prm[3 + k] = (*v)[(size_t)k];
+            return check(ABI(pbrt_hip_set_texture_mapping(scene_, id, 3, prm)), "set_texture_mapping");
+        }
+        return check(ABI(pbrt_hip_set_texture_mapping(scene_, id, mp == "spherical" ? 1 : 2, ctm_.mi)), "set_texture_mapping");  // tex2world.inverse()
+    };
     auto forget = [&]() { gs_.unsupported_textures.erase(name); gs_.float_textures.erase(name); gs_.spectrum_textures.erase(name); gs_.device_textures.erase(name); };
     if (tex_class == "imagemap") {  // ImageTexture::from (textures/src/imagemap.rs:117-160)
         forget();
         const std::string mapping = p.find_one_string("mapping", "uv");
-        if (mapping != "uv") { gs_.unsupported_textures[name] = "imagemap with mapping '" + mapping + "'"; return; }
+        if (!mapping_ok(mapping)) warn("Error 2D texture mapping '" + mapping + "' unknown");
         std::string file = p.find_one_string("filename", "");
         if (file.empty()) { if (error.empty()) error = "imagemap path not specified."; return; }
         if (file[0] != '/' && !scene_dir.empty()) file = scene_dir + "/" + file;
@@ -232,6 +245,7 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
         uint32_t id = 0;
         if (!check(ABI(pbrt_hip_add_texture_imagemap(scene_, mip, p.find_one_float("uscale", 1.0f), p.find_one_float("vscale", 1.0f), p.find_one_float("udelta", 0.0f),
                                                      p.find_one_float("vdelta", 0.0f), &id)), "add_texture_imagemap")) return;
+        if (!attach_mapping(id)) return;
         gs_.device_textures[name] = GraphicsState::DeviceTexture{is_float, id};
         return;
     }
@@ -262,7 +276,7 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
     }
     if ((tex_class == "checkerboard" && p.find_one_int("dimension", 2) != 3) || tex_class == "uv" || tex_class == "bilerp" || tex_class == "dots") {  // 2D procedural textures (textures/src/*.rs)
         const std::string mapping = p.find_one_string("mapping", "uv");
-        if (mapping != "uv") { forget(); gs_.unsupported_textures[name] = tex_class + " with mapping '" + mapping + "'"; return; }
+        if (!mapping_ok(mapping)) warn("Error 2D texture mapping '" + mapping + "' unknown");
         if (tex_class == "checkerboard" && p.find_one_int("dimension", 2) != 2 && p.find_one_int("dimension", 2) != 3) {
             if (error.empty()) error = "Texture \"" + name + "\": " + std::to_string(p.find_one_int("dimension", 2)) + " dimensional checkerboard texture not supported";
             return;
@@ -301,6 +315,7 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
             const std::array<float, 3> v00 = corner("v00", 0.0f), v01 = corner("v01", 1.0f), v10 = corner("v10", 0.0f), v11 = corner("v11", 1.0f);
             ok = check(ABI(pbrt_hip_add_texture_bilerp(scene_, v00.data(), v01.data(), v10.data(), v11.data(), su, sv, du, dv, &id)), "add_texture_bilerp");
         }
+        if (ok) ok = attach_mapping(id);
         if (ok) { forget(); gs_.device_textures[name] = GraphicsState::DeviceTexture{is_float, id}; }
         return;
     }

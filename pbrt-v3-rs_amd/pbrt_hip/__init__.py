@@ -127,6 +127,7 @@ class Binding:
             "add_texture_windy": (C.c_int, [vp, fp, u32p]),
             "add_texture_marble": (C.c_int, [vp, fp, C.c_float, C.c_int, C.c_float, C.c_float, u32p]),
             "add_texture_checkerboard3d": (C.c_int, [vp, C.c_uint32, C.c_uint32, fp, u32p]),
+            "set_texture_mapping": (C.c_int, [vp, C.c_uint32, C.c_int, fp]),
             "add_material_matte_tex": (C.c_int, [vp, C.c_uint32, C.c_float, u32p]),
             "set_material_texture": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32]),
             "texture_eval_batch": (C.c_int, [vp, C.c_uint32, C.c_uint64, fp, fp]),
@@ -521,6 +522,13 @@ class Scene:
 
     def add_texture_checkerboard3d(self, t1, t2, m=IDENTITY):
         out = C.c_uint32(0); self._chk(self.b.fn("add_texture_checkerboard3d")(self.h, t1, t2, _ptr(_f32(m), C.c_float), C.byref(out))); return out.value
+
+    def set_texture_mapping(self, texture, kind, params):
+        """kind "spherical" | "cylindrical" (params = world_to_texture, 16 floats) | "planar" (params = v1, v2, udelta, vdelta: 8 floats)"""
+        k = {"spherical": 1, "cylindrical": 2, "planar": 3}[kind]
+        prm = np.ascontiguousarray(np.asarray(params, np.float32).reshape(-1), dtype=np.float32)
+        assert len(prm) == (8 if k == 3 else 16)
+        self._chk(self.b.fn("set_texture_mapping")(self.h, texture, k, _ptr(prm, C.c_float)))
 
     def add_material_matte_tex(self, kd_texture, sigma=0.0):
         out = C.c_uint32(0); self._chk(self.b.fn("add_material_matte_tex")(self.h, kd_texture, C.c_float(sigma), C.byref(out))); return out.value

@@ -336,3 +336,28 @@ def test_fbm_turbulence_windy_marble_against_a_second_implementation():
     c3 = s.add_texture_checkerboard3d(a_, b_)
     cp = np.array([[0.5, 0.5, 0.5], [1.5, 0.5, 0.5], [1.5, 1.5, 0.5], [-0.5, 0.5, 0.5], [-0.5, -0.5, 0.5]], np.float32)
     assert list(s.texture_eval(c3, np.zeros((5, 2), np.float32), p=cp)[:, 0]) == [1.0, 0.0, 1.0, 0.0, 1.0]
+
+
+def test_spherical_cylindrical_planar_mappings():
+    s = OracleScene()
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    uvt = [s.add_texture_uv() for _ in range(3)]
+    s.set_texture_mapping(uvt[0], "spherical", ident); s.set_texture_mapping(uvt[1], "cylindrical", ident)
+    s.set_texture_mapping(uvt[2], "planar", [0.5, 0, 0, 0, 0.25, 0, 0.1, 0.2])
+    pts = np.array([[0, 0, 2.0], [1, 0, 0], [0, 3, 0], [-1, -1, 0.5], [0.3, -0.7, -0.2]], np.float32)
+    z = np.zeros((5, 2), np.float32)
+    sph = s.texture_eval(uvt[0], z, p=pts); cyl = s.texture_eval(uvt[1], z, p=pts); pla = s.texture_eval(uvt[2], z, p=pts)
+    v = pts.astype(np.float64) / np.linalg.norm(pts.astype(np.float64), axis=1, keepdims=True)
+    theta = np.arccos(np.clip(v[:, 2], -1, 1)) / np.pi
+    phi = np.arctan2(v[:, 1], v[:, 0]); phi = np.where(phi < 0, phi + 2 * np.pi, phi) / (2 * np.pi)
+    frac = lambda a: a - np.floor(a)
+    assert np.allclose(sph[:, 0], frac(theta), atol=1e-6) and np.allclose(sph[:, 1], frac(phi), atol=1e-6)
+    assert np.allclose(cyl[:, 0], frac((np.pi + np.arctan2(v[:, 1], v[:, 0])) / (2 * np.pi)), atol=1e-6) and np.allclose(cyl[:, 1], frac(v[:, 2]), atol=1e-6)
+    assert np.allclose(pla[:, 0], frac(0.1 + 0.5 * pts[:, 0]), atol=1e-6) and np.allclose(pla[:, 1], frac(0.2 + 0.25 * pts[:, 1]), atol=1e-6)
+    # the matrix is applied to the point before the projection
+    m = np.array([[0, 0, 1, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32).reshape(16)   # (x,y,z) -> (z,x,y)
+    t2 = s.add_texture_uv(); s.set_texture_mapping(t2, "spherical", m)
+    assert np.array_equal(s.texture_eval(t2, z, p=pts), s.texture_eval(uvt[0], z, p=pts[:, [2, 0, 1]].copy()))
+    # only 2D textures take one
+    with pytest.raises(Exception):
+        s.set_texture_mapping(s.add_texture_fbm(), "planar", [1, 0, 0, 0, 1, 0, 0, 0])

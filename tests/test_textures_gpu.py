@@ -259,3 +259,43 @@ def test_procedural_3d_lookups_and_scene_bit_exact():
             set_libm_mode(0)
         gxyz, gwt, _ = prod.render_path(max_depth=3)
         assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
+
+
+def test_2d_mappings_lookups_and_scene_bit_exact():
+    rng = np.random.default_rng(10)
+    n = 3000
+    pts = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    dx = (rng.normal(size=(n, 3)) * rng.choice([0.0, 1e-3, 0.05, 1.0], size=(n, 1))).astype(np.float32)
+    dy = (rng.normal(size=(n, 3)) * rng.choice([0.0, 1e-3, 0.05, 1.0], size=(n, 1))).astype(np.float32)
+    host = pbrt_hip.Host()
+    w2t = host.compose(host.rotate(40.0, [1, 1, 0]), host.translate([0.2, -0.1, 0.3]))[1]
+    planar = [0.3, 0.1, 0.0, -0.1, 0.4, 0.2, 0.05, 0.15]
+
+    def textures(sc):
+        out = []
+        for kind, prm in (("spherical", w2t), ("cylindrical", w2t), ("planar", planar)):
+            im = sc.add_texture_imagemap(sc.add_mipmap(make_image(32, 16, seed=3))); sc.set_texture_mapping(im, kind, prm)
+            ck = sc.add_texture_checkerboard(sc.add_texture_constant((0.9, 0.8, 0.1)), sc.add_texture_constant((0.1, 0.1, 0.5)), su=1.0, sv=1.0); sc.set_texture_mapping(ck, kind, prm)
+            dt = sc.add_texture_dots(im, ck); sc.set_texture_mapping(dt, kind, prm)
+            out += [im, ck, dt]
+        return out
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    outs = []
+    for sc in (prod, orc):
+        texs = textures(sc)
+        if sc is orc: set_libm_mode(1)
+        try:
+            outs.append([sc.texture_eval(t, np.zeros((n, 2), np.float32), p=pts, dpdx=dx, dpdy=dy) for t in texs])
+        finally:
+            set_libm_mode(0)
+    for a, b in zip(*outs):
+        assert _bits_equal(a, b)
+    for pick in (0, 4, 8):
+        prod, orc = _render_pair(lambda sc, pick=pick: textures(sc)[pick], res=40)
+        set_libm_mode(1)
+        try:
+            oxyz, owt, _, _ = orc.render_path_ex(max_depth=3)
+        finally:
+            set_libm_mode(0)
+        gxyz, gwt, _ = prod.render_path(max_depth=3)
+        assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
