@@ -178,10 +178,11 @@ int pbrt_hip_add_texture_checkerboard3d(PbrtHipScene*, uint32_t tex1, uint32_t t
 /* Replaces a colour parameter of an existing material by a texture evaluated at every hit (`self.kd.evaluate(..).clamp_default()` in
  * compute_scattering_functions: materials/src/matte.rs:63, plastic.rs:62-70, mirror.rs:53-55, substrate.rs:60-62), with the ray
  * differentials of camera rays (SurfaceInteraction::compute_differentials) driving the MIPMap filter.  Which lobes a hit gets follows the
- * reference's `is_black` tests on the value at that hit.  Texturable so far: matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks;
+ * reference's `is_black` tests on the value at that hit.  Texturable so far: matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, glass Kr / Kt (glass.rs:72-78)
+ * and uber Kd / Ks / Kr / Kt (multiplied by its constant opacity, uber.rs:133-160);
  * the material must have been created with a non-black constant for that parameter.  Scalar parameters (sigma, roughness, ...) stay constants;
  * materials with per-hit textures cannot be children of a mix yet. */
-enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2 };
+enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2, PBRT_HIP_PARAM_KT = 3 };
 int pbrt_hip_set_material_texture(PbrtHipScene*, uint32_t material, int param, uint32_t texture);
 /* = add_material_matte((1,1,1), sigma) + set_material_texture(KD) */
 int pbrt_hip_add_material_matte_tex(PbrtHipScene*, uint32_t kd_texture, float sigma_degrees, uint32_t* out_material);

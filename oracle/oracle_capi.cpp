@@ -101,10 +101,11 @@ int oracle_add_material_glass(OracleScene* s, const float kr[3], const float kt[
         bool is_specular = urough == 0.0f && vrough == 0.0f;
         if (is_specular) {  // allow_multiple_lobes is true on this path (path.rs:143)
             Lobe l; l.kind = LK_FRESNEL_SPEC; l.type = BX_REFL | BX_TRANS | BX_SPEC; l.r = r; l.t = t; l.eta_a = 1.0f; l.eta_b = eta; m.lobes.push_back(l);
+            m.param_lobe[2] = 0; m.param_field[2] = 0; m.param_lobe[3] = 0; m.param_field[3] = 1;
         } else {
             if (remap) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
-            if (!r.is_black()) { Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; l.r = r; set_tr(l, urough, vrough); m.lobes.push_back(l); }
-            if (!t.is_black()) { Lobe l; l.kind = LK_MICRO_T; l.type = BX_TRANS | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; l.t = t; set_tr(l, urough, vrough); m.lobes.push_back(l); }
+            if (!r.is_black()) { Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; l.r = r; set_tr(l, urough, vrough); m.param_lobe[2] = (int)m.lobes.size(); m.lobes.push_back(l); }
+            if (!t.is_black()) { m.param_lobe[3] = (int)m.lobes.size(); m.param_field[3] = 1; Lobe l; l.kind = LK_MICRO_T; l.type = BX_TRANS | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; l.t = t; set_tr(l, urough, vrough); m.lobes.push_back(l); }
         }
     }
     return push_material(s, m, out_id);
@@ -131,18 +132,20 @@ int oracle_add_material_uber(OracleScene* s, const float kd[3], const float ks[3
         Lobe l; l.kind = LK_SPEC_T; l.type = BX_TRANS | BX_SPEC; l.fresnel = FR_DIEL; l.t = t; l.eta_a = 1.0f; l.eta_b = 1.0f; m.lobes.push_back(l);
     } else m.bsdf_eta = e;
     Spec d = op * spec_clamp0(spec3(kd));
-    if (!d.is_black()) { Lobe l; l.kind = LK_LAMBERT; l.type = BX_REFL | BX_DIFF; l.r = d; m.lobes.push_back(l); }
+    m.has_pre = true; m.pre = op;
+    if (!d.is_black()) { Lobe l; l.kind = LK_LAMBERT; l.type = BX_REFL | BX_DIFF; l.r = d; m.param_lobe[0] = (int)m.lobes.size(); m.lobes.push_back(l); }
     Spec sp = op * spec_clamp0(spec3(ks));
     if (!sp.is_black()) {
+        m.param_lobe[1] = (int)m.lobes.size();
         Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.r = sp;
         if (remap) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
         set_tr(l, urough, vrough);
         m.lobes.push_back(l);
     }
     Spec r = op * spec_clamp0(spec3(kr));
-    if (!r.is_black()) { Lobe l; l.kind = LK_SPEC_R; l.type = BX_REFL | BX_SPEC; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.r = r; m.lobes.push_back(l); }
+    if (!r.is_black()) { Lobe l; l.kind = LK_SPEC_R; l.type = BX_REFL | BX_SPEC; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.r = r; m.param_lobe[2] = (int)m.lobes.size(); m.lobes.push_back(l); }
     Spec tt = op * spec_clamp0(spec3(kt));
-    if (!tt.is_black()) { Lobe l; l.kind = LK_SPEC_T; l.type = BX_TRANS | BX_SPEC; l.fresnel = FR_DIEL; l.t = tt; l.eta_a = 1.0f; l.eta_b = e; m.lobes.push_back(l); }
+    if (!tt.is_black()) { m.param_lobe[3] = (int)m.lobes.size(); m.param_field[3] = 1; Lobe l; l.kind = LK_SPEC_T; l.type = BX_TRANS | BX_SPEC; l.fresnel = FR_DIEL; l.t = tt; l.eta_a = 1.0f; l.eta_b = e; m.lobes.push_back(l); }
     return push_material(s, m, out_id);
 }
 
@@ -368,11 +371,12 @@ int oracle_mipmap_level_texels(OracleScene* s, uint32_t mip, int level, float* o
     return 0;
 }
 int oracle_set_material_texture(OracleScene* s, uint32_t material, int param, uint32_t texture) {
-    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || param < 0 || param > 2) return -1;
+    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || param < 0 || param > 3) return -1;
     Material& m = s->sc.materials[material];
     if (m.param_lobe[param] < 0) return -6;
     Lobe& l = m.lobes[(size_t)m.param_lobe[param]];
     if (m.param_field[param] == 0) l.r_tex = (int)texture; else l.t_tex = (int)texture;
+    if (m.has_pre) { l.has_pre = true; l.pre = m.pre; }
     m.textured = true;
     return 0;
 }

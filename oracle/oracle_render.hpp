@@ -924,9 +924,10 @@ struct Renderer {
             int k = 0;
             for (const Lobe& tl : m.lobes) {
                 Lobe l = tl;
-                if (l.r_tex >= 0) l.r = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.r_tex, c));
-                if (l.t_tex >= 0) l.t = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.t_tex, c));
-                const bool keep = l.kind == LK_FRESNEL_BLEND ? !(l.r.is_black() && l.t.is_black()) : !l.r.is_black();
+                if (l.r_tex >= 0) { l.r = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.r_tex, c)); if (l.has_pre) l.r = l.pre * l.r; }
+                if (l.t_tex >= 0) { l.t = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.t_tex, c)); if (l.has_pre) l.t = l.pre * l.t; }
+                const bool keep = (l.kind == LK_FRESNEL_BLEND || l.kind == LK_FRESNEL_SPEC) ? !(l.r.is_black() && l.t.is_black())
+                                : ((l.kind == LK_SPEC_T || l.kind == LK_MICRO_T || l.kind == LK_LAMBERT_T) ? !l.t.is_black() : !l.r.is_black());
                 if (keep) local[k++] = l;
             }
             b.lobes = local; b.n = k;

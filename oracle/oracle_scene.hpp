@@ -40,11 +40,13 @@ struct Lobe {
     Spec c_eta_i, c_eta_t, c_k;  // conductor Fresnel
     int n_scale = 0; Spec scale[2];  // ScaledBxDF wrappers of MixMaterial, innermost first (scaled_bxdf.rs)
     int r_tex = -1, t_tex = -1;      // this colour is a texture evaluated per hit (set_material_texture)
+    bool has_pre = false; Spec pre;  // ... multiplied by `pre` (UberMaterial's opacity, uber.rs:133)
 };
 struct Material {
     Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; bool none = false;  // none: Material "none" / "" -> no BSDF at all
     bool textured = false;  // some lobe colour is a texture: the BSDF's lobe list is made per hit (compute_scattering_functions evaluates the textures there)
-    int param_lobe[3] = {-1, -1, -1}, param_field[3] = {0, 0, 0};  // [Kd, Ks, Kr] -> lobe index / 0 = r, 1 = t
+    int param_lobe[4] = {-1, -1, -1, -1}, param_field[4] = {0, 0, 0, 0};  // [Kd, Ks, Kr, Kt] -> lobe index / 0 = r, 1 = t
+    bool has_pre = false; Spec pre;
 };
 
 enum LightType { L_INFINITE = 0, L_DISTANT = 1, L_POINT = 2, L_AREA = 3, L_SPOT = 4 };

@@ -610,14 +610,15 @@ int pbrt_hip_set_texture_mapping(PbrtHipScene* s, uint32_t texture, int kind, co
 // texture's value at that hit.
 int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param, uint32_t texture) {
     if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: unknown material or texture");
-    if (param < 0 || param > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: param must be PBRT_HIP_PARAM_KD / KS / KR");
+    if (param < 0 || param > 3) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: param must be PBRT_HIP_PARAM_KD / KS / KR / KT");
     const PbrtHipScene::MaterialParams& mp = s->material_params[material];
     if (mp.lobe[param] < 0)
-        return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: this material has no lobe fed by that parameter (matte Kd, plastic Kd / Ks, mirror Kr and substrate Kd / Ks "
-                                                   "take textures; create the material with a non-black placeholder for the parameter)");
+        return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: this material has no lobe fed by that parameter (matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, "
+                                                   "glass Kr / Kt and uber Kd / Ks / Kr / Kt take textures; create the material with a non-black placeholder for the parameter)");
     MaterialRec& m = s->materials[material];
     LobeRec& l = s->lobes[m.lobe_base + (uint32_t)mp.lobe[param]];
     if (mp.field[param] == 0) l.r_tex1 = texture + 1u; else l.t_tex1 = texture + 1u;
+    if (mp.has_pre) { l.has_pre = 1u; std::memcpy(l.pre, mp.pre, 12); }
     m.textured = 1u;
     if (l.kind == PH_LK_LAMBERT || l.kind == PH_LK_OREN) { if (m.n_lobes == 1u) m.kd_tex1 = texture + 1u; }  // MatteMaterial: the one-lobe kernel reads kd_tex1
     s->textured_materials = true;
@@ -728,7 +729,16 @@ int pbrt_hip_add_material_glass(PbrtHipScene* s, const float kr[3], const float 
             if (tb) { LobeRec l = lobe(PH_LK_MICRO_T, T_TRANS | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; std::memcpy(l.t, t, 12); set_tr(l, urough, vrough); lobes.push_back(l); }
         }
     }
-    return push_material(s, m, lobes, true, out_id);
+    const int rc = push_material(s, m, lobes, true, out_id);
+    if (rc == PBRT_HIP_OK) {  // Kr -> the reflection colour, Kt -> the transmission colour (one FresnelSpecular lobe, or the two microfacet lobes)
+        PbrtHipScene::MaterialParams& mp = s->material_params.back();
+        for (size_t i = 0; i < lobes.size(); i++) {
+            if (lobes[i].kind == PH_LK_FRESNEL_SPEC) { mp.lobe[2] = (int)i; mp.field[2] = 0; mp.lobe[3] = (int)i; mp.field[3] = 1; }
+            else if (lobes[i].kind == PH_LK_MICRO_R) { mp.lobe[2] = (int)i; mp.field[2] = 0; }
+            else if (lobes[i].kind == PH_LK_MICRO_T) { mp.lobe[3] = (int)i; mp.field[3] = 1; }
+        }
+    }
+    return rc;
 }
 int pbrt_hip_add_material_metal(PbrtHipScene* s, const float eta[3], const float k[3], float urough, float vrough, int remap_roughness, uint32_t* out_id) {  // metal.rs:62-98
     if (!s || !eta || !k) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_metal: null argument");
@@ -765,8 +775,20 @@ int pbrt_hip_add_material_uber(PbrtHipScene* s, const float kd[3], const float k
         lobes.push_back(l);
     }
     if (scaled(kr, v)) { LobeRec l = lobe(PH_LK_SPEC_R, T_REFL | T_SPEC); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; std::memcpy(l.r, v, 12); lobes.push_back(l); }
-    if (scaled(kt, v)) { LobeRec l = lobe(PH_LK_SPEC_T, T_TRANS | T_SPEC); l.fresnel = PH_FR_DIEL; std::memcpy(l.t, v, 12); l.eta_a = 1.0f; l.eta_b = eta; lobes.push_back(l); }
-    return push_material(s, m, lobes, true, out_id);
+    int kt_lobe = -1;
+    if (scaled(kt, v)) { LobeRec l = lobe(PH_LK_SPEC_T, T_TRANS | T_SPEC); l.fresnel = PH_FR_DIEL; std::memcpy(l.t, v, 12); l.eta_a = 1.0f; l.eta_b = eta; kt_lobe = (int)lobes.size(); lobes.push_back(l); }
+    const int rc = push_material(s, m, lobes, true, out_id);
+    if (rc == PBRT_HIP_OK) {  // texturable: Kd, Ks, Kr, Kt, each multiplied by the (constant) opacity as in `op * k.evaluate().clamp_default()`
+        PbrtHipScene::MaterialParams& mp = s->material_params.back();
+        mp.has_pre = true; std::memcpy(mp.pre, op, 12);
+        for (size_t i = 0; i < lobes.size(); i++) {
+            if (lobes[i].kind == PH_LK_LAMBERT) mp.lobe[0] = (int)i;
+            else if (lobes[i].kind == PH_LK_MICRO_R) mp.lobe[1] = (int)i;
+            else if (lobes[i].kind == PH_LK_SPEC_R) mp.lobe[2] = (int)i;
+        }
+        if (kt_lobe >= 0) { mp.lobe[3] = kt_lobe; mp.field[3] = 1; }
+    }
+    return rc;
 }
 
 int pbrt_hip_add_material_substrate(PbrtHipScene* s, const float kd[3], const float ks[3], float urough, float vrough, int remap_roughness, uint32_t* out_id) {  // substrate.rs:55-84

@@ -73,6 +73,7 @@ struct alignas(16) LobeRec {
     float c_k[3], pad5;
     float scale0[3], pad6;                // innermost ScaledBxDF scale
     float scale1[3], pad7;
+    float pre[3]; uint32_t has_pre;       // a textured colour of this lobe is multiplied by `pre` (UberMaterial: `op * kd.evaluate().clamp_default()`, uber.rs:133)
 };
 
 struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant textures) + the general lobe list
@@ -88,7 +89,7 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     uint32_t textured; // some lobe of the list takes a colour from a texture: the general-BSDF kernel builds the hit's own list
     uint32_t pad[3];
 };
-#define PH_HIT_LOBES 2   // per-thread slots for the per-hit lobe list of a textured material (matte, mirror: 1; plastic: 2; substrate: 1)
+#define PH_HIT_LOBES 5   // per-thread slots for the per-hit lobe list of a textured material (uber: up to 5 lobes)
 
 // ---- textures (textures/src/*.rs, core/src/mipmap/mod.rs).  A texture is a postfix program over a small value stack: the host
 // flattens the scale / mix tree once (api.hip), the device runs it per hit (texture.h).  Float-valued textures are carried as three equal

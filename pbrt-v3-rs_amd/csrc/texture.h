@@ -402,15 +402,19 @@ PH_DEV spec tex_eval_clamped(const DeviceScene* dsc, uint32_t tex, const TexCtx&
     return mks(pclampf(v.r, 0.0f, kInf), pclampf(v.g, 0.0f, kInf), pclampf(v.b, 0.0f, kInf));
 }
 // The hit's own lobe list of a textured material: the template lobes with their textured colours filled in, a lobe dropped where the reference
-// would not add it (`if !kd.is_black()`, plastic.rs:63 / :70, mirror.rs:55, matte.rs:66; FresnelBlend unless both are black, substrate.rs:62).
+// would not add it (`if !kd.is_black()`, plastic.rs:63 / :70, mirror.rs:55, matte.rs:66, uber.rs:134-160; FresnelBlend / FresnelSpecular unless both
+// colours are black, substrate.rs:62, glass.rs:76-78).
 PH_DEV uint32_t build_hit_lobes(const DeviceScene* dsc, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, LobeRec* out) {
     uint32_t k = 0;
     for (uint32_t i = 0; i < n && k < PH_HIT_LOBES; i++) {
         LobeRec l = tmpl[i];
-        if (l.r_tex1) { const spec c = tex_eval_clamped(dsc, l.r_tex1 - 1u, ctx); l.r[0] = c.r; l.r[1] = c.g; l.r[2] = c.b; }
-        if (l.t_tex1) { const spec c = tex_eval_clamped(dsc, l.t_tex1 - 1u, ctx); l.t[0] = c.r; l.t[1] = c.g; l.t[2] = c.b; }
+        const spec pre = l.has_pre ? mks(l.pre[0], l.pre[1], l.pre[2]) : mks1(1.0f);
+        if (l.r_tex1) { spec c = tex_eval_clamped(dsc, l.r_tex1 - 1u, ctx); if (l.has_pre) c = pre * c; l.r[0] = c.r; l.r[1] = c.g; l.r[2] = c.b; }
+        if (l.t_tex1) { spec c = tex_eval_clamped(dsc, l.t_tex1 - 1u, ctx); if (l.has_pre) c = pre * c; l.t[0] = c.r; l.t[1] = c.g; l.t[2] = c.b; }
         const bool r_black = l.r[0] == 0.0f && l.r[1] == 0.0f && l.r[2] == 0.0f, t_black = l.t[0] == 0.0f && l.t[1] == 0.0f && l.t[2] == 0.0f;
-        const bool keep = l.kind == PH_LK_FRESNEL_BLEND ? !(r_black && t_black) : !r_black;
+        // which colour decides whether the reference adds the lobe: both for the two-colour lobes, t for the transmission lobes, r otherwise
+        const bool keep = (l.kind == PH_LK_FRESNEL_BLEND || l.kind == PH_LK_FRESNEL_SPEC) ? !(r_black && t_black)
+                        : ((l.kind == PH_LK_SPEC_T || l.kind == PH_LK_MICRO_T || l.kind == PH_LK_LAMBERT_T) ? !t_black : !r_black);
         if (keep) out[k++] = l;
     }
     return k;

@@ -889,7 +889,8 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     static const bool split_traversal = std::getenv("PBRT_HIP_SPLIT_TRAVERSAL") != nullptr;  // measurement aid: one launch per ray kind
     uint64_t regular = 0, shadow = 0;
     std::vector<ph::IterCounters> hctr((size_t)n_iter_cap + 2);
-    const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, 256 * 16);
+    // general materials with per-hit textures keep PH_HIT_LOBES LobeRec slots per thread of the grid: a smaller grid (each block loops more) bounds that buffer
+    const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, (s->textured_materials && s->general_materials) ? 256 * 4 : 256 * 16);
     wp.hit_lobes = nullptr;
     if (s->textured_materials && s->general_materials) {
         if ((rc = ensure_buf(s, w.d_hit_lobes, (size_t)shade_blocks * PH_SHADE_BLOCK * PH_HIT_LOBES * sizeof(LobeRec)))) return rc;

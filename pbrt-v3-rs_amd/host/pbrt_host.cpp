@@ -441,17 +441,18 @@ void Api::pbrt_area_light_source(const std::string& name, const ParamSet& p) { i
 uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::array<float, 3> kd = {0.5f, 0.5f, 0.5f};
     float sigma = 0.0f;
-    int64_t tex_param[3] = {-1, -1, -1};  // [Kd, Ks, Kr]: the parameter names a texture the library evaluates per hit
+    int64_t tex_param[4] = {-1, -1, -1, -1};  // [Kd, Ks, Kr, Kt]: the parameter names a texture the library evaluates per hit
     auto spectrum_tex = [&](const std::string& pname, std::array<float, 3> d) {
         std::string tn = m.params.find_one_texture(pname);
         if (!tn.empty()) {
             auto dt = gs_.device_textures.find(tn);
             if (dt != gs_.device_textures.end()) {
                 // a texture the library evaluates per hit: the material is created with a white placeholder and the texture attached afterwards
-                const int param = pname == "Kd" ? 0 : (pname == "Ks" ? 1 : (pname == "Kr" ? 2 : -1));
-                const bool takes = (m.type == "matte" && param == 0) || ((m.type == "plastic" || m.type == "substrate") && (param == 0 || param == 1)) || (m.type == "mirror" && param == 2);
+                const int param = pname == "Kd" ? 0 : (pname == "Ks" ? 1 : (pname == "Kr" ? 2 : (pname == "Kt" ? 3 : -1)));
+                const bool takes = (m.type == "matte" && param == 0) || ((m.type == "plastic" || m.type == "substrate") && (param == 0 || param == 1)) || (m.type == "mirror" && param == 2) ||
+                                   (m.type == "glass" && (param == 2 || param == 3)) || (m.type == "uber" && param >= 0);
                 if (!takes || dt->second.is_float) {
-                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": image-based textures are wired to matte Kd, plastic Kd / Ks, mirror Kr and substrate Kd / Ks so far";
+                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit textures are wired to matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, glass Kr / Kt and uber Kd / Ks / Kr / Kt so far";
                     return m.params.find_one_rgb(pname, d);
                 }
                 tex_param[param] = (int64_t)dt->second.id;
@@ -548,7 +549,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     if (!error.empty()) return 0;
     std::string key = t + (remap ? ":r" : ":n");
     for (float v : kv) { uint32_t u; std::memcpy(&u, &v, 4); char b[12]; std::snprintf(b, sizeof b, ":%08x", u); key += b; }
-    for (int k = 0; k < 3; k++) if (tex_param[k] >= 0) key += "|tex" + std::to_string(k) + "=" + std::to_string(tex_param[k]);
+    for (int k = 0; k < 4; k++) if (tex_param[k] >= 0) key += "|tex" + std::to_string(k) + "=" + std::to_string(tex_param[k]);
     auto it = material_cache_.find(key);
     if (it != material_cache_.end()) return it->second;
     uint32_t id = 0;
@@ -564,7 +565,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     else if (t == "mix") rc = ABI(pbrt_hip_add_material_mix(scene_, (uint32_t)f0, (uint32_t)f1, a3.data(), &id));
     else rc = ABI(pbrt_hip_add_material_uber(scene_, a3.data(), b3.data(), c3.data(), d3.data(), e3.data(), f0, f1, f2, remap ? 1 : 0, &id));
     if (!check(rc, "add_material")) return 0;
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 4; k++)
         if (tex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_texture(scene_, id, k, (uint32_t)tex_param[k])), "set_material_texture")) return 0;
     material_cache_[key] = id;
     return id;

@@ -533,10 +533,10 @@ class Scene:
     def add_material_matte_tex(self, kd_texture, sigma=0.0):
         out = C.c_uint32(0); self._chk(self.b.fn("add_material_matte_tex")(self.h, kd_texture, C.c_float(sigma), C.byref(out))); return out.value
 
-    PARAM = {"Kd": 0, "Ks": 1, "Kr": 2}
+    PARAM = {"Kd": 0, "Ks": 1, "Kr": 2, "Kt": 3}
 
     def set_material_texture(self, material, param, texture):
-        """param: "Kd" | "Ks" | "Kr" — that colour of `material` becomes `texture`, evaluated per hit."""
+        """param: "Kd" | "Ks" | "Kr" | "Kt" — that colour of `material` becomes `texture`, evaluated per hit."""
         self._chk(self.b.fn("set_material_texture")(self.h, material, self.PARAM[param], texture))
 
     def texture_eval(self, texture, uv, derivs=None, p=None, dpdx=None, dpdy=None):

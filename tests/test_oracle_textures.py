@@ -190,6 +190,17 @@ def test_a_constant_texture_is_the_constant_parameter():
         m = sc.add_material_mirror((1, 1, 1)); sc.set_material_texture(m, "Kr", tex); return m
     assert np.array_equal(film(mirror_tex), film(lambda sc, tex: sc.add_material_mirror((0.3, 0.6, 0.2))))
     assert np.array_equal(film(lambda sc, tex: sc.add_material_matte_tex(tex, 15.0)), film(lambda sc, tex: sc.add_material_matte((0.3, 0.6, 0.2), 15.0)))
+    def uber_tex(sc, tex):
+        m = sc.add_material_uber((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1), (0.8, 0.7, 0.9), 0.1, 0.2, 1.4, True)
+        for prm in ("Kd", "Ks", "Kr", "Kt"): sc.set_material_texture(m, prm, tex)
+        return m
+    c = (0.3, 0.6, 0.2)
+    assert np.array_equal(film(uber_tex), film(lambda sc, tex: sc.add_material_uber(c, c, c, c, (0.8, 0.7, 0.9), 0.1, 0.2, 1.4, True)))
+    for rough in (0.0, 0.05):
+        def glass_tex(sc, tex, rough=rough):
+            m = sc.add_material_glass((1, 1, 1), (1, 1, 1), rough, rough, 1.5, True)
+            sc.set_material_texture(m, "Kr", tex); sc.set_material_texture(m, "Kt", tex); return m
+        assert np.array_equal(film(glass_tex), film(lambda sc, tex, rough=rough: sc.add_material_glass(c, c, rough, rough, 1.5, True)))
     # a black constant texture removes the lobe exactly as a black constant does
     def black(material):
         s = OracleScene()

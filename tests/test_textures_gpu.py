@@ -146,7 +146,26 @@ def _substrate(sc, tex):
     return m
 
 
+def _uber(sc, tex):
+    m = sc.add_material_uber((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1), (0.8, 0.7, 0.9), 0.1, 0.2, 1.4, True)   # opacity < 1: the pass-through lobe exists too
+    half = sc.add_texture_scale(tex, sc.add_texture_constant((0.5, 0.5, 0.5)))
+    sc.set_material_texture(m, "Kd", tex); sc.set_material_texture(m, "Ks", half)
+    sc.set_material_texture(m, "Kr", sc.add_texture_scale(half, half)); sc.set_material_texture(m, "Kt", half)
+    return m
+
+
+def _glass(rough):
+    def make(sc, tex):
+        m = sc.add_material_glass((1, 1, 1), (1, 1, 1), rough, rough, 1.5, True)
+        sc.set_material_texture(m, "Kr", tex); sc.set_material_texture(m, "Kt", sc.add_texture_mix(tex, sc.add_texture_constant((1, 1, 1)), sc.add_texture_constant(0.5)))
+        return m
+    return make
+
+
 MATERIAL_CASES = {
+    "uber_all_four": (_uber, _tex(kind="checker", w=8, h=8)),
+    "glass_smooth_kr_kt": (_glass(0.0), _tex(kind="checker", w=8, h=8)),
+    "glass_rough_kr_kt": (_glass(0.05), _tex(w=20, h=20)),
     "plastic_kd_ks": (_plastic(), _tex()),
     "plastic_kd_checker_with_black_texels": (_plastic(ks=False), _tex(kind="checker", w=16, h=16)),   # Lambert lobe absent on the black squares
     "plastic_ks_only": (_plastic(kd=False), _tex(kind="checker", w=8, h=8, trilinear=True)),         # microfacet lobe absent there
@@ -174,8 +193,11 @@ def test_set_material_texture_errors():
     s = pbrt_hip.Scene()
     t = s.add_texture_constant((0.5, 0.5, 0.5))
     glass = s.add_material_glass((1, 1, 1), (1, 1, 1), 0.0, 0.0, 1.5, True)
+    metal = s.add_material_metal((0.2, 0.9, 1.1), (3.9, 2.4, 2.1), 0.05, 0.05, True)
     with pytest.raises(pbrt_hip.PbrtHipError, match="no lobe fed by that parameter"):
-        s.set_material_texture(glass, "Kr", t)
+        s.set_material_texture(metal, "Kr", t)
+    with pytest.raises(pbrt_hip.PbrtHipError, match="no lobe fed by that parameter"):
+        s.set_material_texture(glass, "Kd", t)
     black = s.add_material_plastic((0, 0, 0), (0.2, 0.2, 0.2), 0.1, True)     # Kd black: the Lambert lobe was never made
     with pytest.raises(pbrt_hip.PbrtHipError, match="non-black placeholder"):
         s.set_material_texture(black, "Kd", t)
