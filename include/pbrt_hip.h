@@ -184,6 +184,9 @@ int pbrt_hip_add_texture_checkerboard3d(PbrtHipScene*, uint32_t tex1, uint32_t t
  * materials with per-hit textures cannot be children of a mix yet. */
 enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2, PBRT_HIP_PARAM_KT = 3 };
 int pbrt_hip_set_material_texture(PbrtHipScene*, uint32_t material, int param, uint32_t texture);
+/* Bump mapping: Material::bump (core/src/material.rs:62-101) with the float texture `texture` as displacement, run before the BSDF of a hit is made
+ * (every material's `bumpmap` parameter).  Not for Material "none"; not for children of a mix yet. */
+int pbrt_hip_set_material_bump(PbrtHipScene*, uint32_t material, uint32_t texture);
 /* = add_material_matte((1,1,1), sigma) + set_material_texture(KD) */
 int pbrt_hip_add_material_matte_tex(PbrtHipScene*, uint32_t kd_texture, float sigma_degrees, uint32_t* out_material);
 /* Test aids: evaluate a texture on the device at explicit contexts (u, v, du/dx, dv/dx, du/dy, dv/dy, p[3], dp/dx[3], dp/dy[3]); read back the pyramid the host built. */

@@ -380,6 +380,11 @@ int oracle_set_material_texture(OracleScene* s, uint32_t material, int param, ui
     m.textured = true;
     return 0;
 }
+int oracle_set_material_bump(OracleScene* s, uint32_t material, uint32_t texture) {
+    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size()) return -1;
+    if (s->sc.materials[material].none) return -6;
+    s->sc.materials[material].bump_tex = (int)texture; return 0;
+}
 int oracle_add_material_matte_tex(OracleScene* s, uint32_t kd_tex, float sigma, uint32_t* out_id) {  // matte.rs:47-76 with a texture for Kd
     const float one[3] = {1.0f, 1.0f, 1.0f};
     uint32_t id = 0;

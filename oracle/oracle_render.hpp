@@ -322,6 +322,7 @@ struct SurfaceHit {  // the fields of Hit/SurfaceInteraction/Shading the path in
     V2 uv; V3 dpdu, dpdv;   // SurfaceInteraction.uv, der.dpdu / der.dpdv (geometric)
     Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;  // der, filled by compute_differentials
     V3 dpdx, dpdy;
+    V3 dpdv_s, dndu_s, dndv_s;  // shading.dpdv, shading.dndu, shading.dndv (consumed by Material::bump only)
 };
 
 // Ray::offset_origin (core/src/geometry/ray.rs:107-127)
@@ -422,6 +423,7 @@ struct Renderer {
         si.ns = face_forward(si.ns, si.n);
         si.dpdu_s = t.vector(si.dpdu_s);
         si.dpdu = t.vector(si.dpdu); si.dpdv = t.vector(si.dpdv);  // transform.rs:566-590
+        si.dpdv_s = t.vector(si.dpdv_s); si.dndu_s = t.normal(si.dndu_s); si.dndv_s = t.normal(si.dndv_s);
         return si;
     }
     SurfaceHit make_surface_hit_local(const Ray& r, uint32_t prim, const TriHit& h) const {
@@ -443,6 +445,7 @@ struct Renderer {
         if (m.reverse_orientation ^ m.swaps_handedness) si.n = -si.n;
         si.ns = si.n; si.dpdu_s = dpdu;
         si.dpdu = dpdu; si.dpdv = dpdv;
+        si.dpdv_s = dpdv; si.dndu_s = V3(0, 0, 0); si.dndv_s = V3(0, 0, 0);  // SurfaceInteraction::new: shading = geometric, triangles pass dndu = dndv = 0
         { V2 uv[3]; s.tri_uvs(prim, uv); si.uv = V2((b0 * uv[0].x + b1 * uv[1].x) + b2 * uv[2].x, (b0 * uv[0].y + b1 * uv[1].y) + b2 * uv[2].y); }  // triangle.rs:584
         if (m.has_n || m.has_s) {  // :631-721
             V3 ns;
@@ -458,7 +461,24 @@ struct Renderer {
             V3 ts = cross(ss, ns);
             if (length_squared(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
             else coordinate_system(ns, ss, ts);
+            V3 dndu(0, 0, 0), dndv(0, 0, 0);  // triangle.rs:681-715
+            if (m.has_n) {
+                V2 uv[3]; s.tri_uvs(prim, uv);
+                V2 duv02(uv[0].x - uv[2].x, uv[0].y - uv[2].y), duv12(uv[1].x - uv[2].x, uv[1].y - uv[2].y);
+                V3 n0 = s.N[i0], n1 = s.N[i1], n2 = s.N[i2];
+                V3 dn1 = n0 - n2, dn2 = n1 - n2;
+                Float determinant = duv02.x * duv12.y - duv02.y * duv12.x;
+                if (std::fabs(determinant) < 1e-8f) {
+                    V3 dn = cross(n2 - n0, n1 - n0);
+                    if (length_squared(dn) != 0.0f) coordinate_system(dn, dndu, dndv);
+                } else {
+                    Float invdet = 1.0f / determinant;
+                    dndu = (duv12.y * dn1 - duv02.y * dn2) * invdet;
+                    dndv = (-duv12.x * dn1 + duv02.x * dn2) * invdet;
+                }
+            }
             if (m.reverse_orientation) ts = -ts;
+            si.dpdv_s = ts; si.dndu_s = dndu; si.dndv_s = dndv;
             // set_shading_geometry(ss, ts, .., true) (surface_interaction.rs:152-173)
             si.ns = normalize(cross(ss, ts));
             si.n = face_forward(si.n, si.ns);
@@ -914,6 +934,25 @@ struct Renderer {
             return true;
         }
     };
+    // Material::bump (core/src/material.rs:62-101) + set_shading_geometry(.., false) (surface_interaction.rs:152-173)
+    void bump(SurfaceHit& si) const {
+        const Material& m = sc->materials[sc->mesh_of(si.prim).material];
+        if (m.bump_tex < 0) return;
+        TexCtx c; c.uv = si.uv; c.dudx = si.dudx; c.dvdx = si.dvdx; c.dudy = si.dudy; c.dvdy = si.dvdy; c.p = si.p; c.dpdx = si.dpdx; c.dpdy = si.dpdy;
+        Float du = 0.5f * (std::fabs(si.dudx) + std::fabs(si.dudy));
+        if (du == 0.0f) du = 0.0005f;
+        TexCtx cu = c; cu.p = si.p + du * si.dpdu_s; cu.uv = V2(si.uv.x + du, si.uv.y + 0.0f);
+        Float u_displace = tex_eval(sc->textures, sc->mipmaps, m.bump_tex, cu).c[0];
+        Float dv = 0.5f * (std::fabs(si.dvdx) + std::fabs(si.dvdy));
+        if (dv == 0.0f) dv = 0.0005f;
+        TexCtx cv = c; cv.p = si.p + dv * si.dpdv_s; cv.uv = V2(si.uv.x + 0.0f, si.uv.y + dv);
+        Float v_displace = tex_eval(sc->textures, sc->mipmaps, m.bump_tex, cv).c[0];
+        Float displace = tex_eval(sc->textures, sc->mipmaps, m.bump_tex, c).c[0];
+        V3 dpdu = si.dpdu_s + (u_displace - displace) / du * si.ns + displace * si.dndu_s;
+        V3 dpdv = si.dpdv_s + (v_displace - displace) / dv * si.ns + displace * si.dndv_s;
+        si.ns = face_forward(normalize(cross(dpdu, dpdv)), si.n);
+        si.dpdu_s = dpdu; si.dpdv_s = dpdv;
+    }
     // `local` receives the per-hit lobe list of a textured material; the returned BSDF points at it, so it must outlive the BSDF
     BSDF make_bsdf(const SurfaceHit& si, Lobe* local) const {
         const Material& m = sc->materials[sc->mesh_of(si.prim).material];
@@ -1092,6 +1131,7 @@ struct Renderer {
                 continue;
             }
             compute_differentials(isect, ray);  // SurfaceInteraction::compute_scattering_functions (surface_interaction.rs:176-195)
+            bump(isect);
             Lobe hit_lobes[8];
             BSDF bsdf = make_bsdf(isect, hit_lobes);
             V3 shading_n = isect.ns;

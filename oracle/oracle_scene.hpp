@@ -44,6 +44,7 @@ struct Lobe {
 };
 struct Material {
     Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; bool none = false;  // none: Material "none" / "" -> no BSDF at all
+    int bump_tex = -1;      // Material::bump's displacement texture (material.rs:62-101), any material
     bool textured = false;  // some lobe colour is a texture: the BSDF's lobe list is made per hit (compute_scattering_functions evaluates the textures there)
     int param_lobe[4] = {-1, -1, -1, -1}, param_field[4] = {0, 0, 0, 0};  // [Kd, Ks, Kr, Kt] -> lobe index / 0 = r, 1 = t
     bool has_pre = false; Spec pre;

@@ -625,6 +625,15 @@ int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param,
     s->uploaded = false;
     return PBRT_HIP_OK;
 }
+// Material::bump's displacement texture (core/src/material.rs:62-101; the `bumpmap` parameter every material takes)
+int pbrt_hip_set_material_bump(PbrtHipScene* s, uint32_t material, uint32_t texture) {
+    if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_bump: unknown material or texture");
+    if (s->materials[material].none) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_bump: Material \"none\" has no BSDF to bump");
+    s->materials[material].bump_tex1 = texture + 1u;
+    s->textured_materials = true; s->bump_materials = true;
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
 int pbrt_hip_add_material_matte_tex(PbrtHipScene* s, uint32_t kd_tex, float sigma_deg, uint32_t* out_id) {  // matte.rs:47-76, Kd a texture
     if (!s || kd_tex >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_matte_tex: unknown texture");
     const float one[3] = {1.0f, 1.0f, 1.0f};
@@ -836,7 +845,7 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
     for (int c = 0; c < 3; c++) tmp[c] = 1.0f - s1[c];
     clamp3(tmp, s2);
     const MaterialRec a = s->materials[material1], b = s->materials[material2];
-    if (a.textured || b.textured) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a mix of materials with per-hit textures is not supported yet");
+    if (a.textured || b.textured || a.bump_tex1 || b.bump_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a mix of materials with per-hit textures is not supported yet");
     if (a.n_lobes + b.n_lobes > 8) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: more than MAX_BXDFS = 8 lobes (BSDF::add asserts, bsdf.rs:119-125)");
     std::vector<LobeRec> lobes;
     auto take = [&](const MaterialRec& src, const float sc[3]) {

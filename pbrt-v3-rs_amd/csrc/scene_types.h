@@ -87,7 +87,8 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     uint32_t none;     // Material "none": no BSDF, the path integrator skips the surface (path.rs:142-150)
     uint32_t kd_tex1;  // 0, or 1 + the texture MatteMaterial evaluates for Kd at every hit (matte.rs:63): kd / has_bxdf are then per hit
     uint32_t textured; // some lobe of the list takes a colour from a texture: the general-BSDF kernel builds the hit's own list
-    uint32_t pad[3];
+    uint32_t bump_tex1; // 0, or 1 + the displacement texture of Material::bump (core/src/material.rs:62-101)
+    uint32_t pad[2];
 };
 #define PH_HIT_LOBES 5   // per-thread slots for the per-hit lobe list of a textured material (uber: up to 5 lobes)
 

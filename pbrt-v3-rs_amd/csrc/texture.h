@@ -420,4 +420,84 @@ PH_DEV uint32_t build_hit_lobes(const DeviceScene* dsc, const LobeRec* tmpl, uin
     return k;
 }
 
+// Material::bump (core/src/material.rs:62-101): the displacement texture is evaluated at the hit and at two shifted contexts, the shading dp/du,
+// dp/dv are tilted accordingly and set_shading_geometry(.., false) (surface_interaction.rs:152-173) makes the new shading normal.  Out of line; the shading frame's other half (dp/dv, dn/du, dn/dv: triangle.rs:631-721), which the integrator does not carry, is rebuilt from the TriRec.
+struct BumpOut { f3 ns, dpdu_s; };
+struct BumpIn { uint32_t tex, tri_index, inst; f3 bary, p, n, ns, dpdu_s; TexCtx c; };
+// arguments travel through one private struct: with ~40 scalar arguments (most of them on the stack) this function, out of line, corrupted values of OTHER
+// lanes of the wave in the one-lobe kernel on gfx950
+static __device__ __noinline__ void hit_bump(const DeviceScene* dsc, const BumpIn* in, BumpOut* out) {
+    const DeviceScene& sc = *dsc;
+    const uint32_t tex = in->tex, tri_index = in->tri_index, inst = in->inst;
+    const f3 bary = in->bary, p = in->p, n = in->n, ns = in->ns, dpdu_s = in->dpdu_s;
+    const TexCtx c = in->c;
+    const float4* tp = reinterpret_cast<const float4*>(sc.tris + tri_index);
+    const float4 a = tp[0], b = tp[1], cc = tp[2];
+    const uint32_t prim = __float_as_uint(a.w);
+    const MeshRec m = sc.meshes[__float_as_uint(cc.w)];
+    TriVerts t;
+    t.p0 = mk3(a.x, a.y, a.z); t.p1 = mk3(b.x, b.y, b.z); t.p2 = mk3(cc.x, cc.y, cc.z);
+    t.i0 = t.i1 = t.i2 = 0;
+    if (m.flags & (PH_MESH_N | PH_MESH_S | PH_MESH_UV)) { t.i0 = sc.idx[3 * prim]; t.i1 = sc.idx[3 * prim + 1]; t.i2 = sc.idx[3 * prim + 2]; }
+    f3 dpdu, dpdv;
+    tri_dpdu(sc, m, t, dpdu, dpdv);
+    f3 dpdv_s = dpdv, dndu = mk3(0.0f, 0.0f, 0.0f), dndv = dndu;   // SurfaceInteraction::new: shading = geometric, dn/du = dn/dv = 0 for triangles
+    if (m.flags & (PH_MESH_N | PH_MESH_S)) {
+        f3 ng = normalize(cross(t.p0 - t.p2, t.p1 - t.p2));
+        const bool rev = (m.flags & PH_MESH_REV) != 0, swp = (m.flags & PH_MESH_SWAP) != 0;
+        if (rev != swp) ng = -ng;
+        f3 nsh = ng, n0 = ng, n1 = ng, n2 = ng;
+        if (m.flags & PH_MESH_N) {
+            n0 = ld3(sc.N + 3 * (size_t)t.i0); n1 = ld3(sc.N + 3 * (size_t)t.i1); n2 = ld3(sc.N + 3 * (size_t)t.i2);
+            const f3 ns2 = bary.x * n0 + bary.y * n1 + bary.z * n2;
+            nsh = length_squared(ns2) > 0.0f ? normalize(ns2) : ng;
+        }
+        f3 ss;
+        if (m.flags & PH_MESH_S) {
+            const f3 ss2 = bary.x * ld3(sc.S + 3 * (size_t)t.i0) + bary.y * ld3(sc.S + 3 * (size_t)t.i1) + bary.z * ld3(sc.S + 3 * (size_t)t.i2);
+            ss = length_squared(ss2) > 0.0f ? normalize(ss2) : normalize(dpdu);
+        } else ss = normalize(dpdu);
+        f3 ts = cross(ss, nsh);
+        if (length_squared(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, nsh); }
+        else coordinate_system(nsh, ss, ts);
+        if (m.flags & PH_MESH_N) {  // dn/du, dn/dv (triangle.rs:681-715)
+            f2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);
+            if (m.flags & PH_MESH_UV) {
+                uv0 = mk2(sc.UV[2 * (size_t)t.i0], sc.UV[2 * (size_t)t.i0 + 1]); uv1 = mk2(sc.UV[2 * (size_t)t.i1], sc.UV[2 * (size_t)t.i1 + 1]);
+                uv2 = mk2(sc.UV[2 * (size_t)t.i2], sc.UV[2 * (size_t)t.i2 + 1]);
+            }
+            const f2 duv02 = mk2(uv0.x - uv2.x, uv0.y - uv2.y), duv12 = mk2(uv1.x - uv2.x, uv1.y - uv2.y);
+            const f3 dn1 = n0 - n2, dn2 = n1 - n2;
+            const float determinant = duv02.x * duv12.y - duv02.y * duv12.x;
+            if (fabsf(determinant) < 1e-8f) {
+                const f3 dn = cross(n2 - n0, n1 - n0);
+                if (length_squared(dn) != 0.0f) coordinate_system(dn, dndu, dndv);
+            } else {
+                const float invdet = ph_div(1.0f, determinant);
+                dndu = (duv12.y * dn1 - duv02.y * dn2) * invdet;
+                dndv = (-duv12.x * dn1 + duv02.x * dn2) * invdet;
+            }
+        }
+        if (rev) ts = -ts;
+        dpdv_s = ts;
+    }
+    if (inst != 0u) {  // transform_surface_interaction (transform.rs:566-590)
+        const InstRec& I = sc.instances[inst - 1u];
+        if (!(I.flags & PH_INST_IDENTITY)) { dpdv_s = xf_vec(I.i2w, dpdv_s); dndu = xf_normal(I.w2i, dndu); dndv = xf_normal(I.w2i, dndv); }
+    }
+    float du = 0.5f * (pabs(c.dudx) + pabs(c.dudy));
+    if (du == 0.0f) du = 0.0005f;
+    TexCtx cu = c; cu.p = p + du * dpdu_s; cu.uv = mk2(c.uv.x + du, c.uv.y + 0.0f);
+    const float u_displace = tex_eval(dsc, tex, cu).r;
+    float dv = 0.5f * (pabs(c.dvdx) + pabs(c.dvdy));
+    if (dv == 0.0f) dv = 0.0005f;
+    TexCtx cv = c; cv.p = p + dv * dpdv_s; cv.uv = mk2(c.uv.x + 0.0f, c.uv.y + dv);
+    const float v_displace = tex_eval(dsc, tex, cv).r;
+    const float displace = tex_eval(dsc, tex, c).r;
+    const f3 ndpdu = dpdu_s + ph_div(u_displace - displace, du) * ns + displace * dndu;
+    const f3 ndpdv = dpdv_s + ph_div(v_displace - displace, dv) * ns + displace * dndv;
+    out->ns = face_forward(normalize(cross(ndpdu, ndpdv)), n);
+    out->dpdu_s = ndpdu;
+}
+
 }  // namespace ph

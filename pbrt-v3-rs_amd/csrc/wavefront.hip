@@ -211,7 +211,7 @@ template <> struct BsdfOps<true> {
 // 51 spilled registers and gains 6 % from the fourth wave, the general-BSDF kernel would spill 181 and loses, so it stays at 3; so do the
 // texture variants, whose out-of-line calls keep many values live (textured matte: 279 spilled registers at 4 waves, 45 at 3; 19.5 -> 15.9 ms).
 #define PH_SHADE_ATTR __attribute__((amdgpu_waves_per_eu((GEN || TEX) ? 3 : 4, (GEN || TEX) ? 3 : 4)))
-template <bool GEN, bool TEX = false>
+template <bool GEN, bool TEX = false, bool BUMP = false>
 __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(DeviceScene sc, WfParams w, int it) {
     using BO = BsdfOps<GEN>;
     __shared__ float4 stage[3][2][PH_SHADE_BLOCK];           // [ext, mis, shadow][ray halves][thread]
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                 } else {
                     const float4 h1 = hp[1];
                     MeshRec m;
-                    const SurfHit si = make_surface_hit_any(sc, rd, ray.time, __float_as_uint(h1.y), __float_as_uint(h1.z), h0.z, h0.w, h1.x, m);
+                    SurfHit si = make_surface_hit_any(sc, rd, ray.time, __float_as_uint(h1.y), __float_as_uint(h1.z), h0.z, h0.w, h1.x, m);
                     if (emit) {
                         if (m.first_light >= 0) L = L + beta * area_L(sc.lights[(uint32_t)m.first_light + (hprim - m.tri_base)], si.n, -rd);
                         else L = L + beta * mks1(0.0f);
@@ -342,12 +342,14 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         stage[0][0][tid] = make_float4(re.ox, re.oy, re.oz, re.t_max);
                         stage[0][1][tid] = make_float4(re.dx, re.dy, re.dz, re.time);
                     } else if ((int)bounces < w.max_depth) {
-                        typename BO::T bsdf = BO::make(sc, si, m.material);
                         const uint32_t ppix = pid / w.chunk_spp;
                         const int2 xy = w.px_xy[ppix];
+                        TexCtx ctx;
+                        bool tex_hit = false;
                         if (TEX) {  // compiled into separate instantiations: the out-of-line calls would cost the texture-free kernels registers
                             const MaterialRec& mr = sc.materials[m.material];
-                            if (GEN ? mr.textured != 0u : mr.kd_tex1 != 0u) {  // some colour of this material is this hit's (matte.rs:63, plastic.rs:62-70, ...)
+                            tex_hit = (GEN ? mr.textured != 0u : mr.kd_tex1 != 0u) || (BUMP && mr.bump_tex1 != 0u);
+                            if (tex_hit) {  // some colour of this material, or its shading frame, is this hit's (matte.rs:63, plastic.rs:62-70, material.rs:62-101, ...)
                                 const uint32_t camera_ray = (bounces == 0u && !(flags & F_NODIFF)) ? 1u : 0u;  // only camera rays carry differentials
                                 f2 p_film = mk2(0.0f, 0.0f), lens = mk2(0.0f, 0.0f);
                                 if (camera_ray) {
@@ -355,10 +357,22 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                     p_film = mk2(w.rec_L[gsi].w, w.rec_py[gsi]);
                                     if (w.cam.lens_radius > 0.0f) { const float4 la = w.s_A[pid]; lens = mk2(la.x, la.y); }
                                 }
-                                const TexCtx ctx = hit_tex_ctx(sc.self, w.cam_dev, w.sp.spp, __float_as_uint(h1.y), __float_as_uint(h1.z), mk3(h0.z, h0.w, h1.x),
-                                                               si.p, si.n, mk3(ray.ox, ray.oy, ray.oz), rd, p_film, lens, camera_ray);
-                                BO::apply_textures(sc, bsdf, mr, ctx, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr);
+                                ctx = hit_tex_ctx(sc.self, w.cam_dev, w.sp.spp, __float_as_uint(h1.y), __float_as_uint(h1.z), mk3(h0.z, h0.w, h1.x),
+                                                  si.p, si.n, mk3(ray.ox, ray.oy, ray.oz), rd, p_film, lens, camera_ray);
+                                if (BUMP && mr.bump_tex1) {  // (its own instantiations again) Material::bump runs before the BSDF is made: it changes the shading frame the BSDF is built on
+                                    BumpIn bi; bi.tex = mr.bump_tex1 - 1u; bi.tri_index = __float_as_uint(h1.y); bi.inst = __float_as_uint(h1.z); bi.bary = mk3(h0.z, h0.w, h1.x);
+                                    bi.p = si.p; bi.n = si.n; bi.ns = si.ns; bi.dpdu_s = si.dpdu_s; bi.c = ctx;
+                                    BumpOut bo;
+                                    hit_bump(sc.self, &bi, &bo);
+                                    si.ns = bo.ns; si.dpdu_s = bo.dpdu_s;
+                                }
                             }
+                        }
+                        typename BO::T bsdf = BO::make(sc, si, m.material);
+                        if (TEX && tex_hit) {
+                            const MaterialRec& mr = sc.materials[m.material];
+                            if (GEN ? mr.textured != 0u : mr.kd_tex1 != 0u)
+                                BO::apply_textures(sc, bsdf, mr, ctx, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr);
                         }
                         SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid - ppix * w.chunk_spp), dim, hl);
                         // Draw the next 8 dimensions in one (not unrolled) loop: light pick 1D, u_light 2D, u_scattering 2D, BSDF 2D,
@@ -933,7 +947,10 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
                     }))) return rc;
             }
             if ((rc = timed(2, [&]() {
-                    if (s->textured_materials) {
+                    if (s->textured_materials && s->bump_materials) {
+                        if (s->general_materials) hipLaunchKernelGGL((ph::shade_kernel<true, true, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        else hipLaunchKernelGGL((ph::shade_kernel<false, true, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                    } else if (s->textured_materials) {
                         if (s->general_materials) hipLaunchKernelGGL((ph::shade_kernel<true, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         else hipLaunchKernelGGL((ph::shade_kernel<false, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                     } else if (s->general_materials) hipLaunchKernelGGL(ph::shade_kernel<true>, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);

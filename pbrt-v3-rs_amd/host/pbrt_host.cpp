@@ -483,7 +483,23 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
         }
         return m.params.find_one_float(pname, d);
     };
-    if (!m.params.find_one_texture("bumpmap").empty() && error.empty()) error = "'bumpmap' is outside the hot-path scope";
+    // `bumpmap`: get_float_texture_or_none (every material's From<&TextureParams>): a float texture by name, never a literal
+    int64_t bump_tex = -1;
+    {
+        const std::string bn = m.params.find_one_texture("bumpmap");
+        if (!bn.empty()) {
+            auto dt = gs_.device_textures.find(bn);
+            if (dt != gs_.device_textures.end() && dt->second.is_float) bump_tex = (int64_t)dt->second.id;
+            else if (gs_.float_textures.count(bn)) {
+                const float v = gs_.float_textures[bn]; const float c3_[3] = {v, v, v};
+                uint32_t id = 0;
+                if (!check(ABI(pbrt_hip_add_texture_constant(scene_, c3_, &id)), "add_texture_constant")) return 0;
+                bump_tex = (int64_t)id;
+            } else if (gs_.unsupported_textures.count(bn)) { if (error.empty()) error = "'bumpmap' texture '" + bn + "' of class '" + gs_.unsupported_textures[bn] + "' is not evaluated by the library"; }
+            else warn("Couldn't find float texture named '" + bn + "' for parameter 'bumpmap'");
+            if (bump_tex >= 0 && (m.type == "mix" || m.type == "none" || m.type.empty())) bump_tex = -1;   // MixMaterial and "none" have no bump map
+        }
+    }
     const bool remap = m.params.find_one_bool("remaproughness", true);
     // every float that defines the material, in order, is the cache key
     std::vector<float> kv;
@@ -549,6 +565,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     if (!error.empty()) return 0;
     std::string key = t + (remap ? ":r" : ":n");
     for (float v : kv) { uint32_t u; std::memcpy(&u, &v, 4); char b[12]; std::snprintf(b, sizeof b, ":%08x", u); key += b; }
+    if (bump_tex >= 0) key += "|bump=" + std::to_string(bump_tex);
     for (int k = 0; k < 4; k++) if (tex_param[k] >= 0) key += "|tex" + std::to_string(k) + "=" + std::to_string(tex_param[k]);
     auto it = material_cache_.find(key);
     if (it != material_cache_.end()) return it->second;
@@ -567,6 +584,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     if (!check(rc, "add_material")) return 0;
     for (int k = 0; k < 4; k++)
         if (tex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_texture(scene_, id, k, (uint32_t)tex_param[k])), "set_material_texture")) return 0;
+    if (bump_tex >= 0 && !check(ABI(pbrt_hip_set_material_bump(scene_, id, (uint32_t)bump_tex)), "set_material_bump")) return 0;
     material_cache_[key] = id;
     return id;
 }

@@ -130,6 +130,7 @@ class Binding:
             "set_texture_mapping": (C.c_int, [vp, C.c_uint32, C.c_int, fp]),
             "add_material_matte_tex": (C.c_int, [vp, C.c_uint32, C.c_float, u32p]),
             "set_material_texture": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32]),
+            "set_material_bump": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
             "texture_eval_batch": (C.c_int, [vp, C.c_uint32, C.c_uint64, fp, fp]),
             "mipmap_levels": (C.c_int, [vp, C.c_uint32, ip, ip]),
             "mipmap_level_texels": (C.c_int, [vp, C.c_uint32, C.c_int, fp]),
@@ -538,6 +539,10 @@ class Scene:
     def set_material_texture(self, material, param, texture):
         """param: "Kd" | "Ks" | "Kr" | "Kt" — that colour of `material` becomes `texture`, evaluated per hit."""
         self._chk(self.b.fn("set_material_texture")(self.h, material, self.PARAM[param], texture))
+
+    def set_material_bump(self, material, texture):
+        """Material::bump with the float texture `texture` as displacement map."""
+        self._chk(self.b.fn("set_material_bump")(self.h, material, texture))
 
     def texture_eval(self, texture, uv, derivs=None, p=None, dpdx=None, dpdy=None):
         """Evaluates `texture` at uv (n,2) with (du/dx, dv/dx, du/dy, dv/dy) (n,4) and, for the 3D textures, the hit point p (n,3) with dp/dx, dp/dy;

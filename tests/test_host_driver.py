@@ -47,7 +47,7 @@ def test_check_mode_crop_and_outfile(tmp_path):
     ('WorldBegin\nShape "sphere" "float radius" 1\nWorldEnd\n', 'Shape "sphere" is outside the hot-path scope'),
     ('WorldBegin\nMaterial "kdsubsurface"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', 'Material "kdsubsurface"'),
     ('WorldBegin\nMaterial "metal"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "give 'rgb eta' and 'rgb k'"),
-    ('WorldBegin\nTexture "b" "float" "fbm"\nMaterial "plastic" "texture bumpmap" "b"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "bumpmap"),
+    ('WorldBegin\nTexture "b" "float" "ptex"\nMaterial "plastic" "texture bumpmap" "b"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "bumpmap"),
     ('WorldBegin\nMakeNamedMedium "fog" "string type" "homogeneous"\nWorldEnd\n', "directive 'MakeNamedMedium'"),
     ('WorldBegin\nObjectBegin "a"\nAreaLightSource "diffuse"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nObjectEnd\nWorldEnd\n',
      "AreaLightSource inside ObjectBegin"),

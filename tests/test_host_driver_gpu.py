@@ -342,7 +342,8 @@ Material "matte" "texture Kd" "blend"
 Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [{ds.fl(Q)}] "float uv" [{ds.fl(UVQ)}]
 Material "matte" "texture Kd" "hdr" "float sigma" 20
 Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [{ds.fl(W)}] "float st" [{ds.fl(UVW)}]
-Material "plastic" "texture Kd" "wood" "texture Ks" "tint" "float roughness" 0.05
+Texture "bumps" "float" "scale" "texture tex1" "amt" "float tex2" 0.05
+Material "plastic" "texture Kd" "wood" "texture Ks" "tint" "float roughness" 0.05 "texture bumpmap" "bumps"
 Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-3 1 0.01  -1 1 0.01  -2 2.5 1.5] "float uv" [0 0 1 0 0.5 1]
 MakeNamedMaterial "glossy" "string type" "substrate" "texture Kd" "blend" "rgb Ks" [0.05 0.05 0.05] "float uroughness" 0.1 "float vroughness" 0.2
 NamedMaterial "glossy"
@@ -380,6 +381,7 @@ WorldEnd
         s.add_mesh(W, [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(hd, 20.0), UV=UVW)
         tri_uv = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
         pl = s.add_material_plastic((1, 1, 1), (1, 1, 1), 0.05, True); s.set_material_texture(pl, "Kd", wood); s.set_material_texture(pl, "Ks", tint)
+        s.set_material_bump(pl, s.add_texture_scale(amt, s.add_texture_constant(0.05)))
         s.add_mesh(np.array([[-3, 1, 0.01], [-1, 1, 0.01], [-2, 2.5, 1.5]], np.float32), [0, 1, 2], pl, UV=tri_uv)
         sb_ = s.add_material_substrate((1, 1, 1), (0.05, 0.05, 0.05), 0.1, 0.2, True); s.set_material_texture(sb_, "Kd", blend)
         s.add_mesh(np.array([[1, 1, 0.01], [3, 1, 0.01], [2, 2.5, 1.5]], np.float32), [0, 1, 2], sb_, UV=tri_uv)

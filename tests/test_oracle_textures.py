@@ -372,3 +372,35 @@ def test_spherical_cylindrical_planar_mappings():
     # only 2D textures take one
     with pytest.raises(Exception):
         s.set_texture_mapping(s.add_texture_fbm(), "planar", [1, 0, 0, 0, 1, 0, 0, 0])
+
+
+def test_bump_mapping_pins():
+    """A constant displacement on a flat untangented mesh changes nothing (the differences vanish and dn/du = dn/dv = 0); a displacement that is
+    linear in u tilts the shading normal by exactly atan(slope / |dp/du|): checked through the radiance of a mirror looking at a gradient sky is
+    overkill — the shading normal is observable through a Lambertian floor under a distant light: L = Kd/pi * E * cos(theta)."""
+    import pbrt_hip
+    host = pbrt_hip.Host()
+
+    def floor_radiance(bump):
+        s = OracleScene()
+        mat = s.add_material_matte((0.5, 0.5, 0.5), 0.0)
+        if bump is not None: s.set_material_bump(mat, bump(s))
+        P = np.array([[-50, -50, 0], [50, -50, 0], [50, 50, 0], [-50, 50, 0]], np.float32)
+        UV = np.array([[0, 0], [100, 0], [100, 100], [0, 100]], np.float32)      # |dp/du| = |dp/dv| = 1
+        s.add_mesh(P, [0, 1, 2, 0, 2, 3], mat, UV=UV)
+        s.add_light_distant((3.0, 3.0, 3.0), (0.0, 0.0, 1.0))                    # light arriving straight down
+        w2c, c2w = host.look_at((0, 0, 5), (0, 0, 0), (0, 1, 0))
+        s.set_camera_perspective(host.perspective_raster_to_camera(10.0, 8, 8), c2w)
+        cb, table, sb = host.film_box(8, 8)
+        s.set_film(8, 8, cb, (0.5, 0.5), table); s.set_sampler(0, 1, sb); s.build_accel(0, 4)
+        xyz, wt, _, _ = s.render_path_ex(max_depth=1, light_strategy=0)
+        return s.film_to_rgb(xyz, wt).reshape(8, 8, 3)[2:6, 2:6, 1].mean()
+    flat = floor_radiance(None)
+    assert np.isclose(flat, 0.5 / np.pi * 3.0, rtol=1e-5)
+    assert floor_radiance(lambda s: s.add_texture_constant(0.7)) == flat
+    # displacement d = k * u: dp/du' = dp/du + k n  ->  the shading normal tilts by atan(k); the shading normal only enters |wi . ns|
+    # in estimate_direct, while the Lambertian f and the light are unchanged: L = flat * cos(atan(k))
+    for k in (0.5, 2.0):
+        ramp = lambda s, k=k: s.add_texture_bilerp(0.0, 0.0, k, k)                # v00, v01, v10, v11: value = k * u on [0,1]^2 ... and beyond, linearly
+        got = floor_radiance(ramp)
+        assert np.isclose(got, flat * np.cos(np.arctan(k)), rtol=2e-4), (got, flat * np.cos(np.arctan(k)))

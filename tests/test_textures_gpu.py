@@ -321,3 +321,76 @@ def test_2d_mappings_lookups_and_scene_bit_exact():
             set_libm_mode(0)
         gxyz, gwt, _ = prod.render_path(max_depth=3)
         assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
+
+
+def _bumped(base, bump_builder):
+    def make(sc, tex):
+        m = base(sc, tex)
+        sc.set_material_bump(m, bump_builder(sc))
+        return m
+    return make
+
+
+def _float_image(sc, **kw):
+    return sc.add_texture_imagemap(sc.add_mipmap(make_image(32, 32, seed=21), as_float=True, **kw), su=2.0, sv=2.0)
+
+
+BUMP_CASES = {
+    "matte_image_bump": (_bumped(lambda sc, tex: sc.add_material_matte((0.6, 0.6, 0.6), 0.0), _float_image), {}),
+    "textured_matte_trilinear_bump_lens": (_bumped(lambda sc, tex: sc.add_material_matte_tex(tex, 10.0), lambda sc: _float_image(sc, trilinear=True)), dict(lens_radius=0.03)),
+    "plastic_wrinkled_bump_instanced": (_bumped(_plastic(), lambda sc: sc.add_texture_scale(sc.add_texture_fbm(omega=0.6, octaves=5, wrinkled=True), sc.add_texture_constant(0.05))), dict(instance=True)),
+    "glass_dots_bump": (_bumped(_glass(0.0), lambda sc: sc.add_texture_dots(sc.add_texture_constant(0.02), sc.add_texture_constant(0.0), su=6.0, sv=6.0)), {}),
+    "mirror_constant_bump": (_bumped(_mirror, lambda sc: sc.add_texture_constant(0.3)), {}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BUMP_CASES))
+def test_bump_mapping_film_bit_exact(name):
+    material, kw = BUMP_CASES[name]
+    prod, orc = _render_pair(_tex(), material=material, res=48, **kw)
+    set_libm_mode(1)
+    try:
+        oxyz, owt, ost, _ = orc.render_path_ex(max_depth=4)
+    finally:
+        set_libm_mode(0)
+    gxyz, gwt, gst = prod.render_path(max_depth=4)
+    assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
+    assert gst.regular_rays == ost.regular_rays and gst.shadow_rays == ost.shadow_rays
+
+
+def test_bump_on_a_mesh_with_vertex_normals_and_tangents():
+    """dn/du, dn/dv and the shading dp/dv only matter to bump mapping: a curved patch with N, S and UV per vertex, also through an instance."""
+    n = 6
+    g = np.linspace(-1, 1, n + 1, dtype=np.float32)
+    X, Y = np.meshgrid(g, g, indexing="xy")
+    Z = (0.3 * np.cos(1.5 * X) * np.cos(1.2 * Y)).astype(np.float32)
+    P = np.stack([2 * X.ravel(), 2 * Y.ravel(), Z.ravel() + 0.3], axis=1).astype(np.float32)
+    N = np.stack([0.45 * np.sin(1.5 * X) * np.cos(1.2 * Y), 0.36 * np.cos(1.5 * X) * np.sin(1.2 * Y), np.ones_like(X)], axis=2).reshape(-1, 3).astype(np.float32)
+    N /= np.linalg.norm(N, axis=1, keepdims=True)
+    S = np.tile(np.array([[1.0, 0.2, 0.0]], np.float32), (len(P), 1))
+    UV = np.stack([(X.ravel() + 1) * 1.5, (Y.ravel() + 1) * 1.5], axis=1).astype(np.float32)
+    idx = []
+    for j in range(n):
+        for i in range(n):
+            a = j * (n + 1) + i; b = a + 1; c = a + n + 1; d = c + 1
+            idx += [a, b, d, a, d, c]
+    idx = np.array(idx, np.uint32)
+    for instanced in (False, True):
+        def extra(sc):
+            m = sc.add_material_plastic((0.7, 0.3, 0.2), (0.3, 0.3, 0.3), 0.08, True)
+            sc.set_material_bump(m, sc.add_texture_imagemap(sc.add_mipmap(make_image(64, 64, seed=5), as_float=True, scale=0.08), su=1.0, sv=1.0))
+            if instanced:
+                host = pbrt_hip.Host()
+                ob = sc.object_begin(); sc.add_mesh(P, idx, m, N=N, S=S, UV=UV); sc.object_end()
+                t = host.compose(host.translate([0.0, 0.5, 0.6]), host.rotate(15.0, [1, 0, 0]))
+                sc.add_instance(ob, t[0], t[1])
+            else:
+                sc.add_mesh(P + np.array([0, 0.5, 0.6], np.float32), idx, m, N=N, S=S, UV=UV)
+        prod, orc = _render_pair(_tex(), extra=extra, res=48)
+        set_libm_mode(1)
+        try:
+            oxyz, owt, _, _ = orc.render_path_ex(max_depth=3)
+        finally:
+            set_libm_mode(0)
+        gxyz, gwt, _ = prod.render_path(max_depth=3)
+        assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
