@@ -198,6 +198,10 @@ int pbrt_hip_mipmap_level_texels(PbrtHipScene*, uint32_t mipmap, int level, floa
 /* Lights are numbered in call order = position in Scene::lights (core/src/scene.rs:50-75). */
 int pbrt_hip_add_light_infinite(PbrtHipScene*, const float L_rgb[3], const float light_to_world[16],
                                 const float world_to_light[16]);       /* lights/src/infinite.rs:63-107, constant L */
+/* InfiniteAreaLight with a radiance map (`mapname`; lights/src/infinite.rs:52-100): `rgb` = width*height texels as read_image returns them (row 0 = top);
+ * the library multiplies them by L, builds the MIPMap (EWA, repeat; no y flip on this path, as in the reference) and the Distribution2D of the 2w x 2h
+ * scalar image (compute_scalar_image, :326-369).  Le / sample_li / pdf_li / power then follow :127-211. */
+int pbrt_hip_add_light_infinite_map(PbrtHipScene*, const float L[3], int width, int height, const float* rgb, const float light_to_world[16], const float world_to_light[16]);
 int pbrt_hip_add_light_distant(PbrtHipScene*, const float L_rgb[3], const float w_light_world[3]); /* distant.rs:36-50: already transformed+normalized */
 int pbrt_hip_add_light_point(PbrtHipScene*, const float I_rgb[3], const float p_world[3]);         /* point.rs:36-55 */
 int pbrt_hip_add_light_spot(PbrtHipScene*, const float I_rgb[3], const float light_to_world[16], const float world_to_light[16],

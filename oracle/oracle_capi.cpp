@@ -231,6 +231,39 @@ int oracle_add_light_infinite(OracleScene* s, const float L[3], const float l2w[
     s->sc.lights.push_back(l);
     return 0;
 }
+// InfiniteAreaLight::new with a texmap (lights/src/infinite.rs:52-100): texels = image * L (no y flip here), MIPMap (EWA, repeat, 8), scalar image, Distribution2D
+int oracle_add_light_infinite_map(OracleScene* s, const float L[3], int width, int height, const float* rgb, const float l2w[16], const float w2l[16]) {
+    if (!s || !L || !rgb || !l2w || !w2l || width <= 0 || height <= 0) return -1;
+    Light l{}; l.type = L_INFINITE; l.L = spec3(L); l.l2w = Transform(m4_from(l2w), m4_from(w2l)); l.two_sided = 0; l.prim = 0xFFFFFFFFu; l.area = 0;
+    infinite_light_setup(l);  // keeps the constant-light fields defined
+    std::vector<Spec> tex((size_t)width * height);
+    for (size_t i = 0; i < tex.size(); i++) tex[i] = Spec(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]) * l.L;
+    MipMap m; m.filtering = TEX_FILTER_EWA; m.wrap = TEX_WRAP_REPEAT; m.max_anisotropy = 8.0f; m.is_float = false;
+    m.build_from(tex, (size_t)width, (size_t)height);
+    for (int i = 0; i < WEIGHT_LUT_SIZE; i++) { Float r2 = (Float)i / (Float)(WEIGHT_LUT_SIZE - 1); m.weight_lut[i] = std::exp(-2.0f * r2) - std::exp(-2.0f); }
+    const size_t dw = 2 * (size_t)m.pyr[0].w, dh = 2 * (size_t)m.pyr[0].h;   // compute_scalar_image (:326-369)
+    const Float fwidth = 0.5f / (Float)(dw < dh ? dw : dh);
+    l.dw = (int)dw; l.dh = (int)dh;
+    l.d_cond_func.resize(dw * dh); l.d_cond_cdf.resize((dw + 1) * dh); l.d_cond_int.resize(dh);
+    std::vector<Float> marg(dh);
+    for (size_t v = 0; v < dh; v++) {
+        Float vp = ((Float)v + 0.5f) / (Float)dh;
+        Float sin_theta = std::sin(PI * ((Float)v + 0.5f) / (Float)dh);
+        std::vector<Float> row(dw);
+        for (size_t u = 0; u < dw; u++) { Float up = ((Float)u + 0.5f) / (Float)dw; row[u] = m.lookup_triangle_host(V2(up, vp), fwidth).y() * sin_theta; }
+        Dist1D d; d.init(row);
+        for (size_t u = 0; u < dw; u++) l.d_cond_func[v * dw + u] = d.func[u];
+        for (size_t u = 0; u <= dw; u++) l.d_cond_cdf[v * (dw + 1) + u] = d.cdf[u];
+        l.d_cond_int[v] = d.func_int; marg[v] = d.func_int;
+    }
+    Dist1D d; d.init(marg);
+    l.d_marg_func = d.func; l.d_marg_cdf = d.cdf; l.d_marg_int = d.func_int;
+    s->sc.mipmaps.push_back(std::move(m));
+    l.map_mip = (int)s->sc.mipmaps.size() - 1;
+    s->sc.infinite_lights.push_back((int)s->sc.lights.size());
+    s->sc.lights.push_back(l);
+    return 0;
+}
 int oracle_add_light_distant(OracleScene* s, const float L[3], const float w[3]) {
     if (!s || !L || !w) return -1;
     Light l{}; l.type = L_DISTANT; l.L = Spec(L[0], L[1], L[2]); l.w_light = V3(w[0], w[1], w[2]);

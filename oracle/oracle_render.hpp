@@ -305,6 +305,15 @@ inline void infinite_light_setup(Light& l) {  // lights/src/infinite.rs:63-107, 
     for (int i = 0; i < 3; i++) l.marg_cdf[i] = d.cdf[i];
     l.marg_int = d.func_int;
 }
+// Distribution1D::sample_continuous over arrays of any length (distribution_1d.rs:55-79)
+inline Float distn_sample_continuous(const Float* func, const Float* cdf, size_t n, Float func_int, Float u, Float& pdf, size_t& off) {
+    size_t offset = find_interval(n + 1, [&](size_t i) { return cdf[i] <= u; });
+    Float du = u - cdf[offset];
+    if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
+    pdf = func_int > 0.0f ? func[offset] / func_int : 0.0f;
+    off = offset;
+    return ((Float)offset + du) / (Float)n;
+}
 inline Float dist2_sample_continuous(const Float func[2], const Float cdf[3], Float func_int, Float u, Float& pdf, size_t& off) {
     size_t offset = find_interval(3, [&](size_t i) { return cdf[i] <= u; });
     Float du = u - cdf[offset];
@@ -493,6 +502,7 @@ struct Renderer {
         if (l.type != L_INFINITE) return Spec(0.0f);
         V3 w = normalize(l.l2w.inv().vector(ray.d));
         V2 st(spherical_phi(w) * INV_TWO_PI, spherical_theta(w) * INV_PI);
+        if (l.map_mip >= 0) return sc->mipmaps[(size_t)l.map_mip].triangle(0, st);   // lookup_triangle(st, 0.0): level < 0 -> triangle(0, st)
         return infinite_lookup(l.L, st);
     }
     LiSample light_sample_li(const Light& l, const SurfaceHit& hit, V2 u) const {
@@ -500,9 +510,14 @@ struct Renderer {
         const Scene& s = *sc;
         switch (l.type) {
         case L_INFINITE: {  // infinite.rs:133-173
-            Float pdf1, pdf0; size_t v, dummy;
-            Float d1 = dist2_sample_continuous(l.marg_func, l.marg_cdf, l.marg_int, u.y, pdf1, v);
-            Float d0 = dist2_sample_continuous(l.cond_func[v], l.cond_cdf[v], l.cond_int[v], u.x, pdf0, dummy);
+            Float pdf1, pdf0, d1, d0; size_t v, dummy;
+            if (l.map_mip >= 0) {  // Distribution2D::sample_continuous (distribution_2d.rs:31-49)
+                d1 = distn_sample_continuous(l.d_marg_func.data(), l.d_marg_cdf.data(), (size_t)l.dh, l.d_marg_int, u.y, pdf1, v);
+                d0 = distn_sample_continuous(l.d_cond_func.data() + v * (size_t)l.dw, l.d_cond_cdf.data() + v * (size_t)(l.dw + 1), (size_t)l.dw, l.d_cond_int[v], u.x, pdf0, dummy);
+            } else {
+                d1 = dist2_sample_continuous(l.marg_func, l.marg_cdf, l.marg_int, u.y, pdf1, v);
+                d0 = dist2_sample_continuous(l.cond_func[v], l.cond_cdf[v], l.cond_int[v], u.x, pdf0, dummy);
+            }
             Float map_pdf = pdf0 * pdf1;
             if (map_pdf == 0.0f) return r;
             Float theta = d1 * PI, phi = d0 * TWO_PI;
@@ -511,7 +526,7 @@ struct Renderer {
             r.pdf = map_pdf / (TWO_PI * PI * sin_theta);
             if (sin_theta == 0.0f) r.pdf = 0.0f;
             r.vp = hit.p + r.wi * (2.0f * s.world_radius);
-            r.value = infinite_lookup(l.L, V2(d0, d1));
+            r.value = l.map_mip >= 0 ? sc->mipmaps[(size_t)l.map_mip].triangle(0, V2(d0, d1)) : infinite_lookup(l.L, V2(d0, d1));
             r.valid = true; return r;
         }
         case L_DISTANT:  // distant.rs:87-96
@@ -565,6 +580,10 @@ struct Renderer {
             Float theta = spherical_theta(w), phi = spherical_phi(w), sin_theta = o_sin(theta);
             if (sin_theta == 0.0f) return 0.0f;
             V2 p(phi * INV_TWO_PI, theta * INV_PI);  // Distribution2D::pdf (distribution_2d.rs:51-65)
+            if (l.map_mip >= 0) {
+                size_t iu = pclamp<size_t>(f2usize(p.x * (Float)l.dw), 0, (size_t)l.dw - 1), iv = pclamp<size_t>(f2usize(p.y * (Float)l.dh), 0, (size_t)l.dh - 1);
+                return (l.d_cond_func[iv * (size_t)l.dw + iu] / l.d_marg_int) / (TWO_PI * PI * sin_theta);
+            }
             size_t iu = pclamp<size_t>(f2usize(p.x * 2.0f), 0, 1), iv = pclamp<size_t>(f2usize(p.y * 2.0f), 0, 1);
             return (l.cond_func[iv][iu] / l.marg_int) / (TWO_PI * PI * sin_theta);
         }
@@ -581,7 +600,9 @@ struct Renderer {
     Spec light_power(const Light& l) const {
         const Scene& s = *sc;
         switch (l.type) {
-        case L_INFINITE: return PI * s.world_radius * s.world_radius * infinite_lookup(l.L, V2(0.5f, 0.5f));  // infinite.rs:176-183
+        case L_INFINITE:  // infinite.rs:176-183
+            if (l.map_mip >= 0) return PI * s.world_radius * s.world_radius * s.mipmaps[(size_t)l.map_mip].lookup_triangle_host(V2(0.5f, 0.5f), 0.5f);
+            return PI * s.world_radius * s.world_radius * infinite_lookup(l.L, V2(0.5f, 0.5f));
         case L_DISTANT: return l.L * PI * s.world_radius * s.world_radius;                                      // distant.rs:98-101
         case L_SPOT: return l.L * TWO_PI * (1.0f - 0.5f * (l.cos_falloff_start + l.cos_total_width));                    // spot.rs:86-88
         case L_POINT: return (4.0f * PI) * l.L;                                                                 // point.rs:95-97

@@ -64,6 +64,9 @@ struct Light {
     // infinite: 2x2 scalar image distribution (lights/src/infinite.rs:326-369, sampling/distribution_2d.rs)
     Float cond_func[2][2], cond_cdf[2][3], cond_int[2];
     Float marg_func[2], marg_cdf[3], marg_int;
+    // infinite with a radiance map (mapname): the MIPMap (scene.mipmaps[map_mip], built unflipped) and the Distribution2D over its 2w x 2h scalar image
+    int map_mip = -1; int dw = 0, dh = 0;
+    std::vector<Float> d_cond_func, d_cond_cdf, d_cond_int, d_marg_func, d_marg_cdf; Float d_marg_int = 0;
 };
 
 struct Mesh {

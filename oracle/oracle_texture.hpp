@@ -87,6 +87,10 @@ struct MipMap {
                 else img[y * w + x] = Spec(scale * (gamma ? inv_gamma_correct(in.c[0]) : in.c[0]), scale * (gamma ? inv_gamma_correct(in.c[1]) : in.c[1]),
                                            scale * (gamma ? inv_gamma_correct(in.c[2]) : in.c[2]));
             }
+        build_from(img, w, h);
+    }
+    // MIPMap::new on texels that are already in texture orientation (mipmap/mod.rs:115-189)
+    void build_from(std::vector<Spec> img, size_t w, size_t h) {
         size_t rw = w, rh = h;
         auto pow2 = [](size_t v) { return v && !(v & (v - 1)); };
         if (!pow2(w) || !pow2(h)) {  // resample_image (mipmap/mod.rs:383-529)
@@ -139,6 +143,16 @@ struct MipMap {
         }
     }
 
+    // lookup_triangle at BUILD time (InfiniteAreaLight::new, infinite.rs:326-369 / :176-183): host libm log2f, like the reference
+    Spec lookup_triangle_host(V2 st, Float width) const {
+        const size_t levels = pyr.size();
+        Float level = (Float)levels - 1.0f + std::log2(pmax(width, 1e-8f));
+        if (level < 0.0f) return triangle(0, st);
+        if (level >= (Float)(levels - 1)) return texel(levels - 1, 0, 0);
+        size_t il = f2usize(std::floor(level));
+        Float delta = level - (Float)il;
+        return triangle(il, st) * (1.0f - delta) + triangle(il + 1, st) * delta;
+    }
     Spec triangle(size_t level, V2 st) const {  // mipmap/mod.rs:293-312
         level = pclamp<size_t>(level, 0, pyr.size() - 1);
         Float s = st.x * (Float)pyr[level].w - 0.5f, t = st.y * (Float)pyr[level].h - 0.5f;

@@ -100,6 +100,7 @@ int upload_scene(PbrtHipScene* s) {
         if ((rc = upload_vec(s, lut, &d.ewa_lut))) return rc;
     }
     if ((rc = upload_vec(s, s->lights, &d.lights))) return rc;
+    if ((rc = upload_vec(s, s->light_dist, &d.light_dist))) return rc;
     d.n_lights = (uint32_t)s->lights.size();
     if ((rc = upload_vec(s, s->infinite_lights, &d.infinite_lights))) return rc;
     d.n_infinite = (uint32_t)s->infinite_lights.size();
@@ -125,6 +126,44 @@ int upload_scene(PbrtHipScene* s) {
     return PBRT_HIP_OK;
 }
 
+namespace {
+// Host-side MIPMap::texel / triangle / lookup_triangle (mipmap/mod.rs:222-238, 293-312, 569-608) over the texel pool, for what InfiniteAreaLight does at
+// construction time (compute_scalar_image, power): host libm log2f, as in the reference.
+struct Rgb { float c[3]; };
+Rgb hmip_texel(const PbrtHipScene* s, const MipRec& m, uint32_t level, long long x, long long y) {
+    const long long W = (long long)m.level_w[level], H = (long long)m.level_h[level];
+    auto rem = [](long long a, long long b) { long long r = a - (a / b) * b; return r < 0 ? r + b : r; };
+    if (m.wrap == 0u) { x = rem(x, W); y = rem(y, H); }
+    else if (m.wrap == 2u) { x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x); y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y); }
+    else if (x < 0 || x >= W || y < 0 || y >= H) return Rgb{{0.0f, 0.0f, 0.0f}};
+    const Texel& t = s->texels[(size_t)m.level_off[level] + (size_t)y * (size_t)W + (size_t)x];
+    return Rgb{{t.r, t.g, t.b}};
+}
+Rgb hmip_triangle(const PbrtHipScene* s, const MipRec& m, uint32_t level, float u, float v) {
+    if (level > m.n_levels - 1u) level = m.n_levels - 1u;
+    const float x = u * (float)m.level_w[level] - 0.5f, y = v * (float)m.level_h[level] - 0.5f;
+    const float fx = std::floor(x), fy = std::floor(y);
+    const long long x0 = (long long)fx, y0 = (long long)fy;
+    const float ds = x - (float)x0, dt = y - (float)y0;
+    const Rgb a = hmip_texel(s, m, level, x0, y0), b = hmip_texel(s, m, level, x0, y0 + 1), c = hmip_texel(s, m, level, x0 + 1, y0), d = hmip_texel(s, m, level, x0 + 1, y0 + 1);
+    Rgb r;
+    for (int k = 0; k < 3; k++) r.c[k] = ((a.c[k] * (1.0f - ds) * (1.0f - dt) + b.c[k] * (1.0f - ds) * dt) + c.c[k] * ds * (1.0f - dt)) + d.c[k] * ds * dt;
+    return r;
+}
+Rgb hmip_lookup_triangle(const PbrtHipScene* s, const MipRec& m, float u, float v, float width) {
+    const uint32_t levels = m.n_levels;
+    const float level = (float)levels - 1.0f + std::log2(width > 1e-8f ? width : 1e-8f);
+    if (level < 0.0f) return hmip_triangle(s, m, 0u, u, v);
+    if (level >= (float)(levels - 1u)) return hmip_texel(s, m, levels - 1u, 0, 0);
+    const uint32_t il = (uint32_t)std::floor(level);
+    const float delta = level - (float)il;
+    const Rgb a = hmip_triangle(s, m, il, u, v), b = hmip_triangle(s, m, il + 1u, u, v);
+    Rgb r;
+    for (int k = 0; k < 3; k++) r.c[k] = a.c[k] * (1.0f - delta) + b.c[k] * delta;
+    return r;
+}
+}  // namespace
+
 // Light::power().y() per light -> Distribution1D (core/src/integrator/common.rs:304-311); uniform = all ones
 // (core/src/light_distrib/uniform.rs:24-31).  create_light_sample_distribution forces Uniform for a single light.
 int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
@@ -141,6 +180,7 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
             for (int c = 0; c < 3; c++) {
                 switch (l.type) {
                 case PH_L_INFINITE: {  // infinite.rs:176-183: PI * r * r * lookup_triangle((.5,.5), .5)
+                    if (l.map_mip1) { const Rgb t = hmip_lookup_triangle(s, s->mipmaps[l.map_mip1 - 1u], 0.5f, 0.5f, 0.5f); p[c] = hm::kPi * wr * wr * t.c[c]; break; }
                     // 1x1 MIPMap::triangle at st=(0.5,0.5): s = 0, ds = 0 -> tx*1*1 + tx*1*0 + tx*0*1 + tx*0*0
                     float tx = l.L[c];
                     float v = tx * (1.0f - 0.0f) * (1.0f - 0.0f) + tx * (1.0f - 0.0f) * 0.0f + tx * 0.0f * (1.0f - 0.0f) + tx * 0.0f * 0.0f;
@@ -426,24 +466,9 @@ int push_texture(PbrtHipScene* s, PbrtHipScene::TextureHost&& t, uint32_t* out_i
 }
 }  // namespace
 
-// generate_mipmap + MIPMap::new (mipmap/cache.rs:74-120, mipmap/mod.rs:115-189): flip in y, convert texels, resample to powers of
-// two, box-filter the pyramid.  Texels are kept as three floats per texel while building.
-int pbrt_hip_add_mipmap(PbrtHipScene* s, int width, int height, const float* rgb, int as_float, float scale, int gamma, int filtering, int wrap,
-                        float max_anisotropy, uint32_t* out_id) {
-    if (!s || !rgb) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: null argument");
-    if (width <= 0 || height <= 0 || width > 32768 || height > 32768) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: resolution must be within 1..32768");
-    if (filtering < 0 || filtering > 1 || wrap < 0 || wrap > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: unknown filtering / wrap mode");
-    size_t w = (size_t)width, h = (size_t)height;
-    std::vector<float> img(3 * w * h);
-    for (size_t y = 0; y < h; y++)
-        for (size_t x = 0; x < w; x++) {
-            const float* px = rgb + 3 * ((h - 1 - y) * w + x);  // texture space has (0,0) at the lower left
-            float* o = &img[3 * (y * w + x)];
-            if (as_float) {  // ConvertIn<Float> for RGBSpectrum (convert_in.rs:37-47)
-                const float lum = 0.212671f * px[0] + 0.715160f * px[1] + 0.072169f * px[2];
-                o[0] = o[1] = o[2] = scale * (gamma ? inv_gamma_correct(lum) : lum);
-            } else for (int c = 0; c < 3; c++) o[c] = scale * (gamma ? inv_gamma_correct(px[c]) : px[c]);
-        }
+namespace {
+// MIPMap::new (mipmap/mod.rs:115-189) on texels already in texture orientation, three floats per texel
+int build_pyramid(PbrtHipScene* s, std::vector<float> img, size_t w, size_t h, int filtering, int wrap, bool as_float, float max_anisotropy, uint32_t* out_id) {
     auto is_pow2 = [](size_t v) { return (v & (v - 1)) == 0; };
     if (!is_pow2(w) || !is_pow2(h)) {  // resample_image (mipmap/mod.rs:383-529)
         size_t rw = 1, rh = 1;
@@ -510,6 +535,27 @@ int pbrt_hip_add_mipmap(PbrtHipScene* s, int width, int height, const float* rgb
     if (out_id) *out_id = (uint32_t)s->mipmaps.size() - 1;
     s->uploaded = false;
     return PBRT_HIP_OK;
+}
+}  // namespace
+// generate_mipmap + MIPMap::new (mipmap/cache.rs:74-120, mipmap/mod.rs:115-189): flip in y, convert texels, resample to powers of
+// two, box-filter the pyramid.  Texels are kept as three floats per texel while building.
+int pbrt_hip_add_mipmap(PbrtHipScene* s, int width, int height, const float* rgb, int as_float, float scale, int gamma, int filtering, int wrap,
+                        float max_anisotropy, uint32_t* out_id) {
+    if (!s || !rgb) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: null argument");
+    if (width <= 0 || height <= 0 || width > 32768 || height > 32768) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: resolution must be within 1..32768");
+    if (filtering < 0 || filtering > 1 || wrap < 0 || wrap > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: unknown filtering / wrap mode");
+    size_t w = (size_t)width, h = (size_t)height;
+    std::vector<float> img(3 * w * h);
+    for (size_t y = 0; y < h; y++)
+        for (size_t x = 0; x < w; x++) {
+            const float* px = rgb + 3 * ((h - 1 - y) * w + x);  // texture space has (0,0) at the lower left
+            float* o = &img[3 * (y * w + x)];
+            if (as_float) {  // ConvertIn<Float> for RGBSpectrum (convert_in.rs:37-47)
+                const float lum = 0.212671f * px[0] + 0.715160f * px[1] + 0.072169f * px[2];
+                o[0] = o[1] = o[2] = scale * (gamma ? inv_gamma_correct(lum) : lum);
+            } else for (int c = 0; c < 3; c++) o[c] = scale * (gamma ? inv_gamma_correct(px[c]) : px[c]);
+        }
+    return build_pyramid(s, std::move(img), w, h, filtering, wrap, as_float != 0, max_anisotropy, out_id);
 }
 int pbrt_hip_add_texture_constant(PbrtHipScene* s, const float v[3], uint32_t* out_id) {
     if (!s || !v) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_constant: null argument");
@@ -1002,6 +1048,51 @@ int pbrt_hip_add_light_infinite(PbrtHipScene* s, const float L[3], const float l
     l.marg_int = mi;
     s->infinite_lights.push_back((uint32_t)s->lights.size());
     s->lights.push_back(l);
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+// InfiniteAreaLight::new with a texmap (lights/src/infinite.rs:52-100): texels = read_image(texmap) * L — no y flip on this path —, MIPMap (EWA, repeat, 8),
+// compute_scalar_image (:326-369) over 2w x 2h and its Distribution2D.
+int pbrt_hip_add_light_infinite_map(PbrtHipScene* s, const float L[3], int width, int height, const float* rgb, const float l2w[16], const float w2l[16]) {
+    if (!s || !L || !rgb || !l2w || !w2l) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_infinite_map: null argument");
+    if (width <= 0 || height <= 0 || width > 16384 || height > 16384) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_infinite_map: resolution must be within 1..16384");
+    const size_t lights_before = s->lights.size();
+    int rc = pbrt_hip_add_light_infinite(s, L, l2w, w2l);   // fills the common fields (and the constant-light tables, unused with a map)
+    if (rc) return rc;
+    std::vector<float> img(3 * (size_t)width * (size_t)height);
+    for (size_t i = 0; i < (size_t)width * (size_t)height; i++) for (int c = 0; c < 3; c++) img[3 * i + c] = rgb[3 * i + c] * L[c];
+    uint32_t mip = 0;
+    if ((rc = build_pyramid(s, std::move(img), (size_t)width, (size_t)height, 1, 0, false, 8.0f, &mip))) { s->lights.pop_back(); s->infinite_lights.pop_back(); return rc; }
+    const MipRec& m = s->mipmaps[mip];
+    const size_t dw = 2 * (size_t)m.level_w[0], dh = 2 * (size_t)m.level_h[0];
+    const float fwidth = 0.5f / (float)(dw < dh ? dw : dh);
+    LightRec& l = s->lights[lights_before];
+    l.map_mip1 = mip + 1u; l.dw = (uint32_t)dw; l.dh = (uint32_t)dh; l.dist_off = (uint32_t)s->light_dist.size();
+    s->textured_materials = true;   // the radiance-map code lives in the TEX instantiations of the shade kernels
+    std::vector<float> cond_func(dw * dh), cond_cdf((dw + 1) * dh), cond_int(dh), row(dw), cdf;
+    for (size_t v = 0; v < dh; v++) {
+        const float vp = ((float)v + 0.5f) / (float)dh;
+        const float sin_theta = std::sin(hm::kPi * ((float)v + 0.5f) / (float)dh);
+        for (size_t u = 0; u < dw; u++) {
+            const float up = ((float)u + 0.5f) / (float)dw;
+            const Rgb t = hmip_lookup_triangle(s, m, up, vp, fwidth);
+            row[u] = (0.212671f * t.c[0] + 0.715160f * t.c[1] + 0.072169f * t.c[2]) * sin_theta;
+        }
+        float fi;
+        hm::distribution1d(row, cdf, fi);
+        std::copy(row.begin(), row.end(), cond_func.begin() + (long)(v * dw));
+        std::copy(cdf.begin(), cdf.end(), cond_cdf.begin() + (long)(v * (dw + 1)));
+        cond_int[v] = fi;
+    }
+    float mi;
+    hm::distribution1d(cond_int, cdf, mi);
+    std::vector<float>& pool = s->light_dist;
+    pool.insert(pool.end(), cond_func.begin(), cond_func.end());
+    pool.insert(pool.end(), cond_cdf.begin(), cond_cdf.end());
+    pool.insert(pool.end(), cond_int.begin(), cond_int.end());
+    pool.insert(pool.end(), cond_int.begin(), cond_int.end());   // the marginal's func = the rows' integrals
+    pool.insert(pool.end(), cdf.begin(), cdf.end());
+    pool.push_back(mi);
     s->uploaded = false;
     return PBRT_HIP_OK;
 }

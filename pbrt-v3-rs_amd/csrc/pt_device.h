@@ -468,10 +468,17 @@ PH_DEV SurfHit make_surface_hit_any(const DeviceScene& sc, f3 rd_world, float ti
 PH_DEV spec area_L(const LightRec& l, f3 n, f3 w) {  // DiffuseAreaLight::l (lights/src/diffuse.rs:220-226)
     return (l.two_sided || dot(n, w) > 0.0f) ? mks(l.L[0], l.L[1], l.L[2]) : mks1(0.0f);
 }
-PH_DEV spec light_le(const LightRec& l, f3 ray_d) {  // Light::le: InfiniteAreaLight (infinite.rs:188-195); zero for the others
+// Radiance-map variants of the three infinite-light operations, out of line (texture.h): `dsc` = DeviceScene::self
+static __device__ __noinline__ spec envmap_lookup(const DeviceScene* dsc, uint32_t mip, float s, float t);
+static __device__ __noinline__ float envmap_sample(const DeviceScene* dsc, uint32_t dist_off, uint32_t dw, uint32_t dh, float u0, float u1, float* d0, float* d1);
+static __device__ __noinline__ float envmap_pdf(const DeviceScene* dsc, uint32_t dist_off, uint32_t dw, uint32_t dh, float px, float py);
+// MAP = false compiles the radiance-map branches out: the texture-free shade kernels (the headline workload) must not pay for the out-of-line calls
+template <bool MAP = true> PH_DEV spec light_le(const DeviceScene& sc, const LightRec& l, f3 ray_d) {  // Light::le: InfiniteAreaLight (infinite.rs:188-195); zero for the others
     if (l.type != PH_L_INFINITE) return mks1(0.0f);
     f3 w = normalize(xf_vec(l.w2l, ray_d));
-    return infinite_lookup(l, mk2(spherical_phi(w) * kInvTwoPi, spherical_theta(w) * kInvPi));
+    const float s = spherical_phi(w) * kInvTwoPi, t = spherical_theta(w) * kInvPi;
+    if (MAP && l.map_mip1) return envmap_lookup(sc.self, l.map_mip1 - 1u, s, t);
+    return infinite_lookup(l, mk2(s, t));
 }
 // Distribution1D::sample_continuous on a 2-entry function (distribution_1d.rs:55-79)
 PH_DEV float dist2_sample_continuous(const float* func, const float* cdf, float func_int, float u, float& pdf, uint32_t& off) {
@@ -485,15 +492,19 @@ PH_DEV float dist2_sample_continuous(const float* func, const float* cdf, float 
 
 struct LiSample { f3 wi; float pdf; spec value; f3 vp, vperr, vn; bool valid; };
 // Triangle::area-light sampling record, shared by sample_li
-PH_DEV LiSample light_sample_li(const DeviceScene& sc, const LightRec& l, const SurfHit& hit, f2 u) {
+template <bool MAP = true> PH_DEV LiSample light_sample_li(const DeviceScene& sc, const LightRec& l, const SurfHit& hit, f2 u) {
     LiSample r;
     r.valid = false; r.pdf = 0.0f; r.wi = mk3(0, 0, 0); r.value = mks1(0.0f);
     r.vp = mk3(0, 0, 0); r.vperr = mk3(0, 0, 0); r.vn = mk3(0, 0, 0);
     if (l.type == PH_L_INFINITE) {  // infinite.rs:133-173
-        float pdf1, pdf0; uint32_t v, dummy;
-        float d1 = dist2_sample_continuous(l.marg_func, l.marg_cdf, l.marg_int, u.y, pdf1, v);
-        float d0 = dist2_sample_continuous(l.cond_func + 2 * v, l.cond_cdf + 3 * v, l.cond_int[v], u.x, pdf0, dummy);
-        float map_pdf = pdf0 * pdf1;
+        float d0, d1, map_pdf;
+        if (MAP && l.map_mip1) map_pdf = envmap_sample(sc.self, l.dist_off, l.dw, l.dh, u.x, u.y, &d0, &d1);
+        else {
+            float pdf1, pdf0; uint32_t v, dummy;
+            d1 = dist2_sample_continuous(l.marg_func, l.marg_cdf, l.marg_int, u.y, pdf1, v);
+            d0 = dist2_sample_continuous(l.cond_func + 2 * v, l.cond_cdf + 3 * v, l.cond_int[v], u.x, pdf0, dummy);
+            map_pdf = pdf0 * pdf1;
+        }
         if (map_pdf == 0.0f) return r;
         float theta = d1 * kPi, phi = d0 * kTwoPi;
         float cos_theta, sin_theta, sin_phi_, cos_phi_;
@@ -503,7 +514,7 @@ PH_DEV LiSample light_sample_li(const DeviceScene& sc, const LightRec& l, const 
         r.pdf = ph_div(map_pdf, kTwoPi * kPi * sin_theta);
         if (sin_theta == 0.0f) r.pdf = 0.0f;
         r.vp = hit.p + r.wi * (2.0f * sc.world_radius);
-        r.value = infinite_lookup(l, mk2(d0, d1));
+        r.value = (MAP && l.map_mip1) ? envmap_lookup(sc.self, l.map_mip1 - 1u, d0, d1) : infinite_lookup(l, mk2(d0, d1));
         r.valid = true;
     } else if (l.type == PH_L_DISTANT) {  // distant.rs:87-96
         f3 w = mk3(l.v[0], l.v[1], l.v[2]);
@@ -550,11 +561,12 @@ PH_DEV LiSample light_sample_li(const DeviceScene& sc, const LightRec& l, const 
     }
     return r;
 }
-PH_DEV float light_pdf_li(const DeviceScene& sc, const LightRec& l, const SurfHit& hit, f3 wi) {
+template <bool MAP = true> PH_DEV float light_pdf_li(const DeviceScene& sc, const LightRec& l, const SurfHit& hit, f3 wi) {
     if (l.type == PH_L_INFINITE) {  // infinite.rs:201-211 + Distribution2D::pdf (distribution_2d.rs:51-65)
         f3 w = xf_vec(l.w2l, wi);
         float theta = spherical_theta(w), phi = spherical_phi(w), sin_theta = d_sin(theta);
         if (sin_theta == 0.0f) return 0.0f;
+        if (MAP && l.map_mip1) return ph_div(envmap_pdf(sc.self, l.dist_off, l.dw, l.dh, phi * kInvTwoPi, theta * kInvPi), kTwoPi * kPi * sin_theta);
         uint32_t iu = f2u_sat(phi * kInvTwoPi * 2.0f), iv = f2u_sat(theta * kInvPi * 2.0f);
         if (iu > 1) iu = 1;
         if (iv > 1) iv = 1;

@@ -39,6 +39,7 @@ struct PbrtHipScene {
     bool general_materials = false;  // some material is not matte: the renderer uses the general BSDF kernel
     std::vector<LightRec> lights;
     std::vector<uint32_t> infinite_lights;
+    std::vector<float> light_dist;   // Distribution2D tables of infinite lights with a radiance map
     // object instancing (api/src/lib.rs:911-1000): an object is a contiguous triangle range; top_items is the scene's primitive
     // list in directive order (triangle id, or PH_ITEM_INST | instance index)
     struct ObjectHost { uint32_t tri0 = 0, tri1 = 0; };

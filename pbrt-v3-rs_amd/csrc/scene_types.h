@@ -129,15 +129,16 @@ struct LightRec {
     uint32_t prim;       // area: bound triangle
     float area;          // area: Triangle::area()
     float L[3];          // radiance / intensity
-    float pad0;
+    uint32_t map_mip1;   // infinite: 0, or 1 + the MIPMap of its radiance map (`mapname`); then the Distribution2D lives in DeviceScene::light_dist
     float v[3];          // distant: w_light; point / spot: p_light
-    float pad1;
+    uint32_t dist_off;   // first float of {cond_func[dh][dw], cond_cdf[dh][dw+1], cond_int[dh], marg_func[dh], marg_cdf[dh+1], marg_int}
     float l2w[12];       // infinite: rows 0..2 of light_to_world (3x4)
     float w2l[12];       // infinite: rows 0..2 of world_to_light
     // infinite: Distribution2D over the 2x2 scalar image (lights/src/infinite.rs:326-369)
     float cond_func[4], cond_cdf[6], cond_int[2];
     float marg_func[2], marg_cdf[3], marg_int;
     float cos_total_width, cos_falloff_start;  // spot (lights/src/spot.rs:24-25); w2l holds its world_to_light, v its position
+    uint32_t dw, dh;     // radiance map: resolution of the scalar image = 2 x the map's
 };
 
 struct CameraRec {  // cameras/src/perspective_camera.rs
@@ -192,6 +193,7 @@ struct DeviceScene {
     const MipRec* mipmaps;
     const Texel* texels;
     const float* ewa_lut;     // PH_EWA_LUT_SIZE Gaussian weights (mipmap/mod.rs:168-174), made on the host with its expf
+    const float* light_dist;  // Distribution2D tables of infinite lights with a radiance map
     const DeviceScene* self;  // device-resident copy of this struct: out-of-line device functions take it instead of the by-value kernel argument
     const LightRec* lights;
     uint32_t n_lights;

@@ -359,6 +359,41 @@ PH_DEV void compute_differentials(f3 p, f3 n, f3 dpdu, f3 dpdv, const RayDiff& r
     if (!(x0 != x0 || x1 != x1)) { c.dudy = x0; c.dvdy = x1; }
 }
 
+// ---- InfiniteAreaLight with a radiance map (lights/src/infinite.rs:127-211), declared in pt_device.h -------------------------------------
+// l_map.lookup_triangle(st, 0.0): the level is negative for every pyramid that fits memory, i.e. MIPMap::triangle(0, st)
+static __device__ __noinline__ spec envmap_lookup(const DeviceScene* dsc, uint32_t mip, float s, float t) {
+    const DeviceScene& sc = *dsc;
+    return mip_triangle(sc, sc.mipmaps[mip], 0u, mk2(s, t));
+}
+// Distribution1D::sample_continuous (core/src/sampling/distribution_1d.rs:55-79) on an n-entry function
+PH_DEV float distn_sample_continuous(const float* func, const float* cdf, uint32_t n, float func_int, float u, float& pdf, uint32_t& off) {
+    const uint32_t offset = find_interval_cdf(cdf, n + 1u, u);
+    float du = u - cdf[offset];
+    if (cdf[offset + 1] - cdf[offset] > 0.0f) du = ph_div(du, cdf[offset + 1] - cdf[offset]);
+    pdf = func_int > 0.0f ? ph_div(func[offset], func_int) : 0.0f;
+    off = offset;
+    return ph_div((float)offset + du, (float)n);
+}
+// Distribution2D::sample_continuous (distribution_2d.rs:31-49); returns the map pdf
+static __device__ __noinline__ float envmap_sample(const DeviceScene* dsc, uint32_t dist_off, uint32_t dw, uint32_t dh, float u0, float u1, float* d0, float* d1) {
+    const float* base = dsc->light_dist + dist_off;
+    const float* cond_func = base; const float* cond_cdf = cond_func + (size_t)dw * dh; const float* cond_int = cond_cdf + (size_t)(dw + 1u) * dh;
+    const float* marg_func = cond_int + dh; const float* marg_cdf = marg_func + dh; const float marg_int = marg_cdf[dh + 1u];
+    float pdf1, pdf0; uint32_t v, dummy;
+    *d1 = distn_sample_continuous(marg_func, marg_cdf, dh, marg_int, u1, pdf1, v);
+    *d0 = distn_sample_continuous(cond_func + (size_t)v * dw, cond_cdf + (size_t)v * (dw + 1u), dw, cond_int[v], u0, pdf0, dummy);
+    return pdf0 * pdf1;
+}
+// Distribution2D::pdf (distribution_2d.rs:51-65)
+static __device__ __noinline__ float envmap_pdf(const DeviceScene* dsc, uint32_t dist_off, uint32_t dw, uint32_t dh, float px, float py) {
+    const float* base = dsc->light_dist + dist_off;
+    const float* marg_cdf = base + (size_t)dw * dh + (size_t)(dw + 1u) * dh + dh + dh;
+    uint32_t iu = f2u_sat(px * (float)dw), iv = f2u_sat(py * (float)dh);
+    if (iu > dw - 1u) iu = dw - 1u;
+    if (iv > dh - 1u) iv = dh - 1u;
+    return ph_div(base[(size_t)iv * dw + iu], marg_cdf[dh + 1u]);
+}
+
 // The texture-evaluation context of a hit, out of line.  Everything texture evaluation needs beyond what the integrator carries is rebuilt
 // here from the TriRec the traversal reported: uv (triangle.rs:584), the geometric dp/du, dp/dv (:548-574, carried to world space for an
 // instance: transform.rs:566-590) and — for camera rays only — du/dv d x/y.

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                             SurfHit lh = make_surface_hit_any(sc, wi, mr.time, __float_as_uint(h1.y), __float_as_uint(h1.z), h0.z, h0.w, h1.x, m);
                             li2 = area_L(lt, lh.n, -wi);  // SurfaceInteraction::le (surface_interaction.rs:283-289)
                         }
-                    } else li2 = light_le(sc.lights[light_num], wi);
+                    } else li2 = light_le<TEX>(sc, sc.lights[light_num], wi);
                     if (!is_black(li2)) est = est + mks(F4.x, F4.y, F4.z) * li2 * mks1(1.0f) * A4.w / O4.w;  // f*li*tr*weight/scattering_pdf
                 }
                 const spec ldv = mks(O4.x, O4.y, O4.z) * (est / L4.w);  // beta * (estimate / light_pdf)  (path.rs:165)
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                 const bool emit = bounces == 0 || (GEN && (flags & F_SPEC));  // `bounces == 0 || specular_bounce` (path.rs:116)
                 if (!found) {
                     if (emit)
-                        for (uint32_t k = 0; k < sc.n_infinite; k++) L = L + beta * light_le(sc.lights[sc.infinite_lights[k]], rd);
+                        for (uint32_t k = 0; k < sc.n_infinite; k++) L = L + beta * light_le<TEX>(sc, sc.lights[sc.infinite_lights[k]], rd);
                 } else {
                     const float4 h1 = hp[1];
                     MeshRec m;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                     spec A = mks1(0.0f);
                                     // estimate_direct (integrator/common.rs:146-299), specular = false, handle_media = false
                                     {
-                                        const LiSample ls = light_sample_li(sc, light, si, u_light);
+                                        const LiSample ls = light_sample_li<TEX>(sc, light, si, u_light);
                                         if (ls.valid && ls.pdf > 0.0f && !is_black(ls.value)) {
                                             const spec f = BO::f_ns(bsdf, si.wo, ls.wi) * abs_dot(ls.wi, si.ns);
                                             const float scattering_pdf = BO::pdf_ns(bsdf, si.wo, ls.wi);
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                         BO::sample_ns(bsdf, si.wo, u_scatter, f1, spdf, wi2);  // never specular with these flags: sampled_specular = false
                                         const spec f = f1 * abs_dot(wi2, si.ns);
                                         if (!is_black(f) && spdf > 0.0f) {
-                                            const float lp = light_pdf_li(sc, light, si, wi2);
+                                            const float lp = light_pdf_li<TEX>(sc, light, si, wi2);
                                             if (lp != 0.0f) {  // lp == 0 -> `return ld` with the light-sampling part only
                                                 w2 = power_heuristic1(spdf, lp);
                                                 spdf_store = spdf;

@@ -185,7 +185,7 @@ struct Parser {
                 if (!quoted(name) || !quoted(type) || !quoted(cls) || !param_list(ps)) return false;
                 api.pbrt_texture(name, type, cls, ps, scene_dir);
             }
-            else if (d == "LightSource") { if (!name_and_params(name, ps)) return false; api.pbrt_light_source(name, ps); }
+            else if (d == "LightSource") { if (!name_and_params(name, ps)) return false; api.pbrt_light_source(name, ps, scene_dir); }
             else if (d == "AreaLightSource") { if (!name_and_params(name, ps)) return false; api.pbrt_area_light_source(name, ps); }
             else if (d == "Shape") { if (!name_and_params(name, ps)) return false; api.pbrt_shape(name, ps, scene_dir); }
             else if (d == "ObjectBegin") { if (!quoted(name)) return false; api.pbrt_object_begin(name); }

@@ -403,15 +403,27 @@ void Api::pbrt_reverse_orientation() { if (!verify_world("ReverseOrientation")) 
 
 static std::array<float, 3> mul3(std::array<float, 3> a, std::array<float, 3> b) { return {a[0] * b[0], a[1] * b[1], a[2] * b[2]}; }
 
-void Api::pbrt_light_source(const std::string& name, const ParamSet& p) {
+void Api::pbrt_light_source(const std::string& name, const ParamSet& p, const std::string& scene_dir) {
     if (!verify_world("LightSource") || !error.empty() || (!scene_ && !check_only_)) return;
     for (auto& u : p.unsupported) { error = "LightSource \"" + name + "\": parameter '" + u + "' has a spectral type this host cannot evaluate"; return; }
     const std::array<float, 3> one = {1.0f, 1.0f, 1.0f};
     const std::array<float, 3> sc = p.find_one_rgb("scale", one);
     if (name == "infinite" || name == "exinfinite") {
-        if (!p.find_one_string("mapname", "").empty()) { error = "LightSource \"infinite\": environment maps ('mapname') are outside the hot-path scope"; return; }
         auto L = mul3(p.find_one_rgb("L", one), sc);
-        if (check(ABI(pbrt_hip_add_light_infinite(scene_, L.data(), ctm_.m, ctm_.mi)), "add_light_infinite")) n_lights_++;
+        std::string map = p.find_one_string("mapname", "");
+        std::vector<float> rgb; int w = 0, h = 0;
+        if (!map.empty()) {  // InfiniteAreaLight::new: a map that cannot be read leaves a constant light, with a warning (infinite.rs:63-77)
+            if (map[0] != '/' && !scene_dir.empty()) map = scene_dir + "/" + map;
+            std::string err;
+            if (!read_image(map, rgb, w, h, err)) {
+                rgb.clear();
+                // a file the reference could read but this host cannot decode must not silently become a constant sky
+                if (err.find("not decoded by this host") != std::string::npos) { if (error.empty()) error = "LightSource \"infinite\" 'mapname' " + map + ": " + err; return; }
+                warn("Problem reading file '" + map + "'. " + err);
+            }
+        }
+        if (!rgb.empty()) { if (check(ABI(pbrt_hip_add_light_infinite_map(scene_, L.data(), w, h, rgb.data(), ctm_.m, ctm_.mi)), "add_light_infinite_map")) n_lights_++; }
+        else if (check(ABI(pbrt_hip_add_light_infinite(scene_, L.data(), ctm_.m, ctm_.mi)), "add_light_infinite")) n_lights_++;
     } else if (name == "distant") {
         auto L = mul3(p.find_one_rgb("L", one), sc);
         auto from = p.find_one_rgb("from", {0.0f, 0.0f, 0.0f}), to = p.find_one_rgb("to", {0.0f, 0.0f, 1.0f});

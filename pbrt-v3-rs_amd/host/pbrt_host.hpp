@@ -88,7 +88,7 @@ class Api {
     void pbrt_material(const std::string& name, const ParamSet& p);
     void pbrt_make_named_material(const std::string& name, const ParamSet& p);
     void pbrt_named_material(const std::string& name);
-    void pbrt_light_source(const std::string& name, const ParamSet& p);
+    void pbrt_light_source(const std::string& name, const ParamSet& p, const std::string& scene_dir = "");
     void pbrt_area_light_source(const std::string& name, const ParamSet& p);
     void pbrt_shape(const std::string& name, const ParamSet& p, const std::string& scene_dir);
     void pbrt_reverse_orientation();

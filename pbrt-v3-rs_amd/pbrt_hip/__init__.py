@@ -122,6 +122,7 @@ class Binding:
             "add_texture_uv": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
             "add_texture_bilerp": (C.c_int, [vp, fp, fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
             "add_texture_dots": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, u32p]),
+            "add_light_infinite_map": (C.c_int, [vp, fp, C.c_int, C.c_int, fp, fp, fp]),
             "add_texture_fbm": (C.c_int, [vp, fp, C.c_float, C.c_int, u32p]),
             "add_texture_wrinkled": (C.c_int, [vp, fp, C.c_float, C.c_int, u32p]),
             "add_texture_windy": (C.c_int, [vp, fp, u32p]),
@@ -397,6 +398,13 @@ class Scene:
         l2w = _f32(light_to_world if light_to_world is not None else IDENTITY)
         w2l = _f32(world_to_light if world_to_light is not None else IDENTITY)
         self._chk(self.b.fn("add_light_infinite")(self.h, _ptr(_f32(L), C.c_float), _ptr(l2w, C.c_float), _ptr(w2l, C.c_float)))
+
+    def add_light_infinite_map(self, L, image, light_to_world=None, world_to_light=None):
+        """InfiniteAreaLight with a radiance map: image (H, W, 3) float32 as an image reader returns it (top row first)."""
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        l2w = _f32(light_to_world if light_to_world is not None else IDENTITY)
+        w2l = _f32(world_to_light if world_to_light is not None else IDENTITY)
+        self._chk(self.b.fn("add_light_infinite_map")(self.h, _ptr(_f32(L), C.c_float), img.shape[1], img.shape[0], _ptr(img, C.c_float), _ptr(l2w, C.c_float), _ptr(w2l, C.c_float)))
 
     def add_light_distant(self, L, w_light_world):
         self._chk(self.b.fn("add_light_distant")(self.h, _ptr(_f32(L), C.c_float), _ptr(_f32(w_light_world), C.c_float)))

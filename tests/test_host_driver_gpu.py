@@ -320,6 +320,8 @@ def test_textured_pbrt_file_renders_the_oracle_image(tmp_path, host):
     imf.write_png(str(tmp_path / "a.png"), a8)
     imf.write_tga(str(tmp_path / "m.tga"), m8, grey=True, rle=True)
     imf.write_pfm(str(tmp_path / "h.pfm"), hdr)
+    sky = rng.uniform(0.2, 1.0, (8, 16, 3)).astype(np.float32); sky[1, 3] = (30.0, 25.0, 20.0)
+    imf.write_pfm(str(tmp_path / "sky.pfm"), sky)
     Q = np.array([[-4, -4, 0], [4, -4, 0], [4, 4, 0], [-4, 4, 0]], np.float32)
     UVQ = np.array([[0, 0], [2, 0], [2, 2], [0, 2]], np.float32)
     W = np.array([[-2, 3, 0], [2, 3, 0], [2, 3, 2.5], [-2, 3, 2.5]], np.float32)
@@ -332,7 +334,10 @@ Sampler "halton" "integer pixelsamples" {spp}
 PixelFilter "box"
 Integrator "path" "integer maxdepth" {depth} "string lightsamplestrategy" "uniform"
 WorldBegin
-LightSource "infinite" "rgb L" [1 1 1]
+AttributeBegin
+  Rotate 40 0 0 1
+  LightSource "infinite" "rgb L" [1 0.9 0.8] "rgb scale" [0.5 0.5 0.5] "string mapname" "sky.pfm"
+AttributeEnd
 Texture "wood" "color" "imagemap" "string filename" "a.png"
 Texture "tint" "color" "scale" "texture tex1" "wood" "rgb tex2" [0.9 0.6 0.4]
 Texture "amt" "float" "imagemap" "string filename" "m.tga" "bool trilinear" "true" "string wrap" "clamp" "bool gamma" "false"
@@ -376,7 +381,9 @@ WorldEnd
         amt = s.add_texture_imagemap(s.add_mipmap(grey, as_float=True, trilinear=True, wrap="clamp", gamma=False))
         blend = s.add_texture_mix(tint, s.add_texture_constant((0.1, 0.2, 0.8)), amt)
         hd = s.add_texture_imagemap(s.add_mipmap(hdr, scale=0.5, wrap="black"), su=2.0, sv=2.0)
-        s.add_light_infinite((1.0, 1.0, 1.0))
+        ident2 = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+        lt = host.compose(ident2, host.rotate(40.0, [0, 0, 1]))
+        s.add_light_infinite_map(np.float32([1.0, 0.9, 0.8]) * np.float32([0.5, 0.5, 0.5]), sky, lt[0], lt[1])
         s.add_mesh(Q, [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(blend, 0.0), UV=UVQ)
         s.add_mesh(W, [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(hd, 20.0), UV=UVW)
         tri_uv = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)

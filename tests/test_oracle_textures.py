@@ -404,3 +404,44 @@ def test_bump_mapping_pins():
         ramp = lambda s, k=k: s.add_texture_bilerp(0.0, 0.0, k, k)                # v00, v01, v10, v11: value = k * u on [0,1]^2 ... and beyond, linearly
         got = floor_radiance(ramp)
         assert np.isclose(got, flat * np.cos(np.arctan(k)), rtol=2e-4), (got, flat * np.cos(np.arctan(k)))
+
+
+def test_environment_map_light_closed_forms():
+    """InfiniteAreaLight with a radiance map: (1) a constant map is the constant light (same film); (2) a white diffuse floor under a map that is
+    `a` on the upper hemisphere's... simpler: under a map with radiance depending on theta only, E = 2 pi int L(theta) cos sin dtheta; with the
+    two-band map below (L = 2 for theta < pi/2 band boundaries on texel rows) the floor's radiance is Kd/pi * E, checked to Monte Carlo accuracy;
+    (3) sample_li / pdf_li consistency is implied by (2) under MIS: both estimators meet the same closed form."""
+    import pbrt_hip
+    host = pbrt_hip.Host()
+
+    def film(add_light, spp=64, depth=1):
+        s = OracleScene()
+        mat = s.add_material_matte((0.8, 0.8, 0.8), 0.0)
+        P = np.array([[-50, -50, 0], [50, -50, 0], [50, 50, 0], [-50, 50, 0]], np.float32)
+        s.add_mesh(P, [0, 1, 2, 0, 2, 3], mat)
+        add_light(s)
+        w2c, c2w = host.look_at((0, 0, 5), (0, 0, 0), (0, 1, 0))
+        s.set_camera_perspective(host.perspective_raster_to_camera(10.0, 8, 8), c2w)
+        cb, table, sb = host.film_box(8, 8)
+        s.set_film(8, 8, cb, (0.5, 0.5), table); s.set_sampler(0, spp, sb); s.build_accel(0, 4)
+        xyz, wt, _, _ = s.render_path_ex(max_depth=depth, light_strategy=0)
+        return s.film_to_rgb(xyz, wt).reshape(8, 8, 3)
+    const = np.full((4, 8, 3), (0.5, 1.0, 2.0), np.float32)
+    a = film(lambda s: s.add_light_infinite_map((2.0, 1.0, 0.5), const), spp=256)[2:6, 2:6].mean(axis=(0, 1))
+    b = film(lambda s: s.add_light_infinite((1.0, 1.0, 1.0)), spp=256)[2:6, 2:6].mean(axis=(0, 1))
+    # texels * L = (1, 1, 1) everywhere: the same light, sampled through a finer table -> equal in expectation (white furnace: Kd * L = 0.8)
+    assert np.allclose(a, 0.8, rtol=0.02) and np.allclose(b, 0.8, rtol=0.02)
+    # rows of the map are bands of theta = [k pi/H, (k+1) pi/H); light_to_world = identity: theta measured from +z.  Upper hemisphere = rows 0..H/2-1.
+    H, W = 16, 32
+    img = np.zeros((H, W, 3), np.float32)
+    img[:4] = 3.0                                # theta in [0, pi/4): a bright cap around the zenith
+    img[4:8] = 0.5                               # theta in [pi/4, pi/2)
+    got = film(lambda s: s.add_light_infinite_map((1.0, 1.0, 1.0), img), spp=256)[2:6, 2:6, 1].mean()
+    # E = 2 pi [3 int_0^{pi/4} cos sin + 0.5 int_{pi/4}^{pi/2} cos sin] = 2 pi [3 * 0.25 + 0.5 * 0.25]; bilinear lookups blur the band edges by half a
+    # texel each way, symmetric to first order
+    want = 0.8 / np.pi * 2 * np.pi * (3 * 0.25 + 0.5 * 0.25)
+    assert np.isclose(got, want, rtol=0.03), (got, want)
+    # rotating the light by 180 degrees about x puts the bright cap below the floor: only nothing from above the horizon -> black
+    t = host.rotate(180.0, [1, 0, 0])
+    dark = film(lambda s: s.add_light_infinite_map((1.0, 1.0, 1.0), img, t[0], t[1]), spp=16)[2:6, 2:6, 1].mean()
+    assert dark < 0.02 * want

@@ -394,3 +394,40 @@ def test_bump_on_a_mesh_with_vertex_normals_and_tangents():
             set_libm_mode(0)
         gxyz, gwt, _ = prod.render_path(max_depth=3)
         assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
+
+
+@pytest.mark.parametrize("strategy", [0, 1, 2])
+def test_environment_map_light_film_bit_exact(strategy):
+    """InfiniteAreaLight with a radiance map (NPOT, strongly peaked) + a second light, all three light-sampling strategies, glossy and textured surfaces."""
+    rng = np.random.default_rng(31)
+    env = rng.uniform(0.0, 0.3, (12, 20, 3)).astype(np.float32)
+    env[2:4, 5:8] = (40.0, 30.0, 20.0)            # a sun
+    host = pbrt_hip.Host()
+    t = host.compose(host.rotate(35.0, [0, 0, 1]), host.rotate(-60.0, [1, 0, 0]))
+
+    def scene(sc):
+        tex = sc.add_texture_imagemap(sc.add_mipmap(make_image(32, 32, seed=4)))
+        mat = sc.add_material_plastic((1, 1, 1), (0.3, 0.3, 0.3), 0.08, True); sc.set_material_texture(mat, "Kd", tex)
+        grey = sc.add_material_matte((0.6, 0.6, 0.6), 0.0)
+        P = np.array([[-4, -4, 0], [4, -4, 0], [4, 4, 0], [-4, 4, 0]], np.float32)
+        sc.add_mesh(P, [0, 1, 2, 0, 2, 3], mat, UV=np.array([[0, 0], [3, 0], [3, 3], [0, 3]], np.float32))
+        B = np.array([[-0.5, -0.5, 0.2], [0.5, -0.5, 0.2], [0.5, 0.5, 0.2], [-0.5, 0.5, 0.2], [0, 0, 1.2]], np.float32)
+        sc.add_mesh(B, np.array([0, 1, 4, 1, 2, 4, 2, 3, 4, 3, 0, 4], np.uint32), grey)
+        sc.add_light_infinite_map((1.0, 0.9, 0.8), env, t[0], t[1])
+        sc.add_light_point((3.0, 3.0, 3.0), (1.5, -1.0, 2.0))
+        w2c, c2w = host.look_at((0.0, -6.0, 1.2), (0, 0, 0.2), (0, 0, 1))
+        sc.set_camera_perspective(host.perspective_raster_to_camera(40.0, 48, 48), c2w)
+        cb, table, sb = host.film_box(48, 48)
+        sc.set_film(48, 48, cb, (0.5, 0.5), table); sc.set_sampler(0, 4, sb); sc.build_accel(0, 4)
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    scene(prod); scene(orc)
+    set_libm_mode(1)
+    try:
+        oxyz, owt, ost, _ = orc.render_path_ex(max_depth=4, light_strategy=strategy)
+    finally:
+        set_libm_mode(0)
+    gxyz, gwt, gst = prod.render_path(max_depth=4, light_strategy=strategy)
+    assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
+    assert gst.regular_rays == ost.regular_rays and gst.shadow_rays == ost.shadow_rays
+    assert gst.light_distributions_created == ost.light_distributions_created
+    assert float(gxyz.mean()) > 0.0
