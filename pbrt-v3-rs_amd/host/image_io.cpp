@@ -1,7 +1,9 @@
 // read_image (core/src/image_io.rs:42-50): the texel source of ImageTexture.  Returns width*height RGB floats, top row first, exactly as
 // the reference hands them to generate_mipmap: PFM values times |scale| (read_pfm, :127-190), 8-bit formats as u8 / 255.0 (read_8_bit,
 // :192-224 — the reference decodes them with the `image` crate, v0.25, and converts to RGB8).  Decoders here: PFM, TGA (types 2, 3, 10, 11)
-// and PNG (8 bits per channel, non-interlaced; inflate by zlib).  OpenEXR and JPEG are not decoded: convert such maps to PFM / PNG.
+// PNG (8 bits per channel, non-interlaced; inflate by zlib) and OpenEXR (single-part scanline files, NONE / ZIPS / ZIP compression, half or float R G B [A]).
+// write_image (:225-237): PFM, 8-bit PNG / TGA through apply_gamma (:379-390), EXR as uncompressed 32-bit float scanlines.  JPEG, tiled / PIZ / multipart EXR
+// are not decoded: convert such files.
 #include "pbrt_host.hpp"
 #include <cmath>
 #include <cstdio>
@@ -177,12 +179,123 @@ bool read_png(const std::vector<unsigned char>& d, std::vector<float>& rgb, int&
     return true;
 }
 
+// ---- OpenEXR (OpenEXR file layout, openexr.com/TechnicalIntroduction): magic, version, attributes, scanline offset table, blocks --------------
+float half_to_float(uint16_t h) {
+    const uint32_t sgn = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = sgn;
+        else {  // subnormal half: renormalise
+            int ex = -1; uint32_t mm = m;
+            do { ex++; mm <<= 1; } while (!(mm & 1024u));
+            bits = sgn | ((uint32_t)(127 - 15 - ex) << 23) | ((mm & 1023u) << 13);
+        }
+    } else if (e == 31) bits = sgn | 0x7F800000u | (m << 13);
+    else bits = sgn | ((e + 112u) << 23) | (m << 13);
+    float f; std::memcpy(&f, &bits, 4); return f;
+}
+bool read_exr(const std::vector<unsigned char>& d, std::vector<float>& rgb, int& w, int& h, std::string& err) {
+    auto u32 = [&](size_t p) { return (uint32_t)d[p] | ((uint32_t)d[p + 1] << 8) | ((uint32_t)d[p + 2] << 16) | ((uint32_t)d[p + 3] << 24); };
+    auto u64 = [&](size_t p) { return (uint64_t)u32(p) | ((uint64_t)u32(p + 4) << 32); };
+    if (d.size() < 8 || u32(0) != 20000630u) { err = "EXR: bad magic number"; return false; }
+    const uint32_t ver = u32(4);
+    if ((ver & 0xFFu) != 2u || (ver & 0x1A00u)) { err = "EXR: tiled, deep and multipart files are not decoded by this host (convert the map to .pfm, .png or .tga)"; return false; }
+    size_t pos = 8;
+    struct Chan { std::string name; int type; };
+    std::vector<Chan> chans;
+    int compression = -1, dw[4] = {0, 0, -1, -1}, line_order = 0;
+    for (;;) {  // attributes: name\0 type\0 size value
+        if (pos >= d.size()) { err = "EXR: truncated header"; return false; }
+        if (d[pos] == 0) { pos++; break; }
+        std::string name, type;
+        while (pos < d.size() && d[pos]) name.push_back((char)d[pos++]);
+        pos++;
+        while (pos < d.size() && d[pos]) type.push_back((char)d[pos++]);
+        pos++;
+        if (pos + 4 > d.size()) { err = "EXR: truncated header"; return false; }
+        const uint32_t size = u32(pos); pos += 4;
+        if (pos + size > d.size()) { err = "EXR: truncated header"; return false; }
+        if (name == "channels") {
+            size_t q = pos;
+            while (q < pos + size && d[q]) {
+                Chan c;
+                while (d[q]) c.name.push_back((char)d[q++]);
+                q++;
+                c.type = (int)u32(q);
+                const uint32_t xs = u32(q + 8), ys = u32(q + 12);
+                if (xs != 1 || ys != 1) { err = "EXR: subsampled channels are not decoded by this host (convert the map to .pfm, .png or .tga)"; return false; }
+                q += 16;
+                chans.push_back(c);
+            }
+        } else if (name == "compression") compression = d[pos];
+        else if (name == "dataWindow") for (int k = 0; k < 4; k++) dw[k] = (int)u32(pos + 4 * (size_t)k);
+        else if (name == "lineOrder") line_order = d[pos];
+        pos += size;
+    }
+    (void)line_order;
+    if (!(compression == 0 || compression == 2 || compression == 3)) {
+        err = "EXR: compression method " + std::to_string(compression) + " (RLE / PIZ / PXR24 / B44 / DWA) is not decoded by this host (convert the map to .pfm, .png or .tga)";
+        return false;
+    }
+    w = dw[2] - dw[0] + 1; h = dw[3] - dw[1] + 1;
+    if (w <= 0 || h <= 0 || chans.empty()) { err = "EXR: bad data window or no channels"; return false; }
+    int ci[3] = {-1, -1, -1};
+    size_t row_bytes = 0;
+    std::vector<size_t> chan_off(chans.size());
+    for (size_t c = 0; c < chans.size(); c++) {
+        chan_off[c] = row_bytes;
+        if (chans[c].type < 0 || chans[c].type > 2) { err = "EXR: bad pixel type"; return false; }
+        row_bytes += (size_t)w * (chans[c].type == 1 ? 2 : 4);
+        if (chans[c].name == "R") ci[0] = (int)c; else if (chans[c].name == "G") ci[1] = (int)c; else if (chans[c].name == "B") ci[2] = (int)c;
+    }
+    if (ci[0] < 0 || ci[1] < 0 || ci[2] < 0) { err = "EXR: the file has no R, G, B channels"; return false; }
+    const int lines_per_block = compression == 3 ? 16 : 1;
+    const size_t n_blocks = ((size_t)h + lines_per_block - 1) / lines_per_block;
+    if (pos + 8 * n_blocks > d.size()) { err = "EXR: truncated offset table"; return false; }
+    rgb.assign(3 * (size_t)w * h, 0.0f);
+    std::vector<unsigned char> raw, tmp;
+    for (size_t b = 0; b < n_blocks; b++) {
+        const uint64_t off = u64(pos + 8 * b);
+        if (off + 8 > d.size()) { err = "EXR: bad block offset"; return false; }
+        const int y0 = (int)u32((size_t)off) - dw[1];
+        const uint32_t sz = u32((size_t)off + 4);
+        if (off + 8 + sz > d.size() || y0 < 0 || y0 >= h) { err = "EXR: bad scanline block"; return false; }
+        const int nl = std::min(lines_per_block, h - y0);
+        const size_t want = row_bytes * (size_t)nl;
+        const unsigned char* src = &d[(size_t)off + 8];
+        if (compression == 0 || sz == want) raw.assign(src, src + std::min<size_t>(sz, want));   // a block that did not shrink is stored raw
+        else {
+            tmp.resize(want);
+            uLongf out_len = (uLongf)want;
+            if (uncompress(tmp.data(), &out_len, src, sz) != Z_OK || out_len != want) { err = "EXR: inflate failed"; return false; }
+            for (size_t i = 1; i < want; i++) tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);   // undo the byte predictor
+            raw.resize(want);
+            const size_t half = (want + 1) / 2;                                                      // undo the even / odd byte split
+            for (size_t i = 0, a = 0, c2 = half; i < want; ) { raw[i++] = tmp[a++]; if (i < want) raw[i++] = tmp[c2++]; }
+        }
+        if (raw.size() < want) { err = "EXR: short scanline block"; return false; }
+        for (int l = 0; l < nl; l++)
+            for (int k = 0; k < 3; k++) {
+                const Chan& c = chans[(size_t)ci[k]];
+                const unsigned char* row = &raw[row_bytes * (size_t)l + chan_off[(size_t)ci[k]]];
+                for (int x = 0; x < w; x++) {
+                    float v;
+                    if (c.type == 1) v = half_to_float((uint16_t)(row[2 * x] | (row[2 * x + 1] << 8)));
+                    else if (c.type == 2) std::memcpy(&v, row + 4 * x, 4);
+                    else { uint32_t u; std::memcpy(&u, row + 4 * x, 4); v = (float)u; }
+                    rgb[3 * ((size_t)(y0 + l) * w + x) + k] = v;
+                }
+            }
+    }
+    return true;
+}
+
 }  // namespace
 
 bool read_image(const std::string& path, std::vector<float>& rgb, int& w, int& h, std::string& err) {
     const std::string ext = lower_ext(path);
     if (ext.empty()) { err = "Can't determine file type from suffix of filename " + path + "."; return false; }
-    if (ext == ".exr" || ext == ".jpg" || ext == ".jpeg" || ext == ".bmp" || ext == ".gif" || ext == ".tif" || ext == ".tiff" || ext == ".hdr") {
+    if (ext == ".jpg" || ext == ".jpeg" || ext == ".bmp" || ext == ".gif" || ext == ".tif" || ext == ".tiff" || ext == ".hdr") {
         err = "image format '" + ext + "' is not decoded by this host (convert the map to .pfm, .png or .tga)";
         return false;
     }
@@ -191,7 +304,98 @@ bool read_image(const std::string& path, std::vector<float>& rgb, int& w, int& h
     if (ext == ".pfm") return read_pfm(d, rgb, w, h, err);
     if (ext == ".tga") return read_tga(d, rgb, w, h, err);
     if (ext == ".png") return read_png(d, rgb, w, h, err);
+    if (ext == ".exr") return read_exr(d, rgb, w, h, err);
     err = "image format '" + ext + "' is not decoded by this host (convert the map to .pfm, .png or .tga)";
+    return false;
+}
+
+// ---- write_image (core/src/image_io.rs:225-237) ------------------------------------------------------------------------------------------
+namespace {
+inline float gamma_correct(float v) { return v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f; }  // pbrt/common.rs:140-146
+inline unsigned char clamp_byte(float v) {  // image_io.rs:387-390: clamp(255 * gamma_correct(v) + 0.5, 0, 255) as u8
+    const float x = 255.0f * gamma_correct(v) + 0.5f;
+    return (unsigned char)(x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x));   // NaN compares false twice and casts to 0, like `as u8`
+}
+bool put(const std::string& path, const std::vector<unsigned char>& bytes, std::string& err) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) { err = "Error saving output image " + path + ": cannot open"; return false; }
+    const bool ok = std::fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+    std::fclose(f);
+    if (!ok) err = "Error saving output image " + path + ": short write";
+    return ok;
+}
+void be32put(std::vector<unsigned char>& o, uint32_t v) { o.push_back((unsigned char)(v >> 24)); o.push_back((unsigned char)(v >> 16)); o.push_back((unsigned char)(v >> 8)); o.push_back((unsigned char)v); }
+void le32put(std::vector<unsigned char>& o, uint32_t v) { o.push_back((unsigned char)v); o.push_back((unsigned char)(v >> 8)); o.push_back((unsigned char)(v >> 16)); o.push_back((unsigned char)(v >> 24)); }
+void png_chunk(std::vector<unsigned char>& o, const char* ty, const std::vector<unsigned char>& body) {
+    be32put(o, (uint32_t)body.size());
+    const size_t start = o.size();
+    o.insert(o.end(), ty, ty + 4); o.insert(o.end(), body.begin(), body.end());
+    be32put(o, (uint32_t)crc32(0L, &o[start], (uInt)(o.size() - start)));
+}
+}  // namespace
+bool write_image(const std::string& path, const float* rgb, int w, int h, std::string& err) {
+    const std::string ext = lower_ext(path);
+    if (ext == ".pfm") return write_pfm(path, rgb, w, h, err);
+    std::vector<unsigned char> out;
+    if (ext == ".png" || ext == ".tga") {
+        std::vector<unsigned char> px((size_t)w * h * 3);
+        for (size_t i = 0; i < px.size(); i++) px[i] = clamp_byte(rgb[i]);
+        if (ext == ".tga") {  // true colour, 24 bits, top-left origin
+            const unsigned char hd[18] = {0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, (unsigned char)(w & 255), (unsigned char)(w >> 8), (unsigned char)(h & 255), (unsigned char)(h >> 8), 24, 0x20};
+            out.assign(hd, hd + 18);
+            for (size_t i = 0; i < (size_t)w * h; i++) { out.push_back(px[3 * i + 2]); out.push_back(px[3 * i + 1]); out.push_back(px[3 * i]); }
+            return put(path, out, err);
+        }
+        static const unsigned char sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+        out.assign(sig, sig + 8);
+        std::vector<unsigned char> ihdr;
+        be32put(ihdr, (uint32_t)w); be32put(ihdr, (uint32_t)h);
+        const unsigned char tail[5] = {8, 2, 0, 0, 0};
+        ihdr.insert(ihdr.end(), tail, tail + 5);
+        png_chunk(out, "IHDR", ihdr);
+        std::vector<unsigned char> raw;
+        raw.reserve(((size_t)w * 3 + 1) * h);
+        for (int y = 0; y < h; y++) { raw.push_back(0); raw.insert(raw.end(), &px[(size_t)y * w * 3], &px[(size_t)y * w * 3] + (size_t)w * 3); }
+        uLongf clen = compressBound((uLong)raw.size());
+        std::vector<unsigned char> comp(clen);
+        if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { err = "Error saving output image " + path + ": deflate failed"; return false; }
+        comp.resize(clen);
+        png_chunk(out, "IDAT", comp);
+        png_chunk(out, "IEND", {});
+        return put(path, out, err);
+    }
+    if (ext == ".exr") {  // single-part scanline file, no compression, 32-bit float B G R (channels are stored in alphabetical order), increasing y
+        le32put(out, 20000630u); le32put(out, 2u);
+        auto attr = [&](const char* name, const char* type, const std::vector<unsigned char>& v) {
+            out.insert(out.end(), name, name + std::strlen(name) + 1); out.insert(out.end(), type, type + std::strlen(type) + 1);
+            le32put(out, (uint32_t)v.size()); out.insert(out.end(), v.begin(), v.end());
+        };
+        std::vector<unsigned char> v;
+        for (const char* c : {"B", "G", "R"}) { v.push_back((unsigned char)c[0]); v.push_back(0); le32put(v, 2u); le32put(v, 0u); le32put(v, 1u); le32put(v, 1u); }
+        v.push_back(0);
+        attr("channels", "chlist", v);
+        attr("compression", "compression", {0});
+        v.clear(); le32put(v, 0u); le32put(v, 0u); le32put(v, (uint32_t)(w - 1)); le32put(v, (uint32_t)(h - 1));
+        attr("dataWindow", "box2i", v); attr("displayWindow", "box2i", v);
+        attr("lineOrder", "lineOrder", {0});
+        auto f32 = [](float f) { std::vector<unsigned char> b(4); std::memcpy(b.data(), &f, 4); return b; };
+        attr("pixelAspectRatio", "float", f32(1.0f));
+        v = f32(0.0f); { const std::vector<unsigned char> z = f32(0.0f); v.insert(v.end(), z.begin(), z.end()); }
+        attr("screenWindowCenter", "v2f", v);
+        attr("screenWindowWidth", "float", f32(1.0f));
+        out.push_back(0);
+        const size_t row_bytes = (size_t)w * 12, table = out.size();
+        out.resize(out.size() + 8 * (size_t)h);
+        for (int y = 0; y < h; y++) {
+            const uint64_t off = out.size();
+            for (int k = 0; k < 8; k++) out[table + 8 * (size_t)y + (size_t)k] = (unsigned char)(off >> (8 * k));
+            le32put(out, (uint32_t)y); le32put(out, (uint32_t)row_bytes);
+            for (int c = 2; c >= 0; c--)
+                for (int x = 0; x < w; x++) { unsigned char b[4]; std::memcpy(b, &rgb[3 * ((size_t)y * w + x) + c], 4); out.insert(out.end(), b, b + 4); }
+        }
+        return put(path, out, err);
+    }
+    err = ext.empty() ? "Can't determine file type from suffix of filename " + path : "Extension " + ext + " is not supported";
     return false;
 }
 

@@ -14,7 +14,7 @@ static void usage() {
                  "  --tile-size N          sample tile edge (default 16, as the reference)\n"
                  "  --sobol-tables FILE    raw Sobol generator matrices (needed for Sampler \"sobol\")\n"
                  "  --check                parse and validate only: no GPU is touched and nothing is rendered\n"
-                 "  --convert-image IN OUT.pfm   decode a texture file (PFM, TGA, PNG) the way ImageTexture would see it and write it as PFM\n"
+                 "  --convert-image IN OUT       decode an image file (PFM, TGA, PNG, EXR) the way ImageTexture would see it and write it as .pfm / .exr / .png / .tga\n"
                  "  --quiet                no warnings / statistics\n");
 }
 
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
             need(2);
             std::vector<float> rgb; int w = 0, h = 0; std::string err;
             if (!pbrt_host::read_image(argv[i + 1], rgb, w, h, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
-            if (!pbrt_host::write_pfm(argv[i + 2], rgb.data(), w, h, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            if (!pbrt_host::write_image(argv[i + 2], rgb.data(), w, h, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
             return 0;
         }
         else if (a == "--help" || a == "-h") { usage(); return 0; }

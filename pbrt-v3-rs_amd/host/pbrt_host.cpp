@@ -697,7 +697,6 @@ void Api::pbrt_shape(const std::string& name, const ParamSet& p, const std::stri
     if (current_object_.empty()) n_tris_ += n_tris; else object_tris_[current_object_] += n_tris;
 }
 
-static bool ends_with(const std::string& s, const std::string& suf) { return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0; }
 
 int Api::pbrt_world_end(RenderReport& rep) {
     using clk = std::chrono::steady_clock;
@@ -732,11 +731,14 @@ int Api::pbrt_world_end(RenderReport& rep) {
         if (film_p_.strings.count("filename")) warn("Output filename supplied on command line, '" + override_outfile + "' is overriding filename provided in scene description file, '" + filename + "'.");
         filename = override_outfile;
     }
-    if (!ends_with(filename, ".pfm")) {  // this host writes PFM only (image_io.rs:336-374); EXR/PNG/TGA encoders are out of scope
+    {   // write_image (image_io.rs:225-237) knows .exr, .tga, .png and .pfm; anything else is an error before rendering, not after
         size_t dot = filename.find_last_of('.'), slash = filename.find_last_of('/');
-        std::string stem = (dot != std::string::npos && (slash == std::string::npos || dot > slash)) ? filename.substr(0, dot) : filename;
-        warn("Image format of '" + filename + "' is not written by this host; writing '" + stem + ".pfm' instead.");
-        filename = stem + ".pfm";
+        std::string ext = (dot != std::string::npos && (slash == std::string::npos || dot > slash)) ? filename.substr(dot) : "";
+        for (char& c : ext) c = (char)std::tolower((unsigned char)c);
+        if (!(ext == ".exr" || ext == ".tga" || ext == ".png" || ext == ".pfm")) {
+            error = ext.empty() ? "Can't determine file type from suffix of filename " + filename : "Extension " + ext + " is not supported";
+            return PBRT_HIP_ERR_INVALID_ARG;
+        }
     }
     const float film_scale = film_p_.find_one_float("scale", 1.0f);
     const float max_lum = film_p_.find_one_float("maxsampleluminance", std::numeric_limits<float>::infinity());
@@ -827,7 +829,7 @@ int Api::pbrt_world_end(RenderReport& rep) {
     if (!check(rc, "render_path")) return rc;
     if (!check(pbrt_hip_film_to_rgb(scene_, xyz.data(), wt.data(), rgb.data()), "film_to_rgb")) return PBRT_HIP_ERR_DEVICE;
     std::string err;
-    if (!write_pfm(filename, rgb.data(), cb[2] - cb[0], cb[3] - cb[1], err)) { error = err; return PBRT_HIP_ERR_INVALID_ARG; }
+    if (!write_image(filename, rgb.data(), cb[2] - cb[0], cb[3] - cb[1], err)) { error = err; return PBRT_HIP_ERR_INVALID_ARG; }
     rep.out_file = filename; rep.warnings = warnings;
     return PBRT_HIP_OK;
 }

@@ -147,6 +147,9 @@ bool read_ply(const std::string& path, PlyMesh& out, std::string& err);
 // core/src/image_io.rs:42-50 (PFM, TGA, PNG): width*height RGB floats, top row first
 bool read_image(const std::string& path, std::vector<float>& rgb, int& w, int& h, std::string& err);
 
+// core/src/image_io.rs:225-237: .pfm, .exr (uncompressed float), .png / .tga (8-bit through apply_gamma)
+bool write_image(const std::string& path, const float* rgb, int w, int h, std::string& err);
+
 // core/src/image_io.rs:336-374
 bool write_pfm(const std::string& path, const float* rgb, int w, int h, std::string& err);
 

@@ -86,3 +86,65 @@ def write_png(path, img8, color_type=2, filters=(0, 1, 2, 3, 4), palette=None):
         for i in range(0, len(comp), third):
             f.write(chunk(b"IDAT", comp[i:i + third]))
         f.write(chunk(b"IEND", b""))
+
+
+def write_exr(path, img, compression="none", half=False, with_alpha=False, decreasing_y=False):
+    """Single-part scanline OpenEXR (tests only): channels [A] B G R, float or half, compression none | zips | zip."""
+    img = np.asarray(img, np.float32)
+    h, w = img.shape[:2]
+    comp = {"none": 0, "zips": 2, "zip": 3}[compression]
+    names = (["A"] if with_alpha else []) + ["B", "G", "R"]
+    ptype = 1 if half else 2
+
+    def attr(name, ty, val):
+        return name.encode() + b"\0" + ty.encode() + b"\0" + struct.pack("<I", len(val)) + val
+    ch = b"".join(n.encode() + b"\0" + struct.pack("<IBBBBII", ptype, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    hdr = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", ch) + attr("compression", "compression", bytes([comp])) + attr("dataWindow", "box2i", box) + \
+        attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", bytes([1 if decreasing_y else 0])) + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + \
+        attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lpb = 16 if comp == 3 else 1
+    blocks = []
+    for y0 in range(0, h, lpb):
+        raw = bytearray()
+        for y in range(y0, min(y0 + lpb, h)):
+            for n in names:
+                row = np.ones(w, np.float32) if n == "A" else img[y, :, "RGB".index(n)]
+                raw += (row.astype(np.float16) if half else row.astype("<f4")).tobytes()
+        raw = bytes(raw)
+        data = raw
+        if comp:
+            a = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)         # even / odd byte split
+            p = t.copy(); p[1:] = (t[1:] - t[:-1] + 128 + 256) % 256        # byte predictor
+            z = zlib.compress(p.astype(np.uint8).tobytes(), 6)
+            data = z if len(z) < len(raw) else raw                          # blocks that do not shrink are stored raw
+        blocks.append((y0, data))
+    order = list(reversed(blocks)) if decreasing_y else blocks
+    table_pos = len(hdr)
+    body = bytearray(); offs = {}
+    pos = table_pos + 8 * len(blocks)
+    for y0, data in order:
+        offs[y0] = pos
+        body += struct.pack("<iI", y0, len(data)) + data
+        pos += 8 + len(data)
+    table = b"".join(struct.pack("<Q", offs[y0]) for y0, _ in blocks)
+    with open(path, "wb") as f:
+        f.write(hdr + table + bytes(body))
+
+
+def read_png_rgb8(path):
+    """Decoder for the PNGs this repo's host writes (8-bit RGB, filter 0 rows)."""
+    d = open(path, "rb").read()
+    assert d[:8] == b"\x89PNG\r\n\x1a\n"
+    pos = 8; idat = b""; w = h = 0
+    while pos < len(d):
+        n, ty = struct.unpack(">I4s", d[pos:pos + 8])
+        body = d[pos + 8:pos + 8 + n]
+        assert zlib.crc32(ty + body) & 0xFFFFFFFF == struct.unpack(">I", d[pos + 8 + n:pos + 12 + n])[0]
+        if ty == b"IHDR": w, h, depth, ct = struct.unpack(">IIBB", body[:10]); assert (depth, ct) == (8, 2)
+        elif ty == b"IDAT": idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)

@@ -37,10 +37,15 @@ def test_check_mode_crop_and_outfile(tmp_path):
     path = ds.write_files(str(tmp_path), crop=(0.25, 0.75, 0.5, 1.0))
     r = run(["--check", "--quiet", "--outfile", "x.exr", path])
     assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["out_file"] == "x.exr"      # .exr / .png / .tga / .pfm are all written (image_io.rs:225-237)
+    r = run(["--check", "--quiet", "--outfile", "x.jpg", path])
+    assert r.returncode == 1 and "not supported" in r.stderr
+    r = run(["--check", "--quiet", "--outfile", "x.pfm", path])
+    assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["crop"] == [14, 20, 42, 40]
-    assert info["out_file"] == "x.pfm"                  # only PFM is written; the name is adjusted with a warning
-    assert info["warnings"] >= 2
+    assert info["out_file"] == "x.pfm"
+    assert info["warnings"] >= 1
 
 
 @pytest.mark.parametrize("text,needle", [
@@ -55,7 +60,7 @@ def test_check_mode_crop_and_outfile(tmp_path):
     ('Camera "orthographic"\nWorldBegin\nWorldEnd\n', 'Camera "orthographic"'),
     ('Integrator "bdpt"\nWorldBegin\nWorldEnd\n', 'Integrator "bdpt"'),
     ('Sampler "random"\nWorldBegin\nWorldEnd\n', 'Sampler "random"'),
-    ('WorldBegin\nLightSource "infinite" "string mapname" "sky.exr"\nWorldEnd\n', "mapname"),
+    ('WorldBegin\nLightSource "infinite" "string mapname" "sky.jpg"\nWorldEnd\n', "mapname"),
     ('WorldBegin\nTexture "c" "color" "ptex"\nMaterial "matte" "texture Kd" "c"\n'
      'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "ptex"),
     ('WorldBegin\nLightSource "point" "blackbody I" [6500 1]\nWorldEnd\n', "spectral type"),

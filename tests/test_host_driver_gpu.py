@@ -424,3 +424,21 @@ WorldEnd
         sb = capture(s)
         xyz, wt, _ = s.render_path(max_depth=depth, light_strategy=0, pixel_bounds=sb)
         assert (s.film_to_rgb(xyz, wt).reshape(res, res, 3).view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def test_output_formats(tmp_path, host):
+    """Film "filename" with .exr / .png / .tga (core/src/image_io.rs:225-237): the EXR holds the PFM's floats, the 8-bit files its gamma-encoded bytes."""
+    import image_files as imf
+    path = ds.write_files(str(tmp_path))
+    outs = {}
+    for ext in ("pfm", "exr", "png"):
+        r = subprocess.run([ds.RENDER_BIN, "--quiet", "--outfile", str(tmp_path / ("o." + ext)), path], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+    ref = ds.read_pfm(str(tmp_path / "o.pfm"))
+    r = subprocess.run([ds.RENDER_BIN, "--convert-image", str(tmp_path / "o.exr"), str(tmp_path / "back.pfm")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(ds.read_pfm(str(tmp_path / "back.pfm")).view(np.uint32), ref.view(np.uint32))
+    png = imf.read_png_rgb8(str(tmp_path / "o.png"))
+    g = np.where(ref <= 0.0031308, 12.92 * ref, 1.055 * np.power(np.maximum(ref, 0), 1 / 2.4) - 0.055)
+    want = np.clip(255.0 * g + 0.5, 0, 255).astype(np.uint8)
+    assert png.shape == want.shape and np.abs(png.astype(int) - want.astype(int)).max() <= 1

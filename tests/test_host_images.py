@@ -60,9 +60,10 @@ def test_png_colour_types_and_row_filters(tmp_path, ct):
 
 def test_undecodable_files_are_errors_not_black_textures(tmp_path):
     (tmp_path / "x.exr").write_bytes(b"v/1\x01")
+    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0")
     (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\nnonsense")
     (tmp_path / "short.tga").write_bytes(b"\0" * 10)
-    for name, msg in (("x.exr", "not decoded"), ("bad.png", "PNG"), ("short.tga", "TGA"), ("missing.pfm", "cannot open")):
+    for name, msg in (("x.jpg", "not decoded"), ("x.exr", "EXR: bad magic"), ("bad.png", "PNG"), ("short.tga", "TGA"), ("missing.pfm", "cannot open")):
         r, _ = _convert(tmp_path, name)
         assert r.returncode != 0 and msg in r.stderr
     # and a scene that names an undecodable map fails to load, also in --check mode (no GPU involved)
@@ -70,3 +71,42 @@ def test_undecodable_files_are_errors_not_black_textures(tmp_path):
                                      'Texture "t" "color" "imagemap" "string filename" "x.exr"\nWorldEnd\n')
     r = subprocess.run([ds.RENDER_BIN, "--check", str(tmp_path / "s.pbrt")], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "x.exr" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(compression="zips", half=True), dict(compression="zip"), dict(compression="zip", half=True, with_alpha=True, decreasing_y=True)])
+def test_exr_reader(tmp_path, kw):
+    img = np.random.default_rng(4).uniform(0, 50, (37, 21, 3)).astype(np.float32)
+    img[3:9, 2:8] = 1.5                                        # compressible runs
+    img[0, 0] = (0.0, 6.1e-5, 65504.0)                         # half: zero, near the subnormal edge, the largest finite value
+    imf.write_exr(str(tmp_path / "e.exr"), img, **kw)
+    r, got = _convert(tmp_path, "e.exr"); assert r.returncode == 0, r.stderr
+    want = img.astype(np.float16).astype(np.float32) if kw.get("half") else img
+    assert np.array_equal(got, want)
+
+
+def test_half_subnormals_and_specials(tmp_path):
+    vals = np.array([5.96e-8, 1e-7, 6.0e-5, -3.0e-6, np.inf, -np.inf, 1.0, -2.5], np.float32)
+    img = np.tile(vals[None, :, None], (2, 1, 3)).astype(np.float32)
+    imf.write_exr(str(tmp_path / "h.exr"), img, half=True)
+    r, got = _convert(tmp_path, "h.exr"); assert r.returncode == 0, r.stderr
+    assert np.array_equal(got, img.astype(np.float16).astype(np.float32))
+
+
+def test_image_writers_round_trip(tmp_path):
+    """write_image (image_io.rs:225-237): EXR keeps the floats, PNG / TGA store clamp(255 * gamma_correct(v) + 0.5, 0, 255) as u8."""
+    img = np.random.default_rng(6).uniform(-0.1, 1.3, (9, 14, 3)).astype(np.float32)
+    img[0, 0] = (0.0, 0.0031308, 1.0)
+    imf.write_pfm(str(tmp_path / "src.pfm"), img)
+    for ext in ("exr", "png", "tga"):
+        r = subprocess.run([ds.RENDER_BIN, "--convert-image", str(tmp_path / "src.pfm"), str(tmp_path / ("o." + ext))], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+    r, back = _convert(tmp_path, "o.exr"); assert r.returncode == 0 and np.array_equal(back, img)
+    x = img.astype(np.float32)
+    g = np.where(x <= np.float32(0.0031308), np.float32(12.92) * x, np.float32(1.055) * np.power(np.maximum(x, 0), np.float32(1.0 / 2.4), dtype=np.float32) - np.float32(0.055))
+    want = np.clip(np.float32(255.0) * g.astype(np.float32) + np.float32(0.5), 0, 255).astype(np.uint8)
+    png = imf.read_png_rgb8(str(tmp_path / "o.png"))
+    assert np.abs(png.astype(int) - want.astype(int)).max() <= 1 and (png == want).mean() > 0.98     # powf: numpy vs libm may differ in the last bit
+    r, tga = _convert(tmp_path, "o.tga"); assert r.returncode == 0
+    assert np.array_equal(tga, png.astype(np.float32) / np.float32(255.0))
+    bad = subprocess.run([ds.RENDER_BIN, "--convert-image", str(tmp_path / "src.pfm"), str(tmp_path / "o.jpg")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "not supported" in bad.stderr
