@@ -90,6 +90,10 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     uint32_t bump_tex1; // 0, or 1 + the displacement texture of Material::bump (core/src/material.rs:62-101)
     uint32_t pad[2];
 };
+// What the texture pass hands the shade pass for one path vertex (wavefront.hip: texture_kernel): the bumped shading frame and the evaluated,
+// clamped (and pre-multiplied) colours of the material's textured lobe colours, in template-lobe order (r before t).
+#define PH_HIT_COLS 6
+struct TexOut { float ns[3]; uint32_t bumped; float dpdu_s[3]; uint32_t pad; float col[PH_HIT_COLS][4]; };  // 128 B
 #define PH_HIT_LOBES 5   // per-thread slots for the per-hit lobe list of a textured material (uber: up to 5 lobes)
 
 // ---- textures (textures/src/*.rs, core/src/mipmap/mod.rs).  A texture is a postfix program over a small value stack: the host

@@ -397,7 +397,7 @@ static __device__ __noinline__ float envmap_pdf(const DeviceScene* dsc, uint32_t
 // The texture-evaluation context of a hit, out of line.  Everything texture evaluation needs beyond what the integrator carries is rebuilt
 // here from the TriRec the traversal reported: uv (triangle.rs:584), the geometric dp/du, dp/dv (:548-574, carried to world space for an
 // instance: transform.rs:566-590) and — for camera rays only — du/dv d x/y.
-static __device__ __noinline__ TexCtx hit_tex_ctx(const DeviceScene* dsc, const CameraRec* cam, uint32_t spp, uint32_t tri_index, uint32_t inst,
+PH_DEV TexCtx hit_tex_ctx(const DeviceScene* dsc, const CameraRec* cam, uint32_t spp, uint32_t tri_index, uint32_t inst,
                                                   f3 bary, f3 p, f3 n, f3 ro, f3 rd, f2 p_film, f2 lens, uint32_t camera_ray) {
     const DeviceScene& sc = *dsc;
     const float4* tp = reinterpret_cast<const float4*>(sc.tris + tri_index);
@@ -439,18 +439,30 @@ PH_DEV spec tex_eval_clamped(const DeviceScene* dsc, uint32_t tex, const TexCtx&
 // The hit's own lobe list of a textured material: the template lobes with their textured colours filled in, a lobe dropped where the reference
 // would not add it (`if !kd.is_black()`, plastic.rs:63 / :70, mirror.rs:55, matte.rs:66, uber.rs:134-160; FresnelBlend / FresnelSpecular unless both
 // colours are black, substrate.rs:62, glass.rs:76-78).
-PH_DEV uint32_t build_hit_lobes(const DeviceScene* dsc, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, LobeRec* out) {
+PH_DEV bool lobe_keep(const LobeRec& l) {
+    const bool r_black = l.r[0] == 0.0f && l.r[1] == 0.0f && l.r[2] == 0.0f, t_black = l.t[0] == 0.0f && l.t[1] == 0.0f && l.t[2] == 0.0f;
+    // which colour decides whether the reference adds the lobe: both for the two-colour lobes, t for the transmission lobes, r otherwise
+    return (l.kind == PH_LK_FRESNEL_BLEND || l.kind == PH_LK_FRESNEL_SPEC) ? !(r_black && t_black)
+         : ((l.kind == PH_LK_SPEC_T || l.kind == PH_LK_MICRO_T || l.kind == PH_LK_LAMBERT_T) ? !t_black : !r_black);
+}
+// texture pass: the textured colours of a material's template lobes at this hit, in lobe order (r before t), clamped and pre-multiplied
+PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, TexOut& out) {
     uint32_t k = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const LobeRec& l = tmpl[i];
+        const spec pre = l.has_pre ? mks(l.pre[0], l.pre[1], l.pre[2]) : mks1(1.0f);
+        if (l.r_tex1 && k < PH_HIT_COLS) { spec c = tex_eval_clamped(dsc, l.r_tex1 - 1u, ctx); if (l.has_pre) c = pre * c; out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++; }
+        if (l.t_tex1 && k < PH_HIT_COLS) { spec c = tex_eval_clamped(dsc, l.t_tex1 - 1u, ctx); if (l.has_pre) c = pre * c; out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++; }
+    }
+}
+// shade pass: the hit's own lobe list = template lobes with the texture pass's colours filled in, a lobe dropped where the reference would not add it
+PH_DEV uint32_t build_hit_lobes(const LobeRec* tmpl, uint32_t n, const TexOut* in, LobeRec* out) {
+    uint32_t k = 0, ci = 0;
     for (uint32_t i = 0; i < n && k < PH_HIT_LOBES; i++) {
         LobeRec l = tmpl[i];
-        const spec pre = l.has_pre ? mks(l.pre[0], l.pre[1], l.pre[2]) : mks1(1.0f);
-        if (l.r_tex1) { spec c = tex_eval_clamped(dsc, l.r_tex1 - 1u, ctx); if (l.has_pre) c = pre * c; l.r[0] = c.r; l.r[1] = c.g; l.r[2] = c.b; }
-        if (l.t_tex1) { spec c = tex_eval_clamped(dsc, l.t_tex1 - 1u, ctx); if (l.has_pre) c = pre * c; l.t[0] = c.r; l.t[1] = c.g; l.t[2] = c.b; }
-        const bool r_black = l.r[0] == 0.0f && l.r[1] == 0.0f && l.r[2] == 0.0f, t_black = l.t[0] == 0.0f && l.t[1] == 0.0f && l.t[2] == 0.0f;
-        // which colour decides whether the reference adds the lobe: both for the two-colour lobes, t for the transmission lobes, r otherwise
-        const bool keep = (l.kind == PH_LK_FRESNEL_BLEND || l.kind == PH_LK_FRESNEL_SPEC) ? !(r_black && t_black)
-                        : ((l.kind == PH_LK_SPEC_T || l.kind == PH_LK_MICRO_T || l.kind == PH_LK_LAMBERT_T) ? !t_black : !r_black);
-        if (keep) out[k++] = l;
+        if (l.r_tex1 && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; ci++; }
+        if (l.t_tex1 && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; ci++; }
+        if (lobe_keep(l)) out[k++] = l;
     }
     return k;
 }
@@ -461,7 +473,7 @@ struct BumpOut { f3 ns, dpdu_s; };
 struct BumpIn { uint32_t tex, tri_index, inst; f3 bary, p, n, ns, dpdu_s; TexCtx c; };
 // arguments travel through one private struct: with ~40 scalar arguments (most of them on the stack) this function, out of line, corrupted values of OTHER
 // lanes of the wave in the one-lobe kernel on gfx950
-static __device__ __noinline__ void hit_bump(const DeviceScene* dsc, const BumpIn* in, BumpOut* out) {
+PH_DEV void hit_bump(const DeviceScene* dsc, const BumpIn* in, BumpOut* out) {
     const DeviceScene& sc = *dsc;
     const uint32_t tex = in->tex, tri_index = in->tri_index, inst = in->inst;
     const f3 bary = in->bary, p = in->p, n = in->n, ns = in->ns, dpdu_s = in->dpdu_s;

@@ -63,7 +63,8 @@ struct WfParams {
     SpatialRec spatial;
     // materials that evaluate a texture per hit (texture.h): device copy of `cam` for the out-of-line evaluation
     const CameraRec* cam_dev; uint32_t textured;
-    LobeRec* hit_lobes;  // general-BSDF kernel only: one slot per thread of the grid
+    LobeRec* hit_lobes;  // general-BSDF kernel only: PH_HIT_LOBES slots per thread of the grid
+    TexOut* tex_out;     // texture pass -> shade pass, one record per path of the chunk
 };
 
 PH_DEV uint32_t wave_alloc(uint32_t* ctr, bool want) {
@@ -168,6 +169,59 @@ __global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfPar
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Texture pass: one thread per live path whose new vertex lies on a material with per-hit textures or a bump map.  It rebuilds the surface
+// interaction, the texture context (uv, dp/du, dp/dv, camera-ray differentials), runs Material::bump and evaluates the textured lobe colours,
+// and leaves the results in tex_out[pid] for the shade pass.  A pass of its own so that the evaluator's registers and calls stay out of the shade kernel.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void texture_kernel(DeviceScene sc, WfParams w, int it) {
+    const uint32_t n_live = w.ctr[it].n_live;
+    const uint32_t* live_in = w.live[it & 1];
+    const RayIn* rays_in = w.rays_cl[it & 1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_live; i += gridDim.x * blockDim.x) {
+        const uint32_t pid = live_in[i];
+        const uint4 idx4 = w.s_idx[pid];
+        const uint32_t flags = idx4.w & 0xffu, bounces = (idx4.w >> 8) & 0xffu;
+        if (!(flags & F_EXT) || (int)bounces >= w.max_depth) continue;
+        const float4* hp = reinterpret_cast<const float4*>(w.hits_cl + idx4.x);
+        const float4 h0 = hp[0];
+        if (__float_as_uint(h0.y) == 0xFFFFFFFFu) continue;
+        const float4 h1 = hp[1];
+        const RayIn ray = load_ray(rays_in + idx4.x);
+        const f3 rd = mk3(ray.dx, ray.dy, ray.dz);
+        MeshRec m;
+        const SurfHit si = make_surface_hit_any(sc, rd, ray.time, __float_as_uint(h1.y), __float_as_uint(h1.z), h0.z, h0.w, h1.x, m);
+        const MaterialRec& mr = sc.materials[m.material];
+        if (mr.none || !(mr.textured || mr.kd_tex1 || mr.bump_tex1)) continue;
+        const uint32_t camera_ray = (bounces == 0u && !(flags & F_NODIFF)) ? 1u : 0u;  // only camera rays carry differentials
+        f2 p_film = mk2(0.0f, 0.0f), lens = mk2(0.0f, 0.0f);
+        if (camera_ray) {
+            const uint32_t ppix = pid / w.chunk_spp;
+            const size_t gsi = (size_t)(w.s0 + (pid - ppix * w.chunk_spp)) * w.n_px + ppix;
+            p_film = mk2(w.rec_L[gsi].w, w.rec_py[gsi]);
+            if (w.cam.lens_radius > 0.0f) { const float4 la = w.s_A[pid]; lens = mk2(la.x, la.y); }
+        }
+        const TexCtx ctx = hit_tex_ctx(sc.self, w.cam_dev, w.sp.spp, __float_as_uint(h1.y), __float_as_uint(h1.z), mk3(h0.z, h0.w, h1.x), si.p, si.n,
+                                       mk3(ray.ox, ray.oy, ray.oz), rd, p_film, lens, camera_ray);
+        TexOut out;
+        out.bumped = 0u; out.pad = 0u;
+        out.ns[0] = si.ns.x; out.ns[1] = si.ns.y; out.ns[2] = si.ns.z; out.dpdu_s[0] = si.dpdu_s.x; out.dpdu_s[1] = si.dpdu_s.y; out.dpdu_s[2] = si.dpdu_s.z;
+        if (mr.bump_tex1) {
+            BumpIn bi; bi.tex = mr.bump_tex1 - 1u; bi.tri_index = __float_as_uint(h1.y); bi.inst = __float_as_uint(h1.z); bi.bary = mk3(h0.z, h0.w, h1.x);
+            bi.p = si.p; bi.n = si.n; bi.ns = si.ns; bi.dpdu_s = si.dpdu_s; bi.c = ctx;
+            BumpOut bo;
+            hit_bump(sc.self, &bi, &bo);
+            out.ns[0] = bo.ns.x; out.ns[1] = bo.ns.y; out.ns[2] = bo.ns.z; out.dpdu_s[0] = bo.dpdu_s.x; out.dpdu_s[1] = bo.dpdu_s.y; out.dpdu_s[2] = bo.dpdu_s.z;
+            out.bumped = 1u;
+        }
+        for (int k = 0; k < PH_HIT_COLS; k++) out.col[k][0] = out.col[k][1] = out.col[k][2] = out.col[k][3] = 0.0f;
+        if (mr.textured) eval_lobe_colours(sc.self, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out);
+        else if (mr.kd_tex1) { const spec c = tex_eval_clamped(sc.self, mr.kd_tex1 - 1u, ctx); out.col[0][0] = c.r; out.col[0][1] = c.g; out.col[0][2] = c.b; }
+        float4* dst = reinterpret_cast<float4*>(w.tex_out + pid);
+        const float4* src = reinterpret_cast<const float4*>(&out);
+        for (int k = 0; k < (int)(sizeof(TexOut) / 16); k++) dst[k] = src[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // K4 (+K6): one thread per live path.
 // Queue appends are aggregated per BLOCK: rays are staged in LDS the moment they are known (which keeps them out of the
 // register file during the long vertex computation), then one thread per queue claims the block's slots with a single
@@ -185,8 +239,8 @@ template <> struct BsdfOps<false> {
     static PH_DEV void sample_ns(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi) { bsdf_sample_f(b, wo, u, f, pdf, wi); }
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, f, pdf, wi); type = BX_REFL | BX_DIFF; }
     static PH_DEV float eta(const T&) { return 1.0f; }
-    static PH_DEV void apply_textures(const DeviceScene& sc, T& b, const MaterialRec& mr, const TexCtx& ctx, LobeRec*) {
-        const spec kd = tex_eval_clamped(sc.self, mr.kd_tex1 - 1u, ctx);
+    static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec*) {
+        const spec kd = mks(to->col[0][0], to->col[0][1], to->col[0][2]);
         b.r = kd; b.has_bxdf = !is_black(kd);
     }
 };
@@ -200,8 +254,8 @@ template <> struct BsdfOps<true> {
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, BX_ALL, f, pdf, wi, type); }
     static PH_DEV float eta(const T& b) { return b.eta; }
     // the hit's own lobe list goes to the thread's slots of WfParams::hit_lobes
-    static PH_DEV void apply_textures(const DeviceScene& sc, T& b, const MaterialRec&, const TexCtx& ctx, LobeRec* slots) {
-        b.n = build_hit_lobes(sc.self, b.lobes, b.n, ctx, slots);
+    static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec* slots) {
+        b.n = build_hit_lobes(b.lobes, b.n, to, slots);
         b.lobes = slots;
     }
 };
@@ -211,7 +265,7 @@ template <> struct BsdfOps<true> {
 // 51 spilled registers and gains 6 % from the fourth wave, the general-BSDF kernel would spill 181 and loses, so it stays at 3; so do the
 // texture variants, whose out-of-line calls keep many values live (textured matte: 279 spilled registers at 4 waves, 45 at 3; 19.5 -> 15.9 ms).
 #define PH_SHADE_ATTR __attribute__((amdgpu_waves_per_eu((GEN || TEX) ? 3 : 4, (GEN || TEX) ? 3 : 4)))
-template <bool GEN, bool TEX = false, bool BUMP = false>
+template <bool GEN, bool TEX = false>
 __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(DeviceScene sc, WfParams w, int it) {
     using BO = BsdfOps<GEN>;
     __shared__ float4 stage[3][2][PH_SHADE_BLOCK];           // [ext, mis, shadow][ray halves][thread]
@@ -344,35 +398,21 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                     } else if ((int)bounces < w.max_depth) {
                         const uint32_t ppix = pid / w.chunk_spp;
                         const int2 xy = w.px_xy[ppix];
-                        TexCtx ctx;
                         bool tex_hit = false;
-                        if (TEX) {  // compiled into separate instantiations: the out-of-line calls would cost the texture-free kernels registers
+                        if (TEX) {  // the texture pass (texture_kernel) left this vertex's bumped frame and textured colours in tex_out[pid]
                             const MaterialRec& mr = sc.materials[m.material];
-                            tex_hit = (GEN ? mr.textured != 0u : mr.kd_tex1 != 0u) || (BUMP && mr.bump_tex1 != 0u);
-                            if (tex_hit) {  // some colour of this material, or its shading frame, is this hit's (matte.rs:63, plastic.rs:62-70, material.rs:62-101, ...)
-                                const uint32_t camera_ray = (bounces == 0u && !(flags & F_NODIFF)) ? 1u : 0u;  // only camera rays carry differentials
-                                f2 p_film = mk2(0.0f, 0.0f), lens = mk2(0.0f, 0.0f);
-                                if (camera_ray) {
-                                    const size_t gsi = (size_t)(w.s0 + (pid - ppix * w.chunk_spp)) * w.n_px + ppix;
-                                    p_film = mk2(w.rec_L[gsi].w, w.rec_py[gsi]);
-                                    if (w.cam.lens_radius > 0.0f) { const float4 la = w.s_A[pid]; lens = mk2(la.x, la.y); }
-                                }
-                                ctx = hit_tex_ctx(sc.self, w.cam_dev, w.sp.spp, __float_as_uint(h1.y), __float_as_uint(h1.z), mk3(h0.z, h0.w, h1.x),
-                                                  si.p, si.n, mk3(ray.ox, ray.oy, ray.oz), rd, p_film, lens, camera_ray);
-                                if (BUMP && mr.bump_tex1) {  // (its own instantiations again) Material::bump runs before the BSDF is made: it changes the shading frame the BSDF is built on
-                                    BumpIn bi; bi.tex = mr.bump_tex1 - 1u; bi.tri_index = __float_as_uint(h1.y); bi.inst = __float_as_uint(h1.z); bi.bary = mk3(h0.z, h0.w, h1.x);
-                                    bi.p = si.p; bi.n = si.n; bi.ns = si.ns; bi.dpdu_s = si.dpdu_s; bi.c = ctx;
-                                    BumpOut bo;
-                                    hit_bump(sc.self, &bi, &bo);
-                                    si.ns = bo.ns; si.dpdu_s = bo.dpdu_s;
-                                }
+                            tex_hit = (GEN ? mr.textured != 0u : mr.kd_tex1 != 0u) || mr.bump_tex1 != 0u;
+                            if (tex_hit && mr.bump_tex1) {  // Material::bump: the BSDF is made on the bumped frame
+                                const float4* tp = reinterpret_cast<const float4*>(w.tex_out + pid);
+                                const float4 f0 = tp[0], f1 = tp[1];
+                                si.ns = mk3(f0.x, f0.y, f0.z); si.dpdu_s = mk3(f1.x, f1.y, f1.z);
                             }
                         }
                         typename BO::T bsdf = BO::make(sc, si, m.material);
                         if (TEX && tex_hit) {
                             const MaterialRec& mr = sc.materials[m.material];
                             if (GEN ? mr.textured != 0u : mr.kd_tex1 != 0u)
-                                BO::apply_textures(sc, bsdf, mr, ctx, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr);
+                                BO::apply_textures(bsdf, w.tex_out + pid, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr);
                         }
                         SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid - ppix * w.chunk_spp), dim, hl);
                         // Draw the next 8 dimensions in one (not unrolled) loop: light pick 1D, u_light 2D, u_scattering 2D, BSDF 2D,
@@ -678,7 +718,7 @@ struct Wavefront {
     std::vector<int2> px_xy;
     int sb[4] = {0, 0, 0, 0}, ntx = 0, nty = 0, tile_size = 0, part = 0, parts = 0;
     uint32_t slot_w = 0, slot_h = 0;
-    DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats, d_cam, d_hit_lobes;
+    DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats, d_cam, d_hit_lobes, d_tex_out;
     DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_recL, d_recpy, d_tilebuf, d_xyz, d_w;
     DevBuf d_vox_slot, d_sp_pool, d_sp_list, d_sp_ctr, d_sp_halton;  // SpatialLightDistribution tables (spatial.h)
     std::vector<hipEvent_t> events;
@@ -690,7 +730,7 @@ void free_wavefront(PbrtHipScene* s) {
     Wavefront* w = s->wf;
     if (!w) return;
     for (DevBuf* b : {&w->d_tiles, &w->d_px, &w->d_rays_cl[0], &w->d_rays_cl[1], &w->d_hits, &w->d_rays_sh, &w->d_occ, &w->d_live[0], &w->d_live[1], &w->d_ctr,
-                      &w->d_stats, &w->d_cam, &w->d_hit_lobes, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
+                      &w->d_stats, &w->d_cam, &w->d_hit_lobes, &w->d_tex_out, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
                       &w->d_vox_slot, &w->d_sp_pool, &w->d_sp_list, &w->d_sp_ctr, &w->d_sp_halton})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : w->events) (void)hipEventDestroy(e);
@@ -905,7 +945,11 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     std::vector<ph::IterCounters> hctr((size_t)n_iter_cap + 2);
     // general materials with per-hit textures keep PH_HIT_LOBES LobeRec slots per thread of the grid: a smaller grid (each block loops more) bounds that buffer
     const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, (s->textured_materials && s->general_materials) ? 256 * 4 : 256 * 16);
-    wp.hit_lobes = nullptr;
+    wp.hit_lobes = nullptr; wp.tex_out = nullptr;
+    if (s->textured_materials) {
+        if ((rc = ensure_buf(s, w.d_tex_out, (size_t)B * sizeof(TexOut)))) return rc;
+        wp.tex_out = (TexOut*)w.d_tex_out.p;
+    }
     if (s->textured_materials && s->general_materials) {
         if ((rc = ensure_buf(s, w.d_hit_lobes, (size_t)shade_blocks * PH_SHADE_BLOCK * PH_HIT_LOBES * sizeof(LobeRec)))) return rc;
         wp.hit_lobes = (LobeRec*)w.d_hit_lobes.p;
@@ -947,10 +991,8 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
                     }))) return rc;
             }
             if ((rc = timed(2, [&]() {
-                    if (s->textured_materials && s->bump_materials) {
-                        if (s->general_materials) hipLaunchKernelGGL((ph::shade_kernel<true, true, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
-                        else hipLaunchKernelGGL((ph::shade_kernel<false, true, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
-                    } else if (s->textured_materials) {
+                    if (s->textured_materials) {
+                        hipLaunchKernelGGL(ph::texture_kernel, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         if (s->general_materials) hipLaunchKernelGGL((ph::shade_kernel<true, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         else hipLaunchKernelGGL((ph::shade_kernel<false, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                     } else if (s->general_materials) hipLaunchKernelGGL(ph::shade_kernel<true>, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
