@@ -1,0 +1,174 @@
+"""-m gpu: randomized differential test of the texture system on top of tests/test_fuzz_gpu.py's scene generator: random texture trees
+(image maps of random size / filter / wrap / gamma, every procedural class, scale / mix nesting, all mappings) on the colour parameters that
+take them, random bump maps, an optional radiance-map sky.  Film and counters must equal the oracle's bit for bit."""
+import numpy as np
+import pytest
+
+import pbrt_hip
+import scenes
+from oracle_binding import OracleScene, set_libm_mode
+import test_fuzz_gpu as F
+
+pytestmark = pytest.mark.gpu
+
+
+def random_image(rng, hdr=False):
+    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    img = rng.uniform(0.0, 4.0 if hdr else 1.0, (h, w, 3)).astype(np.float32)
+    if rng.integers(0, 3) == 0:
+        img[rng.uniform(0, 1, (h, w)) < 0.3] = 0.0      # exactly black texels: lobes vanish there
+    return img
+
+
+def random_mapping(s, host, rng, tex):
+    k = int(rng.integers(0, 6))
+    if k == 3:
+        s.set_texture_mapping(tex, "spherical", F.random_transform(host, rng)[1])
+    elif k == 4:
+        s.set_texture_mapping(tex, "cylindrical", F.random_transform(host, rng)[1])
+    elif k == 5:
+        s.set_texture_mapping(tex, "planar", np.concatenate([rng.uniform(-1, 1, 6), rng.uniform(-0.5, 0.5, 2)]).astype(np.float32))
+    return tex
+
+
+def random_texture(s, host, rng, as_float, depth=0):
+    """A random texture tree of the requested value type (float textures: three equal channels)."""
+    m = F.random_transform(host, rng)[0]
+    uvp = dict(su=float(rng.uniform(0.3, 5)), sv=float(rng.uniform(0.3, 5)), du=float(rng.uniform(-1, 1)), dv=float(rng.uniform(-1, 1)))
+    k = int(rng.integers(0, 12 if depth < 2 else 9))
+
+    def const():
+        return s.add_texture_constant(float(rng.uniform(0, 1)) if as_float else tuple(rng.uniform(0, 1, 3)))
+    if k == 0:
+        return const()
+    if k in (1, 2):
+        mip = s.add_mipmap(random_image(rng), as_float=as_float, scale=float(rng.choice([1.0, 0.5])), gamma=bool(rng.integers(0, 2)), trilinear=bool(rng.integers(0, 2)),
+                           wrap=str(rng.choice(["repeat", "black", "clamp"])), max_anisotropy=float(rng.choice([8.0, 2.0])))
+        return random_mapping(s, host, rng, s.add_texture_imagemap(mip, **uvp))
+    if k == 3:
+        sub = (lambda: random_texture(s, host, rng, as_float, depth + 1)) if depth < 2 else const
+        return random_mapping(s, host, rng, s.add_texture_checkerboard(sub(), sub(), aa=str(rng.choice(["none", "closedform"])), **uvp))
+    if k == 4:
+        if as_float: return s.add_texture_bilerp(*[float(v) for v in rng.uniform(0, 1, 4)], **uvp)
+        return random_mapping(s, host, rng, s.add_texture_uv(**uvp))
+    if k == 5:
+        return random_mapping(s, host, rng, s.add_texture_dots(const(), const(), **uvp))
+    if k == 6:
+        return s.add_texture_fbm(m, float(rng.uniform(0.3, 0.7)), int(rng.integers(0, 8)), wrinkled=bool(rng.integers(0, 2)))
+    if k == 7:
+        return s.add_texture_windy(m) if as_float or rng.integers(0, 2) else s.add_texture_marble(m, 0.5, int(rng.integers(1, 8)), float(rng.uniform(0.5, 3)), float(rng.uniform(0, 0.5)))
+    if k == 8:
+        return s.add_texture_checkerboard3d(const(), const(), m)
+    if k == 9:
+        return s.add_texture_scale(random_texture(s, host, rng, as_float, depth + 1), random_texture(s, host, rng, as_float, depth + 1))
+    if k == 10:
+        return s.add_texture_mix(random_texture(s, host, rng, as_float, depth + 1), const(), random_texture(s, host, rng, True, depth + 2))
+    return s.add_texture_bilerp(*([float(v) for v in rng.uniform(0, 1, 4)] if as_float else [tuple(rng.uniform(0, 1, 3)) for _ in range(4)]), **uvp)
+
+
+def textured_material(s, host, rng):
+    one = (1, 1, 1)
+    c = lambda lo=0.0, hi=1.0: tuple(rng.uniform(lo, hi, 3))
+    k = int(rng.integers(0, 7))
+    tex = lambda: random_texture(s, host, rng, False)
+    if k == 0:
+        m = s.add_material_matte_tex(tex(), float(rng.choice([0.0, rng.uniform(1, 60)])))
+    elif k == 1:
+        m = s.add_material_plastic(one, one, float(rng.uniform(0.01, 0.4)), bool(rng.integers(0, 2)))
+        s.set_material_texture(m, "Kd", tex())
+        if rng.integers(0, 2): s.set_material_texture(m, "Ks", tex())
+    elif k == 2:
+        m = s.add_material_mirror(one); s.set_material_texture(m, "Kr", tex())
+    elif k == 3:
+        m = s.add_material_substrate(one, one, float(rng.uniform(0.02, 0.4)), float(rng.uniform(0.02, 0.4)), bool(rng.integers(0, 2)))
+        s.set_material_texture(m, "Kd", tex()); s.set_material_texture(m, "Ks", tex())
+    elif k == 4:
+        rough = float(rng.choice([0.0, rng.uniform(0.02, 0.3)]))
+        m = s.add_material_glass(one, one, rough, rough, float(rng.uniform(1.1, 1.8)), True)
+        s.set_material_texture(m, "Kr", tex()); s.set_material_texture(m, "Kt", tex())
+    elif k == 5:
+        op = float(rng.choice([1.0, rng.uniform(0.3, 0.9)]))
+        m = s.add_material_uber(one, one, one, one, (op, op, op), float(rng.uniform(0.02, 0.3)), float(rng.uniform(0.02, 0.3)), float(rng.uniform(1.1, 1.7)), True)
+        for prm in ("Kd", "Ks", "Kr", "Kt"):
+            if rng.integers(0, 2): s.set_material_texture(m, prm, tex())
+    else:
+        m = F.random_material(s, rng)       # a constant material, possibly only bumped
+        if rng.integers(0, 2) == 0: return m
+    mat_none = False
+    try:
+        if rng.integers(0, 2): s.set_material_bump(m, s.add_texture_scale(random_texture(s, host, rng, True), s.add_texture_constant(float(rng.uniform(0.005, 0.2)))))
+    except pbrt_hip.PbrtHipError:
+        mat_none = True                      # "none" has no BSDF to bump: refused identically by both libraries
+    return m
+
+
+def build_case(host, seed):
+    rng = np.random.default_rng(seed + 50000)
+    res = (int(rng.integers(17, 41)), int(rng.integers(13, 37)))
+    spp = int(rng.choice([1, 2, 4, 5]))
+    sky = rng.integers(0, 2)
+    st = rng.integers(0, 2 ** 31)
+    lens = float(rng.choice([0.0, 0.05]))
+
+    def cap(s):
+        g = np.random.default_rng(st)
+        if sky:
+            t = F.random_transform(host, g)
+            img = random_image(g, hdr=True)
+            img[int(g.integers(0, img.shape[0])), int(g.integers(0, img.shape[1]))] = (50.0, 40.0, 30.0)
+            s.add_light_infinite_map(tuple(g.uniform(0.2, 1.0, 3)), img, t[0], t[1])
+        else:
+            s.add_light_infinite(tuple(g.uniform(0.3, 1.0, 3)))
+        if g.integers(0, 2): s.add_light_point(tuple(g.uniform(2, 12, 3)), g.uniform(-1.5, 1.5, 3).astype(np.float32))
+        mats = [textured_material(s, host, g) for _ in range(4)]
+        for k in range(int(g.integers(2, 5))):
+            P, idx = host.gen_random_tris(int(g.integers(5, 120)), int(g.integers(1, 1000)))
+            N = g.normal(size=P.shape).astype(np.float32) if g.integers(0, 2) else None
+            S = g.normal(size=P.shape).astype(np.float32) if g.integers(0, 3) == 0 else None
+            UV = g.uniform(-1, 2, (len(P), 2)).astype(np.float32) if g.integers(0, 3) else None
+            s.add_mesh(P, idx, mats[k % 4], N=N, S=S, UV=UV, reverse_orientation=bool(g.integers(0, 2)), swaps_handedness=bool(g.integers(0, 2)))
+        Pg, ig = scenes.grid_mesh(3, z=-1.3, size=2.5)
+        s.add_mesh(Pg, ig, mats[3], UV=(Pg[:, :2] * np.float32(0.7)).astype(np.float32))
+        if g.integers(0, 2):
+            ob = s.object_begin()
+            P, idx = host.gen_random_tris(int(g.integers(2, 60)), int(g.integers(1, 1000)))
+            s.add_mesh(P * np.float32(0.5), idx, mats[1], N=(g.normal(size=P.shape).astype(np.float32) if g.integers(0, 2) else None), UV=g.uniform(0, 1, (len(P), 2)).astype(np.float32))
+            s.object_end()
+            for _ in range(int(g.integers(1, 4))):
+                t = F.random_transform(host, g)
+                s.add_instance(ob, t[0], t[1])
+        w2c, c2w = host.look_at(g.uniform(-0.5, 0.5, 3) + np.array([0, -4.5, 0.5]), [0, 0, 0], [0, 0, 1])
+        s.set_camera_perspective(host.perspective_raster_to_camera(float(g.uniform(30, 60)), res[0], res[1]), c2w, lens_radius=lens, focal_distance=4.5)
+        cb, table, sb = host.film_box(res[0], res[1])
+        s.set_film(res[0], res[1], cb, (0.5, 0.5), table)
+        s.set_sampler(int(g.integers(0, 1)), spp, sb)
+        s.build_accel(0, int(g.choice([1, 4])))
+        return cb
+    return cap, dict(max_depth=int(rng.integers(1, 7)), light_strategy=int(rng.integers(0, 3)))
+
+
+def run_case(host, seed):
+    cap, kw = build_case(host, seed)
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    try:
+        cap(prod)
+    except pbrt_hip.PbrtHipError as e:
+        if "live values" in str(e): return None, "texture tree deeper than the evaluator's value stack"   # refused, not mis-rendered
+        raise
+    cap(orc)
+    set_libm_mode(1)
+    try:
+        oxyz, owt, ost, _ = orc.render_path_ex(**kw)
+    finally:
+        set_libm_mode(0)
+    gxyz, gwt, gst = prod.render_path(**kw)
+    counters = lambda st: (st.regular_rays, st.shadow_rays, st.paths_total, st.paths_zero_radiance, st.light_distributions_created)
+    nb = int((gxyz.view(np.uint32) != oxyz.view(np.uint32)).any(axis=2).sum())
+    return counters(gst) == counters(ost) and np.array_equal(gwt.view(np.uint32), owt.view(np.uint32)) and nb == 0, (kw, nb, counters(gst), counters(ost))
+
+
+@pytest.mark.parametrize("seed", list(range(1, 21)))
+def test_random_textured_scene_film_bit_exact(host, seed):
+    ok, info = run_case(host, seed)
+    if ok is None: pytest.skip(info)
+    assert ok, (seed, info)
