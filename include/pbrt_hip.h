@@ -141,6 +141,11 @@ int pbrt_hip_object_begin(PbrtHipScene*, uint32_t* out_object_id);
 int pbrt_hip_object_end(PbrtHipScene*);
 int pbrt_hip_add_instance(PbrtHipScene*, uint32_t object_id, const float instance_to_world[16], const float world_to_instance[16]);
 
+/* Alpha masks: the float textures behind a mesh's `alpha` / `shadowalpha` parameters (TriangleMesh::alpha_mask, shadow_alpha_mask: shapes/src/triangle.rs:291-312),
+ * for the mesh added last; 0xFFFFFFFF keeps the constant given to add_mesh.  A candidate hit is rejected where the texture evaluates to exactly 0 at the hit's
+ * uv / point, with no differentials (triangle.rs:587-607; intersect_p also consults shadowalpha, :868-898). */
+int pbrt_hip_set_last_mesh_alpha_textures(PbrtHipScene*, uint32_t alpha_texture, uint32_t shadow_alpha_texture);
+
 /* ---- textures (textures/src/{constant,scale,mix,imagemap}.rs, core/src/mipmap/mod.rs) -------------------------------
  * Float- and spectrum-valued textures share one id space; a float texture is a spectrum texture whose channels are equal.
  * add_mipmap is generate_mipmap + MIPMap::new (core/src/mipmap/cache.rs:74-120, mod.rs:115-189): `rgb` is width*height

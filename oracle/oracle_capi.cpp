@@ -413,6 +413,14 @@ int oracle_set_material_texture(OracleScene* s, uint32_t material, int param, ui
     m.textured = true;
     return 0;
 }
+int oracle_set_last_mesh_alpha_textures(OracleScene* s, uint32_t alpha_tex, uint32_t shadow_alpha_tex) {
+    if (!s || s->sc.meshes.empty()) return -1;
+    if ((alpha_tex != 0xFFFFFFFFu && alpha_tex >= s->sc.textures.size()) || (shadow_alpha_tex != 0xFFFFFFFFu && shadow_alpha_tex >= s->sc.textures.size())) return -1;
+    Mesh& m = s->sc.meshes.back();
+    if (alpha_tex != 0xFFFFFFFFu) m.alpha_tex = (int)alpha_tex;
+    if (shadow_alpha_tex != 0xFFFFFFFFu) m.shadow_alpha_tex = (int)shadow_alpha_tex;
+    return 0;
+}
 int oracle_set_material_bump(OracleScene* s, uint32_t material, uint32_t texture) {
     if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size()) return -1;
     if (s->sc.materials[material].none) return -6;

@@ -76,6 +76,7 @@ struct Mesh {
     int32_t first_light;
     bool reverse_orientation, swaps_handedness;
     Float alpha, shadow_alpha;
+    int alpha_tex = -1, shadow_alpha_tex = -1;   // float textures instead of the constants (triangle.rs:587-607, 868-898)
 };
 
 struct LinearBVHNode {  // accelerators/src/bvh/common.rs:163-179 (32 bytes)
@@ -207,8 +208,17 @@ struct Scene {
             if (tri_is_bogus(prim)) return false;
         }
         if (test_alpha) {
-            if (m.alpha == 0.0f) return false;                    // mask.evaluate(..) == 0.0 (:603, :886)
-            if (shadow && m.shadow_alpha == 0.0f) return false;   // :891
+            if (m.alpha_tex >= 0 || (shadow && m.shadow_alpha_tex >= 0)) {
+                // isect_local: p_hit, uv_hit, no differentials (SurfaceInteraction::new leaves der zero)
+                V2 uv[3]; tri_uvs(prim, uv);
+                TexCtx c; c.uv = V2((b0 * uv[0].x + b1 * uv[1].x) + b2 * uv[2].x, (b0 * uv[0].y + b1 * uv[1].y) + b2 * uv[2].y);
+                c.p = b0 * p0 + b1 * p1 + b2 * p2;
+                if (m.alpha_tex >= 0 ? tex_eval(textures, mipmaps, m.alpha_tex, c).c[0] == 0.0f : m.alpha == 0.0f) return false;
+                if (shadow && (m.shadow_alpha_tex >= 0 ? tex_eval(textures, mipmaps, m.shadow_alpha_tex, c).c[0] == 0.0f : m.shadow_alpha == 0.0f)) return false;
+            } else {
+                if (m.alpha == 0.0f) return false;                    // mask.evaluate(..) == 0.0 (:603, :886)
+                if (shadow && m.shadow_alpha == 0.0f) return false;   // :891
+            }
         }
         h.t = t; h.b0 = b0; h.b1 = b1; h.b2 = b2;
         return true;

@@ -264,6 +264,16 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
         else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst>), g, b, 0, s->stream, s->ds, p);   \
         else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst>), g, b, 0, s->stream, s->ds, p);                 \
     } while (0)
+#define PH_LAUNCH3A(inst)                                                                                                              \
+    do {                                                                                                                              \
+        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, inst, true, true>), g, b, 0, s->stream, s->ds, p);       \
+        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, inst, false, true>), g, b, 0, s->stream, s->ds, p);  \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, inst, false, true>), g, b, 0, s->stream, s->ds, p);                \
+    } while (0)
+    if (s->alpha_textures) {  // meshes with alpha-mask textures: the ALPHA variants (their work counters are not implemented)
+        if (!s->inst_recs.empty()) PH_LAUNCH3A(true); else PH_LAUNCH3A(false);
+        return;
+    }
     if (!s->inst_recs.empty()) {  // scenes with object instances: the TransformedPrimitive-aware kernels
         if (s->count_traversal) PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true);
         else PH_LAUNCH3(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true);
@@ -276,6 +286,7 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
 #undef X
     }
 #undef PH_LAUNCH3
+#undef PH_LAUNCH3A
 }
 
 int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_out, uint32_t n, float* kernel_ms) {
@@ -975,6 +986,26 @@ int pbrt_hip_add_mesh(PbrtHipScene* s, const float* P, uint32_t n_verts, const u
     s->meshes.push_back(m);
     if (s->open_object >= 0) s->objects[s->open_object].tri1 = m.tri_base + n_tris;
     else for (uint32_t t = 0; t < n_tris; t++) s->top_items.push_back(m.tri_base + t);
+    s->built = false; s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+
+// `alpha` / `shadowalpha` float textures of the mesh added last (TriangleMesh::alpha_mask / shadow_alpha_mask, shapes/src/triangle.rs:291-312); 0xFFFFFFFF keeps the
+// constant given to add_mesh.  Candidate hits are then tested in the traversal kernels' ALPHA variants.
+int pbrt_hip_set_last_mesh_alpha_textures(PbrtHipScene* s, uint32_t alpha_tex, uint32_t shadow_alpha_tex) {
+    if (!s || s->meshes.empty()) return set_err(s, PBRT_HIP_ERR_STATE, "set_last_mesh_alpha_textures: no mesh has been added");
+    if ((alpha_tex != 0xFFFFFFFFu && alpha_tex >= s->textures.size()) || (shadow_alpha_tex != 0xFFFFFFFFu && shadow_alpha_tex >= s->textures.size()))
+        return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_last_mesh_alpha_textures: unknown texture");
+    MeshRec& m = s->meshes.back();
+    if (alpha_tex != 0xFFFFFFFFu) m.alpha_tex1 = alpha_tex + 1u;
+    if (shadow_alpha_tex != 0xFFFFFFFFu) m.shadow_alpha_tex1 = shadow_alpha_tex + 1u;
+    for (uint32_t t = m.tri_base; t < m.tri_base + m.n_tris; t++) {
+        uint32_t& tf = s->tri_flags[t];
+        if (m.alpha_tex1) tf &= ~PH_TRI_ALPHA0;              // the texture replaces the constant
+        if (m.shadow_alpha_tex1) tf &= ~PH_TRI_SALPHA0;
+        if (m.alpha_tex1 || m.shadow_alpha_tex1) tf |= PH_TRI_ALPHATEX;
+    }
+    if (m.alpha_tex1 || m.shadow_alpha_tex1) s->alpha_textures = true;
     s->built = false; s->uploaded = false;
     return PBRT_HIP_OK;
 }

@@ -33,6 +33,7 @@ struct PbrtHipScene {
     // which lobe and which of its two colours each texturable parameter of a material feeds (set_material_texture); -1 = that lobe was not made
     struct MaterialParams { int lobe[4] = {-1, -1, -1, -1}; int field[4] = {0, 0, 0, 0}; bool has_pre = false; float pre[3] = {1, 1, 1}; };  // [Kd, Ks, Kr, Kt]; field 0 = r, 1 = t; pre: uber's opacity
     std::vector<MaterialParams> material_params;
+    bool alpha_textures = false;      // some mesh has an alpha / shadowalpha texture: traversal uses the ALPHA kernel variants
     bool bump_materials = false;      // some material has a bump map
     bool textured_materials = false;  // some material evaluates a texture per hit
     bool has_none_material = false;  // some material is "none": paths may need more wavefront iterations than max_depth + 1

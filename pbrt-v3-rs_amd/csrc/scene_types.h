@@ -26,6 +26,7 @@ struct alignas(64) Node64 {
 #define PH_TRI_ALPHA0 4u   // mesh alpha texture == 0.0 (triangle.rs:603)
 #define PH_TRI_SALPHA0 8u  // mesh shadowalpha texture == 0.0 (triangle.rs:891)
 #define PH_TRI_CLASS_SHIFT 8  // bits 8..10: material class of the triangle (shade-side sorting key; 7 = Material "none"), set at build time
+#define PH_TRI_ALPHATEX 32u  // the mesh's alpha or shadowalpha is a texture: the traversal kernel (ALPHA variants) evaluates it at the candidate hit
 #define PH_TRI_INSTANCE 16u  // not a triangle: a TransformedPrimitive (object instance); `prim` = index into DeviceScene::instances
 struct alignas(16) TriRec {
     float p0[3]; uint32_t prim;   // prim = index in add_mesh order
@@ -49,7 +50,7 @@ struct MeshRec {
     uint32_t flags;        // bit0 has N, bit1 has S, bit2 has UV, bit3 reverse_orientation, bit4 swaps_handedness
     uint32_t material;
     int32_t first_light;   // -1 none
-    uint32_t pad[2];
+    uint32_t alpha_tex1, shadow_alpha_tex1;  // 0, or 1 + the float texture that replaces the constant alpha / shadowalpha (triangle.rs:587-607, 868-898)
 };
 #define PH_MESH_N 1u
 #define PH_MESH_S 2u

@@ -547,4 +547,27 @@ PH_DEV void hit_bump(const DeviceScene* dsc, const BumpIn* in, BumpOut* out) {
     out->dpdu_s = ndpdu;
 }
 
+// The alpha-mask test of Triangle::intersect / intersect_p (triangle.rs:587-607, 868-898), declared in traverse.h: isect_local carries the hit point
+// (in the triangle's own space), the interpolated uv and no differentials.
+static __device__ __noinline__ bool alpha_accept(const DeviceScene* dsc, uint32_t tri_index, float b0, float b1, float b2, uint32_t any_hit) {
+    const DeviceScene& sc = *dsc;
+    const float4* tp = reinterpret_cast<const float4*>(sc.tris + tri_index);
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    const uint32_t prim = __float_as_uint(a.w);
+    const MeshRec m = sc.meshes[__float_as_uint(c.w)];
+    f2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);
+    if (m.flags & PH_MESH_UV) {
+        const uint32_t i0 = sc.idx[3 * prim], i1 = sc.idx[3 * prim + 1], i2 = sc.idx[3 * prim + 2];
+        uv0 = mk2(sc.UV[2 * (size_t)i0], sc.UV[2 * (size_t)i0 + 1]); uv1 = mk2(sc.UV[2 * (size_t)i1], sc.UV[2 * (size_t)i1 + 1]); uv2 = mk2(sc.UV[2 * (size_t)i2], sc.UV[2 * (size_t)i2 + 1]);
+    }
+    TexCtx ctx;
+    ctx.uv = mk2((b0 * uv0.x + b1 * uv1.x) + b2 * uv2.x, (b0 * uv0.y + b1 * uv1.y) + b2 * uv2.y);
+    ctx.dudx = ctx.dvdx = ctx.dudy = ctx.dvdy = 0.0f;
+    ctx.p = b0 * mk3(a.x, a.y, a.z) + b1 * mk3(b.x, b.y, b.z) + b2 * mk3(c.x, c.y, c.z);
+    ctx.dpdx = mk3(0.0f, 0.0f, 0.0f); ctx.dpdy = ctx.dpdx;
+    if (m.alpha_tex1 && tex_eval(dsc, m.alpha_tex1 - 1u, ctx).r == 0.0f) return false;
+    if (any_hit && m.shadow_alpha_tex1 && tex_eval(dsc, m.shadow_alpha_tex1 - 1u, ctx).r == 0.0f) return false;
+    return true;
+}
+
 }  // namespace ph

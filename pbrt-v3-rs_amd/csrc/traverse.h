@@ -188,7 +188,12 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
 // MIXED = true serves both ray kinds of one wavefront round from ONE launch: indices [0, n_cl) are closest-hit rays, [n_cl, n_cl + n_sh)
 // any-hit rays (each lane knows its kind).  Every launch ends with a latency-bound tail (the last rays' dependent loads, ~0.4 ms
 // whatever the launch size), so one launch per round instead of two removes one tail per bounce.
-template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1, bool INST = false, bool MIXED = false>
+// ALPHA = true adds alpha-mask textures (triangle.rs:587-607 / 868-898): a candidate hit on a mesh whose alpha or shadowalpha is a texture is
+// accepted only if the texture, evaluated at the hit's uv / p with no differentials, is not 0.  The evaluation is an out-of-line call (alpha_accept,
+// defined next to the texture evaluator); its own instantiations, so every other scene keeps the leaner kernels.
+static __device__ __noinline__ bool alpha_accept(const DeviceScene* dsc, uint32_t tri_index, float b0, float b1, float b2, uint32_t any_hit);
+template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1, bool INST = false, bool MIXED = false,
+          bool ALPHA = false>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
     const uint32_t tid = threadIdx.x;
@@ -350,7 +355,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
                         if (tri_test(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), t, b0, b1, b2)) {
                             // post-t rejections: degenerate triangle (triangle.rs:567-570 / 862-866), alpha == 0 (:603 / :886-893)
                             const uint32_t reject = ah ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
-                            if (!(flags & reject)) {
+                            bool accept = !(flags & reject);
+                            if (ALPHA && accept && (flags & PH_TRI_ALPHATEX)) accept = alpha_accept(sc.self, ti, b0, b1, b2, ah ? 1u : 0u);
+                            if (accept) {
                                 if (ah) occluded = true;
                                 else {
                                     r.t_max = t; hit_prim = __float_as_uint(a.w); hit_tri = ti; hb0 = b0; hb1 = b1; hb2 = b2;

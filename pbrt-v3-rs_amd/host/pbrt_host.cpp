@@ -641,10 +641,13 @@ void Api::pbrt_shape(const std::string& name, const ParamSet& p, const std::stri
         error = "Shape \"" + name + "\" is outside the hot-path scope (supported: trianglemesh, plymesh)";
         return;
     }
-    // alpha / shadowalpha: constant float textures only (triangle.rs:278-312)
+    // alpha / shadowalpha (triangle.rs:278-312): a float texture by name (constant ones fold to the constant, the others are evaluated per candidate hit) or a float
+    uint32_t alpha_tex[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
     auto alpha_of = [&](const char* pname) {
         std::string tn = p.find_one_texture(pname);
         if (!tn.empty()) {
+            auto dt = gs_.device_textures.find(tn);
+            if (dt != gs_.device_textures.end() && dt->second.is_float) { alpha_tex[std::strcmp(pname, "alpha") ? 1 : 0] = dt->second.id; return 1.0f; }
             auto it = gs_.float_textures.find(tn);
             if (it != gs_.float_textures.end()) return it->second;
             auto un = gs_.unsupported_textures.find(tn);
@@ -694,6 +697,7 @@ void Api::pbrt_shape(const std::string& name, const ParamSet& p, const std::stri
     }
     if (!check(ABI(pbrt_hip_add_mesh(scene_, Pw.data(), (uint32_t)nv, idx.data(), n_tris, N.empty() ? nullptr : N.data(), S.empty() ? nullptr : S.data(),
                                  UV.empty() ? nullptr : UV.data(), mat, first_light, flags, alpha, shadow_alpha)), "add_mesh")) return;
+    if ((alpha_tex[0] != 0xFFFFFFFFu || alpha_tex[1] != 0xFFFFFFFFu) && !check(ABI(pbrt_hip_set_last_mesh_alpha_textures(scene_, alpha_tex[0], alpha_tex[1])), "set_last_mesh_alpha_textures")) return;
     if (current_object_.empty()) n_tris_ += n_tris; else object_tris_[current_object_] += n_tris;
 }
 

@@ -132,6 +132,7 @@ class Binding:
             "add_material_matte_tex": (C.c_int, [vp, C.c_uint32, C.c_float, u32p]),
             "set_material_texture": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32]),
             "set_material_bump": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
+            "set_last_mesh_alpha_textures": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
             "texture_eval_batch": (C.c_int, [vp, C.c_uint32, C.c_uint64, fp, fp]),
             "mipmap_levels": (C.c_int, [vp, C.c_uint32, ip, ip]),
             "mipmap_level_texels": (C.c_int, [vp, C.c_uint32, C.c_int, fp]),
@@ -547,6 +548,11 @@ class Scene:
     def set_material_texture(self, material, param, texture):
         """param: "Kd" | "Ks" | "Kr" | "Kt" — that colour of `material` becomes `texture`, evaluated per hit."""
         self._chk(self.b.fn("set_material_texture")(self.h, material, self.PARAM[param], texture))
+
+    def set_last_mesh_alpha_textures(self, alpha=None, shadow_alpha=None):
+        """Float textures for the `alpha` / `shadowalpha` masks of the mesh added last (None keeps the constant)."""
+        none = 0xFFFFFFFF
+        self._chk(self.b.fn("set_last_mesh_alpha_textures")(self.h, none if alpha is None else alpha, none if shadow_alpha is None else shadow_alpha))
 
     def set_material_bump(self, material, texture):
         """Material::bump with the float texture `texture` as displacement map."""

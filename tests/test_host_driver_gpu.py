@@ -342,11 +342,12 @@ Texture "wood" "color" "imagemap" "string filename" "a.png"
 Texture "tint" "color" "scale" "texture tex1" "wood" "rgb tex2" [0.9 0.6 0.4]
 Texture "amt" "float" "imagemap" "string filename" "m.tga" "bool trilinear" "true" "string wrap" "clamp" "bool gamma" "false"
 Texture "blend" "color" "mix" "texture tex1" "tint" "rgb tex2" [0.1 0.2 0.8] "texture amount" "amt"
+Texture "cut" "float" "checkerboard" "float uscale" 4 "float vscale" 4 "string aamode" "none"
 Texture "hdr" "color" "imagemap" "string filename" "h.pfm" "float scale" 0.5 "float uscale" 2 "float vscale" 2 "string wrap" "black"
 Material "matte" "texture Kd" "blend"
 Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [{ds.fl(Q)}] "float uv" [{ds.fl(UVQ)}]
 Material "matte" "texture Kd" "hdr" "float sigma" 20
-Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [{ds.fl(W)}] "float st" [{ds.fl(UVW)}]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [{ds.fl(W)}] "float st" [{ds.fl(UVW)}] "texture alpha" "amt" "texture shadowalpha" "cut"
 Texture "bumps" "float" "scale" "texture tex1" "amt" "float tex2" 0.05
 Material "plastic" "texture Kd" "wood" "texture Ks" "tint" "float roughness" 0.05 "texture bumpmap" "bumps"
 Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-3 1 0.01  -1 1 0.01  -2 2.5 1.5] "float uv" [0 0 1 0 0.5 1]
@@ -380,12 +381,14 @@ WorldEnd
         grey = np.repeat(m8[..., None], 3, axis=2).astype(np.float32) / np.float32(255.0)
         amt = s.add_texture_imagemap(s.add_mipmap(grey, as_float=True, trilinear=True, wrap="clamp", gamma=False))
         blend = s.add_texture_mix(tint, s.add_texture_constant((0.1, 0.2, 0.8)), amt)
+        cut = s.add_texture_checkerboard(s.add_texture_constant(1.0), s.add_texture_constant(0.0), su=4.0, sv=4.0, aa="none")
         hd = s.add_texture_imagemap(s.add_mipmap(hdr, scale=0.5, wrap="black"), su=2.0, sv=2.0)
         ident2 = (np.eye(4, dtype=np.float32).reshape(16),) * 2
         lt = host.compose(ident2, host.rotate(40.0, [0, 0, 1]))
         s.add_light_infinite_map(np.float32([1.0, 0.9, 0.8]) * np.float32([0.5, 0.5, 0.5]), sky, lt[0], lt[1])
         s.add_mesh(Q, [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(blend, 0.0), UV=UVQ)
         s.add_mesh(W, [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(hd, 20.0), UV=UVW)
+        s.set_last_mesh_alpha_textures(amt, cut)
         tri_uv = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
         pl = s.add_material_plastic((1, 1, 1), (1, 1, 1), 0.05, True); s.set_material_texture(pl, "Kd", wood); s.set_material_texture(pl, "Ks", tint)
         s.set_material_bump(pl, s.add_texture_scale(amt, s.add_texture_constant(0.05)))

@@ -431,3 +431,77 @@ def test_environment_map_light_film_bit_exact(strategy):
     assert gst.regular_rays == ost.regular_rays and gst.shadow_rays == ost.shadow_rays
     assert gst.light_distributions_created == ost.light_distributions_created
     assert float(gxyz.mean()) > 0.0
+
+
+def test_alpha_mask_textures_hits_occlusion_and_film_bit_exact():
+    """Alpha-mask textures are part of the traversal: closest hits, any-hit occlusion (alpha and shadowalpha) and a film with cut-out leaves, also
+    through an instance, against the oracle."""
+    import scenes as SC
+    host = pbrt_hip.Host()
+    rng = np.random.default_rng(12)
+    mask = (rng.uniform(0, 1, (16, 16)) > 0.45).astype(np.float32)            # exactly 0 / 1 texels
+    img = np.repeat(mask[..., None], 3, axis=2)
+
+    def scene(sc, instanced):
+        grey = sc.add_material_matte((0.6, 0.6, 0.6), 0.0); green = sc.add_material_matte((0.2, 0.7, 0.2), 0.0)
+        a = sc.add_texture_imagemap(sc.add_mipmap(img, as_float=True, trilinear=True, wrap="clamp"))
+        sa = sc.add_texture_checkerboard(sc.add_texture_constant(1.0), sc.add_texture_constant(0.0), su=5.0, sv=5.0, aa="none")
+        P, idx = SC.grid_mesh(6, z=0.0, size=2.0)
+        UV = ((P[:, :2] + 2.0) / 4.0).astype(np.float32)
+        leaves = [(0.4, (a, None)), (0.8, (None, sa)), (1.2, (a, sa))]
+        if instanced:
+            ob = sc.object_begin()
+            sc.add_mesh(P, idx, green, UV=UV); sc.set_last_mesh_alpha_textures(a, sa)
+            sc.object_end()
+            for z in (0.4, 0.9):
+                t = host.compose(host.translate([0.1, 0.0, z]), host.rotate(20.0 * z, [0, 0, 1]))
+                sc.add_instance(ob, t[0], t[1])
+        else:
+            for z, (al, sh) in leaves:
+                sc.add_mesh(P + np.float32([0, 0, z]), idx, green, UV=UV); sc.set_last_mesh_alpha_textures(al, sh)
+        sc.add_mesh(P * np.float32(2.0) + np.float32([0, 0, -0.2]), idx, grey)                # an opaque floor below
+        sc.add_light_infinite((1.0, 1.0, 1.0))
+        sc.add_light_point((8.0, 8.0, 8.0), (0.5, -0.5, 3.0))
+        w2c, c2w = host.look_at((0.0, -4.0, 4.0), (0, 0, 0.3), (0, 0, 1))
+        sc.set_camera_perspective(host.perspective_raster_to_camera(45.0, 48, 48), c2w)
+        cb, table, sb = host.film_box(48, 48)
+        sc.set_film(48, 48, cb, (0.5, 0.5), table); sc.set_sampler(0, 4, sb); sc.build_accel(0, 4)
+    for instanced in (False, True):
+        prod = pbrt_hip.Scene(); orc = OracleScene()
+        scene(prod, instanced); scene(orc, instanced)
+        rays = SC.random_rays(20000, 5, bound=2.2)
+        gh = prod.intersect_batch(rays); oh = orc.intersect_batch(rays)
+        for f in ("t", "prim", "b0", "b1", "b2"):
+            assert _bits_equal(np.ascontiguousarray(gh[f]), np.ascontiguousarray(oh[f])), f
+        assert np.array_equal(prod.occluded_batch(rays), orc.occluded_batch(rays))
+        holes = int((gh["prim"] == 0xFFFFFFFF).sum())
+        set_libm_mode(1)
+        try:
+            oxyz, owt, ost, _ = orc.render_path_ex(max_depth=3)
+        finally:
+            set_libm_mode(0)
+        gxyz, gwt, gst = prod.render_path(max_depth=3)
+        assert _bits_equal(gxyz, oxyz) and _bits_equal(gwt, owt)
+        assert gst.regular_rays == ost.regular_rays and gst.shadow_rays == ost.shadow_rays
+    # the mask really cuts holes: with an all-ones mask fewer rays get through the leaves
+    prod2 = pbrt_hip.Scene()
+    img_full = np.ones_like(img)
+    def scene_full(sc):
+        green = sc.add_material_matte((0.2, 0.7, 0.2), 0.0)
+        a = sc.add_texture_imagemap(sc.add_mipmap(img_full, as_float=True, trilinear=True, wrap="clamp"))
+        P, idx = SC.grid_mesh(6, z=0.4, size=2.0)
+        sc.add_mesh(P, idx, green, UV=((P[:, :2] + 2.0) / 4.0).astype(np.float32)); sc.set_last_mesh_alpha_textures(a, None)
+        sc.build_accel(0, 4)
+    scene_full(prod2)
+    down = np.zeros(4000, pbrt_hip.RAY_DTYPE); down["o"] = np.c_[rng.uniform(-1.9, 1.9, (4000, 2)), np.full(4000, 3.0)].astype(np.float32); down["d"] = (0, 0, -1); down["t_max"] = np.inf
+    full = int((prod2.intersect_batch(down)["prim"] != 0xFFFFFFFF).sum())
+    prod3 = pbrt_hip.Scene()
+    def scene_mask(sc):
+        green = sc.add_material_matte((0.2, 0.7, 0.2), 0.0)
+        a = sc.add_texture_imagemap(sc.add_mipmap(img, as_float=True, trilinear=True, wrap="clamp"))
+        P, idx = SC.grid_mesh(6, z=0.4, size=2.0)
+        sc.add_mesh(P, idx, green, UV=((P[:, :2] + 2.0) / 4.0).astype(np.float32)); sc.set_last_mesh_alpha_textures(a, None)
+        sc.build_accel(0, 4)
+    scene_mask(prod3)
+    cut = int((prod3.intersect_batch(down)["prim"] != 0xFFFFFFFF).sum())
+    assert full == 4000 and 0.3 * full < cut < 0.97 * full      # bilinear lookups: a hole needs all four neighbouring texels at exactly 0
