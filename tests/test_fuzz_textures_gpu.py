@@ -1,4 +1,4 @@
-"""-m gpu: randomized differential test of the texture system on top of tests/test_fuzz_gpu.py's scene generator: random texture trees
+"""-m gpu: randomized differential test of the texture system (incl. alpha-mask textures inside the traversal) on top of tests/test_fuzz_gpu.py's scene generator: random texture trees
 (image maps of random size / filter / wrap / gamma, every procedural class, scale / mix nesting, all mappings) on the colour parameters that
 take them, random bump maps, an optional radiance-map sky.  Film and counters must equal the oracle's bit for bit."""
 import numpy as np
@@ -66,6 +66,20 @@ def random_texture(s, host, rng, as_float, depth=0):
     return s.add_texture_bilerp(*([float(v) for v in rng.uniform(0, 1, 4)] if as_float else [tuple(rng.uniform(0, 1, 3)) for _ in range(4)]), **uvp)
 
 
+def random_mask(s, host, rng):
+    """A float texture that is exactly 0 somewhere (alpha masks reject only where the value is exactly 0)."""
+    k = int(rng.integers(0, 4))
+    uvp = dict(su=float(rng.uniform(1, 6)), sv=float(rng.uniform(1, 6)))
+    if k == 0:
+        return s.add_texture_checkerboard(s.add_texture_constant(1.0), s.add_texture_constant(0.0), aa="none", **uvp)
+    if k == 1:
+        return s.add_texture_dots(s.add_texture_constant(0.0), s.add_texture_constant(1.0), **uvp)
+    if k == 2:
+        m = (rng.uniform(0, 1, (int(rng.integers(2, 12)), int(rng.integers(2, 12)))) > 0.5).astype(np.float32)
+        return s.add_texture_imagemap(s.add_mipmap(np.repeat(m[..., None], 3, axis=2), as_float=True, trilinear=True, wrap=str(rng.choice(["repeat", "black", "clamp"]))), **uvp)
+    return s.add_texture_checkerboard3d(s.add_texture_constant(0.0), s.add_texture_constant(1.0), F.random_transform(host, rng)[0])
+
+
 def textured_material(s, host, rng):
     one = (1, 1, 1)
     c = lambda lo=0.0, hi=1.0: tuple(rng.uniform(lo, hi, 3))
@@ -97,7 +111,8 @@ def textured_material(s, host, rng):
     mat_none = False
     try:
         if rng.integers(0, 2): s.set_material_bump(m, s.add_texture_scale(random_texture(s, host, rng, True), s.add_texture_constant(float(rng.uniform(0.005, 0.2)))))
-    except pbrt_hip.PbrtHipError:
+    except pbrt_hip.PbrtHipError as e:
+        if "live values" in str(e): raise    # a tree the product's evaluator refuses: the whole case is skipped (the oracle would accept it and the two scenes would diverge)
         mat_none = True                      # "none" has no BSDF to bump: refused identically by both libraries
     return m
 
@@ -127,12 +142,15 @@ def build_case(host, seed):
             S = g.normal(size=P.shape).astype(np.float32) if g.integers(0, 3) == 0 else None
             UV = g.uniform(-1, 2, (len(P), 2)).astype(np.float32) if g.integers(0, 3) else None
             s.add_mesh(P, idx, mats[k % 4], N=N, S=S, UV=UV, reverse_orientation=bool(g.integers(0, 2)), swaps_handedness=bool(g.integers(0, 2)))
+            if g.integers(0, 3) == 0:
+                s.set_last_mesh_alpha_textures(random_mask(s, host, g) if g.integers(0, 2) else None, random_mask(s, host, g) if g.integers(0, 2) else None)
         Pg, ig = scenes.grid_mesh(3, z=-1.3, size=2.5)
         s.add_mesh(Pg, ig, mats[3], UV=(Pg[:, :2] * np.float32(0.7)).astype(np.float32))
         if g.integers(0, 2):
             ob = s.object_begin()
             P, idx = host.gen_random_tris(int(g.integers(2, 60)), int(g.integers(1, 1000)))
             s.add_mesh(P * np.float32(0.5), idx, mats[1], N=(g.normal(size=P.shape).astype(np.float32) if g.integers(0, 2) else None), UV=g.uniform(0, 1, (len(P), 2)).astype(np.float32))
+            if g.integers(0, 2): s.set_last_mesh_alpha_textures(random_mask(s, host, g), None)
             s.object_end()
             for _ in range(int(g.integers(1, 4))):
                 t = F.random_transform(host, g)
