@@ -189,6 +189,10 @@ int pbrt_hip_add_texture_checkerboard3d(PbrtHipScene*, uint32_t tex1, uint32_t t
  * materials with per-hit textures cannot be children of a mix yet. */
 enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2, PBRT_HIP_PARAM_KT = 3 };
 int pbrt_hip_set_material_texture(PbrtHipScene*, uint32_t material, int param, uint32_t texture);
+/* Scalar parameters as float textures, evaluated at every hit: fparam 0 = MatteMaterial's sigma (matte.rs:64-70: Lambert where it evaluates to 0, Oren-Nayar elsewhere),
+ * 1 / 2 = u / v roughness of the Trowbridge-Reitz distribution of plastic, uber, substrate and metal (remapped per hit if the material was created with remap_roughness;
+ * plastic's single `roughness`: set both).  Glass is not wired (its lobe structure switches on roughness == 0). */
+int pbrt_hip_set_material_float_texture(PbrtHipScene*, uint32_t material, int fparam, uint32_t texture);
 /* Bump mapping: Material::bump (core/src/material.rs:62-101) with the float texture `texture` as displacement, run before the BSDF of a hit is made
  * (every material's `bumpmap` parameter).  Not for Material "none"; not for children of a mix yet. */
 int pbrt_hip_set_material_bump(PbrtHipScene*, uint32_t material, uint32_t texture);

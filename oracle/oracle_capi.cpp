@@ -89,6 +89,7 @@ int oracle_add_material_plastic(OracleScene* s, const float kd[3], const float k
         Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.5f; l.eta_b = 1.0f; l.r = sp;
         Float rough = remap ? roughness_to_alpha(roughness) : roughness;
         set_tr(l, rough, rough);
+        m.rough_lobe = (int)m.lobes.size(); m.rough_remap = remap != 0;
         m.lobes.push_back(l);
     }
     return push_material(s, m, out_id);
@@ -117,6 +118,7 @@ int oracle_add_material_metal(OracleScene* s, const float eta[3], const float k[
     Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_COND; l.r = Spec(1.0f);
     l.c_eta_i = Spec(1.0f); l.c_eta_t = spec3(eta); l.c_k = spec3(k);
     set_tr(l, urough, vrough);
+    m.rough_lobe = 0; m.rough_remap = remap != 0;
     m.lobes.push_back(l);
     return push_material(s, m, out_id);
 }
@@ -140,6 +142,7 @@ int oracle_add_material_uber(OracleScene* s, const float kd[3], const float ks[3
         Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.r = sp;
         if (remap) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
         set_tr(l, urough, vrough);
+        m.rough_lobe = (int)m.lobes.size(); m.rough_remap = remap != 0;
         m.lobes.push_back(l);
     }
     Spec r = op * spec_clamp0(spec3(kr));
@@ -421,6 +424,20 @@ int oracle_set_last_mesh_alpha_textures(OracleScene* s, uint32_t alpha_tex, uint
     if (shadow_alpha_tex != 0xFFFFFFFFu) m.shadow_alpha_tex = (int)shadow_alpha_tex;
     return 0;
 }
+int oracle_set_material_float_texture(OracleScene* s, uint32_t material, int fparam, uint32_t texture) {  // 0 sigma, 1 uroughness, 2 vroughness
+    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || fparam < 0 || fparam > 2) return -1;
+    Material& m = s->sc.materials[material];
+    if (fparam == 0) {
+        if (m.general || m.none || m.lobes.size() != 1 || !(m.lobes[0].kind == LK_LAMBERT || m.lobes[0].kind == LK_OREN)) return -6;
+        m.lobes[0].sigma_tex = (int)texture;
+    } else {
+        if (m.rough_lobe < 0) return -6;
+        Lobe& l = m.lobes[(size_t)m.rough_lobe];
+        (fparam == 1 ? l.ax_tex : l.ay_tex) = (int)texture; l.remap = m.rough_remap;
+    }
+    m.textured = true;
+    return 0;
+}
 int oracle_set_material_bump(OracleScene* s, uint32_t material, uint32_t texture) {
     if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size()) return -1;
     if (s->sc.materials[material].none) return -6;
@@ -550,6 +567,7 @@ int oracle_add_material_substrate(OracleScene* s, const float kd[3], const float
     if (!d.is_black() || !sp.is_black()) {
         if (remap) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
         Lobe l; l.kind = LK_FRESNEL_BLEND; l.type = BX_REFL | BX_GLOSSY; l.r = d; l.t = sp; set_tr(l, urough, vrough);
+        m.rough_lobe = (int)m.lobes.size(); m.rough_remap = remap != 0;
         m.lobes.push_back(l);
         m.param_lobe[0] = 0; m.param_field[0] = 0; m.param_lobe[1] = 0; m.param_field[1] = 1;
     }

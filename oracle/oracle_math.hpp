@@ -41,6 +41,7 @@ inline int g_libm_mode = 0;
 inline Float o_sin(Float x) { return g_libm_mode ? (Float)std::sin((double)x) : std::sin(x); }
 inline Float o_cos(Float x) { return g_libm_mode ? (Float)std::cos((double)x) : std::cos(x); }
 inline Float o_acos(Float x) { return g_libm_mode ? (Float)std::acos((double)x) : std::acos(x); }
+inline Float o_log(Float x) { return g_libm_mode ? (Float)std::log((double)x) : std::log(x); }
 inline Float o_atan2(Float y, Float x) { return g_libm_mode ? (Float)std::atan2((double)y, (double)x) : std::atan2(y, x); }
 
 // core/src/pbrt/common.rs:66-107 — generic abs/min/max written with < and > (NaN and -0.0 behaviour matters)

@@ -984,6 +984,20 @@ struct Renderer {
             int k = 0;
             for (const Lobe& tl : m.lobes) {
                 Lobe l = tl;
+                if (l.sigma_tex >= 0) {  // matte.rs:64-70 + OrenNayar::new (oren_nayar.rs:28-39)
+                    Float sig = pclamp(tex_eval(sc->textures, sc->mipmaps, l.sigma_tex, c).c[0], 0.0f, 90.0f);
+                    if (sig == 0.0f) { l.kind = LK_LAMBERT; l.a = 0.0f; l.b = 0.0f; }
+                    else { l.kind = LK_OREN; Float sg = to_radians(sig), s2 = sg * sg; l.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f))); l.b = 0.45f * s2 / (s2 + 0.09f); }
+                }
+                if (l.ax_tex >= 0 || l.ay_tex >= 0) {  // roughness textures, remapped per hit (trowbridge_reitz.rs:21-40)
+                    auto alpha_of = [&](int tex, Float cur) {
+                        if (tex < 0) return cur;
+                        Float r = tex_eval(sc->textures, sc->mipmaps, tex, c).c[0];
+                        if (l.remap) { r = pmax(r, 1e-3f); Float x = o_log(r); r = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x; }
+                        return pmax(0.001f, r);
+                    };
+                    l.ax = alpha_of(l.ax_tex, l.ax); l.ay = alpha_of(l.ay_tex, l.ay);
+                }
                 if (l.r_tex >= 0) { l.r = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.r_tex, c)); if (l.has_pre) l.r = l.pre * l.r; }
                 if (l.t_tex >= 0) { l.t = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.t_tex, c)); if (l.has_pre) l.t = l.pre * l.t; }
                 const bool keep = (l.kind == LK_FRESNEL_BLEND || l.kind == LK_FRESNEL_SPEC) ? !(l.r.is_black() && l.t.is_black())

@@ -682,6 +682,27 @@ int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param,
     s->uploaded = false;
     return PBRT_HIP_OK;
 }
+// Replaces a scalar parameter by a float texture evaluated at every hit: MatteMaterial's sigma (matte.rs:64-70) or the Trowbridge-Reitz roughness of plastic / uber /
+// substrate / metal (remapped per hit when the material was created with remap_roughness).  fparam: 0 sigma, 1 uroughness, 2 vroughness (plastic's single `roughness`: set both).
+int pbrt_hip_set_material_float_texture(PbrtHipScene* s, uint32_t material, int fparam, uint32_t texture) {
+    if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_float_texture: unknown material or texture");
+    if (fparam < 0 || fparam > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_float_texture: fparam must be 0 sigma, 1 uroughness or 2 vroughness");
+    MaterialRec& m = s->materials[material];
+    const PbrtHipScene::MaterialParams& mp = s->material_params[material];
+    if (fparam == 0) {
+        if (m.none || m.n_lobes != 1u || !(s->lobes[m.lobe_base].kind == PH_LK_LAMBERT || s->lobes[m.lobe_base].kind == PH_LK_OREN))
+            return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_float_texture: sigma belongs to MatteMaterial (created with a non-black Kd)");
+        s->lobes[m.lobe_base].sigma_tex1 = texture + 1u; m.sigma_tex1 = texture + 1u;
+    } else {
+        if (mp.rough_lobe < 0) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_float_texture: this material has no microfacet lobe whose roughness could be textured (plastic, uber, substrate and metal have; glass switches lobes on roughness == 0 and is not wired)");
+        LobeRec& l = s->lobes[m.lobe_base + (uint32_t)mp.rough_lobe];
+        (fparam == 1 ? l.ax_tex1 : l.ay_tex1) = texture + 1u; l.remap = mp.rough_remap ? 1u : 0u;
+    }
+    m.textured = 1u;
+    s->textured_materials = true;
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
 // Material::bump's displacement texture (core/src/material.rs:62-101; the `bumpmap` parameter every material takes)
 int pbrt_hip_set_material_bump(PbrtHipScene* s, uint32_t material, uint32_t texture) {
     if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_bump: unknown material or texture");
@@ -775,7 +796,7 @@ int pbrt_hip_add_material_plastic(PbrtHipScene* s, const float kd[3], const floa
     }
     const int kd_lobe = (!lobes.empty() && lobes[0].kind == PH_LK_LAMBERT) ? 0 : -1, ks_lobe = (!lobes.empty() && lobes.back().kind == PH_LK_MICRO_R) ? (int)lobes.size() - 1 : -1;
     const int rc = push_material(s, m, lobes, true, out_id);
-    if (rc == PBRT_HIP_OK) { s->material_params.back().lobe[0] = kd_lobe; s->material_params.back().lobe[1] = ks_lobe; }
+    if (rc == PBRT_HIP_OK) { PbrtHipScene::MaterialParams& mp = s->material_params.back(); mp.lobe[0] = kd_lobe; mp.lobe[1] = ks_lobe; mp.rough_lobe = ks_lobe; mp.rough_remap = remap_roughness != 0; }
     return rc;
 }
 int pbrt_hip_add_material_glass(PbrtHipScene* s, const float kr[3], const float kt[3], float urough, float vrough, float eta, int remap_roughness,
@@ -813,7 +834,9 @@ int pbrt_hip_add_material_metal(PbrtHipScene* s, const float eta[3], const float
     LobeRec l = lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY); l.fresnel = PH_FR_COND;
     l.r[0] = l.r[1] = l.r[2] = 1.0f; std::memcpy(l.c_eta_t, eta, 12); std::memcpy(l.c_k, k, 12);
     set_tr(l, urough, vrough);
-    return push_material(s, m, {l}, true, out_id);
+    const int rc = push_material(s, m, {l}, true, out_id);
+    if (rc == PBRT_HIP_OK) { s->material_params.back().rough_lobe = 0; s->material_params.back().rough_remap = remap_roughness != 0; }
+    return rc;
 }
 int pbrt_hip_add_material_uber(PbrtHipScene* s, const float kd[3], const float ks[3], const float kr[3], const float kt[3], const float opacity[3], float urough,
                                float vrough, float eta, int remap_roughness, uint32_t* out_id) {  // uber.rs:116-186
@@ -849,7 +872,7 @@ int pbrt_hip_add_material_uber(PbrtHipScene* s, const float kd[3], const float k
         mp.has_pre = true; std::memcpy(mp.pre, op, 12);
         for (size_t i = 0; i < lobes.size(); i++) {
             if (lobes[i].kind == PH_LK_LAMBERT) mp.lobe[0] = (int)i;
-            else if (lobes[i].kind == PH_LK_MICRO_R) mp.lobe[1] = (int)i;
+            else if (lobes[i].kind == PH_LK_MICRO_R) { mp.lobe[1] = (int)i; mp.rough_lobe = (int)i; mp.rough_remap = remap_roughness != 0; }
             else if (lobes[i].kind == PH_LK_SPEC_R) mp.lobe[2] = (int)i;
         }
         if (kt_lobe >= 0) { mp.lobe[3] = kt_lobe; mp.field[3] = 1; }
@@ -869,7 +892,7 @@ int pbrt_hip_add_material_substrate(PbrtHipScene* s, const float kd[3], const fl
         lobes.push_back(l);
     }
     const int rc = push_material(s, m, lobes, true, out_id);
-    if (rc == PBRT_HIP_OK && !lobes.empty()) { PbrtHipScene::MaterialParams& mp = s->material_params.back(); mp.lobe[0] = 0; mp.field[0] = 0; mp.lobe[1] = 0; mp.field[1] = 1; }
+    if (rc == PBRT_HIP_OK && !lobes.empty()) { PbrtHipScene::MaterialParams& mp = s->material_params.back(); mp.lobe[0] = 0; mp.field[0] = 0; mp.lobe[1] = 0; mp.field[1] = 1; mp.rough_lobe = 0; mp.rough_remap = remap_roughness != 0; }
     return rc;
 }
 int pbrt_hip_add_material_translucent(PbrtHipScene* s, const float kd[3], const float ks[3], const float reflect[3], const float transmit[3], float roughness,

@@ -74,6 +74,7 @@ struct alignas(16) LobeRec {
     float c_k[3], pad5;
     float scale0[3], pad6;                // innermost ScaledBxDF scale
     float scale1[3], pad7;
+    uint32_t ax_tex1, ay_tex1, remap, sigma_tex1;  // float textures for the Trowbridge-Reitz roughness (remapped per hit if `remap`) / MatteMaterial's sigma: 0 or 1 + id
     float pre[3]; uint32_t has_pre;       // a textured colour of this lobe is multiplied by `pre` (UberMaterial: `op * kd.evaluate().clamp_default()`, uber.rs:133)
 };
 
@@ -89,12 +90,13 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     uint32_t kd_tex1;  // 0, or 1 + the texture MatteMaterial evaluates for Kd at every hit (matte.rs:63): kd / has_bxdf are then per hit
     uint32_t textured; // some lobe of the list takes a colour from a texture: the general-BSDF kernel builds the hit's own list
     uint32_t bump_tex1; // 0, or 1 + the displacement texture of Material::bump (core/src/material.rs:62-101)
-    uint32_t pad[2];
+    uint32_t sigma_tex1; // MatteMaterial: 0, or 1 + the float texture behind sigma (the one-lobe kernel reads it here, the general one in its lobe)
+    uint32_t pad[1];
 };
 // What the texture pass hands the shade pass for one path vertex (wavefront.hip: texture_kernel): the bumped shading frame and the evaluated,
 // clamped (and pre-multiplied) colours of the material's textured lobe colours, in template-lobe order (r before t).
 #define PH_HIT_COLS 6
-struct TexOut { float ns[3]; uint32_t bumped; float dpdu_s[3]; uint32_t pad; float col[PH_HIT_COLS][4]; };  // 128 B
+struct TexOut { float ns[3]; uint32_t bumped; float dpdu_s[3]; uint32_t lambert; float col[PH_HIT_COLS][4]; };  // 128 B; col[0][3], col[1][3]: the per-hit (alpha_x, alpha_y) or Oren-Nayar (A, B); lambert: sigma evaluated to 0
 #define PH_HIT_LOBES 5   // per-thread slots for the per-hit lobe list of a textured material (uber: up to 5 lobes)
 
 // ---- textures (textures/src/*.rs, core/src/mipmap/mod.rs).  A texture is a postfix program over a small value stack: the host

@@ -446,10 +446,31 @@ PH_DEV bool lobe_keep(const LobeRec& l) {
          : ((l.kind == PH_LK_SPEC_T || l.kind == PH_LK_MICRO_T || l.kind == PH_LK_LAMBERT_T) ? !t_black : !r_black);
 }
 // texture pass: the textured colours of a material's template lobes at this hit, in lobe order (r before t), clamped and pre-multiplied
+PH_DEV float d_log(float x) { return (float)log((double)x); }
+// the lobe's scalar parameters when they are textures: MatteMaterial's sigma -> Oren-Nayar A, B (matte.rs:64-70, oren_nayar.rs:28-39); roughness -> Trowbridge-Reitz alpha,
+// remapped per hit (trowbridge_reitz.rs:21-40).  One parametrised lobe per material: the values travel in out.col[0][3], out.col[1][3]
+PH_DEV void eval_lobe_scalars(const DeviceScene* dsc, const LobeRec& l, const TexCtx& ctx, TexOut& out) {
+    if (l.sigma_tex1) {
+        const float sig = pclampf(tex_eval(dsc, l.sigma_tex1 - 1u, ctx).r, 0.0f, 90.0f);
+        if (sig == 0.0f) { out.lambert = 1u; out.col[0][3] = 0.0f; out.col[1][3] = 0.0f; }
+        else { const float sg = sig * (kPi / 180.0f), s2 = sg * sg; out.lambert = 0u; out.col[0][3] = 1.0f - ph_div(s2, 2.0f * (s2 + 0.33f)); out.col[1][3] = ph_div(0.45f * s2, s2 + 0.09f); }
+    }
+    if (l.ax_tex1 || l.ay_tex1) {
+        float a[2] = {l.ax, l.ay};
+        const uint32_t tx[2] = {l.ax_tex1, l.ay_tex1};
+        for (int k = 0; k < 2; k++) if (tx[k]) {
+            float r = tex_eval(dsc, tx[k] - 1u, ctx).r;
+            if (l.remap) { r = pmaxf(r, 1e-3f); const float x = d_log(r); r = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x; }
+            a[k] = pmaxf(0.001f, r);
+        }
+        out.col[0][3] = a[0]; out.col[1][3] = a[1];
+    }
+}
 PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, TexOut& out) {
     uint32_t k = 0;
     for (uint32_t i = 0; i < n; i++) {
         const LobeRec& l = tmpl[i];
+        if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1) eval_lobe_scalars(dsc, l, ctx, out);
         const spec pre = l.has_pre ? mks(l.pre[0], l.pre[1], l.pre[2]) : mks1(1.0f);
         if (l.r_tex1 && k < PH_HIT_COLS) { spec c = tex_eval_clamped(dsc, l.r_tex1 - 1u, ctx); if (l.has_pre) c = pre * c; out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++; }
         if (l.t_tex1 && k < PH_HIT_COLS) { spec c = tex_eval_clamped(dsc, l.t_tex1 - 1u, ctx); if (l.has_pre) c = pre * c; out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++; }
@@ -460,6 +481,8 @@ PH_DEV uint32_t build_hit_lobes(const LobeRec* tmpl, uint32_t n, const TexOut* i
     uint32_t k = 0, ci = 0;
     for (uint32_t i = 0; i < n && k < PH_HIT_LOBES; i++) {
         LobeRec l = tmpl[i];
+        if (l.sigma_tex1) { l.kind = in->lambert ? PH_LK_LAMBERT : PH_LK_OREN; l.a = in->col[0][3]; l.b = in->col[1][3]; }
+        if (l.ax_tex1 || l.ay_tex1) { l.ax = in->col[0][3]; l.ay = in->col[1][3]; }
         if (l.r_tex1 && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; ci++; }
         if (l.t_tex1 && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; ci++; }
         if (lobe_keep(l)) out[k++] = l;

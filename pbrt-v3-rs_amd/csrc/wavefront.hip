@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         MeshRec m;
         const SurfHit si = make_surface_hit_any(sc, rd, ray.time, __float_as_uint(h1.y), __float_as_uint(h1.z), h0.z, h0.w, h1.x, m);
         const MaterialRec& mr = sc.materials[m.material];
-        if (mr.none || !(mr.textured || mr.kd_tex1 || mr.bump_tex1)) continue;
+        if (mr.none || !(mr.textured || mr.bump_tex1)) continue;
         const uint32_t camera_ray = (bounces == 0u && !(flags & F_NODIFF)) ? 1u : 0u;  // only camera rays carry differentials
         f2 p_film = mk2(0.0f, 0.0f), lens = mk2(0.0f, 0.0f);
         if (camera_ray) {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const TexCtx ctx = hit_tex_ctx(sc.self, w.cam_dev, w.sp.spp, __float_as_uint(h1.y), __float_as_uint(h1.z), mk3(h0.z, h0.w, h1.x), si.p, si.n,
                                        mk3(ray.ox, ray.oy, ray.oz), rd, p_film, lens, camera_ray);
         TexOut out;
-        out.bumped = 0u; out.pad = 0u;
+        out.bumped = 0u; out.lambert = 0u;
         out.ns[0] = si.ns.x; out.ns[1] = si.ns.y; out.ns[2] = si.ns.z; out.dpdu_s[0] = si.dpdu_s.x; out.dpdu_s[1] = si.dpdu_s.y; out.dpdu_s[2] = si.dpdu_s.z;
         if (mr.bump_tex1) {
             BumpIn bi; bi.tex = mr.bump_tex1 - 1u; bi.tri_index = __float_as_uint(h1.y); bi.inst = __float_as_uint(h1.z); bi.bary = mk3(h0.z, h0.w, h1.x);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         for (int k = 0; k < PH_HIT_COLS; k++) out.col[k][0] = out.col[k][1] = out.col[k][2] = out.col[k][3] = 0.0f;
         if (mr.textured) eval_lobe_colours(sc.self, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out);
-        else if (mr.kd_tex1) { const spec c = tex_eval_clamped(sc.self, mr.kd_tex1 - 1u, ctx); out.col[0][0] = c.r; out.col[0][1] = c.g; out.col[0][2] = c.b; }
+
         float4* dst = reinterpret_cast<float4*>(w.tex_out + pid);
         const float4* src = reinterpret_cast<const float4*>(&out);
         for (int k = 0; k < (int)(sizeof(TexOut) / 16); k++) dst[k] = src[k];
@@ -239,9 +239,9 @@ template <> struct BsdfOps<false> {
     static PH_DEV void sample_ns(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi) { bsdf_sample_f(b, wo, u, f, pdf, wi); }
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, f, pdf, wi); type = BX_REFL | BX_DIFF; }
     static PH_DEV float eta(const T&) { return 1.0f; }
-    static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec*) {
-        const spec kd = mks(to->col[0][0], to->col[0][1], to->col[0][2]);
-        b.r = kd; b.has_bxdf = !is_black(kd);
+    static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec*, const MaterialRec& mr) {  // MatteMaterial: Kd and / or sigma of this hit
+        if (mr.kd_tex1) { const spec kd = mks(to->col[0][0], to->col[0][1], to->col[0][2]); b.r = kd; b.has_bxdf = !is_black(kd); }
+        if (mr.sigma_tex1) { b.oren = to->lambert == 0u; b.a = to->col[0][3]; b.b = to->col[1][3]; }
     }
 };
 template <> struct BsdfOps<true> {
@@ -254,7 +254,7 @@ template <> struct BsdfOps<true> {
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, BX_ALL, f, pdf, wi, type); }
     static PH_DEV float eta(const T& b) { return b.eta; }
     // the hit's own lobe list goes to the thread's slots of WfParams::hit_lobes
-    static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec* slots) {
+    static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec* slots, const MaterialRec&) {
         b.n = build_hit_lobes(b.lobes, b.n, to, slots);
         b.lobes = slots;
     }
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         bool tex_hit = false;
                         if (TEX) {  // the texture pass (texture_kernel) left this vertex's bumped frame and textured colours in tex_out[pid]
                             const MaterialRec& mr = sc.materials[m.material];
-                            tex_hit = (GEN ? mr.textured != 0u : mr.kd_tex1 != 0u) || mr.bump_tex1 != 0u;
+                            tex_hit = mr.textured != 0u || mr.bump_tex1 != 0u;
                             if (tex_hit && mr.bump_tex1) {  // Material::bump: the BSDF is made on the bumped frame
                                 const float4* tp = reinterpret_cast<const float4*>(w.tex_out + pid);
                                 const float4 f0 = tp[0], f1 = tp[1];
@@ -411,8 +411,8 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         typename BO::T bsdf = BO::make(sc, si, m.material);
                         if (TEX && tex_hit) {
                             const MaterialRec& mr = sc.materials[m.material];
-                            if (GEN ? mr.textured != 0u : mr.kd_tex1 != 0u)
-                                BO::apply_textures(bsdf, w.tex_out + pid, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr);
+                            if (mr.textured)
+                                BO::apply_textures(bsdf, w.tex_out + pid, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr, mr);
                         }
                         SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid - ppix * w.chunk_spp), dim, hl);
                         // Draw the next 8 dimensions in one (not unrolled) loop: light pick 1D, u_light 2D, u_scattering 2D, BSDF 2D,

@@ -453,6 +453,7 @@ void Api::pbrt_area_light_source(const std::string& name, const ParamSet& p) { i
 uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::array<float, 3> kd = {0.5f, 0.5f, 0.5f};
     float sigma = 0.0f;
+    int64_t ftex_param[3] = {-1, -1, -1};     // [sigma, uroughness, vroughness]: the same for float parameters
     int64_t tex_param[4] = {-1, -1, -1, -1};  // [Kd, Ks, Kr, Kt]: the parameter names a texture the library evaluates per hit
     auto spectrum_tex = [&](const std::string& pname, std::array<float, 3> d) {
         std::string tn = m.params.find_one_texture(pname);
@@ -482,9 +483,18 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     auto float_tex = [&](const std::string& pname, float d) {
         std::string tn = m.params.find_one_texture(pname);
         if (!tn.empty()) {
-            if (gs_.device_textures.count(tn)) {
-                if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": image-based textures feed colour parameters only (matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks); scalar parameters stay constants";
-                return m.params.find_one_float(pname, d);
+            auto dtf = gs_.device_textures.find(tn);
+            if (dtf != gs_.device_textures.end()) {
+                // a float texture the library evaluates per hit: sigma (matte) or the microfacet roughness (plastic, uber, substrate, metal)
+                const int fp = pname == "sigma" ? 0 : ((pname == "uroughness" || pname == "roughness") ? 1 : (pname == "vroughness" ? 2 : -1));
+                const bool takes = dtf->second.is_float && ((m.type == "matte" && fp == 0) || ((m.type == "plastic" || m.type == "uber" || m.type == "substrate" || m.type == "metal") && fp > 0));
+                if (!takes) {
+                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit float textures are wired to matte sigma and to the roughness of plastic / uber / substrate / metal so far";
+                    return m.params.find_one_float(pname, d);
+                }
+                if (pname == "roughness") { if (ftex_param[1] < 0) ftex_param[1] = (int64_t)dtf->second.id; if (ftex_param[2] < 0) ftex_param[2] = (int64_t)dtf->second.id; }
+                else ftex_param[fp] = (int64_t)dtf->second.id;
+                return d;   // placeholder: the texture replaces it
             }
             auto it = gs_.float_textures.find(tn);
             if (it != gs_.float_textures.end()) return it->second;
@@ -578,6 +588,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::string key = t + (remap ? ":r" : ":n");
     for (float v : kv) { uint32_t u; std::memcpy(&u, &v, 4); char b[12]; std::snprintf(b, sizeof b, ":%08x", u); key += b; }
     if (bump_tex >= 0) key += "|bump=" + std::to_string(bump_tex);
+    for (int k = 0; k < 3; k++) if (ftex_param[k] >= 0) key += "|ftex" + std::to_string(k) + "=" + std::to_string(ftex_param[k]);
     for (int k = 0; k < 4; k++) if (tex_param[k] >= 0) key += "|tex" + std::to_string(k) + "=" + std::to_string(tex_param[k]);
     auto it = material_cache_.find(key);
     if (it != material_cache_.end()) return it->second;
@@ -596,6 +607,8 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     if (!check(rc, "add_material")) return 0;
     for (int k = 0; k < 4; k++)
         if (tex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_texture(scene_, id, k, (uint32_t)tex_param[k])), "set_material_texture")) return 0;
+    for (int k = 0; k < 3; k++)
+        if (ftex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_float_texture(scene_, id, k, (uint32_t)ftex_param[k])), "set_material_float_texture")) return 0;
     if (bump_tex >= 0 && !check(ABI(pbrt_hip_set_material_bump(scene_, id, (uint32_t)bump_tex)), "set_material_bump")) return 0;
     material_cache_[key] = id;
     return id;

@@ -132,6 +132,7 @@ class Binding:
             "add_material_matte_tex": (C.c_int, [vp, C.c_uint32, C.c_float, u32p]),
             "set_material_texture": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32]),
             "set_material_bump": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
+            "set_material_float_texture": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32]),
             "set_last_mesh_alpha_textures": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
             "texture_eval_batch": (C.c_int, [vp, C.c_uint32, C.c_uint64, fp, fp]),
             "mipmap_levels": (C.c_int, [vp, C.c_uint32, ip, ip]),
@@ -553,6 +554,13 @@ class Scene:
         """Float textures for the `alpha` / `shadowalpha` masks of the mesh added last (None keeps the constant)."""
         none = 0xFFFFFFFF
         self._chk(self.b.fn("set_last_mesh_alpha_textures")(self.h, none if alpha is None else alpha, none if shadow_alpha is None else shadow_alpha))
+
+    FPARAM = {"sigma": 0, "uroughness": 1, "vroughness": 2}
+
+    def set_material_float_texture(self, material, fparam, texture):
+        """fparam: "sigma" (matte) | "uroughness" | "vroughness" | "roughness" (= both) — that scalar of `material` becomes the float texture, evaluated per hit."""
+        for f in (("uroughness", "vroughness") if fparam == "roughness" else (fparam,)):
+            self._chk(self.b.fn("set_material_float_texture")(self.h, material, self.FPARAM[f], texture))
 
     def set_material_bump(self, material, texture):
         """Material::bump with the float texture `texture` as displacement map."""

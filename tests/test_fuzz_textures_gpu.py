@@ -85,17 +85,21 @@ def textured_material(s, host, rng):
     c = lambda lo=0.0, hi=1.0: tuple(rng.uniform(lo, hi, 3))
     k = int(rng.integers(0, 7))
     tex = lambda: random_texture(s, host, rng, False)
+    ftex = lambda scale: s.add_texture_scale(random_texture(s, host, rng, True), s.add_texture_constant(float(scale)))
     if k == 0:
         m = s.add_material_matte_tex(tex(), float(rng.choice([0.0, rng.uniform(1, 60)])))
+        if rng.integers(0, 3) == 0: s.set_material_float_texture(m, "sigma", ftex(60.0))
     elif k == 1:
         m = s.add_material_plastic(one, one, float(rng.uniform(0.01, 0.4)), bool(rng.integers(0, 2)))
         s.set_material_texture(m, "Kd", tex())
         if rng.integers(0, 2): s.set_material_texture(m, "Ks", tex())
+        if rng.integers(0, 3) == 0: s.set_material_float_texture(m, "roughness", ftex(0.5))
     elif k == 2:
         m = s.add_material_mirror(one); s.set_material_texture(m, "Kr", tex())
     elif k == 3:
         m = s.add_material_substrate(one, one, float(rng.uniform(0.02, 0.4)), float(rng.uniform(0.02, 0.4)), bool(rng.integers(0, 2)))
         s.set_material_texture(m, "Kd", tex()); s.set_material_texture(m, "Ks", tex())
+        if rng.integers(0, 3) == 0: s.set_material_float_texture(m, str(rng.choice(["uroughness", "vroughness"])), ftex(0.5))
     elif k == 4:
         rough = float(rng.choice([0.0, rng.uniform(0.02, 0.3)]))
         m = s.add_material_glass(one, one, rough, rough, float(rng.uniform(1.1, 1.8)), True)
@@ -105,6 +109,7 @@ def textured_material(s, host, rng):
         m = s.add_material_uber(one, one, one, one, (op, op, op), float(rng.uniform(0.02, 0.3)), float(rng.uniform(0.02, 0.3)), float(rng.uniform(1.1, 1.7)), True)
         for prm in ("Kd", "Ks", "Kr", "Kt"):
             if rng.integers(0, 2): s.set_material_texture(m, prm, tex())
+        if rng.integers(0, 3) == 0: s.set_material_float_texture(m, "uroughness", ftex(0.4))
     else:
         m = F.random_material(s, rng)       # a constant material, possibly only bumped
         if rng.integers(0, 2) == 0: return m

@@ -201,6 +201,21 @@ def test_a_constant_texture_is_the_constant_parameter():
             m = sc.add_material_glass((1, 1, 1), (1, 1, 1), rough, rough, 1.5, True)
             sc.set_material_texture(m, "Kr", tex); sc.set_material_texture(m, "Kt", tex); return m
         assert np.array_equal(film(glass_tex), film(lambda sc, tex, rough=rough: sc.add_material_glass(c, c, rough, rough, 1.5, True)))
+    # scalar parameters: a constant float texture is the constant (the per-hit remap uses the same polynomial as the constructor)
+    def fconst(v): return lambda sc: sc.add_texture_constant(v)
+    def plastic_rough(sc, tex):
+        m = sc.add_material_plastic(c, c, 0.5, True); sc.set_material_float_texture(m, "roughness", sc.add_texture_constant(0.15)); return m
+    assert np.array_equal(film(plastic_rough), film(lambda sc, tex: sc.add_material_plastic(c, c, 0.15, True)))
+    def matte_sigma(sc, tex):
+        m = sc.add_material_matte(c, 0.0); sc.set_material_float_texture(m, "sigma", sc.add_texture_constant(35.0)); return m
+    assert np.array_equal(film(matte_sigma), film(lambda sc, tex: sc.add_material_matte(c, 35.0)))
+    def matte_sigma0(sc, tex):
+        m = sc.add_material_matte(c, 20.0); sc.set_material_float_texture(m, "sigma", sc.add_texture_constant(0.0)); return m
+    assert np.array_equal(film(matte_sigma0), film(lambda sc, tex: sc.add_material_matte(c, 0.0)))
+    def metal_uv(sc, tex):
+        m = sc.add_material_metal((0.2, 0.9, 1.1), (3.9, 2.4, 2.1), 0.3, 0.3, False)
+        sc.set_material_float_texture(m, "uroughness", sc.add_texture_constant(0.05)); sc.set_material_float_texture(m, "vroughness", sc.add_texture_constant(0.2)); return m
+    assert np.array_equal(film(metal_uv), film(lambda sc, tex: sc.add_material_metal((0.2, 0.9, 1.1), (3.9, 2.4, 2.1), 0.05, 0.2, False)))
     # a black constant texture removes the lobe exactly as a black constant does
     def black(material):
         s = OracleScene()

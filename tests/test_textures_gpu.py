@@ -162,7 +162,46 @@ def _glass(rough):
     return make
 
 
+def _fimg(sc, lo, hi, zeros=False, **kw):
+    img = make_image(24, 24, seed=13)
+    if zeros: img[:, :8] = 0.0
+    t = sc.add_texture_imagemap(sc.add_mipmap(img, as_float=True, **kw), su=2.0, sv=2.0)
+    return sc.add_texture_mix(sc.add_texture_constant(lo), sc.add_texture_constant(hi), t) if not zeros else sc.add_texture_scale(t, sc.add_texture_constant(hi))
+
+
+def _matte_sigma(sc, tex):
+    m = sc.add_material_matte_tex(tex, 10.0); sc.set_material_float_texture(m, "sigma", _fimg(sc, 0.0, 70.0, zeros=True)); return m      # sigma = 0 on a third of the map: Lambert there
+
+
+def _plastic_rough(remap):
+    def make(sc, tex):
+        m = sc.add_material_plastic((1, 1, 1), (0.4, 0.4, 0.4), 0.1, remap); sc.set_material_texture(m, "Kd", tex)
+        sc.set_material_float_texture(m, "roughness", _fimg(sc, 0.02, 0.5, trilinear=True)); return m
+    return make
+
+
+def _uber_rough(sc, tex):
+    m = sc.add_material_uber((0.4, 0.3, 0.2), (0.5, 0.5, 0.5), (0.1, 0.1, 0.1), (0, 0, 0), (1, 1, 1), 0.1, 0.1, 1.5, True)
+    sc.set_material_float_texture(m, "uroughness", _fimg(sc, 0.01, 0.3)); sc.set_material_float_texture(m, "vroughness", _fimg(sc, 0.2, 0.6)); return m
+
+
+def _substrate_metal(sc, tex):
+    m = sc.add_material_substrate((0.5, 0.3, 0.2), (0.1, 0.1, 0.1), 0.1, 0.1, False)
+    sc.set_material_float_texture(m, "uroughness", _fimg(sc, 0.05, 0.4)); sc.set_material_texture(m, "Kd", tex); return m
+
+
+def _metal_rough(sc, tex):
+    m = sc.add_material_metal((0.2, 0.92, 1.1), (3.9, 2.45, 2.14), 0.05, 0.05, True)
+    sc.set_material_float_texture(m, "roughness", _fimg(sc, 0.005, 0.3)); return m
+
+
 MATERIAL_CASES = {
+    "matte_sigma_texture": (_matte_sigma, _tex()),
+    "plastic_roughness_remapped": (_plastic_rough(True), _tex()),
+    "plastic_roughness_raw": (_plastic_rough(False), _tex()),
+    "uber_uv_roughness": (_uber_rough, _tex()),
+    "substrate_uroughness": (_substrate_metal, _tex()),
+    "metal_roughness": (_metal_rough, _tex()),
     "uber_all_four": (_uber, _tex(kind="checker", w=8, h=8)),
     "glass_smooth_kr_kt": (_glass(0.0), _tex(kind="checker", w=8, h=8)),
     "glass_rough_kr_kt": (_glass(0.05), _tex(w=20, h=20)),
