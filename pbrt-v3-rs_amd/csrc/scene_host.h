@@ -84,6 +84,8 @@ int set_err(PbrtHipScene* s, int code, const std::string& msg);
 int hip_fail(PbrtHipScene* s, hipError_t e, const char* what);
 int ensure_buf(PbrtHipScene* s, DevBuf& b, size_t bytes);
 int upload_scene(PbrtHipScene* s);
+// MIPMap::lookup_triangle on the host copy of the texel pool (textures_api.hip), for what InfiniteAreaLight computes at construction time
+void hmip_lookup_triangle(const PbrtHipScene* s, const MipRec& m, float u, float v, float width, float out[3]);
 int upload_light_distribution(PbrtHipScene* s, int light_strategy);
 int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_out, uint32_t n, float* kernel_ms);
 void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph::TravParams& p);  // 0 closest, 1 any hit, 2 both (MIXED)
