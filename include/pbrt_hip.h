@@ -184,14 +184,16 @@ int pbrt_hip_add_texture_checkerboard3d(PbrtHipScene*, uint32_t tex1, uint32_t t
  * compute_scattering_functions: materials/src/matte.rs:63, plastic.rs:62-70, mirror.rs:53-55, substrate.rs:60-62), with the ray
  * differentials of camera rays (SurfaceInteraction::compute_differentials) driving the MIPMap filter.  Which lobes a hit gets follows the
  * reference's `is_black` tests on the value at that hit.  Texturable so far: matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, glass Kr / Kt (glass.rs:72-78)
- * and uber Kd / Ks / Kr / Kt (multiplied by its constant opacity, uber.rs:133-160);
- * the material must have been created with a non-black constant for that parameter.  Scalar parameters (sigma, roughness, ...) stay constants;
- * materials with per-hit textures cannot be children of a mix yet. */
+ * uber Kd / Ks / Kr / Kt (multiplied by its constant opacity, uber.rs:133-160) and translucent Kd / Ks (each feeds a reflection and a transmission
+ * lobe; the texel is tested for black BEFORE its product with the constant reflect / transmit, translucent.rs:77-84, :87);
+ * the material must have been created with a non-black constant for that parameter.  Scalar parameters: see set_material_float_texture.
+ * Materials with per-hit textures may be children of a mix (each lobe is kept or dropped as its own material would, mix.rs:63-87) as long as the
+ * mix has at most 6 textured colours and one textured roughness / sigma; bump-mapped children are refused. */
 enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2, PBRT_HIP_PARAM_KT = 3 };
 int pbrt_hip_set_material_texture(PbrtHipScene*, uint32_t material, int param, uint32_t texture);
 /* Scalar parameters as float textures, evaluated at every hit: fparam 0 = MatteMaterial's sigma (matte.rs:64-70: Lambert where it evaluates to 0, Oren-Nayar elsewhere),
- * 1 / 2 = u / v roughness of the Trowbridge-Reitz distribution of plastic, uber, substrate and metal (remapped per hit if the material was created with remap_roughness;
- * plastic's single `roughness`: set both).  Glass is not wired (its lobe structure switches on roughness == 0). */
+ * 1 / 2 = u / v roughness of the Trowbridge-Reitz distribution of plastic, uber, substrate, translucent and metal (remapped per hit if the material was created with remap_roughness;
+ * plastic's and translucent's single `roughness`: set both).  Glass is not wired (its lobe structure switches on roughness == 0). */
 int pbrt_hip_set_material_float_texture(PbrtHipScene*, uint32_t material, int fparam, uint32_t texture);
 /* Bump mapping: Material::bump (core/src/material.rs:62-101) with the float texture `texture` as displacement, run before the BSDF of a hit is made
  * (every material's `bumpmap` parameter).  Not for Material "none"; not for children of a mix yet. */

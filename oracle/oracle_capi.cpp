@@ -410,9 +410,13 @@ int oracle_set_material_texture(OracleScene* s, uint32_t material, int param, ui
     if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || param < 0 || param > 3) return -1;
     Material& m = s->sc.materials[material];
     if (m.param_lobe[param] < 0) return -6;
-    Lobe& l = m.lobes[(size_t)m.param_lobe[param]];
-    if (m.param_field[param] == 0) l.r_tex = (int)texture; else l.t_tex = (int)texture;
-    if (m.has_pre) { l.has_pre = true; l.pre = m.pre; }
+    const int lobes[2] = {m.param_lobe[param], m.param_lobe2[param]}, fields[2] = {m.param_field[param], m.param_field2[param]};
+    for (int k = 0; k < 2; k++) if (lobes[k] >= 0) {
+        Lobe& l = m.lobes[(size_t)lobes[k]];
+        if (fields[k] == 0) l.r_tex = (int)texture; else l.t_tex = (int)texture;
+        if (m.has_pre) { l.has_pre = true; l.pre = m.pre; }
+        if (l.pre_raw_test) l.has_pre = true;
+    }
     m.textured = true;
     return 0;
 }
@@ -432,8 +436,8 @@ int oracle_set_material_float_texture(OracleScene* s, uint32_t material, int fpa
         m.lobes[0].sigma_tex = (int)texture;
     } else {
         if (m.rough_lobe < 0) return -6;
-        Lobe& l = m.lobes[(size_t)m.rough_lobe];
-        (fparam == 1 ? l.ax_tex : l.ay_tex) = (int)texture; l.remap = m.rough_remap;
+        const int rl[2] = {m.rough_lobe, m.rough_lobe2};
+        for (int k = 0; k < 2; k++) if (rl[k] >= 0) { Lobe& l = m.lobes[(size_t)rl[k]]; (fparam == 1 ? l.ax_tex : l.ay_tex) = (int)texture; l.remap = m.rough_remap; }
     }
     m.textured = true;
     return 0;
@@ -579,16 +583,21 @@ int oracle_add_material_translucent(OracleScene* s, const float kd[3], const flo
     Material m; m.general = true; m.bsdf_eta = 1.5f;
     Spec r = spec_clamp0(spec3(reflect)), t = spec_clamp0(spec3(transmit));
     if (r.is_black() && t.is_black()) { s->err = "translucent with reflect = transmit = 0 leaves the BSDF unset (translucent.rs:73-75): null-BSDF skipping is out of scope"; return -5; }
+    // each lobe remembers the reflect / transmit factor of its product, so that a Kd / Ks texture can be evaluated per hit (set_material_texture)
+    auto feed = [&](int param, int field) { if (m.param_lobe[param] < 0) { m.param_lobe[param] = (int)m.lobes.size(); m.param_field[param] = field; } else { m.param_lobe2[param] = (int)m.lobes.size(); m.param_field2[param] = field; } };
     Spec d = spec_clamp0(spec3(kd));
     if (!d.is_black()) {
-        if (!r.is_black()) { Lobe l; l.kind = LK_LAMBERT; l.type = BX_REFL | BX_DIFF; l.r = r * d; m.lobes.push_back(l); }
-        if (!t.is_black()) { Lobe l; l.kind = LK_LAMBERT_T; l.type = BX_TRANS | BX_DIFF; l.t = t * d; m.lobes.push_back(l); }
+        if (!r.is_black()) { Lobe l; l.kind = LK_LAMBERT; l.type = BX_REFL | BX_DIFF; l.r = r * d; l.pre = r; l.pre_raw_test = true; feed(0, 0); m.lobes.push_back(l); }
+        if (!t.is_black()) { Lobe l; l.kind = LK_LAMBERT_T; l.type = BX_TRANS | BX_DIFF; l.t = t * d; l.pre = t; l.pre_raw_test = true; feed(0, 1); m.lobes.push_back(l); }
     }
     Spec sp = spec_clamp0(spec3(ks));
     if (!sp.is_black() && (!r.is_black() || !t.is_black())) {
         Float rough = remap ? roughness_to_alpha(roughness) : roughness;
-        if (!r.is_black()) { Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; l.r = r * sp; set_tr(l, rough, rough); m.lobes.push_back(l); }
-        if (!t.is_black()) { Lobe l; l.kind = LK_MICRO_T; l.type = BX_TRANS | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; l.t = t * sp; set_tr(l, rough, rough); m.lobes.push_back(l); }
+        m.rough_remap = remap != 0;
+        if (!r.is_black()) { Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; l.r = r * sp; l.pre = r; l.pre_raw_test = true; set_tr(l, rough, rough);
+                             feed(1, 0); m.rough_lobe = (int)m.lobes.size(); m.lobes.push_back(l); }
+        if (!t.is_black()) { Lobe l; l.kind = LK_MICRO_T; l.type = BX_TRANS | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; l.t = t * sp; l.pre = t; l.pre_raw_test = true; set_tr(l, rough, rough);
+                             feed(1, 1); (m.rough_lobe < 0 ? m.rough_lobe : m.rough_lobe2) = (int)m.lobes.size(); m.lobes.push_back(l); }
     }
     return push_material(s, m, out_id);
 }
@@ -601,6 +610,8 @@ int oracle_add_material_mix(OracleScene* s, uint32_t m1, uint32_t m2, const floa
     if (a.lobes.size() + b.lobes.size() > 8) { s->err = "mix: more than MAX_BXDFS = 8 lobes (bsdf.rs:119-125 asserts)"; return -1; }
     for (Lobe l : a.lobes) { if (l.n_scale >= 2) { s->err = "mix nested deeper than two levels"; return -5; } l.scale[l.n_scale++] = s1; m.lobes.push_back(l); }
     for (Lobe l : b.lobes) { if (l.n_scale >= 2) { s->err = "mix nested deeper than two levels"; return -5; } l.scale[l.n_scale++] = s2; m.lobes.push_back(l); }
+    if (a.bump_tex >= 0 || b.bump_tex >= 0) { s->err = "mix of bump-mapped materials: each sub-material bumps the interaction in turn (mix.rs:63-76); not modelled"; return -5; }
+    m.textured = a.textured || b.textured;   // the sub-materials' textures are evaluated per hit, each lobe kept or dropped as its own material would (mix.rs:63-87)
     return push_material(s, m, out_id);
 }
 

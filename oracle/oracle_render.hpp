@@ -998,8 +998,10 @@ struct Renderer {
                     };
                     l.ax = alpha_of(l.ax_tex, l.ax); l.ay = alpha_of(l.ay_tex, l.ay);
                 }
-                if (l.r_tex >= 0) { l.r = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.r_tex, c)); if (l.has_pre) l.r = l.pre * l.r; }
-                if (l.t_tex >= 0) { l.t = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.t_tex, c)); if (l.has_pre) l.t = l.pre * l.t; }
+                bool raw_black = false;   // translucent.rs:77-84, :87: the texel itself is tested, then multiplied by reflect / transmit
+                if (l.r_tex >= 0) { l.r = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.r_tex, c)); if (l.pre_raw_test && l.r.is_black()) raw_black = true; if (l.has_pre) l.r = l.pre * l.r; }
+                if (l.t_tex >= 0) { l.t = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.t_tex, c)); if (l.pre_raw_test && l.t.is_black()) raw_black = true; if (l.has_pre) l.t = l.pre * l.t; }
+                if (l.pre_raw_test) { if (!raw_black) local[k++] = l; continue; }   // an untextured lobe of this material exists because its constant passed the test at creation
                 const bool keep = (l.kind == LK_FRESNEL_BLEND || l.kind == LK_FRESNEL_SPEC) ? !(l.r.is_black() && l.t.is_black())
                                 : ((l.kind == LK_SPEC_T || l.kind == LK_MICRO_T || l.kind == LK_LAMBERT_T) ? !l.t.is_black() : !l.r.is_black());
                 if (keep) local[k++] = l;

@@ -41,6 +41,7 @@ struct Lobe {
     int n_scale = 0; Spec scale[2];  // ScaledBxDF wrappers of MixMaterial, innermost first (scaled_bxdf.rs)
     int r_tex = -1, t_tex = -1;      // this colour is a texture evaluated per hit (set_material_texture)
     bool has_pre = false; Spec pre;  // ... multiplied by `pre` (UberMaterial's opacity, uber.rs:133)
+    bool pre_raw_test = false;       // TranslucentMaterial: `if !kd.is_black() { add(r * kd) }` tests the texel BEFORE the product (translucent.rs:77-84, :87)
     int ax_tex = -1, ay_tex = -1; bool remap = false;  // the microfacet roughness is a float texture (plastic.rs:71-76, uber.rs:140-153, substrate.rs:63-71, metal.rs:69-83)
     int sigma_tex = -1;              // MatteMaterial's sigma is a float texture (matte.rs:64-70)
 };
@@ -49,7 +50,8 @@ struct Material {
     int bump_tex = -1;      // Material::bump's displacement texture (material.rs:62-101), any material
     bool textured = false;  // some lobe colour is a texture: the BSDF's lobe list is made per hit (compute_scattering_functions evaluates the textures there)
     int param_lobe[4] = {-1, -1, -1, -1}, param_field[4] = {0, 0, 0, 0};  // [Kd, Ks, Kr, Kt] -> lobe index / 0 = r, 1 = t
-    int rough_lobe = -1; bool rough_remap = false;   // the lobe that owns the Trowbridge-Reitz distribution (set_material_float_texture)
+    int param_lobe2[4] = {-1, -1, -1, -1}, param_field2[4] = {0, 0, 0, 0};  // a second lobe fed by the same parameter (translucent: the reflection and the transmission lobe)
+    int rough_lobe = -1, rough_lobe2 = -1; bool rough_remap = false;   // the lobe(s) that own the Trowbridge-Reitz distribution (set_material_float_texture)
     bool has_pre = false; Spec pre;
 };
 

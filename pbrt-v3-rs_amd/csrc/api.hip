@@ -540,16 +540,25 @@ int pbrt_hip_add_material_translucent(PbrtHipScene* s, const float kd[3], const 
     if (!rb && !tb)
         return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_translucent: reflect = transmit = 0 leaves the BSDF unset in the reference (translucent.rs:73-75); null-BSDF skipping is out of scope");
     auto prod = [&](const float a[3], const float b[3]) { for (int c = 0; c < 3; c++) v[c] = a[c] * b[c]; };
+    // each lobe keeps the reflect / transmit factor of its product (pre, PH_PRE_RAW_TEST) so that a Kd / Ks texture can replace the other factor per hit
+    PbrtHipScene::MaterialParams mp;
+    auto feed = [&](int param, int field) { if (mp.lobe[param] < 0) { mp.lobe[param] = (int)lobes.size(); mp.field[param] = field; } else { mp.lobe2[param] = (int)lobes.size(); mp.field2[param] = field; } };
+    auto raw = [&](LobeRec& l, const float f[3]) { std::memcpy(l.pre, f, 12); l.has_pre = PH_PRE_RAW_TEST; };
     if (clamp3(kd, d)) {
-        if (rb) { LobeRec l = lobe(PH_LK_LAMBERT, T_REFL | T_DIFF); prod(r, d); std::memcpy(l.r, v, 12); lobes.push_back(l); }
-        if (tb) { LobeRec l = lobe(PH_LK_LAMBERT_T, T_TRANS | T_DIFF); prod(t, d); std::memcpy(l.t, v, 12); lobes.push_back(l); }
+        if (rb) { LobeRec l = lobe(PH_LK_LAMBERT, T_REFL | T_DIFF); prod(r, d); std::memcpy(l.r, v, 12); raw(l, r); feed(0, 0); lobes.push_back(l); }
+        if (tb) { LobeRec l = lobe(PH_LK_LAMBERT_T, T_TRANS | T_DIFF); prod(t, d); std::memcpy(l.t, v, 12); raw(l, t); feed(0, 1); lobes.push_back(l); }
     }
     if (clamp3(ks, sp)) {
         const float rough = remap_roughness ? roughness_to_alpha(roughness) : roughness;
-        if (rb) { LobeRec l = lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; prod(r, sp); std::memcpy(l.r, v, 12); set_tr(l, rough, rough); lobes.push_back(l); }
-        if (tb) { LobeRec l = lobe(PH_LK_MICRO_T, T_TRANS | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; prod(t, sp); std::memcpy(l.t, v, 12); set_tr(l, rough, rough); lobes.push_back(l); }
+        mp.rough_remap = remap_roughness != 0;
+        if (rb) { LobeRec l = lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; prod(r, sp); std::memcpy(l.r, v, 12); set_tr(l, rough, rough); raw(l, r);
+                  feed(1, 0); mp.rough_lobe = (int)lobes.size(); lobes.push_back(l); }
+        if (tb) { LobeRec l = lobe(PH_LK_MICRO_T, T_TRANS | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; prod(t, sp); std::memcpy(l.t, v, 12); set_tr(l, rough, rough); raw(l, t);
+                  feed(1, 1); (mp.rough_lobe < 0 ? mp.rough_lobe : mp.rough_lobe2) = (int)lobes.size(); lobes.push_back(l); }
     }
-    return push_material(s, m, lobes, true, out_id);
+    const int rc = push_material(s, m, lobes, true, out_id);
+    if (rc == PBRT_HIP_OK) s->material_params.back() = mp;
+    return rc;
 }
 int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t material2, const float amount[3], uint32_t* out_id) {  // mix.rs:51-88
     if (!s || !amount) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: null argument");
@@ -560,7 +569,7 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
     for (int c = 0; c < 3; c++) tmp[c] = 1.0f - s1[c];
     clamp3(tmp, s2);
     const MaterialRec a = s->materials[material1], b = s->materials[material2];
-    if (a.textured || b.textured || a.bump_tex1 || b.bump_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a mix of materials with per-hit textures is not supported yet");
+    if (a.bump_tex1 || b.bump_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: each bump-mapped sub-material bumps the interaction in turn (mix.rs:63-76); not supported");
     if (a.n_lobes + b.n_lobes > 8) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: more than MAX_BXDFS = 8 lobes (BSDF::add asserts, bsdf.rs:119-125)");
     std::vector<LobeRec> lobes;
     auto take = [&](const MaterialRec& src, const float sc[3]) {
@@ -573,6 +582,21 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
         return true;
     };
     if (!take(a, s1) || !take(b, s2)) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: mix nested deeper than two levels");
+    if (a.textured || b.textured) {
+        // the sub-materials' textures are evaluated per hit and each lobe is kept or dropped as its own material would (mix.rs:63-87); the per-hit list has
+        // PH_HIT_LOBES lobe slots, PH_HIT_COLS colour slots and ONE pair of per-hit scalars (roughness or sigma)
+        uint32_t cols = 0, scal = 0; const LobeRec* first = nullptr;
+        for (const LobeRec& l : lobes) {
+            cols += (l.r_tex1 ? 1u : 0u) + (l.t_tex1 ? 1u : 0u);
+            if (l.ax_tex1 || l.ay_tex1 || l.sigma_tex1) {
+                if (!first) { first = &l; scal = 1; }
+                else if (l.ax_tex1 != first->ax_tex1 || l.ay_tex1 != first->ay_tex1 || l.remap != first->remap || l.sigma_tex1 != first->sigma_tex1 || l.ax != first->ax || l.ay != first->ay) scal++;
+            }
+        }
+        if (lobes.size() > PH_HIT_LOBES || cols > PH_HIT_COLS || scal > 1u)
+            return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a textured mix may have at most 8 lobes, 6 textured colours and one textured roughness / sigma");
+        m.textured = 1u;
+    }
     return push_material(s, m, lobes, true, out_id);
 }
 

@@ -31,7 +31,7 @@ struct PbrtHipScene {
     std::vector<MipRec> mipmaps;
     std::vector<Texel> texels;
     // which lobe and which of its two colours each texturable parameter of a material feeds (set_material_texture); -1 = that lobe was not made
-    struct MaterialParams { int lobe[4] = {-1, -1, -1, -1}; int field[4] = {0, 0, 0, 0}; bool has_pre = false; float pre[3] = {1, 1, 1}; int rough_lobe = -1; bool rough_remap = false; };  // [Kd, Ks, Kr, Kt]; field 0 = r, 1 = t; pre: uber's opacity; rough_lobe: owner of the Trowbridge-Reitz distribution
+    struct MaterialParams { int lobe[4] = {-1, -1, -1, -1}; int field[4] = {0, 0, 0, 0}; int lobe2[4] = {-1, -1, -1, -1}; int field2[4] = {0, 0, 0, 0}; bool has_pre = false; float pre[3] = {1, 1, 1}; int rough_lobe = -1, rough_lobe2 = -1; bool rough_remap = false; };  // [Kd, Ks, Kr, Kt]; field 0 = r, 1 = t; pre: uber's opacity; lobe2 / field2 / rough_lobe2: a second lobe fed by the same parameter (translucent's reflection + transmission pair); rough_lobe: owner of the Trowbridge-Reitz distribution
     std::vector<MaterialParams> material_params;
     bool alpha_textures = false;      // some mesh has an alpha / shadowalpha texture: traversal uses the ALPHA kernel variants
     bool bump_materials = false;      // some material has a bump map

@@ -63,6 +63,7 @@ struct MeshRec {
 enum { PH_LK_LAMBERT = 0, PH_LK_OREN = 1, PH_LK_SPEC_R = 2, PH_LK_SPEC_T = 3, PH_LK_FRESNEL_SPEC = 4, PH_LK_MICRO_R = 5, PH_LK_MICRO_T = 6,
        PH_LK_FRESNEL_BLEND = 7 /* r = Rd, t = Rs */, PH_LK_LAMBERT_T = 8 };
 enum { PH_FR_NOOP = 0, PH_FR_DIEL = 1, PH_FR_COND = 2 };
+#define PH_PRE_RAW_TEST 2u
 struct alignas(16) LobeRec {
     uint32_t kind, type, fresnel, n_scale; // type = BxDFType bits (bsdf.rs:10-20); n_scale = ScaledBxDF wrappers around the lobe (mix.rs)
     float a, b;                           // Oren-Nayar A, B
@@ -75,7 +76,8 @@ struct alignas(16) LobeRec {
     float scale0[3], pad6;                // innermost ScaledBxDF scale
     float scale1[3], pad7;
     uint32_t ax_tex1, ay_tex1, remap, sigma_tex1;  // float textures for the Trowbridge-Reitz roughness (remapped per hit if `remap`) / MatteMaterial's sigma: 0 or 1 + id
-    float pre[3]; uint32_t has_pre;       // a textured colour of this lobe is multiplied by `pre` (UberMaterial: `op * kd.evaluate().clamp_default()`, uber.rs:133)
+    float pre[3]; uint32_t has_pre;       // 1: a textured colour of this lobe is multiplied by `pre`, then tested (UberMaterial: `op * kd.evaluate().clamp_default()`, uber.rs:133);
+                                          // 2: the texel is tested, then multiplied (TranslucentMaterial: `if !kd.is_black() { add(r * kd) }`, translucent.rs:77-84, :87) -- PH_PRE_RAW_TEST
 };
 
 struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant textures) + the general lobe list
@@ -96,8 +98,8 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
 // What the texture pass hands the shade pass for one path vertex (wavefront.hip: texture_kernel): the bumped shading frame and the evaluated,
 // clamped (and pre-multiplied) colours of the material's textured lobe colours, in template-lobe order (r before t).
 #define PH_HIT_COLS 6
-struct TexOut { float ns[3]; uint32_t bumped; float dpdu_s[3]; uint32_t lambert; float col[PH_HIT_COLS][4]; };  // 128 B; col[0][3], col[1][3]: the per-hit (alpha_x, alpha_y) or Oren-Nayar (A, B); lambert: sigma evaluated to 0
-#define PH_HIT_LOBES 5   // per-thread slots for the per-hit lobe list of a textured material (uber: up to 5 lobes)
+struct TexOut { float ns[3]; uint32_t bumped; float dpdu_s[3]; uint32_t lambert; float col[PH_HIT_COLS][4]; };  // 128 B; col[0][3], col[1][3]: the per-hit (alpha_x, alpha_y) or Oren-Nayar (A, B); lambert: sigma evaluated to 0; bumped bit 8 + k: colour k's texel was black before its PH_PRE_RAW_TEST product
+#define PH_HIT_LOBES 8   // per-thread slots for the per-hit lobe list of a textured material (= MAX_BXDFS, bsdf.rs:22: uber has up to 5, a mix up to 8)
 
 // ---- textures (textures/src/*.rs, core/src/mipmap/mod.rs).  A texture is a postfix program over a small value stack: the host
 // flattens the scale / mix tree once (api.hip), the device runs it per hit (texture.h).  Float-valued textures are carried as three equal

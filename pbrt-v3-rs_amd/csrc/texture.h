@@ -472,8 +472,13 @@ PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const LobeRec* tmpl, uint3
         const LobeRec& l = tmpl[i];
         if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1) eval_lobe_scalars(dsc, l, ctx, out);
         const spec pre = l.has_pre ? mks(l.pre[0], l.pre[1], l.pre[2]) : mks1(1.0f);
-        if (l.r_tex1 && k < PH_HIT_COLS) { spec c = tex_eval_clamped(dsc, l.r_tex1 - 1u, ctx); if (l.has_pre) c = pre * c; out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++; }
-        if (l.t_tex1 && k < PH_HIT_COLS) { spec c = tex_eval_clamped(dsc, l.t_tex1 - 1u, ctx); if (l.has_pre) c = pre * c; out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++; }
+        const uint32_t texs[2] = {l.r_tex1, l.t_tex1};
+        for (int f = 0; f < 2; f++) if (texs[f] && k < PH_HIT_COLS) {
+            spec c = tex_eval_clamped(dsc, texs[f] - 1u, ctx);
+            if (l.has_pre == PH_PRE_RAW_TEST && c.r == 0.0f && c.g == 0.0f && c.b == 0.0f) out.bumped |= 1u << (8u + k);
+            if (l.has_pre) c = pre * c;
+            out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++;
+        }
     }
 }
 // shade pass: the hit's own lobe list = template lobes with the texture pass's colours filled in, a lobe dropped where the reference would not add it
@@ -483,9 +488,11 @@ PH_DEV uint32_t build_hit_lobes(const LobeRec* tmpl, uint32_t n, const TexOut* i
         LobeRec l = tmpl[i];
         if (l.sigma_tex1) { l.kind = in->lambert ? PH_LK_LAMBERT : PH_LK_OREN; l.a = in->col[0][3]; l.b = in->col[1][3]; }
         if (l.ax_tex1 || l.ay_tex1) { l.ax = in->col[0][3]; l.ay = in->col[1][3]; }
-        if (l.r_tex1 && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; ci++; }
-        if (l.t_tex1 && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; ci++; }
-        if (lobe_keep(l)) out[k++] = l;
+        bool raw_black = false;
+        if (l.r_tex1 && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; raw_black = raw_black || ((in->bumped >> (8u + ci)) & 1u); ci++; }
+        if (l.t_tex1 && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; raw_black = raw_black || ((in->bumped >> (8u + ci)) & 1u); ci++; }
+        // TranslucentMaterial's lobes: the texel decided (an untextured one exists because its constant passed the test when the material was made)
+        if (l.has_pre == PH_PRE_RAW_TEST ? !raw_black : lobe_keep(l)) out[k++] = l;
     }
     return k;
 }

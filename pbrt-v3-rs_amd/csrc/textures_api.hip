@@ -289,13 +289,16 @@ int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param,
     const PbrtHipScene::MaterialParams& mp = s->material_params[material];
     if (mp.lobe[param] < 0)
         return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: this material has no lobe fed by that parameter (matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, "
-                                                   "glass Kr / Kt and uber Kd / Ks / Kr / Kt take textures; create the material with a non-black placeholder for the parameter)");
+                                                   "glass Kr / Kt, uber Kd / Ks / Kr / Kt and translucent Kd / Ks take textures; create the material with a non-black placeholder for the parameter)");
     MaterialRec& m = s->materials[material];
-    LobeRec& l = s->lobes[m.lobe_base + (uint32_t)mp.lobe[param]];
-    if (mp.field[param] == 0) l.r_tex1 = texture + 1u; else l.t_tex1 = texture + 1u;
-    if (mp.has_pre) { l.has_pre = 1u; std::memcpy(l.pre, mp.pre, 12); }
+    const int fed[2] = {mp.lobe[param], mp.lobe2[param]}, fields[2] = {mp.field[param], mp.field2[param]};
+    for (int k = 0; k < 2; k++) if (fed[k] >= 0) {
+        LobeRec& l = s->lobes[m.lobe_base + (uint32_t)fed[k]];
+        if (fields[k] == 0) l.r_tex1 = texture + 1u; else l.t_tex1 = texture + 1u;
+        if (mp.has_pre) { l.has_pre = 1u; std::memcpy(l.pre, mp.pre, 12); }
+        if ((l.kind == PH_LK_LAMBERT || l.kind == PH_LK_OREN) && m.n_lobes == 1u && l.has_pre == 0u) m.kd_tex1 = texture + 1u;  // MatteMaterial: the one-lobe kernel reads kd_tex1
+    }
     m.textured = 1u;
-    if (l.kind == PH_LK_LAMBERT || l.kind == PH_LK_OREN) { if (m.n_lobes == 1u) m.kd_tex1 = texture + 1u; }  // MatteMaterial: the one-lobe kernel reads kd_tex1
     s->textured_materials = true;
     s->uploaded = false;
     return PBRT_HIP_OK;
@@ -312,9 +315,9 @@ int pbrt_hip_set_material_float_texture(PbrtHipScene* s, uint32_t material, int 
             return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_float_texture: sigma belongs to MatteMaterial (created with a non-black Kd)");
         s->lobes[m.lobe_base].sigma_tex1 = texture + 1u; m.sigma_tex1 = texture + 1u;
     } else {
-        if (mp.rough_lobe < 0) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_float_texture: this material has no microfacet lobe whose roughness could be textured (plastic, uber, substrate and metal have; glass switches lobes on roughness == 0 and is not wired)");
-        LobeRec& l = s->lobes[m.lobe_base + (uint32_t)mp.rough_lobe];
-        (fparam == 1 ? l.ax_tex1 : l.ay_tex1) = texture + 1u; l.remap = mp.rough_remap ? 1u : 0u;
+        if (mp.rough_lobe < 0) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_float_texture: this material has no microfacet lobe whose roughness could be textured (plastic, uber, substrate, translucent and metal have; glass switches lobes on roughness == 0 and is not wired)");
+        const int rl[2] = {mp.rough_lobe, mp.rough_lobe2};
+        for (int k = 0; k < 2; k++) if (rl[k] >= 0) { LobeRec& l = s->lobes[m.lobe_base + (uint32_t)rl[k]]; (fparam == 1 ? l.ax_tex1 : l.ay_tex1) = texture + 1u; l.remap = mp.rough_remap ? 1u : 0u; }
     }
     m.textured = 1u;
     s->textured_materials = true;

@@ -463,9 +463,9 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
                 // a texture the library evaluates per hit: the material is created with a white placeholder and the texture attached afterwards
                 const int param = pname == "Kd" ? 0 : (pname == "Ks" ? 1 : (pname == "Kr" ? 2 : (pname == "Kt" ? 3 : -1)));
                 const bool takes = (m.type == "matte" && param == 0) || ((m.type == "plastic" || m.type == "substrate") && (param == 0 || param == 1)) || (m.type == "mirror" && param == 2) ||
-                                   (m.type == "glass" && (param == 2 || param == 3)) || (m.type == "uber" && param >= 0);
+                                   (m.type == "glass" && (param == 2 || param == 3)) || (m.type == "uber" && param >= 0) || (m.type == "translucent" && (param == 0 || param == 1));
                 if (!takes || dt->second.is_float) {
-                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit textures are wired to matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, glass Kr / Kt and uber Kd / Ks / Kr / Kt so far";
+                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit textures are wired to matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, glass Kr / Kt, uber Kd / Ks / Kr / Kt and translucent Kd / Ks so far";
                     return m.params.find_one_rgb(pname, d);
                 }
                 tex_param[param] = (int64_t)dt->second.id;
@@ -485,11 +485,11 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
         if (!tn.empty()) {
             auto dtf = gs_.device_textures.find(tn);
             if (dtf != gs_.device_textures.end()) {
-                // a float texture the library evaluates per hit: sigma (matte) or the microfacet roughness (plastic, uber, substrate, metal)
+                // a float texture the library evaluates per hit: sigma (matte) or the microfacet roughness (plastic, uber, substrate, metal, translucent)
                 const int fp = pname == "sigma" ? 0 : ((pname == "uroughness" || pname == "roughness") ? 1 : (pname == "vroughness" ? 2 : -1));
-                const bool takes = dtf->second.is_float && ((m.type == "matte" && fp == 0) || ((m.type == "plastic" || m.type == "uber" || m.type == "substrate" || m.type == "metal") && fp > 0));
+                const bool takes = dtf->second.is_float && ((m.type == "matte" && fp == 0) || ((m.type == "plastic" || m.type == "uber" || m.type == "substrate" || m.type == "metal" || m.type == "translucent") && fp > 0));
                 if (!takes) {
-                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit float textures are wired to matte sigma and to the roughness of plastic / uber / substrate / metal so far";
+                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit float textures are wired to matte sigma and to the roughness of plastic / uber / substrate / metal / translucent so far";
                     return m.params.find_one_float(pname, d);
                 }
                 if (pname == "roughness") { if (ftex_param[1] < 0) ftex_param[1] = (int64_t)dtf->second.id; if (ftex_param[2] < 0) ftex_param[2] = (int64_t)dtf->second.id; }

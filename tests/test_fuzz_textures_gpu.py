@@ -83,7 +83,7 @@ def random_mask(s, host, rng):
 def textured_material(s, host, rng):
     one = (1, 1, 1)
     c = lambda lo=0.0, hi=1.0: tuple(rng.uniform(lo, hi, 3))
-    k = int(rng.integers(0, 7))
+    k = int(rng.integers(0, 9))
     tex = lambda: random_texture(s, host, rng, False)
     ftex = lambda scale: s.add_texture_scale(random_texture(s, host, rng, True), s.add_texture_constant(float(scale)))
     if k == 0:
@@ -110,6 +110,30 @@ def textured_material(s, host, rng):
         for prm in ("Kd", "Ks", "Kr", "Kt"):
             if rng.integers(0, 2): s.set_material_texture(m, prm, tex())
         if rng.integers(0, 3) == 0: s.set_material_float_texture(m, "uroughness", ftex(0.4))
+    elif k == 6 or k == 7:
+        def leaf(rough_ok):
+            refl, trans = c(), c()
+            if rng.integers(0, 4) == 0: refl = (0.0, 0.0, 0.0)
+            elif rng.integers(0, 4) == 0: trans = (0.0, 0.0, 0.0)
+            if rng.integers(0, 4) == 0: refl = (refl[0], 0.0, 0.0)          # products with black channels
+            t = s.add_material_translucent(one, one if rng.integers(0, 2) else (0.0, 0.0, 0.0), refl, trans, float(rng.uniform(0.02, 0.4)), bool(rng.integers(0, 2)))
+            s.set_material_texture(t, "Kd", tex())
+            try:
+                if rng.integers(0, 2): s.set_material_texture(t, "Ks", tex())
+            except (pbrt_hip.PbrtHipError, RuntimeError) as e:
+                if "live values" in str(e): raise                           # else: Ks was black, no lobe to feed -- refused identically by both libraries
+            if rough_ok and rng.integers(0, 3) == 0:
+                try: s.set_material_float_texture(t, "roughness", ftex(0.5))
+                except (pbrt_hip.PbrtHipError, RuntimeError) as e:
+                    if "live values" in str(e): raise
+            return t
+        if k == 6:
+            m = leaf(True)
+        else:                                # MixMaterial over textured sub-materials (never bumped: mix.rs has no bump map)
+            a = s.add_material_plastic(one, c(0.05, 0.5), float(rng.uniform(0.01, 0.4)), bool(rng.integers(0, 2))); s.set_material_texture(a, "Kd", tex())
+            if rng.integers(0, 3) == 0: s.set_material_float_texture(a, "roughness", ftex(0.5))
+            b = leaf(False) if rng.integers(0, 2) else s.add_material_matte_tex(tex(), float(rng.choice([0.0, rng.uniform(1, 60)])))
+            return s.add_material_mix(a, b, c())
     else:
         m = F.random_material(s, rng)       # a constant material, possibly only bumped
         if rng.integers(0, 2) == 0: return m

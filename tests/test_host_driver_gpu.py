@@ -368,6 +368,12 @@ TransformBegin
 TransformEnd
 Material "matte" "texture Kd" "cells"
 Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [2 -4 0.005  4 -4 0.005  4 -2 0.005  2 -2 0.005]
+Material "translucent" "texture Kd" "wood" "rgb Ks" [0.1 0.1 0.1] "rgb reflect" [0.4 0.4 0.4] "rgb transmit" [0.6 0.6 0.6] "texture roughness" "amt"
+Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-1.8 -2.5 0.3  -0.8 -2.5 0.3  -1.3 -2.5 1.3] "float uv" [0 0 1 0 0.5 1]
+MakeNamedMaterial "m1" "string type" "plastic" "texture Kd" "wood" "rgb Ks" [0.2 0.2 0.2]
+MakeNamedMaterial "m2" "string type" "matte" "texture Kd" "spots"
+Material "mix" "string namedmaterial1" "m1" "string namedmaterial2" "m2" "rgb amount" [0.3 0.3 0.3]
+Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0.8 -2.5 0.3  1.8 -2.5 0.3  1.3 -2.5 1.3] "float uv" [0 0 1 0 0.5 1]
 WorldEnd
 """
     (tmp_path / "tex.pbrt").write_text(text)
@@ -406,6 +412,12 @@ WorldEnd
         stone = s.add_texture_marble(ctm, 0.5, 6, 2.0, 0.3)
         cells = s.add_texture_checkerboard3d(stone, s.add_texture_constant((0.05, 0.3, 0.05)), ctm)
         s.add_mesh(np.array([[2, -4, 0.005], [4, -4, 0.005], [4, -2, 0.005], [2, -2, 0.005]], np.float32), [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(cells, 0.0))
+        leaf = s.add_material_translucent((1, 1, 1), (0.1, 0.1, 0.1), (0.4, 0.4, 0.4), (0.6, 0.6, 0.6), 0.1, True)
+        s.set_material_texture(leaf, "Kd", wood); s.set_material_float_texture(leaf, "roughness", amt)
+        s.add_mesh(np.array([[-1.8, -2.5, 0.3], [-0.8, -2.5, 0.3], [-1.3, -2.5, 1.3]], np.float32), [0, 1, 2], leaf, UV=tri_uv)
+        m1 = s.add_material_plastic((1, 1, 1), (0.2, 0.2, 0.2), 0.1, True); s.set_material_texture(m1, "Kd", wood)
+        m2 = s.add_material_matte_tex(spots, 0.0)
+        s.add_mesh(np.array([[0.8, -2.5, 0.3], [1.8, -2.5, 0.3], [1.3, -2.5, 1.3]], np.float32), [0, 1, 2], s.add_material_mix(m1, m2, (0.3, 0.3, 0.3)), UV=tri_uv)
         w2c, c2w = host.look_at((0, -6, 1.5), (0, 0, 0.5), (0, 0, 1))
         s.set_camera_perspective(host.perspective_raster_to_camera(40.0, res, res), c2w)
         cb, table, sb = host.film_box(res, res)

@@ -195,7 +195,42 @@ def _metal_rough(sc, tex):
     sc.set_material_float_texture(m, "roughness", _fimg(sc, 0.005, 0.3)); return m
 
 
+def _translucent(kd=True, ks=True, rough=False, reflect=(0.5, 0.4, 0.6), transmit=(0.4, 0.5, 0.3)):
+    def make(sc, tex):
+        m = sc.add_material_translucent((1, 1, 1) if kd else (0.3, 0.2, 0.1), (1, 1, 1) if ks else (0.2, 0.2, 0.2), reflect, transmit, 0.1, True)
+        if kd: sc.set_material_texture(m, "Kd", tex)
+        if ks: sc.set_material_texture(m, "Ks", sc.add_texture_scale(tex, sc.add_texture_constant((0.5, 0.5, 0.5))))
+        if rough: sc.set_material_float_texture(m, "roughness", _fimg(sc, 0.02, 0.4))
+        return m
+    return make
+
+
+def _translucent_black_product(sc, tex):
+    # Kd has no red, reflect is red only: r * kd is black wherever kd is not, and the reference still adds that (black) Lambertian lobe
+    m = sc.add_material_translucent((1, 1, 1), (0.2, 0.2, 0.2), (0.8, 0, 0), (0.5, 0.5, 0.5), 0.1, True)
+    sc.set_material_texture(m, "Kd", sc.add_texture_scale(tex, sc.add_texture_constant((0.0, 1.0, 1.0))))
+    return m
+
+
+def _mix_textured(second):
+    def make(sc, tex):
+        a = _plastic()(sc, tex)
+        b = second(sc, sc.add_texture_scale(tex, sc.add_texture_constant((0.9, 0.6, 0.3))))
+        return sc.add_material_mix(a, b, (0.3, 0.5, 0.7))
+    return make
+
+
+def _matte_tex(sc, tex):
+    return sc.add_material_matte_tex(tex, 25.0)
+
+
 MATERIAL_CASES = {
+    "translucent_kd_ks_with_black_texels": (_translucent(), _tex(kind="checker", w=8, h=8)),            # all four lobes vanish on the black squares
+    "translucent_kd_only_rough_texture": (_translucent(ks=False, rough=True), _tex()),
+    "translucent_ks_only_reflect_only": (_translucent(kd=False, transmit=(0, 0, 0)), _tex(w=20, h=20)),
+    "translucent_black_product_keeps_the_lobe": (_translucent_black_product, _tex(kind="checker", w=8, h=8)),
+    "mix_of_textured_plastic_and_matte": (_mix_textured(_matte_tex), _tex(kind="checker", w=8, h=8)),
+    "mix_of_textured_plastic_and_translucent": (_mix_textured(_translucent(ks=False)), _tex()),
     "matte_sigma_texture": (_matte_sigma, _tex()),
     "plastic_roughness_remapped": (_plastic_rough(True), _tex()),
     "plastic_roughness_raw": (_plastic_rough(False), _tex()),
@@ -241,8 +276,14 @@ def test_set_material_texture_errors():
     with pytest.raises(pbrt_hip.PbrtHipError, match="non-black placeholder"):
         s.set_material_texture(black, "Kd", t)
     pl = s.add_material_plastic((1, 1, 1), (0.2, 0.2, 0.2), 0.1, True); s.set_material_texture(pl, "Kd", t)
-    with pytest.raises(pbrt_hip.PbrtHipError, match="mix of materials with per-hit textures"):
-        s.add_material_mix(pl, glass, (0.5, 0.5, 0.5))
+    s.add_material_mix(pl, glass, (0.5, 0.5, 0.5))                            # textured sub-materials mix
+    bumpy = s.add_material_matte((0.5, 0.5, 0.5), 0.0); s.set_material_bump(bumpy, s.add_texture_constant(0.1))
+    with pytest.raises(pbrt_hip.PbrtHipError, match="bumps the interaction in turn"):
+        s.add_material_mix(pl, bumpy, (0.5, 0.5, 0.5))
+    r1 = s.add_material_plastic((0.5, 0.5, 0.5), (0.2, 0.2, 0.2), 0.1, True); s.set_material_float_texture(r1, "roughness", s.add_texture_constant(0.2))
+    r2 = s.add_material_plastic((0.5, 0.5, 0.5), (0.2, 0.2, 0.2), 0.1, True); s.set_material_float_texture(r2, "roughness", s.add_texture_constant(0.3))
+    with pytest.raises(pbrt_hip.PbrtHipError, match="one textured roughness"):
+        s.add_material_mix(r1, r2, (0.5, 0.5, 0.5))
     with pytest.raises(pbrt_hip.PbrtHipError):
         s.set_material_texture(pl, "Kd", 999)
 
