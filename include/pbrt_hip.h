@@ -223,6 +223,10 @@ int pbrt_hip_add_light_diffuse_area(PbrtHipScene*, const float L_rgb[3], int two
 /* PerspectiveCamera (cameras/src/perspective_camera.rs:47-95): the two transforms the ray generator uses. */
 int pbrt_hip_set_camera_perspective(PbrtHipScene*, const float raster_to_camera[16], const float camera_to_world[16],
                                     float lens_radius, float focal_distance, float shutter_open, float shutter_close);
+/* OrthographicCamera (cameras/src/orthographic_camera.rs:39-72, :121-178): same two transforms (raster_to_camera from Transform::orthographic(0, 1):
+ * pbrt_hip_host_orthographic_raster_to_camera); rays leave the film point along camera +z, the lens model and the ray differentials are the reference's. */
+int pbrt_hip_set_camera_orthographic(PbrtHipScene*, const float raster_to_camera[16], const float camera_to_world[16],
+                                     float lens_radius, float focal_distance, float shutter_open, float shutter_close);
 
 /* Film (core/src/film/mod.rs:89-146).  cropped_pixel_bounds = {x0,y0,x1,y1}.  filter_table = the 16x16 table of
  * Film::new (:117-129).  max_sample_luminance: INFINITY for none. */

@@ -30,6 +30,8 @@ int pbrt_hip_host_look_at(const float pos[3], const float look[3], const float u
 void pbrt_hip_host_screen_window(int xres, int yres, float out_screen[4]);
 /* PerspectiveCamera::new + ProjectiveCameraData::new (perspective_camera.rs:47-66, core/src/camera.rs:276-306) */
 void pbrt_hip_host_perspective_raster_to_camera(float fov_deg, int xres, int yres, const float screen[4], float out_m[16]);
+/* OrthographicCamera::new + ProjectiveCameraData::new (orthographic_camera.rs:39-56, transform.rs:222-225, core/src/camera.rs:276-306) */
+void pbrt_hip_host_orthographic_raster_to_camera(int xres, int yres, const float screen[4], float out_m[16]);
 /* Film::new with a BoxFilter + Film::get_sample_bounds (core/src/film/mod.rs:89-159, filters/src/boxf.rs) */
 void pbrt_hip_host_film_box(int xres, int yres, const float crop_window[4], const float radius[2], int out_cropped_bounds[4],
                             float out_table[256], int out_sample_bounds[4]);

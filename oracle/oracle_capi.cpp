@@ -306,7 +306,17 @@ int oracle_set_camera_perspective(OracleScene* s, const float r2c[16], const flo
     const Transform& rc = s->r.cam.raster_to_camera;  // perspective_camera.rs:70-74
     s->r.cam.dx_camera = rc.point(V3(1, 0, 0)) - rc.point(V3(0, 0, 0));
     s->r.cam.dy_camera = rc.point(V3(0, 1, 0)) - rc.point(V3(0, 0, 0));
+    s->r.cam.kind = 0;
     s->have_camera = true; return 0;
+}
+int oracle_set_camera_orthographic(OracleScene* s, const float r2c[16], const float c2w[16], float lens_radius, float focal_distance,
+                                   float shutter_open, float shutter_close) {  // OrthographicCamera::new (orthographic_camera.rs:39-72)
+    const int rc_ = oracle_set_camera_perspective(s, r2c, c2w, lens_radius, focal_distance, shutter_open, shutter_close);
+    if (rc_) return rc_;
+    const Transform& rc = s->r.cam.raster_to_camera;
+    s->r.cam.dx_camera = rc.vector(V3(1, 0, 0)); s->r.cam.dy_camera = rc.vector(V3(0, 1, 0));   // :58-64: transform_vector, not a difference of points
+    s->r.cam.kind = 1;
+    return 0;
 }
 
 // ---- textures (oracle_texture.hpp).  One id space for float and spectrum textures; float ones carry three equal channels.
@@ -754,6 +764,14 @@ void oracle_perspective_raster_to_camera(float fov, int xres, int yres, const fl
                     t_translate(V3(-screen[0], -screen[3], 0.0f));
     Transform r2s = s2r.inv();
     Transform r2c = c2s.inv() * r2s;
+    std::memcpy(out_m, r2c.m.m, 64);
+}
+// raster_to_camera for an orthographic camera: Transform::orthographic(0, 1) (orthographic_camera.rs:50-56, transform.rs:222-225)
+void oracle_orthographic_raster_to_camera(int xres, int yres, const float screen[4], float out_m[16]) {
+    Transform c2s = t_scale(1.0f, 1.0f, 1.0f / (1.0f - 0.0f)) * t_translate(V3(0.0f, 0.0f, -0.0f));
+    Transform s2r = t_scale((Float)xres, (Float)yres, 1.0f) * t_scale(1.0f / (screen[1] - screen[0]), 1.0f / (screen[2] - screen[3]), 1.0f) *
+                    t_translate(V3(-screen[0], -screen[3], 0.0f));
+    Transform r2c = c2s.inv() * s2r.inv();
     std::memcpy(out_m, r2c.m.m, 64);
 }
 void oracle_transform_compose(int kind, const float* p, float out_m[16], float out_minv[16]) {  // 0 translate 1 scale 2 rotate(deg,axis)

@@ -373,7 +373,8 @@ struct RayRecorder {  // optional capture of every ray handed to Scene::intersec
     void add(std::vector<Ray>& v, const Ray& r) { std::lock_guard<std::mutex> g(mu); if (v.size() < cap) v.push_back(r); }
 };
 
-struct Camera {  // cameras/src/perspective_camera.rs
+struct Camera {  // cameras/src/perspective_camera.rs, orthographic_camera.rs
+    int kind = 0;  // 0 perspective, 1 orthographic
     Transform raster_to_camera, camera_to_world;
     Float lens_radius = 0, focal_distance = 1e6f, shutter_open = 0, shutter_close = 1;
     V3 dx_camera, dy_camera;  // perspective_camera.rs:70-74, set with the camera
@@ -1202,7 +1203,40 @@ struct Renderer {
     }
 
     // ---- camera (perspective_camera.rs:144-204 + Transform::transform_ray transform.rs:451-476) ---------------------
+    // OrthographicCamera::generate_ray_differential (orthographic_camera.rs:121-178): parallel rays from the film point; with a lens both offset
+    // rays aim at their own focus points, whose distance `ft` uses the main ray's direction AFTER the lens moved it (:157)
+    Ray generate_ray_orthographic(V2 p_film, Float time_s, V2 p_lens_s) const {
+        V3 p_camera = cam.raster_to_camera.point(V3(p_film.x, p_film.y, 0.0f));
+        Ray ray(p_camera, V3(0, 0, 1), INF, lerp(time_s, cam.shutter_open, cam.shutter_close));
+        V3 rx_o, ry_o, rx_d, ry_d;
+        if (cam.lens_radius > 0.0f) {
+            V2 cd = concentric_sample_disk(p_lens_s);
+            V2 p_lens(cam.lens_radius * cd.x, cam.lens_radius * cd.y);
+            Float ft = cam.focal_distance / ray.d.z;
+            V3 p_focus = ray.o + ray.d * ft;
+            ray.o = V3(p_lens.x, p_lens.y, 0.0f);
+            ray.d = normalize(p_focus - ray.o);
+            ft = cam.focal_distance / ray.d.z;
+            p_focus = (p_camera + cam.dx_camera) + (ft * V3(0, 0, 1));
+            rx_o = V3(p_lens.x, p_lens.y, 0.0f); rx_d = normalize(p_focus - rx_o);
+            p_focus = (p_camera + cam.dy_camera) + (ft * V3(0, 0, 1));
+            ry_o = V3(p_lens.x, p_lens.y, 0.0f); ry_d = normalize(p_focus - ry_o);
+        } else {
+            rx_o = ray.o + cam.dx_camera; ry_o = ray.o + cam.dy_camera;
+            rx_d = ray.d; ry_d = ray.d;
+        }
+        V3 o_err; V3 o = cam.camera_to_world.point_with_error(ray.o, o_err);
+        V3 d = cam.camera_to_world.vector(ray.d);
+        Float l2 = length_squared(d), t_max = ray.t_max;
+        if (l2 > 0.0f) { Float dt = dot(vabs(d), o_err) / l2; o = o + d * dt; t_max -= dt; }  // quirk B2
+        Ray out(o, d, t_max, ray.time);
+        out.has_diff = true;
+        out.rx_o = cam.camera_to_world.point(rx_o); out.ry_o = cam.camera_to_world.point(ry_o);
+        out.rx_d = cam.camera_to_world.vector(rx_d); out.ry_d = cam.camera_to_world.vector(ry_d);
+        return out;
+    }
     Ray generate_ray(V2 p_film, Float time_s, V2 p_lens_s) const {
+        if (cam.kind == 1) return generate_ray_orthographic(p_film, time_s, p_lens_s);
         V3 p_camera = cam.raster_to_camera.point(V3(p_film.x, p_film.y, 0.0f));
         Ray ray(V3(0, 0, 0), normalize(p_camera), INF, lerp(time_s, cam.shutter_open, cam.shutter_close));
         if (cam.lens_radius > 0.0f) {

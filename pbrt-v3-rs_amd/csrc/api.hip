@@ -801,7 +801,22 @@ int pbrt_hip_set_camera_perspective(PbrtHipScene* s, const float r2c[16], const 
         pt(0.0f, 0.0f, p0); pt(1.0f, 0.0f, px); pt(0.0f, 1.0f, py);
         for (int k = 0; k < 3; k++) { s->cam.dx_camera[k] = px[k] - p0[k]; s->cam.dy_camera[k] = py[k] - p0[k]; }
     }
+    s->cam.kind = PH_CAM_PERSPECTIVE;
     s->have_camera = true;
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_set_camera_orthographic(PbrtHipScene* s, const float r2c[16], const float c2w[16], float lens_radius, float focal_distance,
+                                     float shutter_open, float shutter_close) {  // OrthographicCamera::new (orthographic_camera.rs:39-72)
+    const int rc = pbrt_hip_set_camera_perspective(s, r2c, c2w, lens_radius, focal_distance, shutter_open, shutter_close);
+    if (rc != PBRT_HIP_OK) return rc;
+    // dx_camera / dy_camera (:58-64): raster_to_camera.transform_vector((1,0,0)) / ((0,1,0)) (transform.rs:373-380)
+    const float* m = r2c;
+    const float vx[3] = {1.0f, 0.0f, 0.0f}, vy[3] = {0.0f, 1.0f, 0.0f};
+    for (int k = 0; k < 3; k++) {
+        s->cam.dx_camera[k] = m[4 * k] * vx[0] + m[4 * k + 1] * vx[1] + m[4 * k + 2] * vx[2];
+        s->cam.dy_camera[k] = m[4 * k] * vy[0] + m[4 * k + 1] * vy[1] + m[4 * k + 2] * vy[2];
+    }
+    s->cam.kind = PH_CAM_ORTHOGRAPHIC;
     return PBRT_HIP_OK;
 }
 

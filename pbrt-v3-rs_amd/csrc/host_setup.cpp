@@ -91,6 +91,18 @@ void pbrt_hip_host_perspective_raster_to_camera(float fov_deg, int xres, int yre
     out16(xf_mul(c2s_inv, r2s).m, out_m);
 }
 
+// raster_to_camera of an OrthographicCamera: Transform::orthographic(0, 1) = scale(1, 1, 1 / (far - near)) * translate(0, 0, -near)
+// (orthographic_camera.rs:50-56, transform.rs:222-225) through the same ProjectiveCameraData::new
+void pbrt_hip_host_orthographic_raster_to_camera(int xres, int yres, const float screen[4], float out_m[16]) {
+    const float z_near = 0.0f, z_far = 1.0f;
+    Xf c2s = xf_mul(xf_scale(1.0f, 1.0f, 1.0f / (z_far - z_near)), xf_translate(0.0f, 0.0f, -z_near));
+    Xf s2r = xf_mul(xf_mul(xf_scale((float)xres, (float)yres, 1.0f), xf_scale(1.0f / (screen[1] - screen[0]), 1.0f / (screen[2] - screen[3]), 1.0f)),
+                    xf_translate(-screen[0], -screen[3], 0.0f));
+    Xf r2s{s2r.mi, s2r.m};
+    Xf c2s_inv{c2s.mi, c2s.m};
+    out16(xf_mul(c2s_inv, r2s).m, out_m);
+}
+
 // Film::new crop bounds (film/mod.rs:101-111), the 16x16 filter table (:113-129) for a BOX filter
 // (filters/src/boxf.rs:31-47: evaluate == 1) and Film::get_sample_bounds (:150-159).
 void pbrt_hip_host_film_box(int xres, int yres, const float crop_window[4] /*x0 x1 y0 y1*/, const float radius[2], int out_cropped_bounds[4],

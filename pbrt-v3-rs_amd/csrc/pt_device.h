@@ -187,9 +187,9 @@ PH_DEV uint32_t find_interval_cdf(const float* cdf, uint32_t size, float u) {
 }
 
 // =============================== camera ============================================================================
-// PerspectiveCamera::generate_ray_differential's main ray (cameras/src/perspective_camera.rs:144-171) followed by
+// PerspectiveCamera / OrthographicCamera::generate_ray_differential's main ray (cameras/src/perspective_camera.rs:144-171, orthographic_camera.rs:121-149) followed by
 // Transform::transform_ray (core/src/geometry/transform.rs:451-476, incl. quirk B2 t_max -= dt).  Differentials are
-// consumed only by textures and every texture on this path is constant, so they are not generated.
+// consumed only by textures: the texture pass rebuilds them at a camera ray's first hit (texture.h: camera_ray_differentials).
 PH_DEV void generate_camera_ray(const CameraRec& cam, f2 p_film, float time_s, f2 lens_s, RayIn& out) {
     const float* m = cam.r2c;
     float xp = m[0] * p_film.x + m[1] * p_film.y + m[2] * 0.0f + m[3];
@@ -198,6 +198,7 @@ PH_DEV void generate_camera_ray(const CameraRec& cam, f2 p_film, float time_s, f
     float wp = m[12] * p_film.x + m[13] * p_film.y + m[14] * 0.0f + m[15];
     f3 p_camera = (wp == 1.0f) ? mk3(xp, yp, zp) : mk3(xp, yp, zp) / wp;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = normalize(p_camera);
+    if (cam.kind == PH_CAM_ORTHOGRAPHIC) { o = p_camera; d = mk3(0.0f, 0.0f, 1.0f); }  // orthographic_camera.rs:127-135: parallel rays from the film point
     const float time = (1.0f - time_s) * cam.shutter_open + time_s * cam.shutter_close;  // lerp (pbrt/common.rs:166-175)
     if (cam.lens_radius > 0.0f) {
         f2 cd = concentric_sample_disk(lens_s);

@@ -308,7 +308,23 @@ PH_DEV RayDiff camera_ray_differentials(const CameraRec& cam, f2 p_film, f2 lens
     const f3 p_camera = xf_point_plain(cam.r2c, mk3(p_film.x, p_film.y, 0.0f));
     const f3 dxc = mk3(cam.dx_camera[0], cam.dx_camera[1], cam.dx_camera[2]), dyc = mk3(cam.dy_camera[0], cam.dy_camera[1], cam.dy_camera[2]);
     f3 rx_o, ry_o, rx_d, ry_d;
-    if (cam.lens_radius > 0.0f) {
+    if (cam.kind == PH_CAM_ORTHOGRAPHIC) {  // orthographic_camera.rs:151-174
+        if (cam.lens_radius > 0.0f) {
+            const f2 cd = concentric_sample_disk(lens_s);
+            const f2 p_lens = mk2(cam.lens_radius * cd.x, cam.lens_radius * cd.y);
+            // the main ray once more (:137-149): `ft` below divides by ITS direction's z, after the lens moved it (:157)
+            const f3 z1 = mk3(0.0f, 0.0f, 1.0f);
+            float ft = ph_div(cam.focal_distance, z1.z);
+            const f3 o_lens = mk3(p_lens.x, p_lens.y, 0.0f);
+            const f3 d_main = normalize((p_camera + z1 * ft) - o_lens);
+            ft = ph_div(cam.focal_distance, d_main.z);
+            rx_o = o_lens; rx_d = normalize(((p_camera + dxc) + (ft * z1)) - rx_o);
+            ry_o = o_lens; ry_d = normalize(((p_camera + dyc) + (ft * z1)) - ry_o);
+        } else {
+            rx_o = p_camera + dxc; ry_o = p_camera + dyc;
+            rx_d = mk3(0.0f, 0.0f, 1.0f); ry_d = rx_d;
+        }
+    } else if (cam.lens_radius > 0.0f) {
         const f2 cd = concentric_sample_disk(lens_s);
         const f2 p_lens = mk2(cam.lens_radius * cd.x, cam.lens_radius * cd.y);
         const f3 dx = normalize(p_camera + dxc);

@@ -81,6 +81,7 @@ class Binding:
             "add_light_spot": (C.c_int, [vp, fp, fp, fp, C.c_float, C.c_float]),
             "add_light_diffuse_area": (C.c_int, [vp, fp, C.c_int, C.c_uint32, u32p]),
             "set_camera_perspective": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]),
+            "set_camera_orthographic": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]),
             "set_film": (C.c_int, [vp, C.c_int, C.c_int, ip, fp, fp, C.c_float, C.c_float]),
             "set_sampler": (C.c_int, [vp, C.c_int, C.c_uint32, ip, C.c_int]),
             "set_sobol_tables": (C.c_int, [vp, u32p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t]),
@@ -175,6 +176,7 @@ class Host:
         L.pbrt_hip_host_gen_random_tris.argtypes = [C.c_uint64, C.c_uint64, fp, C.POINTER(C.c_uint32)]
         L.pbrt_hip_host_rotate.argtypes = [C.c_float, fp, fp, fp]
         L.pbrt_hip_host_perspective_raster_to_camera.argtypes = [C.c_float, C.c_int, C.c_int, fp, fp]
+        L.pbrt_hip_host_orthographic_raster_to_camera.argtypes = [C.c_int, C.c_int, fp, fp]
         L.pbrt_hip_host_transform_points.argtypes = [fp, fp, fp, C.c_size_t]
         L.pbrt_hip_host_transform_vectors.argtypes = [fp, fp, fp, C.c_size_t]
         L.pbrt_hip_host_transform_normals.argtypes = [fp, fp, fp, C.c_size_t]
@@ -226,6 +228,13 @@ class Host:
             screen = self.screen_window(xres, yres)
         m = self._m()
         self.lib.pbrt_hip_host_perspective_raster_to_camera(C.c_float(fov), xres, yres, _ptr(_f32(screen), C.c_float), _ptr(m, C.c_float))
+        return m
+
+    def orthographic_raster_to_camera(self, xres, yres, screen=None):
+        if screen is None:
+            screen = self.screen_window(xres, yres)
+        m = self._m()
+        self.lib.pbrt_hip_host_orthographic_raster_to_camera(xres, yres, _ptr(_f32(screen), C.c_float), _ptr(m, C.c_float))
         return m
 
     def film_box(self, xres, yres, crop_window=(0.0, 1.0, 0.0, 1.0), radius=(0.5, 0.5)):
@@ -426,6 +435,10 @@ class Scene:
     def set_camera_perspective(self, raster_to_camera, camera_to_world, lens_radius=0.0, focal_distance=1e6, shutter_open=0.0, shutter_close=1.0):
         self._chk(self.b.fn("set_camera_perspective")(self.h, _ptr(_f32(raster_to_camera), C.c_float), _ptr(_f32(camera_to_world), C.c_float),
                                                       C.c_float(lens_radius), C.c_float(focal_distance), C.c_float(shutter_open), C.c_float(shutter_close)))
+
+    def set_camera_orthographic(self, raster_to_camera, camera_to_world, lens_radius=0.0, focal_distance=1e6, shutter_open=0.0, shutter_close=1.0):
+        self._chk(self.b.fn("set_camera_orthographic")(self.h, _ptr(_f32(raster_to_camera), C.c_float), _ptr(_f32(camera_to_world), C.c_float),
+                                                       C.c_float(lens_radius), C.c_float(focal_distance), C.c_float(shutter_open), C.c_float(shutter_close)))
 
     def set_film(self, xres, yres, cropped_bounds, radius, table, scale=1.0, max_sample_luminance=float("inf")):
         cb = np.ascontiguousarray(cropped_bounds, dtype=np.int32)

@@ -69,6 +69,12 @@ def test_look_at_and_perspective_match_oracle(host):
         o = _m16()
         ol.oracle_perspective_raster_to_camera(C.c_float(fov), xr, yr, sw.ctypes.data_as(fp), o.ctypes.data_as(fp))
         assert np.array_equal(r2c.view(np.uint32), o.view(np.uint32))
+        r2c = host.orthographic_raster_to_camera(xr, yr, sw)
+        ol.oracle_orthographic_raster_to_camera(xr, yr, sw.ctypes.data_as(fp), o.ctypes.data_as(fp))
+        assert np.array_equal(r2c.view(np.uint32), o.view(np.uint32))
+        # closed form: raster (0, 0) is the window's top-left corner, one pixel spans window / resolution (orthographic_camera.rs:50-64)
+        assert np.allclose(r2c.reshape(4, 4) @ np.array([0, 0, 0, 1.0]), [sw[0], sw[3], 0, 1], atol=1e-6)
+        assert np.allclose(r2c.reshape(4, 4)[:3, 0], [(sw[1] - sw[0]) / xr, 0, 0], atol=1e-7)
     with pytest.raises(pbrt_hip.PbrtHipError):
         host.look_at([0, 0, 0], [0, 0, 1], [0, 0, 2])  # up parallel to the view direction: the reference panics
 

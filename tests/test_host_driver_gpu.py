@@ -441,6 +441,51 @@ WorldEnd
         assert (s.film_to_rgb(xyz, wt).reshape(res, res, 3).view(np.uint32) == ref.view(np.uint32)).all()
 
 
+def test_orthographic_camera_in_a_scene_file(tmp_path, host):
+    """Camera "orthographic" with a screen window, a lens and a textured floor (orthographic_camera.rs:188-244): image equal to the oracle's bit for bit."""
+    res, spp, depth = (40, 30), 4, 3
+    Q = np.array([[-3, -3, 0], [3, -3, 0], [3, 3, 0], [-3, 3, 0]], np.float32)
+    UVQ = np.array([[0, 0], [2, 0], [2, 2], [0, 2]], np.float32)
+    text = f"""LookAt 2 -5 3  0 0 0.3  0 0 1
+Camera "orthographic" "float screenwindow" [-2 2 -1.5 1.5] "float lensradius" 0.03 "float focaldistance" 6
+Film "image" "integer xresolution" [{res[0]}] "integer yresolution" [{res[1]}] "string filename" "ortho.pfm"
+Sampler "halton" "integer pixelsamples" {spp}
+PixelFilter "box"
+Integrator "path" "integer maxdepth" {depth} "string lightsamplestrategy" "uniform"
+WorldBegin
+LightSource "infinite" "rgb L" [0.9 0.9 1.0]
+Texture "checks" "color" "checkerboard" "float uscale" 4 "float vscale" 4 "rgb tex1" [0.8 0.7 0.2] "rgb tex2" [0.1 0.1 0.3]
+Material "matte" "texture Kd" "checks"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [{ds.fl(Q)}] "float uv" [{ds.fl(UVQ)}]
+Material "plastic" "rgb Kd" [0.6 0.2 0.2]
+Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-1 0 0.01  1 0 0.01  0 0.5 1.5]
+WorldEnd
+"""
+    (tmp_path / "ortho.pbrt").write_text(text)
+    r = subprocess.run([ds.RENDER_BIN, "--quiet", str(tmp_path / "ortho.pbrt")], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    img = ds.read_pfm(str(tmp_path / "ortho.pfm"))
+    set_libm_mode(1)
+    try:
+        with OracleScene() as s:
+            s.add_light_infinite((0.9, 0.9, 1.0))
+            checks = s.add_texture_checkerboard(s.add_texture_constant((0.8, 0.7, 0.2)), s.add_texture_constant((0.1, 0.1, 0.3)), su=4.0, sv=4.0)
+            s.add_mesh(Q, [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(checks, 0.0), UV=UVQ)
+            s.add_mesh(np.array([[-1, 0, 0.01], [1, 0, 0.01], [0, 0.5, 1.5]], np.float32), [0, 1, 2], s.add_material_plastic((0.6, 0.2, 0.2), (0.25,) * 3, 0.1, True))
+            w2c, c2w = host.look_at((2, -5, 3), (0, 0, 0.3), (0, 0, 1))
+            s.set_camera_orthographic(host.orthographic_raster_to_camera(res[0], res[1], np.float32([-2, 2, -1.5, 1.5])), c2w, lens_radius=0.03, focal_distance=6.0)
+            cb, table, sb = host.film_box(res[0], res[1])
+            s.set_film(res[0], res[1], cb, (0.5, 0.5), table)
+            s.set_sampler(0, spp, sb)
+            s.build_accel(0, 4)
+            xyz, wt, _ = s.render_path(max_depth=depth, light_strategy=0, pixel_bounds=sb)
+            ref = s.film_to_rgb(xyz, wt).reshape(res[1], res[0], 3)
+    finally:
+        set_libm_mode(0)
+    assert img.shape == ref.shape and float(img.mean()) > 0.05
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), f"{(img != ref).sum()} differing values, max {np.abs(img - ref).max()}"
+
+
 def test_output_formats(tmp_path, host):
     """Film "filename" with .exr / .png / .tga (core/src/image_io.rs:225-237): the EXR holds the PFM's floats, the 8-bit files its gamma-encoded bytes."""
     import image_files as imf

@@ -56,6 +56,38 @@ def test_camera_rays_bit_exact(host):
             assert _bits_equal(np.ascontiguousarray(gr[f]), np.ascontiguousarray(orr[f])), f
 
 
+@pytest.mark.parametrize("lens", [0.0, 0.07])
+def test_orthographic_camera_rays_and_film(host, lens):
+    """OrthographicCamera (cameras/src/orthographic_camera.rs:121-178): rays bit-exact vs the oracle; without a lens they are parallel to the view
+    direction and leave from a regular grid on the film plane (closed form); the film of the C1-style scene equals the oracle's."""
+    spec = pbrt_hip.SceneSpec(n_tris=300, xres=48, yres=40, spp=4)
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    window = np.float32([-1.5, 1.5, -1.25, 1.25])
+    for s in (prod, orc):
+        pbrt_hip.capture_spec(spec, s, host)
+        w2c, c2w = host.look_at(spec.eye, spec.look, spec.up)
+        s.set_camera_orthographic(host.orthographic_raster_to_camera(48, 40, window), c2w, lens_radius=lens, focal_distance=4.0)
+    set_libm_mode(1)
+    try:
+        orr, op = orc.generate_camera_rays([0, 0, 48, 40], 1)
+        o = orc.render_path_ex(max_depth=3)
+    finally:
+        set_libm_mode(0)
+    gr, gp = prod.generate_camera_rays([0, 0, 48, 40], 1)
+    for f in ("o", "d", "t_max", "time"):
+        assert _bits_equal(np.ascontiguousarray(gr[f]), np.ascontiguousarray(orr[f])), f
+    if lens == 0.0:
+        view = np.float32(spec.look) - np.float32(spec.eye); view /= np.linalg.norm(view)
+        assert np.allclose(gr["d"], view[None, :], atol=1e-6)
+        rel = gr["o"].astype(np.float64) - np.float64(spec.eye)
+        assert np.abs(rel @ view.astype(np.float64)).max() < 1e-4                                   # origins lie in the film plane through the eye
+        assert np.abs(np.linalg.norm(rel, axis=1)).max() <= np.hypot(1.5, 1.25) + 1e-4          # ... inside the screen window
+    g = prod.render_path(max_depth=3)
+    assert _bits_equal(g[0], o[0]) and _bits_equal(g[1], o[1])
+    assert (g[2].regular_rays, g[2].shadow_rays, g[2].camera_rays) == (o[2].regular_rays, o[2].shadow_rays, o[2].camera_rays)
+    assert float(g[0].mean()) > 0.0
+
+
 def test_camera_rays_thin_lens(host):
     """lens_radius > 0 goes through concentric_sample_disk (cos/sin): bit-exact against libm mode 1."""
     spec = pbrt_hip.SceneSpec(n_tris=10, xres=64, yres=64, spp=4)

@@ -71,6 +71,8 @@ CASES = {
     "thin_lens": dict(builder=_tex(), lens_radius=0.05),
     "instanced": dict(builder=_tex(kind="ramp"), instance=True),
     "oren_nayar": dict(builder=_tex(), sigma=20.0),
+    "orthographic_camera": dict(builder=_tex(), orthographic=True),                       # differentials = offset origins (orthographic_camera.rs:168-173)
+    "orthographic_camera_thin_lens": dict(builder=_tex(), orthographic=True, lens_radius=0.05),
 }
 
 
