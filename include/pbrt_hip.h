@@ -227,6 +227,9 @@ int pbrt_hip_set_camera_perspective(PbrtHipScene*, const float raster_to_camera[
  * pbrt_hip_host_orthographic_raster_to_camera); rays leave the film point along camera +z, the lens model and the ray differentials are the reference's. */
 int pbrt_hip_set_camera_orthographic(PbrtHipScene*, const float raster_to_camera[16], const float camera_to_world[16],
                                      float lens_radius, float focal_distance, float shutter_open, float shutter_close);
+/* EnvironmentCamera (cameras/src/environment_camera.rs:27-78): directions over the whole sphere from the film position relative to the film's FULL
+ * resolution (pass the same xres / yres as to pbrt_hip_set_film); ray differentials are the Camera trait's finite differences (core/src/camera.rs:29-78). */
+int pbrt_hip_set_camera_environment(PbrtHipScene*, const float camera_to_world[16], int xres, int yres, float shutter_open, float shutter_close);
 
 /* Film (core/src/film/mod.rs:89-146).  cropped_pixel_bounds = {x0,y0,x1,y1}.  filter_table = the 16x16 table of
  * Film::new (:117-129).  max_sample_luminance: INFINITY for none. */

@@ -319,6 +319,16 @@ int oracle_set_camera_orthographic(OracleScene* s, const float r2c[16], const fl
     return 0;
 }
 
+int oracle_set_camera_environment(OracleScene* s, const float c2w[16], int xres, int yres, float shutter_open, float shutter_close) {  // environment_camera.rs:27-41
+    if (!s || !c2w || xres <= 0 || yres <= 0) return -1;
+    s->r.cam = Camera();
+    s->r.cam.camera_to_world = Transform(m4_from(c2w), M4::identity());
+    s->r.cam.shutter_open = shutter_open; s->r.cam.shutter_close = shutter_close;
+    s->r.cam.full_res[0] = (Float)xres; s->r.cam.full_res[1] = (Float)yres;
+    s->r.cam.kind = 2;
+    s->have_camera = true; return 0;
+}
+
 // ---- textures (oracle_texture.hpp).  One id space for float and spectrum textures; float ones carry three equal channels.
 int oracle_add_mipmap(OracleScene* s, int width, int height, const float* rgb, int as_float, float scale, int gamma, int filtering, int wrap,
                       float max_anisotropy, uint32_t* out_id) {

@@ -374,7 +374,8 @@ struct RayRecorder {  // optional capture of every ray handed to Scene::intersec
 };
 
 struct Camera {  // cameras/src/perspective_camera.rs, orthographic_camera.rs
-    int kind = 0;  // 0 perspective, 1 orthographic
+    int kind = 0;  // 0 perspective, 1 orthographic, 2 environment
+    Float full_res[2] = {1, 1};  // EnvironmentCamera reads film.full_resolution (environment_camera.rs:63-64)
     Transform raster_to_camera, camera_to_world;
     Float lens_radius = 0, focal_distance = 1e6f, shutter_open = 0, shutter_close = 1;
     V3 dx_camera, dy_camera;  // perspective_camera.rs:70-74, set with the camera
@@ -1235,8 +1236,33 @@ struct Renderer {
         out.rx_d = cam.camera_to_world.vector(rx_d); out.ry_d = cam.camera_to_world.vector(ry_d);
         return out;
     }
+    // EnvironmentCamera::generate_ray (environment_camera.rs:61-78): the whole sphere of directions, y up in camera space
+    Ray generate_ray_environment_main(V2 p_film, Float time_s) const {
+        Float theta = PI * p_film.y / cam.full_res[1];
+        Float phi = TWO_PI * p_film.x / cam.full_res[0];
+        V3 dir(o_sin(theta) * o_cos(phi), o_cos(theta), o_sin(theta) * o_sin(phi));
+        Ray ray(V3(0, 0, 0), dir, INF, lerp(time_s, cam.shutter_open, cam.shutter_close));
+        V3 o_err; V3 o = cam.camera_to_world.point_with_error(ray.o, o_err);
+        V3 d = cam.camera_to_world.vector(ray.d);
+        Float l2 = length_squared(d), t_max = ray.t_max;
+        if (l2 > 0.0f) { Float dt = dot(vabs(d), o_err) / l2; o = o + d * dt; t_max -= dt; }  // quirk B2
+        return Ray(o, d, t_max, ray.time);
+    }
+    // Camera::generate_ray_differential's default (core/src/camera.rs:29-78): finite differences over a 0.05-pixel shift; every weight is 1, so
+    // only the first eps of each loop is ever used
+    Ray generate_ray_environment(V2 p_film, Float time_s) const {
+        Ray ray = generate_ray_environment_main(p_film, time_s);
+        const Float eps = 0.05f;
+        Ray rx = generate_ray_environment_main(V2(p_film.x + eps, p_film.y), time_s);
+        Ray ry = generate_ray_environment_main(V2(p_film.x, p_film.y + eps), time_s);
+        ray.has_diff = true;
+        ray.rx_o = ray.o + (rx.o - ray.o) / eps; ray.rx_d = ray.d + (rx.d - ray.d) / eps;
+        ray.ry_o = ray.o + (ry.o - ray.o) / eps; ray.ry_d = ray.d + (ry.d - ray.d) / eps;
+        return ray;
+    }
     Ray generate_ray(V2 p_film, Float time_s, V2 p_lens_s) const {
         if (cam.kind == 1) return generate_ray_orthographic(p_film, time_s, p_lens_s);
+        if (cam.kind == 2) return generate_ray_environment(p_film, time_s);
         V3 p_camera = cam.raster_to_camera.point(V3(p_film.x, p_film.y, 0.0f));
         Ray ray(V3(0, 0, 0), normalize(p_camera), INF, lerp(time_s, cam.shutter_open, cam.shutter_close));
         if (cam.lens_radius > 0.0f) {

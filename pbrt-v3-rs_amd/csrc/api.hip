@@ -820,6 +820,19 @@ int pbrt_hip_set_camera_orthographic(PbrtHipScene* s, const float r2c[16], const
     return PBRT_HIP_OK;
 }
 
+int pbrt_hip_set_camera_environment(PbrtHipScene* s, const float c2w[16], int xres, int yres, float shutter_open, float shutter_close) {  // environment_camera.rs:27-41
+    if (!s || !c2w) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_camera_environment: null argument");
+    if (xres <= 0 || yres <= 0) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_camera_environment: the film's full resolution must be positive");
+    s->cam = CameraRec{};
+    for (int k = 0; k < 4; k++) s->cam.r2c[5 * k] = 1.0f;   // unused by this camera; identity keeps the shared prologue of the ray generator finite
+    std::memcpy(s->cam.c2w, c2w, 64);
+    s->cam.focal_distance = 1e6f; s->cam.shutter_open = shutter_open; s->cam.shutter_close = shutter_close;
+    s->cam.full_res[0] = (float)xres; s->cam.full_res[1] = (float)yres;
+    s->cam.kind = PH_CAM_ENVIRONMENT;
+    s->have_camera = true;
+    return PBRT_HIP_OK;
+}
+
 int pbrt_hip_set_film(PbrtHipScene* s, int xres, int yres, const int crop[4], const float radius[2], const float table[256], float scale,
                       float max_lum) {
     if (!s || !crop || !radius || !table) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_film: null argument");

@@ -199,6 +199,11 @@ PH_DEV void generate_camera_ray(const CameraRec& cam, f2 p_film, float time_s, f
     f3 p_camera = (wp == 1.0f) ? mk3(xp, yp, zp) : mk3(xp, yp, zp) / wp;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = normalize(p_camera);
     if (cam.kind == PH_CAM_ORTHOGRAPHIC) { o = p_camera; d = mk3(0.0f, 0.0f, 1.0f); }  // orthographic_camera.rs:127-135: parallel rays from the film point
+    if (cam.kind == PH_CAM_ENVIRONMENT) {   // environment_camera.rs:61-66: the whole sphere of directions, y up in camera space; no lens
+        const float theta = ph_div(kPi * p_film.y, cam.full_res[1]), phi = ph_div(kTwoPi * p_film.x, cam.full_res[0]);
+        const float st = d_sin(theta);
+        d = mk3(st * d_cos(phi), d_cos(theta), st * d_sin(phi));
+    }
     const float time = (1.0f - time_s) * cam.shutter_open + time_s * cam.shutter_close;  // lerp (pbrt/common.rs:166-175)
     if (cam.lens_radius > 0.0f) {
         f2 cd = concentric_sample_disk(lens_s);

@@ -150,13 +150,14 @@ struct LightRec {
     uint32_t dw, dh;     // radiance map: resolution of the scalar image = 2 x the map's
 };
 
-enum { PH_CAM_PERSPECTIVE = 0, PH_CAM_ORTHOGRAPHIC = 1 };
-struct CameraRec {  // cameras/src/perspective_camera.rs, orthographic_camera.rs
+enum { PH_CAM_PERSPECTIVE = 0, PH_CAM_ORTHOGRAPHIC = 1, PH_CAM_ENVIRONMENT = 2 };
+struct CameraRec {  // cameras/src/perspective_camera.rs, orthographic_camera.rs, environment_camera.rs
     float r2c[16];
     float c2w[16];
     float lens_radius, focal_distance, shutter_open, shutter_close;
     float dx_camera[3], dy_camera[3];  // :70-74, for the ray differentials texture filtering needs
     uint32_t kind; float pad[1];
+    float full_res[2];  // EnvironmentCamera: film.full_resolution as floats (environment_camera.rs:63-64)
 };
 
 struct FilmRec {  // core/src/film/mod.rs

@@ -764,7 +764,7 @@ int Api::pbrt_world_end(RenderReport& rep) {
     if (!check(ABI(pbrt_hip_set_film(scene_, xres, yres, cb, rad, table, film_scale, max_lum)), "set_film")) return PBRT_HIP_ERR_INVALID_ARG;
 
     // ---- camera (perspective_camera.rs:358-419, orthographic_camera.rs:188-244: the same parameters minus the field of view)
-    if (camera_name_ != "perspective" && camera_name_ != "orthographic") { error = "Camera \"" + camera_name_ + "\" is outside the hot-path scope (supported: perspective, orthographic)"; return PBRT_HIP_ERR_UNSUPPORTED; }
+    if (camera_name_ != "perspective" && camera_name_ != "orthographic" && camera_name_ != "environment") { error = "Camera \"" + camera_name_ + "\" is outside the hot-path scope (supported: perspective, orthographic, environment)"; return PBRT_HIP_ERR_UNSUPPORTED; }
     float shutter_open = camera_p_.find_one_float("shutteropen", 0.0f), shutter_close = camera_p_.find_one_float("shutterclose", 1.0f);
     if (shutter_close < shutter_open) { warn("Shutter close time < shutter open. Swapping them."); std::swap(shutter_open, shutter_close); }
     const float lens_radius = camera_p_.find_one_float("lensradius", 0.0f), focal_distance = camera_p_.find_one_float("focaldistance", 1e6f);
@@ -780,7 +780,9 @@ int Api::pbrt_world_end(RenderReport& rep) {
     const float half_fov = camera_p_.find_one_float("halffov", -1.0f);
     if (half_fov > 0.0f) fov = 2.0f * half_fov;
     float r2c[16];
-    if (camera_name_ == "orthographic") {
+    if (camera_name_ == "environment") {   // environment_camera.rs:86-104: shutter times only
+        if (!check(ABI(pbrt_hip_set_camera_environment(scene_, camera_to_world_.m, xres, yres, shutter_open, shutter_close)), "set_camera_environment")) return PBRT_HIP_ERR_INVALID_ARG;
+    } else if (camera_name_ == "orthographic") {
         pbrt_hip_host_orthographic_raster_to_camera(xres, yres, screen, r2c);
         if (!check(ABI(pbrt_hip_set_camera_orthographic(scene_, r2c, camera_to_world_.m, lens_radius, focal_distance, shutter_open, shutter_close)), "set_camera_orthographic")) return PBRT_HIP_ERR_INVALID_ARG;
     } else {

@@ -82,6 +82,7 @@ class Binding:
             "add_light_diffuse_area": (C.c_int, [vp, fp, C.c_int, C.c_uint32, u32p]),
             "set_camera_perspective": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]),
             "set_camera_orthographic": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]),
+            "set_camera_environment": (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_float, C.c_float]),
             "set_film": (C.c_int, [vp, C.c_int, C.c_int, ip, fp, fp, C.c_float, C.c_float]),
             "set_sampler": (C.c_int, [vp, C.c_int, C.c_uint32, ip, C.c_int]),
             "set_sobol_tables": (C.c_int, [vp, u32p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t]),
@@ -439,6 +440,9 @@ class Scene:
     def set_camera_orthographic(self, raster_to_camera, camera_to_world, lens_radius=0.0, focal_distance=1e6, shutter_open=0.0, shutter_close=1.0):
         self._chk(self.b.fn("set_camera_orthographic")(self.h, _ptr(_f32(raster_to_camera), C.c_float), _ptr(_f32(camera_to_world), C.c_float),
                                                        C.c_float(lens_radius), C.c_float(focal_distance), C.c_float(shutter_open), C.c_float(shutter_close)))
+
+    def set_camera_environment(self, camera_to_world, xres, yres, shutter_open=0.0, shutter_close=1.0):
+        self._chk(self.b.fn("set_camera_environment")(self.h, _ptr(_f32(camera_to_world), C.c_float), int(xres), int(yres), C.c_float(shutter_open), C.c_float(shutter_close)))
 
     def set_film(self, xres, yres, cropped_bounds, radius, table, scale=1.0, max_sample_luminance=float("inf")):
         cb = np.ascontiguousarray(cropped_bounds, dtype=np.int32)

@@ -57,7 +57,7 @@ def test_check_mode_crop_and_outfile(tmp_path):
     ('WorldBegin\nObjectBegin "a"\nAreaLightSource "diffuse"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nObjectEnd\nWorldEnd\n',
      "AreaLightSource inside ObjectBegin"),
     ('WorldBegin\nLightSource "goniometric"\nWorldEnd\n', 'LightSource "goniometric"'),
-    ('Camera "environment"\nWorldBegin\nWorldEnd\n', 'Camera "environment"'),
+    ('Camera "realistic"\nWorldBegin\nWorldEnd\n', 'Camera "realistic"'),
     ('Integrator "bdpt"\nWorldBegin\nWorldEnd\n', 'Integrator "bdpt"'),
     ('Sampler "random"\nWorldBegin\nWorldEnd\n', 'Sampler "random"'),
     ('WorldBegin\nLightSource "infinite" "string mapname" "sky.jpg"\nWorldEnd\n', "mapname"),

@@ -441,13 +441,17 @@ WorldEnd
         assert (s.film_to_rgb(xyz, wt).reshape(res, res, 3).view(np.uint32) == ref.view(np.uint32)).all()
 
 
-def test_orthographic_camera_in_a_scene_file(tmp_path, host):
-    """Camera "orthographic" with a screen window, a lens and a textured floor (orthographic_camera.rs:188-244): image equal to the oracle's bit for bit."""
+@pytest.mark.parametrize("camera", ["orthographic", "environment"])
+def test_other_cameras_in_a_scene_file(tmp_path, host, camera):
+    """Camera "orthographic" with a screen window and a lens (orthographic_camera.rs:188-244), Camera "environment" (environment_camera.rs:86-104),
+    over a textured floor: image equal to the oracle's bit for bit."""
     res, spp, depth = (40, 30), 4, 3
+    cam_line = 'Camera "orthographic" "float screenwindow" [-2 2 -1.5 1.5] "float lensradius" 0.03 "float focaldistance" 6' if camera == "orthographic" \
+        else 'Camera "environment" "float shutteropen" 0.2 "float shutterclose" 0.1'     # swapped with a warning
     Q = np.array([[-3, -3, 0], [3, -3, 0], [3, 3, 0], [-3, 3, 0]], np.float32)
     UVQ = np.array([[0, 0], [2, 0], [2, 2], [0, 2]], np.float32)
     text = f"""LookAt 2 -5 3  0 0 0.3  0 0 1
-Camera "orthographic" "float screenwindow" [-2 2 -1.5 1.5] "float lensradius" 0.03 "float focaldistance" 6
+{cam_line}
 Film "image" "integer xresolution" [{res[0]}] "integer yresolution" [{res[1]}] "string filename" "ortho.pfm"
 Sampler "halton" "integer pixelsamples" {spp}
 PixelFilter "box"
@@ -473,7 +477,10 @@ WorldEnd
             s.add_mesh(Q, [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(checks, 0.0), UV=UVQ)
             s.add_mesh(np.array([[-1, 0, 0.01], [1, 0, 0.01], [0, 0.5, 1.5]], np.float32), [0, 1, 2], s.add_material_plastic((0.6, 0.2, 0.2), (0.25,) * 3, 0.1, True))
             w2c, c2w = host.look_at((2, -5, 3), (0, 0, 0.3), (0, 0, 1))
-            s.set_camera_orthographic(host.orthographic_raster_to_camera(res[0], res[1], np.float32([-2, 2, -1.5, 1.5])), c2w, lens_radius=0.03, focal_distance=6.0)
+            if camera == "orthographic":
+                s.set_camera_orthographic(host.orthographic_raster_to_camera(res[0], res[1], np.float32([-2, 2, -1.5, 1.5])), c2w, lens_radius=0.03, focal_distance=6.0)
+            else:
+                s.set_camera_environment(c2w, res[0], res[1], shutter_open=0.1, shutter_close=0.2)
             cb, table, sb = host.film_box(res[0], res[1])
             s.set_film(res[0], res[1], cb, (0.5, 0.5), table)
             s.set_sampler(0, spp, sb)

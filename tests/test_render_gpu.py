@@ -88,6 +88,35 @@ def test_orthographic_camera_rays_and_film(host, lens):
     assert float(g[0].mean()) > 0.0
 
 
+def test_environment_camera_rays_and_film(host):
+    """EnvironmentCamera (cameras/src/environment_camera.rs:61-78): rays bit-exact vs the oracle and equal to the closed form
+    (sin t cos p, cos t, sin t sin p), t = pi y / yres, p = 2 pi x / xres, carried to world space; film bit-exact."""
+    spec = pbrt_hip.SceneSpec(n_tris=300, xres=64, yres=32, spp=2)
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    for s in (prod, orc):
+        pbrt_hip.capture_spec(spec, s, host)
+        w2c, c2w = host.look_at((0.1, -0.2, 0.05), spec.look, spec.up)     # inside the cloud of triangles
+        s.set_camera_environment(c2w, 64, 32, shutter_open=0.1, shutter_close=0.6)
+    set_libm_mode(1)
+    try:
+        orr, op = orc.generate_camera_rays([0, 0, 64, 32], 1)
+        o = orc.render_path_ex(max_depth=3)
+    finally:
+        set_libm_mode(0)
+    gr, gp = prod.generate_camera_rays([0, 0, 64, 32], 1)
+    for f in ("o", "d", "t_max", "time"):
+        assert _bits_equal(np.ascontiguousarray(gr[f]), np.ascontiguousarray(orr[f])), f
+    t, ph = np.pi * gp[:, 1].astype(np.float64) / 32.0, 2.0 * np.pi * gp[:, 0].astype(np.float64) / 64.0
+    d_cam = np.stack([np.sin(t) * np.cos(ph), np.cos(t), np.sin(t) * np.sin(ph)], axis=1)
+    M = np.asarray(c2w, np.float64).reshape(4, 4)[:3, :3]
+    assert np.abs(gr["d"] - d_cam @ M.T).max() < 1e-5
+    assert 0.1 <= gr["time"].min() and gr["time"].max() <= 0.6
+    g = prod.render_path(max_depth=3)
+    assert _bits_equal(g[0], o[0]) and _bits_equal(g[1], o[1])
+    assert (g[2].regular_rays, g[2].shadow_rays, g[2].camera_rays) == (o[2].regular_rays, o[2].shadow_rays, o[2].camera_rays)
+    assert float(g[0].mean()) > 0.0
+
+
 def test_camera_rays_thin_lens(host):
     """lens_radius > 0 goes through concentric_sample_disk (cos/sin): bit-exact against libm mode 1."""
     spec = pbrt_hip.SceneSpec(n_tris=10, xres=64, yres=64, spp=4)

@@ -73,6 +73,7 @@ CASES = {
     "oren_nayar": dict(builder=_tex(), sigma=20.0),
     "orthographic_camera": dict(builder=_tex(), orthographic=True),                       # differentials = offset origins (orthographic_camera.rs:168-173)
     "orthographic_camera_thin_lens": dict(builder=_tex(), orthographic=True, lens_radius=0.05),
+    "environment_camera": dict(builder=_tex(), environment=True),                           # finite-difference differentials (core/src/camera.rs:29-78)
 }
 
 

@@ -32,7 +32,7 @@ def probe_points(n, seed):
     return uv, d
 
 
-def textured_quad_scene(scene, host, tex_builder, res=64, spp=4, sigma=0.0, lens_radius=0.0, tilt=True, instance=False, extra=None, material=None, orthographic=False):
+def textured_quad_scene(scene, host, tex_builder, res=64, spp=4, sigma=0.0, lens_radius=0.0, tilt=True, instance=False, extra=None, material=None, orthographic=False, environment=False):
     """A ground quad with UVs tiled 3 x 3 under a matte material whose Kd is the texture `tex_builder(scene)` returns, seen at a
     grazing angle (strongly anisotropic footprints near the horizon) and lit by a white environment; a small mirror-free matte
     block above it gives the bounce rays something to shadow.  instance=True places the quad through an ObjectInstance.
@@ -56,6 +56,13 @@ def textured_quad_scene(scene, host, tex_builder, res=64, spp=4, sigma=0.0, lens
     scene.add_light_infinite((1.0, 1.0, 1.0))
     eye = (0.0, -6.0, 1.2 if tilt else 6.0)
     w2c, c2w = host.look_at(eye, (0, 0, 0.2), (0, 0, 1))
+    if environment:    # EnvironmentCamera a little above the floor: most of the lower hemisphere sees the texture at every footprint size
+        scene.set_camera_environment(host.look_at((0.3, -1.0, 0.8), (0, 0, 0.2), (0, 0, 1))[1], res, res)
+        cb, table, sb = host.film_box(res, res)
+        scene.set_film(res, res, cb, (0.5, 0.5), table)
+        scene.set_sampler(0, spp, sb)
+        scene.build_accel(0, 4)
+        return
     if orthographic:   # OrthographicCamera over a 5 x 5 window
         r2c = host.orthographic_raster_to_camera(res, res, np.float32([-2.5, 2.5, -2.5, 2.5]))
         scene.set_camera_orthographic(r2c, c2w, lens_radius=lens_radius, focal_distance=6.0 if lens_radius > 0 else 1e6)
