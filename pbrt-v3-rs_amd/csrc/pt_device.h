@@ -190,6 +190,13 @@ PH_DEV uint32_t find_interval_cdf(const float* cdf, uint32_t size, float u) {
 // PerspectiveCamera / OrthographicCamera::generate_ray_differential's main ray (cameras/src/perspective_camera.rs:144-171, orthographic_camera.rs:121-149) followed by
 // Transform::transform_ray (core/src/geometry/transform.rs:451-476, incl. quirk B2 t_max -= dt).  Differentials are
 // consumed only by textures: the texture pass rebuilds them at a camera ray's first hit (texture.h: camera_ray_differentials).
+// EnvironmentCamera's direction (environment_camera.rs:61-66): the whole sphere, y up in camera space.  Out of line: four f64 trigonometric
+// evaluations that the projective cameras' ray generators should not carry inline
+__device__ __noinline__ void environment_camera_dir(float px, float py, float xres, float yres, f3* out) {
+    const float theta = ph_div(kPi * py, yres), phi = ph_div(kTwoPi * px, xres);
+    const float st = d_sin(theta);
+    *out = mk3(st * d_cos(phi), d_cos(theta), st * d_sin(phi));
+}
 PH_DEV void generate_camera_ray(const CameraRec& cam, f2 p_film, float time_s, f2 lens_s, RayIn& out) {
     const float* m = cam.r2c;
     float xp = m[0] * p_film.x + m[1] * p_film.y + m[2] * 0.0f + m[3];
@@ -199,11 +206,7 @@ PH_DEV void generate_camera_ray(const CameraRec& cam, f2 p_film, float time_s, f
     f3 p_camera = (wp == 1.0f) ? mk3(xp, yp, zp) : mk3(xp, yp, zp) / wp;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = normalize(p_camera);
     if (cam.kind == PH_CAM_ORTHOGRAPHIC) { o = p_camera; d = mk3(0.0f, 0.0f, 1.0f); }  // orthographic_camera.rs:127-135: parallel rays from the film point
-    if (cam.kind == PH_CAM_ENVIRONMENT) {   // environment_camera.rs:61-66: the whole sphere of directions, y up in camera space; no lens
-        const float theta = ph_div(kPi * p_film.y, cam.full_res[1]), phi = ph_div(kTwoPi * p_film.x, cam.full_res[0]);
-        const float st = d_sin(theta);
-        d = mk3(st * d_cos(phi), d_cos(theta), st * d_sin(phi));
-    }
+    if (cam.kind == PH_CAM_ENVIRONMENT) environment_camera_dir(p_film.x, p_film.y, cam.full_res[0], cam.full_res[1], &d);   // no lens
     const float time = (1.0f - time_s) * cam.shutter_open + time_s * cam.shutter_close;  // lerp (pbrt/common.rs:166-175)
     if (cam.lens_radius > 0.0f) {
         f2 cd = concentric_sample_disk(lens_s);

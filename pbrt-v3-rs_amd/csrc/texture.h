@@ -304,24 +304,26 @@ PH_DEV f3 xf_point_plain(const float* m, f3 p) {  // Transform::transform_point 
     const float w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
     return (w == 1.0f) ? mk3(x, y, z) : mk3(x, y, z) / w;
 }
+// Camera::generate_ray_differential's default (core/src/camera.rs:29-78), used by EnvironmentCamera: finite differences of WORLD-space rays over a
+// 0.05-pixel shift (every weight is 1: only the first eps of each loop is used); `Vector3 / eps` multiplies by the reciprocal.  Out of line, arguments by pointer.
+__device__ __noinline__ void environment_camera_differentials(const CameraRec* cam, f2 p_film, const f3* o_world_p, const f3* d_world_p, uint32_t spp, RayDiff* out) {
+    const f3 o_world = *o_world_p, d_world = *d_world_p;
+    const float eps = 0.05f, inv = ph_div(1.0f, eps);
+    RayIn rx, ry;
+    generate_camera_ray(*cam, mk2(p_film.x + eps, p_film.y), 0.0f, mk2(0.0f, 0.0f), rx);
+    generate_camera_ray(*cam, mk2(p_film.x, p_film.y + eps), 0.0f, mk2(0.0f, 0.0f), ry);
+    RayDiff r;
+    r.rx_o = o_world + (mk3(rx.ox, rx.oy, rx.oz) - o_world) * inv; r.rx_d = d_world + (mk3(rx.dx, rx.dy, rx.dz) - d_world) * inv;
+    r.ry_o = o_world + (mk3(ry.ox, ry.oy, ry.oz) - o_world) * inv; r.ry_d = d_world + (mk3(ry.dx, ry.dy, ry.dz) - d_world) * inv;
+    const float sc = ph_div(1.0f, ph_sqrt((float)spp));
+    r.rx_o = o_world + (r.rx_o - o_world) * sc; r.ry_o = o_world + (r.ry_o - o_world) * sc;
+    r.rx_d = d_world + (r.rx_d - d_world) * sc; r.ry_d = d_world + (r.ry_d - d_world) * sc;
+    *out = r;
+}
 PH_DEV RayDiff camera_ray_differentials(const CameraRec& cam, f2 p_film, f2 lens_s, f3 o_world, f3 d_world, uint32_t spp) {
     const f3 p_camera = xf_point_plain(cam.r2c, mk3(p_film.x, p_film.y, 0.0f));
     const f3 dxc = mk3(cam.dx_camera[0], cam.dx_camera[1], cam.dx_camera[2]), dyc = mk3(cam.dy_camera[0], cam.dy_camera[1], cam.dy_camera[2]);
-    if (cam.kind == PH_CAM_ENVIRONMENT) {
-        // Camera::generate_ray_differential's default (core/src/camera.rs:29-78): finite differences of WORLD-space rays over a 0.05-pixel shift
-        // (every weight is 1: only the first eps of each loop is used); `Vector3 / eps` multiplies by the reciprocal
-        const float eps = 0.05f, inv = ph_div(1.0f, eps);
-        RayIn rx, ry;
-        generate_camera_ray(cam, mk2(p_film.x + eps, p_film.y), 0.0f, lens_s, rx);
-        generate_camera_ray(cam, mk2(p_film.x, p_film.y + eps), 0.0f, lens_s, ry);
-        RayDiff r;
-        r.rx_o = o_world + (mk3(rx.ox, rx.oy, rx.oz) - o_world) * inv; r.rx_d = d_world + (mk3(rx.dx, rx.dy, rx.dz) - d_world) * inv;
-        r.ry_o = o_world + (mk3(ry.ox, ry.oy, ry.oz) - o_world) * inv; r.ry_d = d_world + (mk3(ry.dx, ry.dy, ry.dz) - d_world) * inv;
-        const float sc = ph_div(1.0f, ph_sqrt((float)spp));
-        r.rx_o = o_world + (r.rx_o - o_world) * sc; r.ry_o = o_world + (r.ry_o - o_world) * sc;
-        r.rx_d = d_world + (r.rx_d - d_world) * sc; r.ry_d = d_world + (r.ry_d - d_world) * sc;
-        return r;
-    }
+    if (cam.kind == PH_CAM_ENVIRONMENT) { RayDiff r; environment_camera_differentials(&cam, p_film, &o_world, &d_world, spp, &r); return r; }
     f3 rx_o, ry_o, rx_d, ry_d;
     if (cam.kind == PH_CAM_ORTHOGRAPHIC) {  // orthographic_camera.rs:151-174
         if (cam.lens_radius > 0.0f) {
