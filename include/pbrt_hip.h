@@ -213,6 +213,13 @@ int pbrt_hip_add_light_infinite(PbrtHipScene*, const float L_rgb[3], const float
  * the library multiplies them by L, builds the MIPMap (EWA, repeat; no y flip on this path, as in the reference) and the Distribution2D of the 2w x 2h
  * scalar image (compute_scalar_image, :326-369).  Le / sample_li / pdf_li / power then follow :127-211. */
 int pbrt_hip_add_light_infinite_map(PbrtHipScene*, const float L[3], int width, int height, const float* rgb, const float light_to_world[16], const float world_to_light[16]);
+/* ProjectionLight (lights/src/projection.rs:55-127, :145-203) and GonioPhotometricLight (goniometric.rs:34-126): point lights whose intensity is scaled by an
+ * image looked up by direction (MIPMap::new(.., Ewa, Repeat, 8.0), lookup_triangle(st, 0)).  rgb = width x height x 3 floats, top row first, or NULL for "no image"
+ * (white inside the frustum / in every direction); I = intensity * scale; light_to_world / world_to_light as for the spot light. */
+int pbrt_hip_add_light_projection(PbrtHipScene*, const float I_rgb[3], const float light_to_world[16], const float world_to_light[16], float fov_deg,
+                                  int width, int height, const float* rgb);
+int pbrt_hip_add_light_goniometric(PbrtHipScene*, const float I_rgb[3], const float light_to_world[16], const float world_to_light[16],
+                                   int width, int height, const float* rgb);
 int pbrt_hip_add_light_distant(PbrtHipScene*, const float L_rgb[3], const float w_light_world[3]); /* distant.rs:36-50: already transformed+normalized */
 int pbrt_hip_add_light_point(PbrtHipScene*, const float I_rgb[3], const float p_world[3]);         /* point.rs:36-55 */
 int pbrt_hip_add_light_spot(PbrtHipScene*, const float I_rgb[3], const float light_to_world[16], const float world_to_light[16],

@@ -235,6 +235,42 @@ int oracle_add_light_infinite(OracleScene* s, const float L[3], const float l2w[
     return 0;
 }
 // InfiniteAreaLight::new with a texmap (lights/src/infinite.rs:52-100): texels = image * L (no y flip here), MIPMap (EWA, repeat, 8), scalar image, Distribution2D
+namespace {
+int image_light_mipmap(OracleScene* s, int width, int height, const float* rgb) {   // MIPMap::new(.., Ewa, Repeat, 8.0) (projection.rs:70-80, goniometric.rs:49-58)
+    if (!rgb) return -1;
+    std::vector<Spec> tex((size_t)width * height);
+    for (size_t i = 0; i < tex.size(); i++) tex[i] = Spec(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+    MipMap m; m.filtering = TEX_FILTER_EWA; m.wrap = TEX_WRAP_REPEAT; m.max_anisotropy = 8.0f; m.is_float = false;
+    m.build_from(tex, (size_t)width, (size_t)height);
+    for (int i = 0; i < WEIGHT_LUT_SIZE; i++) { Float r2 = (Float)i / (Float)(WEIGHT_LUT_SIZE - 1); m.weight_lut[i] = std::exp(-2.0f * r2) - std::exp(-2.0f); }
+    s->sc.mipmaps.push_back(std::move(m));
+    return (int)s->sc.mipmaps.size() - 1;
+}
+}  // namespace
+// ProjectionLight::new (projection.rs:55-127); rgb may be null (no image: the light projects white inside its frustum, aspect 1)
+int oracle_add_light_projection(OracleScene* s, const float I[3], const float l2w[16], const float w2l[16], float fov, int width, int height, const float* rgb) {
+    if (!s || !I || !l2w || !w2l || (rgb && (width <= 0 || height <= 0))) return -1;
+    Light l{}; l.type = L_PROJECTION; l.L = spec3(I); l.l2w = Transform(m4_from(l2w), m4_from(w2l)); l.prim = 0xFFFFFFFFu;
+    l.p_light = l.l2w.point(V3(0, 0, 0));
+    l.map_mip = image_light_mipmap(s, width, height, rgb);
+    const Float aspect = rgb ? (Float)width / (Float)height : 1.0f;
+    if (aspect > 1.0f) { l.screen[0] = -aspect; l.screen[1] = aspect; l.screen[2] = -1.0f; l.screen[3] = 1.0f; }
+    else { l.screen[0] = -1.0f; l.screen[1] = 1.0f; l.screen[2] = -1.0f / aspect; l.screen[3] = 1.0f / aspect; }
+    l.light_projection = t_perspective(fov, 1e-3f, 1e30f);
+    V3 wc = normalize(l.light_projection.inv().point(V3(l.screen[1], l.screen[3], 0.0f)));
+    l.cos_total_width = wc.z;
+    s->sc.lights.push_back(l);
+    return 0;
+}
+// GonioPhotometricLight::new (goniometric.rs:34-80)
+int oracle_add_light_goniometric(OracleScene* s, const float I[3], const float l2w[16], const float w2l[16], int width, int height, const float* rgb) {
+    if (!s || !I || !l2w || !w2l || (rgb && (width <= 0 || height <= 0))) return -1;
+    Light l{}; l.type = L_GONIO; l.L = spec3(I); l.l2w = Transform(m4_from(l2w), m4_from(w2l)); l.prim = 0xFFFFFFFFu;
+    l.p_light = l.l2w.point(V3(0, 0, 0));
+    l.map_mip = image_light_mipmap(s, width, height, rgb);
+    s->sc.lights.push_back(l);
+    return 0;
+}
 int oracle_add_light_infinite_map(OracleScene* s, const float L[3], int width, int height, const float* rgb, const float l2w[16], const float w2l[16]) {
     if (!s || !L || !rgb || !l2w || !w2l || width <= 0 || height <= 0) return -1;
     Light l{}; l.type = L_INFINITE; l.L = spec3(L); l.l2w = Transform(m4_from(l2w), m4_from(w2l)); l.two_sided = 0; l.prim = 0xFFFFFFFFu; l.area = 0;

@@ -542,6 +542,33 @@ struct Renderer {
             else { Float delta = (cos_theta - l.cos_total_width) / (l.cos_falloff_start - l.cos_total_width); fall = (delta * delta) * (delta * delta); }
             r.value = l.L * fall / distance_squared(l.p_light, hit.p); r.valid = true; return r;
         }
+        case L_PROJECTION: {   // projection.rs:180-191 + projection() :145-168
+            r.wi = normalize(l.p_light - hit.p); r.pdf = 1.0f; r.vp = l.p_light;
+            const Float near_z = 1e-3f;
+            Spec pr(0.0f);
+            V3 wl = l.l2w.inv().vector(-r.wi);
+            if (!(wl.z < near_z)) {
+                V3 pp = l.light_projection.point(wl);
+                if (pp.x >= l.screen[0] && pp.x <= l.screen[1] && pp.y >= l.screen[2] && pp.y <= l.screen[3]) {
+                    if (l.map_mip < 0) pr = Spec(1.0f);
+                    else {
+                        Float ox = pp.x - l.screen[0], oy = pp.y - l.screen[2];      // Bounds2::offset (bounds2.rs:161-173)
+                        if (l.screen[1] > l.screen[0]) ox /= l.screen[1] - l.screen[0];
+                        if (l.screen[3] > l.screen[2]) oy /= l.screen[3] - l.screen[2];
+                        pr = sc->mipmaps[(size_t)l.map_mip].triangle(0, V2(ox, oy));
+                    }
+                }
+            }
+            r.value = l.L * pr / distance_squared(l.p_light, hit.p); r.valid = true; return r;
+        }
+        case L_GONIO: {        // goniometric.rs:102-113 + scale() :82-96
+            r.wi = normalize(l.p_light - hit.p); r.pdf = 1.0f; r.vp = l.p_light;
+            V3 wp = normalize(l.l2w.inv().vector(-r.wi));
+            { Float t = wp.y; wp.y = wp.z; wp.z = t; }
+            Float theta = spherical_theta(wp), phi = spherical_phi(wp);
+            Spec scl = l.map_mip < 0 ? Spec(1.0f) : sc->mipmaps[(size_t)l.map_mip].triangle(0, V2(phi * INV_TWO_PI, theta * INV_PI));
+            r.value = l.L * scl / distance_squared(l.p_light, hit.p); r.valid = true; return r;
+        }
         case L_POINT:    // point.rs:83-93
             r.wi = normalize(l.p_light - hit.p); r.pdf = 1.0f; r.vp = l.p_light;
             r.value = l.L / distance_squared(l.p_light, hit.p); r.valid = true; return r;
@@ -608,6 +635,14 @@ struct Renderer {
         case L_DISTANT: return l.L * PI * s.world_radius * s.world_radius;                                      // distant.rs:98-101
         case L_SPOT: return l.L * TWO_PI * (1.0f - 0.5f * (l.cos_falloff_start + l.cos_total_width));                    // spot.rs:86-88
         case L_POINT: return (4.0f * PI) * l.L;                                                                 // point.rs:95-97
+        case L_PROJECTION: {   // projection.rs:193-203
+            Spec sp = l.map_mip < 0 ? Spec(1.0f) : s.mipmaps[(size_t)l.map_mip].lookup_triangle_host(V2(0.5f, 0.5f), 0.5f);
+            return sp * l.L * TWO_PI * (1.0f - l.cos_total_width);
+        }
+        case L_GONIO: {        // goniometric.rs:115-126
+            Spec sp = l.map_mip < 0 ? Spec(1.0f) : s.mipmaps[(size_t)l.map_mip].lookup_triangle_host(V2(0.5f, 0.5f), 0.5f);
+            return (4.0f * PI) * l.L * sp;
+        }
         default: return (l.two_sided ? 2.0f : 1.0f) * l.L * l.area * PI;                                        // diffuse.rs:131-134
         }
     }
@@ -1099,7 +1134,7 @@ struct Renderer {
         Float scattering_pdf = 0.0f;
         LiSample ls = light_sample_li(light, hit, u_light);
         V3 wi = ls.valid ? ls.wi : V3(); Float light_pdf = ls.valid ? ls.pdf : 0.0f; Spec li = ls.valid ? ls.value : Spec(0.0f);
-        bool is_delta = light.type == L_DISTANT || light.type == L_POINT || light.type == L_SPOT;
+        bool is_delta = light.type == L_DISTANT || light.type == L_POINT || light.type == L_SPOT || light.type == L_PROJECTION || light.type == L_GONIO;
         if (light_pdf > 0.0f && !li.is_black()) {
             Spec f = bsdf.f(hit.wo, wi, BX_ALL & ~BX_SPEC) * abs_dot(wi, hit.ns);  // bsdf_flags: specular = false (common.rs:157-161)
             scattering_pdf = bsdf.pdf(hit.wo, wi, BX_ALL & ~BX_SPEC);

@@ -55,7 +55,7 @@ struct Material {
     bool has_pre = false; Spec pre;
 };
 
-enum LightType { L_INFINITE = 0, L_DISTANT = 1, L_POINT = 2, L_AREA = 3, L_SPOT = 4 };
+enum LightType { L_INFINITE = 0, L_DISTANT = 1, L_POINT = 2, L_AREA = 3, L_SPOT = 4, L_PROJECTION = 5, L_GONIO = 6 };
 struct Light {
     int type;
     Spec L;             // infinite: lrgb; distant: emitted radiance; point: intensity; area: l_emit
@@ -71,6 +71,8 @@ struct Light {
     Float marg_func[2], marg_cdf[3], marg_int;
     // infinite with a radiance map (mapname): the MIPMap (scene.mipmaps[map_mip], built unflipped) and the Distribution2D over its 2w x 2h scalar image
     int map_mip = -1; int dw = 0, dh = 0;
+    // projection (lights/src/projection.rs): light_projection, screen_bounds {xmin, xmax, ymin, ymax}; cos_total_width above; map_mip = its image (or -1).  goniometric: map_mip only
+    Transform light_projection; Float screen[4] = {0, 0, 0, 0};
     std::vector<Float> d_cond_func, d_cond_cdf, d_cond_int, d_marg_func, d_marg_cdf; Float d_marg_int = 0;
 };
 

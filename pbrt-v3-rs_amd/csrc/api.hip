@@ -82,7 +82,7 @@ int upload_scene(PbrtHipScene* s) {
     if ((rc = upload_vec(s, s->meshes, &d.meshes))) return rc;
     if ((rc = upload_vec(s, s->materials, &d.materials))) return rc;
     if ((rc = upload_vec(s, s->lobes, &d.lobes))) return rc;
-    if (!s->textures.empty()) {
+    if (!s->textures.empty() || !s->mipmaps.empty()) {   // MIPMaps also belong to lights (radiance map, projection image, goniometric diagram)
         std::vector<TexRec> recs; std::vector<TexOp> ops;
         for (const PbrtHipScene::TextureHost& t : s->textures) {
             recs.push_back(TexRec{(uint32_t)ops.size(), (uint32_t)t.prog.size()});
@@ -151,6 +151,12 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
                 }
                 case PH_L_DISTANT: p[c] = l.L[c] * hm::kPi * wr * wr; break;                       // distant.rs:98-101
                 case PH_L_POINT: p[c] = (hm::kPi * 4.0f) * l.L[c]; break;                          // point.rs:95-97
+                case PH_L_PROJECTION: case PH_L_GONIO: {   // projection.rs:193-203: spectrum * I * TWO_PI * (1 - cos_total_width); goniometric.rs:115-126: FOUR_PI * I * spectrum
+                    float t[3] = {1.0f, 1.0f, 1.0f};
+                    if (l.map_mip1) hmip_lookup_triangle(s, s->mipmaps[l.map_mip1 - 1u], 0.5f, 0.5f, 0.5f, t);
+                    p[c] = l.type == PH_L_PROJECTION ? t[c] * l.L[c] * (2.0f * hm::kPi) * (1.0f - l.cos_total_width) : (hm::kPi * 4.0f) * l.L[c] * t[c];
+                    break;
+                }
                 case PH_L_SPOT: p[c] = l.L[c] * (2.0f * hm::kPi) * (1.0f - 0.5f * (l.cos_falloff_start + l.cos_total_width)); break;  // spot.rs:86-88
                 default: p[c] = (l.two_sided ? 2.0f : 1.0f) * l.L[c] * l.area * hm::kPi; break;    // diffuse.rs:131-134
                 }

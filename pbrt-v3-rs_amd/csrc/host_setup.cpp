@@ -103,6 +103,29 @@ void pbrt_hip_host_orthographic_raster_to_camera(int xres, int yres, const float
     out16(xf_mul(c2s_inv, r2s).m, out_m);
 }
 
+// ProjectionLight::new (lights/src/projection.rs:95-111): screen bounds from the image's aspect ratio, light_projection = Transform::perspective(fov, 1e-3, 1e30)
+// and the cosine of the frustum's corner direction.  Internal to the library (scene_host.h), used by pbrt_hip_add_light_projection.
+extern "C++" {
+namespace phost {
+void projection_light_setup(float fov_deg, float aspect, float out_proj[16], float out_screen[4], float* out_cos_total_width) {
+    if (aspect > 1.0f) { out_screen[0] = -aspect; out_screen[1] = aspect; out_screen[2] = -1.0f; out_screen[3] = 1.0f; }
+    else { out_screen[0] = -1.0f; out_screen[1] = 1.0f; out_screen[2] = -1.0f / aspect; out_screen[3] = 1.0f / aspect; }
+    const float n = 1e-3f, f = 1e30f;
+    M4 persp = rows(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, f / (f - n), -f * n / (f - n), 0, 0, 1, 0);
+    float inv_tan_ang = 1.0f / std::tan(to_radians(fov_deg) / 2.0f);
+    Xf proj = xf_mul(xf_scale(inv_tan_ang, inv_tan_ang, 1.0f), Xf{persp, m4_inverse(persp)});
+    out16(proj.m, out_proj);
+    const float* m = &proj.mi.m[0][0];
+    const float x = out_screen[1], y = out_screen[3], z = 0.0f;   // p_corner; Transform::transform_point (transform.rs:288-302)
+    const float xp = m[0] * x + m[1] * y + m[2] * z + m[3], yp = m[4] * x + m[5] * y + m[6] * z + m[7];
+    const float zp = m[8] * x + m[9] * y + m[10] * z + m[11], wp = m[12] * x + m[13] * y + m[14] * z + m[15];
+    V3 c{xp, yp, zp};
+    if (wp != 1.0f) { const float inv = 1.0f / wp; c = V3{inv * xp, inv * yp, inv * zp}; }
+    *out_cos_total_width = normalize(c).z;
+}
+}  // namespace phost
+}  // extern "C++"
+
 // Film::new crop bounds (film/mod.rs:101-111), the 16x16 filter table (:113-129) for a BOX filter
 // (filters/src/boxf.rs:31-47: evaluate == 1) and Film::get_sample_bounds (:150-159).
 void pbrt_hip_host_film_box(int xres, int yres, const float crop_window[4] /*x0 x1 y0 y1*/, const float radius[2], int out_cropped_bounds[4],

@@ -538,6 +538,35 @@ template <bool MAP = true> PH_DEV LiSample light_sample_li(const DeviceScene& sc
         else if (cos_theta >= l.cos_falloff_start) fall = 1.0f;
         else { const float delta = ph_div(cos_theta - l.cos_total_width, l.cos_falloff_start - l.cos_total_width); fall = (delta * delta) * (delta * delta); }
         r.value = mks(l.L[0], l.L[1], l.L[2]) * fall / distance_squared(pl, hit.p); r.valid = true;
+    } else if (l.type == PH_L_PROJECTION) {  // projection.rs:180-191, projection() :145-168
+        f3 pl = mk3(l.v[0], l.v[1], l.v[2]);
+        r.wi = normalize(pl - hit.p); r.pdf = 1.0f; r.vp = pl;
+        spec pr = mks1(0.0f);
+        const f3 wl = xf_vec(l.w2l, -r.wi);
+        if (!(wl.z < 1e-3f)) {
+            const float* m = l.proj;   // Transform::transform_point (transform.rs:288-302)
+            const float xp = m[0] * wl.x + m[1] * wl.y + m[2] * wl.z + m[3], yp = m[4] * wl.x + m[5] * wl.y + m[6] * wl.z + m[7];
+            const float zp = m[8] * wl.x + m[9] * wl.y + m[10] * wl.z + m[11], wp = m[12] * wl.x + m[13] * wl.y + m[14] * wl.z + m[15];
+            const f3 pp = (wp == 1.0f) ? mk3(xp, yp, zp) : mk3(xp, yp, zp) / wp;
+            if (pp.x >= l.screen[0] && pp.x <= l.screen[1] && pp.y >= l.screen[2] && pp.y <= l.screen[3]) {
+                if (!(MAP && l.map_mip1)) pr = mks1(1.0f);
+                else {
+                    float ox = pp.x - l.screen[0], oy = pp.y - l.screen[2];   // Bounds2::offset (bounds2.rs:161-173)
+                    if (l.screen[1] > l.screen[0]) ox = ph_div(ox, l.screen[1] - l.screen[0]);
+                    if (l.screen[3] > l.screen[2]) oy = ph_div(oy, l.screen[3] - l.screen[2]);
+                    pr = envmap_lookup(sc.self, l.map_mip1 - 1u, ox, oy);
+                }
+            }
+        }
+        r.value = mks(l.L[0], l.L[1], l.L[2]) * pr / distance_squared(pl, hit.p); r.valid = true;
+    } else if (l.type == PH_L_GONIO) {  // goniometric.rs:102-113, scale() :82-96
+        f3 pl = mk3(l.v[0], l.v[1], l.v[2]);
+        r.wi = normalize(pl - hit.p); r.pdf = 1.0f; r.vp = pl;
+        f3 wp = normalize(xf_vec(l.w2l, -r.wi));
+        { const float t = wp.y; wp.y = wp.z; wp.z = t; }
+        const float theta = spherical_theta(wp), phi = spherical_phi(wp);
+        const spec scl = (MAP && l.map_mip1) ? envmap_lookup(sc.self, l.map_mip1 - 1u, phi * kInvTwoPi, theta * kInvPi) : mks1(1.0f);
+        r.value = mks(l.L[0], l.L[1], l.L[2]) * scl / distance_squared(pl, hit.p); r.valid = true;
     } else if (l.type == PH_L_POINT) {  // point.rs:83-93
         f3 pl = mk3(l.v[0], l.v[1], l.v[2]);
         r.wi = normalize(pl - hit.p); r.pdf = 1.0f; r.vp = pl;

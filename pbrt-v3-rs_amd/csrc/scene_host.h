@@ -84,6 +84,7 @@ int set_err(PbrtHipScene* s, int code, const std::string& msg);
 int hip_fail(PbrtHipScene* s, hipError_t e, const char* what);
 int ensure_buf(PbrtHipScene* s, DevBuf& b, size_t bytes);
 int upload_scene(PbrtHipScene* s);
+void projection_light_setup(float fov_deg, float aspect, float out_proj[16], float out_screen[4], float* out_cos_total_width);   // host_setup.cpp
 // MIPMap::lookup_triangle on the host copy of the texel pool (textures_api.hip), for what InfiniteAreaLight computes at construction time
 void hmip_lookup_triangle(const PbrtHipScene* s, const MipRec& m, float u, float v, float width, float out[3]);
 int upload_light_distribution(PbrtHipScene* s, int light_strategy);

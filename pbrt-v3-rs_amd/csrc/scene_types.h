@@ -131,7 +131,7 @@ struct MipRec {  // MIPMap<T> (core/src/mipmap/mod.rs:76-96): pyramid levels in 
 };
 #define PH_EWA_LUT_SIZE 128
 
-enum { PH_L_INFINITE = 0, PH_L_DISTANT = 1, PH_L_POINT = 2, PH_L_AREA = 3, PH_L_SPOT = 4 };
+enum { PH_L_INFINITE = 0, PH_L_DISTANT = 1, PH_L_POINT = 2, PH_L_AREA = 3, PH_L_SPOT = 4, PH_L_PROJECTION = 5, PH_L_GONIO = 6 };
 struct LightRec {
     int32_t type;
     int32_t two_sided;
@@ -148,6 +148,8 @@ struct LightRec {
     float marg_func[2], marg_cdf[3], marg_int;
     float cos_total_width, cos_falloff_start;  // spot (lights/src/spot.rs:24-25); w2l holds its world_to_light, v its position
     uint32_t dw, dh;     // radiance map: resolution of the scalar image = 2 x the map's
+    float proj[16];      // projection light: light_projection (lights/src/projection.rs:104); screen = its screen_bounds {xmin, xmax, ymin, ymax};
+    float screen[4];     // map_mip1 = the projected image / the goniometric diagram (0: none), w2l = world_to_light, v = p_light
 };
 
 enum { PH_CAM_PERSPECTIVE = 0, PH_CAM_ORTHOGRAPHIC = 1, PH_CAM_ENVIRONMENT = 2 };

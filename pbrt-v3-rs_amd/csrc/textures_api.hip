@@ -453,4 +453,45 @@ int pbrt_hip_add_light_infinite_map(PbrtHipScene* s, const float L[3], int width
     return PBRT_HIP_OK;
 }
 
+namespace {
+// the part ProjectionLight::new and GonioPhotometricLight::new share: p_light, world_to_light and the image's MIPMap (Ewa, Repeat, 8.0; projection.rs:70-80, goniometric.rs:49-58)
+int add_image_point_light(PbrtHipScene* s, int type, const float I[3], const float l2w[16], const float w2l[16], int width, int height, const float* rgb, LightRec* out) {
+    if (rgb && (width <= 0 || height <= 0 || width > 16384 || height > 16384)) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "image light: resolution must be within 1..16384");
+    LightRec l{}; l.type = type; l.prim = 0xFFFFFFFFu;
+    for (int c = 0; c < 3; c++) l.L[c] = I[c];
+    std::memcpy(l.l2w, l2w, 48); std::memcpy(l.w2l, w2l, 48);
+    // p_light = light_to_world.transform_point(Point3f::ZERO) (transform.rs:288-302)
+    const float xp = l2w[0] * 0.0f + l2w[1] * 0.0f + l2w[2] * 0.0f + l2w[3], yp = l2w[4] * 0.0f + l2w[5] * 0.0f + l2w[6] * 0.0f + l2w[7];
+    const float zp = l2w[8] * 0.0f + l2w[9] * 0.0f + l2w[10] * 0.0f + l2w[11], wp = l2w[12] * 0.0f + l2w[13] * 0.0f + l2w[14] * 0.0f + l2w[15];
+    if (wp == 1.0f) { l.v[0] = xp; l.v[1] = yp; l.v[2] = zp; } else { const float inv = 1.0f / wp; l.v[0] = inv * xp; l.v[1] = inv * yp; l.v[2] = inv * zp; }
+    if (rgb) {
+        std::vector<float> img(rgb, rgb + 3 * (size_t)width * (size_t)height);
+        uint32_t mip = 0;
+        const int rc = build_pyramid(s, std::move(img), (size_t)width, (size_t)height, 1, 0, false, 8.0f, &mip);
+        if (rc) return rc;
+        l.map_mip1 = mip + 1u;
+        s->textured_materials = true;   // the image lookup lives in the TEX instantiations of the shade kernels, like the infinite light's radiance map
+    }
+    *out = l;
+    return PBRT_HIP_OK;
+}
+}  // namespace
+int pbrt_hip_add_light_projection(PbrtHipScene* s, const float I[3], const float l2w[16], const float w2l[16], float fov_deg, int width, int height, const float* rgb) {  // projection.rs:55-127
+    if (!s || !I || !l2w || !w2l) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_projection: null argument");
+    LightRec l;
+    const int rc = add_image_point_light(s, PH_L_PROJECTION, I, l2w, w2l, width, height, rgb, &l);
+    if (rc) return rc;
+    projection_light_setup(fov_deg, rgb ? (float)width / (float)height : 1.0f, l.proj, l.screen, &l.cos_total_width);
+    s->lights.push_back(l); s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+int pbrt_hip_add_light_goniometric(PbrtHipScene* s, const float I[3], const float l2w[16], const float w2l[16], int width, int height, const float* rgb) {  // goniometric.rs:34-80
+    if (!s || !I || !l2w || !w2l) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_goniometric: null argument");
+    LightRec l;
+    const int rc = add_image_point_light(s, PH_L_GONIO, I, l2w, w2l, width, height, rgb, &l);
+    if (rc) return rc;
+    s->lights.push_back(l); s->uploaded = false;
+    return PBRT_HIP_OK;
+}
+
 }  // extern "C"

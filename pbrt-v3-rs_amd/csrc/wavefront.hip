@@ -442,7 +442,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                 if (pick_pdf != 0.0f) {
                                     const LightRec& light = sc.lights[light_num];
                                     const f2 u_light = mk2(s_u[1][tid], s_u[2][tid]), u_scatter = mk2(s_u[3][tid], s_u[4][tid]); c = 5;
-                                    const bool is_delta = light.type == PH_L_DISTANT || light.type == PH_L_POINT || light.type == PH_L_SPOT;
+                                    const bool is_delta = light.type == PH_L_DISTANT || light.type == PH_L_POINT || light.type == PH_L_SPOT || light.type == PH_L_PROJECTION || light.type == PH_L_GONIO;
                                     float w2 = 0.0f, spdf_store = 0.0f;
                                     spec A = mks1(0.0f);
                                     // estimate_direct (integrator/common.rs:146-299), specular = false, handle_media = false

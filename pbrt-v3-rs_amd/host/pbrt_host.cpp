@@ -442,8 +442,25 @@ void Api::pbrt_light_source(const std::string& name, const ParamSet& p, const st
         float l2w[16], w2l[16], cs[2];
         pbrt_hip_host_spot(ctm_.m, ctm_.mi, from.data(), to.data(), p.find_one_float("coneangle", 30.0f), p.find_one_float("conedeltaangle", 5.0f), l2w, w2l, cs);
         if (check(ABI(pbrt_hip_add_light_spot(scene_, I.data(), l2w, w2l, cs[0], cs[1])), "add_light_spot")) n_lights_++;
+    } else if (name == "projection" || name == "goniometric") {   // projection.rs:275-296, goniometric.rs:220-237: light_to_world = the CTM
+        auto I = mul3(p.find_one_rgb("I", one), sc);
+        std::string map = p.find_one_string("mapname", "");
+        std::vector<float> rgb; int w = 0, h = 0;
+        if (map.empty()) warn(name == "projection" ? "No projection image texture provided." : "No goniophotometric image texture provided.");
+        else {   // an image that cannot be read leaves the light without one, with a warning (projection.rs:83-86, goniometric.rs:60-63)
+            if (map[0] != '/' && !scene_dir.empty()) map = scene_dir + "/" + map;
+            std::string err;
+            if (!read_image(map, rgb, w, h, err)) {
+                rgb.clear();
+                if (err.find("not decoded by this host") != std::string::npos) { if (error.empty()) error = "LightSource \"" + name + "\" 'mapname' " + map + ": " + err; return; }
+                warn("Problem reading file '" + map + "'. " + err);
+            }
+        }
+        const float* img = rgb.empty() ? nullptr : rgb.data();
+        if (name == "projection") { if (check(ABI(pbrt_hip_add_light_projection(scene_, I.data(), ctm_.m, ctm_.mi, p.find_one_float("fov", 45.0f), w, h, img)), "add_light_projection")) n_lights_++; }
+        else if (check(ABI(pbrt_hip_add_light_goniometric(scene_, I.data(), ctm_.m, ctm_.mi, w, h, img)), "add_light_goniometric")) n_lights_++;
     } else {
-        error = "LightSource \"" + name + "\" is outside the hot-path scope (supported: infinite, distant, point, spot, and diffuse area lights)";
+        error = "LightSource \"" + name + "\" is outside the hot-path scope (supported: infinite, distant, point, spot, projection, goniometric and diffuse area lights)";
     }
 }
 void Api::pbrt_area_light_source(const std::string& name, const ParamSet& p) { if (!verify_world("AreaLightSource")) return; gs_.area_light = name; gs_.area_light_params = p; }

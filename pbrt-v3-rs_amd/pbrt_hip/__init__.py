@@ -79,6 +79,8 @@ class Binding:
             "add_light_distant": (C.c_int, [vp, fp, fp]),
             "add_light_point": (C.c_int, [vp, fp, fp]),
             "add_light_spot": (C.c_int, [vp, fp, fp, fp, C.c_float, C.c_float]),
+            "add_light_projection": (C.c_int, [vp, fp, fp, fp, C.c_float, C.c_int, C.c_int, fp]),
+            "add_light_goniometric": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_int, fp]),
             "add_light_diffuse_area": (C.c_int, [vp, fp, C.c_int, C.c_uint32, u32p]),
             "set_camera_perspective": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]),
             "set_camera_orthographic": (C.c_int, [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]),
@@ -427,6 +429,18 @@ class Scene:
     def add_light_spot(self, I, light_to_world, world_to_light, cos_total_width, cos_falloff_start):
         self._chk(self.b.fn("add_light_spot")(self.h, _ptr(_f32(I), C.c_float), _ptr(_f32(light_to_world), C.c_float), _ptr(_f32(world_to_light), C.c_float),
                                               C.c_float(cos_total_width), C.c_float(cos_falloff_start)))
+
+    def add_light_projection(self, I, light_to_world, world_to_light, fov, image=None):
+        """ProjectionLight: image (H, W, 3) float32, top row first, or None (white inside the frustum)."""
+        img = None if image is None else np.ascontiguousarray(image, dtype=np.float32)
+        self._chk(self.b.fn("add_light_projection")(self.h, _ptr(_f32(I), C.c_float), _ptr(_f32(light_to_world), C.c_float), _ptr(_f32(world_to_light), C.c_float), C.c_float(fov),
+                                                    0 if img is None else img.shape[1], 0 if img is None else img.shape[0], None if img is None else _ptr(img, C.c_float)))
+
+    def add_light_goniometric(self, I, light_to_world, world_to_light, image=None):
+        """GonioPhotometricLight: image (H, W, 3) float32 indexed by (phi / 2 pi, theta / pi), or None (a point light)."""
+        img = None if image is None else np.ascontiguousarray(image, dtype=np.float32)
+        self._chk(self.b.fn("add_light_goniometric")(self.h, _ptr(_f32(I), C.c_float), _ptr(_f32(light_to_world), C.c_float), _ptr(_f32(world_to_light), C.c_float),
+                                                     0 if img is None else img.shape[1], 0 if img is None else img.shape[0], None if img is None else _ptr(img, C.c_float)))
 
     def add_light_diffuse_area(self, L, n_tris, two_sided=False) -> int:
         out = C.c_uint32(0)

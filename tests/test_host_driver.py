@@ -56,7 +56,7 @@ def test_check_mode_crop_and_outfile(tmp_path):
     ('WorldBegin\nMakeNamedMedium "fog" "string type" "homogeneous"\nWorldEnd\n', "directive 'MakeNamedMedium'"),
     ('WorldBegin\nObjectBegin "a"\nAreaLightSource "diffuse"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nObjectEnd\nWorldEnd\n',
      "AreaLightSource inside ObjectBegin"),
-    ('WorldBegin\nLightSource "goniometric"\nWorldEnd\n', 'LightSource "goniometric"'),
+    ('WorldBegin\nLightSource "laser"\nWorldEnd\n', 'LightSource "laser"'),
     ('Camera "realistic"\nWorldBegin\nWorldEnd\n', 'Camera "realistic"'),
     ('Integrator "bdpt"\nWorldBegin\nWorldEnd\n', 'Integrator "bdpt"'),
     ('Sampler "random"\nWorldBegin\nWorldEnd\n', 'Sampler "random"'),

@@ -458,6 +458,12 @@ PixelFilter "box"
 Integrator "path" "integer maxdepth" {depth} "string lightsamplestrategy" "uniform"
 WorldBegin
 LightSource "infinite" "rgb L" [0.9 0.9 1.0]
+AttributeBegin
+  Translate 0.5 -0.5 3
+  Rotate 175 1 0 0
+  LightSource "projection" "rgb I" [30 30 30] "rgb scale" [0.5 1 1] "float fov" 50 "string mapname" "slide.pfm"
+  LightSource "goniometric" "rgb I" [4 3 2]
+AttributeEnd
 Texture "checks" "color" "checkerboard" "float uscale" 4 "float vscale" 4 "rgb tex1" [0.8 0.7 0.2] "rgb tex2" [0.1 0.1 0.3]
 Material "matte" "texture Kd" "checks"
 Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [{ds.fl(Q)}] "float uv" [{ds.fl(UVQ)}]
@@ -465,6 +471,9 @@ Material "plastic" "rgb Kd" [0.6 0.2 0.2]
 Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-1 0 0.01  1 0 0.01  0 0.5 1.5]
 WorldEnd
 """
+    import image_files as imf
+    slide = np.random.default_rng(3).uniform(0.0, 1.0, (6, 9, 3)).astype(np.float32)
+    imf.write_pfm(str(tmp_path / "slide.pfm"), slide)
     (tmp_path / "ortho.pbrt").write_text(text)
     r = subprocess.run([ds.RENDER_BIN, "--quiet", str(tmp_path / "ortho.pbrt")], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr + r.stdout
@@ -473,6 +482,10 @@ WorldEnd
     try:
         with OracleScene() as s:
             s.add_light_infinite((0.9, 0.9, 1.0))
+            ident = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+            lt = host.compose(host.compose(ident, host.translate([0.5, -0.5, 3])), host.rotate(175.0, [1, 0, 0]))
+            s.add_light_projection(np.float32([30, 30, 30]) * np.float32([0.5, 1, 1]), lt[0], lt[1], 50.0, slide)
+            s.add_light_goniometric((4, 3, 2), lt[0], lt[1], None)
             checks = s.add_texture_checkerboard(s.add_texture_constant((0.8, 0.7, 0.2)), s.add_texture_constant((0.1, 0.1, 0.3)), su=4.0, sv=4.0)
             s.add_mesh(Q, [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(checks, 0.0), UV=UVQ)
             s.add_mesh(np.array([[-1, 0, 0.01], [1, 0, 0.01], [0, 0.5, 1.5]], np.float32), [0, 1, 2], s.add_material_plastic((0.6, 0.2, 0.2), (0.25,) * 3, 0.1, True))

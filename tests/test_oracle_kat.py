@@ -277,3 +277,63 @@ def test_spot_light_closed_form(host):
     # XYZ round trip of the film (rgb -> xyz -> rgb) costs ~1e-6 relative; the falloff edge amplifies f32 rounding of cos
     assert np.allclose(got[lit], expect[lit], rtol=2e-3, atol=1e-6)
     assert np.abs(got[fall == 0]).max() < 1e-7
+
+
+def test_projection_and_goniometric_lights_closed_form(host):
+    """ProjectionLight / GonioPhotometricLight (lights/src/projection.rs, goniometric.rs): a Lambertian floor under one such light, max_depth 1, centred
+    samples.  Projection: Kd/pi * I * texel / d^2 * cos inside the frustum |x/z| <= aspect tan(fov/2), |y/z| <= tan(fov/2) (fov spans the SHORTER image
+    axis), zero outside; a two-texel image tells left from right.  Goniometric: rows of the diagram are selected by the angle from the light's +y axis."""
+    import pbrt_hip
+    from oracle_binding import OracleScene
+    I4 = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+    Iv, kd, fov, res = np.array([30.0, 20.0, 10.0]), np.array([0.6, 0.5, 0.4]), 40.0, 40
+    pl = np.array([0.2, -0.1, 2.5])
+    l2w = host.compose(host.compose(I4, host.translate(pl)), host.rotate(180.0, [1, 0, 0]))      # the light looks down: its +z is world -z, its +y world -y
+    two = np.zeros((1, 2, 3), np.float32); two[0, 0] = (1.0, 0.25, 0.0); two[0, 1] = (0.0, 0.25, 1.0)   # aspect 2: left texel reddish, right texel bluish
+    rows = np.zeros((4, 1, 3), np.float32); rows[:, 0, 0] = (0.1, 0.4, 0.7, 1.0); rows[:, 0, 1] = 0.5; rows[:, 0, 2] = (1.0, 0.7, 0.4, 0.1)
+
+    def render(add_light):
+        with OracleScene() as o:
+            add_light(o)
+            o.add_mesh(np.float32([[-6, -6, 0], [6, -6, 0], [6, 6, 0], [-6, 6, 0]]), [0, 1, 2, 0, 2, 3], o.add_material_matte(kd, 0.0))
+            w2c, c2w = host.look_at([0, -2, 7], [0.1, 0, 0], [0, 0, 1])
+            o.set_camera_perspective(host.perspective_raster_to_camera(60.0, res, res), c2w)
+            cb, table, sb = host.film_box(res, res)
+            o.set_film(res, res, cb, (0.5, 0.5), table)
+            o.set_sampler(0, 1, sb, sample_at_pixel_center=True)
+            o.build_accel(0, 4)
+            xyz, wt, st = o.render_path(max_depth=1, light_strategy=0)
+            rgb = o.film_to_rgb(xyz, wt).reshape(-1, 3).astype(np.float64)
+            rays, _ = o.generate_camera_rays([0, 0, res, res], 0)
+        ro, rd = rays["o"].astype(np.float64), rays["d"].astype(np.float64)
+        P = ro + rd * (-ro[:, 2] / rd[:, 2])[:, None]
+        w = P - pl; d2 = (w ** 2).sum(1); wn = w / np.sqrt(d2)[:, None]
+        base = (kd / np.pi)[None, :] * Iv[None, :] * (np.abs(wn[:, 2]) / d2)[:, None]
+        wl = np.stack([w[:, 0], -w[:, 1], -w[:, 2]], axis=1)      # world -> light: rotate 180 degrees about x
+        return rgb, base, wl
+
+    tan_h = np.tan(np.radians(fov) / 2)
+    rgb, base, wl = render(lambda o: o.add_light_projection(Iv, l2w[0], l2w[1], fov, two))
+    px, py = wl[:, 0] / wl[:, 2] / tan_h, wl[:, 1] / wl[:, 2] / tan_h     # screen coordinates: [-2, 2] x [-1, 1]
+    inside = (np.abs(px) < 1.98) & (np.abs(py) < 0.98); outside = (np.abs(px) > 2.02) | (np.abs(py) > 1.02)
+    assert inside.sum() > 50 and outside.sum() > 50
+    assert np.abs(rgb[outside]).max() < 1e-9
+    sx = (px + 2) / 4 * 2 - 0.5                                              # MIPMap::triangle: continuous texel coordinate, Repeat wrap
+    fx = sx - np.floor(sx); t0 = np.mod(np.floor(sx).astype(int), 2)
+    tex = (1 - fx)[:, None] * two[0, t0].astype(np.float64) + fx[:, None] * two[0, 1 - t0].astype(np.float64)
+    assert np.allclose(rgb[inside], (base * tex)[inside], rtol=2e-3, atol=1e-7)
+    left = inside & (np.abs(px + 1.0) < 0.2); right = inside & (np.abs(px - 1.0) < 0.2)      # around the two texel centres
+    assert (rgb[left][:, 0] > 5 * rgb[left][:, 2]).all() and (rgb[right][:, 2] > 2 * rgb[right][:, 0]).all()
+    rgb0, base0, _ = render(lambda o: o.add_light_projection(Iv, l2w[0], l2w[1], fov, None))   # no image: white inside a square frustum
+    sq = (np.abs(px) < 0.98) & (np.abs(py) < 0.98)
+    assert np.allclose(rgb0[sq], base0[sq], rtol=2e-3) and np.abs(rgb0[(np.abs(px) > 1.02) | (np.abs(py) > 1.02)]).max() < 1e-9
+
+    rgb, base, wl = render(lambda o: o.add_light_goniometric(Iv, l2w[0], l2w[1], rows))
+    wln = wl / np.linalg.norm(wl, axis=1)[:, None]
+    theta = np.arccos(np.clip(wln[:, 1], -1, 1))                               # after swapping y and z the polar axis is the light's +y
+    sy = theta / np.pi * 4 - 0.5
+    fy = sy - np.floor(sy); r0 = np.mod(np.floor(sy).astype(int), 4); r1 = np.mod(r0 + 1, 4)
+    tex = (1 - fy)[:, None] * rows[r0, 0].astype(np.float64) + fy[:, None] * rows[r1, 0].astype(np.float64)
+    assert np.allclose(rgb, base * tex, rtol=2e-3, atol=1e-7)
+    rgb1, base1, _ = render(lambda o: o.add_light_goniometric(Iv, l2w[0], l2w[1], None))          # no diagram: a point light
+    assert np.allclose(rgb1, base1, rtol=2e-3, atol=1e-7)

@@ -329,6 +329,32 @@ def test_spot_lights_bit_exact(host):
         _assert_film_bit_exact(cap, max_depth=4, light_strategy=strategy)
 
 
+def test_projection_and_goniometric_lights_bit_exact(host):
+    """ProjectionLight / GonioPhotometricLight sample_li, power (lights/src/projection.rs, goniometric.rs) with and without their image,
+    under the uniform, power and spatial strategies."""
+    I4 = (np.eye(4, dtype=np.float32).reshape(16),) * 2
+    base = scenes.cornell_like(host, sigma=10.0)
+    rng = np.random.default_rng(5)
+    slide = rng.uniform(0.0, 1.0, (12, 20, 3)).astype(np.float32)
+    diagram = rng.uniform(0.0, 2.0, (9, 16, 3)).astype(np.float32)
+
+    def cap(s):
+        a = host.compose(host.compose(I4, host.translate([0.4, -0.5, 0.9])), host.rotate(170.0, [1, 0.1, 0]))
+        b = host.compose(host.compose(I4, host.translate([-0.6, -0.6, 0.2])), host.rotate(-50.0, [1, 0, -1]))
+        s.add_light_projection((6, 5, 4), a[0], a[1], 55.0, slide)
+        s.add_light_projection((2, 2, 3), b[0], b[1], 30.0, None)
+        s.add_light_goniometric((1, 2, 3), b[0], b[1], diagram)
+        s.add_light_goniometric((0.5, 0.4, 0.3), a[0], a[1], None)
+        base(s)
+    for strategy in (0, 1, 2):
+        _assert_film_bit_exact(cap, max_depth=4, light_strategy=strategy)
+
+    def sky_only(s):   # a radiance map is the scene's only MIPMap (no Texture at all): the pyramids must reach the device all the same
+        s.add_light_infinite_map((0.8, 0.9, 1.0), diagram, *I4)
+        base(s)
+    _assert_film_bit_exact(sky_only, max_depth=3, light_strategy=0)
+
+
 @pytest.mark.parametrize("instances", [0, 3])
 def test_traversal_work_counters_equal_the_oracles(host, instances):
     """The roofline's algorithmic bytes are built from node visits and triangle tests of the REFERENCE's traversal:
