@@ -1,24 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py — Mrays/s of the MI355X wavefront path tracer on BASELINE.json's configs[1]
-("Synthetic 100k random triangles, single BVH, 512x512 @ 64 spp, 1x MI355X").
+"""bench.py — Mrays/s of the MI355X wavefront path tracer on BASELINE.json's configurations (synthetic random-triangle scenes).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one frame: SamplerIntegrator::render of the whole image (raygen -> [extend, shadow, shade] x (maxdepth+1) -> film).
-Scene, BVH and sampler tables are resident in HBM before the timed region.  With N ranks the frame's 16x16 tiles are dealt
-round-robin (tile t -> rank t % N, the reference's tile enumeration), every rank renders its tiles, the per-tile film buffers
-are gathered on rank 0 over RCCL (the path's one exchange step) and merged there in tile order.
-Scaling (N > 1): "weak" by default — the frame is rendered at N x the samples per pixel, so every rank traces as many paths as
-the single GPU does at N = 1 and the job is N frames' worth of work; `--scaling strong` renders the identical N = 1 frame
-instead (same film bits as one rank, tests/test_multi_rank_gpu.py).
+Workload (`--config`, named in the JSON line's config.workload):
+  2 (default at N = 1)  configs[2]: 4.3 M triangles, PathIntegrator maxdepth 8, 1024x1024 @ 256 spp — the largest single-GPU configuration.  The
+                        Ganesha PLY is not available offline; the stand-in is the synthetic generator at the same triangle count.
+  3 (default at N > 1)  configs[3]: 10 M triangles, 2048x2048 @ 64 spp, tiles sharded over the ranks, film tiles gathered with RCCL.  STRONG scaling:
+                        the frame is the same for every N; a short weak-scaling leg (spp x N) is reported alongside under `weak_alongside`.
+  1                     configs[1]: 100 k triangles, 512x512 @ 64 spp.          1M: the north-star 1 M-triangle scene at 512x512 @ 64 spp.
+  --n-tris/--res/--spp/--max-depth override single values (the workload is then labelled "custom").
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (BVH traversal; one launch per wavefront round serves that round's closest-hit
-and any-hit rays): achieved = algorithmic bytes (32 B per reference-format node visit + 48 B per triangle test + 64 B ray in / hit
-out, 33 B for any-hit rays) / its HIP-event time measured inside the timed steps.  `cpu_baseline` times the CPU oracle (oracle/, a port of the reference algorithm — the Rust
-reference cannot be built here) on a bounded sample of the same workload on this box's host cores.
+A step = one frame: SamplerIntegrator::render of the whole image (raygen -> [traverse, shade] x (maxdepth+1) -> film), film read back to the host.
+Scene, BVH and sampler tables are resident in HBM before the timed region.  With N ranks the frame's 16x16 tiles are dealt round-robin
+(tile t -> rank t % N, the reference's tile enumeration), every rank renders its tiles, the per-tile film buffers are gathered on rank 0 over RCCL
+(the path's one exchange step) and merged there in tile order.
+
+Prints ONE JSON line (rank 0).
+`roofline` describes the dominant kernel (ph::traverse_kernel: BVH traversal + triangle tests; one launch per wavefront round serves that round's
+closest-hit and any-hit rays):
+  achieved  = ALGORITHMIC bytes / kernel time: 32 B per reference-format node visit + 48 B per triangle test + 64 B ray in / hit out (33 B for any-hit
+              rays), SURVEY §8d, counted by an untimed counting build of the same kernel on the same frame; time = HIP events around every traversal
+              launch of the timed steps, recorded on the library's own stream.
+  traffic   = memory-side bytes per launch (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, i.e. what left the L2s towards Infinity Cache / HBM), read from
+              profiles/r02_traffic.json when that file holds a PMC run of this exact workload (scripts/pmc_profile.sh writes it), else null + the reason.
+  frac      = traffic / avg launch time / peak: the fraction of the HBM peak the kernel draws at the memory side.  The tree's upper levels are re-read
+              by every ray and are served by L2 / Infinity Cache, so the algorithmic rate (`frac_algorithmic` = achieved / peak) is not an HBM
+              fraction and can exceed 1; it is reported next to it.  Without a matching PMC run frac falls back to the algorithmic ratio and says so.
+`cpu_baseline` times the CPU oracle (oracle/, a port of the reference algorithm — the Rust reference cannot be built here) on a bounded sample of the
+same workload (same scene and resolution, the first few Halton samples of every pixel, about 150 M rays) on this box's host cores.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,25 +41,52 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pbrt-v3-rs_amd"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+INFINITY_CACHE_BYTES = 256 << 20
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+
+CONFIGS = {  # BASELINE.json `configs`, on the synthetic generator of SURVEY §8d
+    "1": dict(n_tris=100_000, res=512, spp=64, max_depth=5, label="configs[1]: synthetic 100 k random triangles, single BVH, 512x512 @ 64 spp"),
+    "2": dict(n_tris=4_300_000, res=1024, spp=256, max_depth=8,
+              label="configs[2]: 4.3 M triangles (synthetic stand-in of the same size for the Ganesha PLY, which is not available offline), PathIntegrator depth 8, 1024x1024 @ 256 spp"),
+    "3": dict(n_tris=10_000_000, res=2048, spp=64, max_depth=5, label="configs[3]: synthetic 10 M triangles, 2048x2048 @ 64 spp, tiles sharded over the ranks, RCCL film-tile gather"),
+    "1M": dict(n_tris=1_000_000, res=512, spp=64, max_depth=5, label="north-star 1 M-triangle scene: synthetic 1 M random triangles, 512x512 @ 64 spp"),
+}
 
 
 def host_cores():
-    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota and by the box's per-GPU
-    CPU share (16)."""
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota and by the box's per-GPU CPU share (16)."""
     n = os.cpu_count() or 1
     try:
         n = len(os.sched_getaffinity(0))
-    except Exception:
+    except (AttributeError, OSError):
         pass
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:
             q, p = f.read().split()
             if q != "max":
                 n = min(n, max(1, int(int(q) / int(p))))
-    except Exception:
+    except (OSError, ValueError):
         pass
     return max(1, min(n, int(os.environ.get("PBRT_HIP_CPU_THREADS", "16"))))
+
+
+def workload_key(n_tris, res, spp, max_depth, seed):
+    return [int(n_tris), int(res), int(spp), int(max_depth), int(seed)]
+
+
+def find_traffic(key):
+    """The PMC record of this workload from profiles/r02_traffic.json, or (None, reason)."""
+    if not os.path.exists(TRAFFIC_FILE):
+        return None, f"{os.path.relpath(TRAFFIC_FILE, ROOT)} does not exist"
+    with open(TRAFFIC_FILE) as f:
+        tj = json.load(f)
+    for e in tj.get("entries", []):
+        if e.get("workload") == key:
+            if "traversal" not in e:
+                return None, "the PMC record of this workload has no traversal kernels"
+            return e, None
+    return None, f"no PMC run of workload {key} in {os.path.relpath(TRAFFIC_FILE, ROOT)} (have: {[e.get('workload') for e in tj.get('entries', [])]})"
 
 
 def main():
@@ -53,34 +94,45 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-tris", type=int, default=100_000)
-    ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--spp", type=int, default=64)
-    ap.add_argument("--max-depth", type=int, default=5)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="BASELINE.json configuration; default 2 at N = 1, 3 at N > 1")
+    ap.add_argument("--n-tris", type=int, default=None)
+    ap.add_argument("--res", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--max-depth", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-spp", type=int, default=64, help="spp of the bounded CPU-baseline sample (same scene, same resolution)")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (same scene, same resolution); 0 = about 150 M rays' worth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-count", action="store_true")
     ap.add_argument("--material", default="matte", choices=["matte", "plastic", "glass", "metal", "uber", "mixed", "textured"],
                     help="material of every triangle; anything but matte runs the general-BSDF shade kernel (not the headline workload)")
     ap.add_argument("--instances", type=int, default=0,
                     help="K > 0: the triangles become one object instanced K times (two-level BVH, TransformedPrimitive path); not the headline workload")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = spp x N (per-GPU work fixed), strong = the N=1 frame split over N ranks")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N>1: strong = the N=1 frame split over N ranks (headline), weak = spp x N (per-GPU work fixed)")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N>1, strong: skip the short weak-scaling leg reported alongside")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = functional rehearsal of the N>1 path on ONE GPU: all ranks share device 0 and film tiles travel through host memory")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import pbrt_hip
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+
+    cfg_name = args.config or ("2" if world == 1 else "3")
+    cfg = dict(CONFIGS[cfg_name])
+    custom = []
+    for k, v in (("n_tris", args.n_tris), ("res", args.res), ("spp", args.spp), ("max_depth", args.max_depth)):
+        if v is not None and v != cfg[k]:
+            cfg[k] = v
+            custom.append(k)
+    n_tris, res, spp, max_depth = cfg["n_tris"], cfg["res"], cfg["spp"], cfg["max_depth"]
+
+    import numpy as np  # noqa: F401
+    import torch
+    import pbrt_hip
+
     dist = None
     if args.backend == "gloo":
         local_rank = 0  # rehearsal mode: every rank drives GPU 0
@@ -98,37 +150,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     host = pbrt_hip.Host()
-    frame_spp = args.spp * (world if args.scaling == "weak" else 1)
-    spec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=frame_spp, max_depth=args.max_depth, material=args.material)
-    scene = pbrt_hip.Scene(device=local_rank)
-    t_setup = time.time()
-    geometry = pbrt_hip.capture_spec(spec, scene, host, instances=args.instances)
-    t_setup = time.time() - t_setup
-
     tile_size = 16
-    floats = max(scene.tile_buffer_floats(tile_size, p, world) for p in range(world))
-    tile_buf = torch.zeros(floats, dtype=torch.float32, device=dev)
-    gather_list = [torch.zeros(floats, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
-    torch.cuda.synchronize()  # the library writes tile_buf on its own stream: torch's fill kernels must have finished
-
-    def step():
-        st = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=args.max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
-        film = None
-        if world > 1:
-            if args.backend == "nccl":
-                dist.gather(tile_buf, gather_list, dst=0)   # RCCL over xGMI, device buffers
-            else:
-                host_parts = [torch.zeros(floats) for _ in range(world)] if rank == 0 else None
-                dist.gather(tile_buf.cpu(), host_parts, dst=0)
-                if rank == 0:
-                    for g, h in zip(gather_list, host_parts):
-                        g.copy_(h)
-            torch.cuda.synchronize()  # the collective runs on torch's stream: finish it before the library reads (rank 0) or rewrites (all) the buffers
-            if rank == 0:
-                film = scene.merge_tiles_device([t.data_ptr() for t in gather_list], tile_size)
-        else:
-            film = scene.merge_tiles_device([tile_buf.data_ptr()], tile_size)
-        return st, film
+    geometry = None
 
     def sync():
         torch.cuda.synchronize()
@@ -141,52 +164,97 @@ def main():
         dist.all_reduce(t, op=op)
         return t.tolist()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    rays = 0
-    ext_s = sh_s = shade_s = 0.0
-    reg = shd = 0
-    film = None
-    for _ in range(args.steps):
-        st, film = step()
-        rays += st.regular_rays + st.shadow_rays
-        reg += st.regular_rays; shd += st.shadow_rays
-        ext_s += st.extend_seconds; sh_s += st.shadow_seconds; shade_s += st.shade_seconds
-    sync()
-    elapsed = time.perf_counter() - t0
+    def run_leg(frame_spp, steps, warmup):
+        """Builds the scene at `frame_spp`, renders warmup + steps frames; returns (scene, tile_buf, stats dict)."""
+        nonlocal geometry
+        spec = pbrt_hip.SceneSpec(n_tris=n_tris, seed=args.seed, xres=res, yres=res, spp=frame_spp, max_depth=max_depth, material=args.material)
+        scene = pbrt_hip.Scene(device=local_rank)
+        t_setup = time.time()
+        geometry = pbrt_hip.capture_spec(spec, scene, host, geometry=geometry, instances=args.instances)
+        t_setup = time.time() - t_setup
+        floats = max(scene.tile_buffer_floats(tile_size, p, world) for p in range(world))
+        tile_buf = torch.zeros(floats, dtype=torch.float32, device=dev)
+        gather_list = [torch.zeros(floats, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+        torch.cuda.synchronize()  # the library writes tile_buf on its own stream: torch's fill kernels must have finished
 
-    if world > 1:
-        elapsed = float(reduce_scalars([elapsed], dist.ReduceOp.MAX, torch.float64)[0])
-        rays, reg, shd = (int(v) for v in reduce_scalars([rays, reg, shd], dist.ReduceOp.SUM, torch.int64))
+        def step():
+            st = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
+            film = None
+            if world > 1:
+                if args.backend == "nccl":
+                    dist.gather(tile_buf, gather_list, dst=0)   # RCCL over xGMI, device buffers
+                else:
+                    host_parts = [torch.zeros(floats) for _ in range(world)] if rank == 0 else None
+                    dist.gather(tile_buf.cpu(), host_parts, dst=0)
+                    if rank == 0:
+                        for g, h in zip(gather_list, host_parts):
+                            g.copy_(h)
+                torch.cuda.synchronize()  # the collective runs on torch's stream: finish it before the library reads (rank 0) or rewrites (all) the buffers
+                if rank == 0:
+                    film = scene.merge_tiles_device([t.data_ptr() for t in gather_list], tile_size)
+            else:
+                film = scene.merge_tiles_device([tile_buf.data_ptr()], tile_size)
+            return st, film
+
+        for _ in range(warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        rays = reg = shd = launches = 0
+        ext_s = sh_s = shade_s = 0.0
+        film = None
+        for _ in range(steps):
+            st, film = step()
+            reg += st.regular_rays; shd += st.shadow_rays
+            ext_s += st.extend_seconds; sh_s += st.shadow_seconds; shade_s += st.shade_seconds
+            launches = int(st.extend_launches + st.shadow_launches)
+        sync()
+        elapsed = time.perf_counter() - t0
+        rays = reg + shd
+        if world > 1:
+            elapsed = float(reduce_scalars([elapsed], dist.ReduceOp.MAX, torch.float64)[0])
+            rays, reg, shd = (int(v) for v in reduce_scalars([rays, reg, shd], dist.ReduceOp.SUM, torch.int64))
+        return scene, tile_buf, dict(elapsed=elapsed, rays=rays, reg=reg, shd=shd, ext_s=ext_s, sh_s=sh_s, shade_s=shade_s, launches=launches, film=film,
+                                     t_setup=t_setup, steps=steps)
+
+    scaling = args.scaling if world > 1 else "weak"  # one GPU: the two coincide; the contract's default label
+    frame_spp = spp * (world if (world > 1 and scaling == "weak") else 1)
+    scene, tile_buf, r = run_leg(frame_spp, args.steps, args.warmup)
 
     out = None
-    spp_note = f" (= {args.spp} x {world} ranks)" if frame_spp != args.spp else ""
     if rank == 0:
-        mrays = rays / elapsed / 1e6
+        mrays = r["rays"] / r["elapsed"] / 1e6
+        label = cfg["label"] if not custom else f"custom ({', '.join(custom)} overridden; base {cfg['label']})"
+        spp_note = f" (= {spp} x {world} ranks, weak scaling)" if frame_spp != spp else ""
+        acc = scene.accel_stats()
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
+            "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("" if not args.instances else f"INSTANCED x{args.instances} (one object, two-level BVH) — ") +
-                                   f"configs[1]: {args.n_tris} random triangles (seed {args.seed}), single SAH BVH, {args.res}x{args.res} @ {frame_spp} spp{spp_note}, "
-                                   f"PathIntegrator maxdepth {args.max_depth}, halton, box filter, constant infinite light, " + ("matte Kd 0.5" if args.material == "matte" else f"material {args.material}"),
-                       "tiles": "16x16, tile t on rank t % n_gpus, film tiles gathered on rank 0 (RCCL)" if world > 1 else "16x16, one rank",
-                       "rays_per_frame": rays // args.steps, "regular_rays_per_frame": reg // args.steps, "shadow_rays_per_frame": shd // args.steps,
-                       "scene_setup_seconds_host": round(t_setup, 3)},
-            "film_sha256": __import__("hashlib").sha256(film[0].tobytes() + film[1].tobytes()).hexdigest(),
-            "stage_ms_per_step_rank0": {"extend": round(ext_s / args.steps * 1e3, 3), "shadow": round(sh_s / args.steps * 1e3, 3),
-                                        "raygen_shade_film": round(shade_s / args.steps * 1e3, 3)},
+            "config": {"workload": ("" if not args.instances else f"INSTANCED x{args.instances} (one object, two-level BVH) — ") + label +
+                                   f" — as run: {n_tris} random triangles (seed {args.seed}), single SAH BVH (maxnodeprims 4), {res}x{res} @ {frame_spp} spp{spp_note}, "
+                                   f"PathIntegrator maxdepth {max_depth}, halton, box filter, constant infinite light, " + ("matte Kd 0.5" if args.material == "matte" else f"material {args.material}"),
+                       "baseline_config": cfg_name if not custom else "custom", "key": workload_key(n_tris, res, frame_spp, max_depth, args.seed),
+                       "tiles": f"16x16, tile t on rank t % {world}, film tiles gathered on rank 0 (RCCL)" if world > 1 else "16x16, one rank",
+                       "rays_per_frame": r["rays"] // args.steps, "regular_rays_per_frame": r["reg"] // args.steps, "shadow_rays_per_frame": r["shd"] // args.steps,
+                       "scene_setup_seconds_host": round(r["t_setup"], 3),
+                       "accel": {"interior_nodes": acc["interior_nodes"], "leaf_records": acc["leaf_records"],
+                                 "resident_bytes": acc["node_bytes"] + acc["leaf_record_bytes"], "host_build_seconds": round(acc["build_seconds"], 3)}},
+            "film_sha256": hashlib.sha256(r["film"][0].tobytes() + r["film"][1].tobytes()).hexdigest(),
+            "stage_ms_per_step_rank0": {"traversal": round((r["ext_s"] + r["sh_s"]) / args.steps * 1e3, 3),
+                                        "raygen_shade_film": round(r["shade_s"] / args.steps * 1e3, 3)},
         }
 
     # ---- roofline of the dominant kernel (BVH traversal, both ray kinds), rank 0's share ------------------------------------------------
     if rank == 0:
-        roof = {"bound": "hbm", "kernel": "ph::traverse_kernel (BVH traversal + triangle tests; one launch per wavefront round serves the round's closest-hit and any-hit rays)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": None, "traffic": None}
+        resident = acc["node_bytes"] + acc["leaf_record_bytes"]
+        roof = {"bound": "hbm" if resident > INFINITY_CACHE_BYTES else "l2+infinity-cache",
+                "bound_note": (f"BVH nodes + leaf records = {resident / 2**20:.0f} MiB " + ("exceed" if resident > INFINITY_CACHE_BYTES else "fit in") + " the 256 MiB Infinity Cache"),
+                "kernel": "ph::traverse_kernel (BVH traversal + triangle tests; one launch per wavefront round serves the round's closest-hit and any-hit rays)",
+                "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         if not args.no_roofline_count:
             scene.set_traversal_counting(True)
-            st_c = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=args.max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
+            scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
             cnt = scene.traversal_counts()
             scene.set_traversal_counting(False)
             cl, ah = cnt["closest"], cnt["any_hit"]
@@ -195,37 +263,37 @@ def main():
             bytes_ah = 32 * ah["ref_node_visits"] + 48 * ah["tri_tests"] + 33 * ah["rays"]
             bytes_per_frame = bytes_cl + bytes_ah
             n_rays = cl["rays"] + ah["rays"]
-            trav_per_frame = (ext_s + sh_s) / args.steps
-            launches = int(st.extend_launches + st.shadow_launches)
-            ach = bytes_per_frame / trav_per_frame / 1e9 if trav_per_frame > 0 else None
-            roof.update({"achieved": round(ach, 1) if ach else None, "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
-                         "algorithmic_bytes_per_launch": bytes_per_frame // max(launches, 1), "launches_per_step": launches,
-                         "avg_launch_ms": round(trav_per_frame / launches * 1e3, 4), "rays_per_step": n_rays,
-                         "closest_hit": {"rays": cl["rays"], "ref_node_visits_per_ray": round(cl["ref_node_visits"] / max(cl["rays"], 1), 2),
-                                         "tri_tests_per_ray": round(cl["tri_tests"] / max(cl["rays"], 1), 2), "bytes_per_ray": round(bytes_cl / max(cl["rays"], 1), 1)},
-                         "any_hit": {"rays": ah["rays"], "ref_node_visits_per_ray": round(ah["ref_node_visits"] / max(ah["rays"], 1), 2),
-                                     "tri_tests_per_ray": round(ah["tri_tests"] / max(ah["rays"], 1), 2), "bytes_per_ray": round(bytes_ah / max(ah["rays"], 1), 1)},
-                         "kernel_Mrays_per_s": round(n_rays / trav_per_frame / 1e6, 1) if trav_per_frame > 0 else None,
-                         "note": "counts from an untimed counting pass of the same frame (node visits and triangle tests the reference's traversal makes for these rays); "
-                                 "time = HIP events around every traversal launch of the timed steps"})
-        # HBM-side traffic of the same kernel from rocprofv3 PMC passes (separate runs of this script under `rocprofv3 --pmc`,
-        # scripts/pmc_profile.sh; summary committed under profiles/).  MI355X_MICROARCH.md prescribes doubling FETCH_SIZE for wide coalesced
-        # streaming reads; this kernel's reads are random 64-B lines (4 x dwordx4 per lane), for which a calibration run on a known byte count
-        # (scripts/calib/fetch_calib.hip, profiles/r01_fetch_calibration.txt) shows FETCH_SIZE to be exact — so it is used unscaled.
-        # Only used when it was collected on this exact workload.
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and roof.get("achieved"):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == [args.n_tris, args.res, args.spp, args.max_depth, args.seed] and world == 1 and args.material == "matte" and not args.instances:
-                    k = tj["traversal"]
-                    per_launch = (float(tj.get("fetch_scale", 1.0)) * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"]
-                    roof["traffic"] = int(per_launch)
-                    roof["traffic_note"] = ("HBM-side bytes per launch from rocprofv3 PMC (FETCH_SIZE + WRITE_SIZE, " + tj.get("source", "profiles/") + "; FETCH_SIZE calibrated exact "
-                                            "for this access pattern, " + tj.get("calibration", "") + "); algorithmic bytes are counted in the reference's 32-B-node format, "
-                                            "most of them are served by L2/MALL (L2 hit %.3f)" % (k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"])))
-            except Exception:
-                pass
+            trav_per_frame = (r["ext_s"] + r["sh_s"]) / args.steps
+            launches = r["launches"]
+            if trav_per_frame > 0 and launches > 0:
+                ach = bytes_per_frame / trav_per_frame / 1e9
+                avg_launch_s = trav_per_frame / launches
+                roof.update({"achieved": round(ach, 1), "frac_algorithmic": round(ach / HBM_PEAK_GBS, 4),
+                             "algorithmic_bytes_per_launch": bytes_per_frame // launches, "launches_per_step": launches,
+                             "avg_launch_ms": round(avg_launch_s * 1e3, 4), "rays_per_step": n_rays,
+                             "closest_hit": {"rays": cl["rays"], "ref_node_visits_per_ray": round(cl["ref_node_visits"] / max(cl["rays"], 1), 2),
+                                             "tri_tests_per_ray": round(cl["tri_tests"] / max(cl["rays"], 1), 2), "bytes_per_ray": round(bytes_cl / max(cl["rays"], 1), 1)},
+                             "any_hit": {"rays": ah["rays"], "ref_node_visits_per_ray": round(ah["ref_node_visits"] / max(ah["rays"], 1), 2),
+                                         "tri_tests_per_ray": round(ah["tri_tests"] / max(ah["rays"], 1), 2), "bytes_per_ray": round(bytes_ah / max(ah["rays"], 1), 1)},
+                             "kernel_Mrays_per_s": round(n_rays / trav_per_frame / 1e6, 1),
+                             "note": "achieved = algorithmic bytes (SURVEY 8d, reference-format 32-B nodes, counted by an untimed counting pass of the same frame) / HIP-event time "
+                                     "of every traversal launch of the timed steps; frac = memory-side PMC bytes / that time / peak when a PMC run of this workload is on file"})
+                # memory-side traffic of the same kernel from rocprofv3 PMC passes (separate runs of this script under `rocprofv3 --pmc`, scripts/pmc_profile.sh;
+                # MI355X_MICROARCH.md: FETCH_SIZE doubles for wide coalesced streaming reads only — this kernel reads random 64-B lines, for which the
+                # calibration run scripts/calib/fetch_calib.hip shows FETCH_SIZE exact, so fetch_scale is 1).  Only a run of this exact workload counts.
+                plain = world == 1 and args.material == "matte" and not args.instances
+                e, why = find_traffic(workload_key(n_tris, res, frame_spp, max_depth, args.seed)) if plain else (None, "PMC records are kept for the plain matte single-GPU workloads only")
+                if e is not None:
+                    k = e["traversal"]
+                    per_launch = (float(e.get("fetch_scale", 1.0)) * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"]
+                    mem_gbs = per_launch / avg_launch_s / 1e9
+                    roof.update({"traffic": int(per_launch), "achieved_memory_side": round(mem_gbs, 1), "frac": round(mem_gbs / HBM_PEAK_GBS, 4),
+                                 "frac_basis": "memory-side: traffic / avg_launch_ms / peak",
+                                 "l2_hit_rate": round(k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]), 4) if k.get("TCC_HIT") and k.get("TCC_MISS") else None,
+                                 "traffic_note": "bytes per launch leaving the L2s (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE over " + str(k["dispatches"]) + " traversal launches of one frame, " +
+                                                 e.get("source", "profiles/") + "; " + e.get("calibration", "") + ")"})
+                else:
+                    roof.update({"frac": round(ach / HBM_PEAK_GBS, 4), "frac_basis": "algorithmic (no PMC record of this workload: " + why + ")", "traffic_error": why})
         out["roofline"] = roof
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores, bounded sample ------------------------
@@ -233,18 +301,32 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle_binding import OracleScene
         cores = host_cores()
-        cspec = pbrt_hip.SceneSpec(n_tris=args.n_tris, seed=args.seed, xres=args.res, yres=args.res, spp=args.cpu_spp, max_depth=args.max_depth, material=args.material)
+        rays_per_spp = max(1, (r["rays"] // args.steps) // frame_spp)
+        cpu_spp = args.cpu_spp if args.cpu_spp > 0 else max(1, min(spp, round(150e6 / rays_per_spp)))
+        cspec = pbrt_hip.SceneSpec(n_tris=n_tris, seed=args.seed, xres=res, yres=res, spp=cpu_spp, max_depth=max_depth, material=args.material)
         orc = OracleScene()
         tb = time.time()
         pbrt_hip.capture_spec(cspec, orc, host, geometry=geometry, instances=args.instances)
         tb = time.time() - tb
-        _, _, ost, _ = orc.render_path_ex(max_depth=args.max_depth, threads=cores)
+        _, _, ost, _ = orc.render_path_ex(max_depth=max_depth, threads=cores)
         crays = ost.regular_rays + ost.shadow_rays
         out["cpu_baseline"] = {"value": round(crays / ost.render_seconds / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                               "sample": f"same scene and resolution at {args.cpu_spp} spp (the first {args.cpu_spp} Halton samples of every pixel): {crays} rays in "
+                               "sample": f"same scene and resolution at {cpu_spp} spp (the first {cpu_spp} Halton samples of every pixel): {crays} rays in "
                                          f"{ost.render_seconds:.2f} s render phase; single-threaded SAH build {tb:.2f} s excluded",
                                "gpu_over_cpu": round(out["value"] / (crays / ost.render_seconds / 1e6), 1)}
         orc.close()
+
+    # ---- N > 1, strong scaling: a short weak-scaling leg alongside (spp x N: every rank traces what one GPU traces at N = 1) ----------------
+    if world > 1 and scaling == "strong" and not args.no_weak_leg:
+        scene.close()
+        del tile_buf
+        torch.cuda.empty_cache()
+        wsteps = max(1, min(args.steps, 3))
+        scene, tile_buf, rw = run_leg(spp * world, wsteps, 1)
+        if rank == 0:
+            out["weak_alongside"] = {"value": round(rw["rays"] / rw["elapsed"] / 1e6, 2), "unit": "Mrays/s", "steps": wsteps, "warmup": 1,
+                                     "ms_per_step": round(rw["elapsed"] / wsteps * 1e3, 3), "spp": spp * world,
+                                     "note": "same scene and resolution at spp x N: per-GPU work equals the N = 1 frame's"}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

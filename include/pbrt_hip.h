@@ -261,6 +261,10 @@ int pbrt_hip_build_accel(PbrtHipScene*, int split_method, int max_prims_in_node)
 /* World bound of the built aggregate (BVHAccel::world_bound, bvh/mod.rs:161-167): {pmin[3], pmax[3]}. */
 int pbrt_hip_world_bound(const PbrtHipScene*, float out_bounds[6]);
 
+/* Measurement aid (not a reference interface): the built structure in the device layout.  out[0] interior nodes (64 B each: both children's boxes),
+ * out[1] leaf records (48 B each), out[2] / out[3] their bytes, out[4] leaves, out[5] depth, out[6] largest leaf, out[7] build time in microseconds. */
+int pbrt_hip_accel_stats(const PbrtHipScene*, uint64_t out[8]);
+
 /* ---- the hot path ---------------------------------------------------------------------------------------- */
 
 /* Primitive::intersect on a batch (accelerators/src/bvh/mod.rs:173-226): host buffers, synchronous. */

@@ -909,6 +909,11 @@ int pbrt_hip_set_sobol_tables(PbrtHipScene* s, const uint32_t* m32, size_t n32, 
 int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_node) {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
     if (split_method == 2) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: splitmethod 'middle' panics in the reference (quirk B6, sah.rs:67-76)");
+    // every DiffuseAreaLight belongs to a shape (api/src/lib.rs:783-812 creates them per triangle): one that no add_mesh claimed would be sampled
+    // through a primitive that does not exist
+    for (size_t i = 0; i < s->lights.size(); i++)
+        if (s->lights[i].type == PH_L_AREA && s->lights[i].prim == 0xFFFFFFFFu)
+            return set_err(s, PBRT_HIP_ERR_STATE, "build_accel: area light " + std::to_string(i) + " was never attached to a mesh (pbrt_hip_add_mesh first_area_light_id)");
     // material classes (shade-side sorting key): materials with the same sequence of lobe kinds share a class; at most 7 classes
     {
         std::vector<uint64_t> sigs;
@@ -1020,6 +1025,17 @@ int pbrt_hip_world_bound(const PbrtHipScene* s, float out[6]) {
     if (!s || !out) return PBRT_HIP_ERR_INVALID_ARG;
     if (!s->built) return PBRT_HIP_ERR_STATE;
     for (int k = 0; k < 3; k++) { out[k] = s->bvh.root_lo[k]; out[3 + k] = s->bvh.root_hi[k]; }
+    return PBRT_HIP_OK;
+}
+
+// measurement aid: sizes of the built acceleration structure in the device layout (bvh/common.rs:8-23 keeps the same tallies as statistics)
+int pbrt_hip_accel_stats(const PbrtHipScene* s, uint64_t out[8]) {
+    if (!s || !out) return PBRT_HIP_ERR_INVALID_ARG;
+    if (!s->built) return PBRT_HIP_ERR_STATE;
+    out[0] = s->bvh.nodes.size(); out[1] = s->bvh.tris.size();
+    out[2] = s->bvh.nodes.size() * sizeof(Node64); out[3] = s->bvh.tris.size() * sizeof(TriRec);
+    out[4] = s->bvh.leaf_nodes; out[5] = (uint64_t)s->bvh.max_depth; out[6] = s->bvh.max_leaf_prims;
+    out[7] = (uint64_t)(s->bvh.build_seconds * 1e6);
     return PBRT_HIP_OK;
 }
 

@@ -718,6 +718,7 @@ struct Wavefront {
     std::vector<int2> px_xy;
     int sb[4] = {0, 0, 0, 0}, ntx = 0, nty = 0, tile_size = 0, part = 0, parts = 0;
     uint32_t slot_w = 0, slot_h = 0;
+    int tiles_key[12] = {0}; bool tiles_valid = false;  // what the lists above (and their device copies) were built for
     DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats, d_cam, d_hit_lobes, d_tex_out;
     DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_recL, d_recpy, d_tilebuf, d_xyz, d_w;
     DevBuf d_vox_slot, d_sp_pool, d_sp_list, d_sp_ctr, d_sp_halton;  // SpatialLightDistribution tables (spatial.h)
@@ -740,21 +741,36 @@ void free_wavefront(PbrtHipScene* s) {
 
 static int sat_i(float v) { if (v != v) return 0; if (v >= 2147483648.0f) return 2147483647; if (v <= -2147483648.0f) return (int)0x80000000; return (int)v; }
 
-// Tile decomposition exactly as SamplerIntegrator::render / render_tile enumerate it (sampler_integrator.rs:252-259, 314-336)
+// Frame-wide tile grid: Film::get_sample_bounds (film/mod.rs:150-159), the tile counts of SamplerIntegrator::render (sampler_integrator.rs:252-259)
+// and the tile-buffer slot big enough for any tile's FilmTile pixel bounds.  Independent of which part of the tiles a rank renders.
+struct TileGrid { int sb[4]; int ntx, nty; uint32_t slot_w, slot_h; };
+static TileGrid tile_grid(const FilmRec& f, int tile_size) {
+    TileGrid g;
+    g.sb[0] = sat_i(std::floor((float)f.crop[0] + 0.5f - f.radius[0])); g.sb[1] = sat_i(std::floor((float)f.crop[1] + 0.5f - f.radius[1]));
+    g.sb[2] = sat_i(std::ceil((float)f.crop[2] - 0.5f + f.radius[0])); g.sb[3] = sat_i(std::ceil((float)f.crop[3] - 0.5f + f.radius[1]));
+    g.ntx = std::max((g.sb[2] - g.sb[0] + tile_size - 1) / tile_size, 0); g.nty = std::max((g.sb[3] - g.sb[1] + tile_size - 1) / tile_size, 0);
+    const int e_lo_x = sat_i(std::floor(0.5f + f.radius[0])), e_hi_x = sat_i(std::floor(f.radius[0] - 0.5f)) + 1;
+    const int e_lo_y = sat_i(std::floor(0.5f + f.radius[1])), e_hi_y = sat_i(std::floor(f.radius[1] - 0.5f)) + 1;
+    g.slot_w = (uint32_t)std::max(tile_size + e_lo_x + e_hi_x, 1); g.slot_h = (uint32_t)std::max(tile_size + e_lo_y + e_hi_y, 1);
+    return g;
+}
+
+// Tile decomposition exactly as SamplerIntegrator::render / render_tile enumerate it (sampler_integrator.rs:252-259, 314-336).
+// The tile and pixel lists of a rank depend only on (film window, filter radius, tile size, part, parts): they are kept on the device
+// between frames and rebuilt only when that key changes.
 static int setup_tiles(PbrtHipScene* s, int tile_size, int part, int parts) {
     if (!s->wf) s->wf = new Wavefront();
     Wavefront& w = *s->wf;
     const FilmRec& f = s->film;
-    // Film::get_sample_bounds (film/mod.rs:150-159)
-    int sb[4] = {sat_i(std::floor((float)f.crop[0] + 0.5f - f.radius[0])), sat_i(std::floor((float)f.crop[1] + 0.5f - f.radius[1])),
-                 sat_i(std::ceil((float)f.crop[2] - 0.5f + f.radius[0])), sat_i(std::ceil((float)f.crop[3] - 0.5f + f.radius[1]))};
-    const int ntx = std::max((sb[2] - sb[0] + tile_size - 1) / tile_size, 0), nty = std::max((sb[3] - sb[1] + tile_size - 1) / tile_size, 0);
+    const TileGrid g = tile_grid(f, tile_size);
+    int key[12] = {f.crop[0], f.crop[1], f.crop[2], f.crop[3], 0, 0, tile_size, part, parts, g.ntx, g.nty, 1};
+    std::memcpy(&key[4], &f.radius[0], 4); std::memcpy(&key[5], &f.radius[1], 4);
+    if (w.tiles_valid && std::memcmp(key, w.tiles_key, sizeof key) == 0) return PBRT_HIP_OK;
+    w.tiles_valid = false;
+    const int* sb = g.sb; const int ntx = g.ntx, nty = g.nty;
     w.tiles.clear(); w.px_xy.clear();
-    std::memcpy(w.sb, sb, sizeof(sb)); w.ntx = ntx; w.nty = nty; w.tile_size = tile_size; w.part = part; w.parts = parts;
-    // slot big enough for any tile's FilmTile pixel bounds
-    const int e_lo_x = sat_i(std::floor(0.5f + f.radius[0])), e_hi_x = sat_i(std::floor(f.radius[0] - 0.5f)) + 1;
-    const int e_lo_y = sat_i(std::floor(0.5f + f.radius[1])), e_hi_y = sat_i(std::floor(f.radius[1] - 0.5f)) + 1;
-    w.slot_w = (uint32_t)std::max(tile_size + e_lo_x + e_hi_x, 1); w.slot_h = (uint32_t)std::max(tile_size + e_lo_y + e_hi_y, 1);
+    std::memcpy(w.sb, sb, sizeof(w.sb)); w.ntx = ntx; w.nty = nty; w.tile_size = tile_size; w.part = part; w.parts = parts;
+    w.slot_w = g.slot_w; w.slot_h = g.slot_h;
     for (int t = part; t < ntx * nty; t += parts) {
         ph::TileInfo ti{};
         const int tx = t % ntx, ty = t / ntx;
@@ -773,20 +789,15 @@ static int setup_tiles(PbrtHipScene* s, int tile_size, int part, int parts) {
     if ((rc = ensure_buf(s, w.d_px, std::max<size_t>(w.px_xy.size(), 1) * sizeof(int2)))) return rc;
     if (!w.tiles.empty()) PH_CHECK(s, hipMemcpy(w.d_tiles.p, w.tiles.data(), w.tiles.size() * sizeof(ph::TileInfo), hipMemcpyHostToDevice));
     if (!w.px_xy.empty()) PH_CHECK(s, hipMemcpy(w.d_px.p, w.px_xy.data(), w.px_xy.size() * sizeof(int2), hipMemcpyHostToDevice));
+    std::memcpy(w.tiles_key, key, sizeof key); w.tiles_valid = true;
     return PBRT_HIP_OK;
 }
 
 static size_t tile_buffer_floats_for(const PbrtHipScene* s, int tile_size, int part, int parts) {
-    const FilmRec& f = s->film;
-    int sb[4] = {sat_i(std::floor((float)f.crop[0] + 0.5f - f.radius[0])), sat_i(std::floor((float)f.crop[1] + 0.5f - f.radius[1])),
-                 sat_i(std::ceil((float)f.crop[2] - 0.5f + f.radius[0])), sat_i(std::ceil((float)f.crop[3] - 0.5f + f.radius[1]))};
-    const int ntx = std::max((sb[2] - sb[0] + tile_size - 1) / tile_size, 0), nty = std::max((sb[3] - sb[1] + tile_size - 1) / tile_size, 0);
-    const int n = ntx * nty;
+    const TileGrid g = tile_grid(s->film, tile_size);
+    const int n = g.ntx * g.nty;
     const size_t local = n > part ? (size_t)(n - part + parts - 1) / parts : 0;
-    const int e_lo_x = sat_i(std::floor(0.5f + f.radius[0])), e_hi_x = sat_i(std::floor(f.radius[0] - 0.5f)) + 1;
-    const int e_lo_y = sat_i(std::floor(0.5f + f.radius[1])), e_hi_y = sat_i(std::floor(f.radius[1] - 0.5f)) + 1;
-    const size_t slot = (size_t)std::max(tile_size + e_lo_x + e_hi_x, 1) * (size_t)std::max(tile_size + e_lo_y + e_hi_y, 1);
-    return std::max<size_t>(local, 1) * slot * 4;
+    return std::max<size_t>(local, 1) * (size_t)g.slot_w * g.slot_h * 4;
 }
 
 static hipEvent_t get_event(PbrtHipScene* s, size_t i) {
@@ -1041,8 +1052,10 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
 }
 
 static int merge_tiles(PbrtHipScene* s, int tile_size, int parts, const void* const* d_bufs, float* out_xyz, float* out_weight) {
+    if (!s->wf) s->wf = new Wavefront();
     Wavefront& w = *s->wf;
     const FilmRec& f = s->film;
+    const TileGrid g = tile_grid(f, tile_size);  // the merge needs the frame-wide grid only, not a rank's tile list
     const int cw = f.crop[2] - f.crop[0], ch = f.crop[3] - f.crop[1];
     const size_t npx = (size_t)std::max(cw, 0) * (size_t)std::max(ch, 0);
     if (npx == 0) return PBRT_HIP_OK;
@@ -1051,8 +1064,8 @@ static int merge_tiles(PbrtHipScene* s, int tile_size, int parts, const void* co
     if ((rc = ensure_buf(s, w.d_w, npx * 4))) return rc;
     ph::MergeParams mp{};
     mp.film = f;
-    for (int i = 0; i < 4; i++) mp.sb[i] = w.sb[i];
-    mp.tile_size = tile_size; mp.ntx = w.ntx; mp.nty = w.nty; mp.parts = parts; mp.slot_w = w.slot_w; mp.slot_h = w.slot_h;
+    for (int i = 0; i < 4; i++) mp.sb[i] = g.sb[i];
+    mp.tile_size = tile_size; mp.ntx = g.ntx; mp.nty = g.nty; mp.parts = parts; mp.slot_w = g.slot_w; mp.slot_h = g.slot_h;
     for (int i = 0; i < parts; i++) mp.bufs[i] = (const float4*)d_bufs[i];
     mp.out_xyz = (float*)w.d_xyz.p; mp.out_w = (float*)w.d_w.p;
     hipLaunchKernelGGL(ph::merge_kernel, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, s->stream, mp);
@@ -1090,8 +1103,6 @@ int pbrt_hip_merge_tiles_device(PbrtHipScene* s, int tile_size, int tile_parts, 
     if (!s->have_film) return set_err(s, PBRT_HIP_ERR_STATE, "merge: set_film first");
     if (tile_size <= 0 || tile_parts <= 0 || tile_parts > 8) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "merge: bad partition");
     PH_CHECK(s, hipSetDevice(s->device));
-    int rc;
-    if ((rc = setup_tiles(s, tile_size, 0, tile_parts))) return rc;
     return merge_tiles(s, tile_size, tile_parts, d_tile_buffers, out_xyz, out_weight);
 }
 

@@ -143,6 +143,7 @@ class Binding:
             "mipmap_level_texels": (C.c_int, [vp, C.c_uint32, C.c_int, fp]),
             "set_traversal_counting": (C.c_int, [vp, C.c_int]),
             "get_traversal_counts": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+            "accel_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         }
         for name, (res, args) in self._optional.items():
             if hasattr(self.lib, prefix + name):
@@ -630,6 +631,13 @@ class Scene:
         self._chk(self.b.fn("get_traversal_counts")(self.h, c))
         return {"closest": {"nodes_passed": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2]), "ref_node_visits": int(c[2]) + 2 * int(c[0])},
                 "any_hit": {"nodes_passed": int(c[3]), "tri_tests": int(c[4]), "rays": int(c[5]), "ref_node_visits": int(c[6])}}
+
+    def accel_stats(self):
+        """Sizes of the built acceleration structure in the device layout (measurement aid)."""
+        c = (C.c_uint64 * 8)()
+        self._chk(self.b.fn("accel_stats")(self.h, c))
+        return {"interior_nodes": int(c[0]), "leaf_records": int(c[1]), "node_bytes": int(c[2]), "leaf_record_bytes": int(c[3]), "leaves": int(c[4]),
+                "depth": int(c[5]), "max_leaf_prims": int(c[6]), "build_seconds": int(c[7]) * 1e-6}
 
     def _film_hw(self):
         if self.film_shape is None:

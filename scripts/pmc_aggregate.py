@@ -33,7 +33,7 @@ for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0)):
         print(f"   -> FETCH_SIZE KB (x2 for wide streaming reads on gfx950, MI355X_MICROARCH.md): {c['FETCH_SIZE']:.0f}")
 
 
-# machine-readable summary of the memory-side counters (bench.py reads profiles/<round>_traffic.json)
+# machine-readable summary of the memory-side counters: one entry of profiles/<round>_traffic.json (bench.py matches it by `workload`)
 import json
 out_json = {}
 for k in agg:
@@ -44,9 +44,22 @@ for k in agg:
                                "TCC_HIT": c.get("TCC_HIT_sum"), "TCC_MISS": c.get("TCC_MISS_sum")}
 # all traversal launches of the frame together (round 0 = closest-hit only kernel, later rounds = the MIXED kernel)
 tk = [k for k in out_json if "traverse_kernel" in k]
+entry = {"kernels": out_json}
 if tk:
-    out_json["traversal"] = {"kernels": tk, "dispatches": sum(out_json[k]["dispatches"] for k in tk),
-                             "FETCH_SIZE_KB": sum(out_json[k]["FETCH_SIZE_KB"] for k in tk), "WRITE_SIZE_KB": sum(out_json[k]["WRITE_SIZE_KB"] for k in tk),
-                             "TCC_HIT": sum(out_json[k]["TCC_HIT"] or 0 for k in tk), "TCC_MISS": sum(out_json[k]["TCC_MISS"] or 0 for k in tk)}
+    entry["traversal"] = {"kernels": tk, "dispatches": sum(out_json[k]["dispatches"] for k in tk),
+                          "FETCH_SIZE_KB": sum(out_json[k]["FETCH_SIZE_KB"] for k in tk), "WRITE_SIZE_KB": sum(out_json[k]["WRITE_SIZE_KB"] for k in tk),
+                          "TCC_HIT": sum(out_json[k]["TCC_HIT"] or 0 for k in tk), "TCC_MISS": sum(out_json[k]["TCC_MISS"] or 0 for k in tk)}
+# the workload the passes ran: every pass is one `bench.py --steps 1 --warmup 0` run whose JSON line was kept next to the counters
+for f in sorted(glob.glob(os.path.join(out, "pass*.json"))):
+    try:
+        line = [l for l in open(f).read().splitlines() if l.startswith("{")][-1]
+        entry["workload"] = json.loads(line)["config"]["key"]
+        entry["workload_label"] = json.loads(line)["config"]["workload"]
+        break
+    except (IndexError, KeyError, ValueError):
+        continue
+entry["fetch_scale"] = 1.0
+entry["calibration"] = ("FETCH_SIZE used unscaled: a calibration kernel with this kernel's access pattern (random 64-B records, 4 x dwordx4 per lane) reports 0.9995 of the "
+                        "known bytes, profiles/r01_fetch_calibration.txt; the x2 of MI355X_MICROARCH.md applies to wide coalesced streaming reads")
 with open(os.path.join(out, "traffic.json"), "w") as f:
-    json.dump(out_json, f, indent=1)
+    json.dump(entry, f, indent=1)

@@ -17,28 +17,31 @@ def _last_json(out):
 
 
 def test_two_ranks_one_gpu_film_identical():
-    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--spp", "4", "--res", "200", "--n-tris", "20000"]
+    common = ["--config", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--spp", "4", "--res", "200", "--n-tris", "20000"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", "strong"] + common, capture_output=True, text=True, env=env, timeout=900)
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common, capture_output=True, text=True, env=env, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     a, b = _last_json(one.stdout), _last_json(two.stdout)
     assert b["n_gpus"] == 2 and a["n_gpus"] == 1
+    assert b["scaling"] == "strong"   # the N > 1 default: the N = 1 frame split over the ranks
     assert a["film_sha256"] == b["film_sha256"]
     assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+    # the short weak-scaling leg reported alongside renders spp x N
+    assert b["weak_alongside"]["spp"] == 8 and b["weak_alongside"]["value"] > 0
 
 
 def test_two_ranks_weak_scaling_doubles_the_samples():
-    """Default N>1 mode: spp x N, so per-rank work equals the one-rank frame; the merged 2-rank frame equals a one-rank render of
+    """--scaling weak: spp x N, so per-rank work equals the one-rank frame; the merged 2-rank frame equals a one-rank render of
     the same 2x-spp frame."""
-    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--res", "128", "--n-tris", "5000"]
+    common = ["--config", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--res", "128", "--n-tris", "5000"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spp", "8"] + common, capture_output=True, text=True, env=env, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29534",
-                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--spp", "4"] + common, capture_output=True, text=True, env=env, timeout=900)
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", "weak", "--spp", "4"] + common, capture_output=True, text=True, env=env, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     a, b = _last_json(one.stdout), _last_json(two.stdout)
     assert b["scaling"] == "weak" and b["n_gpus"] == 2
