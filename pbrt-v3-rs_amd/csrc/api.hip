@@ -224,7 +224,7 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
     ph::TravParams p = p_in;
     p.spill = (uint2*)s->d_spill.p; p.total_threads = s->trav_blocks * PH_TRAV_BLOCK; p.error_flag = (uint32_t*)s->d_error.p;
     p.counts = (unsigned long long*)s->d_counts.p;
-    { static int bt = -1; if (bt < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_BATCH"); bt = e ? std::atoi(e) : PH_BATCH; if (bt < 64) bt = 64; } p.batch = (uint32_t)bt; }
+    { static int bt = -1; if (bt < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_BATCH"); bt = e ? std::atoi(e) : PH_BATCH; if (bt != 64 && bt != 128 && bt != 256 && bt != 512 && bt != 1024) bt = 64; } p.batch = (uint32_t)bt; }
     const dim3 g(blocks), b(PH_TRAV_BLOCK);
 #define PH_LAUNCH3(cnt, lm, rm, ld, ns, inst)                                                                                          \
     do {                                                                                                                              \

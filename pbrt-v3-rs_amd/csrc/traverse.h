@@ -45,6 +45,13 @@ struct TravParams {
     unsigned long long* counts;  // COUNT builds only: [0] interior nodes whose box test passed, [1] triangle tests, [2] rays
     // MIXED kernels only: one launch walks the closest-hit queue (rays/out/n_ptr) and then the any-hit queue below
     const RayIn* rays2; uint8_t* out2; const uint32_t* n2_ptr;
+    // optional (wavefront rounds): `order` = the queue positions regrouped by ray-origin cell (raysort.h), walked instead of 0, 1, 2, ...
+    const uint32_t* order;
+    // optional: n_heads > 1 queue heads, head h serving the head_chunk-ray chunks c with c % n_heads == h.  A block starts on head
+    // blockIdx % n_heads — blocks b and b + 8 share an XCD and its L2 (MI355X_MICROARCH.md) — so with chunks about as long as an XCD's share of the
+    // rays in flight (32 CUs x 6 blocks x 256 lanes = 48 k) one L2 serves ONE contiguous stretch of the (binned) queue instead of an eighth of
+    // every stretch, and all heads still advance through the queue at the same pace (no per-segment tails).  heads[16 * h]; head_chunk % batch == 0.
+    uint32_t* heads; uint32_t n_heads, head_chunk;
 };
 
 struct RayState {
@@ -207,6 +214,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
     bool has_ray = false;
     uint32_t batch_next = 0, batch_end = 0;  // wave-uniform
     bool exhausted = false;                  // wave-uniform: the global queue has nothing left
+    uint32_t head_cur = p.n_heads > 1u ? blockIdx.x % p.n_heads : 0u, heads_dry = 0u;  // wave-uniform: the head this wave pulls from, heads found empty
     uint32_t ray_index = 0;
     RayState r;
     uint32_t cur = PH_INVALID_REF;           // interior node index, or PH_LEAF_BIT | index of the NEXT TriRec to test
@@ -235,7 +243,11 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
         const int floor_sp = (INST && in_inst) ? inst_sp : 0;
         while (sp > floor_sp) {
             sp--;
-            uint2 e = (sp < LDS_DEPTH) ? lds_stack[sp][tid] : p.spill[(size_t)(sp - LDS_DEPTH) * p.total_threads + gtid];
+            // two loads in two address spaces, kept apart by (empty, distinct) asm statements: merged into one load through a generic pointer, the
+            // LDS-aperture test fails instruction selection on this toolchain (ROCm 7.2, gfx950: "Operand has incorrect register class", V_CMP_NE_U32 against src_shared_base)
+            uint2 e;
+            if (sp < LDS_DEPTH) { e = lds_stack[sp][tid]; asm volatile("; stack entry from LDS" : "+v"(e.x), "+v"(e.y)); }
+            else { e = p.spill[(size_t)(sp - LDS_DEPTH) * p.total_threads + gtid]; asm volatile("; stack entry from the spill region" : "+v"(e.x), "+v"(e.y)); }
             if (COUNT && ah) c_visits++;  // the reference fetches and box-tests every node it pops
             if (__uint_as_float(e.y) < r.t_max) return e.x;
         }
@@ -249,17 +261,31 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (n_idle >= (uint32_t)REFILL_MIN || n_idle == 64u || (n_idle && __ballot(has_ray && cur != PH_INVALID_REF) == 0ull)) {
                 if (batch_next == batch_end && !exhausted) {
-                    uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(p.counter, p.batch);
-                    b = __shfl(b, 0);
-                    if (b >= n_rays) exhausted = true;
-                    else { batch_next = b; batch_end = (b + p.batch < n_rays) ? b + p.batch : n_rays; }
+                    if (p.n_heads > 1u) {  // one attempt per pass of the outer loop: a drained head sends the wave to the next one
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(p.heads + 16u * head_cur, p.batch);
+                        b = __shfl(b, 0);
+                        // position b of head h's chunk list -> queue position
+                        const uint32_t chunk = b / p.head_chunk;
+                        const uint64_t q = ((uint64_t)chunk * p.n_heads + head_cur) * p.head_chunk + (b - chunk * p.head_chunk);
+                        if (q < (uint64_t)n_rays) { batch_next = (uint32_t)q; batch_end = ((uint32_t)q + p.batch < n_rays) ? (uint32_t)q + p.batch : n_rays; }
+                        else {
+                            heads_dry++; head_cur = head_cur + 1u == p.n_heads ? 0u : head_cur + 1u;
+                            if (heads_dry >= p.n_heads) exhausted = true;
+                        }
+                    } else {
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(p.counter, p.batch);
+                        b = __shfl(b, 0);
+                        if (b >= n_rays) exhausted = true;
+                        else { batch_next = b; batch_end = (b + p.batch < n_rays) ? b + p.batch : n_rays; }
+                    }
                 }
                 const uint32_t avail = batch_end - batch_next;
                 if (avail) {
                     const uint32_t rank = (uint32_t)__popcll(idle & lane_lt);
                     if (!has_ray && rank < avail) {
-                        ray_index = batch_next + rank;
+                        ray_index = p.order ? p.order[batch_next + rank] : batch_next + rank;
                         if (MIXED) ah = ray_index >= n_first;
                         const float4* rp = reinterpret_cast<const float4*>((MIXED && ah) ? p.rays2 + (ray_index - n_first) : p.rays + ray_index);
                         const float4 a = rp[0], b = rp[1];

@@ -21,6 +21,7 @@
 #include "spatial.h"
 #include "bsdf_general.h"
 #include "texture.h"
+#include "raysort.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -65,6 +66,8 @@ struct WfParams {
     const CameraRec* cam_dev; uint32_t textured;
     LobeRec* hit_lobes;  // general-BSDF kernel only: PH_HIT_LOBES slots per thread of the grid
     TexOut* tex_out;     // texture pass -> shade pass, one record per path of the chunk
+    // ray binning between rounds (raysort.h): the bin key of every ray the shade pass emits, next to the ray
+    RaySortGrid sort_grid; uint32_t* keys_cl; uint32_t* keys_sh;
 };
 
 PH_DEV uint32_t wave_alloc(uint32_t* ctr, bool want) {
@@ -551,16 +554,22 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
             if (want_ext) {
                 ext_slot = cl_slot;
                 float4* d = reinterpret_cast<float4*>(rays_out + ext_slot);
-                d[0] = stage[0][0][tid]; d[1] = stage[0][1][tid];
+                const float4 ro = stage[0][0][tid], rdv = stage[0][1][tid];
+                d[0] = ro; d[1] = rdv;
+                if (w.sort_grid.mode) w.keys_cl[ext_slot] = ray_sort_key(w.sort_grid, ro.x, ro.y, ro.z, rdv.x, rdv.y, rdv.z);
             }
             if (want_mis) {
                 mis_slot = cl_slot + (want_ext ? 1u : 0u);
                 float4* d = reinterpret_cast<float4*>(rays_out + mis_slot);
-                d[0] = stage[1][0][tid]; d[1] = stage[1][1][tid];
+                const float4 ro = stage[1][0][tid], rdv = stage[1][1][tid];
+                d[0] = ro; d[1] = rdv;
+                if (w.sort_grid.mode) w.keys_cl[mis_slot] = ray_sort_key(w.sort_grid, ro.x, ro.y, ro.z, rdv.x, rdv.y, rdv.z);
             }
             if (want_sh) {
                 float4* d = reinterpret_cast<float4*>(w.rays_sh + sh_slot);
-                d[0] = stage[2][0][tid]; d[1] = stage[2][1][tid];
+                const float4 ro = stage[2][0][tid], rdv = stage[2][1][tid];
+                d[0] = ro; d[1] = rdv;
+                if (w.sort_grid.mode) w.keys_sh[sh_slot] = ray_sort_key(w.sort_grid, ro.x, ro.y, ro.z, rdv.x, rdv.y, rdv.z);
             }
             if (still_live) {
                 live_out[lv_slot] = pid;
@@ -722,6 +731,7 @@ struct Wavefront {
     DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats, d_cam, d_hit_lobes, d_tex_out;
     DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_recL, d_recpy, d_tilebuf, d_xyz, d_w;
     DevBuf d_vox_slot, d_sp_pool, d_sp_list, d_sp_ctr, d_sp_halton;  // SpatialLightDistribution tables (spatial.h)
+    DevBuf d_order, d_sort_bins, d_heads, d_keys_cl, d_keys_sh;  // ray binning between rounds (raysort.h), per-XCD queue heads
     std::vector<hipEvent_t> events;
 };
 
@@ -732,7 +742,7 @@ void free_wavefront(PbrtHipScene* s) {
     if (!w) return;
     for (DevBuf* b : {&w->d_tiles, &w->d_px, &w->d_rays_cl[0], &w->d_rays_cl[1], &w->d_hits, &w->d_rays_sh, &w->d_occ, &w->d_live[0], &w->d_live[1], &w->d_ctr,
                       &w->d_stats, &w->d_cam, &w->d_hit_lobes, &w->d_tex_out, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
-                      &w->d_vox_slot, &w->d_sp_pool, &w->d_sp_list, &w->d_sp_ctr, &w->d_sp_halton})
+                      &w->d_vox_slot, &w->d_sp_pool, &w->d_sp_list, &w->d_sp_ctr, &w->d_sp_halton, &w->d_order, &w->d_sort_bins, &w->d_heads, &w->d_keys_cl, &w->d_keys_sh})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : w->events) (void)hipEventDestroy(e);
     delete w;
@@ -910,6 +920,26 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     if ((rc = ensure_buf(s, w.d_recpy, (size_t)n_px * spp * 4))) return rc;
 
     if ((rc = ensure_traversal_workspace(s))) return rc;
+    // ray binning between rounds and per-XCD queue heads (raysort.h, traverse.h)
+    static const int sort_mode = []() { const char* e = std::getenv("PBRT_HIP_SORT_RAYS"); int v = e ? std::atoi(e) : 1; return (v < 0 || v > 2) ? 1 : v; }();
+    static const int n_heads = []() { const char* e = std::getenv("PBRT_HIP_TRAV_HEADS"); int v = e ? std::atoi(e) : 8; return (v < 1 || v > 8) ? 8 : v; }();
+    static const int head_chunk = []() { const char* e = std::getenv("PBRT_HIP_HEAD_CHUNK"); int v = e ? std::atoi(e) : 49152; return (v < 1024 || v > (1 << 24) || (v & 1023)) ? 49152 : v; }();  // a multiple of every batch size
+    ph::RaySortParams sortp{};
+    ph::RaySortGrid sort_grid{};
+    if (sort_mode) {
+        if ((rc = ensure_buf(s, w.d_order, 3 * B * 4))) return rc;
+        if ((rc = ensure_buf(s, w.d_keys_cl, 2 * B * 4))) return rc;
+        if ((rc = ensure_buf(s, w.d_keys_sh, B * 4))) return rc;
+        if ((rc = ensure_buf(s, w.d_sort_bins, 2 * PH_SORT_KEYS * 4))) return rc;
+        sortp.order = (uint32_t*)w.d_order.p; sortp.bin_start = (uint32_t*)w.d_sort_bins.p; sortp.bin_cursor = sortp.bin_start + PH_SORT_KEYS;
+        sortp.keys_cl = (const uint32_t*)w.d_keys_cl.p; sortp.keys_sh = (const uint32_t*)w.d_keys_sh.p;
+        sort_grid.mode = (uint32_t)sort_mode;
+        for (int k = 0; k < 3; k++) {
+            const float ext = s->bvh.root_hi[k] - s->bvh.root_lo[k];
+            sort_grid.lo[k] = s->bvh.root_lo[k]; sort_grid.scale[k] = ext > 0.0f ? 1.0f / ext : 0.0f;
+        }
+    }
+    if (n_heads > 1 && (rc = ensure_buf(s, w.d_heads, (size_t)(n_iter_cap + 2) * 8 * 64))) return rc;
 
     ph::WfParams wp{};
     wp.cam = s->cam; wp.sp = s->sampler;
@@ -929,6 +959,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     wp.s_L = (float4*)w.d_sL.p; wp.s_beta = (float4*)w.d_sbeta.p; wp.s_A = (float4*)w.d_sA.p; wp.s_f2 = (float4*)w.d_sf2.p;
     wp.s_bold = (float4*)w.d_sbold.p; wp.s_idx = (uint4*)w.d_sidx.p;
     wp.rec_L = (float4*)w.d_recL.p; wp.rec_py = (float*)w.d_recpy.p;
+    wp.sort_grid = sort_grid; wp.keys_cl = (uint32_t*)w.d_keys_cl.p; wp.keys_sh = (uint32_t*)w.d_keys_sh.p;
 
     if (spatial) { if ((rc = setup_spatial(s, wp.spatial))) return rc; }
     PH_CHECK(s, hipMemsetAsync(w.d_stats.p, 0, sizeof(ph::DevStats), s->stream));
@@ -970,6 +1001,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
         const uint32_t cs = std::min(chunk_spp, spp - s0);
         wp.chunk_spp = cs; wp.s0 = s0; wp.B = n_px * cs; wp.identity_slots = identity ? 1u : 0u;
         PH_CHECK(s, hipMemsetAsync(w.d_ctr.p, 0, (size_t)(n_iter_cap + 2) * sizeof(ph::IterCounters), s->stream));
+        if (n_heads > 1) PH_CHECK(s, hipMemsetAsync(w.d_heads.p, 0, (size_t)(n_iter_cap + 2) * 8 * 64, s->stream));
         if (identity) hipLaunchKernelGGL(ph::preset_counters_kernel, dim3(1), dim3(1), 0, s->stream, wp.ctr, wp.stats, wp.B);
         if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::raygen_kernel, dim3((wp.B + 255) / 256), dim3(256), 0, s->stream, s->ds, wp); }))) return rc;
         int iters_run = 0;
@@ -985,8 +1017,19 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
             iters_run = it + 1;
             ph::TravParams tp{};
             tp.rays = wp.rays_cl[it & 1]; tp.out = wp.hits_cl; tp.n = 0; tp.n_ptr = &c->n_cl; tp.counter = &c->head_cl;
+            if (n_heads > 1) { tp.heads = (uint32_t*)w.d_heads.p + (size_t)it * 8 * 16; tp.n_heads = (uint32_t)n_heads; tp.head_chunk = (uint32_t)head_chunk; }
             if (it > 0 && !split_traversal) {  // this round's extension rays and the shadow rays of the previous vertices: one launch, one tail
                 tp.rays2 = wp.rays_sh; tp.out2 = wp.occ; tp.n2_ptr = &c->n_sh;
+                if (sort_mode) {  // regroup the round's rays by origin cell; camera rays (round 0) leave raygen in pixel order already
+                    sortp.n_cl = &c->n_cl; sortp.n_sh = &c->n_sh;
+                    if ((rc = timed(3, [&]() {
+                            (void)hipMemsetAsync(sortp.bin_start, 0, PH_SORT_KEYS * 4, s->stream);
+                            hipLaunchKernelGGL(ph::raysort_hist_kernel, dim3(1024), dim3(PH_SORT_BLOCK), 0, s->stream, sortp);
+                            hipLaunchKernelGGL(ph::raysort_scan_kernel, dim3(1), dim3(1024), 0, s->stream, sortp);
+                            hipLaunchKernelGGL(ph::raysort_scatter_kernel, dim3(1024), dim3(PH_SORT_BLOCK), 0, s->stream, sortp);
+                        }))) return rc;
+                    tp.order = sortp.order;
+                }
                 if ((rc = timed(0, [&]() { launch_traverse_kernel(s, 2, s->trav_blocks, tp); }))) return rc;
             } else {
                 if ((rc = timed(0, [&]() { launch_traverse_kernel(s, 0, s->trav_blocks, tp); }))) return rc;
@@ -1043,9 +1086,9 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
         float ms = 0;
         PH_CHECK(s, hipEventElapsedTime(&ms, e_begin, e_end));
         out_stats->render_seconds = ms * 1e-3;
-        double acc[3] = {0, 0, 0};
+        double acc[4] = {0, 0, 0, 0};
         for (const Span& sp : spans) { float m = 0; if (hipEventElapsedTime(&m, sp.a, sp.b) == hipSuccess) acc[sp.kind] += m * 1e-3; }
-        out_stats->extend_seconds = acc[0]; out_stats->shadow_seconds = acc[1]; out_stats->shade_seconds = acc[2];
+        out_stats->extend_seconds = acc[0]; out_stats->shadow_seconds = acc[1]; out_stats->shade_seconds = acc[2] + acc[3];  // ray binning counts as non-traversal time
         for (const Span& sp : spans) { if (sp.kind == 0) out_stats->extend_launches++; else if (sp.kind == 1) out_stats->shadow_launches++; }
     }
     return PBRT_HIP_OK;
