@@ -5,9 +5,10 @@
  *
  * Every entry point below names the reference interface it replaces (path:line relative to the reference repo).
  * Plain C types only: pointers + sizes, caller-allocated outputs, int status codes.  No callbacks, no C++ or
- * torch types, no exceptions across the boundary.  A handle is NOT re-entrant (one in-flight call per handle);
- * one handle drives exactly one GPU (one process per GPU; multi-GPU = one handle per rank + a film-tile gather
- * done by the host with RCCL).
+ * torch types, no exceptions across the boundary.  A handle is NOT re-entrant (one in-flight call per handle).
+ * pbrt_hip_scene_create gives a handle that drives one GPU (one process per GPU: multi-GPU = one handle per rank, the ranks' film
+ * tiles gathered by the host); pbrt_hip_scene_create_multi gives one handle that drives several GPUs of a node
+ * from one process, the library gathering the film tiles itself over RCCL.
  *
  * Inputs are borrowed for the duration of the call and copied.  All floats are IEEE binary32 ("Float = f32",
  * core/src/pbrt/common.rs:13).  Matrices are row-major float[16], m[r*4+c] (core/src/geometry/matrix4x4.rs:13).
@@ -79,6 +80,18 @@ typedef struct PbrtHipStats {
 /* ---- lifetime ------------------------------------------------------------------------------------------- */
 int pbrt_hip_device_count(void);                          /* <0 on HIP failure */
 PbrtHipScene* pbrt_hip_scene_create(int device_ordinal);  /* NULL if no usable device */
+/* One handle over several devices of this node (scene_create(device_ordinals, n_devices); NULL / 0 = every visible device).  It replaces
+ * the reference's tile loop over worker threads (core/src/integrator/sampler_integrator.rs:254-296): capture calls act on the handle, pbrt_hip_render_path
+ * replicates the scene into every device's HBM, deals the handle's 16x16 tiles round-robin to the devices (tile enumeration :254-259, :314-336), gathers the
+ * per-tile film buffers on the first device — ncclSend / ncclRecv over xGMI, the path's one exchange step; RCCL is loaded when first needed — and merges
+ * them there in increasing tile index (Film::merge_film_tile, core/src/film/mod.rs:220-248): the film equals the one-device film bit for bit.
+ * An ordinal may repeat (contexts sharing a GPU, device-to-device copies instead of RCCL): a rehearsal aid for boxes with one GPU.
+ * The batch and *_tiles_device entry points of such a handle act on its first device only. */
+PbrtHipScene* pbrt_hip_scene_create_multi(const int* device_ordinals, int n_devices);
+int pbrt_hip_scene_devices(const PbrtHipScene*, int* out_ordinals, int capacity);   /* returns the number of devices behind the handle */
+/* Self-test of the RCCL binding on the handle's devices (a one-rank communicator on a single-device handle): every device sends n_floats floats to the
+ * first one through the same ncclSend / ncclRecv group the film-tile gather uses; out_wrong = floats that arrived wrong. */
+int pbrt_hip_selftest_rccl_gather(PbrtHipScene*, uint32_t n_floats, uint64_t* out_wrong);
 void pbrt_hip_scene_destroy(PbrtHipScene*);
 const char* pbrt_hip_last_error(const PbrtHipScene*);     /* NUL-terminated, owned by the library; NULL handle -> global */
 

@@ -341,6 +341,7 @@ PbrtHipScene* pbrt_hip_scene_create(int device_ordinal) {
 
 void pbrt_hip_scene_destroy(PbrtHipScene* s) {
     if (!s) return;
+    free_multi(s);  // the other devices' contexts of a multi-device handle
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
     free_wavefront(s);

@@ -11,7 +11,8 @@
 // A counting sort without global atomics per ray: every block histograms its contiguous slice of the queue in LDS and adds the
 // non-empty bins to the global tallies (one atomic per block and bin), a single block scans the 8192 tallies, and the second
 // pass repeats the LDS histogram, claims the block's share of each bin with one atomic per bin and ranks its rays inside LDS.
-// The order inside a bin is whatever the atomics give; it does not matter.
+// The order inside a bin is whatever the atomics give; it does not matter.  (Tried and dropped: one LDS atomic per distinct key of a wave, found with a
+// ballot loop — a wave of the path-ordered queue holds many distinct keys, the loop cost more than the plain atomics: binning 28 -> 70 ms per configs[2] frame.)
 #pragma once
 #include "traverse.h"
 
@@ -56,27 +57,6 @@ PH_DEV uint32_t raysort_key_at(const RaySortParams& p, uint32_t i, uint32_t n_cl
     return i < n_cl ? p.keys_cl[i] : PH_SORT_BINS + p.keys_sh[i - n_cl];
 }
 
-// LDS tally of a key shared by many lanes of a wave (the queues arrive in path order: neighbouring rays leave neighbouring surface points, so a wave
-// usually holds one to three distinct keys): one LDS atomic per distinct key instead of 64 serialised ones on one address.  Returns this lane's rank
-// among the wave's lanes with the same key plus the counter's value before the wave's addition.
-PH_DEV uint32_t wave_key_add(uint32_t* h, uint32_t key, bool valid) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t result = 0u;
-    uint64_t todo = __ballot(valid);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t k = __shfl(key, leader);
-        const uint64_t m = __ballot(valid && key == k);
-        uint32_t base = 0u;
-        if ((int)lane == leader) base = atomicAdd(&h[k], (uint32_t)__popcll(m));
-        base = __shfl(base, leader);
-        if (valid && key == k) result = base + (uint32_t)__popcll(m & lane_lt);
-        todo &= ~m;
-    }
-    return result;
-}
-
 PH_DEV void raysort_slice(const RaySortParams& p, uint32_t n, uint32_t& lo, uint32_t& hi) {
     const uint32_t per = (((n + gridDim.x - 1u) / gridDim.x) + PH_SORT_BLOCK - 1u) & ~(uint32_t)(PH_SORT_BLOCK - 1u);
     lo = blockIdx.x * per; hi = lo + per < n ? lo + per : n;
@@ -91,11 +71,7 @@ __global__ __launch_bounds__(PH_SORT_BLOCK) void raysort_hist_kernel(RaySortPara
     if (lo >= hi) return;
     for (uint32_t k = threadIdx.x; k < PH_SORT_KEYS; k += PH_SORT_BLOCK) h[k] = 0u;
     __syncthreads();
-    for (uint32_t i0 = lo; i0 < hi; i0 += PH_SORT_BLOCK) {  // whole waves take every trip: wave_key_add is a wave-wide operation
-        const uint32_t i = i0 + threadIdx.x;
-        const bool valid = i < hi;
-        wave_key_add(h, valid ? raysort_key_at(p, i, n_cl) : 0u, valid);
-    }
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += PH_SORT_BLOCK) atomicAdd(&h[raysort_key_at(p, i, n_cl)], 1u);
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < PH_SORT_KEYS; k += PH_SORT_BLOCK)
         if (h[k]) atomicAdd(&p.bin_start[k], h[k]);
@@ -128,11 +104,7 @@ __global__ __launch_bounds__(PH_SORT_BLOCK) void raysort_scatter_kernel(RaySortP
     if (lo >= hi) return;
     for (uint32_t k = threadIdx.x; k < PH_SORT_KEYS; k += PH_SORT_BLOCK) h[k] = 0u;
     __syncthreads();
-    for (uint32_t i0 = lo; i0 < hi; i0 += PH_SORT_BLOCK) {
-        const uint32_t i = i0 + threadIdx.x;
-        const bool valid = i < hi;
-        wave_key_add(h, valid ? raysort_key_at(p, i, n_cl) : 0u, valid);
-    }
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += PH_SORT_BLOCK) atomicAdd(&h[raysort_key_at(p, i, n_cl)], 1u);
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < PH_SORT_KEYS; k += PH_SORT_BLOCK) {
         const uint32_t c = h[k];
@@ -140,12 +112,9 @@ __global__ __launch_bounds__(PH_SORT_BLOCK) void raysort_scatter_kernel(RaySortP
         h[k] = 0u;
     }
     __syncthreads();
-    for (uint32_t i0 = lo; i0 < hi; i0 += PH_SORT_BLOCK) {
-        const uint32_t i = i0 + threadIdx.x;
-        const bool valid = i < hi;
-        const uint32_t key = valid ? raysort_key_at(p, i, n_cl) : 0u;
-        const uint32_t rank = wave_key_add(h, key, valid);
-        if (valid) p.order[base[key] + rank] = i;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += PH_SORT_BLOCK) {
+        const uint32_t key = raysort_key_at(p, i, n_cl);
+        p.order[base[key] + atomicAdd(&h[key], 1u)] = i;
     }
 }
 

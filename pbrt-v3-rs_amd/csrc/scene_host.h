@@ -13,11 +13,9 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
-struct PbrtHipScene {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-
+// Everything the capture calls record and build_accel derives, i.e. the part of a scene that does not belong to a device.  A multi-device handle
+// (pbrt_hip_scene_create_multi) copies it as a whole to its per-device contexts (multi.hip).
+struct SceneHostState {
     // ---- captured scene (host copies, add_mesh order) ----------------------------------------------------------------
     std::vector<float> P, N, S, UV;  // N/S/UV are vertex-aligned with P when any mesh has them (zero-filled otherwise)
     bool any_n = false, any_s = false, any_uv = false;
@@ -60,6 +58,15 @@ struct PbrtHipScene {
     // ---- acceleration structure ---------------------------------------------------------------------------------------
     phost::BuildOutput bvh;
     float world_center[3] = {0, 0, 0}, world_radius = 1.0f;
+};
+
+struct MultiDevice;  // multi.hip
+
+struct PbrtHipScene : SceneHostState {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    MultiDevice* multi = nullptr;    // non-null on a handle made by pbrt_hip_scene_create_multi: the other devices' contexts and the exchange state
 
     // ---- device residency ---------------------------------------------------------------------------------------------
     DeviceScene ds{};
@@ -92,6 +99,18 @@ int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_ou
 void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph::TravParams& p);  // 0 closest, 1 any hit, 2 both (MIXED)
 int ensure_traversal_workspace(PbrtHipScene* s);
 void free_wavefront(PbrtHipScene* s);
+// wavefront.hip: the renderer's building blocks, shared with the multi-device driver (multi.hip)
+#define PH_MAX_TILE_PARTS 64
+int check_render_args(PbrtHipScene* s, int max_depth, int light_strategy, const int* pixel_bounds, int tile_size, int part, int parts);
+size_t tile_buffer_floats_for(const PbrtHipScene* s, int tile_size, int part, int parts);
+int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size, int part, int parts, void* d_tile_buffer,
+                 PbrtHipStats* out_stats);
+int merge_tiles(PbrtHipScene* s, int tile_size, int parts, const void* const* d_bufs, float* out_xyz, float* out_weight);
+DevBuf& tile_buffer_of(PbrtHipScene* s);  // the handle's own tile buffer (wavefront workspace)
+// multi.hip
+int render_path_multi(PbrtHipScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size, int tile_part, int tile_parts,
+                      float* out_xyz, float* out_weight, PbrtHipStats* out_stats);
+void free_multi(PbrtHipScene* s);
 }  // namespace phost
 
 #define PH_CHECK(s, call)                                              \

@@ -658,7 +658,7 @@ struct MergeParams {
     FilmRec film;
     int32_t sb[4]; int32_t tile_size, ntx, nty, parts;
     uint32_t slot_w, slot_h;
-    const float4* bufs[8];
+    const float4* bufs[PH_MAX_TILE_PARTS];
     float* out_xyz; float* out_w;
 };
 PH_DEV void tile_pixel_bounds(const FilmRec& f, const int tb[4], int pb[4]) {  // Film::get_film_tile (film/mod.rs:182-198)
@@ -803,7 +803,7 @@ static int setup_tiles(PbrtHipScene* s, int tile_size, int part, int parts) {
     return PBRT_HIP_OK;
 }
 
-static size_t tile_buffer_floats_for(const PbrtHipScene* s, int tile_size, int part, int parts) {
+size_t tile_buffer_floats_for(const PbrtHipScene* s, int tile_size, int part, int parts) {
     const TileGrid g = tile_grid(s->film, tile_size);
     const int n = g.ntx * g.nty;
     const size_t local = n > part ? (size_t)(n - part + parts - 1) / parts : 0;
@@ -816,11 +816,11 @@ static hipEvent_t get_event(PbrtHipScene* s, size_t i) {
     return w.events[i];
 }
 
-static int check_render_args(PbrtHipScene* s, int max_depth, int light_strategy, const int* pixel_bounds, int tile_size, int part, int parts) {
+int check_render_args(PbrtHipScene* s, int max_depth, int light_strategy, const int* pixel_bounds, int tile_size, int part, int parts) {
     if (!s || !pixel_bounds) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: null argument");
     if (!s->built || !s->have_camera || !s->have_film || !s->have_sampler)
         return set_err(s, PBRT_HIP_ERR_STATE, "render: camera, film, sampler and build_accel must be set first");
-    if (tile_size <= 0 || parts <= 0 || parts > 8 || part < 0 || part >= parts) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: bad tile partition");
+    if (tile_size <= 0 || parts <= 0 || parts > PH_MAX_TILE_PARTS || part < 0 || part >= parts) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: bad tile partition");
     if (max_depth < 0 || max_depth > 200) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: max_depth out of range");
     if (light_strategy < 0 || light_strategy > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: bad light strategy");
     if (s->sampler.kind == 1 && s->sobol32.empty()) return set_err(s, PBRT_HIP_ERR_STATE, "render: sobol tables not set (pbrt_hip_set_sobol_tables)");
@@ -877,7 +877,7 @@ static int setup_spatial(PbrtHipScene* s, ph::SpatialRec& sr) {
 }
 
 // renders this rank's tiles into d_tile_buffer (device)
-static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size, int part,
+int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size, int part,
                         int parts, void* d_tile_buffer, PbrtHipStats* out_stats) {
     int rc;
     PH_CHECK(s, hipSetDevice(s->device));
@@ -923,6 +923,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     // ray binning between rounds and per-XCD queue heads (raysort.h, traverse.h)
     static const int sort_mode = []() { const char* e = std::getenv("PBRT_HIP_SORT_RAYS"); int v = e ? std::atoi(e) : 1; return (v < 0 || v > 2) ? 1 : v; }();
     static const int n_heads = []() { const char* e = std::getenv("PBRT_HIP_TRAV_HEADS"); int v = e ? std::atoi(e) : 8; return (v < 1 || v > 8) ? 8 : v; }();
+    static const int sort_blocks = []() { const char* e = std::getenv("PBRT_HIP_SORT_BLOCKS"); int v = e ? std::atoi(e) : 1024; return (v < 64 || v > 8192) ? 1024 : v; }();
     static const int head_chunk = []() { const char* e = std::getenv("PBRT_HIP_HEAD_CHUNK"); int v = e ? std::atoi(e) : 49152; return (v < 1024 || v > (1 << 24) || (v & 1023)) ? 49152 : v; }();  // a multiple of every batch size
     ph::RaySortParams sortp{};
     ph::RaySortGrid sort_grid{};
@@ -1024,9 +1025,9 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
                     sortp.n_cl = &c->n_cl; sortp.n_sh = &c->n_sh;
                     if ((rc = timed(3, [&]() {
                             (void)hipMemsetAsync(sortp.bin_start, 0, PH_SORT_KEYS * 4, s->stream);
-                            hipLaunchKernelGGL(ph::raysort_hist_kernel, dim3(1024), dim3(PH_SORT_BLOCK), 0, s->stream, sortp);
+                            hipLaunchKernelGGL(ph::raysort_hist_kernel, dim3(sort_blocks), dim3(PH_SORT_BLOCK), 0, s->stream, sortp);
                             hipLaunchKernelGGL(ph::raysort_scan_kernel, dim3(1), dim3(1024), 0, s->stream, sortp);
-                            hipLaunchKernelGGL(ph::raysort_scatter_kernel, dim3(1024), dim3(PH_SORT_BLOCK), 0, s->stream, sortp);
+                            hipLaunchKernelGGL(ph::raysort_scatter_kernel, dim3(sort_blocks), dim3(PH_SORT_BLOCK), 0, s->stream, sortp);
                         }))) return rc;
                     tp.order = sortp.order;
                 }
@@ -1094,7 +1095,7 @@ static int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int 
     return PBRT_HIP_OK;
 }
 
-static int merge_tiles(PbrtHipScene* s, int tile_size, int parts, const void* const* d_bufs, float* out_xyz, float* out_weight) {
+int merge_tiles(PbrtHipScene* s, int tile_size, int parts, const void* const* d_bufs, float* out_xyz, float* out_weight) {
     if (!s->wf) s->wf = new Wavefront();
     Wavefront& w = *s->wf;
     const FilmRec& f = s->film;
@@ -1117,6 +1118,11 @@ static int merge_tiles(PbrtHipScene* s, int tile_size, int parts, const void* co
     PH_CHECK(s, hipMemcpyAsync(out_weight, w.d_w.p, npx * 4, hipMemcpyDeviceToHost, s->stream));
     PH_CHECK(s, hipStreamSynchronize(s->stream));
     return PBRT_HIP_OK;
+}
+
+DevBuf& tile_buffer_of(PbrtHipScene* s) {
+    if (!s->wf) s->wf = new Wavefront();
+    return s->wf->d_tilebuf;
 }
 
 }  // namespace phost
@@ -1144,7 +1150,7 @@ int pbrt_hip_render_path_tiles_device(PbrtHipScene* s, int max_depth, float rr_t
 int pbrt_hip_merge_tiles_device(PbrtHipScene* s, int tile_size, int tile_parts, const void* const* d_tile_buffers, float* out_xyz, float* out_weight) {
     if (!s || !d_tile_buffers || !out_xyz || !out_weight) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "merge: null argument");
     if (!s->have_film) return set_err(s, PBRT_HIP_ERR_STATE, "merge: set_film first");
-    if (tile_size <= 0 || tile_parts <= 0 || tile_parts > 8) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "merge: bad partition");
+    if (tile_size <= 0 || tile_parts <= 0 || tile_parts > PH_MAX_TILE_PARTS) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "merge: bad partition");
     PH_CHECK(s, hipSetDevice(s->device));
     return merge_tiles(s, tile_size, tile_parts, d_tile_buffers, out_xyz, out_weight);
 }
@@ -1154,6 +1160,7 @@ int pbrt_hip_render_path(PbrtHipScene* s, int max_depth, float rr_threshold, int
     int rc = check_render_args(s, max_depth, light_strategy, pixel_bounds, tile_size, tile_part, tile_parts);
     if (rc) return rc;
     if (!out_xyz || !out_weight) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: null output");
+    if (s->multi) return render_path_multi(s, max_depth, rr_threshold, light_strategy, pixel_bounds, tile_size, tile_part, tile_parts, out_xyz, out_weight, out_stats);
     if (!s->wf) s->wf = new Wavefront();
     const size_t floats = tile_buffer_floats_for(s, tile_size, tile_part, tile_parts);
     if ((rc = ensure_buf(s, s->wf->d_tilebuf, floats * 4))) return rc;

@@ -1,9 +1,10 @@
 // pbrt_hip_render — command-line front end (src/main.rs + core/src/app/options.rs): parse scene files, render each on
-// one MI355X through libpbrt_hip.so, write the image.  No CPU rendering path exists: without a device it exits non-zero.
+// one MI355X (or, with --devices, on several of one node) through libpbrt_hip.so, write the image.  No CPU rendering path exists: without a device it exits non-zero.
 #include "pbrt_host.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 
 static void usage() {
     std::fprintf(stderr,
@@ -11,6 +12,7 @@ static void usage() {
                  "  --outfile FILE         write the image to FILE (PFM)\n"
                  "  --cropwindow X0 X1 Y0 Y1\n"
                  "  --device N             GPU ordinal (default 0)\n"
+                 "  --devices A,B,...      render every frame on several GPUs of this node (tiles dealt round-robin, film tiles gathered over RCCL); 'all' = every visible GPU\n"
                  "  --tile-size N          sample tile edge (default 16, as the reference)\n"
                  "  --sobol-tables FILE    raw Sobol generator matrices (needed for Sampler \"sobol\")\n"
                  "  --check                parse and validate only: no GPU is touched and nothing is rendered\n"
@@ -21,12 +23,19 @@ static void usage() {
 int main(int argc, char** argv) {
     std::string outfile, sobol; int device = 0, tile = 16; bool quiet = false, has_crop = false, check = false; float crop[4] = {0, 1, 0, 1};
     std::vector<std::string> files;
+    std::vector<int> devices; bool multi = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto need = [&](int n) { if (i + n >= argc) { usage(); std::exit(2); } };
         if (a == "--outfile" || a == "-o") { need(1); outfile = argv[++i]; }
         else if (a == "--cropwindow") { need(4); for (int k = 0; k < 4; k++) crop[k] = std::strtof(argv[++i], nullptr); has_crop = true; }
         else if (a == "--device") { need(1); device = std::atoi(argv[++i]); }
+        else if (a == "--devices") {
+            need(1); multi = true;
+            const std::string v = argv[++i];
+            if (v != "all")
+                for (size_t p = 0; p < v.size();) { size_t q = v.find(',', p); if (q == std::string::npos) q = v.size(); devices.push_back(std::atoi(v.substr(p, q - p).c_str())); p = q + 1; }
+        }
         else if (a == "--tile-size") { need(1); tile = std::atoi(argv[++i]); }
         else if (a == "--sobol-tables") { need(1); sobol = argv[++i]; }
         else if (a == "--quiet") quiet = true;
@@ -44,7 +53,8 @@ int main(int argc, char** argv) {
     }
     if (files.empty()) { usage(); return 2; }
     for (const std::string& fn : files) {
-        pbrt_host::Api api(check ? -1 : device);
+        std::unique_ptr<pbrt_host::Api> api_owner((multi && !check) ? new pbrt_host::Api(devices) : new pbrt_host::Api(check ? -1 : device));
+        pbrt_host::Api& api = *api_owner;
         if (!api.error.empty()) { std::fprintf(stderr, "Error: %s\n", api.error.c_str()); return 3; }
         api.override_outfile = outfile; api.sobol_tables_file = sobol; api.tile_size = tile; api.quiet = quiet;
         api.has_crop_override = has_crop; std::memcpy(api.crop_override, crop, sizeof crop);

@@ -63,6 +63,13 @@ Api::Api(int device) : check_only_(device < 0), ctm_(identity_xform()), camera_t
         error = std::string("no usable gfx950 device: ") + (e ? e : "");
     }
 }
+Api::Api(const std::vector<int>& devices) : check_only_(false), ctm_(identity_xform()), camera_to_world_(identity_xform()) {
+    scene_ = pbrt_hip_scene_create_multi(devices.empty() ? nullptr : devices.data(), (int)devices.size());
+    if (!scene_) {
+        const char* e = pbrt_hip_last_error(nullptr);
+        error = std::string("no usable gfx950 device: ") + (e ? e : "");
+    }
+}
 Api::~Api() {
     if (scene_) pbrt_hip_scene_destroy(scene_);
 }

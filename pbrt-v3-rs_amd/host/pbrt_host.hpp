@@ -60,7 +60,10 @@ struct RenderReport {
 class Api {
   public:
     explicit Api(int device = 0);
+    explicit Api(const std::vector<int>& devices);   // one handle over several GPUs (pbrt_hip_scene_create_multi); empty = every visible device
     ~Api();
+    Api(const Api&) = delete;
+    Api& operator=(const Api&) = delete;
     // --- transformations (api/src/lib.rs:132-326)
     void pbrt_identity();
     void pbrt_translate(float dx, float dy, float dz);

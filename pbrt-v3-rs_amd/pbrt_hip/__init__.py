@@ -144,6 +144,9 @@ class Binding:
             "set_traversal_counting": (C.c_int, [vp, C.c_int]),
             "get_traversal_counts": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
             "accel_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+            "scene_create_multi": (vp, [ip, C.c_int]),
+            "scene_devices": (C.c_int, [vp, ip, C.c_int]),
+            "selftest_rccl_gather": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_uint64)]),
         }
         for name, (res, args) in self._optional.items():
             if hasattr(self.lib, prefix + name):
@@ -311,9 +314,14 @@ IDENTITY = np.eye(4, dtype=np.float32).reshape(16)
 class Scene:
     """One captured scene on one device (PbrtHipScene*).  Not re-entrant, like the C handle."""
 
-    def __init__(self, binding: Binding | None = None, device: int = 0):
+    def __init__(self, binding: Binding | None = None, device: int = 0, devices=None):
+        """device: one GPU.  devices: a list of ordinals -> ONE handle driving all of them (pbrt_hip_scene_create_multi; an ordinal may repeat)."""
         self.b = binding or default_binding()
-        self.h = self.b.fn("scene_create")(device)
+        if devices is not None:
+            arr = np.ascontiguousarray(devices, dtype=np.int32)
+            self.h = self.b.fn("scene_create_multi")(_ptr(arr, C.c_int), len(arr))
+        else:
+            self.h = self.b.fn("scene_create")(device)
         if not self.h:
             msg = self.b.fn("last_error")(None)
             raise PbrtHipError(ERR_NO_DEVICE, (msg or b"scene_create failed").decode())
@@ -632,6 +640,16 @@ class Scene:
         return {"closest": {"nodes_passed": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2]), "ref_node_visits": int(c[2]) + 2 * int(c[0])},
                 "any_hit": {"nodes_passed": int(c[3]), "tri_tests": int(c[4]), "rays": int(c[5]), "ref_node_visits": int(c[6])}}
 
+    def devices(self):
+        out = np.zeros(64, np.int32)
+        n = self.b.fn("scene_devices")(self.h, _ptr(out, C.c_int), 64)
+        return [int(v) for v in out[:n]]
+
+    def selftest_rccl_gather(self, n_floats=1 << 20):
+        wrong = C.c_uint64(0)
+        self._chk(self.b.fn("selftest_rccl_gather")(self.h, n_floats, C.byref(wrong)))
+        return int(wrong.value)
+
     def accel_stats(self):
         """Sizes of the built acceleration structure in the device layout (measurement aid)."""
         c = (C.c_uint64 * 8)()
@@ -703,6 +721,7 @@ class SceneSpec:
     eye: tuple = (0.0, -4.0, 0.0)
     look: tuple = (0.0, 0.0, 0.0)
     up: tuple = (0.0, 0.0, 1.0)
+    crop_window: tuple = (0.0, 1.0, 0.0, 1.0)   # Film "cropwindow" x0 x1 y0 y1 (fractions of the full resolution)
 
 
 def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None, instances: int = 0):
@@ -754,7 +773,7 @@ def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None, insta
     w2c, c2w = host.look_at(spec.eye, spec.look, spec.up)
     r2c = host.perspective_raster_to_camera(spec.fov, spec.xres, spec.yres)
     scene.set_camera_perspective(r2c, c2w)
-    cb, table, sb = host.film_box(spec.xres, spec.yres)
+    cb, table, sb = host.film_box(spec.xres, spec.yres, crop_window=spec.crop_window)
     scene.set_film(spec.xres, spec.yres, cb, (0.5, 0.5), table)
     scene.set_sampler(0, spec.spp, sb)
     scene.build_accel(0, 4)
