@@ -178,16 +178,21 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
 }
 
 // Tuning variants of the traversal kernel, selectable at run time (PBRT_HIP_TRAV_VARIANT) so that one GPU session can
-// compare them on the same data.  {LEAF_MIN, REFILL_MIN, LDS_DEPTH}; variant 0 is the default.
-#define PH_VARIANTS(X) X(0, 20, 12, 12, 3) X(1, 20, 12, 12, 2) X(2, 20, 12, 12, 1) X(3, 24, 12, 12, 2) X(4, 16, 12, 12, 2) X(5, 28, 16, 12, 2) X(6, 20, 16, 12, 2) X(7, 20, 8, 12, 2) X(8, 24, 16, 10, 2) X(9, 24, 12, 12, 4)
+// compare them on the same data.  {LEAF_MIN, REFILL_MIN, LDS_DEPTH, NODE_STEPS, waves per SIMD the kernel is compiled for (0 = the compiler's choice)}; PH_DEFAULT_VARIANT is what ships.
+#define PH_VARIANTS(X) X(0, 20, 12, 12, 3, 0, false) X(1, 20, 12, 12, 2, 0, false) X(2, 20, 12, 12, 1, 0, false) X(3, 24, 12, 12, 2, 0, false) X(4, 16, 12, 12, 2, 0, false) X(5, 28, 16, 12, 2, 0, false) \
+    X(6, 20, 16, 12, 2, 0, false) X(7, 20, 8, 12, 2, 0, false) X(8, 24, 16, 10, 2, 0, false) X(9, 24, 12, 12, 4, 0, false) X(10, 20, 12, 11, 3, 7, false) X(11, 24, 12, 11, 4, 7, false) \
+    X(12, 20, 12, 10, 3, 8, false) X(13, 24, 12, 12, 4, 6, false) X(14, 20, 12, 12, 5, 0, false) X(15, 24, 12, 11, 5, 7, false) \
+    X(16, 24, 12, 11, 4, 7, true) X(17, 24, 12, 12, 4, 6, true) X(18, 20, 12, 12, 3, 0, true) X(19, 24, 12, 12, 5, 6, false)
+#define PH_N_VARIANTS 20
+#define PH_DEFAULT_VARIANT 19   // measured on configs[2] / configs[1] with binned queues: 742.6 / 31.3 ms of traversal per frame against 760.2 / 31.7 for variant 0 (gpurun r02h)
 static int trav_variant() {
     static int v = -1;
-    if (v < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_VARIANT"); v = e ? std::atoi(e) : 0; if (v < 0 || v > 9) v = 0; }
+    if (v < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_VARIANT"); v = e ? std::atoi(e) : PH_DEFAULT_VARIANT; if (v < 0 || v >= PH_N_VARIANTS) v = PH_DEFAULT_VARIANT; }
     return v;
 }
 static int variant_lds_depth(int v) {
     switch (v) {
-#define X(id, lm, rm, ld, ns) case id: return ld;
+#define X(id, lm, rm, ld, ns, wpe, pk) case id: return ld;
         PH_VARIANTS(X)
 #undef X
     }
@@ -200,7 +205,7 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
         PH_CHECK(s, hipGetDeviceProperties(&prop, s->device));
         int per_cu = 0;
         switch (trav_variant()) {
-#define X(id, lm, rm, ld, ns) case id: PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false, lm, rm, ld, ns>, PH_TRAV_BLOCK, 0)); break;
+#define X(id, lm, rm, ld, ns, wpe, pk) case id: PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false, lm, rm, ld, ns, false, true, false, wpe, pk>, PH_TRAV_BLOCK, 0)); if (wpe) per_cu = std::min(per_cu, wpe); break;
             PH_VARIANTS(X)
 #undef X
         }
@@ -226,11 +231,11 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
     p.counts = (unsigned long long*)s->d_counts.p;
     { static int bt = -1; if (bt < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_BATCH"); bt = e ? std::atoi(e) : PH_BATCH; if (bt != 64 && bt != 128 && bt != 256 && bt != 512 && bt != 1024) bt = 64; } p.batch = (uint32_t)bt; }
     const dim3 g(blocks), b(PH_TRAV_BLOCK);
-#define PH_LAUNCH3(cnt, lm, rm, ld, ns, inst)                                                                                          \
-    do {                                                                                                                              \
-        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, true>), g, b, 0, s->stream, s->ds, p); \
-        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst>), g, b, 0, s->stream, s->ds, p);   \
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst>), g, b, 0, s->stream, s->ds, p);                 \
+#define PH_LAUNCH3(cnt, lm, rm, ld, ns, inst, wpe, pk)                                                                                                  \
+    do {                                                                                                                                           \
+        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, true, false, wpe, pk>), g, b, 0, s->stream, s->ds, p);   \
+        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, false, wpe, pk>), g, b, 0, s->stream, s->ds, p); \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, false, wpe, pk>), g, b, 0, s->stream, s->ds, p);             \
     } while (0)
 #define PH_LAUNCH3A(inst)                                                                                                              \
     do {                                                                                                                              \
@@ -243,13 +248,13 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
         return;
     }
     if (!s->inst_recs.empty()) {  // scenes with object instances: the TransformedPrimitive-aware kernels
-        if (s->count_traversal) PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true);
-        else PH_LAUNCH3(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true);
+        if (s->count_traversal) PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 0, false);
+        else PH_LAUNCH3(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true, 0, false);
         return;
     }
-    if (s->count_traversal) { PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false); return; }
+    if (s->count_traversal) { PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false, 0, false); return; }
     switch (trav_variant()) {
-#define X(id, lm, rm, ld, ns) case id: PH_LAUNCH3(false, lm, rm, ld, ns, false); break;
+#define X(id, lm, rm, ld, ns, wpe, pk) case id: PH_LAUNCH3(false, lm, rm, ld, ns, false, wpe, pk); break;
         PH_VARIANTS(X)
 #undef X
     }

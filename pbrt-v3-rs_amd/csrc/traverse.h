@@ -100,27 +100,60 @@ PH_DEV RayIn xf_ray(const float* c, const RayState& r, float time) {
     return out;
 }
 
+// v_max3_f32 / v_min3_f32 as the hardware defines them (IEEE mode: a quiet NaN operand is ignored, the result is the extreme of the others)
+PH_DEV float vmax3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#else
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+#endif
+}
+PH_DEV float vmin3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#else
+    return a < b ? (a < c ? a : c) : (b < c ? b : c);
+#endif
+}
+
 // Bounds3::intersect_p_inv without its final `t_min < ray.t_max` clause; returns t_min via reference.
-// Quirk B1 (z far plane not widened) is reproduced.  Written branch-free: the reference's early `return false`s only skip
-// arithmetic whose results are then unused, so evaluating everything and AND-ing the verdicts gives the same answer
-// (NaNs included: every comparison below is the reference's comparison, in the reference's direction).
+// Quirk B1 (z far plane not widened) is reproduced.  The reference interleaves four "miss" comparisons with four conditional updates of t_min / t_max
+// (bounds3.rs:299-323); here the three entry distances go through one v_max3_f32, the three exit distances through one v_min3_f32 and the verdict is
+// `t_min <= t_max`.  Same answer in every case:
+//  * numbers: the reference's tests are `entry_i > exit_j -> miss` for the pairs (x,y) (y,x) (xy,z) (z,xy); with the merges in between that is
+//    "every entry <= every exit of ANOTHER axis".  max3 <= min3 adds the same-axis pairs: z's always holds (unscaled, monotone arithmetic), x's or y's
+//    can only fail when the exit distance is negative (the 1 + 2 gamma_3 factor moves a negative exit below its entry), and then the reference misses
+//    too through its final `t_max > 0`.  The merged t_min / t_max are the same numbers (the sign of a zero is not observable: they are only compared).
+//  * NaNs (0 x inf: a ray parallel to a slab with its origin on the slab's plane): every comparison with a NaN is false.  A NaN y or z distance
+//    therefore neither misses nor replaces t_min / t_max in the reference — exactly what the hardware's max3 / min3 do with a quiet NaN operand.  A NaN
+//    x distance is what t_min / t_max START as, survives every update and fails the final comparison: the reference misses; hence the `ordered` term.
+// PK: the six subtractions and six multiplications of a box written as three + three two-float operations (v_pk_add_f32 / v_pk_mul_f32)
+typedef float ph_v2f __attribute__((ext_vector_type(2)));
+template <bool PK = false>
 PH_DEV bool box_test(const RayState& r, float xn, float xf, float yn, float yf, float zn, float zf, float& t_min_out) {
-    float t_min = (xn - r.ox) * r.ix;
-    float t_max = (xf - r.ox) * r.ix;
-    const float t_y_min = (yn - r.oy) * r.iy;
-    float t_y_max = (yf - r.oy) * r.iy;
-    t_max *= kBoxScale;
+    float t_x_min, t_x_max, t_y_min, t_y_max, t_z_min, t_z_max;
+    if (PK) {
+    const ph_v2f one_s = {1.0f, kBoxScale};
+    ph_v2f tx = ((ph_v2f){xn, xf} - (ph_v2f){r.ox, r.ox}) * (ph_v2f){r.ix, r.ix};
+    ph_v2f ty = ((ph_v2f){yn, yf} - (ph_v2f){r.oy, r.oy}) * (ph_v2f){r.iy, r.iy};
+    const ph_v2f tz = ((ph_v2f){zn, zf} - (ph_v2f){r.oz, r.oz}) * (ph_v2f){r.iz, r.iz};
+    tx = tx * one_s;   // x * 1.0f is x, bit for bit: only the far planes of x and y are widened
+    ty = ty * one_s;
+    t_x_min = tx.x; t_x_max = tx.y; t_y_min = ty.x; t_y_max = ty.y; t_z_min = tz.x; t_z_max = tz.y;
+    } else {
+    t_x_min = (xn - r.ox) * r.ix;
+    t_x_max = (xf - r.ox) * r.ix;
+    t_y_min = (yn - r.oy) * r.iy;
+    t_y_max = (yf - r.oy) * r.iy;
+    t_x_max *= kBoxScale;
     t_y_max *= kBoxScale;
-    const bool miss_xy = (t_min > t_y_max) | (t_y_min > t_max);
-    t_min = (t_y_min > t_min) ? t_y_min : t_min;
-    t_max = (t_y_max < t_max) ? t_y_max : t_max;
-    const float t_z_min = (zn - r.oz) * r.iz;
-    const float t_z_max = (zf - r.oz) * r.iz;
-    const bool miss_z = (t_min > t_z_max) | (t_z_min > t_max);
-    t_min = (t_z_min > t_min) ? t_z_min : t_min;
-    t_max = (t_z_max < t_max) ? t_z_max : t_max;
+    t_z_min = (zn - r.oz) * r.iz;
+    t_z_max = (zf - r.oz) * r.iz;
+    }
+    const float t_min = vmax3(t_x_min, t_y_min, t_z_min);
+    const float t_max = vmin3(t_x_max, t_y_max, t_z_max);
     t_min_out = t_min;
-    return !miss_xy & !miss_z & (t_max > 0.0f);
+    return (t_min <= t_max) & (t_max > 0.0f) & ((t_x_min == t_x_min) & (t_x_max == t_x_max));
 }
 
 // Triangle::intersect up to `if t <= delta_t` (triangle.rs:441-545).  Returns true when the reference proceeds past it.
@@ -199,9 +232,11 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
 // accepted only if the texture, evaluated at the hit's uv / p with no differentials, is not 0.  The evaluation is an out-of-line call (alpha_accept,
 // defined next to the texture evaluator); its own instantiations, so every other scene keeps the leaner kernels.
 static __device__ __noinline__ bool alpha_accept(const DeviceScene* dsc, uint32_t tri_index, float b0, float b1, float b2, uint32_t any_hit);
+// WPE > 0 compiles the kernel for exactly that many waves per SIMD (= resident 256-thread blocks per CU): the register allocator then fits the budget
+// (7: 72 VGPRs, 8: 64) instead of taking what it likes; 0 leaves the choice to the compiler (same code as before).
 template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1, bool INST = false, bool MIXED = false,
-          bool ALPHA = false>
-__global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc, TravParams p) {
+          bool ALPHA = false, int WPE = 0, bool PK = false>
+__global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -323,9 +358,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) void traverse_kernel(DeviceScene sc,
             if (COUNT) c_nodes[(MIXED && ah) ? 1 : 0]++;
             // q0 = x0[0],x0[1],y0[0],y0[1]; q1 = z0[0],z0[1],x1[0],x1[1]; q2 = y1[0],y1[1],z1[0],z1[1]
             float t0, t1;
-            bool h0 = box_test(r, r.nx ? q0.y : q0.x, r.nx ? q0.x : q0.y, r.ny ? q0.w : q0.z, r.ny ? q0.z : q0.w,
+            bool h0 = box_test<PK>(r, r.nx ? q0.y : q0.x, r.nx ? q0.x : q0.y, r.ny ? q0.w : q0.z, r.ny ? q0.z : q0.w,
                                r.nz ? q1.y : q1.x, r.nz ? q1.x : q1.y, t0);
-            bool h1 = box_test(r, r.nx ? q1.w : q1.z, r.nx ? q1.z : q1.w, r.ny ? q2.y : q2.x, r.ny ? q2.x : q2.y,
+            bool h1 = box_test<PK>(r, r.nx ? q1.w : q1.z, r.nx ? q1.z : q1.w, r.ny ? q2.y : q2.x, r.ny ? q2.x : q2.y,
                                r.nz ? q2.w : q2.z, r.nz ? q2.z : q2.w, t1);
             h0 = h0 & (t0 < r.t_max);
             h1 = h1 & (t1 < r.t_max);

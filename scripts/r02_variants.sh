@@ -6,7 +6,7 @@ O=$R/gpurun_out/$T; mkdir -p $O
 cd $R
 for CFG in "$@"; do
   echo "== config $CFG"
-  for v in 0 1 2 3 4 5 6 7 8 9; do
+  for v in ${VARIANTS:-0 1 2 3 4 5 6 7 8 9}; do
     PBRT_HIP_TRAV_VARIANT=$v python3 bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-roofline-count > $O/v${v}_$CFG.json 2> $O/v${v}_$CFG.err || { echo "v$v FAILED"; continue; }
     python3 - <<PY
 import json

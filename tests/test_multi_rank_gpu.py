@@ -46,3 +46,19 @@ def test_two_ranks_weak_scaling_doubles_the_samples():
     a, b = _last_json(one.stdout), _last_json(two.stdout)
     assert b["scaling"] == "weak" and b["n_gpus"] == 2
     assert a["film_sha256"] == b["film_sha256"] and a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+
+
+def test_two_ranks_at_config3_size():
+    """The N > 1 default workload — configs[3]: 10 M triangles, 2048 x 2048 @ 64 spp, strong scaling — rehearsed with 2 ranks on the one GPU:
+    the merged film and the ray counts equal the one-rank frame's."""
+    common = ["--config", "3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29535",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-weak-leg"] + common, capture_output=True, text=True, env=env, timeout=1200)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = _last_json(one.stdout), _last_json(two.stdout)
+    assert a["config"]["baseline_config"] == b["config"]["baseline_config"] == "3" and b["scaling"] == "strong" and b["n_gpus"] == 2
+    assert a["film_sha256"] == b["film_sha256"]
+    assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
