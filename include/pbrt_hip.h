@@ -201,15 +201,21 @@ int pbrt_hip_add_texture_checkerboard3d(PbrtHipScene*, uint32_t tex1, uint32_t t
  * lobe; the texel is tested for black BEFORE its product with the constant reflect / transmit, translucent.rs:77-84, :87);
  * the material must have been created with a non-black constant for that parameter.  Scalar parameters: see set_material_float_texture.
  * Materials with per-hit textures may be children of a mix (each lobe is kept or dropped as its own material would, mix.rs:63-87) as long as the
- * mix has at most 6 textured colours and one textured roughness / sigma; bump-mapped children are refused. */
-enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2, PBRT_HIP_PARAM_KT = 3 };
+ * mix has at most 6 textured colours and one textured roughness / sigma. */
+/* More per-hit parameters (same call): OPACITY — UberMaterial's opacity (uber.rs:126-160: it decides the pass-through lobe, multiplies Kd / Ks / Kr / Kt and picks BSDF::eta);
+ * AMOUNT — MixMaterial's amount (mix.rs:59-60: s1 = amount(hit), s2 = 1 - s1, clamped); ETA / K — MetalMaterial's conductor indices (metal.rs:121-125, not clamped).
+ * GlassMaterial's u / v roughness go through set_material_float_texture: a hit where both evaluate to 0 gets FresnelSpecular, any other the microfacet pair (glass.rs:110-141).
+ * A bump-mapped material may be a child of a mix: the FIRST child's bump map shapes the mixture's shading frame, the second child's has no effect (mix.rs:63-76 builds the
+ * BSDF on the interaction the first child bumped). */
+enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2, PBRT_HIP_PARAM_KT = 3, PBRT_HIP_PARAM_OPACITY = 4, PBRT_HIP_PARAM_AMOUNT = 5, PBRT_HIP_PARAM_ETA = 6,
+       PBRT_HIP_PARAM_K = 7 };
 int pbrt_hip_set_material_texture(PbrtHipScene*, uint32_t material, int param, uint32_t texture);
 /* Scalar parameters as float textures, evaluated at every hit: fparam 0 = MatteMaterial's sigma (matte.rs:64-70: Lambert where it evaluates to 0, Oren-Nayar elsewhere),
  * 1 / 2 = u / v roughness of the Trowbridge-Reitz distribution of plastic, uber, substrate, translucent and metal (remapped per hit if the material was created with remap_roughness;
- * plastic's and translucent's single `roughness`: set both).  Glass is not wired (its lobe structure switches on roughness == 0). */
+ * plastic's and translucent's single `roughness`: set both), and of glass, whose lobe structure switches per hit on `urough == 0 && vrough == 0` (glass.rs:110-141). */
 int pbrt_hip_set_material_float_texture(PbrtHipScene*, uint32_t material, int fparam, uint32_t texture);
 /* Bump mapping: Material::bump (core/src/material.rs:62-101) with the float texture `texture` as displacement, run before the BSDF of a hit is made
- * (every material's `bumpmap` parameter).  Not for Material "none"; not for children of a mix yet. */
+ * (every material's `bumpmap` parameter).  Not for Material "none".  Set it before the material becomes a child of a mix. */
 int pbrt_hip_set_material_bump(PbrtHipScene*, uint32_t material, uint32_t texture);
 /* = add_material_matte((1,1,1), sigma) + set_material_texture(KD) */
 int pbrt_hip_add_material_matte_tex(PbrtHipScene*, uint32_t kd_texture, float sigma_degrees, uint32_t* out_material);

@@ -97,6 +97,7 @@ int oracle_add_material_plastic(OracleScene* s, const float kd[3], const float k
 int oracle_add_material_glass(OracleScene* s, const float kr[3], const float kt[3], float urough, float vrough, float eta, int remap, uint32_t* out_id) {  // glass.rs:62-118
     if (!s || !kr || !kt) return -1;
     Material m; m.general = true;  // BSDF::new(.., None): eta stays 1 (glass.rs:82)
+    m.made_as = 2; m.raw_k[2] = spec3(kr); m.raw_k[3] = spec3(kt); m.raw_eta = eta; m.raw_ur = urough; m.raw_vr = vrough; m.raw_remap = remap != 0;
     Spec r = spec_clamp0(spec3(kr)), t = spec_clamp0(spec3(kt));
     if (!(r.is_black() && t.is_black())) {
         bool is_specular = urough == 0.0f && vrough == 0.0f;
@@ -113,7 +114,7 @@ int oracle_add_material_glass(OracleScene* s, const float kr[3], const float kt[
 }
 int oracle_add_material_metal(OracleScene* s, const float eta[3], const float k[3], float urough, float vrough, int remap, uint32_t* out_id) {  // metal.rs:62-98
     if (!s || !eta || !k) return -1;
-    Material m; m.general = true;
+    Material m; m.general = true; m.made_as = 3;
     if (remap) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
     Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_COND; l.r = Spec(1.0f);
     l.c_eta_i = Spec(1.0f); l.c_eta_t = spec3(eta); l.c_k = spec3(k);
@@ -126,6 +127,7 @@ int oracle_add_material_uber(OracleScene* s, const float kd[3], const float ks[3
                              float vrough, float eta, int remap, uint32_t* out_id) {  // uber.rs:116-186
     if (!s || !kd || !ks || !kr || !kt || !opacity) return -1;
     Material m; m.general = true;
+    m.made_as = 1; m.raw_k[0] = spec3(kd); m.raw_k[1] = spec3(ks); m.raw_k[2] = spec3(kr); m.raw_k[3] = spec3(kt); m.raw_eta = eta; m.raw_ur = urough; m.raw_vr = vrough; m.raw_remap = remap != 0;
     Float e = eta;
     Spec op = spec_clamp0(spec3(opacity));
     Spec t = spec_clamp0(-op + Spec(1.0f));
@@ -462,9 +464,94 @@ int oracle_mipmap_level_texels(OracleScene* s, uint32_t mip, int level, float* o
     for (size_t i = 0; i < l.t.size(); i++) { out_rgb[3 * i] = l.t[i].c[0]; out_rgb[3 * i + 1] = l.t[i].c[1]; out_rgb[3 * i + 2] = l.t[i].c[2]; }
     return 0;
 }
+// UberMaterial with an opacity texture: the lobe list becomes every lobe the material CAN have (uber.rs:126-160), colours decided per hit
+static void uber_rebuild_for_opacity(Material& m) {
+    if (m.rebuilt) return;
+    const std::vector<Lobe> old = m.lobes;
+    int oldp[4]; for (int k = 0; k < 4; k++) oldp[k] = m.param_lobe[k];
+    const int old_rough = m.rough_lobe;
+    m.lobes.clear();
+    for (int k = 0; k < 4; k++) { m.param_lobe[k] = -1; m.param_field[k] = 0; }
+    m.rough_lobe = -1;
+    { Lobe l; l.kind = LK_SPEC_T; l.type = BX_TRANS | BX_SPEC; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.0f; l.pre_mode = 4; m.lobes.push_back(l); }
+    const Float e = m.raw_eta;
+    for (int k = 0; k < 4; k++) {
+        const Spec base = spec_clamp0(m.raw_k[k]);
+        const Lobe* ol = oldp[k] >= 0 ? &old[(size_t)oldp[k]] : nullptr;
+        const int tex = ol ? (k == 3 ? ol->t_tex : ol->r_tex) : -1;
+        if (base.is_black() && tex < 0) continue;   // op * 0 is black at every hit: the lobe is never added
+        Lobe l; l.pre_mode = 3; l.pre = base;
+        if (k == 0) { l.kind = LK_LAMBERT; l.type = BX_REFL | BX_DIFF; l.r_tex = tex; }
+        else if (k == 1) {
+            l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.r_tex = tex;
+            Float ur = m.raw_ur, vr = m.raw_vr;
+            if (m.raw_remap) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+            set_tr(l, ur, vr);
+            if (old_rough >= 0) { const Lobe& r = old[(size_t)old_rough]; l.ax_tex = r.ax_tex; l.ay_tex = r.ay_tex; l.remap = r.remap; }
+            m.rough_lobe = (int)m.lobes.size();
+        }
+        else if (k == 2) { l.kind = LK_SPEC_R; l.type = BX_REFL | BX_SPEC; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.r_tex = tex; }
+        else { l.kind = LK_SPEC_T; l.type = BX_TRANS | BX_SPEC; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.t_tex = tex; m.param_field[3] = 1; }
+        m.param_lobe[k] = (int)m.lobes.size();
+        m.lobes.push_back(l);
+    }
+    m.has_pre = false;   // the per-hit opacity takes the constant's place
+    m.bsdf_eta_alt = e;
+    m.rebuilt = true;
+}
+// GlassMaterial with a roughness texture: which lobes a hit gets depends on `urough == 0 && vrough == 0` there (glass.rs:110-141)
+static void glass_rebuild_for_roughness(Material& m) {
+    if (m.rebuilt) return;
+    const std::vector<Lobe> old = m.lobes;
+    int rtex = -1, ttex = -1;
+    for (const Lobe& l : old) { if (l.r_tex >= 0) rtex = l.r_tex; if (l.t_tex >= 0) ttex = l.t_tex; }
+    const Spec r = spec_clamp0(m.raw_k[2]), t = spec_clamp0(m.raw_k[3]);
+    m.lobes.clear();
+    for (int k = 0; k < 4; k++) { m.param_lobe[k] = m.param_lobe2[k] = -1; m.param_field[k] = m.param_field2[k] = 0; }
+    m.rough_lobe = m.rough_lobe2 = -1;
+    const bool has_r = !r.is_black() || rtex >= 0, has_t = !t.is_black() || ttex >= 0;
+    if (has_r || has_t) {
+        Float ur = m.raw_ur, vr = m.raw_vr;
+        if (m.raw_remap) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+        Lobe f; f.kind = LK_FRESNEL_SPEC; f.type = BX_REFL | BX_TRANS | BX_SPEC; f.r = r; f.t = t; f.r_tex = rtex; f.t_tex = ttex; f.eta_a = 1.0f; f.eta_b = m.raw_eta;
+        f.alt = 1; f.ur_raw = m.raw_ur; f.vr_raw = m.raw_vr; set_tr(f, ur, vr);
+        m.param_lobe[2] = 0; m.param_field[2] = 0; m.param_lobe[3] = 0; m.param_field[3] = 1;
+        m.lobes.push_back(f);
+        if (has_r) { Lobe l; l.kind = LK_MICRO_R; l.type = BX_REFL | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = m.raw_eta; l.r = r; l.r_tex = rtex; l.alt = 2; l.ur_raw = m.raw_ur; l.vr_raw = m.raw_vr;
+                     set_tr(l, ur, vr); m.param_lobe2[2] = (int)m.lobes.size(); m.param_field2[2] = 0; m.lobes.push_back(l); }
+        if (has_t) { Lobe l; l.kind = LK_MICRO_T; l.type = BX_TRANS | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = m.raw_eta; l.t = t; l.t_tex = ttex; l.alt = 2; l.ur_raw = m.raw_ur; l.vr_raw = m.raw_vr;
+                     set_tr(l, ur, vr); m.param_lobe2[3] = (int)m.lobes.size(); m.param_field2[3] = 1; m.lobes.push_back(l); }
+    }
+    m.rebuilt = true;
+}
+// param: 0 Kd, 1 Ks, 2 Kr, 3 Kt; 4 uber opacity, 5 mix amount, 6 metal eta, 7 metal k
 int oracle_set_material_texture(OracleScene* s, uint32_t material, int param, uint32_t texture) {
-    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || param < 0 || param > 3) return -1;
+    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || param < 0 || param > 7) return -1;
     Material& m = s->sc.materials[material];
+    if (param == 4) {
+        if (m.made_as != 1) return -6;
+        uber_rebuild_for_opacity(m);
+        m.opacity_tex = (int)texture; m.textured = true;
+        return 0;
+    }
+    if (param == 5) {
+        if (m.made_as != 4) return -6;
+        {   // the product carries at most six per-hit colours per material (its texture pass hands them to the shade pass in six slots): refuse what it refuses
+            int cols = 1;
+            for (const Lobe& l : m.lobes)
+                cols += ((l.r_tex >= 0 || (l.pre_mode == 3 && l.kind != LK_SPEC_T)) ? 1 : 0) + ((l.t_tex >= 0 || (l.pre_mode == 3 && l.kind == LK_SPEC_T) || l.pre_mode == 4) ? 1 : 0) +
+                        (l.eta_tex >= 0 ? 1 : 0) + (l.k_tex >= 0 ? 1 : 0);
+            if (cols > 6) { s->err = "set_material_texture: a mix with a textured amount may have at most 5 more per-hit colours"; return -5; }
+        }
+        for (size_t i = 0; i < m.lobes.size(); i++) { Lobe& l = m.lobes[i]; l.amt_side = (int)i < m.mix_n1 ? 1 : 2; l.amt_level = l.n_scale - 1; }
+        m.amount_tex = (int)texture; m.textured = true;
+        return 0;
+    }
+    if (param == 6 || param == 7) {
+        if (m.made_as != 3) return -6;
+        (param == 6 ? m.lobes[0].eta_tex : m.lobes[0].k_tex) = (int)texture; m.textured = true;
+        return 0;
+    }
     if (m.param_lobe[param] < 0) return -6;
     const int lobes[2] = {m.param_lobe[param], m.param_lobe2[param]}, fields[2] = {m.param_field[param], m.param_field2[param]};
     for (int k = 0; k < 2; k++) if (lobes[k] >= 0) {
@@ -490,6 +577,10 @@ int oracle_set_material_float_texture(OracleScene* s, uint32_t material, int fpa
     if (fparam == 0) {
         if (m.general || m.none || m.lobes.size() != 1 || !(m.lobes[0].kind == LK_LAMBERT || m.lobes[0].kind == LK_OREN)) return -6;
         m.lobes[0].sigma_tex = (int)texture;
+    } else if (m.made_as == 2) {  // glass: every alternative lobe carries the textures (the smooth one for its `== 0` test)
+        glass_rebuild_for_roughness(m);
+        if (m.lobes.empty()) return -6;
+        for (Lobe& l : m.lobes) { (fparam == 1 ? l.ax_tex : l.ay_tex) = (int)texture; l.remap = m.raw_remap; }
     } else {
         if (m.rough_lobe < 0) return -6;
         const int rl[2] = {m.rough_lobe, m.rough_lobe2};
@@ -666,7 +757,13 @@ int oracle_add_material_mix(OracleScene* s, uint32_t m1, uint32_t m2, const floa
     if (a.lobes.size() + b.lobes.size() > 8) { s->err = "mix: more than MAX_BXDFS = 8 lobes (bsdf.rs:119-125 asserts)"; return -1; }
     for (Lobe l : a.lobes) { if (l.n_scale >= 2) { s->err = "mix nested deeper than two levels"; return -5; } l.scale[l.n_scale++] = s1; m.lobes.push_back(l); }
     for (Lobe l : b.lobes) { if (l.n_scale >= 2) { s->err = "mix nested deeper than two levels"; return -5; } l.scale[l.n_scale++] = s2; m.lobes.push_back(l); }
-    if (a.bump_tex >= 0 || b.bump_tex >= 0) { s->err = "mix of bump-mapped materials: each sub-material bumps the interaction in turn (mix.rs:63-76); not modelled"; return -5; }
+    // mix.rs:63-76: m1 bumps `si` itself, m2 a clone of it; the mixture's BSDF is then made on `si` (BSDF::new(&si.hit, &si.shading, None)), so the first
+    // material's bump map shapes the frame of every lobe and the second one's changes nothing that is used
+    m.bump_tex = a.bump_tex;
+    if (a.amount_tex >= 0 || b.amount_tex >= 0) { s->err = "mix of a mix whose amount is a texture: not modelled"; return -5; }
+    if (a.opacity_tex >= 0 && b.opacity_tex >= 0) { s->err = "mix of two uber materials with opacity textures: not modelled"; return -5; }
+    m.opacity_tex = a.opacity_tex >= 0 ? a.opacity_tex : b.opacity_tex;
+    m.made_as = 4; m.mix_n1 = (int)a.lobes.size();
     m.textured = a.textured || b.textured;   // the sub-materials' textures are evaluated per hit, each lobe kept or dropped as its own material would (mix.rs:63-87)
     return push_material(s, m, out_id);
 }

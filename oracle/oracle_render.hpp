@@ -1019,30 +1019,51 @@ struct Renderer {
         if (m.textured) {  // compute_scattering_functions evaluates the textures at this hit (matte.rs:63-71, plastic.rs:62-81, mirror.rs:53-57, substrate.rs:60-80)
             TexCtx c; c.uv = si.uv; c.dudx = si.dudx; c.dvdx = si.dvdx; c.dudy = si.dudy; c.dvdy = si.dvdy; c.p = si.p; c.dpdx = si.dpdx; c.dpdy = si.dpdy;
             int k = 0;
+            Spec s1(1.0f), s2(0.0f), op(1.0f);
+            if (m.amount_tex >= 0) { s1 = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, m.amount_tex, c)); s2 = spec_clamp0(Spec(1.0f) - s1); }   // mix.rs:59-60
+            if (m.opacity_tex >= 0) op = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, m.opacity_tex, c));                                        // uber.rs:126
+            bool passthrough = false;
             for (const Lobe& tl : m.lobes) {
                 Lobe l = tl;
                 if (l.sigma_tex >= 0) {  // matte.rs:64-70 + OrenNayar::new (oren_nayar.rs:28-39)
                     Float sig = pclamp(tex_eval(sc->textures, sc->mipmaps, l.sigma_tex, c).c[0], 0.0f, 90.0f);
                     if (sig == 0.0f) { l.kind = LK_LAMBERT; l.a = 0.0f; l.b = 0.0f; }
-                    else { l.kind = LK_OREN; Float sg = to_radians(sig), s2 = sg * sg; l.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f))); l.b = 0.45f * s2 / (s2 + 0.09f); }
+                    else { l.kind = LK_OREN; Float sg = to_radians(sig), s2o = sg * sg; l.a = 1.0f - (s2o / (2.0f * (s2o + 0.33f))); l.b = 0.45f * s2o / (s2o + 0.09f); }
                 }
+                bool is_specular = false;
                 if (l.ax_tex >= 0 || l.ay_tex >= 0) {  // roughness textures, remapped per hit (trowbridge_reitz.rs:21-40)
-                    auto alpha_of = [&](int tex, Float cur) {
+                    const Float ur = l.ax_tex >= 0 ? tex_eval(sc->textures, sc->mipmaps, l.ax_tex, c).c[0] : l.ur_raw;
+                    const Float vr = l.ay_tex >= 0 ? tex_eval(sc->textures, sc->mipmaps, l.ay_tex, c).c[0] : l.vr_raw;
+                    is_specular = ur == 0.0f && vr == 0.0f;   // glass.rs:111, on the values as the textures give them
+                    auto alpha_of = [&](int tex, Float raw, Float cur) {
                         if (tex < 0) return cur;
-                        Float r = tex_eval(sc->textures, sc->mipmaps, tex, c).c[0];
+                        Float r = raw;
                         if (l.remap) { r = pmax(r, 1e-3f); Float x = o_log(r); r = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x; }
                         return pmax(0.001f, r);
                     };
-                    l.ax = alpha_of(l.ax_tex, l.ax); l.ay = alpha_of(l.ay_tex, l.ay);
+                    l.ax = alpha_of(l.ax_tex, ur, l.ax); l.ay = alpha_of(l.ay_tex, vr, l.ay);
                 }
+                if ((l.alt == 1 && !is_specular) || (l.alt == 2 && is_specular)) continue;   // glass.rs:112-141: FresnelSpecular, or the microfacet pair
                 bool raw_black = false;   // translucent.rs:77-84, :87: the texel itself is tested, then multiplied by reflect / transmit
-                if (l.r_tex >= 0) { l.r = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.r_tex, c)); if (l.pre_raw_test && l.r.is_black()) raw_black = true; if (l.has_pre) l.r = l.pre * l.r; }
-                if (l.t_tex >= 0) { l.t = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.t_tex, c)); if (l.pre_raw_test && l.t.is_black()) raw_black = true; if (l.has_pre) l.t = l.pre * l.t; }
+                if (l.pre_mode == 4) l.t = spec_clamp0(op * -1.0f + Spec(1.0f));    // (-op + ONE).clamp_default() (uber.rs:127)
+                else if (l.pre_mode == 3) {   // op * k.evaluate(..).clamp_default() (uber.rs:141, :147, :169, :175)
+                    const bool trans = l.kind == LK_SPEC_T;
+                    const int tex = trans ? l.t_tex : l.r_tex;
+                    const Spec base = tex >= 0 ? spec_clamp0(tex_eval(sc->textures, sc->mipmaps, tex, c)) : l.pre;
+                    (trans ? l.t : l.r) = op * base;
+                } else {
+                    if (l.r_tex >= 0) { l.r = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.r_tex, c)); if (l.pre_raw_test && l.r.is_black()) raw_black = true; if (l.has_pre) l.r = l.pre * l.r; }
+                    if (l.t_tex >= 0) { l.t = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, l.t_tex, c)); if (l.pre_raw_test && l.t.is_black()) raw_black = true; if (l.has_pre) l.t = l.pre * l.t; }
+                }
+                if (l.eta_tex >= 0) l.c_eta_t = tex_eval(sc->textures, sc->mipmaps, l.eta_tex, c);   // metal.rs:121-125: no clamp
+                if (l.k_tex >= 0) l.c_k = tex_eval(sc->textures, sc->mipmaps, l.k_tex, c);
+                if (l.amt_side) l.scale[l.amt_level] = l.amt_side == 1 ? s1 : s2;
                 if (l.pre_raw_test) { if (!raw_black) local[k++] = l; continue; }   // an untextured lobe of this material exists because its constant passed the test at creation
                 const bool keep = (l.kind == LK_FRESNEL_BLEND || l.kind == LK_FRESNEL_SPEC) ? !(l.r.is_black() && l.t.is_black())
                                 : ((l.kind == LK_SPEC_T || l.kind == LK_MICRO_T || l.kind == LK_LAMBERT_T) ? !l.t.is_black() : !l.r.is_black());
-                if (keep) local[k++] = l;
+                if (keep) { if (l.pre_mode == 4) passthrough = true; local[k++] = l; }
             }
+            if (m.opacity_tex >= 0 && m.made_as == 1) b.eta = passthrough ? 1.0f : m.bsdf_eta_alt;   // uber.rs:128-137
             b.lobes = local; b.n = k;
         }
         return b;

@@ -44,6 +44,11 @@ struct Lobe {
     bool pre_raw_test = false;       // TranslucentMaterial: `if !kd.is_black() { add(r * kd) }` tests the texel BEFORE the product (translucent.rs:77-84, :87)
     int ax_tex = -1, ay_tex = -1; bool remap = false;  // the microfacet roughness is a float texture (plastic.rs:71-76, uber.rs:140-153, substrate.rs:63-71, metal.rs:69-83)
     int sigma_tex = -1;              // MatteMaterial's sigma is a float texture (matte.rs:64-70)
+    int eta_tex = -1, k_tex = -1;    // MetalMaterial's eta / k are textures (metal.rs:121-125): evaluated per hit, NOT clamped
+    int amt_side = 0, amt_level = 0; // MixMaterial with an `amount` texture (mix.rs:59-60): scale[amt_level] is s1 (side 1) or s2 = clamp(1 - s1) (side 2) of the hit
+    int alt = 0;                     // GlassMaterial with roughness textures (glass.rs:110-141): 1 = the lobe of a hit where urough == vrough == 0, 2 = a lobe of the other hits
+    Float ur_raw = 0, vr_raw = 0;    // ... the constant roughnesses BEFORE remapping (what `is_specular` compares with 0)
+    int pre_mode = 0;                // UberMaterial with an opacity texture (uber.rs:126-160): 3 = colour = op(hit) * (texel, or the constant kept in `pre`), 4 = colour = clamp(1 - op(hit))
 };
 struct Material {
     Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; bool none = false;  // none: Material "none" / "" -> no BSDF at all
@@ -53,6 +58,13 @@ struct Material {
     int param_lobe2[4] = {-1, -1, -1, -1}, param_field2[4] = {0, 0, 0, 0};  // a second lobe fed by the same parameter (translucent: the reflection and the transmission lobe)
     int rough_lobe = -1, rough_lobe2 = -1; bool rough_remap = false;   // the lobe(s) that own the Trowbridge-Reitz distribution (set_material_float_texture)
     bool has_pre = false; Spec pre;
+    int opacity_tex = -1;   // UberMaterial's opacity is a texture: which lobes a hit gets, their colours and BSDF::eta are decided per hit
+    Float bsdf_eta_alt = 1.0f;  // ... BSDF::eta where the pass-through lobe is NOT added (uber.rs:136)
+    int amount_tex = -1;    // MixMaterial's amount is a texture
+    int mix_n1 = 0;         // MixMaterial: how many of the lobes come from the first material
+    // what the material was created from, for the setters that have to rebuild the lobe list (opacity / glass roughness textures)
+    int made_as = 0;        // 0 other, 1 uber, 2 glass, 3 metal, 4 mix
+    Spec raw_k[4]; Float raw_eta = 1.5f, raw_ur = 0, raw_vr = 0; bool raw_remap = false; bool rebuilt = false;
 };
 
 enum LightType { L_INFINITE = 0, L_DISTANT = 1, L_POINT = 2, L_AREA = 3, L_SPOT = 4, L_PROJECTION = 5, L_GONIO = 6 };

@@ -450,6 +450,7 @@ int pbrt_hip_add_material_glass(PbrtHipScene* s, const float kr[3], const float 
                                 uint32_t* out_id) {  // glass.rs:62-118 with allow_multiple_lobes = true (path.rs:143)
     if (!s || !kr || !kt) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_glass: null argument");
     MaterialRec m{}; m.bsdf_eta = 1.0f;  // BSDF::new(.., None) (glass.rs:82)
+    const float glass_raw_ur = urough, glass_raw_vr = vrough;   // before remapping: what a later roughness texture's `== 0` test is combined with
     std::vector<LobeRec> lobes;
     float r[3], t[3];
     const bool rb = clamp3(kr, r), tb = clamp3(kt, t);
@@ -463,9 +464,12 @@ int pbrt_hip_add_material_glass(PbrtHipScene* s, const float kr[3], const float 
             if (tb) { LobeRec l = lobe(PH_LK_MICRO_T, T_TRANS | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = eta; std::memcpy(l.t, t, 12); set_tr(l, urough, vrough); lobes.push_back(l); }
         }
     }
+    const float raw_ur = urough, raw_vr = vrough;
     const int rc = push_material(s, m, lobes, true, out_id);
     if (rc == PBRT_HIP_OK) {  // Kr -> the reflection colour, Kt -> the transmission colour (one FresnelSpecular lobe, or the two microfacet lobes)
         PbrtHipScene::MaterialParams& mp = s->material_params.back();
+        mp.made_as = 2; std::memcpy(mp.raw_k[2], kr, 12); std::memcpy(mp.raw_k[3], kt, 12); mp.raw_eta = eta; mp.raw_ur = glass_raw_ur; mp.raw_vr = glass_raw_vr; mp.raw_remap = remap_roughness != 0;
+        (void)raw_ur; (void)raw_vr;
         for (size_t i = 0; i < lobes.size(); i++) {
             if (lobes[i].kind == PH_LK_FRESNEL_SPEC) { mp.lobe[2] = (int)i; mp.field[2] = 0; mp.lobe[3] = (int)i; mp.field[3] = 1; }
             else if (lobes[i].kind == PH_LK_MICRO_R) { mp.lobe[2] = (int)i; mp.field[2] = 0; }
@@ -482,13 +486,14 @@ int pbrt_hip_add_material_metal(PbrtHipScene* s, const float eta[3], const float
     l.r[0] = l.r[1] = l.r[2] = 1.0f; std::memcpy(l.c_eta_t, eta, 12); std::memcpy(l.c_k, k, 12);
     set_tr(l, urough, vrough);
     const int rc = push_material(s, m, {l}, true, out_id);
-    if (rc == PBRT_HIP_OK) { s->material_params.back().rough_lobe = 0; s->material_params.back().rough_remap = remap_roughness != 0; }
+    if (rc == PBRT_HIP_OK) { s->material_params.back().rough_lobe = 0; s->material_params.back().rough_remap = remap_roughness != 0; s->material_params.back().made_as = 3; }
     return rc;
 }
 int pbrt_hip_add_material_uber(PbrtHipScene* s, const float kd[3], const float ks[3], const float kr[3], const float kt[3], const float opacity[3], float urough,
                                float vrough, float eta, int remap_roughness, uint32_t* out_id) {  // uber.rs:116-186
     if (!s || !kd || !ks || !kr || !kt || !opacity) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_uber: null argument");
     MaterialRec m{};
+    const float uber_raw_ur = urough, uber_raw_vr = vrough;
     std::vector<LobeRec> lobes;
     float op[3], t[3], tmp[3];
     clamp3(opacity, op);
@@ -517,6 +522,8 @@ int pbrt_hip_add_material_uber(PbrtHipScene* s, const float kd[3], const float k
     if (rc == PBRT_HIP_OK) {  // texturable: Kd, Ks, Kr, Kt, each multiplied by the (constant) opacity as in `op * k.evaluate().clamp_default()`
         PbrtHipScene::MaterialParams& mp = s->material_params.back();
         mp.has_pre = true; std::memcpy(mp.pre, op, 12);
+        mp.made_as = 1; std::memcpy(mp.raw_k[0], kd, 12); std::memcpy(mp.raw_k[1], ks, 12); std::memcpy(mp.raw_k[2], kr, 12); std::memcpy(mp.raw_k[3], kt, 12);
+        mp.raw_eta = eta; mp.raw_ur = uber_raw_ur; mp.raw_vr = uber_raw_vr; mp.raw_remap = remap_roughness != 0;
         for (size_t i = 0; i < lobes.size(); i++) {
             if (lobes[i].kind == PH_LK_LAMBERT) mp.lobe[0] = (int)i;
             else if (lobes[i].kind == PH_LK_MICRO_R) { mp.lobe[1] = (int)i; mp.rough_lobe = (int)i; mp.rough_remap = remap_roughness != 0; }
@@ -581,7 +588,12 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
     for (int c = 0; c < 3; c++) tmp[c] = 1.0f - s1[c];
     clamp3(tmp, s2);
     const MaterialRec a = s->materials[material1], b = s->materials[material2];
-    if (a.bump_tex1 || b.bump_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: each bump-mapped sub-material bumps the interaction in turn (mix.rs:63-76); not supported");
+    // mix.rs:63-76: m1 bumps `si` itself, m2 a clone of it, and the mixture's BSDF is made on `si`: the first material's bump map shapes the frame of every
+    // lobe, the second one's changes nothing that is used
+    m.bump_tex1 = a.bump_tex1;
+    if (a.amount_tex1 || b.amount_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a sub-material is a mix whose amount is a texture; not supported");
+    if (a.opacity_tex1 && b.opacity_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: both sub-materials are uber materials with opacity textures; not supported");
+    m.opacity_tex1 = a.opacity_tex1 ? a.opacity_tex1 : b.opacity_tex1;
     if (a.n_lobes + b.n_lobes > 8) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: more than MAX_BXDFS = 8 lobes (BSDF::add asserts, bsdf.rs:119-125)");
     std::vector<LobeRec> lobes;
     auto take = [&](const MaterialRec& src, const float sc[3]) {
@@ -599,7 +611,8 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
         // PH_HIT_LOBES lobe slots, PH_HIT_COLS colour slots and ONE pair of per-hit scalars (roughness or sigma)
         uint32_t cols = 0, scal = 0; const LobeRec* first = nullptr;
         for (const LobeRec& l : lobes) {
-            cols += (l.r_tex1 ? 1u : 0u) + (l.t_tex1 ? 1u : 0u);
+            cols += (l.r_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T) ? 1u : 0u) + (l.t_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH ? 1u : 0u) +
+                    (l.eta_tex1 ? 1u : 0u) + (l.k_tex1 ? 1u : 0u);
             if (l.ax_tex1 || l.ay_tex1 || l.sigma_tex1) {
                 if (!first) { first = &l; scal = 1; }
                 else if (l.ax_tex1 != first->ax_tex1 || l.ay_tex1 != first->ay_tex1 || l.remap != first->remap || l.sigma_tex1 != first->sigma_tex1 || l.ax != first->ax || l.ay != first->ay) scal++;
@@ -609,8 +622,91 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
             return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a textured mix may have at most 8 lobes, 6 textured colours and one textured roughness / sigma");
         m.textured = 1u;
     }
-    return push_material(s, m, lobes, true, out_id);
+    const int rc = push_material(s, m, lobes, true, out_id);
+    if (rc == PBRT_HIP_OK) { s->material_params.back().made_as = 4; s->material_params.back().mix_n1 = (int)a.n_lobes; if (m.bump_tex1) { s->textured_materials = true; s->bump_materials = true; } }
+    return rc;
 }
+
+}  // extern "C"
+
+namespace phost {
+// UberMaterial with an opacity texture: the lobe list becomes every lobe the material CAN have (uber.rs:126-160); colours, presence and BSDF::eta are decided per hit.
+// The new list is appended to the lobe pool (the old one stays behind, unused).
+int uber_rebuild_for_opacity(PbrtHipScene* s, uint32_t material) {
+    PbrtHipScene::MaterialParams& mp = s->material_params[material];
+    MaterialRec& m = s->materials[material];
+    if (mp.rebuilt) return PBRT_HIP_OK;
+    std::vector<LobeRec> old(s->lobes.begin() + m.lobe_base, s->lobes.begin() + m.lobe_base + m.n_lobes), lobes;
+    int oldp[4]; for (int k = 0; k < 4; k++) oldp[k] = mp.lobe[k];
+    const int old_rough = mp.rough_lobe;
+    for (int k = 0; k < 4; k++) { mp.lobe[k] = -1; mp.field[k] = 0; }
+    mp.rough_lobe = -1;
+    { LobeRec l = lobe(PH_LK_SPEC_T, T_TRANS | T_SPEC); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.0f; l.has_pre = PH_PRE_PASSTHROUGH; lobes.push_back(l); }
+    const float e = mp.raw_eta;
+    for (int k = 0; k < 4; k++) {
+        float base[3];
+        const bool nonblack = clamp3(mp.raw_k[k], base);
+        const LobeRec* ol = oldp[k] >= 0 ? &old[(size_t)oldp[k]] : nullptr;
+        const uint32_t tex1 = ol ? (k == 3 ? ol->t_tex1 : ol->r_tex1) : 0u;
+        if (!nonblack && !tex1) continue;   // op * 0 is black at every hit: the lobe is never added
+        LobeRec l;
+        if (k == 0) { l = lobe(PH_LK_LAMBERT, T_REFL | T_DIFF); l.r_tex1 = tex1; }
+        else if (k == 1) {
+            l = lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.r_tex1 = tex1;
+            float ur = mp.raw_ur, vr = mp.raw_vr;
+            if (mp.raw_remap) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+            set_tr(l, ur, vr);
+            if (old_rough >= 0) { const LobeRec& r = old[(size_t)old_rough]; l.ax_tex1 = r.ax_tex1; l.ay_tex1 = r.ay_tex1; l.remap = r.remap; }
+            mp.rough_lobe = (int)lobes.size(); mp.rough_remap = mp.raw_remap;
+        }
+        else if (k == 2) { l = lobe(PH_LK_SPEC_R, T_REFL | T_SPEC); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.r_tex1 = tex1; }
+        else { l = lobe(PH_LK_SPEC_T, T_TRANS | T_SPEC); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = e; l.t_tex1 = tex1; mp.field[3] = 1; }
+        l.has_pre = PH_PRE_OPACITY; std::memcpy(l.pre, base, 12);
+        mp.lobe[k] = (int)lobes.size();
+        lobes.push_back(l);
+    }
+    mp.has_pre = false;   // the per-hit opacity takes the constant's place (set_material_texture must not overwrite has_pre = PH_PRE_OPACITY)
+    m.lobe_base = (uint32_t)s->lobes.size(); m.n_lobes = (uint32_t)lobes.size();
+    s->lobes.insert(s->lobes.end(), lobes.begin(), lobes.end());
+    m.bsdf_eta = 1.0f; m.bsdf_eta_alt = e; m.uber_eta = 1u;
+    mp.rebuilt = true;
+    return PBRT_HIP_OK;
+}
+// GlassMaterial with a roughness texture: which lobes a hit gets depends on `urough == 0 && vrough == 0` there (glass.rs:110-141): the list holds the smooth
+// alternative (FresnelSpecular; allow_multiple_lobes is true on this path) and the rough one (the microfacet pair)
+int glass_rebuild_for_roughness(PbrtHipScene* s, uint32_t material) {
+    PbrtHipScene::MaterialParams& mp = s->material_params[material];
+    MaterialRec& m = s->materials[material];
+    if (mp.rebuilt) return PBRT_HIP_OK;
+    uint32_t rtex1 = 0, ttex1 = 0;
+    for (uint32_t k = 0; k < m.n_lobes; k++) { const LobeRec& l = s->lobes[m.lobe_base + k]; if (l.r_tex1) rtex1 = l.r_tex1; if (l.t_tex1) ttex1 = l.t_tex1; }
+    float r[3], t[3];
+    const bool rb = clamp3(mp.raw_k[2], r), tb = clamp3(mp.raw_k[3], t);
+    std::vector<LobeRec> lobes;
+    for (int k = 0; k < 4; k++) { mp.lobe[k] = mp.lobe2[k] = -1; mp.field[k] = mp.field2[k] = 0; }
+    mp.rough_lobe = mp.rough_lobe2 = -1;
+    const bool has_r = rb || rtex1, has_t = tb || ttex1;
+    if (has_r || has_t) {
+        float ur = mp.raw_ur, vr = mp.raw_vr;
+        if (mp.raw_remap) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+        auto tag = [&](LobeRec& l, uint32_t alt) { l.alt = alt; l.ur_raw = mp.raw_ur; l.vr_raw = mp.raw_vr; set_tr(l, ur, vr); };
+        LobeRec f = lobe(PH_LK_FRESNEL_SPEC, T_REFL | T_TRANS | T_SPEC); std::memcpy(f.r, r, 12); std::memcpy(f.t, t, 12); f.r_tex1 = rtex1; f.t_tex1 = ttex1; f.eta_a = 1.0f; f.eta_b = mp.raw_eta;
+        tag(f, 1u);
+        mp.lobe[2] = 0; mp.field[2] = 0; mp.lobe[3] = 0; mp.field[3] = 1;
+        lobes.push_back(f);
+        if (has_r) { LobeRec l = lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = mp.raw_eta; std::memcpy(l.r, r, 12); l.r_tex1 = rtex1; tag(l, 2u);
+                     mp.lobe2[2] = (int)lobes.size(); mp.field2[2] = 0; lobes.push_back(l); }
+        if (has_t) { LobeRec l = lobe(PH_LK_MICRO_T, T_TRANS | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = mp.raw_eta; std::memcpy(l.t, t, 12); l.t_tex1 = ttex1; tag(l, 2u);
+                     mp.lobe2[3] = (int)lobes.size(); mp.field2[3] = 1; lobes.push_back(l); }
+    }
+    m.lobe_base = (uint32_t)s->lobes.size(); m.n_lobes = (uint32_t)lobes.size();
+    s->lobes.insert(s->lobes.end(), lobes.begin(), lobes.end());
+    mp.rebuilt = true;
+    return PBRT_HIP_OK;
+}
+}  // namespace phost
+
+extern "C" {
 
 // "the intersection is bogus" (triangle.rs:548-574): depends only on the triangle, so it is decided once here.
 static bool triangle_is_bogus(hm::V3 p0, hm::V3 p1, hm::V3 p2, const float* uv0, const float* uv1, const float* uv2) {

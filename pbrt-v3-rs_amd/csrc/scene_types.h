@@ -68,17 +68,22 @@ struct alignas(16) LobeRec {
     uint32_t kind, type, fresnel, n_scale; // type = BxDFType bits (bsdf.rs:10-20); n_scale = ScaledBxDF wrappers around the lobe (mix.rs)
     float a, b;                           // Oren-Nayar A, B
     float ax, ay;                         // Trowbridge-Reitz alpha_x, alpha_y (already max(0.001, .))
-    float eta_a, eta_b, pad1[2];          // dielectric Fresnel (eta_i, eta_t) / transmission lobes (etaA, etaB)
+    float eta_a, eta_b;                   // dielectric Fresnel (eta_i, eta_t) / transmission lobes (etaA, etaB)
+    uint32_t eta_tex1, k_tex1;            // MetalMaterial: 0, or 1 + the texture behind the conductor's eta / k (metal.rs:121-125; evaluated per hit, NOT clamped)
     float r[3]; uint32_t r_tex1;          // r_tex1 / t_tex1: 0, or 1 + the texture that supplies this colour at every hit (set_material_texture)
     float t[3]; uint32_t t_tex1;
-    float c_eta_t[3], pad4;               // conductor Fresnel: eta_t and k (eta_i is ONE, metal.rs:84-88)
-    float c_k[3], pad5;
-    float scale0[3], pad6;                // innermost ScaledBxDF scale
-    float scale1[3], pad7;
+    float c_eta_t[3]; uint32_t amt;       // conductor Fresnel: eta_t and k (eta_i is ONE, metal.rs:84-88).  amt: MixMaterial with an `amount` texture: bits 0-1 = 1: this lobe's
+    float c_k[3]; uint32_t alt;           //   scale[(amt >> 8) & 3] is the hit's s1, = 2: it is s2 = clamp(1 - s1) (mix.rs:59-60).  alt: GlassMaterial with roughness textures
+    float scale0[3], ur_raw;              //   (glass.rs:110-141): 1 = the lobe of hits where urough == vrough == 0, 2 = a lobe of the other hits; ur_raw / vr_raw: the constant
+    float scale1[3], vr_raw;              //   roughnesses before remapping.  scale0: innermost ScaledBxDF scale
     uint32_t ax_tex1, ay_tex1, remap, sigma_tex1;  // float textures for the Trowbridge-Reitz roughness (remapped per hit if `remap`) / MatteMaterial's sigma: 0 or 1 + id
     float pre[3]; uint32_t has_pre;       // 1: a textured colour of this lobe is multiplied by `pre`, then tested (UberMaterial: `op * kd.evaluate().clamp_default()`, uber.rs:133);
                                           // 2: the texel is tested, then multiplied (TranslucentMaterial: `if !kd.is_black() { add(r * kd) }`, translucent.rs:77-84, :87) -- PH_PRE_RAW_TEST
+                                          // 3: UberMaterial with an OPACITY TEXTURE: the colour is op(hit) * (texel, or the constant kept in `pre`) -- PH_PRE_OPACITY; 4: the pass-through
+                                          //    lobe's colour clamp(1 - op(hit)) (uber.rs:126-160) -- PH_PRE_PASSTHROUGH.  Lobes of kind 3 / 4 always take a colour slot of the texture pass
 };
+#define PH_PRE_OPACITY 3u
+#define PH_PRE_PASSTHROUGH 4u
 
 struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant textures) + the general lobe list
     float kd[3];      // already clamp_default()'ed
@@ -93,7 +98,10 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     uint32_t textured; // some lobe of the list takes a colour from a texture: the general-BSDF kernel builds the hit's own list
     uint32_t bump_tex1; // 0, or 1 + the displacement texture of Material::bump (core/src/material.rs:62-101)
     uint32_t sigma_tex1; // MatteMaterial: 0, or 1 + the float texture behind sigma (the one-lobe kernel reads it here, the general one in its lobe)
-    uint32_t pad[1];
+    uint32_t opacity_tex1; // UberMaterial (or a mix holding one): 0, or 1 + the opacity texture; lobes with has_pre 3 / 4 depend on it
+    uint32_t amount_tex1;  // MixMaterial: 0, or 1 + the `amount` texture (takes the FIRST colour slot of the texture pass)
+    float bsdf_eta_alt;    // UberMaterial with an opacity texture: BSDF::eta of the hits that do not get the pass-through lobe (uber.rs:128-137)
+    uint32_t uber_eta;     // 1: this material IS that uber (a mix holding one keeps eta 1)
 };
 // What the texture pass hands the shade pass for one path vertex (wavefront.hip: texture_kernel): the bumped shading frame and the evaluated,
 // clamped (and pre-multiplied) colours of the material's textured lobe colours, in template-lobe order (r before t).

@@ -485,48 +485,81 @@ PH_DEV float d_log(float x) { return (float)log((double)x); }
 PH_DEV void eval_lobe_scalars(const DeviceScene* dsc, const LobeRec& l, const TexCtx& ctx, TexOut& out) {
     if (l.sigma_tex1) {
         const float sig = pclampf(tex_eval(dsc, l.sigma_tex1 - 1u, ctx).r, 0.0f, 90.0f);
-        if (sig == 0.0f) { out.lambert = 1u; out.col[0][3] = 0.0f; out.col[1][3] = 0.0f; }
-        else { const float sg = sig * (kPi / 180.0f), s2 = sg * sg; out.lambert = 0u; out.col[0][3] = 1.0f - ph_div(s2, 2.0f * (s2 + 0.33f)); out.col[1][3] = ph_div(0.45f * s2, s2 + 0.09f); }
+        if (sig == 0.0f) { out.lambert |= 1u; out.col[0][3] = 0.0f; out.col[1][3] = 0.0f; }
+        else { const float sg = sig * (kPi / 180.0f), s2 = sg * sg; out.col[0][3] = 1.0f - ph_div(s2, 2.0f * (s2 + 0.33f)); out.col[1][3] = ph_div(0.45f * s2, s2 + 0.09f); }
     }
     if (l.ax_tex1 || l.ay_tex1) {
         float a[2] = {l.ax, l.ay};
+        float raw[2] = {l.ur_raw, l.vr_raw};   // GlassMaterial: `is_specular = urough == 0 && vrough == 0` on the values as the textures give them (glass.rs:111)
         const uint32_t tx[2] = {l.ax_tex1, l.ay_tex1};
         for (int k = 0; k < 2; k++) if (tx[k]) {
             float r = tex_eval(dsc, tx[k] - 1u, ctx).r;
+            raw[k] = r;
             if (l.remap) { r = pmaxf(r, 1e-3f); const float x = d_log(r); r = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x; }
             a[k] = pmaxf(0.001f, r);
         }
         out.col[0][3] = a[0]; out.col[1][3] = a[1];
+        if (l.alt && raw[0] == 0.0f && raw[1] == 0.0f) out.lambert |= 2u;
     }
 }
-PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, TexOut& out) {
+// does this colour of the lobe come from the texture pass?  (r before t; PH_PRE_OPACITY / PH_PRE_PASSTHROUGH lobes always: their colour depends on the hit's opacity)
+PH_DEV bool lobe_slot_r(const LobeRec& l) { return l.r_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T); }
+PH_DEV bool lobe_slot_t(const LobeRec& l) { return l.t_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH; }
+PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const MaterialRec& mr, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, TexOut& out) {
     uint32_t k = 0;
+    auto put = [&](spec c) { if (k < PH_HIT_COLS) { out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++; } };
+    if (mr.amount_tex1) put(tex_eval_clamped(dsc, mr.amount_tex1 - 1u, ctx));                           // mix.rs:59: s1 (s2 is made from it in the shade pass)
+    spec op = mks1(1.0f);
+    if (mr.opacity_tex1) op = tex_eval_clamped(dsc, mr.opacity_tex1 - 1u, ctx);                          // uber.rs:126
     for (uint32_t i = 0; i < n; i++) {
         const LobeRec& l = tmpl[i];
         if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1) eval_lobe_scalars(dsc, l, ctx, out);
-        const spec pre = l.has_pre ? mks(l.pre[0], l.pre[1], l.pre[2]) : mks1(1.0f);
-        const uint32_t texs[2] = {l.r_tex1, l.t_tex1};
-        for (int f = 0; f < 2; f++) if (texs[f] && k < PH_HIT_COLS) {
-            spec c = tex_eval_clamped(dsc, texs[f] - 1u, ctx);
-            if (l.has_pre == PH_PRE_RAW_TEST && c.r == 0.0f && c.g == 0.0f && c.b == 0.0f) out.bumped |= 1u << (8u + k);
-            if (l.has_pre) c = pre * c;
-            out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++;
+        if (l.has_pre == PH_PRE_PASSTHROUGH) { const spec t = op * -1.0f + mks1(1.0f); put(mks(pclampf(t.r, 0.0f, kInf), pclampf(t.g, 0.0f, kInf), pclampf(t.b, 0.0f, kInf))); continue; }   // (-op + ONE).clamp_default() (uber.rs:127)
+        if (l.has_pre == PH_PRE_OPACITY) {   // op * k.evaluate(..).clamp_default() (uber.rs:141, :147, :169, :175)
+            const uint32_t tex = l.kind == PH_LK_SPEC_T ? l.t_tex1 : l.r_tex1;
+            const spec base = tex ? tex_eval_clamped(dsc, tex - 1u, ctx) : mks(l.pre[0], l.pre[1], l.pre[2]);
+            put(op * base);
+        } else {
+            const spec pre = l.has_pre ? mks(l.pre[0], l.pre[1], l.pre[2]) : mks1(1.0f);
+            const uint32_t texs[2] = {l.r_tex1, l.t_tex1};
+            for (int f = 0; f < 2; f++) if (texs[f] && k < PH_HIT_COLS) {
+                spec c = tex_eval_clamped(dsc, texs[f] - 1u, ctx);
+                if (l.has_pre == PH_PRE_RAW_TEST && c.r == 0.0f && c.g == 0.0f && c.b == 0.0f) out.bumped |= 1u << (8u + k);
+                if (l.has_pre) c = pre * c;
+                put(c);
+            }
         }
+        if (l.eta_tex1) put(tex_eval(dsc, l.eta_tex1 - 1u, ctx));   // metal.rs:121-125: as the textures give them, no clamp
+        if (l.k_tex1) put(tex_eval(dsc, l.k_tex1 - 1u, ctx));
     }
 }
-// shade pass: the hit's own lobe list = template lobes with the texture pass's colours filled in, a lobe dropped where the reference would not add it
-PH_DEV uint32_t build_hit_lobes(const LobeRec* tmpl, uint32_t n, const TexOut* in, LobeRec* out) {
+// shade pass: the hit's own lobe list = template lobes with the texture pass's colours filled in, a lobe dropped where the reference would not add it.
+// eta_out: BSDF::eta of the hit when the material is an uber with an opacity texture (uber.rs:128-137), untouched otherwise.
+PH_DEV uint32_t build_hit_lobes(const MaterialRec& mr, const LobeRec* tmpl, uint32_t n, const TexOut* in, LobeRec* out, float& eta_out) {
     uint32_t k = 0, ci = 0;
+    float s1[3] = {1.0f, 1.0f, 1.0f}, s2[3] = {0.0f, 0.0f, 0.0f};
+    if (mr.amount_tex1) { for (int c = 0; c < 3; c++) { s1[c] = in->col[0][c]; s2[c] = pclampf(1.0f - s1[c], 0.0f, kInf); } ci = 1; }   // mix.rs:59-60
+    const bool is_specular = (in->lambert & 2u) != 0u;
+    bool passthrough = false;
     for (uint32_t i = 0; i < n && k < PH_HIT_LOBES; i++) {
         LobeRec l = tmpl[i];
-        if (l.sigma_tex1) { l.kind = in->lambert ? PH_LK_LAMBERT : PH_LK_OREN; l.a = in->col[0][3]; l.b = in->col[1][3]; }
+        if (l.sigma_tex1) { l.kind = (in->lambert & 1u) ? PH_LK_LAMBERT : PH_LK_OREN; l.a = in->col[0][3]; l.b = in->col[1][3]; }
         if (l.ax_tex1 || l.ay_tex1) { l.ax = in->col[0][3]; l.ay = in->col[1][3]; }
         bool raw_black = false;
-        if (l.r_tex1 && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; raw_black = raw_black || ((in->bumped >> (8u + ci)) & 1u); ci++; }
-        if (l.t_tex1 && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; raw_black = raw_black || ((in->bumped >> (8u + ci)) & 1u); ci++; }
+        if (lobe_slot_r(l) && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; raw_black = raw_black || ((in->bumped >> (8u + ci)) & 1u); ci++; }
+        if (lobe_slot_t(l) && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; raw_black = raw_black || ((in->bumped >> (8u + ci)) & 1u); ci++; }
+        if (l.eta_tex1 && ci < PH_HIT_COLS) { l.c_eta_t[0] = in->col[ci][0]; l.c_eta_t[1] = in->col[ci][1]; l.c_eta_t[2] = in->col[ci][2]; ci++; }
+        if (l.k_tex1 && ci < PH_HIT_COLS) { l.c_k[0] = in->col[ci][0]; l.c_k[1] = in->col[ci][1]; l.c_k[2] = in->col[ci][2]; ci++; }
+        if (l.amt & 3u) {
+            float* sc = ((l.amt >> 8) & 3u) == 0u ? l.scale0 : l.scale1;
+            const float* v = (l.amt & 3u) == 1u ? s1 : s2;
+            sc[0] = v[0]; sc[1] = v[1]; sc[2] = v[2];
+        }
+        if ((l.alt == 1u && !is_specular) || (l.alt == 2u && is_specular)) continue;   // glass.rs:112-141: FresnelSpecular, or the microfacet pair (slots consumed either way)
         // TranslucentMaterial's lobes: the texel decided (an untextured one exists because its constant passed the test when the material was made)
-        if (l.has_pre == PH_PRE_RAW_TEST ? !raw_black : lobe_keep(l)) out[k++] = l;
+        if (l.has_pre == PH_PRE_RAW_TEST ? !raw_black : lobe_keep(l)) { if (l.has_pre == PH_PRE_PASSTHROUGH) passthrough = true; out[k++] = l; }
     }
+    if (mr.uber_eta) eta_out = passthrough ? 1.0f : mr.bsdf_eta_alt;
     return k;
 }
 

@@ -285,7 +285,36 @@ int pbrt_hip_set_texture_mapping(PbrtHipScene* s, uint32_t texture, int kind, co
 // texture's value at that hit.
 int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param, uint32_t texture) {
     if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: unknown material or texture");
-    if (param < 0 || param > 3) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: param must be PBRT_HIP_PARAM_KD / KS / KR / KT");
+    if (param < 0 || param > 7) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: param must be PBRT_HIP_PARAM_KD / KS / KR / KT / OPACITY / AMOUNT / ETA / K");
+    if (param >= PBRT_HIP_PARAM_OPACITY) {   // parameters that are not one lobe's colour
+        PbrtHipScene::MaterialParams& mq = s->material_params[material];
+        MaterialRec& mm = s->materials[material];
+        if (param == PBRT_HIP_PARAM_OPACITY) {      // uber.rs:126-160
+            if (mq.made_as != 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: opacity belongs to UberMaterial");
+            const int rc = uber_rebuild_for_opacity(s, material);
+            if (rc) return rc;
+            mm.opacity_tex1 = texture + 1u;
+        } else if (param == PBRT_HIP_PARAM_AMOUNT) {  // mix.rs:59-60
+            if (mq.made_as != 4) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: amount belongs to MixMaterial");
+            uint32_t cols = 1;
+            for (uint32_t i = 0; i < mm.n_lobes; i++) {
+                LobeRec& l = s->lobes[mm.lobe_base + i];
+                l.amt = ((int)i < mq.mix_n1 ? 1u : 2u) | ((l.n_scale - 1u) << 8);
+                cols += (l.r_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T) ? 1u : 0u) + (l.t_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH ? 1u : 0u) +
+                        (l.eta_tex1 ? 1u : 0u) + (l.k_tex1 ? 1u : 0u);
+            }
+            if (cols > PH_HIT_COLS || mm.n_lobes > PH_HIT_LOBES) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: a mix with a textured amount may have at most 5 more per-hit colours");
+            mm.amount_tex1 = texture + 1u;
+        } else {                                     // metal.rs:121-125
+            if (mq.made_as != 3) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: eta / k belong to MetalMaterial");
+            LobeRec& l = s->lobes[mm.lobe_base];
+            (param == PBRT_HIP_PARAM_ETA ? l.eta_tex1 : l.k_tex1) = texture + 1u;
+        }
+        mm.textured = 1u;
+        s->textured_materials = true;
+        s->uploaded = false;
+        return PBRT_HIP_OK;
+    }
     const PbrtHipScene::MaterialParams& mp = s->material_params[material];
     if (mp.lobe[param] < 0)
         return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: this material has no lobe fed by that parameter (matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, "
@@ -295,7 +324,7 @@ int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param,
     for (int k = 0; k < 2; k++) if (fed[k] >= 0) {
         LobeRec& l = s->lobes[m.lobe_base + (uint32_t)fed[k]];
         if (fields[k] == 0) l.r_tex1 = texture + 1u; else l.t_tex1 = texture + 1u;
-        if (mp.has_pre) { l.has_pre = 1u; std::memcpy(l.pre, mp.pre, 12); }
+        if (mp.has_pre && l.has_pre < PH_PRE_OPACITY) { l.has_pre = 1u; std::memcpy(l.pre, mp.pre, 12); }
         if ((l.kind == PH_LK_LAMBERT || l.kind == PH_LK_OREN) && m.n_lobes == 1u && l.has_pre == 0u) m.kd_tex1 = texture + 1u;  // MatteMaterial: the one-lobe kernel reads kd_tex1
     }
     m.textured = 1u;
@@ -314,6 +343,12 @@ int pbrt_hip_set_material_float_texture(PbrtHipScene* s, uint32_t material, int 
         if (m.none || m.n_lobes != 1u || !(s->lobes[m.lobe_base].kind == PH_LK_LAMBERT || s->lobes[m.lobe_base].kind == PH_LK_OREN))
             return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_float_texture: sigma belongs to MatteMaterial (created with a non-black Kd)");
         s->lobes[m.lobe_base].sigma_tex1 = texture + 1u; m.sigma_tex1 = texture + 1u;
+    } else if (mp.made_as == 2) {   // glass: both alternatives carry the textures (the smooth one for its `== 0` test), glass.rs:110-141
+        const int rc = glass_rebuild_for_roughness(s, material);
+        if (rc) return rc;
+        MaterialRec& mg = s->materials[material];
+        if (mg.n_lobes == 0) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_float_texture: this glass has neither reflection nor transmission");
+        for (uint32_t i = 0; i < mg.n_lobes; i++) { LobeRec& l = s->lobes[mg.lobe_base + i]; (fparam == 1 ? l.ax_tex1 : l.ay_tex1) = texture + 1u; l.remap = s->material_params[material].raw_remap ? 1u : 0u; }
     } else {
         if (mp.rough_lobe < 0) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_float_texture: this material has no microfacet lobe whose roughness could be textured (plastic, uber, substrate, translucent and metal have; glass switches lobes on roughness == 0 and is not wired)");
         const int rl[2] = {mp.rough_lobe, mp.rough_lobe2};

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             out.bumped = 1u;
         }
         for (int k = 0; k < PH_HIT_COLS; k++) out.col[k][0] = out.col[k][1] = out.col[k][2] = out.col[k][3] = 0.0f;
-        if (mr.textured) eval_lobe_colours(sc.self, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out);
+        if (mr.textured) eval_lobe_colours(sc.self, mr, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out);
 
         float4* dst = reinterpret_cast<float4*>(w.tex_out + pid);
         const float4* src = reinterpret_cast<const float4*>(&out);
@@ -244,7 +244,7 @@ template <> struct BsdfOps<false> {
     static PH_DEV float eta(const T&) { return 1.0f; }
     static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec*, const MaterialRec& mr) {  // MatteMaterial: Kd and / or sigma of this hit
         if (mr.kd_tex1) { const spec kd = mks(to->col[0][0], to->col[0][1], to->col[0][2]); b.r = kd; b.has_bxdf = !is_black(kd); }
-        if (mr.sigma_tex1) { b.oren = to->lambert == 0u; b.a = to->col[0][3]; b.b = to->col[1][3]; }
+        if (mr.sigma_tex1) { b.oren = (to->lambert & 1u) == 0u; b.a = to->col[0][3]; b.b = to->col[1][3]; }
     }
 };
 template <> struct BsdfOps<true> {
@@ -257,8 +257,8 @@ template <> struct BsdfOps<true> {
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, BX_ALL, f, pdf, wi, type); }
     static PH_DEV float eta(const T& b) { return b.eta; }
     // the hit's own lobe list goes to the thread's slots of WfParams::hit_lobes
-    static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec* slots, const MaterialRec&) {
-        b.n = build_hit_lobes(b.lobes, b.n, to, slots);
+    static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec* slots, const MaterialRec& mr) {
+        b.n = build_hit_lobes(mr, b.lobes, b.n, to, slots, b.eta);
         b.lobes = slots;
     }
 };

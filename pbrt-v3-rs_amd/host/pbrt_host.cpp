@@ -478,18 +478,19 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::array<float, 3> kd = {0.5f, 0.5f, 0.5f};
     float sigma = 0.0f;
     int64_t ftex_param[3] = {-1, -1, -1};     // [sigma, uroughness, vroughness]: the same for float parameters
-    int64_t tex_param[4] = {-1, -1, -1, -1};  // [Kd, Ks, Kr, Kt]: the parameter names a texture the library evaluates per hit
+    int64_t tex_param[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // [Kd, Ks, Kr, Kt, opacity, amount, eta, k]: the parameter names a texture the library evaluates per hit
     auto spectrum_tex = [&](const std::string& pname, std::array<float, 3> d) {
         std::string tn = m.params.find_one_texture(pname);
         if (!tn.empty()) {
             auto dt = gs_.device_textures.find(tn);
             if (dt != gs_.device_textures.end()) {
                 // a texture the library evaluates per hit: the material is created with a white placeholder and the texture attached afterwards
-                const int param = pname == "Kd" ? 0 : (pname == "Ks" ? 1 : (pname == "Kr" ? 2 : (pname == "Kt" ? 3 : -1)));
+                const int param = pname == "Kd" ? 0 : (pname == "Ks" ? 1 : (pname == "Kr" ? 2 : (pname == "Kt" ? 3 : (pname == "opacity" ? 4 : (pname == "amount" ? 5 : (pname == "eta" ? 6 : (pname == "k" ? 7 : -1)))))));
                 const bool takes = (m.type == "matte" && param == 0) || ((m.type == "plastic" || m.type == "substrate") && (param == 0 || param == 1)) || (m.type == "mirror" && param == 2) ||
-                                   (m.type == "glass" && (param == 2 || param == 3)) || (m.type == "uber" && param >= 0) || (m.type == "translucent" && (param == 0 || param == 1));
+                                   (m.type == "glass" && (param == 2 || param == 3)) || (m.type == "uber" && param >= 0 && param <= 4) || (m.type == "translucent" && (param == 0 || param == 1)) ||
+                                   (m.type == "mix" && param == 5) || (m.type == "metal" && (param == 6 || param == 7));
                 if (!takes || dt->second.is_float) {
-                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit textures are wired to matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, glass Kr / Kt, uber Kd / Ks / Kr / Kt and translucent Kd / Ks so far";
+                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit spectrum textures are wired to matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, glass Kr / Kt, uber Kd / Ks / Kr / Kt / opacity, translucent Kd / Ks, mix amount and metal eta / k";
                     return m.params.find_one_rgb(pname, d);
                 }
                 tex_param[param] = (int64_t)dt->second.id;
@@ -511,9 +512,10 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
             if (dtf != gs_.device_textures.end()) {
                 // a float texture the library evaluates per hit: sigma (matte) or the microfacet roughness (plastic, uber, substrate, metal, translucent)
                 const int fp = pname == "sigma" ? 0 : ((pname == "uroughness" || pname == "roughness") ? 1 : (pname == "vroughness" ? 2 : -1));
-                const bool takes = dtf->second.is_float && ((m.type == "matte" && fp == 0) || ((m.type == "plastic" || m.type == "uber" || m.type == "substrate" || m.type == "metal" || m.type == "translucent") && fp > 0));
+                const bool takes = dtf->second.is_float && ((m.type == "matte" && fp == 0) || ((m.type == "plastic" || m.type == "uber" || m.type == "substrate" || m.type == "metal" || m.type == "translucent") && fp > 0) ||
+                                                            (m.type == "glass" && fp > 0 && pname != "roughness"));
                 if (!takes) {
-                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit float textures are wired to matte sigma and to the roughness of plastic / uber / substrate / metal / translucent so far";
+                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit float textures are wired to matte sigma and to the roughness of plastic / uber / substrate / metal / translucent / glass";
                     return m.params.find_one_float(pname, d);
                 }
                 if (pname == "roughness") { if (ftex_param[1] < 0) ftex_param[1] = (int64_t)dtf->second.id; if (ftex_param[2] < 0) ftex_param[2] = (int64_t)dtf->second.id; }
@@ -574,9 +576,10 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
         a3 = spectrum_tex("Kr", one); b3 = spectrum_tex("Kt", one); f0 = float_tex("uroughness", 0.0f); f1 = float_tex("vroughness", 0.0f); f2 = eta_of();
         put3(a3); put3(b3); kv.push_back(f0); kv.push_back(f1); kv.push_back(f2);
     } else if (t == "metal") {
-        if (!(m.params.floats.count("eta") && m.params.floats.count("k")) && error.empty())
-            error = "Material \"metal\": give 'rgb eta' and 'rgb k' (the reference's copper default and named spectra need its spectral tables, which this host does not carry)";
-        a3 = m.params.find_one_rgb("eta", one); b3 = m.params.find_one_rgb("k", one); uv_rough(0.01f, f0, f1);
+        const bool eta_given = m.params.floats.count("eta") || !m.params.find_one_texture("eta").empty(), k_given = m.params.floats.count("k") || !m.params.find_one_texture("k").empty();
+        if (!(eta_given && k_given) && error.empty())
+            error = "Material \"metal\": give 'rgb eta' and 'rgb k' (or textures for them; the reference's copper default and named spectra need its spectral tables, which this host does not carry)";
+        a3 = spectrum_tex("eta", one); b3 = spectrum_tex("k", one); uv_rough(0.01f, f0, f1);
         put3(a3); put3(b3); kv.push_back(f0); kv.push_back(f1);
     } else if (t == "uber") {
         a3 = spectrum_tex("Kd", quarter); b3 = spectrum_tex("Ks", quarter); c3 = spectrum_tex("Kr", zero); d3 = spectrum_tex("Kt", zero); e3 = spectrum_tex("opacity", one);
@@ -613,7 +616,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     for (float v : kv) { uint32_t u; std::memcpy(&u, &v, 4); char b[12]; std::snprintf(b, sizeof b, ":%08x", u); key += b; }
     if (bump_tex >= 0) key += "|bump=" + std::to_string(bump_tex);
     for (int k = 0; k < 3; k++) if (ftex_param[k] >= 0) key += "|ftex" + std::to_string(k) + "=" + std::to_string(ftex_param[k]);
-    for (int k = 0; k < 4; k++) if (tex_param[k] >= 0) key += "|tex" + std::to_string(k) + "=" + std::to_string(tex_param[k]);
+    for (int k = 0; k < 8; k++) if (tex_param[k] >= 0) key += "|tex" + std::to_string(k) + "=" + std::to_string(tex_param[k]);
     auto it = material_cache_.find(key);
     if (it != material_cache_.end()) return it->second;
     uint32_t id = 0;
@@ -629,10 +632,13 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     else if (t == "mix") rc = ABI(pbrt_hip_add_material_mix(scene_, (uint32_t)f0, (uint32_t)f1, a3.data(), &id));
     else rc = ABI(pbrt_hip_add_material_uber(scene_, a3.data(), b3.data(), c3.data(), d3.data(), e3.data(), f0, f1, f2, remap ? 1 : 0, &id));
     if (!check(rc, "add_material")) return 0;
+    // colours first, then the scalars, then the structural parameters (opacity / amount rebuild or annotate the lobe list the others have filled in)
     for (int k = 0; k < 4; k++)
         if (tex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_texture(scene_, id, k, (uint32_t)tex_param[k])), "set_material_texture")) return 0;
     for (int k = 0; k < 3; k++)
         if (ftex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_float_texture(scene_, id, k, (uint32_t)ftex_param[k])), "set_material_float_texture")) return 0;
+    for (int k = 4; k < 8; k++)
+        if (tex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_texture(scene_, id, k, (uint32_t)tex_param[k])), "set_material_texture")) return 0;
     if (bump_tex >= 0 && !check(ABI(pbrt_hip_set_material_bump(scene_, id, (uint32_t)bump_tex)), "set_material_bump")) return 0;
     material_cache_[key] = id;
     return id;

@@ -584,10 +584,10 @@ class Scene:
     def add_material_matte_tex(self, kd_texture, sigma=0.0):
         out = C.c_uint32(0); self._chk(self.b.fn("add_material_matte_tex")(self.h, kd_texture, C.c_float(sigma), C.byref(out))); return out.value
 
-    PARAM = {"Kd": 0, "Ks": 1, "Kr": 2, "Kt": 3}
+    PARAM = {"Kd": 0, "Ks": 1, "Kr": 2, "Kt": 3, "opacity": 4, "amount": 5, "eta": 6, "k": 7}
 
     def set_material_texture(self, material, param, texture):
-        """param: "Kd" | "Ks" | "Kr" | "Kt" — that colour of `material` becomes `texture`, evaluated per hit."""
+        """param: "Kd" | "Ks" | "Kr" | "Kt" | "opacity" (uber) | "amount" (mix) | "eta" | "k" (metal) — that parameter of `material` becomes `texture`, evaluated per hit."""
         self._chk(self.b.fn("set_material_texture")(self.h, material, self.PARAM[param], texture))
 
     def set_last_mesh_alpha_textures(self, alpha=None, shadow_alpha=None):

@@ -102,14 +102,20 @@ def textured_material(s, host, rng):
         if rng.integers(0, 3) == 0: s.set_material_float_texture(m, str(rng.choice(["uroughness", "vroughness"])), ftex(0.5))
     elif k == 4:
         rough = float(rng.choice([0.0, rng.uniform(0.02, 0.3)]))
-        m = s.add_material_glass(one, one, rough, rough, float(rng.uniform(1.1, 1.8)), True)
+        m = s.add_material_glass(one, one, rough, rough, float(rng.uniform(1.1, 1.8)), bool(rng.integers(0, 2)))
         s.set_material_texture(m, "Kr", tex()); s.set_material_texture(m, "Kt", tex())
+        if rng.integers(0, 2):   # roughness textures: a checkerboard of 0 and a rough value makes both lobe structures appear in one image (glass.rs:110-141)
+            zero_or = lambda: s.add_texture_checkerboard(s.add_texture_constant(0.0), s.add_texture_constant(float(rng.uniform(0.05, 0.4))), su=float(rng.uniform(2, 9)), sv=float(rng.uniform(2, 9)), aa="none")
+            which = int(rng.integers(0, 3))
+            if which != 1: s.set_material_float_texture(m, "uroughness", zero_or() if rng.integers(0, 2) else ftex(0.4))
+            if which != 0: s.set_material_float_texture(m, "vroughness", zero_or() if rng.integers(0, 2) else ftex(0.4))
     elif k == 5:
         op = float(rng.choice([1.0, rng.uniform(0.3, 0.9)]))
         m = s.add_material_uber(one, one, one, one, (op, op, op), float(rng.uniform(0.02, 0.3)), float(rng.uniform(0.02, 0.3)), float(rng.uniform(1.1, 1.7)), True)
         for prm in ("Kd", "Ks", "Kr", "Kt"):
             if rng.integers(0, 2): s.set_material_texture(m, prm, tex())
         if rng.integers(0, 3) == 0: s.set_material_float_texture(m, "uroughness", ftex(0.4))
+        if rng.integers(0, 2): s.set_material_texture(m, "opacity", tex())   # uber.rs:126-160: pass-through lobe, colours and BSDF::eta per hit
     elif k == 6 or k == 7:
         def leaf(rough_ok):
             refl, trans = c(), c()
@@ -133,7 +139,21 @@ def textured_material(s, host, rng):
             a = s.add_material_plastic(one, c(0.05, 0.5), float(rng.uniform(0.01, 0.4)), bool(rng.integers(0, 2))); s.set_material_texture(a, "Kd", tex())
             if rng.integers(0, 3) == 0: s.set_material_float_texture(a, "roughness", ftex(0.5))
             b = leaf(False) if rng.integers(0, 2) else s.add_material_matte_tex(tex(), float(rng.choice([0.0, rng.uniform(1, 60)])))
-            return s.add_material_mix(a, b, c())
+            for sub in (a, b):   # bump-mapped children: the first one's map shapes the mixture's frame, the second one's changes nothing (mix.rs:63-76)
+                if rng.integers(0, 3) == 0:
+                    s.set_material_bump(sub, s.add_texture_scale(random_texture(s, host, rng, True), s.add_texture_constant(float(rng.uniform(0.005, 0.2)))))
+            mx = s.add_material_mix(a, b, c())
+            if rng.integers(0, 2):
+                try: s.set_material_texture(mx, "amount", tex())
+                except (pbrt_hip.PbrtHipError, RuntimeError) as e:
+                    if "per-hit colours" not in str(e): raise            # more than six colour slots: the product refuses; the constant amount stays on both sides
+                    return mx
+            return mx
+    elif k == 8 and rng.integers(0, 2):
+        m = s.add_material_metal(c(0.1, 2.0), c(1.0, 4.0), float(rng.uniform(0.01, 0.3)), float(rng.uniform(0.01, 0.3)), bool(rng.integers(0, 2)))
+        if rng.integers(0, 2): s.set_material_texture(m, "eta", s.add_texture_scale(tex(), s.add_texture_constant(2.0)))
+        s.set_material_texture(m, "k", s.add_texture_scale(tex(), s.add_texture_constant(4.0)))
+        if rng.integers(0, 3) == 0: s.set_material_float_texture(m, "roughness", ftex(0.5))
     else:
         m = F.random_material(s, rng)       # a constant material, possibly only bumped
         if rng.integers(0, 2) == 0: return m

@@ -281,8 +281,12 @@ def test_set_material_texture_errors():
     pl = s.add_material_plastic((1, 1, 1), (0.2, 0.2, 0.2), 0.1, True); s.set_material_texture(pl, "Kd", t)
     s.add_material_mix(pl, glass, (0.5, 0.5, 0.5))                            # textured sub-materials mix
     bumpy = s.add_material_matte((0.5, 0.5, 0.5), 0.0); s.set_material_bump(bumpy, s.add_texture_constant(0.1))
-    with pytest.raises(pbrt_hip.PbrtHipError, match="bumps the interaction in turn"):
-        s.add_material_mix(pl, bumpy, (0.5, 0.5, 0.5))
+    s.add_material_mix(pl, bumpy, (0.5, 0.5, 0.5))                            # bump-mapped children are taken (films: tests/test_textured_params.py)
+    mx = s.add_material_mix(bumpy, pl, (0.5, 0.5, 0.5)); s.set_material_texture(mx, "amount", t)
+    with pytest.raises(pbrt_hip.PbrtHipError, match="amount is a texture"):
+        s.add_material_mix(mx, pl, (0.5, 0.5, 0.5))
+    with pytest.raises(pbrt_hip.PbrtHipError, match="opacity belongs to UberMaterial"):
+        s.set_material_texture(pl, "opacity", t)
     r1 = s.add_material_plastic((0.5, 0.5, 0.5), (0.2, 0.2, 0.2), 0.1, True); s.set_material_float_texture(r1, "roughness", s.add_texture_constant(0.2))
     r2 = s.add_material_plastic((0.5, 0.5, 0.5), (0.2, 0.2, 0.2), 0.1, True); s.set_material_float_texture(r2, "roughness", s.add_texture_constant(0.3))
     with pytest.raises(pbrt_hip.PbrtHipError, match="one textured roughness"):
