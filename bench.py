@@ -290,6 +290,10 @@ def main():
                     roof.update({"traffic": int(per_launch), "achieved_memory_side": round(mem_gbs, 1), "frac": round(mem_gbs / HBM_PEAK_GBS, 4),
                                  "frac_basis": "memory-side: traffic / avg_launch_ms / peak",
                                  "l2_hit_rate": round(k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]), 4) if k.get("TCC_HIT") and k.get("TCC_MISS") else None,
+                                 "pmc": k.get("sq"),
+                                 "limiter": ("VALU issue, not memory: the SIMDs' vector pipes are busy %.0f %% of the time (PMC SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per SIMD) at a lane utilisation of %.2f, "
+                                             "L2 serves %.0f %% of the requests since the rays of a launch are binned by origin cell" %
+                                             (100.0 * min(1.0, k["sq"]["valu_active_of_wave_cycles"] * 6.0), k["sq"]["valu_lane_utilisation"], 100.0 * k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]))) if k.get("sq") else None,
                                  "traffic_note": "bytes per launch leaving the L2s (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE over " + str(k["dispatches"]) + " traversal launches of one frame, " +
                                                  e.get("source", "profiles/") + "; " + e.get("calibration", "") + ")"})
                 else:

@@ -277,6 +277,11 @@ int pbrt_hip_set_sobol_tables(PbrtHipScene*, const uint32_t* sobol_matrices32, s
  * and returns UNSUPPORTED. */
 int pbrt_hip_build_accel(PbrtHipScene*, int split_method, int max_prims_in_node);
 
+/* The same for split_method 1 with the tree constructed on the GPU (Morton codes, radix sort, one treelet per thread, SAH over the treelet roots on the host;
+ * accelerators/src/bvh/hlbvh.rs:33-449, morton.rs:33-120): identical topology, leaf order and boxes, so hits do not depend on where the tree was built.
+ * SAH (0) and EqualCounts (3) are host builds: UNSUPPORTED here; so are scenes with object instances. */
+int pbrt_hip_build_accel_device(PbrtHipScene*, int split_method, int max_prims_in_node);
+
 /* World bound of the built aggregate (BVHAccel::world_bound, bvh/mod.rs:161-167): {pmin[3], pmax[3]}. */
 int pbrt_hip_world_bound(const PbrtHipScene*, float out_bounds[6]);
 

@@ -1040,9 +1040,16 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
     };
     s->inst_recs.clear();
     if (s->objects.empty()) {
-        const int brc = phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh);
+        int brc;
+        if (s->build_on_device) {   // pbrt_hip_build_accel_device: the same HLBVH, made by kernels (bvh_device.hip)
+            PH_CHECK(s, hipSetDevice(s->device));
+            std::string e;
+            brc = phost::build_hlbvh_device(in, max_prims_in_node, s->stream, s->bvh, e);
+            if (brc == -1) return set_err(s, PBRT_HIP_ERR_DEVICE, "build_accel_device: " + e);
+        } else brc = phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh);
         if (brc != 0) return fail(brc);
     } else {
+        if (s->build_on_device) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel_device: scenes with object instances take the host builder");
         if (s->open_object >= 0) return set_err(s, PBRT_HIP_ERR_STATE, "build_accel: an object definition is still open (missing ObjectEnd)");
         // 1. one aggregate per instanced object (make_accelerator at ObjectInstance time, lib.rs:953-971), appended to shared arrays
         struct Built { bool done = false; uint32_t root_ref = PH_INVALID_REF; float lo[3], hi[3]; bool single = false; };
@@ -1121,6 +1128,16 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
     }
     s->built = true; s->uploaded = false;
     return PBRT_HIP_OK;
+}
+
+// BVHAccel::from with splitmethod "hlbvh", constructed on the GPU (bvh_device.hip): same tree, same leaf order as pbrt_hip_build_accel(s, 1, ..)
+int pbrt_hip_build_accel_device(PbrtHipScene* s, int split_method, int max_prims_in_node) {
+    if (!s) return PBRT_HIP_ERR_INVALID_ARG;
+    if (split_method != 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel_device: the device builder makes the HLBVH tree (split_method 1); SAH and EqualCounts are built on the host");
+    s->build_on_device = true;
+    const int rc = pbrt_hip_build_accel(s, split_method, max_prims_in_node);
+    s->build_on_device = false;
+    return rc;
 }
 
 int pbrt_hip_world_bound(const PbrtHipScene* s, float out[6]) {

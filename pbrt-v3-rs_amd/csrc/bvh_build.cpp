@@ -359,6 +359,46 @@ struct Builder {
 
 }  // namespace
 
+int build_upper_sah(const float* root_bounds, size_t n_roots, std::vector<UpperNode>& out_nodes, int& out_root) {
+    out_nodes.clear(); out_root = -1;
+    if (n_roots == 0) return 0;
+    Builder B;
+    B.pool.resize(2 * n_roots + 2 * Builder::kArenaChunk);
+    std::vector<BNode> leaves(n_roots);
+    std::vector<BNode*> roots(n_roots);
+    for (size_t t = 0; t < n_roots; t++) {
+        BNode& l = leaves[t];
+        for (int k = 0; k < 3; k++) { l.b.lo[k] = root_bounds[6 * t + k]; l.b.hi[k] = root_bounds[6 * t + 3 + k]; }
+        l.kid[0] = l.kid[1] = nullptr; l.first = (uint32_t)t; l.count = 1; l.axis = 0;
+        roots[t] = &l;
+    }
+    BNode* root = B.upper_sah(roots, 0, n_roots);
+    if (B.panic) return -2;
+    // pre-order flattening; a node that is one of `leaves` stands for its treelet
+    auto is_treelet = [&](const BNode* nd) { return nd >= leaves.data() && nd < leaves.data() + n_roots; };
+    if (is_treelet(root)) { out_root = -1 - (int)(root - leaves.data()); return 0; }
+    struct Item { const BNode* n; int self; };
+    std::vector<Item> stack;
+    out_nodes.emplace_back();
+    out_root = 0;
+    stack.push_back({root, 0});
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        int kid[2];
+        for (int c = 0; c < 2; c++) {
+            const BNode* k = it.n->kid[c];
+            if (is_treelet(k)) kid[c] = -1 - (int)(k - leaves.data());
+            else { kid[c] = (int)out_nodes.size(); out_nodes.emplace_back(); }
+        }
+        UpperNode& u = out_nodes[(size_t)it.self];
+        for (int k = 0; k < 3; k++) { u.lo[k] = it.n->b.lo[k]; u.hi[k] = it.n->b.hi[k]; }
+        u.kid[0] = kid[0]; u.kid[1] = kid[1]; u.axis = it.n->axis;
+        if (kid[1] >= 0) stack.push_back({it.n->kid[1], kid[1]});
+        if (kid[0] >= 0) stack.push_back({it.n->kid[0], kid[0]});
+    }
+    return 0;
+}
+
 int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int n_threads, BuildOutput& out) {
     if (split_method != 0 && split_method != 1 && split_method != 3) return -1;
     out = BuildOutput();

@@ -43,4 +43,10 @@ struct BuildOutput {
 // Returns 0 on success, -1 on invalid arguments, -2 where the reference's HLBVH build would hit an assertion.
 int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int n_threads, BuildOutput& out);
 
+// HLBVH's SAH over the treelet roots (hlbvh.rs:296-432) on its own, for the device builder (bvh_device.hip): root_bounds = {lo xyz, hi xyz} per treelet.
+// Nodes come out in pre-order; a child >= 0 is another UpperNode, a child < 0 is treelet -1 - child.  root likewise (a single treelet: root = -1, no nodes).
+// Returns 0, or -2 where the reference's assertions fire (:338, :356, :418).
+struct UpperNode { float lo[3], hi[3]; int kid[2]; int axis; };
+int build_upper_sah(const float* root_bounds, size_t n_roots, std::vector<UpperNode>& out_nodes, int& out_root);
+
 }  // namespace phost

@@ -69,6 +69,7 @@ struct PbrtHipScene : SceneHostState {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    bool build_on_device = false;    // set for the duration of pbrt_hip_build_accel_device
     MultiDevice* multi = nullptr;    // non-null on a handle made by pbrt_hip_scene_create_multi: the other devices' contexts and the exchange state
 
     // ---- device residency ---------------------------------------------------------------------------------------------
@@ -102,6 +103,7 @@ int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_ou
 void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph::TravParams& p);  // 0 closest, 1 any hit, 2 both (MIXED)
 int ensure_traversal_workspace(PbrtHipScene* s);
 void free_wavefront(PbrtHipScene* s);
+int build_hlbvh_device(const BuildInput& in, int max_prims_in_node, hipStream_t stream, BuildOutput& out, std::string& err);   // bvh_device.hip
 int uber_rebuild_for_opacity(PbrtHipScene* s, uint32_t material);    // api.hip: lobe lists remade when a structural parameter becomes a texture
 int glass_rebuild_for_roughness(PbrtHipScene* s, uint32_t material);
 // wavefront.hip: the renderer's building blocks, shared with the multi-device driver (multi.hip)

@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <zlib.h>
 
 namespace pbrt_host {
@@ -52,7 +54,7 @@ bool read_pfm(const std::vector<unsigned char>& d, std::vector<float>& rgb, int&
     if (!nc) { err = "PFM: invalid type '" + ty + "'"; return false; }
     w = std::atoi(sw.c_str()); h = std::atoi(sh.c_str());
     float scale = std::strtof(ss.c_str(), nullptr);
-    if (w <= 0 || h <= 0) { err = "PFM: bad resolution"; return false; }
+    if (w <= 0 || h <= 0 || (long long)w * h > (1ll << 28)) { err = "PFM: bad resolution (or larger than 2^28 pixels)"; return false; }
     const bool little = scale < 0.0f;
     scale = std::fabs(scale);
     const size_t n = (size_t)nc * (size_t)w * (size_t)h;
@@ -138,6 +140,7 @@ bool read_png(const std::vector<unsigned char>& d, std::vector<float>& rgb, int&
         pos += 12 + (size_t)len;
     }
     if (!have_hdr || w <= 0 || h <= 0) { err = "PNG: missing IHDR"; return false; }
+    if ((long long)w * h > (1ll << 28)) { err = "PNG: larger than 2^28 pixels"; return false; }
     if (depth != 8 || interlace != 0) { err = "PNG: only 8 bits per channel, non-interlaced images are decoded"; return false; }
     int ch;
     switch (ctype) { case 0: ch = 1; break; case 2: ch = 3; break; case 3: ch = 1; break; case 4: ch = 2; break; case 6: ch = 4; break; default: err = "PNG: bad colour type"; return false; }
@@ -217,19 +220,21 @@ bool read_exr(const std::vector<unsigned char>& d, std::vector<float>& rgb, int&
         if (pos + size > d.size()) { err = "EXR: truncated header"; return false; }
         if (name == "channels") {
             size_t q = pos;
-            while (q < pos + size && d[q]) {
+            const size_t end = pos + size;   // every cursor stays inside the attribute (which the check above keeps inside the file)
+            while (q < end && d[q]) {
                 Chan c;
-                while (d[q]) c.name.push_back((char)d[q++]);
+                while (q < end && d[q]) c.name.push_back((char)d[q++]);
                 q++;
+                if (q + 16 > end) { err = "EXR: truncated channel list"; return false; }
                 c.type = (int)u32(q);
                 const uint32_t xs = u32(q + 8), ys = u32(q + 12);
                 if (xs != 1 || ys != 1) { err = "EXR: subsampled channels are not decoded by this host (convert the map to .pfm, .png or .tga)"; return false; }
                 q += 16;
                 chans.push_back(c);
             }
-        } else if (name == "compression") compression = d[pos];
-        else if (name == "dataWindow") for (int k = 0; k < 4; k++) dw[k] = (int)u32(pos + 4 * (size_t)k);
-        else if (name == "lineOrder") line_order = d[pos];
+        } else if (name == "compression") { if (size < 1) { err = "EXR: empty compression attribute"; return false; } compression = d[pos]; }
+        else if (name == "dataWindow") { if (size < 16) { err = "EXR: short dataWindow attribute"; return false; } for (int k = 0; k < 4; k++) dw[k] = (int)u32(pos + 4 * (size_t)k); }
+        else if (name == "lineOrder") { if (size < 1) { err = "EXR: empty lineOrder attribute"; return false; } line_order = d[pos]; }
         pos += size;
     }
     (void)line_order;
@@ -237,8 +242,9 @@ bool read_exr(const std::vector<unsigned char>& d, std::vector<float>& rgb, int&
         err = "EXR: compression method " + std::to_string(compression) + " (RLE / PIZ / PXR24 / B44 / DWA) is not decoded by this host (convert the map to .pfm, .png or .tga)";
         return false;
     }
-    w = dw[2] - dw[0] + 1; h = dw[3] - dw[1] + 1;
-    if (w <= 0 || h <= 0 || chans.empty()) { err = "EXR: bad data window or no channels"; return false; }
+    const long long w64 = (long long)dw[2] - (long long)dw[0] + 1, h64 = (long long)dw[3] - (long long)dw[1] + 1;
+    if (w64 <= 0 || h64 <= 0 || w64 > 65536 || h64 > 65536 || w64 * h64 > (1ll << 28) || chans.empty()) { err = "EXR: bad data window (or larger than 2^28 pixels) or no channels"; return false; }
+    w = (int)w64; h = (int)h64;
     int ci[3] = {-1, -1, -1};
     size_t row_bytes = 0;
     std::vector<size_t> chan_off(chans.size());
@@ -251,15 +257,16 @@ bool read_exr(const std::vector<unsigned char>& d, std::vector<float>& rgb, int&
     if (ci[0] < 0 || ci[1] < 0 || ci[2] < 0) { err = "EXR: the file has no R, G, B channels"; return false; }
     const int lines_per_block = compression == 3 ? 16 : 1;
     const size_t n_blocks = ((size_t)h + lines_per_block - 1) / lines_per_block;
-    if (pos + 8 * n_blocks > d.size()) { err = "EXR: truncated offset table"; return false; }
+    if (n_blocks > (d.size() - pos) / 8) { err = "EXR: truncated offset table"; return false; }
     rgb.assign(3 * (size_t)w * h, 0.0f);
     std::vector<unsigned char> raw, tmp;
     for (size_t b = 0; b < n_blocks; b++) {
         const uint64_t off = u64(pos + 8 * b);
-        if (off + 8 > d.size()) { err = "EXR: bad block offset"; return false; }
-        const int y0 = (int)u32((size_t)off) - dw[1];
+        if (d.size() < 8 || off > d.size() - 8) { err = "EXR: bad block offset"; return false; }   // `off` comes from the file: no arithmetic on it before this test
+        const long long y0l = (long long)(int)u32((size_t)off) - (long long)dw[1];
         const uint32_t sz = u32((size_t)off + 4);
-        if (off + 8 + sz > d.size() || y0 < 0 || y0 >= h) { err = "EXR: bad scanline block"; return false; }
+        if (sz > d.size() - 8 - (size_t)off || y0l < 0 || y0l >= h) { err = "EXR: bad scanline block"; return false; }
+        const int y0 = (int)y0l;
         const int nl = std::min(lines_per_block, h - y0);
         const size_t want = row_bytes * (size_t)nl;
         const unsigned char* src = &d[(size_t)off + 8];
@@ -292,7 +299,7 @@ bool read_exr(const std::vector<unsigned char>& d, std::vector<float>& rgb, int&
 
 }  // namespace
 
-bool read_image(const std::string& path, std::vector<float>& rgb, int& w, int& h, std::string& err) {
+static bool read_image_unchecked(const std::string& path, std::vector<float>& rgb, int& w, int& h, std::string& err) {
     const std::string ext = lower_ext(path);
     if (ext.empty()) { err = "Can't determine file type from suffix of filename " + path + "."; return false; }
     if (ext == ".jpg" || ext == ".jpeg" || ext == ".bmp" || ext == ".gif" || ext == ".tif" || ext == ".tiff" || ext == ".hdr") {
@@ -307,6 +314,22 @@ bool read_image(const std::string& path, std::vector<float>& rgb, int& w, int& h
     if (ext == ".exr") return read_exr(d, rgb, w, h, err);
     err = "image format '" + ext + "' is not decoded by this host (convert the map to .pfm, .png or .tga)";
     return false;
+}
+
+// A file the decoders cannot hold in memory is a file that "cannot be read": the caller warns and goes on as the reference does (imagemap.rs / infinite.rs),
+// it does not die in an allocation
+bool read_image(const std::string& path, std::vector<float>& rgb, int& w, int& h, std::string& err) {
+    try {
+        return read_image_unchecked(path, rgb, w, h, err);
+    } catch (const std::bad_alloc&) {
+        err = "image " + path + ": not enough memory to decode";
+        rgb.clear(); w = h = 0;
+        return false;
+    } catch (const std::length_error&) {
+        err = "image " + path + ": implausible size";
+        rgb.clear(); w = h = 0;
+        return false;
+    }
 }
 
 // ---- write_image (core/src/image_io.rs:225-237) ------------------------------------------------------------------------------------------

@@ -144,6 +144,7 @@ class Binding:
             "set_traversal_counting": (C.c_int, [vp, C.c_int]),
             "get_traversal_counts": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
             "accel_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+            "build_accel_device": (C.c_int, [vp, C.c_int, C.c_int]),
             "scene_create_multi": (vp, [ip, C.c_int]),
             "scene_devices": (C.c_int, [vp, ip, C.c_int]),
             "selftest_rccl_gather": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_uint64)]),
@@ -484,6 +485,10 @@ class Scene:
         m32 = np.ascontiguousarray(m32, dtype=np.uint32); vdc = np.ascontiguousarray(vdc, dtype=np.uint64); vdci = np.ascontiguousarray(vdc_inv, dtype=np.uint64)
         assert len(vdc) == len(vdci)
         self._chk(self.b.fn("set_sobol_tables")(self.h, _ptr(m32, C.c_uint32), len(m32), _ptr(vdc, C.c_uint64), _ptr(vdci, C.c_uint64), len(vdc)))
+
+    def build_accel_device(self, split_method=1, max_prims_in_node=4):
+        """The HLBVH tree (split_method 1) constructed on the GPU: same tree as build_accel(1, ..)."""
+        self._chk(self.b.fn("build_accel_device")(self.h, split_method, max_prims_in_node))
 
     def build_accel(self, split_method=0, max_prims_in_node=4):
         self._chk(self.b.fn("build_accel")(self.h, split_method, max_prims_in_node))

@@ -49,6 +49,14 @@ if tk:
     entry["traversal"] = {"kernels": tk, "dispatches": sum(out_json[k]["dispatches"] for k in tk),
                           "FETCH_SIZE_KB": sum(out_json[k]["FETCH_SIZE_KB"] for k in tk), "WRITE_SIZE_KB": sum(out_json[k]["WRITE_SIZE_KB"] for k in tk),
                           "TCC_HIT": sum(out_json[k]["TCC_HIT"] or 0 for k in tk), "TCC_MISS": sum(out_json[k]["TCC_MISS"] or 0 for k in tk)}
+    # what the SIMDs were doing in those launches (same passes): the numbers behind "issue bound, not memory bound"
+    sq = {n: sum(agg[k].get(n, 0.0) for k in agg if "traverse_kernel" in k) for n in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVES",
+                                                                                    "SQ_INSTS_VALU", "SQ_INSTS_SALU", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCC_READ_REQ_sum")}
+    if sq["SQ_WAVE_CYCLES"]:
+        entry["traversal"]["sq"] = {"valu_lane_utilisation": round(sq["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"]), 4) if sq["SQ_ACTIVE_INST_VALU"] else None,
+                                    "valu_active_of_wave_cycles": round(sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], 4), "wait_any_of_wave_cycles": round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 4),
+                                    "wait_inst_of_wave_cycles": round(sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"], 4), "valu_insts": sq["SQ_INSTS_VALU"], "salu_insts": sq["SQ_INSTS_SALU"],
+                                    "mean_l2_read_latency_cycles": round(sq["TCP_TCC_READ_REQ_LATENCY_sum"] / sq["TCP_TCC_READ_REQ_sum"], 1) if sq["TCP_TCC_READ_REQ_sum"] else None}
 # the workload the passes ran: every pass is one `bench.py --steps 1 --warmup 0` run whose JSON line was kept next to the counters
 for f in sorted(glob.glob(os.path.join(out, "pass*.json"))):
     try:

@@ -1,0 +1,75 @@
+"""-m gpu: the HLBVH built on the device (csrc/bvh_device.hip) against the host builder and the oracle: hlbvh.rs + morton.rs restated a third time, as kernels.
+Same leaves in the same depth-first order, same leaf ends, the same set of child boxes, the same root bound — so hits cannot depend on where the tree was built."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pbrt_hip
+import scenes
+from oracle_binding import OracleScene
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(lib, which, P, idx, n_tris, max_prims):
+    order = np.zeros(n_tris, np.uint32); last = np.zeros(n_tris, np.uint32)
+    nodes = np.zeros((max(n_tris - 1, 1), 16), np.uint32); info = np.zeros(5, np.uint64); rb = np.zeros(6, np.float32)
+    if which == "host":
+        lib.pbrt_hip_host_build_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = lib.pbrt_hip_host_build_bvh(P.ctypes.data, idx.ctypes.data, n_tris, 1, max_prims, 4, order.ctypes.data, last.ctypes.data, nodes.ctypes.data, info.ctypes.data, rb.ctypes.data)
+    else:
+        lib.pbrt_hip_device_build_bvh.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = lib.pbrt_hip_device_build_bvh(0, P.ctypes.data, idx.ctypes.data, n_tris, 1, max_prims, order.ctypes.data, last.ctypes.data, nodes.ctypes.data, info.ctypes.data, rb.ctypes.data, None)
+    assert rc == 0, rc
+    f = nodes.view(np.float32)
+    n_int = int(info[0])
+    boxes = {(f[k, c], f[k, c + 2], f[k, c + 4], f[k, c + 1], f[k, c + 3], f[k, c + 5]) for k in range(n_int) for c in (0, 6)}
+    ends = np.flatnonzero(last); starts = np.concatenate([[0], ends[:-1] + 1]) if len(ends) else np.zeros(0, int)
+    leaves = [tuple(order[a:b + 1]) for a, b in zip(starts, ends)]
+    return dict(order=order, last=last, info=info[:3].copy(), rb=rb, boxes=boxes, leaves=leaves, nodes=nodes[:n_int].copy())
+
+
+@pytest.mark.parametrize("n_tris,seed,max_prims", [(1, 1, 4), (2, 1, 4), (3, 5, 4), (17, 2, 4), (300, 8, 2), (5000, 3, 4), (5000, 4, 1), (20000, 6, 8), (300000, 7, 4)])
+def test_device_hlbvh_equals_host_and_oracle(host, product, n_tris, seed, max_prims):
+    P, idx = host.gen_random_tris(n_tris, seed)
+    h = _build(product.lib, "host", P, idx, n_tris, max_prims)
+    d = _build(product.lib, "device", P, idx, n_tris, max_prims)
+    assert np.array_equal(d["order"], h["order"]), "primitive order differs"
+    assert np.array_equal(d["last"], h["last"]), "leaf ends differ"
+    assert np.array_equal(d["info"], h["info"])          # interior nodes, leaves, largest leaf
+    assert np.array_equal(d["rb"], h["rb"])
+    assert d["boxes"] == h["boxes"]
+    if n_tris <= 20000:
+        orc = OracleScene()
+        m = orc.add_material_matte(); orc.add_mesh(P, idx, m); orc.build_accel(1, max_prims)
+        onodes = orc.bvh_nodes()
+        oprims = np.zeros(n_tris, np.uint32); orc.b.lib.oracle_bvh_ordered_prims(orc.h, oprims.ctypes.data)
+        ol = onodes[onodes["n_primitives"] > 0]
+        assert d["leaves"] == [tuple(oprims[l["offset"]:l["offset"] + l["n_primitives"]]) for l in ol]
+        if len(onodes) > 1:
+            assert d["boxes"] == {tuple(n["pmin"]) + tuple(n["pmax"]) for n in onodes[1:]}
+
+
+def test_scene_built_on_the_device_traces_like_the_host_built_one(host):
+    P, idx = host.gen_random_tris(30000, 12)
+    rays = np.concatenate([scenes.random_rays(80000, 4), scenes.axis_rays()])
+
+    def scene(device_build):
+        s = pbrt_hip.Scene()
+        s.add_mesh(P, idx, s.add_material_matte())
+        (s.build_accel_device if device_build else s.build_accel)(1, 4)
+        return s
+    a, b = scene(False), scene(True)
+    ha, hb = a.intersect_batch(rays), b.intersect_batch(rays)
+    assert scenes.hits_equal(hb, ha).all()
+    assert np.array_equal(a.occluded_batch(rays), b.occluded_batch(rays))
+    assert np.array_equal(a.world_bound(), b.world_bound())
+    assert a.accel_stats()["interior_nodes"] == b.accel_stats()["interior_nodes"] and a.accel_stats()["leaves"] == b.accel_stats()["leaves"]
+    orc = OracleScene(); orc.add_mesh(P, idx, orc.add_material_matte()); orc.build_accel(1, 4)
+    want, _ = orc.intersect_batch_stats(rays)
+    assert scenes.hits_equal(hb, want).all()
+    with pytest.raises(pbrt_hip.PbrtHipError) as e:
+        b.build_accel_device(0, 4)          # SAH stays a host build
+    assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
+    a.close(); b.close(); orc.close()

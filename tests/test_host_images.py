@@ -110,3 +110,44 @@ def test_image_writers_round_trip(tmp_path):
     assert np.array_equal(tga, png.astype(np.float32) / np.float32(255.0))
     bad = subprocess.run([ds.RENDER_BIN, "--convert-image", str(tmp_path / "src.pfm"), str(tmp_path / "o.jpg")], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "not supported" in bad.stderr
+
+
+def test_corrupt_and_truncated_files_fail_cleanly(tmp_path):
+    """A malformed texture must end in the decoder's error message (the front end then warns, or fails the load) — never in a crash or an out-of-bounds
+    read: every cursor of the decoders is bounded by the file, sizes taken from the file are capped."""
+    import struct
+    img = np.random.default_rng(9).uniform(0, 1, (9, 7, 3)).astype(np.float32)
+    imf.write_exr(str(tmp_path / "ok.exr"), img)
+    good = (tmp_path / "ok.exr").read_bytes()
+    cases = {}
+    for cut in (9, 20, 60, len(good) // 2, len(good) - 5):                      # truncated at the header, the channel list, the offset table, the pixel data
+        cases[f"cut{cut}.exr"] = good[:cut]
+    huge = bytearray(good)
+    k = good.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    huge[k:k + 16] = struct.pack("<4i", 0, 0, 2 ** 31 - 2, 2 ** 31 - 2)         # a 2^31-wide window: the size products must not wrap
+    cases["huge.exr"] = bytes(huge)
+    neg = bytearray(good); neg[k:k + 16] = struct.pack("<4i", 5, 5, -2 ** 31, -2 ** 31); cases["neg.exr"] = bytes(neg)
+    chan = bytearray(good)
+    c = good.index(b"channels\0chlist\0") + len(b"channels\0chlist\0")
+    chan[c:c + 4] = struct.pack("<I", 3)                                          # a channel list that ends inside a channel name
+    cases["chan.exr"] = bytes(chan)
+    # the first scanline block's offset points past the end of the file (a uint64 from the file: `off + 8` must not wrap)
+    hdr_end = good.index(b"\0", good.rindex(b"lineOrder")) if b"lineOrder" in good else None
+    badoff = bytearray(good)
+    # the offset table follows the header's terminating zero byte: find it as the position of the first table entry that points at a plausible block
+    for p in range(8, len(good) - 8):
+        off = struct.unpack_from("<Q", good, p)[0]
+        if p + 8 * 9 <= off < len(good) and struct.unpack_from("<i", good, off)[0] == 0:   # block of scanline y = 0
+            badoff[p:p + 8] = struct.pack("<Q", 2 ** 64 - 4); break
+    cases["badoff.exr"] = bytes(badoff)
+    imf.write_png(str(tmp_path / "ok.png"), (img * 255).astype(np.uint8), color_type=2)
+    png = (tmp_path / "ok.png").read_bytes()
+    big = bytearray(png); big[16:24] = struct.pack(">II", 2 ** 31 - 1, 2 ** 31 - 1); cases["big.png"] = bytes(big)   # IHDR says 2^31 x 2^31
+    cases["cut.png"] = png[:len(png) // 2]
+    cases["big.pfm"] = b"PF\n2000000 2000000\n-1.0\n" + b"\0" * 64
+    cases["cut.pfm"] = b"PF\n4 4\n-1.0\n" + b"\0" * 20
+    for name, data in cases.items():
+        (tmp_path / name).write_bytes(data)
+        r, _ = _convert(tmp_path, name)
+        assert r.returncode == 1, (name, r.returncode, r.stderr[-300:])          # the decoder's own error exit, not a signal
+        assert any(t in r.stderr for t in ("EXR:", "PNG:", "PFM:")), (name, r.stderr[-300:])
