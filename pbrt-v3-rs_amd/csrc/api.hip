@@ -184,6 +184,7 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
     X(12, 20, 12, 10, 3, 8, false) X(13, 24, 12, 12, 4, 6, false) X(14, 20, 12, 12, 5, 0, false) X(15, 24, 12, 11, 5, 7, false) \
     X(16, 24, 12, 11, 4, 7, true) X(17, 24, 12, 12, 4, 6, true) X(18, 20, 12, 12, 3, 0, true) X(19, 24, 12, 12, 5, 6, false)
 #define PH_N_VARIANTS 20
+#define PH_DEFAULT_INST_VARIANT 1   // 1 000 instances x 10 k triangles: 95.0 ms of traversal per frame against 102.9 (variant 0), 101.7 (2), 109.0 (3) (gpurun r02n)
 #define PH_DEFAULT_VARIANT 19   // measured on configs[2] / configs[1] with binned queues: 742.6 / 31.3 ms of traversal per frame against 760.2 / 31.7 for variant 0 (gpurun r02h)
 static int trav_variant() {
     static int v = -1;
@@ -249,7 +250,15 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
     }
     if (!s->inst_recs.empty()) {  // scenes with object instances: the TransformedPrimitive-aware kernels
         if (s->count_traversal) PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 0, false);
-        else PH_LAUNCH3(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true, 0, false);
+        else {
+            static const int iv = []() { const char* e = std::getenv("PBRT_HIP_INST_VARIANT"); const int v = e ? std::atoi(e) : PH_DEFAULT_INST_VARIANT; return (v < 0 || v > 3) ? PH_DEFAULT_INST_VARIANT : v; }();
+            switch (iv) {   // the instancing kernel carries 111 VGPRs (4 waves per SIMD) when left to the compiler
+                case 1: PH_LAUNCH3(false, 24, 12, PH_LDS_DEPTH, 5, true, 0, false); break;
+                case 2: PH_LAUNCH3(false, 24, 12, PH_LDS_DEPTH, 5, true, 5, false); break;   // 96 VGPRs, 9 spilled
+                case 3: PH_LAUNCH3(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true, 5, false); break;
+                default: PH_LAUNCH3(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true, 0, false); break;
+            }
+        }
         return;
     }
     if (s->count_traversal) { PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false, 0, false); return; }
