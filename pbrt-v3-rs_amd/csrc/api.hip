@@ -80,6 +80,23 @@ int upload_scene(PbrtHipScene* s) {
     if ((rc = upload_vec(s, s->tri_mesh, &d.tri_mesh))) return rc;
     if ((rc = upload_vec(s, s->tri_flags, &d.tri_flags))) return rc;
     if ((rc = upload_vec(s, s->meshes, &d.meshes))) return rc;
+    {   // per material: what the texture pass has to hand to the shade pass (texture.h: eval_lobe_colours / build_hit_lobes use the same slot rules)
+        for (MaterialRec& m : s->materials) {
+            uint32_t cols = m.amount_tex1 ? 1u : 0u; bool hdr = m.bump_tex1 != 0u || m.sigma_tex1 != 0u;
+            for (uint32_t k = 0; k < m.n_lobes; k++) {
+                const LobeRec& l = s->lobes[m.lobe_base + k];
+                cols += (l.r_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T) ? 1u : 0u) + (l.t_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH ? 1u : 0u) +
+                        (l.eta_tex1 ? 1u : 0u) + (l.k_tex1 ? 1u : 0u);
+                if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1 || l.alt || l.has_pre == PH_PRE_RAW_TEST) hdr = true;
+            }
+            if (m.sigma_tex1 || hdr) cols = std::max(cols, 2u);   // the per-hit scalars travel in the fourth component of the first two colour slots
+            m.tex_cols = std::min<uint32_t>(cols, PH_HIT_COLS); m.tex_hdr = hdr ? 1u : 0u;
+        }
+        s->simple_textures = true;
+        for (const PbrtHipScene::TextureHost& t : s->textures)
+            for (const TexOp& op : t.prog)
+                if (!(op.op == PH_TOP_CONST || op.op == PH_TOP_MUL || op.op == PH_TOP_MIX || (op.op == PH_TOP_IMAGE && op.mapping == 0u))) s->simple_textures = false;
+    }
     if ((rc = upload_vec(s, s->materials, &d.materials))) return rc;
     if ((rc = upload_vec(s, s->lobes, &d.lobes))) return rc;
     if (!s->textures.empty() || !s->mipmaps.empty()) {   // MIPMaps also belong to lights (radiance map, projection image, goniometric diagram)

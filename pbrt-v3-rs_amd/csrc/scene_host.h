@@ -39,6 +39,7 @@ struct SceneHostState {
     bool textured_materials = false;  // some material evaluates a texture per hit
     bool has_none_material = false;  // some material is "none": paths may need more wavefront iterations than max_depth + 1
     bool general_materials = false;  // some material is not matte: the renderer uses the general BSDF kernel
+    bool simple_textures = false;    // every texture program is made of constants, image maps (uv mapping), scale and mix: the texture pass runs its lean instantiation (set at upload)
     std::vector<LightRec> lights;
     std::vector<uint32_t> infinite_lights;
     std::vector<float> light_dist;   // Distribution2D tables of infinite lights with a radiance map

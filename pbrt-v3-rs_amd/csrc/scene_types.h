@@ -102,6 +102,8 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     uint32_t amount_tex1;  // MixMaterial: 0, or 1 + the `amount` texture (takes the FIRST colour slot of the texture pass)
     float bsdf_eta_alt;    // UberMaterial with an opacity texture: BSDF::eta of the hits that do not get the pass-through lobe (uber.rs:128-137)
     uint32_t uber_eta;     // 1: this material IS that uber (a mix holding one keeps eta 1)
+    uint32_t tex_cols;     // colour slots of TexOut the texture pass fills for this material (set at upload)
+    uint32_t tex_hdr;      // the shade pass reads TexOut's header (bumped frame, per-hit scalars, lambert / glass / raw-black bits) for this material; else only the colours are written
 };
 // What the texture pass hands the shade pass for one path vertex (wavefront.hip: texture_kernel): the bumped shading frame and the evaluated,
 // clamped (and pre-multiplied) colours of the material's textured lobe colours, in template-lobe order (r before t).

@@ -196,7 +196,10 @@ PH_DEV void map_2d(const TexOp& op, const TexCtx& c, f2& st, f2& dstdx, f2& dstd
 
 // Runs texture `id`'s postfix program.  Kept out of line: the shade kernels call it only for materials that carry a texture.
 // `dsc` = DeviceScene::self (the by-value kernel argument must not have its address taken: it would be copied to scratch).
-static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id, TexCtx c) {
+// SIMPLE = the scene's texture programs consist of constants, image maps, scale and mix only (what most scene files use): the procedural classes and their Perlin noise are
+// compiled out, the caller's register budget shrinks with them (an out-of-line callee's registers count towards its kernel's)
+template <bool SIMPLE>
+static __device__ __forceinline__ spec tex_eval_body(const DeviceScene* dsc, uint32_t id, const TexCtx& c) {
     const DeviceScene& sc = *dsc;
     const TexRec tr = sc.textures[id];
     spec st[PH_TEX_STACK];
@@ -211,7 +214,7 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
             break;
         }
         case PH_TOP_MUL: { sp--; st[sp - 1] = st[sp - 1] * st[sp]; break; }                          // scale.rs:33
-        case PH_TOP_CHECKER: {  // checkerboard_2d.rs:60-104; stack = tex1, tex2 (both are evaluated: they have no side effects)
+        case PH_TOP_CHECKER: if (!SIMPLE) {  // checkerboard_2d.rs:60-104; stack = tex1, tex2 (both are evaluated: they have no side effects)
             sp--;
             const spec a = st[sp - 1], b = st[sp];
             f2 p, dstdx, dstdy; map_2d(op, c, p, dstdx, dstdy);
@@ -227,21 +230,18 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
                 }
             }
             st[sp - 1] = r;
-            break;
-        }
-        case PH_TOP_UV: {  // uv.rs:33-38
+            } break;
+        case PH_TOP_UV: if (!SIMPLE) {  // uv.rs:33-38
             f2 p, dx_, dy_; map_2d(op, c, p, dx_, dy_);
             st[sp++] = mks(p.x - floorf(p.x), p.y - floorf(p.y), 0.0f);
-            break;
-        }
-        case PH_TOP_BILERP: {  // bilerp.rs:58-71; stack = v00, v01, v10, v11
+            } break;
+        case PH_TOP_BILERP: if (!SIMPLE) {  // bilerp.rs:58-71; stack = v00, v01, v10, v11
             sp -= 3;
             f2 p, dx_, dy_; map_2d(op, c, p, dx_, dy_);
             const float s00 = (1.0f - p.x) * (1.0f - p.y), s01 = (1.0f - p.x) * p.y, s10 = p.x * (1.0f - p.y), s11 = p.x * p.y;
             st[sp - 1] = (st[sp - 1] * s00) + (st[sp] * s01) + (st[sp + 1] * s10) + (st[sp + 2] * s11);
-            break;
-        }
-        case PH_TOP_FBM: case PH_TOP_WRINKLED: case PH_TOP_WINDY: case PH_TOP_MARBLE: case PH_TOP_CHECKER3D: {  // IdentityMapping3D::map (identity_3d.rs)
+            } break;
+        case PH_TOP_FBM: case PH_TOP_WRINKLED: case PH_TOP_WINDY: case PH_TOP_MARBLE: case PH_TOP_CHECKER3D: if (!SIMPLE) {  // IdentityMapping3D::map (identity_3d.rs)
             const f3 dpdx = xf_vec(op.m, c.dpdx), dpdy = xf_vec(op.m, c.dpdy);
             f3 p = xf_point16(op.m, c.p);
             if (op.op == PH_TOP_FBM) st[sp++] = mks1(tex_fbm(p, dpdx, dpdy, op.omega, op.octaves, false));            // fbm.rs:45-50
@@ -267,9 +267,8 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
                 s0 = (1.0f - tt) * s0 + tt * s1; s1 = (1.0f - tt) * s1 + tt * s2;
                 st[sp++] = 1.5f * ((1.0f - tt) * s0 + tt * s1);
             }
-            break;
-        }
-        case PH_TOP_DOTS: {  // dots.rs:48-69; stack = inside, outside
+            } break;
+        case PH_TOP_DOTS: if (!SIMPLE) {  // dots.rs:48-69; stack = inside, outside
             sp--;
             f2 p, dx_, dy_; map_2d(op, c, p, dx_, dy_);
             const float s_cell = floorf(p.x + 0.5f), t_cell = floorf(p.y + 0.5f);
@@ -282,8 +281,7 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
                 inside = ddx * ddx + ddy * ddy < radius * radius;
             }
             st[sp - 1] = inside ? st[sp - 1] : st[sp];
-            break;
-        }
+            } break;
         default: {  // PH_TOP_MIX: (1 - amt) * t1 + amt * t2 (mix.rs:36-41); stack = t1, t2, amount
             sp -= 2;
             const float amt = st[sp + 1].r;
@@ -294,6 +292,17 @@ static __device__ __noinline__ spec tex_eval(const DeviceScene* dsc, uint32_t id
     }
     return st[0];
 }
+template <bool SIMPLE = false> struct TexEval;
+template <> struct TexEval<false> { static __device__ __noinline__ spec run(const DeviceScene* dsc, uint32_t id, TexCtx c) { return tex_eval_body<false>(dsc, id, c); } };
+#ifndef PH_TEX_SIMPLE_INLINE
+#define PH_TEX_SIMPLE_INLINE 0
+#endif
+#if PH_TEX_SIMPLE_INLINE
+template <> struct TexEval<true> { static __device__ __forceinline__ spec run(const DeviceScene* dsc, uint32_t id, const TexCtx& c) { return tex_eval_body<true>(dsc, id, c); } };
+#else
+template <> struct TexEval<true> { static __device__ __noinline__ spec run(const DeviceScene* dsc, uint32_t id, TexCtx c) { return tex_eval_body<true>(dsc, id, c); } };
+#endif
+template <bool SIMPLE = false> PH_DEV spec tex_eval(const DeviceScene* dsc, uint32_t id, const TexCtx& c) { return TexEval<SIMPLE>::run(dsc, id, c); }
 
 // ---- ray differentials of a camera ray, in world space, scaled as render_tile does (sampler_integrator.rs:358) --------------
 struct RayDiff { f3 rx_o, ry_o, rx_d, ry_d; };
@@ -465,8 +474,9 @@ PH_DEV TexCtx hit_tex_ctx(const DeviceScene* dsc, const CameraRec* cam, uint32_t
     return ctx;
 }
 // `tex.evaluate(..).clamp_default()` (matte.rs:63, plastic.rs:62-70, mirror.rs:53, substrate.rs:60-61)
+template <bool SIMPLE = false>
 PH_DEV spec tex_eval_clamped(const DeviceScene* dsc, uint32_t tex, const TexCtx& ctx) {
-    const spec v = tex_eval(dsc, tex, ctx);
+    const spec v = tex_eval<SIMPLE>(dsc, tex, ctx);
     return mks(pclampf(v.r, 0.0f, kInf), pclampf(v.g, 0.0f, kInf), pclampf(v.b, 0.0f, kInf));
 }
 // The hit's own lobe list of a textured material: the template lobes with their textured colours filled in, a lobe dropped where the reference
@@ -482,9 +492,10 @@ PH_DEV bool lobe_keep(const LobeRec& l) {
 PH_DEV float d_log(float x) { return (float)log((double)x); }
 // the lobe's scalar parameters when they are textures: MatteMaterial's sigma -> Oren-Nayar A, B (matte.rs:64-70, oren_nayar.rs:28-39); roughness -> Trowbridge-Reitz alpha,
 // remapped per hit (trowbridge_reitz.rs:21-40).  One parametrised lobe per material: the values travel in out.col[0][3], out.col[1][3]
+template <bool SIMPLE = false>
 PH_DEV void eval_lobe_scalars(const DeviceScene* dsc, const LobeRec& l, const TexCtx& ctx, TexOut& out) {
     if (l.sigma_tex1) {
-        const float sig = pclampf(tex_eval(dsc, l.sigma_tex1 - 1u, ctx).r, 0.0f, 90.0f);
+        const float sig = pclampf(tex_eval<SIMPLE>(dsc, l.sigma_tex1 - 1u, ctx).r, 0.0f, 90.0f);
         if (sig == 0.0f) { out.lambert |= 1u; out.col[0][3] = 0.0f; out.col[1][3] = 0.0f; }
         else { const float sg = sig * (kPi / 180.0f), s2 = sg * sg; out.col[0][3] = 1.0f - ph_div(s2, 2.0f * (s2 + 0.33f)); out.col[1][3] = ph_div(0.45f * s2, s2 + 0.09f); }
     }
@@ -493,7 +504,7 @@ PH_DEV void eval_lobe_scalars(const DeviceScene* dsc, const LobeRec& l, const Te
         float raw[2] = {l.ur_raw, l.vr_raw};   // GlassMaterial: `is_specular = urough == 0 && vrough == 0` on the values as the textures give them (glass.rs:111)
         const uint32_t tx[2] = {l.ax_tex1, l.ay_tex1};
         for (int k = 0; k < 2; k++) if (tx[k]) {
-            float r = tex_eval(dsc, tx[k] - 1u, ctx).r;
+            float r = tex_eval<SIMPLE>(dsc, tx[k] - 1u, ctx).r;
             raw[k] = r;
             if (l.remap) { r = pmaxf(r, 1e-3f); const float x = d_log(r); r = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x; }
             a[k] = pmaxf(0.001f, r);
@@ -505,32 +516,33 @@ PH_DEV void eval_lobe_scalars(const DeviceScene* dsc, const LobeRec& l, const Te
 // does this colour of the lobe come from the texture pass?  (r before t; PH_PRE_OPACITY / PH_PRE_PASSTHROUGH lobes always: their colour depends on the hit's opacity)
 PH_DEV bool lobe_slot_r(const LobeRec& l) { return l.r_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T); }
 PH_DEV bool lobe_slot_t(const LobeRec& l) { return l.t_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH; }
+template <bool SIMPLE = false>
 PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const MaterialRec& mr, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, TexOut& out) {
     uint32_t k = 0;
     auto put = [&](spec c) { if (k < PH_HIT_COLS) { out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++; } };
-    if (mr.amount_tex1) put(tex_eval_clamped(dsc, mr.amount_tex1 - 1u, ctx));                           // mix.rs:59: s1 (s2 is made from it in the shade pass)
+    if (mr.amount_tex1) put(tex_eval_clamped<SIMPLE>(dsc, mr.amount_tex1 - 1u, ctx));                           // mix.rs:59: s1 (s2 is made from it in the shade pass)
     spec op = mks1(1.0f);
-    if (mr.opacity_tex1) op = tex_eval_clamped(dsc, mr.opacity_tex1 - 1u, ctx);                          // uber.rs:126
+    if (mr.opacity_tex1) op = tex_eval_clamped<SIMPLE>(dsc, mr.opacity_tex1 - 1u, ctx);                          // uber.rs:126
     for (uint32_t i = 0; i < n; i++) {
         const LobeRec& l = tmpl[i];
-        if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1) eval_lobe_scalars(dsc, l, ctx, out);
+        if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1) eval_lobe_scalars<SIMPLE>(dsc, l, ctx, out);
         if (l.has_pre == PH_PRE_PASSTHROUGH) { const spec t = op * -1.0f + mks1(1.0f); put(mks(pclampf(t.r, 0.0f, kInf), pclampf(t.g, 0.0f, kInf), pclampf(t.b, 0.0f, kInf))); continue; }   // (-op + ONE).clamp_default() (uber.rs:127)
         if (l.has_pre == PH_PRE_OPACITY) {   // op * k.evaluate(..).clamp_default() (uber.rs:141, :147, :169, :175)
             const uint32_t tex = l.kind == PH_LK_SPEC_T ? l.t_tex1 : l.r_tex1;
-            const spec base = tex ? tex_eval_clamped(dsc, tex - 1u, ctx) : mks(l.pre[0], l.pre[1], l.pre[2]);
+            const spec base = tex ? tex_eval_clamped<SIMPLE>(dsc, tex - 1u, ctx) : mks(l.pre[0], l.pre[1], l.pre[2]);
             put(op * base);
         } else {
             const spec pre = l.has_pre ? mks(l.pre[0], l.pre[1], l.pre[2]) : mks1(1.0f);
             const uint32_t texs[2] = {l.r_tex1, l.t_tex1};
             for (int f = 0; f < 2; f++) if (texs[f] && k < PH_HIT_COLS) {
-                spec c = tex_eval_clamped(dsc, texs[f] - 1u, ctx);
+                spec c = tex_eval_clamped<SIMPLE>(dsc, texs[f] - 1u, ctx);
                 if (l.has_pre == PH_PRE_RAW_TEST && c.r == 0.0f && c.g == 0.0f && c.b == 0.0f) out.bumped |= 1u << (8u + k);
                 if (l.has_pre) c = pre * c;
                 put(c);
             }
         }
-        if (l.eta_tex1) put(tex_eval(dsc, l.eta_tex1 - 1u, ctx));   // metal.rs:121-125: as the textures give them, no clamp
-        if (l.k_tex1) put(tex_eval(dsc, l.k_tex1 - 1u, ctx));
+        if (l.eta_tex1) put(tex_eval<SIMPLE>(dsc, l.eta_tex1 - 1u, ctx));   // metal.rs:121-125: as the textures give them, no clamp
+        if (l.k_tex1) put(tex_eval<SIMPLE>(dsc, l.k_tex1 - 1u, ctx));
     }
 }
 // shade pass: the hit's own lobe list = template lobes with the texture pass's colours filled in, a lobe dropped where the reference would not add it.
@@ -539,15 +551,17 @@ PH_DEV uint32_t build_hit_lobes(const MaterialRec& mr, const LobeRec* tmpl, uint
     uint32_t k = 0, ci = 0;
     float s1[3] = {1.0f, 1.0f, 1.0f}, s2[3] = {0.0f, 0.0f, 0.0f};
     if (mr.amount_tex1) { for (int c = 0; c < 3; c++) { s1[c] = in->col[0][c]; s2[c] = pclampf(1.0f - s1[c], 0.0f, kInf); } ci = 1; }   // mix.rs:59-60
-    const bool is_specular = (in->lambert & 2u) != 0u;
+    // materials whose lobes need neither per-hit scalars nor the raw-black bits leave the record's header unwritten (texture_kernel): do not read it
+    const uint32_t hdr_lambert = mr.tex_hdr ? in->lambert : 0u, hdr_bumped = mr.tex_hdr ? in->bumped : 0u;
+    const bool is_specular = (hdr_lambert & 2u) != 0u;
     bool passthrough = false;
     for (uint32_t i = 0; i < n && k < PH_HIT_LOBES; i++) {
         LobeRec l = tmpl[i];
-        if (l.sigma_tex1) { l.kind = (in->lambert & 1u) ? PH_LK_LAMBERT : PH_LK_OREN; l.a = in->col[0][3]; l.b = in->col[1][3]; }
+        if (l.sigma_tex1) { l.kind = (hdr_lambert & 1u) ? PH_LK_LAMBERT : PH_LK_OREN; l.a = in->col[0][3]; l.b = in->col[1][3]; }
         if (l.ax_tex1 || l.ay_tex1) { l.ax = in->col[0][3]; l.ay = in->col[1][3]; }
         bool raw_black = false;
-        if (lobe_slot_r(l) && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; raw_black = raw_black || ((in->bumped >> (8u + ci)) & 1u); ci++; }
-        if (lobe_slot_t(l) && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; raw_black = raw_black || ((in->bumped >> (8u + ci)) & 1u); ci++; }
+        if (lobe_slot_r(l) && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; raw_black = raw_black || ((hdr_bumped >> (8u + ci)) & 1u); ci++; }
+        if (lobe_slot_t(l) && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; raw_black = raw_black || ((hdr_bumped >> (8u + ci)) & 1u); ci++; }
         if (l.eta_tex1 && ci < PH_HIT_COLS) { l.c_eta_t[0] = in->col[ci][0]; l.c_eta_t[1] = in->col[ci][1]; l.c_eta_t[2] = in->col[ci][2]; ci++; }
         if (l.k_tex1 && ci < PH_HIT_COLS) { l.c_k[0] = in->col[ci][0]; l.c_k[1] = in->col[ci][1]; l.c_k[2] = in->col[ci][2]; ci++; }
         if (l.amt & 3u) {
@@ -569,6 +583,7 @@ struct BumpOut { f3 ns, dpdu_s; };
 struct BumpIn { uint32_t tex, tri_index, inst; f3 bary, p, n, ns, dpdu_s; TexCtx c; };
 // arguments travel through one private struct: with ~40 scalar arguments (most of them on the stack) this function, out of line, corrupted values of OTHER
 // lanes of the wave in the one-lobe kernel on gfx950
+template <bool SIMPLE = false>
 PH_DEV void hit_bump(const DeviceScene* dsc, const BumpIn* in, BumpOut* out) {
     const DeviceScene& sc = *dsc;
     const uint32_t tex = in->tex, tri_index = in->tri_index, inst = in->inst;
@@ -631,12 +646,12 @@ PH_DEV void hit_bump(const DeviceScene* dsc, const BumpIn* in, BumpOut* out) {
     float du = 0.5f * (pabs(c.dudx) + pabs(c.dudy));
     if (du == 0.0f) du = 0.0005f;
     TexCtx cu = c; cu.p = p + du * dpdu_s; cu.uv = mk2(c.uv.x + du, c.uv.y + 0.0f);
-    const float u_displace = tex_eval(dsc, tex, cu).r;
+    const float u_displace = tex_eval<SIMPLE>(dsc, tex, cu).r;
     float dv = 0.5f * (pabs(c.dvdx) + pabs(c.dvdy));
     if (dv == 0.0f) dv = 0.0005f;
     TexCtx cv = c; cv.p = p + dv * dpdv_s; cv.uv = mk2(c.uv.x + 0.0f, c.uv.y + dv);
-    const float v_displace = tex_eval(dsc, tex, cv).r;
-    const float displace = tex_eval(dsc, tex, c).r;
+    const float v_displace = tex_eval<SIMPLE>(dsc, tex, cv).r;
+    const float displace = tex_eval<SIMPLE>(dsc, tex, c).r;
     const f3 ndpdu = dpdu_s + ph_div(u_displace - displace, du) * ns + displace * dndu;
     const f3 ndpdv = dpdv_s + ph_div(v_displace - displace, dv) * ns + displace * dndv;
     out->ns = face_forward(normalize(cross(ndpdu, ndpdv)), n);

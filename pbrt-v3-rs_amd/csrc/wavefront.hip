@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfPar
 // Texture pass: one thread per live path whose new vertex lies on a material with per-hit textures or a bump map.  It rebuilds the surface
 // interaction, the texture context (uv, dp/du, dp/dv, camera-ray differentials), runs Material::bump and evaluates the textured lobe colours,
 // and leaves the results in tex_out[pid] for the shade pass.  A pass of its own so that the evaluator's registers and calls stay out of the shade kernel.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void texture_kernel(DeviceScene sc, WfParams w, int it) {
+// SIMPLE: the scene's textures are constants, image maps, scale and mix only: the evaluator is compiled without the procedural classes and fits more waves
+template <bool SIMPLE, int WAVES = 3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void texture_kernel(DeviceScene sc, WfParams w, int it) {
     const uint32_t n_live = w.ctr[it].n_live;
     const uint32_t* live_in = w.live[it & 1];
     const RayIn* rays_in = w.rays_cl[it & 1];
@@ -211,16 +213,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             BumpIn bi; bi.tex = mr.bump_tex1 - 1u; bi.tri_index = __float_as_uint(h1.y); bi.inst = __float_as_uint(h1.z); bi.bary = mk3(h0.z, h0.w, h1.x);
             bi.p = si.p; bi.n = si.n; bi.ns = si.ns; bi.dpdu_s = si.dpdu_s; bi.c = ctx;
             BumpOut bo;
-            hit_bump(sc.self, &bi, &bo);
+            hit_bump<SIMPLE>(sc.self, &bi, &bo);
             out.ns[0] = bo.ns.x; out.ns[1] = bo.ns.y; out.ns[2] = bo.ns.z; out.dpdu_s[0] = bo.dpdu_s.x; out.dpdu_s[1] = bo.dpdu_s.y; out.dpdu_s[2] = bo.dpdu_s.z;
             out.bumped = 1u;
         }
         for (int k = 0; k < PH_HIT_COLS; k++) out.col[k][0] = out.col[k][1] = out.col[k][2] = out.col[k][3] = 0.0f;
-        if (mr.textured) eval_lobe_colours(sc.self, mr, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out);
+        if (mr.textured) eval_lobe_colours<SIMPLE>(sc.self, mr, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out);
 
+        // only what the shade pass reads for this material: the two header quads if it needs them, then the colour slots in use (a matte with an image map: 16 of the 128 bytes)
         float4* dst = reinterpret_cast<float4*>(w.tex_out + pid);
         const float4* src = reinterpret_cast<const float4*>(&out);
-        for (int k = 0; k < (int)(sizeof(TexOut) / 16); k++) dst[k] = src[k];
+        if (mr.tex_hdr) { dst[0] = src[0]; dst[1] = src[1]; }
+        for (uint32_t k = 0; k < mr.tex_cols; k++) dst[2 + k] = src[2 + k];
     }
 }
 
@@ -263,6 +267,7 @@ template <> struct BsdfOps<true> {
     }
 };
 
+#define PH_TEX_SIMPLE_WAVES 3   // waves per SIMD the image-map-only texture pass is compiled for: textured configs[1] 54.3 ms per frame at 3, 56.4 at 4 (254 spilled registers), 55.7 at 2 (gpurun r02q)
 #define PH_SHADE_BLOCK 256
 // Waves per SIMD the shade kernels are compiled for.  40 KB of LDS per block allow 4 blocks per CU; the one-lobe kernel fits 128 VGPRs with
 // 51 spilled registers and gains 6 % from the fourth wave, the general-BSDF kernel would spill 181 and loses, so it stays at 3; so do the
@@ -1047,7 +1052,11 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
             }
             if ((rc = timed(2, [&]() {
                     if (s->textured_materials) {
-                        hipLaunchKernelGGL(ph::texture_kernel, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        static const int tex_waves = []() { const char* e = std::getenv("PBRT_HIP_TEX_WAVES"); const int v = e ? std::atoi(e) : PH_TEX_SIMPLE_WAVES; return (v < 2 || v > 4) ? PH_TEX_SIMPLE_WAVES : v; }();
+                        if (!s->simple_textures || tex_waves == 0) hipLaunchKernelGGL((ph::texture_kernel<false, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        else if (tex_waves == 2) hipLaunchKernelGGL((ph::texture_kernel<true, 2>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        else if (tex_waves == 3) hipLaunchKernelGGL((ph::texture_kernel<true, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        else hipLaunchKernelGGL((ph::texture_kernel<true, 4>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         if (s->general_materials) hipLaunchKernelGGL((ph::shade_kernel<true, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         else hipLaunchKernelGGL((ph::shade_kernel<false, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                     } else if (s->general_materials) hipLaunchKernelGGL(ph::shade_kernel<true>, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
