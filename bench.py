@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--max-depth", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--ply", default=None, help="a PLY mesh to render instead of the synthetic triangles (e.g. the Ganesha mesh of configs[2], which is not available offline): "
+                                               "normalised into the synthetic scene's [-1, 1]^3 so that camera and light are unchanged")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (same scene, same resolution); 0 = about 150 M rays' worth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-count", action="store_true")
@@ -129,7 +131,7 @@ def main():
             custom.append(k)
     n_tris, res, spp, max_depth = cfg["n_tris"], cfg["res"], cfg["spp"], cfg["max_depth"]
 
-    import numpy as np  # noqa: F401
+    import numpy as np
     import torch
     import pbrt_hip
 
@@ -152,6 +154,13 @@ def main():
     host = pbrt_hip.Host()
     tile_size = 16
     geometry = None
+    if args.ply:
+        P, idx = pbrt_hip.read_ply(args.ply)
+        lo, hi = P.min(axis=0), P.max(axis=0)
+        P = ((P - (lo + hi) * 0.5) * np.float32(2.0 / float((hi - lo).max()))).astype(np.float32)
+        geometry = (np.ascontiguousarray(P), idx)
+        n_tris = len(idx) // 3
+        custom.append(f"mesh from {os.path.basename(args.ply)}")
 
     def sync():
         torch.cuda.synchronize()

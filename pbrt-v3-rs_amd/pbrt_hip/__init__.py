@@ -708,6 +708,80 @@ class Scene:
         return xyz, wt
 
 
+def read_ply(path):
+    """Vertices and triangles of a PLY file as shapes/src/plymesh.rs:21-249 reads them: `x y z` of element vertex (any other vertex property is skipped here), faces
+    `vertex_indices` / `vertex_index` of 3 or 4 (a quad a b c d -> a b c, d a c); ascii and binary, either endianness.  Returns (P float32 (n, 3), idx uint32 (3 n_tris,))."""
+    with open(path, "rb") as f:
+        data = f.read()
+    end = data.index(b"end_header") + len(b"end_header")
+    end = data.index(b"\n", end) + 1
+    header = data[:end].decode("ascii", "replace").split("\n")
+    fmt = None; elements = []
+    for line in header:
+        t = line.split()
+        if not t: continue
+        if t[0] == "format": fmt = t[1]
+        elif t[0] == "element": elements.append({"name": t[1], "n": int(t[2]), "props": []})
+        elif t[0] == "property" and elements:
+            if t[1] == "list": elements[-1]["props"].append(("list", t[2], t[3], t[4]))
+            else: elements[-1]["props"].append(("scalar", t[1], t[2]))
+    types = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4",
+             "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+    P = None; tris = []
+    if fmt == "ascii":
+        tok = data[end:].split(); pos = 0
+        for e in elements:
+            if e["name"] == "vertex":
+                names = [p[2] for p in e["props"]]; w = len(names)
+                a = np.array(tok[pos:pos + w * e["n"]], dtype=np.float64).reshape(e["n"], w); pos += w * e["n"]
+                P = np.stack([a[:, names.index(c)] for c in "xyz"], axis=1).astype(np.float32)
+            else:
+                for _ in range(e["n"]):
+                    for pr in e["props"]:
+                        if pr[0] == "list":
+                            k = int(tok[pos]); v = [int(x) for x in tok[pos + 1:pos + 1 + k]]; pos += 1 + k
+                            if e["name"] == "face" and pr[3] in ("vertex_indices", "vertex_index"): tris.append(v)
+                        else: pos += 1
+    else:
+        bo = "<" if fmt == "binary_little_endian" else ">"
+        off = end
+        for e in elements:
+            if all(p[0] == "scalar" for p in e["props"]):
+                dt = np.dtype([(p[2], bo + types[p[1]]) for p in e["props"]])
+                a = np.frombuffer(data, dt, e["n"], off); off += dt.itemsize * e["n"]
+                if e["name"] == "vertex": P = np.stack([a[c] for c in "xyz"], axis=1).astype(np.float32)
+            else:
+                if e["name"] == "face" and len(e["props"]) == 1:   # the common case: one list per face; try the fixed-size fast paths first
+                    _, ct, it, nm = e["props"][0]; cdt = np.dtype(bo + types[ct]); idt = np.dtype(bo + types[it])
+                    done = False
+                    for k in (3, 4):
+                        rec = np.dtype([("n", cdt), ("v", idt, (k,))])
+                        if off + rec.itemsize * e["n"] <= len(data):
+                            a = np.frombuffer(data, rec, e["n"], off)
+                            if (a["n"] == k).all():
+                                if nm in ("vertex_indices", "vertex_index"): tris = a["v"].astype(np.int64)
+                                off += rec.itemsize * e["n"]; done = True; break
+                    if done: continue
+                for _ in range(e["n"]):
+                    for pr in e["props"]:
+                        if pr[0] == "list":
+                            cdt = np.dtype(bo + types[pr[1]]); idt = np.dtype(bo + types[pr[2]])
+                            k = int(np.frombuffer(data, cdt, 1, off)[0]); off += cdt.itemsize
+                            v = np.frombuffer(data, idt, k, off).astype(np.int64).tolist(); off += idt.itemsize * k
+                            if e["name"] == "face" and pr[3] in ("vertex_indices", "vertex_index"): tris.append(v)
+                        else: off += np.dtype(types[pr[1]]).itemsize
+    if P is None: raise ValueError(f"{path}: no vertex element")
+    if isinstance(tris, np.ndarray):
+        idx = tris.reshape(-1, 3) if tris.shape[1] == 3 else np.concatenate([tris[:, [0, 1, 2]], tris[:, [3, 0, 2]]], axis=1).reshape(-1, 3)
+    else:
+        out = []
+        for v in tris:
+            if len(v) == 3: out.append(v)
+            elif len(v) == 4: out.append([v[0], v[1], v[2]]); out.append([v[3], v[0], v[2]])   # plymesh.rs:228-236
+        idx = np.array(out, np.int64).reshape(-1, 3)
+    return np.ascontiguousarray(P), np.ascontiguousarray(idx.reshape(-1), dtype=np.uint32)
+
+
 @dataclass
 class SceneSpec:
     """The synthetic measurement scene of BASELINE.md §3 / SURVEY §8d, as plain data, so that the same description can

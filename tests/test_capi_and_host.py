@@ -179,3 +179,34 @@ def test_error_codes_and_state_machine_on_oracle_binding(host):
         s.add_mesh(np.zeros((3, 3), np.float32), [0, 1, 2], m + 5)       # unknown material
     with pytest.raises(pbrt_hip.PbrtHipError):
         s.intersect_batch(np.zeros(1, pbrt_hip.RAY_DTYPE))               # before build_accel
+
+
+def test_python_ply_reader_reads_what_the_front_end_reads(tmp_path):
+    """pbrt_hip.read_ply (bench.py --ply) against shapes/src/plymesh.rs's rules: x y z, triangle and quad faces (a b c d -> a b c, d a c), ascii and both binary byte orders."""
+    import struct
+    import pbrt_hip
+    P = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 0.5, 1]], np.float32)
+    N = np.array([[0, 0, 1]] * 5, np.float32)
+    faces = [[0, 1, 2, 3], [2, 3, 4], [0, 1, 4]]
+    want = np.array([0, 1, 2, 3, 0, 2, 2, 3, 4, 0, 1, 4], np.uint32)
+    hdr = "ply\nformat {} 1.0\ncomment t\nelement vertex 5\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\nelement face 3\nproperty list uchar int vertex_indices\nend_header\n"
+    for fmt, bo in (("binary_little_endian", "<"), ("binary_big_endian", ">")):
+        with open(tmp_path / (fmt + ".ply"), "wb") as fh:
+            fh.write(hdr.format(fmt).encode())
+            for p, n in zip(P, N): fh.write(struct.pack(bo + "6f", *p, *n))
+            for f in faces: fh.write(struct.pack(bo + "B%di" % len(f), len(f), *f))
+        gp, gi = pbrt_hip.read_ply(str(tmp_path / (fmt + ".ply")))
+        assert np.array_equal(gp, P) and np.array_equal(gi, want)
+    with open(tmp_path / "a.ply", "w") as fh:
+        fh.write(hdr.format("ascii"))
+        for p, n in zip(P, N): fh.write(" ".join(repr(float(v)) for v in list(p) + list(n)) + "\n")
+        for f in faces: fh.write(" ".join(str(v) for v in [len(f)] + f) + "\n")
+    gp, gi = pbrt_hip.read_ply(str(tmp_path / "a.ply"))
+    assert np.array_equal(gp, P) and np.array_equal(gi, want)
+    # all-triangle binary files take the vectorised path
+    with open(tmp_path / "t.ply", "wb") as fh:
+        fh.write(hdr.format("binary_little_endian").replace("element face 3", "element face 2").encode())
+        for p, n in zip(P, N): fh.write(struct.pack("<6f", *p, *n))
+        for f in ([2, 3, 4], [0, 1, 4]): fh.write(struct.pack("<B3i", 3, *f))
+    gp, gi = pbrt_hip.read_ply(str(tmp_path / "t.ply"))
+    assert np.array_equal(gi, np.array([2, 3, 4, 0, 1, 4], np.uint32))

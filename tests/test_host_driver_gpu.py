@@ -38,6 +38,21 @@ def test_pbrt_file_renders_the_oracle_image(tmp_path, host, filt, strategy):
     assert f"{st.regular_rays} regular + {st.shadow_rays} shadow rays" in r.stdout
 
 
+def test_hlbvh_scene_file_is_built_on_the_device_and_renders_the_same_image(tmp_path, host):
+    """Accelerator "bvh" "string splitmethod" "hlbvh": the front end has the tree made by the device builder (csrc/bvh_device.hip).  Closest hits do not depend on the
+    tree (no exact-t ties in this scene), so the image equals the oracle's, which traces its SAH tree."""
+    path = ds.write_files(str(tmp_path), filter_line=ds.FILTERS["box"][0], strategy="uniform")
+    text = open(path).read().replace('Accelerator "bvh" "integer maxnodeprims" 2', 'Accelerator "bvh" "string splitmethod" "hlbvh" "integer maxnodeprims" 2')
+    assert "hlbvh" in text
+    open(path, "w").write(text)
+    r = subprocess.run([ds.RENDER_BIN, path], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    img = ds.read_pfm(str(tmp_path / "scene.pfm"))
+    ref, st = oracle_image(host, "box", 0)
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), f"{(img != ref).sum()} differing values"
+    assert f"{st.regular_rays} regular + {st.shadow_rays} shadow rays" in r.stdout
+
+
 def test_crop_window_and_outfile(tmp_path, host):
     crop = (0.25, 0.75, 0.5, 1.0)
     path = ds.write_files(str(tmp_path), crop=crop)
