@@ -184,6 +184,11 @@ def main():
         floats = max(scene.tile_buffer_floats(tile_size, p, world) for p in range(world))
         tile_buf = torch.zeros(floats, dtype=torch.float32, device=dev)
         gather_list = [torch.zeros(floats, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+        # the film comes back into page-locked host arrays allocated once (67 MB at 2048 x 2048: a DMA transfer instead of a staged copy into freshly faulted pages every frame)
+        film_out = None
+        if rank == 0:
+            fh, fw = scene.film_shape
+            film_out = (torch.empty((fh, fw, 3), dtype=torch.float32, pin_memory=True).numpy(), torch.empty((fh, fw), dtype=torch.float32, pin_memory=True).numpy())
         torch.cuda.synchronize()  # the library writes tile_buf on its own stream: torch's fill kernels must have finished
 
         def step():
@@ -200,9 +205,9 @@ def main():
                             g.copy_(h)
                 torch.cuda.synchronize()  # the collective runs on torch's stream: finish it before the library reads (rank 0) or rewrites (all) the buffers
                 if rank == 0:
-                    film = scene.merge_tiles_device([t.data_ptr() for t in gather_list], tile_size)
+                    film = scene.merge_tiles_device([t.data_ptr() for t in gather_list], tile_size, out=film_out)
             else:
-                film = scene.merge_tiles_device([tile_buf.data_ptr()], tile_size)
+                film = scene.merge_tiles_device([tile_buf.data_ptr()], tile_size, out=film_out)
             return st, film
 
         for _ in range(warmup):

@@ -700,9 +700,15 @@ class Scene:
                                                         d_tile_buffer_ptr, C.byref(st)))
         return st
 
-    def merge_tiles_device(self, d_ptrs, tile_size=16):
+    def merge_tiles_device(self, d_ptrs, tile_size=16, out=None):
+        """out = (xyz (h, w, 3) float32, weight (h, w) float32) to fill instead of fresh arrays — page-locked ones (e.g. torch.empty(.., pin_memory=True).numpy())
+        make the read-back of a large film a DMA transfer instead of a staged copy into freshly faulted pages."""
         h, w = self._film_hw()
-        xyz = np.zeros((h, w, 3), np.float32); wt = np.zeros((h, w), np.float32)
+        if out is not None:
+            xyz, wt = out
+            assert xyz.shape == (h, w, 3) and wt.shape == (h, w) and xyz.dtype == np.float32 and wt.dtype == np.float32 and xyz.flags.c_contiguous and wt.flags.c_contiguous
+        else:
+            xyz = np.zeros((h, w, 3), np.float32); wt = np.zeros((h, w), np.float32)
         arr = (C.c_void_p * len(d_ptrs))(*d_ptrs)
         self._chk(self.b.fn("merge_tiles_device")(self.h, tile_size, len(d_ptrs), arr, _ptr(xyz, C.c_float), _ptr(wt, C.c_float)))
         return xyz, wt
