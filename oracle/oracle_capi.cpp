@@ -893,7 +893,97 @@ void oracle_geom_op(int op, const float* a, float* out) {
         V3 inv(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z); int neg[3] = {inv.x < 0, inv.y < 0, inv.z < 0};
         out[0] = Scene::box_hit(b, r, inv, neg) ? 1.0f : 0.0f; break;
     }
+    // the rest of the Vector3 / Point3 / Normal3 proptests (one POD for the three types): a[6] = scalar
+    case 14: { V3 c = u + v; out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 15: { V3 c = u - v; out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 16: { V3 c = u * a[6], d = a[6] * u; out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = d.x; out[4] = d.y; out[5] = d.z; break; }
+    case 17: { V3 c = u / a[6]; out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 18: { V3 c = -u; out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 19: { V3 c = vmin(u, v); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 20: { V3 c = vmax(u, v); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 21: out[0] = min_component(u); break;
+    case 22: { V3 c = vfloor(u); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 23: { V3 c = vceil(u); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 24: { V3 c = lerp(a[6], u, v); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+    case 25: out[0] = distance(u, v); break;
+    case 26: out[0] = abs_dot(u, v); break;
+    case 27: out[0] = has_nans(u) ? 1.0f : 0.0f; break;
+    case 28: {  // Ray::scale_differentials (ray.rs:90-99): a = o, d, s, rx_origin, ry_origin, rx_direction, ry_direction -> the four scaled
+        Ray r(u, v, INF, 0.0f); r.has_diff = true;
+        r.rx_o = V3(a[7], a[8], a[9]); r.ry_o = V3(a[10], a[11], a[12]); r.rx_d = V3(a[13], a[14], a[15]); r.ry_d = V3(a[16], a[17], a[18]);
+        Renderer::scale_differentials(r, a[6]);
+        const V3 q[4] = {r.rx_o, r.ry_o, r.rx_d, r.ry_d};
+        for (int k = 0; k < 4; k++) { out[3 * k] = q[k].x; out[3 * k + 1] = q[k].y; out[3 * k + 2] = q[k].z; }
+        break;
     }
+    }
+}
+// Vector2 / Point2 probes: u = a[0..1], v = a[2..3], scalar a[4], permutation a[5..6]
+void oracle_geom2_op(int op, const float* a, float* out) {
+    V2 u(a[0], a[1]), v(a[2], a[3]);
+    auto put = [&](V2 c) { out[0] = c.x; out[1] = c.y; };
+    switch (op) {
+    case 0: out[0] = dot(u, v); out[1] = abs_dot(u, v); break;
+    case 2: put(normalize(u)); break;
+    case 3: out[0] = length(u); out[1] = length_squared(u); break;
+    case 4: put(vabs(u)); break;
+    case 5: out[0] = max_component(u); out[1] = min_component(u); break;
+    case 6: out[0] = (float)max_dimension(u); break;
+    case 7: put(permute(u, (int)a[5], (int)a[6])); break;
+    case 12: out[0] = distance_squared(u, v); out[1] = distance(u, v); break;
+    case 14: put(u + v); break;
+    case 15: put(u - v); break;
+    case 16: { V2 c = u * a[4], d = a[4] * u; out[0] = c.x; out[1] = c.y; out[2] = d.x; out[3] = d.y; break; }
+    case 17: put(u / a[4]); break;
+    case 18: put(-u); break;
+    case 19: put(vmin(u, v)); break;
+    case 20: put(vmax(u, v)); break;
+    case 22: put(vfloor(u)); break;
+    case 23: put(vceil(u)); break;
+    case 24: put(lerp(a[4], u, v)); break;
+    case 27: out[0] = has_nans(u) ? 1.0f : 0.0f; break;
+    }
+}
+// Bounds2 probes (bounds2.rs).  b1 = a[0..3] and b2 = a[4..7] are taken as given (x0, y0, x1, y1; no sorting), p = a[8..9], scalar a[10].
+// op: 0 new(a[0..1], a[2..3]) 1 empty 2 from(p) 3 is_empty 4 diagonal 5 area 6 maximum_extent 7 overlaps 8 offset 9 contains 10 contains_exclusive
+//     11 bounding_circle 12 lerp(t = p) 13 expand 14 corner(k = a[10]) 15 union(p) 16 union(b2) 17 intersect(b2) 18 iterate (Bounds2i: out = n, then the points)
+}  // extern "C"
+template <class T> static void bounds2_op(int op, const T* a, T* out) {
+    typedef B2<T> B;
+    const B b1 = B::raw(a[0], a[1], a[2], a[3]), b2 = B::raw(a[4], a[5], a[6], a[7]);
+    auto put = [&](const B& b) { out[0] = b.x0; out[1] = b.y0; out[2] = b.x1; out[3] = b.y1; };
+    switch (op) {
+    case 0: put(B::make(a[0], a[1], a[2], a[3])); break;
+    case 1: put(B::empty()); break;
+    case 2: put(B::from_point(a[8], a[9])); break;
+    case 3: out[0] = b1.is_empty() ? 1 : 0; break;
+    case 4: b1.diagonal(out[0], out[1]); break;
+    case 5: out[0] = b1.area(); break;
+    case 6: out[0] = (T)b1.maximum_extent(); break;
+    case 7: out[0] = b1.overlaps(b2) ? 1 : 0; break;
+    case 9: out[0] = b1.contains(a[8], a[9]) ? 1 : 0; break;
+    case 10: out[0] = b1.contains_exclusive(a[8], a[9]) ? 1 : 0; break;
+    case 13: put(b1.expand(a[10])); break;
+    case 14: b1.corner((int)a[10], out[0], out[1]); break;
+    case 15: put(b1.union_p(a[8], a[9])); break;
+    case 16: put(b1.union_b(b2)); break;
+    case 17: put(b1.intersect(b2)); break;
+    }
+}
+extern "C" {
+void oracle_bounds2f_op(int op, const float* a, float* out) {
+    const Bounds2f b1 = Bounds2f::raw(a[0], a[1], a[2], a[3]);
+    if (op == 8) b1.offset(a[8], a[9], out[0], out[1]);
+    else if (op == 11) { V2 c; Float r; b2_bounding_circle(b1, c, r); out[0] = c.x; out[1] = c.y; out[2] = r; }
+    else if (op == 12) { V2 c = b2_lerp(b1, V2(a[8], a[9])); out[0] = c.x; out[1] = c.y; }
+    else bounds2_op<float>(op, a, out);
+}
+void oracle_bounds2i_op(int op, const int* a, int* out, int out_cap) {
+    if (op == 18) {
+        int n = 0;
+        Bounds2i::raw(a[0], a[1], a[2], a[3]).for_each([&](int x, int y) { if (2 * n + 2 < out_cap) { out[1 + 2 * n] = x; out[2 + 2 * n] = y; } n++; });
+        out[0] = n;
+    } else bounds2_op<int>(op, a, out);
 }
 // scene-construction helpers restating the reference's Transform factories (transform.rs) for host-side tests
 void oracle_look_at(const float pos[3], const float look[3], const float up[3], float out_m[16], float out_minv[16]) {

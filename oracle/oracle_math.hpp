@@ -2,8 +2,8 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, link or call this code.
 // The product (pbrt-v3-rs_amd/) never includes or links anything under oracle/.
 //
-// Parity pin status: the reference's own tests cover only core/src/geometry; those expression-order
-// pins are replayed in tests/test_oracle_geometry.py.  BVH/Triangle/sampler/path/film have NO reference tests or
+// Parity pin status: the reference's own tests cover only core/src/geometry (277 #[test]s); every one of them is
+// replayed or accounted for in tests/test_reference_proptests.py (+ tests/test_oracle_geometry.py).  BVH/Triangle/sampler/path/film have NO reference tests or
 // golden vectors and the reference (Rust) cannot be built here, so for those parts parity is "unpinned" except
 // for the PCG32 / Halton-permutation KATs of SURVEY Appendix C (tests/golden/).
 //
@@ -149,7 +149,93 @@ inline void coordinate_system(V3 v1, V3& v2, V3& v3) {
 inline Float spherical_theta(V3 v) { return o_acos(pclamp(v.z, -1.0f, 1.0f)); }
 inline Float spherical_phi(V3 v) { Float p = o_atan2(v.y, v.x); return p < 0.0f ? p + TWO_PI : p; }
 
-struct V2 { Float x, y; V2() : x(0), y(0) {} V2(Float a, Float b) : x(a), y(b) {} };
+// the rest of the Vector3 / Point3 / Normal3 surface the reference's own proptests exercise (vector3.rs:77-91, 125-149; point3.rs:86-150)
+inline Float min_component(V3 a) {                                                            // vector3.rs:77-91
+    if (a.x < a.y) return a.x < a.z ? a.x : a.z;
+    return a.y < a.z ? a.y : a.z;
+}
+inline V3 vmin(V3 a, V3 b) { return V3(pmin(a.x, b.x), pmin(a.y, b.y), pmin(a.z, b.z)); }    // component-wise pbrt::min (common.rs:83-92)
+inline V3 vmax(V3 a, V3 b) { return V3(pmax(a.x, b.x), pmax(a.y, b.y), pmax(a.z, b.z)); }
+inline V3 vfloor(V3 a) { return V3(std::floor(a.x), std::floor(a.y), std::floor(a.z)); }
+inline V3 vceil(V3 a) { return V3(std::ceil(a.x), std::ceil(a.y), std::ceil(a.z)); }
+inline bool has_nans(V3 a) { return a.x != a.x || a.y != a.y || a.z != a.z; }
+
+// Vector2f / Point2f (core/src/geometry/{vector2,point2}.rs): same arithmetic as the 3-D types, one POD here
+struct V2 {
+    Float x, y;
+    V2() : x(0), y(0) {}
+    V2(Float a, Float b) : x(a), y(b) {}
+    Float operator[](int i) const { return i == 0 ? x : y; }
+};
+inline V2 operator+(V2 a, V2 b) { return V2(a.x + b.x, a.y + b.y); }
+inline V2 operator-(V2 a, V2 b) { return V2(a.x - b.x, a.y - b.y); }
+inline V2 operator-(V2 a) { return V2(-a.x, -a.y); }
+inline V2 operator*(V2 a, Float f) { return V2(a.x * f, a.y * f); }
+inline V2 operator*(Float f, V2 a) { return V2(a.x * f, a.y * f); }
+inline V2 operator/(V2 a, Float f) { Float inv = 1.0f / f; return V2(inv * a.x, inv * a.y); }   // vector2.rs:304-309, point2.rs:390-395
+inline Float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+inline Float abs_dot(V2 a, V2 b) { return pabs(dot(a, b)); }
+inline Float length_squared(V2 a) { return a.x * a.x + a.y * a.y; }
+inline Float length(V2 a) { return std::sqrt(length_squared(a)); }
+inline V2 normalize(V2 a) { return a / length(a); }
+inline V2 vabs(V2 a) { return V2(pabs(a.x), pabs(a.y)); }
+inline Float min_component(V2 a) { return a.x < a.y ? a.x : a.y; }
+inline Float max_component(V2 a) { return a.x > a.y ? a.x : a.y; }
+inline int max_dimension(V2 a) { return a.x > a.y ? 0 : 1; }
+inline V2 vmin(V2 a, V2 b) { return V2(pmin(a.x, b.x), pmin(a.y, b.y)); }
+inline V2 vmax(V2 a, V2 b) { return V2(pmax(a.x, b.x), pmax(a.y, b.y)); }
+inline V2 permute(V2 a, int x, int y) { return V2(a[x], a[y]); }
+inline V2 vfloor(V2 a) { return V2(std::floor(a.x), std::floor(a.y)); }
+inline V2 vceil(V2 a) { return V2(std::ceil(a.x), std::ceil(a.y)); }
+inline Float distance_squared(V2 a, V2 b) { return length_squared(a - b); }
+inline Float distance(V2 a, V2 b) { return length(a - b); }
+inline V2 lerp(Float t, V2 a, V2 b) { return (1.0f - t) * a + t * b; }
+inline bool has_nans(V2 a) { return a.x != a.x || a.y != a.y; }
+
+// Bounds2<T> (core/src/geometry/bounds2.rs:57-359), T = Float (Bounds2f) or int (Bounds2i): the film's crop window, sample bounds, tile bounds and
+// FilmTile pixel bounds are these (film/mod.rs:150-198, sampler_integrator.rs:254-336).  Corners are kept as given: only make() sorts them.
+template <class T> struct B2 {
+    T x0, y0, x1, y1;  // p_min, p_max
+    static T hi() { return std::numeric_limits<T>::max(); }
+    static T lo() { return std::numeric_limits<T>::lowest(); }
+    static B2 raw(T a, T b, T c, T d) { B2 r; r.x0 = a; r.y0 = b; r.x1 = c; r.y1 = d; return r; }
+    static B2 make(T ax, T ay, T bx, T by) { return raw(pmin(ax, bx), pmin(ay, by), pmax(ax, bx), pmax(ay, by)); }   // Bounds2::new (:62-71)
+    static B2 empty() { return raw(hi(), hi(), lo(), lo()); }                                                       // :74-84 (not through new(): it would flip the corners)
+    static B2 from_point(T x, T y) { return raw(x, y, x, y); }                                                      // :24-31
+    bool is_empty() const { return x1 < x0 || y1 < y0; }                                                            // :87-92
+    void diagonal(T& dx, T& dy) const { dx = x1 - x0; dy = y1 - y0; }                                               // :95-97
+    T area() const { if (is_empty()) return (T)0; T dx, dy; diagonal(dx, dy); return dx * dy; }                     // :100-111
+    int maximum_extent() const { T dx, dy; diagonal(dx, dy); return dx > dy ? 0 : 1; }                              // :114-126
+    bool overlaps(const B2& o) const {                                                                              // :129-136
+        const bool x = (x1 >= o.x0) && (x0 <= o.x1), y = (y1 >= o.y0) && (y0 <= o.y1);
+        return x && y;
+    }
+    void offset(T px, T py, T& ox, T& oy) const {                                                                   // :142-156 (Float only)
+        ox = px - x0; oy = py - y0;
+        if (x1 > x0) ox /= x1 - x0;
+        if (y1 > y0) oy /= y1 - y0;
+    }
+    bool contains(T px, T py) const { return px >= x0 && px <= x1 && py >= y0 && py <= y1; }                        // :159-164
+    bool contains_exclusive(T px, T py) const { return px >= x0 && px < x1 && py >= y0 && py < y1; }                // :170-175
+    B2 expand(T d) const { return raw(x0 - d, y0 - d, x1 + d, y1 + d); }                                            // :208-219 (no sorting)
+    void corner(int k, T& cx, T& cy) const { cx = (k & 1) ? x1 : x0; cy = (k & 2) ? y1 : y0; }                      // :222-230
+    B2 union_p(T px, T py) const { return raw(pmin(x0, px), pmin(y0, py), pmax(x1, px), pmax(y1, py)); }            // :248-257
+    B2 union_b(const B2& o) const { return raw(pmin(x0, o.x0), pmin(y0, o.y0), pmax(x1, o.x1), pmax(y1, o.y1)); }   // :260-269
+    B2 intersect(const B2& o) const { return raw(pmax(x0, o.x0), pmax(y0, o.y0), pmin(x1, o.x1), pmin(y1, o.y1)); } // :272-281
+    // Bounds2i iteration (:312-359): y outer, x inner, p_max excluded — except that an axis with p_min == p_max is walked as ONE row / column
+    template <class F> void for_each(F f) const {
+        const T mx = (x0 == x1) ? x1 + 1 : x1, my = (y0 == y1) ? y1 + 1 : y1;
+        for (T y = y0; y < my; y++)
+            for (T x = x0; x < mx; x++) f(x, y);
+    }
+};
+typedef B2<Float> Bounds2f;
+typedef B2<int> Bounds2i;
+inline V2 b2_lerp(const Bounds2f& b, V2 t) { return V2(lerp(t.x, b.x0, b.x1), lerp(t.y, b.y0, b.y1)); }            // :195-203
+inline void b2_bounding_circle(const Bounds2f& b, V2& center, Float& radius) {                                      // :178-190
+    center = lerp(0.5f, V2(b.x0, b.y0), V2(b.x1, b.y1));
+    radius = b.contains(center.x, center.y) ? distance(center, V2(b.x1, b.y1)) : 0.0f;
+}
 
 // RGBSpectrum (core/src/spectrum/rgb_spectrum.rs)
 struct Spec {

@@ -1406,8 +1406,8 @@ struct Renderer {
         FilmTile t;
         int p0x = f2i32(std::ceil((Float)sb[0] - 0.5f - film.radius[0])), p0y = f2i32(std::ceil((Float)sb[1] - 0.5f - film.radius[1]));
         int p1x = f2i32(std::floor((Float)sb[2] - 0.5f + film.radius[0])) + 1, p1y = f2i32(std::floor((Float)sb[3] - 0.5f + film.radius[1])) + 1;
-        t.b[0] = pmax(p0x, film.crop[0]); t.b[1] = pmax(p0y, film.crop[1]);
-        t.b[2] = pmin(p1x, film.crop[2]); t.b[3] = pmin(p1y, film.crop[3]);
+        const Bounds2i tp = Bounds2i::raw(p0x, p0y, p1x, p1y).intersect(Bounds2i::raw(film.crop[0], film.crop[1], film.crop[2], film.crop[3]));  // Bounds2i { p0, p1 }.intersect(&cropped_pixel_bounds)
+        t.b[0] = tp.x0; t.b[1] = tp.y0; t.b[2] = tp.x1; t.b[3] = tp.y1;
         int w = t.b[2] - t.b[0], hgt = t.b[3] - t.b[1];
         size_t n = (w > 0 && hgt > 0) ? (size_t)w * hgt : 0;
         t.contrib.assign(3 * n, 0.0f); t.wsum.assign(n, 0.0f);
@@ -1439,10 +1439,10 @@ struct Renderer {
 
     // ---- render_tile (sampler_integrator.rs:312-415) -----------------------------------------------------------------
     template <class S> void render_tile_with(S& sampler, const int tb[4], FilmTile& ft) {
-        for (int y = tb[1]; y < tb[3]; y++)
-            for (int x = tb[0]; x < tb[2]; x++) {  // Bounds2i iteration: row-major (bounds2.rs:347-359)
+        const Bounds2i pxb = Bounds2i::raw(pixel_bounds[0], pixel_bounds[1], pixel_bounds[2], pixel_bounds[3]);
+        Bounds2i::raw(tb[0], tb[1], tb[2], tb[3]).for_each([&](int x, int y) {  // `for pixel in tile_bounds`: row-major (bounds2.rs:312-359)
                 sampler.start_pixel(x, y);
-                if (!(x >= pixel_bounds[0] && x < pixel_bounds[2] && y >= pixel_bounds[1] && y < pixel_bounds[3])) continue;
+                if (!pxb.contains_exclusive(x, y)) return;  // sampler_integrator.rs:348-350
                 for (;;) {
                     V2 fs = sampler.get_2d();
                     V2 p_film((Float)x + fs.x, (Float)y + fs.y);
@@ -1458,13 +1458,15 @@ struct Renderer {
                     add_sample(ft, p_film, L, 1.0f);
                     if (!sampler.start_next_sample()) break;
                 }
-            }
+            });
     }
 
     void tile_bounds(int tile_idx, int ntx, const int sb[4], int tile_size, int tb[4]) const {
         int tx = tile_idx % ntx, ty = tile_idx / ntx;
-        tb[0] = sb[0] + tx * tile_size; tb[2] = pmin(tb[0] + tile_size, sb[2]);
-        tb[1] = sb[1] + ty * tile_size; tb[3] = pmin(tb[1] + tile_size, sb[3]);
+        const int x0 = sb[0] + tx * tile_size, x1 = pmin(x0 + tile_size, sb[2]);
+        const int y0 = sb[1] + ty * tile_size, y1 = pmin(y0 + tile_size, sb[3]);
+        const Bounds2i b = Bounds2i::make(x0, y0, x1, y1);  // Bounds2i::new(Point2i::new(x0, y0), Point2i::new(x1, y1)) (sampler_integrator.rs:331-336)
+        tb[0] = b.x0; tb[1] = b.y0; tb[2] = b.x1; tb[3] = b.y1;
     }
 
     // SamplerIntegrator::render (sampler_integrator.rs:243-304).  Tiles are merged in increasing tile index
