@@ -196,6 +196,51 @@ int oracle_add_mesh(OracleScene* s, const float* P, uint32_t n_verts, const uint
     return 0;
 }
 
+// Shape "sphere" (shapes/src/sphere.rs:494-520 reads radius / zmin / zmax / phimax) — ORACLE ONLY, for BASELINE.json's configs[0].  object_to_world is handed over
+// as the reference's Transform holds it: the matrix AND the inverse the CTM accumulated (transform.rs:644-656 multiplies the inverses, it never inverts a product).
+// The sphere takes one slot of the scene's primitive list, in directive order with the meshes.
+int oracle_add_sphere(OracleScene* s, const float o2w_m[16], const float o2w_minv[16], float radius, float z_min, float z_max, float phi_max, uint32_t material_id, uint32_t flags) {
+    if (!s || !o2w_m || !o2w_minv) return -1;
+    Scene& sc = s->sc;
+    if (material_id >= sc.materials.size()) { s->err = "bad material id"; return -1; }
+    if (sc.open_object >= 0) { s->err = "spheres inside object instances are not restated"; return -5; }
+    const Transform o2w(m4_from(o2w_m), m4_from(o2w_minv));
+    Mesh m;
+    m.vert_base = (uint32_t)sc.P.size(); m.tri_base = (uint32_t)sc.n_tris(); m.n_verts = 1; m.n_tris = 1;
+    m.has_n = m.has_s = m.has_uv = false;
+    m.material = material_id; m.first_light = -1;
+    m.reverse_orientation = flags & 1; m.swaps_handedness = o2w.swaps_handedness();
+    m.alpha = 1.0f; m.shadow_alpha = 1.0f;
+    m.sphere = (int)sc.spheres.size();
+    sc.spheres.push_back(Sphere(o2w, (flags & 1) != 0, radius, z_min, z_max, phi_max));
+    sc.P.push_back(o2w.point(V3(0, 0, 0))); sc.N.push_back(V3()); sc.S.push_back(V3()); sc.UV.push_back(V2());  // one vertex so that the slot's index triple is valid; never read
+    const uint32_t mesh_id = (uint32_t)sc.meshes.size();
+    for (int k = 0; k < 3; k++) sc.idx.push_back(m.vert_base);
+    sc.tri_mesh.push_back(mesh_id);
+    sc.meshes.push_back(m);
+    sc.top_items.push_back(m.tri_base);
+    s->built = false;
+    return 0;
+}
+// one ray against one sphere, outside any scene: out = {hit, t, p.xyz (world), n.xyz (world), u, v}
+int oracle_sphere_probe(const float o2w_m[16], const float o2w_minv[16], float radius, float z_min, float z_max, float phi_max, uint32_t flags,
+                        const float o[3], const float d[3], float t_max, float* out) {
+    Scene sc; Renderer rr; rr.sc = &sc;
+    const Transform o2w(m4_from(o2w_m), m4_from(o2w_minv));
+    sc.spheres.push_back(Sphere(o2w, (flags & 1) != 0, radius, z_min, z_max, phi_max));
+    Mesh m{}; m.sphere = 0; m.n_tris = 1; m.n_verts = 1; m.first_light = -1; m.alpha = m.shadow_alpha = 1.0f; m.alpha_tex = m.shadow_alpha_tex = -1;
+    sc.meshes.push_back(m); sc.tri_mesh.push_back(0); sc.P.push_back(V3()); for (int k = 0; k < 3; k++) sc.idx.push_back(0);
+    const Ray r(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), t_max, 0.0f);
+    TriHit h;
+    const bool hit = sc.sphere_intersect(r, sc.spheres[0], h);
+    out[0] = hit ? 1.0f : 0.0f;
+    if (!hit) return 0;
+    const SurfaceHit si = rr.make_sphere_hit(r, 0, h, sc.spheres[0]);
+    out[1] = h.t; out[2] = si.p.x; out[3] = si.p.y; out[4] = si.p.z; out[5] = si.n.x; out[6] = si.n.y; out[7] = si.n.z; out[8] = si.uv.x; out[9] = si.uv.y;
+    out[10] = si.p_error.x; out[11] = si.p_error.y; out[12] = si.p_error.z;
+    return 0;
+}
+
 // ObjectBegin / ObjectEnd / ObjectInstance (api/src/lib.rs:911-1000)
 int oracle_object_begin(OracleScene* s, uint32_t* out_id) {
     if (!s || !out_id) return -1;

@@ -3,9 +3,11 @@
 // The product (pbrt-v3-rs_amd/) never includes or links anything under oracle/.
 //
 // Parity pin status: the reference's own tests cover only core/src/geometry (277 #[test]s); every one of them is
-// replayed or accounted for in tests/test_reference_proptests.py (+ tests/test_oracle_geometry.py).  BVH/Triangle/sampler/path/film have NO reference tests or
-// golden vectors and the reference (Rust) cannot be built here, so for those parts parity is "unpinned" except
-// for the PCG32 / Halton-permutation KATs of SURVEY Appendix C (tests/golden/).
+// replayed or accounted for in tests/test_reference_proptests.py (+ tests/test_oracle_geometry.py).  The reference's own RENDERS of ten in-scope scenes
+// (renders/**.png) are reproduced to a fraction of an 8-bit level (tests/test_reference_renders.py), its render of scenes/shapes/sphere.pbrt pins the Sphere's
+// silhouettes (tests/test_oracle_sphere.py).  Beyond the first bounce (indirect light, Russian roulette) and for the non-matte materials there are NO reference
+// outputs or golden vectors and the reference (Rust) cannot be built here: for those parts parity is "unpinned" except for the PCG32 / Halton-permutation
+// KATs of SURVEY Appendix C (tests/golden/) and the closed forms of tests/test_oracle_*.py.
 //
 // Build: g++ -O2 -ffp-contract=off -fno-fast-math (Rust never contracts a*b+c).
 //
@@ -272,6 +274,43 @@ inline void rgb_to_xyz(const Float rgb[3], Float xyz[3]) {
     xyz[2] = 0.019334f * rgb[0] + 0.119193f * rgb[1] + 0.950227f * rgb[2];
 }
 
+// EFloat (core/src/efloat.rs): a value with a conservative interval, release build (no v_precise).  Only the oracle-only Sphere uses it.
+struct EFloat {
+    Float v, low, high;
+    EFloat() : v(0), low(0), high(0) {}
+    EFloat(Float v_, Float err = 0.0f) : v(v_) {                                             // EFloat::new (:14-33)
+        if (err == 0.0f) { low = v_; high = v_; }
+        else { low = next_float_down(v_ - err); high = next_float_up(v_ + err); }
+    }
+    static EFloat raw(Float v, Float lo, Float hi) { EFloat r; r.v = v; r.low = lo; r.high = hi; return r; }
+    Float lower_bound() const { return low; }
+    Float upper_bound() const { return high; }
+};
+inline EFloat operator+(EFloat a, EFloat b) { return EFloat::raw(a.v + b.v, next_float_down(a.low + b.low), next_float_up(a.high + b.high)); }   // :150-163
+inline EFloat operator-(EFloat a, EFloat b) { return EFloat::raw(a.v - b.v, next_float_down(a.low - b.high), next_float_up(a.high - b.low)); }   // :180-192
+inline EFloat operator*(EFloat a, EFloat b) {                                                                                                    // :209-228
+    const Float pr[4] = {a.low * b.low, a.high * b.low, a.low * b.high, a.high * b.high};
+    return EFloat::raw(a.v * b.v, next_float_down(std::fmin(std::fmin(pr[0], pr[1]), std::fmin(pr[2], pr[3]))),
+                       next_float_up(std::fmax(std::fmax(pr[0], pr[1]), std::fmax(pr[2], pr[3]))));
+}
+inline EFloat operator/(EFloat a, EFloat b) {                                                                                                    // :245-270
+    if (b.low < 0.0f && b.high > 0.0f) return EFloat::raw(a.v / b.v, -INF, INF);  // the divisor straddles zero
+    const Float dv[4] = {a.low / b.low, a.high / b.low, a.low / b.high, a.high / b.high};
+    return EFloat::raw(a.v / b.v, next_float_down(std::fmin(std::fmin(dv[0], dv[1]), std::fmin(dv[2], dv[3]))),
+                       next_float_up(std::fmax(std::fmax(dv[0], dv[1]), std::fmax(dv[2], dv[3]))));
+}
+// Quadratic::solve_efloat (:301-327): discriminant in f64 from the values, roots with intervals, ordered by value
+inline bool quadratic_efloat(EFloat a, EFloat b, EFloat c, EFloat& t0, EFloat& t1) {
+    const double discrim = (double)b.v * (double)b.v - 4.0 * (double)a.v * (double)c.v;
+    if (discrim < 0.0) return false;
+    const Float root = (Float)std::sqrt(discrim);
+    const EFloat ef_root(root, MACHINE_EPSILON * root);
+    const EFloat q = b.v < 0.0f ? EFloat(-0.5f) * (b - ef_root) : EFloat(-0.5f) * (b + ef_root);
+    t0 = q / a; t1 = c / q;
+    if (t0.v > t1.v) { EFloat t = t0; t0 = t1; t1 = t; }
+    return true;
+}
+
 // core/src/geometry/bounds3.rs
 struct Bounds3 {
     V3 pmin, pmax;
@@ -409,6 +448,13 @@ struct Transform {
         return V3(m.m[0][0] * v.x + m.m[0][1] * v.y + m.m[0][2] * v.z,
                   m.m[1][0] * v.x + m.m[1][1] * v.y + m.m[1][2] * v.z,
                   m.m[2][0] * v.x + m.m[2][1] * v.y + m.m[2][2] * v.z);
+    }
+    V3 vector_with_error(V3 v, V3& err) const {                                               // transform.rs:385-403
+        Float x = v.x, y = v.y, z = v.z, g3 = gamma_n(3);
+        err = V3(g3 * (pabs(m.m[0][0] * x) + pabs(m.m[0][1] * y) + pabs(m.m[0][2] * z)),
+                 g3 * (pabs(m.m[1][0] * x) + pabs(m.m[1][1] * y) + pabs(m.m[1][2] * z)),
+                 g3 * (pabs(m.m[2][0] * x) + pabs(m.m[2][1] * y) + pabs(m.m[2][2] * z)));
+        return V3(m.m[0][0] * x + m.m[0][1] * y + m.m[0][2] * z, m.m[1][0] * x + m.m[1][1] * y + m.m[1][2] * z, m.m[2][0] * x + m.m[2][1] * y + m.m[2][2] * z);
     }
     V3 normal(V3 n) const {                                                                   // transform.rs:441-448
         return V3(m_inv.m[0][0] * n.x + m_inv.m[1][0] * n.y + m_inv.m[2][0] * n.z,

@@ -437,8 +437,49 @@ struct Renderer {
         si.dpdv_s = t.vector(si.dpdv_s); si.dndu_s = t.normal(si.dndu_s); si.dndv_s = t.normal(si.dndv_s);
         return si;
     }
+    // ---- tail of Sphere::intersect (sphere.rs:173-241): parametric form, normal derivatives from the fundamental forms, SurfaceInteraction::new
+    // (surface_interaction.rs:69-98), then object_to_world.transform_surface_interaction (transform.rs:566-590)
+    SurfaceHit make_sphere_hit(const Ray& r_world, uint32_t prim, const TriHit& h, const Sphere& sp) const {
+        SurfaceHit si; si.prim = prim; si.time = r_world.time;
+        const V3 p = h.sp; const Float phi = h.sphi;
+        const Float u = phi / sp.phi_max;
+        const Float theta = o_acos(pclamp(p.z / sp.radius, -1.0f, 1.0f));
+        const Float v = (theta - sp.theta_min) / (sp.theta_max - sp.theta_min);
+        const Float z_radius = std::sqrt(p.x * p.x + p.y * p.y);
+        const Float inv_z_radius = 1.0f / z_radius;
+        const Float cos_phi = p.x * inv_z_radius, sin_phi = p.y * inv_z_radius;
+        const V3 dpdu(-sp.phi_max * p.y, sp.phi_max * p.x, 0.0f);
+        const V3 dpdv = (sp.theta_max - sp.theta_min) * V3(p.z * cos_phi, p.z * sin_phi, -sp.radius * o_sin(theta));
+        const V3 d2p_duu = (-sp.phi_max * sp.phi_max) * V3(p.x, p.y, 0.0f);
+        const V3 d2p_duv = ((sp.theta_max - sp.theta_min) * p.z * sp.phi_max) * V3(-sin_phi, cos_phi, 0.0f);
+        const V3 d2p_dvv = (-(sp.theta_max - sp.theta_min) * (sp.theta_max - sp.theta_min)) * V3(p.x, p.y, p.z);
+        const V3 nn = normalize(cross(dpdu, dpdv));
+        const Float e1 = dot(dpdu, dpdu), f1 = dot(dpdu, dpdv), g1 = dot(dpdv, dpdv);
+        const Float e2 = dot(nn, d2p_duu), f2 = dot(nn, d2p_duv), g2 = dot(nn, d2p_dvv);
+        const Float inv_egf_1 = 1.0f / (e1 * g1 - f1 * f1);
+        const V3 dndu = ((f2 * f1 - e2 * g1) * inv_egf_1) * dpdu + ((e2 * f1 - f2 * e1) * inv_egf_1) * dpdv;
+        const V3 dndv = ((g2 * f1 - f2 * g1) * inv_egf_1) * dpdu + ((f2 * f1 - g2 * e1) * inv_egf_1) * dpdv;
+        const V3 p_error = gamma_n(5) * vabs(p);
+        // SurfaceInteraction::new with wo = -ray.d of the OBJECT-space ray
+        V3 n = nn;
+        if (sp.reverse_orientation ^ sp.swaps_handedness) n = n * -1.0f;
+        V3 wo = -sp.w2o.vector(r_world.d); const Float l2 = length_squared(wo);
+        wo = (l2 == 0.0f) ? wo : wo / std::sqrt(l2);  // Hit::new (interaction/mod.rs:137-156)
+        // to world space
+        const Transform& t = sp.o2w;
+        V3 pe; si.p = t.point_with_abs_error(p, p_error, pe); si.p_error = pe;
+        si.wo = normalize(t.vector(wo));
+        si.n = normalize(t.normal(n));
+        si.dpdu = t.vector(dpdu); si.dpdv = t.vector(dpdv);
+        si.ns = face_forward(normalize(t.normal(n)), si.n);
+        si.dpdu_s = t.vector(dpdu); si.dpdv_s = t.vector(dpdv);
+        si.dndu_s = t.normal(dndu); si.dndv_s = t.normal(dndv);
+        si.uv = V2(u, v);
+        return si;
+    }
     SurfaceHit make_surface_hit_local(const Ray& r, uint32_t prim, const TriHit& h) const {
         const Scene& s = *sc; const Mesh& m = s.mesh_of(prim);
+        if (m.sphere >= 0) return make_sphere_hit(r, prim, h, s.spheres[(size_t)m.sphere]);
         uint32_t i0 = s.idx[3 * prim], i1 = s.idx[3 * prim + 1], i2 = s.idx[3 * prim + 2];
         V3 p0 = s.P[i0], p1 = s.P[i1], p2 = s.P[i2];
         Float b0 = h.b0, b1 = h.b1, b2 = h.b2;

@@ -96,6 +96,24 @@ struct Mesh {
     bool reverse_orientation, swaps_handedness;
     Float alpha, shadow_alpha;
     int alpha_tex = -1, shadow_alpha_tex = -1;   // float textures instead of the constants (triangle.rs:587-607, 868-898)
+    int sphere = -1;        // >= 0: this record stands for ONE Sphere (scene.spheres[sphere]) that occupies one slot of the primitive list; no vertices
+};
+
+// Sphere (shapes/src/sphere.rs:10-57) — ORACLE ONLY: BASELINE.json's configs[0] (scenes/shapes/sphere.pbrt) is "CPU reference only (plumbing)", the product renders triangles
+struct Sphere {
+    Transform o2w, w2o;
+    bool reverse_orientation = false, swaps_handedness = false;
+    Float radius = 1, z_min = -1, z_max = 1, theta_min = 0, theta_max = 0, phi_max = 0;
+    Sphere() {}
+    Sphere(const Transform& o2w_, bool rev, Float radius_, Float zmin, Float zmax, Float phimax_deg) : o2w(o2w_), w2o(o2w_.inv()), reverse_orientation(rev), radius(radius_) {  // Sphere::new (:21-44)
+        swaps_handedness = o2w.swaps_handedness();  // ShapeData::new
+        z_min = pclamp(pmin(zmin, zmax), -radius, radius);
+        z_max = pclamp(pmax(zmin, zmax), -radius, radius);
+        theta_min = o_acos(pclamp(pmin(zmin, zmax) / radius, -1.0f, 1.0f));
+        theta_max = o_acos(pclamp(pmax(zmin, zmax) / radius, -1.0f, 1.0f));
+        phi_max = pclamp(phimax_deg, 0.0f, 360.0f) * (PI / 180.0f);  // f32::to_radians
+    }
+    Bounds3 object_bound() const { return Bounds3(V3(-radius, -radius, z_min)).union_p(V3(radius, radius, z_max)); }  // :53-58 (Bounds3::new of two sorted corners)
 };
 
 struct LinearBVHNode {  // accelerators/src/bvh/common.rs:163-179 (32 bytes)
@@ -105,7 +123,7 @@ struct LinearBVHNode {  // accelerators/src/bvh/common.rs:163-179 (32 bytes)
     uint8_t axis, pad;
 };
 
-struct TriHit { Float t, b0, b1, b2; uint32_t inst = 0; };  // inst = instance number + 1 when the hit lies inside an ObjectInstance
+struct TriHit { Float t, b0, b1, b2; uint32_t inst = 0; V3 sp; Float sphi = 0; };  // sp / sphi: a Sphere hit's refined object-space point and phi  // inst = instance number + 1 when the hit lies inside an ObjectInstance
 
 // Object instancing (api/src/lib.rs:911-1000, core/src/primitives/transformed_primitive.rs).  An object is a contiguous range
 // of the scene's triangles; when it is instanced the reference wraps its primitives in one aggregate (the BVH the Accelerator
@@ -149,6 +167,7 @@ struct Scene {
     std::vector<MipMap> mipmaps;
     std::vector<Light> lights;
     std::vector<int> infinite_lights;
+    std::vector<Sphere> spheres;      // oracle-only shapes; each owns one Mesh record and one primitive slot
     // objects / instances; top_items = the scene's primitive list in directive order (triangle id, or ORC_INST_BIT | instance)
     std::vector<Object> objects;
     std::vector<Instance> instances;
@@ -167,7 +186,46 @@ struct Scene {
 
     // ---- Triangle::world_bound (triangle.rs:427-431)
     Bounds3 tri_bound(uint32_t prim) const {
+        if (mesh_of(prim).sphere >= 0) { const Sphere& sp = spheres[(size_t)mesh_of(prim).sphere]; return transform_bounds(sp.o2w, sp.object_bound()); }  // Shape::world_bound (shape.rs)
         return Bounds3(P[idx[3 * prim]]).union_p(P[idx[3 * prim + 1]]).union_p(P[idx[3 * prim + 2]]);
+    }
+
+    // ---- Sphere::intersect / intersect_p up to the accept decision (sphere.rs:59-171 / 243-330): the two run the same tests.  Fills t and the
+    // refined object-space hit point + phi; the SurfaceInteraction is built from them by the renderer (sphere.rs:173-241).
+    bool sphere_intersect(const Ray& r, const Sphere& sp, TriHit& h) const {
+        V3 o_err, d_err;
+        V3 o = sp.w2o.point_with_error(r.o, o_err);          // transform_ray_with_error (transform.rs:481-510): t_max is NOT shortened here
+        const V3 d = sp.w2o.vector_with_error(r.d, d_err);
+        const Float l2 = length_squared(d);
+        if (l2 > 0.0f) { const Float dt = dot(vabs(d), o_err) / l2; o = o + d * dt; }
+        const EFloat ox(o.x, o_err.x), oy(o.y, o_err.y), oz(o.z, o_err.z), dx(d.x, d_err.x), dy(d.y, d_err.y), dz(d.z, d_err.z);
+        const EFloat a = dx * dx + dy * dy + dz * dz;
+        const EFloat b = EFloat(2.0f) * (dx * ox + dy * oy + dz * oz);
+        const EFloat c = ox * ox + oy * oy + oz * oz - EFloat(sp.radius) * EFloat(sp.radius);
+        EFloat t0, t1;
+        if (!quadratic_efloat(a, b, c, t0, t1)) return false;
+        if (t0.upper_bound() > r.t_max || t1.lower_bound() <= 0.0f) return false;
+        EFloat t_hit = t0;
+        if (t_hit.lower_bound() <= 0.0f) { t_hit = t1; if (t_hit.upper_bound() > r.t_max) return false; }
+        V3 p_hit; Float phi;
+        auto locate = [&]() {
+            p_hit = o + d * t_hit.v;                                          // ray.at(t)
+            p_hit = p_hit * (sp.radius / distance(p_hit, V3(0, 0, 0)));      // refine
+            if (p_hit.x == 0.0f && p_hit.y == 0.0f) p_hit.x = 1e-5f * sp.radius;
+            phi = o_atan2(p_hit.y, p_hit.x);
+            if (phi < 0.0f) phi += TWO_PI;
+        };
+        auto clipped = [&]() { return (sp.z_min > -sp.radius && p_hit.z < sp.z_min) || (sp.z_max < sp.radius && p_hit.z > sp.z_max) || phi > sp.phi_max; };
+        locate();
+        if (clipped()) {
+            if (t_hit.v == t1.v) return false;  // EFloat == compares the values (efloat.rs:143-147)
+            if (t1.upper_bound() > r.t_max) return false;
+            t_hit = t1;
+            locate();
+            if (clipped()) return false;
+        }
+        h.t = t_hit.v; h.b0 = h.b1 = h.b2 = 0.0f; h.sp = p_hit; h.sphi = phi;
+        return true;
     }
     void tri_uvs(uint32_t prim, V2 uv[3]) const {  // triangle.rs:384-394
         if (mesh_of(prim).has_uv) { uv[0] = UV[idx[3 * prim]]; uv[1] = UV[idx[3 * prim + 1]]; uv[2] = UV[idx[3 * prim + 2]]; }
@@ -292,7 +350,8 @@ struct Scene {
         if (!(ref & ORC_INST_BIT)) {
             TriHit h;
             if (st) st->tri_tests++;
-            if (tri_intersect(r, ref, true, false, h)) { r.t_max = h.t; prim_out = ref; hit_out = h; return true; }
+            const bool hit = mesh_of(ref).sphere >= 0 ? sphere_intersect(r, spheres[(size_t)mesh_of(ref).sphere], h) : tri_intersect(r, ref, true, false, h);
+            if (hit) { r.t_max = h.t; prim_out = ref; hit_out = h; return true; }
             return false;
         }
         const uint32_t ii = ref & ~ORC_INST_BIT;
@@ -307,7 +366,11 @@ struct Scene {
         return true;
     }
     bool prim_intersect_p(const Ray& r, uint32_t ref, TraversalStats* st) const {
-        if (!(ref & ORC_INST_BIT)) { TriHit h; if (st) st->tri_tests++; return tri_intersect(r, ref, true, true, h); }
+        if (!(ref & ORC_INST_BIT)) {
+            TriHit h; if (st) st->tri_tests++;
+            if (mesh_of(ref).sphere >= 0) return sphere_intersect(r, spheres[(size_t)mesh_of(ref).sphere], h);
+            return tri_intersect(r, ref, true, true, h);
+        }
         const Instance& in = instances[ref & ~ORC_INST_BIT]; const Object& ob = objects[in.object];
         Ray ray = transform_ray(in.i2w.inv(), r);
         if (ob.tri1 - ob.tri0 == 1) return prim_intersect_p(ray, ob.tri0, st);

@@ -314,8 +314,11 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
             if (aa != "none" && aa != "closedform") { warn("Antialiasing mode '" + aa + "' not understood by Checkerboard2DTexture; using 'closedform'"); aa = "closedform"; }
             if (ok) ok = check(ABI(pbrt_hip_add_texture_checkerboard(scene_, t1, t2, su, sv, du, dv, aa == "none" ? 0 : 1, &id)), "add_texture_checkerboard");
         } else if (tex_class == "dots") {
-            const uint32_t in = operand("inside", 1.0f), out = operand("outside", 0.0f);
-            if (ok) ok = check(ABI(pbrt_hip_add_texture_dots(scene_, in, out, su, sv, du, dv, &id)), "add_texture_dots");
+            // Quirk B11 (textures/src/dots.rs:61-66): the reference's constructor from parameters hands (inside, outside) to DotsTexture::new(outside_dot, inside_dot), so
+            // a scene file's "inside" value is what shows OUTSIDE the dots and "outside" fills them — its own render of scenes/shapes/triangles-alpha-mask.pbrt (an opaque
+            // cube with holes where `"float inside" 1 "float outside" 0` asks for the opposite) confirms it.  The C ABI keeps DotsTexture's meaning; the swap lives here.
+            const uint32_t param_inside = operand("inside", 1.0f), param_outside = operand("outside", 0.0f);
+            if (ok) ok = check(ABI(pbrt_hip_add_texture_dots(scene_, /*inside_dot=*/param_outside, /*outside_dot=*/param_inside, su, sv, du, dv, &id)), "add_texture_dots");
         } else if (tex_class == "uv") ok = check(ABI(pbrt_hip_add_texture_uv(scene_, su, sv, du, dv, &id)), "add_texture_uv");
         else {
             auto corner = [&](const char* pn, float d) { std::array<float, 3> v = {d, d, d}; if (is_float) { const float f = p.find_one_float(pn, d); v = {f, f, f}; } else v = p.find_one_rgb(pn, v); return v; };

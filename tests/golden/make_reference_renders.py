@@ -1,0 +1,23 @@
+"""Decodes the reference's own renders of the scenes tests/reference_scenes.py restates (renders/**.png, 8-bit RGB) -> tests/golden/ref_renders/<dir>_<name>.npz
+(the pixels exactly as the reference wrote them).  Run in the build container: python3 tests/golden/make_reference_renders.py"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_sphere_mask import read_png  # noqa: E402
+
+NAMES = ["shapes/triangles-alpha-mask", "cameras/perspective", "cameras/orthographic", "cameras/environment", "lights/point", "lights/distant", "lights/spot",
+         "lights/infinite-no-map", "lights/goniometric", "objects/instances"]
+if __name__ == "__main__":
+    os.makedirs(os.path.join(HERE, "ref_renders"), exist_ok=True)
+    for n in NAMES:
+        img = read_png(os.path.join("/root/reference/renders", n + ".png"))
+        np.savez_compressed(os.path.join(HERE, "ref_renders", n.replace("/", "_") + ".npz"), rgb=np.ascontiguousarray(img, np.uint8))
+        print(n, img.shape)
+    # the one image INPUT among these scenes (scenes/lights/goniometric.pbrt "string mapname")
+    img = read_png("/root/reference/scenes/images/goniometric-upward-downward.png")
+    np.savez_compressed(os.path.join(HERE, "ref_renders", "image_goniometric-upward-downward.npz"), rgb=np.ascontiguousarray(img, np.uint8))
+    print("goniometric map", img.shape)

@@ -1,0 +1,230 @@
+"""Scenes of the reference's own `scenes/` directory that lie inside the product's feature set (triangles only, no external assets), restated through the C ABI
+(`pbrt_hip.Scene`, product or oracle), and the reference's own renders of them (`renders/**.png`, decoded into tests/golden/ref_renders/*.npz by
+tests/golden/make_reference_renders.py).  The reference rendered them with `Integrator "whitted"`: direct lighting from every light plus specular recursion.  For matte
+surfaces under delta lights that is the path integrator at maxdepth 1 (one light: the same single term; k lights: uniform_sample_one_light picks each with 1 / k and
+divides by it), so the comparison is quantitative: the render through the C ABI, pushed through the reference's 8-bit output curve (image_io.rs `apply_gamma`), against
+the reference's PNG, within what 8-bit rounding and pixel-edge sampling allow."""
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+IDENT = None
+
+
+def _ident():
+    import pbrt_hip
+    return (pbrt_hip.IDENTITY.copy(), pbrt_hip.IDENTITY.copy())
+
+
+def ctm(host, *steps):
+    t = _ident()
+    for s in steps:
+        t = host.compose(t, s)
+    return t
+
+
+def to_8bit(rgb):
+    """image_io.rs write_8_bit / apply_gamma: clamp(255 * gamma_correct(v) + 0.5, 0, 255) as u8"""
+    v = np.asarray(rgb, np.float32)
+    g = np.where(v <= 0.0031308, 12.92 * v, 1.055 * np.power(np.maximum(v, 0.0), 1.0 / 2.4) - 0.055)
+    return np.clip(255.0 * g + 0.5, 0.0, 255.0).astype(np.uint8)
+
+
+def reference_render(name):
+    z = np.load(os.path.join(HERE, "golden", "ref_renders", name + ".npz"))
+    return z["rgb"]  # (H, W, 3) uint8
+
+
+def camera_film(s, host, eye, look, up, fov, xres, yres, spp, screen=None):
+    w2c, c2w = host.look_at(eye, look, up)
+    s.set_camera_perspective(host.perspective_raster_to_camera(fov, xres, yres, screen), c2w)
+    cb, table, sb = host.film_box(xres, yres)
+    s.set_film(xres, yres, cb, (0.5, 0.5), table)
+    s.set_sampler(0, spp, sb)
+
+
+CUBE_P = np.array([[-1, -1, -1], [-1, 1, -1], [1, 1, -1], [1, -1, -1], [-1, -1, 1], [-1, 1, 1], [1, 1, 1], [1, -1, 1]], np.float32)
+CUBE_ST = np.array([[0, 0], [0, 1], [1, 1], [1, 0], [1, 0], [1, 1], [0, 1], [0, 0]], np.float32)
+CUBE_IDX = np.array([0, 1, 2, 3, 0, 2, 1, 5, 6, 2, 1, 6, 4, 5, 1, 0, 4, 1, 3, 2, 6, 7, 3, 6, 6, 5, 4, 6, 4, 7, 4, 0, 3, 7, 4, 3], np.uint32)
+QUAD_IDX = np.array([0, 1, 2, 0, 2, 3], np.uint32)
+QUAD_ST = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+
+
+def quad(size):
+    return np.array([[-size, -size, 0], [size, -size, 0], [size, size, 0], [-size, size, 0]], np.float32)
+
+
+def triangles_alpha_mask(s, host, spp=32, res=400):
+    """scenes/shapes/triangles-alpha-mask.pbrt -> renders/shapes/triangles-alpha-mask.png (400 x 400, the reference used 128 spp)"""
+    s.add_light_point((0.4 * 200, 0.45 * 200, 0.5 * 200), (-5.0, 0.0, 5.0))
+    # "float inside" 1 "float outside" 0 — which the reference's constructor hands over swapped (dots.rs:61-66, quirk B11): alpha is 0 INSIDE the dots
+    alpha = s.add_texture_dots(s.add_texture_constant(0.0), s.add_texture_constant(1.0), 10.0, 10.0)
+    t = ctm(host, host.rotate(135.0, (0, 0, 1)))
+    m1 = s.add_material_matte((0.2, 0.01, 0.01))
+    s.add_mesh(host.transform_points(t[0], CUBE_P), CUBE_IDX, m1, UV=CUBE_ST)
+    s.set_last_mesh_alpha_textures(alpha=alpha)
+    t = ctm(host, host.translate((0, 0, -1)))
+    checks = s.add_texture_checkerboard(s.add_texture_constant((0.3, 0.3, 0.3)), s.add_texture_constant((0.8, 0.8, 0.8)), 24.0, 24.0)
+    m2 = s.add_material_matte_tex(checks)
+    s.add_mesh(host.transform_points(t[0], quad(20.0)), QUAD_IDX, m2, UV=QUAD_ST)
+    camera_film(s, host, (0, 5, 3), (0, 0, 0), (0, 0, 1), 90.0, res, res, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="shapes_triangles-alpha-mask")
+
+
+def _cube_and_checker_floor(s, host, cube_rotate_deg=45.0, tex1=0.3):
+    """the stage most of scenes/lights/*.pbrt share: geometry/cube.pbrt rotated about z, matte (.2 .01 .01), above a 40 x 40 quad at z = -1 with a 24 x 24 checkerboard"""
+    m1 = s.add_material_matte((0.2, 0.01, 0.01))
+    t = ctm(host, host.rotate(cube_rotate_deg, (0, 0, 1)))
+    s.add_mesh(host.transform_points(t[0], CUBE_P), CUBE_IDX, m1, UV=CUBE_ST)
+    t = ctm(host, host.translate((0, 0, -1)))
+    checks = s.add_texture_checkerboard(s.add_texture_constant((tex1, tex1, tex1)), s.add_texture_constant((0.8, 0.8, 0.8)), 24.0, 24.0)
+    s.add_mesh(host.transform_points(t[0], quad(20.0)), QUAD_IDX, s.add_material_matte_tex(checks), UV=QUAD_ST)
+
+
+def lights_point(s, host, spp=32, res=400):
+    """scenes/lights/point.pbrt -> renders/lights/point.png"""
+    s.add_light_point((80.0, 90.0, 100.0), (-5.0, 0.0, 5.0))  # "rgb I" [.4 .45 .5] x "rgb scale" [200 200 200]
+    _cube_and_checker_floor(s, host)
+    camera_film(s, host, (0, 5, 3), (0, 0, 0), (0, 0, 1), 90.0, res, res, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="lights_point")
+
+
+def lights_spot(s, host, spp=32, res=400):
+    """scenes/lights/spot.pbrt -> renders/lights/spot.png: "float coneangle" 25; the file's "float conedelta" 20 is not a parameter the reference reads
+    (spot.rs:155-156 looks up "conedeltaangle"), so the default 5 applies — its render shows the 5-degree rim"""
+    l2w, w2l, cos_total, cos_start = host.spot(_ident(), (-5.0, 0.0, 5.0), (0.0, 0.0, 0.0), 25.0, 5.0)
+    s.add_light_spot((80.0, 90.0, 100.0), l2w, w2l, cos_total, cos_start)
+    _cube_and_checker_floor(s, host)
+    camera_film(s, host, (0, 5, 3), (0, 0, 0), (0, 0, 1), 90.0, res, res, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="lights_spot")
+
+
+def lights_infinite_no_map(s, host, spp=64, res=400):
+    """scenes/lights/infinite-no-map.pbrt -> renders/lights/infinite-no-map.png.  Whitted takes one light sample per camera sample, the path integrator's direct term adds
+    the BSDF-sampled MIS partner: same expectation, both noisy (the reference used 128 spp)."""
+    s.add_light_infinite((0.4, 0.45, 0.5))
+    _cube_and_checker_floor(s, host)
+    camera_film(s, host, (0, 5, 3), (0, 0, 0), (0, 0, 1), 90.0, res, res, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="lights_infinite-no-map", noisy=True)
+
+
+def lights_goniometric(s, host, spp=32, res=400):
+    """scenes/lights/goniometric.pbrt -> renders/lights/goniometric.png; the map is scenes/images/goniometric-upward-downward.png (fixture: its pixels / 255 as read_8_bit returns them)"""
+    img = np.load(os.path.join(HERE, "golden", "ref_renders", "image_goniometric-upward-downward.npz"))["rgb"].astype(np.float32) / np.float32(255.0)
+    t = ctm(host, host.translate((-5, 0, 5)), host.rotate(135.0, (1, 0, 0)), host.rotate(60.0, (0, 1, 0)))
+    s.add_light_goniometric((80.0, 90.0, 100.0), t[0], t[1], img)
+    _cube_and_checker_floor(s, host)
+    camera_film(s, host, (0, 5, 3), (0, 0, 0), (0, 0, 1), 90.0, res, res, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="lights_goniometric")
+
+
+def blackbody(key):
+    """RGB of a `"blackbody L" [T scale]` parameter (tests/golden/blackbody_rgb.json, made by make_blackbody_fixture.py from the reference's CIE tables)"""
+    import json
+    return tuple(json.load(open(os.path.join(HERE, "golden", "blackbody_rgb.json")))[key])
+
+
+def lights_distant(s, host, spp=32, res=400):
+    """scenes/lights/distant.pbrt -> renders/lights/distant.png: "point from" [-5 0 5] "point to" [0 0 0] "blackbody L" [4500 1.5]"""
+    s.add_light_distant(blackbody("4500x1.5"), host.distant_direction(_ident()[0], (-5.0, 0.0, 5.0), (0.0, 0.0, 0.0)))
+    _cube_and_checker_floor(s, host)
+    camera_film(s, host, (0, 5, 3), (0, 0, 0), (0, 0, 1), 90.0, res, res, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="lights_distant")
+
+
+def _sky_and_sun(s, host, t=None):
+    """LightSource "infinite" "rgb L" [.4 .45 .5] + LightSource "distant" "point from" [-30 40 100] "blackbody L" [3000 1.5] under the CTM `t`"""
+    t = t if t is not None else _ident()
+    s.add_light_infinite((0.4, 0.45, 0.5), t[0], t[1])
+    s.add_light_distant(blackbody("3000x1.5"), host.distant_direction(t[0], (-30.0, 40.0, 100.0), (0.0, 0.0, 0.0)))
+
+
+def cameras_perspective(s, host, spp=64, res=400):
+    """scenes/cameras/perspective.pbrt -> renders/cameras/perspective.png (two lights: Whitted adds both per camera sample, the path integrator picks one of the two)"""
+    _sky_and_sun(s, host)
+    _cube_and_checker_floor(s, host, tex1=0.1)
+    camera_film(s, host, (0, 2, 2), (0, 0, 0), (0, 0, 1), 90.0, res, res, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="cameras_perspective", noisy=True)
+
+
+def cameras_orthographic(s, host, spp=64, res=400):
+    """scenes/cameras/orthographic.pbrt -> renders/cameras/orthographic.png: `Scale 0.25 0.25 0.25` follows the two LightSource lines, so it sits under the shapes only"""
+    sc = host.scale((0.25, 0.25, 0.25))
+    _sky_and_sun(s, host)
+    m1 = s.add_material_matte((0.2, 0.01, 0.01))
+    t = ctm(host, sc, host.rotate(45.0, (0, 0, 1)))
+    s.add_mesh(host.transform_points(t[0], CUBE_P), CUBE_IDX, m1, UV=CUBE_ST)
+    t = ctm(host, sc, host.translate((0, 0, -1)))
+    checks = s.add_texture_checkerboard(s.add_texture_constant((0.1, 0.1, 0.1)), s.add_texture_constant((0.8, 0.8, 0.8)), 24.0, 24.0)
+    s.add_mesh(host.transform_points(t[0], quad(20.0)), QUAD_IDX, s.add_material_matte_tex(checks), UV=QUAD_ST)
+    w2c, c2w = host.look_at((0, 10, 10), (0, 0, 0), (0, 0, 1))
+    s.set_camera_orthographic(host.orthographic_raster_to_camera(res, res), c2w)
+    cb, table, sb = host.film_box(res, res)
+    s.set_film(res, res, cb, (0.5, 0.5), table)
+    s.set_sampler(0, spp, sb)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="cameras_orthographic", noisy=True)
+
+
+def _ring_transforms(host):
+    return [ctm(host, host.rotate(36.0 * k, (0, 0, 1)), host.translate((0, 5, 0)), host.rotate(45.0, (0, 0, 1))) if k else
+            ctm(host, host.translate((0, 5, 0)), host.rotate(45.0, (0, 0, 1))) for k in range(10)]
+
+
+def _checker_floor(s, host, tex1):
+    t = ctm(host, host.translate((0, 0, -1)))
+    checks = s.add_texture_checkerboard(s.add_texture_constant((tex1, tex1, tex1)), s.add_texture_constant((0.8, 0.8, 0.8)), 24.0, 24.0)
+    s.add_mesh(host.transform_points(t[0], quad(20.0)), QUAD_IDX, s.add_material_matte_tex(checks), UV=QUAD_ST)
+
+
+def cameras_environment(s, host, spp=64, res=400):
+    """scenes/cameras/environment.pbrt -> renders/cameras/environment.png (800 x 400): ten cubes on a ring around the camera"""
+    _sky_and_sun(s, host)
+    m = s.add_material_matte((0.8, 0.1, 0.01))
+    for t in _ring_transforms(host):
+        s.add_mesh(host.transform_points(t[0], CUBE_P), CUBE_IDX, m, UV=CUBE_ST)
+    _checker_floor(s, host, 0.1)
+    w2c, c2w = host.look_at((0, 0, 1), (0, 1, 0), (0, 0, 1))
+    s.set_camera_environment(c2w, 2 * res, res)
+    cb, table, sb = host.film_box(2 * res, res)
+    s.set_film(2 * res, res, cb, (0.5, 0.5), table)
+    s.set_sampler(0, spp, sb)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="cameras_environment", noisy=True)
+
+
+def objects_instances(s, host, spp=64, res=400):
+    """scenes/objects/instances.pbrt -> renders/objects/instances.png: ONE cube object, ten ObjectInstances; `Translate 0 -1 0` follows LookAt, so it is part of the camera transform"""
+    _sky_and_sun(s, host)
+    m = s.add_material_matte((0.8, 0.1, 0.01))
+    ob = s.object_begin(); s.add_mesh(CUBE_P, CUBE_IDX, m, UV=CUBE_ST); s.object_end()
+    for t in _ring_transforms(host):
+        s.add_instance(ob, t[0], t[1])
+    _checker_floor(s, host, 0.1)
+    cam = host.compose(host.look_at((0, 7, 15), (0, 0, 0), (0, 0, 1)), host.translate((0, -1, 0)))  # world -> camera and its inverse
+    s.set_camera_perspective(host.perspective_raster_to_camera(45.0, res, res), cam[1])
+    cb, table, sb = host.film_box(res, res)
+    s.set_film(res, res, cb, (0.5, 0.5), table)
+    s.set_sampler(0, spp, sb)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="objects_instances", noisy=True)
+
+
+def compare(rgb_linear, ref_u8, block=8):
+    """-> dict: mean |delta| in 8-bit levels per pixel, fraction of pixels with a channel off by more than 12 levels, and the same two over block x block means (sampling
+    noise averages out of those: the path integrator's estimator differs from Whitted's where a scene has an area-like light or several lights)"""
+    mine = to_8bit(rgb_linear).astype(np.float64); ref = ref_u8.astype(np.float64)
+    d = np.abs(mine - ref)
+    h, w, _ = d.shape
+    bm = lambda a: a[: h // block * block, : w // block * block].reshape(h // block, block, w // block, block, 3).mean((1, 3))
+    db = np.abs(bm(mine) - bm(ref))
+    return dict(mean=float(d.mean()), bad=float((d.max(-1) > 12).mean()), block_mean=float(db.mean()), block_bad=float((db.max(-1) > 6).mean()),
+                bias=[float(v) for v in (mine - ref).mean((0, 1))])
