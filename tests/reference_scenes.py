@@ -218,6 +218,22 @@ def objects_instances(s, host, spp=64, res=400):
     return dict(max_depth=1, render="objects_instances", noisy=True)
 
 
+def materials_bump(s, host, spp=64, res=400):
+    """scenes/materials/bump.pbrt -> renders/materials/bump.png: a matte SPHERE (oracle only) whose bump map is the `windy` texture, above a matte floor"""
+    from test_oracle_sphere import add_sphere
+    s.add_light_infinite((0.8, 0.9, 1.0))
+    s.add_light_distant(blackbody("3000x1.5"), host.distant_direction(_ident()[0], (-30.0, 40.0, 100.0), (0.0, 0.0, 0.0)))
+    bump = s.add_texture_windy()
+    m = s.add_material_matte((0.5, 0.5, 0.5))
+    s.set_material_bump(m, bump)
+    add_sphere(s, ctm(host, host.scale((1.5, 1.5, 1.5)), host.rotate(135, (1, 0, 0)), host.rotate(-15, (0, 0, 1)), host.rotate(15, (0, 1, 0))), 1.0, material=m)
+    t = ctm(host, host.translate((0, 0, -1.5)))
+    s.add_mesh(host.transform_points(t[0], quad(20.0)), QUAD_IDX, s.add_material_matte((0.5, 0.5, 0.5)), UV=QUAD_ST)
+    camera_film(s, host, (0, 5, 1.5), (0, 0, 0), (0, 0, 1), 45.0, res, res, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="materials_bump", noisy=True)
+
+
 def compare(rgb_linear, ref_u8, block=8):
     """-> dict: mean |delta| in 8-bit levels per pixel, fraction of pixels with a channel off by more than 12 levels, and the same two over block x block means (sampling
     noise averages out of those: the path integrator's estimator differs from Whitted's where a scene has an area-like light or several lights)"""

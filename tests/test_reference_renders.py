@@ -65,3 +65,16 @@ def test_the_comparison_has_teeth():
     # a one-level exposure error (x 1.01) on a matching render is caught by the bias bound
     rgb, info, _ = render(oracle_binding(), "lights_point", 8)
     assert max(abs(b) for b in R.compare(rgb * 1.02, R.reference_render(info["render"]))["bias"]) > 0.2
+
+
+def test_oracle_equals_the_references_render_of_the_bump_mapped_sphere():
+    """scenes/materials/bump.pbrt: a matte Sphere (ORACLE ONLY, see test_oracle_sphere.py) displaced by the `windy` float texture, sky + sun.  Pins Material::bump, the windy /
+    fBm noise stack and the sphere's dpdu / dpdv / dndu / dndv against the reference's pixels: every crease of the relief has to fall where the reference put it."""
+    rgb, info, _ = render(oracle_binding(), "materials_bump", 96)
+    c = R.compare(rgb, R.reference_render(info["render"]))
+    assert c["mean"] < 5.0 and c["block_mean"] < 0.4 and c["block_bad"] < 0.002 and max(abs(b) for b in c["bias"]) < 0.25, c
+    # the relief itself, noise averaged out: gradients of the 4 x 4 block means on the sphere correlate with the reference's
+    ref = R.reference_render(info["render"]).astype(np.float64).mean(-1); mine = R.to_8bit(rgb).astype(np.float64).mean(-1)
+    bm = lambda a: a.reshape(100, 4, 100, 4).mean((1, 3))[25:75, 30:70]
+    gx = lambda a: np.diff(bm(a), axis=1).ravel()
+    assert np.corrcoef(gx(ref), gx(mine))[0, 1] > 0.9
