@@ -899,8 +899,18 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     if ((uint64_t)n_px * spp >= (1ull << 40)) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: too many samples");
 
     // ---- chunking: B = n_px * chunk_spp paths in flight ----------------------------------------------------------------------
-    size_t max_paths = 32u << 20;
-    if (const char* e = std::getenv("PBRT_HIP_MAX_PATHS")) { long v = std::atol(e); if (v > 0) max_paths = (size_t)v; }
+    // 128 Mi paths per chunk where the card has room for them (353 B of queues and path state per path, 481 B with a texture pass: 47 – 65 GB of the MI355X's 288 GB):
+    // large chunks bin better (more rays per origin cell and round) and pay fewer launch tails — configs[2] 913 -> 878 ms per frame, configs[3] 934 -> 898 ms against the
+    // 32 Mi of round 1 (gpurun r02aa; 256 Mi, the whole frame at once, adds nothing: 875 / 899 ms).  At most 30 % of the device's memory goes to one chunk.
+    size_t max_paths = 128u << 20;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
+            const size_t per_path = 353 + (s->textured_materials ? sizeof(TexOut) : 0);
+            max_paths = std::max<size_t>(4u << 20, std::min<size_t>(max_paths, total_b / 10 * 3 / per_path));
+        }
+    }
+    if (const char* e = std::getenv("PBRT_HIP_MAX_PATHS")) { long long v = std::atoll(e); if (v > 0) max_paths = (size_t)v; }
     uint32_t chunk_spp = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, max_paths / std::max<uint32_t>(n_px, 1)));
     const size_t B = (size_t)n_px * chunk_spp;
     if (B >= 0x7FFF0000ull) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: tile range too large for one rank; use more tile_parts");

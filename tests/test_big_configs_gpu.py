@@ -88,7 +88,7 @@ def test_config2_crop_bit_exact_and_full_frame_invariants(host, monkeypatch):
     assert g[1].shape == (46, 61)
     _assert_bit_exact(g, o, "configs[2] crop")
     st = _full_frame_invariants(host, C2, geom, monkeypatch, chunk_paths=12_000_000)
-    assert st.extend_launches >= 9 * 8   # depth 8 -> 9 rounds per chunk of 32 Mi paths, 8 chunks
+    assert st.extend_launches >= 9 * 2   # depth 8 -> 9 rounds per chunk; 268 M paths in chunks of at most 128 Mi (the 12 M-path rerun above makes 23 chunks of it)
 
 
 def test_config3_crop_bit_exact_and_tile_parts(host, monkeypatch):
