@@ -53,6 +53,11 @@ void pbrt_hip_host_point_position(const float l2w[16], const float l2w_inv[16], 
 void pbrt_hip_host_spot(const float ctm_m[16], const float ctm_minv[16], const float from[3], const float to[3], float cone_angle,
                         float cone_delta, float out_l2w[16], float out_w2l[16], float out_cos[2]);
 
+/* Spectral parameter types of a scene description -> RGB, as the reference's ParamSet turns them into RGBSpectrum (core/src/paramset/mod.rs:236-262,
+ * core/src/spectrum/common.rs:315-398, rgb_spectrum.rs:82-103): `"blackbody L" [T scale]` and `"spectrum name" [lambda value ...]` (or the pairs of an SPD file). */
+void pbrt_hip_host_blackbody_rgb(float temperature_kelvin, float scale, float out_rgb[3]);
+int pbrt_hip_host_sampled_rgb(const float* lambda_value_pairs, size_t n_samples, float out_rgb[3]);
+
 /* Synthetic measurement scene of BASELINE.md §3: n_tris random triangles from PCG32 stream `seed`
  * (core/src/rng.rs semantics). out_P: 9 floats per triangle, out_idx: 3 per triangle (unshared vertices). */
 void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, float* out_P, uint32_t* out_idx);

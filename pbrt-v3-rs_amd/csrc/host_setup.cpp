@@ -296,3 +296,72 @@ extern "C" int pbrt_hip_host_build_bvh(const float* P, const uint32_t* idx, uint
     if (out_root_bounds) { for (int k = 0; k < 3; k++) { out_root_bounds[k] = out.root_lo[k]; out_root_bounds[3 + k] = out.root_hi[k]; } }
     return 0;
 }
+
+// ---- spectral parameter types of the scene description -> RGB ------------------------------------------------------------------------------------
+// ParamSet::add_blackbody_spectrum / add_sampled_spectrum (core/src/paramset/mod.rs:236-262), blackbody / blackbody_normalized / interpolate_spectrum_samples
+// (core/src/spectrum/common.rs:315-398), RGBSpectrum::from(&Vec<Sample>) (core/src/spectrum/rgb_spectrum.rs:82-103), all in f32 as the reference computes them.
+#include "cie_table.inc"
+#include <cmath>
+#include <vector>
+namespace {
+float planck(float lambda_nm, float t) {  // spectrum/common.rs:361-380, one wavelength
+    const float c = 299792458.0f, h = 6.62606957e-34f, kb = 1.3806488e-23f;
+    const float l = lambda_nm * 1e-9f;
+    const float lambda5 = (l * l) * (l * l) * l;
+    return (2.0f * h * c * c) / (lambda5 * (std::exp((h * c) / (l * kb * t)) - 1.0f));
+}
+size_t find_interval_sz(size_t size, const std::vector<std::pair<float, float>>& s, float l) {  // pbrt/common.rs:251-276 with the predicate `samples[i].lambda <= l`
+    size_t first = 0, len = size;
+    while (len > 0) {
+        const size_t half = len >> 1, middle = first + half;
+        if (s[middle].first <= l) { first = middle + 1; len -= half + 1; } else len = half;
+    }
+    if (first == 0) return 0;
+    const size_t v = first - 1;
+    return v > size - 2 ? size - 2 : v;
+}
+float interpolate_samples(const std::vector<std::pair<float, float>>& s, float l) {  // spectrum/common.rs:315-331
+    const size_t n = s.size();
+    if (l <= s[0].first) return s[0].second;
+    if (l >= s[n - 1].first) return s[n - 1].second;
+    const size_t o = find_interval_sz(n, s, l);
+    const float t = (l - s[o].first) / (s[o + 1].first - s[o].first);
+    return (1.0f - t) * s[o].second + t * s[o + 1].second;
+}
+void samples_to_rgb(const std::vector<std::pair<float, float>>& s, float out[3]) {  // rgb_spectrum.rs:82-103 + xyz_to_rgb
+    float xyz[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < 471; i++) {
+        const float val = interpolate_samples(s, (float)(360 + i));
+        xyz[0] += val * kCieXyz[i][0]; xyz[1] += val * kCieXyz[i][1]; xyz[2] += val * kCieXyz[i][2];
+    }
+    const float scale = (float)(830 - 360) / (kCieYIntegral * (float)471);
+    xyz[0] *= scale; xyz[1] *= scale; xyz[2] *= scale;
+    out[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];
+    out[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+    out[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
+}
+}  // namespace
+
+extern "C" void pbrt_hip_host_blackbody_rgb(float temperature, float scale, float out_rgb[3]) {
+    std::vector<std::pair<float, float>> s(471);
+    float mx = 1.0f;
+    if (temperature > 0.0f) mx = planck(2.8977721e-3f / temperature * 1e9f, temperature);  // Wien's displacement law, metres -> nanometres
+    for (int i = 0; i < 471; i++) {
+        const float lam = (float)(360 + i);
+        s[i] = {lam, temperature > 0.0f ? planck(lam, temperature) / mx : 0.0f};
+    }
+    samples_to_rgb(s, out_rgb);
+    for (int k = 0; k < 3; k++) out_rgb[k] = scale * out_rgb[k];
+}
+
+// (wavelength nm, value) pairs.  Unsorted input is sorted by wavelength first: the reference sorts a copy and then interpolates the ORIGINAL order, where its
+// interval assertion fails (rgb_spectrum.rs:84-91, common.rs:327) — there is no result of the reference to match for unsorted samples.  Returns -1 for n == 0.
+extern "C" int pbrt_hip_host_sampled_rgb(const float* lambda_value_pairs, size_t n_samples, float out_rgb[3]) {
+    if (!lambda_value_pairs || n_samples == 0) return -1;
+    std::vector<std::pair<float, float>> s(n_samples);
+    for (size_t i = 0; i < n_samples; i++) s[i] = {lambda_value_pairs[2 * i], lambda_value_pairs[2 * i + 1]};
+    std::stable_sort(s.begin(), s.end(), [](const std::pair<float, float>& a, const std::pair<float, float>& b) { return a.first < b.first; });
+    if (n_samples == 1) { s.push_back(s[0]); }  // a single sample is a constant spectrum (both clamps of interpolate_spectrum_samples return it)
+    samples_to_rgb(s, out_rgb);
+    return 0;
+}

@@ -42,6 +42,26 @@ struct Lexer {
     }
 };
 
+// parse_float_file (core/src/float_file): numbers separated by white space, '#' starts a comment that runs to the end of the line
+bool read_float_file(const std::string& path, std::vector<float>& out, std::string& err) {
+    std::ifstream f(path);
+    if (!f) { err = "Error reading file '" + path + "': " + std::strerror(errno); return false; }
+    std::string line; int line_no = 0;
+    while (std::getline(f, line)) {
+        line_no++;
+        const size_t hash = line.find('#');
+        if (hash != std::string::npos) line.resize(hash);
+        std::istringstream ls(line);
+        std::string tok;
+        while (ls >> tok) {
+            char* end = nullptr; const float v = std::strtof(tok.c_str(), &end);
+            if (!end || *end) { err = "Error parsing floating point number '" + tok + "', line " + std::to_string(line_no) + "."; return false; }
+            out.push_back(v);
+        }
+    }
+    return true;
+}
+
 struct Parser {
     Api& api; std::string scene_dir; RenderReport* report; int depth;
     Lexer lx; Token cur;
@@ -141,8 +161,35 @@ struct Parser {
                 std::vector<std::string> sv;
                 for (auto& v : vals) { if (v.kind != Token::Str) return fail("parameter '" + name + "' expects strings"); sv.push_back(v.text); }
                 (type == "string" ? ps.strings : ps.textures)[name] = sv;
-            } else if (type == "spectrum" || type == "blackbody") {
-                ps.unsupported.push_back(type + " " + name);  // sampled SPDs need the CIE tables: reported where the value is consumed
+            } else if (type == "blackbody") {  // ParamSet::add_blackbody_spectrum (paramset/mod.rs:236-249): (temperature, scale) pairs
+                std::vector<float> f, rgb;
+                if (!as_floats(f)) return false;
+                if (f.size() % 2) return fail("parameter '" + name + "': blackbody values come in (temperature, scale) pairs");
+                for (size_t k = 0; k + 1 < f.size(); k += 2) { float c[3]; pbrt_hip_host_blackbody_rgb(f[k], f[k + 1], c); rgb.insert(rgb.end(), c, c + 3); }
+                ps.floats[name] = rgb;
+            } else if (type == "spectrum") {
+                std::vector<float> rgb;
+                if (!vals.empty() && vals[0].kind == Token::Str) {  // SPD files (add_sampled_spectrum_files, :268-315): one spectrum per file name
+                    for (auto& v : vals) {
+                        if (v.kind != Token::Str) return fail("parameter '" + name + "' mixes file names and numbers");
+                        const std::string path = (v.text.empty() || v.text[0] == '/' || scene_dir.empty()) ? v.text : scene_dir + "/" + v.text;
+                        std::vector<float> pairs; std::string ferr;
+                        float c[3] = {0.0f, 0.0f, 0.0f};
+                        if (!read_float_file(path, pairs, ferr)) api.warn("Unable to read SPD file '" + v.text + "'. Using black distribution. " + ferr);
+                        else {
+                            if (pairs.size() % 2) api.warn("Extra value found in spectrum file '" + v.text + "'. Ignoring it.");
+                            if (pairs.size() >= 2) pbrt_hip_host_sampled_rgb(pairs.data(), pairs.size() / 2, c);
+                        }
+                        rgb.insert(rgb.end(), c, c + 3);
+                    }
+                } else {  // inline (wavelength, value) pairs: ONE spectrum (add_sampled_spectrum, :255-262)
+                    std::vector<float> f;
+                    if (!as_floats(f)) return false;
+                    if (f.size() < 2 || f.size() % 2) return fail("parameter '" + name + "': a sampled spectrum is a list of (wavelength, value) pairs");
+                    float c[3]; pbrt_hip_host_sampled_rgb(f.data(), f.size() / 2, c);
+                    rgb.assign(c, c + 3);
+                }
+                ps.floats[name] = rgb;
             } else return fail("unknown parameter type '" + type + "'");
         }
         return true;

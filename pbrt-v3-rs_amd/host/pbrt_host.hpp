@@ -111,6 +111,7 @@ class Api {
     std::vector<std::string> warnings;
     std::string error;
 
+    void warn(const std::string& w);   // also used by the parser (unreadable SPD files leave a black spectrum with a warning, paramset/mod.rs:296-299)
   private:
     bool check_only_ = false;
     bool world_block_ = false;
@@ -131,7 +132,6 @@ class Api {
     std::map<std::string, uint64_t> object_tris_;
     std::string current_object_;                // "" outside ObjectBegin/ObjectEnd
     uint64_t n_instances_ = 0;
-    void warn(const std::string& w);
     bool verify_options(const char* func);
     bool verify_world(const char* func);
     void concat(const Xform& t);

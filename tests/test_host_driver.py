@@ -63,7 +63,8 @@ def test_check_mode_crop_and_outfile(tmp_path):
     ('WorldBegin\nLightSource "infinite" "string mapname" "sky.jpg"\nWorldEnd\n', "mapname"),
     ('WorldBegin\nTexture "c" "color" "ptex"\nMaterial "matte" "texture Kd" "c"\n'
      'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "ptex"),
-    ('WorldBegin\nLightSource "point" "blackbody I" [6500 1]\nWorldEnd\n', "spectral type"),
+    ('WorldBegin\nLightSource "point" "blackbody I" [6500]\nWorldEnd\n', "(temperature, scale) pairs"),
+    ('WorldBegin\nLightSource "point" "spectrum I" [400 1 500]\nWorldEnd\n', "(wavelength, value) pairs"),
     ('Frobnicate 1 2 3\n', "unknown directive"),
     ('Translate 1 2\nWorldBegin\n', "expected a number"),
     ('Film "image" "float cropwindow" [0 1 0]\nWorldBegin\nWorldEnd\n', "cropwindow"),
@@ -187,3 +188,49 @@ def test_filter_tables(host):
     assert np.allclose(ts, ref, rtol=1e-4, atol=2e-6)
     with pytest.raises(Exception):
         host.film_filter(9, 10, 6, (1, 1))
+
+
+def test_spectral_parameter_types(tmp_path):
+    """`blackbody`, inline `spectrum` pairs and SPD files become RGB as the reference's ParamSet makes them (paramset/mod.rs:236-315); an unreadable SPD file is a black
+    spectrum with a warning, not an error."""
+    import ctypes as C
+    import numpy as np
+    import pbrt_hip
+    L = pbrt_hip.default_binding().lib
+    fp = C.POINTER(C.c_float)
+    L.pbrt_hip_host_blackbody_rgb.argtypes = [C.c_float, C.c_float, fp]
+    L.pbrt_hip_host_sampled_rgb.argtypes = [fp, C.c_size_t, fp]
+    L.pbrt_hip_host_sampled_rgb.restype = C.c_int
+
+    def blackbody(t, sc):
+        out = np.zeros(3, np.float32); L.pbrt_hip_host_blackbody_rgb(t, sc, out.ctypes.data_as(fp)); return out
+
+    def sampled(pairs):
+        a = np.ascontiguousarray(pairs, np.float32).reshape(-1); out = np.zeros(3, np.float32)
+        assert L.pbrt_hip_host_sampled_rgb(a.ctypes.data_as(fp), len(a) // 2, out.ctypes.data_as(fp)) == 0
+        return out
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "blackbody_rgb.json")))  # restated in numpy f32 from the reference's tables
+    assert np.allclose(blackbody(3000.0, 1.5), want["3000x1.5"], rtol=3e-6) and np.allclose(blackbody(4500.0, 1.5), want["4500x1.5"], rtol=3e-6)
+    assert np.array_equal(blackbody(0.0, 1.0), np.zeros(3, np.float32))           # t <= 0: a black emitter (spectrum/common.rs:362-364)
+    assert np.allclose(blackbody(6500.0, 2.0), 2.0 * blackbody(6500.0, 1.0), rtol=1e-6)
+    r, g, b = blackbody(6500.0, 1.0); assert abs(r - g) < 0.12 * g and abs(b - g) < 0.12 * g and r > b * 0.9   # near D65: close to neutral in these primaries
+    r, g, b = blackbody(2000.0, 1.0); assert r > 2 * g > 4 * b                     # a candle: red >> green >> blue
+    lum = lambda c: 0.212671 * c[0] + 0.715160 * c[1] + 0.072169 * c[2]
+    flat = sampled([[360, 1], [830, 1]])
+    assert abs(lum(flat) - 470.0 / 471.0) < 2e-5                                   # Y of the constant spectrum: sum(y-bar) * (830 - 360) / (CIE_Y_INTEGRAL * 471) (rgb_spectrum.rs:97)
+    assert np.array_equal(sampled([[500, 1]]), flat) and np.array_equal(sampled([[360, 1], [600, 1], [830, 1]]), flat)
+    assert np.allclose(sampled([[400, 3], [700, 3]]), 3.0 * flat, rtol=1e-5)       # clamped outside the samples, linear in the values
+    ramp = sampled([[360, 0], [830, 1]]); rev = sampled([[360, 1], [830, 0]])
+    assert np.allclose(ramp + rev, flat, atol=2e-5)                               # piecewise-linear interpolation is linear in the spectrum
+    assert np.array_equal(sampled([[830, 1], [360, 0]]), ramp)                     # unsorted input is sorted first
+    (tmp_path / "cu.spd").write_text("# wavelength value\n400 0.2\n500 0.4  # trailing comment\n600 0.9\n700 1.0\n")
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+    p = tmp_path / "s.pbrt"
+    p.write_text('WorldBegin\nLightSource "distant" "blackbody L" [3000 1.5]\nLightSource "point" "spectrum I" [400 1 700 2]\n'
+                 'Material "metal" "spectrum eta" "cu.spd" "spectrum k" [400 3 700 4]\n' + tri +
+                 'Material "matte" "spectrum Kd" "missing.spd"\n' + tri + 'WorldEnd\n')
+    r = run(["--check", str(p)])
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["lights"] == 2 and info["triangles"] == 2
+    assert "Unable to read SPD file 'missing.spd'" in r.stderr

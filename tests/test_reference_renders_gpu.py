@@ -38,3 +38,49 @@ def test_device_film_equals_the_oracle_film_on_the_reference_scenes(host, name):
     for f in ("camera_rays", "regular_rays", "shadow_rays"):
         assert getattr(gst, f) == getattr(ost, f), f
     prod.close(); orc.close()
+
+
+# ---- the same scenes as scene-description TEXT through the front end (pbrt_hip_render): parser, CTM / attribute stacks, `blackbody` parameters, ObjectBegin / ObjectInstance,
+# the orthographic camera's directive order.  The text is written here from the numbers of tests/reference_scenes.py (only the Integrator line differs from the reference's files:
+# the hot path is the path integrator, at maxdepth 1 it is Whitted's direct term for these scenes).
+def _nums(a):
+    return " ".join(repr(float(v)) for v in np.asarray(a, np.float32).ravel())
+
+
+CUBE_TXT = f'Shape "trianglemesh" "point P" [{_nums(R.CUBE_P)}] "float st" [{_nums(R.CUBE_ST)}] "integer indices" [{" ".join(str(int(i)) for i in R.CUBE_IDX)}]'
+
+
+def _floor_txt(tex1):
+    return (f'AttributeBegin\n Translate 0 0 -1\n Texture "checks" "spectrum" "checkerboard" "float uscale" [24] "float vscale" [24] "rgb tex1" [{tex1} {tex1} {tex1}] "rgb tex2" [.8 .8 .8]\n'
+            f' Material "matte" "texture Kd" "checks"\n Shape "trianglemesh" "point P" [{_nums(R.quad(20.0))}] "float st" [{_nums(R.QUAD_ST)}] "integer indices" [0 1 2 0 2 3]\nAttributeEnd\n')
+
+
+def _head(lookat, camera, xres, yres, spp, extra=""):
+    return (f'LookAt {lookat}\n{extra}Camera {camera}\nSampler "halton" "integer pixelsamples" {spp}\nIntegrator "path" "integer maxdepth" 1\n'
+            f'Film "image" "string filename" "out.pfm" "integer xresolution" [{xres}] "integer yresolution" [{yres}]\nWorldBegin\n')
+
+
+SKY_AND_SUN = 'LightSource "infinite" "rgb L" [.4 .45 .5]\nLightSource "distant" "point from" [ -30 40 100 ] "blackbody L" [3000 1.5]\n'
+RED_CUBE = f'AttributeBegin\n Rotate 45 0 0 1\n Material "matte" "rgb Kd" [.2 .01 .01]\n {CUBE_TXT}\nAttributeEnd\n'
+SCENE_TEXTS = {
+    "lights_distant": (lambda spp: _head("0 5 3  0 0 0  0 0 1", '"perspective" "float fov" 90', 400, 400, spp) +
+                       'LightSource "distant" "point from" [ -5 0 5 ] "point to" [0 0 0] "blackbody L" [4500 1.5]\n' + RED_CUBE + _floor_txt(.3) + "WorldEnd\n", 32, False),
+    "cameras_orthographic": (lambda spp: _head("0 10 10  0 0 0  0 0 1", '"orthographic"', 400, 400, spp) + SKY_AND_SUN + "Scale 0.25 0.25 0.25\n" + RED_CUBE + _floor_txt(.1) + "WorldEnd\n",
+                             64, True),
+    "objects_instances": (lambda spp: _head("0 7 15  0 0 0  0 0 1", '"perspective" "float fov" 45', 400, 400, spp, extra="Translate 0 -1 0\n") + SKY_AND_SUN +
+                          f'Material "matte" "rgb Kd" [.8 .1 .01]\nObjectBegin "cube"\n {CUBE_TXT}\nObjectEnd\n' +
+                          "".join(f'AttributeBegin\n{"" if k == 0 else f" Rotate {36 * k} 0 0 1" + chr(10)} Translate 0 5 0\n Rotate 45 0 0 1\n ObjectInstance "cube"\nAttributeEnd\n' for k in range(10)) +
+                          _floor_txt(.1) + "WorldEnd\n", 64, True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENE_TEXTS))
+def test_front_end_renders_the_references_scene_text_like_the_reference(tmp_path, name):
+    import subprocess
+    import driver_scene as ds
+    make, spp, noisy = SCENE_TEXTS[name]
+    (tmp_path / "scene.pbrt").write_text(make(spp))
+    r = subprocess.run([ds.RENDER_BIN, "--quiet", str(tmp_path / "scene.pbrt")], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    img = ds.read_pfm(str(tmp_path / "out.pfm"))
+    check_against_reference(img, dict(render=name), noisy)
