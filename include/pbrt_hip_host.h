@@ -57,6 +57,8 @@ void pbrt_hip_host_spot(const float ctm_m[16], const float ctm_minv[16], const f
  * core/src/spectrum/common.rs:315-398, rgb_spectrum.rs:82-103): `"blackbody L" [T scale]` and `"spectrum name" [lambda value ...]` (or the pairs of an SPD file). */
 void pbrt_hip_host_blackbody_rgb(float temperature_kelvin, float scale, float out_rgb[3]);
 int pbrt_hip_host_sampled_rgb(const float* lambda_value_pairs, size_t n_samples, float out_rgb[3]);
+/* `Material "metal"` without `eta` / `k`: the reference's copper spectra as RGB (materials/src/metal.rs:136-147) */
+void pbrt_hip_host_copper_rgb(float out_eta[3], float out_k[3]);
 
 /* Synthetic measurement scene of BASELINE.md §3: n_tris random triangles from PCG32 stream `seed`
  * (core/src/rng.rs semantics). out_P: 9 floats per triangle, out_idx: 3 per triangle (unshared vertices). */

@@ -301,6 +301,7 @@ extern "C" int pbrt_hip_host_build_bvh(const float* P, const uint32_t* idx, uint
 // ParamSet::add_blackbody_spectrum / add_sampled_spectrum (core/src/paramset/mod.rs:236-262), blackbody / blackbody_normalized / interpolate_spectrum_samples
 // (core/src/spectrum/common.rs:315-398), RGBSpectrum::from(&Vec<Sample>) (core/src/spectrum/rgb_spectrum.rs:82-103), all in f32 as the reference computes them.
 #include "cie_table.inc"
+#include "copper_table.inc"
 #include <cmath>
 #include <vector>
 namespace {
@@ -364,4 +365,11 @@ extern "C" int pbrt_hip_host_sampled_rgb(const float* lambda_value_pairs, size_t
     if (n_samples == 1) { s.push_back(s[0]); }  // a single sample is a constant spectrum (both clamps of interpolate_spectrum_samples return it)
     samples_to_rgb(s, out_rgb);
     return 0;
+}
+
+// MetalMaterial's defaults (materials/src/metal.rs:136-147): RGB of the copper n and k spectra
+extern "C" void pbrt_hip_host_copper_rgb(float out_eta[3], float out_k[3]) {
+    std::vector<std::pair<float, float>> n(56), k(56);
+    for (int i = 0; i < 56; i++) { n[i] = {kCopper[i][0], kCopper[i][1]}; k[i] = {kCopper[i][0], kCopper[i][2]}; }
+    samples_to_rgb(n, out_eta); samples_to_rgb(k, out_k);
 }

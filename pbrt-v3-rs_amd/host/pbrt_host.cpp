@@ -579,10 +579,9 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
         a3 = spectrum_tex("Kr", one); b3 = spectrum_tex("Kt", one); f0 = float_tex("uroughness", 0.0f); f1 = float_tex("vroughness", 0.0f); f2 = eta_of();
         put3(a3); put3(b3); kv.push_back(f0); kv.push_back(f1); kv.push_back(f2);
     } else if (t == "metal") {
-        const bool eta_given = m.params.floats.count("eta") || !m.params.find_one_texture("eta").empty(), k_given = m.params.floats.count("k") || !m.params.find_one_texture("k").empty();
-        if (!(eta_given && k_given) && error.empty())
-            error = "Material \"metal\": give 'rgb eta' and 'rgb k' (or textures for them; the reference's copper default and named spectra need its spectral tables, which this host does not carry)";
-        a3 = spectrum_tex("eta", one); b3 = spectrum_tex("k", one); uv_rough(0.01f, f0, f1);
+        std::array<float, 3> cu_n, cu_k;   // the defaults are copper's measured n and k (metal.rs:136-147)
+        pbrt_hip_host_copper_rgb(cu_n.data(), cu_k.data());
+        a3 = spectrum_tex("eta", cu_n); b3 = spectrum_tex("k", cu_k); uv_rough(0.01f, f0, f1);
         put3(a3); put3(b3); kv.push_back(f0); kv.push_back(f1);
     } else if (t == "uber") {
         a3 = spectrum_tex("Kd", quarter); b3 = spectrum_tex("Ks", quarter); c3 = spectrum_tex("Kr", zero); d3 = spectrum_tex("Kt", zero); e3 = spectrum_tex("opacity", one);

@@ -51,7 +51,6 @@ def test_check_mode_crop_and_outfile(tmp_path):
 @pytest.mark.parametrize("text,needle", [
     ('WorldBegin\nShape "sphere" "float radius" 1\nWorldEnd\n', 'Shape "sphere" is outside the hot-path scope'),
     ('WorldBegin\nMaterial "kdsubsurface"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', 'Material "kdsubsurface"'),
-    ('WorldBegin\nMaterial "metal"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "give 'rgb eta' and 'rgb k'"),
     ('WorldBegin\nTexture "b" "float" "ptex"\nMaterial "plastic" "texture bumpmap" "b"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "bumpmap"),
     ('WorldBegin\nMakeNamedMedium "fog" "string type" "homogeneous"\nWorldEnd\n', "directive 'MakeNamedMedium'"),
     ('WorldBegin\nObjectBegin "a"\nAreaLightSource "diffuse"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nObjectEnd\nWorldEnd\n',
@@ -234,3 +233,10 @@ def test_spectral_parameter_types(tmp_path):
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["lights"] == 2 and info["triangles"] == 2
     assert "Unable to read SPD file 'missing.spd'" in r.stderr
+    # Material "metal" without eta / k is copper (metal.rs:136-147): RGB of its measured n and k, close to the values every pbrt scene quotes for Cu
+    a = np.zeros(3, np.float32); b = np.zeros(3, np.float32)
+    L.pbrt_hip_host_copper_rgb(a.ctypes.data_as(fp), b.ctypes.data_as(fp))
+    assert np.allclose(a, (0.200, 0.922, 1.100), atol=2e-3) and np.allclose(b, (3.905, 2.448, 2.138), atol=2e-3)
+    p.write_text('WorldBegin\nLightSource "infinite"\nMaterial "metal"\n' + tri + 'WorldEnd\n')
+    r = run(["--check", "--quiet", str(p)])
+    assert r.returncode == 0, r.stderr
