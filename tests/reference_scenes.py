@@ -234,6 +234,28 @@ def materials_bump(s, host, spp=64, res=400):
     return dict(max_depth=1, render="materials_bump", noisy=True)
 
 
+def samplers_scene(s, host, sampler, spp=16):
+    """scenes/samplers/{halton,sobol}.pbrt -> renders/samplers/{halton,sobol}.png (64 x 64, 16 spp): a matte SPHERE (oracle only) seen through a wide thin lens
+    (lensradius 0.1, focaldistance 1, the sphere at z = 4: heavily defocused), sky 0.8 + a distant light.  No LookAt: the camera sits at the origin looking down +z."""
+    from test_oracle_sphere import add_sphere
+    s.add_light_infinite((0.8, 0.8, 0.8))
+    s.add_light_distant((1.0, 1.0, 1.0), host.distant_direction(_ident()[0], (-1.0, 1.0, -1.0), (0.0, 0.0, 0.0)))
+    m = s.add_material_matte((0.2, 0.2, 0.2))
+    add_sphere(s, ctm(host, host.translate((0, 0, 4))), 1.0, material=m)
+    ident = _ident()
+    s.set_camera_perspective(host.perspective_raster_to_camera(35.0, 64, 64), ident[1], lens_radius=0.1, focal_distance=1.0)
+    cb, table, sb = host.film_box(64, 64)
+    s.set_film(64, 64, cb, (0.5, 0.5), table)
+    if sampler == "sobol":
+        z = np.load(os.path.join(HERE, "golden", "sobol_subset.npz"))
+        s.set_sobol_tables(z["m32"], z["vdc"], z["vdc_inv"])
+        s.set_sampler(1, spp, sb)
+    else:
+        s.set_sampler(0, spp, sb)
+    s.build_accel(0, 4)
+    return dict(max_depth=1, render="samplers_" + sampler)
+
+
 def compare(rgb_linear, ref_u8, block=8):
     """-> dict: mean |delta| in 8-bit levels per pixel, fraction of pixels with a channel off by more than 12 levels, and the same two over block x block means (sampling
     noise averages out of those: the path integrator's estimator differs from Whitted's where a scene has an area-like light or several lights)"""

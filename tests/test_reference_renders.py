@@ -78,3 +78,29 @@ def test_oracle_equals_the_references_render_of_the_bump_mapped_sphere():
     bm = lambda a: a.reshape(100, 4, 100, 4).mean((1, 3))[25:75, 30:70]
     gx = lambda a: np.diff(bm(a), axis=1).ravel()
     assert np.corrcoef(gx(ref), gx(mine))[0, 1] > 0.9
+
+
+def test_sampler_scenes_background_masks_equal_the_references_renders():
+    """scenes/samplers/{halton,sobol}.pbrt (64 x 64, 16 spp): a matte Sphere (oracle only) seen through a wide thin lens, so every pixel of the blur ring depends on where
+    each of its 16 film + lens samples falls.  Whitted and the path integrator draw different dimensions for the lights, but the camera sample (dimensions 0-4) is the same:
+    the set of pixels in which ALL 16 rays miss the sphere (pure sky, 8-bit 231) is a function of the sampler's first five dimensions, the pixel-to-sample mapping, the thin lens and
+    the sphere alone.  The oracle's set equals the reference's in 99.6 - 99.8 % of the pixels with its own sampler and in only 97 % with the other one (so the comparison
+    tells Halton from Sobol); scaling the lens by 2 % already triples the disagreement.  The residue (7 pixels with Halton, 16 with Sobol) is one-sided — the oracle finds ONE sphere
+    hit among the 16 rays where the reference's render shows none, always a ray from the outer lens that meets the sphere 0.1 - 7 % inside its rim — and is not explained: the
+    reference's sphere / BVH code reads the same as the restatement, so either the committed PNG predates a change in the reference or a difference remains that the reading has
+    not found.  It is recorded here rather than tuned away."""
+    bg8 = R.to_8bit(np.array([0.8, 0.8, 0.8], np.float32))
+    host = pbrt_hip.Host()
+    masks = {}
+    for smp in ("halton", "sobol"):
+        with pbrt_hip.Scene(oracle_binding()) as s:
+            info = R.samplers_scene(s, host, smp)
+            xyz, wt, _ = s.render_path(max_depth=1)
+            masks[smp] = np.all(np.abs(s.film_to_rgb(xyz, wt) - 0.8) < 1e-5, -1)
+    ref = {smp: np.all(R.reference_render("samplers_" + smp) == bg8, -1) for smp in ("halton", "sobol")}
+    for smp, other in (("halton", "sobol"), ("sobol", "halton")):
+        assert 0.15 < ref[smp].mean() < 0.25
+        same, cross = int((masks[smp] != ref[smp]).sum()), int((masks[smp] != ref[other]).sum())
+        assert same <= 20, (smp, same)                 # <= 0.5 % of 4096 pixels
+        assert int((masks[smp] & ~ref[smp]).sum()) == 0  # never a hit in the reference that the oracle lacks
+        assert cross >= 80, (smp, cross)               # the other sampler's pattern is a different one
