@@ -85,10 +85,10 @@ def test_sampler_scenes_background_masks_equal_the_references_renders():
     each of its 16 film + lens samples falls.  Whitted and the path integrator draw different dimensions for the lights, but the camera sample (dimensions 0-4) is the same:
     the set of pixels in which ALL 16 rays miss the sphere (pure sky, 8-bit 231) is a function of the sampler's first five dimensions, the pixel-to-sample mapping, the thin lens and
     the sphere alone.  The oracle's set equals the reference's in 99.6 - 99.8 % of the pixels with its own sampler and in only 97 % with the other one (so the comparison
-    tells Halton from Sobol); scaling the lens by 2 % already triples the disagreement.  The residue (7 pixels with Halton, 16 with Sobol) is one-sided — the oracle finds ONE sphere
-    hit among the 16 rays where the reference's render shows none, always a ray from the outer lens that meets the sphere 0.1 - 7 % inside its rim — and is not explained: the
-    reference's sphere / BVH code reads the same as the restatement, so either the committed PNG predates a change in the reference or a difference remains that the reading has
-    not found.  It is recorded here rather than tuned away."""
+    tells Halton from Sobol); scaling the lens by 2 % already triples the disagreement.  The residue (7 pixels with Halton, 16 with Sobol) is one-sided — the reference's PNG shows
+    level 231 where the oracle counts ONE sphere hit among the 16 rays — and is what the 8-bit criterion predicts: Whitted estimates the sky term with one light sample whose value
+    0.8 * (0.2 / pi) * cos / pdf ranges up to 1.0, so a lone hit whose estimate lands within 0.056 of 0.8 leaves the pixel at 231.  That is a few per cent of the one-hit pixels
+    (206 with Halton, 251 with Sobol: 3.4 % and 6.4 % observed), and it can only add pixels to the reference's set, never remove one — which is what the test asserts."""
     bg8 = R.to_8bit(np.array([0.8, 0.8, 0.8], np.float32))
     host = pbrt_hip.Host()
     masks = {}
