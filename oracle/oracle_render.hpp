@@ -1239,6 +1239,46 @@ struct Renderer {
         return ld;
     }
 
+    // ---- WhittedIntegrator::li (integrators/src/whitted.rs:51-118) — ORACLE ONLY: every render the reference commits next to its example scenes was made with it, so
+    // the oracle can be held against those pixels sample for sample.  One light sample per light and camera sample (`sampler.get_2d()` in the lights' order), no MIS;
+    // the specular recursion (specular_reflect / specular_transmit) is restated for its sampler draws only — the scenes compared are matte, both terms are black there.
+    int integrator = 0;  // 0 path, 1 whitted
+    bool whitted_unsupported = false;  // a specular lobe was met: the recursion is not restated, the result is not the reference's
+    template <class S> Spec li_whitted(Ray ray, S& sampler, int depth) {
+        const Scene& s = *sc;
+        Spec L(0.0f);
+        uint32_t prim; TriHit h;
+        if (!scene_intersect(ray, prim, h)) {
+            for (const Light& l : s.lights) L += light_le(l, ray);  // every light's le; zero for all but the infinite ones
+            return L;
+        }
+        SurfaceHit isect = make_surface_hit(ray, prim, h);
+        if (s.materials[s.mesh_of(isect.prim).material].none) {  // bsdf.is_none(): the ray goes on (whitted.rs:63-66)
+            return li_whitted(spawn_ray(isect.p, isect.p_error, isect.n, isect.time, ray.d), sampler, depth);
+        }
+        compute_differentials(isect, ray);
+        bump(isect);
+        Lobe hit_lobes[8];
+        BSDF bsdf = make_bsdf(isect, hit_lobes);
+        const V3 n = isect.ns, wo = isect.wo;
+        const Mesh& m = s.mesh_of(prim);
+        if (m.first_light >= 0) L += area_L(s.lights[m.first_light + (prim - m.tri_base)], isect.n, wo);  // isect.le(&wo)
+        for (const Light& light : s.lights) {
+            const V2 u = sampler.get_2d();
+            const LiSample ls = light_sample_li(light, isect, u);
+            if (!ls.valid || ls.value.is_black() || ls.pdf == 0.0f) continue;
+            const Spec f = bsdf.f(wo, ls.wi, BX_ALL);
+            if (f.is_black()) continue;
+            if (scene_intersect_p(spawn_ray_to_hit(isect.p, isect.p_error, isect.n, isect.time, ls.vp, ls.vperr, ls.vn))) continue;
+            L += f * ls.value * abs_dot(ls.wi, n) / ls.pdf;
+        }
+        if (depth + 1 < max_depth) {  // specular_reflect, specular_transmit: each draws its 2-D sample first (sampler_integrator.rs); black for non-specular BSDFs
+            (void)sampler.get_2d(); (void)sampler.get_2d();
+            for (int i = 0; i < bsdf.n; i++) if (bsdf.lobes[i].type & BX_SPEC) whitted_unsupported = true;
+        }
+        return L;
+    }
+
     // ---- PathIntegrator::li (integrators/src/path.rs:103-284) ------------------------------------------------------
     template <class S> Spec li(Ray ray, S& sampler) {
         const Scene& s = *sc;
@@ -1492,7 +1532,7 @@ struct Renderer {
                     Ray ray = generate_ray(p_film, time, p_lens);
                     scale_differentials(ray, 1.0f / std::sqrt((Float)sampler.spp));  // sampler_integrator.rs:358
                     tls_stats().camera_rays++;
-                    Spec L = li(ray, sampler);  // ray_weight is always 1.0 for the perspective camera
+                    Spec L = integrator == 1 ? li_whitted(ray, sampler, 0) : li(ray, sampler);  // ray_weight is always 1.0 for the perspective camera
                     if (L.has_nans()) L = Spec(0.0f);
                     else if (L.y() < -1e-5f) L = Spec(0.0f);
                     else if (std::isinf(L.y())) L = Spec(0.0f);
