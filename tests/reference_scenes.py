@@ -140,10 +140,11 @@ def lights_distant(s, host, spp=32, res=400):
 
 
 def _sky_and_sun(s, host, t=None):
-    """LightSource "infinite" "rgb L" [.4 .45 .5] + LightSource "distant" "point from" [-30 40 100] "blackbody L" [3000 1.5] under the CTM `t`"""
+    """LightSource "infinite" "rgb L" [.4 .45 .5] + LightSource "distant" "point from" [-30 40 100] "blackbody L" [3000 1.5] under the CTM `t`; no "point to" in the
+    files: the default is (0, 0, 1) (distant.rs:180-181), so the light points along from - to = (-30, 40, 99)"""
     t = t if t is not None else _ident()
     s.add_light_infinite((0.4, 0.45, 0.5), t[0], t[1])
-    s.add_light_distant(blackbody("3000x1.5"), host.distant_direction(t[0], (-30.0, 40.0, 100.0), (0.0, 0.0, 0.0)))
+    s.add_light_distant(blackbody("3000x1.5"), host.distant_direction(t[0], (-30.0, 40.0, 100.0), (0.0, 0.0, 1.0)))
 
 
 def cameras_perspective(s, host, spp=64, res=400):
@@ -222,7 +223,7 @@ def materials_bump(s, host, spp=64, res=400):
     """scenes/materials/bump.pbrt -> renders/materials/bump.png: a matte SPHERE (oracle only) whose bump map is the `windy` texture, above a matte floor"""
     from test_oracle_sphere import add_sphere
     s.add_light_infinite((0.8, 0.9, 1.0))
-    s.add_light_distant(blackbody("3000x1.5"), host.distant_direction(_ident()[0], (-30.0, 40.0, 100.0), (0.0, 0.0, 0.0)))
+    s.add_light_distant(blackbody("3000x1.5"), host.distant_direction(_ident()[0], (-30.0, 40.0, 100.0), (0.0, 0.0, 1.0)))
     bump = s.add_texture_windy()
     m = s.add_material_matte((0.5, 0.5, 0.5))
     s.set_material_bump(m, bump)
@@ -239,7 +240,7 @@ def samplers_scene(s, host, sampler, spp=16):
     (lensradius 0.1, focaldistance 1, the sphere at z = 4: heavily defocused), sky 0.8 + a distant light.  No LookAt: the camera sits at the origin looking down +z."""
     from test_oracle_sphere import add_sphere
     s.add_light_infinite((0.8, 0.8, 0.8))
-    s.add_light_distant((1.0, 1.0, 1.0), host.distant_direction(_ident()[0], (-1.0, 1.0, -1.0), (0.0, 0.0, 0.0)))
+    s.add_light_distant((1.0, 1.0, 1.0), host.distant_direction(_ident()[0], (-1.0, 1.0, -1.0), (0.0, 0.0, 1.0)))
     m = s.add_material_matte((0.2, 0.2, 0.2))
     add_sphere(s, ctm(host, host.translate((0, 0, 4))), 1.0, material=m)
     ident = _ident()
