@@ -1260,6 +1260,21 @@ struct Renderer {
         bump(isect);
         Lobe hit_lobes[8];
         BSDF bsdf = make_bsdf(isect, hit_lobes);
+        // Whitted asks the materials for allow_multiple_lobes = false: smooth glass is then SpecularReflection(Kr, FresnelDielectric(1, eta)) + SpecularTransmission(Kt, 1, eta),
+        // not the one FresnelSpecular lobe the path integrator gets (glass.rs:112-129)
+        for (int i = 0; i < bsdf.n; i++) {
+            if (bsdf.lobes[i].kind != LK_FRESNEL_SPEC) continue;
+            Lobe split[8]; int k = 0;
+            for (int j = 0; j < bsdf.n; j++) {
+                if (j != i) { split[k++] = bsdf.lobes[j]; continue; }
+                const Lobe& g = bsdf.lobes[j];
+                if (!g.r.is_black()) { Lobe l; l.kind = LK_SPEC_R; l.type = BX_REFL | BX_SPEC; l.fresnel = FR_DIEL; l.eta_a = g.eta_a; l.eta_b = g.eta_b; l.r = g.r; split[k++] = l; }
+                if (!g.t.is_black()) { Lobe l; l.kind = LK_SPEC_T; l.type = BX_TRANS | BX_SPEC; l.fresnel = FR_DIEL; l.eta_a = g.eta_a; l.eta_b = g.eta_b; l.t = g.t; split[k++] = l; }
+            }
+            for (int j = 0; j < k; j++) hit_lobes[j] = split[j];
+            bsdf.lobes = hit_lobes; bsdf.n = k;
+            break;
+        }
         const V3 n = isect.ns, wo = isect.wo;
         const Mesh& m = s.mesh_of(prim);
         if (m.first_light >= 0) L += area_L(s.lights[m.first_light + (prim - m.tri_base)], isect.n, wo);  // isect.le(&wo)
@@ -1272,11 +1287,46 @@ struct Renderer {
             if (scene_intersect_p(spawn_ray_to_hit(isect.p, isect.p_error, isect.n, isect.time, ls.vp, ls.vperr, ls.vn))) continue;
             L += f * ls.value * abs_dot(ls.wi, n) / ls.pdf;
         }
-        if (depth + 1 < max_depth) {  // specular_reflect, specular_transmit: each draws its 2-D sample first (sampler_integrator.rs); black for non-specular BSDFs
-            (void)sampler.get_2d(); (void)sampler.get_2d();
-            for (int i = 0; i < bsdf.n; i++) if (bsdf.lobes[i].type & BX_SPEC) whitted_unsupported = true;
+        if (depth + 1 < max_depth) {  // whitted.rs:108-113
+            const Spec refl = whitted_specular(ray, isect, bsdf, sampler, depth, false);
+            const Spec trans = whitted_specular(ray, isect, bsdf, sampler, depth, true);
+            L += refl + trans;
         }
         return L;
+    }
+    // SamplerIntegrator::specular_reflect / specular_transmit (core/src/integrator/sampler_integrator.rs:79-127, 137-238): the mirror / refracted ray carries
+    // differentials derived from the surface's dndu / dndv, so that textures seen in a reflection are filtered as the reference filters them
+    template <class S> Spec whitted_specular(const Ray& ray, const SurfaceHit& isect, const BSDF& bsdf, S& sampler, int depth, bool transmit) {
+        const V3 wo = isect.wo;
+        const V2 u = sampler.get_2d();
+        Spec f; Float pdf = 0.0f; V3 wi; int st = 0;
+        bsdf.sample_f(wo, u, f, pdf, wi, (transmit ? BX_TRANS : BX_REFL) | BX_SPEC, &st);
+        V3 ns = isect.ns;
+        if (!(pdf > 0.0f && !f.is_black() && abs_dot(wi, ns) != 0.0f)) return Spec(0.0f);
+        Ray rd = spawn_ray(isect.p, isect.p_error, isect.n, isect.time, wi);
+        if (ray.has_diff) {
+            rd.has_diff = true;
+            rd.rx_o = isect.p + isect.dpdx; rd.ry_o = isect.p + isect.dpdy;
+            V3 dndx = isect.dndu_s * isect.dudx + isect.dndv_s * isect.dvdx;
+            V3 dndy = isect.dndu_s * isect.dudy + isect.dndv_s * isect.dvdy;
+            if (!transmit) {
+                const V3 dwodx = -ray.rx_d - wo, dwody = -ray.ry_d - wo;
+                const Float ddndx = dot(dwodx, ns) + dot(wo, dndx), ddndy = dot(dwody, ns) + dot(wo, dndy);
+                rd.rx_d = wi - dwodx + 2.0f * (dot(wo, ns) * dndx + ddndx * ns);
+                rd.ry_d = wi - dwody + 2.0f * (dot(wo, ns) * dndy + ddndy * ns);
+            } else {
+                Float eta = 1.0f / bsdf.eta;  // the BSDF's eta: 1 for glass in this reference (BSDF::new(.., None), glass.rs:109)
+                if (dot(wo, ns) < 0.0f) { eta = 1.0f / eta; ns = -ns; dndx = -dndx; dndy = -dndy; }
+                const V3 dwodx = -ray.rx_d - wo, dwody = -ray.ry_d - wo;
+                const Float ddndx = dot(dwodx, ns) + dot(wo, dndx), ddndy = dot(dwody, ns) + dot(wo, dndy);
+                const Float mu = eta * dot(wo, ns) - abs_dot(wi, ns);
+                const Float dmudx = (eta - (eta * eta * dot(wo, ns)) / abs_dot(wi, ns)) * ddndx;
+                const Float dmudy = (eta - (eta * eta * dot(wo, ns)) / abs_dot(wi, ns)) * ddndy;
+                rd.rx_d = wi - eta * dwodx + (mu * dndx + dmudx * ns);
+                rd.ry_d = wi - eta * dwody + (mu * dndy + dmudy * ns);
+            }
+        }
+        return f * li_whitted(rd, sampler, depth + 1) * abs_dot(wi, ns) / pdf;
     }
 
     // ---- PathIntegrator::li (integrators/src/path.rs:103-284) ------------------------------------------------------

@@ -559,8 +559,18 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::array<float, 3> a3 = zero, b3 = zero, c3 = zero, d3 = zero, e3 = zero;
     float f0 = 0, f1 = 0, f2 = 0;
     const std::string& t = m.type;
-    auto eta_of = [&]() {  // `eta`, else `index`, else 1.5 (glass.rs:124-127, uber.rs:201-204)
-        if (m.params.floats.count("eta") || !m.params.find_one_texture("eta").empty()) return float_tex("eta", 1.5f);
+    // Quirk B12 (glass.rs:158-161, uber.rs:201-204): the reference asks `tp.get_float_texture("eta")`, which is a lookup in the table of NAMED float textures — one
+    // declared as `Texture "eta" "float" ...` — and not a parameter look-up: the `"float eta" 2` that pbrt-v3 scenes (and the reference's own depth-of-field.pbrt) write is never
+    // read.  Without such a texture the index of refraction is the "index" parameter, default 1.5.  Its render of depth-of-field.pbrt shows eta 1.5 spheres, pixel for pixel.
+    auto eta_of = [&]() {
+        auto named = gs_.float_textures.find("eta");
+        if (named != gs_.float_textures.end()) return named->second;   // a constant float texture that happens to be called "eta"
+        if (gs_.device_textures.count("eta") || gs_.unsupported_textures.count("eta")) {
+            if (error.empty()) error = "Material \"" + m.type + "\": the float texture named \"eta\" would set the index of refraction per hit (glass.rs:158), which the library does not evaluate";
+            return 1.5f;
+        }
+        if (m.params.floats.count("eta") || !m.params.find_one_texture("eta").empty())
+            warn("Material \"" + m.type + "\": the reference does not read the parameter \"eta\" (it looks up a float texture NAMED \"eta\", glass.rs:158 / uber.rs:201); using \"index\"");
         return float_tex("index", 1.5f);
     };
     auto uv_rough = [&](float dflt, float& u, float& v) {  // `uroughness` / `vroughness` fall back to `roughness` (metal.rs:69-76, uber.rs:148-155)

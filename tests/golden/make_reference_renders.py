@@ -10,7 +10,7 @@ sys.path.insert(0, HERE)
 from make_sphere_mask import read_png  # noqa: E402
 
 NAMES = ["shapes/triangles-alpha-mask", "cameras/perspective", "cameras/orthographic", "cameras/environment", "lights/point", "lights/distant", "lights/spot",
-         "lights/infinite-no-map", "lights/goniometric", "objects/instances", "materials/bump", "samplers/halton", "samplers/sobol"]
+         "lights/infinite-no-map", "lights/goniometric", "objects/instances", "materials/bump", "samplers/halton", "samplers/sobol", "cameras/depth-of-field"]
 if __name__ == "__main__":
     os.makedirs(os.path.join(HERE, "ref_renders"), exist_ok=True)
     for n in NAMES:

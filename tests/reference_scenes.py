@@ -257,6 +257,28 @@ def samplers_scene(s, host, sampler, spp=16):
     return dict(max_depth=1, render="samplers_" + sampler)
 
 
+def cameras_depth_of_field(s, host, spp=128, crop=(0.0, 1.0, 0.0, 1.0)):
+    """scenes/cameras/depth-of-field.pbrt -> renders/cameras/depth-of-field.png (800 x 400): five GLASS SPHERES (oracle only; Kr .2, coloured Kt, eta 2) in a row on the checkered
+    floor, lensradius 0.25, focaldistance 7.12.  `crop`: Film "cropwindow" (the samples of a pixel do not depend on it)."""
+    from test_oracle_sphere import add_sphere
+    _sky_and_sun(s, host)
+    kts = [(0.9, 0.2, 0.2), (0.2, 0.9, 0.2), (0.2, 0.2, 0.9), (0.9, 0.9, 0.2), (0.2, 0.9, 0.9)]
+    t = ctm(host, host.translate((3, 3, 0)))
+    for k, kt in enumerate(kts):
+        if k:
+            t = host.compose(t, host.translate((-3, -3, 0)))  # the five Translate directives accumulate inside one attribute block
+        # "float eta" 2 in the file — which the reference does not read: glass.rs:158 looks up a float TEXTURE named "eta", finds none, and falls back to "index", 1.5 (quirk B12)
+        add_sphere(s, t, 1.0, material=s.add_material_glass((0.2, 0.2, 0.2), kt, 0.0, 0.0, 1.5, True))
+    _checker_floor(s, host, 0.1)
+    w2c, c2w = host.look_at((1, 8, 1), (0, 0, 0), (0, 0, 1))
+    s.set_camera_perspective(host.perspective_raster_to_camera(50.0, 800, 400), c2w, lens_radius=0.25, focal_distance=7.12)
+    cb, table, sb = host.film_box(800, 400, crop_window=crop)
+    s.set_film(800, 400, cb, (0.5, 0.5), table)
+    s.set_sampler(0, spp, sb)
+    s.build_accel(0, 4)
+    return dict(max_depth=5, render="cameras_depth-of-field", crop=[int(v) for v in cb])
+
+
 def compare(rgb_linear, ref_u8, block=8):
     """-> dict: mean |delta| in 8-bit levels per pixel, fraction of pixels with a channel off by more than 12 levels, and the same two over block x block means (sampling
     noise averages out of those: the path integrator's estimator differs from Whitted's where a scene has an area-like light or several lights)"""

@@ -240,3 +240,18 @@ def test_spectral_parameter_types(tmp_path):
     p.write_text('WorldBegin\nLightSource "infinite"\nMaterial "metal"\n' + tri + 'WorldEnd\n')
     r = run(["--check", "--quiet", str(p)])
     assert r.returncode == 0, r.stderr
+
+
+def test_glass_and_uber_take_their_index_of_refraction_from_index_not_eta(tmp_path):
+    """Quirk B12: `tp.get_float_texture("eta")` (glass.rs:158, uber.rs:201) is a look-up among the NAMED float textures, so the parameter "eta" is never read; "index" is.
+    The reference's render of its own cameras/depth-of-field.pbrt ("float eta" 2) shows index-1.5 spheres (tests/test_reference_renders.py).  The front end warns."""
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+    p = tmp_path / "s.pbrt"
+    p.write_text('WorldBegin\nLightSource "infinite"\nMaterial "glass" "float eta" 2\n' + tri + 'Material "uber" "float eta" 1.2\n' + tri +
+                 'Material "glass" "float index" 1.7\n' + tri + 'WorldEnd\n')
+    r = run(["--check", str(p)])
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count('does not read the parameter "eta"') == 2
+    p.write_text('WorldBegin\nLightSource "infinite"\nTexture "eta" "float" "constant" "float value" 1.9\nMaterial "glass"\n' + tri + 'WorldEnd\n')
+    r = run(["--check", str(p)])
+    assert r.returncode == 0 and 'does not read' not in r.stderr, r.stderr

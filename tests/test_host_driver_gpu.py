@@ -228,9 +228,10 @@ WorldEnd
             t = mul(mul(mul(I, host.translate([-1.2, 0.3, 0.6])), host.rotate(60, [1, 0, 0])), host.scale([0.6, 0.6, 0.6]))
             put(o, t, o.add_material_metal((0.14, 0.37, 1.44), (3.98, 2.38, 1.6), 0.1, 0.1, True))
             t = mul(mul(mul(I, host.translate([0, -0.4, 0.7])), host.rotate(75, [1, 0, 0])), host.scale([0.5, 0.5, 0.5]))
-            put(o, t, o.add_material_glass((1, 1, 1), (1, 1, 1), 0.0, 0.0, 1.4, True))
+            # the file says "float eta" 1.4, which the reference never reads (quirk B12: glass.rs:158 looks up a float texture NAMED "eta", then the parameter "index"): 1.5
+            put(o, t, o.add_material_glass((1, 1, 1), (1, 1, 1), 0.0, 0.0, 1.5, True))
             t = mul(t, host.translate([0, 0, -0.6]))
-            put(o, t, o.add_material_glass((1, 1, 1), (1, 1, 1), 0.2, 0.2, 1.4, True))
+            put(o, t, o.add_material_glass((1, 1, 1), (1, 1, 1), 0.2, 0.2, 1.5, True))
             t = mul(mul(mul(I, host.translate([1.3, 0.2, 0.5])), host.rotate(80, [1, 0.2, 0])), host.scale([0.6, 0.6, 0.6]))
             put(o, t, o.add_material_uber((0.2, 0.3, 0.2), (0.3, 0.3, 0.3), (0.1, 0.1, 0.1), (0, 0, 0), (0.8, 0.8, 0.8), 0.1, 0.1, 1.33, True))
             t = mul(t, host.translate([0, 0, -0.8]))
