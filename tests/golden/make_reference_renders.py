@@ -10,11 +10,14 @@ sys.path.insert(0, HERE)
 from make_sphere_mask import read_png  # noqa: E402
 
 NAMES = ["shapes/triangles-alpha-mask", "cameras/perspective", "cameras/orthographic", "cameras/environment", "lights/point", "lights/distant", "lights/spot",
-         "lights/infinite-no-map", "lights/goniometric", "objects/instances", "materials/bump", "samplers/halton", "samplers/sobol", "cameras/depth-of-field"]
+         "lights/infinite-no-map", "lights/goniometric", "objects/instances", "materials/bump", "samplers/halton", "samplers/sobol", "cameras/depth-of-field", "textures/fbm", "textures/marble", "textures/wrinkled", "textures/windy", "textures/dots", "textures/bilerp", "textures/uv", "textures/mix", "textures/scale", "textures/2d-checkerboard"]
+TEX_CROP = (60, 195, 5, 145)  # rows, columns
 if __name__ == "__main__":
     os.makedirs(os.path.join(HERE, "ref_renders"), exist_ok=True)
     for n in NAMES:
         img = read_png(os.path.join("/root/reference/renders", n + ".png"))
+        if n.startswith("textures/"):
+            img = img[TEX_CROP[0]:TEX_CROP[1], TEX_CROP[2]:TEX_CROP[3]]   # the sphere of the six-shape texture scenes and the wall around it
         np.savez_compressed(os.path.join(HERE, "ref_renders", n.replace("/", "_") + ".npz"), rgb=np.ascontiguousarray(img, np.uint8))
         print(n, img.shape)
     # the one image INPUT among these scenes (scenes/lights/goniometric.pbrt "string mapname")

@@ -279,6 +279,46 @@ def cameras_depth_of_field(s, host, spp=128, crop=(0.0, 1.0, 0.0, 1.0)):
     return dict(max_depth=5, render="cameras_depth-of-field", crop=[int(v) for v in cb])
 
 
+TEX_CROP = (60, 195, 5, 145)  # rows, columns of the 400 x 400 texture renders kept in the fixtures: the sphere and the wall around it
+
+
+def textures_sphere(s, host, which, spp=64):
+    """scenes/textures/<which>.pbrt -> renders/textures/<which>.png: six quadrics wearing one texture in front of a wall, lit by a white sky.  Only the SPHERE (oracle only) and the
+    wall are restated — the other five shapes take a little sky from it, so this comparison is statistical (the pattern has to sit where the reference put it), not pixel-exact."""
+    from test_oracle_sphere import add_sphere
+    c = s.add_texture_constant
+    checks = lambda su, sv: s.add_texture_checkerboard(c(1.0), c(0.0), su, sv)
+    if which == "fbm":
+        mat = s.add_material_matte_tex(s.add_texture_fbm())
+    elif which == "wrinkled":
+        mat = s.add_material_matte_tex(s.add_texture_fbm(wrinkled=True))
+    elif which == "windy":
+        mat = s.add_material_matte_tex(s.add_texture_windy())
+    elif which == "marble":  # a mix material: 0.1 of the blue matte over the marble one
+        mat = s.add_material_mix(s.add_material_matte_tex(s.add_texture_marble(scale=2.0, variation=10.0)), s.add_material_matte((0.01, 0.04, 0.17)), (0.1, 0.1, 0.1))
+    elif which == "dots":    # "rgb inside" [.8 .8 .8] "rgb outside" [.211 .213 .270], handed over swapped (quirk B11)
+        mat = s.add_material_matte_tex(s.add_texture_dots(c((0.211, 0.213, 0.270)), c((0.8, 0.8, 0.8)), 12.0, 12.0))
+    elif which == "bilerp":
+        mat = s.add_material_matte_tex(s.add_texture_bilerp((1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1)))
+    elif which == "uv":
+        mat = s.add_material_matte_tex(s.add_texture_uv(-1.0, -1.0))
+    elif which == "mix":     # the sphere's own: "float amount" 0
+        mat = s.add_material_matte_tex(s.add_texture_mix(s.add_texture_windy(), checks(-16.0, -16.0), c(0.0)))
+    elif which == "scale":
+        mat = s.add_material_matte_tex(s.add_texture_scale(s.add_texture_windy(), checks(-16.0, -16.0)))
+    elif which == "2d-checkerboard":
+        mat = s.add_material_matte_tex(checks(-16.0, -16.0))
+    else:
+        raise ValueError(which)
+    s.add_light_infinite((1.0, 1.0, 1.0))
+    add_sphere(s, ctm(host, host.translate((-1.8, 0, 1)), host.rotate(15, (0, 1, 0)), host.rotate(200, (1, 0, 0)), host.rotate(-30, (0, 0, 1))), 0.8, material=mat)
+    t = ctm(host, host.translate((0, -1, 0)))
+    s.add_mesh(host.transform_points(t[0], np.array([[-20, 0, -20], [20, 0, -20], [20, 0, 20], [-20, 0, 20]], np.float32)), QUAD_IDX, s.add_material_matte((0.5, 0.5, 0.5)), UV=QUAD_ST)
+    camera_film(s, host, (0, 22, 0), (0, 0, 0), (0, 0, 1), 15.0, 400, 400, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=5, render="textures_" + which)
+
+
 def compare(rgb_linear, ref_u8, block=8):
     """-> dict: mean |delta| in 8-bit levels per pixel, fraction of pixels with a channel off by more than 12 levels, and the same two over block x block means (sampling
     noise averages out of those: the path integrator's estimator differs from Whitted's where a scene has an area-like light or several lights)"""
