@@ -176,7 +176,7 @@ int pbrt_hip_add_texture_imagemap(PbrtHipScene*, uint32_t mipmap, float su, floa
 /* Procedural 2D textures over the same uv mapping: CheckerboardTexture2D (textures/src/checkerboard_2d.rs; aa_mode 0 "none", 1 "closedform"),
  * UVTexture (uv.rs), BilerpTexture (bilerp.rs; four constant corner values), DotsTexture (dots.rs; Perlin noise of core/src/texture/common.rs).
  * add_texture_dots takes DotsTexture's fields: `inside` is evaluated inside a dot.  A caller that translates SCENE-FILE parameters must swap them: the reference builds the
- * texture with DotsTexture::new(outside_dot = "inside" parameter, inside_dot = "outside" parameter) (dots.rs:61-66, quirk B11; pbrt_hip_render does the swap). */
+ * texture with DotsTexture::new(outside_dot = "inside" parameter, inside_dot = "outside" parameter) (dots.rs:61-66, quirk B13; pbrt_hip_render does the swap). */
 int pbrt_hip_add_texture_checkerboard(PbrtHipScene*, uint32_t tex1, uint32_t tex2, float su, float sv, float du, float dv, int aa_mode, uint32_t* out_texture);
 int pbrt_hip_add_texture_uv(PbrtHipScene*, float su, float sv, float du, float dv, uint32_t* out_texture);
 int pbrt_hip_add_texture_bilerp(PbrtHipScene*, const float v00[3], const float v01[3], const float v10[3], const float v11[3], float su, float sv, float du, float dv,

@@ -314,7 +314,7 @@ void Api::pbrt_texture(const std::string& name, const std::string& type, const s
             if (aa != "none" && aa != "closedform") { warn("Antialiasing mode '" + aa + "' not understood by Checkerboard2DTexture; using 'closedform'"); aa = "closedform"; }
             if (ok) ok = check(ABI(pbrt_hip_add_texture_checkerboard(scene_, t1, t2, su, sv, du, dv, aa == "none" ? 0 : 1, &id)), "add_texture_checkerboard");
         } else if (tex_class == "dots") {
-            // Quirk B11 (textures/src/dots.rs:61-66): the reference's constructor from parameters hands (inside, outside) to DotsTexture::new(outside_dot, inside_dot), so
+            // Quirk B13 (textures/src/dots.rs:61-66): the reference's constructor from parameters hands (inside, outside) to DotsTexture::new(outside_dot, inside_dot), so
             // a scene file's "inside" value is what shows OUTSIDE the dots and "outside" fills them — its own render of scenes/shapes/triangles-alpha-mask.pbrt (an opaque
             // cube with holes where `"float inside" 1 "float outside" 0` asks for the opposite) confirms it.  The C ABI keeps DotsTexture's meaning; the swap lives here.
             const uint32_t param_inside = operand("inside", 1.0f), param_outside = operand("outside", 0.0f);
@@ -559,7 +559,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::array<float, 3> a3 = zero, b3 = zero, c3 = zero, d3 = zero, e3 = zero;
     float f0 = 0, f1 = 0, f2 = 0;
     const std::string& t = m.type;
-    // Quirk B12 (glass.rs:158-161, uber.rs:201-204): the reference asks `tp.get_float_texture("eta")`, which is a lookup in the table of NAMED float textures — one
+    // Quirk B14 (glass.rs:158-161, uber.rs:201-204): the reference asks `tp.get_float_texture("eta")`, which is a lookup in the table of NAMED float textures — one
     // declared as `Texture "eta" "float" ...` — and not a parameter look-up: the `"float eta" 2` that pbrt-v3 scenes (and the reference's own depth-of-field.pbrt) write is never
     // read.  Without such a texture the index of refraction is the "index" parameter, default 1.5.  Its render of depth-of-field.pbrt shows eta 1.5 spheres, pixel for pixel.
     auto eta_of = [&]() {

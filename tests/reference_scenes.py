@@ -58,7 +58,7 @@ def quad(size):
 def triangles_alpha_mask(s, host, spp=32, res=400):
     """scenes/shapes/triangles-alpha-mask.pbrt -> renders/shapes/triangles-alpha-mask.png (400 x 400, the reference used 128 spp)"""
     s.add_light_point((0.4 * 200, 0.45 * 200, 0.5 * 200), (-5.0, 0.0, 5.0))
-    # "float inside" 1 "float outside" 0 — which the reference's constructor hands over swapped (dots.rs:61-66, quirk B11): alpha is 0 INSIDE the dots
+    # "float inside" 1 "float outside" 0 — which the reference's constructor hands over swapped (dots.rs:61-66, quirk B13): alpha is 0 INSIDE the dots
     alpha = s.add_texture_dots(s.add_texture_constant(0.0), s.add_texture_constant(1.0), 10.0, 10.0)
     t = ctm(host, host.rotate(135.0, (0, 0, 1)))
     m1 = s.add_material_matte((0.2, 0.01, 0.01))
@@ -267,7 +267,7 @@ def cameras_depth_of_field(s, host, spp=128, crop=(0.0, 1.0, 0.0, 1.0)):
     for k, kt in enumerate(kts):
         if k:
             t = host.compose(t, host.translate((-3, -3, 0)))  # the five Translate directives accumulate inside one attribute block
-        # "float eta" 2 in the file — which the reference does not read: glass.rs:158 looks up a float TEXTURE named "eta", finds none, and falls back to "index", 1.5 (quirk B12)
+        # "float eta" 2 in the file — which the reference does not read: glass.rs:158 looks up a float TEXTURE named "eta", finds none, and falls back to "index", 1.5 (quirk B14)
         add_sphere(s, t, 1.0, material=s.add_material_glass((0.2, 0.2, 0.2), kt, 0.0, 0.0, 1.5, True))
     _checker_floor(s, host, 0.1)
     w2c, c2w = host.look_at((1, 8, 1), (0, 0, 0), (0, 0, 1))
@@ -296,7 +296,7 @@ def textures_sphere(s, host, which, spp=64):
         mat = s.add_material_matte_tex(s.add_texture_windy())
     elif which == "marble":  # a mix material: 0.1 of the blue matte over the marble one
         mat = s.add_material_mix(s.add_material_matte_tex(s.add_texture_marble(scale=2.0, variation=10.0)), s.add_material_matte((0.01, 0.04, 0.17)), (0.1, 0.1, 0.1))
-    elif which == "dots":    # "rgb inside" [.8 .8 .8] "rgb outside" [.211 .213 .270], handed over swapped (quirk B11)
+    elif which == "dots":    # "rgb inside" [.8 .8 .8] "rgb outside" [.211 .213 .270], handed over swapped (quirk B13)
         mat = s.add_material_matte_tex(s.add_texture_dots(c((0.211, 0.213, 0.270)), c((0.8, 0.8, 0.8)), 12.0, 12.0))
     elif which == "bilerp":
         mat = s.add_material_matte_tex(s.add_texture_bilerp((1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1)))

@@ -243,7 +243,7 @@ def test_spectral_parameter_types(tmp_path):
 
 
 def test_glass_and_uber_take_their_index_of_refraction_from_index_not_eta(tmp_path):
-    """Quirk B12: `tp.get_float_texture("eta")` (glass.rs:158, uber.rs:201) is a look-up among the NAMED float textures, so the parameter "eta" is never read; "index" is.
+    """Quirk B14: `tp.get_float_texture("eta")` (glass.rs:158, uber.rs:201) is a look-up among the NAMED float textures, so the parameter "eta" is never read; "index" is.
     The reference's render of its own cameras/depth-of-field.pbrt ("float eta" 2) shows index-1.5 spheres (tests/test_reference_renders.py).  The front end warns."""
     tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
     p = tmp_path / "s.pbrt"

@@ -228,7 +228,7 @@ WorldEnd
             t = mul(mul(mul(I, host.translate([-1.2, 0.3, 0.6])), host.rotate(60, [1, 0, 0])), host.scale([0.6, 0.6, 0.6]))
             put(o, t, o.add_material_metal((0.14, 0.37, 1.44), (3.98, 2.38, 1.6), 0.1, 0.1, True))
             t = mul(mul(mul(I, host.translate([0, -0.4, 0.7])), host.rotate(75, [1, 0, 0])), host.scale([0.5, 0.5, 0.5]))
-            # the file says "float eta" 1.4, which the reference never reads (quirk B12: glass.rs:158 looks up a float texture NAMED "eta", then the parameter "index"): 1.5
+            # the file says "float eta" 1.4, which the reference never reads (quirk B14: glass.rs:158 looks up a float texture NAMED "eta", then the parameter "index"): 1.5
             put(o, t, o.add_material_glass((1, 1, 1), (1, 1, 1), 0.0, 0.0, 1.5, True))
             t = mul(t, host.translate([0, 0, -0.6]))
             put(o, t, o.add_material_glass((1, 1, 1), (1, 1, 1), 0.2, 0.2, 1.5, True))
@@ -420,7 +420,7 @@ WorldEnd
         mi = s.add_material_mirror((1, 1, 1)); s.set_material_texture(mi, "Kr", wood)
         s.add_mesh(np.array([[-1, -1, 0.01], [1, -1, 0.01], [0, 0, 1.2]], np.float32), [0, 1, 2], mi)
         checks = s.add_texture_checkerboard(wood, s.add_texture_constant((0.1, 0.1, 0.1)), su=6.0, sv=6.0)
-        spots = s.add_texture_dots(s.add_texture_constant((0.7, 0.2, 0.2)), checks, su=3.0, sv=3.0)  # quirk B11: the file's "inside" lands outside the dots (dots.rs:61-66)
+        spots = s.add_texture_dots(s.add_texture_constant((0.7, 0.2, 0.2)), checks, su=3.0, sv=3.0)  # quirk B13: the file's "inside" lands outside the dots (dots.rs:61-66)
         s.add_mesh(np.array([[-4, -4, 0.005], [-2, -4, 0.005], [-2, -2, 0.005], [-4, -2, 0.005]], np.float32), [0, 1, 2, 0, 2, 3], s.add_material_matte_tex(spots, 0.0),
                    UV=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32))
         ident = (np.eye(4, dtype=np.float32).reshape(16),) * 2

@@ -2,7 +2,7 @@
 directory that need nothing outside the product's scope (tests/reference_scenes.py restates them through the C ABI; tests/golden/ref_renders/*.npz hold the reference's
 pixels, decoded by tests/golden/make_reference_renders.py).  Cameras (perspective, orthographic, environment), lights (point, spot, distant, infinite, goniometric),
 checkerboard and dots textures, alpha masks, object instancing, the triangle intersector, the BVH, the Halton sampler, the box-filtered film and the 8-bit output curve all
-have to agree for these to pass.  Two divergences of the first version were found this way: the reference builds DotsTexture with its two operands swapped (quirk B11) and
+have to agree for these to pass.  Two divergences of the first version were found this way: the reference builds DotsTexture with its two operands swapped (quirk B13) and
 reads the spot light's rim from "conedeltaangle" (the scene file's "conedelta" is ignored)."""
 import numpy as np
 import pytest
@@ -140,7 +140,7 @@ def test_oracle_whitted_reproduces_the_glass_spheres_of_depth_of_field():
     """scenes/cameras/depth-of-field.pbrt: five glass spheres (ORACLE ONLY) on the checkered floor through a lens of radius 0.25, 128 spp, Whitted depth 5 — the specular
     recursion with its ray differentials (sampler_integrator.rs:79-238), smooth glass as SpecularReflection + SpecularTransmission (allow_multiple_lobes = false), the dielectric
     Fresnel term and Snell refraction.  A 400 x 199 crop around the focused green sphere equals the reference's PNG in 99.98 % of its pixels.  It does so with index of refraction
-    1.5: the file's `"float eta" 2` is a parameter the reference never reads (quirk B12, glass.rs:158) — with 2.0 a third of the crop differs by up to 125 levels."""
+    1.5: the file's `"float eta" 2` is a parameter the reference never reads (quirk B14, glass.rs:158) — with 2.0 a third of the crop differs by up to 125 levels."""
     import ctypes as C
     host = pbrt_hip.Host()
     with pbrt_hip.Scene(oracle_binding()) as s:
