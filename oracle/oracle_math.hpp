@@ -285,6 +285,7 @@ struct EFloat {
     static EFloat raw(Float v, Float lo, Float hi) { EFloat r; r.v = v; r.low = lo; r.high = hi; return r; }
     Float lower_bound() const { return low; }
     Float upper_bound() const { return high; }
+    Float absolute_error() const { return next_float_up(pmax(pabs(high - v), pabs(v - low))); }  // get_absolute_error (:96-98)
 };
 inline EFloat operator+(EFloat a, EFloat b) { return EFloat::raw(a.v + b.v, next_float_down(a.low + b.low), next_float_up(a.high + b.high)); }   // :150-163
 inline EFloat operator-(EFloat a, EFloat b) { return EFloat::raw(a.v - b.v, next_float_down(a.low - b.high), next_float_up(a.high - b.low)); }   // :180-192

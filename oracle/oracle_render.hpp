@@ -460,26 +460,48 @@ struct Renderer {
         const V3 dndu = ((f2 * f1 - e2 * g1) * inv_egf_1) * dpdu + ((e2 * f1 - f2 * e1) * inv_egf_1) * dpdv;
         const V3 dndv = ((g2 * f1 - f2 * g1) * inv_egf_1) * dpdu + ((f2 * f1 - g2 * e1) * inv_egf_1) * dpdv;
         const V3 p_error = gamma_n(5) * vabs(p);
-        // SurfaceInteraction::new with wo = -ray.d of the OBJECT-space ray
-        V3 n = nn;
-        if (sp.reverse_orientation ^ sp.swaps_handedness) n = n * -1.0f;
-        V3 wo = -sp.w2o.vector(r_world.d); const Float l2 = length_squared(wo);
+        quadric_to_world(si, sp.o2w, sp.w2o, sp.reverse_orientation ^ sp.swaps_handedness, r_world, p, p_error, V2(u, v), dpdu, dpdv, dndu, dndv);
+        return si;
+    }
+    // SurfaceInteraction::new (surface_interaction.rs:69-98) with wo = -ray.d of the OBJECT-space ray, then object_to_world.transform_surface_interaction (transform.rs:566-590)
+    static void quadric_to_world(SurfaceHit& si, const Transform& o2w, const Transform& w2o, bool flip_n, const Ray& r_world, V3 p, V3 p_error, V2 uv, V3 dpdu, V3 dpdv, V3 dndu, V3 dndv) {
+        V3 n = normalize(cross(dpdu, dpdv));
+        if (flip_n) n = n * -1.0f;
+        V3 wo = -w2o.vector(r_world.d); const Float l2 = length_squared(wo);
         wo = (l2 == 0.0f) ? wo : wo / std::sqrt(l2);  // Hit::new (interaction/mod.rs:137-156)
-        // to world space
-        const Transform& t = sp.o2w;
-        V3 pe; si.p = t.point_with_abs_error(p, p_error, pe); si.p_error = pe;
-        si.wo = normalize(t.vector(wo));
-        si.n = normalize(t.normal(n));
-        si.dpdu = t.vector(dpdu); si.dpdv = t.vector(dpdv);
-        si.ns = face_forward(normalize(t.normal(n)), si.n);
-        si.dpdu_s = t.vector(dpdu); si.dpdv_s = t.vector(dpdv);
-        si.dndu_s = t.normal(dndu); si.dndv_s = t.normal(dndv);
-        si.uv = V2(u, v);
+        V3 pe; si.p = o2w.point_with_abs_error(p, p_error, pe); si.p_error = pe;
+        si.wo = normalize(o2w.vector(wo));
+        si.n = normalize(o2w.normal(n));
+        si.dpdu = o2w.vector(dpdu); si.dpdv = o2w.vector(dpdv);
+        si.ns = face_forward(normalize(o2w.normal(n)), si.n);
+        si.dpdu_s = o2w.vector(dpdu); si.dpdv_s = o2w.vector(dpdv);
+        si.dndu_s = o2w.normal(dndu); si.dndv_s = o2w.normal(dndv);
+        si.uv = uv;
+    }
+    // ---- tail of Hyperboloid::intersect (hyperboloid.rs:192-262)
+    SurfaceHit make_hyperboloid_hit(const Ray& r_world, uint32_t prim, const TriHit& h, const Hyperboloid& hy) const {
+        SurfaceHit si; si.prim = prim; si.time = r_world.time;
+        const V3 p = h.sp; const Float phi = h.sphi;
+        const Float u = phi / hy.phi_max;
+        const Float cos_phi = o_cos(phi), sin_phi = o_sin(phi);
+        const V3 dpdu(-hy.phi_max * p.y, hy.phi_max * p.x, 0.0f);
+        const V3 dpdv((hy.p2.x - hy.p1.x) * cos_phi - (hy.p2.y - hy.p1.y) * sin_phi, (hy.p2.x - hy.p1.x) * sin_phi + (hy.p2.y - hy.p1.y) * cos_phi, hy.p2.z - hy.p1.z);
+        const V3 d2p_duu = (-hy.phi_max * hy.phi_max) * V3(p.x, p.y, 0.0f);
+        const V3 d2p_duv = hy.phi_max * V3(-dpdv.y, dpdv.x, 0.0f);
+        const V3 d2p_dvv(0.0f, 0.0f, 0.0f);
+        const V3 nn = normalize(cross(dpdu, dpdv));
+        const Float e1 = dot(dpdu, dpdu), f1 = dot(dpdu, dpdv), g1 = dot(dpdv, dpdv);
+        const Float e2 = dot(nn, d2p_duu), f2 = dot(nn, d2p_duv), g2 = dot(nn, d2p_dvv);
+        const Float inv_egf_1 = 1.0f / (e1 * g1 - f1 * f1);
+        const V3 dndu = ((f2 * f1 - e2 * g1) * inv_egf_1) * dpdu + ((e2 * f1 - f2 * e1) * inv_egf_1) * dpdv;
+        const V3 dndv = ((g2 * f1 - f2 * g1) * inv_egf_1) * dpdu + ((f2 * f1 - g2 * e1) * inv_egf_1) * dpdv;
+        quadric_to_world(si, hy.o2w, hy.w2o, hy.reverse_orientation ^ hy.swaps_handedness, r_world, p, h.sperr, V2(u, h.sv), dpdu, dpdv, dndu, dndv);
         return si;
     }
     SurfaceHit make_surface_hit_local(const Ray& r, uint32_t prim, const TriHit& h) const {
         const Scene& s = *sc; const Mesh& m = s.mesh_of(prim);
         if (m.sphere >= 0) return make_sphere_hit(r, prim, h, s.spheres[(size_t)m.sphere]);
+        if (m.hyper >= 0) return make_hyperboloid_hit(r, prim, h, s.hyperboloids[(size_t)m.hyper]);
         uint32_t i0 = s.idx[3 * prim], i1 = s.idx[3 * prim + 1], i2 = s.idx[3 * prim + 2];
         V3 p0 = s.P[i0], p1 = s.P[i1], p2 = s.P[i2];
         Float b0 = h.b0, b1 = h.b1, b2 = h.b2;

@@ -97,6 +97,7 @@ struct Mesh {
     Float alpha, shadow_alpha;
     int alpha_tex = -1, shadow_alpha_tex = -1;   // float textures instead of the constants (triangle.rs:587-607, 868-898)
     int sphere = -1;        // >= 0: this record stands for ONE Sphere (scene.spheres[sphere]) that occupies one slot of the primitive list; no vertices
+    int hyper = -1;         // the same for a Hyperboloid (scene.hyperboloids[hyper])
 };
 
 // Sphere (shapes/src/sphere.rs:10-57) — ORACLE ONLY: BASELINE.json's configs[0] (scenes/shapes/sphere.pbrt) is "CPU reference only (plumbing)", the product renders triangles
@@ -116,6 +117,31 @@ struct Sphere {
     Bounds3 object_bound() const { return Bounds3(V3(-radius, -radius, z_min)).union_p(V3(radius, radius, z_max)); }  // :53-58 (Bounds3::new of two sorted corners)
 };
 
+// Hyperboloid (shapes/src/hyperboloid.rs:24-110) — ORACLE ONLY, for the reference's textures/2d-mappings scene (image maps under the four 2-D mappings)
+struct Hyperboloid {
+    Transform o2w, w2o;
+    bool reverse_orientation = false, swaps_handedness = false;
+    V3 p1, p2; Float z_min = 0, z_max = 0, phi_max = 0, r_max = 0, ah = 0, ch = 0;
+    Hyperboloid() {}
+    Hyperboloid(const Transform& o2w_, bool rev, V3 point1, V3 point2, Float phimax_deg) : o2w(o2w_), w2o(o2w_.inv()), reverse_orientation(rev) {
+        swaps_handedness = o2w.swaps_handedness();
+        p1 = point1; p2 = point2;
+        const Float radius1 = std::sqrt(p1.x * p1.x + p1.y * p1.y), radius2 = std::sqrt(p2.x * p2.x + p2.y * p2.y);
+        r_max = pmax(radius1, radius2); z_min = pmin(p1.z, p2.z); z_max = pmax(p1.z, p2.z);
+        if (p2.z == 0.0f) { V3 t = p1; p1 = p2; p2 = t; }
+        V3 pp = p1;
+        for (int count = 0;; count++) {  // :70-88
+            pp = pp + 2.0f * (p2 - p1);
+            const Float xy1 = pp.x * pp.x + pp.y * pp.y, xy2 = p2.x * p2.x + p2.y * p2.y;
+            ah = (1.0f / xy1 - (pp.z * pp.z) / (xy1 * p2.z * p2.z)) / (1.0f - (xy2 * pp.z * pp.z) / (xy1 * p2.z * p2.z));
+            ch = (ah * xy2 - 1.0f) / (p2.z * p2.z);
+            if (std::isfinite(ah) || count > 100000) break;
+        }
+        phi_max = pclamp(phimax_deg, 0.0f, 360.0f) * (PI / 180.0f);
+    }
+    Bounds3 object_bound() const { return Bounds3(V3(-r_max, -r_max, z_min)).union_p(V3(r_max, r_max, z_max)); }
+};
+
 struct LinearBVHNode {  // accelerators/src/bvh/common.rs:163-179 (32 bytes)
     Bounds3 bounds;
     uint32_t offset;
@@ -123,7 +149,7 @@ struct LinearBVHNode {  // accelerators/src/bvh/common.rs:163-179 (32 bytes)
     uint8_t axis, pad;
 };
 
-struct TriHit { Float t, b0, b1, b2; uint32_t inst = 0; V3 sp; Float sphi = 0; };  // sp / sphi: a Sphere hit's refined object-space point and phi  // inst = instance number + 1 when the hit lies inside an ObjectInstance
+struct TriHit { Float t, b0, b1, b2; uint32_t inst = 0; V3 sp; Float sphi = 0; V3 sperr; Float sv = 0; };  // sp / sphi: a Sphere hit's refined object-space point and phi  // inst = instance number + 1 when the hit lies inside an ObjectInstance
 
 // Object instancing (api/src/lib.rs:911-1000, core/src/primitives/transformed_primitive.rs).  An object is a contiguous range
 // of the scene's triangles; when it is instanced the reference wraps its primitives in one aggregate (the BVH the Accelerator
@@ -168,6 +194,7 @@ struct Scene {
     std::vector<Light> lights;
     std::vector<int> infinite_lights;
     std::vector<Sphere> spheres;      // oracle-only shapes; each owns one Mesh record and one primitive slot
+    std::vector<Hyperboloid> hyperboloids;
     // objects / instances; top_items = the scene's primitive list in directive order (triangle id, or ORC_INST_BIT | instance)
     std::vector<Object> objects;
     std::vector<Instance> instances;
@@ -187,6 +214,7 @@ struct Scene {
     // ---- Triangle::world_bound (triangle.rs:427-431)
     Bounds3 tri_bound(uint32_t prim) const {
         if (mesh_of(prim).sphere >= 0) { const Sphere& sp = spheres[(size_t)mesh_of(prim).sphere]; return transform_bounds(sp.o2w, sp.object_bound()); }  // Shape::world_bound (shape.rs)
+        if (mesh_of(prim).hyper >= 0) { const Hyperboloid& hy = hyperboloids[(size_t)mesh_of(prim).hyper]; return transform_bounds(hy.o2w, hy.object_bound()); }
         return Bounds3(P[idx[3 * prim]]).union_p(P[idx[3 * prim + 1]]).union_p(P[idx[3 * prim + 2]]);
     }
 
@@ -230,6 +258,46 @@ struct Scene {
     void tri_uvs(uint32_t prim, V2 uv[3]) const {  // triangle.rs:384-394
         if (mesh_of(prim).has_uv) { uv[0] = UV[idx[3 * prim]]; uv[1] = UV[idx[3 * prim + 1]]; uv[2] = UV[idx[3 * prim + 2]]; }
         else { uv[0] = V2(0, 0); uv[1] = V2(1, 0); uv[2] = V2(1, 1); }
+    }
+
+    // ---- Hyperboloid::intersect / intersect_p up to the accept decision (hyperboloid.rs:124-190 / 266-340).  Fills t, the object-space point, phi, v and the point's error bound
+    bool hyperboloid_intersect(const Ray& r, const Hyperboloid& hy, TriHit& h) const {
+        V3 o_err, d_err;
+        V3 o = hy.w2o.point_with_error(r.o, o_err);
+        const V3 d = hy.w2o.vector_with_error(r.d, d_err);
+        const Float l2 = length_squared(d);
+        if (l2 > 0.0f) { const Float dt = dot(vabs(d), o_err) / l2; o = o + d * dt; }
+        const EFloat ox(o.x, o_err.x), oy(o.y, o_err.y), oz(o.z, o_err.z), dx(d.x, d_err.x), dy(d.y, d_err.y), dz(d.z, d_err.z);
+        const EFloat ah(hy.ah), ch(hy.ch);
+        const EFloat a = ah * dx * dx + ah * dy * dy - ch * dz * dz;
+        const EFloat b = EFloat(2.0f) * (ah * dx * ox + ah * dy * oy - ch * dz * oz);
+        const EFloat c = ah * ox * ox + ah * oy * oy - ch * oz * oz - EFloat(1.0f);
+        EFloat t0, t1;
+        if (!quadratic_efloat(a, b, c, t0, t1)) return false;
+        if (t0.upper_bound() > r.t_max || t1.lower_bound() <= 0.0f) return false;
+        EFloat t_hit = t0;
+        if (t_hit.lower_bound() <= 0.0f) { t_hit = t1; if (t_hit.upper_bound() > r.t_max) return false; }
+        V3 p_hit; Float phi, v;
+        auto locate = [&]() {
+            p_hit = o + d * t_hit.v;
+            v = (p_hit.z - hy.p1.z) / (hy.p2.z - hy.p1.z);
+            const V3 pr = (1.0f - v) * hy.p1 + v * hy.p2;
+            phi = o_atan2(pr.x * p_hit.y - p_hit.x * pr.y, p_hit.x * pr.x + p_hit.y * pr.y);
+            if (phi < 0.0f) phi += TWO_PI;
+        };
+        auto clipped = [&]() { return p_hit.z < hy.z_min || p_hit.z > hy.z_max || phi > hy.phi_max; };
+        locate();
+        if (clipped()) {
+            if (t_hit.v == t1.v) return false;
+            t_hit = t1;
+            if (t1.upper_bound() > r.t_max) return false;
+            locate();
+            if (clipped()) return false;
+        }
+        const EFloat px = ox + t_hit * dx, py = oy + t_hit * dy, pz = oz + t_hit * dz;  // :236-243
+        h.t = t_hit.v; h.b0 = h.b1 = h.b2 = 0.0f; h.sp = p_hit; h.sphi = phi; h.sv = v;
+        h.sperr = V3(px.absolute_error(), py.absolute_error(), pz.absolute_error());
+        return true;
     }
 
     // ---- Triangle::intersect up to the accept decision (triangle.rs:438-575 / 731-861).
@@ -350,7 +418,8 @@ struct Scene {
         if (!(ref & ORC_INST_BIT)) {
             TriHit h;
             if (st) st->tri_tests++;
-            const bool hit = mesh_of(ref).sphere >= 0 ? sphere_intersect(r, spheres[(size_t)mesh_of(ref).sphere], h) : tri_intersect(r, ref, true, false, h);
+            const Mesh& mm = mesh_of(ref);
+            const bool hit = mm.sphere >= 0 ? sphere_intersect(r, spheres[(size_t)mm.sphere], h) : (mm.hyper >= 0 ? hyperboloid_intersect(r, hyperboloids[(size_t)mm.hyper], h) : tri_intersect(r, ref, true, false, h));
             if (hit) { r.t_max = h.t; prim_out = ref; hit_out = h; return true; }
             return false;
         }
@@ -369,6 +438,7 @@ struct Scene {
         if (!(ref & ORC_INST_BIT)) {
             TriHit h; if (st) st->tri_tests++;
             if (mesh_of(ref).sphere >= 0) return sphere_intersect(r, spheres[(size_t)mesh_of(ref).sphere], h);
+            if (mesh_of(ref).hyper >= 0) return hyperboloid_intersect(r, hyperboloids[(size_t)mesh_of(ref).hyper], h);
             return tri_intersect(r, ref, true, true, h);
         }
         const Instance& in = instances[ref & ~ORC_INST_BIT]; const Object& ob = objects[in.object];

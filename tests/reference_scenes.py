@@ -319,6 +319,41 @@ def textures_sphere(s, host, which, spp=64):
     return dict(max_depth=5, render="textures_" + which)
 
 
+def add_hyperboloid(scene, t, p1, p2, phimax=360.0, material=0):
+    import ctypes as C
+    L = scene.b.lib
+    fp = C.POINTER(C.c_float)
+    L.oracle_add_hyperboloid.argtypes = [C.c_void_p, fp, fp, fp, fp, C.c_float, C.c_uint32, C.c_uint32]
+    f = lambda a: np.ascontiguousarray(a, np.float32).ctypes.data_as(fp)
+    scene._chk(L.oracle_add_hyperboloid(scene.h, f(t[0]), f(t[1]), f(p1), f(p2), phimax, material, 0))
+
+
+def textures_2d_mappings(s, host, spp=128, crop=(0.0, 1.0, 0.0, 1.0)):
+    """scenes/textures/2d-mappings.pbrt -> renders/textures/2d-mappings.png (800 x 400): four HYPERBOLOIDS (oracle only) wearing the image map scenes/images/checkerboard.png under the
+    uv, spherical, cylindrical and planar mappings (EWA filtering, gamma on, repeat), in front of a wall, under a white sky"""
+    img = np.load(os.path.join(HERE, "golden", "ref_renders", "image_checkerboard.npz"))["rgb"].astype(np.float32) / np.float32(255.0)   # read_8_bit: u8 / 255
+    s.add_light_infinite((1.0, 1.0, 1.0))
+    mip = s.add_mipmap(img, gamma=True)   # imagemap defaults for a .png: gamma on, EWA, maxanisotropy 8, repeat, scale 1
+    rot = host.rotate(90.0, (1, 0, 0))
+    for k, (x, kind) in enumerate(((-3.0, "uv"), (-1.0, "spherical"), (1.0, "cylindrical"), (3.0, "planar"))):
+        t = ctm(host, host.translate((x, 0, 0)))
+        tex = s.add_texture_imagemap(mip)
+        if kind in ("spherical", "cylindrical"):
+            s.set_texture_mapping(tex, kind, host.compose(t, rot)[1])   # world_to_texture = inverse of the CTM the Texture directive saw
+        elif kind == "planar":
+            s.set_texture_mapping(tex, kind, [0.0, -0.3, -0.3, 0.3, 0.0, 0.3, 0.0, 0.0])
+        add_hyperboloid(s, t, (0.6, 0.6, 1.0), (0.6, -0.6, -1.0), material=s.add_material_matte_tex(tex))
+    t = ctm(host, host.translate((0, -0.6, 0)))
+    s.add_mesh(host.transform_points(t[0], np.array([[-20, 0, -20], [20, 0, -20], [20, 0, 20], [-20, 0, 20]], np.float32)), QUAD_IDX, s.add_material_matte((0.5, 0.5, 0.5)), UV=QUAD_ST)
+    w2c, c2w = host.look_at((0, 15, 0), (0, 0, 0), (0, 0, 1))
+    s.set_camera_perspective(host.perspective_raster_to_camera(15.0, 800, 400), c2w)
+    cb, table, sb = host.film_box(800, 400, crop_window=crop)
+    s.set_film(800, 400, cb, (0.5, 0.5), table)
+    s.set_sampler(0, spp, sb)
+    s.build_accel(0, 4)
+    return dict(max_depth=5, render="textures_2d-mappings", crop=[int(v) for v in cb])
+
+
 def compare(rgb_linear, ref_u8, block=8):
     """-> dict: mean |delta| in 8-bit levels per pixel, fraction of pixels with a channel off by more than 12 levels, and the same two over block x block means (sampling
     noise averages out of those: the path integrator's estimator differs from Whitted's where a scene has an area-like light or several lights)"""
