@@ -246,6 +246,31 @@ int oracle_add_hyperboloid(OracleScene* s, const float o2w_m[16], const float o2
     s->built = false;
     return 0;
 }
+// Shape "cylinder" (radius, zmin, zmax) / "cone" (radius, height) / "paraboloid" (radius, zmin, zmax) / "disk" (radius, height, innerradius) — ORACLE ONLY.
+// kind: 0 cylinder, 1 cone, 2 paraboloid, 3 disk; a, b: (zmin, zmax) / (height, -) / (zmin, zmax) / (height, innerradius)
+int oracle_add_quadric(OracleScene* s, int kind, const float o2w_m[16], const float o2w_minv[16], float radius, float a, float b, float phi_max, uint32_t material_id, uint32_t flags) {
+    if (!s || !o2w_m || !o2w_minv || kind < 0 || kind > 3) return -1;
+    Scene& sc = s->sc;
+    if (material_id >= sc.materials.size()) { s->err = "bad material id"; return -1; }
+    if (sc.open_object >= 0) { s->err = "quadrics inside object instances are not restated"; return -5; }
+    const Transform o2w(m4_from(o2w_m), m4_from(o2w_minv));
+    Mesh m;
+    m.vert_base = (uint32_t)sc.P.size(); m.tri_base = (uint32_t)sc.n_tris(); m.n_verts = 1; m.n_tris = 1;
+    m.has_n = m.has_s = m.has_uv = false;
+    m.material = material_id; m.first_light = -1;
+    m.reverse_orientation = flags & 1; m.swaps_handedness = o2w.swaps_handedness();
+    m.alpha = 1.0f; m.shadow_alpha = 1.0f;
+    m.quadric = (int)sc.quadrics.size();
+    sc.quadrics.push_back(Quadric(kind, o2w, (flags & 1) != 0, radius, a, b, phi_max));
+    sc.P.push_back(o2w.point(V3(0, 0, 0))); sc.N.push_back(V3()); sc.S.push_back(V3()); sc.UV.push_back(V2());
+    const uint32_t mesh_id = (uint32_t)sc.meshes.size();
+    for (int k = 0; k < 3; k++) sc.idx.push_back(m.vert_base);
+    sc.tri_mesh.push_back(mesh_id);
+    sc.meshes.push_back(m);
+    sc.top_items.push_back(m.tri_base);
+    s->built = false;
+    return 0;
+}
 // one ray against one sphere, outside any scene: out = {hit, t, p.xyz (world), n.xyz (world), u, v}
 int oracle_sphere_probe(const float o2w_m[16], const float o2w_minv[16], float radius, float z_min, float z_max, float phi_max, uint32_t flags,
                         const float o[3], const float d[3], float t_max, float* out) {

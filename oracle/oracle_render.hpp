@@ -478,6 +478,43 @@ struct Renderer {
         si.dndu_s = o2w.normal(dndu); si.dndv_s = o2w.normal(dndv);
         si.uv = uv;
     }
+    // ---- tails of Cylinder / Cone / Paraboloid / Disk ::intersect (cylinder.rs:146-196, cone.rs:132-190, paraboloid.rs:132-200, disk.rs:106-140)
+    SurfaceHit make_quadric_hit(const Ray& r_world, uint32_t prim, const TriHit& h, const Quadric& q) const {
+        SurfaceHit si; si.prim = prim; si.time = r_world.time;
+        V3 p = h.sp; const Float phi = h.sphi;
+        const Float u = phi / q.phi_max;
+        Float v = 0.0f;
+        V3 dpdu(-q.phi_max * p.y, q.phi_max * p.x, 0.0f), dpdv, dndu(0, 0, 0), dndv(0, 0, 0);
+        if (q.kind == Q_DISK) {
+            const Float r_hit = std::sqrt(h.sv);  // sv = dist2
+            v = (q.radius - r_hit) / (q.radius - q.inner_radius);
+            dpdv = V3(p.x, p.y, 0.0f) * (q.inner_radius - q.radius) / r_hit;
+            p.z = q.height;  // refine (disk.rs:118)
+        } else {
+            V3 d2p_duu = (-q.phi_max * q.phi_max) * V3(p.x, p.y, 0.0f), d2p_duv(0, 0, 0), d2p_dvv(0, 0, 0);
+            if (q.kind == Q_CYLINDER) {
+                v = (p.z - q.z_min) / (q.z_max - q.z_min);
+                dpdv = V3(0.0f, 0.0f, q.z_max - q.z_min);
+            } else if (q.kind == Q_CONE) {
+                v = p.z / q.height;
+                dpdv = V3(-p.x / (1.0f - v), -p.y / (1.0f - v), q.height);
+                d2p_duv = (q.phi_max / (1.0f - v)) * V3(p.y, -p.x, 0.0f);
+            } else {
+                v = (p.z - q.z_min) / (q.z_max - q.z_min);
+                dpdv = (q.z_max - q.z_min) * V3(p.x / (2.0f * p.z), p.y / (2.0f * p.z), 1.0f);
+                d2p_duv = ((q.z_max - q.z_min) * q.phi_max) * V3(-p.y / (2.0f * p.z), p.x / (2.0f * p.z), 0.0f);
+                d2p_dvv = (-(q.z_max - q.z_min) * (q.z_max - q.z_min)) * V3(p.x / (4.0f * p.z * p.z), p.y / (4.0f * p.z * p.z), 0.0f);
+            }
+            const V3 nn = normalize(cross(dpdu, dpdv));
+            const Float e1 = dot(dpdu, dpdu), f1 = dot(dpdu, dpdv), g1 = dot(dpdv, dpdv);
+            const Float e2 = dot(nn, d2p_duu), f2 = dot(nn, d2p_duv), g2 = dot(nn, d2p_dvv);
+            const Float inv_egf_1 = 1.0f / (e1 * g1 - f1 * f1);
+            dndu = ((f2 * f1 - e2 * g1) * inv_egf_1) * dpdu + ((e2 * f1 - f2 * e1) * inv_egf_1) * dpdv;
+            dndv = ((g2 * f1 - f2 * g1) * inv_egf_1) * dpdu + ((f2 * f1 - g2 * e1) * inv_egf_1) * dpdv;
+        }
+        quadric_to_world(si, q.o2w, q.w2o, q.reverse_orientation ^ q.swaps_handedness, r_world, p, h.sperr, V2(u, v), dpdu, dpdv, dndu, dndv);
+        return si;
+    }
     // ---- tail of Hyperboloid::intersect (hyperboloid.rs:192-262)
     SurfaceHit make_hyperboloid_hit(const Ray& r_world, uint32_t prim, const TriHit& h, const Hyperboloid& hy) const {
         SurfaceHit si; si.prim = prim; si.time = r_world.time;
@@ -502,6 +539,7 @@ struct Renderer {
         const Scene& s = *sc; const Mesh& m = s.mesh_of(prim);
         if (m.sphere >= 0) return make_sphere_hit(r, prim, h, s.spheres[(size_t)m.sphere]);
         if (m.hyper >= 0) return make_hyperboloid_hit(r, prim, h, s.hyperboloids[(size_t)m.hyper]);
+        if (m.quadric >= 0) return make_quadric_hit(r, prim, h, s.quadrics[(size_t)m.quadric]);
         uint32_t i0 = s.idx[3 * prim], i1 = s.idx[3 * prim + 1], i2 = s.idx[3 * prim + 2];
         V3 p0 = s.P[i0], p1 = s.P[i1], p2 = s.P[i2];
         Float b0 = h.b0, b1 = h.b1, b2 = h.b2;

@@ -98,6 +98,7 @@ struct Mesh {
     int alpha_tex = -1, shadow_alpha_tex = -1;   // float textures instead of the constants (triangle.rs:587-607, 868-898)
     int sphere = -1;        // >= 0: this record stands for ONE Sphere (scene.spheres[sphere]) that occupies one slot of the primitive list; no vertices
     int hyper = -1;         // the same for a Hyperboloid (scene.hyperboloids[hyper])
+    int quadric = -1;       // ... and for a Cylinder / Cone / Paraboloid / Disk (scene.quadrics[quadric])
 };
 
 // Sphere (shapes/src/sphere.rs:10-57) — ORACLE ONLY: BASELINE.json's configs[0] (scenes/shapes/sphere.pbrt) is "CPU reference only (plumbing)", the product renders triangles
@@ -140,6 +141,29 @@ struct Hyperboloid {
         phi_max = pclamp(phimax_deg, 0.0f, 360.0f) * (PI / 180.0f);
     }
     Bounds3 object_bound() const { return Bounds3(V3(-r_max, -r_max, z_min)).union_p(V3(r_max, r_max, z_max)); }
+};
+
+// Cylinder, Cone, Paraboloid, Disk (shapes/src/{cylinder,cone,paraboloid,disk}.rs) — ORACLE ONLY: the other four quadrics of the reference's six-shape texture scenes
+enum QuadricKind { Q_CYLINDER = 0, Q_CONE = 1, Q_PARABOLOID = 2, Q_DISK = 3 };
+struct Quadric {
+    int kind = Q_CYLINDER;
+    Transform o2w, w2o;
+    bool reverse_orientation = false, swaps_handedness = false;
+    Float radius = 1, z_min = 0, z_max = 1, height = 1, inner_radius = 0, phi_max = 0;
+    Quadric() {}
+    // a, b: cylinder / paraboloid (zmin, zmax); cone (height, -); disk (height, innerradius)
+    Quadric(int kind_, const Transform& o2w_, bool rev, Float radius_, Float a, Float b, Float phimax_deg) : kind(kind_), o2w(o2w_), w2o(o2w_.inv()), reverse_orientation(rev), radius(radius_) {
+        swaps_handedness = o2w.swaps_handedness();
+        if (kind == Q_CYLINDER || kind == Q_PARABOLOID) { z_min = pmin(a, b); z_max = pmax(a, b); }
+        else if (kind == Q_CONE) height = a;
+        else { height = a; inner_radius = b; }
+        phi_max = pclamp(phimax_deg, 0.0f, 360.0f) * (PI / 180.0f);
+    }
+    Bounds3 object_bound() const {
+        if (kind == Q_CONE) return Bounds3(V3(-radius, -radius, 0.0f)).union_p(V3(radius, radius, height));
+        if (kind == Q_DISK) return Bounds3(V3(-radius, -radius, height)).union_p(V3(radius, radius, height));
+        return Bounds3(V3(-radius, -radius, z_min)).union_p(V3(radius, radius, z_max));
+    }
 };
 
 struct LinearBVHNode {  // accelerators/src/bvh/common.rs:163-179 (32 bytes)
@@ -195,6 +219,7 @@ struct Scene {
     std::vector<int> infinite_lights;
     std::vector<Sphere> spheres;      // oracle-only shapes; each owns one Mesh record and one primitive slot
     std::vector<Hyperboloid> hyperboloids;
+    std::vector<Quadric> quadrics;
     // objects / instances; top_items = the scene's primitive list in directive order (triangle id, or ORC_INST_BIT | instance)
     std::vector<Object> objects;
     std::vector<Instance> instances;
@@ -215,6 +240,7 @@ struct Scene {
     Bounds3 tri_bound(uint32_t prim) const {
         if (mesh_of(prim).sphere >= 0) { const Sphere& sp = spheres[(size_t)mesh_of(prim).sphere]; return transform_bounds(sp.o2w, sp.object_bound()); }  // Shape::world_bound (shape.rs)
         if (mesh_of(prim).hyper >= 0) { const Hyperboloid& hy = hyperboloids[(size_t)mesh_of(prim).hyper]; return transform_bounds(hy.o2w, hy.object_bound()); }
+        if (mesh_of(prim).quadric >= 0) { const Quadric& q = quadrics[(size_t)mesh_of(prim).quadric]; return transform_bounds(q.o2w, q.object_bound()); }
         return Bounds3(P[idx[3 * prim]]).union_p(P[idx[3 * prim + 1]]).union_p(P[idx[3 * prim + 2]]);
     }
 
@@ -297,6 +323,77 @@ struct Scene {
         const EFloat px = ox + t_hit * dx, py = oy + t_hit * dy, pz = oz + t_hit * dz;  // :236-243
         h.t = t_hit.v; h.b0 = h.b1 = h.b2 = 0.0f; h.sp = p_hit; h.sphi = phi; h.sv = v;
         h.sperr = V3(px.absolute_error(), py.absolute_error(), pz.absolute_error());
+        return true;
+    }
+
+    // ---- Cylinder / Cone / Paraboloid / Disk ::intersect and ::intersect_p up to the accept decision (cylinder.rs:64-144, cone.rs:66-130, paraboloid.rs:66-130, disk.rs:64-104)
+    bool quadric_intersect(const Ray& r, const Quadric& q, TriHit& h) const {
+        V3 o_err, d_err;
+        V3 o = q.w2o.point_with_error(r.o, o_err);
+        const V3 d = q.w2o.vector_with_error(r.d, d_err);
+        const Float l2 = length_squared(d);
+        if (l2 > 0.0f) { const Float dt = dot(vabs(d), o_err) / l2; o = o + d * dt; }
+        if (q.kind == Q_DISK) {
+            if (d.z == 0.0f) return false;
+            const Float t = (q.height - o.z) / d.z;
+            if (t <= 0.0f || t >= r.t_max) return false;
+            V3 p = o + d * t;
+            const Float dist2 = p.x * p.x + p.y * p.y;
+            if (dist2 > q.radius * q.radius || dist2 < q.inner_radius * q.inner_radius) return false;
+            Float phi = o_atan2(p.y, p.x);
+            if (phi < 0.0f) phi += TWO_PI;
+            if (phi > q.phi_max) return false;
+            h.t = t; h.b0 = h.b1 = h.b2 = 0.0f; h.sp = p; h.sphi = phi; h.sv = dist2; h.sperr = V3(0, 0, 0);  // sv carries dist2 for the disk
+            return true;
+        }
+        const EFloat ox(o.x, o_err.x), oy(o.y, o_err.y), oz(o.z, o_err.z), dx(d.x, d_err.x), dy(d.y, d_err.y), dz(d.z, d_err.z);
+        EFloat a, b, c;
+        if (q.kind == Q_CYLINDER) {
+            a = dx * dx + dy * dy;
+            b = EFloat(2.0f) * (dx * ox + dy * oy);
+            c = ox * ox + oy * oy - EFloat(q.radius) * EFloat(q.radius);
+        } else if (q.kind == Q_CONE) {
+            EFloat k = EFloat(q.radius) / EFloat(q.height);
+            k = k * k;
+            a = dx * dx + dy * dy - k * dz * dz;
+            b = EFloat(2.0f) * (dx * ox + dy * oy - k * dz * (oz - EFloat(q.height)));
+            c = ox * ox + oy * oy - k * (oz - EFloat(q.height)) * (oz - EFloat(q.height));
+        } else {
+            const EFloat k = EFloat(q.z_max) / (EFloat(q.radius) * EFloat(q.radius));
+            a = k * (dx * dx + dy * dy);
+            b = EFloat(2.0f) * k * (dx * ox + dy * oy) - dz;
+            c = k * (ox * ox + oy * oy) - oz;
+        }
+        EFloat t0, t1;
+        if (!quadratic_efloat(a, b, c, t0, t1)) return false;
+        if (t0.upper_bound() > r.t_max || t1.lower_bound() <= 0.0f) return false;
+        EFloat t_hit = t0;
+        if (t_hit.lower_bound() <= 0.0f) { t_hit = t1; if (t_hit.upper_bound() > r.t_max) return false; }
+        V3 p_hit; Float phi;
+        auto locate = [&]() {
+            p_hit = o + d * t_hit.v;
+            if (q.kind == Q_CYLINDER) {  // refine (cylinder.rs:107-109)
+                const Float hit_rad = std::sqrt(p_hit.x * p_hit.x + p_hit.y * p_hit.y);
+                p_hit.x *= q.radius / hit_rad; p_hit.y *= q.radius / hit_rad;
+            }
+            phi = o_atan2(p_hit.y, p_hit.x);
+            if (phi < 0.0f) phi += TWO_PI;
+        };
+        auto clipped = [&]() {
+            if (q.kind == Q_CONE) return p_hit.z < 0.0f || p_hit.z > q.height || phi > q.phi_max;
+            return p_hit.z < q.z_min || p_hit.z > q.z_max || phi > q.phi_max;
+        };
+        locate();
+        if (clipped()) {
+            if (t_hit.v == t1.v) return false;
+            t_hit = t1;
+            if (t1.upper_bound() > r.t_max) return false;
+            locate();
+            if (clipped()) return false;
+        }
+        h.t = t_hit.v; h.b0 = h.b1 = h.b2 = 0.0f; h.sp = p_hit; h.sphi = phi; h.sv = 0.0f;
+        if (q.kind == Q_CYLINDER) h.sperr = gamma_n(3) * vabs(V3(p_hit.x, p_hit.y, 0.0f));
+        else { const EFloat px = ox + t_hit * dx, py = oy + t_hit * dy, pz = oz + t_hit * dz; h.sperr = V3(px.absolute_error(), py.absolute_error(), pz.absolute_error()); }
         return true;
     }
 
@@ -419,7 +516,7 @@ struct Scene {
             TriHit h;
             if (st) st->tri_tests++;
             const Mesh& mm = mesh_of(ref);
-            const bool hit = mm.sphere >= 0 ? sphere_intersect(r, spheres[(size_t)mm.sphere], h) : (mm.hyper >= 0 ? hyperboloid_intersect(r, hyperboloids[(size_t)mm.hyper], h) : tri_intersect(r, ref, true, false, h));
+            const bool hit = mm.sphere >= 0 ? sphere_intersect(r, spheres[(size_t)mm.sphere], h) : (mm.hyper >= 0 ? hyperboloid_intersect(r, hyperboloids[(size_t)mm.hyper], h) : (mm.quadric >= 0 ? quadric_intersect(r, quadrics[(size_t)mm.quadric], h) : tri_intersect(r, ref, true, false, h)));
             if (hit) { r.t_max = h.t; prim_out = ref; hit_out = h; return true; }
             return false;
         }
@@ -439,6 +536,7 @@ struct Scene {
             TriHit h; if (st) st->tri_tests++;
             if (mesh_of(ref).sphere >= 0) return sphere_intersect(r, spheres[(size_t)mesh_of(ref).sphere], h);
             if (mesh_of(ref).hyper >= 0) return hyperboloid_intersect(r, hyperboloids[(size_t)mesh_of(ref).hyper], h);
+            if (mesh_of(ref).quadric >= 0) return quadric_intersect(r, quadrics[(size_t)mesh_of(ref).quadric], h);
             return tri_intersect(r, ref, true, true, h);
         }
         const Instance& in = instances[ref & ~ORC_INST_BIT]; const Object& ob = objects[in.object];

@@ -10,13 +10,15 @@ sys.path.insert(0, HERE)
 from make_sphere_mask import read_png  # noqa: E402
 
 NAMES = ["shapes/triangles-alpha-mask", "cameras/perspective", "cameras/orthographic", "cameras/environment", "lights/point", "lights/distant", "lights/spot",
-         "lights/infinite-no-map", "lights/goniometric", "objects/instances", "materials/bump", "samplers/halton", "samplers/sobol", "cameras/depth-of-field", "textures/fbm", "textures/marble", "textures/wrinkled", "textures/windy", "textures/dots", "textures/bilerp", "textures/uv", "textures/mix", "textures/scale", "textures/2d-checkerboard", "textures/2d-mappings"]
+         "lights/infinite-no-map", "lights/goniometric", "objects/instances", "materials/bump", "samplers/halton", "samplers/sobol", "cameras/depth-of-field", "textures/fbm", "textures/marble", "textures/wrinkled", "textures/windy", "textures/dots", "textures/bilerp", "textures/uv", "textures/mix", "textures/scale", "textures/2d-checkerboard", "textures/2d-mappings", "textures/constant"]
 TEX_CROP = (60, 195, 5, 145)  # rows, columns
+# the 3-D textures do not depend on a shape's parameterisation: the sphere's corner of the image is kept; the scenes with 2-D (u, v) textures are kept whole
+TEX_CROPPED = ("textures/fbm", "textures/wrinkled", "textures/windy", "textures/marble")
 if __name__ == "__main__":
     os.makedirs(os.path.join(HERE, "ref_renders"), exist_ok=True)
     for n in NAMES:
         img = read_png(os.path.join("/root/reference/renders", n + ".png"))
-        if n.startswith("textures/") and n != "textures/2d-mappings":
+        if n in TEX_CROPPED:
             img = img[TEX_CROP[0]:TEX_CROP[1], TEX_CROP[2]:TEX_CROP[3]]   # the sphere of the six-shape texture scenes and the wall around it
         np.savez_compressed(os.path.join(HERE, "ref_renders", n.replace("/", "_") + ".npz"), rgb=np.ascontiguousarray(img, np.uint8))
         print(n, img.shape)

@@ -282,43 +282,6 @@ def cameras_depth_of_field(s, host, spp=128, crop=(0.0, 1.0, 0.0, 1.0)):
 TEX_CROP = (60, 195, 5, 145)  # rows, columns of the 400 x 400 texture renders kept in the fixtures: the sphere and the wall around it
 
 
-def textures_sphere(s, host, which, spp=64):
-    """scenes/textures/<which>.pbrt -> renders/textures/<which>.png: six quadrics wearing one texture in front of a wall, lit by a white sky.  Only the SPHERE (oracle only) and the
-    wall are restated — the other five shapes take a little sky from it, so this comparison is statistical (the pattern has to sit where the reference put it), not pixel-exact."""
-    from test_oracle_sphere import add_sphere
-    c = s.add_texture_constant
-    checks = lambda su, sv: s.add_texture_checkerboard(c(1.0), c(0.0), su, sv)
-    if which == "fbm":
-        mat = s.add_material_matte_tex(s.add_texture_fbm())
-    elif which == "wrinkled":
-        mat = s.add_material_matte_tex(s.add_texture_fbm(wrinkled=True))
-    elif which == "windy":
-        mat = s.add_material_matte_tex(s.add_texture_windy())
-    elif which == "marble":  # a mix material: 0.1 of the blue matte over the marble one
-        mat = s.add_material_mix(s.add_material_matte_tex(s.add_texture_marble(scale=2.0, variation=10.0)), s.add_material_matte((0.01, 0.04, 0.17)), (0.1, 0.1, 0.1))
-    elif which == "dots":    # "rgb inside" [.8 .8 .8] "rgb outside" [.211 .213 .270], handed over swapped (quirk B13)
-        mat = s.add_material_matte_tex(s.add_texture_dots(c((0.211, 0.213, 0.270)), c((0.8, 0.8, 0.8)), 12.0, 12.0))
-    elif which == "bilerp":
-        mat = s.add_material_matte_tex(s.add_texture_bilerp((1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1)))
-    elif which == "uv":
-        mat = s.add_material_matte_tex(s.add_texture_uv(-1.0, -1.0))
-    elif which == "mix":     # the sphere's own: "float amount" 0
-        mat = s.add_material_matte_tex(s.add_texture_mix(s.add_texture_windy(), checks(-16.0, -16.0), c(0.0)))
-    elif which == "scale":
-        mat = s.add_material_matte_tex(s.add_texture_scale(s.add_texture_windy(), checks(-16.0, -16.0)))
-    elif which == "2d-checkerboard":
-        mat = s.add_material_matte_tex(checks(-16.0, -16.0))
-    else:
-        raise ValueError(which)
-    s.add_light_infinite((1.0, 1.0, 1.0))
-    add_sphere(s, ctm(host, host.translate((-1.8, 0, 1)), host.rotate(15, (0, 1, 0)), host.rotate(200, (1, 0, 0)), host.rotate(-30, (0, 0, 1))), 0.8, material=mat)
-    t = ctm(host, host.translate((0, -1, 0)))
-    s.add_mesh(host.transform_points(t[0], np.array([[-20, 0, -20], [20, 0, -20], [20, 0, 20], [-20, 0, 20]], np.float32)), QUAD_IDX, s.add_material_matte((0.5, 0.5, 0.5)), UV=QUAD_ST)
-    camera_film(s, host, (0, 22, 0), (0, 0, 0), (0, 0, 1), 15.0, 400, 400, spp)
-    s.build_accel(0, 4)
-    return dict(max_depth=5, render="textures_" + which)
-
-
 def add_hyperboloid(scene, t, p1, p2, phimax=360.0, material=0):
     import ctypes as C
     L = scene.b.lib
@@ -352,6 +315,58 @@ def textures_2d_mappings(s, host, spp=128, crop=(0.0, 1.0, 0.0, 1.0)):
     s.set_sampler(0, spp, sb)
     s.build_accel(0, 4)
     return dict(max_depth=5, render="textures_2d-mappings", crop=[int(v) for v in cb])
+
+
+def add_quadric(scene, kind, t, radius, a, b, phimax=360.0, material=0):
+    """kind: "cylinder" (a, b = zmin, zmax) | "cone" (a = height) | "paraboloid" (zmin, zmax) | "disk" (a = height, b = innerradius) — oracle only"""
+    import ctypes as C
+    L = scene.b.lib
+    fp = C.POINTER(C.c_float)
+    L.oracle_add_quadric.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32]
+    f = lambda m: np.ascontiguousarray(m, np.float32).ctypes.data_as(fp)
+    scene._chk(L.oracle_add_quadric(scene.h, {"cylinder": 0, "cone": 1, "paraboloid": 2, "disk": 3}[kind], f(t[0]), f(t[1]), radius, a, b, phimax, material, 0))
+
+
+def textures_six_shapes(s, host, which, spp=128):
+    """scenes/textures/<which>.pbrt -> renders/textures/<which>.png in full: sphere, hyperboloid, cone, paraboloid, cylinder, disk (all ORACLE ONLY) in the files' order, each with the
+    texture the file gives it, in front of the wall, under a white sky"""
+    from test_oracle_sphere import add_sphere
+    c = s.add_texture_constant
+    matte = s.add_material_matte_tex
+    checks = lambda su, sv: s.add_texture_checkerboard(c(1.0), c(0.0), su, sv)
+    if which in ("fbm", "wrinkled", "windy", "marble", "dots", "bilerp", "scale"):
+        if which == "fbm": m = matte(s.add_texture_fbm())
+        elif which == "wrinkled": m = matte(s.add_texture_fbm(wrinkled=True))
+        elif which == "windy": m = matte(s.add_texture_windy())
+        elif which == "marble": m = s.add_material_mix(matte(s.add_texture_marble(scale=2.0, variation=10.0)), s.add_material_matte((0.01, 0.04, 0.17)), (0.1, 0.1, 0.1))
+        elif which == "dots": m = matte(s.add_texture_dots(c((0.211, 0.213, 0.270)), c((0.8, 0.8, 0.8)), 12.0, 12.0))   # quirk B13: operands handed over swapped
+        elif which == "bilerp": m = matte(s.add_texture_bilerp((1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1)))
+        else: m = matte(s.add_texture_scale(s.add_texture_windy(), checks(-16.0, -16.0)))
+        mats = [m] * 6
+    elif which == "uv":
+        mats = [matte(s.add_texture_uv(su, sv)) for su, sv in ((-1, -1), (-1, 1), (-1, 1), (1, 1), (1, 1), (-1, 1))]
+    elif which == "2d-checkerboard":
+        mats = [matte(checks(su, sv)) for su, sv in ((-16, -16), (-16, 16), (-16, 16), (16, 16), (16, 16), (-16, 16))]
+    elif which == "mix":
+        t1, t2 = s.add_texture_windy(), checks(-16.0, -16.0)
+        mats = [matte(s.add_texture_mix(t1, t2, c(a))) for a in (0.0, 0.51, 0.17, 0.68, 0.34, 1.0)]
+    elif which == "constant":
+        mats = [matte(c(v)) for v in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (0, 1, 1), (1, 0, 1))]
+    else:
+        raise ValueError(which)
+    s.add_light_infinite((1.0, 1.0, 1.0))
+    R_ = host.rotate; T_ = host.translate
+    add_sphere(s, ctm(host, T_((-1.8, 0, 1)), R_(15, (0, 1, 0)), R_(200, (1, 0, 0)), R_(-30, (0, 0, 1))), 0.8, material=mats[0])
+    add_hyperboloid(s, ctm(host, T_((-1.8, 0, -1)), R_(15, (0, 1, 0)), R_(200, (1, 0, 0)), R_(-15, (0, 0, 1))), (0.6, 0.6, 0.6), (0.6, -0.6, -0.6), material=mats[1])
+    add_quadric(s, "cone", ctm(host, T_((0, 0, 0.4)), R_(15, (0, 1, 0)), R_(15, (1, 0, 0)), R_(150, (0, 0, 1))), 0.8, 1.4, 0.0, material=mats[2])
+    add_quadric(s, "paraboloid", ctm(host, T_((-0.2, 0, -1.8)), R_(15, (0, 1, 0)), R_(15, (1, 0, 0)), R_(30, (0, 0, 1))), 0.8, 0.0, 1.4, material=mats[3])
+    add_quadric(s, "cylinder", ctm(host, T_((1.8, 0, 0.75)), R_(15, (0, 1, 0)), R_(15, (1, 0, 0)), R_(30, (0, 0, 1))), 0.8, -0.6, 0.6, material=mats[4])
+    add_quadric(s, "disk", ctm(host, T_((1.8, 0, -1)), R_(200, (0, 1, 0)), R_(-150, (1, 0, 0)), R_(210, (0, 0, 1))), 0.8, 0.0, 0.0, material=mats[5])
+    t = ctm(host, T_((0, -1, 0)))
+    s.add_mesh(host.transform_points(t[0], np.array([[-20, 0, -20], [20, 0, -20], [20, 0, 20], [-20, 0, 20]], np.float32)), QUAD_IDX, s.add_material_matte((0.5, 0.5, 0.5)), UV=QUAD_ST)
+    camera_film(s, host, (0, 22, 0), (0, 0, 0), (0, 0, 1), 15.0, 400, 400, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=5, render="textures_" + which)
 
 
 def compare(rgb_linear, ref_u8, block=8):

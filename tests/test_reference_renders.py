@@ -155,30 +155,28 @@ def test_oracle_whitted_reproduces_the_glass_spheres_of_depth_of_field():
     assert (d == 0).mean() >= 0.999 and (d <= 1).mean() >= 0.9999 and d.max() <= 4, ((d == 0).mean(), (d <= 1).mean(), d.max())
 
 
-@pytest.mark.parametrize("which", ["fbm", "wrinkled", "windy", "marble", "dots", "bilerp", "uv", "mix", "scale", "2d-checkerboard"])
-def test_oracle_textures_on_the_sphere_sit_where_the_reference_put_them(which):
-    """scenes/textures/<which>.pbrt: six quadrics wearing one texture.  The oracle restates the sphere (oracle only) and the wall; the other five shapes are missing, so a few
-    per cent of the sphere's sky samples that the reference found blocked are open here: the sphere comes out 0.5 - 1.2 of an 8-bit level brighter and not every pixel can be equal.
-    What has to hold: over the sphere's disc the two images correlate above 0.998 (measured 0.9986 - 0.9999), more than half of the pixels are IDENTICAL and the mean difference
-    stays under two levels — fbm, wrinkled (turbulence), windy, marble (as one side of a mix material), dots, bilerp, uv, the mix and scale textures over windy x checkerboard, and
-    the 2-D checkerboard with negative scales all produce the reference's pattern at the reference's place."""
+@pytest.mark.parametrize("which", ["fbm", "wrinkled", "windy", "marble", "dots", "bilerp", "uv", "mix", "scale", "constant", "2d-checkerboard"])
+def test_oracle_whitted_reproduces_the_six_shape_texture_scenes_pixel_for_pixel(which):
+    """scenes/textures/<which>.pbrt: a sphere, a hyperboloid, a cone, a paraboloid, a cylinder and a disk (all six ORACLE ONLY: sphere.rs, hyperboloid.rs, cone.rs, paraboloid.rs,
+    cylinder.rs, disk.rs with EFloat) wearing the file's texture in front of a wall under a white sky, 128 spp.  The oracle's render equals the reference's PNG in 99.996 - 99.999 %
+    of the pixels, the rest one 8-bit level apart: fbm, wrinkled (turbulence), windy, marble inside a mix MATERIAL, dots (operands swapped, quirk B13), bilerp, uv, the mix and scale
+    TEXTURES over windy x checkerboard, constant, and the 2-D checkerboard with its closed-form filter and negative scales — each on six different (u, v) parameterisations.
+    (The four 3-D textures keep only the sphere's corner of the reference image as fixture; the (u, v)-dependent ones are compared whole.)"""
     import ctypes as C
     host = pbrt_hip.Host()
     with pbrt_hip.Scene(oracle_binding()) as s:
-        info = R.textures_sphere(s, host, which, spp=128)
+        info = R.textures_six_shapes(s, host, which, spp=128)
         s.b.lib.oracle_set_integrator.argtypes = [C.c_void_p, C.c_int]
         assert s.b.lib.oracle_set_integrator(s.h, 1) == 0
         xyz, wt, _ = s.render_path(max_depth=5)
         rgb = s.film_to_rgb(xyz, wt)
-    r0, r1, c0, c1 = R.TEX_CROP
-    ref = R.reference_render(info["render"]).astype(np.float64); mine = R.to_8bit(rgb)[r0:r1, c0:c1].astype(np.float64)
-    yy, xx = np.mgrid[0:r1 - r0, 0:c1 - c0]
-    disc = ((yy - 67) ** 2 + (xx - 70) ** 2) < 45 ** 2          # inside the sphere's silhouette
-    a, b = mine[disc].ravel(), ref[disc].ravel()
-    d = np.abs(mine - ref).max(-1)[disc]
-    assert np.corrcoef(a, b)[0, 1] > 0.998
-    assert np.abs(a - b).mean() < 2.0 and -0.2 < (a - b).mean() < 2.0
-    assert (d == 0).mean() > 0.5 and (d <= 2).mean() > 0.8
+    ref = R.reference_render(info["render"])
+    mine = R.to_8bit(rgb)
+    if ref.shape[0] != 400:
+        r0, r1, c0, c1 = R.TEX_CROP
+        mine = mine[r0:r1, c0:c1]
+    d = np.abs(mine.astype(np.int32) - ref.astype(np.int32)).max(-1)
+    assert (d == 0).mean() >= 0.9995 and d.max() <= 2, ((d == 0).mean(), d.max())
 
 
 def test_oracle_whitted_reproduces_the_image_maps_under_the_four_2d_mappings():
