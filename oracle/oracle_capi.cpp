@@ -222,6 +222,19 @@ int oracle_add_sphere(OracleScene* s, const float o2w_m[16], const float o2w_min
     s->built = false;
     return 0;
 }
+// AreaLightSource "diffuse" on the sphere added LAST (ORACLE ONLY): the sphere becomes the shape of a DiffuseAreaLight (lights/src/diffuse.rs) with radiance L
+int oracle_make_last_sphere_a_light(OracleScene* s, const float L[3], int two_sided) {
+    if (!s || !L) return -1;
+    Scene& sc = s->sc;
+    if (sc.spheres.empty() || sc.meshes.empty() || sc.meshes.back().sphere != (int)sc.spheres.size() - 1) { s->err = "the last shape is not a sphere"; return -2; }
+    Light l{}; l.type = L_AREA; l.L = spec3(L); l.two_sided = two_sided; l.sphere = (int)sc.spheres.size() - 1; l.prim = sc.meshes.back().tri_base;
+    const Sphere& sp = sc.spheres.back();
+    l.area = sp.phi_max * sp.radius * (sp.z_max - sp.z_min);
+    sc.meshes.back().first_light = (int32_t)sc.lights.size();
+    sc.lights.push_back(l);
+    s->built = false;
+    return 0;
+}
 // Shape "hyperboloid" (hyperboloid.rs:392-416 reads p1, p2, phimax) — ORACLE ONLY
 int oracle_add_hyperboloid(OracleScene* s, const float o2w_m[16], const float o2w_minv[16], const float p1[3], const float p2[3], float phi_max, uint32_t material_id, uint32_t flags) {
     if (!s || !o2w_m || !o2w_minv || !p1 || !p2) return -1;

@@ -674,6 +674,46 @@ struct Renderer {
             r.wi = normalize(l.p_light - hit.p); r.pdf = 1.0f; r.vp = l.p_light;
             r.value = l.L / distance_squared(l.p_light, hit.p); r.valid = true; return r;
         case L_AREA: {   // diffuse.rs:114-129 -> Shape::sample_solid_angle (shape.rs:64-84) -> Triangle::sample (triangle.rs:918-949)
+            if (l.sphere >= 0) {   // Sphere::sample_solid_angle (sphere.rs:344-410): uniform over the cone the sphere subtends, or over its area from inside
+                const Sphere& sp = s.spheres[(size_t)l.sphere];
+                const V3 p_center = sp.o2w.point(V3(0, 0, 0));
+                V3 p, n, p_error; Float pdf;
+                const V3 p_origin = offset_origin(hit.p, hit.p_error, hit.n, p_center - hit.p);
+                if (distance_squared(p_origin, p_center) <= sp.radius * sp.radius) {
+                    const Float z = 1.0f - 2.0f * u.x, rr = std::sqrt(pmax(0.0f, 1.0f - z * z)), phi = TWO_PI * u.y;   // uniform_sample_sphere
+                    V3 p_obj = sp.radius * V3(rr * o_cos(phi), rr * o_sin(phi), z);
+                    n = normalize(sp.o2w.normal(p_obj));
+                    if (sp.reverse_orientation) n = n * -1.0f;
+                    p_obj = p_obj * (sp.radius / distance(p_obj, V3(0, 0, 0)));
+                    V3 pe; p = sp.o2w.point_with_abs_error(p_obj, gamma_n(5) * vabs(p_obj), pe); p_error = pe;
+                    pdf = 1.0f / (sp.phi_max * sp.radius * (sp.z_max - sp.z_min));   // 1 / area()
+                    V3 wi = p - hit.p;
+                    if (length_squared(wi) == 0.0f) pdf = 0.0f;
+                    else { wi = normalize(wi); pdf *= distance_squared(hit.p, p) / abs_dot(n, -wi); }
+                    if (std::isinf(pdf)) pdf = 0.0f;
+                } else {
+                    const Float dc = distance(hit.p, p_center), inv_dc = 1.0f / dc;
+                    const V3 wc = (p_center - hit.p) * inv_dc;
+                    V3 wc_x, wc_y; coordinate_system(wc, wc_x, wc_y);
+                    const Float sin_theta_max = sp.radius * inv_dc, sin_theta_max2 = sin_theta_max * sin_theta_max, inv_sin_theta_max = 1.0f / sin_theta_max;
+                    const Float cos_theta_max = std::sqrt(pmax(0.0f, 1.0f - sin_theta_max2));
+                    Float cos_theta = (cos_theta_max - 1.0f) * u.x + 1.0f, sin_theta2 = 1.0f - cos_theta * cos_theta;
+                    if (sin_theta_max2 < 0.00068523f) { sin_theta2 = sin_theta_max2 * u.x; cos_theta = std::sqrt(1.0f - sin_theta2); }
+                    const Float cos_alpha = sin_theta2 * inv_sin_theta_max + cos_theta * std::sqrt(pmax(0.0f, 1.0f - sin_theta2 * inv_sin_theta_max * inv_sin_theta_max));
+                    const Float sin_alpha = std::sqrt(pmax(0.0f, 1.0f - cos_alpha * cos_alpha));
+                    const Float phi = u.y * TWO_PI;
+                    const V3 n_world = (sin_alpha * o_cos(phi)) * (-wc_x) + (sin_alpha * o_sin(phi)) * (-wc_y) + cos_alpha * (-wc);   // spherical_direction_in_coord_frame
+                    p = p_center + sp.radius * n_world;
+                    p_error = gamma_n(5) * vabs(p);
+                    n = n_world;
+                    if (sp.reverse_orientation) n = n * -1.0f;
+                    pdf = 1.0f / (TWO_PI * (1.0f - cos_theta_max));   // uniform_cone_pdf
+                }
+                V3 wi2 = p - hit.p; const Float l2 = length_squared(wi2);   // DiffuseAreaLight::sample_li (diffuse.rs:114-129)
+                if (pdf == 0.0f || l2 == 0.0f) return r;
+                wi2 = wi2 / std::sqrt(l2);
+                r.wi = wi2; r.pdf = pdf; r.value = area_L(l, n, -wi2); r.vp = p; r.vperr = p_error; r.vn = n; r.valid = true; return r;
+            }
             uint32_t prim = l.prim; const Mesh& m = s.mesh_of(prim);
             uint32_t i0 = s.idx[3 * prim], i1 = s.idx[3 * prim + 1], i2 = s.idx[3 * prim + 2];
             V3 p0 = s.P[i0], p1 = s.P[i1], p2 = s.P[i2];

@@ -77,6 +77,7 @@ struct Light {
     Float cos_total_width = 0, cos_falloff_start = 0;  // spot (lights/src/spot.rs:24-25); l2w holds its light_to_world
     int two_sided;      // area
     uint32_t prim;      // area: global triangle index bound to this light
+    int sphere = -1;    // area light whose shape is scene.spheres[sphere] (ORACLE ONLY, for the reference's lights/diffuse.pbrt); prim is then the sphere's primitive slot
     Float area;         // area: Triangle::area()
     // infinite: 2x2 scalar image distribution (lights/src/infinite.rs:326-369, sampling/distribution_2d.rs)
     Float cond_func[2][2], cond_cdf[2][3], cond_int[2];

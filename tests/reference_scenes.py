@@ -369,6 +369,20 @@ def textures_six_shapes(s, host, which, spp=128):
     return dict(max_depth=5, render="textures_" + which)
 
 
+def lights_diffuse(s, host, spp=128, res=400):
+    """scenes/lights/diffuse.pbrt -> renders/lights/diffuse.png: a SPHERE of radius 3 (oracle only) as the shape of a DiffuseAreaLight (L = 20), over the cube and the checkered floor"""
+    import ctypes as C
+    from test_oracle_sphere import add_sphere
+    add_sphere(s, ctm(host, host.translate((-10, 0, 10))), 3.0, material=s.add_material_matte((0.0, 0.0, 0.0)))
+    L = s.b.lib
+    L.oracle_make_last_sphere_a_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    s._chk(L.oracle_make_last_sphere_a_light(s.h, np.array([20.0, 20.0, 20.0], np.float32).ctypes.data_as(C.POINTER(C.c_float)), 0))
+    _cube_and_checker_floor(s, host)
+    camera_film(s, host, (0, 5, 3), (0, 0, 0), (0, 0, 1), 90.0, res, res, spp)
+    s.build_accel(0, 4)
+    return dict(max_depth=5, render="lights_diffuse")
+
+
 def compare(rgb_linear, ref_u8, block=8):
     """-> dict: mean |delta| in 8-bit levels per pixel, fraction of pixels with a channel off by more than 12 levels, and the same two over block x block means (sampling
     noise averages out of those: the path integrator's estimator differs from Whitted's where a scene has an area-like light or several lights)"""

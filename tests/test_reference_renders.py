@@ -110,7 +110,7 @@ def test_sampler_scenes_background_masks_equal_the_references_renders():
 # needs no statistics: same samples, same light draws, same pixels.
 WHITTED = [("triangles_alpha_mask", 128), ("lights_point", 128), ("lights_spot", 128), ("lights_goniometric", 128), ("lights_distant", 128), ("lights_infinite_no_map", 128),
            ("cameras_perspective", 128), ("cameras_orthographic", 128), ("cameras_environment", 128), ("objects_instances", 128), ("materials_bump", 128),
-           ("samplers_halton", 16), ("samplers_sobol", 16)]
+           ("samplers_halton", 16), ("samplers_sobol", 16), ("lights_diffuse", 128)]   # lights_diffuse: a spherical DiffuseAreaLight (oracle only), soft shadows
 
 
 @pytest.mark.parametrize("name,spp", WHITTED)
