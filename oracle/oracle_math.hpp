@@ -3,7 +3,7 @@
 // The product (pbrt-v3-rs_amd/) never includes or links anything under oracle/.
 //
 // Parity pin status: the reference's own tests cover only core/src/geometry (277 #[test]s); every one of them is
-// replayed or accounted for in tests/test_reference_proptests.py (+ tests/test_oracle_geometry.py).  The reference's own RENDERS of 27 scenes
+// replayed or accounted for in tests/test_reference_proptests.py (+ tests/test_oracle_geometry.py).  The reference's own RENDERS of 28 scenes
 // (renders/**.png, all made with its Whitted integrator, which the oracle restates for this purpose) are reproduced PIXEL FOR PIXEL, Monte Carlo noise included
 // (tests/test_reference_renders.py); its render of scenes/shapes/sphere.pbrt pins the Sphere's silhouettes (tests/test_oracle_sphere.py).  Beyond the first bounce (indirect light, Russian roulette) and for the non-matte materials there are NO reference
 // outputs or golden vectors and the reference (Rust) cannot be built here: for those parts parity is "unpinned" except for the PCG32 / Halton-permutation

@@ -177,6 +177,18 @@ struct HaltonSampler {
     }
 };
 
+// RandomSampler (samplers/src/random.rs) — ORACLE ONLY (its draws depend on the order in which a tile's pixels and samples are visited): `clone_sampler(seed)` gives every
+// tile an RNG on sequence `seed` = the tile's index (sampler_integrator.rs:322); every value is the next uniform_float of that stream, camera samples and light samples alike
+struct RandomSampler {
+    RNG rng; uint32_t spp, sample_num = 0;
+    RandomSampler(const SamplerConfig& c, uint64_t seed) : rng(seed), spp(c.spp) {}
+    void start_pixel(int, int) { sample_num = 0; }   // no sample arrays are requested on this path: start_pixel draws nothing
+    bool start_next_sample() { sample_num++; return sample_num < spp; }
+    void set_sample_number(uint32_t s) { sample_num = s; }
+    Float get_1d() { return rng.uniform_float(); }
+    V2 get_2d() { const Float x = rng.uniform_float(); const Float y = rng.uniform_float(); return V2(x, y); }
+};
+
 // SobolSampler (samplers/src/sobol.rs:35-93, core/src/low_discrepency.rs:1770-1848)
 struct SobolSampler {
     SobolTables tb; uint32_t spp; int bounds[4]; int resolution, log2_res;
@@ -1726,6 +1738,7 @@ struct Renderer {
                 int tb[4]; tile_bounds(t, ntx, sb, tile_size, tb);
                 tiles[t] = get_film_tile(tb);
                 if (scfg.kind == 0) { HaltonSampler sp(scfg); render_tile_with(sp, tb, tiles[t]); }
+                else if (scfg.kind == 2) { RandomSampler sp(scfg, (uint64_t)t); render_tile_with(sp, tb, tiles[t]); }
                 else { SobolSampler sp(scfg); render_tile_with(sp, tb, tiles[t]); }
             }
         };

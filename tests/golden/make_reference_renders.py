@@ -10,7 +10,7 @@ sys.path.insert(0, HERE)
 from make_sphere_mask import read_png  # noqa: E402
 
 NAMES = ["shapes/triangles-alpha-mask", "cameras/perspective", "cameras/orthographic", "cameras/environment", "lights/point", "lights/distant", "lights/spot",
-         "lights/infinite-no-map", "lights/goniometric", "objects/instances", "materials/bump", "samplers/halton", "samplers/sobol", "cameras/depth-of-field", "textures/fbm", "textures/marble", "textures/wrinkled", "textures/windy", "textures/dots", "textures/bilerp", "textures/uv", "textures/mix", "textures/scale", "textures/2d-checkerboard", "textures/2d-mappings", "textures/constant", "lights/diffuse"]
+         "lights/infinite-no-map", "lights/goniometric", "objects/instances", "materials/bump", "samplers/halton", "samplers/sobol", "cameras/depth-of-field", "textures/fbm", "textures/marble", "textures/wrinkled", "textures/windy", "textures/dots", "textures/bilerp", "textures/uv", "textures/mix", "textures/scale", "textures/2d-checkerboard", "textures/2d-mappings", "textures/constant", "lights/diffuse", "samplers/random"]
 TEX_CROP = (60, 195, 5, 145)  # rows, columns
 # the 3-D textures do not depend on a shape's parameterisation: the sphere's corner of the image is kept; the scenes with 2-D (u, v) textures are kept whole
 TEX_CROPPED = ("textures/fbm", "textures/wrinkled", "textures/windy", "textures/marble")

@@ -251,6 +251,8 @@ def samplers_scene(s, host, sampler, spp=16):
         z = np.load(os.path.join(HERE, "golden", "sobol_subset.npz"))
         s.set_sobol_tables(z["m32"], z["vdc"], z["vdc_inv"])
         s.set_sampler(1, spp, sb)
+    elif sampler == "random":
+        s.set_sampler(2, spp, sb)   # oracle only
     else:
         s.set_sampler(0, spp, sb)
     s.build_accel(0, 4)

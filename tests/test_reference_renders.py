@@ -110,7 +110,7 @@ def test_sampler_scenes_background_masks_equal_the_references_renders():
 # needs no statistics: same samples, same light draws, same pixels.
 WHITTED = [("triangles_alpha_mask", 128), ("lights_point", 128), ("lights_spot", 128), ("lights_goniometric", 128), ("lights_distant", 128), ("lights_infinite_no_map", 128),
            ("cameras_perspective", 128), ("cameras_orthographic", 128), ("cameras_environment", 128), ("objects_instances", 128), ("materials_bump", 128),
-           ("samplers_halton", 16), ("samplers_sobol", 16), ("lights_diffuse", 128)]   # lights_diffuse: a spherical DiffuseAreaLight (oracle only), soft shadows
+           ("samplers_halton", 16), ("samplers_sobol", 16), ("samplers_random", 16), ("lights_diffuse", 128)]   # lights_diffuse: a spherical DiffuseAreaLight (oracle only), soft shadows
 
 
 @pytest.mark.parametrize("name,spp", WHITTED)
@@ -125,6 +125,8 @@ def test_oracle_whitted_reproduces_the_references_render_pixel_for_pixel(name, s
     host = pbrt_hip.Host()
     with pbrt_hip.Scene(oracle_binding()) as s:
         info = R.samplers_scene(s, host, name.split("_")[1], spp=spp) if name.startswith("samplers_") else getattr(R, name)(s, host, spp=spp)
+        # samplers_random: the RandomSampler (oracle only) — one PCG32 stream per tile, seeded with the tile's index, drawn from in the order render_tile visits pixels and samples:
+        # equal pixels mean the same tile enumeration, the same pixel loop and the same number of draws per camera sample as the reference
         s.b.lib.oracle_set_integrator.argtypes = [C.c_void_p, C.c_int]
         s.b.lib.oracle_whitted_met_specular.argtypes = [C.c_void_p]
         assert s.b.lib.oracle_set_integrator(s.h, 1) == 0
