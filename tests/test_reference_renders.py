@@ -12,7 +12,7 @@ import reference_scenes as R
 from oracle_binding import oracle_binding
 
 # (builder, samples per pixel here; the reference used 128)
-DETERMINISTIC = [("triangles_alpha_mask", 32), ("lights_point", 32), ("lights_spot", 32), ("lights_goniometric", 32), ("lights_distant", 32)]
+DETERMINISTIC = [("triangles_alpha_mask", 128), ("lights_point", 128), ("lights_spot", 128), ("lights_goniometric", 128), ("lights_distant", 128)]
 NOISY = [("lights_infinite_no_map", 64), ("cameras_perspective", 64), ("cameras_orthographic", 64), ("cameras_environment", 64), ("objects_instances", 64)]
 
 
@@ -30,6 +30,10 @@ def check_against_reference(rgb, info, noisy):
         # one delta light on matte surfaces: Whitted's sum and the path integrator's direct term are the same single product; what is left is 8-bit rounding and the
         # pixel-edge estimate (the reference averaged 128 samples per pixel)
         assert c["mean"] < 0.2 and c["bad"] < 0.003 and c["block_mean"] < 0.06 and c["block_bad"] == 0.0, c
+        # ... and at the reference's own 128 spp the PATH integrator at maxdepth 1 draws the same camera samples and evaluates the same single light term as Whitted (only the
+        # order of two multiplications differs): the render equals the reference's PNG pixel for pixel (measured: 99.999 - 100 % identical, never more than one level apart)
+        d = np.abs(R.to_8bit(rgb).astype(np.int32) - R.reference_render(info["render"]).astype(np.int32)).max(-1)
+        assert (d == 0).mean() >= 0.9995 and d.max() <= 2, ((d == 0).mean(), d.max())
     else:
         # an infinite light (one light sample in Whitted, light + BSDF sample with MIS here) and / or two lights (both in Whitted, one of the two picked here): same expectation
         assert c["mean"] < 4.0 and c["bad"] < 0.06 and c["block_mean"] < 0.35 and c["block_bad"] < 0.002, c

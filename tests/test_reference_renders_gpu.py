@@ -1,4 +1,5 @@
-"""-m gpu: the PRODUCT against output of the reference itself — the ten scenes of tests/test_reference_renders.py rendered by libpbrt_hip.so on the MI355X and held
+"""-m gpu: the PRODUCT against output of the reference itself (for the five delta-light scenes PIXEL FOR PIXEL: at the reference's 128 spp the device's path integrator at maxdepth 1
+draws the same camera samples and evaluates the same light term as the reference's Whitted render) — the ten scenes of tests/test_reference_renders.py rendered by libpbrt_hip.so on the MI355X and held
 against the renders the reference commits (renders/**.png), with the same thresholds as the oracle; and, for every scene, the device film against the oracle's film bit
 for bit (libm mode 1), so that "oracle == reference render" and "device == oracle" are shown on the same inputs."""
 import numpy as np
@@ -64,7 +65,7 @@ SKY_AND_SUN = 'LightSource "infinite" "rgb L" [.4 .45 .5]\nLightSource "distant"
 RED_CUBE = f'AttributeBegin\n Rotate 45 0 0 1\n Material "matte" "rgb Kd" [.2 .01 .01]\n {CUBE_TXT}\nAttributeEnd\n'
 SCENE_TEXTS = {
     "lights_distant": (lambda spp: _head("0 5 3  0 0 0  0 0 1", '"perspective" "float fov" 90', 400, 400, spp) +
-                       'LightSource "distant" "point from" [ -5 0 5 ] "point to" [0 0 0] "blackbody L" [4500 1.5]\n' + RED_CUBE + _floor_txt(.3) + "WorldEnd\n", 32, False),
+                       'LightSource "distant" "point from" [ -5 0 5 ] "point to" [0 0 0] "blackbody L" [4500 1.5]\n' + RED_CUBE + _floor_txt(.3) + "WorldEnd\n", 128, False),
     "cameras_orthographic": (lambda spp: _head("0 10 10  0 0 0  0 0 1", '"orthographic"', 400, 400, spp) + SKY_AND_SUN + "Scale 0.25 0.25 0.25\n" + RED_CUBE + _floor_txt(.1) + "WorldEnd\n",
                              64, True),
     "objects_instances": (lambda spp: _head("0 7 15  0 0 0  0 0 1", '"perspective" "float fov" 45', 400, 400, spp, extra="Translate 0 -1 0\n") + SKY_AND_SUN +
