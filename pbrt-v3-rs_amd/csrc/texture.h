@@ -22,7 +22,9 @@ PH_DEV long long rem_ll(long long a, long long b) { long long r = a - (a / b) * 
 
 PH_DEV spec mip_texel(const DeviceScene& sc, const MipRec& m, uint32_t level, long long s, long long t) {
     const long long w = (long long)m.level_w[level], h = (long long)m.level_h[level];
-    if (m.wrap == 0u) { s = rem_ll(s, w); t = rem_ll(t, h); }
+    // repeat: every pyramid level is a power of two wide and high (MIPMap::new resamples other sizes first, mipmap/mod.rs:383-529), and for a power of two `rem(a, b)` with its
+    // "negative remainder + b" (pbrt/common.rs:116-126) is the two's-complement mask — no 64-bit division per texel
+    if (m.wrap == 0u) { s = s & (w - 1); t = t & (h - 1); }
     else if (m.wrap == 2u) { s = s < 0 ? 0 : (s > w - 1 ? w - 1 : s); t = t < 0 ? 0 : (t > h - 1 ? h - 1 : t); }
     else if (s < 0 || s >= w || t < 0 || t >= h) return mks1(0.0f);
     const float4 v = *reinterpret_cast<const float4*>(sc.texels + ((size_t)m.level_off[level] + (size_t)t * (size_t)w + (size_t)s));
