@@ -924,10 +924,9 @@ int oracle_render_path(OracleScene* s, int max_depth, float rr_threshold, int li
 // ORACLE ONLY: render_path runs WhittedIntegrator::li instead of PathIntegrator::li (0 restores the path integrator); max_depth keeps its meaning
 int oracle_set_integrator(OracleScene* s, int kind) {
     if (!s || kind < 0 || kind > 1) return -1;
-    s->r.integrator = kind; s->r.whitted_unsupported = false;
+    s->r.integrator = kind;
     return 0;
 }
-int oracle_whitted_met_specular(const OracleScene* s) { return s && s->r.whitted_unsupported ? 1 : 0; }
 int oracle_film_to_rgb(const OracleScene* s, const float* xyz, const float* weight, float* rgb) {
     if (!s || !xyz || !weight || !rgb) return -1;
     s->r.film_to_rgb(xyz, weight, rgb); return 0;

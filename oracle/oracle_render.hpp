@@ -1352,10 +1352,9 @@ struct Renderer {
     }
 
     // ---- WhittedIntegrator::li (integrators/src/whitted.rs:51-118) — ORACLE ONLY: every render the reference commits next to its example scenes was made with it, so
-    // the oracle can be held against those pixels sample for sample.  One light sample per light and camera sample (`sampler.get_2d()` in the lights' order), no MIS;
-    // the specular recursion (specular_reflect / specular_transmit) is restated for its sampler draws only — the scenes compared are matte, both terms are black there.
+    // the oracle can be held against those pixels sample for sample.  One light sample per light and camera sample (`sampler.get_2d()` in the lights' order), no MIS,
+    // then the specular recursion (whitted_specular below).
     int integrator = 0;  // 0 path, 1 whitted
-    bool whitted_unsupported = false;  // a specular lobe was met: the recursion is not restated, the result is not the reference's
     template <class S> Spec li_whitted(Ray ray, S& sampler, int depth) {
         const Scene& s = *sc;
         Spec L(0.0f);

@@ -132,10 +132,8 @@ def test_oracle_whitted_reproduces_the_references_render_pixel_for_pixel(name, s
         # samplers_random: the RandomSampler (oracle only) — one PCG32 stream per tile, seeded with the tile's index, drawn from in the order render_tile visits pixels and samples:
         # equal pixels mean the same tile enumeration, the same pixel loop and the same number of draws per camera sample as the reference
         s.b.lib.oracle_set_integrator.argtypes = [C.c_void_p, C.c_int]
-        s.b.lib.oracle_whitted_met_specular.argtypes = [C.c_void_p]
         assert s.b.lib.oracle_set_integrator(s.h, 1) == 0
         xyz, wt, _ = s.render_path(max_depth=5)   # Integrator "whitted" default maxdepth
-        assert s.b.lib.oracle_whitted_met_specular(s.h) == 0
         rgb = s.film_to_rgb(xyz, wt)
     d = np.abs(R.to_8bit(rgb).astype(np.int32) - R.reference_render(info["render"]).astype(np.int32)).max(-1)
     assert (d == 0).mean() >= 0.999, ((d == 0).mean(), d.max())
