@@ -75,13 +75,46 @@ SCENE_TEXTS = {
 }
 
 
+CHECKS_ALPHA = ('AttributeBegin\n Texture "alpha" "float" "dots" "float inside" 1 "float outside" 0 "float uscale" 10 "float vscale" 10\n Rotate 135 0 0 1\n'
+                f' Material "matte" "rgb Kd" [.2 .01 .01]\n {CUBE_TXT} "texture alpha" "alpha"\nAttributeEnd\n')
+POINT = 'LightSource "point" "rgb I" [.4 .45 .5] "point from" [-5 0 5] "rgb scale" [200 200 200]\n'
+HEAD_LIGHTS = lambda spp: _head("0 5 3  0 0 0  0 0 1", '"perspective" "float fov" 90', 400, 400, spp)
+SCENE_TEXTS.update({
+    # the dots texture with the file's own "inside" 1 / "outside" 0 (the front end swaps them as the reference does, quirk B13), as alpha mask of the cube
+    "triangles_alpha_mask": (lambda spp: HEAD_LIGHTS(spp) + POINT + CHECKS_ALPHA + _floor_txt(.3) + "WorldEnd\n", 128, False),
+    "lights_point": (lambda spp: HEAD_LIGHTS(spp) + POINT + RED_CUBE + _floor_txt(.3) + "WorldEnd\n", 128, False),
+    # "float conedelta" 20 is what the reference's file says; nothing reads it (spot.rs:156 asks for "conedeltaangle"): the default rim of 5 degrees applies
+    "lights_spot": (lambda spp: HEAD_LIGHTS(spp) + 'LightSource "spot" "rgb I" [.4 .45 .5] "point from" [-5 0 5] "point to" [0 0 0] "rgb scale" [200 200 200] "float coneangle" 25 "float conedelta" 20\n' +
+                    RED_CUBE + _floor_txt(.3) + "WorldEnd\n", 128, False),
+    # the goniometric map is written next to the scene as a PNG (from the fixture's pixels) and read back by the front end's own PNG decoder
+    "lights_goniometric": (lambda spp: HEAD_LIGHTS(spp) + 'AttributeBegin\n Translate -5 0 5\n Rotate 135 1 0 0\n Rotate 60 0 1 0\n LightSource "goniometric" "rgb I" [.4 .45 .5] "rgb scale" [200 200 200] '
+                           '"float fov" 45 "string mapname" "gonio.png"\nAttributeEnd\n' + RED_CUBE + _floor_txt(.3) + "WorldEnd\n", 128, False),
+    "cameras_environment": (lambda spp: _head("0 0 1  0 1 0  0 0 1", '"environment"', 800, 400, spp) + SKY_AND_SUN + 'Material "matte" "rgb Kd" [.8 .1 .01]\n' +
+                            "".join(f'AttributeBegin\n{"" if k == 0 else f" Rotate {36 * k} 0 0 1" + chr(10)} Translate 0 5 0\n Rotate 45 0 0 1\n {CUBE_TXT}\nAttributeEnd\n' for k in range(10)) +
+                            _floor_txt(.1) + "WorldEnd\n", 64, True),
+})
+
+
+def _write_png(path, rgb_u8):
+    import struct
+    import zlib
+    h, w, _ = rgb_u8.shape
+    raw = b"".join(b"\x00" + rgb_u8[y].tobytes() for y in range(h))
+    chunk = lambda t, c: struct.pack(">I", len(c)) + t + c + struct.pack(">I", zlib.crc32(t + c) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
 @pytest.mark.parametrize("name", sorted(SCENE_TEXTS))
 def test_front_end_renders_the_references_scene_text_like_the_reference(tmp_path, name):
     import subprocess
     import driver_scene as ds
     make, spp, noisy = SCENE_TEXTS[name]
     (tmp_path / "scene.pbrt").write_text(make(spp))
+    if name == "lights_goniometric":
+        import os
+        _write_png(str(tmp_path / "gonio.png"), np.load(os.path.join(R.HERE, "golden", "ref_renders", "image_goniometric-upward-downward.npz"))["rgb"])
     r = subprocess.run([ds.RENDER_BIN, "--quiet", str(tmp_path / "scene.pbrt")], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     img = ds.read_pfm(str(tmp_path / "out.pfm"))
-    check_against_reference(img, dict(render=name), noisy)
+    check_against_reference(img, dict(render={"triangles_alpha_mask": "shapes_triangles-alpha-mask"}.get(name, name)), noisy)
