@@ -199,13 +199,13 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
 #define PH_VARIANTS(X) X(0, 20, 12, 12, 3, 0, false) X(1, 20, 12, 12, 2, 0, false) X(2, 20, 12, 12, 1, 0, false) X(3, 24, 12, 12, 2, 0, false) X(4, 16, 12, 12, 2, 0, false) X(5, 28, 16, 12, 2, 0, false) \
     X(6, 20, 16, 12, 2, 0, false) X(7, 20, 8, 12, 2, 0, false) X(8, 24, 16, 10, 2, 0, false) X(9, 24, 12, 12, 4, 0, false) X(10, 20, 12, 11, 3, 7, false) X(11, 24, 12, 11, 4, 7, false) \
     X(12, 20, 12, 10, 3, 8, false) X(13, 24, 12, 12, 4, 6, false) X(14, 20, 12, 12, 5, 0, false) X(15, 24, 12, 11, 5, 7, false) \
-    X(16, 24, 12, 11, 4, 7, true) X(17, 24, 12, 12, 4, 6, true) X(18, 20, 12, 12, 3, 0, true) X(19, 24, 12, 12, 5, 6, false)
+    X(19, 24, 12, 12, 5, 6, false)   /* 16 - 18 were the packed-arithmetic kernels of round 2 (dropped) */
 #define PH_N_VARIANTS 20
 #define PH_DEFAULT_INST_VARIANT 1   // 1 000 instances x 10 k triangles: 95.0 ms of traversal per frame against 102.9 (variant 0), 101.7 (2), 109.0 (3) (gpurun r02n)
 #define PH_DEFAULT_VARIANT 19   // measured on configs[2] / configs[1] with binned queues: 742.6 / 31.3 ms of traversal per frame against 760.2 / 31.7 for variant 0 (gpurun r02h)
 static int trav_variant() {
     static int v = -1;
-    if (v < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_VARIANT"); v = e ? std::atoi(e) : PH_DEFAULT_VARIANT; if (v < 0 || v >= PH_N_VARIANTS) v = PH_DEFAULT_VARIANT; }
+    if (v < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_VARIANT"); v = e ? std::atoi(e) : PH_DEFAULT_VARIANT; if (v < 0 || v >= PH_N_VARIANTS || (v >= 16 && v <= 18)) v = PH_DEFAULT_VARIANT; }
     return v;
 }
 static int variant_lds_depth(int v) {
@@ -223,7 +223,7 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
         PH_CHECK(s, hipGetDeviceProperties(&prop, s->device));
         int per_cu = 0;
         switch (trav_variant()) {
-#define X(id, lm, rm, ld, ns, wpe, pk) case id: PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false, lm, rm, ld, ns, false, true, false, wpe, pk>, PH_TRAV_BLOCK, 0)); if (wpe) per_cu = std::min(per_cu, wpe); break;
+#define X(id, lm, rm, ld, ns, wpe, pk) case id: PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false, lm, rm, ld, ns, false, true, false, wpe>, PH_TRAV_BLOCK, 0)); if (wpe) per_cu = std::min(per_cu, wpe); break;
             PH_VARIANTS(X)
 #undef X
         }
@@ -251,9 +251,9 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
     const dim3 g(blocks), b(PH_TRAV_BLOCK);
 #define PH_LAUNCH3(cnt, lm, rm, ld, ns, inst, wpe, pk)                                                                                                  \
     do {                                                                                                                                           \
-        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, true, false, wpe, pk>), g, b, 0, s->stream, s->ds, p);   \
-        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, false, wpe, pk>), g, b, 0, s->stream, s->ds, p); \
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, false, wpe, pk>), g, b, 0, s->stream, s->ds, p);             \
+        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, true, false, wpe>), g, b, 0, s->stream, s->ds, p);   \
+        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, false, wpe>), g, b, 0, s->stream, s->ds, p); \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, false, wpe>), g, b, 0, s->stream, s->ds, p);             \
     } while (0)
 #define PH_LAUNCH3A(inst)                                                                                                              \
     do {                                                                                                                              \

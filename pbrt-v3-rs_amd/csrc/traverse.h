@@ -127,29 +127,16 @@ PH_DEV float vmin3(float a, float b, float c) {
 //  * NaNs (0 x inf: a ray parallel to a slab with its origin on the slab's plane): every comparison with a NaN is false.  A NaN y or z distance
 //    therefore neither misses nor replaces t_min / t_max in the reference — exactly what the hardware's max3 / min3 do with a quiet NaN operand.  A NaN
 //    x distance is what t_min / t_max START as, survives every update and fails the final comparison: the reference misses; hence the `ordered` term.
-// PK: the six subtractions and six multiplications of a box written as three + three two-float operations (v_pk_add_f32 / v_pk_mul_f32)
-typedef float ph_v2f __attribute__((ext_vector_type(2)));
-template <bool PK = false>
 PH_DEV bool box_test(const RayState& r, float xn, float xf, float yn, float yf, float zn, float zf, float& t_min_out) {
-    float t_x_min, t_x_max, t_y_min, t_y_max, t_z_min, t_z_max;
-    if (PK) {
-    const ph_v2f one_s = {1.0f, kBoxScale};
-    ph_v2f tx = ((ph_v2f){xn, xf} - (ph_v2f){r.ox, r.ox}) * (ph_v2f){r.ix, r.ix};
-    ph_v2f ty = ((ph_v2f){yn, yf} - (ph_v2f){r.oy, r.oy}) * (ph_v2f){r.iy, r.iy};
-    const ph_v2f tz = ((ph_v2f){zn, zf} - (ph_v2f){r.oz, r.oz}) * (ph_v2f){r.iz, r.iz};
-    tx = tx * one_s;   // x * 1.0f is x, bit for bit: only the far planes of x and y are widened
-    ty = ty * one_s;
-    t_x_min = tx.x; t_x_max = tx.y; t_y_min = ty.x; t_y_max = ty.y; t_z_min = tz.x; t_z_max = tz.y;
-    } else {
-    t_x_min = (xn - r.ox) * r.ix;
-    t_x_max = (xf - r.ox) * r.ix;
-    t_y_min = (yn - r.oy) * r.iy;
-    t_y_max = (yf - r.oy) * r.iy;
+    // (the same arithmetic as three + three packed two-float operations, v_pk_add_f32 / v_pk_mul_f32, was measured in round 2: more registers, no gain — DESIGN §7b)
+    float t_x_min = (xn - r.ox) * r.ix;
+    float t_x_max = (xf - r.ox) * r.ix;
+    const float t_y_min = (yn - r.oy) * r.iy;
+    float t_y_max = (yf - r.oy) * r.iy;
     t_x_max *= kBoxScale;
     t_y_max *= kBoxScale;
-    t_z_min = (zn - r.oz) * r.iz;
-    t_z_max = (zf - r.oz) * r.iz;
-    }
+    const float t_z_min = (zn - r.oz) * r.iz;
+    const float t_z_max = (zf - r.oz) * r.iz;
     const float t_min = vmax3(t_x_min, t_y_min, t_z_min);
     const float t_max = vmin3(t_x_max, t_y_max, t_z_max);
     t_min_out = t_min;
@@ -235,7 +222,7 @@ static __device__ __noinline__ bool alpha_accept(const DeviceScene* dsc, uint32_
 // WPE > 0 compiles the kernel for exactly that many waves per SIMD (= resident 256-thread blocks per CU): the register allocator then fits the budget
 // (7: 72 VGPRs, 8: 64) instead of taking what it likes; 0 leaves the choice to the compiler (same code as before).
 template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1, bool INST = false, bool MIXED = false,
-          bool ALPHA = false, int WPE = 0, bool PK = false>
+          bool ALPHA = false, int WPE = 0>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
     const uint32_t tid = threadIdx.x;
@@ -358,9 +345,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
             if (COUNT) c_nodes[(MIXED && ah) ? 1 : 0]++;
             // q0 = x0[0],x0[1],y0[0],y0[1]; q1 = z0[0],z0[1],x1[0],x1[1]; q2 = y1[0],y1[1],z1[0],z1[1]
             float t0, t1;
-            bool h0 = box_test<PK>(r, r.nx ? q0.y : q0.x, r.nx ? q0.x : q0.y, r.ny ? q0.w : q0.z, r.ny ? q0.z : q0.w,
+            bool h0 = box_test(r, r.nx ? q0.y : q0.x, r.nx ? q0.x : q0.y, r.ny ? q0.w : q0.z, r.ny ? q0.z : q0.w,
                                r.nz ? q1.y : q1.x, r.nz ? q1.x : q1.y, t0);
-            bool h1 = box_test<PK>(r, r.nx ? q1.w : q1.z, r.nx ? q1.z : q1.w, r.ny ? q2.y : q2.x, r.ny ? q2.x : q2.y,
+            bool h1 = box_test(r, r.nx ? q1.w : q1.z, r.nx ? q1.z : q1.w, r.ny ? q2.y : q2.x, r.ny ? q2.x : q2.y,
                                r.nz ? q2.w : q2.z, r.nz ? q2.z : q2.w, t1);
             h0 = h0 & (t0 < r.t_max);
             h1 = h1 & (t1 < r.t_max);
