@@ -30,6 +30,15 @@ PH_DEV spec mip_texel(const DeviceScene& sc, const MipRec& m, uint32_t level, lo
     const float4 v = *reinterpret_cast<const float4*>(sc.texels + ((size_t)m.level_off[level] + (size_t)t * (size_t)w + (size_t)s));
     return mks(v.x, v.y, v.z);
 }
+// the same texel with 32-bit coordinates, for callers that know them to be small (|s|, |t| < 2^30; a level is at most 2^30 wide and high and the pool holds at most 2^32 texels: textures_api.hip checks both at upload)
+PH_DEV spec mip_texel_i(const DeviceScene& sc, const MipRec& m, uint32_t level, int s, int t) {
+    const int w = (int)m.level_w[level], h = (int)m.level_h[level];
+    if (m.wrap == 0u) { s = s & (w - 1); t = t & (h - 1); }
+    else if (m.wrap == 2u) { s = s < 0 ? 0 : (s > w - 1 ? w - 1 : s); t = t < 0 ? 0 : (t > h - 1 ? h - 1 : t); }
+    else if (s < 0 || s >= w || t < 0 || t >= h) return mks1(0.0f);
+    const float4 v = *reinterpret_cast<const float4*>(sc.texels + ((size_t)m.level_off[level] + (size_t)((uint32_t)t * (uint32_t)w + (uint32_t)s)));
+    return mks(v.x, v.y, v.z);
+}
 PH_DEV spec mip_triangle(const DeviceScene& sc, const MipRec& m, uint32_t level, f2 st) {
     if (level > m.n_levels - 1u) level = m.n_levels - 1u;
     const float s = st.x * (float)m.level_w[level] - 0.5f, t = st.y * (float)m.level_h[level] - 0.5f;
@@ -55,17 +64,35 @@ PH_DEV spec mip_ewa(const DeviceScene& sc, const MipRec& m, uint32_t level, f2 s
     const long long t0 = f2ll_sat(ceilf(t - 2.0f * inv_det * v_sqrt)), t1 = f2ll_sat(floorf(t + 2.0f * inv_det * v_sqrt));
     spec sum = mks1(0.0f);
     float sum_wts = 0.0f;
-    for (long long it = t0; it <= t1; it++) {
-        const float tt = (float)it - t;
-        for (long long is = s0; is <= s1; is++) {
-            const float ss = (float)is - s;
-            const float r2 = a * ss * ss + b * ss * tt + c * tt * tt;
-            if (r2 < 1.0f) {
-                uint32_t index = f2u_sat(r2 * (float)PH_EWA_LUT_SIZE);
-                if (index > PH_EWA_LUT_SIZE - 1u) index = PH_EWA_LUT_SIZE - 1u;
-                const float weight = sc.ewa_lut[index];
-                sum = sum + mip_texel(sc, m, level, is, it) * weight;
-                sum_wts += weight;
+    const long long lim = 1ll << 30;
+    if (s0 > -lim && s1 < lim && t0 > -lim && t1 < lim) {   // the ellipse's box in 32-bit counters (always, short of degenerate differentials): (float)(int) == (float)(long long) here
+        for (int it = (int)t0; it <= (int)t1; it++) {
+            const float tt = (float)it - t;
+            for (int is = (int)s0; is <= (int)s1; is++) {
+                const float ss = (float)is - s;
+                const float r2 = a * ss * ss + b * ss * tt + c * tt * tt;
+                if (r2 < 1.0f) {
+                    uint32_t index = f2u_sat(r2 * (float)PH_EWA_LUT_SIZE);
+                    if (index > PH_EWA_LUT_SIZE - 1u) index = PH_EWA_LUT_SIZE - 1u;
+                    const float weight = sc.ewa_lut[index];
+                    sum = sum + mip_texel_i(sc, m, level, is, it) * weight;
+                    sum_wts += weight;
+                }
+            }
+        }
+    } else {
+        for (long long it = t0; it <= t1; it++) {
+            const float tt = (float)it - t;
+            for (long long is = s0; is <= s1; is++) {
+                const float ss = (float)is - s;
+                const float r2 = a * ss * ss + b * ss * tt + c * tt * tt;
+                if (r2 < 1.0f) {
+                    uint32_t index = f2u_sat(r2 * (float)PH_EWA_LUT_SIZE);
+                    if (index > PH_EWA_LUT_SIZE - 1u) index = PH_EWA_LUT_SIZE - 1u;
+                    const float weight = sc.ewa_lut[index];
+                    sum = sum + mip_texel(sc, m, level, is, it) * weight;
+                    sum_wts += weight;
+                }
             }
         }
     }

@@ -139,6 +139,7 @@ int build_pyramid(PbrtHipScene* s, std::vector<float> img, size_t w, size_t h, i
         if (m.n_levels >= PH_MIP_MAX_LEVELS) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: too many pyramid levels");
         const uint32_t L = m.n_levels++;
         if (s->texels.size() + lw * lh > 0xFFFFFFFFull) return set_err(s, PBRT_HIP_ERR_OOM, "add_mipmap: texel pool exceeds 2^32 texels");
+        if (lw > (1u << 30) || lh > (1u << 30)) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: a level wider or higher than 2^30 texels");  // mip_texel_i's 32-bit coordinates
         m.level_off[L] = (uint32_t)s->texels.size(); m.level_w[L] = (uint32_t)lw; m.level_h[L] = (uint32_t)lh;
         for (size_t i = 0; i < lw * lh; i++) s->texels.push_back(Texel{cur[3 * i], cur[3 * i + 1], cur[3 * i + 2], 0.0f});
         if (lw == 1 && lh == 1) break;
