@@ -279,9 +279,11 @@ int pbrt_hip_set_sobol_tables(PbrtHipScene*, const uint32_t* sobol_matrices32, s
  * and returns UNSUPPORTED. */
 int pbrt_hip_build_accel(PbrtHipScene*, int split_method, int max_prims_in_node);
 
-/* The same for split_method 1 with the tree constructed on the GPU (Morton codes, radix sort, one treelet per thread, SAH over the treelet roots on the host;
- * accelerators/src/bvh/hlbvh.rs:33-449, morton.rs:33-120): identical topology, leaf order and boxes, so hits do not depend on where the tree was built.
- * SAH (0) and EqualCounts (3) are host builds: UNSUPPORTED here; so are scenes with object instances. */
+/* The same with the tree constructed on the GPU: identical topology, leaf order and boxes, so hits do not depend on where the tree was built.
+ * split_method 0 (SAH, the reference's default; accelerators/src/bvh/sah.rs:26-367): one level of the tree per round of kernels — bucket boxes by atomics,
+ * the reference's cost loop per node, itertools::partition's element order from a prefix sum.  split_method 1 (HLBVH; hlbvh.rs:33-449, morton.rs:33-120):
+ * Morton codes, radix sort, one treelet per thread, SAH over the treelet roots on the host.  EqualCounts (3) is a host build: UNSUPPORTED here; so are
+ * scenes with object instances. */
 int pbrt_hip_build_accel_device(PbrtHipScene*, int split_method, int max_prims_in_node);
 
 /* World bound of the built aggregate (BVHAccel::world_bound, bvh/mod.rs:161-167): {pmin[3], pmax[3]}. */

@@ -71,7 +71,7 @@ void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, float* out_P,
 int pbrt_hip_host_build_bvh(const float* P, const uint32_t* idx, uint64_t n_tris, int split_method, int max_prims_in_node,
                             int n_threads, uint32_t* out_ordered_prims, uint32_t* out_leaf_last, void* out_nodes,
                             uint64_t* out_info, float* out_root_bounds);
-/* The same outputs from the device HLBVH builder (csrc/bvh_device.hip) on GPU `device`; split_method must be 1.  out_seconds: wall time of the build incl. transfers. */
+/* The same outputs from the device builders (csrc/bvh_sah_device.hip: split_method 0, csrc/bvh_device.hip: split_method 1) on GPU `device`.  out_seconds: wall time of the build incl. transfers. */
 int pbrt_hip_device_build_bvh(int device, const float* P, const uint32_t* idx, uint64_t n_tris, int split_method, int max_prims_in_node, uint32_t* out_ordered_prims,
                               uint32_t* out_leaf_last, void* out_nodes, uint64_t* out_info, float* out_root_bounds, double* out_seconds);
 

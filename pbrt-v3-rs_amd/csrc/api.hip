@@ -1067,10 +1067,10 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
     s->inst_recs.clear();
     if (s->objects.empty()) {
         int brc;
-        if (s->build_on_device) {   // pbrt_hip_build_accel_device: the same HLBVH, made by kernels (bvh_device.hip)
+        if (s->build_on_device) {   // pbrt_hip_build_accel_device: the same tree, made by kernels (HLBVH: bvh_device.hip, SAH: bvh_sah_device.hip)
             PH_CHECK(s, hipSetDevice(s->device));
             std::string e;
-            brc = phost::build_hlbvh_device(in, max_prims_in_node, s->stream, s->bvh, e);
+            brc = split_method == 1 ? phost::build_hlbvh_device(in, max_prims_in_node, s->stream, s->bvh, e) : phost::build_sah_device(in, max_prims_in_node, s->stream, s->bvh, e);
             if (brc == -1) return set_err(s, PBRT_HIP_ERR_DEVICE, "build_accel_device: " + e);
         } else brc = phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh);
         if (brc != 0) return fail(brc);
@@ -1156,10 +1156,10 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
     return PBRT_HIP_OK;
 }
 
-// BVHAccel::from with splitmethod "hlbvh", constructed on the GPU (bvh_device.hip): same tree, same leaf order as pbrt_hip_build_accel(s, 1, ..)
+// BVHAccel::from with splitmethod "sah" (the default) or "hlbvh", constructed on the GPU (bvh_sah_device.hip, bvh_device.hip): same tree, same leaf order as pbrt_hip_build_accel
 int pbrt_hip_build_accel_device(PbrtHipScene* s, int split_method, int max_prims_in_node) {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
-    if (split_method != 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel_device: the device builder makes the HLBVH tree (split_method 1); SAH and EqualCounts are built on the host");
+    if (split_method != 0 && split_method != 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel_device: the device builders make the SAH (0) and the HLBVH (1) tree; EqualCounts is built on the host");
     s->build_on_device = true;
     const int rc = pbrt_hip_build_accel(s, split_method, max_prims_in_node);
     s->build_on_device = false;

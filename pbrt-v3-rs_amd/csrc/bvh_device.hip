@@ -399,12 +399,13 @@ fail:
 // Test / measurement hook with the signature of pbrt_hip_host_build_bvh (host_setup.cpp): the same tree, built on device `device`.
 extern "C" int pbrt_hip_device_build_bvh(int device, const float* P, const uint32_t* idx, uint64_t n_tris, int split_method, int max_prims_in_node, uint32_t* out_ordered_prims,
                                          uint32_t* out_leaf_last, void* out_nodes, uint64_t* out_info, float* out_root_bounds, double* out_seconds) {
-    if (split_method != 1) return -1;
+    if (split_method != 0 && split_method != 1) return -1;
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return -1; }
     phost::BuildInput in{P, idx, (size_t)n_tris, nullptr, nullptr};
     phost::BuildOutput out;
     std::string err;
-    const int rc = phost::build_hlbvh_device(in, max_prims_in_node, nullptr, out, err);
+    const int rc = split_method == 1 ? phost::build_hlbvh_device(in, max_prims_in_node, nullptr, out, err) : phost::build_sah_device(in, max_prims_in_node, nullptr, out, err);
+    if (rc && !err.empty()) std::fprintf(stderr, "pbrt_hip_device_build_bvh: %s\n", err.c_str());
     if (rc) return rc;
     for (size_t i = 0; i < out.tris.size(); i++) {
         if (out_ordered_prims) out_ordered_prims[i] = out.tris[i].prim;
