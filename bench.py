@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--ply", default=None, help="a PLY mesh to render instead of the synthetic triangles (e.g. the Ganesha mesh of configs[2], which is not available offline): "
                                                "normalised into the synthetic scene's [-1, 1]^3 so that camera and light are unchanged")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (same scene, same resolution); 0 = about 150 M rays' worth")
+    ap.add_argument("--host-build", action="store_true", help="build the BVH with the library's host builder instead of on the GPU (the same tree either way; outside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-count", action="store_true")
     ap.add_argument("--material", default="matte", choices=["matte", "plastic", "glass", "metal", "uber", "mixed", "textured"],
@@ -179,7 +180,7 @@ def main():
         spec = pbrt_hip.SceneSpec(n_tris=n_tris, seed=args.seed, xres=res, yres=res, spp=frame_spp, max_depth=max_depth, material=args.material)
         scene = pbrt_hip.Scene(device=local_rank)
         t_setup = time.time()
-        geometry = pbrt_hip.capture_spec(spec, scene, host, geometry=geometry, instances=args.instances)
+        geometry = pbrt_hip.capture_spec(spec, scene, host, geometry=geometry, instances=args.instances, device_build=not args.host_build)
         t_setup = time.time() - t_setup
         floats = max(scene.tile_buffer_floats(tile_size, p, world) for p in range(world))
         tile_buf = torch.zeros(floats, dtype=torch.float32, device=dev)
@@ -253,7 +254,7 @@ def main():
                        "rays_per_frame": r["rays"] // args.steps, "regular_rays_per_frame": r["reg"] // args.steps, "shadow_rays_per_frame": r["shd"] // args.steps,
                        "scene_setup_seconds_host": round(r["t_setup"], 3),
                        "accel": {"interior_nodes": acc["interior_nodes"], "leaf_records": acc["leaf_records"],
-                                 "resident_bytes": acc["node_bytes"] + acc["leaf_record_bytes"], "host_build_seconds": round(acc["build_seconds"], 3)}},
+                                 "resident_bytes": acc["node_bytes"] + acc["leaf_record_bytes"], "build_seconds": round(acc["build_seconds"], 3), "built_on": "host" if (args.host_build or args.instances) else "device"}},
             "film_sha256": hashlib.sha256(r["film"][0].tobytes() + r["film"][1].tobytes()).hexdigest(),
             "stage_ms_per_step_rank0": {"traversal": round((r["ext_s"] + r["sh_s"]) / args.steps * 1e3, 3),
                                         "raygen_shade_film": round(r["shade_s"] / args.steps * 1e3, 3)},

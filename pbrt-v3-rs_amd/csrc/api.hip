@@ -46,6 +46,20 @@ template <class T> static int upload_vec(PbrtHipScene* s, const std::vector<T>& 
     return PBRT_HIP_OK;
 }
 
+void free_tree_dev(PbrtHipScene* s) {
+    if (s->tree_dev_nodes) (void)hipFree(s->tree_dev_nodes);
+    if (s->tree_dev_tris) (void)hipFree(s->tree_dev_tris);
+    s->tree_dev_nodes = s->tree_dev_tris = nullptr; s->tree_dev_n_tris = 0;
+}
+int ensure_host_tree(PbrtHipScene* s) {
+    if (!s->tree_dev_tris || !s->bvh.tris.empty()) return PBRT_HIP_OK;
+    PH_CHECK(s, hipSetDevice(s->device));
+    s->bvh.nodes.resize(s->bvh.interior_nodes); s->bvh.tris.resize(s->tree_dev_n_tris);
+    if (s->bvh.interior_nodes) PH_CHECK(s, hipMemcpy(s->bvh.nodes.data(), s->tree_dev_nodes, s->bvh.interior_nodes * sizeof(Node64), hipMemcpyDeviceToHost));
+    PH_CHECK(s, hipMemcpy(s->bvh.tris.data(), s->tree_dev_tris, s->tree_dev_n_tris * sizeof(TriRec), hipMemcpyDeviceToHost));
+    return PBRT_HIP_OK;
+}
+
 static void free_owned(PbrtHipScene* s) {
     for (void* p : s->owned) (void)hipFree(p);
     s->owned.clear();
@@ -66,8 +80,11 @@ int upload_scene(PbrtHipScene* s) {
     DeviceScene& d = s->ds;
     std::memset(&d, 0, sizeof(d));
     int rc;
-    if ((rc = upload_vec(s, s->bvh.nodes, &d.nodes))) return rc;
-    if ((rc = upload_vec(s, s->bvh.tris, &d.tris))) return rc;
+    if (s->tree_dev_tris) { d.nodes = reinterpret_cast<const Node64*>(s->tree_dev_nodes); d.tris = reinterpret_cast<const TriRec*>(s->tree_dev_tris); }   // built here, never left
+    else {
+        if ((rc = upload_vec(s, s->bvh.nodes, &d.nodes))) return rc;
+        if ((rc = upload_vec(s, s->bvh.tris, &d.tris))) return rc;
+    }
     d.root_ref = s->bvh.root_ref;
     d.n_tris = (uint32_t)(s->idx.size() / 3);
     for (int k = 0; k < 3; k++) { d.root_lo[k] = s->bvh.root_lo[k]; d.root_hi[k] = s->bvh.root_hi[k]; d.world_center[k] = s->world_center[k]; }
@@ -377,6 +394,7 @@ void pbrt_hip_scene_destroy(PbrtHipScene* s) {
     (void)hipStreamSynchronize(s->stream);
     free_wavefront(s);
     free_owned(s);
+    free_tree_dev(s);
     for (DevBuf* b : {&s->d_ld_func, &s->d_ld_cdf, &s->d_counter, &s->d_spill, &s->d_error, &s->d_counts, &s->d_rays_tmp, &s->d_out_tmp})
         if (b->p) (void)hipFree(b->p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -1056,6 +1074,7 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
             if (m.none) m.sort_class = 7u;
         }
     }
+    if (s->tree_dev_tris) { PH_CHECK(s, hipSetDevice(s->device)); free_tree_dev(s); }   // a rebuild: the tree an earlier device build left there goes first
     std::vector<uint32_t> build_flags(s->tri_flags);
     for (size_t t = 0; t < build_flags.size(); t++) build_flags[t] |= s->materials[s->meshes[s->tri_mesh[t]].material].sort_class << PH_TRI_CLASS_SHIFT;
     phost::BuildInput in;
@@ -1070,7 +1089,11 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
         if (s->build_on_device) {   // pbrt_hip_build_accel_device: the same tree, made by kernels (HLBVH: bvh_device.hip, SAH: bvh_sah_device.hip)
             PH_CHECK(s, hipSetDevice(s->device));
             std::string e;
-            brc = split_method == 1 ? phost::build_hlbvh_device(in, max_prims_in_node, s->stream, s->bvh, e) : phost::build_sah_device(in, max_prims_in_node, s->stream, s->bvh, e);
+            if (split_method == 1) brc = phost::build_hlbvh_device(in, max_prims_in_node, s->stream, s->bvh, e);
+            else {
+                brc = phost::build_sah_device(in, max_prims_in_node, s->stream, s->bvh, e, &s->tree_dev_nodes, &s->tree_dev_tris);
+                if (brc == 0 && s->tree_dev_tris) s->tree_dev_n_tris = in.n_tris;
+            }
             if (brc == -1) return set_err(s, PBRT_HIP_ERR_DEVICE, "build_accel_device: " + e);
         } else brc = phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh);
         if (brc != 0) return fail(brc);
@@ -1177,8 +1200,8 @@ int pbrt_hip_world_bound(const PbrtHipScene* s, float out[6]) {
 int pbrt_hip_accel_stats(const PbrtHipScene* s, uint64_t out[8]) {
     if (!s || !out) return PBRT_HIP_ERR_INVALID_ARG;
     if (!s->built) return PBRT_HIP_ERR_STATE;
-    out[0] = s->bvh.nodes.size(); out[1] = s->bvh.tris.size();
-    out[2] = s->bvh.nodes.size() * sizeof(Node64); out[3] = s->bvh.tris.size() * sizeof(TriRec);
+    out[0] = s->tree_dev_tris ? s->bvh.interior_nodes : s->bvh.nodes.size(); out[1] = s->tree_dev_tris ? s->tree_dev_n_tris : s->bvh.tris.size();
+    out[2] = out[0] * sizeof(Node64); out[3] = out[1] * sizeof(TriRec);
     out[4] = s->bvh.leaf_nodes; out[5] = (uint64_t)s->bvh.max_depth; out[6] = s->bvh.max_leaf_prims;
     out[7] = (uint64_t)(s->bvh.build_seconds * 1e6);
     return PBRT_HIP_OK;

@@ -11,6 +11,8 @@
 #include "scene_host.h"
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -123,13 +125,15 @@ namespace phost {
     do { hipError_t e__ = (call); if (e__ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e__); (void)hipGetLastError(); goto fail; } } while (0)
 
 // Builds the SAH tree of `in` on the current device.  Returns 0, or -1 (bad arguments / device failure, `err` says which).
-int build_sah_device(const BuildInput& in, int max_prims_in_node, hipStream_t stream, BuildOutput& out, std::string& err) {
+int build_sah_device(const BuildInput& in, int max_prims_in_node, hipStream_t stream, BuildOutput& out, std::string& err, void** keep_nodes, void** keep_tris) {
     using namespace phs;
     out = BuildOutput();
     if (in.items || in.n_tris >= 0x3FFFFFFFu) { err = "device build: instanced scenes and more than 2^30 triangles take the host builder"; return -1; }
     const uint32_t n = (uint32_t)in.n_tris;
     if (n == 0) return 0;
     auto t0 = std::chrono::steady_clock::now();
+    const bool prof = std::getenv("PBRT_HIP_BUILD_PROFILE") != nullptr;
+    auto lap = [&](const char* what) { if (prof) { (void)hipStreamSynchronize(stream); std::fprintf(stderr, "build_sah_device n=%u: %-28s at %.3f s\n", n, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); } };
     std::vector<void*> allocs;
     auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { (void)hipGetLastError(); return nullptr; } allocs.push_back(p); return p; };
     size_t n_verts = 0;
@@ -164,6 +168,7 @@ int build_sah_device(const BuildInput& in, int max_prims_in_node, hipStream_t st
         if (d_mesh) PHS_CHECK(hipMemcpyAsync(d_mesh, in.tri_mesh, (size_t)n * 4, hipMemcpyHostToDevice, stream));
         PHS_CHECK(hipMemsetAsync(c.leaf_last, 0, (size_t)n * 4, stream));
         const dim3 per_elem((n + 255u) / 256u), per_chunk(n_chunks), b(256);
+        lap("allocations and uploads");
         hipLaunchKernelGGL(k_init, per_chunk, b, 0, stream, c);
         hipLaunchKernelGGL(k_root, dim3(1), dim3(64), 0, stream, c);
         uint32_t lv0 = 0, lv1 = 1;
@@ -200,6 +205,7 @@ int build_sah_device(const BuildInput& in, int max_prims_in_node, hipStream_t st
             if (host_counters[0] > 2u * n) { err = "device build: node count out of range"; goto fail; }
             lv0 = lv1; lv1 = host_counters[0];
         }
+        lap("tree levels");
         for (size_t L = levels.size(); L-- > 0;) hipLaunchKernelGGL(k_size, dim3((levels[L].second - levels[L].first + 255u) / 256u), b, 0, stream, c, levels[L].first, levels[L].second);
         SNode root;
         PHS_CHECK(hipMemcpyAsync(&root, c.nodes, sizeof(SNode), hipMemcpyDeviceToHost, stream));
@@ -210,12 +216,20 @@ int build_sah_device(const BuildInput& in, int max_prims_in_node, hipStream_t st
         for (size_t L = 0; L < levels.size(); L++) hipLaunchKernelGGL(k_number, dim3((levels[L].second - levels[L].first + 255u) / 256u), b, 0, stream, c, levels[L].first, levels[L].second);
         hipLaunchKernelGGL(k_emit, per_elem, b, 0, stream, c);
         PHS_CHECK(hipGetLastError());
-        out.nodes.resize(out.interior_nodes);
-        out.tris.resize(n);
-        if (out.interior_nodes) PHS_CHECK(hipMemcpyAsync(out.nodes.data(), c.out_nodes, out.interior_nodes * sizeof(Node64), hipMemcpyDeviceToHost, stream));
-        PHS_CHECK(hipMemcpyAsync(out.tris.data(), c.out_tris, (size_t)n * sizeof(TriRec), hipMemcpyDeviceToHost, stream));
+        lap("sizes, numbering, records");
+        if (keep_nodes && keep_tris) {   // the tree stays where it is
+            *keep_nodes = c.out_nodes; *keep_tris = c.out_tris;
+            for (void*& p : allocs) if (p == (void*)c.out_nodes || p == (void*)c.out_tris) p = nullptr;
+        } else {
+            out.nodes.resize(out.interior_nodes);
+            out.tris.resize(n);
+            lap("host vectors");
+            if (out.interior_nodes) PHS_CHECK(hipMemcpyAsync(out.nodes.data(), c.out_nodes, out.interior_nodes * sizeof(Node64), hipMemcpyDeviceToHost, stream));
+            PHS_CHECK(hipMemcpyAsync(out.tris.data(), c.out_tris, (size_t)n * sizeof(TriRec), hipMemcpyDeviceToHost, stream));
+        }
         PHS_CHECK(hipMemcpyAsync(host_counters, c.counters, 64, hipMemcpyDeviceToHost, stream));
         PHS_CHECK(hipStreamSynchronize(stream));
+        lap("downloads");
         out.root_ref = out.interior_nodes ? 0u : (PH_LEAF_BIT | 0u);
         for (int k = 0; k < 3; k++) { out.root_lo[k] = root.lo[k]; out.root_hi[k] = root.hi[k]; }
         out.leaf_nodes = host_counters[2]; out.max_leaf_prims = host_counters[3]; out.max_depth = depth;

@@ -83,6 +83,7 @@ void free_multi(PbrtHipScene* s) {
 static void sync_replicas(PbrtHipScene* s) {
     MultiDevice& m = *s->multi;
     const bool bulk = !m.replicas_current || !s->uploaded;
+    if (bulk) (void)ensure_host_tree(s);   // a tree built on the first device travels to the others through its host copy
     for (PbrtHipScene* r : m.replicas) {
         if (bulk) {
             static_cast<SceneHostState&>(*r) = static_cast<const SceneHostState&>(*s);

@@ -76,6 +76,8 @@ struct PbrtHipScene : SceneHostState {
     // ---- device residency ---------------------------------------------------------------------------------------------
     DeviceScene ds{};
     std::vector<void*> owned;        // every hipMalloc of the scene, freed on destroy / rebuild
+    // a tree pbrt_hip_build_accel_device(0, ..) left where it was built: `bvh.nodes` / `bvh.tris` stay empty on the host until something needs them there (ensure_host_tree)
+    void* tree_dev_nodes = nullptr; void* tree_dev_tris = nullptr; size_t tree_dev_n_tris = 0;
     bool uploaded = false;
     int light_strategy_uploaded = -1;
     DevBuf d_ld_func, d_ld_cdf;
@@ -105,7 +107,10 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
 int ensure_traversal_workspace(PbrtHipScene* s);
 void free_wavefront(PbrtHipScene* s);
 int build_hlbvh_device(const BuildInput& in, int max_prims_in_node, hipStream_t stream, BuildOutput& out, std::string& err);   // bvh_device.hip
-int build_sah_device(const BuildInput& in, int max_prims_in_node, hipStream_t stream, BuildOutput& out, std::string& err);     // bvh_sah_device.hip
+// bvh_sah_device.hip.  keep_nodes / keep_tris non-null: the Node64 / TriRec arrays are not copied to `out` but handed over as device allocations (the caller frees them)
+int build_sah_device(const BuildInput& in, int max_prims_in_node, hipStream_t stream, BuildOutput& out, std::string& err, void** keep_nodes = nullptr, void** keep_tris = nullptr);
+void free_tree_dev(PbrtHipScene* s);
+int ensure_host_tree(PbrtHipScene* s);   // api.hip: the host copy of a tree that lives on the device only (the multi-device driver replicates from the host copy)
 int uber_rebuild_for_opacity(PbrtHipScene* s, uint32_t material);    // api.hip: lobe lists remade when a structural parameter becomes a texture
 int glass_rebuild_for_roughness(PbrtHipScene* s, uint32_t material);
 // wavefront.hip: the renderer's building blocks, shared with the multi-device driver (multi.hip)

@@ -864,9 +864,9 @@ int Api::pbrt_world_end(RenderReport& rep) {
     const int max_prims = accel_p_.find_one_int("maxnodeprims", 4);
     if (n_lights_ == 0) warn("No light sources defined in scene; rendering a black image.");
     auto t0 = clk::now();
-    // "hlbvh" trees of scenes without object instances are made on the GPU (same tree: csrc/bvh_device.hip); everything else by the library's host builder
+    // "sah" and "hlbvh" trees of scenes without object instances are made on the GPU (same trees: csrc/bvh_sah_device.hip, bvh_device.hip); everything else by the library's host builder
     int brc = PBRT_HIP_ERR_UNSUPPORTED;
-    if (split == 1 && !check_only_) brc = pbrt_hip_build_accel_device(scene_, split, max_prims);   // UNSUPPORTED for scenes with object definitions: the host builder makes the same tree
+    if ((split == 0 || split == 1) && !check_only_) brc = pbrt_hip_build_accel_device(scene_, split, max_prims);   // UNSUPPORTED for scenes with object definitions: the host builder makes the same tree
     if (brc == PBRT_HIP_ERR_UNSUPPORTED) brc = ABI(pbrt_hip_build_accel(scene_, split, max_prims));
     if (!check(brc, "build_accel")) return PBRT_HIP_ERR_DEVICE;
     rep.build_seconds = std::chrono::duration<double>(clk::now() - t0).count();

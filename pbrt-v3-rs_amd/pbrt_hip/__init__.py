@@ -487,7 +487,7 @@ class Scene:
         self._chk(self.b.fn("set_sobol_tables")(self.h, _ptr(m32, C.c_uint32), len(m32), _ptr(vdc, C.c_uint64), _ptr(vdci, C.c_uint64), len(vdc)))
 
     def build_accel_device(self, split_method=1, max_prims_in_node=4):
-        """The HLBVH tree (split_method 1) constructed on the GPU: same tree as build_accel(1, ..)."""
+        """The SAH (0) or HLBVH (1) tree constructed on the GPU: same tree as build_accel(split_method, ..)."""
         self._chk(self.b.fn("build_accel_device")(self.h, split_method, max_prims_in_node))
 
     def build_accel(self, split_method=0, max_prims_in_node=4):
@@ -809,7 +809,7 @@ class SceneSpec:
     crop_window: tuple = (0.0, 1.0, 0.0, 1.0)   # Film "cropwindow" x0 x1 y0 y1 (fractions of the full resolution)
 
 
-def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None, instances: int = 0):
+def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None, instances: int = 0, device_build: bool = False):
     """LookAt 0 -4 0  0 0 0  0 0 1 / perspective fov 40 / box filter / halton / matte 0.5 / infinite L=1.
     instances = K > 0: the triangles form ONE object placed K times (ObjectInstance) on a jittered lattice inside the unit
     cube, each copy scaled by K^(-1/3) and rotated — K x n_tris instanced triangles behind a two-level BVH."""
@@ -861,5 +861,6 @@ def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None, insta
     cb, table, sb = host.film_box(spec.xres, spec.yres, crop_window=spec.crop_window)
     scene.set_film(spec.xres, spec.yres, cb, (0.5, 0.5), table)
     scene.set_sampler(0, spec.spp, sb)
-    scene.build_accel(0, 4)
+    if device_build and not instances: scene.build_accel_device(0, 4)   # the same tree, made on the GPU and left there (csrc/bvh_sah_device.hip)
+    else: scene.build_accel(0, 4)
     return P, idx

@@ -32,7 +32,7 @@ def _crop_pair(host, cfg, crop):
     """The same crop of the same full-size scene on the device and in the oracle; returns (device film, oracle film)."""
     spec = pbrt_hip.SceneSpec(**cfg, crop_window=crop)
     prod = pbrt_hip.Scene()
-    geom = pbrt_hip.capture_spec(spec, prod, host)
+    geom = pbrt_hip.capture_spec(spec, prod, host, device_build=True)   # the tree made on the GPU (csrc/bvh_sah_device.hip); the oracle below builds its own with sah.rs' recursion
     g = prod.render_path(max_depth=cfg["max_depth"])
     prod.close()
     orc = OracleScene()
@@ -176,7 +176,7 @@ def test_config1_full_size_meets_the_stated_tolerance_in_glibc_mode(host):
     Stated tolerance: RMSE <= 1e-3 x mean luminance and <= 0.1 % of the pixels off by more than 1e-2 x mean."""
     cfg = dict(n_tris=100_000, seed=1, xres=512, yres=512, spp=64, max_depth=5)
     prod = pbrt_hip.Scene()
-    geom = pbrt_hip.capture_spec(pbrt_hip.SceneSpec(**cfg), prod, host)
+    geom = pbrt_hip.capture_spec(pbrt_hip.SceneSpec(**cfg), prod, host, device_build=True)
     gx, gw, gst = prod.render_path()
     orc = OracleScene()
     pbrt_hip.capture_spec(pbrt_hip.SceneSpec(**cfg), orc, host, geometry=geom)
