@@ -493,6 +493,16 @@ class Scene:
     def build_accel(self, split_method=0, max_prims_in_node=4):
         self._chk(self.b.fn("build_accel")(self.h, split_method, max_prims_in_node))
 
+    def build_accel_best(self, split_method=0, max_prims_in_node=4):
+        """build_accel_device where it applies (SAH / HLBVH trees of scenes without object instances), build_accel elsewhere: the same tree either way."""
+        if split_method in (0, 1) and self.b.has("build_accel_device"):
+            try:
+                return self.build_accel_device(split_method, max_prims_in_node)
+            except PbrtHipError as e:
+                if e.code != ERR_UNSUPPORTED:
+                    raise
+        self.build_accel(split_method, max_prims_in_node)
+
     def world_bound(self):
         out = np.zeros(6, np.float32)
         self._chk(self.b.fn("world_bound")(self.h, _ptr(out, C.c_float)))

@@ -113,7 +113,7 @@ def build_case(host, seed, big=False):
         cb, table, sb = host.film_filter(fkind, res[0], res[1], radius, fparams, crop)
         s.set_film(res[0], res[1], cb, radius, table, scale=1.0, max_sample_luminance=float(g.choice([np.inf, 5.0])))
         s.set_sampler(0, spp, sb)
-        s.build_accel(split, int(g.choice([1, 4, 8])))
+        s.build_accel_best(split, int(g.choice([1, 4, 8])))   # the product builds on the GPU where it can (same tree); the oracle has one builder
         return cb
     return cap, dict(max_depth=int(rng.integers(1, 9)), light_strategy=int(rng.integers(0, 3)), rr_threshold=float(rng.choice([1.0, 0.5, 10.0])))
 

@@ -209,7 +209,7 @@ def build_case(host, seed):
         cb, table, sb = host.film_box(res[0], res[1])
         s.set_film(res[0], res[1], cb, (0.5, 0.5), table)
         s.set_sampler(int(g.integers(0, 1)), spp, sb)
-        s.build_accel(0, int(g.choice([1, 4])))
+        s.build_accel_best(0, int(g.choice([1, 4])))
         return cb
     return cap, dict(max_depth=int(rng.integers(1, 7)), light_strategy=int(rng.integers(0, 3)))
 
