@@ -18,7 +18,8 @@ SPEC = dict(n_tris=30_000, seed=3, xres=200, yres=136, spp=8, max_depth=5)
 
 def _render(host, devices=None, **kw):
     s = pbrt_hip.Scene(devices=devices) if devices is not None else pbrt_hip.Scene()
-    pbrt_hip.capture_spec(pbrt_hip.SceneSpec(**SPEC), s, host)
+    # the multi-device handles build their tree on the first GPU (it reaches the other contexts through its host copy), the one-device scene on the host: the same tree
+    pbrt_hip.capture_spec(pbrt_hip.SceneSpec(**SPEC), s, host, device_build=devices is not None)
     out = s.render_path(**kw)
     return s, out
 
@@ -63,7 +64,7 @@ def test_multi_device_scene_change_reaches_every_context(host):
         s.add_light_point((20, 18, 15), (0.2, -1.5, 1.0))
         P = np.array([[-1, -1, -1.2], [1, -1, -1.2], [0, 1, -1.2]], np.float32)
         s.add_mesh(P, [0, 1, 2], s.add_material_matte((0.8, 0.2, 0.2), 0.0))
-        s.build_accel(0, 4)
+        s.build_accel_best(0, 4)
         return s.render_path(light_strategy=1)
     a = pbrt_hip.Scene(); b = pbrt_hip.Scene(devices=[0, 0, 0])
     xa, wa, sa = build(a); xb, wb, sb = build(b)
