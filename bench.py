@@ -27,7 +27,7 @@ closest-hit and any-hit rays):
               profiles/r02_traffic.json when that file holds a PMC run of this exact workload (scripts/pmc_profile.sh writes it), else null + the reason.
   frac      = traffic / avg launch time / peak: the fraction of the HBM peak the kernel draws at the memory side.  The tree's upper levels are re-read
               by every ray and are served by L2 / Infinity Cache, so the algorithmic rate (`frac_algorithmic` = achieved / peak) is not an HBM
-              fraction and can exceed 1; it is reported next to it.  Without a matching PMC run frac falls back to the algorithmic ratio and says so.
+              fraction and can exceed 1; it is reported next to it.  Without a matching PMC run of the workload frac is null.
 `cpu_baseline` times the CPU oracle (oracle/, a port of the reference algorithm — the Rust reference cannot be built here) on a bounded sample of the
 same workload (same scene and resolution, the first few Halton samples of every pixel, about 150 M rays) on this box's host cores.
 """
@@ -312,7 +312,7 @@ def main():
                                  "traffic_note": "bytes per launch leaving the L2s (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE over " + str(k["dispatches"]) + " traversal launches of one frame, " +
                                                  e.get("source", "profiles/") + "; " + e.get("calibration", "") + ")"})
                 else:
-                    roof.update({"frac": round(ach / HBM_PEAK_GBS, 4), "frac_basis": "algorithmic (no PMC record of this workload: " + why + ")", "traffic_error": why})
+                    roof.update({"frac": None, "frac_basis": "none: no PMC record of this workload (" + why + "); frac_algorithmic is not an HBM fraction", "traffic_error": why})
         out["roofline"] = roof
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores, bounded sample ------------------------
