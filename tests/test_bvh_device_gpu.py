@@ -64,14 +64,24 @@ def _awkward_tris(n_tris, seed, mode):
     if mode == 2:
         same = (np.arange(n_tris) & 3) != 0
         c[same] = (0.25, -0.5, 0.75); d[same] = 0; d[same, 1, 0] = 0.05; d[same, 2, 1] = 0.05
+    if mode == 3:   # a regular k x k grid of quads in a plane, shared vertices: rows of equal centroid coordinates, bucket boundaries that fall on them, a degenerate axis
+        k = int(np.sqrt(n_tris // 2))
+        u = np.linspace(-1, 1, k + 1, dtype=np.float32)
+        X, Y = np.meshgrid(u, u, indexing="xy")
+        P = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size, np.float32)], 1).astype(np.float32)
+        i, j = np.meshgrid(np.arange(k), np.arange(k), indexing="xy")
+        a = (j * (k + 1) + i).ravel(); b = a + 1; c2 = a + k + 1; d2 = c2 + 1
+        idx = np.stack([a, b, d2, a, d2, c2], 1).reshape(-1).astype(np.uint32)
+        return np.ascontiguousarray(P), idx
     P = (c[:, None, :] + d).reshape(-1, 3).astype(np.float32)
     return np.ascontiguousarray(P), np.arange(3 * n_tris, dtype=np.uint32)
 
 
 @pytest.mark.parametrize("n_tris,seed,max_prims,mode", [(1, 1, 4, 0), (2, 1, 4, 0), (3, 5, 4, 0), (5, 2, 1, 0), (17, 2, 4, 0), (300, 8, 2, 0), (5000, 3, 4, 0), (5000, 4, 1, 0), (20000, 6, 8, 0),
-                                                        (20000, 9, 255, 0), (3000, 1, 4, 1), (3000, 2, 4, 2), (40000, 3, 4, 1), (300000, 7, 4, 0), (1000000, 11, 4, 0)])
+                                                        (20000, 9, 255, 0), (3000, 1, 4, 1), (3000, 2, 4, 2), (40000, 3, 4, 1), (300000, 7, 4, 0), (1000000, 11, 4, 0), (20000, 1, 4, 3), (2000000, 1, 4, 3)])
 def test_device_sah_build_equals_host_and_oracle(host, product, n_tris, seed, max_prims, mode):
     P, idx = host.gen_random_tris(n_tris, seed) if mode == 0 else _awkward_tris(n_tris, seed, mode)
+    n_tris = len(idx) // 3
     h = _build(product.lib, "host", P, idx, n_tris, max_prims, split=0)
     d = _build(product.lib, "device", P, idx, n_tris, max_prims, split=0)
     assert np.array_equal(d["order"], h["order"]), "primitive order differs"
