@@ -285,11 +285,9 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
     if (!s->inst_recs.empty()) {  // scenes with object instances: the TransformedPrimitive-aware kernels
         if (s->count_traversal) PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 0, false);
         else {
-            static const int iv = []() { const char* e = std::getenv("PBRT_HIP_INST_VARIANT"); const int v = e ? std::atoi(e) : PH_DEFAULT_INST_VARIANT; return (v < 0 || v > 3) ? PH_DEFAULT_INST_VARIANT : v; }();
-            switch (iv) {   // the instancing kernel carries 111 VGPRs (4 waves per SIMD) when left to the compiler
+            static const int iv = []() { const char* e = std::getenv("PBRT_HIP_INST_VARIANT"); const int v = e ? std::atoi(e) : PH_DEFAULT_INST_VARIANT; return (v < 0 || v > 1) ? PH_DEFAULT_INST_VARIANT : v; }();
+            switch (iv) {   // the instancing kernel carries 111 VGPRs (4 waves per SIMD = 4 blocks per CU, which is also what its 38 KB of LDS per block allow); the 5-wave builds of round 2 (96 VGPRs, 9 spilled) were slower
                 case 1: PH_LAUNCH3(false, 24, 12, PH_LDS_DEPTH, 5, true, 0, false); break;
-                case 2: PH_LAUNCH3(false, 24, 12, PH_LDS_DEPTH, 5, true, 5, false); break;   // 96 VGPRs, 9 spilled
-                case 3: PH_LAUNCH3(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true, 5, false); break;
                 default: PH_LAUNCH3(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true, 0, false); break;
             }
         }

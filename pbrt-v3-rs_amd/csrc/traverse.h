@@ -225,6 +225,9 @@ template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFIL
           bool ALPHA = false, int WPE = 0>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
+    // INST: the scene-level ray and what ray_setup derived from it (six IEEE divides), parked while the lane walks an instance: leaving an instance is then thirteen LDS reads instead of
+    // a reload of the ray and a second ray_setup.  (The instancing kernels run 4 blocks per CU: 24.5 KB of stack + 13 KB of this fit the 40 KB a block may take.)
+    __shared__ float inst_save[INST ? 13 : 1][INST ? PH_TRAV_BLOCK : 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * PH_TRAV_BLOCK + tid;
@@ -388,6 +391,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                             const InstRec& I = sc.instances[__float_as_uint(a.w)];
                             world_tmax = r.t_max; cont_ref = last ? PH_INVALID_REF : cur + 1u;
                             in_inst = __float_as_uint(a.w) + 1u; inst_sp = sp; inst_hit = false;
+                            inst_save[0][tid] = r.ox; inst_save[1][tid] = r.oy; inst_save[2][tid] = r.oz; inst_save[3][tid] = r.dx; inst_save[4][tid] = r.dy; inst_save[5][tid] = r.dz;
+                            inst_save[6][tid] = r.ix; inst_save[7][tid] = r.iy; inst_save[8][tid] = r.iz; inst_save[9][tid] = r.sx; inst_save[10][tid] = r.sy; inst_save[11][tid] = r.sz;
+                            inst_save[12][tid] = __uint_as_float((uint32_t)(r.nx | (r.ny << 1) | (r.nz << 2) | (r.kx << 3) | (r.ky << 5) | (r.kz << 7)));
                             const RayIn in = xf_ray(I.w2i, r, 0.0f);
                             ray_setup(r, in);
                             cur = PH_INVALID_REF;
@@ -427,10 +433,11 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
         if (INST && has_ray && in_inst && cur == PH_INVALID_REF) {
             if (!(ah && occluded)) {
                 const float t_new = inst_hit ? r.t_max : world_tmax;
-                const float4* rp = reinterpret_cast<const float4*>((MIXED && ah) ? p.rays2 + (ray_index - n_first) : p.rays + ray_index);
-                const float4 a = rp[0], b = rp[1];
-                RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = t_new; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
-                ray_setup(r, in);
+                r.ox = inst_save[0][tid]; r.oy = inst_save[1][tid]; r.oz = inst_save[2][tid]; r.dx = inst_save[3][tid]; r.dy = inst_save[4][tid]; r.dz = inst_save[5][tid];
+                r.ix = inst_save[6][tid]; r.iy = inst_save[7][tid]; r.iz = inst_save[8][tid]; r.sx = inst_save[9][tid]; r.sy = inst_save[10][tid]; r.sz = inst_save[11][tid];
+                const uint32_t pk = __float_as_uint(inst_save[12][tid]);
+                r.nx = (int)(pk & 1u); r.ny = (int)((pk >> 1) & 1u); r.nz = (int)((pk >> 2) & 1u); r.kx = (int)((pk >> 3) & 3u); r.ky = (int)((pk >> 5) & 3u); r.kz = (int)((pk >> 7) & 3u);
+                r.t_max = t_new;
                 in_inst = 0;
                 cur = (cont_ref != PH_INVALID_REF) ? cont_ref : pop();
             } else in_inst = 0;
