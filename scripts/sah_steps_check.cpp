@@ -3,6 +3,8 @@
 // tested on the GPU (tests/test_bvh_device_gpu.py).  Build and run:  bash scripts/sah_steps_check.sh
 #include "../pbrt-v3-rs_amd/csrc/bvh_sah_steps.h"
 #include "../pbrt-v3-rs_amd/csrc/bvh_build.h"
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <random>
 #include <string>
@@ -25,6 +27,17 @@ static int run(size_t n, unsigned seed, int max_prims, int mode) {
             for (int k = 0; k < 3; k++) P.push_back(c[k] + d[k]);
             idx.push_back((uint32_t)(3 * t + v));
         }
+    }
+    if (mode == 3) {   // a regular k x k grid of quads with shared vertices in the plane z = 0: rows of equal centroid coordinates, a degenerate axis
+        P.clear(); idx.clear();
+        const size_t k = std::max<size_t>(1, (size_t)std::sqrt((double)n / 2.0));
+        for (size_t j = 0; j <= k; j++) for (size_t i = 0; i <= k; i++) { P.push_back(-1.0f + 2.0f * (float)i / (float)k); P.push_back(-1.0f + 2.0f * (float)j / (float)k); P.push_back(0.0f); }
+        for (size_t j = 0; j < k; j++) for (size_t i = 0; i < k; i++) {
+            const uint32_t a = (uint32_t)(j * (k + 1) + i), b = a + 1, c = a + (uint32_t)k + 1, d = c + 1;
+            const uint32_t q[6] = {a, b, d, a, d, c};
+            idx.insert(idx.end(), q, q + 6);
+        }
+        n = idx.size() / 3;
     }
     phost::BuildInput in{P.data(), idx.data(), n, nullptr, nullptr};
     phost::BuildOutput want;
@@ -92,7 +105,7 @@ int main(int argc, char** argv) {
     int bad = 0, cases = 0;
     const std::vector<size_t> sizes = quick ? std::vector<size_t>{1, 2, 3, 5, 17, 300, 5000} : std::vector<size_t>{1, 2, 3, 4, 5, 7, 17, 64, 300, 1000, 5000, 40000};
     for (size_t n : sizes)
-        for (int mode = 0; mode < 3; mode++)
+        for (int mode = 0; mode < 4; mode++)
             for (int mp : {1, 4, 8, 255})
                 for (unsigned seed = 1; seed <= (quick ? 1u : (n <= 300 ? 6u : 2u)); seed++) { bad += run(n, seed * 7919u + (unsigned)n, mp, mode); cases++; }
     std::printf("%d cases, %d differences\n", cases, bad);
