@@ -2,7 +2,11 @@
 """bench.py — Mrays/s of the MI355X wavefront path tracer on BASELINE.json's configurations (synthetic random-triangle scenes).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 runs one rank per GPU.  Started under torch.distributed.run (WORLD_SIZE set) it is one of the ranks; started plainly it launches
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` as a CHILD process BEFORE torch or
+  HIP are touched (a process that has initialised the GPU is never re-executed), relays the ranks' one JSON line and exits with their return code.
+  --multi-handle: ONE process, one handle over the N GPUs (pbrt_hip_scene_create_multi: one host thread per GPU, film tiles gathered inside the
+  library with ncclSend / ncclRecv); same partition, same film.
 
 Workload (`--config`, named in the JSON line's config.workload):
   2 (default at N = 1)  configs[2]: 4.3 M triangles, PathIntegrator maxdepth 8, 1024x1024 @ 256 spp — the largest single-GPU configuration.  The
@@ -89,6 +93,26 @@ def find_traffic(key):
     return None, f"no PMC run of workload {key} in {os.path.relpath(TRAFFIC_FILE, ROOT)} (have: {[e.get('workload') for e in tj.get('entries', [])]})"
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a fresh child (this process has not imported torch nor touched HIP), relay
+    their output and return code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:   # rank 0 prints the one JSON line; anything else a rank writes to stdout goes to stderr so that stdout stays one line
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,15 +139,23 @@ def main():
     ap.add_argument("--no-weak-leg", action="store_true", help="N>1, strong: skip the short weak-scaling leg reported alongside")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = functional rehearsal of the N>1 path on ONE GPU: all ranks share device 0 and film tiles travel through host memory")
+    ap.add_argument("--multi-handle", action="store_true",
+                    help="N>1 from ONE process: one pbrt_hip_scene_create_multi handle over the N GPUs, the film-tile gather inside the library (RCCL send / recv); "
+                         "with --backend gloo the N contexts share GPU 0 (rehearsal)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.multi_handle:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.multi_handle and world > 1:
+        raise SystemExit("bench.py --multi-handle is one process over N GPUs: do not start it under torch.distributed.run")
+    if not args.multi_handle and world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree")
 
-    cfg_name = args.config or ("2" if world == 1 else "3")
+    n_gpus = args.gpus if args.multi_handle else world
+    cfg_name = args.config or ("2" if n_gpus == 1 else "3")
     cfg = dict(CONFIGS[cfg_name])
     custom = []
     for k, v in (("n_tris", args.n_tris), ("res", args.res), ("spp", args.spp), ("max_depth", args.max_depth)):
@@ -139,6 +171,8 @@ def main():
     dist = None
     if args.backend == "gloo":
         local_rank = 0  # rehearsal mode: every rank drives GPU 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -147,8 +181,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -178,7 +210,10 @@ def main():
         """Builds the scene at `frame_spp`, renders warmup + steps frames; returns (scene, tile_buf, stats dict)."""
         nonlocal geometry
         spec = pbrt_hip.SceneSpec(n_tris=n_tris, seed=args.seed, xres=res, yres=res, spp=frame_spp, max_depth=max_depth, material=args.material)
-        scene = pbrt_hip.Scene(device=local_rank)
+        if args.multi_handle:   # one handle over the N GPUs (rehearsal: N contexts on GPU 0)
+            scene = pbrt_hip.Scene(devices=[0] * n_gpus if args.backend == "gloo" else list(range(n_gpus)))
+        else:
+            scene = pbrt_hip.Scene(device=local_rank)
         t_setup = time.time()
         geometry = pbrt_hip.capture_spec(spec, scene, host, geometry=geometry, instances=args.instances, device_build=not args.host_build)
         t_setup = time.time() - t_setup
@@ -193,6 +228,9 @@ def main():
         torch.cuda.synchronize()  # the library writes tile_buf on its own stream: torch's fill kernels must have finished
 
         def step():
+            if args.multi_handle:   # tiles dealt to the handle's devices, gathered and merged inside the library
+                xyz, wt, st = scene.render_path(max_depth=max_depth, tile_size=tile_size, out=film_out)
+                return st, (xyz, wt)
             st = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
             film = None
             if world > 1:
@@ -232,25 +270,27 @@ def main():
         return scene, tile_buf, dict(elapsed=elapsed, rays=rays, reg=reg, shd=shd, ext_s=ext_s, sh_s=sh_s, shade_s=shade_s, launches=launches, film=film,
                                      t_setup=t_setup, steps=steps)
 
-    scaling = args.scaling if world > 1 else "weak"  # one GPU: the two coincide; the contract's default label
-    frame_spp = spp * (world if (world > 1 and scaling == "weak") else 1)
+    scaling = args.scaling if n_gpus > 1 else "weak"  # one GPU: the two coincide; the contract's default label
+    frame_spp = spp * (n_gpus if (n_gpus > 1 and scaling == "weak") else 1)
     scene, tile_buf, r = run_leg(frame_spp, args.steps, args.warmup)
 
     out = None
     if rank == 0:
         mrays = r["rays"] / r["elapsed"] / 1e6
         label = cfg["label"] if not custom else f"custom ({', '.join(custom)} overridden; base {cfg['label']})"
-        spp_note = f" (= {spp} x {world} ranks, weak scaling)" if frame_spp != spp else ""
+        spp_note = f" (= {spp} x {n_gpus} GPUs, weak scaling)" if frame_spp != spp else ""
         acc = scene.accel_stats()
         out = {
-            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("" if not args.instances else f"INSTANCED x{args.instances} (one object, two-level BVH) — ") + label +
                                    f" — as run: {n_tris} random triangles (seed {args.seed}), single SAH BVH (maxnodeprims 4), {res}x{res} @ {frame_spp} spp{spp_note}, "
                                    f"PathIntegrator maxdepth {max_depth}, halton, box filter, constant infinite light, " + ("matte Kd 0.5" if args.material == "matte" else f"material {args.material}"),
                        "baseline_config": cfg_name if not custom else "custom", "key": workload_key(n_tris, res, frame_spp, max_depth, args.seed),
-                       "tiles": f"16x16, tile t on rank t % {world}, film tiles gathered on rank 0 (RCCL)" if world > 1 else "16x16, one rank",
+                       "tiles": (f"16x16, tile t on device t % {n_gpus} of ONE multi-device handle (one host thread per device), film tiles gathered on the first device inside the library"
+                                 + (" (RCCL send / recv)" if args.backend == "nccl" else " (device-to-device copies: the contexts share GPU 0)")) if args.multi_handle else
+                                f"16x16, tile t on rank t % {world}, film tiles gathered on rank 0 (" + ("RCCL" if args.backend == "nccl" else "gloo, through host memory: rehearsal on one GPU") + ")" if world > 1 else "16x16, one rank",
                        "rays_per_frame": r["rays"] // args.steps, "regular_rays_per_frame": r["reg"] // args.steps, "shadow_rays_per_frame": r["shd"] // args.steps,
                        "scene_setup_seconds_host": round(r["t_setup"], 3),
                        "accel": {"interior_nodes": acc["interior_nodes"], "leaf_records": acc["leaf_records"],
@@ -269,7 +309,8 @@ def main():
                 "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         if not args.no_roofline_count:
             scene.set_traversal_counting(True)
-            scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
+            # (a multi-device handle's *_tiles_device entry points act on its first device: that device's share of the frame)
+            scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=max_depth, tile_size=tile_size, tile_part=rank, tile_parts=n_gpus)
             cnt = scene.traversal_counts()
             scene.set_traversal_counting(False)
             cl, ah = cnt["closest"], cnt["any_hit"]
@@ -296,7 +337,7 @@ def main():
                 # memory-side traffic of the same kernel from rocprofv3 PMC passes (separate runs of this script under `rocprofv3 --pmc`, scripts/pmc_profile.sh;
                 # MI355X_MICROARCH.md: FETCH_SIZE doubles for wide coalesced streaming reads only — this kernel reads random 64-B lines, for which the
                 # calibration run scripts/calib/fetch_calib.hip shows FETCH_SIZE exact, so fetch_scale is 1).  Only a run of this exact workload counts.
-                plain = world == 1 and args.material == "matte" and not args.instances
+                plain = n_gpus == 1 and args.material == "matte" and not args.instances
                 e, why = find_traffic(workload_key(n_tris, res, frame_spp, max_depth, args.seed)) if plain else (None, "PMC records are kept for the plain matte single-GPU workloads only")
                 if e is not None:
                     k = e["traversal"]
@@ -316,7 +357,7 @@ def main():
         out["roofline"] = roof
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores, bounded sample ------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle_binding import OracleScene
         cores = host_cores()
@@ -336,15 +377,15 @@ def main():
         orc.close()
 
     # ---- N > 1, strong scaling: a short weak-scaling leg alongside (spp x N: every rank traces what one GPU traces at N = 1) ----------------
-    if world > 1 and scaling == "strong" and not args.no_weak_leg:
+    if n_gpus > 1 and scaling == "strong" and not args.no_weak_leg:
         scene.close()
         del tile_buf
         torch.cuda.empty_cache()
         wsteps = max(1, min(args.steps, 3))
-        scene, tile_buf, rw = run_leg(spp * world, wsteps, 1)
+        scene, tile_buf, rw = run_leg(spp * n_gpus, wsteps, 1)
         if rank == 0:
             out["weak_alongside"] = {"value": round(rw["rays"] / rw["elapsed"] / 1e6, 2), "unit": "Mrays/s", "steps": wsteps, "warmup": 1,
-                                     "ms_per_step": round(rw["elapsed"] / wsteps * 1e3, 3), "spp": spp * world,
+                                     "ms_per_step": round(rw["elapsed"] / wsteps * 1e3, 3), "spp": spp * n_gpus,
                                      "note": "same scene and resolution at spp x N: per-GPU work equals the N = 1 frame's"}
 
     if rank == 0:

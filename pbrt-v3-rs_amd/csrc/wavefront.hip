@@ -1051,6 +1051,7 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
                 if ((rc = timed(0, [&]() { launch_traverse_kernel(s, 0, s->trav_blocks, tp); }))) return rc;
                 if (it > 0) {
                     tp.rays = wp.rays_sh; tp.out = wp.occ; tp.n_ptr = &c->n_sh; tp.counter = &c->head_sh;
+                    tp.heads = nullptr; tp.n_heads = 0;   // the round's queue heads were drained by the closest-hit launch: this one pulls from its own single head
                     if ((rc = timed(1, [&]() { launch_traverse_kernel(s, 1, s->trav_blocks, tp); }))) return rc;
                 }
             }

@@ -677,9 +677,14 @@ class Scene:
             raise PbrtHipError(ERR_STATE, "set_film must be called before rendering")
         return self.film_shape
 
-    def render_path(self, max_depth=5, rr_threshold=1.0, light_strategy=2, pixel_bounds=None, tile_size=16, tile_part=0, tile_parts=1):
+    def render_path(self, max_depth=5, rr_threshold=1.0, light_strategy=2, pixel_bounds=None, tile_size=16, tile_part=0, tile_parts=1, out=None):
+        """out = (xyz, weight) arrays to fill instead of fresh ones (see merge_tiles_device)."""
         h, w = self._film_hw()
-        xyz = np.zeros((h, w, 3), np.float32); wt = np.zeros((h, w), np.float32)
+        if out is not None:
+            xyz, wt = out
+            assert xyz.shape == (h, w, 3) and wt.shape == (h, w) and xyz.dtype == np.float32 and wt.dtype == np.float32 and xyz.flags.c_contiguous and wt.flags.c_contiguous
+        else:
+            xyz = np.zeros((h, w, 3), np.float32); wt = np.zeros((h, w), np.float32)
         pb = np.ascontiguousarray(pixel_bounds if pixel_bounds is not None else self.sample_bounds, dtype=np.int32)
         st = Stats()
         self._chk(self.b.fn("render_path")(self.h, max_depth, C.c_float(rr_threshold), light_strategy, _ptr(pb, C.c_int), tile_size, tile_part, tile_parts,

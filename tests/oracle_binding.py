@@ -21,7 +21,7 @@ _binding = None
 
 
 def build_oracle():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_math.hpp", "oracle_scene.hpp", "oracle_render.hpp")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp"))]   # every source: a header left out would leave a stale library
     if not os.path.exists(ORACLE_LIB) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 

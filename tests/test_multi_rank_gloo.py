@@ -56,3 +56,18 @@ def test_two_rank_tile_sharding_equals_single_rank(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     ok = np.load(out)
     assert ok.all(), ok
+
+
+def test_bench_without_a_launcher_starts_its_ranks_and_relays_their_return_code():
+    """`python bench.py --gpus 2` (no WORLD_SIZE): bench.py itself starts torch.distributed.run with two ranks as a child process and hands back what they
+    return.  There is no GPU here, so both ranks stop with "needs a GPU" — which proves that the ranks were started (the old behaviour was to refuse at once)
+    and that a failing rank reaches the caller as a non-zero exit code with nothing on stdout."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: tests/test_multi_rank_gpu.py covers the launcher")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode != 0
+    assert "bench.py needs a GPU" in r.stderr and "torch.distributed" in r.stderr, r.stderr[-3000:]   # said by a rank that the elastic launcher started
+    assert r.stdout.strip() == ""

@@ -62,3 +62,49 @@ def test_two_ranks_at_config3_size():
     assert a["config"]["baseline_config"] == b["config"]["baseline_config"] == "3" and b["scaling"] == "strong" and b["n_gpus"] == 2
     assert a["film_sha256"] == b["film_sha256"]
     assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (what the driver's command line looks like): bench.py starts torch.distributed.run as a child before
+    it touches torch or HIP and relays the ranks' single JSON line; the film equals the one-rank film."""
+    common = ["--config", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--spp", "4", "--res", "160", "--n-tris", "8000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-weak-leg"] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.strip().splitlines() if l.strip()]
+    assert len(lines) == 1, lines   # ONE JSON line on stdout
+    a, b = _last_json(one.stdout), json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong"
+    assert a["film_sha256"] == b["film_sha256"] and a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+
+
+def test_bench_multi_handle_two_contexts():
+    """--multi-handle: ONE process, one pbrt_hip_scene_create_multi handle over 2 contexts (sharing GPU 0 under --backend gloo), tiles gathered and merged
+    inside the library; same film and ray count as the one-device frame."""
+    common = ["--config", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--spp", "4", "--res", "160", "--n-tris", "8000"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--multi-handle", "--backend", "gloo", "--no-weak-leg"] + common,
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = _last_json(one.stdout), _last_json(two.stdout)
+    assert b["n_gpus"] == 2 and "multi-device handle" in b["config"]["tiles"]
+    assert a["film_sha256"] == b["film_sha256"] and a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+
+
+def test_split_traversal_env_gives_the_same_film():
+    """PBRT_HIP_SPLIT_TRAVERSAL (measurement aid: one launch per ray kind) must trace every shadow ray: film and ray counts equal the default path's.
+    (The any-hit launch used to find the round's queue heads already drained by the closest-hit launch.)"""
+    common = ["--config", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--spp", "4", "--res", "160", "--n-tris", "8000"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PBRT_HIP_SPLIT_TRAVERSAL", None)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=dict(env, PBRT_HIP_SPLIT_TRAVERSAL="1"), timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = _last_json(one.stdout), _last_json(two.stdout)
+    assert a["film_sha256"] == b["film_sha256"] and a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
