@@ -14,6 +14,8 @@ Workload (`--config`, named in the JSON line's config.workload):
   3 (default at N > 1)  configs[3]: 10 M triangles, 2048x2048 @ 64 spp, tiles sharded over the ranks, film tiles gathered with RCCL.  STRONG scaling:
                         the frame is the same for every N; a short weak-scaling leg (spp x N) is reported alongside under `weak_alongside`.
   1                     configs[1]: 100 k triangles, 512x512 @ 64 spp.          1M: the north-star 1 M-triangle scene at 512x512 @ 64 spp.
+  4                     configs[4]: "San Miguel (instanced, ~10 M tris, many materials), 1920x1080 @ 512 spp" on the generator of pbrt_hip/sanmiguel.py (the asset
+                        is not available offline): two-level BVH, TransformedPrimitive traversal, alpha masks, textured general materials, spatial light sampling.
   --n-tris/--res/--spp/--max-depth override single values (the workload is then labelled "custom").
 
 A step = one frame: SamplerIntegrator::render of the whole image (raygen -> [traverse, shade] x (maxdepth+1) -> film), film read back to the host.
@@ -55,6 +57,11 @@ CONFIGS = {  # BASELINE.json `configs`, on the synthetic generator of SURVEY §8
               label="configs[2]: 4.3 M triangles (synthetic stand-in of the same size for the Ganesha PLY, which is not available offline), PathIntegrator depth 8, 1024x1024 @ 256 spp"),
     "3": dict(n_tris=10_000_000, res=2048, spp=64, max_depth=5, label="configs[3]: synthetic 10 M triangles, 2048x2048 @ 64 spp, tiles sharded over the ranks, RCCL film-tile gather"),
     "1M": dict(n_tris=1_000_000, res=512, spp=64, max_depth=5, label="north-star 1 M-triangle scene: synthetic 1 M random triangles, 512x512 @ 64 spp"),
+    # configs[4]: the San Miguel asset is not available offline; pbrt_hip/sanmiguel.py generates a scene of the same shape (n_tris is filled in from the generator)
+    "4": dict(n_tris=0, res=1920, yres=1080, spp=512, max_depth=5,
+              label="configs[4]: San-Miguel-shaped synthetic scene (the asset is not available offline): 128 objects, 1 100 instances = 10.2 M instanced + 0.4 M top-level triangles, "
+                    "26 materials (image maps, procedural textures, bump maps, alpha-masked foliage, glass / metal / uber / translucent / mix), radiance-map sky + sun + point + 8 emissive "
+                    "triangles (spatial light distribution), 1920x1080 @ 512 spp"),
 }
 
 
@@ -75,8 +82,8 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PBRT_HIP_CPU_THREADS", "16"))))
 
 
-def workload_key(n_tris, res, spp, max_depth, seed):
-    return [int(n_tris), int(res), int(spp), int(max_depth), int(seed)]
+def workload_key(n_tris, res, spp, max_depth, seed, yres=None):
+    return [int(n_tris), int(res), int(spp), int(max_depth), int(seed)] + ([int(yres)] if yres and yres != res else [])
 
 
 def find_traffic(key):
@@ -139,6 +146,7 @@ def main():
     ap.add_argument("--no-weak-leg", action="store_true", help="N>1, strong: skip the short weak-scaling leg reported alongside")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = functional rehearsal of the N>1 path on ONE GPU: all ranks share device 0 and film tiles travel through host memory")
+    ap.add_argument("--sm-scale", type=float, default=1.0, help="--config 4: tessellation scale of the generated scene (triangle counts ~ scale; 1 = the configuration's size)")
     ap.add_argument("--multi-handle", action="store_true",
                     help="N>1 from ONE process: one pbrt_hip_scene_create_multi handle over the N GPUs, the film-tile gather inside the library (RCCL send / recv); "
                          "with --backend gloo the N contexts share GPU 0 (rehearsal)")
@@ -163,6 +171,7 @@ def main():
             cfg[k] = v
             custom.append(k)
     n_tris, res, spp, max_depth = cfg["n_tris"], cfg["res"], cfg["spp"], cfg["max_depth"]
+    yres = cfg.get("yres", res) if args.res is None else res
 
     import numpy as np
     import torch
@@ -195,6 +204,25 @@ def main():
         n_tris = len(idx) // 3
         custom.append(f"mesh from {os.path.basename(args.ply)}")
 
+    sm = None
+    if cfg_name == "4":
+        if args.ply or args.instances or args.material != "matte":
+            raise SystemExit("--config 4 is a fixed scene: --ply / --instances / --material do not apply")
+        from pbrt_hip.sanmiguel import SanMiguelScene
+        sm = SanMiguelScene(host, scale=args.sm_scale, seed=args.seed + 4)
+        n_tris = sm.counts()["total_triangles_as_instanced"]
+        if args.sm_scale != 1.0:
+            custom.append(f"tessellation scale {args.sm_scale}")
+
+    def capture(scene, frame_spp, device_build):
+        """The workload's scene into `scene` (the product's handle, or the oracle's for the CPU baseline); returns nothing, builds the accelerator."""
+        nonlocal geometry
+        if sm is not None:
+            sm.capture(scene, res, yres, frame_spp, device_build=device_build)
+            return
+        spec = pbrt_hip.SceneSpec(n_tris=n_tris, seed=args.seed, xres=res, yres=yres, spp=frame_spp, max_depth=max_depth, material=args.material)
+        geometry = pbrt_hip.capture_spec(spec, scene, host, geometry=geometry, instances=args.instances, device_build=device_build)
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
@@ -208,14 +236,12 @@ def main():
 
     def run_leg(frame_spp, steps, warmup):
         """Builds the scene at `frame_spp`, renders warmup + steps frames; returns (scene, tile_buf, stats dict)."""
-        nonlocal geometry
-        spec = pbrt_hip.SceneSpec(n_tris=n_tris, seed=args.seed, xres=res, yres=res, spp=frame_spp, max_depth=max_depth, material=args.material)
         if args.multi_handle:   # one handle over the N GPUs (rehearsal: N contexts on GPU 0)
             scene = pbrt_hip.Scene(devices=[0] * n_gpus if args.backend == "gloo" else list(range(n_gpus)))
         else:
             scene = pbrt_hip.Scene(device=local_rank)
         t_setup = time.time()
-        geometry = pbrt_hip.capture_spec(spec, scene, host, geometry=geometry, instances=args.instances, device_build=not args.host_build)
+        capture(scene, frame_spp, device_build=not args.host_build)
         t_setup = time.time() - t_setup
         floats = max(scene.tile_buffer_floats(tile_size, p, world) for p in range(world))
         tile_buf = torch.zeros(floats, dtype=torch.float32, device=dev)
@@ -285,16 +311,19 @@ def main():
             "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("" if not args.instances else f"INSTANCED x{args.instances} (one object, two-level BVH) — ") + label +
-                                   f" — as run: {n_tris} random triangles (seed {args.seed}), single SAH BVH (maxnodeprims 4), {res}x{res} @ {frame_spp} spp{spp_note}, "
-                                   f"PathIntegrator maxdepth {max_depth}, halton, box filter, constant infinite light, " + ("matte Kd 0.5" if args.material == "matte" else f"material {args.material}"),
-                       "baseline_config": cfg_name if not custom else "custom", "key": workload_key(n_tris, res, frame_spp, max_depth, args.seed),
+                                   (f" — as run: {n_tris} random triangles (seed {args.seed}), single SAH BVH (maxnodeprims 4), {res}x{yres} @ {frame_spp} spp{spp_note}, "
+                                    f"PathIntegrator maxdepth {max_depth}, halton, box filter, constant infinite light, " + ("matte Kd 0.5" if args.material == "matte" else f"material {args.material}")
+                                    if sm is None else
+                                    f" — as run: {json.dumps(sm.counts())}, {sm.n_materials} materials, two-level SAH BVH (maxnodeprims 4), {res}x{yres} @ {frame_spp} spp{spp_note}, "
+                                    f"PathIntegrator maxdepth {max_depth}, halton, box filter, lightsamplestrategy spatial"),
+                       "baseline_config": cfg_name if not custom else "custom", "key": workload_key(n_tris, res, frame_spp, max_depth, args.seed, yres),
                        "tiles": (f"16x16, tile t on device t % {n_gpus} of ONE multi-device handle (one host thread per device), film tiles gathered on the first device inside the library"
                                  + (" (RCCL send / recv)" if args.backend == "nccl" else " (device-to-device copies: the contexts share GPU 0)")) if args.multi_handle else
                                 f"16x16, tile t on rank t % {world}, film tiles gathered on rank 0 (" + ("RCCL" if args.backend == "nccl" else "gloo, through host memory: rehearsal on one GPU") + ")" if world > 1 else "16x16, one rank",
                        "rays_per_frame": r["rays"] // args.steps, "regular_rays_per_frame": r["reg"] // args.steps, "shadow_rays_per_frame": r["shd"] // args.steps,
                        "scene_setup_seconds_host": round(r["t_setup"], 3),
                        "accel": {"interior_nodes": acc["interior_nodes"], "leaf_records": acc["leaf_records"],
-                                 "resident_bytes": acc["node_bytes"] + acc["leaf_record_bytes"], "build_seconds": round(acc["build_seconds"], 3), "built_on": "host" if (args.host_build or args.instances) else "device"}},
+                                 "resident_bytes": acc["node_bytes"] + acc["leaf_record_bytes"], "build_seconds": round(acc["build_seconds"], 3), "built_on": "host" if args.host_build else "device"}},
             "film_sha256": hashlib.sha256(r["film"][0].tobytes() + r["film"][1].tobytes()).hexdigest(),
             "stage_ms_per_step_rank0": {"traversal": round((r["ext_s"] + r["sh_s"]) / args.steps * 1e3, 3),
                                         "raygen_shade_film": round(r["shade_s"] / args.steps * 1e3, 3)},
@@ -338,7 +367,7 @@ def main():
                 # MI355X_MICROARCH.md: FETCH_SIZE doubles for wide coalesced streaming reads only — this kernel reads random 64-B lines, for which the
                 # calibration run scripts/calib/fetch_calib.hip shows FETCH_SIZE exact, so fetch_scale is 1).  Only a run of this exact workload counts.
                 plain = n_gpus == 1 and args.material == "matte" and not args.instances
-                e, why = find_traffic(workload_key(n_tris, res, frame_spp, max_depth, args.seed)) if plain else (None, "PMC records are kept for the plain matte single-GPU workloads only")
+                e, why = find_traffic(workload_key(n_tris, res, frame_spp, max_depth, args.seed, yres)) if plain else (None, "PMC records are kept for the single-GPU BASELINE workloads only")
                 if e is not None:
                     k = e["traversal"]
                     per_launch = (float(e.get("fetch_scale", 1.0)) * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"]
@@ -363,10 +392,9 @@ def main():
         cores = host_cores()
         rays_per_spp = max(1, (r["rays"] // args.steps) // frame_spp)
         cpu_spp = args.cpu_spp if args.cpu_spp > 0 else max(1, min(spp, round(150e6 / rays_per_spp)))
-        cspec = pbrt_hip.SceneSpec(n_tris=n_tris, seed=args.seed, xres=res, yres=res, spp=cpu_spp, max_depth=max_depth, material=args.material)
         orc = OracleScene()
         tb = time.time()
-        pbrt_hip.capture_spec(cspec, orc, host, geometry=geometry, instances=args.instances)
+        capture(orc, cpu_spp, device_build=False)
         tb = time.time() - tb
         _, _, ost, _ = orc.render_path_ex(max_depth=max_depth, threads=cores)
         crays = ost.regular_rays + ost.shadow_rays

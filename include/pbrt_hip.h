@@ -148,8 +148,10 @@ int pbrt_hip_add_mesh(PbrtHipScene*, const float* P, uint32_t n_verts, const uin
  * object_begin and object_end belong to the object, not to the scene (ObjectBegin/ObjectEnd); add_instance places one
  * TransformedPrimitive(object aggregate, instance_to_world) in the scene's primitive list (ObjectInstance) — nothing if the
  * object is empty.  The object's aggregate uses the split method of pbrt_hip_build_accel; an object with exactly one
- * primitive is used directly (lib.rs:953-971).  Area lights inside objects are refused (the reference drops them with a
- * warning, lib.rs:877-881).  Transforms are static (AnimatedTransform with equal end points). */
+ * primitive is used directly (lib.rs:953-971).  Area lights of meshes inside an object definition behave as in the reference
+ * ("Area lights not supported with object instancing", lib.rs:877-881): the call succeeds, pbrt_hip_last_error holds that warning, the triangles keep their
+ * emission where a path looks at them (SurfaceInteraction::le) and the lights leave the scene's light list — nothing samples them; they must be the lights
+ * created last, so that no other light's number changes.  Transforms are static (AnimatedTransform with equal end points). */
 int pbrt_hip_object_begin(PbrtHipScene*, uint32_t* out_object_id);
 int pbrt_hip_object_end(PbrtHipScene*);
 int pbrt_hip_add_instance(PbrtHipScene*, uint32_t object_id, const float instance_to_world[16], const float world_to_instance[16]);
@@ -282,8 +284,8 @@ int pbrt_hip_build_accel(PbrtHipScene*, int split_method, int max_prims_in_node)
 /* The same with the tree constructed on the GPU: identical topology, leaf order and boxes, so hits do not depend on where the tree was built.
  * split_method 0 (SAH, the reference's default; accelerators/src/bvh/sah.rs:26-367): one level of the tree per round of kernels — bucket boxes by atomics,
  * the reference's cost loop per node, itertools::partition's element order from a prefix sum.  split_method 1 (HLBVH; hlbvh.rs:33-449, morton.rs:33-120):
- * Morton codes, radix sort, one treelet per thread, SAH over the treelet roots on the host.  EqualCounts (3) is a host build: UNSUPPORTED here; so are
- * scenes with object instances. */
+ * Morton codes, radix sort, one treelet per thread, SAH over the treelet roots on the host.  EqualCounts (3) is a host build: UNSUPPORTED here.  Scenes with object
+ * instances (SAH only): the scene's aggregate and every instanced object's are built side by side as one forest, level by level. */
 int pbrt_hip_build_accel_device(PbrtHipScene*, int split_method, int max_prims_in_node);
 
 /* World bound of the built aggregate (BVHAccel::world_bound, bvh/mod.rs:161-167): {pmin[3], pmax[3]}. */
@@ -292,6 +294,8 @@ int pbrt_hip_world_bound(const PbrtHipScene*, float out_bounds[6]);
 /* Measurement aid (not a reference interface): the built structure in the device layout.  out[0] interior nodes (64 B each: both children's boxes),
  * out[1] leaf records (48 B each), out[2] / out[3] their bytes, out[4] leaves, out[5] depth, out[6] largest leaf, out[7] build time in microseconds. */
 int pbrt_hip_accel_stats(const PbrtHipScene*, uint64_t out[8]);
+/* Test aid: copies the structure out (out[0] x 64-byte nodes, out[1] x 48-byte leaf records), from wherever it was built. */
+int pbrt_hip_accel_copy(PbrtHipScene*, void* out_nodes, uint64_t node_capacity, void* out_leaf_records, uint64_t record_capacity);
 
 /* ---- the hot path ---------------------------------------------------------------------------------------- */
 

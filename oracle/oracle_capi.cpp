@@ -161,7 +161,16 @@ int oracle_add_mesh(OracleScene* s, const float* P, uint32_t n_verts, const uint
     if (material_id >= s->sc.materials.size()) { s->err = "bad material id"; return -1; }
     for (uint32_t i = 0; i < 3 * n_tris; i++) if (indices[i] >= n_verts) { s->err = "vertex index out of bounds"; return -1; }
     Scene& sc = s->sc;
-    if (sc.open_object >= 0 && first_area_light_id >= 0) { s->err = "area lights are not supported inside an object instance (lib.rs:877-881)"; return -5; }
+    if (sc.open_object >= 0 && first_area_light_id >= 0) {
+        // "Area lights not supported with object instancing" (api/src/lib.rs:877-881): the primitives keep their area light (its emission), the scene's light list does not get it
+        if ((size_t)first_area_light_id + n_tris != sc.lights.size()) { s->err = "area lights of a shape inside an object definition must be the ones created last"; return -1; }
+        for (uint32_t k = 0; k < n_tris; k++) if (sc.lights[first_area_light_id + k].type != L_AREA) { s->err = "light is not an area light"; return -1; }
+        const int32_t first = -2 - (int32_t)sc.emission_only.size();
+        sc.emission_only.insert(sc.emission_only.end(), sc.lights.begin() + first_area_light_id, sc.lights.end());
+        sc.lights.resize((size_t)first_area_light_id);
+        first_area_light_id = first;
+        s->err = "warning: Area lights not supported with object instancing.";
+    }
     Mesh m;
     m.vert_base = (uint32_t)sc.P.size(); m.tri_base = (uint32_t)sc.n_tris(); m.n_verts = n_verts; m.n_tris = n_tris;
     m.has_n = N != nullptr; m.has_s = S != nullptr; m.has_uv = UV != nullptr;

@@ -613,6 +613,12 @@ struct Renderer {
 
     // ---- lights ------------------------------------------------------------------------------------------------
     Spec area_L(const Light& l, V3 n, V3 w) const { return (l.two_sided || dot(n, w) > 0.0f) ? l.L : Spec(0.0f); }  // diffuse.rs:220-226
+    // SurfaceInteraction::le (surface_interaction.rs:283-289): the emission of the primitive's area light, whether or not that light is one of the scene's (Scene::emission_only)
+    Spec prim_le(const Mesh& m, uint32_t prim, V3 n, V3 w) const {
+        if (m.first_light >= 0) return area_L(sc->lights[m.first_light + (prim - m.tri_base)], n, w);
+        if (m.first_light <= -2) return area_L(sc->emission_only[(size_t)(-2 - m.first_light) + (prim - m.tri_base)], n, w);
+        return Spec(0.0f);
+    }
     Spec light_le(const Light& l, const Ray& ray) const {  // Light::le: infinite.rs:188-195; others Spectrum::ZERO
         if (l.type != L_INFINITE) return Spec(0.0f);
         V3 w = normalize(l.l2w.inv().vector(ray.d));
@@ -1388,7 +1394,7 @@ struct Renderer {
         }
         const V3 n = isect.ns, wo = isect.wo;
         const Mesh& m = s.mesh_of(prim);
-        if (m.first_light >= 0) L += area_L(s.lights[m.first_light + (prim - m.tri_base)], isect.n, wo);  // isect.le(&wo)
+        L += prim_le(m, prim, isect.n, wo);  // isect.le(&wo)
         for (const Light& light : s.lights) {
             const V2 u = sampler.get_2d();
             const LiSample ls = light_sample_li(light, isect, u);
@@ -1455,9 +1461,7 @@ struct Renderer {
             if (bounces == 0 || specular_bounce) {
                 if (found) {
                     const Mesh& m = s.mesh_of(prim);
-                    Spec le(0.0f);
-                    if (m.first_light >= 0) le = area_L(s.lights[m.first_light + (prim - m.tri_base)], isect.n, -ray.d);
-                    L += beta * le;
+                    L += beta * prim_le(m, prim, isect.n, -ray.d);
                 } else {
                     for (int li_ : s.infinite_lights) L += beta * light_le(s.lights[li_], ray);
                 }

@@ -217,6 +217,9 @@ struct Scene {
     std::vector<Texture> textures;    // float and spectrum textures share one id space
     std::vector<MipMap> mipmaps;
     std::vector<Light> lights;
+    // DiffuseAreaLights of shapes inside an object definition: the reference keeps them on the primitives (their emission is seen where a path looks at the surface) but
+    // never adds them to the scene's lights — "Area lights not supported with object instancing" (api/src/lib.rs:877-881).  Mesh::first_light = -2 - index for those.
+    std::vector<Light> emission_only;
     std::vector<int> infinite_lights;
     std::vector<Sphere> spheres;      // oracle-only shapes; each owns one Mesh record and one primitive slot
     std::vector<Hyperboloid> hyperboloids;

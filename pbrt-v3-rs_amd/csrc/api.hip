@@ -96,7 +96,12 @@ int upload_scene(PbrtHipScene* s) {
     if ((rc = upload_vec(s, s->idx, &d.idx))) return rc;
     if ((rc = upload_vec(s, s->tri_mesh, &d.tri_mesh))) return rc;
     if ((rc = upload_vec(s, s->tri_flags, &d.tri_flags))) return rc;
-    if ((rc = upload_vec(s, s->meshes, &d.meshes))) return rc;
+    if (s->emission_only.empty()) { if ((rc = upload_vec(s, s->meshes, &d.meshes))) return rc; }
+    else {   // emission-only area lights sit behind the scene's lights on the device: their meshes point there
+        std::vector<MeshRec> meshes(s->meshes);
+        for (MeshRec& m : meshes) if (m.first_light <= -2) m.first_light = (int32_t)(s->lights.size() + (size_t)(-2 - m.first_light));
+        if ((rc = upload_vec(s, meshes, &d.meshes))) return rc;
+    }
     {   // per material: what the texture pass has to hand to the shade pass (texture.h: eval_lobe_colours / build_hit_lobes use the same slot rules)
         for (MaterialRec& m : s->materials) {
             uint32_t cols = m.amount_tex1 ? 1u : 0u; bool hdr = m.bump_tex1 != 0u || m.sigma_tex1 != 0u;
@@ -133,7 +138,12 @@ int upload_scene(PbrtHipScene* s) {
         if ((rc = upload_vec(s, s->texels, &d.texels))) return rc;
         if ((rc = upload_vec(s, lut, &d.ewa_lut))) return rc;
     }
-    if ((rc = upload_vec(s, s->lights, &d.lights))) return rc;
+    if (s->emission_only.empty()) { if ((rc = upload_vec(s, s->lights, &d.lights))) return rc; }
+    else {
+        std::vector<LightRec> all(s->lights);
+        all.insert(all.end(), s->emission_only.begin(), s->emission_only.end());
+        if ((rc = upload_vec(s, all, &d.lights))) return rc;
+    }
     if ((rc = upload_vec(s, s->light_dist, &d.light_dist))) return rc;
     d.n_lights = (uint32_t)s->lights.size();
     if ((rc = upload_vec(s, s->infinite_lights, &d.infinite_lights))) return rc;
@@ -272,14 +282,15 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
         else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, false, wpe>), g, b, 0, s->stream, s->ds, p); \
         else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, false, wpe>), g, b, 0, s->stream, s->ds, p);             \
     } while (0)
-#define PH_LAUNCH3A(inst)                                                                                                              \
+#define PH_LAUNCH3A(cnt, ns, inst)                                                                                                     \
     do {                                                                                                                              \
-        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, inst, true, true>), g, b, 0, s->stream, s->ds, p);       \
-        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, inst, false, true>), g, b, 0, s->stream, s->ds, p);  \
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, inst, false, true>), g, b, 0, s->stream, s->ds, p);                \
+        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, ns, inst, true, true>), g, b, 0, s->stream, s->ds, p);       \
+        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, ns, inst, false, true>), g, b, 0, s->stream, s->ds, p);  \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, ns, inst, false, true>), g, b, 0, s->stream, s->ds, p);                \
     } while (0)
-    if (s->alpha_textures) {  // meshes with alpha-mask textures: the ALPHA variants (their work counters are not implemented)
-        if (!s->inst_recs.empty()) PH_LAUNCH3A(true); else PH_LAUNCH3A(false);
+    if (s->alpha_textures) {  // meshes with alpha-mask textures: the ALPHA variants
+        if (s->count_traversal) { if (!s->inst_recs.empty()) PH_LAUNCH3A(true, 1, true); else PH_LAUNCH3A(true, 1, false); }
+        else if (!s->inst_recs.empty()) PH_LAUNCH3A(false, 3, true); else PH_LAUNCH3A(false, 3, false);
         return;
     }
     if (!s->inst_recs.empty()) {  // scenes with object instances: the TransformedPrimitive-aware kernels
@@ -784,8 +795,18 @@ int pbrt_hip_add_mesh(PbrtHipScene* s, const float* P, uint32_t n_verts, const u
             if (s->lights[first_area_light_id + k].type != PH_L_AREA || s->lights[first_area_light_id + k].prim != 0xFFFFFFFFu)
                 return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mesh: light is not an unbound diffuse area light");
     }
-    if (s->open_object >= 0 && first_area_light_id >= 0)
-        return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_mesh: area lights are not supported inside an object instance (the reference warns and drops them, api/src/lib.rs:877-881)");
+    bool dropped_lights = false;
+    if (s->open_object >= 0 && first_area_light_id >= 0) {
+        // "Area lights not supported with object instancing" (api/src/lib.rs:877-881): a warning, the primitives keep their area light — a path that looks at such a surface
+        // sees its emission (SurfaceInteraction::le) — and the light is not added to the scene's lights: nothing samples it.
+        if ((size_t)first_area_light_id + n_tris != s->lights.size())
+            return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mesh: the area lights of a shape inside an object definition must be the lights created last (they leave the scene's light list)");
+        const int32_t first = -2 - (int32_t)s->emission_only.size();
+        s->emission_only.insert(s->emission_only.end(), s->lights.begin() + first_area_light_id, s->lights.end());
+        s->lights.resize((size_t)first_area_light_id);
+        first_area_light_id = first;
+        dropped_lights = true;
+    }
     MeshRec m{};
     m.vert_base = (uint32_t)(s->P.size() / 3); m.tri_base = (uint32_t)(s->idx.size() / 3); m.n_tris = n_tris;
     m.flags = (N ? PH_MESH_N : 0) | (S ? PH_MESH_S : 0) | (UV ? PH_MESH_UV : 0) | ((flags & 1) ? PH_MESH_REV : 0) | ((flags & 2) ? PH_MESH_SWAP : 0);
@@ -809,8 +830,8 @@ int pbrt_hip_add_mesh(PbrtHipScene* s, const float* P, uint32_t n_verts, const u
         if (alpha == 0.0f) tf |= PH_TRI_ALPHA0;
         if (shadow_alpha == 0.0f) tf |= PH_TRI_SALPHA0;
         s->tri_flags.push_back(tf);
-        if (first_area_light_id >= 0) {
-            LightRec& l = s->lights[first_area_light_id + t];
+        if (first_area_light_id >= 0 || dropped_lights) {
+            LightRec& l = dropped_lights ? s->emission_only[(size_t)(-2 - first_area_light_id) + t] : s->lights[first_area_light_id + t];
             l.prim = m.tri_base + t;
             l.area = 0.5f * hm::len(hm::cross(hm::sub(p1, p0), hm::sub(p2, p0)));  // Triangle::area (triangle.rs:906-911)
         }
@@ -819,6 +840,7 @@ int pbrt_hip_add_mesh(PbrtHipScene* s, const float* P, uint32_t n_verts, const u
     if (s->open_object >= 0) s->objects[s->open_object].tri1 = m.tri_base + n_tris;
     else for (uint32_t t = 0; t < n_tris; t++) s->top_items.push_back(m.tri_base + t);
     s->built = false; s->uploaded = false;
+    if (dropped_lights) s->err = "warning: Area lights not supported with object instancing.";   // the reference's warn! (lib.rs:878); the call succeeds
     return PBRT_HIP_OK;
 }
 
@@ -1096,71 +1118,42 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
         } else brc = phost::build_bvh(in, split_method, max_prims_in_node, 0, s->bvh);
         if (brc != 0) return fail(brc);
     } else {
-        if (s->build_on_device) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel_device: scenes with object instances take the host builder");
         if (s->open_object >= 0) return set_err(s, PBRT_HIP_ERR_STATE, "build_accel: an object definition is still open (missing ObjectEnd)");
-        // 1. one aggregate per instanced object (make_accelerator at ObjectInstance time, lib.rs:953-971), appended to shared arrays
-        struct Built { bool done = false; uint32_t root_ref = PH_INVALID_REF; float lo[3], hi[3]; bool single = false; };
-        std::vector<Built> built(s->objects.size());
-        std::vector<Node64> obj_nodes; std::vector<TriRec> obj_tris;
-        for (const PbrtHipScene::InstanceHost& ih : s->instances) {
-            Built& b = built[ih.object];
-            if (b.done) continue;
-            b.done = true;
-            const PbrtHipScene::ObjectHost& ob = s->objects[ih.object];
-            std::vector<uint32_t> items(ob.tri1 - ob.tri0);
-            for (uint32_t t = ob.tri0; t < ob.tri1; t++) items[t - ob.tri0] = t;
-            phost::BuildInput oi = in; oi.items = items.data(); oi.n_items = items.size();
-            phost::BuildOutput bo;
-            const int brc = phost::build_bvh(oi, split_method, max_prims_in_node, 0, bo);
+        if (s->build_on_device && split_method != 0) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel_device: scenes with object instances are built on the device with the SAH method only");
+        // One aggregate per instanced object (make_accelerator at ObjectInstance time, lib.rs:953-971) and the scene's own over its triangles and TransformedPrimitives,
+        // in one node array and one TriRec array: [scene | objects] (bvh_build.h)
+        std::vector<uint32_t> tri0(s->objects.size()), tri1(s->objects.size()), inst_object(s->instances.size());
+        std::vector<float> inst_i2w(16 * s->instances.size());
+        for (size_t k = 0; k < s->objects.size(); k++) { tri0[k] = s->objects[k].tri0; tri1[k] = s->objects[k].tri1; }
+        for (size_t k = 0; k < s->instances.size(); k++) { inst_object[k] = s->instances[k].object; std::memcpy(&inst_i2w[16 * k], s->instances[k].i2w, 64); }
+        const phost::InstancedScene isc{tri0.data(), tri1.data(), tri0.size(), inst_object.data(), inst_i2w.data(), inst_object.size(), s->top_items.data(), s->top_items.size()};
+        phost::ForestLayout layout;
+        phost::forest_layout(isc, layout);
+        std::vector<phost::ForestTreeOut> trees;
+        if (s->build_on_device) {
+            PH_CHECK(s, hipSetDevice(s->device));
+            std::string e;
+            const phost::ForestSpec spec = layout.spec(isc);
+            const int brc = phost::build_sah_device(in, max_prims_in_node, s->stream, s->bvh, e, &s->tree_dev_nodes, &s->tree_dev_tris, &spec, &trees);
+            if (brc == -1) return set_err(s, PBRT_HIP_ERR_DEVICE, "build_accel_device: " + e);
             if (brc != 0) return fail(brc);
-            const uint32_t node_off = (uint32_t)obj_nodes.size(), tri_off = (uint32_t)obj_tris.size();
-            auto fix = [&](uint32_t ref) { return (ref & PH_LEAF_BIT) ? (PH_LEAF_BIT | ((ref & ~PH_LEAF_BIT) + tri_off)) : ref + node_off; };
-            for (Node64 nd : bo.nodes) { nd.c0 = fix(nd.c0); nd.c1 = fix(nd.c1); obj_nodes.push_back(nd); }
-            obj_tris.insert(obj_tris.end(), bo.tris.begin(), bo.tris.end());
-            b.root_ref = fix(bo.root_ref); b.single = items.size() == 1;
-            for (int k = 0; k < 3; k++) { b.lo[k] = bo.root_lo[k]; b.hi[k] = bo.root_hi[k]; }
+            if (s->tree_dev_tris) s->tree_dev_n_tris = layout.items.size();
+        } else {
+            const int brc = phost::build_forest_host(in, isc, layout, split_method, max_prims_in_node, s->bvh, trees);
+            if (brc != 0) return fail(brc);
         }
-        // 2. TransformedPrimitive::world_bound = Transform::transform_bounds of the aggregate's bound (transform.rs:552-561): the 8 corners
-        //    in the reference's order, each through transform_point (:288-302)
-        std::vector<float> ibounds(6 * s->instances.size());
         for (size_t k = 0; k < s->instances.size(); k++) {
             const PbrtHipScene::InstanceHost& ih = s->instances[k];
-            const Built& b = built[ih.object];
-            const float* m = ih.i2w;
-            auto xf = [&](float x, float y, float z, float* o) {
-                const float xp = m[0] * x + m[1] * y + m[2] * z + m[3], yp = m[4] * x + m[5] * y + m[6] * z + m[7];
-                const float zp = m[8] * x + m[9] * y + m[10] * z + m[11], wp = m[12] * x + m[13] * y + m[14] * z + m[15];
-                if (wp == 1.0f) { o[0] = xp; o[1] = yp; o[2] = zp; } else { const float inv = 1.0f / wp; o[0] = inv * xp; o[1] = inv * yp; o[2] = inv * zp; }
-            };
-            const float* lo = b.lo; const float* hi = b.hi;
-            const float corners[8][3] = {{lo[0], lo[1], lo[2]}, {hi[0], lo[1], lo[2]}, {lo[0], hi[1], lo[2]}, {lo[0], lo[1], hi[2]},
-                                         {lo[0], hi[1], hi[2]}, {hi[0], hi[1], lo[2]}, {hi[0], lo[1], hi[2]}, {hi[0], hi[1], hi[2]}};
-            float* ob = &ibounds[6 * k];
-            for (int c = 0; c < 8; c++) {
-                float q[3]; xf(corners[c][0], corners[c][1], corners[c][2], q);
-                for (int a = 0; a < 3; a++) {
-                    if (c == 0) { ob[a] = ob[3 + a] = q[a]; }
-                    else { ob[a] = ob[a] < q[a] ? ob[a] : q[a]; ob[3 + a] = ob[3 + a] > q[a] ? ob[3 + a] : q[a]; }
-                }
-            }
+            const phost::ForestTreeOut& b = trees[layout.inst_tree[k]];
             InstRec r{};
             std::memcpy(r.w2i, ih.w2i, 64); std::memcpy(r.i2w, ih.i2w, 64);
             for (int a = 0; a < 3; a++) { r.lo[a] = b.lo[a]; r.hi[a] = b.hi[a]; }
-            r.root_ref = b.root_ref; r.flags = b.single ? PH_INST_SINGLE : 0u;
+            r.root_ref = b.root_ref; r.flags = b.n_items == 1 ? PH_INST_SINGLE : 0u;   // an object with one primitive is used directly, without an aggregate (lib.rs:953-956)
             bool ident = true;
             for (int a = 0; a < 16; a++) if (ih.i2w[a] != ((a % 5 == 0) ? 1.0f : 0.0f)) ident = false;
             if (ident) r.flags |= PH_INST_IDENTITY;
             s->inst_recs.push_back(r);
         }
-        // 3. the scene aggregate over triangles and instances, then one node / TriRec array: [scene | objects]
-        phost::BuildInput ti = in; ti.items = s->top_items.data(); ti.n_items = s->top_items.size(); ti.inst_bounds = ibounds.data();
-        const int brc = phost::build_bvh(ti, split_method, max_prims_in_node, 0, s->bvh);
-        if (brc != 0) return fail(brc);
-        const uint32_t node_off = (uint32_t)s->bvh.nodes.size(), tri_off = (uint32_t)s->bvh.tris.size();
-        auto fix = [&](uint32_t ref) { return (ref & PH_LEAF_BIT) ? (PH_LEAF_BIT | ((ref & ~PH_LEAF_BIT) + tri_off)) : ref + node_off; };
-        for (Node64 nd : obj_nodes) { nd.c0 = fix(nd.c0); nd.c1 = fix(nd.c1); s->bvh.nodes.push_back(nd); }
-        s->bvh.tris.insert(s->bvh.tris.end(), obj_tris.begin(), obj_tris.end());
-        for (InstRec& r : s->inst_recs) r.root_ref = fix(r.root_ref);
     }
     // Light::preprocess: bounding sphere of the world bound (bounds3.rs:196-208; infinite.rs:113-117, distant.rs:54-58)
     s->world_radius = 1.0f; s->world_center[0] = s->world_center[1] = s->world_center[2] = 0.0f;
@@ -1202,6 +1195,23 @@ int pbrt_hip_accel_stats(const PbrtHipScene* s, uint64_t out[8]) {
     out[2] = out[0] * sizeof(Node64); out[3] = out[1] * sizeof(TriRec);
     out[4] = s->bvh.leaf_nodes; out[5] = (uint64_t)s->bvh.max_depth; out[6] = s->bvh.max_leaf_prims;
     out[7] = (uint64_t)(s->bvh.build_seconds * 1e6);
+    return PBRT_HIP_OK;
+}
+
+// test aid: the built structure itself (device layout), wherever it lives
+int pbrt_hip_accel_copy(PbrtHipScene* s, void* out_nodes, uint64_t node_capacity, void* out_leaf_records, uint64_t record_capacity) {
+    if (!s) return PBRT_HIP_ERR_INVALID_ARG;
+    if (!s->built) return set_err(s, PBRT_HIP_ERR_STATE, "accel_copy: build_accel first");
+    const size_t nn = s->tree_dev_tris ? s->bvh.interior_nodes : s->bvh.nodes.size(), nt = s->tree_dev_tris ? s->tree_dev_n_tris : s->bvh.tris.size();
+    if (node_capacity < nn || record_capacity < nt) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "accel_copy: buffers too small (pbrt_hip_accel_stats gives the sizes)");
+    if (s->tree_dev_tris) {
+        PH_CHECK(s, hipSetDevice(s->device));
+        if (nn && out_nodes) PH_CHECK(s, hipMemcpy(out_nodes, s->tree_dev_nodes, nn * sizeof(Node64), hipMemcpyDeviceToHost));
+        if (nt && out_leaf_records) PH_CHECK(s, hipMemcpy(out_leaf_records, s->tree_dev_tris, nt * sizeof(TriRec), hipMemcpyDeviceToHost));
+    } else {
+        if (nn && out_nodes) std::memcpy(out_nodes, s->bvh.nodes.data(), nn * sizeof(Node64));
+        if (nt && out_leaf_records) std::memcpy(out_leaf_records, s->bvh.tris.data(), nt * sizeof(TriRec));
+    }
     return PBRT_HIP_OK;
 }
 

@@ -505,4 +505,77 @@ int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int
     return 0;
 }
 
+void forest_layout(const InstancedScene& sc, ForestLayout& out) {
+    out.items.assign(sc.top_items, sc.top_items + sc.n_top);
+    out.tree_start.assign({0u, (uint32_t)sc.n_top});
+    out.inst_tree.assign(sc.n_inst, 0u);
+    std::vector<uint32_t> tree_of_object(sc.n_objects, 0u);
+    for (size_t k = 0; k < sc.n_inst; k++) {
+        const uint32_t ob = sc.inst_object[k];
+        if (!tree_of_object[ob]) {   // make_accelerator at the object's first ObjectInstance (lib.rs:953-971)
+            tree_of_object[ob] = (uint32_t)out.tree_start.size() - 1u;
+            for (uint32_t t = sc.obj_tri0[ob]; t < sc.obj_tri1[ob]; t++) out.items.push_back(t);
+            out.tree_start.push_back((uint32_t)out.items.size());
+        }
+        out.inst_tree[k] = tree_of_object[ob];
+    }
+}
+
+void transform_bounds(const float* m, const float* lo, const float* hi, float* ob) {
+    auto xf = [&](float x, float y, float z, float* o) {
+        const float xp = m[0] * x + m[1] * y + m[2] * z + m[3], yp = m[4] * x + m[5] * y + m[6] * z + m[7];
+        const float zp = m[8] * x + m[9] * y + m[10] * z + m[11], wp = m[12] * x + m[13] * y + m[14] * z + m[15];
+        if (wp == 1.0f) { o[0] = xp; o[1] = yp; o[2] = zp; } else { const float inv = 1.0f / wp; o[0] = inv * xp; o[1] = inv * yp; o[2] = inv * zp; }
+    };
+    const float corners[8][3] = {{lo[0], lo[1], lo[2]}, {hi[0], lo[1], lo[2]}, {lo[0], hi[1], lo[2]}, {lo[0], lo[1], hi[2]},
+                                 {lo[0], hi[1], hi[2]}, {hi[0], hi[1], lo[2]}, {hi[0], lo[1], hi[2]}, {hi[0], hi[1], hi[2]}};
+    for (int c = 0; c < 8; c++) {
+        float q[3]; xf(corners[c][0], corners[c][1], corners[c][2], q);
+        for (int a = 0; a < 3; a++) {
+            if (c == 0) { ob[a] = ob[3 + a] = q[a]; }
+            else { ob[a] = ob[a] < q[a] ? ob[a] : q[a]; ob[3 + a] = ob[3 + a] > q[a] ? ob[3 + a] : q[a]; }
+        }
+    }
+}
+
+int build_forest_host(const BuildInput& in, const InstancedScene& sc, const ForestLayout& L, int split_method, int max_prims_in_node, BuildOutput& out, std::vector<ForestTreeOut>& trees) {
+    auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n_trees = (uint32_t)L.tree_start.size() - 1u;
+    trees.assign(n_trees, ForestTreeOut{});
+    std::vector<BuildOutput> built(n_trees);
+    // 1. the objects' aggregates
+    for (uint32_t t = 1; t < n_trees; t++) {
+        BuildInput oi = in; oi.items = L.items.data() + L.tree_start[t]; oi.n_items = L.tree_start[t + 1] - L.tree_start[t]; oi.inst_bounds = nullptr;
+        const int brc = build_bvh(oi, split_method, max_prims_in_node, 0, built[t]);
+        if (brc != 0) return brc;
+    }
+    // 2. TransformedPrimitive::world_bound of every instance, then the scene's aggregate
+    std::vector<float> ibounds(6 * sc.n_inst);
+    for (size_t k = 0; k < sc.n_inst; k++) transform_bounds(sc.inst_i2w + 16 * k, built[L.inst_tree[k]].root_lo, built[L.inst_tree[k]].root_hi, &ibounds[6 * k]);
+    {
+        BuildInput ti = in; ti.items = L.items.data(); ti.n_items = L.tree_start[1]; ti.inst_bounds = ibounds.data();
+        const int brc = build_bvh(ti, split_method, max_prims_in_node, 0, built[0]);
+        if (brc != 0) return brc;
+    }
+    // 3. one node array, one TriRec array
+    out = BuildOutput();
+    for (uint32_t t = 0; t < n_trees; t++) {
+        const BuildOutput& bo = built[t];
+        const uint32_t node_off = (uint32_t)out.nodes.size(), tri_off = (uint32_t)out.tris.size();
+        auto fix = [&](uint32_t ref) { return (ref & PH_LEAF_BIT) ? (PH_LEAF_BIT | ((ref & ~PH_LEAF_BIT) + tri_off)) : ref + node_off; };
+        for (Node64 nd : bo.nodes) { nd.c0 = fix(nd.c0); nd.c1 = fix(nd.c1); out.nodes.push_back(nd); }
+        out.tris.insert(out.tris.end(), bo.tris.begin(), bo.tris.end());
+        ForestTreeOut& fo = trees[t];
+        fo.root_ref = fix(bo.root_ref); fo.n_items = L.tree_start[t + 1] - L.tree_start[t];
+        for (int k = 0; k < 3; k++) { fo.lo[k] = bo.root_lo[k]; fo.hi[k] = bo.root_hi[k]; }
+        out.interior_nodes += bo.interior_nodes; out.leaf_nodes += bo.leaf_nodes;
+        out.max_leaf_prims = std::max(out.max_leaf_prims, bo.max_leaf_prims); out.max_depth = std::max(out.max_depth, bo.max_depth);
+    }
+    out.root_ref = trees[0].root_ref;
+    for (int k = 0; k < 3; k++) { out.root_lo[k] = trees[0].lo[k]; out.root_hi[k] = trees[0].hi[k]; }
+    out.total_nodes = out.interior_nodes + out.leaf_nodes;
+    out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
 }  // namespace phost

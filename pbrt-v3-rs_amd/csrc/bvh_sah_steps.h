@@ -83,10 +83,18 @@ struct alignas(16) SNode {   // a build node: 96 B
     uint32_t pad[2];
 };
 
-// counters[]: 0 nodes made, 1 bucket slots handed out this level, 2 leaves, 3 largest leaf, 4..15 the root's bound and centroid bound (ordered uints)
+// A FOREST is built in one go: tree t owns the positions [tree_start[t], tree_start[t + 1]) and starts as build node t.  Scenes with object instances use it — tree 0 is the scene's
+// aggregate over its own triangles and its TransformedPrimitives, trees 1.. are the aggregates of the instanced objects (one accelerator per object, api/src/lib.rs:953-971) — and every
+// tree's nodes are numbered after the previous tree's, so the arrays come out as the host builder lays them out: [scene | object | object ..].  A single tree is a forest of one.
+// counters[]: 0 nodes made, 1 bucket slots handed out this level, 2 leaves, 3 largest leaf (4..15 spare)
 struct Ctx {
     uint32_t n, max_prims;
     const float* P; const uint32_t* idx; const uint32_t* tri_flags; const uint32_t* tri_mesh;
+    const uint32_t* items;           // per position before the build: triangle id, or PH_ITEM_INST | k (bounds in inst_bounds[6k..]); null = the triangles 0 .. n-1
+    const float* inst_bounds;
+    const uint32_t* tree_start;      // n_trees + 1 entries
+    uint32_t n_trees;
+    uint32_t* root_words;            // 12 per tree: bound and centroid bound of the tree's primitives as ordered uints
     Elem* e_lo; Elem* e_hi;          // the primitives in their current order: box corners, id in e_lo[i].w  (BVHPrimitiveInfo, bvh/common.rs:62-91)
     uint32_t* seg;                   // per POSITION: the build node whose range holds it, PHS_NONE once that node is a leaf
     uint8_t* bkt;                    // per position: the bucket of the primitive there (this level)
@@ -121,17 +129,29 @@ PHS_HD uint32_t bucket_of(float clo, float chi, float c) {   // sah.rs:309-313 (
 PHS_HD float axis_of(const Elem& e, int k) { return k == 0 ? e.x : (k == 1 ? e.y : e.z); }
 PHS_HD float centroid(const Elem& lo, const Elem& hi, int k) { return 0.5f * (axis_of(lo, k) + axis_of(hi, k)); }   // bvh/common.rs:74-80
 
-// ---- pass 0: Triangle::world_bound (triangle.rs:427-431) per primitive, and the root's two bounds into dst[12] ------------------------------------
-PHS_HD void init_elem(const Ctx& c, uint32_t i, uint32_t* dst) {
-    const float* a = c.P + 3 * (size_t)c.idx[3 * (size_t)i];
-    const float* b = c.P + 3 * (size_t)c.idx[3 * (size_t)i + 1];
-    const float* d = c.P + 3 * (size_t)c.idx[3 * (size_t)i + 2];
+#define PHS_ITEM_INST 0x80000000u      // = PH_ITEM_INST (bvh_build.h)
+PHS_HD uint32_t tree_of(const Ctx& c, uint32_t i) {   // the tree whose range holds position i
+    uint32_t lo = 0u, hi = c.n_trees;
+    while (hi - lo > 1u) { const uint32_t m = (lo + hi) >> 1; if (c.tree_start[m] <= i) lo = m; else hi = m; }
+    return lo;
+}
+// ---- pass 0: Triangle::world_bound (triangle.rs:427-431) — or the TransformedPrimitive's, handed in — per primitive, and its tree's two bounds into dst[12] --------------
+PHS_HD void init_elem(const Ctx& c, uint32_t i, uint32_t tree, uint32_t* dst) {
+    const uint32_t id = c.items ? c.items[i] : i;
     float lo[3], hi[3];
-    for (int k = 0; k < 3; k++) { lo[k] = fmn(fmn(a[k], b[k]), d[k]); hi[k] = fmx(fmx(a[k], b[k]), d[k]); }
+    if (id & PHS_ITEM_INST) {
+        const float* bb = c.inst_bounds + 6 * (size_t)(id & ~PHS_ITEM_INST);
+        for (int k = 0; k < 3; k++) { lo[k] = bb[k]; hi[k] = bb[3 + k]; }
+    } else {
+        const float* a = c.P + 3 * (size_t)c.idx[3 * (size_t)id];
+        const float* b = c.P + 3 * (size_t)c.idx[3 * (size_t)id + 1];
+        const float* d = c.P + 3 * (size_t)c.idx[3 * (size_t)id + 2];
+        for (int k = 0; k < 3; k++) { lo[k] = fmn(fmn(a[k], b[k]), d[k]); hi[k] = fmx(fmx(a[k], b[k]), d[k]); }
+    }
     Elem l, h;
-    l.x = lo[0]; l.y = lo[1]; l.z = lo[2]; l.w = i;
+    l.x = lo[0]; l.y = lo[1]; l.z = lo[2]; l.w = id;
     h.x = hi[0]; h.y = hi[1]; h.z = hi[2]; h.w = 0u;
-    c.e_lo[i] = l; c.e_hi[i] = h; c.seg[i] = 0u;
+    c.e_lo[i] = l; c.e_hi[i] = h; c.seg[i] = tree;
     for (int k = 0; k < 3; k++) {
         const float ctr = 0.5f * (lo[k] + hi[k]);
         a_min(dst + k, f2ord(lo[k])); a_max(dst + 3 + k, f2ord(hi[k]));
@@ -141,14 +161,16 @@ PHS_HD void init_elem(const Ctx& c, uint32_t i, uint32_t* dst) {
 PHS_HD void init_bounds_words(uint32_t* dst) {   // an empty Bounds3f (bounds3.rs:23-30) as ordered uints, twice
     for (int k = 0; k < 3; k++) { dst[k] = f2ord(PHS_FLT_MAX); dst[3 + k] = f2ord(-PHS_FLT_MAX); dst[6 + k] = f2ord(PHS_FLT_MAX); dst[9 + k] = f2ord(-PHS_FLT_MAX); }
 }
-PHS_HD void make_root(const Ctx& c) {
+PHS_HD void make_root(const Ctx& c, uint32_t t) {   // build node t = the root of tree t; its numbers (A, index) are set once the trees' sizes are known (root_numbers)
     SNode r;
-    const uint32_t* g = c.counters + 4;
+    const uint32_t* g = c.root_words + 12u * t;
     for (int k = 0; k < 3; k++) { r.lo[k] = ord2f(g[k]); r.hi[k] = ord2f(g[3 + k]); r.clo[k] = ord2f(g[6 + k]); r.chi[k] = ord2f(g[9 + k]); }
-    r.start = 0u; r.end = c.n; r.kid0 = PHS_NONE; r.axis = 0u; r.slot = PHS_NONE; r.best = 0u; r.mid = 0u; r.size = 0u; r.A = 1u; r.index = 0u; r.pad[0] = r.pad[1] = 0u;
-    c.nodes[0] = r;
-    c.counters[0] = 1u;
+    r.start = c.tree_start[t]; r.end = c.tree_start[t + 1u]; r.kid0 = PHS_NONE; r.axis = 0u; r.slot = PHS_NONE; r.best = 0u; r.mid = 0u; r.size = 0u; r.A = 1u; r.index = 0u; r.pad[0] = r.pad[1] = 0u;
+    c.nodes[t] = r;
+    if (t == 0u) c.counters[0] = c.n_trees;
 }
+// tree t's interior nodes take the slots [base, base + size): base = the interior nodes of the trees before it
+PHS_HD void root_numbers(const Ctx& c, uint32_t t, uint32_t base) { c.nodes[t].index = base; c.nodes[t].A = base + 1u; }
 
 PHS_HD void count_leaf(const Ctx& c, uint32_t n_prims) { a_add(c.counters + 2, 1u); a_max(c.counters + 3, n_prims); }
 
@@ -330,6 +352,13 @@ PHS_HD void number_node(const Ctx& c, uint32_t v) {
 }
 PHS_HD void emit_tri(const Ctx& c, uint32_t i) {
     const uint32_t id = c.e_lo[i].w;
+    if (id & PHS_ITEM_INST) {   // a TransformedPrimitive: the 48-byte record names the instance (bvh_build.cpp does the same)
+        TriRec r;
+        memset(&r, 0, sizeof r);
+        r.prim = id & ~PHS_ITEM_INST; r.flags = PH_TRI_INSTANCE | (c.leaf_last[i] ? PH_TRI_LAST : 0u);
+        c.out_tris[i] = r;
+        return;
+    }
     const float* p0 = c.P + 3 * (size_t)c.idx[3 * (size_t)id]; const float* p1 = c.P + 3 * (size_t)c.idx[3 * (size_t)id + 1]; const float* p2 = c.P + 3 * (size_t)c.idx[3 * (size_t)id + 2];
     TriRec r;
     r.p0[0] = p0[0]; r.p0[1] = p0[1]; r.p0[2] = p0[2]; r.prim = id;

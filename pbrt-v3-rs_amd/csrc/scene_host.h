@@ -41,6 +41,9 @@ struct SceneHostState {
     bool general_materials = false;  // some material is not matte: the renderer uses the general BSDF kernel
     bool simple_textures = false;    // every texture program is made of constants, image maps (uv mapping), scale and mix: the texture pass runs its lean instantiation (set at upload)
     std::vector<LightRec> lights;
+    // DiffuseAreaLights of shapes inside an object definition ("Area lights not supported with object instancing", api/src/lib.rs:877-881): the primitives keep their emission,
+    // Scene::lights never sees them.  MeshRec::first_light = -2 - index on the host; uploaded behind the scene's lights (DeviceScene::n_lights does not count them).
+    std::vector<LightRec> emission_only;
     std::vector<uint32_t> infinite_lights;
     std::vector<float> light_dist;   // Distribution2D tables of infinite lights with a radiance map
     // object instancing (api/src/lib.rs:911-1000): an object is a contiguous triangle range; top_items is the scene's primitive
@@ -108,7 +111,9 @@ int ensure_traversal_workspace(PbrtHipScene* s);
 void free_wavefront(PbrtHipScene* s);
 int build_hlbvh_device(const BuildInput& in, int max_prims_in_node, hipStream_t stream, BuildOutput& out, std::string& err);   // bvh_device.hip
 // bvh_sah_device.hip.  keep_nodes / keep_tris non-null: the Node64 / TriRec arrays are not copied to `out` but handed over as device allocations (the caller frees them)
-int build_sah_device(const BuildInput& in, int max_prims_in_node, hipStream_t stream, BuildOutput& out, std::string& err, void** keep_nodes = nullptr, void** keep_tris = nullptr);
+// forest non-null: the scene's aggregate and its instanced objects' aggregates in one build, laid out as build_forest_host lays them out; trees_out: every tree's root
+int build_sah_device(const BuildInput& in, int max_prims_in_node, hipStream_t stream, BuildOutput& out, std::string& err, void** keep_nodes = nullptr, void** keep_tris = nullptr,
+                     const ForestSpec* forest = nullptr, std::vector<ForestTreeOut>* trees_out = nullptr);
 void free_tree_dev(PbrtHipScene* s);
 int ensure_host_tree(PbrtHipScene* s);   // api.hip: the host copy of a tree that lives on the device only (the multi-device driver replicates from the host copy)
 int uber_rebuild_for_opacity(PbrtHipScene* s, uint32_t material);    // api.hip: lobe lists remade when a structural parameter becomes a texture

@@ -736,10 +736,7 @@ void Api::pbrt_shape(const std::string& name, const ParamSet& p, const std::stri
     const uint32_t flags = (gs_.reverse_orientation ? 1u : 0u) | (pbrt_hip_host_swaps_handedness(ctm_.m) ? 2u : 0u);
 
     int32_t first_light = -1;
-    if (!gs_.area_light.empty() && !current_object_.empty()) {
-        error = "AreaLightSource inside ObjectBegin/ObjectEnd: the reference keeps the emission but drops the light (lib.rs:877-881); not offered";
-        return;
-    }
+    const bool in_object = !current_object_.empty();
     if (!gs_.area_light.empty()) {  // one DiffuseAreaLight per triangle, numbered where the Shape directive stands (lib.rs:783-812)
         if (gs_.area_light != "diffuse" && gs_.area_light != "area") { error = "AreaLightSource \"" + gs_.area_light + "\" unknown"; return; }
         const ParamSet& ap = gs_.area_light_params;
@@ -748,7 +745,8 @@ void Api::pbrt_shape(const std::string& name, const ParamSet& p, const std::stri
         uint32_t id = 0;
         if (!check(ABI(pbrt_hip_add_light_diffuse_area(scene_, L.data(), ap.find_one_bool("twosided", false) ? 1 : 0, n_tris, &id)), "add_light_diffuse_area")) return;
         first_light = (int32_t)id;
-        n_lights_ += n_tris;
+        if (in_object) warn("Area lights not supported with object instancing.");   // lib.rs:877-881: the shape keeps its emission, the scene's lights do not get the light (pbrt_hip_add_mesh does the same)
+        else n_lights_ += n_tris;
     }
     if (!check(ABI(pbrt_hip_add_mesh(scene_, Pw.data(), (uint32_t)nv, idx.data(), n_tris, N.empty() ? nullptr : N.data(), S.empty() ? nullptr : S.data(),
                                  UV.empty() ? nullptr : UV.data(), mat, first_light, flags, alpha, shadow_alpha)), "add_mesh")) return;

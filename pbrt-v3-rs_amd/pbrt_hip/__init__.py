@@ -144,6 +144,7 @@ class Binding:
             "set_traversal_counting": (C.c_int, [vp, C.c_int]),
             "get_traversal_counts": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
             "accel_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+            "accel_copy": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64]),
             "build_accel_device": (C.c_int, [vp, C.c_int, C.c_int]),
             "scene_create_multi": (vp, [ip, C.c_int]),
             "scene_devices": (C.c_int, [vp, ip, C.c_int]),
@@ -672,6 +673,13 @@ class Scene:
         return {"interior_nodes": int(c[0]), "leaf_records": int(c[1]), "node_bytes": int(c[2]), "leaf_record_bytes": int(c[3]), "leaves": int(c[4]),
                 "depth": int(c[5]), "max_leaf_prims": int(c[6]), "build_seconds": int(c[7]) * 1e-6}
 
+    def accel_copy(self):
+        """(nodes (n, 16) uint32, leaf records (m, 12) uint32): the built structure in the device layout, copied from wherever it lives (test aid)."""
+        st = self.accel_stats()
+        nodes = np.zeros((max(st["interior_nodes"], 1), 16), np.uint32); recs = np.zeros((max(st["leaf_records"], 1), 12), np.uint32)
+        self._chk(self.b.fn("accel_copy")(self.h, nodes.ctypes.data, st["interior_nodes"], recs.ctypes.data, st["leaf_records"]))
+        return nodes[:st["interior_nodes"]], recs[:st["leaf_records"]]
+
     def _film_hw(self):
         if self.film_shape is None:
             raise PbrtHipError(ERR_STATE, "set_film must be called before rendering")
@@ -876,6 +884,6 @@ def capture_spec(spec: SceneSpec, scene: Scene, host: Host, geometry=None, insta
     cb, table, sb = host.film_box(spec.xres, spec.yres, crop_window=spec.crop_window)
     scene.set_film(spec.xres, spec.yres, cb, (0.5, 0.5), table)
     scene.set_sampler(0, spec.spp, sb)
-    if device_build and not instances: scene.build_accel_device(0, 4)   # the same tree, made on the GPU and left there (csrc/bvh_sah_device.hip)
+    if device_build: scene.build_accel_device(0, 4)   # the same tree(s), made on the GPU and left there (csrc/bvh_sah_device.hip)
     else: scene.build_accel(0, 4)
     return P, idx

@@ -171,6 +171,39 @@ def test_config4_standin_instanced_many_materials(host):
     s.close()
 
 
+def test_config4_at_its_stated_size(host):
+    """configs[4] at the size BASELINE.json states — the San-Miguel-shaped scene of pbrt_hip/sanmiguel.py: 128 objects, 1 100 instances, 10.2 M instanced + 0.4 M top-level
+    triangles, 26 materials (image maps, bump maps, alpha-masked foliage, every BSDF class), eleven lights, 1920 x 1080 @ 512 spp, depth 5.  A crop of that scene at the full
+    sample count against the oracle bit for bit (trees built on the DEVICE: the scene's aggregate and the 128 objects' as one forest), then the whole frame on the device
+    through its accounting and the 8-way tile partition of the multi-GPU path."""
+    from pbrt_hip.sanmiguel import SanMiguelScene
+    sm = SanMiguelScene(host, scale=1.0)
+    cnt = sm.counts()
+    assert cnt["objects"] >= 100 and cnt["instances"] >= 1000 and cnt["total_triangles_as_instanced"] >= 10_000_000 and sm.images
+    crop = (0.46, 0.485, 0.55, 0.59)     # 48 x 43 pixels across foliage, furniture and floor
+    prod = pbrt_hip.Scene(); sm.capture(prod, 1920, 1080, 512, crop=crop, device_build=True)
+    assert sm.n_materials >= 20
+    g = prod.render_path(max_depth=5)
+    prod.close()
+    orc = OracleScene(); sm.capture(orc, 1920, 1080, 512, crop=crop)
+    o = _oracle_f64(orc, max_depth=5)
+    orc.close()
+    assert g[2].light_distributions_created == o[2].light_distributions_created > 0
+    _assert_bit_exact(g, o, "configs[4] crop")
+    # the whole frame, 1.06 G camera samples
+    s = pbrt_hip.Scene(); sm.capture(s, 1920, 1080, 512, device_build=True)
+    fx, fw, st = s.render_path(max_depth=5)
+    assert st.camera_rays == 1920 * 1080 * 512 and (fw >= 512).all() and (fw <= 514).all() and np.isfinite(fx).all() and float(fx.min()) >= 0.0
+    assert st.regular_rays > 2 * st.camera_rays and st.shadow_rays > 0
+    accx = np.zeros_like(fx); accw = np.zeros_like(fw); rays = 0
+    for p in range(8):
+        x, w, sp = s.render_path(max_depth=5, tile_part=p, tile_parts=8)
+        accx += x; accw += w; rays += sp.regular_rays + sp.shadow_rays
+    assert rays == st.regular_rays + st.shadow_rays
+    assert np.array_equal(accx.view(np.uint32), fx.view(np.uint32)) and np.array_equal(accw, fw)
+    s.close()
+
+
 def test_config1_full_size_meets_the_stated_tolerance_in_glibc_mode(host):
     """configs[1] at full size against the oracle with glibc's f32 transcendentals (libm mode 0 = what a Rust build of the reference links).
     Stated tolerance: RMSE <= 1e-3 x mean luminance and <= 0.1 % of the pixels off by more than 1e-2 x mean."""

@@ -144,3 +144,38 @@ def test_scene_built_on_the_device_traces_like_the_host_built_one(host):
         b.build_accel_device(3, 4)          # EqualCounts stays a host build
     assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
     a.close(); b.close(); orc.close()
+
+
+def _forest_pair(capture):
+    """The same instanced scene built by the host builder and on the device: node array, leaf records, statistics."""
+    out = []
+    for dev in (False, True):
+        s = pbrt_hip.Scene(); capture(s, dev)
+        out.append((s.accel_copy(), s.accel_stats(), s))
+    return out
+
+
+@pytest.mark.parametrize("n_tris,instances,seed", [(1, 3, 2), (40, 7, 3), (3000, 27, 4), (20000, 200, 5)])
+def test_device_forest_equals_host_forest_one_object(host, n_tris, instances, seed):
+    """One object instanced K times (two-level BVH): the scene's aggregate over the TransformedPrimitives and the object's aggregate, built as one forest on the device, are
+    the host builder's arrays entry by entry — and the films are the same bits."""
+    spec = pbrt_hip.SceneSpec(n_tris=n_tris, seed=seed, xres=48, yres=48, spp=4)
+    (h, hs, sh), (d, ds, sd) = _forest_pair(lambda s, dev: pbrt_hip.capture_spec(spec, s, host, instances=instances, device_build=dev))
+    assert np.array_equal(h[0], d[0]) and np.array_equal(h[1], d[1])
+    assert {k: v for k, v in hs.items() if k != "build_seconds"} == {k: v for k, v in ds.items() if k != "build_seconds"}
+    fh, fd = sh.render_path(), sd.render_path()
+    assert np.array_equal(fh[0].view(np.uint32), fd[0].view(np.uint32)) and (fh[2].regular_rays, fh[2].shadow_rays) == (fd[2].regular_rays, fd[2].shadow_rays)
+    sh.close(); sd.close()
+
+
+def test_device_forest_equals_host_forest_many_objects(host):
+    """The configs[4] scene at a twentieth of its tessellation: 128 object definitions (among them meshes with alpha textures, several meshes per object), 1 100 instances and
+    the courtyard's own triangles — 129 trees in one device build, against the host builder's arrays and film."""
+    from pbrt_hip.sanmiguel import SanMiguelScene
+    sm = SanMiguelScene(host, scale=0.05)
+    (h, hs, sh), (d, ds, sd) = _forest_pair(lambda s, dev: sm.capture(s, 160, 90, 4, device_build=dev))
+    assert np.array_equal(h[0], d[0]) and np.array_equal(h[1], d[1])
+    assert {k: v for k, v in hs.items() if k != "build_seconds"} == {k: v for k, v in ds.items() if k != "build_seconds"}
+    fh, fd = sh.render_path(), sd.render_path()
+    assert np.array_equal(fh[0].view(np.uint32), fd[0].view(np.uint32)) and (fh[2].regular_rays, fh[2].shadow_rays) == (fd[2].regular_rays, fd[2].shadow_rays)
+    sh.close(); sd.close()

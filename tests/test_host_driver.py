@@ -53,8 +53,6 @@ def test_check_mode_crop_and_outfile(tmp_path):
     ('WorldBegin\nMaterial "kdsubsurface"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', 'Material "kdsubsurface"'),
     ('WorldBegin\nTexture "b" "float" "ptex"\nMaterial "plastic" "texture bumpmap" "b"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "bumpmap"),
     ('WorldBegin\nMakeNamedMedium "fog" "string type" "homogeneous"\nWorldEnd\n', "directive 'MakeNamedMedium'"),
-    ('WorldBegin\nObjectBegin "a"\nAreaLightSource "diffuse"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nObjectEnd\nWorldEnd\n',
-     "AreaLightSource inside ObjectBegin"),
     ('WorldBegin\nLightSource "laser"\nWorldEnd\n', 'LightSource "laser"'),
     ('Camera "realistic"\nWorldBegin\nWorldEnd\n', 'Camera "realistic"'),
     ('Integrator "bdpt"\nWorldBegin\nWorldEnd\n', 'Integrator "bdpt"'),
@@ -86,6 +84,18 @@ def test_wrong_block_directives_are_ignored_with_a_warning(tmp_path):
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["triangles"] == 0 and info["xres"] == 8 and info["lights"] == 1
     assert "must be inside world block" in r.stderr and "cannot be set inside world block" in r.stderr and "Unmatched AttributeEnd" in r.stderr
+
+
+def test_area_light_inside_an_object_definition_is_a_warning(tmp_path):
+    """api/src/lib.rs:877-881: the shape joins the instance with its emission, the light is dropped with the reference's warning — the scene still renders."""
+    p = tmp_path / "s.pbrt"
+    p.write_text('WorldBegin\nLightSource "distant"\nObjectBegin "a"\nAreaLightSource "diffuse"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+                 'ObjectEnd\nObjectInstance "a"\nWorldEnd\n')
+    r = run(["--check", str(p)])
+    assert r.returncode == 0, r.stderr
+    assert "Area lights not supported with object instancing" in r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["lights"] == 1 and info["warnings"] >= 1      # the distant light only
 
 
 def test_object_instancing_directives(tmp_path):

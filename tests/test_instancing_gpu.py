@@ -95,10 +95,13 @@ def test_instancing_errors(host):
         ob = s.object_begin()
         with pytest.raises(pbrt_hip.PbrtHipError):
             s.object_begin()                                   # nested definition
+        first = s.add_light_diffuse_area((1, 1, 1), 1)
         lid = s.add_light_diffuse_area((1, 1, 1), 1)
         with pytest.raises(pbrt_hip.PbrtHipError) as e:
-            s.add_mesh(np.eye(3, dtype=np.float32), [0, 1, 2], m, first_area_light=lid)   # area light inside an object
-        assert e.value.code == pbrt_hip.ERR_UNSUPPORTED
+            s.add_mesh(np.eye(3, dtype=np.float32), [0, 1, 2], m, first_area_light=first)   # area light inside an object that is not the light created last
+        assert e.value.code == pbrt_hip.ERR_INVALID_ARG
+        s.add_mesh(np.eye(3, dtype=np.float32), [0, 1, 2], m, first_area_light=lid)         # the reference's warn-and-drop (api/src/lib.rs:877-881): succeeds with a warning
+        assert "Area lights not supported with object instancing" in s.b.fn("last_error")(s.h).decode()
         with pytest.raises(pbrt_hip.PbrtHipError):
             s.add_instance(ob, *I4)                            # ObjectInstance inside a definition
         s.object_end()
@@ -106,3 +109,23 @@ def test_instancing_errors(host):
             s.object_end()
         with pytest.raises(pbrt_hip.PbrtHipError):
             s.add_instance(99, *I4)
+
+
+def test_area_light_inside_an_object_keeps_its_emission_and_leaves_the_light_list(host):
+    """api/src/lib.rs:877-881: a shape with an AreaLightSource inside ObjectBegin / ObjectEnd is added to the instance WITH its area light (so SurfaceInteraction::le still
+    returns its emission) while the light itself is dropped with a warning.  Device film = oracle film bit for bit, through a rotated instance and seen in a mirror."""
+    from emissive_object_scene import emissive_object_scene
+    for strategy in (0, 2):
+        prod = pbrt_hip.Scene(); orc = OracleScene()
+        emissive_object_scene(prod, host); emissive_object_scene(orc, host)
+        set_libm_mode(1)
+        try:
+            oxyz, owt, ost, _ = orc.render_path_ex(max_depth=4, light_strategy=strategy)
+        finally:
+            set_libm_mode(0)
+        gxyz, gwt, gst = prod.render_path(max_depth=4, light_strategy=strategy)
+        assert (gst.regular_rays, gst.shadow_rays) == (ost.regular_rays, ost.shadow_rays)
+        assert np.array_equal(gwt.view(np.uint32), owt.view(np.uint32))
+        nb = int((gxyz.view(np.uint32) != oxyz.view(np.uint32)).any(axis=2).sum())
+        assert nb == 0, f"{nb} pixels differ (strategy {strategy})"
+        assert float(oxyz.max()) > 5.0     # the emitter is in the picture

@@ -52,3 +52,25 @@ def test_instanced_scene_matches_flattened_scene(host):
     # TransformedPrimitive::world_bound = transform_bounds of the object's box: never tighter than the flattened triangles' box
     wa, wb = a.world_bound(), b.world_bound()
     assert (wa[:3] <= wb[:3] + 1e-5).all() and (wa[3:] >= wb[3:] - 1e-5).all()
+
+
+def test_area_light_inside_an_object_is_emission_without_a_light(host):
+    """api/src/lib.rs:877-881 ("Area lights not supported with object instancing"): the shapes of an object definition keep their area light — a camera ray or a specular chain that
+    reaches one sees its emission, SurfaceInteraction::le — but the light never joins Scene::lights, so nothing samples it and no diffuse surface is lit by it.
+    Pin: against the same scene without the AreaLightSource, pixels differ only where the emitter is seen directly or in the mirror, there by its radiance L; the matte floor
+    next to it receives nothing from it."""
+    from emissive_object_scene import emissive_object_scene, L_EMIT
+    a = OracleScene(); emissive_object_scene(a, host, emissive=True)
+    b = OracleScene(); emissive_object_scene(b, host, emissive=False)
+    xa, wa, sa, _ = a.render_path_ex(max_depth=4, threads=4); xb, wb, sb, _ = b.render_path_ex(max_depth=4, threads=4)
+    assert (sa.regular_rays, sa.shadow_rays) == (sb.regular_rays, sb.shadow_rays)      # same paths: no light was added, no sampling decision changed
+    ra, rb = a.film_to_rgb(xa, wa), b.film_to_rgb(xb, wb)
+    d = ra - rb
+    lit = np.abs(d).max(axis=2) > 1e-6
+    assert 20 < lit.sum() < 0.4 * lit.size                                             # the two quads and their mirror images, nothing else
+    full = np.abs(d - np.float32(L_EMIT)).max(axis=2) < 1e-3                          # pixels whose every sample looks at the emitter: exactly its radiance on top of the black surface
+    assert full.sum() >= 10 and (full <= lit).all()
+    assert (d[lit] >= -1e-6).all() and (d[lit] <= np.float32(L_EMIT) * 1.001 + 1e-5).all()   # partial coverage and the 0.9 mirror: a fraction of L, never more
+    # the floor right under the emitters is lit by the distant light alone in both renders: no radiance arrives from the dropped light
+    floor_rows = slice(int(0.8 * ra.shape[0]), ra.shape[0])
+    assert np.array_equal(ra[floor_rows], rb[floor_rows]) and float(ra[floor_rows].mean()) > 0.01
