@@ -114,6 +114,12 @@ int upload_scene(PbrtHipScene* s) {
             if (m.sigma_tex1 || hdr) cols = std::max(cols, 2u);   // the per-hit scalars travel in the fourth component of the first two colour slots
             m.tex_cols = std::min<uint32_t>(cols, PH_HIT_COLS); m.tex_hdr = hdr ? 1u : 0u;
         }
+        s->alpha_lean = s->alpha_textures;
+        for (const MeshRec& m : s->meshes)
+            for (uint32_t t1 : {m.alpha_tex1, m.shadow_alpha_tex1})
+                if (t1)
+                    for (const TexOp& op : s->textures[t1 - 1u].prog)
+                        if (!(op.op == PH_TOP_CONST || op.op == PH_TOP_MUL || op.op == PH_TOP_MIX || (op.op == PH_TOP_IMAGE && op.mapping == 0u))) s->alpha_lean = false;
         s->simple_textures = true;
         for (const PbrtHipScene::TextureHost& t : s->textures)
             for (const TexOp& op : t.prog)
@@ -250,7 +256,7 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
         PH_CHECK(s, hipGetDeviceProperties(&prop, s->device));
         int per_cu = 0;
         switch (trav_variant()) {
-#define X(id, lm, rm, ld, ns, wpe, pk) case id: PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false, lm, rm, ld, ns, false, true, false, wpe>, PH_TRAV_BLOCK, 0)); if (wpe) per_cu = std::min(per_cu, wpe); break;
+#define X(id, lm, rm, ld, ns, wpe, pk) case id: PH_CHECK(s, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ph::traverse_kernel<false, false, lm, rm, ld, ns, false, true, 0, wpe>, PH_TRAV_BLOCK, 0)); if (wpe) per_cu = std::min(per_cu, wpe); break;
             PH_VARIANTS(X)
 #undef X
         }
@@ -278,19 +284,25 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
     const dim3 g(blocks), b(PH_TRAV_BLOCK);
 #define PH_LAUNCH3(cnt, lm, rm, ld, ns, inst, wpe, pk)                                                                                                  \
     do {                                                                                                                                           \
-        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, true, false, wpe>), g, b, 0, s->stream, s->ds, p);   \
-        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, false, wpe>), g, b, 0, s->stream, s->ds, p); \
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, false, wpe>), g, b, 0, s->stream, s->ds, p);             \
+        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, true, 0, wpe>), g, b, 0, s->stream, s->ds, p);   \
+        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, 0, wpe>), g, b, 0, s->stream, s->ds, p); \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, 0, wpe>), g, b, 0, s->stream, s->ds, p);             \
     } while (0)
-#define PH_LAUNCH3A(cnt, ns, inst)                                                                                                     \
+#define PH_LAUNCH3A(cnt, lm, rm, ns, inst, alpha)                                                                                      \
     do {                                                                                                                              \
-        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, ns, inst, true, true>), g, b, 0, s->stream, s->ds, p);       \
-        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, ns, inst, false, true>), g, b, 0, s->stream, s->ds, p);  \
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, ns, inst, false, true>), g, b, 0, s->stream, s->ds, p);                \
+        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, PH_LDS_DEPTH, ns, inst, true, alpha>), g, b, 0, s->stream, s->ds, p);       \
+        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, PH_LDS_DEPTH, ns, inst, false, alpha>), g, b, 0, s->stream, s->ds, p);  \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, PH_LDS_DEPTH, ns, inst, false, alpha>), g, b, 0, s->stream, s->ds, p);                \
     } while (0)
-    if (s->alpha_textures) {  // meshes with alpha-mask textures: the ALPHA variants
-        if (s->count_traversal) { if (!s->inst_recs.empty()) PH_LAUNCH3A(true, 1, true); else PH_LAUNCH3A(true, 1, false); }
-        else if (!s->inst_recs.empty()) PH_LAUNCH3A(false, 3, true); else PH_LAUNCH3A(false, 3, false);
+    if (s->alpha_textures) {  // meshes with alpha-mask textures: the ALPHA variants — 1 = the inlined test for image-map masks, 2 = the general evaluator out of line (traverse.h)
+        const bool inst = !s->inst_recs.empty();
+        if (s->alpha_lean) {
+            if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, 1, true, 1); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, 1, false, 1); }
+            else if (inst) PH_LAUNCH3A(false, 24, 12, 5, true, 1); else PH_LAUNCH3A(false, 24, 12, 5, false, 1);
+        } else {
+            if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, 1, true, 2); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, 1, false, 2); }
+            else if (inst) PH_LAUNCH3A(false, PH_LEAF_MIN, PH_REFILL_MIN, 3, true, 2); else PH_LAUNCH3A(false, PH_LEAF_MIN, PH_REFILL_MIN, 3, false, 2);
+        }
         return;
     }
     if (!s->inst_recs.empty()) {  // scenes with object instances: the TransformedPrimitive-aware kernels

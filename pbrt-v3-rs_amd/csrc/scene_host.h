@@ -35,6 +35,7 @@ struct SceneHostState {
                             bool raw_remap = false, rebuilt = false; int mix_n1 = 0; };  // [Kd, Ks, Kr, Kt]; field 0 = r, 1 = t; pre: uber's opacity; lobe2 / field2 / rough_lobe2: a second lobe fed by the same parameter (translucent's reflection + transmission pair); rough_lobe: owner of the Trowbridge-Reitz distribution
     std::vector<MaterialParams> material_params;
     bool alpha_textures = false;      // some mesh has an alpha / shadowalpha texture: traversal uses the ALPHA kernel variants
+    bool alpha_lean = false;          // ... and all of them are constants / uv-mapped image maps / scale / mix: the inlined test (set at upload)
     bool bump_materials = false;      // some material has a bump map
     bool textured_materials = false;  // some material evaluates a texture per hit
     bool has_none_material = false;  // some material is "none": paths may need more wavefront iterations than max_depth + 1

@@ -687,6 +687,38 @@ PH_DEV void hit_bump(const DeviceScene* dsc, const BumpIn* in, BumpOut* out) {
     out->dpdu_s = ndpdu;
 }
 
+// The lean form of the alpha test (traverse.h, ALPHA = 1): texture programs of constants, uv-mapped image maps, scale and mix, evaluated in the red channel only — every one
+// of those operations works channel by channel (mix's amount is its operand's red channel, mix.rs:36-41), and the test reads the red channel (a float texture's three are
+// equal).  The value stack lives in six registers that shift, so nothing is indexed dynamically.
+PH_DEV float alpha_prog_r(const DeviceScene& sc, uint32_t id, f2 uv) {
+    const TexRec tr = sc.textures[id];
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f, s5 = 0.0f;   // s0 = top of the stack
+    for (uint32_t k = 0; k < tr.n_ops; k++) {
+        const TexOp& op = sc.tex_ops[tr.first_op + k];
+        const uint32_t o = op.op;
+        if (o == PH_TOP_CONST || o == PH_TOP_IMAGE) {
+            float v = op.c[0];
+            if (o == PH_TOP_IMAGE) v = mip_triangle(sc, sc.mipmaps[op.mip], 0u, mk2(op.su * uv.x + op.du, op.sv * uv.y + op.dv)).r;   // UVMapping2D::map (uv_2d.rs:52-60); no differentials: MIPMap::lookup ends in triangle(0, st)
+            s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
+        } else if (o == PH_TOP_MUL) { s0 = s1 * s0; s1 = s2; s2 = s3; s3 = s4; s4 = s5; }                                  // scale.rs:33: tex1 * tex2
+        else { s0 = (1.0f - s0) * s2 + s0 * s1; s1 = s3; s2 = s4; s3 = s5; }                                                 // mix.rs:36-41: stack = t1, t2, amount
+    }
+    return s0;
+}
+static __device__ __forceinline__ bool alpha_accept_lean(const DeviceScene& sc, uint32_t prim, uint32_t mesh, float b0, float b1, float b2, bool any_hit) {
+    const MeshRec& m = sc.meshes[mesh];
+    const uint32_t mflags = m.flags, at = m.alpha_tex1, st = m.shadow_alpha_tex1;
+    f2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);
+    if (mflags & PH_MESH_UV) {
+        const uint32_t i0 = sc.idx[3 * prim], i1 = sc.idx[3 * prim + 1], i2 = sc.idx[3 * prim + 2];
+        uv0 = mk2(sc.UV[2 * (size_t)i0], sc.UV[2 * (size_t)i0 + 1]); uv1 = mk2(sc.UV[2 * (size_t)i1], sc.UV[2 * (size_t)i1 + 1]); uv2 = mk2(sc.UV[2 * (size_t)i2], sc.UV[2 * (size_t)i2 + 1]);
+    }
+    const f2 uv = mk2((b0 * uv0.x + b1 * uv1.x) + b2 * uv2.x, (b0 * uv0.y + b1 * uv1.y) + b2 * uv2.y);
+    if (at && alpha_prog_r(sc, at - 1u, uv) == 0.0f) return false;
+    if (any_hit && st && alpha_prog_r(sc, st - 1u, uv) == 0.0f) return false;
+    return true;
+}
+
 // The alpha-mask test of Triangle::intersect / intersect_p (triangle.rs:587-607, 868-898), declared in traverse.h: isect_local carries the hit point
 // (in the triangle's own space), the interpolated uv and no differentials.
 static __device__ __noinline__ bool alpha_accept(const DeviceScene* dsc, uint32_t tri_index, float b0, float b1, float b2, uint32_t any_hit) {

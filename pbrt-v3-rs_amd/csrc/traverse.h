@@ -215,14 +215,19 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
 // MIXED = true serves both ray kinds of one wavefront round from ONE launch: indices [0, n_cl) are closest-hit rays, [n_cl, n_cl + n_sh)
 // any-hit rays (each lane knows its kind).  Every launch ends with a latency-bound tail (the last rays' dependent loads, ~0.4 ms
 // whatever the launch size), so one launch per round instead of two removes one tail per bounce.
-// ALPHA = true adds alpha-mask textures (triangle.rs:587-607 / 868-898): a candidate hit on a mesh whose alpha or shadowalpha is a texture is
-// accepted only if the texture, evaluated at the hit's uv / p with no differentials, is not 0.  The evaluation is an out-of-line call (alpha_accept,
-// defined next to the texture evaluator); its own instantiations, so every other scene keeps the leaner kernels.
+// ALPHA != 0 adds alpha-mask textures (triangle.rs:587-607 / 868-898): a candidate hit on a mesh whose alpha or shadowalpha is a texture is
+// accepted only if the texture, evaluated at the hit's uv / p with no differentials, is not 0.  Its own instantiations, so every other scene keeps the leaner kernels.
+//   ALPHA = 1: every alpha texture of the scene is made of image maps under the uv mapping, constants, scale and mix — what scene files use for cut-outs.  Without
+//              differentials an image map is one bilinear look-up on the finest level whatever its filter (mipmap/mod.rs:222-231, :250-262), so the whole test is a few
+//              dozen instructions and is inlined (alpha_accept_lean, texture.h).
+//   ALPHA = 2: any texture class: an out-of-line call of the general evaluator (alpha_accept).  The callee's register appetite becomes the kernel's (336 VGPRs, one wave
+//              per SIMD: measured 30 x slower on a foliage scene than ALPHA = 1) — correct, and kept for the procedural masks only.
 static __device__ __noinline__ bool alpha_accept(const DeviceScene* dsc, uint32_t tri_index, float b0, float b1, float b2, uint32_t any_hit);
+static __device__ __forceinline__ bool alpha_accept_lean(const DeviceScene& sc, uint32_t prim, uint32_t mesh, float b0, float b1, float b2, bool any_hit);
 // WPE > 0 compiles the kernel for exactly that many waves per SIMD (= resident 256-thread blocks per CU): the register allocator then fits the budget
 // (7: 72 VGPRs, 8: 64) instead of taking what it likes; 0 leaves the choice to the compiler (same code as before).
 template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1, bool INST = false, bool MIXED = false,
-          bool ALPHA = false, int WPE = 0>
+          int ALPHA = 0, int WPE = 0>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
     // INST: the scene-level ray and what ray_setup derived from it (six IEEE divides), parked while the lane walks an instance: leaving an instance is then thirteen LDS reads instead of
@@ -410,7 +415,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                             // post-t rejections: degenerate triangle (triangle.rs:567-570 / 862-866), alpha == 0 (:603 / :886-893)
                             const uint32_t reject = ah ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
                             bool accept = !(flags & reject);
-                            if (ALPHA && accept && (flags & PH_TRI_ALPHATEX)) accept = alpha_accept(sc.self, ti, b0, b1, b2, ah ? 1u : 0u);
+                            if (ALPHA && accept && (flags & PH_TRI_ALPHATEX))
+                                accept = ALPHA == 1 ? alpha_accept_lean(sc, __float_as_uint(a.w), __float_as_uint(c.w), b0, b1, b2, ah) : alpha_accept(sc.self, ti, b0, b1, b2, ah ? 1u : 0u);
                             if (accept) {
                                 if (ah) occluded = true;
                                 else {

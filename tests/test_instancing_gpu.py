@@ -129,3 +129,23 @@ def test_area_light_inside_an_object_keeps_its_emission_and_leaves_the_light_lis
         nb = int((gxyz.view(np.uint32) != oxyz.view(np.uint32)).any(axis=2).sum())
         assert nb == 0, f"{nb} pixels differ (strategy {strategy})"
         assert float(oxyz.max()) > 5.0     # the emitter is in the picture
+
+
+def test_san_miguel_shaped_scene_small_film_bit_exact(host):
+    """The configs[4] scene description at a twentieth of its tessellation (pbrt_hip/sanmiguel.py: 128 objects, 1 100 instances, 26 materials, image-map alpha masks through
+    the traversal kernel's inlined test, bump maps, eleven lights) against the oracle, film and counters bit for bit, trees built on the device."""
+    from pbrt_hip.sanmiguel import SanMiguelScene
+    sm = SanMiguelScene(host, scale=0.05)
+    prod = pbrt_hip.Scene(); orc = OracleScene()
+    sm.capture(prod, 160, 90, 8, device_build=True); sm.capture(orc, 160, 90, 8)
+    set_libm_mode(1)
+    try:
+        oxyz, owt, ost, _ = orc.render_path_ex(max_depth=5, threads=16)
+    finally:
+        set_libm_mode(0)
+    gxyz, gwt, gst = prod.render_path(max_depth=5)
+    assert (gst.regular_rays, gst.shadow_rays, gst.paths_total, gst.paths_zero_radiance) == (ost.regular_rays, ost.shadow_rays, ost.paths_total, ost.paths_zero_radiance)
+    assert gst.light_distributions_created == ost.light_distributions_created > 0
+    assert np.array_equal(gwt.view(np.uint32), owt.view(np.uint32))
+    nb = int((gxyz.view(np.uint32) != oxyz.view(np.uint32)).any(axis=2).sum())
+    assert nb == 0, f"{nb} pixels differ"
