@@ -428,13 +428,16 @@ M4 m4_inverse(const M4& a) {
 extern "C" {
 
 int pbrt_hip_device_count(void) {
+    return ph_guard(nullptr, "pbrt_hip_device_count", [&]() -> int {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorNoDevice ? 0 : PBRT_HIP_ERR_DEVICE; }
     return n;
+    });
 }
 
 PbrtHipScene* pbrt_hip_scene_create(int device_ordinal) {
+    return ph_guard_ptr<PbrtHipScene>("pbrt_hip_scene_create", [&]() -> PbrtHipScene* {
     int n = pbrt_hip_device_count();
     if (n <= 0 || device_ordinal < 0 || device_ordinal >= n) {
         set_err(nullptr, PBRT_HIP_ERR_NO_DEVICE, "pbrt_hip_scene_create: no usable HIP device (this library has no CPU path)");
@@ -449,9 +452,11 @@ PbrtHipScene* pbrt_hip_scene_create(int device_ordinal) {
         return nullptr;
     }
     return s;
+    });
 }
 
 void pbrt_hip_scene_destroy(PbrtHipScene* s) {
+    ph_guard_void([&]() {
     if (!s) return;
     free_multi(s);  // the other devices' contexts of a multi-device handle
     (void)hipSetDevice(s->device);
@@ -465,6 +470,7 @@ void pbrt_hip_scene_destroy(PbrtHipScene* s) {
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
+    });
 }
 
 const char* pbrt_hip_last_error(const PbrtHipScene* s) {
@@ -500,6 +506,7 @@ int push_material(PbrtHipScene* s, MaterialRec& m, const std::vector<LobeRec>& l
 }  // namespace
 
 int pbrt_hip_add_material_matte(PbrtHipScene* s, const float kd[3], float sigma_deg, uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_material_matte", [&]() -> int {
     if (!s || !kd) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_matte: null argument");
     MaterialRec m{};
     for (int c = 0; c < 3; c++) m.kd[c] = hm::clampf(kd[c], 0.0f, hm::kInf);  // clamp_default (matte.rs:63)
@@ -520,14 +527,18 @@ int pbrt_hip_add_material_matte(PbrtHipScene* s, const float kd[3], float sigma_
     const int rc = push_material(s, m, lobes, false, out_id);
     if (rc == PBRT_HIP_OK && m.has_bxdf) s->material_params.back().lobe[0] = 0;
     return rc;
+    });
 }
 int pbrt_hip_add_material_none(PbrtHipScene* s, uint32_t* out_id) {  // Material "none" / "" (graphics_state.rs make_material -> None)
+    return ph_guard(s, "pbrt_hip_add_material_none", [&]() -> int {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
     MaterialRec m{}; m.bsdf_eta = 1.0f; m.none = 1u;
     s->has_none_material = true;
     return push_material(s, m, {}, false, out_id);
+    });
 }
 int pbrt_hip_add_material_mirror(PbrtHipScene* s, const float kr[3], uint32_t* out_id) {  // mirror.rs:40-62
+    return ph_guard(s, "pbrt_hip_add_material_mirror", [&]() -> int {
     if (!s || !kr) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mirror: null argument");
     MaterialRec m{}; m.bsdf_eta = 1.0f;
     std::vector<LobeRec> lobes;
@@ -536,8 +547,10 @@ int pbrt_hip_add_material_mirror(PbrtHipScene* s, const float kr[3], uint32_t* o
     const int rc = push_material(s, m, lobes, true, out_id);
     if (rc == PBRT_HIP_OK && !lobes.empty()) s->material_params.back().lobe[2] = 0;
     return rc;
+    });
 }
 int pbrt_hip_add_material_plastic(PbrtHipScene* s, const float kd[3], const float ks[3], float roughness, int remap_roughness, uint32_t* out_id) {  // plastic.rs:50-82
+    return ph_guard(s, "pbrt_hip_add_material_plastic", [&]() -> int {
     if (!s || !kd || !ks) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_plastic: null argument");
     MaterialRec m{}; m.bsdf_eta = 1.0f;
     std::vector<LobeRec> lobes;
@@ -553,9 +566,11 @@ int pbrt_hip_add_material_plastic(PbrtHipScene* s, const float kd[3], const floa
     const int rc = push_material(s, m, lobes, true, out_id);
     if (rc == PBRT_HIP_OK) { PbrtHipScene::MaterialParams& mp = s->material_params.back(); mp.lobe[0] = kd_lobe; mp.lobe[1] = ks_lobe; mp.rough_lobe = ks_lobe; mp.rough_remap = remap_roughness != 0; }
     return rc;
+    });
 }
 int pbrt_hip_add_material_glass(PbrtHipScene* s, const float kr[3], const float kt[3], float urough, float vrough, float eta, int remap_roughness,
                                 uint32_t* out_id) {  // glass.rs:62-118 with allow_multiple_lobes = true (path.rs:143)
+    return ph_guard(s, "pbrt_hip_add_material_glass", [&]() -> int {
     if (!s || !kr || !kt) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_glass: null argument");
     MaterialRec m{}; m.bsdf_eta = 1.0f;  // BSDF::new(.., None) (glass.rs:82)
     const float glass_raw_ur = urough, glass_raw_vr = vrough;   // before remapping: what a later roughness texture's `== 0` test is combined with
@@ -585,8 +600,10 @@ int pbrt_hip_add_material_glass(PbrtHipScene* s, const float kr[3], const float 
         }
     }
     return rc;
+    });
 }
 int pbrt_hip_add_material_metal(PbrtHipScene* s, const float eta[3], const float k[3], float urough, float vrough, int remap_roughness, uint32_t* out_id) {  // metal.rs:62-98
+    return ph_guard(s, "pbrt_hip_add_material_metal", [&]() -> int {
     if (!s || !eta || !k) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_metal: null argument");
     MaterialRec m{}; m.bsdf_eta = 1.0f;
     if (remap_roughness) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
@@ -596,9 +613,11 @@ int pbrt_hip_add_material_metal(PbrtHipScene* s, const float eta[3], const float
     const int rc = push_material(s, m, {l}, true, out_id);
     if (rc == PBRT_HIP_OK) { s->material_params.back().rough_lobe = 0; s->material_params.back().rough_remap = remap_roughness != 0; s->material_params.back().made_as = 3; }
     return rc;
+    });
 }
 int pbrt_hip_add_material_uber(PbrtHipScene* s, const float kd[3], const float ks[3], const float kr[3], const float kt[3], const float opacity[3], float urough,
                                float vrough, float eta, int remap_roughness, uint32_t* out_id) {  // uber.rs:116-186
+    return ph_guard(s, "pbrt_hip_add_material_uber", [&]() -> int {
     if (!s || !kd || !ks || !kr || !kt || !opacity) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_uber: null argument");
     MaterialRec m{};
     const float uber_raw_ur = urough, uber_raw_vr = vrough;
@@ -640,9 +659,11 @@ int pbrt_hip_add_material_uber(PbrtHipScene* s, const float kd[3], const float k
         if (kt_lobe >= 0) { mp.lobe[3] = kt_lobe; mp.field[3] = 1; }
     }
     return rc;
+    });
 }
 
 int pbrt_hip_add_material_substrate(PbrtHipScene* s, const float kd[3], const float ks[3], float urough, float vrough, int remap_roughness, uint32_t* out_id) {  // substrate.rs:55-84
+    return ph_guard(s, "pbrt_hip_add_material_substrate", [&]() -> int {
     if (!s || !kd || !ks) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_substrate: null argument");
     MaterialRec m{}; m.bsdf_eta = 1.0f;
     std::vector<LobeRec> lobes;
@@ -656,9 +677,11 @@ int pbrt_hip_add_material_substrate(PbrtHipScene* s, const float kd[3], const fl
     const int rc = push_material(s, m, lobes, true, out_id);
     if (rc == PBRT_HIP_OK && !lobes.empty()) { PbrtHipScene::MaterialParams& mp = s->material_params.back(); mp.lobe[0] = 0; mp.field[0] = 0; mp.lobe[1] = 0; mp.field[1] = 1; mp.rough_lobe = 0; mp.rough_remap = remap_roughness != 0; }
     return rc;
+    });
 }
 int pbrt_hip_add_material_translucent(PbrtHipScene* s, const float kd[3], const float ks[3], const float reflect[3], const float transmit[3], float roughness,
                                       int remap_roughness, uint32_t* out_id) {  // translucent.rs:57-112
+    return ph_guard(s, "pbrt_hip_add_material_translucent", [&]() -> int {
     if (!s || !kd || !ks || !reflect || !transmit) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_translucent: null argument");
     MaterialRec m{}; m.bsdf_eta = 1.5f;
     std::vector<LobeRec> lobes;
@@ -686,8 +709,10 @@ int pbrt_hip_add_material_translucent(PbrtHipScene* s, const float kd[3], const 
     const int rc = push_material(s, m, lobes, true, out_id);
     if (rc == PBRT_HIP_OK) s->material_params.back() = mp;
     return rc;
+    });
 }
 int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t material2, const float amount[3], uint32_t* out_id) {  // mix.rs:51-88
+    return ph_guard(s, "pbrt_hip_add_material_mix", [&]() -> int {
     if (!s || !amount) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: null argument");
     if (material1 >= s->materials.size() || material2 >= s->materials.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: unknown material id");
     MaterialRec m{}; m.bsdf_eta = 1.0f;
@@ -733,6 +758,7 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
     const int rc = push_material(s, m, lobes, true, out_id);
     if (rc == PBRT_HIP_OK) { s->material_params.back().made_as = 4; s->material_params.back().mix_n1 = (int)a.n_lobes; if (m.bump_tex1) { s->textured_materials = true; s->bump_materials = true; } }
     return rc;
+    });
 }
 
 }  // extern "C"
@@ -840,6 +866,7 @@ static bool triangle_is_bogus(hm::V3 p0, hm::V3 p1, hm::V3 p2, const float* uv0,
 int pbrt_hip_add_mesh(PbrtHipScene* s, const float* P, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, const float* N,
                       const float* S, const float* UV, uint32_t material_id, int32_t first_area_light_id, uint32_t flags, float alpha,
                       float shadow_alpha) {
+    return ph_guard(s, "pbrt_hip_add_mesh", [&]() -> int {
     if (!s || !P || !indices) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mesh: null argument");
     if (material_id >= s->materials.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mesh: unknown material id");
     for (uint32_t i = 0; i < 3 * n_tris; i++)
@@ -897,10 +924,12 @@ int pbrt_hip_add_mesh(PbrtHipScene* s, const float* P, uint32_t n_verts, const u
     s->built = false; s->uploaded = false;
     if (dropped_lights) s->err = "warning: Area lights not supported with object instancing.";   // the reference's warn! (lib.rs:878); the call succeeds
     return PBRT_HIP_OK;
+    });
 }
 
 // ObjectBegin / ObjectEnd / ObjectInstance (api/src/lib.rs:911-1000)
 int pbrt_hip_object_begin(PbrtHipScene* s, uint32_t* out_object_id) {
+    return ph_guard(s, "pbrt_hip_object_begin", [&]() -> int {
     if (!s || !out_object_id) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "object_begin: null argument");
     if (s->open_object >= 0) return set_err(s, PBRT_HIP_ERR_STATE, "object_begin: ObjectBegin called inside of an instance definition");
     PbrtHipScene::ObjectHost ob; ob.tri0 = ob.tri1 = (uint32_t)(s->idx.size() / 3);
@@ -908,14 +937,18 @@ int pbrt_hip_object_begin(PbrtHipScene* s, uint32_t* out_object_id) {
     s->open_object = (int)s->objects.size() - 1;
     *out_object_id = (uint32_t)s->open_object;
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_object_end(PbrtHipScene* s) {
+    return ph_guard(s, "pbrt_hip_object_end", [&]() -> int {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
     if (s->open_object < 0) return set_err(s, PBRT_HIP_ERR_STATE, "object_end: ObjectEnd called outside of instance definition");
     s->open_object = -1;
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_add_instance(PbrtHipScene* s, uint32_t object_id, const float i2w[16], const float w2i[16]) {
+    return ph_guard(s, "pbrt_hip_add_instance", [&]() -> int {
     if (!s || !i2w || !w2i) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_instance: null argument");
     if (s->open_object >= 0) return set_err(s, PBRT_HIP_ERR_STATE, "add_instance: ObjectInstance can't be called inside of instance definition");
     if (object_id >= s->objects.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_instance: unknown object");
@@ -926,6 +959,7 @@ int pbrt_hip_add_instance(PbrtHipScene* s, uint32_t object_id, const float i2w[1
     s->top_items.push_back(PH_ITEM_INST | (uint32_t)(s->instances.size() - 1));
     s->built = false; s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 
 // 1x1 MIPMap::triangle (core/src/mipmap/mod.rs:293-311) for a constant environment
@@ -937,6 +971,7 @@ static float env_lookup(float tx, float s_, float t_) {
 }
 
 int pbrt_hip_add_light_infinite(PbrtHipScene* s, const float L[3], const float l2w[16], const float w2l[16]) {
+    return ph_guard(s, "pbrt_hip_add_light_infinite", [&]() -> int {
     if (!s || !L || !l2w || !w2l) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_infinite: null argument");
     LightRec l{};
     l.type = PH_L_INFINITE; l.prim = 0xFFFFFFFFu;
@@ -970,22 +1005,28 @@ int pbrt_hip_add_light_infinite(PbrtHipScene* s, const float L[3], const float l
     s->lights.push_back(l);
     s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_add_light_distant(PbrtHipScene* s, const float L[3], const float w[3]) {
+    return ph_guard(s, "pbrt_hip_add_light_distant", [&]() -> int {
     if (!s || !L || !w) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_distant: null argument");
     LightRec l{}; l.type = PH_L_DISTANT; l.prim = 0xFFFFFFFFu;
     for (int c = 0; c < 3; c++) { l.L[c] = L[c]; l.v[c] = w[c]; }
     s->lights.push_back(l); s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_add_light_point(PbrtHipScene* s, const float I[3], const float p[3]) {
+    return ph_guard(s, "pbrt_hip_add_light_point", [&]() -> int {
     if (!s || !I || !p) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_point: null argument");
     LightRec l{}; l.type = PH_L_POINT; l.prim = 0xFFFFFFFFu;
     for (int c = 0; c < 3; c++) { l.L[c] = I[c]; l.v[c] = p[c]; }
     s->lights.push_back(l); s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_add_light_spot(PbrtHipScene* s, const float I[3], const float l2w[16], const float w2l[16], float cos_total_width, float cos_falloff_start) {  // spot.rs:27-50
+    return ph_guard(s, "pbrt_hip_add_light_spot", [&]() -> int {
     if (!s || !I || !l2w || !w2l) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_spot: null argument");
     LightRec l{}; l.type = PH_L_SPOT; l.prim = 0xFFFFFFFFu;
     for (int c = 0; c < 3; c++) l.L[c] = I[c];
@@ -997,8 +1038,10 @@ int pbrt_hip_add_light_spot(PbrtHipScene* s, const float I[3], const float l2w[1
     l.cos_total_width = cos_total_width; l.cos_falloff_start = cos_falloff_start;
     s->lights.push_back(l); s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_add_light_diffuse_area(PbrtHipScene* s, const float L[3], int two_sided, uint32_t n_tris, uint32_t* out_first_id) {
+    return ph_guard(s, "pbrt_hip_add_light_diffuse_area", [&]() -> int {
     if (!s || !L) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_diffuse_area: null argument");
     if (out_first_id) *out_first_id = (uint32_t)s->lights.size();
     for (uint32_t i = 0; i < n_tris; i++) {
@@ -1008,10 +1051,12 @@ int pbrt_hip_add_light_diffuse_area(PbrtHipScene* s, const float L[3], int two_s
     }
     s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 
 int pbrt_hip_set_camera_perspective(PbrtHipScene* s, const float r2c[16], const float c2w[16], float lens_radius, float focal_distance,
                                     float shutter_open, float shutter_close) {
+    return ph_guard(s, "pbrt_hip_set_camera_perspective", [&]() -> int {
     if (!s || !r2c || !c2w) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_camera_perspective: null argument");
     std::memcpy(s->cam.r2c, r2c, 64); std::memcpy(s->cam.c2w, c2w, 64);
     s->cam.lens_radius = lens_radius; s->cam.focal_distance = focal_distance;
@@ -1031,9 +1076,11 @@ int pbrt_hip_set_camera_perspective(PbrtHipScene* s, const float r2c[16], const 
     s->cam.kind = PH_CAM_PERSPECTIVE;
     s->have_camera = true;
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_set_camera_orthographic(PbrtHipScene* s, const float r2c[16], const float c2w[16], float lens_radius, float focal_distance,
                                      float shutter_open, float shutter_close) {  // OrthographicCamera::new (orthographic_camera.rs:39-72)
+    return ph_guard(s, "pbrt_hip_set_camera_orthographic", [&]() -> int {
     const int rc = pbrt_hip_set_camera_perspective(s, r2c, c2w, lens_radius, focal_distance, shutter_open, shutter_close);
     if (rc != PBRT_HIP_OK) return rc;
     // dx_camera / dy_camera (:58-64): raster_to_camera.transform_vector((1,0,0)) / ((0,1,0)) (transform.rs:373-380)
@@ -1045,9 +1092,11 @@ int pbrt_hip_set_camera_orthographic(PbrtHipScene* s, const float r2c[16], const
     }
     s->cam.kind = PH_CAM_ORTHOGRAPHIC;
     return PBRT_HIP_OK;
+    });
 }
 
 int pbrt_hip_set_camera_environment(PbrtHipScene* s, const float c2w[16], int xres, int yres, float shutter_open, float shutter_close) {  // environment_camera.rs:27-41
+    return ph_guard(s, "pbrt_hip_set_camera_environment", [&]() -> int {
     if (!s || !c2w) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_camera_environment: null argument");
     if (xres <= 0 || yres <= 0) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_camera_environment: the film's full resolution must be positive");
     s->cam = CameraRec{};
@@ -1058,10 +1107,12 @@ int pbrt_hip_set_camera_environment(PbrtHipScene* s, const float c2w[16], int xr
     s->cam.kind = PH_CAM_ENVIRONMENT;
     s->have_camera = true;
     return PBRT_HIP_OK;
+    });
 }
 
 int pbrt_hip_set_film(PbrtHipScene* s, int xres, int yres, const int crop[4], const float radius[2], const float table[256], float scale,
                       float max_lum) {
+    return ph_guard(s, "pbrt_hip_set_film", [&]() -> int {
     if (!s || !crop || !radius || !table) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_film: null argument");
     if (!(radius[0] > 0.0f) || !(radius[1] > 0.0f)) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_film: filter radius must be positive");
     FilmRec& f = s->film;
@@ -1073,6 +1124,7 @@ int pbrt_hip_set_film(PbrtHipScene* s, int xres, int yres, const int crop[4], co
     std::memcpy(f.table, table, sizeof(f.table));
     s->have_film = true;
     return PBRT_HIP_OK;
+    });
 }
 
 static void ext_gcd(uint64_t a, uint64_t b, int64_t& x, int64_t& y) {  // halton.rs:294-302
@@ -1089,6 +1141,7 @@ static uint64_t mult_inverse(int64_t a, int64_t n) {  // halton.rs:304-311
 }
 
 int pbrt_hip_set_sampler(PbrtHipScene* s, int kind, uint32_t spp, const int sb[4], int at_center) {
+    return ph_guard(s, "pbrt_hip_set_sampler", [&]() -> int {
     if (!s || !sb) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_sampler: null argument");
     if (kind != 0 && kind != 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_sampler: only halton (0) and sobol (1) are GPU-friendly (SURVEY §8a-S)");
     if (spp == 0) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_sampler: spp must be > 0");
@@ -1118,16 +1171,20 @@ int pbrt_hip_set_sampler(PbrtHipScene* s, int kind, uint32_t spp, const int sb[4
     }
     s->have_sampler = true;
     return PBRT_HIP_OK;
+    });
 }
 
 int pbrt_hip_set_sobol_tables(PbrtHipScene* s, const uint32_t* m32, size_t n32, const uint64_t* vdc, const uint64_t* vdc_inv, size_t n_each) {
+    return ph_guard(s, "pbrt_hip_set_sobol_tables", [&]() -> int {
     if (!s || !m32 || !vdc || !vdc_inv) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_sobol_tables: null argument");
     s->sobol32.assign(m32, m32 + n32); s->vdc.assign(vdc, vdc + n_each); s->vdc_inv.assign(vdc_inv, vdc_inv + n_each);
     s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 
 int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_node) {
+    return ph_guard(s, "pbrt_hip_build_accel", [&]() -> int {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
     if (split_method == 2) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: splitmethod 'middle' panics in the reference (quirk B6, sah.rs:67-76)");
     // every DiffuseAreaLight belongs to a shape (api/src/lib.rs:783-812 creates them per triangle): one that no add_mesh claimed would be sampled
@@ -1223,27 +1280,33 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
     }
     s->built = true; s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 
 // BVHAccel::from with splitmethod "sah" (the default) or "hlbvh", constructed on the GPU (bvh_sah_device.hip, bvh_device.hip): same tree, same leaf order as pbrt_hip_build_accel
 int pbrt_hip_build_accel_device(PbrtHipScene* s, int split_method, int max_prims_in_node) {
+    return ph_guard(s, "pbrt_hip_build_accel_device", [&]() -> int {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
     if (split_method != 0 && split_method != 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel_device: the device builders make the SAH (0) and the HLBVH (1) tree; EqualCounts is built on the host");
     s->build_on_device = true;
     const int rc = pbrt_hip_build_accel(s, split_method, max_prims_in_node);
     s->build_on_device = false;
     return rc;
+    });
 }
 
 int pbrt_hip_world_bound(const PbrtHipScene* s, float out[6]) {
+    return ph_guard(const_cast<PbrtHipScene*>(s), "pbrt_hip_world_bound", [&]() -> int {
     if (!s || !out) return PBRT_HIP_ERR_INVALID_ARG;
     if (!s->built) return PBRT_HIP_ERR_STATE;
     for (int k = 0; k < 3; k++) { out[k] = s->bvh.root_lo[k]; out[3 + k] = s->bvh.root_hi[k]; }
     return PBRT_HIP_OK;
+    });
 }
 
 // measurement aid: sizes of the built acceleration structure in the device layout (bvh/common.rs:8-23 keeps the same tallies as statistics)
 int pbrt_hip_accel_stats(const PbrtHipScene* s, uint64_t out[8]) {
+    return ph_guard(const_cast<PbrtHipScene*>(s), "pbrt_hip_accel_stats", [&]() -> int {
     if (!s || !out) return PBRT_HIP_ERR_INVALID_ARG;
     if (!s->built) return PBRT_HIP_ERR_STATE;
     out[0] = s->tree_dev_tris ? s->bvh.interior_nodes : s->bvh.nodes.size(); out[1] = s->tree_dev_tris ? s->tree_dev_n_tris : s->bvh.tris.size();
@@ -1251,10 +1314,12 @@ int pbrt_hip_accel_stats(const PbrtHipScene* s, uint64_t out[8]) {
     out[4] = s->bvh.leaf_nodes; out[5] = (uint64_t)s->bvh.max_depth; out[6] = s->bvh.max_leaf_prims;
     out[7] = (uint64_t)(s->bvh.build_seconds * 1e6);
     return PBRT_HIP_OK;
+    });
 }
 
 // test aid: the built structure itself (device layout), wherever it lives
 int pbrt_hip_accel_copy(PbrtHipScene* s, void* out_nodes, uint64_t node_capacity, void* out_leaf_records, uint64_t record_capacity) {
+    return ph_guard(s, "pbrt_hip_accel_copy", [&]() -> int {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
     if (!s->built) return set_err(s, PBRT_HIP_ERR_STATE, "accel_copy: build_accel first");
     const size_t nn = s->tree_dev_tris ? s->bvh.interior_nodes : s->bvh.nodes.size(), nt = s->tree_dev_tris ? s->tree_dev_n_tris : s->bvh.tris.size();
@@ -1268,6 +1333,7 @@ int pbrt_hip_accel_copy(PbrtHipScene* s, void* out_nodes, uint64_t node_capacity
         if (nt && out_leaf_records) std::memcpy(out_leaf_records, s->bvh.tris.data(), nt * sizeof(TriRec));
     }
     return PBRT_HIP_OK;
+    });
 }
 
 static int check_error_flag(PbrtHipScene* s) {
@@ -1303,15 +1369,16 @@ static int batch_common(PbrtHipScene* s, bool anyhit, const void* rays, void* ou
     return check_error_flag(s);
 }
 
-int pbrt_hip_intersect_batch(PbrtHipScene* s, const PbrtHipRay* rays, PbrtHipHit* hits, uint64_t n) { return batch_common(s, false, rays, hits, n, false, nullptr); }
-int pbrt_hip_occluded_batch(PbrtHipScene* s, const PbrtHipRay* rays, uint8_t* out, uint64_t n) { return batch_common(s, true, rays, out, n, false, nullptr); }
-int pbrt_hip_intersect_batch_device(PbrtHipScene* s, const void* d_rays, void* d_hits, uint64_t n, float* ms) { return batch_common(s, false, d_rays, d_hits, n, true, ms); }
-int pbrt_hip_occluded_batch_device(PbrtHipScene* s, const void* d_rays, void* d_occ, uint64_t n, float* ms) { return batch_common(s, true, d_rays, d_occ, n, true, ms); }
+int pbrt_hip_intersect_batch(PbrtHipScene* s, const PbrtHipRay* rays, PbrtHipHit* hits, uint64_t n) { return ph_guard(s, "pbrt_hip_intersect_batch", [&]() -> int { return batch_common(s, false, rays, hits, n, false, nullptr); }); }
+int pbrt_hip_occluded_batch(PbrtHipScene* s, const PbrtHipRay* rays, uint8_t* out, uint64_t n) { return ph_guard(s, "pbrt_hip_occluded_batch", [&]() -> int { return batch_common(s, true, rays, out, n, false, nullptr); }); }
+int pbrt_hip_intersect_batch_device(PbrtHipScene* s, const void* d_rays, void* d_hits, uint64_t n, float* ms) { return ph_guard(s, "pbrt_hip_intersect_batch_device", [&]() -> int { return batch_common(s, false, d_rays, d_hits, n, true, ms); }); }
+int pbrt_hip_occluded_batch_device(PbrtHipScene* s, const void* d_rays, void* d_occ, uint64_t n, float* ms) { return ph_guard(s, "pbrt_hip_occluded_batch_device", [&]() -> int { return batch_common(s, true, d_rays, d_occ, n, true, ms); }); }
 
 // Roofline bookkeeping: with counting on, every traversal launch also accumulates the work it did.
 // out[0..2] closest-hit {interior nodes passed, triangle tests, rays}, out[3..5] any-hit.  Reference-format node visits of
 // the closest-hit rays = rays + 2*out[0] (see traverse.h).  Reading resets the counters.
 int pbrt_hip_set_traversal_counting(PbrtHipScene* s, int on) {
+    return ph_guard(s, "pbrt_hip_set_traversal_counting", [&]() -> int {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
     PH_CHECK(s, hipSetDevice(s->device));
     int rc;
@@ -1319,8 +1386,10 @@ int pbrt_hip_set_traversal_counting(PbrtHipScene* s, int on) {
     PH_CHECK(s, hipMemset(s->d_counts.p, 0, 64));
     s->count_traversal = on != 0;
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_get_traversal_counts(PbrtHipScene* s, uint64_t out[8]) {
+    return ph_guard(s, "pbrt_hip_get_traversal_counts", [&]() -> int {
     if (!s || !out) return PBRT_HIP_ERR_INVALID_ARG;
     if (!s->d_counts.p) { for (int i = 0; i < 8; i++) out[i] = 0; return PBRT_HIP_OK; }
     PH_CHECK(s, hipSetDevice(s->device));
@@ -1328,10 +1397,12 @@ int pbrt_hip_get_traversal_counts(PbrtHipScene* s, uint64_t out[8]) {
     PH_CHECK(s, hipMemcpy(out, s->d_counts.p, 64, hipMemcpyDeviceToHost));
     PH_CHECK(s, hipMemset(s->d_counts.p, 0, 64));
     return PBRT_HIP_OK;
+    });
 }
 
 // Film::get_pixel_rgb (core/src/film/mod.rs:392-417); splat is identically zero for the path integrator (quirk B3 kept)
 int pbrt_hip_film_to_rgb(const PbrtHipScene* s, const float* xyz, const float* weight, float* out_rgb) {
+    return ph_guard(const_cast<PbrtHipScene*>(s), "pbrt_hip_film_to_rgb", [&]() -> int {
     if (!s || !xyz || !weight || !out_rgb) return PBRT_HIP_ERR_INVALID_ARG;
     if (!s->have_film) return PBRT_HIP_ERR_STATE;
     const FilmRec& f = s->film;
@@ -1357,6 +1428,7 @@ int pbrt_hip_film_to_rgb(const PbrtHipScene* s, const float* xyz, const float* w
         }
     }
     return PBRT_HIP_OK;
+    });
 }
 
 }  // extern "C"

@@ -1,5 +1,6 @@
 // See bvh_build.h.  Host C++ only (no device code).
 #include "bvh_build.h"
+#include "guard.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -76,13 +77,13 @@ struct Builder {
     void release_helpers(int n) { if (n > 0) spare_threads.fetch_add(n); }
     template <class F> static void parallel_chunks(size_t start, size_t end, int helpers, F f) {
         const size_t n = end - start, parts = (size_t)helpers + 1, step = (n + parts - 1) / parts;
-        std::vector<std::thread> th;
+        ThreadGroup th;
         for (int t = 1; t <= helpers; t++) {
             const size_t a = std::min(end, start + (size_t)t * step), b = std::min(end, a + step);
-            th.emplace_back([=]() { f(t, a, b); });
+            th.run([=]() { f(t, a, b); });
         }
         f(0, start, std::min(end, start + step));
-        for (std::thread& x : th) x.join();
+        th.join();
     }
 
     static uint32_t bucket_of(const Box& cb, const float* c, int dim) {  // sah.rs:309-313 (saturating `as usize`)
@@ -185,7 +186,8 @@ struct Builder {
         // fork the larger subtrees onto spare threads
         if (n > 32768 && spare_threads.fetch_sub(1) > 0) {
             BNode* left = nullptr;
-            std::thread t([&]() { left = build(start, mid); });
+            ThreadGroup t;
+            t.run([&]() { left = build(start, mid); });
             node->kid[1] = build(mid, end);
             t.join();
             node->kid[0] = left;
@@ -336,10 +338,10 @@ struct Builder {
         std::vector<BNode*> roots(spans.size());
         std::atomic<size_t> next{0};
         auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < spans.size();) roots[i] = emit_lbvh(spans[i].first, spans[i].n, 29 - 12); };
-        std::vector<std::thread> pool_threads;
-        for (int t = 1; t < n_threads && (size_t)t < spans.size(); t++) pool_threads.emplace_back(work);
+        ThreadGroup pool_threads;
+        for (int t = 1; t < n_threads && (size_t)t < spans.size(); t++) pool_threads.run(work);
         work();
-        for (std::thread& t : pool_threads) t.join();
+        pool_threads.join();
         BNode* root = upper_sah(roots, 0, roots.size());
         // lay the leaves out depth first: prims[] becomes the final primitive order, leaf ranges point into it
         std::vector<Prim> ordered; ordered.reserve(n);
@@ -450,11 +452,11 @@ int build_bvh(const BuildInput& in, int split_method, int max_prims_in_node, int
     };
     {  // the gather of vertex positions is a random walk over P: spread it over the threads
         const int nt = (n >= (1u << 16)) ? std::max(n_threads, 1) : 1;
-        std::vector<std::thread> th;
+        ThreadGroup th;
         const size_t step = (n + nt - 1) / nt;
-        for (int t = 1; t < nt; t++) th.emplace_back(fill, std::min(n, (size_t)t * step), std::min(n, (size_t)(t + 1) * step));
+        for (int t = 1; t < nt; t++) { const size_t a = std::min(n, (size_t)t * step), b = std::min(n, (size_t)(t + 1) * step); th.run([&fill, a, b]() { fill(a, b); }); }
         fill(0, std::min(n, step));
-        for (std::thread& x : th) x.join();
+        th.join();
     }
     for (int k = 0; k < 3; k++) { out.root_lo[k] = root->b.lo[k]; out.root_hi[k] = root->b.hi[k]; }
 

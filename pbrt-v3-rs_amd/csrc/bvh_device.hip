@@ -399,6 +399,7 @@ fail:
 // Test / measurement hook with the signature of pbrt_hip_host_build_bvh (host_setup.cpp): the same tree, built on device `device`.
 extern "C" int pbrt_hip_device_build_bvh(int device, const float* P, const uint32_t* idx, uint64_t n_tris, int split_method, int max_prims_in_node, uint32_t* out_ordered_prims,
                                          uint32_t* out_leaf_last, void* out_nodes, uint64_t* out_info, float* out_root_bounds, double* out_seconds) {
+    return phost::ph_guard(nullptr, "pbrt_hip_device_build_bvh", [&]() -> int {
     if (split_method != 0 && split_method != 1) return -1;
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return -1; }
     phost::BuildInput in{P, idx, (size_t)n_tris, nullptr, nullptr};
@@ -416,4 +417,5 @@ extern "C" int pbrt_hip_device_build_bvh(int device, const float* P, const uint3
     if (out_root_bounds) { for (int k = 0; k < 3; k++) { out_root_bounds[k] = out.root_lo[k]; out_root_bounds[3 + k] = out.root_hi[k]; } }
     if (out_seconds) *out_seconds = out.build_seconds;
     return 0;
+    });
 }

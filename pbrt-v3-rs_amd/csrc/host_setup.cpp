@@ -6,7 +6,10 @@
 //   Film::new / get_sample_bounds                                  core/src/film/mod.rs:89-159
 #include "../../include/pbrt_hip_host.h"
 #include "host_math.h"
+#include "guard.h"
 #include <algorithm>
+using phost::ph_guard;
+using phost::ph_guard_void;
 
 using namespace hm;
 
@@ -60,6 +63,7 @@ void pbrt_hip_host_invert(const float m[16], float out[16]) { out16(m4_inverse(i
 // Transform::look_at (transform.rs:165-189): out_m = world->camera, out_minv = camera->world.  Returns -1 when `up`
 // and the viewing direction are parallel (the reference panics).
 int pbrt_hip_host_look_at(const float pos[3], const float look[3], const float up[3], float out_m[16], float out_minv[16]) {
+    return ph_guard(nullptr, "pbrt_hip_host_look_at", [&]() -> int {
     V3 p = ld(pos), dir = normalize(sub(ld(look), p));
     V3 right = cross(normalize(ld(up)), dir);
     if (len(right) == 0.0f) return -1;
@@ -68,6 +72,7 @@ int pbrt_hip_host_look_at(const float pos[3], const float look[3], const float u
     M4 c2w = rows(right.x, new_up.x, dir.x, p.x, right.y, new_up.y, dir.y, p.y, right.z, new_up.z, dir.z, p.z, 0, 0, 0, 1);
     out16(m4_inverse(c2w), out_m); out16(c2w, out_minv);
     return 0;
+    });
 }
 
 // Default screen window from the frame aspect ratio (perspective_camera.rs:381-389): {xmin, xmax, ymin, ymax}
@@ -150,6 +155,7 @@ void pbrt_hip_host_film_box(int xres, int yres, const float crop_window[4] /*x0 
 // Returns -1 for an unknown kind.  exp/sin are the host libm's f32 routines, as they are for the reference's host.
 int pbrt_hip_host_film_filter(int kind, const float params[2], int xres, int yres, const float crop_window[4], const float radius[2],
                               int out_cropped_bounds[4], float out_table[256], int out_sample_bounds[4]) {
+    return ph_guard(nullptr, "pbrt_hip_host_film_filter", [&]() -> int {
     if (kind < 0 || kind > 4) return -1;
     pbrt_hip_host_film_box(xres, yres, crop_window, radius, out_cropped_bounds, out_table, out_sample_bounds);
     const float rx = radius[0], ry = radius[1];
@@ -185,6 +191,7 @@ int pbrt_hip_host_film_filter(int kind, const float params[2], int xres, int yre
             out_table[o] = v;
         }
     return 0;
+    });
 }
 
 // transform_point / transform_vector / transform_normal (transform.rs:288-302,373-380,441-448) for mesh vertices:
@@ -263,6 +270,7 @@ void pbrt_hip_host_spot(const float ctm_m[16], const float ctm_minv[16], const f
 }
 
 void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, float* out_P /*9 per tri*/, uint32_t* out_idx /*3 per tri*/) {
+    ph_guard_void([&]() {
     Pcg32 rng;
     rng.state = 0; rng.inc = (seed << 1) | 1;  // RNG::set_sequence
     rng.next(); rng.state += 0x853c49e6748fea9bULL; rng.next();
@@ -275,6 +283,7 @@ void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, float* out_P 
             for (int k = 0; k < 3; k++) out_P[9 * t + 3 * v + k] = c[k] + s * (2.0f * uf() - 1.0f);
         out_idx[3 * t] = (uint32_t)(3 * t); out_idx[3 * t + 1] = (uint32_t)(3 * t + 1); out_idx[3 * t + 2] = (uint32_t)(3 * t + 2);
     }
+    });
 }
 
 // ---- host-only view of the BVH builder (no device needed): used by the CPU test-suite to pin the topology contract of
@@ -283,6 +292,7 @@ void pbrt_hip_host_gen_random_tris(uint64_t n_tris, uint64_t seed, float* out_P 
 #include "bvh_build.h"
 extern "C" int pbrt_hip_host_build_bvh(const float* P, const uint32_t* idx, uint64_t n_tris, int split_method, int max_prims_in_node, int n_threads,
                                        uint32_t* out_ordered_prims, uint32_t* out_leaf_last, void* out_nodes, uint64_t* out_info, float* out_root_bounds) {
+    return ph_guard(nullptr, "pbrt_hip_host_build_bvh", [&]() -> int {
     phost::BuildInput in{P, idx, (size_t)n_tris, nullptr, nullptr};
     phost::BuildOutput out;
     int rc = phost::build_bvh(in, split_method, max_prims_in_node, n_threads, out);
@@ -295,6 +305,7 @@ extern "C" int pbrt_hip_host_build_bvh(const float* P, const uint32_t* idx, uint
     if (out_info) { out_info[0] = out.interior_nodes; out_info[1] = out.leaf_nodes; out_info[2] = out.max_leaf_prims; out_info[3] = (uint64_t)out.max_depth; out_info[4] = out.root_ref; }
     if (out_root_bounds) { for (int k = 0; k < 3; k++) { out_root_bounds[k] = out.root_lo[k]; out_root_bounds[3 + k] = out.root_hi[k]; } }
     return 0;
+    });
 }
 
 // ---- spectral parameter types of the scene description -> RGB ------------------------------------------------------------------------------------
@@ -358,6 +369,7 @@ extern "C" void pbrt_hip_host_blackbody_rgb(float temperature, float scale, floa
 // (wavelength nm, value) pairs.  Unsorted input is sorted by wavelength first: the reference sorts a copy and then interpolates the ORIGINAL order, where its
 // interval assertion fails (rgb_spectrum.rs:84-91, common.rs:327) — there is no result of the reference to match for unsorted samples.  Returns -1 for n == 0.
 extern "C" int pbrt_hip_host_sampled_rgb(const float* lambda_value_pairs, size_t n_samples, float out_rgb[3]) {
+    return ph_guard(nullptr, "pbrt_hip_host_sampled_rgb", [&]() -> int {
     if (!lambda_value_pairs || n_samples == 0) return -1;
     std::vector<std::pair<float, float>> s(n_samples);
     for (size_t i = 0; i < n_samples; i++) s[i] = {lambda_value_pairs[2 * i], lambda_value_pairs[2 * i + 1]};
@@ -365,6 +377,7 @@ extern "C" int pbrt_hip_host_sampled_rgb(const float* lambda_value_pairs, size_t
     if (n_samples == 1) { s.push_back(s[0]); }  // a single sample is a constant spectrum (both clamps of interpolate_spectrum_samples return it)
     samples_to_rgb(s, out_rgb);
     return 0;
+    });
 }
 
 // MetalMaterial's defaults (materials/src/metal.rs:136-147): RGB of the copper n and k spectra

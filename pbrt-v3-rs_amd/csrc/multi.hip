@@ -79,28 +79,47 @@ void free_multi(PbrtHipScene* s) {
     s->multi = nullptr;
 }
 
-// the handle's captured state -> every replica (bulk copy only when something changed since the replicas last uploaded it)
-static void sync_replicas(PbrtHipScene* s) {
-    MultiDevice& m = *s->multi;
-    const bool bulk = !m.replicas_current || !s->uploaded;
-    if (bulk) (void)ensure_host_tree(s);   // a tree built on the first device travels to the others through its host copy
-    for (PbrtHipScene* r : m.replicas) {
-        if (bulk) {
-            static_cast<SceneHostState&>(*r) = static_cast<const SceneHostState&>(*s);
-            r->uploaded = false; r->light_strategy_uploaded = -1;
-        } else {  // what set_camera_* / set_film / set_sampler change without touching the uploaded scene
-            r->cam = s->cam; r->film = s->film; r->sampler = s->sampler;
-            r->have_camera = s->have_camera; r->have_film = s->have_film; r->have_sampler = s->have_sampler; r->built = s->built;
-        }
-        r->count_traversal = false;
-    }
-    m.replicas_current = true;
-}
-
 // after a replica has uploaded: the arrays only upload_scene reads go back to the allocator (a 10 M-triangle scene keeps ~1.4 GB of them per context)
 static void drop_bulk(PbrtHipScene* r) {
     auto drop = [](auto& v) { std::remove_reference_t<decltype(v)> e; v.swap(e); };
     drop(r->P); drop(r->N); drop(r->S); drop(r->UV); drop(r->idx); drop(r->tri_mesh); drop(r->tri_flags); drop(r->bvh.nodes); drop(r->bvh.tris);
+}
+
+// The handle's captured state -> every replica.  A bulk copy only when something changed since the replicas last uploaded it, and then ONE replica at a time (copy, upload,
+// drop the bulky host arrays again): at most one extra copy of the scene is ever held on the host.  A tree that was built on the first device and lives only there
+// (pbrt_hip_build_accel_device) goes to the other devices by hipMemcpyPeer — no 730 MB round trip through the host for 10 M triangles.
+static int sync_replicas(PbrtHipScene* s) {
+    MultiDevice& m = *s->multi;
+    const bool bulk = !m.replicas_current || !s->uploaded;
+    for (PbrtHipScene* r : m.replicas) {
+        if (bulk) {
+            m.replicas_current = false;   // until every replica has the new state
+            PH_CHECK(s, hipSetDevice(r->device));
+            free_tree_dev(r);
+            static_cast<SceneHostState&>(*r) = static_cast<const SceneHostState&>(*s);   // (a device-built tree leaves bvh.nodes / bvh.tris empty: nothing bulky to copy there)
+            r->uploaded = false; r->light_strategy_uploaded = -1; r->count_traversal = false;
+            if (s->tree_dev_tris) {
+                const size_t nb = s->bvh.interior_nodes * sizeof(Node64), tb = s->tree_dev_n_tris * sizeof(TriRec);
+                if (hipMalloc(&r->tree_dev_nodes, nb ? nb : 16) != hipSuccess || hipMalloc(&r->tree_dev_tris, tb ? tb : 16) != hipSuccess) {
+                    (void)hipGetLastError(); free_tree_dev(r);
+                    return set_err(s, PBRT_HIP_ERR_OOM, "render: no device memory for the tree on device " + std::to_string(r->device));
+                }
+                r->tree_dev_n_tris = s->tree_dev_n_tris;
+                if (nb) PH_CHECK(s, hipMemcpyPeer(r->tree_dev_nodes, r->device, s->tree_dev_nodes, s->device, nb));
+                if (tb) PH_CHECK(s, hipMemcpyPeer(r->tree_dev_tris, r->device, s->tree_dev_tris, s->device, tb));
+            }
+            const int rc = upload_scene(r);
+            if (rc != PBRT_HIP_OK) { s->err = "device " + std::to_string(r->device) + ": " + r->err; return rc; }
+            drop_bulk(r);
+        } else {  // what set_camera_* / set_film / set_sampler change without touching the uploaded scene
+            r->cam = s->cam; r->film = s->film; r->sampler = s->sampler;
+            r->have_camera = s->have_camera; r->have_film = s->have_film; r->have_sampler = s->have_sampler; r->built = s->built;
+            r->count_traversal = false;
+        }
+    }
+    PH_CHECK(s, hipSetDevice(s->device));
+    m.replicas_current = true;
+    return PBRT_HIP_OK;
 }
 
 static int exchange(PbrtHipScene* s, const std::vector<PbrtHipScene*>& devs, const std::vector<size_t>& floats) {
@@ -148,9 +167,9 @@ int render_path_multi(PbrtHipScene* s, int max_depth, float rr_threshold, int li
     const int n = (int)devs.size();
     const int parts = tile_parts * n;   // device k renders the tiles t with t % parts == tile_part + tile_parts * k: the handle's share, dealt round-robin
     if (parts > PH_MAX_TILE_PARTS) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: tile_parts x devices exceeds " + std::to_string(PH_MAX_TILE_PARTS));
-    sync_replicas(s);
-    std::vector<size_t> floats((size_t)n);
     int rc;
+    if ((rc = sync_replicas(s))) return rc;
+    std::vector<size_t> floats((size_t)n);
     for (int k = 0; k < n; k++) {
         floats[k] = tile_buffer_floats_for(s, tile_size, tile_part + tile_parts * k, parts);
         PH_CHECK(s, hipSetDevice(devs[k]->device));
@@ -167,14 +186,15 @@ int render_path_multi(PbrtHipScene* s, int max_depth, float rr_threshold, int li
     auto work = [&](int k) {
         PbrtHipScene* d = devs[k];
         if (hipSetDevice(d->device) != hipSuccess) { rcs[k] = set_err(d, PBRT_HIP_ERR_DEVICE, "hipSetDevice failed"); return; }
-        rcs[k] = render_tiles(d, max_depth, rr_threshold, light_strategy, pixel_bounds, tile_size, tile_part + tile_parts * k, parts, tile_buffer_of(d).p, &stats[k]);
-        if (rcs[k] == PBRT_HIP_OK && k > 0) drop_bulk(d);
+        rcs[k] = ph_guard(d, "render (device worker)", [&]() -> int {
+            return render_tiles(d, max_depth, rr_threshold, light_strategy, pixel_bounds, tile_size, tile_part + tile_parts * k, parts, tile_buffer_of(d).p, &stats[k]);
+        });
     };
     {
-        std::vector<std::thread> th;
-        for (int k = 1; k < n; k++) th.emplace_back(work, k);
+        ThreadGroup th;   // (a thread the system cannot start runs its device's share on this one)
+        for (int k = 1; k < n; k++) th.run([&work, k]() { work(k); });
         work(0);
-        for (std::thread& t : th) t.join();
+        th.join();
     }
     for (int k = 0; k < n; k++)
         if (rcs[k] != PBRT_HIP_OK) { if (k) s->err = "device " + std::to_string(devs[k]->device) + ": " + devs[k]->err; m.replicas_current = false; return rcs[k]; }
@@ -206,9 +226,19 @@ int render_path_multi(PbrtHipScene* s, int max_depth, float rr_threshold, int li
             out_stats->shade_seconds = std::max(out_stats->shade_seconds, t.shade_seconds);
             out_stats->extend_launches = std::max(out_stats->extend_launches, t.extend_launches);
             out_stats->shadow_launches = std::max(out_stats->shadow_launches, t.shadow_launches);
-            // every device fills the voxels ITS paths touch: the count of one device is the largest any reports, the union is not tracked
-            out_stats->light_distributions_created = std::max(out_stats->light_distributions_created, t.light_distributions_created);
         }
+        // "Distributions created" (spatial.rs:17-21) of a one-device render = the voxels any path touched: here the UNION of the voxels the devices filled
+        if (out_stats->light_distributions_created || n > 1) {
+            std::vector<uint8_t> touched;
+            uint64_t count = 0; bool any = false;
+            for (int k = 0; k < n; k++) {
+                if (!stats[k].light_distributions_created) continue;
+                any = true;
+                if ((rc = spatial_voxels_touched(devs[k], touched, &count))) { if (k) s->err = devs[k]->err; return rc; }
+            }
+            if (any) out_stats->light_distributions_created = count;
+        }
+        PH_CHECK(s, hipSetDevice(s->device));
     }
     return PBRT_HIP_OK;
 }
@@ -220,6 +250,7 @@ using namespace phost;
 extern "C" {
 
 PbrtHipScene* pbrt_hip_scene_create_multi(const int* device_ordinals, int n_devices) {
+    return ph_guard_ptr<PbrtHipScene>("pbrt_hip_scene_create_multi", [&]() -> PbrtHipScene* {
     const int visible = pbrt_hip_device_count();
     std::vector<int> ord;
     if (!device_ordinals || n_devices <= 0) { for (int i = 0; i < visible; i++) ord.push_back(i); }
@@ -239,19 +270,23 @@ PbrtHipScene* pbrt_hip_scene_create_multi(const int* device_ordinals, int n_devi
     }
     (void)hipSetDevice(s->device);
     return s;
+    });
 }
 
 int pbrt_hip_scene_devices(const PbrtHipScene* s, int* out_ordinals, int capacity) {
+    return ph_guard(const_cast<PbrtHipScene*>(s), "pbrt_hip_scene_devices", [&]() -> int {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
     const int n = 1 + (s->multi ? (int)s->multi->replicas.size() : 0);
     if (out_ordinals)
         for (int k = 0; k < n && k < capacity; k++) out_ordinals[k] = k == 0 ? s->device : s->multi->replicas[(size_t)k - 1]->device;
     return n;
+    });
 }
 
 // Self-test of the RCCL binding on whatever devices the handle has: loads the library, builds the communicator (a one-rank communicator on a
 // single-device handle) and sends `n_floats` floats from every device to the first one, itself included; returns the number of wrong floats received.
 int pbrt_hip_selftest_rccl_gather(PbrtHipScene* s, uint32_t n_floats, uint64_t* out_wrong) {
+    return ph_guard(s, "pbrt_hip_selftest_rccl_gather", [&]() -> int {
     if (!s || !out_wrong || n_floats == 0) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "selftest_rccl_gather: bad argument");
     std::vector<PbrtHipScene*> devs{s};
     if (s->multi) devs.insert(devs.end(), s->multi->replicas.begin(), s->multi->replicas.end());
@@ -300,6 +335,7 @@ int pbrt_hip_selftest_rccl_gather(PbrtHipScene* s, uint32_t n_floats, uint64_t* 
     cleanup();
     *out_wrong = wrong;
     return PBRT_HIP_OK;
+    });
 }
 
 }  // extern "C"

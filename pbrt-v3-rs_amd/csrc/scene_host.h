@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/pbrt_hip.h"
 #include "bvh_build.h"
+#include "guard.h"
 #include "scene_types.h"
 #include <hip/hip_runtime.h>
 namespace ph { struct TravParams; }
@@ -127,6 +128,8 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
                  PbrtHipStats* out_stats);
 int merge_tiles(PbrtHipScene* s, int tile_size, int parts, const void* const* d_bufs, float* out_xyz, float* out_weight);
 DevBuf& tile_buffer_of(PbrtHipScene* s);  // the handle's own tile buffer (wavefront workspace)
+// ORs the voxels whose light distribution the context's last spatial render filled into `touched` (one byte per voxel, sized on first use); *count = voxels set so far
+int spatial_voxels_touched(PbrtHipScene* s, std::vector<uint8_t>& touched, uint64_t* count);
 // multi.hip
 int render_path_multi(PbrtHipScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size, int tile_part, int tile_parts,
                       float* out_xyz, float* out_weight, PbrtHipStats* out_stats);

@@ -171,6 +171,7 @@ int build_pyramid(PbrtHipScene* s, std::vector<float> img, size_t w, size_t h, i
 // two, box-filter the pyramid.  Texels are kept as three floats per texel while building.
 int pbrt_hip_add_mipmap(PbrtHipScene* s, int width, int height, const float* rgb, int as_float, float scale, int gamma, int filtering, int wrap,
                         float max_anisotropy, uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_mipmap", [&]() -> int {
     if (!s || !rgb) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: null argument");
     if (width <= 0 || height <= 0 || width > 32768 || height > 32768) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: resolution must be within 1..32768");
     if (filtering < 0 || filtering > 1 || wrap < 0 || wrap > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_mipmap: unknown filtering / wrap mode");
@@ -186,26 +187,34 @@ int pbrt_hip_add_mipmap(PbrtHipScene* s, int width, int height, const float* rgb
             } else for (int c = 0; c < 3; c++) o[c] = scale * (gamma ? inv_gamma_correct(px[c]) : px[c]);
         }
     return build_pyramid(s, std::move(img), w, h, filtering, wrap, as_float != 0, max_anisotropy, out_id);
+    });
 }
 int pbrt_hip_add_texture_constant(PbrtHipScene* s, const float v[3], uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_texture_constant", [&]() -> int {
     if (!s || !v) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_constant: null argument");
     PbrtHipScene::TextureHost t; TexOp op{}; op.op = PH_TOP_CONST; std::memcpy(op.c, v, 12); t.prog.push_back(op);
     return push_texture(s, std::move(t), out_id);
+    });
 }
 int pbrt_hip_add_texture_imagemap(PbrtHipScene* s, uint32_t mipmap, float su, float sv, float du, float dv, uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_texture_imagemap", [&]() -> int {
     if (!s || mipmap >= s->mipmaps.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_imagemap: unknown mipmap");
     PbrtHipScene::TextureHost t; TexOp op{}; op.op = PH_TOP_IMAGE; op.mip = mipmap; op.su = su; op.sv = sv; op.du = du; op.dv = dv; t.prog.push_back(op);
     return push_texture(s, std::move(t), out_id);
+    });
 }
 int pbrt_hip_add_texture_scale(PbrtHipScene* s, uint32_t t1, uint32_t t2, uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_texture_scale", [&]() -> int {
     if (!s || t1 >= s->textures.size() || t2 >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_scale: unknown texture");
     PbrtHipScene::TextureHost t; const PbrtHipScene::TextureHost &a = s->textures[t1], &b = s->textures[t2];
     t.prog = a.prog; t.prog.insert(t.prog.end(), b.prog.begin(), b.prog.end());
     TexOp op{}; op.op = PH_TOP_MUL; t.prog.push_back(op);
     t.stack_need = std::max(a.stack_need, 1 + b.stack_need);
     return push_texture(s, std::move(t), out_id);
+    });
 }
 int pbrt_hip_add_texture_mix(PbrtHipScene* s, uint32_t t1, uint32_t t2, uint32_t amount, uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_texture_mix", [&]() -> int {
     if (!s || t1 >= s->textures.size() || t2 >= s->textures.size() || amount >= s->textures.size())
         return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_mix: unknown texture");
     PbrtHipScene::TextureHost t; const PbrtHipScene::TextureHost &a = s->textures[t1], &b = s->textures[t2], &c = s->textures[amount];
@@ -213,36 +222,45 @@ int pbrt_hip_add_texture_mix(PbrtHipScene* s, uint32_t t1, uint32_t t2, uint32_t
     TexOp op{}; op.op = PH_TOP_MIX; t.prog.push_back(op);
     t.stack_need = std::max(a.stack_need, std::max(1 + b.stack_need, 2 + c.stack_need));
     return push_texture(s, std::move(t), out_id);
+    });
 }
 int pbrt_hip_add_texture_checkerboard(PbrtHipScene* s, uint32_t t1, uint32_t t2, float su, float sv, float du, float dv, int aa_mode, uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_texture_checkerboard", [&]() -> int {
     if (!s || t1 >= s->textures.size() || t2 >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_checkerboard: unknown texture");
     PbrtHipScene::TextureHost t; const PbrtHipScene::TextureHost &a = s->textures[t1], &b = s->textures[t2];
     t.prog = a.prog; t.prog.insert(t.prog.end(), b.prog.begin(), b.prog.end());
     TexOp op{}; op.op = PH_TOP_CHECKER; op.mip = aa_mode ? 1u : 0u; op.su = su; op.sv = sv; op.du = du; op.dv = dv; t.prog.push_back(op);
     t.stack_need = std::max(a.stack_need, 1 + b.stack_need);
     return push_texture(s, std::move(t), out_id);
+    });
 }
 int pbrt_hip_add_texture_uv(PbrtHipScene* s, float su, float sv, float du, float dv, uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_texture_uv", [&]() -> int {
     if (!s) return PBRT_HIP_ERR_INVALID_ARG;
     PbrtHipScene::TextureHost t; TexOp op{}; op.op = PH_TOP_UV; op.su = su; op.sv = sv; op.du = du; op.dv = dv; t.prog.push_back(op);
     return push_texture(s, std::move(t), out_id);
+    });
 }
 int pbrt_hip_add_texture_bilerp(PbrtHipScene* s, const float v00[3], const float v01[3], const float v10[3], const float v11[3], float su, float sv, float du, float dv,
                                 uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_texture_bilerp", [&]() -> int {
     if (!s || !v00 || !v01 || !v10 || !v11) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_bilerp: null argument");
     PbrtHipScene::TextureHost t;
     for (const float* v : {v00, v01, v10, v11}) { TexOp c{}; c.op = PH_TOP_CONST; std::memcpy(c.c, v, 12); t.prog.push_back(c); }
     TexOp op{}; op.op = PH_TOP_BILERP; op.su = su; op.sv = sv; op.du = du; op.dv = dv; t.prog.push_back(op);
     t.stack_need = 4;
     return push_texture(s, std::move(t), out_id);
+    });
 }
 int pbrt_hip_add_texture_dots(PbrtHipScene* s, uint32_t inside, uint32_t outside, float su, float sv, float du, float dv, uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_texture_dots", [&]() -> int {
     if (!s || inside >= s->textures.size() || outside >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_dots: unknown texture");
     PbrtHipScene::TextureHost t; const PbrtHipScene::TextureHost &a = s->textures[inside], &b = s->textures[outside];
     t.prog = a.prog; t.prog.insert(t.prog.end(), b.prog.begin(), b.prog.end());
     TexOp op{}; op.op = PH_TOP_DOTS; op.su = su; op.sv = sv; op.du = du; op.dv = dv; t.prog.push_back(op);
     t.stack_need = std::max(a.stack_need, 1 + b.stack_need);
     return push_texture(s, std::move(t), out_id);
+    });
 }
 namespace {
 int push_texture3d(PbrtHipScene* s, uint32_t opc, const float m[16], float omega, int octaves, float scale, float variation, const char* what, uint32_t* out_id,
@@ -256,20 +274,25 @@ int push_texture3d(PbrtHipScene* s, uint32_t opc, const float m[16], float omega
     return push_texture(s, std::move(t), out_id);
 }
 }  // namespace
-int pbrt_hip_add_texture_fbm(PbrtHipScene* s, const float m[16], float omega, int octaves, uint32_t* out_id) { return push_texture3d(s, PH_TOP_FBM, m, omega, octaves, 1.0f, 0.0f, "add_texture_fbm", out_id); }
-int pbrt_hip_add_texture_wrinkled(PbrtHipScene* s, const float m[16], float omega, int octaves, uint32_t* out_id) { return push_texture3d(s, PH_TOP_WRINKLED, m, omega, octaves, 1.0f, 0.0f, "add_texture_wrinkled", out_id); }
-int pbrt_hip_add_texture_windy(PbrtHipScene* s, const float m[16], uint32_t* out_id) { return push_texture3d(s, PH_TOP_WINDY, m, 0.5f, 0, 1.0f, 0.0f, "add_texture_windy", out_id); }
+int pbrt_hip_add_texture_fbm(PbrtHipScene* s, const float m[16], float omega, int octaves, uint32_t* out_id) { return ph_guard(s, "pbrt_hip_add_texture_fbm", [&]() -> int { return push_texture3d(s, PH_TOP_FBM, m, omega, octaves, 1.0f, 0.0f, "add_texture_fbm", out_id); }); }
+int pbrt_hip_add_texture_wrinkled(PbrtHipScene* s, const float m[16], float omega, int octaves, uint32_t* out_id) { return ph_guard(s, "pbrt_hip_add_texture_wrinkled", [&]() -> int { return push_texture3d(s, PH_TOP_WRINKLED, m, omega, octaves, 1.0f, 0.0f, "add_texture_wrinkled", out_id); }); }
+int pbrt_hip_add_texture_windy(PbrtHipScene* s, const float m[16], uint32_t* out_id) { return ph_guard(s, "pbrt_hip_add_texture_windy", [&]() -> int { return push_texture3d(s, PH_TOP_WINDY, m, 0.5f, 0, 1.0f, 0.0f, "add_texture_windy", out_id); }); }
 int pbrt_hip_add_texture_marble(PbrtHipScene* s, const float m[16], float omega, int octaves, float scale, float variation, uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_texture_marble", [&]() -> int {
     return push_texture3d(s, PH_TOP_MARBLE, m, omega, octaves, scale, variation, "add_texture_marble", out_id);
+    });
 }
 int pbrt_hip_add_texture_checkerboard3d(PbrtHipScene* s, uint32_t t1, uint32_t t2, const float m[16], uint32_t* out_id) {
+    return ph_guard(s, "pbrt_hip_add_texture_checkerboard3d", [&]() -> int {
     if (!s || t1 >= s->textures.size() || t2 >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_texture_checkerboard3d: unknown texture");
     const PbrtHipScene::TextureHost a = s->textures[t1], b = s->textures[t2];
     return push_texture3d(s, PH_TOP_CHECKER3D, m, 0.0f, 0, 1.0f, 0.0f, "add_texture_checkerboard3d", out_id, &a, &b);
+    });
 }
 // TextureMapping2D other than uv for a 2D texture (imagemap, checkerboard, uv, bilerp, dots).  Programs are copied into their parents when those
 // are created, so the mapping has to be set before the texture is used as an operand.
 int pbrt_hip_set_texture_mapping(PbrtHipScene* s, uint32_t texture, int kind, const float* params) {
+    return ph_guard(s, "pbrt_hip_set_texture_mapping", [&]() -> int {
     if (!s || texture >= s->textures.size() || !params) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_texture_mapping: bad argument");
     if (kind < 1 || kind > 3) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_texture_mapping: kind must be 1 spherical, 2 cylindrical or 3 planar");
     TexOp& op = s->textures[texture].prog.back();
@@ -280,11 +303,13 @@ int pbrt_hip_set_texture_mapping(PbrtHipScene* s, uint32_t texture, int kind, co
     else std::memcpy(op.m, params, 64);
     s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 // Replaces a material's constant colour parameter by a texture evaluated at every hit.  The material must have been created with a non-black
 // constant for that parameter (so that its lobe exists); which lobes a hit finally gets follows the reference's `is_black` tests on the
 // texture's value at that hit.
 int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param, uint32_t texture) {
+    return ph_guard(s, "pbrt_hip_set_material_texture", [&]() -> int {
     if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: unknown material or texture");
     if (param < 0 || param > 7) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: param must be PBRT_HIP_PARAM_KD / KS / KR / KT / OPACITY / AMOUNT / ETA / K");
     if (param >= PBRT_HIP_PARAM_OPACITY) {   // parameters that are not one lobe's colour
@@ -332,10 +357,12 @@ int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param,
     s->textured_materials = true;
     s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 // Replaces a scalar parameter by a float texture evaluated at every hit: MatteMaterial's sigma (matte.rs:64-70) or the Trowbridge-Reitz roughness of plastic / uber /
 // substrate / metal (remapped per hit when the material was created with remap_roughness).  fparam: 0 sigma, 1 uroughness, 2 vroughness (plastic's single `roughness`: set both).
 int pbrt_hip_set_material_float_texture(PbrtHipScene* s, uint32_t material, int fparam, uint32_t texture) {
+    return ph_guard(s, "pbrt_hip_set_material_float_texture", [&]() -> int {
     if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_float_texture: unknown material or texture");
     if (fparam < 0 || fparam > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_float_texture: fparam must be 0 sigma, 1 uroughness or 2 vroughness");
     MaterialRec& m = s->materials[material];
@@ -359,17 +386,21 @@ int pbrt_hip_set_material_float_texture(PbrtHipScene* s, uint32_t material, int 
     s->textured_materials = true;
     s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 // Material::bump's displacement texture (core/src/material.rs:62-101; the `bumpmap` parameter every material takes)
 int pbrt_hip_set_material_bump(PbrtHipScene* s, uint32_t material, uint32_t texture) {
+    return ph_guard(s, "pbrt_hip_set_material_bump", [&]() -> int {
     if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_bump: unknown material or texture");
     if (s->materials[material].none) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_bump: Material \"none\" has no BSDF to bump");
     s->materials[material].bump_tex1 = texture + 1u;
     s->textured_materials = true; s->bump_materials = true;
     s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_add_material_matte_tex(PbrtHipScene* s, uint32_t kd_tex, float sigma_deg, uint32_t* out_id) {  // matte.rs:47-76, Kd a texture
+    return ph_guard(s, "pbrt_hip_add_material_matte_tex", [&]() -> int {
     if (!s || kd_tex >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_matte_tex: unknown texture");
     const float one[3] = {1.0f, 1.0f, 1.0f};
     uint32_t id = 0;
@@ -377,6 +408,7 @@ int pbrt_hip_add_material_matte_tex(PbrtHipScene* s, uint32_t kd_tex, float sigm
     if (rc == PBRT_HIP_OK) rc = pbrt_hip_set_material_texture(s, id, 0, kd_tex);
     if (rc == PBRT_HIP_OK && out_id) *out_id = id;
     return rc;
+    });
 }
 // ---- texture probes (test aids: the device's texture evaluation on explicit inputs, and the pyramid the host built) ----------------
 namespace ph {
@@ -391,6 +423,7 @@ __global__ void texture_eval_kernel(DeviceScene sc, uint32_t tex, uint32_t n, co
 }
 }  // namespace ph
 int pbrt_hip_texture_eval_batch(PbrtHipScene* s, uint32_t tex, uint64_t n, const float* uv_and_derivatives, float* out_rgb) {
+    return ph_guard(s, "pbrt_hip_texture_eval_batch", [&]() -> int {
     if (!s || (n && (!uv_and_derivatives || !out_rgb))) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "texture_eval_batch: null argument");
     if (tex >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "texture_eval_batch: unknown texture");
     if (n == 0) return PBRT_HIP_OK;
@@ -407,25 +440,31 @@ int pbrt_hip_texture_eval_batch(PbrtHipScene* s, uint32_t tex, uint64_t n, const
     PH_CHECK(s, hipMemcpyAsync(out_rgb, s->d_out_tmp.p, n * 12, hipMemcpyDeviceToHost, s->stream));
     PH_CHECK(s, hipStreamSynchronize(s->stream));
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_mipmap_levels(PbrtHipScene* s, uint32_t mip, int* out_levels, int* out_wh) {
+    return ph_guard(s, "pbrt_hip_mipmap_levels", [&]() -> int {
     if (!s || !out_levels || !out_wh || mip >= s->mipmaps.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "mipmap_levels: bad argument");
     const MipRec& m = s->mipmaps[mip];
     *out_levels = (int)m.n_levels;
     for (uint32_t i = 0; i < m.n_levels; i++) { out_wh[2 * i] = (int)m.level_w[i]; out_wh[2 * i + 1] = (int)m.level_h[i]; }
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_mipmap_level_texels(PbrtHipScene* s, uint32_t mip, int level, float* out_rgb) {
+    return ph_guard(s, "pbrt_hip_mipmap_level_texels", [&]() -> int {
     if (!s || !out_rgb || mip >= s->mipmaps.size() || level < 0 || (uint32_t)level >= s->mipmaps[mip].n_levels)
         return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "mipmap_level_texels: bad argument");
     const MipRec& m = s->mipmaps[mip];
     const size_t n = (size_t)m.level_w[level] * m.level_h[level];
     for (size_t i = 0; i < n; i++) { const Texel& t = s->texels[m.level_off[level] + i]; out_rgb[3 * i] = t.r; out_rgb[3 * i + 1] = t.g; out_rgb[3 * i + 2] = t.b; }
     return PBRT_HIP_OK;
+    });
 }
 // `alpha` / `shadowalpha` float textures of the mesh added last (TriangleMesh::alpha_mask / shadow_alpha_mask, shapes/src/triangle.rs:291-312); 0xFFFFFFFF keeps the
 // constant given to add_mesh.  Candidate hits are then tested in the traversal kernels' ALPHA variants.
 int pbrt_hip_set_last_mesh_alpha_textures(PbrtHipScene* s, uint32_t alpha_tex, uint32_t shadow_alpha_tex) {
+    return ph_guard(s, "pbrt_hip_set_last_mesh_alpha_textures", [&]() -> int {
     if (!s || s->meshes.empty()) return set_err(s, PBRT_HIP_ERR_STATE, "set_last_mesh_alpha_textures: no mesh has been added");
     if ((alpha_tex != 0xFFFFFFFFu && alpha_tex >= s->textures.size()) || (shadow_alpha_tex != 0xFFFFFFFFu && shadow_alpha_tex >= s->textures.size()))
         return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_last_mesh_alpha_textures: unknown texture");
@@ -441,11 +480,13 @@ int pbrt_hip_set_last_mesh_alpha_textures(PbrtHipScene* s, uint32_t alpha_tex, u
     if (m.alpha_tex1 || m.shadow_alpha_tex1) s->alpha_textures = true;
     s->built = false; s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 
 // InfiniteAreaLight::new with a texmap (lights/src/infinite.rs:52-100): texels = read_image(texmap) * L — no y flip on this path —, MIPMap (EWA, repeat, 8),
 // compute_scalar_image (:326-369) over 2w x 2h and its Distribution2D.
 int pbrt_hip_add_light_infinite_map(PbrtHipScene* s, const float L[3], int width, int height, const float* rgb, const float l2w[16], const float w2l[16]) {
+    return ph_guard(s, "pbrt_hip_add_light_infinite_map", [&]() -> int {
     if (!s || !L || !rgb || !l2w || !w2l) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_infinite_map: null argument");
     if (width <= 0 || height <= 0 || width > 16384 || height > 16384) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_infinite_map: resolution must be within 1..16384");
     const size_t lights_before = s->lights.size();
@@ -487,6 +528,7 @@ int pbrt_hip_add_light_infinite_map(PbrtHipScene* s, const float L[3], int width
     pool.push_back(mi);
     s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 
 namespace {
@@ -513,6 +555,7 @@ int add_image_point_light(PbrtHipScene* s, int type, const float I[3], const flo
 }
 }  // namespace
 int pbrt_hip_add_light_projection(PbrtHipScene* s, const float I[3], const float l2w[16], const float w2l[16], float fov_deg, int width, int height, const float* rgb) {  // projection.rs:55-127
+    return ph_guard(s, "pbrt_hip_add_light_projection", [&]() -> int {
     if (!s || !I || !l2w || !w2l) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_projection: null argument");
     LightRec l;
     const int rc = add_image_point_light(s, PH_L_PROJECTION, I, l2w, w2l, width, height, rgb, &l);
@@ -520,14 +563,17 @@ int pbrt_hip_add_light_projection(PbrtHipScene* s, const float I[3], const float
     projection_light_setup(fov_deg, rgb ? (float)width / (float)height : 1.0f, l.proj, l.screen, &l.cos_total_width);
     s->lights.push_back(l); s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 int pbrt_hip_add_light_goniometric(PbrtHipScene* s, const float I[3], const float l2w[16], const float w2l[16], int width, int height, const float* rgb) {  // goniometric.rs:34-80
+    return ph_guard(s, "pbrt_hip_add_light_goniometric", [&]() -> int {
     if (!s || !I || !l2w || !w2l) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_light_goniometric: null argument");
     LightRec l;
     const int rc = add_image_point_light(s, PH_L_GONIO, I, l2w, w2l, width, height, rgb, &l);
     if (rc) return rc;
     s->lights.push_back(l); s->uploaded = false;
     return PBRT_HIP_OK;
+    });
 }
 
 }  // extern "C"

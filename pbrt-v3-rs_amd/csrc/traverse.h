@@ -241,6 +241,12 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
 #ifndef PH_BATCH
 #define PH_BATCH 64
 #endif
+#ifndef PH_INST_PRETEST
+#define PH_INST_PRETEST 1    // A/B switches of the instance entry (scripts/build_variant.sh): the proven-miss pre-test ...
+#endif
+#ifndef PH_INST_LAZY_TRI
+#define PH_INST_LAZY_TRI 1   // ... and the triangle half of ray_setup postponed to the first triangle met inside the object
+#endif
 #ifndef PH_LEAF_STEPS
 #define PH_LEAF_STEPS 1   // triangles a lane may test per leaf step (a leaf holds up to max_prims_in_node of them)
 #endif
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                             // TransformedPrimitive::intersect / intersect_p (transformed_primitive.rs:51-73)
                             const InstRec& I = sc.instances[__float_as_uint(a.w)];
                             const RayIn in = xf_ray(I.w2i, r, 0.0f);
-                            if (!COUNT && !(I.flags & PH_INST_SINGLE) && box_surely_missed(in, I.lo, I.hi)) {
+                            if (PH_INST_PRETEST && !COUNT && !(I.flags & PH_INST_SINGLE) && box_surely_missed(in, I.lo, I.hi)) {
                                 // proven: the instance-space ray misses the object's bound, intersect returns None and the ray is as it was.  Decided with three hardware
                                 // reciprocals, before the lane parks its world ray and pays the set-up's IEEE divisions (box_surely_missed)
                                 cur = last ? pop() : cur + 1u;
@@ -444,8 +450,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                             inst_save[12][tid] = __uint_as_float((uint32_t)(r.nx | (r.ny << 1) | (r.nz << 2) | (r.kx << 3) | (r.ky << 5) | (r.kz << 7)));
                             // the box-side half of the set-up only: the triangle test's permutation and shear (three more IEEE divisions) wait until the ray meets a triangle
                             // inside the object (tri_ready) — most entries end at the object's root box or a few nodes below it
-                            ray_setup_box(r, in);
-                            tri_ready = false;
+                            if (PH_INST_LAZY_TRI) { ray_setup_box(r, in); tri_ready = false; } else ray_setup(r, in);
                             cur = PH_INVALID_REF;
                             if (I.flags & PH_INST_SINGLE) cur = I.root_ref;  // the lone primitive itself, no aggregate
                             else {

@@ -737,6 +737,7 @@ struct Wavefront {
     DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_recL, d_recpy, d_tilebuf, d_xyz, d_w;
     DevBuf d_vox_slot, d_sp_pool, d_sp_list, d_sp_ctr, d_sp_halton;  // SpatialLightDistribution tables (spatial.h)
     DevBuf d_order, d_sort_bins, d_heads, d_keys_cl, d_keys_sh;  // ray binning between rounds (raysort.h), per-XCD queue heads
+    size_t n_vox = 0;   // voxels of the last spatial render's table (d_vox_slot)
     std::vector<hipEvent_t> events;
 };
 
@@ -862,6 +863,7 @@ static int setup_spatial(PbrtHipScene* s, ph::SpatialRec& sr) {
     sr.capacity = (uint32_t)cap;
     int rc;
     if ((rc = ensure_buf(s, w.d_vox_slot, nvox * 4))) return rc;
+    w.n_vox = nvox;
     if ((rc = ensure_buf(s, w.d_sp_list, cap * 4))) return rc;
     if ((rc = ensure_buf(s, w.d_sp_ctr, 64))) return rc;
     if ((rc = ensure_buf(s, w.d_sp_pool, cap * slot_bytes))) return rc;
@@ -1140,6 +1142,17 @@ int merge_tiles(PbrtHipScene* s, int tile_size, int parts, const void* const* d_
     return PBRT_HIP_OK;
 }
 
+int spatial_voxels_touched(PbrtHipScene* s, std::vector<uint8_t>& touched, uint64_t* count) {
+    if (!s->wf || !s->wf->d_vox_slot.p || !s->wf->n_vox) return PBRT_HIP_OK;
+    PH_CHECK(s, hipSetDevice(s->device));
+    std::vector<int32_t> slot(s->wf->n_vox);
+    PH_CHECK(s, hipMemcpy(slot.data(), s->wf->d_vox_slot.p, slot.size() * 4, hipMemcpyDeviceToHost));
+    if (touched.size() < slot.size()) touched.resize(slot.size(), 0);
+    for (size_t v = 0; v < slot.size(); v++)
+        if (slot[v] >= 0 && !touched[v]) { touched[v] = 1; (*count)++; }
+    return PBRT_HIP_OK;
+}
+
 DevBuf& tile_buffer_of(PbrtHipScene* s) {
     if (!s->wf) s->wf = new Wavefront();
     return s->wf->d_tilebuf;
@@ -1152,31 +1165,38 @@ using namespace phost;
 extern "C" {
 
 int pbrt_hip_tile_buffer_floats(PbrtHipScene* s, int tile_size, int tile_part, int tile_parts, uint64_t* out_floats) {
+    return ph_guard(s, "pbrt_hip_tile_buffer_floats", [&]() -> int {
     if (!s || !out_floats) return PBRT_HIP_ERR_INVALID_ARG;
     if (!s->have_film) return set_err(s, PBRT_HIP_ERR_STATE, "tile_buffer_floats: set_film first");
     if (tile_size <= 0 || tile_parts <= 0 || tile_part < 0 || tile_part >= tile_parts) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "tile_buffer_floats: bad partition");
     *out_floats = tile_buffer_floats_for(s, tile_size, tile_part, tile_parts);
     return PBRT_HIP_OK;
+    });
 }
 
 int pbrt_hip_render_path_tiles_device(PbrtHipScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size,
                                       int tile_part, int tile_parts, void* d_tile_buffer, PbrtHipStats* out_stats) {
+    return ph_guard(s, "pbrt_hip_render_path_tiles_device", [&]() -> int {
     int rc = check_render_args(s, max_depth, light_strategy, pixel_bounds, tile_size, tile_part, tile_parts);
     if (rc) return rc;
     if (!d_tile_buffer) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: null tile buffer");
     return render_tiles(s, max_depth, rr_threshold, light_strategy, pixel_bounds, tile_size, tile_part, tile_parts, d_tile_buffer, out_stats);
+    });
 }
 
 int pbrt_hip_merge_tiles_device(PbrtHipScene* s, int tile_size, int tile_parts, const void* const* d_tile_buffers, float* out_xyz, float* out_weight) {
+    return ph_guard(s, "pbrt_hip_merge_tiles_device", [&]() -> int {
     if (!s || !d_tile_buffers || !out_xyz || !out_weight) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "merge: null argument");
     if (!s->have_film) return set_err(s, PBRT_HIP_ERR_STATE, "merge: set_film first");
     if (tile_size <= 0 || tile_parts <= 0 || tile_parts > PH_MAX_TILE_PARTS) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "merge: bad partition");
     PH_CHECK(s, hipSetDevice(s->device));
     return merge_tiles(s, tile_size, tile_parts, d_tile_buffers, out_xyz, out_weight);
+    });
 }
 
 int pbrt_hip_render_path(PbrtHipScene* s, int max_depth, float rr_threshold, int light_strategy, const int pixel_bounds[4], int tile_size, int tile_part,
                          int tile_parts, float* out_xyz, float* out_weight, PbrtHipStats* out_stats) {
+    return ph_guard(s, "pbrt_hip_render_path", [&]() -> int {
     int rc = check_render_args(s, max_depth, light_strategy, pixel_bounds, tile_size, tile_part, tile_parts);
     if (rc) return rc;
     if (!out_xyz || !out_weight) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "render: null output");
@@ -1205,9 +1225,11 @@ int pbrt_hip_render_path(PbrtHipScene* s, int max_depth, float rr_threshold, int
     rc = merge_tiles(s, tile_size, tile_parts, bufs.data(), out_xyz, out_weight);
     for (auto& z : zeros) if (z.p) (void)hipFree(z.p);
     return rc;
+    });
 }
 
 int pbrt_hip_generate_camera_rays(PbrtHipScene* s, const int pb[4], uint32_t sample_index, PbrtHipRay* out_rays, float* out_pfilm) {
+    return ph_guard(s, "pbrt_hip_generate_camera_rays", [&]() -> int {
     if (!s || !pb || !out_rays) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "generate_camera_rays: null argument");
     if (!s->have_camera || !s->have_sampler) return set_err(s, PBRT_HIP_ERR_STATE, "generate_camera_rays: camera and sampler must be set");
     if (s->sampler.kind == 1 && s->sobol32.empty()) return set_err(s, PBRT_HIP_ERR_STATE, "generate_camera_rays: sobol tables not set");
@@ -1227,6 +1249,7 @@ int pbrt_hip_generate_camera_rays(PbrtHipScene* s, const int pb[4], uint32_t sam
     if (out_pfilm) PH_CHECK(s, hipMemcpyAsync(out_pfilm, s->d_out_tmp.p, n * 8, hipMemcpyDeviceToHost, s->stream));
     PH_CHECK(s, hipStreamSynchronize(s->stream));
     return PBRT_HIP_OK;
+    });
 }
 
 }  // extern "C"

@@ -17,7 +17,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libpbrt_hip.so")
+LIB_PATH = os.environ.get("PBRT_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libpbrt_hip.so")   # PBRT_HIP_LIB: another build of the library (same-box A/B, scripts/build_variant.sh)
 
 OK = 0
 ERR_INVALID_ARG, ERR_STATE, ERR_DEVICE, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = -1, -2, -3, -4, -5, -6

@@ -210,3 +210,35 @@ def test_python_ply_reader_reads_what_the_front_end_reads(tmp_path):
         for f in ([2, 3, 4], [0, 1, 4]): fh.write(struct.pack("<B3i", 3, *f))
     gp, gi = pbrt_hip.read_ply(str(tmp_path / "t.ply"))
     assert np.array_equal(gi, np.array([2, 3, 4, 0, 1, 4], np.uint32))
+
+
+def test_no_cpp_exception_crosses_the_c_abi():
+    """SURVEY §8b Errors row: every extern "C" body runs inside a guard (csrc/guard.h).  In a fresh child whose address space is capped (RLIMIT_AS), the host BVH builder —
+    std::vector and std::thread inside an extern "C" call — runs out of memory on a 3 M-triangle build: the call RETURNS PBRT_HIP_ERR_OOM (-6) with a message instead of letting
+    std::bad_alloc unwind through the C frame (undefined behaviour for a Rust caller; an uncaught one aborts the process), and a small build still works afterwards."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import ctypes as C, resource, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        import pbrt_hip
+        b = pbrt_hip.default_binding(); lib = b.lib
+        n = 3_000_000
+        P = np.random.default_rng(1).uniform(-1, 1, (3 * n, 3)).astype(np.float32); idx = np.arange(3 * n, dtype=np.uint32)
+        order = np.zeros(n, np.uint32); last = np.zeros(n, np.uint32); nodes = np.zeros((n, 16), np.uint32); info = np.zeros(5, np.uint64); rb = np.zeros(6, np.float32)
+        lib.pbrt_hip_host_build_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+        lib.pbrt_hip_host_build_bvh.restype = C.c_int
+        with open("/proc/self/statm") as f: vm = int(f.read().split()[0]) * resource.getpagesize()
+        soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+        resource.setrlimit(resource.RLIMIT_AS, (vm + (96 << 20), hard))     # the build needs several hundred MB more than that
+        rc = lib.pbrt_hip_host_build_bvh(P.ctypes.data, idx.ctypes.data, n, 0, 4, 4, order.ctypes.data, last.ctypes.data, nodes.ctypes.data, info.ctypes.data, rb.ctypes.data)
+        msg = b.fn("last_error")(None)
+        resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+        rc2 = lib.pbrt_hip_host_build_bvh(P.ctypes.data, idx.ctypes.data, 1000, 0, 4, 1, order.ctypes.data, last.ctypes.data, nodes.ctypes.data, info.ctypes.data, rb.ctypes.data)
+        print("RC", rc, rc2, (msg or b"").decode())
+    ''') % os.path.join(ROOT, "pbrt-v3-rs_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])     # no abort, no terminate
+    line = [l for l in r.stdout.splitlines() if l.startswith("RC")][-1].split(" ", 3)
+    assert int(line[1]) == -6 and int(line[2]) == 0, r.stdout
+    assert "out of host memory" in line[3] and "pbrt_hip_host_build_bvh" in line[3]
