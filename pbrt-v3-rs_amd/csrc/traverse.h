@@ -62,21 +62,6 @@ struct RayState {
     float sx, sy, sz;       // triangle.rs:467-469
 };
 
-// what the box tests need of a ray (bvh/mod.rs:176-177) ...
-PH_DEV void ray_setup_box(RayState& r, const RayIn& in) {
-    r.ox = in.ox; r.oy = in.oy; r.oz = in.oz; r.dx = in.dx; r.dy = in.dy; r.dz = in.dz; r.t_max = in.t_max;
-    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-    r.nx = r.ix < 0.0f ? 1 : 0; r.ny = r.iy < 0.0f ? 1 : 0; r.nz = r.iz < 0.0f ? 1 : 0;
-}
-// ... and what the triangle test derives from its direction (triangle.rs:457-469)
-PH_DEV void ray_setup_tri(RayState& r) {
-    f3 d = mk3(r.dx, r.dy, r.dz);
-    r.kz = max_dimension(vabs(d));
-    r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0;
-    r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0;
-    f3 dp = permute(d, r.kx, r.ky, r.kz);
-    r.sx = -dp.x / dp.z; r.sy = -dp.y / dp.z; r.sz = 1.0f / dp.z;
-}
 PH_DEV void ray_setup(RayState& r, const RayIn& in) {
     r.ox = in.ox; r.oy = in.oy; r.oz = in.oz; r.dx = in.dx; r.dy = in.dy; r.dz = in.dz; r.t_max = in.t_max;
     r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
@@ -129,27 +114,6 @@ PH_DEV float vmin3(float a, float b, float c) {
 #else
     return a < b ? (a < c ? a : c) : (b < c ? b : c);
 #endif
-}
-
-// A cheap PROOF that a ray misses a box, for the instance entry of the INST kernels: the slab distances with hardware reciprocals (v_rcp_f32: 1 ulp) instead of the three
-// IEEE divisions of ray_setup, every entry distance lowered and every exit distance raised by far more than the two computations can differ (1 / d: 1.5 ulp apart;
-// the products and the 1 + 2 gamma_3 scale: half an ulp each -> below 4e-7 relative; 2e-6 is taken, plus 1e-30 absolute for results near the denormal range).
-// true = box_test(..) && t_min < t_max is CERTAINLY false for the exact arithmetic, so TransformedPrimitive::intersect returns None and changes nothing
-// (transformed_primitive.rs:51-56); false = no statement (the exact test decides).  Directions with a component outside [1e-30, 1e30] — zero included — are never judged here.
-PH_DEV bool box_surely_missed(const RayIn& in, const float* lo, const float* hi) {
-    const float ax = pabs(in.dx), ay = pabs(in.dy), az = pabs(in.dz);
-    if (!(ax > 1e-30f && ax < 1e30f && ay > 1e-30f && ay < 1e30f && az > 1e-30f && az < 1e30f)) return false;
-    const float rx = __builtin_amdgcn_rcpf(in.dx), ry = __builtin_amdgcn_rcpf(in.dy), rz = __builtin_amdgcn_rcpf(in.dz);
-    const float nx_ = (in.dx < 0.0f ? hi[0] : lo[0]) - in.ox, fx_ = (in.dx < 0.0f ? lo[0] : hi[0]) - in.ox;
-    const float ny_ = (in.dy < 0.0f ? hi[1] : lo[1]) - in.oy, fy_ = (in.dy < 0.0f ? lo[1] : hi[1]) - in.oy;
-    const float nz_ = (in.dz < 0.0f ? hi[2] : lo[2]) - in.oz, fz_ = (in.dz < 0.0f ? lo[2] : hi[2]) - in.oz;
-    const float s = 2e-6f, a = 1e-30f;
-    float tnx = nx_ * rx, tny = ny_ * ry, tnz = nz_ * rz;
-    float tfx = fx_ * rx * kBoxScale, tfy = fy_ * ry * kBoxScale, tfz = fz_ * rz;
-    tnx = tnx - pabs(tnx) * s - a; tny = tny - pabs(tny) * s - a; tnz = tnz - pabs(tnz) * s - a;
-    tfx = tfx + pabs(tfx) * s + a; tfy = tfy + pabs(tfy) * s + a; tfz = tfz + pabs(tfz) * s + a;
-    const float tn = vmax3(tnx, tny, tnz), tf = vmin3(tfx, tfy, tfz);   // (a NaN operand is ignored: fewer proofs, never a wrong one)
-    return (tn > tf) | (tf < 0.0f) | (tn > in.t_max);
 }
 
 // Bounds3::intersect_p_inv without its final `t_min < ray.t_max` clause; returns t_min via reference.
@@ -241,12 +205,6 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
 #ifndef PH_BATCH
 #define PH_BATCH 64
 #endif
-#ifndef PH_INST_PRETEST
-#define PH_INST_PRETEST 1    // A/B switches of the instance entry (scripts/build_variant.sh): the proven-miss pre-test ...
-#endif
-#ifndef PH_INST_LAZY_TRI
-#define PH_INST_LAZY_TRI 1   // ... and the triangle half of ray_setup postponed to the first triangle met inside the object
-#endif
 #ifndef PH_LEAF_STEPS
 #define PH_LEAF_STEPS 1   // triangles a lane may test per leaf step (a leaf holds up to max_prims_in_node of them)
 #endif
@@ -301,7 +259,6 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
     float world_tmax = 0.0f;              // the scene-level ray's t_max at entry
     uint32_t cont_ref = PH_INVALID_REF;   // next record of the scene-level leaf, or PH_INVALID_REF = pop
     bool inst_hit = false;                // a primitive of the current instance was accepted
-    bool tri_ready = true;                // r.kx .. r.sz belong to the ray the lane holds (false between an instance entry and the first triangle met inside)
     uint32_t hit_inst = 0;
 
     auto push = [&](uint32_t ref, float tmin) {
@@ -365,7 +322,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = a.w; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
                         ray_setup(r, in);
                         has_ray = true; sp = 0; hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hb0 = hb1 = hb2 = 0.0f; occluded = false;
-                        if (INST) { in_inst = 0; hit_inst = 0; tri_ready = true; }
+                        if (INST) { in_inst = 0; hit_inst = 0; }
                         // root: the reference tests nodes[0].bounds first (bvh/mod.rs:189-190)
                         cur = PH_INVALID_REF;
                         if (COUNT && ah) c_visits++;
@@ -437,20 +394,16 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         if (INST && (flags & PH_TRI_INSTANCE)) {
                             // TransformedPrimitive::intersect / intersect_p (transformed_primitive.rs:51-73)
                             const InstRec& I = sc.instances[__float_as_uint(a.w)];
-                            const RayIn in = xf_ray(I.w2i, r, 0.0f);
-                            if (PH_INST_PRETEST && !COUNT && !(I.flags & PH_INST_SINGLE) && box_surely_missed(in, I.lo, I.hi)) {
-                                // proven: the instance-space ray misses the object's bound, intersect returns None and the ray is as it was.  Decided with three hardware
-                                // reciprocals, before the lane parks its world ray and pays the set-up's IEEE divisions (box_surely_missed)
-                                cur = last ? pop() : cur + 1u;
-                            } else {
                             world_tmax = r.t_max; cont_ref = last ? PH_INVALID_REF : cur + 1u;
                             in_inst = __float_as_uint(a.w) + 1u; inst_sp = sp; inst_hit = false;
                             inst_save[0][tid] = r.ox; inst_save[1][tid] = r.oy; inst_save[2][tid] = r.oz; inst_save[3][tid] = r.dx; inst_save[4][tid] = r.dy; inst_save[5][tid] = r.dz;
                             inst_save[6][tid] = r.ix; inst_save[7][tid] = r.iy; inst_save[8][tid] = r.iz; inst_save[9][tid] = r.sx; inst_save[10][tid] = r.sy; inst_save[11][tid] = r.sz;
                             inst_save[12][tid] = __uint_as_float((uint32_t)(r.nx | (r.ny << 1) | (r.nz << 2) | (r.kx << 3) | (r.ky << 5) | (r.kz << 7)));
-                            // the box-side half of the set-up only: the triangle test's permutation and shear (three more IEEE divisions) wait until the ray meets a triangle
-                            // inside the object (tri_ready) — most entries end at the object's root box or a few nodes below it
-                            if (PH_INST_LAZY_TRI) { ray_setup_box(r, in); tri_ready = false; } else ray_setup(r, in);
+                            // (round 3, measured and not kept: proving a miss of the object's bound with three hardware reciprocals before paying this set-up — the proof rarely
+                            //  succeeds once the instance's world bound has been passed, 86.6 -> 93.2 ms on 1 000 x 10 k instances — and postponing the triangle half of ray_setup
+                            //  to the first triangle met inside: no difference, gpurun r03g)
+                            const RayIn in = xf_ray(I.w2i, r, 0.0f);
+                            ray_setup(r, in);
                             cur = PH_INVALID_REF;
                             if (I.flags & PH_INST_SINGLE) cur = I.root_ref;  // the lone primitive itself, no aggregate
                             else {
@@ -459,10 +412,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                                                         r.nz ? I.hi[2] : I.lo[2], r.nz ? I.lo[2] : I.hi[2], tmin);
                                 if (h && tmin < r.t_max) cur = I.root_ref;
                             }
-                            }
                         } else {
                         if (COUNT) c_tris[(MIXED && ah) ? 1 : 0]++;
-                        if (INST && !tri_ready) { ray_setup_tri(r); tri_ready = true; }
                         if (tri_test(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), t, b0, b1, b2)) {
                             // post-t rejections: degenerate triangle (triangle.rs:567-570 / 862-866), alpha == 0 (:603 / :886-893)
                             const uint32_t reject = ah ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
@@ -496,7 +447,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                 const uint32_t pk = __float_as_uint(inst_save[12][tid]);
                 r.nx = (int)(pk & 1u); r.ny = (int)((pk >> 1) & 1u); r.nz = (int)((pk >> 2) & 1u); r.kx = (int)((pk >> 3) & 3u); r.ky = (int)((pk >> 5) & 3u); r.kz = (int)((pk >> 7) & 3u);
                 r.t_max = t_new;
-                in_inst = 0; tri_ready = true;
+                in_inst = 0;
                 cur = (cont_ref != PH_INVALID_REF) ? cont_ref : pop();
             } else in_inst = 0;
         }

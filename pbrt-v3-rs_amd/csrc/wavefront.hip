@@ -56,8 +56,11 @@ struct WfParams {
     RayIn* rays_cl[2]; HitOut* hits_cl; RayIn* rays_sh; uint8_t* occ; uint32_t* live[2];
     IterCounters* ctr;
     DevStats* stats;
-    // path state
-    float4* s_L; float4* s_beta; float4* s_A; float4* s_f2; float4* s_bold; uint4* s_idx;
+    // path state, in QUEUE order and double-buffered: round `it` reads buffer it & 1 at the path's position in that round's live list (streaming reads) and writes the
+    // survivors' state to the other buffer at their position in the next round's list.  s_idx / s_L / s_beta travel with the compacted list; the data of a vertex's
+    // pending light sample (s_A, s_f2, s_bold — known in the middle of the vertex code, before the survivor's slot is) is written at the WRITING thread's own position
+    // and found again through s_prev.  (Rounds 1-2 addressed all of this by path id: scattered 16-byte records from six 2 GB arrays.)
+    float4* s_L[2]; float4* s_beta[2]; float4* s_A[2]; float4* s_f2[2]; float4* s_bold[2]; uint4* s_idx[2]; uint32_t* s_prev[2];
     // per-sample records of the whole render: {L.rgb, p_film.x} {p_film.y}
     float4* rec_L; float* rec_py;
     // light sampling: SpatialLightDistribution tables when enabled, else the scene-wide Distribution1D of DeviceScene
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
     const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = pid < w.B;
     RayIn ray;
+    f2 lens_keep = mk2(0.0f, 0.0f);
     if (active) {
         const uint32_t pix = pid / w.chunk_spp, j = pid - pix * w.chunk_spp, s = w.s0 + j;  // a wave = consecutive samples of one pixel (coherent rays)
         const int2 xy = w.px_xy[pix];
@@ -119,9 +123,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
             generate_camera_ray(w.cam, p_film, time, lens, ray);
             w.rec_L[gsi] = make_float4(0.0f, 0.0f, 0.0f, p_film.x);
             w.rec_py[gsi] = p_film.y;
-            w.s_L[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            w.s_beta[pid] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // beta, eta_scale
-            if (w.textured && w.cam.lens_radius > 0.0f) w.s_A[pid] = make_float4(lens.x, lens.y, 0.0f, 0.0f);  // for the first hit's ray differentials (s_A is idle until then)
+            lens_keep = lens;
         } else {
             w.rec_L[gsi] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0x7fc00000u));  // NaN p_film.x marks "no sample"
             w.rec_py[gsi] = 0.0f;
@@ -133,7 +135,11 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
     if (active) {
         store_ray(w.rays_cl[0] + slot, ray);
         w.live[0][lslot] = pid;
-        w.s_idx[pid] = make_uint4(slot, 0u, 0u, F_EXT | (0u << 8) | (5u << 16));  // bounces 0, next sampler dimension 5
+        w.s_idx[0][lslot] = make_uint4(slot, 0u, 0u, F_EXT | (0u << 8) | (5u << 16));  // bounces 0, next sampler dimension 5
+        w.s_L[0][lslot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        w.s_beta[0][lslot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // beta, eta_scale
+        w.s_prev[0][lslot] = lslot;
+        if (w.textured && w.cam.lens_radius > 0.0f) w.s_A[0][lslot] = make_float4(lens_keep.x, lens_keep.y, 0.0f, 0.0f);  // for the first hit's ray differentials (s_A is idle until then)
         if (!w.identity_slots) atomicAdd(&w.stats->camera_rays, 1ull);
     }
 }
@@ -143,11 +149,9 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
 // vertex names its voxel; the first path to touch a voxel claims a pool slot for it (spatial_compute_kernel fills it).
 __global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfParams w, int it) {
     const uint32_t n_live = w.ctr[it].n_live;
-    const uint32_t* live_in = w.live[it & 1];
     const SpatialRec& sr = w.spatial;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_live; i += gridDim.x * blockDim.x) {
-        const uint32_t pid = live_in[i];
-        const uint4 idx4 = w.s_idx[pid];
+        const uint4 idx4 = w.s_idx[it & 1][i];
         const uint32_t flags = idx4.w & 0xffu, bounces = (idx4.w >> 8) & 0xffu;
         if (!(flags & F_EXT) || (int)bounces >= w.max_depth) continue;
         const float4* hp = reinterpret_cast<const float4*>(w.hits_cl + idx4.x);
@@ -182,8 +186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     const uint32_t* live_in = w.live[it & 1];
     const RayIn* rays_in = w.rays_cl[it & 1];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_live; i += gridDim.x * blockDim.x) {
-        const uint32_t pid = live_in[i];
-        const uint4 idx4 = w.s_idx[pid];
+        const uint4 idx4 = w.s_idx[it & 1][i];
         const uint32_t flags = idx4.w & 0xffu, bounces = (idx4.w >> 8) & 0xffu;
         if (!(flags & F_EXT) || (int)bounces >= w.max_depth) continue;
         const float4* hp = reinterpret_cast<const float4*>(w.hits_cl + idx4.x);
@@ -199,10 +202,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
         const uint32_t camera_ray = (bounces == 0u && !(flags & F_NODIFF)) ? 1u : 0u;  // only camera rays carry differentials
         f2 p_film = mk2(0.0f, 0.0f), lens = mk2(0.0f, 0.0f);
         if (camera_ray) {
+            const uint32_t pid = live_in[i];
             const uint32_t ppix = pid / w.chunk_spp;
             const size_t gsi = (size_t)(w.s0 + (pid - ppix * w.chunk_spp)) * w.n_px + ppix;
             p_film = mk2(w.rec_L[gsi].w, w.rec_py[gsi]);
-            if (w.cam.lens_radius > 0.0f) { const float4 la = w.s_A[pid]; lens = mk2(la.x, la.y); }
+            if (w.cam.lens_radius > 0.0f) { const float4 la = w.s_A[it & 1][w.s_prev[it & 1][i]]; lens = mk2(la.x, la.y); }
         }
         const TexCtx ctx = hit_tex_ctx(sc.self, w.cam_dev, w.sp.spp, __float_as_uint(h1.y), __float_as_uint(h1.z), mk3(h0.z, h0.w, h1.x), si.p, si.n,
                                        mk3(ray.ox, ray.oy, ray.oz), rd, p_film, lens, camera_ray);
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
         if (mr.textured) eval_lobe_colours<SIMPLE>(sc.self, mr, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out);
 
         // only what the shade pass reads for this material: the two header quads if it needs them, then the colour slots in use (a matte with an image map: 16 of the 128 bytes)
-        float4* dst = reinterpret_cast<float4*>(w.tex_out + pid);
+        float4* dst = reinterpret_cast<float4*>(w.tex_out + i);   // by position in this round's list: the shade pass reads it from there
         const float4* src = reinterpret_cast<const float4*>(&out);
         if (mr.tex_hdr) { dst[0] = src[0]; dst[1] = src[1]; }
         for (uint32_t k = 0; k < mr.tex_cols; k++) dst[2 + k] = src[2 + k];
@@ -312,10 +316,10 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
             // (class = distinct lobe-kind signature, recorded by the traversal kernel in HitOut.pad[2]), so that a wave walks one kind of
             // lobe list.  Paths with nothing to shade (miss / only pending shadow + MIS results) form the last group.  Which thread
             // handles which path is free: paths are independent and the film is accumulated by sample index.
-            uint32_t cls = 8u, cand = 0u;
+            uint32_t cls = 8u;
+            const uint32_t cand = i;   // positions of this round's list are sorted, not path ids: the state is addressed by position
             if (active) {
-                cand = live_in[i];
-                const uint4 c4 = w.s_idx[cand];
+                const uint4 c4 = w.s_idx[it & 1][i];
                 cls = 7u;
                 if (c4.w & F_EXT) {
                     const float4 ch = reinterpret_cast<const float4*>(w.hits_cl + c4.x)[1];
@@ -335,22 +339,24 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
             __syncthreads();
         }
         if (active) {
-            pid = GEN ? sort_pid[tid] : live_in[i];
-            const uint4 idx4 = w.s_idx[pid];
+            const uint32_t pos = GEN ? sort_pid[tid] : i;   // this thread's path: its position in the round's list
+            pid = live_in[pos];
+            const uint4 idx4 = w.s_idx[it & 1][pos];
             flags = idx4.w & 0xffu; bounces = (idx4.w >> 8) & 0xffu; dim = idx4.w >> 16;
-            const float4 L4 = w.s_L[pid], b4 = w.s_beta[pid];
+            const float4 L4 = w.s_L[it & 1][pos], b4 = w.s_beta[it & 1][pos];
             L = mks(L4.x, L4.y, L4.z); beta = mks(b4.x, b4.y, b4.z);
             if (GEN) eta_scale = b4.w;
 
             // ---- K6: finish uniform_sample_one_light of the previous vertex (integrator/common.rs:196-221, 276-295, 132) --------
             if (flags & (F_PSH | F_PMIS)) {
-                const float4 A4 = w.s_A[pid], O4 = w.s_bold[pid];
+                const uint32_t prev = w.s_prev[it & 1][pos];   // where the thread that made this vertex's light sample left it
+                const float4 A4 = w.s_A[it & 1][prev], O4 = w.s_bold[it & 1][prev];
                 spec est = mks1(0.0f);
                 if (flags & F_PSH) {
                     if (!w.occ[idx4.z]) est = est + mks(A4.x, A4.y, A4.z);
                 }
                 if (flags & F_PMIS) {
-                    const float4 F4 = w.s_f2[pid];
+                    const float4 F4 = w.s_f2[it & 1][prev];
                     const uint32_t light_num = __float_as_uint(F4.w);
                     const RayIn mr = load_ray(rays_in + idx4.y);
                     const float4* hp = reinterpret_cast<const float4*>(w.hits_cl + idx4.y);
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                             const MaterialRec& mr = sc.materials[m.material];
                             tex_hit = mr.textured != 0u || mr.bump_tex1 != 0u;
                             if (tex_hit && mr.bump_tex1) {  // Material::bump: the BSDF is made on the bumped frame
-                                const float4* tp = reinterpret_cast<const float4*>(w.tex_out + pid);
+                                const float4* tp = reinterpret_cast<const float4*>(w.tex_out + pos);
                                 const float4 f0 = tp[0], f1 = tp[1];
                                 si.ns = mk3(f0.x, f0.y, f0.z); si.dpdu_s = mk3(f1.x, f1.y, f1.z);
                             }
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         if (TEX && tex_hit) {
                             const MaterialRec& mr = sc.materials[m.material];
                             if (mr.textured)
-                                BO::apply_textures(bsdf, w.tex_out + pid, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr, mr);
+                                BO::apply_textures(bsdf, w.tex_out + pos, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr, mr);
                         }
                         SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid - ppix * w.chunk_spp), dim, hl);
                         // Draw the next 8 dimensions in one (not unrolled) loop: light pick 1D, u_light 2D, u_scattering 2D, BSDF 2D,
@@ -483,14 +489,14 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                                 stage[1][0][tid] = make_float4(rm.ox, rm.oy, rm.oz, rm.t_max);
                                                 stage[1][1][tid] = make_float4(rm.dx, rm.dy, rm.dz, rm.time);
                                                 want_mis = true;
-                                                w.s_f2[pid] = make_float4(f.r, f.g, f.b, __uint_as_float(light_num));
+                                                w.s_f2[(it + 1) & 1][i] = make_float4(f.r, f.g, f.b, __uint_as_float(light_num));
                                                 flags |= F_PMIS;
                                             }
                                         }
                                     }
                                     if (flags & (F_PSH | F_PMIS)) {
-                                        w.s_A[pid] = make_float4(A.r, A.g, A.b, w2);
-                                        w.s_bold[pid] = make_float4(beta.r, beta.g, beta.b, spdf_store);
+                                        w.s_A[(it + 1) & 1][i] = make_float4(A.r, A.g, A.b, w2);   // at THIS thread's position (coalesced); the survivor's s_prev points here
+                                        w.s_bold[(it + 1) & 1][i] = make_float4(beta.r, beta.g, beta.b, spdf_store);
                                     }
                                 }
                             }
@@ -578,9 +584,10 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
             }
             if (still_live) {
                 live_out[lv_slot] = pid;
-                w.s_idx[pid] = make_uint4(ext_slot, mis_slot, sh_slot, flags | (bounces << 8) | (dim << 16));
-                w.s_L[pid] = make_float4(L.r, L.g, L.b, pick_pdf);
-                w.s_beta[pid] = make_float4(beta.r, beta.g, beta.b, eta_scale);
+                w.s_idx[(it + 1) & 1][lv_slot] = make_uint4(ext_slot, mis_slot, sh_slot, flags | (bounces << 8) | (dim << 16));
+                w.s_L[(it + 1) & 1][lv_slot] = make_float4(L.r, L.g, L.b, pick_pdf);
+                w.s_beta[(it + 1) & 1][lv_slot] = make_float4(beta.r, beta.g, beta.b, eta_scale);
+                w.s_prev[(it + 1) & 1][lv_slot] = i;
             } else {
                 // path finished: radiance sanitising of render_tile (sampler_integrator.rs:373-397)
                 if (has_nans(L)) L = mks1(0.0f);
@@ -734,7 +741,7 @@ struct Wavefront {
     uint32_t slot_w = 0, slot_h = 0;
     int tiles_key[12] = {0}; bool tiles_valid = false;  // what the lists above (and their device copies) were built for
     DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats, d_cam, d_hit_lobes, d_tex_out;
-    DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_recL, d_recpy, d_tilebuf, d_xyz, d_w;
+    DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_sprev, d_recL, d_recpy, d_tilebuf, d_xyz, d_w;
     DevBuf d_vox_slot, d_sp_pool, d_sp_list, d_sp_ctr, d_sp_halton;  // SpatialLightDistribution tables (spatial.h)
     DevBuf d_order, d_sort_bins, d_heads, d_keys_cl, d_keys_sh;  // ray binning between rounds (raysort.h), per-XCD queue heads
     size_t n_vox = 0;   // voxels of the last spatial render's table (d_vox_slot)
@@ -747,7 +754,7 @@ void free_wavefront(PbrtHipScene* s) {
     Wavefront* w = s->wf;
     if (!w) return;
     for (DevBuf* b : {&w->d_tiles, &w->d_px, &w->d_rays_cl[0], &w->d_rays_cl[1], &w->d_hits, &w->d_rays_sh, &w->d_occ, &w->d_live[0], &w->d_live[1], &w->d_ctr,
-                      &w->d_stats, &w->d_cam, &w->d_hit_lobes, &w->d_tex_out, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
+                      &w->d_stats, &w->d_cam, &w->d_hit_lobes, &w->d_tex_out, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_sprev, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
                       &w->d_vox_slot, &w->d_sp_pool, &w->d_sp_list, &w->d_sp_ctr, &w->d_sp_halton, &w->d_order, &w->d_sort_bins, &w->d_heads, &w->d_keys_cl, &w->d_keys_sh})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : w->events) (void)hipEventDestroy(e);
@@ -908,7 +915,7 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
-            const size_t per_path = 353 + (s->textured_materials ? sizeof(TexOut) : 0);
+            const size_t per_path = 353 + 100 + 24 + (s->textured_materials ? sizeof(TexOut) : 0);   // queues and path state (double-buffered since round 3: + 100), sort keys and order (24)
             max_paths = std::max<size_t>(4u << 20, std::min<size_t>(max_paths, total_b / 10 * 3 / per_path));
         }
     }
@@ -932,7 +939,8 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     if ((rc = ensure_buf(s, w.d_ctr, (size_t)(n_iter_cap + 2) * sizeof(ph::IterCounters)))) return rc;
     if ((rc = ensure_buf(s, w.d_stats, sizeof(ph::DevStats)))) return rc;
     for (DevBuf* b : {&w.d_sL, &w.d_sbeta, &w.d_sA, &w.d_sf2, &w.d_sbold, &w.d_sidx})
-        if ((rc = ensure_buf(s, *b, B * 16))) return rc;
+        if ((rc = ensure_buf(s, *b, 2 * B * 16))) return rc;   // two buffers each: queue-ordered, read from one and written to the other (WfParams)
+    if ((rc = ensure_buf(s, w.d_sprev, 2 * B * 4))) return rc;
     if ((rc = ensure_buf(s, w.d_recL, (size_t)n_px * spp * 16))) return rc;
     if ((rc = ensure_buf(s, w.d_recpy, (size_t)n_px * spp * 4))) return rc;
 
@@ -974,8 +982,11 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     wp.hits_cl = (ph::HitOut*)w.d_hits.p; wp.rays_sh = (ph::RayIn*)w.d_rays_sh.p; wp.occ = (uint8_t*)w.d_occ.p;
     wp.live[0] = (uint32_t*)w.d_live[0].p; wp.live[1] = (uint32_t*)w.d_live[1].p;
     wp.ctr = (ph::IterCounters*)w.d_ctr.p; wp.stats = (ph::DevStats*)w.d_stats.p;
-    wp.s_L = (float4*)w.d_sL.p; wp.s_beta = (float4*)w.d_sbeta.p; wp.s_A = (float4*)w.d_sA.p; wp.s_f2 = (float4*)w.d_sf2.p;
-    wp.s_bold = (float4*)w.d_sbold.p; wp.s_idx = (uint4*)w.d_sidx.p;
+    for (int k = 0; k < 2; k++) {
+        wp.s_L[k] = (float4*)w.d_sL.p + (size_t)k * B; wp.s_beta[k] = (float4*)w.d_sbeta.p + (size_t)k * B; wp.s_A[k] = (float4*)w.d_sA.p + (size_t)k * B;
+        wp.s_f2[k] = (float4*)w.d_sf2.p + (size_t)k * B; wp.s_bold[k] = (float4*)w.d_sbold.p + (size_t)k * B; wp.s_idx[k] = (uint4*)w.d_sidx.p + (size_t)k * B;
+        wp.s_prev[k] = (uint32_t*)w.d_sprev.p + (size_t)k * B;
+    }
     wp.rec_L = (float4*)w.d_recL.p; wp.rec_py = (float*)w.d_recpy.p;
     wp.sort_grid = sort_grid; wp.keys_cl = (uint32_t*)w.d_keys_cl.p; wp.keys_sh = (uint32_t*)w.d_keys_sh.p;
 
