@@ -228,18 +228,16 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
     return PBRT_HIP_OK;
 }
 
-// Tuning variants of the traversal kernel, selectable at run time (PBRT_HIP_TRAV_VARIANT) so that one GPU session can
-// compare them on the same data.  {LEAF_MIN, REFILL_MIN, LDS_DEPTH, NODE_STEPS, waves per SIMD the kernel is compiled for (0 = the compiler's choice)}; PH_DEFAULT_VARIANT is what ships.
-#define PH_VARIANTS(X) X(0, 20, 12, 12, 3, 0, false) X(1, 20, 12, 12, 2, 0, false) X(2, 20, 12, 12, 1, 0, false) X(3, 24, 12, 12, 2, 0, false) X(4, 16, 12, 12, 2, 0, false) X(5, 28, 16, 12, 2, 0, false) \
-    X(6, 20, 16, 12, 2, 0, false) X(7, 20, 8, 12, 2, 0, false) X(8, 24, 16, 10, 2, 0, false) X(9, 24, 12, 12, 4, 0, false) X(10, 20, 12, 11, 3, 7, false) X(11, 24, 12, 11, 4, 7, false) \
-    X(12, 20, 12, 10, 3, 8, false) X(13, 24, 12, 12, 4, 6, false) X(14, 20, 12, 12, 5, 0, false) X(15, 24, 12, 11, 5, 7, false) \
-    X(19, 24, 12, 12, 5, 6, false)   /* 16 - 18 were the packed-arithmetic kernels of round 2 (dropped) */
-#define PH_N_VARIANTS 20
+// The traversal kernel's shape: {LEAF_MIN, REFILL_MIN, LDS_DEPTH, NODE_STEPS, waves per SIMD the kernel is compiled for (0 = the compiler's choice)}.  Slot 0 is what ships
+// (measured on configs[2] / configs[1] with binned queues: 742.6 / 31.3 ms of traversal per frame against 760.2 / 31.7 for the round-1 shape, gpurun r02h); slot 1 is the one
+// spare A/B slot (PBRT_HIP_TRAV_VARIANT=1), holding the round-1 shape.  The seventeen other shapes rounds 1 and 2 compared are in DESIGN §4 / §7b with their numbers.
+#define PH_VARIANTS(X) X(0, 24, 12, 12, 5, 6, false) X(1, 20, 12, 12, 3, 0, false)
+#define PH_N_VARIANTS 2
 #define PH_DEFAULT_INST_VARIANT 1   // 1 000 instances x 10 k triangles: 95.0 ms of traversal per frame against 102.9 (variant 0), 101.7 (2), 109.0 (3) (gpurun r02n)
-#define PH_DEFAULT_VARIANT 19   // measured on configs[2] / configs[1] with binned queues: 742.6 / 31.3 ms of traversal per frame against 760.2 / 31.7 for variant 0 (gpurun r02h)
+#define PH_DEFAULT_VARIANT 0
 static int trav_variant() {
     static int v = -1;
-    if (v < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_VARIANT"); v = e ? std::atoi(e) : PH_DEFAULT_VARIANT; if (v < 0 || v >= PH_N_VARIANTS || (v >= 16 && v <= 18)) v = PH_DEFAULT_VARIANT; }
+    if (v < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_VARIANT"); v = e ? std::atoi(e) : PH_DEFAULT_VARIANT; if (v < 0 || v >= PH_N_VARIANTS) v = PH_DEFAULT_VARIANT; }
     return v;
 }
 static int variant_lds_depth(int v) {

@@ -19,7 +19,7 @@ namespace ph {
 #define PH_SLOT_FREE 0xFFFFFFFEu   // `cur` of a slot without a ray (PH_INVALID_REF = a finished ray that waits to be written out)
 #define PH_SLOT_NOHIT 0xFFFFFFFFu
 
-template <bool ANYHIT, bool MIXED, int S, int D, int K, int LEAF_MIN, int REFILL_MIN, int WPE>
+template <bool ANYHIT, bool MIXED, int S, int D, int K, int LEAF_MIN, int REFILL_MIN, int WPE, int NODE_MIN = 48>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void traverse_slots_kernel(DeviceScene sc, TravParams p) {
     static_assert(S > 64 && S <= 128, "a lane looks after the slots lane and lane + 64");
     constexpr int W = PH_TRAV_BLOCK / 64;
@@ -133,8 +133,17 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
             continue;
         }
 
+        // ---- ONE kind of work per pass: the one that fills the wave best (a pass costs a sort of the slots, ~40 instructions, whatever it then does) ----------
+        // node steps when at least NODE_MIN slots want them, else triangle tests when LEAF_MIN slots wait at leaves, else the write-out of 16 or more finished rays;
+        // when nothing reaches its threshold, whatever has the most takers
+        int phase;
+        if (n_node >= (uint32_t)NODE_MIN) phase = 0;
+        else if (n_leaf >= (uint32_t)LEAF_MIN) phase = 1;
+        else if (n_done >= 16u) phase = 2;
+        else phase = (n_node >= n_leaf && n_node >= n_done) ? 0 : (n_leaf >= n_done ? 1 : 2);
+
         // ---- K interior-node steps for (up to 64 of) the node-phase slots ---------------------------------------------------------------------
-        if (n_node) {
+        if (phase == 0) {
             if (node0) LIST[__popcll(mn0 & lane_lt)] = (uint8_t)h0;
             if (node1) LIST[__popcll(mn0) + __popcll(mn1 & lane_lt)] = (uint8_t)h1;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -171,8 +180,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
         }
 
         // ---- one triangle for (up to 64 of) the slots that were waiting at a leaf when the pass began ------------------------------------------
-        if (n_leaf && (n_leaf >= (uint32_t)LEAF_MIN || n_node < 40u || exhausted)) {
-            __builtin_amdgcn_wave_barrier();
+        if (phase == 1) {
             if (leaf0) LIST[__popcll(ml0 & lane_lt)] = (uint8_t)h0;
             if (leaf1) LIST[__popcll(ml0) + __popcll(ml1 & lane_lt)] = (uint8_t)h1;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -207,8 +215,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
         }
 
         // ---- write out the rays that had finished when the pass began; their slots are free again -----------------------------------------------
-        if (n_done && (n_done >= 16u || n_node + n_leaf < 48u || exhausted)) {
-            __builtin_amdgcn_wave_barrier();
+        if (phase == 2) {
             if (done0) LIST[__popcll(md0 & lane_lt)] = (uint8_t)h0;
             if (done1) LIST[__popcll(md0) + __popcll(md1 & lane_lt)] = (uint8_t)h1;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

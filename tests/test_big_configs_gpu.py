@@ -171,6 +171,39 @@ def test_config4_standin_instanced_many_materials(host):
     s.close()
 
 
+C1M = dict(n_tris=1_000_000, seed=1, xres=512, yres=512, spp=64, max_depth=5)      # the north-star's own scene ("≥ 100 x the reference CPU Mrays/s on a 1M-triangle scene")
+
+
+def test_north_star_1M_crop_bit_exact_and_full_frame_invariants(host, monkeypatch):
+    """The 1 M-triangle scene the north-star's speed target is quoted on, 512 x 512 @ 64 spp: a crop against the oracle bit for bit, the whole frame through its accounting,
+    the 8-way tile partition and the sample chunking."""
+    g, o, geom = _crop_pair(host, C1M, (0.40, 0.52, 0.44, 0.55))    # 61 x 56 pixels
+    _assert_bit_exact(g, o, "1 M-triangle crop")
+    _full_frame_invariants(host, C1M, geom, monkeypatch, chunk_paths=5_000_000)
+
+
+def test_config2_crop_meets_the_stated_tolerance_in_glibc_mode(host):
+    """configs[2] (4.3 M triangles, depth 8, 256 spp) against the oracle with glibc's f32 transcendentals — what a Rust build of the reference links — on a crop of the
+    full-size scene: the stated tolerance (RMSE <= 1e-3 x mean luminance, <= 0.1 % of the pixels off by more than 1e-2 x mean)."""
+    spec = pbrt_hip.SceneSpec(**C2, crop_window=(0.40, 0.50, 0.45, 0.55))     # 102 x 102 pixels at 256 spp
+    prod = pbrt_hip.Scene()
+    geom = pbrt_hip.capture_spec(spec, prod, host, device_build=True)
+    gx, gw, gst = prod.render_path(max_depth=C2["max_depth"])
+    orc = OracleScene()
+    pbrt_hip.capture_spec(spec, orc, host, geometry=geom)
+    set_libm_mode(0)
+    ox, ow, ost, _ = orc.render_path_ex(max_depth=C2["max_depth"], threads=16)
+    assert gst.camera_rays == ost.camera_rays and np.array_equal(gw, ow)
+    grgb, orgb = prod.film_to_rgb(gx, gw), prod.film_to_rgb(ox, ow)
+    mean = float(orgb.mean())
+    rmse = float(np.sqrt(((grgb - orgb) ** 2).mean()))
+    outliers = float((np.abs(grgb - orgb).max(axis=2) > 1e-2 * mean).mean())
+    assert rmse <= 1e-3 * mean, (rmse, mean)
+    assert outliers <= 1e-3, outliers
+    assert abs(int(gst.regular_rays + gst.shadow_rays) - int(ost.regular_rays + ost.shadow_rays)) <= 2e-5 * (ost.regular_rays + ost.shadow_rays)
+    prod.close(); orc.close()
+
+
 def test_config4_at_its_stated_size(host):
     """configs[4] at the size BASELINE.json states — the San-Miguel-shaped scene of pbrt_hip/sanmiguel.py: 128 objects, 1 100 instances, 10.2 M instanced + 0.4 M top-level
     triangles, 26 materials (image maps, bump maps, alpha-masked foliage, every BSDF class), eleven lights, 1920 x 1080 @ 512 spp, depth 5.  A crop of that scene at the full
