@@ -49,7 +49,7 @@ sys.path.insert(0, os.path.join(ROOT, "pbrt-v3-rs_amd"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 INFINITY_CACHE_BYTES = 256 << 20
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 CONFIGS = {  # BASELINE.json `configs`, on the synthetic generator of SURVEY §8d
     "1": dict(n_tris=100_000, res=512, spp=64, max_depth=5, label="configs[1]: synthetic 100 k random triangles, single BVH, 512x512 @ 64 spp"),
@@ -82,12 +82,24 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PBRT_HIP_CPU_THREADS", "16"))))
 
 
-def workload_key(n_tris, res, spp, max_depth, seed, yres=None):
-    return [int(n_tris), int(res), int(spp), int(max_depth), int(seed)] + ([int(yres)] if yres and yres != res else [])
+def workload_key(n_tris, res, spp, max_depth, seed, yres=None, instances=0):
+    return [int(n_tris), int(res), int(spp), int(max_depth), int(seed)] + ([int(yres)] if yres and yres != res else []) + (["instances", int(instances)] if instances else [])
+
+
+def library_identity():
+    """(sha256 over the library's sources — every file of pbrt-v3-rs_amd/csrc, which is what decides the kernels; a rebuild of the same sources keeps it —, the PBRT_HIP_*
+    tuning variables in force): what a PMC record must have been measured on to describe this run."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "pbrt-v3-rs_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".h", ".hip", ".cpp", ".inc")) or name == "Makefile":
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest(), {k: v for k, v in sorted(os.environ.items()) if k.startswith("PBRT_HIP_") and k not in ("PBRT_HIP_CPU_THREADS", "PBRT_HIP_LIB")}
 
 
 def find_traffic(key):
-    """The PMC record of this workload from profiles/r02_traffic.json, or (None, reason)."""
+    """The PMC record of this workload from profiles/r03_traffic.json — measured on THIS library build under this tuning environment —, or (None, reason)."""
     if not os.path.exists(TRAFFIC_FILE):
         return None, f"{os.path.relpath(TRAFFIC_FILE, ROOT)} does not exist"
     with open(TRAFFIC_FILE) as f:
@@ -96,6 +108,11 @@ def find_traffic(key):
         if e.get("workload") == key:
             if "traversal" not in e:
                 return None, "the PMC record of this workload has no traversal kernels"
+            sha, env = library_identity()
+            if e.get("lib_sha256") != sha:
+                return None, f"the PMC record of this workload was measured on another build of the library (record {str(e.get('lib_sha256'))[:12]}, running {sha[:12]}): re-run scripts/pmc_profile.sh"
+            if e.get("env", {}) != env:
+                return None, f"the PMC record of this workload was measured under another tuning environment ({e.get('env')} vs {env})"
             return e, None
     return None, f"no PMC run of workload {key} in {os.path.relpath(TRAFFIC_FILE, ROOT)} (have: {[e.get('workload') for e in tj.get('entries', [])]})"
 
@@ -316,7 +333,7 @@ def main():
                                     if sm is None else
                                     f" — as run: {json.dumps(sm.counts())}, {sm.n_materials} materials, two-level SAH BVH (maxnodeprims 4), {res}x{yres} @ {frame_spp} spp{spp_note}, "
                                     f"PathIntegrator maxdepth {max_depth}, halton, box filter, lightsamplestrategy spatial"),
-                       "baseline_config": cfg_name if not custom else "custom", "key": workload_key(n_tris, res, frame_spp, max_depth, args.seed, yres),
+                       "baseline_config": cfg_name if not custom else "custom", "key": workload_key(n_tris, res, frame_spp, max_depth, args.seed, yres, args.instances),
                        "tiles": (f"16x16, tile t on device t % {n_gpus} of ONE multi-device handle (one host thread per device), film tiles gathered on the first device inside the library"
                                  + (" (RCCL send / recv)" if args.backend == "nccl" else " (device-to-device copies: the contexts share GPU 0)")) if args.multi_handle else
                                 f"16x16, tile t on rank t % {world}, film tiles gathered on rank 0 (" + ("RCCL" if args.backend == "nccl" else "gloo, through host memory: rehearsal on one GPU") + ")" if world > 1 else "16x16, one rank",
@@ -366,8 +383,8 @@ def main():
                 # memory-side traffic of the same kernel from rocprofv3 PMC passes (separate runs of this script under `rocprofv3 --pmc`, scripts/pmc_profile.sh;
                 # MI355X_MICROARCH.md: FETCH_SIZE doubles for wide coalesced streaming reads only — this kernel reads random 64-B lines, for which the
                 # calibration run scripts/calib/fetch_calib.hip shows FETCH_SIZE exact, so fetch_scale is 1).  Only a run of this exact workload counts.
-                plain = n_gpus == 1 and args.material == "matte" and not args.instances
-                e, why = find_traffic(workload_key(n_tris, res, frame_spp, max_depth, args.seed, yres)) if plain else (None, "PMC records are kept for the single-GPU BASELINE workloads only")
+                plain = n_gpus == 1 and args.material == "matte"
+                e, why = find_traffic(workload_key(n_tris, res, frame_spp, max_depth, args.seed, yres, args.instances)) if plain else (None, "PMC records are kept for the single-GPU BASELINE workloads only")
                 if e is not None:
                     k = e["traversal"]
                     per_launch = (float(e.get("fetch_scale", 1.0)) * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"]
@@ -378,7 +395,12 @@ def main():
                                  "pmc": k.get("sq"),
                                  "limiter": ("VALU issue, not memory: the SIMDs' vector pipes are busy %.0f %% of the time (PMC SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per SIMD) at a lane utilisation of %.2f, "
                                              "L2 serves %.0f %% of the requests since the rays of a launch are binned by origin cell" %
-                                             (100.0 * min(1.0, k["sq"]["valu_active_of_wave_cycles"] * 6.0), k["sq"]["valu_lane_utilisation"], 100.0 * k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]))) if k.get("sq") else None,
+                                             (100.0 * min(1.0, k["sq"]["valu_active_of_wave_cycles"] * float(e.get("waves_per_simd", 4.0 if sm is not None or args.instances else 6.0))), k["sq"]["valu_lane_utilisation"], 100.0 * k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]))) if k.get("sq") else None,
+                                 "valu": ({"issue_frac": round(min(1.0, k["sq"]["valu_active_of_wave_cycles"] * float(e.get("waves_per_simd", 4.0 if sm is not None or args.instances else 6.0))), 4),
+                                           "lane_util": k["sq"]["valu_lane_utilisation"],
+                                           "effective": round(min(1.0, k["sq"]["valu_active_of_wave_cycles"] * float(e.get("waves_per_simd", 4.0 if sm is not None or args.instances else 6.0))) * k["sq"]["valu_lane_utilisation"], 4),
+                                           "note": "the roofline that binds this kernel: share of the SIMDs' issue cycles spent on VALU instructions x share of the 64 lanes those instructions use"}
+                                          if k.get("sq") else None),
                                  "traffic_note": "bytes per launch leaving the L2s (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE over " + str(k["dispatches"]) + " traversal launches of one frame, " +
                                                  e.get("source", "profiles/") + "; " + e.get("calibration", "") + ")"})
                 else:

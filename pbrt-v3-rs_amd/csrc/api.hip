@@ -4,7 +4,6 @@
 #include "host_math.h"
 #include "scene_host.h"
 #include "traverse.h"
-#include "traverse_slots.h"
 #include "texture.h"
 #include <algorithm>
 #include <cstdio>
@@ -249,22 +248,6 @@ static int variant_lds_depth(int v) {
     return PH_LDS_DEPTH;
 }
 
-// The slot kernels of traverse_slots.h (rays decoupled from lanes), for flat scenes, selected with PBRT_HIP_TRAV_SLOTS = 1 .. : {slots per wave, LDS stack entries, node steps per pass,
-// leaf threshold, refill threshold, blocks per CU}
-#define PH_SLOT_VARIANTS(X) X(1, 96, 8, 5, 32, 24, 3) X(2, 80, 8, 5, 24, 16, 4) X(3, 112, 6, 5, 40, 32, 3) X(4, 96, 8, 3, 32, 24, 3) X(5, 96, 8, 8, 32, 24, 3) X(6, 80, 8, 3, 24, 16, 4)
-static int slots_variant() {
-    static const int v = []() { const char* e = std::getenv("PBRT_HIP_TRAV_SLOTS"); const int x = e ? std::atoi(e) : 0; return (x < 0 || x > 6) ? 0 : x; }();
-    return v;
-}
-static void slots_shape(int v, int& S, int& D, int& per_cu) {
-    S = D = per_cu = 0;
-    switch (v) {
-#define X(id, s_, d_, k_, lm, rm, wpe) case id: S = s_; D = d_; per_cu = wpe; break;
-        PH_SLOT_VARIANTS(X)
-#undef X
-    }
-}
-
 int ensure_traversal_workspace(PbrtHipScene* s) {
     if (!s->trav_blocks) {
         hipDeviceProp_t prop;
@@ -286,14 +269,7 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
     if ((rc = ensure_buf(s, s->d_counts, 64))) return rc;
     const int stack_cap = s->inst_recs.empty() ? PH_MAX_STACK : 2 * PH_MAX_STACK;  // with instances the scene-level and object-level entries share one stack
     const int lds_depth = s->inst_recs.empty() ? variant_lds_depth(trav_variant()) : PH_LDS_DEPTH;
-    size_t spill_bytes = (size_t)(stack_cap - lds_depth) * total_threads * sizeof(uint2);
-    if (slots_variant()) {
-        hipDeviceProp_t prop;
-        PH_CHECK(s, hipGetDeviceProperties(&prop, s->device));
-        int S, D, per_cu; slots_shape(slots_variant(), S, D, per_cu);
-        spill_bytes = std::max(spill_bytes, (size_t)(PH_MAX_STACK - D) * ((size_t)prop.multiProcessorCount * per_cu * (PH_TRAV_BLOCK / 64) * S) * sizeof(uint2));
-    }
-    if ((rc = ensure_buf(s, s->d_spill, spill_bytes))) return rc;
+    if ((rc = ensure_buf(s, s->d_spill, (size_t)(stack_cap - lds_depth) * total_threads * sizeof(uint2)))) return rc;
     return PBRT_HIP_OK;
 }
 
@@ -339,25 +315,6 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
         return;
     }
     if (s->count_traversal) { PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false, 0, false); return; }
-    if (slots_variant()) {   // the round-3 experiment: rays live in LDS slots, lanes take whatever work is due (traverse_slots.h)
-        int S, D, per_cu; slots_shape(slots_variant(), S, D, per_cu);
-        const uint32_t full = (s->trav_blocks / 6u ? s->trav_blocks / 6u : 1u);   // (trav_blocks = CUs x 6 for the default kernel)
-        hipDeviceProp_t prop;
-        const uint32_t cus = hipGetDeviceProperties(&prop, s->device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : full;
-        const dim3 gs(std::min<uint32_t>(blocks, cus * (uint32_t)per_cu));
-        p.total_threads = cus * (uint32_t)per_cu * (PH_TRAV_BLOCK / 64) * (uint32_t)S;
-        switch (slots_variant()) {
-#define X(id, s_, d_, k_, lm, rm, wpe)                                                                                                                                    \
-    case id:                                                                                                                                                              \
-        if (mode == 2) hipLaunchKernelGGL((ph::traverse_slots_kernel<false, true, s_, d_, k_, lm, rm, wpe>), gs, b, 0, s->stream, s->ds, p);                                \
-        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_slots_kernel<true, false, s_, d_, k_, lm, rm, wpe>), gs, b, 0, s->stream, s->ds, p);                           \
-        else hipLaunchKernelGGL((ph::traverse_slots_kernel<false, false, s_, d_, k_, lm, rm, wpe>), gs, b, 0, s->stream, s->ds, p);                                         \
-        break;
-            PH_SLOT_VARIANTS(X)
-#undef X
-        }
-        return;
-    }
     switch (trav_variant()) {
 #define X(id, lm, rm, ld, ns, wpe, pk) case id: PH_LAUNCH3(false, lm, rm, ld, ns, false, wpe, pk); break;
         PH_VARIANTS(X)

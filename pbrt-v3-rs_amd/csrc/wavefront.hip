@@ -634,17 +634,26 @@ __global__ __launch_bounds__(256) void film_tiles_kernel(FilmParams p) {
         const int x = t.pb[0] + kx, y = t.pb[1] + ky;
         const float rx = p.film.radius[0], ry = p.film.radius[1];
         // a sample at film position p reaches pixel x iff ceil(p-.5-r) <= x <= floor(p-.5+r), i.e. p in [x+.5-r, x+.5+r]; samples of
-        // pixel sx have p in [sx, sx+1), so only sx in [floor(x+.5-r), floor(x+.5+r)] can contribute (evaluated in f64: exact).
-        const int sx0 = pmaxi((int)floor((double)x + 0.5 - (double)rx), t.tb[0]), sx1 = pmini((int)floor((double)x + 0.5 + (double)rx), t.tb[2] - 1);
-        const int sy0 = pmaxi((int)floor((double)y + 0.5 - (double)ry), t.tb[1]), sy1 = pmini((int)floor((double)y + 0.5 + (double)ry), t.tb[3] - 1);
+        // pixel sx have p in [sx, sx+1), so only sx in [floor(x+.5-r), floor(x+.5+r)] can contribute (evaluated in f64: exact) ...
+        const int sx0n = (int)floor((double)x + 0.5 - (double)rx), sy0n = (int)floor((double)y + 0.5 - (double)ry);
+        // ... except that `pixel + offset` is an f32 sum: an offset within half an ulp of 1 puts the sample ON the next pixel's coordinate, p = sx + 1 (beyond x = 512
+        // every offset above 1 - 2^-15 does; at 512 spp the Halton points reach 1 - 2^-17).  Where x + .5 - r is a whole number such a sample of pixel sx0n - 1 still
+        // reaches x: that column / row is scanned too, for the samples whose position is exactly sx + 1 (round 3: found by the configs[4] crop at 512 spp)
+        const int sx0e = (int)ceil((double)x - 0.5 - (double)rx) < sx0n ? sx0n - 1 : sx0n, sy0e = (int)ceil((double)y - 0.5 - (double)ry) < sy0n ? sy0n - 1 : sy0n;
+        const int sx0 = pmaxi(sx0e, t.tb[0]), sx1 = pmini((int)floor((double)x + 0.5 + (double)rx), t.tb[2] - 1);
+        const int sy0 = pmaxi(sy0e, t.tb[1]), sy1 = pmini((int)floor((double)y + 0.5 + (double)ry), t.tb[3] - 1);
         const int tw = t.tb[2] - t.tb[0];
         for (int sy = sy0; sy <= sy1; sy++)
             for (int sx = sx0; sx <= sx1; sx++) {
                 const size_t pix = (size_t)t.px_off + (size_t)(sy - t.tb[1]) * tw + (size_t)(sx - t.tb[0]);
+                const bool up_x = sx < sx0n, up_y = sy < sy0n;   // only samples rounded up onto the next column / row matter from here
                 for (uint32_t s = 0; s < p.spp; s++) {
+                    const float pfy = p.rec_py[(size_t)s * p.n_px + pix];
+                    if (up_y && pfy != (float)(sy + 1)) continue;
                     const float4 r = p.rec_L[(size_t)s * p.n_px + pix];
                     if (r.w != r.w) continue;  // pixel outside pixel_bounds: no sample was taken
-                    const float pfx = r.w, pfy = p.rec_py[(size_t)s * p.n_px + pix];
+                    if (up_x && r.w != (float)(sx + 1)) continue;
+                    const float pfx = r.w;
                     spec l = mks(r.x, r.y, r.z);
                     const float ly = lum_y(l);
                     if (ly > p.film.max_lum) l = l * p.film.max_lum / ly;
@@ -911,51 +920,74 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     // 128 Mi paths per chunk where the card has room for them (353 B of queues and path state per path, 481 B with a texture pass: 47 – 65 GB of the MI355X's 288 GB):
     // large chunks bin better (more rays per origin cell and round) and pay fewer launch tails — configs[2] 913 -> 878 ms per frame, configs[3] 934 -> 898 ms against the
     // 32 Mi of round 1 (gpurun r02aa; 256 Mi, the whole frame at once, adds nothing: 875 / 899 ms).  At most 30 % of the device's memory goes to one chunk.
+    const size_t per_path = 2 * 2 * sizeof(ph::RayIn) + 2 * sizeof(ph::HitOut) + sizeof(ph::RayIn) + 1 + 2 * 4 + 6 * 2 * 16 + 2 * 4   // ray / hit queues, live lists, path state (two buffers)
+                            + 3 * 4 + 3 * 4 + (s->textured_materials ? sizeof(TexOut) : 0);                                               // + bin keys and order + the texture pass's records
+    // everything in this context that grows with the chunk, as allocated now: a chunk may reuse it
+    auto chunk_bufs = [&]() { return std::vector<DevBuf*>{&w.d_rays_cl[0], &w.d_rays_cl[1], &w.d_hits, &w.d_rays_sh, &w.d_occ, &w.d_live[0], &w.d_live[1], &w.d_sL, &w.d_sbeta, &w.d_sA, &w.d_sf2,
+                                                         &w.d_sbold, &w.d_sidx, &w.d_sprev, &w.d_order, &w.d_keys_cl, &w.d_keys_sh, &w.d_tex_out}; };
     size_t max_paths = 128u << 20;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
-            const size_t per_path = 353 + 100 + 24 + (s->textured_materials ? sizeof(TexOut) : 0);   // queues and path state (double-buffered since round 3: + 100), sort keys and order (24)
-            max_paths = std::max<size_t>(4u << 20, std::min<size_t>(max_paths, total_b / 10 * 3 / per_path));
+            size_t held = 0;
+            for (DevBuf* b : chunk_bufs()) held += b->bytes;
+            const size_t rec_need = (size_t)n_px * spp * 20, rec_have = w.d_recL.bytes + w.d_recpy.bytes;
+            size_t avail = free_b / 10 * 8 + held;   // what this context holds already counts as available to it; other contexts on the card (repeated-ordinal handles, other ranks) keep theirs
+            avail = avail > (rec_need > rec_have ? rec_need - rec_have : 0) ? avail - (rec_need > rec_have ? rec_need - rec_have : 0) : 0;
+            max_paths = std::max<size_t>(1u << 20, std::min<size_t>(max_paths, std::min(total_b / 10 * 3, avail) / per_path));
         }
     }
     if (const char* e = std::getenv("PBRT_HIP_MAX_PATHS")) { long long v = std::atoll(e); if (v > 0) max_paths = (size_t)v; }
     uint32_t chunk_spp = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, max_paths / std::max<uint32_t>(n_px, 1)));
-    const size_t B = (size_t)n_px * chunk_spp;
-    if (B >= 0x7FFF0000ull) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: tile range too large for one rank; use more tile_parts");
     const int n_iter = max_depth + 1;
     // Material "none" surfaces are passed through without counting a bounce, so a path may need more rounds than max_depth + 1: those are
     // run one at a time while paths remain (host reads the live count), up to kMaxNullSkips more.
     const int kMaxNullSkips = 1024;
     const int n_iter_cap = s->has_none_material ? n_iter + kMaxNullSkips : n_iter;
-
-    if ((rc = ensure_buf(s, w.d_rays_cl[0], 2 * B * sizeof(ph::RayIn)))) return rc;
-    if ((rc = ensure_buf(s, w.d_rays_cl[1], 2 * B * sizeof(ph::RayIn)))) return rc;
-    if ((rc = ensure_buf(s, w.d_hits, 2 * B * sizeof(ph::HitOut)))) return rc;
-    if ((rc = ensure_buf(s, w.d_rays_sh, B * sizeof(ph::RayIn)))) return rc;
-    if ((rc = ensure_buf(s, w.d_occ, B))) return rc;
-    if ((rc = ensure_buf(s, w.d_live[0], B * 4))) return rc;
-    if ((rc = ensure_buf(s, w.d_live[1], B * 4))) return rc;
+    static const int sort_mode = []() { const char* e = std::getenv("PBRT_HIP_SORT_RAYS"); int v = e ? std::atoi(e) : 1; return (v < 0 || v > 2) ? 1 : v; }();
     if ((rc = ensure_buf(s, w.d_ctr, (size_t)(n_iter_cap + 2) * sizeof(ph::IterCounters)))) return rc;
     if ((rc = ensure_buf(s, w.d_stats, sizeof(ph::DevStats)))) return rc;
-    for (DevBuf* b : {&w.d_sL, &w.d_sbeta, &w.d_sA, &w.d_sf2, &w.d_sbold, &w.d_sidx})
-        if ((rc = ensure_buf(s, *b, 2 * B * 16))) return rc;   // two buffers each: queue-ordered, read from one and written to the other (WfParams)
-    if ((rc = ensure_buf(s, w.d_sprev, 2 * B * 4))) return rc;
     if ((rc = ensure_buf(s, w.d_recL, (size_t)n_px * spp * 16))) return rc;
     if ((rc = ensure_buf(s, w.d_recpy, (size_t)n_px * spp * 4))) return rc;
+    auto alloc_chunk = [&](size_t Bc) -> int {
+        int r;
+        if ((r = ensure_buf(s, w.d_rays_cl[0], 2 * Bc * sizeof(ph::RayIn)))) return r;
+        if ((r = ensure_buf(s, w.d_rays_cl[1], 2 * Bc * sizeof(ph::RayIn)))) return r;
+        if ((r = ensure_buf(s, w.d_hits, 2 * Bc * sizeof(ph::HitOut)))) return r;
+        if ((r = ensure_buf(s, w.d_rays_sh, Bc * sizeof(ph::RayIn)))) return r;
+        if ((r = ensure_buf(s, w.d_occ, Bc))) return r;
+        if ((r = ensure_buf(s, w.d_live[0], Bc * 4))) return r;
+        if ((r = ensure_buf(s, w.d_live[1], Bc * 4))) return r;
+        for (DevBuf* b : {&w.d_sL, &w.d_sbeta, &w.d_sA, &w.d_sf2, &w.d_sbold, &w.d_sidx})
+            if ((r = ensure_buf(s, *b, 2 * Bc * 16))) return r;   // two buffers each: queue-ordered, read from one and written to the other (WfParams)
+        if ((r = ensure_buf(s, w.d_sprev, 2 * Bc * 4))) return r;
+        if (sort_mode) {
+            if ((r = ensure_buf(s, w.d_order, 3 * Bc * 4))) return r;
+            if ((r = ensure_buf(s, w.d_keys_cl, 2 * Bc * 4))) return r;
+            if ((r = ensure_buf(s, w.d_keys_sh, Bc * 4))) return r;
+        }
+        if (s->textured_materials && (r = ensure_buf(s, w.d_tex_out, Bc * sizeof(TexOut)))) return r;
+        return PBRT_HIP_OK;
+    };
+    // the estimate above can be wrong (fragmentation, another context allocating meanwhile): on hipErrorOutOfMemory the chunk is halved and tried again before the call gives up
+    for (;;) {
+        if ((size_t)n_px * chunk_spp >= 0x7FFF0000ull) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: tile range too large for one rank; use more tile_parts");
+        rc = alloc_chunk((size_t)n_px * chunk_spp);
+        if (rc == PBRT_HIP_OK) break;
+        if (rc != PBRT_HIP_ERR_OOM || chunk_spp == 1) return rc;
+        for (DevBuf* b : chunk_bufs()) if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->bytes = 0; }
+        chunk_spp = (chunk_spp + 1) / 2;
+    }
+    const size_t B = (size_t)n_px * chunk_spp;
 
     if ((rc = ensure_traversal_workspace(s))) return rc;
     // ray binning between rounds and per-XCD queue heads (raysort.h, traverse.h)
-    static const int sort_mode = []() { const char* e = std::getenv("PBRT_HIP_SORT_RAYS"); int v = e ? std::atoi(e) : 1; return (v < 0 || v > 2) ? 1 : v; }();
     static const int n_heads = []() { const char* e = std::getenv("PBRT_HIP_TRAV_HEADS"); int v = e ? std::atoi(e) : 8; return (v < 1 || v > 8) ? 8 : v; }();
     static const int sort_blocks = []() { const char* e = std::getenv("PBRT_HIP_SORT_BLOCKS"); int v = e ? std::atoi(e) : 1024; return (v < 64 || v > 8192) ? 1024 : v; }();
     static const int head_chunk = []() { const char* e = std::getenv("PBRT_HIP_HEAD_CHUNK"); int v = e ? std::atoi(e) : 49152; return (v < 1024 || v > (1 << 24) || (v & 1023)) ? 49152 : v; }();  // a multiple of every batch size
     ph::RaySortParams sortp{};
     ph::RaySortGrid sort_grid{};
     if (sort_mode) {
-        if ((rc = ensure_buf(s, w.d_order, 3 * B * 4))) return rc;
-        if ((rc = ensure_buf(s, w.d_keys_cl, 2 * B * 4))) return rc;
-        if ((rc = ensure_buf(s, w.d_keys_sh, B * 4))) return rc;
         if ((rc = ensure_buf(s, w.d_sort_bins, 2 * PH_SORT_KEYS * 4))) return rc;
         sortp.order = (uint32_t*)w.d_order.p; sortp.bin_start = (uint32_t*)w.d_sort_bins.p; sortp.bin_cursor = sortp.bin_start + PH_SORT_KEYS;
         sortp.keys_cl = (const uint32_t*)w.d_keys_cl.p; sortp.keys_sh = (const uint32_t*)w.d_keys_sh.p;
@@ -1017,10 +1049,7 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     // general materials with per-hit textures keep PH_HIT_LOBES LobeRec slots per thread of the grid: a smaller grid (each block loops more) bounds that buffer
     const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, (s->textured_materials && s->general_materials) ? 256 * 4 : 256 * 16);
     wp.hit_lobes = nullptr; wp.tex_out = nullptr;
-    if (s->textured_materials) {
-        if ((rc = ensure_buf(s, w.d_tex_out, (size_t)B * sizeof(TexOut)))) return rc;
-        wp.tex_out = (TexOut*)w.d_tex_out.p;
-    }
+    if (s->textured_materials) wp.tex_out = (TexOut*)w.d_tex_out.p;
     if (s->textured_materials && s->general_materials) {
         if ((rc = ensure_buf(s, w.d_hit_lobes, (size_t)shade_blocks * PH_SHADE_BLOCK * PH_HIT_LOBES * sizeof(LobeRec)))) return rc;
         wp.hit_lobes = (LobeRec*)w.d_hit_lobes.p;
