@@ -216,7 +216,11 @@ enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2, PBRT
 int pbrt_hip_set_material_texture(PbrtHipScene*, uint32_t material, int param, uint32_t texture);
 /* Scalar parameters as float textures, evaluated at every hit: fparam 0 = MatteMaterial's sigma (matte.rs:64-70: Lambert where it evaluates to 0, Oren-Nayar elsewhere),
  * 1 / 2 = u / v roughness of the Trowbridge-Reitz distribution of plastic, uber, substrate, translucent and metal (remapped per hit if the material was created with remap_roughness;
- * plastic's and translucent's single `roughness`: set both), and of glass, whose lobe structure switches per hit on `urough == 0 && vrough == 0` (glass.rs:110-141). */
+ * plastic's and translucent's single `roughness`: set both), and of glass, whose lobe structure switches per hit on `urough == 0 && vrough == 0` (glass.rs:110-141);
+ * 3 = `index` of GlassMaterial and UberMaterial (glass.rs:102, uber.rs:128): the hit's index of refraction, taken as the texture gives it, for FresnelSpecular, the
+ * FresnelDielectric(1, index) of the reflection lobes, the transmission lobes and — uber — BSDF::eta; an uber's constant opacity then becomes a per-hit constant as well.
+ * (TranslucentMaterial's `reflect` / `transmit` stay constants: where both textures are black the reference makes NO BSDF for that hit, translucent.rs:70-73, which the
+ * wavefront's fixed per-material "none" handling cannot express per hit.) */
 int pbrt_hip_set_material_float_texture(PbrtHipScene*, uint32_t material, int fparam, uint32_t texture);
 /* Bump mapping: Material::bump (core/src/material.rs:62-101) with the float texture `texture` as displacement, run before the BSDF of a hit is made
  * (every material's `bumpmap` parameter).  Not for Material "none".  Set it before the material becomes a child of a mix. */

@@ -687,8 +687,23 @@ int oracle_set_last_mesh_alpha_textures(OracleScene* s, uint32_t alpha_tex, uint
     if (shadow_alpha_tex != 0xFFFFFFFFu) m.shadow_alpha_tex = (int)shadow_alpha_tex;
     return 0;
 }
-int oracle_set_material_float_texture(OracleScene* s, uint32_t material, int fparam, uint32_t texture) {  // 0 sigma, 1 uroughness, 2 vroughness
-    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || fparam < 0 || fparam > 2) return -1;
+int oracle_set_material_float_texture(OracleScene* s, uint32_t material, int fparam, uint32_t texture) {  // 0 sigma, 1 uroughness, 2 vroughness, 3 index
+    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || fparam < 0 || fparam > 3) return -1;
+    if (fparam == 3) {   // glass.rs:102, uber.rs:128
+        if (s->sc.materials[material].made_as != 1 && s->sc.materials[material].made_as != 2) return -6;
+        if (s->sc.materials[material].made_as == 1 && s->sc.materials[material].opacity_tex < 0) {   // uber: everything about the hit's lobe list becomes per hit (as in the reference)
+            const Material mq = s->sc.materials[material];
+            const float op[3] = {mq.has_pre ? mq.pre.c[0] : 1.0f, mq.has_pre ? mq.pre.c[1] : 1.0f, mq.has_pre ? mq.pre.c[2] : 1.0f};
+            uint32_t op_tex = 0;
+            if (oracle_add_texture_constant(s, op, &op_tex) != 0) return -1;
+            const int rc = oracle_set_material_texture(s, material, 4, op_tex);
+            if (rc) return rc;
+        }
+        Material& mi = s->sc.materials[material];
+        if (mi.lobes.empty()) return -6;
+        mi.index_tex = (int)texture; mi.textured = true;
+        return 0;
+    }
     Material& m = s->sc.materials[material];
     if (fparam == 0) {
         if (m.general || m.none || m.lobes.size() != 1 || !(m.lobes[0].kind == LK_LAMBERT || m.lobes[0].kind == LK_OREN)) return -6;

@@ -1182,8 +1182,10 @@ struct Renderer {
             if (m.amount_tex >= 0) { s1 = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, m.amount_tex, c)); s2 = spec_clamp0(Spec(1.0f) - s1); }   // mix.rs:59-60
             if (m.opacity_tex >= 0) op = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, m.opacity_tex, c));                                        // uber.rs:126
             bool passthrough = false;
+            const Float e_hit = m.index_tex >= 0 ? tex_eval(sc->textures, sc->mipmaps, m.index_tex, c).c[0] : 0.0f;   // glass.rs:102 / uber.rs:128
             for (const Lobe& tl : m.lobes) {
                 Lobe l = tl;
+                if (m.index_tex >= 0 && l.pre_mode != 4 && (l.kind == LK_FRESNEL_SPEC || l.fresnel == FR_DIEL)) l.eta_b = e_hit;   // every dielectric lobe but the opacity pass-through (built with 1, 1: uber.rs:134)
                 if (l.sigma_tex >= 0) {  // matte.rs:64-70 + OrenNayar::new (oren_nayar.rs:28-39)
                     Float sig = pclamp(tex_eval(sc->textures, sc->mipmaps, l.sigma_tex, c).c[0], 0.0f, 90.0f);
                     if (sig == 0.0f) { l.kind = LK_LAMBERT; l.a = 0.0f; l.b = 0.0f; }
@@ -1222,7 +1224,7 @@ struct Renderer {
                                 : ((l.kind == LK_SPEC_T || l.kind == LK_MICRO_T || l.kind == LK_LAMBERT_T) ? !l.t.is_black() : !l.r.is_black());
                 if (keep) { if (l.pre_mode == 4) passthrough = true; local[k++] = l; }
             }
-            if (m.opacity_tex >= 0 && m.made_as == 1) b.eta = passthrough ? 1.0f : m.bsdf_eta_alt;   // uber.rs:128-137
+            if (m.opacity_tex >= 0 && m.made_as == 1) b.eta = passthrough ? 1.0f : (m.index_tex >= 0 ? e_hit : m.bsdf_eta_alt);   // uber.rs:128-137
             b.lobes = local; b.n = k;
         }
         return b;

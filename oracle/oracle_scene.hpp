@@ -58,6 +58,7 @@ struct Material {
     int param_lobe2[4] = {-1, -1, -1, -1}, param_field2[4] = {0, 0, 0, 0};  // a second lobe fed by the same parameter (translucent: the reflection and the transmission lobe)
     int rough_lobe = -1, rough_lobe2 = -1; bool rough_remap = false;   // the lobe(s) that own the Trowbridge-Reitz distribution (set_material_float_texture)
     bool has_pre = false; Spec pre;
+    int index_tex = -1;     // GlassMaterial / UberMaterial: `index` is a float texture, evaluated at every hit (glass.rs:102, uber.rs:128)
     int opacity_tex = -1;   // UberMaterial's opacity is a texture: which lobes a hit gets, their colours and BSDF::eta are decided per hit
     Float bsdf_eta_alt = 1.0f;  // ... BSDF::eta where the pass-through lobe is NOT added (uber.rs:136)
     int amount_tex = -1;    // MixMaterial's amount is a texture

@@ -112,6 +112,7 @@ int upload_scene(PbrtHipScene* s) {
                 if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1 || l.alt || l.has_pre == PH_PRE_RAW_TEST) hdr = true;
             }
             if (m.sigma_tex1 || hdr) cols = std::max(cols, 2u);   // the per-hit scalars travel in the fourth component of the first two colour slots
+            if (m.index_tex1) cols = std::max(cols, 3u);          // ... the per-hit index of refraction in the third one's
             m.tex_cols = std::min<uint32_t>(cols, PH_HIT_COLS); m.tex_hdr = hdr ? 1u : 0u;
         }
         s->alpha_lean = s->alpha_textures;
@@ -680,6 +681,7 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
     // lobe, the second one's changes nothing that is used
     m.bump_tex1 = a.bump_tex1;
     if (a.amount_tex1 || b.amount_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a sub-material is a mix whose amount is a texture; not supported");
+    if (a.index_tex1 || b.index_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a sub-material with a textured index of refraction is not supported");
     if (a.opacity_tex1 && b.opacity_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: both sub-materials are uber materials with opacity textures; not supported");
     m.opacity_tex1 = a.opacity_tex1 ? a.opacity_tex1 : b.opacity_tex1;
     if (a.n_lobes + b.n_lobes > 8) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "add_material_mix: more than MAX_BXDFS = 8 lobes (BSDF::add asserts, bsdf.rs:119-125)");

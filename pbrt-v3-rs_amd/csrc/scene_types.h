@@ -102,13 +102,14 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     uint32_t amount_tex1;  // MixMaterial: 0, or 1 + the `amount` texture (takes the FIRST colour slot of the texture pass)
     float bsdf_eta_alt;    // UberMaterial with an opacity texture: BSDF::eta of the hits that do not get the pass-through lobe (uber.rs:128-137)
     uint32_t uber_eta;     // 1: this material IS that uber (a mix holding one keeps eta 1)
+    uint32_t index_tex1;   // GlassMaterial / UberMaterial: 0, or 1 + the float texture behind `index` (glass.rs:102, uber.rs:128): the dielectric lobes' eta of a hit (TexOut::col[2][3])
     uint32_t tex_cols;     // colour slots of TexOut the texture pass fills for this material (set at upload)
     uint32_t tex_hdr;      // the shade pass reads TexOut's header (bumped frame, per-hit scalars, lambert / glass / raw-black bits) for this material; else only the colours are written
 };
 // What the texture pass hands the shade pass for one path vertex (wavefront.hip: texture_kernel): the bumped shading frame and the evaluated,
 // clamped (and pre-multiplied) colours of the material's textured lobe colours, in template-lobe order (r before t).
 #define PH_HIT_COLS 6
-struct TexOut { float ns[3]; uint32_t bumped; float dpdu_s[3]; uint32_t lambert; float col[PH_HIT_COLS][4]; };  // 128 B; col[0][3], col[1][3]: the per-hit (alpha_x, alpha_y) or Oren-Nayar (A, B); lambert: sigma evaluated to 0; bumped bit 8 + k: colour k's texel was black before its PH_PRE_RAW_TEST product
+struct TexOut { float ns[3]; uint32_t bumped; float dpdu_s[3]; uint32_t lambert; float col[PH_HIT_COLS][4]; };  // 128 B; col[0][3], col[1][3]: the per-hit (alpha_x, alpha_y) or Oren-Nayar (A, B); col[2][3]: the per-hit index of refraction; lambert: sigma evaluated to 0; bumped bit 8 + k: colour k's texel was black before its PH_PRE_RAW_TEST product
 #define PH_HIT_LOBES 8   // per-thread slots for the per-hit lobe list of a textured material (= MAX_BXDFS, bsdf.rs:22: uber has up to 5, a mix up to 8)
 
 // ---- textures (textures/src/*.rs, core/src/mipmap/mod.rs).  A texture is a postfix program over a small value stack: the host

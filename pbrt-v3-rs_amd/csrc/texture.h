@@ -549,6 +549,7 @@ template <bool SIMPLE = false>
 PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const MaterialRec& mr, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, TexOut& out) {
     uint32_t k = 0;
     auto put = [&](spec c) { if (k < PH_HIT_COLS) { out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++; } };
+    if (mr.index_tex1) out.col[2][3] = tex_eval<SIMPLE>(dsc, mr.index_tex1 - 1u, ctx).r;                         // glass.rs:102 / uber.rs:128: as the texture gives it
     if (mr.amount_tex1) put(tex_eval_clamped<SIMPLE>(dsc, mr.amount_tex1 - 1u, ctx));                           // mix.rs:59: s1 (s2 is made from it in the shade pass)
     spec op = mks1(1.0f);
     if (mr.opacity_tex1) op = tex_eval_clamped<SIMPLE>(dsc, mr.opacity_tex1 - 1u, ctx);                          // uber.rs:126
@@ -588,6 +589,8 @@ PH_DEV uint32_t build_hit_lobes(const MaterialRec& mr, const LobeRec* tmpl, uint
         LobeRec l = tmpl[i];
         if (l.sigma_tex1) { l.kind = (hdr_lambert & 1u) ? PH_LK_LAMBERT : PH_LK_OREN; l.a = in->col[0][3]; l.b = in->col[1][3]; }
         if (l.ax_tex1 || l.ay_tex1) { l.ax = in->col[0][3]; l.ay = in->col[1][3]; }
+        // the hit's index of refraction: FresnelSpecular / FresnelDielectric(1, eta) / the transmission lobes (glass.rs:113-139, uber.rs:145-176) — not the opacity pass-through, which is built with (1, 1)
+        if (mr.index_tex1 && l.has_pre != PH_PRE_PASSTHROUGH && (l.kind == PH_LK_FRESNEL_SPEC || l.fresnel == PH_FR_DIEL)) l.eta_b = in->col[2][3];
         bool raw_black = false;
         if (lobe_slot_r(l) && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; raw_black = raw_black || ((hdr_bumped >> (8u + ci)) & 1u); ci++; }
         if (lobe_slot_t(l) && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; raw_black = raw_black || ((hdr_bumped >> (8u + ci)) & 1u); ci++; }
@@ -602,7 +605,7 @@ PH_DEV uint32_t build_hit_lobes(const MaterialRec& mr, const LobeRec* tmpl, uint
         // TranslucentMaterial's lobes: the texel decided (an untextured one exists because its constant passed the test when the material was made)
         if (l.has_pre == PH_PRE_RAW_TEST ? !raw_black : lobe_keep(l)) { if (l.has_pre == PH_PRE_PASSTHROUGH) passthrough = true; out[k++] = l; }
     }
-    if (mr.uber_eta) eta_out = passthrough ? 1.0f : mr.bsdf_eta_alt;
+    if (mr.uber_eta) eta_out = passthrough ? 1.0f : (mr.index_tex1 ? in->col[2][3] : mr.bsdf_eta_alt);
     return k;
 }
 

@@ -364,7 +364,26 @@ int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param,
 int pbrt_hip_set_material_float_texture(PbrtHipScene* s, uint32_t material, int fparam, uint32_t texture) {
     return ph_guard(s, "pbrt_hip_set_material_float_texture", [&]() -> int {
     if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_float_texture: unknown material or texture");
-    if (fparam < 0 || fparam > 2) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_float_texture: fparam must be 0 sigma, 1 uroughness or 2 vroughness");
+    if (fparam < 0 || fparam > 3) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_float_texture: fparam must be 0 sigma, 1 uroughness, 2 vroughness or 3 index");
+    if (fparam == 3) {   // `let eta = self.index.evaluate(..)` (glass.rs:102) / `let e = self.index.evaluate(..)` (uber.rs:128): every dielectric lobe of the hit takes it
+        const int made_as = s->material_params[material].made_as;
+        if (made_as != 1 && made_as != 2) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_float_texture: index belongs to GlassMaterial and UberMaterial");
+        if (made_as == 1 && !s->materials[material].opacity_tex1) {
+            // UberMaterial decides BSDF::eta and the pass-through lobe per hit once anything about them is per hit: the constant opacity becomes a constant texture (same values at every hit)
+            const PbrtHipScene::MaterialParams mq = s->material_params[material];
+            const float one[3] = {1.0f, 1.0f, 1.0f};
+            uint32_t op_tex = 0;
+            int rc = pbrt_hip_add_texture_constant(s, mq.has_pre ? mq.pre : one, &op_tex);
+            if (rc == PBRT_HIP_OK) rc = pbrt_hip_set_material_texture(s, material, PBRT_HIP_PARAM_OPACITY, op_tex);
+            if (rc) return rc;
+        }
+        MaterialRec& mi = s->materials[material];
+        if (mi.n_lobes == 0) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_float_texture: this material has no lobe (black Kr and Kt)");
+        mi.index_tex1 = texture + 1u; mi.textured = 1u;
+        s->textured_materials = true; s->general_materials = true;
+        s->uploaded = false;
+        return PBRT_HIP_OK;
+    }
     MaterialRec& m = s->materials[material];
     const PbrtHipScene::MaterialParams& mp = s->material_params[material];
     if (fparam == 0) {

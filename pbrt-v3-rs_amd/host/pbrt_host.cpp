@@ -480,7 +480,7 @@ void Api::pbrt_area_light_source(const std::string& name, const ParamSet& p) { i
 uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::array<float, 3> kd = {0.5f, 0.5f, 0.5f};
     float sigma = 0.0f;
-    int64_t ftex_param[3] = {-1, -1, -1};     // [sigma, uroughness, vroughness]: the same for float parameters
+    int64_t ftex_param[4] = {-1, -1, -1, -1};     // [sigma, uroughness, vroughness, index]: the same for float parameters
     int64_t tex_param[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // [Kd, Ks, Kr, Kt, opacity, amount, eta, k]: the parameter names a texture the library evaluates per hit
     auto spectrum_tex = [&](const std::string& pname, std::array<float, 3> d) {
         std::string tn = m.params.find_one_texture(pname);
@@ -514,9 +514,9 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
             auto dtf = gs_.device_textures.find(tn);
             if (dtf != gs_.device_textures.end()) {
                 // a float texture the library evaluates per hit: sigma (matte) or the microfacet roughness (plastic, uber, substrate, metal, translucent)
-                const int fp = pname == "sigma" ? 0 : ((pname == "uroughness" || pname == "roughness") ? 1 : (pname == "vroughness" ? 2 : -1));
-                const bool takes = dtf->second.is_float && ((m.type == "matte" && fp == 0) || ((m.type == "plastic" || m.type == "uber" || m.type == "substrate" || m.type == "metal" || m.type == "translucent") && fp > 0) ||
-                                                            (m.type == "glass" && fp > 0 && pname != "roughness"));
+                const int fp = pname == "sigma" ? 0 : ((pname == "uroughness" || pname == "roughness") ? 1 : (pname == "vroughness" ? 2 : (pname == "index" ? 3 : -1)));
+                const bool takes = dtf->second.is_float && ((m.type == "matte" && fp == 0) || ((m.type == "plastic" || m.type == "uber" || m.type == "substrate" || m.type == "metal" || m.type == "translucent") && (fp == 1 || fp == 2)) ||
+                                                            (m.type == "glass" && (fp == 1 || fp == 2) && pname != "roughness") || ((m.type == "glass" || m.type == "uber") && fp == 3));
                 if (!takes) {
                     if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit float textures are wired to matte sigma and to the roughness of plastic / uber / substrate / metal / translucent / glass";
                     return m.params.find_one_float(pname, d);
@@ -565,8 +565,10 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     auto eta_of = [&]() {
         auto named = gs_.float_textures.find("eta");
         if (named != gs_.float_textures.end()) return named->second;   // a constant float texture that happens to be called "eta"
-        if (gs_.device_textures.count("eta") || gs_.unsupported_textures.count("eta")) {
-            if (error.empty()) error = "Material \"" + m.type + "\": the float texture named \"eta\" would set the index of refraction per hit (glass.rs:158), which the library does not evaluate";
+        auto dev = gs_.device_textures.find("eta");
+        if (dev != gs_.device_textures.end() && dev->second.is_float) { ftex_param[3] = (int64_t)dev->second.id; return 1.5f; }   // the float texture NAMED "eta": the index of refraction of every hit (glass.rs:158-161)
+        if (dev != gs_.device_textures.end() || gs_.unsupported_textures.count("eta")) {
+            if (error.empty()) error = "Material \"" + m.type + "\": the texture named \"eta\" would set the index of refraction per hit (glass.rs:158), but it is not a float texture the library evaluates";
             return 1.5f;
         }
         if (m.params.floats.count("eta") || !m.params.find_one_texture("eta").empty())
@@ -627,7 +629,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::string key = t + (remap ? ":r" : ":n");
     for (float v : kv) { uint32_t u; std::memcpy(&u, &v, 4); char b[12]; std::snprintf(b, sizeof b, ":%08x", u); key += b; }
     if (bump_tex >= 0) key += "|bump=" + std::to_string(bump_tex);
-    for (int k = 0; k < 3; k++) if (ftex_param[k] >= 0) key += "|ftex" + std::to_string(k) + "=" + std::to_string(ftex_param[k]);
+    for (int k = 0; k < 4; k++) if (ftex_param[k] >= 0) key += "|ftex" + std::to_string(k) + "=" + std::to_string(ftex_param[k]);
     for (int k = 0; k < 8; k++) if (tex_param[k] >= 0) key += "|tex" + std::to_string(k) + "=" + std::to_string(tex_param[k]);
     auto it = material_cache_.find(key);
     if (it != material_cache_.end()) return it->second;
@@ -651,6 +653,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
         if (ftex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_float_texture(scene_, id, k, (uint32_t)ftex_param[k])), "set_material_float_texture")) return 0;
     for (int k = 4; k < 8; k++)
         if (tex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_texture(scene_, id, k, (uint32_t)tex_param[k])), "set_material_texture")) return 0;
+    if (ftex_param[3] >= 0 && !check(ABI(pbrt_hip_set_material_float_texture(scene_, id, 3, (uint32_t)ftex_param[3])), "set_material_float_texture")) return 0;   // index: after opacity (an uber's is made per hit with it)
     if (bump_tex >= 0 && !check(ABI(pbrt_hip_set_material_bump(scene_, id, (uint32_t)bump_tex)), "set_material_bump")) return 0;
     material_cache_[key] = id;
     return id;

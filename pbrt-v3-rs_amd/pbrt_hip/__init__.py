@@ -611,10 +611,10 @@ class Scene:
         none = 0xFFFFFFFF
         self._chk(self.b.fn("set_last_mesh_alpha_textures")(self.h, none if alpha is None else alpha, none if shadow_alpha is None else shadow_alpha))
 
-    FPARAM = {"sigma": 0, "uroughness": 1, "vroughness": 2}
+    FPARAM = {"sigma": 0, "uroughness": 1, "vroughness": 2, "index": 3}
 
     def set_material_float_texture(self, material, fparam, texture):
-        """fparam: "sigma" (matte) | "uroughness" | "vroughness" | "roughness" (= both) — that scalar of `material` becomes the float texture, evaluated per hit."""
+        """fparam: "sigma" (matte) | "uroughness" | "vroughness" | "roughness" (= both) | "index" (glass, uber) — that scalar of `material` becomes the float texture, evaluated per hit."""
         for f in (("uroughness", "vroughness") if fparam == "roughness" else (fparam,)):
             self._chk(self.b.fn("set_material_float_texture")(self.h, material, self.FPARAM[f], texture))
 

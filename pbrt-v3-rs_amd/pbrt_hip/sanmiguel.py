@@ -264,6 +264,10 @@ class SanMiguelScene:
         T["fabric"] = s.add_texture_imagemap(s.add_mipmap(im["fabric"], gamma=True), su=3.0, sv=3.0)
         T["bronze"] = s.add_texture_imagemap(s.add_mipmap(im["bronze"]))
         T["leaf_alpha"] = s.add_texture_imagemap(s.add_mipmap(im["leaf_alpha"], as_float=True, trilinear=True, wrap="clamp"))
+        import os
+        if os.environ.get("PBRT_SM_SIMPLE_TEXTURES"):   # measurement aid: the procedural textures replaced by image maps / constants (how much of the texture pass is theirs?)
+            T["fbm_h"] = T["wrinkled_h"] = T["tiles_h"]; T["marble"] = T["plaster"]; T["checker"] = T["tiles"]; T["dots"] = T["fabric"]
+            return self._finish_materials(s, T)
         sc = np.diag([18.0, 18.0, 18.0, 1.0]).astype(np.float32).reshape(16)
         T["fbm_h"] = s.add_texture_scale(s.add_texture_fbm(sc, 0.5, 4), s.add_texture_constant(0.003))
         T["wrinkled_h"] = s.add_texture_scale(s.add_texture_fbm(sc, 0.6, 5, wrinkled=True), s.add_texture_constant(0.004))
@@ -273,6 +277,9 @@ class SanMiguelScene:
         T["marble"] = s.add_texture_mix(stone, s.add_texture_constant((0.7, 0.68, 0.62)), s.add_texture_scale(s.add_texture_windy(np.diag([3.0, 3.0, 3.0, 1.0]).astype(np.float32).reshape(16)), s.add_texture_constant(0.5)))
         T["checker"] = s.add_texture_checkerboard(s.add_texture_constant((0.8, 0.8, 0.75)), s.add_texture_constant((0.15, 0.2, 0.3)), su=6.0, sv=6.0)
         T["dots"] = s.add_texture_dots(s.add_texture_constant((0.9, 0.3, 0.2)), s.add_texture_constant((0.9, 0.85, 0.7)), su=5.0, sv=5.0)
+        return self._finish_materials(s, T)
+
+    def _finish_materials(self, s, T):
         M = {}
         M["floor"] = s.add_material_matte_tex(T["tiles"], 0.0); s.set_material_bump(M["floor"], T["tiles_h"])
         M["wall"] = s.add_material_matte_tex(T["plaster"], 20.0); s.set_material_bump(M["wall"], T["fbm_h"])

@@ -62,11 +62,22 @@ def mix(amount, textured=None, bump_first=False, bump_second=False):
     return make
 
 
-def glass(ur, vr, utex=None, vtex=None, remap=True):
+def glass(ur, vr, utex=None, vtex=None, remap=True, eta=1.5, index_tex=None):
     def make(sc):
-        m = sc.add_material_glass((0.9, 0.9, 0.9), (0.8, 0.85, 0.9), ur, vr, 1.5, remap)
+        m = sc.add_material_glass((0.9, 0.9, 0.9), (0.8, 0.85, 0.9), ur, vr, eta, remap)
         if utex is not None: sc.set_material_float_texture(m, "uroughness", utex(sc))
         if vtex is not None: sc.set_material_float_texture(m, "vroughness", vtex(sc))
+        if index_tex is not None: sc.set_material_float_texture(m, "index", index_tex(sc))   # glass.rs:102: `let eta = self.index.evaluate(..)`
+        return m
+    return make
+
+
+def uber_index(opacity, eta, index_tex=None, opacity_tex=None):
+    """UberMaterial whose index of refraction (uber.rs:128) is the constant `eta` or a texture; Kt non-black so that BSDF::eta matters."""
+    def make(sc):
+        m = sc.add_material_uber((0.4, 0.35, 0.3), (0.3, 0.3, 0.3), (0.25, 0.25, 0.25), (0.5, 0.55, 0.6), ONE if opacity_tex is not None else opacity, 0.1, 0.2, eta, True)
+        if opacity_tex is not None: sc.set_material_texture(m, "opacity", opacity_tex(sc))
+        if index_tex is not None: sc.set_material_float_texture(m, "index", index_tex(sc))
         return m
     return make
 
@@ -95,6 +106,12 @@ PINS = [   # (name, constant material, the same through a constant texture)
     ("glass rough", glass(0.2, 0.1), glass(0.0, 0.0, const(0.2), const(0.1))),
     ("glass u texture only", glass(0.25, 0.1), glass(0.0, 0.1, const(0.25), None)),
     ("glass rough, no remap", glass(0.2, 0.1, remap=False), glass(0.0, 0.0, const(0.2), const(0.1), remap=False)),
+    ("glass smooth, index 1.7", glass(0.0, 0.0, eta=1.7), glass(0.0, 0.0, index_tex=const(1.7))),
+    ("glass rough, index 1.33", glass(0.2, 0.1, eta=1.33), glass(0.2, 0.1, index_tex=const(1.33))),
+    ("glass roughness textures + index", glass(0.2, 0.1, eta=1.8), glass(0.0, 0.0, const(0.2), const(0.1), index_tex=const(1.8))),
+    ("uber index 1.7, opacity 1", uber_index(ONE, 1.7), uber_index(ONE, 1.5, const(1.7))),
+    ("uber index 1.3, opacity 0.6", uber_index((0.6, 0.6, 0.6), 1.3), uber_index((0.6, 0.6, 0.6), 1.5, const(1.3))),
+    ("uber index 1.3, opacity texture", uber_index((0.7, 0.5, 0.9), 1.3), uber_index(None, 1.5, const(1.3), const((0.7, 0.5, 0.9)))),
     ("metal eta k", metal((0.2, 0.9, 1.1), (3.9, 2.4, 2.1)), metal(ONE, ONE, const((0.2, 0.9, 1.1)), const((3.9, 2.4, 2.1)))),
     ("metal k only", metal((0.2, 0.9, 1.1), (3.9, 2.4, 2.1)), metal((0.2, 0.9, 1.1), ONE, None, const((3.9, 2.4, 2.1)))),
 ]
@@ -110,6 +127,10 @@ TEXTURED = [   # genuinely varying parameters: device against oracle
     ("glass u checker, v constant 0", glass(0.0, 0.0, checker(0.0, 0.3, 4.0), None)),
     ("glass roughness image", glass(0.1, 0.1, image(9, 0.4), image(10, 0.4))),
     ("metal eta k images", metal(ONE, ONE, image(11, 2.0), image(12, 4.0))),
+    ("glass index checker 1.2 / 1.9", glass(0.0, 0.0, index_tex=checker(1.2, 1.9))),
+    ("glass rough, index image", glass(0.15, 0.1, index_tex=lambda sc: sc.add_texture_mix(sc.add_texture_constant(1.1), sc.add_texture_constant(2.2), sc.add_texture_imagemap(sc.add_mipmap(make_image(24, 24, seed=13), as_float=True))))),
+    ("uber index checker, opacity checker", uber_index(None, 1.5, checker(1.25, 1.8, 5.0), checker(ONE, (0.3, 0.4, 0.5), 3.0))),
+    ("uber index image, constant opacity 0.8", uber_index((0.8, 0.8, 0.8), 1.5, lambda sc: sc.add_texture_mix(sc.add_texture_constant(1.2), sc.add_texture_constant(1.9), sc.add_texture_imagemap(sc.add_mipmap(make_image(24, 24, seed=14), as_float=True))))),
 ]
 
 
@@ -160,6 +181,19 @@ def test_device_textured_parameter_films_bit_exact(host, name, mat, instance):
     g = _film(pbrt_hip.Scene, host, mat, depth=5, res=48, instance=instance)
     assert float(o[0].max()) > 0
     assert _same(g, o), f"{name}: {(g[0].view(np.uint32) != o[0].view(np.uint32)).any(axis=2).sum()} pixels differ, counters {g[2]} vs {o[2]}"
+
+
+def test_oracle_checkerboard_index_is_one_of_the_two_constants_per_pixel(host):
+    """A glass floor whose index of refraction is a checkerboard of 1.2 and 1.9, seen at depth 1 with one sample per pixel: a pixel whose sample lands on a square of one
+    kind shows exactly the film of the glass made with that constant (the Fresnel term, and with it the lobe choice and the reflected radiance, depend on the index)."""
+    c = _film(OracleScene, host, glass(0.0, 0.0, index_tex=checker(1.2, 1.9, 2.0)), depth=1, res=32, spp=1)
+    a = _film(OracleScene, host, glass(0.0, 0.0, eta=1.2), depth=1, res=32, spp=1)
+    b = _film(OracleScene, host, glass(0.0, 0.0, eta=1.9), depth=1, res=32, spp=1)
+    eq_a = (c[0].view(np.uint32) == a[0].view(np.uint32)).all(axis=2)
+    eq_b = (c[0].view(np.uint32) == b[0].view(np.uint32)).all(axis=2)
+    single = c[1] == 1.0
+    assert single.sum() > 900 and (eq_a | eq_b)[single].all()
+    assert (eq_a & ~eq_b).any() and (eq_b & ~eq_a).any()
 
 
 @pytest.mark.gpu
