@@ -63,6 +63,7 @@ struct WfParams {
     float4* s_L[2]; float4* s_beta[2]; float4* s_A[2]; float4* s_f2[2]; float4* s_bold[2]; uint4* s_idx[2]; uint32_t* s_prev[2];
     // per-sample records of the whole render: {L.rgb, p_film.x} {p_film.y}
     float4* rec_L; float* rec_py;
+    uint8_t* px_rounded;    // per pixel of the rank's list: some sample's f32 film position rounded UP onto the next pixel's coordinate (film_tiles_kernel looks at those pixels' samples from the neighbour's side too)
     // light sampling: SpatialLightDistribution tables when enabled, else the scene-wide Distribution1D of DeviceScene
     SpatialRec spatial;
     // materials that evaluate a texture per hit (texture.h): device copy of `cam` for the out-of-line evaluation
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
             generate_camera_ray(w.cam, p_film, time, lens, ray);
             w.rec_L[gsi] = make_float4(0.0f, 0.0f, 0.0f, p_film.x);
             w.rec_py[gsi] = p_film.y;
+            if (p_film.x == (float)(xy.x + 1) || p_film.y == (float)(xy.y + 1)) w.px_rounded[pix] = 1u;   // (every writer writes the same byte)
             lens_keep = lens;
         } else {
             w.rec_L[gsi] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0x7fc00000u));  // NaN p_film.x marks "no sample"
@@ -619,6 +621,7 @@ struct FilmParams {
     uint32_t slot_w, slot_h;      // per-tile slot in the tile buffer: slot_w*slot_h float4 {contrib rgb, weight sum}
     uint32_t spp, n_px;
     const float4* rec_L; const float* rec_py;   // [sample][pixel of the rank's pixel list]
+    const uint8_t* px_rounded;                  // pixels with a sample that rounded up onto the next pixel's coordinate (raygen_kernel)
     float4* tile_buf;
 };
 __global__ __launch_bounds__(256) void film_tiles_kernel(FilmParams p) {
@@ -646,7 +649,8 @@ __global__ __launch_bounds__(256) void film_tiles_kernel(FilmParams p) {
         for (int sy = sy0; sy <= sy1; sy++)
             for (int sx = sx0; sx <= sx1; sx++) {
                 const size_t pix = (size_t)t.px_off + (size_t)(sy - t.tb[1]) * tw + (size_t)(sx - t.tb[0]);
-                const bool up_x = sx < sx0n, up_y = sy < sy0n;   // only samples rounded up onto the next column / row matter from here
+                const bool up_x = sx < sx0n, up_y = sy < sy0n;   // only samples rounded up onto the next column / row matter from here ...
+                if ((up_x || up_y) && !p.px_rounded[pix]) continue;   // ... and raygen noted which pixels have any (a few per cent of them at 512 spp)
                 for (uint32_t s = 0; s < p.spp; s++) {
                     const float pfy = p.rec_py[(size_t)s * p.n_px + pix];
                     if (up_y && pfy != (float)(sy + 1)) continue;
@@ -750,7 +754,7 @@ struct Wavefront {
     uint32_t slot_w = 0, slot_h = 0;
     int tiles_key[12] = {0}; bool tiles_valid = false;  // what the lists above (and their device copies) were built for
     DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats, d_cam, d_hit_lobes, d_tex_out;
-    DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_sprev, d_recL, d_recpy, d_tilebuf, d_xyz, d_w;
+    DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_sprev, d_recL, d_recpy, d_rounded, d_tilebuf, d_xyz, d_w;
     DevBuf d_vox_slot, d_sp_pool, d_sp_list, d_sp_ctr, d_sp_halton;  // SpatialLightDistribution tables (spatial.h)
     DevBuf d_order, d_sort_bins, d_heads, d_keys_cl, d_keys_sh;  // ray binning between rounds (raysort.h), per-XCD queue heads
     size_t n_vox = 0;   // voxels of the last spatial render's table (d_vox_slot)
@@ -763,7 +767,7 @@ void free_wavefront(PbrtHipScene* s) {
     Wavefront* w = s->wf;
     if (!w) return;
     for (DevBuf* b : {&w->d_tiles, &w->d_px, &w->d_rays_cl[0], &w->d_rays_cl[1], &w->d_hits, &w->d_rays_sh, &w->d_occ, &w->d_live[0], &w->d_live[1], &w->d_ctr,
-                      &w->d_stats, &w->d_cam, &w->d_hit_lobes, &w->d_tex_out, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_sprev, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
+                      &w->d_stats, &w->d_cam, &w->d_hit_lobes, &w->d_tex_out, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_sprev, &w->d_rounded, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
                       &w->d_vox_slot, &w->d_sp_pool, &w->d_sp_list, &w->d_sp_ctr, &w->d_sp_halton, &w->d_order, &w->d_sort_bins, &w->d_heads, &w->d_keys_cl, &w->d_keys_sh})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : w->events) (void)hipEventDestroy(e);
@@ -949,6 +953,8 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     if ((rc = ensure_buf(s, w.d_stats, sizeof(ph::DevStats)))) return rc;
     if ((rc = ensure_buf(s, w.d_recL, (size_t)n_px * spp * 16))) return rc;
     if ((rc = ensure_buf(s, w.d_recpy, (size_t)n_px * spp * 4))) return rc;
+    if ((rc = ensure_buf(s, w.d_rounded, (size_t)n_px))) return rc;
+    PH_CHECK(s, hipMemsetAsync(w.d_rounded.p, 0, (size_t)n_px, s->stream));
     auto alloc_chunk = [&](size_t Bc) -> int {
         int r;
         if ((r = ensure_buf(s, w.d_rays_cl[0], 2 * Bc * sizeof(ph::RayIn)))) return r;
@@ -1019,7 +1025,7 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
         wp.s_f2[k] = (float4*)w.d_sf2.p + (size_t)k * B; wp.s_bold[k] = (float4*)w.d_sbold.p + (size_t)k * B; wp.s_idx[k] = (uint4*)w.d_sidx.p + (size_t)k * B;
         wp.s_prev[k] = (uint32_t*)w.d_sprev.p + (size_t)k * B;
     }
-    wp.rec_L = (float4*)w.d_recL.p; wp.rec_py = (float*)w.d_recpy.p;
+    wp.rec_L = (float4*)w.d_recL.p; wp.rec_py = (float*)w.d_recpy.p; wp.px_rounded = (uint8_t*)w.d_rounded.p;
     wp.sort_grid = sort_grid; wp.keys_cl = (uint32_t*)w.d_keys_cl.p; wp.keys_sh = (uint32_t*)w.d_keys_sh.p;
 
     if (spatial) { if ((rc = setup_spatial(s, wp.spatial))) return rc; }
@@ -1124,7 +1130,7 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     // ---- film: per-tile accumulation in reference order ---------------------------------------------------------------------------
     ph::FilmParams fp{};
     fp.film = s->film; fp.tiles = (const ph::TileInfo*)w.d_tiles.p; fp.n_tiles = (uint32_t)w.tiles.size();
-    fp.slot_w = w.slot_w; fp.slot_h = w.slot_h; fp.spp = spp; fp.n_px = n_px; fp.rec_L = wp.rec_L; fp.rec_py = wp.rec_py; fp.tile_buf = (float4*)d_tile_buffer;
+    fp.slot_w = w.slot_w; fp.slot_h = w.slot_h; fp.spp = spp; fp.n_px = n_px; fp.rec_L = wp.rec_L; fp.rec_py = wp.rec_py; fp.px_rounded = wp.px_rounded; fp.tile_buf = (float4*)d_tile_buffer;
     const uint64_t film_threads = (uint64_t)fp.n_tiles * w.slot_w * w.slot_h;
     if ((rc = timed(2, [&]() { hipLaunchKernelGGL(ph::film_tiles_kernel, dim3((uint32_t)((film_threads + 255) / 256)), dim3(256), 0, s->stream, fp); }))) return rc;
     PH_CHECK(s, hipEventRecord(e_end, s->stream));
