@@ -6,7 +6,7 @@
 //   K2  Morton codes                           hlbvh.rs:97-135, morton.rs:33-48, :101-118
 //   K3  stable LSD radix sort, 4 x 8 bits      morton.rs:50-98 sorts 5 x 6 bits; any stable sort by the 30-bit code gives the same order
 //   K4  treelet ranges (top 12 code bits)      hlbvh.rs:62-84
-//   K5  emit_lbvh, one thread per treelet      hlbvh.rs:199-294 (the reference also builds treelets independently)
+//   K5  emit_lbvh, one level per launch        hlbvh.rs:199-294 (all treelets side by side; round 3 — rounds 1 - 2 gave each treelet one thread)
 //   --  SAH over the <= 4096 treelet roots     hlbvh.rs:296-432, on the host (bvh_build.cpp: build_upper_sah)
 //   K6  Node64 / TriRec emission               the device layout of scene_types.h; leaves in depth-first order as flatten_bvh_tree leaves them
 //
@@ -151,72 +151,98 @@ __global__ void treelet_start_kernel(const uint32_t* codes, uint32_t n, uint32_t
     start[k] = lo;
 }
 
-// K5: emit_lbvh (hlbvh.rs:199-294) of one treelet per thread: the recursion unrolled over an explicit stack (its depth is bounded by the 18 code bits below the treelet key)
+// K5: emit_lbvh (hlbvh.rs:199-294) for all treelets at once, one LEVEL of the recursion per launch (round 3).  The reference's Morton quirk (B10) leaves a few treelets with
+// millions of primitives; one thread per treelet — rounds 1 - 2 — spent 0.3 s of a 10 M-triangle build walking those alone.  emit_lbvh only ever cuts a sorted range in two
+// at the first index whose code differs in the current bit, so a node is known by its range: every node of a level is decided independently (skip the bits that do not
+// split, leaf or binary search), and what the recursion's order decides — the interior nodes' creation (pre-order) numbers, the boxes — follows from two more sweeps over the
+// levels: bottom-up the boxes and the number of interior nodes below each node, top-down `dense` = the parent's number + 1 (+ the first child's subtree for the second child).
+// A node's pool slot is a function of its range (interior: 2 x its split position; leaf: 2 x its first position + 1; a treelet's root: 2 x the treelet's first position,
+// where the host looks for it), so no slot counter is shared.
 struct TreeletInfo { uint32_t first, n, interior, leaves, max_leaf, depth, pad[2]; };
-__global__ __launch_bounds__(64) void emit_kernel(const uint32_t* tl_first, const uint32_t* tl_n, uint32_t n_treelets, const uint32_t* codes, const uint32_t* ids, const float* blo, const float* bhi,
-                                                  uint32_t max_prims, DNode* pool, uint32_t* leaf_last, TreeletInfo* info) {
+struct EmitItem { uint32_t first, n, slot_of_parent, tree; int bit; uint32_t which, self, pad; };   // which: 0 / 1 = first / second child, 2 = a treelet's root
+#define PHD_MAX_LEVELS 20   // a split consumes at least one of the 18 code bits below the treelet key: 19 levels at most
+
+__global__ __launch_bounds__(256) void emit_roots_kernel(const uint32_t* tl_first, const uint32_t* tl_n, uint32_t n_treelets, EmitItem* items, uint32_t* lvl /*[PHD_MAX_LEVELS + 2], [0] = 0*/, uint32_t* n_items,
+                                                         TreeletInfo* info) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) { lvl[0] = 0u; lvl[1] = n_treelets; *n_items = n_treelets; }
     if (t >= n_treelets) return;
-    const uint32_t T0 = tl_first[t], TN = tl_n[t];
-    uint32_t next = 2u * T0;   // the treelet's nodes live in pool[2 * first, 2 * first + 2 n - 1)
-    uint32_t n_interior = 0, n_leaves = 0, max_leaf = 0, max_depth = 0;
-    struct Fr { uint32_t first, n, self, hi; int bit, stage; };
-    Fr st[24];
-    int sp = 0;
-    st[0] = Fr{T0, TN, next++, 0u, 29 - 12, 0};
-    while (sp >= 0) {
-        Fr& f = st[sp];
-        if (f.stage == 0) {
-            int bit = f.bit;
-            bool leaf = false;
-            for (;;) {
-                if (bit == -1 || f.n < max_prims) { leaf = true; break; }
-                const uint32_t mask = 1u << bit;
-                if ((codes[f.first] & mask) != (codes[f.first + f.n - 1] & mask)) break;
-                bit--;   // no split on this bit
-            }
-            DNode& nd = pool[f.self];
-            if (leaf) {
-                float lo[3], hi[3];
-                for (uint32_t i = 0; i < f.n; i++) {
-                    const size_t id = ids[f.first + i];
-                    for (int k = 0; k < 3; k++) {
-                        const float l = blo[3 * id + k], h = bhi[3 * id + k];
-                        lo[k] = i == 0 ? l : fmn(lo[k], l); hi[k] = i == 0 ? h : fmx(hi[k], h);
-                    }
-                }
-                for (int k = 0; k < 3; k++) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
-                nd.kid0 = nd.kid1 = PHD_NONE; nd.first = f.first; nd.count = f.n; nd.axis = 0; nd.dense = 0;
-                leaf_last[f.first + f.n - 1] = 1u;
-                n_leaves++; if (f.n > max_leaf) max_leaf = f.n; if ((uint32_t)sp + 1 > max_depth) max_depth = (uint32_t)sp + 1;
-                sp--;
-                continue;
-            }
-            const uint32_t mask = 1u << bit;
-            uint32_t lo = 0, hi = f.n - 1;   // hlbvh.rs:253-268: first index whose bit differs from the first primitive's
-            while (lo + 1 != hi) {
-                const uint32_t mid = (lo + hi) / 2;
-                if ((codes[f.first + lo] & mask) == (codes[f.first + mid] & mask)) lo = mid; else hi = mid;
-            }
-            f.bit = bit; f.hi = hi; f.stage = 1;
-            nd.dense = n_interior++; nd.count = 0; nd.first = 0; nd.axis = (uint32_t)(bit % 3);
-            const uint32_t kid = next++;
-            nd.kid0 = kid;
-            st[++sp] = Fr{f.first, hi, kid, 0u, bit - 1, 0};
-        } else if (f.stage == 1) {
-            f.stage = 2;
-            const uint32_t kid = next++;
-            pool[f.self].kid1 = kid;
-            const Fr c{f.first + f.hi, f.n - f.hi, kid, 0u, f.bit - 1, 0};
-            st[++sp] = c;
-        } else {
-            DNode& nd = pool[f.self];
-            const DNode& a = pool[nd.kid0]; const DNode& b = pool[nd.kid1];
-            for (int k = 0; k < 3; k++) { nd.lo[k] = fmn(a.lo[k], b.lo[k]); nd.hi[k] = fmx(a.hi[k], b.hi[k]); }
-            sp--;
+    items[t] = EmitItem{tl_first[t], tl_n[t], PHD_NONE, t, 29 - 12, 2u, 0u, 0u};
+    info[t] = TreeletInfo{tl_first[t], tl_n[t], 0u, 0u, 0u, 0u, {0u, 0u}};
+}
+// one level: every item decides leaf / split, writes its node, tells its parent where it lives and appends its two children to the next level
+__global__ __launch_bounds__(256) void emit_level_kernel(EmitItem* items, const uint32_t* lvl, int level, uint32_t* n_items, const uint32_t* codes, uint32_t max_prims, DNode* pool, uint32_t* leaf_last,
+                                                         TreeletInfo* info) {
+    const uint32_t i = lvl[level] + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lvl[level + 1]) return;
+    EmitItem it = items[i];
+    int bit = it.bit;
+    bool leaf = false;
+    for (;;) {
+        if (bit == -1 || it.n < max_prims) { leaf = true; break; }
+        const uint32_t mask = 1u << bit;
+        if ((codes[it.first] & mask) != (codes[it.first + it.n - 1] & mask)) break;
+        bit--;   // no split on this bit
+    }
+    uint32_t hi = 0;
+    if (!leaf) {   // hlbvh.rs:253-268: first index whose bit differs from the first primitive's
+        const uint32_t mask = 1u << bit;
+        uint32_t lo = 0; hi = it.n - 1;
+        while (lo + 1 != hi) {
+            const uint32_t mid = (lo + hi) / 2;
+            if ((codes[it.first + lo] & mask) == (codes[it.first + mid] & mask)) lo = mid; else hi = mid;
         }
     }
-    info[t] = TreeletInfo{T0, TN, n_interior, n_leaves, max_leaf, max_depth, {0, 0}};
+    const uint32_t self = it.which == 2u ? 2u * it.first : (leaf ? 2u * it.first + 1u : 2u * (it.first + hi));
+    items[i].self = self; items[i].bit = leaf ? -2 : bit;   // (-2: a leaf, for the two sweeps that follow)
+    if (it.which == 0u) pool[it.slot_of_parent].kid0 = self; else if (it.which == 1u) pool[it.slot_of_parent].kid1 = self;
+    DNode& nd = pool[self];
+    if (leaf) {
+        nd.kid0 = nd.kid1 = PHD_NONE; nd.first = it.first; nd.count = it.n; nd.axis = 0; nd.dense = 0;
+        leaf_last[it.first + it.n - 1] = 1u;
+        atomicAdd(&info[it.tree].leaves, 1u); atomicMax(&info[it.tree].max_leaf, it.n); atomicMax(&info[it.tree].depth, (uint32_t)level + 1u);
+        return;
+    }
+    nd.count = 0; nd.first = 0; nd.axis = (uint32_t)(bit % 3); nd.dense = 0;
+    const uint32_t at = atomicAdd(n_items, 2u);
+    items[at] = EmitItem{it.first, hi, self, it.tree, bit - 1, 0u, 0u, 0u};
+    items[at + 1u] = EmitItem{it.first + hi, it.n - hi, self, it.tree, bit - 1, 1u, 0u, 0u};
+}
+__global__ void emit_close_level_kernel(uint32_t* lvl, int level, const uint32_t* n_items) { if (threadIdx.x == 0 && blockIdx.x == 0) lvl[level + 2] = *n_items; }
+// bottom-up: boxes, and in `first` of an interior node the number of interior nodes of its subtree
+__global__ __launch_bounds__(256) void emit_up_kernel(const EmitItem* items, const uint32_t* lvl, int level, const uint32_t* ids, const float* blo, const float* bhi, DNode* pool) {
+    const uint32_t i = lvl[level] + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lvl[level + 1]) return;
+    const EmitItem it = items[i];
+    DNode& nd = pool[it.self];
+    if (it.bit == -2) {
+        float lo[3], hi[3];
+        for (uint32_t k = 0; k < it.n; k++) {
+            const size_t id = ids[it.first + k];
+            for (int q = 0; q < 3; q++) {
+                const float l = blo[3 * id + q], h = bhi[3 * id + q];
+                lo[q] = k == 0 ? l : fmn(lo[q], l); hi[q] = k == 0 ? h : fmx(hi[q], h);
+            }
+        }
+        for (int q = 0; q < 3; q++) { nd.lo[q] = lo[q]; nd.hi[q] = hi[q]; }
+        return;
+    }
+    const DNode& a = pool[nd.kid0]; const DNode& b = pool[nd.kid1];
+    for (int q = 0; q < 3; q++) { nd.lo[q] = fmn(a.lo[q], b.lo[q]); nd.hi[q] = fmx(a.hi[q], b.hi[q]); }
+    nd.first = 1u + (a.kid0 == PHD_NONE ? 0u : a.first) + (b.kid0 == PHD_NONE ? 0u : b.first);
+}
+// top-down: the creation numbers of the recursion (a node, then its whole first subtree, then the second)
+__global__ __launch_bounds__(256) void emit_down_kernel(const EmitItem* items, const uint32_t* lvl, int level, DNode* pool, TreeletInfo* info) {
+    const uint32_t i = lvl[level] + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lvl[level + 1]) return;
+    const EmitItem it = items[i];
+    if (it.bit == -2) return;
+    DNode& nd = pool[it.self];
+    if (it.which == 2u) { nd.dense = 0u; info[it.tree].interior = nd.first; }
+    DNode& a = pool[nd.kid0]; DNode& b = pool[nd.kid1];
+    const uint32_t below_a = a.kid0 == PHD_NONE ? 0u : a.first;
+    if (a.kid0 != PHD_NONE) a.dense = nd.dense + 1u;
+    if (b.kid0 != PHD_NONE) b.dense = nd.dense + 1u + below_a;
 }
 
 // K6a: every interior build node of every treelet -> its Node64 (both children's boxes, child references in the final numbering)
@@ -321,7 +347,20 @@ int build_hlbvh_device(const BuildInput& in, int max_prims_in_node, hipStream_t 
         PHD_CHECK(hipMemcpyAsync(d_tl_n, tl_n.data(), (size_t)nt * 4, hipMemcpyHostToDevice, stream));
         PHD_CHECK(hipMemsetAsync(pool, 0xFF, (size_t)2 * n * sizeof(phd::DNode), stream));
         PHD_CHECK(hipMemsetAsync(leaf_last, 0, (size_t)n * 4, stream));
-        hipLaunchKernelGGL(phd::emit_kernel, dim3((nt + 63u) / 64u), dim3(64), 0, stream, d_tl_first, d_tl_n, nt, codes, ids, blo, bhi, max_prims, pool, leaf_last, d_info);
+        {   // emit_lbvh, level by level (K5)
+            phd::EmitItem* items = (phd::EmitItem*)dalloc((size_t)2 * n * sizeof(phd::EmitItem));
+            uint32_t* lvl = (uint32_t*)dalloc((PHD_MAX_LEVELS + 2) * 4); uint32_t* n_items = (uint32_t*)dalloc(16);
+            if (!items || !lvl || !n_items) { err = "device build: out of device memory"; goto fail; }
+            PHD_CHECK(hipMemsetAsync(lvl, 0, (PHD_MAX_LEVELS + 2) * 4, stream));
+            hipLaunchKernelGGL(phd::emit_roots_kernel, dim3((nt + 255u) / 256u), dim3(256), 0, stream, d_tl_first, d_tl_n, nt, items, lvl, n_items, d_info);
+            auto grid_of = [&](int L) { const uint64_t most = std::min<uint64_t>((uint64_t)n, (uint64_t)nt << std::min(L, 24)); return dim3((uint32_t)((most + 255u) / 256u)); };   // a level holds at most 2^L nodes per treelet, and never more than n
+            for (int L = 0; L < PHD_MAX_LEVELS; L++) {
+                hipLaunchKernelGGL(phd::emit_level_kernel, grid_of(L), dim3(256), 0, stream, items, lvl, L, n_items, codes, max_prims, pool, leaf_last, d_info);
+                hipLaunchKernelGGL(phd::emit_close_level_kernel, dim3(1), dim3(64), 0, stream, lvl, L, n_items);
+            }
+            for (int L = PHD_MAX_LEVELS - 1; L >= 0; L--) hipLaunchKernelGGL(phd::emit_up_kernel, grid_of(L), dim3(256), 0, stream, items, lvl, L, ids, blo, bhi, pool);
+            for (int L = 0; L < PHD_MAX_LEVELS; L++) hipLaunchKernelGGL(phd::emit_down_kernel, grid_of(L), dim3(256), 0, stream, items, lvl, L, pool, d_info);
+        }
         PHD_CHECK(hipGetLastError());
         info.resize(nt);
         PHD_CHECK(hipMemcpyAsync(info.data(), d_info, (size_t)nt * sizeof(phd::TreeletInfo), hipMemcpyDeviceToHost, stream));
