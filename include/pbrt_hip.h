@@ -113,7 +113,7 @@ int pbrt_hip_add_material_matte(PbrtHipScene*, const float kd_rgb[3], float sigm
  *                                              SpecularTransmission(Kt); pass urough = vrough = roughness when the file gives one value
  *   substrate   materials/src/substrate.rs:55-84   FresnelBlend(Kd, Ks, TR(urough, vrough))
  *   translucent materials/src/translucent.rs:57-112 Lambertian R/T (reflect*Kd, transmit*Kd) + Microfacet R/T (reflect*Ks, transmit*Ks), eta 1.5;
- *                                               reflect = transmit = 0 is refused (the reference leaves the BSDF unset there)
+ *                                               reflect = transmit = 0: no BSDF at any hit (the reference returns before making one), i.e. Material "none"
  *   mix         materials/src/mix.rs:51-88        the two materials' lobes as ScaledBxDF(amount) / ScaledBxDF(1 - amount); at most 8 lobes,
  *                                               mixes of mixes up to two levels
  * Bump maps are outside the scope (constant textures have no gradient: Material::bump is the identity for them). */
@@ -211,16 +211,18 @@ int pbrt_hip_add_texture_checkerboard3d(PbrtHipScene*, uint32_t tex1, uint32_t t
  * GlassMaterial's u / v roughness go through set_material_float_texture: a hit where both evaluate to 0 gets FresnelSpecular, any other the microfacet pair (glass.rs:110-141).
  * A bump-mapped material may be a child of a mix: the FIRST child's bump map shapes the mixture's shading frame, the second child's has no effect (mix.rs:63-76 builds the
  * BSDF on the interaction the first child bumped). */
+/* REFLECT / TRANSMIT — TranslucentMaterial's `reflect` / `transmit` (translucent.rs:70-98): evaluated and clamped at every hit; a lobe is added where its reflect-or-transmit value and its
+ * Kd-or-Ks value are both non-black, with their product as colour; where reflect and transmit are BOTH black the reference makes no BSDF for the hit (:72-74) and PathIntegrator::li passes
+ * through the surface without counting a bounce (path.rs:142-150) — so does the library, per hit.  (Constants reflect = transmit = 0 behave like Material "none" everywhere.) */
 enum { PBRT_HIP_PARAM_KD = 0, PBRT_HIP_PARAM_KS = 1, PBRT_HIP_PARAM_KR = 2, PBRT_HIP_PARAM_KT = 3, PBRT_HIP_PARAM_OPACITY = 4, PBRT_HIP_PARAM_AMOUNT = 5, PBRT_HIP_PARAM_ETA = 6,
-       PBRT_HIP_PARAM_K = 7 };
+       PBRT_HIP_PARAM_K = 7, PBRT_HIP_PARAM_REFLECT = 8, PBRT_HIP_PARAM_TRANSMIT = 9 };
 int pbrt_hip_set_material_texture(PbrtHipScene*, uint32_t material, int param, uint32_t texture);
 /* Scalar parameters as float textures, evaluated at every hit: fparam 0 = MatteMaterial's sigma (matte.rs:64-70: Lambert where it evaluates to 0, Oren-Nayar elsewhere),
  * 1 / 2 = u / v roughness of the Trowbridge-Reitz distribution of plastic, uber, substrate, translucent and metal (remapped per hit if the material was created with remap_roughness;
  * plastic's and translucent's single `roughness`: set both), and of glass, whose lobe structure switches per hit on `urough == 0 && vrough == 0` (glass.rs:110-141);
  * 3 = `index` of GlassMaterial and UberMaterial (glass.rs:102, uber.rs:128): the hit's index of refraction, taken as the texture gives it, for FresnelSpecular, the
  * FresnelDielectric(1, index) of the reflection lobes, the transmission lobes and — uber — BSDF::eta; an uber's constant opacity then becomes a per-hit constant as well.
- * (TranslucentMaterial's `reflect` / `transmit` stay constants: where both textures are black the reference makes NO BSDF for that hit, translucent.rs:70-73, which the
- * wavefront's fixed per-material "none" handling cannot express per hit.) */
+ */
 int pbrt_hip_set_material_float_texture(PbrtHipScene*, uint32_t material, int fparam, uint32_t texture);
 /* Bump mapping: Material::bump (core/src/material.rs:62-101) with the float texture `texture` as displacement, run before the BSDF of a hit is made
  * (every material's `bumpmap` parameter).  Not for Material "none".  Set it before the material becomes a child of a mix. */

@@ -640,10 +640,48 @@ static void glass_rebuild_for_roughness(Material& m) {
     }
     m.rebuilt = true;
 }
-// param: 0 Kd, 1 Ks, 2 Kr, 3 Kt; 4 uber opacity, 5 mix amount, 6 metal eta, 7 metal k
+// TranslucentMaterial with a reflect / transmit texture: every lobe the material can have (translucent.rs:76-98), colours and presence decided per hit
+static void translucent_rebuild_rt(Material& m) {
+    if (m.rt_mode) return;
+    const std::vector<Lobe> old = m.lobes;
+    int btex[2] = {-1, -1};   // Kd / Ks textures already set
+    for (int k = 0; k < 2; k++) if (m.param_lobe[k] >= 0) { const Lobe& l = old[(size_t)m.param_lobe[k]]; btex[k] = m.param_field[k] == 0 ? l.r_tex : l.t_tex; }
+    int axt = -1, ayt = -1;
+    if (m.rough_lobe >= 0) { axt = old[(size_t)m.rough_lobe].ax_tex; ayt = old[(size_t)m.rough_lobe].ay_tex; }
+    m.lobes.clear();
+    for (int k = 0; k < 4; k++) { m.param_lobe[k] = m.param_lobe2[k] = -1; m.param_field[k] = m.param_field2[k] = 0; }
+    m.rough_lobe = m.rough_lobe2 = -1;
+    for (int k = 0; k < 2; k++) {
+        if (m.raw_k[k].is_black() && btex[k] < 0) continue;   // Kd / Ks black at every hit: `if !kd.is_black()` never holds
+        for (int side = 0; side < 2; side++) {
+            Lobe l;
+            if (k == 0) { l.kind = side ? LK_LAMBERT_T : LK_LAMBERT; l.type = (side ? BX_TRANS : BX_REFL) | BX_DIFF; }
+            else {
+                l.kind = side ? LK_MICRO_T : LK_MICRO_R; l.type = (side ? BX_TRANS : BX_REFL) | BX_GLOSSY; l.fresnel = FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f;
+                const Float rough = m.raw_remap ? roughness_to_alpha(m.raw_ur) : m.raw_ur;
+                set_tr(l, rough, rough);
+                l.ax_tex = axt; l.ay_tex = ayt; l.remap = m.raw_remap;
+                (side ? m.rough_lobe2 : m.rough_lobe) = (int)m.lobes.size();
+            }
+            l.pre_mode = 5; l.pre = m.raw_k[k];
+            (side ? l.t_tex : l.r_tex) = btex[k];
+            (side ? m.param_lobe2[k] : m.param_lobe[k]) = (int)m.lobes.size(); (side ? m.param_field2[k] : m.param_field[k]) = side;
+            m.lobes.push_back(l);
+        }
+    }
+    m.rough_remap = m.raw_remap;
+    m.none = false; m.rt_mode = true;
+}
+// param: 0 Kd, 1 Ks, 2 Kr, 3 Kt; 4 uber opacity, 5 mix amount, 6 metal eta, 7 metal k, 8 translucent reflect, 9 translucent transmit
 int oracle_set_material_texture(OracleScene* s, uint32_t material, int param, uint32_t texture) {
-    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || param < 0 || param > 7) return -1;
+    if (!s || material >= s->sc.materials.size() || texture >= s->sc.textures.size() || param < 0 || param > 9) return -1;
     Material& m = s->sc.materials[material];
+    if (param >= 8) {   // translucent.rs:70-71
+        if (m.made_as != 5) return -6;
+        translucent_rebuild_rt(m);
+        (param == 8 ? m.refl_tex : m.trans_tex) = (int)texture; m.textured = true;
+        return 0;
+    }
     if (param == 4) {
         if (m.made_as != 1) return -6;
         uber_rebuild_for_opacity(m);
@@ -860,7 +898,8 @@ int oracle_add_material_translucent(OracleScene* s, const float kd[3], const flo
     if (!s || !kd || !ks || !reflect || !transmit) return -1;
     Material m; m.general = true; m.bsdf_eta = 1.5f;
     Spec r = spec_clamp0(spec3(reflect)), t = spec_clamp0(spec3(transmit));
-    if (r.is_black() && t.is_black()) { s->err = "translucent with reflect = transmit = 0 leaves the BSDF unset (translucent.rs:73-75): null-BSDF skipping is out of scope"; return -5; }
+    m.made_as = 5; m.raw_k[0] = spec_clamp0(spec3(kd)); m.raw_k[1] = spec_clamp0(spec3(ks)); m.raw_k[2] = r; m.raw_k[3] = t; m.raw_ur = roughness; m.raw_remap = remap != 0;
+    if (r.is_black() && t.is_black()) m.none = true;   // `return` before a BSDF is made (translucent.rs:72-74): every hit is skipped like Material "none" — until a texture replaces reflect / transmit
     // each lobe remembers the reflect / transmit factor of its product, so that a Kd / Ks texture can be evaluated per hit (set_material_texture)
     auto feed = [&](int param, int field) { if (m.param_lobe[param] < 0) { m.param_lobe[param] = (int)m.lobes.size(); m.param_field[param] = field; } else { m.param_lobe2[param] = (int)m.lobes.size(); m.param_field2[param] = field; } };
     Spec d = spec_clamp0(spec3(kd));

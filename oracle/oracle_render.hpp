@@ -809,6 +809,7 @@ struct Renderer {
     // ---- BSDF (core/src/reflection/bsdf.rs) over the lobes of a material ------------------------------------------------
     struct BSDF {
         V3 ns, ng, ss, ts; const Lobe* lobes = nullptr; int n = 0; Float eta = 1.0f;
+        bool null = false;   // compute_scattering_functions left `bsdf` at None for this hit (TranslucentMaterial where reflect and transmit are both black, translucent.rs:72-74)
         V3 w2l(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
         V3 l2w(V3 v) const {
             return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
@@ -1181,6 +1182,12 @@ struct Renderer {
             Spec s1(1.0f), s2(0.0f), op(1.0f);
             if (m.amount_tex >= 0) { s1 = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, m.amount_tex, c)); s2 = spec_clamp0(Spec(1.0f) - s1); }   // mix.rs:59-60
             if (m.opacity_tex >= 0) op = spec_clamp0(tex_eval(sc->textures, sc->mipmaps, m.opacity_tex, c));                                        // uber.rs:126
+            Spec rt_r(0.0f), rt_t(0.0f);
+            if (m.rt_mode) {   // translucent.rs:70-74
+                rt_r = m.refl_tex >= 0 ? spec_clamp0(tex_eval(sc->textures, sc->mipmaps, m.refl_tex, c)) : m.raw_k[2];
+                rt_t = m.trans_tex >= 0 ? spec_clamp0(tex_eval(sc->textures, sc->mipmaps, m.trans_tex, c)) : m.raw_k[3];
+                if (rt_r.is_black() && rt_t.is_black()) { b.null = true; b.lobes = local; b.n = 0; return b; }
+            }
             bool passthrough = false;
             const Float e_hit = m.index_tex >= 0 ? tex_eval(sc->textures, sc->mipmaps, m.index_tex, c).c[0] : 0.0f;   // glass.rs:102 / uber.rs:128
             for (const Lobe& tl : m.lobes) {
@@ -1206,6 +1213,16 @@ struct Renderer {
                 }
                 if ((l.alt == 1 && !is_specular) || (l.alt == 2 && is_specular)) continue;   // glass.rs:112-141: FresnelSpecular, or the microfacet pair
                 bool raw_black = false;   // translucent.rs:77-84, :87: the texel itself is tested, then multiplied by reflect / transmit
+                if (l.pre_mode == 5) {   // translucent.rs:76-98 with reflect / transmit evaluated at the hit: `if !kd.is_black() { if !r.is_black() { add(r * kd) } .. }`
+                    const bool refl = l.kind == LK_LAMBERT || l.kind == LK_MICRO_R;
+                    const Spec A = refl ? rt_r : rt_t;
+                    const int tex = refl ? l.r_tex : l.t_tex;
+                    const Spec B = tex >= 0 ? spec_clamp0(tex_eval(sc->textures, sc->mipmaps, tex, c)) : l.pre;
+                    if (A.is_black() || B.is_black()) continue;
+                    (refl ? l.r : l.t) = A * B;
+                    local[k++] = l;
+                    continue;
+                }
                 if (l.pre_mode == 4) l.t = spec_clamp0(op * -1.0f + Spec(1.0f));    // (-op + ONE).clamp_default() (uber.rs:127)
                 else if (l.pre_mode == 3) {   // op * k.evaluate(..).clamp_default() (uber.rs:141, :147, :169, :175)
                     const bool trans = l.kind == LK_SPEC_T;
@@ -1477,6 +1494,10 @@ struct Renderer {
             bump(isect);
             Lobe hit_lobes[8];
             BSDF bsdf = make_bsdf(isect, hit_lobes);
+            if (bsdf.null) {   // `if isect.bsdf.is_none() { ray = spawn_ray; bounces -= 1; continue }` (path.rs:142-150), decided by this hit's textures
+                ray = spawn_ray(isect.p, isect.p_error, isect.n, isect.time, ray.d);
+                continue;
+            }
             V3 shading_n = isect.ns;
             if (spatial) (void)spatial_lookup(isect.p);  // light_distribution.lookup(&isect.hit.p) happens for every vertex (path.rs:156-157)
             if (bsdf.num_components(BX_ALL & ~BX_SPEC) > 0) {

@@ -48,7 +48,8 @@ struct Lobe {
     int amt_side = 0, amt_level = 0; // MixMaterial with an `amount` texture (mix.rs:59-60): scale[amt_level] is s1 (side 1) or s2 = clamp(1 - s1) (side 2) of the hit
     int alt = 0;                     // GlassMaterial with roughness textures (glass.rs:110-141): 1 = the lobe of a hit where urough == vrough == 0, 2 = a lobe of the other hits
     Float ur_raw = 0, vr_raw = 0;    // ... the constant roughnesses BEFORE remapping (what `is_specular` compares with 0)
-    int pre_mode = 0;                // UberMaterial with an opacity texture (uber.rs:126-160): 3 = colour = op(hit) * (texel, or the constant kept in `pre`), 4 = colour = clamp(1 - op(hit))
+    int pre_mode = 0;                // UberMaterial with an opacity texture (uber.rs:126-160): 3 = colour = op(hit) * (texel, or the constant kept in `pre`), 4 = colour = clamp(1 - op(hit));
+                                     // 5 = TranslucentMaterial with a reflect / transmit texture (translucent.rs:70-98): colour = reflect-or-transmit(hit) * (texel, or the constant Kd / Ks kept in `pre`), both tested for black
 };
 struct Material {
     Spec kd; Float sigma; std::vector<Lobe> lobes; Float bsdf_eta = 1.0f; bool general = false; bool none = false;  // none: Material "none" / "" -> no BSDF at all
@@ -64,7 +65,9 @@ struct Material {
     int amount_tex = -1;    // MixMaterial's amount is a texture
     int mix_n1 = 0;         // MixMaterial: how many of the lobes come from the first material
     // what the material was created from, for the setters that have to rebuild the lobe list (opacity / glass roughness textures)
-    int made_as = 0;        // 0 other, 1 uber, 2 glass, 3 metal, 4 mix
+    int refl_tex = -1, trans_tex = -1;   // TranslucentMaterial: reflect / transmit are textures (translucent.rs:70-71); where both are black a hit has NO BSDF (:72-74)
+    bool rt_mode = false;                // ... the lobe list is in the per-hit form (pre_mode 5 lobes)
+    int made_as = 0;        // 0 other, 1 uber, 2 glass, 3 metal, 4 mix, 5 translucent
     Spec raw_k[4]; Float raw_eta = 1.5f, raw_ur = 0, raw_vr = 0; bool raw_remap = false; bool rebuilt = false;
 };
 

@@ -107,12 +107,14 @@ int upload_scene(PbrtHipScene* s) {
             uint32_t cols = m.amount_tex1 ? 1u : 0u; bool hdr = m.bump_tex1 != 0u || m.sigma_tex1 != 0u;
             for (uint32_t k = 0; k < m.n_lobes; k++) {
                 const LobeRec& l = s->lobes[m.lobe_base + k];
-                cols += (l.r_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T) ? 1u : 0u) + (l.t_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH ? 1u : 0u) +
+                if (l.has_pre == PH_PRE_RT) { cols += 1u; hdr = true; }   // one product colour per lobe, its black bit and the material's null-BSDF bit in the header
+                else cols += (l.r_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T) ? 1u : 0u) + (l.t_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH ? 1u : 0u) +
                         (l.eta_tex1 ? 1u : 0u) + (l.k_tex1 ? 1u : 0u);
                 if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1 || l.alt || l.has_pre == PH_PRE_RAW_TEST) hdr = true;
             }
             if (m.sigma_tex1 || hdr) cols = std::max(cols, 2u);   // the per-hit scalars travel in the fourth component of the first two colour slots
             if (m.index_tex1) cols = std::max(cols, 3u);          // ... the per-hit index of refraction in the third one's
+            if (m.rt_mode) hdr = true;
             m.tex_cols = std::min<uint32_t>(cols, PH_HIT_COLS); m.tex_hdr = hdr ? 1u : 0u;
         }
         s->alpha_lean = s->alpha_textures;
@@ -643,8 +645,7 @@ int pbrt_hip_add_material_translucent(PbrtHipScene* s, const float kd[3], const 
     std::vector<LobeRec> lobes;
     float r[3], t[3], d[3], sp[3], v[3];
     const bool rb = clamp3(reflect, r), tb = clamp3(transmit, t);
-    if (!rb && !tb)
-        return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_translucent: reflect = transmit = 0 leaves the BSDF unset in the reference (translucent.rs:73-75); null-BSDF skipping is out of scope");
+    if (!rb && !tb) { m.none = 1u; s->has_none_material = true; }   // `return` before a BSDF is made (translucent.rs:72-74): every hit is passed through, as with Material "none" — until a texture takes reflect's / transmit's place
     auto prod = [&](const float a[3], const float b[3]) { for (int c = 0; c < 3; c++) v[c] = a[c] * b[c]; };
     // each lobe keeps the reflect / transmit factor of its product (pre, PH_PRE_RAW_TEST) so that a Kd / Ks texture can replace the other factor per hit
     PbrtHipScene::MaterialParams mp;
@@ -662,6 +663,7 @@ int pbrt_hip_add_material_translucent(PbrtHipScene* s, const float kd[3], const 
         if (tb) { LobeRec l = lobe(PH_LK_MICRO_T, T_TRANS | T_GLOSSY); l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f; prod(t, sp); std::memcpy(l.t, v, 12); set_tr(l, rough, rough); raw(l, t);
                   feed(1, 1); (mp.rough_lobe < 0 ? mp.rough_lobe : mp.rough_lobe2) = (int)lobes.size(); lobes.push_back(l); }
     }
+    mp.made_as = 5; clamp3(kd, mp.raw_k[0]); clamp3(ks, mp.raw_k[1]); std::memcpy(mp.raw_k[2], r, 12); std::memcpy(mp.raw_k[3], t, 12); mp.raw_ur = roughness; mp.raw_remap = remap_roughness != 0;
     const int rc = push_material(s, m, lobes, true, out_id);
     if (rc == PBRT_HIP_OK) s->material_params.back() = mp;
     return rc;
@@ -681,6 +683,7 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
     // lobe, the second one's changes nothing that is used
     m.bump_tex1 = a.bump_tex1;
     if (a.amount_tex1 || b.amount_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a sub-material is a mix whose amount is a texture; not supported");
+    if (a.rt_mode || b.rt_mode) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a translucent sub-material with a reflect / transmit texture (a per-hit null BSDF) is not supported");
     if (a.index_tex1 || b.index_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: a sub-material with a textured index of refraction is not supported");
     if (a.opacity_tex1 && b.opacity_tex1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "add_material_mix: both sub-materials are uber materials with opacity textures; not supported");
     m.opacity_tex1 = a.opacity_tex1 ? a.opacity_tex1 : b.opacity_tex1;
@@ -721,6 +724,48 @@ int pbrt_hip_add_material_mix(PbrtHipScene* s, uint32_t material1, uint32_t mate
 }  // extern "C"
 
 namespace phost {
+// TranslucentMaterial with a reflect / transmit texture: the lobe list becomes every lobe the material CAN have (translucent.rs:76-98); a lobe's colour is the product of the hit's
+// reflect or transmit with the hit's Kd or Ks, kept where neither factor is black (PH_PRE_RT); where reflect and transmit are both black the hit has no BSDF at all.
+int translucent_rebuild_rt(PbrtHipScene* s, uint32_t material) {
+    PbrtHipScene::MaterialParams& mp = s->material_params[material];
+    MaterialRec& m = s->materials[material];
+    if (m.rt_mode) return PBRT_HIP_OK;
+    std::vector<LobeRec> old(s->lobes.begin() + m.lobe_base, s->lobes.begin() + m.lobe_base + m.n_lobes), lobes;
+    uint32_t btex1[2] = {0u, 0u}, axt = 0u, ayt = 0u;   // Kd / Ks and roughness textures set so far
+    for (int k = 0; k < 2; k++) if (mp.lobe[k] >= 0) { const LobeRec& l = old[(size_t)mp.lobe[k]]; btex1[k] = mp.field[k] == 0 ? l.r_tex1 : l.t_tex1; }
+    if (mp.rough_lobe >= 0) { axt = old[(size_t)mp.rough_lobe].ax_tex1; ayt = old[(size_t)mp.rough_lobe].ay_tex1; }
+    for (int k = 0; k < 4; k++) { mp.lobe[k] = mp.lobe2[k] = -1; mp.field[k] = mp.field2[k] = 0; }
+    mp.rough_lobe = mp.rough_lobe2 = -1;
+    for (int k = 0; k < 2; k++) {
+        const bool black = mp.raw_k[k][0] == 0.0f && mp.raw_k[k][1] == 0.0f && mp.raw_k[k][2] == 0.0f;
+        if (black && !btex1[k]) continue;   // Kd / Ks black at every hit
+        for (int side = 0; side < 2; side++) {
+            LobeRec l;
+            if (k == 0) l = side ? lobe(PH_LK_LAMBERT_T, T_TRANS | T_DIFF) : lobe(PH_LK_LAMBERT, T_REFL | T_DIFF);
+            else {
+                l = side ? lobe(PH_LK_MICRO_T, T_TRANS | T_GLOSSY) : lobe(PH_LK_MICRO_R, T_REFL | T_GLOSSY);
+                l.fresnel = PH_FR_DIEL; l.eta_a = 1.0f; l.eta_b = 1.5f;
+                const float rough = mp.raw_remap ? roughness_to_alpha(mp.raw_ur) : mp.raw_ur;
+                set_tr(l, rough, rough);
+                l.ax_tex1 = axt; l.ay_tex1 = ayt; l.remap = mp.raw_remap ? 1u : 0u;
+                (side ? mp.rough_lobe2 : mp.rough_lobe) = (int)lobes.size();
+            }
+            l.has_pre = PH_PRE_RT; std::memcpy(l.pre, mp.raw_k[k], 12);
+            (side ? l.t_tex1 : l.r_tex1) = btex1[k];
+            (side ? mp.lobe2[k] : mp.lobe[k]) = (int)lobes.size(); (side ? mp.field2[k] : mp.field[k]) = side;
+            lobes.push_back(l);
+        }
+    }
+    mp.rough_remap = mp.raw_remap; mp.has_pre = false;
+    m.lobe_base = (uint32_t)s->lobes.size(); m.n_lobes = (uint32_t)lobes.size();
+    s->lobes.insert(s->lobes.end(), lobes.begin(), lobes.end());
+    m.rt_mode = 1u; m.none = 0u; m.textured = 1u;
+    std::memcpy(m.refl_c, mp.raw_k[2], 12); std::memcpy(m.trans_c, mp.raw_k[3], 12);
+    s->has_none_material = true;   // some hits of this material may have no BSDF: paths can need more rounds than max_depth + 1
+    s->textured_materials = true; s->general_materials = true;
+    s->uploaded = false;
+    return PBRT_HIP_OK;
+}
 // UberMaterial with an opacity texture: the lobe list becomes every lobe the material CAN have (uber.rs:126-160); colours, presence and BSDF::eta are decided per hit.
 // The new list is appended to the lobe pool (the old one stays behind, unused).
 int uber_rebuild_for_opacity(PbrtHipScene* s, uint32_t material) {

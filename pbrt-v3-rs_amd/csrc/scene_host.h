@@ -32,7 +32,7 @@ struct SceneHostState {
     // which lobe and which of its two colours each texturable parameter of a material feeds (set_material_texture); -1 = that lobe was not made
     struct MaterialParams { int lobe[4] = {-1, -1, -1, -1}; int field[4] = {0, 0, 0, 0}; int lobe2[4] = {-1, -1, -1, -1}; int field2[4] = {0, 0, 0, 0}; bool has_pre = false; float pre[3] = {1, 1, 1}; int rough_lobe = -1, rough_lobe2 = -1; bool rough_remap = false;
                             // what the material was made from, for the setters that rebuild the lobe list (uber opacity / glass roughness textures), and the mix's split
-                            int made_as = 0;  /* 0 other, 1 uber, 2 glass, 3 metal, 4 mix */ float raw_k[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}; float raw_eta = 1.5f, raw_ur = 0, raw_vr = 0;
+                            int made_as = 0;  /* 0 other, 1 uber, 2 glass, 3 metal, 4 mix, 5 translucent */ float raw_k[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}; float raw_eta = 1.5f, raw_ur = 0, raw_vr = 0;
                             bool raw_remap = false, rebuilt = false; int mix_n1 = 0; };  // [Kd, Ks, Kr, Kt]; field 0 = r, 1 = t; pre: uber's opacity; lobe2 / field2 / rough_lobe2: a second lobe fed by the same parameter (translucent's reflection + transmission pair); rough_lobe: owner of the Trowbridge-Reitz distribution
     std::vector<MaterialParams> material_params;
     bool alpha_textures = false;      // some mesh has an alpha / shadowalpha texture: traversal uses the ALPHA kernel variants
@@ -120,6 +120,7 @@ void free_tree_dev(PbrtHipScene* s);
 int ensure_host_tree(PbrtHipScene* s);   // api.hip: the host copy of a tree that lives on the device only (the multi-device driver replicates from the host copy)
 int uber_rebuild_for_opacity(PbrtHipScene* s, uint32_t material);    // api.hip: lobe lists remade when a structural parameter becomes a texture
 int glass_rebuild_for_roughness(PbrtHipScene* s, uint32_t material);
+int translucent_rebuild_rt(PbrtHipScene* s, uint32_t material);      // api.hip: TranslucentMaterial -> its per-hit form (a reflect / transmit texture)
 // wavefront.hip: the renderer's building blocks, shared with the multi-device driver (multi.hip)
 #define PH_MAX_TILE_PARTS 64
 int check_render_args(PbrtHipScene* s, int max_depth, int light_strategy, const int* pixel_bounds, int tile_size, int part, int parts);

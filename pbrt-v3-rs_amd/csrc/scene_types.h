@@ -84,6 +84,8 @@ struct alignas(16) LobeRec {
 };
 #define PH_PRE_OPACITY 3u
 #define PH_PRE_PASSTHROUGH 4u
+#define PH_PRE_RT 5u   // TranslucentMaterial with a reflect / transmit texture (translucent.rs:70-98): colour = reflect-or-transmit(hit) * (texel, or the constant Kd / Ks kept in `pre`); both factors tested for black
+#define PH_TEXOUT_NULL_BSDF (1u << 16)   // TexOut::bumped: this hit has no BSDF (reflect and transmit both black, translucent.rs:72-74): the path passes through like Material "none"
 
 struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant textures) + the general lobe list
     float kd[3];      // already clamp_default()'ed
@@ -102,6 +104,9 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
     uint32_t amount_tex1;  // MixMaterial: 0, or 1 + the `amount` texture (takes the FIRST colour slot of the texture pass)
     float bsdf_eta_alt;    // UberMaterial with an opacity texture: BSDF::eta of the hits that do not get the pass-through lobe (uber.rs:128-137)
     uint32_t uber_eta;     // 1: this material IS that uber (a mix holding one keeps eta 1)
+    uint32_t rt_mode;      // TranslucentMaterial in the per-hit form (PH_PRE_RT lobes): reflect / transmit below are evaluated at every hit, a hit where both are black has no BSDF
+    uint32_t refl_tex1, trans_tex1;   // 0, or 1 + the texture behind `reflect` / `transmit`
+    float refl_c[3], trans_c[3];      // ... their clamped constants where they are not textures
     uint32_t index_tex1;   // GlassMaterial / UberMaterial: 0, or 1 + the float texture behind `index` (glass.rs:102, uber.rs:128): the dielectric lobes' eta of a hit (TexOut::col[2][3])
     uint32_t tex_cols;     // colour slots of TexOut the texture pass fills for this material (set at upload)
     uint32_t tex_hdr;      // the shade pass reads TexOut's header (bumped frame, per-hit scalars, lambert / glass / raw-black bits) for this material; else only the colours are written

@@ -543,8 +543,9 @@ PH_DEV void eval_lobe_scalars(const DeviceScene* dsc, const LobeRec& l, const Te
     }
 }
 // does this colour of the lobe come from the texture pass?  (r before t; PH_PRE_OPACITY / PH_PRE_PASSTHROUGH lobes always: their colour depends on the hit's opacity)
-PH_DEV bool lobe_slot_r(const LobeRec& l) { return l.r_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T); }
-PH_DEV bool lobe_slot_t(const LobeRec& l) { return l.t_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH; }
+PH_DEV bool lobe_is_reflection(const LobeRec& l) { return l.kind == PH_LK_LAMBERT || l.kind == PH_LK_MICRO_R; }   // (of a PH_PRE_RT lobe: LambertianReflection / MicrofacetReflection against their transmission twins)
+PH_DEV bool lobe_slot_r(const LobeRec& l) { return l.has_pre == PH_PRE_RT ? lobe_is_reflection(l) : (l.r_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T)); }
+PH_DEV bool lobe_slot_t(const LobeRec& l) { return l.has_pre == PH_PRE_RT ? !lobe_is_reflection(l) : (l.t_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH); }
 template <bool SIMPLE = false>
 PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const MaterialRec& mr, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, TexOut& out) {
     uint32_t k = 0;
@@ -553,9 +554,24 @@ PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const MaterialRec& mr, con
     if (mr.amount_tex1) put(tex_eval_clamped<SIMPLE>(dsc, mr.amount_tex1 - 1u, ctx));                           // mix.rs:59: s1 (s2 is made from it in the shade pass)
     spec op = mks1(1.0f);
     if (mr.opacity_tex1) op = tex_eval_clamped<SIMPLE>(dsc, mr.opacity_tex1 - 1u, ctx);                          // uber.rs:126
+    spec rt_r = mks1(0.0f), rt_t = mks1(0.0f);
+    if (mr.rt_mode) {   // translucent.rs:70-74: reflect and transmit of this hit; both black -> the hit has no BSDF
+        rt_r = mr.refl_tex1 ? tex_eval_clamped<SIMPLE>(dsc, mr.refl_tex1 - 1u, ctx) : mks(mr.refl_c[0], mr.refl_c[1], mr.refl_c[2]);
+        rt_t = mr.trans_tex1 ? tex_eval_clamped<SIMPLE>(dsc, mr.trans_tex1 - 1u, ctx) : mks(mr.trans_c[0], mr.trans_c[1], mr.trans_c[2]);
+        if (is_black(rt_r) && is_black(rt_t)) { out.bumped |= PH_TEXOUT_NULL_BSDF; return; }
+    }
     for (uint32_t i = 0; i < n; i++) {
         const LobeRec& l = tmpl[i];
         if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1) eval_lobe_scalars<SIMPLE>(dsc, l, ctx, out);
+        if (l.has_pre == PH_PRE_RT) {   // `if !kd.is_black() { if !r.is_black() { add(r * kd) } if !t.is_black() { add(t * kd) } }` and the same with Ks (translucent.rs:76-98)
+            const bool refl = lobe_is_reflection(l);
+            const spec A = refl ? rt_r : rt_t;
+            const uint32_t tex = refl ? l.r_tex1 : l.t_tex1;
+            const spec B = tex ? tex_eval_clamped<SIMPLE>(dsc, tex - 1u, ctx) : mks(l.pre[0], l.pre[1], l.pre[2]);
+            if ((is_black(A) || is_black(B)) && k < PH_HIT_COLS) out.bumped |= 1u << (8u + k);
+            put(A * B);
+            continue;
+        }
         if (l.has_pre == PH_PRE_PASSTHROUGH) { const spec t = op * -1.0f + mks1(1.0f); put(mks(pclampf(t.r, 0.0f, kInf), pclampf(t.g, 0.0f, kInf), pclampf(t.b, 0.0f, kInf))); continue; }   // (-op + ONE).clamp_default() (uber.rs:127)
         if (l.has_pre == PH_PRE_OPACITY) {   // op * k.evaluate(..).clamp_default() (uber.rs:141, :147, :169, :175)
             const uint32_t tex = l.kind == PH_LK_SPEC_T ? l.t_tex1 : l.r_tex1;
@@ -603,7 +619,7 @@ PH_DEV uint32_t build_hit_lobes(const MaterialRec& mr, const LobeRec* tmpl, uint
         }
         if ((l.alt == 1u && !is_specular) || (l.alt == 2u && is_specular)) continue;   // glass.rs:112-141: FresnelSpecular, or the microfacet pair (slots consumed either way)
         // TranslucentMaterial's lobes: the texel decided (an untextured one exists because its constant passed the test when the material was made)
-        if (l.has_pre == PH_PRE_RAW_TEST ? !raw_black : lobe_keep(l)) { if (l.has_pre == PH_PRE_PASSTHROUGH) passthrough = true; out[k++] = l; }
+        if ((l.has_pre == PH_PRE_RAW_TEST || l.has_pre == PH_PRE_RT) ? !raw_black : lobe_keep(l)) { if (l.has_pre == PH_PRE_PASSTHROUGH) passthrough = true; out[k++] = l; }
     }
     if (mr.uber_eta) eta_out = passthrough ? 1.0f : (mr.index_tex1 ? in->col[2][3] : mr.bsdf_eta_alt);
     return k;

@@ -311,9 +311,18 @@ int pbrt_hip_set_texture_mapping(PbrtHipScene* s, uint32_t texture, int kind, co
 int pbrt_hip_set_material_texture(PbrtHipScene* s, uint32_t material, int param, uint32_t texture) {
     return ph_guard(s, "pbrt_hip_set_material_texture", [&]() -> int {
     if (!s || material >= s->materials.size() || texture >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: unknown material or texture");
-    if (param < 0 || param > 7) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: param must be PBRT_HIP_PARAM_KD / KS / KR / KT / OPACITY / AMOUNT / ETA / K");
+    if (param < 0 || param > 9) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "set_material_texture: param must be PBRT_HIP_PARAM_KD / KS / KR / KT / OPACITY / AMOUNT / ETA / K / REFLECT / TRANSMIT");
     if (param >= PBRT_HIP_PARAM_OPACITY) {   // parameters that are not one lobe's colour
         PbrtHipScene::MaterialParams& mq = s->material_params[material];
+        if (param == PBRT_HIP_PARAM_REFLECT || param == PBRT_HIP_PARAM_TRANSMIT) {   // translucent.rs:70-71
+            if (mq.made_as != 5) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: reflect / transmit belong to TranslucentMaterial");
+            const int rc = translucent_rebuild_rt(s, material);
+            if (rc) return rc;
+            MaterialRec& mt = s->materials[material];
+            (param == PBRT_HIP_PARAM_REFLECT ? mt.refl_tex1 : mt.trans_tex1) = texture + 1u;
+            s->uploaded = false;
+            return PBRT_HIP_OK;
+        }
         MaterialRec& mm = s->materials[material];
         if (param == PBRT_HIP_PARAM_OPACITY) {      // uber.rs:126-160
             if (mq.made_as != 1) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "set_material_texture: opacity belongs to UberMaterial");

@@ -70,6 +70,7 @@ struct WfParams {
     const CameraRec* cam_dev; uint32_t textured;
     LobeRec* hit_lobes;  // general-BSDF kernel only: PH_HIT_LOBES slots per thread of the grid
     TexOut* tex_out;     // texture pass -> shade pass, one record per path of the chunk
+    uint32_t any_rt;     // some TranslucentMaterial decides per hit whether it has a BSDF at all (MaterialRec::rt_mode): the texture pass runs first and says so in TexOut::bumped
     // ray binning between rounds (raysort.h): the bin key of every ray the shade pass emits, next to the ray
     RaySortGrid sort_grid; uint32_t* keys_cl; uint32_t* keys_sh;
 };
@@ -163,6 +164,8 @@ __global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfPar
         if ((__float_as_uint(h1.w) & 7u) == 7u) continue;  // Material "none": the surface is skipped before the lookup (path.rs:146-150)
         const float4* tp = reinterpret_cast<const float4*>(sc.tris + __float_as_uint(h1.y));
         const float4 a = tp[0], b = tp[1], c = tp[2];
+        // ... and so is a hit for which this round's texture pass found no BSDF (a TranslucentMaterial whose reflect and transmit are black there)
+        if (w.any_rt && sc.materials[sc.meshes[__float_as_uint(c.w)].material].rt_mode && (w.tex_out[i].bumped & PH_TEXOUT_NULL_BSDF)) continue;
         f3 p = h0.z * mk3(a.x, a.y, a.z) + h0.w * mk3(b.x, b.y, b.z) + h1.x * mk3(c.x, c.y, c.z);  // = SurfHit::p (make_surface_hit_tv)
         const uint32_t inst = __float_as_uint(h1.z);
         if (inst != 0u && !(sc.instances[inst - 1u].flags & PH_INST_IDENTITY)) {  // world-space p of an instanced hit (make_surface_hit_any)
@@ -404,7 +407,9 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         if (m.first_light >= 0) L = L + beta * area_L(sc.lights[(uint32_t)m.first_light + (hprim - m.tri_base)], si.n, -rd);
                         else L = L + beta * mks1(0.0f);
                     }
-                    if ((int)bounces < w.max_depth && sc.materials[m.material].none) {
+                    bool no_bsdf = sc.materials[m.material].none != 0u;
+                    if (TEX && !no_bsdf && sc.materials[m.material].rt_mode) no_bsdf = (w.tex_out[pos].bumped & PH_TEXOUT_NULL_BSDF) != 0u;   // translucent.rs:72-74, decided by this hit's textures
+                    if ((int)bounces < w.max_depth && no_bsdf) {
                         // null BSDF (Material "none"): `*ray = isect.spawn_ray(&ray.d); continue;` — bounces, the sampler dimension and the
                         // specular flag stay as they are (path.rs:142-150)
                         const RayIn re = spawn_ray(si, rd);
@@ -1008,6 +1013,8 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     ph::WfParams wp{};
     wp.cam = s->cam; wp.sp = s->sampler;
     wp.textured = s->textured_materials ? 1u : 0u; wp.cam_dev = nullptr;
+    wp.any_rt = 0u;
+    for (const MaterialRec& mr : s->materials) if (mr.rt_mode) wp.any_rt = 1u;
     if (s->textured_materials) {
         if ((rc = ensure_buf(s, w.d_cam, sizeof(CameraRec)))) return rc;
         PH_CHECK(s, hipMemcpyAsync(w.d_cam.p, &s->cam, sizeof(CameraRec), hipMemcpyHostToDevice, s->stream));
@@ -1103,6 +1110,17 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
                     if ((rc = timed(1, [&]() { launch_traverse_kernel(s, 1, s->trav_blocks, tp); }))) return rc;
                 }
             }
+            // the texture pass first: besides colours and bumped frames it finds the hits that have no BSDF at all (TexOut::bumped, PH_TEXOUT_NULL_BSDF), which the
+            // light-distribution pass must skip as the reference's `continue` does (path.rs:142-157)
+            if (s->textured_materials) {
+                if ((rc = timed(2, [&]() {
+                        static const int tex_waves = []() { const char* e = std::getenv("PBRT_HIP_TEX_WAVES"); const int v = e ? std::atoi(e) : PH_TEX_SIMPLE_WAVES; return (v < 2 || v > 4) ? PH_TEX_SIMPLE_WAVES : v; }();
+                        if (!s->simple_textures || tex_waves == 0) hipLaunchKernelGGL((ph::texture_kernel<false, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        else if (tex_waves == 2) hipLaunchKernelGGL((ph::texture_kernel<true, 2>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        else if (tex_waves == 3) hipLaunchKernelGGL((ph::texture_kernel<true, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        else hipLaunchKernelGGL((ph::texture_kernel<true, 4>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                    }))) return rc;
+            }
             if (spatial && (it < max_depth || s->has_none_material)) {  // vertices reached at bounce == max_depth sample no light (path.rs:136-139)
                 if ((rc = timed(2, [&]() {
                         hipLaunchKernelGGL(ph::spatial_mark_kernel, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
@@ -1111,11 +1129,6 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
             }
             if ((rc = timed(2, [&]() {
                     if (s->textured_materials) {
-                        static const int tex_waves = []() { const char* e = std::getenv("PBRT_HIP_TEX_WAVES"); const int v = e ? std::atoi(e) : PH_TEX_SIMPLE_WAVES; return (v < 2 || v > 4) ? PH_TEX_SIMPLE_WAVES : v; }();
-                        if (!s->simple_textures || tex_waves == 0) hipLaunchKernelGGL((ph::texture_kernel<false, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
-                        else if (tex_waves == 2) hipLaunchKernelGGL((ph::texture_kernel<true, 2>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
-                        else if (tex_waves == 3) hipLaunchKernelGGL((ph::texture_kernel<true, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
-                        else hipLaunchKernelGGL((ph::texture_kernel<true, 4>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         if (s->general_materials) hipLaunchKernelGGL((ph::shade_kernel<true, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         else hipLaunchKernelGGL((ph::shade_kernel<false, true>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                     } else if (s->general_materials) hipLaunchKernelGGL(ph::shade_kernel<true>, dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);

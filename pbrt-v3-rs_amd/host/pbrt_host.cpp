@@ -481,19 +481,19 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     std::array<float, 3> kd = {0.5f, 0.5f, 0.5f};
     float sigma = 0.0f;
     int64_t ftex_param[4] = {-1, -1, -1, -1};     // [sigma, uroughness, vroughness, index]: the same for float parameters
-    int64_t tex_param[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // [Kd, Ks, Kr, Kt, opacity, amount, eta, k]: the parameter names a texture the library evaluates per hit
+    int64_t tex_param[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // [Kd, Ks, Kr, Kt, opacity, amount, eta, k, reflect, transmit]: the parameter names a texture the library evaluates per hit
     auto spectrum_tex = [&](const std::string& pname, std::array<float, 3> d) {
         std::string tn = m.params.find_one_texture(pname);
         if (!tn.empty()) {
             auto dt = gs_.device_textures.find(tn);
             if (dt != gs_.device_textures.end()) {
                 // a texture the library evaluates per hit: the material is created with a white placeholder and the texture attached afterwards
-                const int param = pname == "Kd" ? 0 : (pname == "Ks" ? 1 : (pname == "Kr" ? 2 : (pname == "Kt" ? 3 : (pname == "opacity" ? 4 : (pname == "amount" ? 5 : (pname == "eta" ? 6 : (pname == "k" ? 7 : -1)))))));
+                const int param = pname == "Kd" ? 0 : (pname == "Ks" ? 1 : (pname == "Kr" ? 2 : (pname == "Kt" ? 3 : (pname == "opacity" ? 4 : (pname == "amount" ? 5 : (pname == "eta" ? 6 : (pname == "k" ? 7 : (pname == "reflect" ? 8 : (pname == "transmit" ? 9 : -1)))))))));
                 const bool takes = (m.type == "matte" && param == 0) || ((m.type == "plastic" || m.type == "substrate") && (param == 0 || param == 1)) || (m.type == "mirror" && param == 2) ||
-                                   (m.type == "glass" && (param == 2 || param == 3)) || (m.type == "uber" && param >= 0 && param <= 4) || (m.type == "translucent" && (param == 0 || param == 1)) ||
+                                   (m.type == "glass" && (param == 2 || param == 3)) || (m.type == "uber" && param >= 0 && param <= 4) || (m.type == "translucent" && (param == 0 || param == 1 || param == 8 || param == 9)) ||
                                    (m.type == "mix" && param == 5) || (m.type == "metal" && (param == 6 || param == 7));
                 if (!takes || dt->second.is_float) {
-                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit spectrum textures are wired to matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, glass Kr / Kt, uber Kd / Ks / Kr / Kt / opacity, translucent Kd / Ks, mix amount and metal eta / k";
+                    if (error.empty()) error = "texture '" + tn + "' on parameter '" + pname + "' of Material \"" + m.type + "\": per-hit spectrum textures are wired to matte Kd, plastic Kd / Ks, mirror Kr, substrate Kd / Ks, glass Kr / Kt, uber Kd / Ks / Kr / Kt / opacity, translucent Kd / Ks / reflect / transmit, mix amount and metal eta / k";
                     return m.params.find_one_rgb(pname, d);
                 }
                 tex_param[param] = (int64_t)dt->second.id;
@@ -630,7 +630,7 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     for (float v : kv) { uint32_t u; std::memcpy(&u, &v, 4); char b[12]; std::snprintf(b, sizeof b, ":%08x", u); key += b; }
     if (bump_tex >= 0) key += "|bump=" + std::to_string(bump_tex);
     for (int k = 0; k < 4; k++) if (ftex_param[k] >= 0) key += "|ftex" + std::to_string(k) + "=" + std::to_string(ftex_param[k]);
-    for (int k = 0; k < 8; k++) if (tex_param[k] >= 0) key += "|tex" + std::to_string(k) + "=" + std::to_string(tex_param[k]);
+    for (int k = 0; k < 10; k++) if (tex_param[k] >= 0) key += "|tex" + std::to_string(k) + "=" + std::to_string(tex_param[k]);
     auto it = material_cache_.find(key);
     if (it != material_cache_.end()) return it->second;
     uint32_t id = 0;
@@ -654,6 +654,8 @@ uint32_t Api::material_id_for(const MaterialDesc& m) {
     for (int k = 4; k < 8; k++)
         if (tex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_texture(scene_, id, k, (uint32_t)tex_param[k])), "set_material_texture")) return 0;
     if (ftex_param[3] >= 0 && !check(ABI(pbrt_hip_set_material_float_texture(scene_, id, 3, (uint32_t)ftex_param[3])), "set_material_float_texture")) return 0;   // index: after opacity (an uber's is made per hit with it)
+    for (int k = 8; k < 10; k++)   // translucent's reflect / transmit: after Kd / Ks and the roughness (the per-hit lobe list takes their textures over)
+        if (tex_param[k] >= 0 && !check(ABI(pbrt_hip_set_material_texture(scene_, id, k, (uint32_t)tex_param[k])), "set_material_texture")) return 0;
     if (bump_tex >= 0 && !check(ABI(pbrt_hip_set_material_bump(scene_, id, (uint32_t)bump_tex)), "set_material_bump")) return 0;
     material_cache_[key] = id;
     return id;

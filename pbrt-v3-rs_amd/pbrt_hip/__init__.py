@@ -600,10 +600,10 @@ class Scene:
     def add_material_matte_tex(self, kd_texture, sigma=0.0):
         out = C.c_uint32(0); self._chk(self.b.fn("add_material_matte_tex")(self.h, kd_texture, C.c_float(sigma), C.byref(out))); return out.value
 
-    PARAM = {"Kd": 0, "Ks": 1, "Kr": 2, "Kt": 3, "opacity": 4, "amount": 5, "eta": 6, "k": 7}
+    PARAM = {"Kd": 0, "Ks": 1, "Kr": 2, "Kt": 3, "opacity": 4, "amount": 5, "eta": 6, "k": 7, "reflect": 8, "transmit": 9}
 
     def set_material_texture(self, material, param, texture):
-        """param: "Kd" | "Ks" | "Kr" | "Kt" | "opacity" (uber) | "amount" (mix) | "eta" | "k" (metal) — that parameter of `material` becomes `texture`, evaluated per hit."""
+        """param: "Kd" | "Ks" | "Kr" | "Kt" | "opacity" (uber) | "amount" (mix) | "eta" | "k" (metal) | "reflect" | "transmit" (translucent) — that parameter of `material` becomes `texture`, evaluated per hit."""
         self._chk(self.b.fn("set_material_texture")(self.h, material, self.PARAM[param], texture))
 
     def set_last_mesh_alpha_textures(self, alpha=None, shadow_alpha=None):

@@ -91,6 +91,18 @@ def metal(eta, k, eta_tex=None, k_tex=None):
     return make
 
 
+def translucent(reflect, transmit, rtex=None, ttex=None, kd_tex=False, rough_tex=None, kd=(0.6, 0.5, 0.4), ks=(0.3, 0.3, 0.3)):
+    """TranslucentMaterial whose reflect / transmit (translucent.rs:70-71) are constants or textures."""
+    def make(sc):
+        m = sc.add_material_translucent(kd, ks, reflect, transmit, 0.2, True)
+        if kd_tex: sc.set_material_texture(m, "Kd", sc.add_texture_imagemap(sc.add_mipmap(make_image(16, 16, seed=4))))
+        if rough_tex is not None: sc.set_material_float_texture(m, "roughness", rough_tex(sc))
+        if rtex is not None: sc.set_material_texture(m, "reflect", rtex(sc))
+        if ttex is not None: sc.set_material_texture(m, "transmit", ttex(sc))
+        return m
+    return make
+
+
 const = lambda v: (lambda sc: sc.add_texture_constant(v))
 checker = lambda a, b, n=6.0: (lambda sc: sc.add_texture_checkerboard(sc.add_texture_constant(a), sc.add_texture_constant(b), su=n, sv=n, aa="none"))
 image = lambda seed, scale=1.0: (lambda sc: sc.add_texture_scale(sc.add_texture_imagemap(sc.add_mipmap(make_image(24, 24, seed=seed))), sc.add_texture_constant(scale)))
@@ -112,6 +124,12 @@ PINS = [   # (name, constant material, the same through a constant texture)
     ("uber index 1.7, opacity 1", uber_index(ONE, 1.7), uber_index(ONE, 1.5, const(1.7))),
     ("uber index 1.3, opacity 0.6", uber_index((0.6, 0.6, 0.6), 1.3), uber_index((0.6, 0.6, 0.6), 1.5, const(1.3))),
     ("uber index 1.3, opacity texture", uber_index((0.7, 0.5, 0.9), 1.3), uber_index(None, 1.5, const(1.3), const((0.7, 0.5, 0.9)))),
+    ("translucent reflect texture", translucent((0.7, 0.6, 0.5), (0.3, 0.4, 0.5)), translucent((0.1, 0.1, 0.1), (0.3, 0.4, 0.5), const((0.7, 0.6, 0.5)))),
+    ("translucent both textures", translucent((0.7, 0.6, 0.5), (0.3, 0.4, 0.5)), translucent(ONE, ONE, const((0.7, 0.6, 0.5)), const((0.3, 0.4, 0.5)))),
+    ("translucent transmit texture, reflect 0", translucent((0.0, 0.0, 0.0), (0.6, 0.6, 0.7)), translucent((0.0, 0.0, 0.0), (0.1, 0.1, 0.1), None, const((0.6, 0.6, 0.7)))),
+    ("translucent reflect texture black, transmit only", translucent((0.0, 0.0, 0.0), (0.5, 0.5, 0.5)), translucent((0.4, 0.4, 0.4), (0.5, 0.5, 0.5), const((0.0, 0.0, 0.0)))),
+    ("translucent textures + Kd image + roughness texture", translucent((0.7, 0.6, 0.5), (0.3, 0.4, 0.5), kd_tex=True, rough_tex=const(0.3)), translucent(ONE, ONE, const((0.7, 0.6, 0.5)), const((0.3, 0.4, 0.5)), kd_tex=True, rough_tex=const(0.3))),
+    ("translucent no Ks", translucent((0.7, 0.6, 0.5), (0.3, 0.4, 0.5), ks=(0.0, 0.0, 0.0)), translucent(ONE, ONE, const((0.7, 0.6, 0.5)), const((0.3, 0.4, 0.5)), ks=(0.0, 0.0, 0.0))),
     ("metal eta k", metal((0.2, 0.9, 1.1), (3.9, 2.4, 2.1)), metal(ONE, ONE, const((0.2, 0.9, 1.1)), const((3.9, 2.4, 2.1)))),
     ("metal k only", metal((0.2, 0.9, 1.1), (3.9, 2.4, 2.1)), metal((0.2, 0.9, 1.1), ONE, None, const((3.9, 2.4, 2.1)))),
 ]
@@ -127,6 +145,9 @@ TEXTURED = [   # genuinely varying parameters: device against oracle
     ("glass u checker, v constant 0", glass(0.0, 0.0, checker(0.0, 0.3, 4.0), None)),
     ("glass roughness image", glass(0.1, 0.1, image(9, 0.4), image(10, 0.4))),
     ("metal eta k images", metal(ONE, ONE, image(11, 2.0), image(12, 4.0))),
+    ("translucent reflect checker, transmit image", translucent(ONE, ONE, checker((0.8, 0.7, 0.6), (0.1, 0.2, 0.3)), image(15))),
+    ("translucent reflect / transmit checkers with black squares (null BSDF where both are black)", translucent(ONE, ONE, checker((0.0, 0.0, 0.0), (0.7, 0.7, 0.7), 4.0), checker((0.0, 0.0, 0.0), (0.5, 0.6, 0.7), 4.0))),
+    ("translucent transmit checker 0 / 1 + Kd image", translucent((0.5, 0.5, 0.5), ONE, None, checker((0.0, 0.0, 0.0), ONE, 3.0), kd_tex=True)),
     ("glass index checker 1.2 / 1.9", glass(0.0, 0.0, index_tex=checker(1.2, 1.9))),
     ("glass rough, index image", glass(0.15, 0.1, index_tex=lambda sc: sc.add_texture_mix(sc.add_texture_constant(1.1), sc.add_texture_constant(2.2), sc.add_texture_imagemap(sc.add_mipmap(make_image(24, 24, seed=13), as_float=True))))),
     ("uber index checker, opacity checker", uber_index(None, 1.5, checker(1.25, 1.8, 5.0), checker(ONE, (0.3, 0.4, 0.5), 3.0))),
@@ -194,6 +215,25 @@ def test_oracle_checkerboard_index_is_one_of_the_two_constants_per_pixel(host):
     single = c[1] == 1.0
     assert single.sum() > 900 and (eq_a | eq_b)[single].all()
     assert (eq_a & ~eq_b).any() and (eq_b & ~eq_a).any()
+
+
+def test_oracle_translucent_null_bsdf_where_reflect_and_transmit_are_black(host):
+    """translucent.rs:72-74: where reflect and transmit both evaluate to black the material makes NO BSDF for the hit and the path integrator passes through the surface
+    without counting a bounce (path.rs:142-150).  A floor whose reflect and transmit are the same 0 / 1 checkerboard, against (a) the same floor made of Material "none"
+    and (b) the translucent of the non-black constants: at depth 1 with one sample per pixel every single-sample pixel equals one of the two films."""
+    chk = checker((0.0, 0.0, 0.0), ONE, 2.0)
+    c = _film(OracleScene, host, translucent(ONE, ONE, chk, chk), depth=1, res=32, spp=1)
+    a = _film(OracleScene, host, translucent(ONE, ONE), depth=1, res=32, spp=1)
+    b = _film(OracleScene, host, lambda sc: sc.add_material_none(), depth=1, res=32, spp=1)
+    eq_a = (c[0].view(np.uint32) == a[0].view(np.uint32)).all(axis=2)
+    eq_b = (c[0].view(np.uint32) == b[0].view(np.uint32)).all(axis=2)
+    single = c[1] == 1.0
+    assert single.sum() > 900 and (eq_a | eq_b)[single].all()
+    assert (eq_a & ~eq_b).any() and (eq_b & ~eq_a).any()
+    # reflect = transmit = 0 as constants: the same as Material "none" everywhere
+    z = _film(OracleScene, host, translucent((0.0, 0.0, 0.0), (0.0, 0.0, 0.0)), depth=3, res=32, spp=2)
+    n = _film(OracleScene, host, lambda sc: sc.add_material_none(), depth=3, res=32, spp=2)
+    assert _same(z, n)
 
 
 @pytest.mark.gpu
