@@ -109,6 +109,8 @@ def textured_material(s, host, rng):
             which = int(rng.integers(0, 3))
             if which != 1: s.set_material_float_texture(m, "uroughness", zero_or() if rng.integers(0, 2) else ftex(0.4))
             if which != 0: s.set_material_float_texture(m, "vroughness", zero_or() if rng.integers(0, 2) else ftex(0.4))
+        if rng.integers(0, 3) == 0:   # glass.rs:102: the index of refraction of every hit
+            s.set_material_float_texture(m, "index", s.add_texture_mix(s.add_texture_constant(float(rng.uniform(1.05, 1.4))), s.add_texture_constant(float(rng.uniform(1.5, 2.4))), ftex(1.0)))
     elif k == 5:
         op = float(rng.choice([1.0, rng.uniform(0.3, 0.9)]))
         m = s.add_material_uber(one, one, one, one, (op, op, op), float(rng.uniform(0.02, 0.3)), float(rng.uniform(0.02, 0.3)), float(rng.uniform(1.1, 1.7)), True)
@@ -116,6 +118,8 @@ def textured_material(s, host, rng):
             if rng.integers(0, 2): s.set_material_texture(m, prm, tex())
         if rng.integers(0, 3) == 0: s.set_material_float_texture(m, "uroughness", ftex(0.4))
         if rng.integers(0, 2): s.set_material_texture(m, "opacity", tex())   # uber.rs:126-160: pass-through lobe, colours and BSDF::eta per hit
+        if rng.integers(0, 3) == 0:   # uber.rs:128: `e` per hit (after the opacity: a constant one becomes a per-hit constant)
+            s.set_material_float_texture(m, "index", s.add_texture_checkerboard(s.add_texture_constant(float(rng.uniform(1.1, 1.4))), s.add_texture_constant(float(rng.uniform(1.5, 2.0))), su=float(rng.uniform(2, 9)), sv=float(rng.uniform(2, 9)), aa="none"))
     elif k == 6 or k == 7:
         def leaf(rough_ok):
             refl, trans = c(), c()
@@ -135,6 +139,11 @@ def textured_material(s, host, rng):
             return t
         if k == 6:
             m = leaf(True)
+            if rng.integers(0, 2):   # translucent.rs:70-74: reflect / transmit per hit; a checkerboard with black squares on both makes hits without any BSDF
+                black_or = lambda: s.add_texture_checkerboard(s.add_texture_constant((0.0, 0.0, 0.0)), s.add_texture_constant(c()), su=float(rng.uniform(2, 7)), sv=float(rng.uniform(2, 7)), aa="none")
+                which = int(rng.integers(0, 3))
+                if which != 1: s.set_material_texture(m, "reflect", black_or() if rng.integers(0, 2) else tex())
+                if which != 0: s.set_material_texture(m, "transmit", black_or() if rng.integers(0, 2) else tex())
         else:                                # MixMaterial over textured sub-materials (never bumped: mix.rs has no bump map)
             a = s.add_material_plastic(one, c(0.05, 0.5), float(rng.uniform(0.01, 0.4)), bool(rng.integers(0, 2))); s.set_material_texture(a, "Kd", tex())
             if rng.integers(0, 3) == 0: s.set_material_float_texture(a, "roughness", ftex(0.5))
