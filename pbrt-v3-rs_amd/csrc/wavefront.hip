@@ -657,11 +657,10 @@ __global__ __launch_bounds__(256) void film_tiles_kernel(FilmParams p) {
                 const bool up_x = sx < sx0n, up_y = sy < sy0n;   // only samples rounded up onto the next column / row matter from here ...
                 if ((up_x || up_y) && !p.px_rounded[pix]) continue;   // ... and raygen noted which pixels have any (a few per cent of them at 512 spp)
                 for (uint32_t s = 0; s < p.spp; s++) {
+                    const float4 r = p.rec_L[(size_t)s * p.n_px + pix];   // (both loads issued before either is tested: one latency per sample, not two)
                     const float pfy = p.rec_py[(size_t)s * p.n_px + pix];
-                    if (up_y && pfy != (float)(sy + 1)) continue;
-                    const float4 r = p.rec_L[(size_t)s * p.n_px + pix];
                     if (r.w != r.w) continue;  // pixel outside pixel_bounds: no sample was taken
-                    if (up_x && r.w != (float)(sx + 1)) continue;
+                    if ((up_y && pfy != (float)(sy + 1)) || (up_x && r.w != (float)(sx + 1))) continue;
                     const float pfx = r.w;
                     spec l = mks(r.x, r.y, r.z);
                     const float ly = lum_y(l);
@@ -1115,7 +1114,11 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
             if (s->textured_materials) {
                 if ((rc = timed(2, [&]() {
                         static const int tex_waves = []() { const char* e = std::getenv("PBRT_HIP_TEX_WAVES"); const int v = e ? std::atoi(e) : PH_TEX_SIMPLE_WAVES; return (v < 2 || v > 4) ? PH_TEX_SIMPLE_WAVES : v; }();
-                        if (!s->simple_textures || tex_waves == 0) hipLaunchKernelGGL((ph::texture_kernel<false, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        // the evaluator with the procedural classes: 2 waves per SIMD (246 VGPRs, no spills) against 3 (168 VGPRs, 317 spilled registers, 592 B of scratch per thread —
+                        // the pass then writes 3.2 TB of scratch per configs[4] frame): configs[4] at 64 spp 989 -> 851 ms of shade-side time per frame, same film (gpurun r03m)
+                        static const int full_waves = []() { const char* e = std::getenv("PBRT_HIP_TEX_FULL_WAVES"); const int v = e ? std::atoi(e) : 2; return (v < 2 || v > 3) ? 2 : v; }();
+                        if (!s->simple_textures && full_waves == 2) hipLaunchKernelGGL((ph::texture_kernel<false, 2>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        else if (!s->simple_textures || tex_waves == 0) hipLaunchKernelGGL((ph::texture_kernel<false, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         else if (tex_waves == 2) hipLaunchKernelGGL((ph::texture_kernel<true, 2>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         else if (tex_waves == 3) hipLaunchKernelGGL((ph::texture_kernel<true, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
                         else hipLaunchKernelGGL((ph::texture_kernel<true, 4>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
