@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = functional rehearsal of the N>1 path on ONE GPU: all ranks share device 0 and film tiles travel through host memory")
     ap.add_argument("--sm-scale", type=float, default=1.0, help="--config 4: tessellation scale of the generated scene (triangle counts ~ scale; 1 = the configuration's size)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the N > 1 code path (process group, barrier, film-tile gather over RCCL, merge of the gathered buffers) with the ranks there are, "
+                         "also with ONE — under `python -m torch.distributed.run --nproc-per-node 1`: the same torch.distributed / RCCL calls as on an 8-GPU node")
     ap.add_argument("--multi-handle", action="store_true",
                     help="N>1 from ONE process: one pbrt_hip_scene_create_multi handle over the N GPUs, the film-tile gather inside the library (RCCL send / recv); "
                          "with --backend gloo the N contexts share GPU 0 (rehearsal)")
@@ -199,7 +202,8 @@ def main():
         local_rank = 0  # rehearsal mode: every rank drives GPU 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    if world > 1:
+    use_dist = world > 1 or (args.force_dist and "RANK" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -242,7 +246,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -262,7 +266,7 @@ def main():
         t_setup = time.time() - t_setup
         floats = max(scene.tile_buffer_floats(tile_size, p, world) for p in range(world))
         tile_buf = torch.zeros(floats, dtype=torch.float32, device=dev)
-        gather_list = [torch.zeros(floats, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+        gather_list = [torch.zeros(floats, dtype=torch.float32, device=dev) for _ in range(world)] if (use_dist and rank == 0) else None
         # the film comes back into page-locked host arrays allocated once (67 MB at 2048 x 2048: a DMA transfer instead of a staged copy into freshly faulted pages every frame)
         film_out = None
         if rank == 0:
@@ -276,7 +280,7 @@ def main():
                 return st, (xyz, wt)
             st = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
             film = None
-            if world > 1:
+            if use_dist:
                 if args.backend == "nccl":
                     dist.gather(tile_buf, gather_list, dst=0)   # RCCL over xGMI, device buffers
                 else:
@@ -307,7 +311,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         rays = reg + shd
-        if world > 1:
+        if use_dist:
             elapsed = float(reduce_scalars([elapsed], dist.ReduceOp.MAX, torch.float64)[0])
             rays, reg, shd = (int(v) for v in reduce_scalars([rays, reg, shd], dist.ReduceOp.SUM, torch.int64))
         return scene, tile_buf, dict(elapsed=elapsed, rays=rays, reg=reg, shd=shd, ext_s=ext_s, sh_s=sh_s, shade_s=shade_s, launches=launches, film=film,
@@ -441,7 +445,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     scene.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -108,3 +108,19 @@ def test_split_traversal_env_gives_the_same_film():
     assert two.returncode == 0, two.stderr[-2000:]
     a, b = _last_json(one.stdout), _last_json(two.stdout)
     assert a["film_sha256"] == b["film_sha256"] and a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+
+
+def test_bench_nccl_code_path_with_one_rank():
+    """The N > 1 code path of bench.py over the REAL backend — `init_process_group("nccl")` (= RCCL), barrier, `dist.gather` of the device tile buffer, all_reduce of the timings, merge of
+    the gathered buffers — exercised with the one rank a one-GPU box has (`--force-dist` under torch.distributed.run --nproc-per-node 1): the very calls an 8-GPU node makes, and the
+    same film as the plain run."""
+    common = ["--config", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--spp", "4", "--res", "160", "--n-tris", "8000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    rc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                         os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl"] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert rc.returncode == 0, rc.stderr[-3000:]
+    a, b = _last_json(one.stdout), _last_json(rc.stdout)
+    assert a["film_sha256"] == b["film_sha256"] and a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
