@@ -382,6 +382,7 @@ def main():
                              "any_hit": {"rays": ah["rays"], "ref_node_visits_per_ray": round(ah["ref_node_visits"] / max(ah["rays"], 1), 2),
                                          "tri_tests_per_ray": round(ah["tri_tests"] / max(ah["rays"], 1), 2), "bytes_per_ray": round(bytes_ah / max(ah["rays"], 1), 1)},
                              "kernel_Mrays_per_s": round(n_rays / trav_per_frame / 1e6, 1),
+                             "node_steps_per_ray": round((cl["nodes_passed"] + ah["nodes_passed"]) / max(n_rays, 1), 2),
                              "note": "achieved = algorithmic bytes (SURVEY 8d, reference-format 32-B nodes, counted by an untimed counting pass of the same frame) / HIP-event time "
                                      "of every traversal launch of the timed steps; frac = memory-side PMC bytes / that time / peak when a PMC run of this workload is on file"})
                 # memory-side traffic of the same kernel from rocprofv3 PMC passes (separate runs of this script under `rocprofv3 --pmc`, scripts/pmc_profile.sh;

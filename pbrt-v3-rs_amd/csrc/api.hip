@@ -230,10 +230,11 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
     return PBRT_HIP_OK;
 }
 
-// The traversal kernel's shape: {LEAF_MIN, REFILL_MIN, LDS_DEPTH, NODE_STEPS, waves per SIMD the kernel is compiled for (0 = the compiler's choice)}.  Slot 0 is what ships
-// (measured on configs[2] / configs[1] with binned queues: 742.6 / 31.3 ms of traversal per frame against 760.2 / 31.7 for the round-1 shape, gpurun r02h); slot 1 is the one
-// spare A/B slot (PBRT_HIP_TRAV_VARIANT=1), holding the round-1 shape.  The seventeen other shapes rounds 1 and 2 compared are in DESIGN §4 / §7b with their numbers.
-#define PH_VARIANTS(X) X(0, 24, 12, 12, 5, 6, false) X(1, 20, 12, 12, 3, 0, false)
+// The traversal kernel's shape: {LEAF_MIN, REFILL_MIN, LDS_DEPTH, NODE_STEPS, waves per SIMD the kernel is compiled for (0 = the compiler's choice)}.  Slot 0 is what ships:
+// 7 waves per SIMD (63 VGPRs since the round-3 register diet — signs and permutation in one word, the hit remembered by its TriRec alone —, 11 stack entries in LDS), lanes wait
+// for 16 companions at leaves and for 20 idle lanes before a refill, 6 node steps per pass: configs[2] / configs[1] 681.8 / 30.5 ms of traversal per frame against 706.9 / 31.7 for
+// slot 1, the shape rounds 2 shipped (6 waves, 24 / 12 / 5; gpurun r03s - r03w, three sweeps of nine shapes each around it).  PBRT_HIP_TRAV_VARIANT=1 selects slot 1 for A/B runs.
+#define PH_VARIANTS(X) X(0, 16, 20, 11, 6, 7, false) X(1, 24, 12, 12, 5, 6, false)
 #define PH_N_VARIANTS 2
 #define PH_DEFAULT_INST_VARIANT 1   // 1 000 instances x 10 k triangles: 95.0 ms of traversal per frame against 102.9 (variant 0), 101.7 (2), 109.0 (3) (gpurun r02n)
 #define PH_DEFAULT_VARIANT 0

@@ -57,20 +57,23 @@ struct TravParams {
 struct RayState {
     float ox, oy, oz, dx, dy, dz, t_max;
     float ix, iy, iz;       // 1/d (three IEEE divides, bvh/mod.rs:176)
-    int nx, ny, nz;         // dir_is_neg
-    int kx, ky, kz;         // triangle.rs:457-459
+    uint32_t sgn;           // bits 0..2: dir_is_neg x, y, z (bvh/mod.rs:177-181); bits 3..4: kz of the triangle test (triangle.rs:457-459: kx = kz + 1, ky = kx + 1, both modulo 3)
     float sx, sy, sz;       // triangle.rs:467-469
+    PH_DEV bool nx() const { return (sgn & 1u) != 0u; }
+    PH_DEV bool ny() const { return (sgn & 2u) != 0u; }
+    PH_DEV bool nz() const { return (sgn & 4u) != 0u; }
+    PH_DEV int kz() const { return (int)((sgn >> 3) & 3u); }
+    PH_DEV int kx() const { const int k = kz() + 1; return k == 3 ? 0 : k; }
+    PH_DEV int ky() const { const int k = kx() + 1; return k == 3 ? 0 : k; }
 };
 
 PH_DEV void ray_setup(RayState& r, const RayIn& in) {
     r.ox = in.ox; r.oy = in.oy; r.oz = in.oz; r.dx = in.dx; r.dy = in.dy; r.dz = in.dz; r.t_max = in.t_max;
     r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-    r.nx = r.ix < 0.0f ? 1 : 0; r.ny = r.iy < 0.0f ? 1 : 0; r.nz = r.iz < 0.0f ? 1 : 0;
     f3 d = mk3(r.dx, r.dy, r.dz);
-    r.kz = max_dimension(vabs(d));
-    r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0;
-    r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0;
-    f3 dp = permute(d, r.kx, r.ky, r.kz);
+    const int kz = max_dimension(vabs(d));
+    r.sgn = (r.ix < 0.0f ? 1u : 0u) | (r.iy < 0.0f ? 2u : 0u) | (r.iz < 0.0f ? 4u : 0u) | ((uint32_t)kz << 3);
+    f3 dp = permute(d, r.kx(), r.ky(), kz);
     r.sx = -dp.x / dp.z; r.sy = -dp.y / dp.z; r.sz = 1.0f / dp.z;
 }
 
@@ -143,12 +146,78 @@ PH_DEV bool box_test(const RayState& r, float xn, float xf, float yn, float yf, 
     return (t_min <= t_max) & (t_max > 0.0f) & ((t_x_min == t_x_min) & (t_x_max == t_x_max));
 }
 
+// Both boxes of a Node64 against one ray: box_test twice (incl. its caller's `t_min < ray.t_max`), written for the packed two-float VALU operations of gfx950.
+// A node stores each slab as the pair (lo, hi) in adjacent dwords, so (lo - o) * inv and (hi - o) * inv are ONE v_pk_add_f32 and ONE v_pk_mul_f32 per axis and box, on
+// the registers the load filled; the near / far choice (dir_is_neg, bounds3.rs:296-298 indexes the bounds with it) is made on the two products afterwards — the same
+// operands meet in the same operations, so every product has the bits box_test's have —, the widening factor goes onto (far x, far y) as one more packed multiply.
+// 15 VALU instructions per box instead of 22.  The NaN test of the x slab is symmetric in (near, far) and widening keeps a NaN a NaN and a number a number, so it reads the raw pair.
+#ifndef PH_NODE_PK
+#define PH_NODE_PK 1
+#endif
+typedef float ph_v2f __attribute__((ext_vector_type(2)));
+// A per-lane condition as the wave's lane mask (the active lanes' bits) and back: conditions combined as masks cost scalar instructions, not vector ones.
+typedef unsigned long long ph_mask;
+PH_DEV ph_mask lanes(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(c);
+#else
+    return c ? 1ull : 0ull;
+#endif
+}
+PH_DEV bool lane_of(ph_mask m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_inverse_ballot_w64(m);
+#else
+    return (m & 1ull) != 0ull;
+#endif
+}
+// (lo, hi) - o and * inv with the ray's scalar taken from one half of a register pair for BOTH results (op_sel), so the ray needs no duplicated registers:
+// SEL = 0 reads the pair's low dword, 1 its high dword.  a - b is a + (-b) in IEEE arithmetic (neg_lo / neg_hi).
+template <int SEL> PH_DEV ph_v2f pk_sub_bcast(ph_v2f a, ph_v2f p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    ph_v2f d;
+    if (SEL == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(p));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(p));
+    return d;
+#else
+    const float o = SEL ? p.y : p.x; return (ph_v2f){a.x - o, a.y - o};
+#endif
+}
+template <int SEL> PH_DEV ph_v2f pk_mul_bcast(ph_v2f a, ph_v2f p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    ph_v2f d;
+    if (SEL == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(p));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(p));
+    return d;
+#else
+    const float o = SEL ? p.y : p.x; return (ph_v2f){a.x * o, a.y * o};
+#endif
+}
+PH_DEV void node_boxes(const RayState& r, float4 q0, float4 q1, float4 q2, ph_mask& m0, float& t0, ph_mask& m1, float& t1) {
+    const ph_v2f pxy = {r.ox, r.oy}, pzi = {r.oz, r.ix}, pii = {r.iy, r.iz};
+    const ph_v2f ax = pk_mul_bcast<1>(pk_sub_bcast<0>((ph_v2f){q0.x, q0.y}, pxy), pzi), ay = pk_mul_bcast<0>(pk_sub_bcast<1>((ph_v2f){q0.z, q0.w}, pxy), pii),
+                 az = pk_mul_bcast<1>(pk_sub_bcast<0>((ph_v2f){q1.x, q1.y}, pzi), pii);
+    const ph_v2f bx = pk_mul_bcast<1>(pk_sub_bcast<0>((ph_v2f){q1.z, q1.w}, pxy), pzi), by = pk_mul_bcast<0>(pk_sub_bcast<1>((ph_v2f){q2.x, q2.y}, pxy), pii),
+                 bz = pk_mul_bcast<1>(pk_sub_bcast<0>((ph_v2f){q2.z, q2.w}, pzi), pii);
+    const bool nx = r.nx(), ny = r.ny(), nz = r.nz();
+    const ph_v2f scale = {kBoxScale, kBoxScale};
+    const ph_v2f a_far = (ph_v2f){nx ? ax.x : ax.y, ny ? ay.x : ay.y} * scale;
+    const ph_v2f b_far = (ph_v2f){nx ? bx.x : bx.y, ny ? by.x : by.y} * scale;
+    t0 = vmax3(nx ? ax.y : ax.x, ny ? ay.y : ay.x, nz ? az.y : az.x);
+    const float a_max = vmin3(a_far.x, a_far.y, nz ? az.x : az.y);
+    t1 = vmax3(nx ? bx.y : bx.x, ny ? by.y : by.x, nz ? bz.y : bz.x);
+    const float b_max = vmin3(b_far.x, b_far.y, nz ? bz.x : bz.y);
+    // the verdicts as lane masks (one scalar AND per clause; kept as per-lane booleans they travel through vector registers)
+    m0 = lanes(t0 <= a_max) & lanes(a_max > 0.0f) & lanes(!__builtin_isunordered(ax.x, ax.y)) & lanes(t0 < r.t_max);
+    m1 = lanes(t1 <= b_max) & lanes(b_max > 0.0f) & lanes(!__builtin_isunordered(bx.x, bx.y)) & lanes(t1 < r.t_max);
+}
 // Triangle::intersect up to `if t <= delta_t` (triangle.rs:441-545).  Returns true when the reference proceeds past it.
 PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float& b0_out, float& b1_out, float& b2_out) {
     f3 o = mk3(r.ox, r.oy, r.oz);
-    f3 p0t = permute(p0 - o, r.kx, r.ky, r.kz);
-    f3 p1t = permute(p1 - o, r.kx, r.ky, r.kz);
-    f3 p2t = permute(p2 - o, r.kx, r.ky, r.kz);
+    const int kx = r.kx(), ky = r.ky(), kz = r.kz();
+    f3 p0t = permute(p0 - o, kx, ky, kz);
+    f3 p1t = permute(p1 - o, kx, ky, kz);
+    f3 p2t = permute(p2 - o, kx, ky, kz);
     p0t.x += r.sx * p0t.z; p0t.y += r.sy * p0t.z;
     p1t.x += r.sx * p1t.z; p1t.y += r.sy * p1t.z;
     p2t.x += r.sx * p2t.z; p2t.y += r.sy * p2t.z;
@@ -184,6 +253,34 @@ PH_DEV bool tri_test(const RayState& r, f3 p0, f3 p1, f3 p2, float& t_out, float
     if (t <= delta_t) return false;
     t_out = t; b0_out = b0; b1_out = b1; b2_out = b2;
     return true;
+}
+
+// The barycentrics of tri_test alone (its e0 .. e2, det and inv_det, operation for operation): a kernel that does not carry an accepted hit's b0 .. b2 through the walk
+// (traverse_kernel without instancing: five registers less) recomputes them from the winning triangle when the ray retires.  No rejection test is repeated — at that point
+// r.t_max is the hit's own t, and `t_scaled > t_max * det` could reject it by a rounding of the product.
+PH_DEV void tri_bary(const RayState& r, f3 p0, f3 p1, f3 p2, float& b0_out, float& b1_out, float& b2_out) {
+    f3 o = mk3(r.ox, r.oy, r.oz);
+    const int kx = r.kx(), ky = r.ky(), kz = r.kz();
+    f3 p0t = permute(p0 - o, kx, ky, kz);
+    f3 p1t = permute(p1 - o, kx, ky, kz);
+    f3 p2t = permute(p2 - o, kx, ky, kz);
+    p0t.x += r.sx * p0t.z; p0t.y += r.sy * p0t.z;
+    p1t.x += r.sx * p1t.z; p1t.y += r.sy * p1t.z;
+    p2t.x += r.sx * p2t.z; p2t.y += r.sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        double a = (double)p2t.x * (double)p1t.y, b = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(b - a);
+        a = (double)p0t.x * (double)p2t.y; b = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(b - a);
+        a = (double)p1t.x * (double)p0t.y; b = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(b - a);
+    }
+    const float det = e0 + e1 + e2;
+    const float inv_det = 1.0f / det;
+    b0_out = e0 * inv_det; b1_out = e1 * inv_det; b2_out = e2 * inv_det;
 }
 
 // COUNT = true adds per-ray work counters (roofline bookkeeping, never used in a timed run).  For closest-hit rays the
@@ -249,7 +346,10 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
     RayState r;
     uint32_t cur = PH_INVALID_REF;           // interior node index, or PH_LEAF_BIT | index of the NEXT TriRec to test
     int sp = 0;
-    uint32_t hit_prim = 0xFFFFFFFFu, hit_tri = 0u, hit_cls = 0u;
+    // LEAN (no instancing): an accepted hit is remembered by its TriRec alone (hit_tri, none = all ones); primitive id, material class and barycentrics are read / recomputed
+    // from it when the ray retires (tri_bary) — five registers the walk does not carry.  With instancing the hit may lie in an instance's space, and that kernel is not register-bound.
+    constexpr bool LEAN = !INST;
+    uint32_t hit_prim = 0xFFFFFFFFu, hit_tri = LEAN ? 0xFFFFFFFFu : 0u, hit_cls = 0u;
     float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     bool occluded = false;
     uint32_t c_nodes[2] = {0, 0}, c_tris[2] = {0, 0}, c_rays[2] = {0, 0}, c_visits = 0;  // COUNT: [0] this launch's first kind, [1] MIXED any-hit
@@ -321,16 +421,17 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         const float4 a = rp[0], b = rp[1];
                         RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = a.w; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
                         ray_setup(r, in);
-                        has_ray = true; sp = 0; hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hb0 = hb1 = hb2 = 0.0f; occluded = false;
+                        has_ray = true; sp = 0; occluded = false;
+                        if (LEAN) hit_tri = 0xFFFFFFFFu; else { hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hb0 = hb1 = hb2 = 0.0f; }
                         if (INST) { in_inst = 0; hit_inst = 0; }
                         // root: the reference tests nodes[0].bounds first (bvh/mod.rs:189-190)
                         cur = PH_INVALID_REF;
                         if (COUNT && ah) c_visits++;
                         if (sc.root_ref != PH_INVALID_REF) {
                             float tmin;
-                            const bool h = box_test(r, r.nx ? sc.root_hi[0] : sc.root_lo[0], r.nx ? sc.root_lo[0] : sc.root_hi[0],
-                                                    r.ny ? sc.root_hi[1] : sc.root_lo[1], r.ny ? sc.root_lo[1] : sc.root_hi[1],
-                                                    r.nz ? sc.root_hi[2] : sc.root_lo[2], r.nz ? sc.root_lo[2] : sc.root_hi[2], tmin);
+                            const bool h = box_test(r, r.nx() ? sc.root_hi[0] : sc.root_lo[0], r.nx() ? sc.root_lo[0] : sc.root_hi[0],
+                                                    r.ny() ? sc.root_hi[1] : sc.root_lo[1], r.ny() ? sc.root_lo[1] : sc.root_hi[1],
+                                                    r.nz() ? sc.root_hi[2] : sc.root_lo[2], r.nz() ? sc.root_lo[2] : sc.root_hi[2], tmin);
                             if (h && tmin < r.t_max) cur = sc.root_ref;
                         }
                     }
@@ -353,17 +454,33 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
             if (COUNT) c_nodes[(MIXED && ah) ? 1 : 0]++;
             // q0 = x0[0],x0[1],y0[0],y0[1]; q1 = z0[0],z0[1],x1[0],x1[1]; q2 = y1[0],y1[1],z1[0],z1[1]
             float t0, t1;
-            bool h0 = box_test(r, r.nx ? q0.y : q0.x, r.nx ? q0.x : q0.y, r.ny ? q0.w : q0.z, r.ny ? q0.z : q0.w,
-                               r.nz ? q1.y : q1.x, r.nz ? q1.x : q1.y, t0);
-            bool h1 = box_test(r, r.nx ? q1.w : q1.z, r.nx ? q1.z : q1.w, r.ny ? q2.y : q2.x, r.ny ? q2.x : q2.y,
-                               r.nz ? q2.w : q2.z, r.nz ? q2.z : q2.w, t1);
+#if PH_NODE_PK
+            ph_mask m0, m1;
+            node_boxes(r, q0, q1, q2, m0, t0, m1, t1);
+            // bvh/mod.rs:206-214: dir_is_neg[axis] -> second child first
+#if defined(__HIP_DEVICE_COMPILE__)
+            const ph_mask m_neg = lanes(__builtin_amdgcn_ubfe(r.sgn, q3.z, 1u) != 0u);
+#else
+            const ph_mask m_neg = lanes(((r.sgn >> q3.z) & 1u) != 0u);
+#endif
+            const bool neg_axis = lane_of(m_neg);
+            const uint32_t near_ref = neg_axis ? q3.y : q3.x, far_ref = neg_axis ? q3.x : q3.y;
+            const bool near_hit = lane_of((m_neg & m1) | (~m_neg & m0)), far_hit = lane_of((m_neg & m0) | (~m_neg & m1));
+            const float far_t = neg_axis ? t0 : t1;
+#else
+            bool h0, h1;
+            h0 = box_test(r, r.nx() ? q0.y : q0.x, r.nx() ? q0.x : q0.y, r.ny() ? q0.w : q0.z, r.ny() ? q0.z : q0.w,
+                               r.nz() ? q1.y : q1.x, r.nz() ? q1.x : q1.y, t0);
+            h1 = box_test(r, r.nx() ? q1.w : q1.z, r.nx() ? q1.z : q1.w, r.ny() ? q2.y : q2.x, r.ny() ? q2.x : q2.y,
+                               r.nz() ? q2.w : q2.z, r.nz() ? q2.z : q2.w, t1);
             h0 = h0 & (t0 < r.t_max);
             h1 = h1 & (t1 < r.t_max);
-            const int neg_axis = q3.z == 0 ? r.nx : (q3.z == 1 ? r.ny : r.nz);
+            const int neg_axis = (int)((r.sgn >> q3.z) & 1u);
             // bvh/mod.rs:206-214: dir_is_neg[axis] -> second child first
             const uint32_t near_ref = neg_axis ? q3.y : q3.x, far_ref = neg_axis ? q3.x : q3.y;
             const bool near_hit = neg_axis ? h1 : h0, far_hit = neg_axis ? h0 : h1;
             const float far_t = neg_axis ? t0 : t1;
+#endif
             if (COUNT && ah) {
                 // any-hit rays stop early, so "nodes the reference visits" is counted as it goes: the near child always, the far child when
                 // it is popped — also when its box test fails, hence the NaN-keyed entry (pop() counts it and skips it)
@@ -398,7 +515,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                             in_inst = __float_as_uint(a.w) + 1u; inst_sp = sp; inst_hit = false;
                             inst_save[0][tid] = r.ox; inst_save[1][tid] = r.oy; inst_save[2][tid] = r.oz; inst_save[3][tid] = r.dx; inst_save[4][tid] = r.dy; inst_save[5][tid] = r.dz;
                             inst_save[6][tid] = r.ix; inst_save[7][tid] = r.iy; inst_save[8][tid] = r.iz; inst_save[9][tid] = r.sx; inst_save[10][tid] = r.sy; inst_save[11][tid] = r.sz;
-                            inst_save[12][tid] = __uint_as_float((uint32_t)(r.nx | (r.ny << 1) | (r.nz << 2) | (r.kx << 3) | (r.ky << 5) | (r.kz << 7)));
+                            inst_save[12][tid] = __uint_as_float(r.sgn);
                             // (round 3, measured and not kept: proving a miss of the object's bound with three hardware reciprocals before paying this set-up — the proof rarely
                             //  succeeds once the instance's world bound has been passed, 86.6 -> 93.2 ms on 1 000 x 10 k instances — and postponing the triangle half of ray_setup
                             //  to the first triangle met inside: no difference, gpurun r03g)
@@ -408,8 +525,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                             if (I.flags & PH_INST_SINGLE) cur = I.root_ref;  // the lone primitive itself, no aggregate
                             else {
                                 float tmin;
-                                const bool h = box_test(r, r.nx ? I.hi[0] : I.lo[0], r.nx ? I.lo[0] : I.hi[0], r.ny ? I.hi[1] : I.lo[1], r.ny ? I.lo[1] : I.hi[1],
-                                                        r.nz ? I.hi[2] : I.lo[2], r.nz ? I.lo[2] : I.hi[2], tmin);
+                                const bool h = box_test(r, r.nx() ? I.hi[0] : I.lo[0], r.nx() ? I.lo[0] : I.hi[0], r.ny() ? I.hi[1] : I.lo[1], r.ny() ? I.lo[1] : I.hi[1],
+                                                        r.nz() ? I.hi[2] : I.lo[2], r.nz() ? I.lo[2] : I.hi[2], tmin);
                                 if (h && tmin < r.t_max) cur = I.root_ref;
                             }
                         } else {
@@ -423,8 +540,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                             if (accept) {
                                 if (ah) occluded = true;
                                 else {
-                                    r.t_max = t; hit_prim = __float_as_uint(a.w); hit_tri = ti; hb0 = b0; hb1 = b1; hb2 = b2;
-                                    hit_cls = (flags >> PH_TRI_CLASS_SHIFT) & 7u;
+                                    r.t_max = t; hit_tri = ti;
+                                    if (!LEAN) { hit_prim = __float_as_uint(a.w); hb0 = b0; hb1 = b1; hb2 = b2; hit_cls = (flags >> PH_TRI_CLASS_SHIFT) & 7u; }
                                     if (INST) { hit_inst = in_inst; inst_hit = true; }
                                 }
                             }
@@ -444,8 +561,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                 const float t_new = inst_hit ? r.t_max : world_tmax;
                 r.ox = inst_save[0][tid]; r.oy = inst_save[1][tid]; r.oz = inst_save[2][tid]; r.dx = inst_save[3][tid]; r.dy = inst_save[4][tid]; r.dz = inst_save[5][tid];
                 r.ix = inst_save[6][tid]; r.iy = inst_save[7][tid]; r.iz = inst_save[8][tid]; r.sx = inst_save[9][tid]; r.sy = inst_save[10][tid]; r.sz = inst_save[11][tid];
-                const uint32_t pk = __float_as_uint(inst_save[12][tid]);
-                r.nx = (int)(pk & 1u); r.ny = (int)((pk >> 1) & 1u); r.nz = (int)((pk >> 2) & 1u); r.kx = (int)((pk >> 3) & 3u); r.ky = (int)((pk >> 5) & 3u); r.kz = (int)((pk >> 7) & 3u);
+                r.sgn = __float_as_uint(inst_save[12][tid]);
                 r.t_max = t_new;
                 in_inst = 0;
                 cur = (cont_ref != PH_INVALID_REF) ? cont_ref : pop();
@@ -458,6 +574,14 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
             else if (!MIXED && ANYHIT) reinterpret_cast<uint8_t*>(p.out)[ray_index] = occluded ? 1 : 0;
             else {
                 float4* hp = reinterpret_cast<float4*>(reinterpret_cast<HitOut*>(p.out) + ray_index);
+                if (LEAN) {
+                    if (hit_tri != 0xFFFFFFFFu) {
+                        const float4* tp = reinterpret_cast<const float4*>(sc.tris + hit_tri);
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        tri_bary(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), hb0, hb1, hb2);
+                        hit_prim = __float_as_uint(a.w); hit_cls = (__float_as_uint(b.w) >> PH_TRI_CLASS_SHIFT) & 7u;
+                    } else { hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hit_cls = 0u; hb0 = hb1 = hb2 = 0.0f; }
+                }
                 hp[0] = make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1);
                 hp[1] = make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), __uint_as_float(hit_cls));  // pad[0] = the hit's TriRec, pad[1] = instance + 1, pad[2] = material class
             }

@@ -9,6 +9,7 @@ first, last = int(sys.argv[1]), int(sys.argv[2])
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
 bad = []
 for seed in range(first, last):
+    if (seed - first) % 50 == 0: print('progress: seed', seed, 'bad so far', bad, flush=True)
     cap, kw = T.build_case(host, seed, big)
     prod = pbrt_hip.Scene(); orc = OracleScene()
     try:

@@ -8,6 +8,7 @@ host = pbrt_hip.Host()
 first, last = int(sys.argv[1]), int(sys.argv[2])
 bad = []; skipped = 0
 for seed in range(first, last):
+    if (seed - first) % 50 == 0: print('progress: seed', seed, 'bad so far', bad, flush=True)
     ok, info = T.run_case(host, seed)
     if ok is None: skipped += 1
     elif not ok: bad.append(seed); print("MISMATCH seed", seed, info, flush=True)

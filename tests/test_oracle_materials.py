@@ -187,8 +187,8 @@ def test_substrate_translucent_mix():
         assert fm[:3] == pytest.approx(np.array([0.25, 0.5, 0.75]) * np.array([0.5, 0.4, 0.3]) / np.pi, rel=1e-5)
         sm = o.bsdf_probe(mix, 1, wo=wo, u=(0.75, 0.5))       # second of two components: the mirror
         assert sm[7] == SPEC | REFL and sm[:3] == pytest.approx(np.array([0.75, 0.5, 0.25]) * 0.9 / wo[2], rel=1e-5) and sm[3] == pytest.approx(0.5)
-        with pytest.raises(Exception):
-            o.add_material_translucent((0.3,) * 3, (0.2,) * 3, (0, 0, 0), (0, 0, 0), 0.1, True)
+        # reflect = transmit = 0: the reference makes no BSDF at such a hit (translucent.rs:72-74), i.e. the surface behaves as Material "none" — accepted since round 3
+        assert o.add_material_translucent((0.3,) * 3, (0.2,) * 3, (0, 0, 0), (0, 0, 0), 0.1, True) >= 0
 
 
 def test_none_material_is_passed_through(host):
