@@ -236,7 +236,7 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
 // slot 1, the shape rounds 2 shipped (6 waves, 24 / 12 / 5; gpurun r03s - r03w, three sweeps of nine shapes each around it).  PBRT_HIP_TRAV_VARIANT=1 selects slot 1 for A/B runs.
 #define PH_VARIANTS(X) X(0, 16, 20, 11, 6, 7, false) X(1, 24, 12, 12, 5, 6, false)
 #define PH_N_VARIANTS 2
-#define PH_DEFAULT_INST_VARIANT 1   // 1 000 instances x 10 k triangles: 95.0 ms of traversal per frame against 102.9 (variant 0), 101.7 (2), 109.0 (3) (gpurun r02n)
+#define PH_DEFAULT_INST_VARIANT 2   // the 5-wave instancing kernel (launch_traverse_kernel); 1 = the 4-wave form, kept as the A/B slot
 #define PH_DEFAULT_VARIANT 0
 static int trav_variant() {
     static int v = -1;
@@ -272,7 +272,7 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
     if ((rc = ensure_buf(s, s->d_error, 64))) return rc;
     if ((rc = ensure_buf(s, s->d_counts, 64))) return rc;
     const int stack_cap = s->inst_recs.empty() ? PH_MAX_STACK : 2 * PH_MAX_STACK;  // with instances the scene-level and object-level entries share one stack
-    const int lds_depth = s->inst_recs.empty() ? variant_lds_depth(trav_variant()) : PH_LDS_DEPTH;
+    const int lds_depth = s->inst_recs.empty() ? variant_lds_depth(trav_variant()) : 11;   // (the shallowest LDS stack any instancing kernel is compiled with)
     if ((rc = ensure_buf(s, s->d_spill, (size_t)(stack_cap - lds_depth) * total_threads * sizeof(uint2)))) return rc;
     return PBRT_HIP_OK;
 }
@@ -290,30 +290,33 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
         else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, 0, wpe>), g, b, 0, s->stream, s->ds, p); \
         else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, 0, wpe>), g, b, 0, s->stream, s->ds, p);             \
     } while (0)
-#define PH_LAUNCH3A(cnt, lm, rm, ns, inst, alpha, wpe)                                                                                 \
+#define PH_LAUNCH3A(cnt, lm, rm, ld, ns, inst, alpha, wpe)                                                                             \
     do {                                                                                                                              \
-        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, PH_LDS_DEPTH, ns, inst, true, alpha, wpe>), g, b, 0, s->stream, s->ds, p);       \
-        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, PH_LDS_DEPTH, ns, inst, false, alpha, wpe>), g, b, 0, s->stream, s->ds, p);  \
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, PH_LDS_DEPTH, ns, inst, false, alpha, wpe>), g, b, 0, s->stream, s->ds, p);                \
+        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, true, alpha, wpe>), g, b, 0, s->stream, s->ds, p);       \
+        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, alpha, wpe>), g, b, 0, s->stream, s->ds, p);  \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, alpha, wpe>), g, b, 0, s->stream, s->ds, p);                \
     } while (0)
     if (s->alpha_textures) {  // meshes with alpha-mask textures: the ALPHA variants — 1 = the inlined test for image-map masks, 2 = the general evaluator out of line (traverse.h)
         const bool inst = !s->inst_recs.empty();
         if (s->alpha_lean) {
-            if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, 1, true, 1, 0); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, 1, false, 1, 0); }
-            else if (inst) PH_LAUNCH3A(false, 24, 12, 5, true, 1, 4); else PH_LAUNCH3A(false, 24, 12, 5, false, 1, 0);   // (the instancing form: compiled for the 4 waves per SIMD its LDS allows)
+            if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 1, 0); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false, 1, 0); }
+            else if (inst) PH_LAUNCH3A(false, 24, 12, PH_LDS_DEPTH, 5, true, 1, 4);   // (with the alpha test inlined the instancing form needs 115 registers: compiled for 5 waves per SIMD it spills 18 and configs[4]'s traversal takes 6.83 s instead of 6.35, gpurun r03ae)
+            else PH_LAUNCH3A(false, 24, 12, PH_LDS_DEPTH, 5, false, 1, 0);
         } else {
-            if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, 1, true, 2, 0); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, 1, false, 2, 0); }
-            else if (inst) PH_LAUNCH3A(false, PH_LEAF_MIN, PH_REFILL_MIN, 3, true, 2, 0); else PH_LAUNCH3A(false, PH_LEAF_MIN, PH_REFILL_MIN, 3, false, 2, 0);
+            if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 2, 0); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false, 2, 0); }
+            else if (inst) PH_LAUNCH3A(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true, 2, 0); else PH_LAUNCH3A(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, false, 2, 0);
         }
         return;
     }
     if (!s->inst_recs.empty()) {  // scenes with object instances: the TransformedPrimitive-aware kernels
         if (s->count_traversal) PH_LAUNCH3(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 0, false);
         else {
-            static const int iv = []() { const char* e = std::getenv("PBRT_HIP_INST_VARIANT"); const int v = e ? std::atoi(e) : PH_DEFAULT_INST_VARIANT; return (v < 0 || v > 1) ? PH_DEFAULT_INST_VARIANT : v; }();
-            switch (iv) {   // the instancing kernel carries 111 VGPRs (4 waves per SIMD = 4 blocks per CU, which is also what its 38 KB of LDS per block allow); the 5-wave builds of round 2 (96 VGPRs, 9 spilled) were slower
+            static const int iv = []() { const char* e = std::getenv("PBRT_HIP_INST_VARIANT"); const int v = e ? std::atoi(e) : PH_DEFAULT_INST_VARIANT; return (v < 1 || v > 2) ? PH_DEFAULT_INST_VARIANT : v; }();
+            switch (iv) {   // round 3: 96 VGPRs without spills (102 where the compiler is free) and 31 KB of LDS (11 stack entries + 9 parked words per lane): FIVE blocks per CU.  1 000 x 10 k
+                            // instances: 1 181 ms of traversal per frame against 1 293 for the 4-wave form of round 2 (slot 1; 108 VGPRs, 12 + 13 words of LDS), gpurun r03ad.  Seven more
+                            // loop shapes around 24 / 12 / 5 (16-24 / 12-20 / 4-8) measured 1 308 - 1 387 ms against 1 295 at 4 waves (gpurun r03z).
                 case 1: PH_LAUNCH3(false, 24, 12, PH_LDS_DEPTH, 5, true, 0, false); break;
-                default: PH_LAUNCH3(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true, 0, false); break;
+                default: PH_LAUNCH3(false, 24, 12, 11, 5, true, 5, false); break;
             }
         }
         return;

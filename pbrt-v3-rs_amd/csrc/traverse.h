@@ -55,7 +55,7 @@ struct TravParams {
 };
 
 struct RayState {
-    float ox, oy, oz, dx, dy, dz, t_max;
+    float ox, oy, oz, t_max;   // (the direction is not kept: after ray_setup only its reciprocals, signs and the shear are used; the instancing kernel keeps the scene-level one beside it)
     float ix, iy, iz;       // 1/d (three IEEE divides, bvh/mod.rs:176)
     uint32_t sgn;           // bits 0..2: dir_is_neg x, y, z (bvh/mod.rs:177-181); bits 3..4: kz of the triangle test (triangle.rs:457-459: kx = kz + 1, ky = kx + 1, both modulo 3)
     float sx, sy, sz;       // triangle.rs:467-469
@@ -68,9 +68,9 @@ struct RayState {
 };
 
 PH_DEV void ray_setup(RayState& r, const RayIn& in) {
-    r.ox = in.ox; r.oy = in.oy; r.oz = in.oz; r.dx = in.dx; r.dy = in.dy; r.dz = in.dz; r.t_max = in.t_max;
-    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-    f3 d = mk3(r.dx, r.dy, r.dz);
+    r.ox = in.ox; r.oy = in.oy; r.oz = in.oz; r.t_max = in.t_max;
+    r.ix = 1.0f / in.dx; r.iy = 1.0f / in.dy; r.iz = 1.0f / in.dz;
+    f3 d = mk3(in.dx, in.dy, in.dz);
     const int kz = max_dimension(vabs(d));
     r.sgn = (r.ix < 0.0f ? 1u : 0u) | (r.iy < 0.0f ? 2u : 0u) | (r.iz < 0.0f ? 4u : 0u) | ((uint32_t)kz << 3);
     f3 dp = permute(d, r.kx(), r.ky(), kz);
@@ -80,7 +80,7 @@ PH_DEV void ray_setup(RayState& r, const RayIn& in) {
 // Transform::transform_ray (core/src/geometry/transform.rs:451-476) by a row-major 4x4 `c`: transform_point_with_error on the
 // origin (:304-328), transform_vector on the direction, origin pushed to the edge of its error box and t_max shortened by the
 // same dt (quirk B2).  Used when a ray enters an object instance (transformed_primitive.rs:51-53).
-PH_DEV RayIn xf_ray(const float* c, const RayState& r, float time) {
+PH_DEV RayIn xf_ray(const float* c, const RayState& r, f3 rd, float time) {
     const float x = r.ox, y = r.oy, z = r.oz;
     const float ox = (c[0] * x + c[1] * y) + (c[2] * z + c[3]);
     const float oy = (c[4] * x + c[5] * y) + (c[6] * z + c[7]);
@@ -91,7 +91,7 @@ PH_DEV RayIn xf_ray(const float* c, const RayState& r, float time) {
     const float zs = pabs(c[8] * x) + pabs(c[9] * y) + pabs(c[10] * z) + pabs(c[11]);
     const f3 o_err = kGamma3 * mk3(xs, ys, zs);
     f3 o = (ow == 1.0f) ? mk3(ox, oy, oz) : mk3(ox, oy, oz) / ow;
-    const f3 d = mk3(c[0] * r.dx + c[1] * r.dy + c[2] * r.dz, c[4] * r.dx + c[5] * r.dy + c[6] * r.dz, c[8] * r.dx + c[9] * r.dy + c[10] * r.dz);
+    const f3 d = mk3(c[0] * rd.x + c[1] * rd.y + c[2] * rd.z, c[4] * rd.x + c[5] * rd.y + c[6] * rd.z, c[8] * rd.x + c[9] * rd.y + c[10] * rd.z);
     const float l2 = length_squared(d);
     float t_max = r.t_max;
     if (l2 > 0.0f) {
@@ -327,9 +327,10 @@ template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFIL
           int ALPHA = 0, int WPE = 0>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
-    // INST: the scene-level ray and what ray_setup derived from it (six IEEE divides), parked while the lane walks an instance: leaving an instance is then thirteen LDS reads instead of
-    // a reload of the ray and a second ray_setup.  (The instancing kernels run 4 blocks per CU: 24.5 KB of stack + 13 KB of this fit the 40 KB a block may take.)
-    __shared__ float inst_save[INST ? 13 : 1][INST ? PH_TRAV_BLOCK : 1];
+    // INST: the scene-level ray's origin and what ray_setup derived from it (six IEEE divides), parked while the lane walks an instance: leaving an instance is then nine LDS reads instead of
+    // a reload of the ray and a second ray_setup.  The direction is not parked — the scene-level one stays in three registers of its own (re-reading it from the ray queue at every instance cost 4 %:
+    // by then the ray's line has left the caches) —, the signs come back from the reciprocals and kz waits in the top bits of in_inst: 9 KB per block instead of 13, so that five blocks of (11-entry stack + this) fit a CU.
+    __shared__ float inst_save[INST ? 9 : 1][INST ? PH_TRAV_BLOCK : 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * PH_TRAV_BLOCK + tid;
@@ -347,13 +348,15 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
     uint32_t cur = PH_INVALID_REF;           // interior node index, or PH_LEAF_BIT | index of the NEXT TriRec to test
     int sp = 0;
     // LEAN (no instancing): an accepted hit is remembered by its TriRec alone (hit_tri, none = all ones); primitive id, material class and barycentrics are read / recomputed
-    // from it when the ray retires (tri_bary) — five registers the walk does not carry.  With instancing the hit may lie in an instance's space, and that kernel is not register-bound.
+    // from it when the ray retires (tri_bary) — five registers the walk does not carry.  Not with instancing: a hit inside an instance would have to carry the scene-level ray into
+    // that instance's space again at the end, and that second transform + set-up in the kernel costs more registers than it frees (102 -> 115, measured).
     constexpr bool LEAN = !INST;
     uint32_t hit_prim = 0xFFFFFFFFu, hit_tri = LEAN ? 0xFFFFFFFFu : 0u, hit_cls = 0u;
     float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     bool occluded = false;
     uint32_t c_nodes[2] = {0, 0}, c_tris[2] = {0, 0}, c_rays[2] = {0, 0}, c_visits = 0;  // COUNT: [0] this launch's first kind, [1] MIXED any-hit
     // instancing state (INST only)
+    float wdx = 0.0f, wdy = 0.0f, wdz = 0.0f;   // the scene-level ray's direction: every instance it meets transforms it anew (RayState does not keep directions)
     uint32_t in_inst = 0;                 // instance number + 1 while inside an object's aggregate
     int inst_sp = 0;                      // stack height at entry: the object's entries live above it
     float world_tmax = 0.0f;              // the scene-level ray's t_max at entry
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         ray_setup(r, in);
                         has_ray = true; sp = 0; occluded = false;
                         if (LEAN) hit_tri = 0xFFFFFFFFu; else { hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hb0 = hb1 = hb2 = 0.0f; }
-                        if (INST) { in_inst = 0; hit_inst = 0; }
+                        if (INST) { in_inst = 0; hit_inst = 0; wdx = in.dx; wdy = in.dy; wdz = in.dz; }
                         // root: the reference tests nodes[0].bounds first (bvh/mod.rs:189-190)
                         cur = PH_INVALID_REF;
                         if (COUNT && ah) c_visits++;
@@ -512,14 +515,13 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                             // TransformedPrimitive::intersect / intersect_p (transformed_primitive.rs:51-73)
                             const InstRec& I = sc.instances[__float_as_uint(a.w)];
                             world_tmax = r.t_max; cont_ref = last ? PH_INVALID_REF : cur + 1u;
-                            in_inst = __float_as_uint(a.w) + 1u; inst_sp = sp; inst_hit = false;
-                            inst_save[0][tid] = r.ox; inst_save[1][tid] = r.oy; inst_save[2][tid] = r.oz; inst_save[3][tid] = r.dx; inst_save[4][tid] = r.dy; inst_save[5][tid] = r.dz;
-                            inst_save[6][tid] = r.ix; inst_save[7][tid] = r.iy; inst_save[8][tid] = r.iz; inst_save[9][tid] = r.sx; inst_save[10][tid] = r.sy; inst_save[11][tid] = r.sz;
-                            inst_save[12][tid] = __uint_as_float(r.sgn);
+                            in_inst = (__float_as_uint(a.w) + 1u) | ((r.sgn >> 3) << 30); inst_sp = sp; inst_hit = false;   // bits 30..31: the scene-level ray's kz
+                            inst_save[0][tid] = r.ox; inst_save[1][tid] = r.oy; inst_save[2][tid] = r.oz;
+                            inst_save[3][tid] = r.ix; inst_save[4][tid] = r.iy; inst_save[5][tid] = r.iz; inst_save[6][tid] = r.sx; inst_save[7][tid] = r.sy; inst_save[8][tid] = r.sz;
                             // (round 3, measured and not kept: proving a miss of the object's bound with three hardware reciprocals before paying this set-up — the proof rarely
                             //  succeeds once the instance's world bound has been passed, 86.6 -> 93.2 ms on 1 000 x 10 k instances — and postponing the triangle half of ray_setup
                             //  to the first triangle met inside: no difference, gpurun r03g)
-                            const RayIn in = xf_ray(I.w2i, r, 0.0f);
+                            const RayIn in = xf_ray(I.w2i, r, mk3(wdx, wdy, wdz), 0.0f);
                             ray_setup(r, in);
                             cur = PH_INVALID_REF;
                             if (I.flags & PH_INST_SINGLE) cur = I.root_ref;  // the lone primitive itself, no aggregate
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                                 else {
                                     r.t_max = t; hit_tri = ti;
                                     if (!LEAN) { hit_prim = __float_as_uint(a.w); hb0 = b0; hb1 = b1; hb2 = b2; hit_cls = (flags >> PH_TRI_CLASS_SHIFT) & 7u; }
-                                    if (INST) { hit_inst = in_inst; inst_hit = true; }
+                                    if (INST) { hit_inst = in_inst & 0x3FFFFFFFu; inst_hit = true; }
                                 }
                             }
                         }
@@ -559,9 +561,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
         if (INST && has_ray && in_inst && cur == PH_INVALID_REF) {
             if (!(ah && occluded)) {
                 const float t_new = inst_hit ? r.t_max : world_tmax;
-                r.ox = inst_save[0][tid]; r.oy = inst_save[1][tid]; r.oz = inst_save[2][tid]; r.dx = inst_save[3][tid]; r.dy = inst_save[4][tid]; r.dz = inst_save[5][tid];
-                r.ix = inst_save[6][tid]; r.iy = inst_save[7][tid]; r.iz = inst_save[8][tid]; r.sx = inst_save[9][tid]; r.sy = inst_save[10][tid]; r.sz = inst_save[11][tid];
-                r.sgn = __float_as_uint(inst_save[12][tid]);
+                r.ox = inst_save[0][tid]; r.oy = inst_save[1][tid]; r.oz = inst_save[2][tid];
+                r.ix = inst_save[3][tid]; r.iy = inst_save[4][tid]; r.iz = inst_save[5][tid]; r.sx = inst_save[6][tid]; r.sy = inst_save[7][tid]; r.sz = inst_save[8][tid];
+                r.sgn = (r.ix < 0.0f ? 1u : 0u) | (r.iy < 0.0f ? 2u : 0u) | (r.iz < 0.0f ? 4u : 0u) | ((in_inst >> 30) << 3);
                 r.t_max = t_new;
                 in_inst = 0;
                 cur = (cont_ref != PH_INVALID_REF) ? cont_ref : pop();
