@@ -47,6 +47,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pbrt-v3-rs_amd"))
 
+L1_LOOKUP_PEAK_G = 880.0   # G L1 (TCP) tag look-ups per second the chip sustains for one random 64-B record per lane read as 4 x dwordx4 (scripts/calib/node_fetch.hip, mode A, L2-resident table)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 INFINITY_CACHE_BYTES = 256 << 20
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
@@ -398,14 +399,26 @@ def main():
                                  "frac_basis": "memory-side: traffic / avg_launch_ms / peak",
                                  "l2_hit_rate": round(k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]), 4) if k.get("TCC_HIT") and k.get("TCC_MISS") else None,
                                  "pmc": k.get("sq"),
-                                 "limiter": ("VALU issue, not memory: the SIMDs' vector pipes are busy %.0f %% of the time (PMC SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per SIMD) at a lane utilisation of %.2f, "
-                                             "L2 serves %.0f %% of the requests since the rays of a launch are binned by origin cell" %
-                                             (100.0 * min(1.0, k["sq"]["valu_active_of_wave_cycles"] * float(e.get("waves_per_simd", 4.0 if sm is not None or args.instances else 6.0))), k["sq"]["valu_lane_utilisation"], 100.0 * k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]))) if k.get("sq") else None,
-                                 "valu": ({"issue_frac": round(min(1.0, k["sq"]["valu_active_of_wave_cycles"] * float(e.get("waves_per_simd", 4.0 if sm is not None or args.instances else 6.0))), 4),
-                                           "lane_util": k["sq"]["valu_lane_utilisation"],
-                                           "effective": round(min(1.0, k["sq"]["valu_active_of_wave_cycles"] * float(e.get("waves_per_simd", 4.0 if sm is not None or args.instances else 6.0))) * k["sq"]["valu_lane_utilisation"], 4),
-                                           "note": "the roofline that binds this kernel: share of the SIMDs' issue cycles spent on VALU instructions x share of the 64 lanes those instructions use"}
-                                          if k.get("sq") else None),
+                                 "limiter": (("no single pipe is saturated: of the chip's cycles the vector ALUs issue in %.0f %% (lane utilisation %.2f), the scalar units take %.2f instructions per CU-cycle, "
+                                              "the L1 tag pipes %.2f look-ups per CU-cycle (each lane's 64-B node costs four); L2 serves %.0f %% of the requests since the rays of a launch are binned by origin cell.  "
+                                              "Three measured cuts — 16 %% fewer vector instructions, 11 %% fewer L1 look-ups, neither — left the time unchanged; the rate follows the resident waves "
+                                              "(3 -> 4 -> 5 -> 6 -> 7 blocks per CU: +21, +13, +9, +1..3 %%): a walk of dependent fetches whose latency the other waves hide until the pipes above queue (DESIGN 4)") %
+                                             (100.0 * k["sq"]["valu_issue_of_simd_quads"], k["sq"]["valu_lane_utilisation"], k["sq"]["scalar_and_branch_per_cu_cycle"], k["sq"]["l1_accesses_per_cu_cycle"],
+                                              100.0 * k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]))) if k.get("sq") and k["sq"].get("valu_issue_of_simd_quads") is not None else None,
+                                 "pipes": ({"valu_issue": k["sq"]["valu_issue_of_simd_quads"], "valu_lane_util": k["sq"]["valu_lane_utilisation"],
+                                            "scalar_and_branch_insts_per_cu_cycle": k["sq"]["scalar_and_branch_per_cu_cycle"],
+                                            "l1_lookups_per_cu_cycle": k["sq"]["l1_accesses_per_cu_cycle"],
+                                            "l1_lookups_G_per_s": round(k["sq"]["l1_accesses"] / k["dispatches"] / avg_launch_s / 1e9, 1),
+                                            "l1_lookups_G_per_s_calibrated_peak": L1_LOOKUP_PEAK_G,
+                                            "l1_frac_of_calibrated_peak": round(k["sq"]["l1_accesses"] / k["dispatches"] / avg_launch_s / 1e9 / L1_LOOKUP_PEAK_G, 4),
+                                            "note": "PMC: SQ_ACTIVE_INST_VALU, SQ_INSTS_SALU + SQ_INSTS_BRANCH, TCP_TOTAL_CACHE_ACCESSES over GRBM_GUI_ACTIVE (sum of the 8 XCDs; x 32 = CU-cycles = SIMD quads); "
+                                                    "the L1 peak is what scripts/calib/node_fetch.hip reaches with this kernel's access pattern (one random 64-B record per lane, 4 x dwordx4, L2-resident table): "
+                                                    "220 G records/s = 880 G look-ups/s, profiles/r03_calib_node_fetch.txt"}
+                                           if k.get("sq") and k["sq"].get("valu_issue_of_simd_quads") is not None else None),
+                                 "valu": ({"issue_frac": k["sq"]["valu_issue_of_simd_quads"], "lane_util": k["sq"]["valu_lane_utilisation"],
+                                           "effective": round(k["sq"]["valu_issue_of_simd_quads"] * k["sq"]["valu_lane_utilisation"], 4),
+                                           "note": "share of the SIMDs' issue quads spent on VALU instructions x share of the 64 lanes those instructions use; round 3 showed that this pipe does not bind the kernel (see limiter)"}
+                                          if k.get("sq") and k["sq"].get("valu_issue_of_simd_quads") is not None else None),
                                  "traffic_note": "bytes per launch leaving the L2s (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE over " + str(k["dispatches"]) + " traversal launches of one frame, " +
                                                  e.get("source", "profiles/") + "; " + e.get("calibration", "") + ")"})
                 else:

@@ -15,6 +15,7 @@ for SET in \
   "FETCH_SIZE TCC_HIT_sum" \
   "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum" \
+  "SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY" \
   "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
   i=$((i+1))
   rocprofv3 --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $R/bench.py $ARGS > $OUT/pass$i.json 2> $OUT/pass$i.err || { tail -5 $OUT/pass$i.err; echo "pass $i failed"; }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 measurement set on one GPU box: PMC records (-> profiles/r03_traffic.json, tied to the library sources), kernel traces, bench lines.
-# usage: bash scripts/r03_profiles.sh   (from the repo root on the GPU box; everything lands in gpurun_out/r03p/ and is copied to profiles/ afterwards by the caller)
+# usage: bash scripts/r03_profiles.sh [A|B|C|ABC]   (from the repo root on the GPU box; everything lands in gpurun_out/r03p/ and is copied to profiles/ afterwards by the caller)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r03p; mkdir -p $O
 cd $R
@@ -11,13 +11,20 @@ pmc() {  # tag, waves per SIMD, bench args...
   python3 scripts/traffic_merge.py gpurun_out/pmc_r03p_$T/traffic.json profiles/r03_pmc_summary_$T.txt $W >> $O/merge.log 2>&1
   echo "pmc $T done"
 }
-pmc config2 6 --config 2
+# stages (a gpurun call lasts 20 minutes at most): A = PMC of configs[2], [1], 1M; B = PMC of configs[4], [3], the instanced workload; C = kernel traces + bench lines
+STAGE=${1:-ABC}
+if [[ $STAGE == *A* ]]; then
+pmc config2 7 --config 2
+pmc config1 7 --config 1
+pmc 1M 7 --config 1M
+fi
+if [[ $STAGE == *B* ]]; then
 pmc config4 4 --config 4
-pmc config3 6 --config 3
-pmc config1 6 --config 1
-pmc 1M 6 --config 1M
-pmc instanced_1000x10k 4 --config 3 --instances 1000 --n-tris 10000
+pmc config3 7 --config 3
+pmc instanced_1000x10k 5 --config 3 --instances 1000 --n-tris 10000
+fi
 cp profiles/r03_traffic.json $O/r03_traffic.json
+if [[ $STAGE != *C* ]]; then exit 0; fi
 bash scripts/kstats.sh r03p_k2 --config 2 --steps 3 --warmup 1 > $O/kstats_config2.txt 2>&1; cp $(ls gpurun_out/r03p_k2_stats/*/*kernel_stats.csv | tail -1) $O/r03_kernel_stats_config2.csv
 bash scripts/kstats.sh r03p_k4 --config 4 --steps 1 --warmup 1 > $O/kstats_config4.txt 2>&1; cp $(ls gpurun_out/r03p_k4_stats/*/*kernel_stats.csv | tail -1) $O/r03_kernel_stats_config4.csv
 echo "kernel traces done"
