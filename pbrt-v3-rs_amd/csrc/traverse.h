@@ -32,6 +32,22 @@ struct alignas(16) HitOut { float t; uint32_t prim; float b0, b1, b2; uint32_t p
 #endif
 #define PH_MAX_STACK 64  // the reference's nodes_to_visit[64] (bvh/mod.rs:185)
 
+// Rays, queue order and results are touched once per launch: they are read / written with the non-temporal hint so that they do not displace tree nodes from the caches
+// (configs[2] / configs[3] traversal 705.4 -> 701.9 / 735.8 -> 732.4 ms per frame, same-box A/B gpurun r03al; -DPH_STREAM_NT=0 is the plain form).
+#ifndef PH_STREAM_NT
+#define PH_STREAM_NT 1
+#endif
+#if PH_STREAM_NT && defined(__HIP_DEVICE_COMPILE__)
+typedef float ph_v4f __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ float4 ph_stream_load(const float4* p) { const ph_v4f v = __builtin_nontemporal_load(reinterpret_cast<const ph_v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+static __device__ __forceinline__ uint32_t ph_stream_load(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+static __device__ __forceinline__ void ph_stream_store(float4 v, float4* p) { const ph_v4f w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<ph_v4f*>(p)); }
+#define PH_STREAM_LOAD(p) ph_stream_load(p)
+#define PH_STREAM_STORE(v, p) ph_stream_store(v, p)
+#else
+#define PH_STREAM_LOAD(p) (*(p))
+#define PH_STREAM_STORE(v, p) (*(p) = (v))
+#endif
 struct TravParams {
     const RayIn* rays;
     void* out;              // HitOut* (closest) or uint8_t* (any-hit)
@@ -418,10 +434,10 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                 if (avail) {
                     const uint32_t rank = (uint32_t)__popcll(idle & lane_lt);
                     if (!has_ray && rank < avail) {
-                        ray_index = p.order ? p.order[batch_next + rank] : batch_next + rank;
+                        ray_index = p.order ? PH_STREAM_LOAD(p.order + batch_next + rank) : batch_next + rank;
                         if (MIXED) ah = ray_index >= n_first;
                         const float4* rp = reinterpret_cast<const float4*>((MIXED && ah) ? p.rays2 + (ray_index - n_first) : p.rays + ray_index);
-                        const float4 a = rp[0], b = rp[1];
+                        const float4 a = PH_STREAM_LOAD(rp), b = PH_STREAM_LOAD(rp + 1);
                         RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = a.w; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
                         ray_setup(r, in);
                         has_ray = true; sp = 0; occluded = false;
@@ -584,8 +600,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         hit_prim = __float_as_uint(a.w); hit_cls = (__float_as_uint(b.w) >> PH_TRI_CLASS_SHIFT) & 7u;
                     } else { hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hit_cls = 0u; hb0 = hb1 = hb2 = 0.0f; }
                 }
-                hp[0] = make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1);
-                hp[1] = make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), __uint_as_float(hit_cls));  // pad[0] = the hit's TriRec, pad[1] = instance + 1, pad[2] = material class
+                PH_STREAM_STORE(make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1), hp);
+                PH_STREAM_STORE(make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), __uint_as_float(hit_cls)), hp + 1);  // pad[0] = the hit's TriRec, pad[1] = instance + 1, pad[2] = material class
             }
             has_ray = false;
             if (COUNT) c_rays[(MIXED && ah) ? 1 : 0]++;
