@@ -10,6 +10,7 @@
 // Child reference: bit 31 set -> leaf, low 31 bits = offset of its first TriRec; else index of an interior Node64.
 #define PH_LEAF_BIT 0x80000000u
 #define PH_INVALID_REF 0xFFFFFFFFu
+#define PH_NEED_POP 0xFFFFFFFEu   // traversal-kernel state only (traverse.h): the lane's next reference is on its stack
 struct alignas(64) Node64 {
     // planes interleaved so that the dir_is_neg select touches one float2 per axis:
     float x0[2], y0[2], z0[2];  // child 0: {min,max} per axis

@@ -387,10 +387,18 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
         else { *p.error_flag = 1u; return; }
         sp++;
     };
-    // pops entries until one survives `t_min < ray.t_max`; returns PH_INVALID_REF when the stack is empty
-    auto pop = [&]() -> uint32_t {
+    // Pops are DEFERRED (round 3): where the walk needs the next stack entry it only notes so (cur = PH_NEED_POP, or PH_INVALID_REF at once when the stack is empty), and every node step
+    // begins with ONE pop attempt for the lanes that owe one — an entry that fails `t_min < ray.t_max` leaves the lane owing the next.  The entries are popped in the same order and
+    // tested against the same t_max (a lane that owes a pop is at no leaf, so nothing shrinks its t_max meanwhile): same visits, same bits.  The pop loop with its two address spaces was
+    // expanded inline at three places: this form issues a third fewer scalar instructions and branches per frame (SQ_INSTS_SALU 2.60e11 -> 1.71e11 on configs[2]).  Worth 5.5 % on the
+    // instancing kernel (1 180 -> 1 115 ms of traversal per frame on 1 000 x 10 k instances), nothing on the flat one (703.5 against 705.7 ms; gpurun r03an) — DESIGN 4, "what bounds the kernel".
+    auto owe_pop = [&]() -> uint32_t {
         const int floor_sp = (INST && in_inst) ? inst_sp : 0;
-        while (sp > floor_sp) {
+        return sp > floor_sp ? PH_NEED_POP : PH_INVALID_REF;
+    };
+    auto pop_once = [&]() {
+        const int floor_sp = (INST && in_inst) ? inst_sp : 0;
+        if (sp > floor_sp) {
             sp--;
             // two loads in two address spaces, kept apart by (empty, distinct) asm statements: merged into one load through a generic pointer, the
             // LDS-aperture test fails instruction selection on this toolchain (ROCm 7.2, gfx950: "Operand has incorrect register class", V_CMP_NE_U32 against src_shared_base)
@@ -398,9 +406,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
             if (sp < LDS_DEPTH) { e = lds_stack[sp][tid]; asm volatile("; stack entry from LDS" : "+v"(e.x), "+v"(e.y)); }
             else { e = p.spill[(size_t)(sp - LDS_DEPTH) * p.total_threads + gtid]; asm volatile("; stack entry from the spill region" : "+v"(e.x), "+v"(e.y)); }
             if (COUNT && ah) c_visits++;  // the reference fetches and box-tests every node it pops
-            if (__uint_as_float(e.y) < r.t_max) return e.x;
-        }
-        return PH_INVALID_REF;
+            cur = (__uint_as_float(e.y) < r.t_max) ? e.x : PH_NEED_POP;
+        } else cur = PH_INVALID_REF;
     };
 
     for (;;) {
@@ -465,8 +472,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
 
         // ---- NODE_STEPS interior-node steps for every lane that is at an interior node ---------------------------------------------------
 #pragma unroll
-        for (int step = 0; step < NODE_STEPS; step++)
-        if (has_ray && cur != PH_INVALID_REF && !(cur & PH_LEAF_BIT)) {
+        for (int step = 0; step < NODE_STEPS; step++) {
+        if (has_ray && cur == PH_NEED_POP) pop_once();
+        if (has_ray && !(cur & PH_LEAF_BIT)) {   // (PH_INVALID_REF and PH_NEED_POP have the leaf bit set)
             const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
             const float4 q0 = np[0], q1 = np[1], q2 = np[2];
             const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
@@ -508,19 +516,20 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
             }
             if (near_hit) { cur = near_ref; if (far_hit) push(far_ref, far_t); }
             else if (far_hit) cur = far_ref;
-            else cur = pop();
+            else cur = owe_pop();
+        }
         }
 
         // ---- leaf work: one triangle per lane, once enough lanes are waiting at leaves ----------------------------------------------------
         {
-            const bool at_leaf = has_ray && cur != PH_INVALID_REF && (cur & PH_LEAF_BIT);
+            const bool at_leaf = has_ray && cur < PH_NEED_POP && (cur & PH_LEAF_BIT);
             const uint64_t lm = __ballot(at_leaf);
             if (lm != 0ull) {
-                const uint64_t nm = __ballot(has_ray && cur != PH_INVALID_REF && !(cur & PH_LEAF_BIT));
+                const uint64_t nm = __ballot(has_ray && (cur == PH_NEED_POP || !(cur & PH_LEAF_BIT)));
                 if ((uint32_t)__popcll(lm) >= (uint32_t)LEAF_MIN || nm == 0ull || exhausted) {  // queue drained: no throughput left to protect, only the tail's latency
 #pragma unroll
                     for (int ls = 0; ls < PH_LEAF_STEPS; ls++)
-                    if (has_ray && cur != PH_INVALID_REF && (cur & PH_LEAF_BIT)) {
+                    if (has_ray && cur < PH_NEED_POP && (cur & PH_LEAF_BIT)) {
                         const uint32_t ti = cur & ~PH_LEAF_BIT;
                         const float4* tp = reinterpret_cast<const float4*>(sc.tris + ti);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                             }
                         }
                         if (ah && occluded) cur = PH_INVALID_REF;
-                        else if (last) cur = pop();
+                        else if (last) cur = owe_pop();
                         else cur = cur + 1u;
                         }
                     }
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                 r.sgn = (r.ix < 0.0f ? 1u : 0u) | (r.iy < 0.0f ? 2u : 0u) | (r.iz < 0.0f ? 4u : 0u) | ((in_inst >> 30) << 3);
                 r.t_max = t_new;
                 in_inst = 0;
-                cur = (cont_ref != PH_INVALID_REF) ? cont_ref : pop();
+                cur = (cont_ref != PH_INVALID_REF) ? cont_ref : owe_pop();
             } else in_inst = 0;
         }
 
