@@ -300,7 +300,7 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
         const bool inst = !s->inst_recs.empty();
         if (s->alpha_lean) {
             if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 1, 0); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false, 1, 0); }
-            else if (inst) PH_LAUNCH3A(false, 24, 12, PH_LDS_DEPTH, 5, true, 1, 4);   // (with the alpha test inlined the instancing form needs 115 registers: compiled for 5 waves per SIMD it spills 18 and configs[4]'s traversal takes 6.83 s instead of 6.35, gpurun r03ae)
+            else if (inst) PH_LAUNCH3A(false, 24, 12, 11, 5, true, 1, 5);   // (the instancing form, five waves per SIMD: 107 registers where the compiler is free, 11 spilled at 96 — and still faster: configs[4]'s traversal 6.04 -> 5.66 s per frame, gpurun r03aq; before the deferred pops it needed 115 and lost)
             else PH_LAUNCH3A(false, 24, 12, PH_LDS_DEPTH, 5, false, 1, 0);
         } else {
             if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 2, 0); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false, 2, 0); }
@@ -313,8 +313,8 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
         else {
             static const int iv = []() { const char* e = std::getenv("PBRT_HIP_INST_VARIANT"); const int v = e ? std::atoi(e) : PH_DEFAULT_INST_VARIANT; return (v < 1 || v > 2) ? PH_DEFAULT_INST_VARIANT : v; }();
             switch (iv) {   // round 3: 96 VGPRs without spills (102 where the compiler is free) and 31 KB of LDS (11 stack entries + 9 parked words per lane): FIVE blocks per CU.  1 000 x 10 k
-                            // instances: 1 181 ms of traversal per frame against 1 293 for the 4-wave form of round 2 (slot 1; 108 VGPRs, 12 + 13 words of LDS), gpurun r03ad.  Seven more
-                            // loop shapes around 24 / 12 / 5 (16-24 / 12-20 / 4-8) measured 1 308 - 1 387 ms against 1 295 at 4 waves (gpurun r03z).
+                            // instances: 1 181 ms of traversal per frame against 1 293 for the 4-wave form of round 2 (slot 1; 108 VGPRs, 12 + 13 words of LDS), gpurun r03ad; 1 115 with the deferred pops (traverse.h).  Seven more
+                            // loop shapes around 24 / 12 / 5 (16-24 / 12-20 / 4-8) measured 1 308 - 1 387 ms against 1 295 at 4 waves (gpurun r03z), four at 5 waves 1 114 - 1 135 against 1 117 (r03aq).
                 case 1: PH_LAUNCH3(false, 24, 12, PH_LDS_DEPTH, 5, true, 0, false); break;
                 default: PH_LAUNCH3(false, 24, 12, 11, 5, true, 5, false); break;
             }
