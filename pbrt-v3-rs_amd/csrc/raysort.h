@@ -43,7 +43,7 @@ PH_DEV uint32_t part1by2(uint32_t v) {  // 4 bits -> every third bit
 
 // bin of a ray with origin (ox, oy, oz) and direction (dx, dy, dz); < PH_SORT_BINS
 PH_DEV uint32_t ray_sort_key(const RaySortGrid& g, float ox, float oy, float oz, float dx, float dy, float dz) {
-    const float cells = g.mode == 2u ? 8.0f : 16.0f;
+    const float cells = (g.mode == 2u || g.mode == 3u) ? 8.0f : 16.0f;   // (mode 3: 8^3 cells without the octant — a measurement aid that isolates what the octant is worth)
     const float fx = (ox - g.lo[0]) * g.scale[0], fy = (oy - g.lo[1]) * g.scale[1], fz = (oz - g.lo[2]) * g.scale[2];
     // NaN / out-of-bound origins land in the border cells: any bin is a correct bin
     const uint32_t cx = (uint32_t)pmini(pmaxi((int)(fx * cells), 0), (int)cells - 1);

@@ -952,7 +952,7 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     // run one at a time while paths remain (host reads the live count), up to kMaxNullSkips more.
     const int kMaxNullSkips = 1024;
     const int n_iter_cap = s->has_none_material ? n_iter + kMaxNullSkips : n_iter;
-    static const int sort_mode = []() { const char* e = std::getenv("PBRT_HIP_SORT_RAYS"); int v = e ? std::atoi(e) : 1; return (v < 0 || v > 2) ? 1 : v; }();
+    static const int sort_mode = []() { const char* e = std::getenv("PBRT_HIP_SORT_RAYS"); int v = e ? std::atoi(e) : 1; return (v < 0 || v > 3) ? 1 : v; }();
     if ((rc = ensure_buf(s, w.d_ctr, (size_t)(n_iter_cap + 2) * sizeof(ph::IterCounters)))) return rc;
     if ((rc = ensure_buf(s, w.d_stats, sizeof(ph::DevStats)))) return rc;
     if ((rc = ensure_buf(s, w.d_recL, (size_t)n_px * spp * 16))) return rc;
