@@ -110,6 +110,30 @@ def test_split_traversal_env_gives_the_same_film():
     assert a["film_sha256"] == b["film_sha256"] and a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
 
 
+def test_ab_slots_and_binning_modes_give_the_same_film():
+    """The kernels kept as A/B slots (PBRT_HIP_TRAV_VARIANT=1: the 6-wave loop shape of round 2; PBRT_HIP_INST_VARIANT=1: the 4-wave instancing kernel) and every ray-binning mode
+    (PBRT_HIP_SORT_RAYS 0 / 2 / 3) trace the frame the shipping configuration traces: the order in which a round's rays are traced, the loop thresholds and the occupancy are free
+    choices, the film is not."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("PBRT_HIP_TRAV_VARIANT", "PBRT_HIP_INST_VARIANT", "PBRT_HIP_SORT_RAYS"):
+        env.pop(k, None)
+
+    def run(extra_args, extra_env):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--spp", "4", "--res", "160"] + extra_args,
+                           capture_output=True, text=True, env=dict(env, **extra_env), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = _last_json(r.stdout)
+        return d["film_sha256"], d["config"]["rays_per_frame"]
+
+    flat = ["--n-tris", "8000"]
+    base = run(flat, {})
+    for e in ({"PBRT_HIP_TRAV_VARIANT": "1"}, {"PBRT_HIP_SORT_RAYS": "0"}, {"PBRT_HIP_SORT_RAYS": "2"}, {"PBRT_HIP_SORT_RAYS": "3"}):
+        assert run(flat, e) == base, e
+    inst = ["--n-tris", "500", "--instances", "40"]
+    base_i = run(inst, {})
+    assert run(inst, {"PBRT_HIP_INST_VARIANT": "1"}) == base_i
+
+
 def test_bench_nccl_code_path_with_one_rank():
     """The N > 1 code path of bench.py over the REAL backend — `init_process_group("nccl")` (= RCCL), barrier, `dist.gather` of the device tile buffer, all_reduce of the timings, merge of
     the gathered buffers — exercised with the one rank a one-GPU box has (`--force-dist` under torch.distributed.run --nproc-per-node 1): the very calls an 8-GPU node makes, and the
