@@ -10,7 +10,11 @@
 //  * a child's box is tested when its PARENT is visited instead of when the child is popped.  The box test depends on
 //    the ray's t_max only through its last clause `t_min < ray.t_max`; the entry distance t_min is kept on the stack and
 //    that clause is re-evaluated with the current t_max when the entry is popped -> same visit/skip decision;
-//  * box and triangle arithmetic is the reference's expression order, compiled with -ffp-contract=off.
+//  * box and triangle arithmetic is the reference's expression order, compiled with -ffp-contract=off.  A node step's twelve subtractions and multiplications are issued as six +
+//    six packed two-float operations on (lo, hi) pairs and the near / far choice is made on the products (node_boxes): the same operands meet in the same IEEE operations;
+//  * stack entries are popped in the reference's order and tested against the t_max of the moment the reference would test them — one entry per node step (deferred pops: a lane
+//    that owes a pop is at no leaf, so its t_max cannot change in between);
+//  * the flat kernels remember an accepted hit by its TriRec alone and recompute its barycentrics when the ray retires (tri_bary: the test's own e / det / inv_det operations).
 //
 // Execution shape: persistent waves pull rays from a global counter (one atomic per refill, wave-aggregated with
 // ballot/popcount), per-lane replacement of finished rays, while-while traversal, traversal stack in LDS
