@@ -230,11 +230,12 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
     return PBRT_HIP_OK;
 }
 
-// The traversal kernel's shape: {LEAF_MIN, REFILL_MIN, LDS_DEPTH, NODE_STEPS, waves per SIMD the kernel is compiled for (0 = the compiler's choice)}.  Slot 0 is what ships:
-// 7 waves per SIMD (63 VGPRs since the round-3 register diet — signs and permutation in one word, the hit remembered by its TriRec alone —, 11 stack entries in LDS), lanes wait
-// for 16 companions at leaves and for 20 idle lanes before a refill, 6 node steps per pass: configs[2] / configs[1] 681.8 / 30.5 ms of traversal per frame against 706.9 / 31.7 for
-// slot 1, the shape rounds 2 shipped (6 waves, 24 / 12 / 5; gpurun r03s - r03w, three sweeps of nine shapes each around it).  PBRT_HIP_TRAV_VARIANT=1 selects slot 1 for A/B runs.
-#define PH_VARIANTS(X) X(0, 16, 20, 11, 6, 7, false) X(1, 24, 12, 12, 5, 6, false)
+// The traversal kernel's shape: {LEAF_MIN, REFILL_MIN, LDS_DEPTH, NODE_STEPS, waves per SIMD the kernel is compiled for (0 = the compiler's choice)}.  Slot 0 is what ships: 6 waves per
+// SIMD with 12 stack entries in LDS (the kernel needs 59 VGPRs since the round-3 register diet and would fit 8 — but a seventh wave buys nothing and costs the stack an entry: same-box,
+// configs[2] / configs[3] 689.5 / 717.0 ms of traversal per frame at 6 waves x 12 entries against 705.5 / 735.5 at 7 x 11; at 6 waves the depth is worth 12 -> 10 -> 8 -> 6 entries:
+// 687 -> 692 -> 708 -> 759 ms, a 13th nothing), lanes wait for 16 companions at leaves and for 20 idle lanes before a refill, 6 node steps per pass (27 shapes swept at 7 waves, 6 more at 6;
+// gpurun r03s - r03x, r03aw, r03ax).  Slot 1 is the shape rounds 2 shipped (24 / 12 / 5), kept for A/B runs (PBRT_HIP_TRAV_VARIANT=1): - 2.3 % traversal time from it to slot 0.
+#define PH_VARIANTS(X) X(0, 16, 20, 12, 6, 6, false) X(1, 24, 12, 12, 5, 6, false)
 #define PH_N_VARIANTS 2
 #define PH_DEFAULT_INST_VARIANT 2   // the 5-wave instancing kernel (launch_traverse_kernel); 1 = the 4-wave form, kept as the A/B slot
 #define PH_DEFAULT_VARIANT 0
