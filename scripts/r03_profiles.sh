@@ -14,13 +14,13 @@ pmc() {  # tag, waves per SIMD, bench args...
 # stages (a gpurun call lasts 20 minutes at most): A = PMC of configs[2], [1], 1M; B = PMC of configs[4], [3], the instanced workload; C = kernel traces + bench lines
 STAGE=${1:-ABC}
 if [[ $STAGE == *A* ]]; then
-pmc config2 7 --config 2
-pmc config1 7 --config 1
-pmc 1M 7 --config 1M
+pmc config2 6 --config 2
+pmc config1 6 --config 1
+pmc 1M 6 --config 1M
 fi
 if [[ $STAGE == *B* ]]; then
-pmc config4 4 --config 4
-pmc config3 7 --config 3
+pmc config4 5 --config 4
+pmc config3 6 --config 3
 pmc instanced_1000x10k 5 --config 3 --instances 1000 --n-tris 10000
 fi
 cp profiles/r03_traffic.json $O/r03_traffic.json
