@@ -74,6 +74,34 @@ static hm::HaltonTables& halton_tables() {
     return t;
 }
 
+// Scenes with object instances, once per upload: every instance's leaf record receives what a ray entering it reads (scene_types.h, InstRec) and the hints that let the traversal kernel
+// fetch the transform together with the record.  In place on the device arrays (device-built trees never visit the host); idempotent.
+__global__ void patch_inst_records_kernel(TriRec* tris, uint32_t n_top, const InstRec* inst, float* extra) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_top) return;
+    uint32_t f = tris[i].flags & ~PH_TRI_NEXT_INST;
+    if (!(f & PH_TRI_LAST) && i + 1u < n_top && (tris[i + 1u].flags & PH_TRI_INSTANCE)) f |= PH_TRI_NEXT_INST;   // (this kernel never changes a PH_TRI_INSTANCE bit: no race with the neighbour's thread)
+    if (f & PH_TRI_INSTANCE) {
+        const InstRec& I = inst[tris[i].prim];
+        const bool general = !(I.w2i[12] == 0.0f && I.w2i[13] == 0.0f && I.w2i[14] == 0.0f && I.w2i[15] == 1.0f);
+        for (int k = 0; k < 3; k++) { tris[i].p0[k] = I.lo[k]; tris[i].p1[k] = I.hi[k]; }
+        tris[i].p2[0] = __uint_as_float(I.root_ref); tris[i].p2[1] = __uint_as_float(I.flags | (general ? PH_INST_GENERAL : 0u)); tris[i].p2[2] = 0.0f;
+        for (int k = 0; k < 12; k++) extra[12 * (size_t)i + k] = I.w2i[k];
+    }
+    tris[i].flags = f;
+}
+__global__ void patch_leaf_refs_kernel(Node64* nodes, uint32_t n_nodes, const TriRec* tris, uint32_t n_top) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    uint32_t c[2] = {nodes[i].c0, nodes[i].c1};
+    for (int k = 0; k < 2; k++)
+        if ((c[k] & PH_LEAF_BIT) && c[k] < PH_NEED_POP) {
+            const uint32_t t = c[k] & ~(PH_LEAF_BIT | PH_LEAF_INST_HINT);
+            c[k] = PH_LEAF_BIT | t | ((t < n_top && (tris[t].flags & PH_TRI_INSTANCE)) ? PH_LEAF_INST_HINT : 0u);
+        }
+    nodes[i].c0 = c[0]; nodes[i].c1 = c[1];
+}
+
 int upload_scene(PbrtHipScene* s) {
     if (s->uploaded) return PBRT_HIP_OK;
     free_owned(s);
@@ -159,6 +187,16 @@ int upload_scene(PbrtHipScene* s) {
     d.n_infinite = (uint32_t)s->infinite_lights.size();
     if ((rc = upload_vec(s, s->inst_recs, &d.instances))) return rc;
     d.n_instances = (uint32_t)s->inst_recs.size();
+    if (!s->inst_recs.empty() && !s->top_items.empty() && d.nodes && d.tris) {   // instance leaf records + hints (patch_inst_records_kernel)
+        const uint32_t n_top = (uint32_t)s->top_items.size();
+        const uint32_t n_nodes = (uint32_t)(s->tree_dev_tris ? s->bvh.interior_nodes : s->bvh.nodes.size());
+        void* extra = nullptr;
+        PH_CHECK(s, hipMalloc(&extra, (size_t)n_top * 48)); s->owned.push_back(extra);
+        hipLaunchKernelGGL(patch_inst_records_kernel, dim3((n_top + 255u) / 256u), dim3(256), 0, s->stream, const_cast<TriRec*>(d.tris), n_top, d.instances, static_cast<float*>(extra));
+        if (n_nodes) hipLaunchKernelGGL(patch_leaf_refs_kernel, dim3((n_nodes + 255u) / 256u), dim3(256), 0, s->stream, const_cast<Node64*>(d.nodes), n_nodes, d.tris, n_top);
+        PH_CHECK(s, hipGetLastError());
+        d.inst_extra = static_cast<const float*>(extra);
+    }
     hm::HaltonTables& ht = halton_tables();
     if ((rc = upload_vec(s, ht.perms, &d.halton_perms))) return rc;
     if ((rc = upload_vec(s, ht.primes, &d.primes))) return rc;
@@ -1335,6 +1373,10 @@ int pbrt_hip_accel_copy(PbrtHipScene* s, void* out_nodes, uint64_t node_capacity
         PH_CHECK(s, hipSetDevice(s->device));
         if (nn && out_nodes) PH_CHECK(s, hipMemcpy(out_nodes, s->tree_dev_nodes, nn * sizeof(Node64), hipMemcpyDeviceToHost));
         if (nt && out_leaf_records) PH_CHECK(s, hipMemcpy(out_leaf_records, s->tree_dev_tris, nt * sizeof(TriRec), hipMemcpyDeviceToHost));
+        if (!s->inst_recs.empty()) {   // an upload may have filled the instance records and set the hints in place (patch_inst_records_kernel): hand out the builder's form
+            if (out_nodes) { Node64* nd = static_cast<Node64*>(out_nodes); for (size_t i = 0; i < nn; i++) { if ((nd[i].c0 & PH_LEAF_BIT) && nd[i].c0 < PH_NEED_POP) nd[i].c0 &= ~PH_LEAF_INST_HINT; if ((nd[i].c1 & PH_LEAF_BIT) && nd[i].c1 < PH_NEED_POP) nd[i].c1 &= ~PH_LEAF_INST_HINT; } }
+            if (out_leaf_records) { TriRec* tr = static_cast<TriRec*>(out_leaf_records); for (size_t i = 0; i < nt; i++) { tr[i].flags &= ~PH_TRI_NEXT_INST; if (tr[i].flags & PH_TRI_INSTANCE) { const uint32_t prim = tr[i].prim, fl = tr[i].flags; std::memset(&tr[i], 0, sizeof(TriRec)); tr[i].prim = prim; tr[i].flags = fl; } } }
+        }
     } else {
         if (nn && out_nodes) std::memcpy(out_nodes, s->bvh.nodes.data(), nn * sizeof(Node64));
         if (nt && out_leaf_records) std::memcpy(out_leaf_records, s->bvh.tris.data(), nt * sizeof(TriRec));

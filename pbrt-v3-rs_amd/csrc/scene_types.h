@@ -11,6 +11,10 @@
 #define PH_LEAF_BIT 0x80000000u
 #define PH_INVALID_REF 0xFFFFFFFFu
 #define PH_NEED_POP 0xFFFFFFFEu   // traversal-kernel state only (traverse.h): the lane's next reference is on its stack
+// Scenes with object instances: a leaf reference whose FIRST record is an instance carries this hint (set by patch_leaf_refs_kernel when the scene is uploaded, api.hip), and a record whose
+// successor in the same leaf is an instance carries PH_TRI_NEXT_INST: the traversal kernel then fetches the instance's transform (DeviceScene::inst_extra, addressed by the RECORD's own
+// position) together with the record instead of one dependent round trip later.  Only hints: a record met without one is handled the slow way, with the same result.
+#define PH_LEAF_INST_HINT 0x40000000u
 struct alignas(64) Node64 {
     // planes interleaved so that the dir_is_neg select touches one float2 per axis:
     float x0[2], y0[2], z0[2];  // child 0: {min,max} per axis
@@ -28,6 +32,7 @@ struct alignas(64) Node64 {
 #define PH_TRI_SALPHA0 8u  // mesh shadowalpha texture == 0.0 (triangle.rs:891)
 #define PH_TRI_CLASS_SHIFT 8  // bits 8..10: material class of the triangle (shade-side sorting key; 7 = Material "none"), set at build time
 #define PH_TRI_ALPHATEX 32u  // the mesh's alpha or shadowalpha is a texture: the traversal kernel (ALPHA variants) evaluates it at the candidate hit
+#define PH_TRI_NEXT_INST 64u  // the next record of this leaf is an instance (see PH_LEAF_INST_HINT)
 #define PH_TRI_INSTANCE 16u  // not a triangle: a TransformedPrimitive (object instance); `prim` = index into DeviceScene::instances
 struct alignas(16) TriRec {
     float p0[3]; uint32_t prim;   // prim = index in add_mesh order
@@ -38,7 +43,10 @@ struct alignas(16) TriRec {
 // One ObjectInstance = TransformedPrimitive (core/src/primitives/transformed_primitive.rs): the object's aggregate lives in the
 // same node / TriRec arrays as the scene's; a ray entering it is carried to instance space by transform_ray (transform.rs:451-476).
 #define PH_INST_SINGLE 1u    // the object holds exactly one primitive: it is used directly, no aggregate and no root box test (lib.rs:953-971)
+#define PH_INST_GENERAL 4u   // (only in an instance's LEAF RECORD, see below) the last row of world-to-instance is not (0, 0, 0, 1): the kernel reads the whole matrix from the InstRec
 #define PH_INST_IDENTITY 2u  // instance_to_world is the identity: transform_surface_interaction is skipped (transformed_primitive.rs:58)
+// An instance's leaf record (TriRec with PH_TRI_INSTANCE) is filled in when the scene is uploaded: p0 / p1 = the object's root bounds, p2[0] / p2[1] = its root reference and PH_INST_* flags
+// (as bit patterns); rows 0 .. 2 of world-to-instance go to DeviceScene::inst_extra[3 * record position ..].  What a ray entering the instance needs then arrives with the record.
 struct InstRec {
     float w2i[16], i2w[16];   // row-major 4x4
     float lo[3], hi[3];       // object aggregate's root bounds (instance space)
@@ -230,6 +238,7 @@ struct DeviceScene {
     const uint32_t* infinite_lights;
     uint32_t n_infinite;
     const InstRec* instances;
+    const float* inst_extra;    // 12 floats (read as 3 float4) per scene-level leaf record: rows 0 .. 2 of world-to-instance where the record is an instance (else unused)
     uint32_t n_instances;
     // light-selection Distribution1D (core/src/sampling/distribution_1d.rs)
     const float* ld_func;

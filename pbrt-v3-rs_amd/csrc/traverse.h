@@ -534,31 +534,40 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
 #pragma unroll
                     for (int ls = 0; ls < PH_LEAF_STEPS; ls++)
                     if (has_ray && cur < PH_NEED_POP && (cur & PH_LEAF_BIT)) {
-                        const uint32_t ti = cur & ~PH_LEAF_BIT;
+                        const uint32_t ti = INST ? (cur & ~(PH_LEAF_BIT | PH_LEAF_INST_HINT)) : (cur & ~PH_LEAF_BIT);
                         const float4* tp = reinterpret_cast<const float4*>(sc.tris + ti);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
+                        // INST: a reference that carries the hint names an instance record: its transform is fetched with it (scene_types.h, PH_LEAF_INST_HINT)
+                        const bool hinted = INST && (cur & PH_LEAF_INST_HINT) != 0u;
+                        float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0, e2 = e0;
+                        if (INST && hinted) { const float4* ep = reinterpret_cast<const float4*>(sc.inst_extra) + 3u * (size_t)ti; e0 = ep[0]; e1 = ep[1]; e2 = ep[2]; }
                         const uint32_t flags = __float_as_uint(b.w);
                         bool last = (flags & PH_TRI_LAST) != 0;
+                        // the next record of this leaf (with its own hint)
+                        const uint32_t next_ref = INST ? (((cur & ~PH_LEAF_INST_HINT) + 1u) | ((flags & PH_TRI_NEXT_INST) ? PH_LEAF_INST_HINT : 0u)) : cur + 1u;
                         float t, b0, b1, b2;
                         if (INST && (flags & PH_TRI_INSTANCE)) {
-                            // TransformedPrimitive::intersect / intersect_p (transformed_primitive.rs:51-73)
-                            const InstRec& I = sc.instances[__float_as_uint(a.w)];
-                            world_tmax = r.t_max; cont_ref = last ? PH_INVALID_REF : cur + 1u;
+                            // TransformedPrimitive::intersect / intersect_p (transformed_primitive.rs:51-73).  The record itself holds the object's bounds, root and flags (filled in at upload)
+                            if (!hinted) { const float4* ep = reinterpret_cast<const float4*>(sc.inst_extra) + 3u * (size_t)ti; e0 = ep[0]; e1 = ep[1]; e2 = ep[2]; }   // no hint (e.g. a root that is a leaf): one more round trip, same numbers
+                            const uint32_t iflags = __float_as_uint(c.y), iroot = __float_as_uint(c.x);
+                            float w2i[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, 0.0f, 0.0f, 0.0f, 1.0f};
+                            if (iflags & PH_INST_GENERAL) { const InstRec& I = sc.instances[__float_as_uint(a.w)]; for (int k = 12; k < 16; k++) w2i[k] = I.w2i[k]; }   // a projective last row: from the InstRec
+                            world_tmax = r.t_max; cont_ref = last ? PH_INVALID_REF : next_ref;
                             in_inst = (__float_as_uint(a.w) + 1u) | ((r.sgn >> 3) << 30); inst_sp = sp; inst_hit = false;   // bits 30..31: the scene-level ray's kz
                             inst_save[0][tid] = r.ox; inst_save[1][tid] = r.oy; inst_save[2][tid] = r.oz;
                             inst_save[3][tid] = r.ix; inst_save[4][tid] = r.iy; inst_save[5][tid] = r.iz; inst_save[6][tid] = r.sx; inst_save[7][tid] = r.sy; inst_save[8][tid] = r.sz;
                             // (round 3, measured and not kept: proving a miss of the object's bound with three hardware reciprocals before paying this set-up — the proof rarely
                             //  succeeds once the instance's world bound has been passed, 86.6 -> 93.2 ms on 1 000 x 10 k instances — and postponing the triangle half of ray_setup
                             //  to the first triangle met inside: no difference, gpurun r03g)
-                            const RayIn in = xf_ray(I.w2i, r, mk3(wdx, wdy, wdz), 0.0f);
+                            const RayIn in = xf_ray(w2i, r, mk3(wdx, wdy, wdz), 0.0f);
                             ray_setup(r, in);
                             cur = PH_INVALID_REF;
-                            if (I.flags & PH_INST_SINGLE) cur = I.root_ref;  // the lone primitive itself, no aggregate
+                            if (iflags & PH_INST_SINGLE) cur = iroot;  // the lone primitive itself, no aggregate
                             else {
-                                float tmin;
-                                const bool h = box_test(r, r.nx() ? I.hi[0] : I.lo[0], r.nx() ? I.lo[0] : I.hi[0], r.ny() ? I.hi[1] : I.lo[1], r.ny() ? I.lo[1] : I.hi[1],
-                                                        r.nz() ? I.hi[2] : I.lo[2], r.nz() ? I.lo[2] : I.hi[2], tmin);
-                                if (h && tmin < r.t_max) cur = I.root_ref;
+                                float tmin;   // the record's p0 / p1 = the object's root bounds
+                                const bool h = box_test(r, r.nx() ? b.x : a.x, r.nx() ? a.x : b.x, r.ny() ? b.y : a.y, r.ny() ? a.y : b.y,
+                                                        r.nz() ? b.z : a.z, r.nz() ? a.z : b.z, tmin);
+                                if (h && tmin < r.t_max) cur = iroot;
                             }
                         } else {
                         if (COUNT) c_tris[(MIXED && ah) ? 1 : 0]++;
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         }
                         if (ah && occluded) cur = PH_INVALID_REF;
                         else if (last) cur = owe_pop();
-                        else cur = cur + 1u;
+                        else cur = next_ref;
                         }
                     }
                 }
