@@ -59,6 +59,45 @@ def test_instanced_hits_bit_exact(host, split):
     assert np.array_equal(prod.world_bound(), orc.world_bound())
 
 
+@pytest.mark.parametrize("device_build", [False, True])
+@pytest.mark.parametrize("n_inst", [1, 3, 9])
+def test_instance_records_with_and_without_hints(host, device_build, n_inst):
+    """The instance's leaf record carries the object's bounds / root and its transform is fetched from the record's own position (api.hip: patch_inst_records_kernel), announced by
+    hints on leaf references and on the preceding record.  With maxnodeprims 4 and up to four items the scene-level ROOT is a leaf — no reference, no hint: the kernel's slow path —,
+    with nine items leaves mix triangles and instances in directive order.  Hits (incl. instance ids), occlusion and the builder's arrays handed out by accel_copy stay the reference's."""
+    P, idx = host.gen_random_tris(200, 11)
+    Ts = _transforms(host)
+
+    def capture(s):
+        m = s.add_material_matte((0.5, 0.5, 0.5), 0.0)
+        ob = s.object_begin(); s.add_mesh(P, idx, m); s.object_end()
+        for k in range(n_inst):
+            if k % 3 == 1:
+                s.add_mesh(P[:3] * np.float32(1.5) + np.float32([0.1 * k, 0, 0]), [0, 1, 2], m)   # a lone scene-level triangle between instances
+            s.add_instance(ob, *Ts[k % len(Ts)])
+        if device_build and not isinstance(s, OracleScene):
+            s.build_accel_device(0, 4)
+        else:
+            s.build_accel(0, 4)
+
+    prod, orc = scenes.build_pair(capture, OracleScene)
+    rays = np.concatenate([scenes.random_rays(30000, 5, bound=3.5), scenes.axis_rays()])
+    got = prod.intersect_batch(rays)
+    want, _ = orc.intersect_batch_stats(rays)
+    eq = scenes.hits_equal(got, want)
+    assert eq.all(), f"{(~eq).sum()} of {len(rays)} differ; first {np.flatnonzero(~eq)[:5]}"
+    assert np.array_equal(prod.occluded_batch(rays), orc.occluded_batch_stats(rays)[0])
+    # after the upload has filled the records in place, accel_copy still hands out the builder's form: no hint bit in a leaf reference, zeroed instance records
+    nodes, recs = prod.accel_copy()     # words: Node64 = 12 plane floats, c0, c1, axis, pad; TriRec = p0[3], prim, p1[3], flags, p2[3], mesh
+    flags = recs[:, 7]
+    assert not (flags & 64).any()                                            # PH_TRI_NEXT_INST
+    inst = (flags & 16) != 0                                                 # PH_TRI_INSTANCE
+    assert inst.sum() == n_inst and not recs[inst][:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].any()
+    for c in (nodes[:, 12], nodes[:, 13]):
+        leaf = (c & 0x80000000) != 0
+        assert not (c[leaf] & 0x40000000).any()
+
+
 def test_instanced_scene_film_bit_exact(host):
     base = _instanced_scene(host, 0, with_normals=True)
 
