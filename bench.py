@@ -50,7 +50,8 @@ sys.path.insert(0, os.path.join(ROOT, "pbrt-v3-rs_amd"))
 L1_LOOKUP_PEAK_G = 880.0   # G L1 (TCP) tag look-ups per second the chip sustains for one random 64-B record per lane read as 4 x dwordx4 (scripts/calib/node_fetch.hip, mode A, L2-resident table)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 INFINITY_CACHE_BYTES = 256 << 20
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+L2_PEAK_GBS = 34500.0      # aggregate L2 read bandwidth of the 8 XCDs (MI355X_MICROARCH.md)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 
 CONFIGS = {  # BASELINE.json `configs`, on the synthetic generator of SURVEY §8d
     "1": dict(n_tris=100_000, res=512, spp=64, max_depth=5, label="configs[1]: synthetic 100 k random triangles, single BVH, 512x512 @ 64 spp"),
@@ -100,7 +101,7 @@ def library_identity():
 
 
 def find_traffic(key):
-    """The PMC record of this workload from profiles/r03_traffic.json — measured on THIS library build under this tuning environment —, or (None, reason)."""
+    """The PMC record of this workload from profiles/r04_traffic.json — measured on THIS library build under this tuning environment —, or (None, reason)."""
     if not os.path.exists(TRAFFIC_FILE):
         return None, f"{os.path.relpath(TRAFFIC_FILE, ROOT)} does not exist"
     with open(TRAFFIC_FILE) as f:
@@ -123,6 +124,12 @@ def launch_ranks(n):
     their output and return code."""
     import socket
     import subprocess
+    # under rocprofv3 the profiler's preloaded library has already initialised the GPU in THIS process: starting a launcher from it is the exec-after-GPU-init
+    # this pool forbids.  Profile multi-rank runs by putting rocprofv3 around each rank (before any GPU call), or use --multi-handle (one process).
+    if any(k.startswith("ROCPROFILER_") or k.startswith("ROCPROF_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        sys.stderr.write("bench.py --gpus N > 1 cannot start its own ranks under rocprofv3 (the GPU is already initialised in this process); "
+                         "profile each rank separately or use --multi-handle\n")
+        return 2
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -275,11 +282,22 @@ def main():
             film_out = (torch.empty((fh, fw, 3), dtype=torch.float32, pin_memory=True).numpy(), torch.empty((fh, fw), dtype=torch.float32, pin_memory=True).numpy())
         torch.cuda.synchronize()  # the library writes tile_buf on its own stream: torch's fill kernels must have finished
 
+        stage = {"render": 0.0, "gather_merge": 0.0}   # host clock per stage of this rank's steps (the render call returns after its stream has drained)
+
         def step():
+            ts = time.perf_counter()
             if args.multi_handle:   # tiles dealt to the handle's devices, gathered and merged inside the library
                 xyz, wt, st = scene.render_path(max_depth=max_depth, tile_size=tile_size, out=film_out)
+                stage["render"] += time.perf_counter() - ts
                 return st, (xyz, wt)
             st = scene.render_path_tiles_device(tile_buf.data_ptr(), max_depth=max_depth, tile_size=tile_size, tile_part=rank, tile_parts=world)
+            tr = time.perf_counter()
+            stage["render"] += tr - ts
+            film = step_tail()
+            stage["gather_merge"] += time.perf_counter() - tr
+            return st, film
+
+        def step_tail():
             film = None
             if use_dist:
                 if args.backend == "nccl":
@@ -295,11 +313,12 @@ def main():
                     film = scene.merge_tiles_device([t.data_ptr() for t in gather_list], tile_size, out=film_out)
             else:
                 film = scene.merge_tiles_device([tile_buf.data_ptr()], tile_size, out=film_out)
-            return st, film
+            return film
 
         for _ in range(warmup):
             step()
         sync()
+        stage["render"] = stage["gather_merge"] = 0.0
         t0 = time.perf_counter()
         rays = reg = shd = launches = 0
         ext_s = sh_s = shade_s = 0.0
@@ -312,11 +331,17 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         rays = reg + shd
+        per_rank = None
         if use_dist:
+            # every rank's own clock, render time and ray count (what the first real N-GPU line needs to be diagnosable): gathered, not only reduced
+            mine = torch.tensor([elapsed, stage["render"], stage["gather_merge"], float(rays)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(allv, mine)
+            per_rank = [[float(x) for x in v.tolist()] for v in allv]
             elapsed = float(reduce_scalars([elapsed], dist.ReduceOp.MAX, torch.float64)[0])
             rays, reg, shd = (int(v) for v in reduce_scalars([rays, reg, shd], dist.ReduceOp.SUM, torch.int64))
         return scene, tile_buf, dict(elapsed=elapsed, rays=rays, reg=reg, shd=shd, ext_s=ext_s, sh_s=sh_s, shade_s=shade_s, launches=launches, film=film,
-                                     t_setup=t_setup, steps=steps)
+                                     t_setup=t_setup, steps=steps, stage=dict(stage), per_rank=per_rank)
 
     scaling = args.scaling if n_gpus > 1 else "weak"  # one GPU: the two coincide; the contract's default label
     frame_spp = spp * (n_gpus if (n_gpus > 1 and scaling == "weak") else 1)
@@ -349,7 +374,18 @@ def main():
             "film_sha256": hashlib.sha256(r["film"][0].tobytes() + r["film"][1].tobytes()).hexdigest(),
             "stage_ms_per_step_rank0": {"traversal": round((r["ext_s"] + r["sh_s"]) / args.steps * 1e3, 3),
                                         "raygen_shade_film": round(r["shade_s"] / args.steps * 1e3, 3)},
+            # host clock around the two halves of a step on rank 0: the render call (returns after its stream drained) and what follows it (N > 1: the gather of the
+            # film-tile buffers + the merge in tile order + film read-back; N = 1: merge + read-back)
+            "stage_ms": {"render": round(r["stage"]["render"] / args.steps * 1e3, 3), "gather_merge": round(r["stage"]["gather_merge"] / args.steps * 1e3, 3)},
         }
+        if r["per_rank"]:
+            rm = [v[1] / args.steps * 1e3 for v in r["per_rank"]]
+            out["ranks"] = {"render_ms": {"min": round(min(rm), 3), "mean": round(sum(rm) / len(rm), 3), "max": round(max(rm), 3), "per_rank": [round(v, 3) for v in rm]},
+                            "imbalance": round(max(rm) / (sum(rm) / len(rm)), 4),
+                            "gather_merge_ms_per_rank": [round(v[2] / args.steps * 1e3, 3) for v in r["per_rank"]],
+                            "rays_per_rank": [int(v[3]) // args.steps for v in r["per_rank"]],
+                            "elapsed_s_per_rank": [round(v[0], 4) for v in r["per_rank"]]}
+            out["rccl"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank": dist.get_rank()}
 
     # ---- roofline of the dominant kernel (BVH traversal, both ray kinds), rank 0's share ------------------------------------------------
     if rank == 0:
@@ -376,6 +412,8 @@ def main():
                 ach = bytes_per_frame / trav_per_frame / 1e9
                 avg_launch_s = trav_per_frame / launches
                 roof.update({"achieved": round(ach, 1), "frac_algorithmic": round(ach / HBM_PEAK_GBS, 4),
+                             "frac_algorithmic_note": ("> 1: served from L2, not an HBM fraction" if ach / HBM_PEAK_GBS > 1.0 else
+                                                       "algorithmic bytes over time over the HBM peak: an upper bound on the HBM fraction only if every node visit missed the caches; see `frac` (counters) and `bound`"),
                              "algorithmic_bytes_per_launch": bytes_per_frame // launches, "launches_per_step": launches,
                              "avg_launch_ms": round(avg_launch_s * 1e3, 4), "rays_per_step": n_rays,
                              "closest_hit": {"rays": cl["rays"], "ref_node_visits_per_ray": round(cl["ref_node_visits"] / max(cl["rays"], 1), 2),
@@ -395,9 +433,27 @@ def main():
                     k = e["traversal"]
                     per_launch = (float(e.get("fetch_scale", 1.0)) * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"]
                     mem_gbs = per_launch / avg_launch_s / 1e9
+                    l2_hit = k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]) if k.get("TCC_HIT") and k.get("TCC_MISS") else None
+                    hbm_frac = mem_gbs / HBM_PEAK_GBS
+                    # what binds, from the counters alone: a launch whose requests are served by L2 and that draws a small share of the HBM peak is paced by the
+                    # latency of its dependent L2 hits, not by memory bandwidth
+                    if l2_hit is not None and l2_hit > 0.8 and hbm_frac < 0.2:
+                        roof["bound"] = "l2-latency"
+                        roof["bound_note"] = (f"derived from the PMC record: L2 hit rate {l2_hit:.3f} > 0.8 and memory-side traffic = {hbm_frac:.3f} of the HBM peak < 0.2 -> a chain of dependent "
+                                              f"L2 hits; `frac` stays the HBM counter fraction, `l2` and `l1_frac_of_calibrated` place the kernel against the roofs that are nearer (" + roof["bound_note"] + ")")
+                    elif hbm_frac >= 0.2:
+                        roof["bound"] = "hbm"
+                    sqk = k.get("sq") or {}
+                    if sqk.get("tcp_tcc_read_req"):
+                        l2_bytes = sqk["tcp_tcc_read_req"] * 64.0 / k["dispatches"]
+                        roof["l2"] = {"bytes": int(l2_bytes), "GBs": round(l2_bytes / avg_launch_s / 1e9, 1), "peak_GBs": L2_PEAK_GBS,
+                                      "frac_of_34.5TBs": round(l2_bytes / avg_launch_s / 1e9 / L2_PEAK_GBS, 4),
+                                      "note": "TCP_TCC_READ_REQ x 64 B per launch / avg launch time, against the 8 XCDs' aggregate L2 read bandwidth"}
+                    if sqk.get("l1_accesses"):
+                        roof["l1_frac_of_calibrated"] = round(sqk["l1_accesses"] / k["dispatches"] / avg_launch_s / 1e9 / L1_LOOKUP_PEAK_G, 4)
                     roof.update({"traffic": int(per_launch), "achieved_memory_side": round(mem_gbs, 1), "frac": round(mem_gbs / HBM_PEAK_GBS, 4),
                                  "frac_basis": "memory-side: traffic / avg_launch_ms / peak",
-                                 "l2_hit_rate": round(k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]), 4) if k.get("TCC_HIT") and k.get("TCC_MISS") else None,
+                                 "l2_hit_rate": round(l2_hit, 4) if l2_hit is not None else None,
                                  "pmc": k.get("sq"),
                                  "limiter": (("no single pipe is saturated: of the chip's cycles the vector ALUs issue in %.0f %% (lane utilisation %.2f), the scalar units take %.2f instructions per CU-cycle, "
                                               "the L1 tag pipes %.2f look-ups per CU-cycle (each lane's 64-B node costs four); L2 serves %.0f %% of the requests since the rays of a launch are binned by origin cell.  "

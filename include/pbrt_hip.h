@@ -231,6 +231,9 @@ int pbrt_hip_set_material_bump(PbrtHipScene*, uint32_t material, uint32_t textur
 int pbrt_hip_add_material_matte_tex(PbrtHipScene*, uint32_t kd_texture, float sigma_degrees, uint32_t* out_material);
 /* Test aids: evaluate a texture on the device at explicit contexts (u, v, du/dx, dv/dx, du/dy, dv/dy, p[3], dp/dx[3], dp/dy[3]); read back the pyramid the host built. */
 int pbrt_hip_texture_eval_batch(PbrtHipScene*, uint32_t texture, uint64_t n, const float* contexts /*15 per point*/, float* out_rgb /*3 per point*/);
+/* The same through the evaluator the renderer uses for every ray but a camera ray (no differentials: an image map's look-up ends in MIPMap::triangle(0, st), mipmap/mod.rs:222-231,
+ * :250-262): the contexts' derivative fields are ignored as if zero.  Must equal pbrt_hip_texture_eval_batch on contexts whose derivatives ARE zero. */
+int pbrt_hip_texture_eval_batch_nodiff(PbrtHipScene*, uint32_t texture, uint64_t n, const float* contexts /*15 per point*/, float* out_rgb /*3 per point*/);
 int pbrt_hip_mipmap_levels(PbrtHipScene*, uint32_t mipmap, int* out_levels, int* out_width_height /*2 per level, <= 16 levels*/);
 int pbrt_hip_mipmap_level_texels(PbrtHipScene*, uint32_t mipmap, int level, float* out_rgb);
 
@@ -290,7 +293,7 @@ int pbrt_hip_build_accel(PbrtHipScene*, int split_method, int max_prims_in_node)
 /* The same with the tree constructed on the GPU: identical topology, leaf order and boxes, so hits do not depend on where the tree was built.
  * split_method 0 (SAH, the reference's default; accelerators/src/bvh/sah.rs:26-367): one level of the tree per round of kernels — bucket boxes by atomics,
  * the reference's cost loop per node, itertools::partition's element order from a prefix sum.  split_method 1 (HLBVH; hlbvh.rs:33-449, morton.rs:33-120):
- * Morton codes, radix sort, one treelet per thread, SAH over the treelet roots on the host.  EqualCounts (3) is a host build: UNSUPPORTED here.  Scenes with object
+ * Morton codes, radix sort, the treelets emitted side by side one tree LEVEL per launch, SAH over the treelet roots on the host.  EqualCounts (3) is a host build: UNSUPPORTED here.  Scenes with object
  * instances (SAH only): the scene's aggregate and every instanced object's are built side by side as one forest, level by level. */
 int pbrt_hip_build_accel_device(PbrtHipScene*, int split_method, int max_prims_in_node);
 

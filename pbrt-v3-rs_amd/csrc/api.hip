@@ -51,14 +51,6 @@ void free_tree_dev(PbrtHipScene* s) {
     if (s->tree_dev_tris) (void)hipFree(s->tree_dev_tris);
     s->tree_dev_nodes = s->tree_dev_tris = nullptr; s->tree_dev_n_tris = 0;
 }
-int ensure_host_tree(PbrtHipScene* s) {
-    if (!s->tree_dev_tris || !s->bvh.tris.empty()) return PBRT_HIP_OK;
-    PH_CHECK(s, hipSetDevice(s->device));
-    s->bvh.nodes.resize(s->bvh.interior_nodes); s->bvh.tris.resize(s->tree_dev_n_tris);
-    if (s->bvh.interior_nodes) PH_CHECK(s, hipMemcpy(s->bvh.nodes.data(), s->tree_dev_nodes, s->bvh.interior_nodes * sizeof(Node64), hipMemcpyDeviceToHost));
-    PH_CHECK(s, hipMemcpy(s->bvh.tris.data(), s->tree_dev_tris, s->tree_dev_n_tris * sizeof(TriRec), hipMemcpyDeviceToHost));
-    return PBRT_HIP_OK;
-}
 
 static void free_owned(PbrtHipScene* s) {
     for (void* p : s->owned) (void)hipFree(p);
@@ -158,6 +150,22 @@ int upload_scene(PbrtHipScene* s) {
     }
     if ((rc = upload_vec(s, s->materials, &d.materials))) return rc;
     if ((rc = upload_vec(s, s->lobes, &d.lobes))) return rc;
+    {   // keys of the shade-side work queues (matsort.h): materials the texture pass has work for first, then the others, then "emission only" and "no new vertex"
+        const uint32_t kMaxTex = 500u, kMaxPlain = 500u;
+        std::vector<uint16_t> key(std::max<size_t>(s->materials.size(), 1), 0);
+        uint32_t n_tex = 0, n_plain = 0;
+        for (const MaterialRec& m : s->materials) if (!m.none && (m.textured || m.bump_tex1)) n_tex++;
+        const uint32_t T = std::min(n_tex, kMaxTex);
+        uint32_t jt = 0, jp = 0;
+        for (size_t i = 0; i < s->materials.size(); i++) {
+            const MaterialRec& m = s->materials[i];
+            if (!m.none && (m.textured || m.bump_tex1)) key[i] = (uint16_t)std::min(jt++, kMaxTex - 1u);
+            else { key[i] = (uint16_t)(T + std::min(jp++, kMaxPlain - 1u)); n_plain++; }
+        }
+        const uint32_t U = std::min(n_plain, kMaxPlain);
+        if ((rc = upload_vec(s, key, &d.mat_key))) return rc;
+        d.ms_tex_keys = T; d.ms_key_emit = T + U; d.ms_key_idle = T + U + 1u;
+    }
     if (!s->textures.empty() || !s->mipmaps.empty()) {   // MIPMaps also belong to lights (radiance map, projection image, goniometric diagram)
         std::vector<TexRec> recs; std::vector<TexOp> ops;
         for (const PbrtHipScene::TextureHost& t : s->textures) {
@@ -187,7 +195,8 @@ int upload_scene(PbrtHipScene* s) {
     d.n_infinite = (uint32_t)s->infinite_lights.size();
     if ((rc = upload_vec(s, s->inst_recs, &d.instances))) return rc;
     d.n_instances = (uint32_t)s->inst_recs.size();
-    if (!s->inst_recs.empty() && !s->top_items.empty() && d.nodes && d.tris) {   // instance leaf records + hints (patch_inst_records_kernel)
+    // a forest whose trees are all single leaves has no interior node at all (d.nodes == nullptr): the records still need their bounds / root / transform
+    if (!s->inst_recs.empty() && !s->top_items.empty() && d.tris) {   // instance leaf records + hints (patch_inst_records_kernel)
         const uint32_t n_top = (uint32_t)s->top_items.size();
         const uint32_t n_nodes = (uint32_t)(s->tree_dev_tris ? s->bvh.interior_nodes : s->bvh.nodes.size());
         void* extra = nullptr;
@@ -1253,7 +1262,10 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
     }
     if (s->tree_dev_tris) { PH_CHECK(s, hipSetDevice(s->device)); free_tree_dev(s); }   // a rebuild: the tree an earlier device build left there goes first
     std::vector<uint32_t> build_flags(s->tri_flags);
-    for (size_t t = 0; t < build_flags.size(); t++) build_flags[t] |= s->materials[s->meshes[s->tri_mesh[t]].material].sort_class << PH_TRI_CLASS_SHIFT;
+    for (size_t t = 0; t < build_flags.size(); t++) {   // shade-side sorting keys travel in the TriRec: the material's class and its id (scene_types.h)
+        const uint32_t mat = s->meshes[s->tri_mesh[t]].material;
+        build_flags[t] |= (s->materials[mat].sort_class << PH_TRI_CLASS_SHIFT) | (std::min<uint32_t>(mat, 0xFFFu) << PH_TRI_MAT_SHIFT);
+    }
     phost::BuildInput in;
     in.P = s->P.data(); in.idx = s->idx.data(); in.n_tris = s->idx.size() / 3; in.tri_flags = build_flags.data(); in.tri_mesh = s->tri_mesh.data();
     auto fail = [&](int brc) {
@@ -1286,6 +1298,8 @@ int pbrt_hip_build_accel(PbrtHipScene* s, int split_method, int max_prims_in_nod
         const phost::InstancedScene isc{tri0.data(), tri1.data(), tri0.size(), inst_object.data(), inst_i2w.data(), inst_object.size(), s->top_items.data(), s->top_items.size()};
         phost::ForestLayout layout;
         phost::forest_layout(isc, layout);
+        // bit 30 of a leaf reference is PH_LEAF_INST_HINT in an instanced scene: the forest's records must stay below it (both builders)
+        if (layout.items.size() >= 0x40000000ull) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "build_accel: an instanced scene may hold at most 2^30 leaf records");
         std::vector<phost::ForestTreeOut> trees;
         if (s->build_on_device) {
             PH_CHECK(s, hipSetDevice(s->device));

@@ -81,7 +81,7 @@ struct PbrtHipScene : SceneHostState {
     // ---- device residency ---------------------------------------------------------------------------------------------
     DeviceScene ds{};
     std::vector<void*> owned;        // every hipMalloc of the scene, freed on destroy / rebuild
-    // a tree pbrt_hip_build_accel_device(0, ..) left where it was built: `bvh.nodes` / `bvh.tris` stay empty on the host until something needs them there (ensure_host_tree)
+    // a tree pbrt_hip_build_accel_device(0, ..) left where it was built: `bvh.nodes` / `bvh.tris` stay empty on the host (accel_copy reads them back on request; the multi-device driver replicates by hipMemcpyPeer)
     void* tree_dev_nodes = nullptr; void* tree_dev_tris = nullptr; size_t tree_dev_n_tris = 0;
     bool uploaded = false;
     int light_strategy_uploaded = -1;
@@ -117,7 +117,6 @@ int build_hlbvh_device(const BuildInput& in, int max_prims_in_node, hipStream_t 
 int build_sah_device(const BuildInput& in, int max_prims_in_node, hipStream_t stream, BuildOutput& out, std::string& err, void** keep_nodes = nullptr, void** keep_tris = nullptr,
                      const ForestSpec* forest = nullptr, std::vector<ForestTreeOut>* trees_out = nullptr);
 void free_tree_dev(PbrtHipScene* s);
-int ensure_host_tree(PbrtHipScene* s);   // api.hip: the host copy of a tree that lives on the device only (the multi-device driver replicates from the host copy)
 int uber_rebuild_for_opacity(PbrtHipScene* s, uint32_t material);    // api.hip: lobe lists remade when a structural parameter becomes a texture
 int glass_rebuild_for_roughness(PbrtHipScene* s, uint32_t material);
 int translucent_rebuild_rt(PbrtHipScene* s, uint32_t material);      // api.hip: TranslucentMaterial -> its per-hit form (a reflect / transmit texture)

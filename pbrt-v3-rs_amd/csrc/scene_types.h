@@ -31,6 +31,8 @@ struct alignas(64) Node64 {
 #define PH_TRI_ALPHA0 4u   // mesh alpha texture == 0.0 (triangle.rs:603)
 #define PH_TRI_SALPHA0 8u  // mesh shadowalpha texture == 0.0 (triangle.rs:891)
 #define PH_TRI_CLASS_SHIFT 8  // bits 8..10: material class of the triangle (shade-side sorting key; 7 = Material "none"), set at build time
+#define PH_TRI_MAT_SHIFT 11    // bits 11..22: the triangle's material id (0xFFF: "look it up through the mesh" — a scene with more than 4094 materials), set at build time with the class
+#define PH_TRI_KEY_MASK 0x7FFFu  // (flags >> PH_TRI_CLASS_SHIFT) & this = class | material << 3: what the traversal kernel reports in HitOut::pad[2] (shade-side queues, matsort.h)
 #define PH_TRI_ALPHATEX 32u  // the mesh's alpha or shadowalpha is a texture: the traversal kernel (ALPHA variants) evaluates it at the candidate hit
 #define PH_TRI_NEXT_INST 64u  // the next record of this leaf is an instance (see PH_LEAF_INST_HINT)
 #define PH_TRI_INSTANCE 16u  // not a triangle: a TransformedPrimitive (object instance); `prim` = index into DeviceScene::instances
@@ -237,6 +239,8 @@ struct DeviceScene {
     uint32_t n_lights;
     const uint32_t* infinite_lights;
     uint32_t n_infinite;
+    const uint16_t* mat_key;    // per material: its key in the shade-side work queues (matsort.h): materials with per-hit textures / a bump map hold keys [0, ms_tex_keys), the others follow,
+    uint32_t ms_tex_keys, ms_key_emit, ms_key_idle;   // then ms_key_emit (new vertex at the bounce limit: emission only) and ms_key_idle (no new vertex)
     const InstRec* instances;
     const float* inst_extra;    // 12 floats (read as 3 float4) per scene-level leaf record: rows 0 .. 2 of world-to-instance where the record is an instance (else unused)
     uint32_t n_instances;

@@ -223,29 +223,62 @@ PH_DEV void map_2d(const TexOp& op, const TexCtx& c, f2& st, f2& dstdx, f2& dstd
     }
 }
 
+// the (s, t) of map_2d alone, for look-ups without differentials
+PH_DEV f2 map_2d_st(const TexOp& op, const TexCtx& c) {
+    if (op.mapping == 0u) return mk2(op.su * c.uv.x + op.du, op.sv * c.uv.y + op.dv);
+    if (op.mapping == 3u) return mk2(op.du + dot(c.p, mk3(op.m[0], op.m[1], op.m[2])), op.dv + dot(c.p, mk3(op.m[3], op.m[4], op.m[5])));
+    return op.mapping == 1u ? map_sphere(op.m, c.p) : map_cylinder(op.m, c.p);
+}
+
+// The evaluator's value stack lives in LDS as [depth][channel][thread of the block] (conflict-free, no scratch): indexed dynamically by the program, a per-thread array
+// would go to scratch memory — 72 B per thread that the texture pass of configs[4] wrote and re-read 3.2 TB of per frame (round 3).  Kernels that evaluate textures run
+// blocks of at most PH_TEX_LDS_THREADS threads (texture_kernel, the ALPHA = 2 traversal kernel: 256).
+#define PH_TEX_LDS_THREADS 256
+struct TexStack {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float* base;   // &lds[0][0][threadIdx.x]
+    PH_DEV void put(int k, spec v) { base[(3 * k) * PH_TEX_LDS_THREADS] = v.r; base[(3 * k + 1) * PH_TEX_LDS_THREADS] = v.g; base[(3 * k + 2) * PH_TEX_LDS_THREADS] = v.b; }
+    PH_DEV spec get(int k) const { return mks(base[(3 * k) * PH_TEX_LDS_THREADS], base[(3 * k + 1) * PH_TEX_LDS_THREADS], base[(3 * k + 2) * PH_TEX_LDS_THREADS]); }
+#else
+    spec v_[PH_TEX_STACK];
+    void put(int k, spec v) { v_[k] = v; }
+    spec get(int k) const { return v_[k]; }
+#endif
+};
+
 // Runs texture `id`'s postfix program.  Kept out of line: the shade kernels call it only for materials that carry a texture.
 // `dsc` = DeviceScene::self (the by-value kernel argument must not have its address taken: it would be copied to scratch).
 // SIMPLE = the scene's texture programs consist of constants, image maps, scale and mix only (what most scene files use): the procedural classes and their Perlin noise are
 // compiled out, the caller's register budget shrinks with them (an out-of-line callee's registers count towards its kernel's)
-template <bool SIMPLE>
+// NODIFF = the context carries no differentials (every ray but a camera ray: `c`'s du/dv d x/y and dp d x/y are zero): an image map's filtered look-up then ends in
+// MIPMap::triangle(0, st) whatever its filter — trilinear: width 0 -> level = levels - 1 + log2(1e-8) < 0 (a pyramid has at most PH_MIP_MAX_LEVELS = 16 levels),
+// mipmap/mod.rs:222-231; EWA: minor_length == 0, :250-262 — and the evaluator is compiled without the EWA / trilinear code (the mapping's differentials, zero for finite
+// mapping parameters, are not formed).  The procedural classes run their general code on the zero differentials.
+template <bool SIMPLE, bool NODIFF>
 static __device__ __forceinline__ spec tex_eval_body(const DeviceScene* dsc, uint32_t id, const TexCtx& c) {
     const DeviceScene& sc = *dsc;
     const TexRec tr = sc.textures[id];
-    spec st[PH_TEX_STACK];
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ float tex_stack_lds[PH_TEX_STACK * 3][PH_TEX_LDS_THREADS];
+    TexStack stk; stk.base = &tex_stack_lds[0][threadIdx.x];
+#else
+    TexStack stk;
+#endif
     int sp = 0;
     for (uint32_t k = 0; k < tr.n_ops; k++) {
         const TexOp& op = sc.tex_ops[tr.first_op + k];
         switch (op.op) {
-        case PH_TOP_CONST: st[sp++] = mks(op.c[0], op.c[1], op.c[2]); break;
+        case PH_TOP_CONST: stk.put(sp++, mks(op.c[0], op.c[1], op.c[2])); break;
         case PH_TOP_IMAGE: {
+            if (NODIFF) { stk.put(sp++, mip_triangle(sc, sc.mipmaps[op.mip], 0u, map_2d_st(op, c))); break; }
             f2 p, dstdx, dstdy; map_2d(op, c, p, dstdx, dstdy);
-            st[sp++] = mip_lookup(sc, sc.mipmaps[op.mip], p, dstdx, dstdy);
+            stk.put(sp++, mip_lookup(sc, sc.mipmaps[op.mip], p, dstdx, dstdy));
             break;
         }
-        case PH_TOP_MUL: { sp--; st[sp - 1] = st[sp - 1] * st[sp]; break; }                          // scale.rs:33
+        case PH_TOP_MUL: { sp--; stk.put(sp - 1, stk.get(sp - 1) * stk.get(sp)); break; }                          // scale.rs:33
         case PH_TOP_CHECKER: if (!SIMPLE) {  // checkerboard_2d.rs:60-104; stack = tex1, tex2 (both are evaluated: they have no side effects)
             sp--;
-            const spec a = st[sp - 1], b = st[sp];
+            const spec a = stk.get(sp - 1), b = stk.get(sp);
             f2 p, dstdx, dstdy; map_2d(op, c, p, dstdx, dstdy);
             const bool even = (int)((uint32_t)f2i_sat(floorf(p.x)) + (uint32_t)f2i_sat(floorf(p.y))) % 2 == 0;
             spec r = even ? a : b;
@@ -258,30 +291,30 @@ static __device__ __forceinline__ spec tex_eval_body(const DeviceScene* dsc, uin
                     r = a * (1.0f - area2) + b * area2;
                 }
             }
-            st[sp - 1] = r;
+            stk.put(sp - 1, r);
             } break;
         case PH_TOP_UV: if (!SIMPLE) {  // uv.rs:33-38
             f2 p, dx_, dy_; map_2d(op, c, p, dx_, dy_);
-            st[sp++] = mks(p.x - floorf(p.x), p.y - floorf(p.y), 0.0f);
+            stk.put(sp++, mks(p.x - floorf(p.x), p.y - floorf(p.y), 0.0f));
             } break;
         case PH_TOP_BILERP: if (!SIMPLE) {  // bilerp.rs:58-71; stack = v00, v01, v10, v11
             sp -= 3;
             f2 p, dx_, dy_; map_2d(op, c, p, dx_, dy_);
             const float s00 = (1.0f - p.x) * (1.0f - p.y), s01 = (1.0f - p.x) * p.y, s10 = p.x * (1.0f - p.y), s11 = p.x * p.y;
-            st[sp - 1] = (st[sp - 1] * s00) + (st[sp] * s01) + (st[sp + 1] * s10) + (st[sp + 2] * s11);
+            stk.put(sp - 1, (stk.get(sp - 1) * s00) + (stk.get(sp) * s01) + (stk.get(sp + 1) * s10) + (stk.get(sp + 2) * s11));
             } break;
         case PH_TOP_FBM: case PH_TOP_WRINKLED: case PH_TOP_WINDY: case PH_TOP_MARBLE: case PH_TOP_CHECKER3D: if (!SIMPLE) {  // IdentityMapping3D::map (identity_3d.rs)
             const f3 dpdx = xf_vec(op.m, c.dpdx), dpdy = xf_vec(op.m, c.dpdy);
             f3 p = xf_point16(op.m, c.p);
-            if (op.op == PH_TOP_FBM) st[sp++] = mks1(tex_fbm(p, dpdx, dpdy, op.omega, op.octaves, false));            // fbm.rs:45-50
-            else if (op.op == PH_TOP_WRINKLED) st[sp++] = mks1(tex_fbm(p, dpdx, dpdy, op.omega, op.octaves, true));   // wrinkled.rs:45-50
+            if (op.op == PH_TOP_FBM) stk.put(sp++, mks1(tex_fbm(p, dpdx, dpdy, op.omega, op.octaves, false)));            // fbm.rs:45-50
+            else if (op.op == PH_TOP_WRINKLED) stk.put(sp++, mks1(tex_fbm(p, dpdx, dpdy, op.omega, op.octaves, true)));   // wrinkled.rs:45-50
             else if (op.op == PH_TOP_WINDY) {                                                                          // windy.rs:36-44
                 const float wind = tex_fbm(0.1f * p, 0.1f * dpdx, 0.1f * dpdy, 0.5f, 3u, false), wave = tex_fbm(p, dpdx, dpdy, 0.5f, 6u, false);
-                st[sp++] = mks1(pabs(wind) * wave);
+                stk.put(sp++, mks1(pabs(wind) * wave));
             } else if (op.op == PH_TOP_CHECKER3D) {                                                                    // checkerboard_3d.rs:44-53
                 sp--;
                 const uint32_t sum = (uint32_t)f2i_sat(floorf(p.x)) + (uint32_t)f2i_sat(floorf(p.y)) + (uint32_t)f2i_sat(floorf(p.z));
-                st[sp - 1] = ((int)sum % 2 == 0) ? st[sp - 1] : st[sp];
+                stk.put(sp - 1, ((int)sum % 2 == 0) ? stk.get(sp - 1) : stk.get(sp));
             } else {                                                                                                   // marble.rs:54-85
                 p = p * op.scale;
                 const float marble = p.y + op.variation * tex_fbm(p, op.scale * dpdx, op.scale * dpdy, op.omega, op.octaves, false);
@@ -294,7 +327,7 @@ static __device__ __forceinline__ spec tex_eval_body(const DeviceScene* dsc, uin
                 spec s0 = (1.0f - tt) * c0 + tt * c1, s1 = (1.0f - tt) * c1 + tt * c2;
                 const spec s2 = (1.0f - tt) * c2 + tt * c3;
                 s0 = (1.0f - tt) * s0 + tt * s1; s1 = (1.0f - tt) * s1 + tt * s2;
-                st[sp++] = 1.5f * ((1.0f - tt) * s0 + tt * s1);
+                stk.put(sp++, 1.5f * ((1.0f - tt) * s0 + tt * s1));
             }
             } break;
         case PH_TOP_DOTS: if (!SIMPLE) {  // dots.rs:48-69; stack = inside, outside
@@ -309,29 +342,21 @@ static __device__ __forceinline__ spec tex_eval_body(const DeviceScene* dsc, uin
                 const float ddx = p.x - s_center, ddy = p.y - t_center;
                 inside = ddx * ddx + ddy * ddy < radius * radius;
             }
-            st[sp - 1] = inside ? st[sp - 1] : st[sp];
+            stk.put(sp - 1, inside ? stk.get(sp - 1) : stk.get(sp));
             } break;
         default: {  // PH_TOP_MIX: (1 - amt) * t1 + amt * t2 (mix.rs:36-41); stack = t1, t2, amount
             sp -= 2;
-            const float amt = st[sp + 1].r;
-            st[sp - 1] = (1.0f - amt) * st[sp - 1] + amt * st[sp];
+            const float amt = stk.get(sp + 1).r;
+            stk.put(sp - 1, (1.0f - amt) * stk.get(sp - 1) + amt * stk.get(sp));
             break;
         }
         }
     }
-    return st[0];
+    return stk.get(0);
 }
-template <bool SIMPLE = false> struct TexEval;
-template <> struct TexEval<false> { static __device__ __noinline__ spec run(const DeviceScene* dsc, uint32_t id, TexCtx c) { return tex_eval_body<false>(dsc, id, c); } };
-#ifndef PH_TEX_SIMPLE_INLINE
-#define PH_TEX_SIMPLE_INLINE 0
-#endif
-#if PH_TEX_SIMPLE_INLINE
-template <> struct TexEval<true> { static __device__ __forceinline__ spec run(const DeviceScene* dsc, uint32_t id, const TexCtx& c) { return tex_eval_body<true>(dsc, id, c); } };
-#else
-template <> struct TexEval<true> { static __device__ __noinline__ spec run(const DeviceScene* dsc, uint32_t id, TexCtx c) { return tex_eval_body<true>(dsc, id, c); } };
-#endif
-template <bool SIMPLE = false> PH_DEV spec tex_eval(const DeviceScene* dsc, uint32_t id, const TexCtx& c) { return TexEval<SIMPLE>::run(dsc, id, c); }
+// out of line: the evaluator's registers and code stay out of its callers (several call sites per material class)
+template <bool SIMPLE, bool NODIFF> struct TexEval { static __device__ __noinline__ spec run(const DeviceScene* dsc, uint32_t id, TexCtx c) { return tex_eval_body<SIMPLE, NODIFF>(dsc, id, c); } };
+template <bool SIMPLE = false, bool NODIFF = false> PH_DEV spec tex_eval(const DeviceScene* dsc, uint32_t id, const TexCtx& c) { return TexEval<SIMPLE, NODIFF>::run(dsc, id, c); }
 
 // ---- ray differentials of a camera ray, in world space, scaled as render_tile does (sampler_integrator.rs:358) --------------
 struct RayDiff { f3 rx_o, ry_o, rx_d, ry_d; };
@@ -503,9 +528,9 @@ PH_DEV TexCtx hit_tex_ctx(const DeviceScene* dsc, const CameraRec* cam, uint32_t
     return ctx;
 }
 // `tex.evaluate(..).clamp_default()` (matte.rs:63, plastic.rs:62-70, mirror.rs:53, substrate.rs:60-61)
-template <bool SIMPLE = false>
+template <bool SIMPLE = false, bool NODIFF = false>
 PH_DEV spec tex_eval_clamped(const DeviceScene* dsc, uint32_t tex, const TexCtx& ctx) {
-    const spec v = tex_eval<SIMPLE>(dsc, tex, ctx);
+    const spec v = tex_eval<SIMPLE, NODIFF>(dsc, tex, ctx);
     return mks(pclampf(v.r, 0.0f, kInf), pclampf(v.g, 0.0f, kInf), pclampf(v.b, 0.0f, kInf));
 }
 // The hit's own lobe list of a textured material: the template lobes with their textured colours filled in, a lobe dropped where the reference
@@ -521,10 +546,10 @@ PH_DEV bool lobe_keep(const LobeRec& l) {
 PH_DEV float d_log(float x) { return (float)log((double)x); }
 // the lobe's scalar parameters when they are textures: MatteMaterial's sigma -> Oren-Nayar A, B (matte.rs:64-70, oren_nayar.rs:28-39); roughness -> Trowbridge-Reitz alpha,
 // remapped per hit (trowbridge_reitz.rs:21-40).  One parametrised lobe per material: the values travel in out.col[0][3], out.col[1][3]
-template <bool SIMPLE = false>
+template <bool SIMPLE = false, bool NODIFF = false>
 PH_DEV void eval_lobe_scalars(const DeviceScene* dsc, const LobeRec& l, const TexCtx& ctx, TexOut& out) {
     if (l.sigma_tex1) {
-        const float sig = pclampf(tex_eval<SIMPLE>(dsc, l.sigma_tex1 - 1u, ctx).r, 0.0f, 90.0f);
+        const float sig = pclampf(tex_eval<SIMPLE, NODIFF>(dsc, l.sigma_tex1 - 1u, ctx).r, 0.0f, 90.0f);
         if (sig == 0.0f) { out.lambert |= 1u; out.col[0][3] = 0.0f; out.col[1][3] = 0.0f; }
         else { const float sg = sig * (kPi / 180.0f), s2 = sg * sg; out.col[0][3] = 1.0f - ph_div(s2, 2.0f * (s2 + 0.33f)); out.col[1][3] = ph_div(0.45f * s2, s2 + 0.09f); }
     }
@@ -533,7 +558,7 @@ PH_DEV void eval_lobe_scalars(const DeviceScene* dsc, const LobeRec& l, const Te
         float raw[2] = {l.ur_raw, l.vr_raw};   // GlassMaterial: `is_specular = urough == 0 && vrough == 0` on the values as the textures give them (glass.rs:111)
         const uint32_t tx[2] = {l.ax_tex1, l.ay_tex1};
         for (int k = 0; k < 2; k++) if (tx[k]) {
-            float r = tex_eval<SIMPLE>(dsc, tx[k] - 1u, ctx).r;
+            float r = tex_eval<SIMPLE, NODIFF>(dsc, tx[k] - 1u, ctx).r;
             raw[k] = r;
             if (l.remap) { r = pmaxf(r, 1e-3f); const float x = d_log(r); r = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x; }
             a[k] = pmaxf(0.001f, r);
@@ -546,28 +571,28 @@ PH_DEV void eval_lobe_scalars(const DeviceScene* dsc, const LobeRec& l, const Te
 PH_DEV bool lobe_is_reflection(const LobeRec& l) { return l.kind == PH_LK_LAMBERT || l.kind == PH_LK_MICRO_R; }   // (of a PH_PRE_RT lobe: LambertianReflection / MicrofacetReflection against their transmission twins)
 PH_DEV bool lobe_slot_r(const LobeRec& l) { return l.has_pre == PH_PRE_RT ? lobe_is_reflection(l) : (l.r_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T)); }
 PH_DEV bool lobe_slot_t(const LobeRec& l) { return l.has_pre == PH_PRE_RT ? !lobe_is_reflection(l) : (l.t_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH); }
-template <bool SIMPLE = false>
+template <bool SIMPLE = false, bool NODIFF = false>
 PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const MaterialRec& mr, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, TexOut& out) {
     uint32_t k = 0;
     auto put = [&](spec c) { if (k < PH_HIT_COLS) { out.col[k][0] = c.r; out.col[k][1] = c.g; out.col[k][2] = c.b; k++; } };
-    if (mr.index_tex1) out.col[2][3] = tex_eval<SIMPLE>(dsc, mr.index_tex1 - 1u, ctx).r;                         // glass.rs:102 / uber.rs:128: as the texture gives it
-    if (mr.amount_tex1) put(tex_eval_clamped<SIMPLE>(dsc, mr.amount_tex1 - 1u, ctx));                           // mix.rs:59: s1 (s2 is made from it in the shade pass)
+    if (mr.index_tex1) out.col[2][3] = tex_eval<SIMPLE, NODIFF>(dsc, mr.index_tex1 - 1u, ctx).r;                         // glass.rs:102 / uber.rs:128: as the texture gives it
+    if (mr.amount_tex1) put(tex_eval_clamped<SIMPLE, NODIFF>(dsc, mr.amount_tex1 - 1u, ctx));                           // mix.rs:59: s1 (s2 is made from it in the shade pass)
     spec op = mks1(1.0f);
-    if (mr.opacity_tex1) op = tex_eval_clamped<SIMPLE>(dsc, mr.opacity_tex1 - 1u, ctx);                          // uber.rs:126
+    if (mr.opacity_tex1) op = tex_eval_clamped<SIMPLE, NODIFF>(dsc, mr.opacity_tex1 - 1u, ctx);                          // uber.rs:126
     spec rt_r = mks1(0.0f), rt_t = mks1(0.0f);
     if (mr.rt_mode) {   // translucent.rs:70-74: reflect and transmit of this hit; both black -> the hit has no BSDF
-        rt_r = mr.refl_tex1 ? tex_eval_clamped<SIMPLE>(dsc, mr.refl_tex1 - 1u, ctx) : mks(mr.refl_c[0], mr.refl_c[1], mr.refl_c[2]);
-        rt_t = mr.trans_tex1 ? tex_eval_clamped<SIMPLE>(dsc, mr.trans_tex1 - 1u, ctx) : mks(mr.trans_c[0], mr.trans_c[1], mr.trans_c[2]);
+        rt_r = mr.refl_tex1 ? tex_eval_clamped<SIMPLE, NODIFF>(dsc, mr.refl_tex1 - 1u, ctx) : mks(mr.refl_c[0], mr.refl_c[1], mr.refl_c[2]);
+        rt_t = mr.trans_tex1 ? tex_eval_clamped<SIMPLE, NODIFF>(dsc, mr.trans_tex1 - 1u, ctx) : mks(mr.trans_c[0], mr.trans_c[1], mr.trans_c[2]);
         if (is_black(rt_r) && is_black(rt_t)) { out.bumped |= PH_TEXOUT_NULL_BSDF; return; }
     }
     for (uint32_t i = 0; i < n; i++) {
         const LobeRec& l = tmpl[i];
-        if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1) eval_lobe_scalars<SIMPLE>(dsc, l, ctx, out);
+        if (l.sigma_tex1 || l.ax_tex1 || l.ay_tex1) eval_lobe_scalars<SIMPLE, NODIFF>(dsc, l, ctx, out);
         if (l.has_pre == PH_PRE_RT) {   // `if !kd.is_black() { if !r.is_black() { add(r * kd) } if !t.is_black() { add(t * kd) } }` and the same with Ks (translucent.rs:76-98)
             const bool refl = lobe_is_reflection(l);
             const spec A = refl ? rt_r : rt_t;
             const uint32_t tex = refl ? l.r_tex1 : l.t_tex1;
-            const spec B = tex ? tex_eval_clamped<SIMPLE>(dsc, tex - 1u, ctx) : mks(l.pre[0], l.pre[1], l.pre[2]);
+            const spec B = tex ? tex_eval_clamped<SIMPLE, NODIFF>(dsc, tex - 1u, ctx) : mks(l.pre[0], l.pre[1], l.pre[2]);
             if ((is_black(A) || is_black(B)) && k < PH_HIT_COLS) out.bumped |= 1u << (8u + k);
             put(A * B);
             continue;
@@ -575,20 +600,20 @@ PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const MaterialRec& mr, con
         if (l.has_pre == PH_PRE_PASSTHROUGH) { const spec t = op * -1.0f + mks1(1.0f); put(mks(pclampf(t.r, 0.0f, kInf), pclampf(t.g, 0.0f, kInf), pclampf(t.b, 0.0f, kInf))); continue; }   // (-op + ONE).clamp_default() (uber.rs:127)
         if (l.has_pre == PH_PRE_OPACITY) {   // op * k.evaluate(..).clamp_default() (uber.rs:141, :147, :169, :175)
             const uint32_t tex = l.kind == PH_LK_SPEC_T ? l.t_tex1 : l.r_tex1;
-            const spec base = tex ? tex_eval_clamped<SIMPLE>(dsc, tex - 1u, ctx) : mks(l.pre[0], l.pre[1], l.pre[2]);
+            const spec base = tex ? tex_eval_clamped<SIMPLE, NODIFF>(dsc, tex - 1u, ctx) : mks(l.pre[0], l.pre[1], l.pre[2]);
             put(op * base);
         } else {
             const spec pre = l.has_pre ? mks(l.pre[0], l.pre[1], l.pre[2]) : mks1(1.0f);
             const uint32_t texs[2] = {l.r_tex1, l.t_tex1};
             for (int f = 0; f < 2; f++) if (texs[f] && k < PH_HIT_COLS) {
-                spec c = tex_eval_clamped<SIMPLE>(dsc, texs[f] - 1u, ctx);
+                spec c = tex_eval_clamped<SIMPLE, NODIFF>(dsc, texs[f] - 1u, ctx);
                 if (l.has_pre == PH_PRE_RAW_TEST && c.r == 0.0f && c.g == 0.0f && c.b == 0.0f) out.bumped |= 1u << (8u + k);
                 if (l.has_pre) c = pre * c;
                 put(c);
             }
         }
-        if (l.eta_tex1) put(tex_eval<SIMPLE>(dsc, l.eta_tex1 - 1u, ctx));   // metal.rs:121-125: as the textures give them, no clamp
-        if (l.k_tex1) put(tex_eval<SIMPLE>(dsc, l.k_tex1 - 1u, ctx));
+        if (l.eta_tex1) put(tex_eval<SIMPLE, NODIFF>(dsc, l.eta_tex1 - 1u, ctx));   // metal.rs:121-125: as the textures give them, no clamp
+        if (l.k_tex1) put(tex_eval<SIMPLE, NODIFF>(dsc, l.k_tex1 - 1u, ctx));
     }
 }
 // shade pass: the hit's own lobe list = template lobes with the texture pass's colours filled in, a lobe dropped where the reference would not add it.
@@ -631,7 +656,7 @@ struct BumpOut { f3 ns, dpdu_s; };
 struct BumpIn { uint32_t tex, tri_index, inst; f3 bary, p, n, ns, dpdu_s; TexCtx c; };
 // arguments travel through one private struct: with ~40 scalar arguments (most of them on the stack) this function, out of line, corrupted values of OTHER
 // lanes of the wave in the one-lobe kernel on gfx950
-template <bool SIMPLE = false>
+template <bool SIMPLE = false, bool NODIFF = false>
 PH_DEV void hit_bump(const DeviceScene* dsc, const BumpIn* in, BumpOut* out) {
     const DeviceScene& sc = *dsc;
     const uint32_t tex = in->tex, tri_index = in->tri_index, inst = in->inst;
@@ -694,12 +719,12 @@ PH_DEV void hit_bump(const DeviceScene* dsc, const BumpIn* in, BumpOut* out) {
     float du = 0.5f * (pabs(c.dudx) + pabs(c.dudy));
     if (du == 0.0f) du = 0.0005f;
     TexCtx cu = c; cu.p = p + du * dpdu_s; cu.uv = mk2(c.uv.x + du, c.uv.y + 0.0f);
-    const float u_displace = tex_eval<SIMPLE>(dsc, tex, cu).r;
+    const float u_displace = tex_eval<SIMPLE, NODIFF>(dsc, tex, cu).r;
     float dv = 0.5f * (pabs(c.dvdx) + pabs(c.dvdy));
     if (dv == 0.0f) dv = 0.0005f;
     TexCtx cv = c; cv.p = p + dv * dpdv_s; cv.uv = mk2(c.uv.x + 0.0f, c.uv.y + dv);
-    const float v_displace = tex_eval<SIMPLE>(dsc, tex, cv).r;
-    const float displace = tex_eval<SIMPLE>(dsc, tex, c).r;
+    const float v_displace = tex_eval<SIMPLE, NODIFF>(dsc, tex, cv).r;
+    const float displace = tex_eval<SIMPLE, NODIFF>(dsc, tex, c).r;
     const f3 ndpdu = dpdu_s + ph_div(u_displace - displace, du) * ns + displace * dndu;
     const f3 ndpdv = dpdv_s + ph_div(v_displace - displace, dv) * ns + displace * dndv;
     out->ns = face_forward(normalize(cross(ndpdu, ndpdv)), n);
@@ -756,8 +781,9 @@ static __device__ __noinline__ bool alpha_accept(const DeviceScene* dsc, uint32_
     ctx.dudx = ctx.dvdx = ctx.dudy = ctx.dvdy = 0.0f;
     ctx.p = b0 * mk3(a.x, a.y, a.z) + b1 * mk3(b.x, b.y, b.z) + b2 * mk3(c.x, c.y, c.z);
     ctx.dpdx = mk3(0.0f, 0.0f, 0.0f); ctx.dpdy = ctx.dpdx;
-    if (m.alpha_tex1 && tex_eval(dsc, m.alpha_tex1 - 1u, ctx).r == 0.0f) return false;
-    if (any_hit && m.shadow_alpha_tex1 && tex_eval(dsc, m.shadow_alpha_tex1 - 1u, ctx).r == 0.0f) return false;
+    // (no differentials here: the evaluator's NODIFF form, without the filtered look-ups' code)
+    if (m.alpha_tex1 && tex_eval<false, true>(dsc, m.alpha_tex1 - 1u, ctx).r == 0.0f) return false;
+    if (any_hit && m.shadow_alpha_tex1 && tex_eval<false, true>(dsc, m.shadow_alpha_tex1 - 1u, ctx).r == 0.0f) return false;
     return true;
 }
 

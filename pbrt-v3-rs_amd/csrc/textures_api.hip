@@ -440,18 +440,25 @@ int pbrt_hip_add_material_matte_tex(PbrtHipScene* s, uint32_t kd_tex, float sigm
 }
 // ---- texture probes (test aids: the device's texture evaluation on explicit inputs, and the pyramid the host built) ----------------
 namespace ph {
-__global__ void texture_eval_kernel(DeviceScene sc, uint32_t tex, uint32_t n, const float* in, float* out) {
+__global__ void texture_eval_kernel(DeviceScene sc, uint32_t tex, uint32_t n, const float* in, float* out, uint32_t nodiff) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* q = in + 15 * (size_t)i;
     TexCtx c; c.uv = mk2(q[0], q[1]); c.dudx = q[2]; c.dvdx = q[3]; c.dudy = q[4]; c.dvdy = q[5];
     c.p = mk3(q[6], q[7], q[8]); c.dpdx = mk3(q[9], q[10], q[11]); c.dpdy = mk3(q[12], q[13], q[14]);
-    const spec v = tex_eval(sc.self, tex, c);
+    const spec v = nodiff ? tex_eval<false, true>(sc.self, tex, c) : tex_eval<false, false>(sc.self, tex, c);
     out[3 * i] = v.r; out[3 * i + 1] = v.g; out[3 * i + 2] = v.b;
 }
 }  // namespace ph
+static int texture_eval_batch(PbrtHipScene* s, uint32_t tex, uint64_t n, const float* uv_and_derivatives, float* out_rgb, bool nodiff);
 int pbrt_hip_texture_eval_batch(PbrtHipScene* s, uint32_t tex, uint64_t n, const float* uv_and_derivatives, float* out_rgb) {
-    return ph_guard(s, "pbrt_hip_texture_eval_batch", [&]() -> int {
+    return ph_guard(s, "pbrt_hip_texture_eval_batch", [&]() -> int { return texture_eval_batch(s, tex, n, uv_and_derivatives, out_rgb, false); });
+}
+int pbrt_hip_texture_eval_batch_nodiff(PbrtHipScene* s, uint32_t tex, uint64_t n, const float* uv_and_derivatives, float* out_rgb) {
+    return ph_guard(s, "pbrt_hip_texture_eval_batch_nodiff", [&]() -> int { return texture_eval_batch(s, tex, n, uv_and_derivatives, out_rgb, true); });
+}
+static int texture_eval_batch(PbrtHipScene* s, uint32_t tex, uint64_t n, const float* uv_and_derivatives, float* out_rgb, bool nodiff) {
+    {
     if (!s || (n && (!uv_and_derivatives || !out_rgb))) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "texture_eval_batch: null argument");
     if (tex >= s->textures.size()) return set_err(s, PBRT_HIP_ERR_INVALID_ARG, "texture_eval_batch: unknown texture");
     if (n == 0) return PBRT_HIP_OK;
@@ -463,12 +470,12 @@ int pbrt_hip_texture_eval_batch(PbrtHipScene* s, uint32_t tex, uint64_t n, const
     if ((rc = ensure_buf(s, s->d_rays_tmp, n * 60))) return rc;
     if ((rc = ensure_buf(s, s->d_out_tmp, n * 12))) return rc;
     PH_CHECK(s, hipMemcpyAsync(s->d_rays_tmp.p, uv_and_derivatives, n * 60, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(ph::texture_eval_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s->stream, s->ds, tex, (uint32_t)n, (const float*)s->d_rays_tmp.p, (float*)s->d_out_tmp.p);
+    hipLaunchKernelGGL(ph::texture_eval_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s->stream, s->ds, tex, (uint32_t)n, (const float*)s->d_rays_tmp.p, (float*)s->d_out_tmp.p, nodiff ? 1u : 0u);
     PH_CHECK(s, hipGetLastError());
     PH_CHECK(s, hipMemcpyAsync(out_rgb, s->d_out_tmp.p, n * 12, hipMemcpyDeviceToHost, s->stream));
     PH_CHECK(s, hipStreamSynchronize(s->stream));
     return PBRT_HIP_OK;
-    });
+    }
 }
 int pbrt_hip_mipmap_levels(PbrtHipScene* s, uint32_t mip, int* out_levels, int* out_wh) {
     return ph_guard(s, "pbrt_hip_mipmap_levels", [&]() -> int {

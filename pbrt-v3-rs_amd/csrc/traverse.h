@@ -581,7 +581,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                                 if (ah) occluded = true;
                                 else {
                                     r.t_max = t; hit_tri = ti;
-                                    if (!LEAN) { hit_prim = __float_as_uint(a.w); hb0 = b0; hb1 = b1; hb2 = b2; hit_cls = (flags >> PH_TRI_CLASS_SHIFT) & 7u; }
+                                    if (!LEAN) { hit_prim = __float_as_uint(a.w); hb0 = b0; hb1 = b1; hb2 = b2; hit_cls = (flags >> PH_TRI_CLASS_SHIFT) & PH_TRI_KEY_MASK; }
                                     if (INST) { hit_inst = in_inst & 0x3FFFFFFFu; inst_hit = true; }
                                 }
                             }
@@ -619,11 +619,11 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         const float4* tp = reinterpret_cast<const float4*>(sc.tris + hit_tri);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
                         tri_bary(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), hb0, hb1, hb2);
-                        hit_prim = __float_as_uint(a.w); hit_cls = (__float_as_uint(b.w) >> PH_TRI_CLASS_SHIFT) & 7u;
+                        hit_prim = __float_as_uint(a.w); hit_cls = (__float_as_uint(b.w) >> PH_TRI_CLASS_SHIFT) & PH_TRI_KEY_MASK;
                     } else { hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hit_cls = 0u; hb0 = hb1 = hb2 = 0.0f; }
                 }
                 PH_STREAM_STORE(make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1), hp);
-                PH_STREAM_STORE(make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), __uint_as_float(hit_cls)), hp + 1);  // pad[0] = the hit's TriRec, pad[1] = instance + 1, pad[2] = material class
+                PH_STREAM_STORE(make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), __uint_as_float(hit_cls)), hp + 1);  // pad[0] = the hit's TriRec, pad[1] = instance + 1, pad[2] = material class | material id << 3
             }
             has_ray = false;
             if (COUNT) c_rays[(MIXED && ah) ? 1 : 0]++;

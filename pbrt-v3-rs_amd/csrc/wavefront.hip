@@ -22,6 +22,7 @@
 #include "bsdf_general.h"
 #include "texture.h"
 #include "raysort.h"
+#include "matsort.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -73,6 +74,8 @@ struct WfParams {
     uint32_t any_rt;     // some TranslucentMaterial decides per hit whether it has a BSDF at all (MaterialRec::rt_mode): the texture pass runs first and says so in TexOut::bumped
     // ray binning between rounds (raysort.h): the bin key of every ray the shade pass emits, next to the ray
     RaySortGrid sort_grid; uint32_t* keys_cl; uint32_t* keys_sh;
+    // shade-side work queues (matsort.h): this round's list positions grouped by material key, and the bins' starts; null = the texture / light-distribution / shade passes walk the list in queue order
+    const uint32_t* m_order; const uint32_t* m_bins;
 };
 
 PH_DEV uint32_t wave_alloc(uint32_t* ctr, bool want) {
@@ -153,7 +156,10 @@ __global__ __launch_bounds__(256) void raygen_kernel(DeviceScene sc, WfParams w)
 __global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfParams w, int it) {
     const uint32_t n_live = w.ctr[it].n_live;
     const SpatialRec& sr = w.spatial;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_live; i += gridDim.x * blockDim.x) {
+    // (with the work queues: only the paths in front of the "emission only" and "no new vertex" bins have a vertex that samples a light)
+    const uint32_t n_work = w.m_order ? w.m_bins[sc.ms_key_emit] : n_live;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_work; j += gridDim.x * blockDim.x) {
+        const uint32_t i = w.m_order ? w.m_order[j] : j;   // the path's position in the round's list; the texture pass's record of it is at j
         const uint4 idx4 = w.s_idx[it & 1][i];
         const uint32_t flags = idx4.w & 0xffu, bounces = (idx4.w >> 8) & 0xffu;
         if (!(flags & F_EXT) || (int)bounces >= w.max_depth) continue;
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfPar
         const float4* tp = reinterpret_cast<const float4*>(sc.tris + __float_as_uint(h1.y));
         const float4 a = tp[0], b = tp[1], c = tp[2];
         // ... and so is a hit for which this round's texture pass found no BSDF (a TranslucentMaterial whose reflect and transmit are black there)
-        if (w.any_rt && sc.materials[sc.meshes[__float_as_uint(c.w)].material].rt_mode && (w.tex_out[i].bumped & PH_TEXOUT_NULL_BSDF)) continue;
+        if (w.any_rt && sc.materials[sc.meshes[__float_as_uint(c.w)].material].rt_mode && (w.tex_out[j].bumped & PH_TEXOUT_NULL_BSDF)) continue;
         f3 p = h0.z * mk3(a.x, a.y, a.z) + h0.w * mk3(b.x, b.y, b.z) + h1.x * mk3(c.x, c.y, c.z);  // = SurfHit::p (make_surface_hit_tv)
         const uint32_t inst = __float_as_uint(h1.z);
         if (inst != 0u && !(sc.instances[inst - 1u].flags & PH_INST_IDENTITY)) {  // world-space p of an instanced hit (make_surface_hit_any)
@@ -183,14 +189,19 @@ __global__ __launch_bounds__(256) void spatial_mark_kernel(DeviceScene sc, WfPar
 // ---------------------------------------------------------------------------------------------------------------------------
 // Texture pass: one thread per live path whose new vertex lies on a material with per-hit textures or a bump map.  It rebuilds the surface
 // interaction, the texture context (uv, dp/du, dp/dv, camera-ray differentials), runs Material::bump and evaluates the textured lobe colours,
-// and leaves the results in tex_out[pid] for the shade pass.  A pass of its own so that the evaluator's registers and calls stay out of the shade kernel.
-// SIMPLE: the scene's textures are constants, image maps, scale and mix only: the evaluator is compiled without the procedural classes and fits more waves
-template <bool SIMPLE, int WAVES = 3>
+// and leaves the results in tex_out for the shade pass.  A pass of its own so that the evaluator's registers and calls stay out of the shade kernel.
+// With the work queues (matsort.h, round 4) its work is the PREFIX of the sorted list — order[0 .. bins[ms_tex_keys]) — in material order: full waves, one material's
+// texture programs per wave (round 3 walked the whole live list and `continue`d past three paths in four on configs[4]); record j of tex_out belongs to order[j].
+// SIMPLE: the scene's textures are constants, image maps, scale and mix only: the evaluator is compiled without the procedural classes and fits more waves.
+// CAMERA: round 0, whose rays are the camera rays — the only ones that carry differentials (path.rs:107, sampler_integrator.rs:358); every later round's vertices are
+//   evaluated without (NODIFF evaluator, texture.h: no EWA / trilinear code, no differentials of the camera ray) — a leaner kernel for five rounds of six.
+template <bool SIMPLE, bool CAMERA, int WAVES = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void texture_kernel(DeviceScene sc, WfParams w, int it) {
-    const uint32_t n_live = w.ctr[it].n_live;
+    const uint32_t n_work = w.m_order ? w.m_bins[sc.ms_tex_keys] : w.ctr[it].n_live;
     const uint32_t* live_in = w.live[it & 1];
     const RayIn* rays_in = w.rays_cl[it & 1];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_live; i += gridDim.x * blockDim.x) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_work; j += gridDim.x * blockDim.x) {
+        const uint32_t i = w.m_order ? w.m_order[j] : j;   // the path's position in the round's list
         const uint4 idx4 = w.s_idx[it & 1][i];
         const uint32_t flags = idx4.w & 0xffu, bounces = (idx4.w >> 8) & 0xffu;
         if (!(flags & F_EXT) || (int)bounces >= w.max_depth) continue;
@@ -204,9 +215,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
         const SurfHit si = make_surface_hit_any(sc, rd, ray.time, __float_as_uint(h1.y), __float_as_uint(h1.z), h0.z, h0.w, h1.x, m);
         const MaterialRec& mr = sc.materials[m.material];
         if (mr.none || !(mr.textured || mr.bump_tex1)) continue;
-        const uint32_t camera_ray = (bounces == 0u && !(flags & F_NODIFF)) ? 1u : 0u;  // only camera rays carry differentials
+        const uint32_t camera_ray = (CAMERA && bounces == 0u && !(flags & F_NODIFF)) ? 1u : 0u;  // only camera rays carry differentials
         f2 p_film = mk2(0.0f, 0.0f), lens = mk2(0.0f, 0.0f);
-        if (camera_ray) {
+        if (CAMERA && camera_ray) {
             const uint32_t pid = live_in[i];
             const uint32_t ppix = pid / w.chunk_spp;
             const size_t gsi = (size_t)(w.s0 + (pid - ppix * w.chunk_spp)) * w.n_px + ppix;
@@ -222,15 +233,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
             BumpIn bi; bi.tex = mr.bump_tex1 - 1u; bi.tri_index = __float_as_uint(h1.y); bi.inst = __float_as_uint(h1.z); bi.bary = mk3(h0.z, h0.w, h1.x);
             bi.p = si.p; bi.n = si.n; bi.ns = si.ns; bi.dpdu_s = si.dpdu_s; bi.c = ctx;
             BumpOut bo;
-            hit_bump<SIMPLE>(sc.self, &bi, &bo);
+            hit_bump<SIMPLE, !CAMERA>(sc.self, &bi, &bo);
             out.ns[0] = bo.ns.x; out.ns[1] = bo.ns.y; out.ns[2] = bo.ns.z; out.dpdu_s[0] = bo.dpdu_s.x; out.dpdu_s[1] = bo.dpdu_s.y; out.dpdu_s[2] = bo.dpdu_s.z;
             out.bumped = 1u;
         }
         for (int k = 0; k < PH_HIT_COLS; k++) out.col[k][0] = out.col[k][1] = out.col[k][2] = out.col[k][3] = 0.0f;
-        if (mr.textured) eval_lobe_colours<SIMPLE>(sc.self, mr, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out);
+        if (mr.textured) eval_lobe_colours<SIMPLE, !CAMERA>(sc.self, mr, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out);
 
         // only what the shade pass reads for this material: the two header quads if it needs them, then the colour slots in use (a matte with an image map: 16 of the 128 bytes)
-        float4* dst = reinterpret_cast<float4*>(w.tex_out + i);   // by position in this round's list: the shade pass reads it from there
+        float4* dst = reinterpret_cast<float4*>(w.tex_out + j);   // by position in the round's (sorted) walk: the shade pass's thread j reads it from there
         const float4* src = reinterpret_cast<const float4*>(&out);
         if (mr.tex_hdr) { dst[0] = src[0]; dst[1] = src[1]; }
         for (uint32_t k = 0; k < mr.tex_cols; k++) dst[2 + k] = src[2 + k];
@@ -290,7 +301,6 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
     __shared__ uint32_t q_base[3];
     __shared__ HaltonLds halton_lds;
     __shared__ float s_u[8][PH_SHADE_BLOCK];  // the (up to) 8 sampler dimensions a vertex can consume, drawn by ONE loop
-    __shared__ uint32_t sort_cnt[9], sort_pid[GEN ? PH_SHADE_BLOCK : 1];   // GEN: block-local material sorting
     const uint32_t n_live = w.ctr[it].n_live;
     const HaltonLds* hl = nullptr;
     if (w.sp.kind == 0 && blockIdx.x * blockDim.x < n_live) { halton_lds_fill(&halton_lds, sc); hl = &halton_lds; }
@@ -316,35 +326,11 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
         float pick_pdf = 0.0f, eta_scale = 1.0f;
         bool want_ext = false, want_mis = false, want_sh = false;
 
-        if (GEN) {
-            // ---- block-local material sorting: the 256 paths of this round are regrouped by the material class of the surface they hit
-            // (class = distinct lobe-kind signature, recorded by the traversal kernel in HitOut.pad[2]), so that a wave walks one kind of
-            // lobe list.  Paths with nothing to shade (miss / only pending shadow + MIS results) form the last group.  Which thread
-            // handles which path is free: paths are independent and the film is accumulated by sample index.
-            uint32_t cls = 8u;
-            const uint32_t cand = i;   // positions of this round's list are sorted, not path ids: the state is addressed by position
-            if (active) {
-                const uint4 c4 = w.s_idx[it & 1][i];
-                cls = 7u;
-                if (c4.w & F_EXT) {
-                    const float4 ch = reinterpret_cast<const float4*>(w.hits_cl + c4.x)[1];
-                    const float4 c0 = reinterpret_cast<const float4*>(w.hits_cl + c4.x)[0];
-                    if (__float_as_uint(c0.y) != 0xFFFFFFFFu) cls = __float_as_uint(ch.w) & 7u;
-                    if (cls == 7u) cls = 6u;
-                }
-            }
-            __syncthreads();
-            if (tid < 9) sort_cnt[tid] = 0u;
-            __syncthreads();
-            const uint32_t my_rank = atomicAdd(&sort_cnt[cls], 1u);   // LDS atomic; order inside a class is irrelevant
-            __syncthreads();
-            uint32_t off = 0;
-            for (uint32_t k = 0; k < cls; k++) off += sort_cnt[k];
-            sort_pid[off + my_rank] = cand;
-            __syncthreads();
-        }
         if (active) {
-            const uint32_t pos = GEN ? sort_pid[tid] : i;   // this thread's path: its position in the round's list
+            // this thread's path: its position in the round's list.  With the work queues (matsort.h) the walk goes through `order`: a wave holds paths of ONE material (its
+            // lobe list, texture slots and light-sampling branches are then the wave's), paths with nothing to shade sit at the end.  Which thread handles which path is free:
+            // paths are independent and the film is accumulated by sample index.  (Rounds 1 - 3 sorted the 256 paths of a block by material class in LDS: ~9 paths per class.)
+            const uint32_t pos = w.m_order ? w.m_order[i] : i;
             pid = live_in[pos];
             const uint4 idx4 = w.s_idx[it & 1][pos];
             flags = idx4.w & 0xffu; bounces = (idx4.w >> 8) & 0xffu; dim = idx4.w >> 16;
@@ -408,7 +394,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         else L = L + beta * mks1(0.0f);
                     }
                     bool no_bsdf = sc.materials[m.material].none != 0u;
-                    if (TEX && !no_bsdf && sc.materials[m.material].rt_mode) no_bsdf = (w.tex_out[pos].bumped & PH_TEXOUT_NULL_BSDF) != 0u;   // translucent.rs:72-74, decided by this hit's textures
+                    if (TEX && !no_bsdf && sc.materials[m.material].rt_mode) no_bsdf = (w.tex_out[i].bumped & PH_TEXOUT_NULL_BSDF) != 0u;   // translucent.rs:72-74, decided by this hit's textures
                     if ((int)bounces < w.max_depth && no_bsdf) {
                         // null BSDF (Material "none"): `*ray = isect.spawn_ray(&ray.d); continue;` — bounces, the sampler dimension and the
                         // specular flag stay as they are (path.rs:142-150)
@@ -420,11 +406,11 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         const uint32_t ppix = pid / w.chunk_spp;
                         const int2 xy = w.px_xy[ppix];
                         bool tex_hit = false;
-                        if (TEX) {  // the texture pass (texture_kernel) left this vertex's bumped frame and textured colours in tex_out[pid]
+                        if (TEX) {  // the texture pass (texture_kernel) left this vertex's bumped frame and textured colours in tex_out[i] (i = this thread's place in the round's walk)
                             const MaterialRec& mr = sc.materials[m.material];
                             tex_hit = mr.textured != 0u || mr.bump_tex1 != 0u;
                             if (tex_hit && mr.bump_tex1) {  // Material::bump: the BSDF is made on the bumped frame
-                                const float4* tp = reinterpret_cast<const float4*>(w.tex_out + pos);
+                                const float4* tp = reinterpret_cast<const float4*>(w.tex_out + i);
                                 const float4 f0 = tp[0], f1 = tp[1];
                                 si.ns = mk3(f0.x, f0.y, f0.z); si.dpdu_s = mk3(f1.x, f1.y, f1.z);
                             }
@@ -433,7 +419,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         if (TEX && tex_hit) {
                             const MaterialRec& mr = sc.materials[m.material];
                             if (mr.textured)
-                                BO::apply_textures(bsdf, w.tex_out + pos, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr, mr);
+                                BO::apply_textures(bsdf, w.tex_out + i, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr, mr);
                         }
                         SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid - ppix * w.chunk_spp), dim, hl);
                         // Draw the next 8 dimensions in one (not unrolled) loop: light pick 1D, u_light 2D, u_scattering 2D, BSDF 2D,
@@ -761,6 +747,7 @@ struct Wavefront {
     DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_sprev, d_recL, d_recpy, d_rounded, d_tilebuf, d_xyz, d_w;
     DevBuf d_vox_slot, d_sp_pool, d_sp_list, d_sp_ctr, d_sp_halton;  // SpatialLightDistribution tables (spatial.h)
     DevBuf d_order, d_sort_bins, d_heads, d_keys_cl, d_keys_sh;  // ray binning between rounds (raysort.h), per-XCD queue heads
+    DevBuf d_morder, d_mkeys, d_mbins;  // shade-side work queues (matsort.h)
     size_t n_vox = 0;   // voxels of the last spatial render's table (d_vox_slot)
     std::vector<hipEvent_t> events;
 };
@@ -772,7 +759,7 @@ void free_wavefront(PbrtHipScene* s) {
     if (!w) return;
     for (DevBuf* b : {&w->d_tiles, &w->d_px, &w->d_rays_cl[0], &w->d_rays_cl[1], &w->d_hits, &w->d_rays_sh, &w->d_occ, &w->d_live[0], &w->d_live[1], &w->d_ctr,
                       &w->d_stats, &w->d_cam, &w->d_hit_lobes, &w->d_tex_out, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_sprev, &w->d_rounded, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
-                      &w->d_vox_slot, &w->d_sp_pool, &w->d_sp_list, &w->d_sp_ctr, &w->d_sp_halton, &w->d_order, &w->d_sort_bins, &w->d_heads, &w->d_keys_cl, &w->d_keys_sh})
+                      &w->d_vox_slot, &w->d_sp_pool, &w->d_sp_list, &w->d_sp_ctr, &w->d_sp_halton, &w->d_order, &w->d_sort_bins, &w->d_heads, &w->d_keys_cl, &w->d_keys_sh, &w->d_morder, &w->d_mkeys, &w->d_mbins})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : w->events) (void)hipEventDestroy(e);
     delete w;
@@ -929,10 +916,11 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     // large chunks bin better (more rays per origin cell and round) and pay fewer launch tails — configs[2] 913 -> 878 ms per frame, configs[3] 934 -> 898 ms against the
     // 32 Mi of round 1 (gpurun r02aa; 256 Mi, the whole frame at once, adds nothing: 875 / 899 ms).  At most 30 % of the device's memory goes to one chunk.
     const size_t per_path = 2 * 2 * sizeof(ph::RayIn) + 2 * sizeof(ph::HitOut) + sizeof(ph::RayIn) + 1 + 2 * 4 + 6 * 2 * 16 + 2 * 4   // ray / hit queues, live lists, path state (two buffers)
-                            + 3 * 4 + 3 * 4 + (s->textured_materials ? sizeof(TexOut) : 0);                                               // + bin keys and order + the texture pass's records
+                            + 3 * 4 + 3 * 4 + (s->textured_materials ? sizeof(TexOut) : 0)                                                // + bin keys and order + the texture pass's records
+                            + 4 + 2;                                                                                                       // + the shade-side work queues' order and keys
     // everything in this context that grows with the chunk, as allocated now: a chunk may reuse it
     auto chunk_bufs = [&]() { return std::vector<DevBuf*>{&w.d_rays_cl[0], &w.d_rays_cl[1], &w.d_hits, &w.d_rays_sh, &w.d_occ, &w.d_live[0], &w.d_live[1], &w.d_sL, &w.d_sbeta, &w.d_sA, &w.d_sf2,
-                                                         &w.d_sbold, &w.d_sidx, &w.d_sprev, &w.d_order, &w.d_keys_cl, &w.d_keys_sh, &w.d_tex_out}; };
+                                                         &w.d_sbold, &w.d_sidx, &w.d_sprev, &w.d_order, &w.d_keys_cl, &w.d_keys_sh, &w.d_tex_out, &w.d_morder, &w.d_mkeys}; };
     size_t max_paths = 128u << 20;
     {
         size_t free_b = 0, total_b = 0;
@@ -953,6 +941,10 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     const int kMaxNullSkips = 1024;
     const int n_iter_cap = s->has_none_material ? n_iter + kMaxNullSkips : n_iter;
     static const int sort_mode = []() { const char* e = std::getenv("PBRT_HIP_SORT_RAYS"); int v = e ? std::atoi(e) : 1; return (v < 0 || v > 3) ? 1 : v; }();
+    // shade-side work queues (matsort.h): scenes with anything but constant matte — the general-BSDF kernel's branches and the texture pass's programs depend on the material.
+    // PBRT_HIP_MATERIAL_QUEUES=0 walks the list in queue order as rounds 1 - 3 did (A/B aid; same film)
+    static const bool mq_env = []() { const char* e = std::getenv("PBRT_HIP_MATERIAL_QUEUES"); return !(e && std::atoi(e) == 0); }();
+    const bool mat_queues = mq_env && (s->general_materials || s->textured_materials);
     if ((rc = ensure_buf(s, w.d_ctr, (size_t)(n_iter_cap + 2) * sizeof(ph::IterCounters)))) return rc;
     if ((rc = ensure_buf(s, w.d_stats, sizeof(ph::DevStats)))) return rc;
     if ((rc = ensure_buf(s, w.d_recL, (size_t)n_px * spp * 16))) return rc;
@@ -977,13 +969,23 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
             if ((r = ensure_buf(s, w.d_keys_sh, Bc * 4))) return r;
         }
         if (s->textured_materials && (r = ensure_buf(s, w.d_tex_out, Bc * sizeof(TexOut)))) return r;
+        if (mat_queues) {
+            if ((r = ensure_buf(s, w.d_morder, Bc * 4))) return r;
+            if ((r = ensure_buf(s, w.d_mkeys, Bc * 2))) return r;
+        }
         return PBRT_HIP_OK;
     };
     // the estimate above can be wrong (fragmentation, another context allocating meanwhile): on hipErrorOutOfMemory the chunk is halved and tried again before the call gives up
+    // (test hook: PBRT_HIP_TEST_CHUNK_OOM=k makes the first k attempts of every render call fail as an out-of-memory allocation would)
+    int forced_oom = 0;
+    if (const char* e = std::getenv("PBRT_HIP_TEST_CHUNK_OOM")) forced_oom = std::max(0, std::atoi(e));
+    bool retried = false;
     for (;;) {
         if ((size_t)n_px * chunk_spp >= 0x7FFF0000ull) return set_err(s, PBRT_HIP_ERR_UNSUPPORTED, "render: tile range too large for one rank; use more tile_parts");
-        rc = alloc_chunk((size_t)n_px * chunk_spp);
-        if (rc == PBRT_HIP_OK) break;
+        if (forced_oom > 0) { forced_oom--; rc = set_err(s, PBRT_HIP_ERR_OOM, "render: out of device memory (forced by PBRT_HIP_TEST_CHUNK_OOM)"); }
+        else rc = alloc_chunk((size_t)n_px * chunk_spp);
+        if (rc == PBRT_HIP_OK) { if (retried) s->err.clear(); break; }   // a retry that succeeded leaves no error text behind
+        retried = true;
         if (rc != PBRT_HIP_ERR_OOM || chunk_spp == 1) return rc;
         for (DevBuf* b : chunk_bufs()) if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->bytes = 0; }
         chunk_spp = (chunk_spp + 1) / 2;
@@ -1008,6 +1010,14 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
         }
     }
     if (n_heads > 1 && (rc = ensure_buf(s, w.d_heads, (size_t)(n_iter_cap + 2) * 8 * 64))) return rc;
+    ph::MatSortParams msp{};
+    if (mat_queues) {
+        if ((rc = ensure_buf(s, w.d_mbins, (size_t)(2 * PH_MS_BINS + 1) * 4))) return rc;
+        msp.max_depth = max_depth; msp.mat_key = s->ds.mat_key; msp.key_emit = s->ds.ms_key_emit; msp.key_idle = s->ds.ms_key_idle;
+        msp.tris = s->ds.tris; msp.meshes = s->ds.meshes; msp.hits = (const ph::HitOut*)w.d_hits.p;
+        msp.keys = (uint16_t*)w.d_mkeys.p; msp.order = (uint32_t*)w.d_morder.p;
+        msp.bin_start = (uint32_t*)w.d_mbins.p; msp.bin_cursor = msp.bin_start + PH_MS_BINS + 1;
+    }
 
     ph::WfParams wp{};
     wp.cam = s->cam; wp.sp = s->sampler;
@@ -1033,6 +1043,7 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     }
     wp.rec_L = (float4*)w.d_recL.p; wp.rec_py = (float*)w.d_recpy.p; wp.px_rounded = (uint8_t*)w.d_rounded.p;
     wp.sort_grid = sort_grid; wp.keys_cl = (uint32_t*)w.d_keys_cl.p; wp.keys_sh = (uint32_t*)w.d_keys_sh.p;
+    wp.m_order = mat_queues ? (const uint32_t*)w.d_morder.p : nullptr; wp.m_bins = mat_queues ? (const uint32_t*)w.d_mbins.p : nullptr;
 
     if (spatial) { if ((rc = setup_spatial(s, wp.spatial))) return rc; }
     PH_CHECK(s, hipMemsetAsync(w.d_stats.p, 0, sizeof(ph::DevStats), s->stream));
@@ -1109,19 +1120,33 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
                     if ((rc = timed(1, [&]() { launch_traverse_kernel(s, 1, s->trav_blocks, tp); }))) return rc;
                 }
             }
+            // the shade side's work queues: this round's list regrouped by what has to be done for each path (matsort.h)
+            if (mat_queues) {
+                msp.s_idx = wp.s_idx[it & 1]; msp.n_live = &c->n_live;
+                if ((rc = timed(2, [&]() {
+                        (void)hipMemsetAsync(msp.bin_start, 0, (PH_MS_BINS + 1) * 4, s->stream);
+                        hipLaunchKernelGGL(ph::matsort_hist_kernel, dim3(sort_blocks), dim3(PH_MS_BLOCK), 0, s->stream, msp);
+                        hipLaunchKernelGGL(ph::matsort_scan_kernel, dim3(1), dim3(PH_MS_BINS), 0, s->stream, msp);
+                        hipLaunchKernelGGL(ph::matsort_scatter_kernel, dim3(sort_blocks), dim3(PH_MS_BLOCK), 0, s->stream, msp);
+                    }))) return rc;
+            }
             // the texture pass first: besides colours and bumped frames it finds the hits that have no BSDF at all (TexOut::bumped, PH_TEXOUT_NULL_BSDF), which the
             // light-distribution pass must skip as the reference's `continue` does (path.rs:142-157)
             if (s->textured_materials) {
                 if ((rc = timed(2, [&]() {
-                        static const int tex_waves = []() { const char* e = std::getenv("PBRT_HIP_TEX_WAVES"); const int v = e ? std::atoi(e) : PH_TEX_SIMPLE_WAVES; return (v < 2 || v > 4) ? PH_TEX_SIMPLE_WAVES : v; }();
-                        // the evaluator with the procedural classes: 2 waves per SIMD (246 VGPRs, no spills) against 3 (168 VGPRs, 317 spilled registers, 592 B of scratch per thread —
-                        // the pass then writes 3.2 TB of scratch per configs[4] frame): configs[4] at 64 spp 989 -> 851 ms of shade-side time per frame, same film (gpurun r03m)
-                        static const int full_waves = []() { const char* e = std::getenv("PBRT_HIP_TEX_FULL_WAVES"); const int v = e ? std::atoi(e) : 2; return (v < 2 || v > 3) ? 2 : v; }();
-                        if (!s->simple_textures && full_waves == 2) hipLaunchKernelGGL((ph::texture_kernel<false, 2>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
-                        else if (!s->simple_textures || tex_waves == 0) hipLaunchKernelGGL((ph::texture_kernel<false, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
-                        else if (tex_waves == 2) hipLaunchKernelGGL((ph::texture_kernel<true, 2>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
-                        else if (tex_waves == 3) hipLaunchKernelGGL((ph::texture_kernel<true, 3>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
-                        else hipLaunchKernelGGL((ph::texture_kernel<true, 4>), dim3(shade_blocks), dim3(256), 0, s->stream, s->ds, wp, it);
+                        // waves per SIMD the variants are compiled for (PBRT_HIP_TEX_WAVES = "<camera round><later rounds>", e.g. 23; A/B aid)
+                        static const int tw = []() { const char* e = std::getenv("PBRT_HIP_TEX_WAVES"); const int v = e ? std::atoi(e) : 0; return (v / 10 >= 2 && v / 10 <= 3 && v % 10 >= 2 && v % 10 <= 4) ? v : 0; }();
+                        const dim3 g(shade_blocks), b(256);
+                        if (it == 0) {   // camera rays: differentials, filtered look-ups
+                            if (s->simple_textures) hipLaunchKernelGGL((ph::texture_kernel<true, true, 3>), g, b, 0, s->stream, s->ds, wp, it);
+                            else if (tw / 10 == 3) hipLaunchKernelGGL((ph::texture_kernel<false, true, 3>), g, b, 0, s->stream, s->ds, wp, it);
+                            else hipLaunchKernelGGL((ph::texture_kernel<false, true, 2>), g, b, 0, s->stream, s->ds, wp, it);
+                        } else {
+                            if (s->simple_textures) { if (tw % 10 == 3) hipLaunchKernelGGL((ph::texture_kernel<true, false, 3>), g, b, 0, s->stream, s->ds, wp, it); else hipLaunchKernelGGL((ph::texture_kernel<true, false, 4>), g, b, 0, s->stream, s->ds, wp, it); }
+                            else if (tw % 10 == 2) hipLaunchKernelGGL((ph::texture_kernel<false, false, 2>), g, b, 0, s->stream, s->ds, wp, it);
+                            else if (tw % 10 == 4) hipLaunchKernelGGL((ph::texture_kernel<false, false, 4>), g, b, 0, s->stream, s->ds, wp, it);
+                            else hipLaunchKernelGGL((ph::texture_kernel<false, false, 3>), g, b, 0, s->stream, s->ds, wp, it);
+                        }
                     }))) return rc;
             }
             if (spatial && (it < max_depth || s->has_none_material)) {  // vertices reached at bounce == max_depth sample no light (path.rs:136-139)

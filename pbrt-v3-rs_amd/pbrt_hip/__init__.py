@@ -139,6 +139,7 @@ class Binding:
             "set_material_float_texture": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32]),
             "set_last_mesh_alpha_textures": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
             "texture_eval_batch": (C.c_int, [vp, C.c_uint32, C.c_uint64, fp, fp]),
+            "texture_eval_batch_nodiff": (C.c_int, [vp, C.c_uint32, C.c_uint64, fp, fp]),
             "mipmap_levels": (C.c_int, [vp, C.c_uint32, ip, ip]),
             "mipmap_level_texels": (C.c_int, [vp, C.c_uint32, C.c_int, fp]),
             "set_traversal_counting": (C.c_int, [vp, C.c_int]),
@@ -346,6 +347,10 @@ class Scene:
 
     def __exit__(self, *a):
         self.close()
+
+    def last_error(self) -> str:
+        """pbrt_hip_last_error: the text of the handle's last failed call (or a warning a successful call left), "" when there is none."""
+        return (self.b.fn("last_error")(self.h) or b"").decode()
 
     def _chk(self, rc):
         if rc != OK:
@@ -632,6 +637,12 @@ class Scene:
         inp = np.ascontiguousarray(np.concatenate(cols, axis=1), dtype=np.float32)
         out = np.zeros((len(uv), 3), np.float32)
         self._chk(self.b.fn("texture_eval_batch")(self.h, texture, len(uv), _ptr(inp, C.c_float), _ptr(out, C.c_float)))
+        if not inp[:, 2:6].any() and not inp[:, 9:15].any():
+            # contexts without differentials: the renderer evaluates them with the NODIFF form of the evaluator (every ray but a camera ray) — the two must agree bit for bit
+            out2 = np.zeros_like(out)
+            self._chk(self.b.fn("texture_eval_batch_nodiff")(self.h, texture, len(uv), _ptr(inp, C.c_float), _ptr(out2, C.c_float)))
+            if not np.array_equal(out.view(np.uint32), out2.view(np.uint32)):
+                raise AssertionError("texture_eval: the no-differentials evaluator differs from the general one on zero differentials")
         return out
 
     def mipmap_pyramid(self, mipmap):

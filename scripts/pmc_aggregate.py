@@ -64,7 +64,7 @@ if tk:
                                     "mean_l2_read_latency_cycles": round(sq["TCP_TCC_READ_REQ_LATENCY_sum"] / sq["TCP_TCC_READ_REQ_sum"], 1) if sq["TCP_TCC_READ_REQ_sum"] else None,
                                     # the three pipes the kernel loads: GRBM_GUI_ACTIVE sums the 8 XCDs, 32 x it = the chip's CU-cycles = its SIMD-quads
                                     "branch_insts": sq["SQ_INSTS_BRANCH"], "vmem_insts": sq["SQ_INSTS_VMEM_RD"] + sq["SQ_INSTS_VMEM_WR"], "lds_insts": sq["SQ_INSTS_LDS"],
-                                    "l1_accesses": sq["TCP_TOTAL_CACHE_ACCESSES_sum"], "gpu_busy_cycles_sum_over_xcds": sq["GRBM_GUI_ACTIVE"],
+                                    "l1_accesses": sq["TCP_TOTAL_CACHE_ACCESSES_sum"], "tcp_tcc_read_req": sq["TCP_TCC_READ_REQ_sum"], "gpu_busy_cycles_sum_over_xcds": sq["GRBM_GUI_ACTIVE"],
                                     "valu_issue_of_simd_quads": round(sq["SQ_ACTIVE_INST_VALU"] / (32.0 * sq["GRBM_GUI_ACTIVE"]), 4) if sq["GRBM_GUI_ACTIVE"] else None,
                                     "scalar_and_branch_per_cu_cycle": round((sq["SQ_INSTS_SALU"] + sq["SQ_INSTS_BRANCH"]) / (32.0 * sq["GRBM_GUI_ACTIVE"]), 4) if sq["GRBM_GUI_ACTIVE"] else None,
                                     "l1_accesses_per_cu_cycle": round(sq["TCP_TOTAL_CACHE_ACCESSES_sum"] / (32.0 * sq["GRBM_GUI_ACTIVE"]), 4) if sq["GRBM_GUI_ACTIVE"] else None}

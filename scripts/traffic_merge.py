@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Adds (or replaces) one PMC record in profiles/r03_traffic.json.  The record is tied to the library build it was measured on (sha256 of libpbrt_hip.so) and to the tuning
+"""Adds (or replaces) one PMC record in profiles/r04_traffic.json.  The record is tied to the library build it was measured on (sha256 of libpbrt_hip.so) and to the tuning
 environment (PBRT_HIP_* variables): bench.py reports a memory-side roofline fraction only from a record that matches the library it is running.
 usage: scripts/traffic_merge.py <gpurun_out/pmc_TAG/traffic.json> <source label, e.g. profiles/r03_pmc_summary_config2.txt> [waves per SIMD of the traversal kernel]"""
 import hashlib
@@ -8,7 +8,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(ROOT, "profiles", "r03_traffic.json")
+dst = os.path.join(ROOT, "profiles", "r04_traffic.json")
 entry = json.load(open(sys.argv[1]))
 entry["source"] = sys.argv[2]
 sys.path.insert(0, ROOT)

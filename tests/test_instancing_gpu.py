@@ -98,6 +98,45 @@ def test_instance_records_with_and_without_hints(host, device_build, n_inst):
         assert not (c[leaf] & 0x40000000).any()
 
 
+@pytest.mark.parametrize("device_build", [False, True])
+@pytest.mark.parametrize("n_obj_tris", [1, 3])
+def test_forest_without_any_interior_node(host, device_build, n_obj_tris):
+    """ONE instance of a 1- or 3-triangle object and nothing else: with maxnodeprims 4 every tree of the forest is a single leaf, the node array is EMPTY (host builder:
+    `bvh.nodes` has no element, its upload is a null pointer) — and the instance's leaf record must still be filled in at upload (bounds, root, flags, transform).
+    Round-3 ADVICE: the patch was gated on a non-null node pointer and such a scene read through null in the traversal kernel."""
+    P1, _ = host.gen_random_tris(1, 21)
+    # three almost coincident triangles: no split lowers the SAH cost, so the object's aggregate is ONE leaf (sah.rs:340-356)
+    P = np.concatenate([P1 + np.float32(1e-3 * k) for k in range(n_obj_tris)]); idx = np.arange(3 * n_obj_tris, dtype=np.uint32)
+    T = _transforms(host)[0]
+
+    def capture(s):
+        m = s.add_material_matte((0.5, 0.5, 0.5), 0.0)
+        ob = s.object_begin(); s.add_mesh(P, idx, m); s.object_end()
+        s.add_instance(ob, *T)
+        if device_build and not isinstance(s, OracleScene):
+            s.build_accel_device(0, 4)
+        else:
+            s.build_accel(0, 4)
+
+    prod, orc = scenes.build_pair(capture, OracleScene)
+    assert prod.accel_stats()["interior_nodes"] == 0
+    # rays aimed at the instance (world-space copies of the object's triangles) + random ones + the axis-parallel set
+    i2w = np.asarray(T[0], dtype=np.float64).reshape(4, 4)
+    Pw = (np.c_[P.astype(np.float64), np.ones(len(P))] @ i2w.T)[:, :3]
+    rng = np.random.default_rng(3)
+    tgt = Pw[rng.integers(0, len(Pw), 4000)] * 0.6 + Pw[rng.integers(0, len(Pw), 4000)] * 0.4
+    org = rng.uniform(-4, 4, size=(4000, 3))
+    aimed = np.zeros(4000, pbrt_hip.RAY_DTYPE)
+    aimed["o"] = org.astype(np.float32); aimed["t_max"] = np.inf; aimed["d"] = (tgt - org).astype(np.float32)
+    rays = np.concatenate([aimed, scenes.random_rays(8000, 7, bound=3.5), scenes.axis_rays()])
+    got = prod.intersect_batch(rays)
+    want, _ = orc.intersect_batch_stats(rays)
+    eq = scenes.hits_equal(got, want)
+    assert eq.all(), f"{(~eq).sum()} of {len(rays)} differ; first {np.flatnonzero(~eq)[:5]}"
+    assert (want["prim"] != 0xFFFFFFFF).sum() > 100
+    assert np.array_equal(prod.occluded_batch(rays), orc.occluded_batch_stats(rays)[0])
+
+
 def test_instanced_scene_film_bit_exact(host):
     base = _instanced_scene(host, 0, with_normals=True)
 

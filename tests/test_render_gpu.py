@@ -258,6 +258,23 @@ def test_chunked_render_equals_unchunked(host, monkeypatch):
     assert _bits_equal(x1, x2) and _bits_equal(w1, w2)
 
 
+def test_chunk_oom_retry_halves_the_chunk_and_leaves_no_error(host, monkeypatch):
+    """The chunk allocation that runs out of device memory is halved and retried (render_tiles): forced here by the test hook PBRT_HIP_TEST_CHUNK_OOM — two failed attempts, so
+    8 spp are rendered as four chunks of 2 —; the film equals the unchunked one and no error text survives the successful retry (round-3 ADVICE)."""
+    spec = pbrt_hip.SceneSpec(n_tris=1000, seed=15, xres=64, yres=64, spp=8)
+    a = pbrt_hip.Scene(); pbrt_hip.capture_spec(spec, a, host)
+    x1, w1, s1 = a.render_path()
+    monkeypatch.setenv("PBRT_HIP_TEST_CHUNK_OOM", "2")
+    x2, w2, s2 = a.render_path()
+    assert s2.extend_launches == 4 * s1.extend_launches
+    assert _bits_equal(x1, x2) and _bits_equal(w1, w2)
+    assert a.last_error() == ""
+    monkeypatch.setenv("PBRT_HIP_TEST_CHUNK_OOM", "9")   # 8 -> 4 -> 2 -> 1 spp and still failing: the call gives up with ERR_OOM
+    with pytest.raises(pbrt_hip.PbrtHipError) as e:
+        a.render_path()
+    assert e.value.code == pbrt_hip.ERR_OOM
+
+
 def test_unsupported_and_state_errors(host):
     s = pbrt_hip.Scene()
     spec = pbrt_hip.SceneSpec(n_tris=10, xres=16, yres=16, spp=1)
