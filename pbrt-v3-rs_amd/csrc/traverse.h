@@ -374,7 +374,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
     uint32_t hit_prim = 0xFFFFFFFFu, hit_tri = LEAN ? 0xFFFFFFFFu : 0u, hit_cls = 0u;
     float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     bool occluded = false;
-    uint32_t c_nodes[2] = {0, 0}, c_tris[2] = {0, 0}, c_rays[2] = {0, 0}, c_visits = 0;  // COUNT: [0] this launch's first kind, [1] MIXED any-hit
+    uint32_t c_nodes[2] = {0, 0}, c_tris[2] = {0, 0}, c_rays[2] = {0, 0}, c_visits = 0, c_culled = 0;   // c_culled: stack entries dropped at pop time (their box lies behind a hit found since)  // COUNT: [0] this launch's first kind, [1] MIXED any-hit
     // instancing state (INST only)
     float wdx = 0.0f, wdy = 0.0f, wdz = 0.0f;   // the scene-level ray's direction: every instance it meets transforms it anew (RayState does not keep directions)
     uint32_t in_inst = 0;                 // instance number + 1 while inside an object's aggregate
@@ -410,6 +410,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
             if (sp < LDS_DEPTH) { e = lds_stack[sp][tid]; asm volatile("; stack entry from LDS" : "+v"(e.x), "+v"(e.y)); }
             else { e = p.spill[(size_t)(sp - LDS_DEPTH) * p.total_threads + gtid]; asm volatile("; stack entry from the spill region" : "+v"(e.x), "+v"(e.y)); }
             if (COUNT && ah) c_visits++;  // the reference fetches and box-tests every node it pops
+            if (COUNT && !(__uint_as_float(e.y) < r.t_max)) c_culled++;
             cur = (__uint_as_float(e.y) < r.t_max) ? e.x : PH_NEED_POP;
         } else cur = PH_INVALID_REF;
     };
@@ -641,6 +642,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
             atomicAdd(p.counts + 5, (unsigned long long)c_rays[1]);
         }
         atomicAdd(p.counts + 6, (unsigned long long)c_visits);
+        atomicAdd(p.counts + 7, (unsigned long long)c_culled);
     }
 }
 

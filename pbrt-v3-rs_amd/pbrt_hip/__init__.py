@@ -665,7 +665,8 @@ class Scene:
         c = (C.c_uint64 * 8)()
         self._chk(self.b.fn("get_traversal_counts")(self.h, c))
         return {"closest": {"nodes_passed": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2]), "ref_node_visits": int(c[2]) + 2 * int(c[0])},
-                "any_hit": {"nodes_passed": int(c[3]), "tri_tests": int(c[4]), "rays": int(c[5]), "ref_node_visits": int(c[6])}}
+                "any_hit": {"nodes_passed": int(c[3]), "tri_tests": int(c[4]), "rays": int(c[5]), "ref_node_visits": int(c[6])},
+                "culled_pops": int(c[7])}
 
     def devices(self):
         out = np.zeros(64, np.int32)
