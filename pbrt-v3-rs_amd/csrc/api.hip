@@ -318,7 +318,7 @@ int ensure_traversal_workspace(PbrtHipScene* s) {
     int rc;
     if ((rc = ensure_buf(s, s->d_counter, 64))) return rc;
     if ((rc = ensure_buf(s, s->d_error, 64))) return rc;
-    if ((rc = ensure_buf(s, s->d_counts, 64))) return rc;
+    if ((rc = ensure_buf(s, s->d_counts, 64 + 36 * 8))) return rc;
     const int stack_cap = s->inst_recs.empty() ? PH_MAX_STACK : 2 * PH_MAX_STACK;  // with instances the scene-level and object-level entries share one stack
     const int lds_depth = s->inst_recs.empty() ? variant_lds_depth(trav_variant()) : 11;   // (the shallowest LDS stack any instancing kernel is compiled with)
     if ((rc = ensure_buf(s, s->d_spill, (size_t)(stack_cap - lds_depth) * total_threads * sizeof(uint2)))) return rc;
@@ -330,6 +330,9 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
     ph::TravParams p = p_in;
     p.spill = (uint2*)s->d_spill.p; p.total_threads = s->trav_blocks * PH_TRAV_BLOCK; p.error_flag = (uint32_t*)s->d_error.p;
     p.counts = (unsigned long long*)s->d_counts.p;
+#if PH_PHASE_CLOCK
+    p.phase = (unsigned long long*)s->d_counts.p + 8;   // (the measurement build's phase tallies sit behind the eight counters)
+#endif
     { static int bt = -1; if (bt < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_BATCH"); bt = e ? std::atoi(e) : PH_BATCH; if (bt != 64 && bt != 128 && bt != 256 && bt != 512 && bt != 1024) bt = 64; } p.batch = (uint32_t)bt; }
     const dim3 g(blocks), b(PH_TRAV_BLOCK);
 #define PH_LAUNCH3(cnt, lm, rm, ld, ns, inst, wpe, pk)                                                                                                  \
@@ -1446,7 +1449,7 @@ int pbrt_hip_set_traversal_counting(PbrtHipScene* s, int on) {
     PH_CHECK(s, hipSetDevice(s->device));
     int rc;
     if ((rc = ensure_traversal_workspace(s))) return rc;
-    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 64));
+    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 64 + 36 * 8));
     s->count_traversal = on != 0;
     return PBRT_HIP_OK;
     });
@@ -1458,7 +1461,19 @@ int pbrt_hip_get_traversal_counts(PbrtHipScene* s, uint64_t out[8]) {
     PH_CHECK(s, hipSetDevice(s->device));
     PH_CHECK(s, hipStreamSynchronize(s->stream));
     PH_CHECK(s, hipMemcpy(out, s->d_counts.p, 64, hipMemcpyDeviceToHost));
-    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 64));
+#if PH_PHASE_CLOCK
+    {   // measurement build: the waves' phase clocks since the last call, to stderr
+        unsigned long long ph[36];
+        PH_CHECK(s, hipMemcpy(ph, (const char*)s->d_counts.p + 64, sizeof ph, hipMemcpyDeviceToHost));
+        static const char* names[10] = {"refill", "node_steps", "instance_entry", "triangle_test", "alpha_test", "instance_exit", "retire", "whole_loop", "stack_pops", "leaf_step_whole"};
+        for (int k = 0; k < 10; k++)
+            std::fprintf(stderr, "PHASE_CLOCK %-15s cycles %14llu (%5.1f %% of the loop)  executions %12llu  mean active lanes %5.1f\n", names[k], ph[k], ph[7] ? 100.0 * (double)ph[k] / (double)ph[7] : 0.0,
+                         ph[12 + k], ph[12 + k] ? (double)ph[24 + k] / (double)ph[12 + k] : 0.0);
+    }
+    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 64 + 36 * 8));
+#else
+    PH_CHECK(s, hipMemset(s->d_counts.p, 0, 64 + 36 * 8));
+#endif
     return PBRT_HIP_OK;
     });
 }

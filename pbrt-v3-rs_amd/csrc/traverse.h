@@ -72,6 +72,7 @@ struct TravParams {
     // rays in flight (32 CUs x 6 blocks x 256 lanes = 48 k) one L2 serves ONE contiguous stretch of the (binned) queue instead of an eighth of
     // every stretch, and all heads still advance through the queue at the same pace (no per-segment tails).  heads[16 * h]; head_chunk % batch == 0.
     uint32_t* heads; uint32_t n_heads, head_chunk;
+    unsigned long long* phase;   // PH_PHASE_CLOCK builds only (measurement): [phase] cycles, [12 + phase] executions, [24 + phase] active lanes, summed over all waves
 };
 
 struct RayState {
@@ -303,6 +304,26 @@ PH_DEV void tri_bary(const RayState& r, f3 p0, f3 p1, f3 p2, float& b0_out, floa
     b0_out = e0 * inv_det; b1_out = e1 * inv_det; b2_out = e2 * inv_det;
 }
 
+// -DPH_PHASE_CLOCK=1 (a measurement build, never shipped or timed): every wave clocks the phases of its loop with s_memtime and adds cycles, executions and active lanes per phase to
+// TravParams::phase through LDS tallies (no long-lived registers: the kernel's occupancy stays what it is).  Phases: 0 refill (queue pull, ray load, set-up, root test), 1 node steps,
+// 2 instance entry, 3 triangle test, 4 alpha-mask test, 5 instance exit, 6 retire, 7 the whole loop, 8 stack pops, 9 the leaf step as a whole (record fetch + 2 / 3 / 4).
+#ifndef PH_PHASE_CLOCK
+#define PH_PHASE_CLOCK 0
+#endif
+#if PH_PHASE_CLOCK && defined(__HIP_DEVICE_COMPILE__)
+#define PHC_BEGIN(k) const unsigned long long phc_t##k = __builtin_amdgcn_s_memtime()
+#define PHC_END(k)                                                                                                                  \
+    do {                                                                                                                            \
+        const unsigned long long phc_dt = __builtin_amdgcn_s_memtime() - phc_t##k;                                                  \
+        const unsigned long long phc_m = __ballot(true);                                                                            \
+        if ((int)(threadIdx.x & 63u) == __ffsll((long long)phc_m) - 1) {                                                            \
+            atomicAdd(&phc_lds[k], phc_dt); atomicAdd(&phc_lds[12 + k], 1ull); atomicAdd(&phc_lds[24 + k], (unsigned long long)__popcll(phc_m)); \
+        }                                                                                                                           \
+    } while (0)
+#else
+#define PHC_BEGIN(k) do { } while (0)
+#define PHC_END(k) do { } while (0)
+#endif
 // COUNT = true adds per-ray work counters (roofline bookkeeping, never used in a timed run).  For closest-hit rays the
 // reference's "nodes visited" is exactly 1 + 2 * (interior nodes whose box test passed): it fetches and tests both children
 // of every such node (the far one when it is popped), and nothing else.
@@ -352,6 +373,12 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
     // by then the ray's line has left the caches) —, the signs come back from the reciprocals and kz waits in the top bits of in_inst: 9 KB per block instead of 13, so that five blocks of (11-entry stack + this) fit a CU.
     __shared__ float inst_save[INST ? 9 : 1][INST ? PH_TRAV_BLOCK : 1];
     const uint32_t tid = threadIdx.x;
+#if PH_PHASE_CLOCK && defined(__HIP_DEVICE_COMPILE__)
+    __shared__ unsigned long long phc_lds[36];
+    if (tid < 36) phc_lds[tid] = 0ull;
+    __syncthreads();
+#endif
+    PHC_BEGIN(7);
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * PH_TRAV_BLOCK + tid;
     const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -415,12 +442,40 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
         } else cur = PH_INVALID_REF;
     };
 
+    // A finished ray (cur == PH_INVALID_REF outside any instance) is written out when the wave next refills — all the lanes that finished since the last refill together (round 4;
+    // rounds 1 - 3 retired a ray in the pass it finished in: 4.2 lanes per execution of this code on configs[2], 5.4 % of the waves' cycles, scripts/phase_clock.py).  Until then the
+    // lane idles exactly as an empty one does: every test of the loop below excludes cur == PH_INVALID_REF.
+    auto retire = [&]() {
+            PHC_BEGIN(6);
+            if (MIXED && ah) p.out2[ray_index - n_first] = occluded ? 1 : 0;
+            else if (!MIXED && ANYHIT) reinterpret_cast<uint8_t*>(p.out)[ray_index] = occluded ? 1 : 0;
+            else {
+                float4* hp = reinterpret_cast<float4*>(reinterpret_cast<HitOut*>(p.out) + ray_index);
+                if (LEAN) {
+                    if (hit_tri != 0xFFFFFFFFu) {
+                        const float4* tp = reinterpret_cast<const float4*>(sc.tris + hit_tri);
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        tri_bary(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), hb0, hb1, hb2);
+                        hit_prim = __float_as_uint(a.w); hit_cls = (__float_as_uint(b.w) >> PH_TRI_CLASS_SHIFT) & PH_TRI_KEY_MASK;
+                    } else { hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hit_cls = 0u; hb0 = hb1 = hb2 = 0.0f; }
+                }
+                PH_STREAM_STORE(make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1), hp);
+                PH_STREAM_STORE(make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), __uint_as_float(hit_cls)), hp + 1);  // pad[0] = the hit's TriRec, pad[1] = instance + 1, pad[2] = material class | material id << 3
+            }
+            has_ray = false;
+            if (COUNT) c_rays[(MIXED && ah) ? 1 : 0]++;
+            PHC_END(6);
+    };
+
     for (;;) {
         // ---- refill idle lanes from the wave's batch; grab a new batch with one atomic when it runs dry ---------------------------
         {
-            const uint64_t idle = __ballot(!has_ray);
+            PHC_BEGIN(0);
+            const bool finished = has_ray && cur == PH_INVALID_REF && !(INST && in_inst);
+            const uint64_t idle = __ballot(!has_ray || finished);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (n_idle >= (uint32_t)REFILL_MIN || n_idle == 64u || (n_idle && __ballot(has_ray && cur != PH_INVALID_REF) == 0ull)) {
+            if (n_idle >= (uint32_t)REFILL_MIN || n_idle == 64u || (n_idle && __ballot(has_ray && !finished) == 0ull)) {
+                if (finished) retire();
                 if (batch_next == batch_end && !exhausted) {
                     if (p.n_heads > 1u) {  // one attempt per pass of the outer loop: a drained head sends the wave to the next one
                         uint32_t b = 0;
@@ -468,6 +523,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                     }
                     batch_next += (n_idle < avail) ? n_idle : avail;
                 }
+                PHC_END(0);
             }
         }
         if (__ballot(has_ray) == 0ull) {
@@ -478,8 +534,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
         // ---- NODE_STEPS interior-node steps for every lane that is at an interior node ---------------------------------------------------
 #pragma unroll
         for (int step = 0; step < NODE_STEPS; step++) {
-        if (has_ray && cur == PH_NEED_POP) pop_once();
+        if (has_ray && cur == PH_NEED_POP) { PHC_BEGIN(8); pop_once(); PHC_END(8); }
         if (has_ray && !(cur & PH_LEAF_BIT)) {   // (PH_INVALID_REF and PH_NEED_POP have the leaf bit set)
+            PHC_BEGIN(1);
             const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
             const float4 q0 = np[0], q1 = np[1], q2 = np[2];
             const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
@@ -522,6 +579,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
             if (near_hit) { cur = near_ref; if (far_hit) push(far_ref, far_t); }
             else if (far_hit) cur = far_ref;
             else cur = owe_pop();
+            PHC_END(1);
         }
         }
 
@@ -535,6 +593,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
 #pragma unroll
                     for (int ls = 0; ls < PH_LEAF_STEPS; ls++)
                     if (has_ray && cur < PH_NEED_POP && (cur & PH_LEAF_BIT)) {
+                        PHC_BEGIN(9);
                         const uint32_t ti = INST ? (cur & ~(PH_LEAF_BIT | PH_LEAF_INST_HINT)) : (cur & ~PH_LEAF_BIT);
                         const float4* tp = reinterpret_cast<const float4*>(sc.tris + ti);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
@@ -548,6 +607,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         const uint32_t next_ref = INST ? (((cur & ~PH_LEAF_INST_HINT) + 1u) | ((flags & PH_TRI_NEXT_INST) ? PH_LEAF_INST_HINT : 0u)) : cur + 1u;
                         float t, b0, b1, b2;
                         if (INST && (flags & PH_TRI_INSTANCE)) {
+                            PHC_BEGIN(2);
                             // TransformedPrimitive::intersect / intersect_p (transformed_primitive.rs:51-73).  The record itself holds the object's bounds, root and flags (filled in at upload)
                             if (!hinted) { const float4* ep = reinterpret_cast<const float4*>(sc.inst_extra) + 3u * (size_t)ti; e0 = ep[0]; e1 = ep[1]; e2 = ep[2]; }   // no hint (e.g. a root that is a leaf): one more round trip, same numbers
                             const uint32_t iflags = __float_as_uint(c.y), iroot = __float_as_uint(c.x);
@@ -570,14 +630,19 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                                                         r.nz() ? b.z : a.z, r.nz() ? a.z : b.z, tmin);
                                 if (h && tmin < r.t_max) cur = iroot;
                             }
+                            PHC_END(2);
                         } else {
+                        PHC_BEGIN(3);
                         if (COUNT) c_tris[(MIXED && ah) ? 1 : 0]++;
                         if (tri_test(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), t, b0, b1, b2)) {
                             // post-t rejections: degenerate triangle (triangle.rs:567-570 / 862-866), alpha == 0 (:603 / :886-893)
                             const uint32_t reject = ah ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
                             bool accept = !(flags & reject);
-                            if (ALPHA && accept && (flags & PH_TRI_ALPHATEX))
+                            if (ALPHA && accept && (flags & PH_TRI_ALPHATEX)) {
+                                PHC_BEGIN(4);
                                 accept = ALPHA == 1 ? alpha_accept_lean(sc, __float_as_uint(a.w), __float_as_uint(c.w), b0, b1, b2, ah) : alpha_accept(sc.self, ti, b0, b1, b2, ah ? 1u : 0u);
+                                PHC_END(4);
+                            }
                             if (accept) {
                                 if (ah) occluded = true;
                                 else {
@@ -590,7 +655,9 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         if (ah && occluded) cur = PH_INVALID_REF;
                         else if (last) cur = owe_pop();
                         else cur = next_ref;
+                        PHC_END(3);
                         }
+                        PHC_END(9);
                     }
                 }
             }
@@ -598,6 +665,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
 
         // ---- leave an exhausted instance: back to the scene-level ray, `r.t_max = ray.t_max` only if something was hit inside ----------
         if (INST && has_ray && in_inst && cur == PH_INVALID_REF) {
+            PHC_BEGIN(5);
             if (!(ah && occluded)) {
                 const float t_new = inst_hit ? r.t_max : world_tmax;
                 r.ox = inst_save[0][tid]; r.oy = inst_save[1][tid]; r.oz = inst_save[2][tid];
@@ -607,29 +675,15 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                 in_inst = 0;
                 cur = (cont_ref != PH_INVALID_REF) ? cont_ref : owe_pop();
             } else in_inst = 0;
+            PHC_END(5);
         }
 
-        // ---- retire finished rays --------------------------------------------------------------------------------------------------------
-        if (has_ray && cur == PH_INVALID_REF) {
-            if (MIXED && ah) p.out2[ray_index - n_first] = occluded ? 1 : 0;
-            else if (!MIXED && ANYHIT) reinterpret_cast<uint8_t*>(p.out)[ray_index] = occluded ? 1 : 0;
-            else {
-                float4* hp = reinterpret_cast<float4*>(reinterpret_cast<HitOut*>(p.out) + ray_index);
-                if (LEAN) {
-                    if (hit_tri != 0xFFFFFFFFu) {
-                        const float4* tp = reinterpret_cast<const float4*>(sc.tris + hit_tri);
-                        const float4 a = tp[0], b = tp[1], c = tp[2];
-                        tri_bary(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), hb0, hb1, hb2);
-                        hit_prim = __float_as_uint(a.w); hit_cls = (__float_as_uint(b.w) >> PH_TRI_CLASS_SHIFT) & PH_TRI_KEY_MASK;
-                    } else { hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hit_cls = 0u; hb0 = hb1 = hb2 = 0.0f; }
-                }
-                PH_STREAM_STORE(make_float4(r.t_max, __uint_as_float(hit_prim), hb0, hb1), hp);
-                PH_STREAM_STORE(make_float4(hb2, __uint_as_float(hit_tri), __uint_as_float(INST ? hit_inst : 0u), __uint_as_float(hit_cls)), hp + 1);  // pad[0] = the hit's TriRec, pad[1] = instance + 1, pad[2] = material class | material id << 3
-            }
-            has_ray = false;
-            if (COUNT) c_rays[(MIXED && ah) ? 1 : 0]++;
-        }
     }
+    PHC_END(7);
+#if PH_PHASE_CLOCK && defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+    if (tid < 36 && p.phase) atomicAdd(p.phase + tid, phc_lds[tid]);
+#endif
     if (COUNT) {
         // p.counts: closest-hit {nodes, tris, rays} any-hit {nodes, tris, rays} any-hit reference node visits
         const int k0 = (!MIXED && ANYHIT) ? 3 : 0;
