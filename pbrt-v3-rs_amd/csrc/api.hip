@@ -291,6 +291,10 @@ static int trav_variant() {
     if (v < 0) { const char* e = std::getenv("PBRT_HIP_TRAV_VARIANT"); v = e ? std::atoi(e) : PH_DEFAULT_VARIANT; if (v < 0 || v >= PH_N_VARIANTS) v = PH_DEFAULT_VARIANT; }
     return v;
 }
+static int alpha_min() {   // PBRT_HIP_ALPHA_MIN: lanes that wait for an alpha-mask verdict before the wave evaluates the masks together (traverse.h, ALPHA_MIN); A/B aid for the instancing kernel: 0 (inside the leaf step, rounds 2 - 3), 4, 20; default 12
+    static const int v = []() { const char* e = std::getenv("PBRT_HIP_ALPHA_MIN"); const int x = e ? std::atoi(e) : 12; return (x == 0 || x == 4 || x == 20) ? x : 12; }();
+    return v;
+}
 static int variant_lds_depth(int v) {
     switch (v) {
 #define X(id, lm, rm, ld, ns, wpe, pk) case id: return ld;
@@ -341,21 +345,27 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
         else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, 0, wpe>), g, b, 0, s->stream, s->ds, p); \
         else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, 0, wpe>), g, b, 0, s->stream, s->ds, p);             \
     } while (0)
-#define PH_LAUNCH3A(cnt, lm, rm, ld, ns, inst, alpha, wpe)                                                                             \
+#define PH_LAUNCH3AM(cnt, lm, rm, ld, ns, inst, alpha, wpe, amin)                                                                      \
     do {                                                                                                                              \
-        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, true, alpha, wpe>), g, b, 0, s->stream, s->ds, p);       \
-        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, alpha, wpe>), g, b, 0, s->stream, s->ds, p);  \
-        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, alpha, wpe>), g, b, 0, s->stream, s->ds, p);                \
+        if (mode == 2) hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, true, alpha, wpe, amin>), g, b, 0, s->stream, s->ds, p);       \
+        else if (mode == 1) hipLaunchKernelGGL((ph::traverse_kernel<true, cnt, lm, rm, ld, ns, inst, false, alpha, wpe, amin>), g, b, 0, s->stream, s->ds, p);  \
+        else hipLaunchKernelGGL((ph::traverse_kernel<false, cnt, lm, rm, ld, ns, inst, false, alpha, wpe, amin>), g, b, 0, s->stream, s->ds, p);                \
     } while (0)
+#define PH_LAUNCH3A(cnt, lm, rm, ld, ns, inst, alpha, wpe) PH_LAUNCH3AM(cnt, lm, rm, ld, ns, inst, alpha, wpe, 0)
     if (s->alpha_textures) {  // meshes with alpha-mask textures: the ALPHA variants — 1 = the inlined test for image-map masks, 2 = the general evaluator out of line (traverse.h)
         const bool inst = !s->inst_recs.empty();
         if (s->alpha_lean) {
             if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 1, 0); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false, 1, 0); }
-            else if (inst) PH_LAUNCH3A(false, 24, 12, 11, 5, true, 1, 5);   // (the instancing form, five waves per SIMD: 107 registers where the compiler is free, 11 spilled at 96 — and still faster: configs[4]'s traversal 6.04 -> 5.66 s per frame, gpurun r03aq; before the deferred pops it needed 115 and lost)
-            else PH_LAUNCH3A(false, 24, 12, PH_LDS_DEPTH, 5, false, 1, 0);
+            // Round 4: lanes whose candidate hit needs its alpha mask's verdict wait at their record until 12 of the wave's lanes do (traverse.h, ALPHA_MIN): configs[4]'s traversal
+            // 5 301 -> 4 520 ms per frame, same film (thresholds 4 / 8 / 12 / 20: 4 936 / 4 594 / 4 520 / 4 683 ms; same box, gpurun r04n).  PBRT_HIP_ALPHA_MIN=0 is the round-3 form.
+            else if (inst && alpha_min() == 0) PH_LAUNCH3A(false, 24, 12, 11, 5, true, 1, 5);   // (the instancing form, five waves per SIMD: 107 registers where the compiler is free, 20 spilled at 96 — and still faster: configs[4]'s traversal 6.04 -> 5.66 s per frame, gpurun r03aq; before the deferred pops it needed 115 and lost)
+            else if (inst && alpha_min() == 4) PH_LAUNCH3AM(false, 24, 12, 11, 5, true, 1, 5, 4);
+            else if (inst && alpha_min() == 20) PH_LAUNCH3AM(false, 24, 12, 11, 5, true, 1, 5, 20);
+            else if (inst) PH_LAUNCH3AM(false, 24, 12, 11, 5, true, 1, 5, 12);
+            else PH_LAUNCH3AM(false, 24, 12, PH_LDS_DEPTH, 5, false, 1, 0, 12);
         } else {
             if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 2, 0); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false, 2, 0); }
-            else if (inst) PH_LAUNCH3A(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true, 2, 0); else PH_LAUNCH3A(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, false, 2, 0);
+            else if (inst) PH_LAUNCH3AM(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, true, 2, 0, 12); else PH_LAUNCH3AM(false, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 3, false, 2, 0, 12);
         }
         return;
     }
@@ -380,6 +390,7 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
     }
 #undef PH_LAUNCH3
 #undef PH_LAUNCH3A
+#undef PH_LAUNCH3AM
 }
 
 int launch_traverse(PbrtHipScene* s, bool anyhit, const void* d_rays, void* d_out, uint32_t n, float* kernel_ms) {

@@ -362,10 +362,15 @@ PH_DEV void tri_bary(const RayState& r, f3 p0, f3 p1, f3 p2, float& b0_out, floa
 //              per SIMD: measured 30 x slower on a foliage scene than ALPHA = 1) — correct, and kept for the procedural masks only.
 static __device__ __noinline__ bool alpha_accept(const DeviceScene* dsc, uint32_t tri_index, float b0, float b1, float b2, uint32_t any_hit);
 static __device__ __forceinline__ bool alpha_accept_lean(const DeviceScene& sc, uint32_t prim, uint32_t mesh, float b0, float b1, float b2, bool any_hit);
+// ALPHA_MIN > 0 (round 4) makes the alpha-mask test a PHASE of its own.  The test is a chain of dependent fetches (mesh record -> vertex indices -> uv -> texture program -> MIPMap
+//   record -> four texels): on configs[4] it ran in 85 % of the leaf steps for 3.2 lanes on average and took a third of the waves' cycles (scripts/phase_clock.py,
+//   profiles/r04_phase_clock_config4_*).  A lane whose candidate hit needs the mask's verdict now stays at its record with `alpha_wait` set; once ALPHA_MIN lanes of the wave wait (or
+//   the wave has no interior-node work left) they fetch their records again, repeat the triangle test — same ray, same t_max, same numbers; cheaper than carrying t and the
+//   barycentrics in registers this kernel does not have — and evaluate their masks together.  The order of tests along a ray is unchanged, so the result is.
 // WPE > 0 compiles the kernel for exactly that many waves per SIMD (= resident 256-thread blocks per CU): the register allocator then fits the budget
 // (7: 72 VGPRs, 8: 64) instead of taking what it likes; 0 leaves the choice to the compiler (same code as before).
 template <bool ANYHIT, bool COUNT = false, int LEAF_MIN = PH_LEAF_MIN, int REFILL_MIN = PH_REFILL_MIN, int LDS_DEPTH = PH_LDS_DEPTH, int NODE_STEPS = 1, bool INST = false, bool MIXED = false,
-          int ALPHA = 0, int WPE = 0>
+          int ALPHA = 0, int WPE = 0, int ALPHA_MIN = 0>
 __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void traverse_kernel(DeviceScene sc, TravParams p) {
     __shared__ uint2 lds_stack[LDS_DEPTH][PH_TRAV_BLOCK];
     // INST: the scene-level ray's origin and what ray_setup derived from it (six IEEE divides), parked while the lane walks an instance: leaving an instance is then nine LDS reads instead of
@@ -410,6 +415,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
     uint32_t cont_ref = PH_INVALID_REF;   // next record of the scene-level leaf, or PH_INVALID_REF = pop
     bool inst_hit = false;                // a primitive of the current instance was accepted
     uint32_t hit_inst = 0;
+    bool alpha_wait = false;              // ALPHA_MIN > 0: the triangle at `cur` passed the geometric test and waits for its alpha mask's verdict
 
     auto push = [&](uint32_t ref, float tmin) {
         uint2 e = make_uint2(ref, __float_as_uint(tmin));
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         const float4 a = PH_STREAM_LOAD(rp), b = PH_STREAM_LOAD(rp + 1);
                         RayIn in; in.ox = a.x; in.oy = a.y; in.oz = a.z; in.t_max = a.w; in.dx = b.x; in.dy = b.y; in.dz = b.z; in.time = b.w;
                         ray_setup(r, in);
-                        has_ray = true; sp = 0; occluded = false;
+                        has_ray = true; sp = 0; occluded = false; alpha_wait = false;
                         if (LEAN) hit_tri = 0xFFFFFFFFu; else { hit_prim = 0xFFFFFFFFu; hit_tri = 0u; hb0 = hb1 = hb2 = 0.0f; }
                         if (INST) { in_inst = 0; hit_inst = 0; wdx = in.dx; wdy = in.dy; wdz = in.dz; }
                         // root: the reference tests nodes[0].bounds first (bvh/mod.rs:189-190)
@@ -585,14 +591,18 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
 
         // ---- leaf work: one triangle per lane, once enough lanes are waiting at leaves ----------------------------------------------------
         {
-            const bool at_leaf = has_ray && cur < PH_NEED_POP && (cur & PH_LEAF_BIT);
-            const uint64_t lm = __ballot(at_leaf);
-            if (lm != 0ull) {
+            // ALPHA_MIN > 0: lanes that wait for an alpha-mask verdict stand at their record too, but only join a leaf step that fires FOR THEM (enough of them wait)
+            const bool waiting = ALPHA && ALPHA_MIN > 0 && has_ray && alpha_wait;
+            const bool at_leaf = has_ray && cur < PH_NEED_POP && (cur & PH_LEAF_BIT) && !waiting;
+            const uint64_t lm = __ballot(at_leaf), am = (ALPHA && ALPHA_MIN > 0) ? __ballot(waiting) : 0ull;
+            if ((lm | am) != 0ull) {
                 const uint64_t nm = __ballot(has_ray && (cur == PH_NEED_POP || !(cur & PH_LEAF_BIT)));
-                if ((uint32_t)__popcll(lm) >= (uint32_t)LEAF_MIN || nm == 0ull || exhausted) {  // queue drained: no throughput left to protect, only the tail's latency
+                const bool fire_leaf = lm != 0ull && ((uint32_t)__popcll(lm) >= (uint32_t)LEAF_MIN || nm == 0ull || exhausted);  // queue drained: no throughput left to protect, only the tail's latency
+                const bool fire_alpha = am != 0ull && ((uint32_t)__popcll(am) >= (uint32_t)(ALPHA_MIN > 0 ? ALPHA_MIN : 1) || nm == 0ull || exhausted);
+                if (fire_leaf || fire_alpha) {
 #pragma unroll
                     for (int ls = 0; ls < PH_LEAF_STEPS; ls++)
-                    if (has_ray && cur < PH_NEED_POP && (cur & PH_LEAF_BIT)) {
+                    if ((at_leaf && fire_leaf && cur < PH_NEED_POP && (cur & PH_LEAF_BIT)) || (waiting && fire_alpha)) {
                         PHC_BEGIN(9);
                         const uint32_t ti = INST ? (cur & ~(PH_LEAF_BIT | PH_LEAF_INST_HINT)) : (cur & ~PH_LEAF_BIT);
                         const float4* tp = reinterpret_cast<const float4*>(sc.tris + ti);
@@ -634,14 +644,19 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                         } else {
                         PHC_BEGIN(3);
                         if (COUNT) c_tris[(MIXED && ah) ? 1 : 0]++;
+                        const bool second_meeting = ALPHA && ALPHA_MIN > 0 && alpha_wait;   // the lane waited at this record for its alpha mask's verdict: the test below is the one it already passed
+                        alpha_wait = false;
                         if (tri_test(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), t, b0, b1, b2)) {
                             // post-t rejections: degenerate triangle (triangle.rs:567-570 / 862-866), alpha == 0 (:603 / :886-893)
                             const uint32_t reject = ah ? (PH_TRI_BOGUS | PH_TRI_ALPHA0 | PH_TRI_SALPHA0) : (PH_TRI_BOGUS | PH_TRI_ALPHA0);
                             bool accept = !(flags & reject);
                             if (ALPHA && accept && (flags & PH_TRI_ALPHATEX)) {
+                                if (ALPHA_MIN > 0 && !second_meeting) { alpha_wait = true; accept = false; }   // first meeting: the lane stays at this record and waits for companions
+                                else {   // (second meeting: same ray, same t_max, same numbers — now followed by the mask's verdict)
                                 PHC_BEGIN(4);
                                 accept = ALPHA == 1 ? alpha_accept_lean(sc, __float_as_uint(a.w), __float_as_uint(c.w), b0, b1, b2, ah) : alpha_accept(sc.self, ti, b0, b1, b2, ah ? 1u : 0u);
                                 PHC_END(4);
+                                }
                             }
                             if (accept) {
                                 if (ah) occluded = true;
@@ -652,7 +667,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                                 }
                             }
                         }
-                        if (ah && occluded) cur = PH_INVALID_REF;
+                        if (ALPHA && ALPHA_MIN > 0 && alpha_wait) { }   // (not advanced)
+                        else if (ah && occluded) cur = PH_INVALID_REF;
                         else if (last) cur = owe_pop();
                         else cur = next_ref;
                         PHC_END(3);
