@@ -359,9 +359,9 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
             // Round 4: lanes whose candidate hit needs its alpha mask's verdict wait at their record until 12 of the wave's lanes do (traverse.h, ALPHA_MIN): configs[4]'s traversal
             // 5 301 -> 4 520 ms per frame, same film (thresholds 4 / 8 / 12 / 20: 4 936 / 4 594 / 4 520 / 4 683 ms; same box, gpurun r04n).  PBRT_HIP_ALPHA_MIN=0 is the round-3 form.
             else if (inst && alpha_min() == 0) PH_LAUNCH3A(false, 24, 12, 11, 5, true, 1, 5);   // (the instancing form, five waves per SIMD: 107 registers where the compiler is free, 20 spilled at 96 — and still faster: configs[4]'s traversal 6.04 -> 5.66 s per frame, gpurun r03aq; before the deferred pops it needed 115 and lost)
-            else if (inst && alpha_min() == 4) PH_LAUNCH3AM(false, 24, 12, 11, 5, true, 1, 5, 4);
-            else if (inst && alpha_min() == 20) PH_LAUNCH3AM(false, 24, 12, 11, 5, true, 1, 5, 20);
-            else if (inst) PH_LAUNCH3AM(false, 24, 12, 11, 5, true, 1, 5, 12);
+            else if (inst && alpha_min() == 4) PH_LAUNCH3AM(false, 16, 12, 11, 5, true, 1, 5, 4);
+            else if (inst && alpha_min() == 20) PH_LAUNCH3AM(false, 16, 12, 11, 5, true, 1, 5, 20);
+            else if (inst) PH_LAUNCH3AM(false, 16, 12, 11, 5, true, 1, 5, 12);   // (leaf threshold 16: with the mask lanes waiting apart, fewer lanes need to gather at leaves — 4 513 -> 4 466 ms; 32: 4 717; refill at 20: 4 627; 3 / 8 node steps per pass: 4 510 / 4 795, gpurun r04q)
             else PH_LAUNCH3AM(false, 24, 12, PH_LDS_DEPTH, 5, false, 1, 0, 12);
         } else {
             if (s->count_traversal) { if (inst) PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, true, 2, 0); else PH_LAUNCH3A(true, PH_LEAF_MIN, PH_REFILL_MIN, PH_LDS_DEPTH, 1, false, 2, 0); }
