@@ -310,20 +310,7 @@ PH_DEV void tri_bary(const RayState& r, f3 p0, f3 p1, f3 p2, float& b0_out, floa
 #ifndef PH_PHASE_CLOCK
 #define PH_PHASE_CLOCK 0
 #endif
-#if PH_PHASE_CLOCK && defined(__HIP_DEVICE_COMPILE__)
-#define PHC_BEGIN(k) const unsigned long long phc_t##k = __builtin_amdgcn_s_memtime()
-#define PHC_END(k)                                                                                                                  \
-    do {                                                                                                                            \
-        const unsigned long long phc_dt = __builtin_amdgcn_s_memtime() - phc_t##k;                                                  \
-        const unsigned long long phc_m = __ballot(true);                                                                            \
-        if ((int)(threadIdx.x & 63u) == __ffsll((long long)phc_m) - 1) {                                                            \
-            atomicAdd(&phc_lds[k], phc_dt); atomicAdd(&phc_lds[12 + k], 1ull); atomicAdd(&phc_lds[24 + k], (unsigned long long)__popcll(phc_m)); \
-        }                                                                                                                           \
-    } while (0)
-#else
-#define PHC_BEGIN(k) do { } while (0)
-#define PHC_END(k) do { } while (0)
-#endif
+#include "phase_clock.h"
 // COUNT = true adds per-ray work counters (roofline bookkeeping, never used in a timed run).  For closest-hit rays the
 // reference's "nodes visited" is exactly 1 + 2 * (interior nodes whose box test passed): it fetches and tests both children
 // of every such node (the far one when it is popped), and nothing else.

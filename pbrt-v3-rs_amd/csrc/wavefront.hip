@@ -22,6 +22,7 @@
 #include "bsdf_general.h"
 #include "texture.h"
 #include "raysort.h"
+#include "phase_clock.h"
 #include "matsort.h"
 #include <algorithm>
 #include <cstdlib>
@@ -76,6 +77,7 @@ struct WfParams {
     RaySortGrid sort_grid; uint32_t* keys_cl; uint32_t* keys_sh;
     // shade-side work queues (matsort.h): this round's list positions grouped by material key, and the bins' starts; null = the texture / light-distribution / shade passes walk the list in queue order
     const uint32_t* m_order; const uint32_t* m_bins;
+    unsigned long long* phase;   // PH_PHASE_CLOCK builds: the shade kernel's phase tallies (phase_clock.h)
 };
 
 PH_DEV uint32_t wave_alloc(uint32_t* ctr, bool want) {
@@ -302,6 +304,12 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
     __shared__ HaltonLds halton_lds;
     __shared__ float s_u[8][PH_SHADE_BLOCK];  // the (up to) 8 sampler dimensions a vertex can consume, drawn by ONE loop
     const uint32_t n_live = w.ctr[it].n_live;
+#if PH_PHASE_CLOCK && defined(__HIP_DEVICE_COMPILE__)
+    __shared__ unsigned long long phc_lds[3 * PHC_N];
+    if (threadIdx.x < 3 * PHC_N) phc_lds[threadIdx.x] = 0ull;
+    __syncthreads();
+#endif
+    PHC_BEGIN(10);
     const HaltonLds* hl = nullptr;
     if (w.sp.kind == 0 && blockIdx.x * blockDim.x < n_live) { halton_lds_fill(&halton_lds, sc); hl = &halton_lds; }
     __syncthreads();
@@ -330,6 +338,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
             // this thread's path: its position in the round's list.  With the work queues (matsort.h) the walk goes through `order`: a wave holds paths of ONE material (its
             // lobe list, texture slots and light-sampling branches are then the wave's), paths with nothing to shade sit at the end.  Which thread handles which path is free:
             // paths are independent and the film is accumulated by sample index.  (Rounds 1 - 3 sorted the 256 paths of a block by material class in LDS: ~9 paths per class.)
+            PHC_BEGIN(0);
             const uint32_t pos = w.m_order ? w.m_order[i] : i;
             pid = live_in[pos];
             const uint4 idx4 = w.s_idx[it & 1][pos];
@@ -371,6 +380,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                 L = L + ldv;
                 flags &= ~(F_PSH | F_PMIS);
             }
+            PHC_END(0);
 
             // ---- the new vertex: body of li's loop (path.rs:116-279) ---------------------------------------------------------------
             if (flags & F_EXT) {
@@ -388,11 +398,13 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                 } else {
                     const float4 h1 = hp[1];
                     MeshRec m;
+                    PHC_BEGIN(1);
                     SurfHit si = make_surface_hit_any(sc, rd, ray.time, __float_as_uint(h1.y), __float_as_uint(h1.z), h0.z, h0.w, h1.x, m);
                     if (emit) {
                         if (m.first_light >= 0) L = L + beta * area_L(sc.lights[(uint32_t)m.first_light + (hprim - m.tri_base)], si.n, -rd);
                         else L = L + beta * mks1(0.0f);
                     }
+                    PHC_END(1);
                     bool no_bsdf = sc.materials[m.material].none != 0u;
                     if (TEX && !no_bsdf && sc.materials[m.material].rt_mode) no_bsdf = (w.tex_out[i].bumped & PH_TEXOUT_NULL_BSDF) != 0u;   // translucent.rs:72-74, decided by this hit's textures
                     if ((int)bounces < w.max_depth && no_bsdf) {
@@ -415,12 +427,15 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                 si.ns = mk3(f0.x, f0.y, f0.z); si.dpdu_s = mk3(f1.x, f1.y, f1.z);
                             }
                         }
+                        PHC_BEGIN(2);
                         typename BO::T bsdf = BO::make(sc, si, m.material);
                         if (TEX && tex_hit) {
                             const MaterialRec& mr = sc.materials[m.material];
                             if (mr.textured)
                                 BO::apply_textures(bsdf, w.tex_out + i, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr, mr);
                         }
+                        PHC_END(2);
+                        PHC_BEGIN(3);
                         SamplerCursor cur = cursor_for(sc, w.sp, xy.x, xy.y, w.s0 + (pid - ppix * w.chunk_spp), dim, hl);
                         // Draw the next 8 dimensions in one (not unrolled) loop: light pick 1D, u_light 2D, u_scattering 2D, BSDF 2D,
                         // Russian roulette 1D.  li consumes a prefix of them that depends on the vertex (A4 ledger); which VALUE lands in
@@ -428,11 +443,13 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         // radical-inverse code instead of ten keeps the kernel inside the instruction cache).
 #pragma unroll 1
                         for (uint32_t k = 0; k < 8; k++) s_u[k][tid] = sampler_dim(sc, w.sp, cur, dim + k);
+                        PHC_END(3);
                         uint32_t c = 0;  // dimensions consumed so far at this vertex
                         if (BO::has_non_specular(bsdf)) {  // num_components(all & !SPECULAR) > 0 (path.rs:161-172)
                             n_paths_total++;
                             // uniform_sample_one_light (integrator/common.rs:89-133)
                             if (sc.n_lights > 0) {
+                                PHC_BEGIN(4);
                                 const float sample = s_u[0][tid]; c = 1;
                                 // sample_discrete; with a single light the CDF is {0, 1} and the answer is 0 for every sample in [0,1):
                                 // keeping that case wave-uniform lets the light record be fetched with scalar loads
@@ -446,6 +463,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                 }
                                 const uint32_t light_num = (sc.n_lights == 1) ? 0u : find_interval_cdf(ld_cdf, sc.n_lights + 1, sample);
                                 pick_pdf = ld_func_int > 0.0f ? ph_div(ld_func[light_num], ld_func_int * (float)sc.n_lights) : 0.0f;
+                                PHC_END(4);
                                 if (pick_pdf != 0.0f) {
                                     const LightRec& light = sc.lights[light_num];
                                     const f2 u_light = mk2(s_u[1][tid], s_u[2][tid]), u_scatter = mk2(s_u[3][tid], s_u[4][tid]); c = 5;
@@ -454,7 +472,10 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                     spec A = mks1(0.0f);
                                     // estimate_direct (integrator/common.rs:146-299), specular = false, handle_media = false
                                     {
+                                        PHC_BEGIN(5);
                                         const LiSample ls = light_sample_li<TEX>(sc, light, si, u_light);
+                                        PHC_END(5);
+                                        PHC_BEGIN(6);
                                         if (ls.valid && ls.pdf > 0.0f && !is_black(ls.value)) {
                                             const spec f = BO::f_ns(bsdf, si.wo, ls.wi) * abs_dot(ls.wi, si.ns);
                                             const float scattering_pdf = BO::pdf_ns(bsdf, si.wo, ls.wi);
@@ -468,8 +489,10 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                                 flags |= F_PSH;
                                             }
                                         }
+                                        PHC_END(6);
                                     }
                                     if (!is_delta) {
+                                        PHC_BEGIN(7);
                                         spec f1; float spdf; f3 wi2;
                                         BO::sample_ns(bsdf, si.wo, u_scatter, f1, spdf, wi2);  // never specular with these flags: sampled_specular = false
                                         const spec f = f1 * abs_dot(wi2, si.ns);
@@ -486,6 +509,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                                                 flags |= F_PMIS;
                                             }
                                         }
+                                        PHC_END(7);
                                     }
                                     if (flags & (F_PSH | F_PMIS)) {
                                         w.s_A[(it + 1) & 1][i] = make_float4(A.r, A.g, A.b, w2);   // at THIS thread's position (coalesced); the survivor's s_prev points here
@@ -496,6 +520,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                             if (!(flags & (F_PSH | F_PMIS))) n_paths_zero++;  // ld is black
                         }
                         // sample the BSDF for the next direction (path.rs:174-206)
+                        PHC_BEGIN(8);
                         const f2 u = mk2(s_u[c][tid], s_u[c + 1][tid]); c += 2;
                         spec f; float pdf; f3 wi; uint32_t stype;
                         BO::sample_all(bsdf, -rd, u, f, pdf, wi, stype);
@@ -526,6 +551,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         }
                         cur.dim = dim + c;
                         dim = cur.dim;
+                        PHC_END(8);
                     }
                 }
             }
@@ -533,6 +559,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
         const bool still_live = active && (flags & (F_EXT | F_PSH | F_PMIS)) != 0;
 
         // ---- block-aggregated queue appends --------------------------------------------------------------------------------------------
+        PHC_BEGIN(9);
         const uint64_t m_ext = __ballot(want_ext), m_mis = __ballot(want_mis), m_sh = __ballot(want_sh), m_lv = __ballot(still_live);
         if (lane == 0) {
             wave_cnt[0][wid] = (uint32_t)(__popcll(m_ext) + __popcll(m_mis));
@@ -594,7 +621,13 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
             }
         }
         __syncthreads();  // stage / wave_cnt are reused by the next grid-stride round
+        PHC_END(9);
     }
+    PHC_END(10);
+#if PH_PHASE_CLOCK && defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+    if (threadIdx.x < 3 * PHC_N && w.phase) atomicAdd(w.phase + threadIdx.x, phc_lds[threadIdx.x]);
+#endif
     for (int o = 32; o > 0; o >>= 1) { n_paths_total += __shfl_xor(n_paths_total, o); n_paths_zero += __shfl_xor(n_paths_zero, o); }
     if (lane == 0) { atomicAdd(&blk_stats[0], n_paths_total); atomicAdd(&blk_stats[1], n_paths_zero); }
     __syncthreads();
@@ -946,7 +979,7 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     static const bool mq_env = []() { const char* e = std::getenv("PBRT_HIP_MATERIAL_QUEUES"); return !(e && std::atoi(e) == 0); }();
     const bool mat_queues = mq_env && (s->general_materials || s->textured_materials);
     if ((rc = ensure_buf(s, w.d_ctr, (size_t)(n_iter_cap + 2) * sizeof(ph::IterCounters)))) return rc;
-    if ((rc = ensure_buf(s, w.d_stats, sizeof(ph::DevStats)))) return rc;
+    if ((rc = ensure_buf(s, w.d_stats, 64 + 3 * PHC_N * 8))) return rc;   // DevStats (+ the shade kernel's phase tallies in measurement builds)
     if ((rc = ensure_buf(s, w.d_recL, (size_t)n_px * spp * 16))) return rc;
     if ((rc = ensure_buf(s, w.d_recpy, (size_t)n_px * spp * 4))) return rc;
     if ((rc = ensure_buf(s, w.d_rounded, (size_t)n_px))) return rc;
@@ -1046,7 +1079,8 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     wp.m_order = mat_queues ? (const uint32_t*)w.d_morder.p : nullptr; wp.m_bins = mat_queues ? (const uint32_t*)w.d_mbins.p : nullptr;
 
     if (spatial) { if ((rc = setup_spatial(s, wp.spatial))) return rc; }
-    PH_CHECK(s, hipMemsetAsync(w.d_stats.p, 0, sizeof(ph::DevStats), s->stream));
+    PH_CHECK(s, hipMemsetAsync(w.d_stats.p, 0, 64 + 3 * PHC_N * 8, s->stream));
+    wp.phase = PH_PHASE_CLOCK ? (unsigned long long*)((char*)w.d_stats.p + 64) : nullptr;
     bool identity = true;  // does pixel_bounds cover every pixel of this rank's tiles?
     for (const ph::TileInfo& t : w.tiles)
         if (t.tb[0] < pixel_bounds[0] || t.tb[1] < pixel_bounds[1] || t.tb[2] > pixel_bounds[2] || t.tb[3] > pixel_bounds[3]) { identity = false; break; }
@@ -1187,6 +1221,16 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
             return set_err(s, PBRT_HIP_ERR_OOM, "render: SpatialLightDistribution pool exhausted (" + std::to_string(sp_ctr[ph::SP_CLAIMED]) + " voxels x " +
                                                 std::to_string(s->lights.size()) + " lights); use lightsamplestrategy power/uniform or a larger GPU memory budget");
     }
+#if PH_PHASE_CLOCK
+    {   // measurement build: the shade kernel's phase clocks of this render, to stderr
+        unsigned long long ph_[3 * PHC_N];
+        PH_CHECK(s, hipMemcpy(ph_, (const char*)w.d_stats.p + 64, sizeof ph_, hipMemcpyDeviceToHost));
+        static const char* names[11] = {"state+resolve", "surface+emission", "bsdf+textures", "sampler_dims", "light_pick", "light_sample_li", "f/pdf+shadow_ray", "mis_half", "bsdf_sample+rr", "queue_append", "whole_kernel"};
+        for (int k = 0; k < 11; k++)
+            std::fprintf(stderr, "SHADE_PHASE %-17s cycles %14llu (%5.1f %% of the kernel)  executions %12llu  mean active lanes %5.1f\n", names[k], ph_[k], ph_[10] ? 100.0 * (double)ph_[k] / (double)ph_[10] : 0.0,
+                         ph_[PHC_N + k], ph_[PHC_N + k] ? (double)ph_[2 * PHC_N + k] / (double)ph_[PHC_N + k] : 0.0);
+    }
+#endif
     if (out_stats) {
         out_stats->light_distributions_created = sp_ctr[ph::SP_DONE];
         ph::DevStats ds;
