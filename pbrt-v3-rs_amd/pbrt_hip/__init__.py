@@ -637,7 +637,7 @@ class Scene:
         inp = np.ascontiguousarray(np.concatenate(cols, axis=1), dtype=np.float32)
         out = np.zeros((len(uv), 3), np.float32)
         self._chk(self.b.fn("texture_eval_batch")(self.h, texture, len(uv), _ptr(inp, C.c_float), _ptr(out, C.c_float)))
-        if not inp[:, 2:6].any() and not inp[:, 9:15].any():
+        if self.b.has("texture_eval_batch_nodiff") and not inp[:, 2:6].any() and not inp[:, 9:15].any():   # (the product only: the oracle has one evaluator)
             # contexts without differentials: the renderer evaluates them with the NODIFF form of the evaluator (every ray but a camera ray) — the two must agree bit for bit
             out2 = np.zeros_like(out)
             self._chk(self.b.fn("texture_eval_batch_nodiff")(self.h, texture, len(uv), _ptr(inp, C.c_float), _ptr(out2, C.c_float)))
