@@ -443,6 +443,11 @@ def main():
                                               f"L2 hits; `frac` stays the HBM counter fraction, `l2` and `l1_frac_of_calibrated` place the kernel against the roofs that are nearer (" + roof["bound_note"] + ")")
                     elif hbm_frac >= 0.2:
                         roof["bound"] = "hbm"
+                    # round 4: what the "l2-latency" label does and does not mean for THIS kernel (profiles/r04_quad_experiment/, r04_phase_clock_*): its data is L2-resident and every
+                    # step waits on an L2 hit, but halving the number of dependent fetches per ray at equal fetch volume made it 11 % slower — the waves' time goes to instruction
+                    # issue at a lane utilisation below one half, not to the length of the chain
+                    roof["bound_evidence"] = ("round-4 experiment: two tree levels per fetch halve the dependent chain (58.4 -> 29.4 steps per ray, same L1 look-ups) and cost 11 % — the chain's length "
+                                              "does not pace the kernel; issue slots at the lane utilisation in `valu` do (profiles/r04_quad_experiment/README.txt, profiles/r04_phase_clock_config2_32spp.txt)")
                     sqk = k.get("sq") or {}
                     if sqk.get("tcp_tcc_read_req"):
                         l2_bytes = sqk["tcp_tcc_read_req"] * 64.0 / k["dispatches"]
