@@ -464,7 +464,7 @@ def main():
                                               "the L1 tag pipes %.2f look-ups per CU-cycle (each lane's 64-B node costs four); L2 serves %.0f %% of the requests since the rays of a launch are binned by origin cell.  "
                                               "Measured cuts — 16 %% fewer vector instructions, 11 %% fewer L1 look-ups, a seventh wave per SIMD — each left the time unchanged on the same box; the rate follows the resident waves only up to there "
                                               "(3 -> 4 -> 5 -> 6 blocks per CU: +21, +13, +9 %%) and the locality of a launch's rays (unbinned queues: -20 %%): a walk of dependent 64-B fetches at ~70 %% of what the L1 / L2 path sustains "
-                                              "for this access pattern (DESIGN 4)") %
+                                              "for this access pattern (HISTORY §4; DESIGN §4.1 for round 4's reading)") %
                                              (100.0 * k["sq"]["valu_issue_of_simd_quads"], k["sq"]["valu_lane_utilisation"], k["sq"]["scalar_and_branch_per_cu_cycle"], k["sq"]["l1_accesses_per_cu_cycle"],
                                               100.0 * k["TCC_HIT"] / (k["TCC_HIT"] + k["TCC_MISS"]))) if k.get("sq") and k["sq"].get("valu_issue_of_simd_quads") is not None else None,
                                  "pipes": ({"valu_issue": k["sq"]["valu_issue_of_simd_quads"], "valu_lane_util": k["sq"]["valu_lane_utilisation"],

@@ -152,7 +152,7 @@ PH_DEV float vmin3(float a, float b, float c) {
 //    therefore neither misses nor replaces t_min / t_max in the reference — exactly what the hardware's max3 / min3 do with a quiet NaN operand.  A NaN
 //    x distance is what t_min / t_max START as, survives every update and fails the final comparison: the reference misses; hence the `ordered` term.
 PH_DEV bool box_test(const RayState& r, float xn, float xf, float yn, float yf, float zn, float zf, float& t_min_out) {
-    // (the same arithmetic as three + three packed two-float operations, v_pk_add_f32 / v_pk_mul_f32, was measured in round 2: more registers, no gain — DESIGN §7b)
+    // (the same arithmetic as three + three packed two-float operations, v_pk_add_f32 / v_pk_mul_f32, was measured in round 2: more registers, no gain — HISTORY §7b)
     float t_x_min = (xn - r.ox) * r.ix;
     float t_x_max = (xf - r.ox) * r.ix;
     const float t_y_min = (yn - r.oy) * r.iy;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
     // begins with ONE pop attempt for the lanes that owe one — an entry that fails `t_min < ray.t_max` leaves the lane owing the next.  The entries are popped in the same order and
     // tested against the same t_max (a lane that owes a pop is at no leaf, so nothing shrinks its t_max meanwhile): same visits, same bits.  The pop loop with its two address spaces was
     // expanded inline at three places: this form issues a third fewer scalar instructions and branches per frame (SQ_INSTS_SALU 2.60e11 -> 1.71e11 on configs[2]).  Worth 5.5 % on the
-    // instancing kernel (1 180 -> 1 115 ms of traversal per frame on 1 000 x 10 k instances), nothing on the flat one (703.5 against 705.7 ms; gpurun r03an) — DESIGN 4, "what bounds the kernel".
+    // instancing kernel (1 180 -> 1 115 ms of traversal per frame on 1 000 x 10 k instances), nothing on the flat one (703.5 against 705.7 ms; gpurun r03an) — HISTORY §4, "what bounds the kernel".
     auto owe_pop = [&]() -> uint32_t {
         const int floor_sp = (INST && in_inst) ? inst_sp : 0;
         return sp > floor_sp ? PH_NEED_POP : PH_INVALID_REF;

@@ -1,4 +1,4 @@
-"""-m gpu: regression test for the "wrong values in OTHER lanes" bug DESIGN §4 records (found with scripts/bump_probe.py).
+"""-m gpu: regression test for the "wrong values in OTHER lanes" bug HISTORY.md §4 records (found with scripts/bump_probe.py).
 
 An earlier version of the one-lobe shade kernel called the bump-map evaluator out of line with about forty scalar arguments, most of them passed on
 the stack; on gfx950 (ROCm 7.2) lanes of the wave that did NOT take the call then carried wrong values — visible as whole columns of differing pixels

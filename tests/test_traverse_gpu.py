@@ -146,4 +146,4 @@ def test_other_split_methods_bit_exact(host, split_method, max_prims):
     assert eq.all(), f"{(~eq).sum()} of {len(rays)} rays differ"
     assert np.array_equal(prod.occluded_batch(rays), orc.occluded_batch_stats(rays)[0])
     if split_method == 1:
-        assert st.nodes_visited / st.rays > 300   # the reference's HLBVH is not spatially coherent (DESIGN quirk B10)
+        assert st.nodes_visited / st.rays > 300   # the reference's HLBVH is not spatially coherent (quirk B10, HISTORY §3a)
