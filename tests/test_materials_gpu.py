@@ -140,3 +140,36 @@ def test_none_material_veils_bit_exact(host):
         base(s)
     for strategy, depth in ((0, 3), (2, 5), (1, 1)):
         _check(cap, strategy=strategy, max_depth=depth)
+
+
+@pytest.mark.parametrize("n_materials", [700, 4300])
+def test_more_materials_than_work_queue_bins_or_triangle_flag_bits(host, n_materials):
+    """The shade-side work queues (csrc/matsort.h) key a path by its hit's material: 1 024 bins (materials beyond 500 textured / 500 plain share the last key of their
+    group), and the material id travels with the hit in 12 bits of the TriRec's flags (ids from 4 095 on are looked up through the mesh).  A scene with 700 and one with 4 300
+    materials — every triangle its own, every third one image-textured, plastic / matte alternating — renders the oracle's film bit for bit: sharing a key or taking the slow
+    look-up changes who shades a path when, not what is computed."""
+    from texture_scenes import make_image
+    P, idx = host.gen_random_tris(n_materials, 31)
+    img = make_image(32, 32, seed=3)
+
+    def cap(s):
+        s.add_light_infinite((0.6, 0.65, 0.7))
+        s.add_light_point((6, 5, 5), (0.4, -2.5, 1.5))
+        tex = s.add_texture_imagemap(s.add_mipmap(img), su=3.0, sv=2.0)
+        r = np.random.default_rng(7)
+        for t in range(n_materials):
+            c = tuple(float(v) for v in r.uniform(0.2, 0.9, 3))
+            if t % 3 == 0:
+                m = s.add_material_matte_tex(tex, float(r.uniform(0, 30)))
+            elif t % 2:
+                m = s.add_material_plastic(c, (0.2, 0.2, 0.2), 0.1, True)
+            else:
+                m = s.add_material_matte(c, 0.0)
+            s.add_mesh(P[3 * t:3 * t + 3], np.array([0, 1, 2], np.uint32), m)
+        w2c, c2w = host.look_at([0, -4, 0], [0, 0, 0], [0, 0, 1])
+        s.set_camera_perspective(host.perspective_raster_to_camera(40.0, 48, 48), c2w)
+        cb, table, sb = host.film_box(48, 48)
+        s.set_film(48, 48, cb, (0.5, 0.5), table)
+        s.set_sampler(0, 8, sb)
+        s.build_accel(0, 4)
+    _check(cap, strategy=0, max_depth=4)
