@@ -51,7 +51,7 @@ typedef struct PbrtHipRay {
  * For a hit inside an object instance prim is the triangle's number in add_mesh order (object meshes included) and pad[1] =
  * instance number + 1 (add_instance call order); t, b0..b2 are those of the instance-space ray, as TransformedPrimitive::intersect
  * leaves them in `r.t_max` (transformed_primitive.rs:56).  pad[1] = 0 otherwise.
- * pad[0] carries the library's leaf-order index of the hit triangle (an internal shortcut for the shade stage); ignore it. */
+ * pad[0] carries the library's leaf-order index of the hit triangle and pad[2] its material class | material id << 3 (internal shortcuts for the shade stage and its work queues); ignore them. */
 typedef struct PbrtHipHit {
     float t;
     uint32_t prim;
