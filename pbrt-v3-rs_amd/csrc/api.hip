@@ -126,6 +126,7 @@ int upload_scene(PbrtHipScene* s) {
         for (MaterialRec& m : s->materials) {
             uint32_t cols = m.amount_tex1 ? 1u : 0u; bool hdr = m.bump_tex1 != 0u || m.sigma_tex1 != 0u;
             for (uint32_t k = 0; k < m.n_lobes; k++) {
+                s->lobes[m.lobe_base + k].slot0 = cols;   // where this lobe's colours start in TexOut (bsdf_general.h: patch_lobe reads them from there)
                 const LobeRec& l = s->lobes[m.lobe_base + k];
                 if (l.has_pre == PH_PRE_RT) { cols += 1u; hdr = true; }   // one product colour per lobe, its black bit and the material's null-BSDF bit in the header
                 else cols += (l.r_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T) ? 1u : 0u) + (l.t_tex1 || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH ? 1u : 0u) +

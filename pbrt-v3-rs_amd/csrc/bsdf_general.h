@@ -13,18 +13,81 @@ namespace ph {
 
 enum : uint32_t { BX_REFL = 1u, BX_TRANS = 2u, BX_DIFF = 4u, BX_GLOSSY = 8u, BX_SPEC = 16u, BX_ALL = 31u };  // BxDFType (bsdf.rs:10-20)
 
+// The BSDF of a hit = the material's TEMPLATE lobe list (built by the host, api.hip) seen through the hit: `keep` says which template lobes the reference would have added at this
+// hit, and where the material takes colours / roughnesses / an index of refraction from textures, lobe_at() patches the template lobe on the fly from the texture pass's record of
+// the hit (TexOut, 128 B per thread, read through L1).  Rounds 1 - 3 materialised a hit's list as up to eight 176-byte LobeRec copies in global memory per thread (1.4 KB slots,
+// ~0.7 TB written per configs[4] frame and read back through L2); round 4 reads the template — the same for every lane of a material-sorted wave — and the record.
 struct GBsdf {
     f3 ns, ng, ss, ts;
-    const LobeRec* lobes;
+    const LobeRec* lobes;      // the material's template list
     uint32_t n;
     float eta;
+    const TexOut* hit;         // null: constant material, the template IS the list
+    const MaterialRec* mr;
+    uint32_t keep;             // bit i: template lobe i is part of this hit's list
 };
 PH_DEV GBsdf make_gbsdf(const DeviceScene& sc, const SurfHit& si, uint32_t material) {
     const MaterialRec& m = sc.materials[material];
     GBsdf b;
     b.ns = si.ns; b.ng = si.n; b.ss = normalize(si.dpdu_s); b.ts = cross(b.ns, b.ss);  // bsdf.rs:100-116
     b.lobes = sc.lobes + m.lobe_base; b.n = m.n_lobes; b.eta = m.bsdf_eta;
+    b.hit = nullptr; b.mr = &m; b.keep = 0xFFFFFFFFu;
     return b;
+}
+// ---- a textured material's lobe at a hit -------------------------------------------------------------------------------------------------------------------------
+// The hit's own list = template lobes with the texture pass's colours filled in, a lobe dropped where the reference would not add it (`if !kd.is_black()`, plastic.rs:63 / :70,
+// mirror.rs:55, matte.rs:66, uber.rs:134-160; FresnelBlend / FresnelSpecular unless both colours are black, substrate.rs:62, glass.rs:76-78).
+PH_DEV bool lobe_keep(const LobeRec& l) {
+    const bool r_black = l.r[0] == 0.0f && l.r[1] == 0.0f && l.r[2] == 0.0f, t_black = l.t[0] == 0.0f && l.t[1] == 0.0f && l.t[2] == 0.0f;
+    // which colour decides whether the reference adds the lobe: both for the two-colour lobes, t for the transmission lobes, r otherwise
+    return (l.kind == PH_LK_FRESNEL_BLEND || l.kind == PH_LK_FRESNEL_SPEC) ? !(r_black && t_black)
+         : ((l.kind == PH_LK_SPEC_T || l.kind == PH_LK_MICRO_T || l.kind == PH_LK_LAMBERT_T) ? !t_black : !r_black);
+}
+// does this colour of the lobe come from the texture pass?  (r before t; PH_PRE_OPACITY / PH_PRE_PASSTHROUGH lobes always: their colour depends on the hit's opacity)
+PH_DEV bool lobe_is_reflection(const LobeRec& l) { return l.kind == PH_LK_LAMBERT || l.kind == PH_LK_MICRO_R; }   // (of a PH_PRE_RT lobe: LambertianReflection / MicrofacetReflection against their transmission twins)
+PH_DEV bool lobe_slot_r(const LobeRec& l) { return l.has_pre == PH_PRE_RT ? lobe_is_reflection(l) : (l.r_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T)); }
+PH_DEV bool lobe_slot_t(const LobeRec& l) { return l.has_pre == PH_PRE_RT ? !lobe_is_reflection(l) : (l.t_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH); }
+// template lobe `l` of material `mr` as the hit `in` has it; returns whether a texel that decides the lobe's presence was black (PH_PRE_RAW_TEST / PH_PRE_RT lobes)
+PH_DEV bool patch_lobe(const MaterialRec& mr, LobeRec& l, const TexOut* in) {
+    // materials whose lobes need neither per-hit scalars nor the raw-black bits leave the record's header unwritten (texture_kernel): do not read it
+    const uint32_t hdr_lambert = mr.tex_hdr ? in->lambert : 0u, hdr_bumped = mr.tex_hdr ? in->bumped : 0u;
+    if (l.sigma_tex1) { l.kind = (hdr_lambert & 1u) ? PH_LK_LAMBERT : PH_LK_OREN; l.a = in->col[0][3]; l.b = in->col[1][3]; }
+    if (l.ax_tex1 || l.ay_tex1) { l.ax = in->col[0][3]; l.ay = in->col[1][3]; }
+    // the hit's index of refraction: FresnelSpecular / FresnelDielectric(1, eta) / the transmission lobes (glass.rs:113-139, uber.rs:145-176) — not the opacity pass-through, which is built with (1, 1)
+    if (mr.index_tex1 && l.has_pre != PH_PRE_PASSTHROUGH && (l.kind == PH_LK_FRESNEL_SPEC || l.fresnel == PH_FR_DIEL)) l.eta_b = in->col[2][3];
+    uint32_t ci = l.slot0;
+    bool raw_black = false;
+    if (lobe_slot_r(l) && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; raw_black = raw_black || ((hdr_bumped >> (8u + ci)) & 1u); ci++; }
+    if (lobe_slot_t(l) && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; raw_black = raw_black || ((hdr_bumped >> (8u + ci)) & 1u); ci++; }
+    if (l.eta_tex1 && ci < PH_HIT_COLS) { l.c_eta_t[0] = in->col[ci][0]; l.c_eta_t[1] = in->col[ci][1]; l.c_eta_t[2] = in->col[ci][2]; ci++; }
+    if (l.k_tex1 && ci < PH_HIT_COLS) { l.c_k[0] = in->col[ci][0]; l.c_k[1] = in->col[ci][1]; l.c_k[2] = in->col[ci][2]; ci++; }
+    if (l.amt & 3u) {   // MixMaterial with an `amount` texture: s1 = the hit's amount (the first colour slot), s2 = clamp(1 - s1) (mix.rs:59-60)
+        float* sc = ((l.amt >> 8) & 3u) == 0u ? l.scale0 : l.scale1;
+        const bool first = (l.amt & 3u) == 1u;
+        for (int c = 0; c < 3; c++) { const float s1 = in->col[0][c]; sc[c] = first ? s1 : pclampf(1.0f - s1, 0.0f, kInf); }
+    }
+    return raw_black;
+}
+// which template lobes make up the hit's list (bit mask), and BSDF::eta of the hit when the material is an uber with an opacity texture (uber.rs:128-137; untouched otherwise)
+PH_DEV uint32_t hit_lobe_mask(const MaterialRec& mr, const LobeRec* tmpl, uint32_t n, const TexOut* in, float& eta_out) {
+    const bool is_specular = mr.tex_hdr && (in->lambert & 2u) != 0u;
+    bool passthrough = false;
+    uint32_t keep = 0u;
+    for (uint32_t i = 0; i < n && i < PH_HIT_LOBES; i++) {
+        LobeRec l = tmpl[i];
+        const bool raw_black = patch_lobe(mr, l, in);
+        if ((l.alt == 1u && !is_specular) || (l.alt == 2u && is_specular)) continue;   // glass.rs:112-141: FresnelSpecular, or the microfacet pair
+        // TranslucentMaterial's lobes: the texel decided (an untextured one exists because its constant passed the test when the material was made)
+        if ((l.has_pre == PH_PRE_RAW_TEST || l.has_pre == PH_PRE_RT) ? !raw_black : lobe_keep(l)) { if (l.has_pre == PH_PRE_PASSTHROUGH) passthrough = true; keep |= 1u << i; }
+    }
+    if (mr.uber_eta) eta_out = passthrough ? 1.0f : (mr.index_tex1 ? in->col[2][3] : mr.bsdf_eta_alt);
+    return keep;
+}
+PH_DEV bool lobe_in(const GBsdf& b, uint32_t i) { return ((b.keep >> i) & 1u) != 0u; }
+PH_DEV LobeRec lobe_at(const GBsdf& b, uint32_t i) {
+    LobeRec l = b.lobes[i];
+    if (b.hit) (void)patch_lobe(*b.mr, l, b.hit);
+    return l;
 }
 PH_DEV f3 w2l(const GBsdf& b, f3 v) { return mk3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
 PH_DEV f3 l2w(const GBsdf& b, f3 v) {
@@ -329,9 +392,11 @@ PH_DEV uint32_t lobe_sample_f_raw(const LobeRec& l, f3 wo, f2 u, spec& f, float&
 }
 
 PH_DEV bool lobe_matches(const LobeRec& l, uint32_t flags) { return (l.type & flags) == l.type; }
+// (a lobe's BxDFType is never patched: membership and type tests read the template)
+PH_DEV bool lobe_sel(const GBsdf& b, uint32_t i, uint32_t flags) { return lobe_in(b, i) && lobe_matches(b.lobes[i], flags); }
 PH_DEV uint32_t bsdf_num_components(const GBsdf& b, uint32_t flags) {
     uint32_t c = 0;
-    for (uint32_t i = 0; i < b.n; i++) if (lobe_matches(b.lobes[i], flags)) c++;
+    for (uint32_t i = 0; i < b.n; i++) if (lobe_sel(b, i, flags)) c++;
     return c;
 }
 PH_DEV spec bsdf_f(const GBsdf& b, f3 wo_w, f3 wi_w, uint32_t flags) {  // bsdf.rs:133-158
@@ -340,17 +405,17 @@ PH_DEV spec bsdf_f(const GBsdf& b, f3 wo_w, f3 wi_w, uint32_t flags) {  // bsdf.
     const bool reflect = dot(wi_w, b.ng) * dot(wo_w, b.ng) > 0.0f;
     spec f = mks1(0.0f);
     for (uint32_t i = 0; i < b.n; i++) {
-        const LobeRec& l = b.lobes[i];
-        if (lobe_matches(l, flags) && ((reflect && (l.type & BX_REFL)) || (!reflect && (l.type & BX_TRANS)))) f = f + lobe_f(l, wo, wi);
+        const uint32_t ty = b.lobes[i].type;
+        if (lobe_sel(b, i, flags) && ((reflect && (ty & BX_REFL)) || (!reflect && (ty & BX_TRANS)))) f = f + lobe_f(lobe_at(b, i), wo, wi);
     }
     return f;
 }
 PH_DEV float bsdf_pdf(const GBsdf& b, f3 wo_w, f3 wi_w, uint32_t flags) {  // bsdf.rs:331-356
-    if (b.n == 0) return 0.0f;
+    if ((b.keep & ((b.n >= 32u) ? 0xFFFFFFFFu : ((1u << b.n) - 1u))) == 0u) return 0.0f;   // `self.bxdfs.len() == 0`
     const f3 wo = w2l(b, wo_w), wi = w2l(b, wi_w);
     if (wo.z == 0.0f) return 0.0f;
     uint32_t matching = 0; float pdf = 0.0f;
-    for (uint32_t i = 0; i < b.n; i++) if (lobe_matches(b.lobes[i], flags)) { matching++; pdf += lobe_pdf(b.lobes[i], wo, wi); }
+    for (uint32_t i = 0; i < b.n; i++) if (lobe_sel(b, i, flags)) { matching++; pdf += lobe_pdf(lobe_at(b, i), wo, wi); }
     return matching > 0 ? ph_div(pdf, (float)matching) : 0.0f;
 }
 // BSDF::sample_f (bsdf.rs:160-292); a failed sample is BxDFSample::default(): zeros and type NONE
@@ -361,23 +426,23 @@ PH_DEV void bsdf_sample_f(const GBsdf& b, f3 wo_w, f2 u, uint32_t flags, spec& f
     uint32_t comp = f2u_sat(floorf(u.x * (float)matching));
     if (comp > matching - 1u) comp = matching - 1u;
     uint32_t idx = 0, count = comp;
-    for (uint32_t i = 0; i < b.n; i++) if (lobe_matches(b.lobes[i], flags)) { if (count == 0u) { idx = i; break; } count--; }
+    for (uint32_t i = 0; i < b.n; i++) if (lobe_sel(b, i, flags)) { if (count == 0u) { idx = i; break; } count--; }
     const f2 ur = mk2(pminf(u.x * (float)matching - (float)comp, kOneMinusEps), u.y);
     const f3 wo = w2l(b, wo_w);
     if (wo.z == 0.0f) return;
     spec f; float pdf; f3 wi;
-    const uint32_t st = lobe_sample_f(b.lobes[idx], wo, ur, f, pdf, wi);
+    const uint32_t st = lobe_sample_f(lobe_at(b, idx), wo, ur, f, pdf, wi);
     if (pdf == 0.0f) return;
     const f3 wi_w = l2w(b, wi);
     if (!(st & BX_SPEC) && matching > 1u)
-        for (uint32_t i = 0; i < b.n; i++) if (i != idx && lobe_matches(b.lobes[i], flags)) pdf += lobe_pdf(b.lobes[i], wo, wi);
+        for (uint32_t i = 0; i < b.n; i++) if (i != idx && lobe_sel(b, i, flags)) pdf += lobe_pdf(lobe_at(b, i), wo, wi);
     if (matching > 1u) pdf = ph_div(pdf, (float)matching);
     if (!(st & BX_SPEC)) {
         const bool reflect = dot(wi_w, b.ng) * dot(wo_w, b.ng) > 0.0f;
         f = mks1(0.0f);
         for (uint32_t i = 0; i < b.n; i++) {
-            const LobeRec& l = b.lobes[i];
-            if (lobe_matches(l, flags) && ((reflect && (l.type & BX_REFL)) || (!reflect && (l.type & BX_TRANS)))) f = f + lobe_f(l, wo, wi);
+            const uint32_t ty = b.lobes[i].type;
+            if (lobe_sel(b, i, flags) && ((reflect && (ty & BX_REFL)) || (!reflect && (ty & BX_TRANS)))) f = f + lobe_f(lobe_at(b, i), wo, wi);
         }
     }
     f_out = f; pdf_out = pdf; wi_out = wi_w; type_out = st;

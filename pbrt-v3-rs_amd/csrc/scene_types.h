@@ -88,6 +88,7 @@ struct alignas(16) LobeRec {
     float scale0[3], ur_raw;              //   (glass.rs:110-141): 1 = the lobe of hits where urough == vrough == 0, 2 = a lobe of the other hits; ur_raw / vr_raw: the constant
     float scale1[3], vr_raw;              //   roughnesses before remapping.  scale0: innermost ScaledBxDF scale
     uint32_t ax_tex1, ay_tex1, remap, sigma_tex1;  // float textures for the Trowbridge-Reitz roughness (remapped per hit if `remap`) / MatteMaterial's sigma: 0 or 1 + id
+    uint32_t slot0, pad0_[3];             // the first colour slot of TexOut this lobe's textured colours come from (set at upload: the slots taken by the lobes in front of it)
     float pre[3]; uint32_t has_pre;       // 1: a textured colour of this lobe is multiplied by `pre`, then tested (UberMaterial: `op * kd.evaluate().clamp_default()`, uber.rs:133);
                                           // 2: the texel is tested, then multiplied (TranslucentMaterial: `if !kd.is_black() { add(r * kd) }`, translucent.rs:77-84, :87) -- PH_PRE_RAW_TEST
                                           // 3: UberMaterial with an OPACITY TEXTURE: the colour is op(hit) * (texel, or the constant kept in `pre`) -- PH_PRE_OPACITY; 4: the pass-through
@@ -126,7 +127,7 @@ struct MaterialRec {  // matte fast path (materials/src/matte.rs with constant t
 // clamped (and pre-multiplied) colours of the material's textured lobe colours, in template-lobe order (r before t).
 #define PH_HIT_COLS 6
 struct TexOut { float ns[3]; uint32_t bumped; float dpdu_s[3]; uint32_t lambert; float col[PH_HIT_COLS][4]; };  // 128 B; col[0][3], col[1][3]: the per-hit (alpha_x, alpha_y) or Oren-Nayar (A, B); col[2][3]: the per-hit index of refraction; lambert: sigma evaluated to 0; bumped bit 8 + k: colour k's texel was black before its PH_PRE_RAW_TEST product
-#define PH_HIT_LOBES 8   // per-thread slots for the per-hit lobe list of a textured material (= MAX_BXDFS, bsdf.rs:22: uber has up to 5, a mix up to 8)
+#define PH_HIT_LOBES 8   // lobes a material's template list may hold (= MAX_BXDFS, bsdf.rs:22: uber has up to 5, a mix up to 8): a hit's own list is a bit mask over them
 
 // ---- textures (textures/src/*.rs, core/src/mipmap/mod.rs).  A texture is a postfix program over a small value stack: the host
 // flattens the scale / mix tree once (api.hip), the device runs it per hit (texture.h).  Float-valued textures are carried as three equal

@@ -6,6 +6,7 @@
 // same policy as the trigonometric functions: DESIGN.md section 2).
 #pragma once
 #include "pt_device.h"
+#include "bsdf_general.h"
 
 namespace ph {
 
@@ -533,15 +534,6 @@ PH_DEV spec tex_eval_clamped(const DeviceScene* dsc, uint32_t tex, const TexCtx&
     const spec v = tex_eval<SIMPLE, NODIFF>(dsc, tex, ctx);
     return mks(pclampf(v.r, 0.0f, kInf), pclampf(v.g, 0.0f, kInf), pclampf(v.b, 0.0f, kInf));
 }
-// The hit's own lobe list of a textured material: the template lobes with their textured colours filled in, a lobe dropped where the reference
-// would not add it (`if !kd.is_black()`, plastic.rs:63 / :70, mirror.rs:55, matte.rs:66, uber.rs:134-160; FresnelBlend / FresnelSpecular unless both
-// colours are black, substrate.rs:62, glass.rs:76-78).
-PH_DEV bool lobe_keep(const LobeRec& l) {
-    const bool r_black = l.r[0] == 0.0f && l.r[1] == 0.0f && l.r[2] == 0.0f, t_black = l.t[0] == 0.0f && l.t[1] == 0.0f && l.t[2] == 0.0f;
-    // which colour decides whether the reference adds the lobe: both for the two-colour lobes, t for the transmission lobes, r otherwise
-    return (l.kind == PH_LK_FRESNEL_BLEND || l.kind == PH_LK_FRESNEL_SPEC) ? !(r_black && t_black)
-         : ((l.kind == PH_LK_SPEC_T || l.kind == PH_LK_MICRO_T || l.kind == PH_LK_LAMBERT_T) ? !t_black : !r_black);
-}
 // texture pass: the textured colours of a material's template lobes at this hit, in lobe order (r before t), clamped and pre-multiplied
 PH_DEV float d_log(float x) { return (float)log((double)x); }
 // the lobe's scalar parameters when they are textures: MatteMaterial's sigma -> Oren-Nayar A, B (matte.rs:64-70, oren_nayar.rs:28-39); roughness -> Trowbridge-Reitz alpha,
@@ -567,10 +559,6 @@ PH_DEV void eval_lobe_scalars(const DeviceScene* dsc, const LobeRec& l, const Te
         if (l.alt && raw[0] == 0.0f && raw[1] == 0.0f) out.lambert |= 2u;
     }
 }
-// does this colour of the lobe come from the texture pass?  (r before t; PH_PRE_OPACITY / PH_PRE_PASSTHROUGH lobes always: their colour depends on the hit's opacity)
-PH_DEV bool lobe_is_reflection(const LobeRec& l) { return l.kind == PH_LK_LAMBERT || l.kind == PH_LK_MICRO_R; }   // (of a PH_PRE_RT lobe: LambertianReflection / MicrofacetReflection against their transmission twins)
-PH_DEV bool lobe_slot_r(const LobeRec& l) { return l.has_pre == PH_PRE_RT ? lobe_is_reflection(l) : (l.r_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind != PH_LK_SPEC_T)); }
-PH_DEV bool lobe_slot_t(const LobeRec& l) { return l.has_pre == PH_PRE_RT ? !lobe_is_reflection(l) : (l.t_tex1 != 0u || (l.has_pre == PH_PRE_OPACITY && l.kind == PH_LK_SPEC_T) || l.has_pre == PH_PRE_PASSTHROUGH); }
 template <bool SIMPLE = false, bool NODIFF = false>
 PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const MaterialRec& mr, const LobeRec* tmpl, uint32_t n, const TexCtx& ctx, TexOut& out) {
     uint32_t k = 0;
@@ -616,39 +604,7 @@ PH_DEV void eval_lobe_colours(const DeviceScene* dsc, const MaterialRec& mr, con
         if (l.k_tex1) put(tex_eval<SIMPLE, NODIFF>(dsc, l.k_tex1 - 1u, ctx));
     }
 }
-// shade pass: the hit's own lobe list = template lobes with the texture pass's colours filled in, a lobe dropped where the reference would not add it.
-// eta_out: BSDF::eta of the hit when the material is an uber with an opacity texture (uber.rs:128-137), untouched otherwise.
-PH_DEV uint32_t build_hit_lobes(const MaterialRec& mr, const LobeRec* tmpl, uint32_t n, const TexOut* in, LobeRec* out, float& eta_out) {
-    uint32_t k = 0, ci = 0;
-    float s1[3] = {1.0f, 1.0f, 1.0f}, s2[3] = {0.0f, 0.0f, 0.0f};
-    if (mr.amount_tex1) { for (int c = 0; c < 3; c++) { s1[c] = in->col[0][c]; s2[c] = pclampf(1.0f - s1[c], 0.0f, kInf); } ci = 1; }   // mix.rs:59-60
-    // materials whose lobes need neither per-hit scalars nor the raw-black bits leave the record's header unwritten (texture_kernel): do not read it
-    const uint32_t hdr_lambert = mr.tex_hdr ? in->lambert : 0u, hdr_bumped = mr.tex_hdr ? in->bumped : 0u;
-    const bool is_specular = (hdr_lambert & 2u) != 0u;
-    bool passthrough = false;
-    for (uint32_t i = 0; i < n && k < PH_HIT_LOBES; i++) {
-        LobeRec l = tmpl[i];
-        if (l.sigma_tex1) { l.kind = (hdr_lambert & 1u) ? PH_LK_LAMBERT : PH_LK_OREN; l.a = in->col[0][3]; l.b = in->col[1][3]; }
-        if (l.ax_tex1 || l.ay_tex1) { l.ax = in->col[0][3]; l.ay = in->col[1][3]; }
-        // the hit's index of refraction: FresnelSpecular / FresnelDielectric(1, eta) / the transmission lobes (glass.rs:113-139, uber.rs:145-176) — not the opacity pass-through, which is built with (1, 1)
-        if (mr.index_tex1 && l.has_pre != PH_PRE_PASSTHROUGH && (l.kind == PH_LK_FRESNEL_SPEC || l.fresnel == PH_FR_DIEL)) l.eta_b = in->col[2][3];
-        bool raw_black = false;
-        if (lobe_slot_r(l) && ci < PH_HIT_COLS) { l.r[0] = in->col[ci][0]; l.r[1] = in->col[ci][1]; l.r[2] = in->col[ci][2]; raw_black = raw_black || ((hdr_bumped >> (8u + ci)) & 1u); ci++; }
-        if (lobe_slot_t(l) && ci < PH_HIT_COLS) { l.t[0] = in->col[ci][0]; l.t[1] = in->col[ci][1]; l.t[2] = in->col[ci][2]; raw_black = raw_black || ((hdr_bumped >> (8u + ci)) & 1u); ci++; }
-        if (l.eta_tex1 && ci < PH_HIT_COLS) { l.c_eta_t[0] = in->col[ci][0]; l.c_eta_t[1] = in->col[ci][1]; l.c_eta_t[2] = in->col[ci][2]; ci++; }
-        if (l.k_tex1 && ci < PH_HIT_COLS) { l.c_k[0] = in->col[ci][0]; l.c_k[1] = in->col[ci][1]; l.c_k[2] = in->col[ci][2]; ci++; }
-        if (l.amt & 3u) {
-            float* sc = ((l.amt >> 8) & 3u) == 0u ? l.scale0 : l.scale1;
-            const float* v = (l.amt & 3u) == 1u ? s1 : s2;
-            sc[0] = v[0]; sc[1] = v[1]; sc[2] = v[2];
-        }
-        if ((l.alt == 1u && !is_specular) || (l.alt == 2u && is_specular)) continue;   // glass.rs:112-141: FresnelSpecular, or the microfacet pair (slots consumed either way)
-        // TranslucentMaterial's lobes: the texel decided (an untextured one exists because its constant passed the test when the material was made)
-        if ((l.has_pre == PH_PRE_RAW_TEST || l.has_pre == PH_PRE_RT) ? !raw_black : lobe_keep(l)) { if (l.has_pre == PH_PRE_PASSTHROUGH) passthrough = true; out[k++] = l; }
-    }
-    if (mr.uber_eta) eta_out = passthrough ? 1.0f : (mr.index_tex1 ? in->col[2][3] : mr.bsdf_eta_alt);
-    return k;
-}
+// (shade pass: the hit's lobe list is the template seen through this record — bsdf_general.h: patch_lobe / hit_lobe_mask use the same slot rules)
 
 // Material::bump (core/src/material.rs:62-101): the displacement texture is evaluated at the hit and at two shifted contexts, the shading dp/du,
 // dp/dv are tilted accordingly and set_shading_geometry(.., false) (surface_interaction.rs:152-173) makes the new shading normal.  Out of line; the shading frame's other half (dp/dv, dn/du, dn/dv: triangle.rs:631-721), which the integrator does not carry, is rebuilt from the TriRec.

@@ -70,7 +70,6 @@ struct WfParams {
     SpatialRec spatial;
     // materials that evaluate a texture per hit (texture.h): device copy of `cam` for the out-of-line evaluation
     const CameraRec* cam_dev; uint32_t textured;
-    LobeRec* hit_lobes;  // general-BSDF kernel only: PH_HIT_LOBES slots per thread of the grid
     TexOut* tex_out;     // texture pass -> shade pass, one record per path of the chunk
     uint32_t any_rt;     // some TranslucentMaterial decides per hit whether it has a BSDF at all (MaterialRec::rt_mode): the texture pass runs first and says so in TexOut::bumped
     // ray binning between rounds (raysort.h): the bin key of every ray the shade pass emits, next to the ray
@@ -268,7 +267,7 @@ template <> struct BsdfOps<false> {
     static PH_DEV void sample_ns(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi) { bsdf_sample_f(b, wo, u, f, pdf, wi); }
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, f, pdf, wi); type = BX_REFL | BX_DIFF; }
     static PH_DEV float eta(const T&) { return 1.0f; }
-    static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec*, const MaterialRec& mr) {  // MatteMaterial: Kd and / or sigma of this hit
+    static PH_DEV void apply_textures(T& b, const TexOut* to, const MaterialRec& mr) {  // MatteMaterial: Kd and / or sigma of this hit
         if (mr.kd_tex1) { const spec kd = mks(to->col[0][0], to->col[0][1], to->col[0][2]); b.r = kd; b.has_bxdf = !is_black(kd); }
         if (mr.sigma_tex1) { b.oren = (to->lambert & 1u) == 0u; b.a = to->col[0][3]; b.b = to->col[1][3]; }
     }
@@ -282,10 +281,10 @@ template <> struct BsdfOps<true> {
     static PH_DEV void sample_ns(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi) { uint32_t t; bsdf_sample_f(b, wo, u, BX_ALL & ~BX_SPEC, f, pdf, wi, t); }
     static PH_DEV void sample_all(const T& b, f3 wo, f2 u, spec& f, float& pdf, f3& wi, uint32_t& type) { bsdf_sample_f(b, wo, u, BX_ALL, f, pdf, wi, type); }
     static PH_DEV float eta(const T& b) { return b.eta; }
-    // the hit's own lobe list goes to the thread's slots of WfParams::hit_lobes
-    static PH_DEV void apply_textures(T& b, const TexOut* to, LobeRec* slots, const MaterialRec& mr) {
-        b.n = build_hit_lobes(mr, b.lobes, b.n, to, slots, b.eta);
-        b.lobes = slots;
+    // the hit's own lobe list: which template lobes it holds; their textured fields are read from the texture pass's record when a lobe is used (bsdf_general.h)
+    static PH_DEV void apply_textures(T& b, const TexOut* to, const MaterialRec& mr) {
+        b.keep = hit_lobe_mask(mr, b.lobes, b.n, to, b.eta);
+        b.hit = to;
     }
 };
 
@@ -432,7 +431,7 @@ __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(Dev
                         if (TEX && tex_hit) {
                             const MaterialRec& mr = sc.materials[m.material];
                             if (mr.textured)
-                                BO::apply_textures(bsdf, w.tex_out + i, w.hit_lobes ? w.hit_lobes + ((size_t)blockIdx.x * PH_SHADE_BLOCK + tid) * PH_HIT_LOBES : nullptr, mr);
+                                BO::apply_textures(bsdf, w.tex_out + i, mr);
                         }
                         PHC_END(2);
                         PHC_BEGIN(3);
@@ -776,7 +775,7 @@ struct Wavefront {
     int sb[4] = {0, 0, 0, 0}, ntx = 0, nty = 0, tile_size = 0, part = 0, parts = 0;
     uint32_t slot_w = 0, slot_h = 0;
     int tiles_key[12] = {0}; bool tiles_valid = false;  // what the lists above (and their device copies) were built for
-    DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats, d_cam, d_hit_lobes, d_tex_out;
+    DevBuf d_tiles, d_px, d_rays_cl[2], d_hits, d_rays_sh, d_occ, d_live[2], d_ctr, d_stats, d_cam, d_tex_out;
     DevBuf d_sL, d_sbeta, d_sA, d_sf2, d_sbold, d_sidx, d_sprev, d_recL, d_recpy, d_rounded, d_tilebuf, d_xyz, d_w;
     DevBuf d_vox_slot, d_sp_pool, d_sp_list, d_sp_ctr, d_sp_halton;  // SpatialLightDistribution tables (spatial.h)
     DevBuf d_order, d_sort_bins, d_heads, d_keys_cl, d_keys_sh;  // ray binning between rounds (raysort.h), per-XCD queue heads
@@ -791,7 +790,7 @@ void free_wavefront(PbrtHipScene* s) {
     Wavefront* w = s->wf;
     if (!w) return;
     for (DevBuf* b : {&w->d_tiles, &w->d_px, &w->d_rays_cl[0], &w->d_rays_cl[1], &w->d_hits, &w->d_rays_sh, &w->d_occ, &w->d_live[0], &w->d_live[1], &w->d_ctr,
-                      &w->d_stats, &w->d_cam, &w->d_hit_lobes, &w->d_tex_out, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_sprev, &w->d_rounded, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
+                      &w->d_stats, &w->d_cam, &w->d_tex_out, &w->d_sL, &w->d_sbeta, &w->d_sA, &w->d_sf2, &w->d_sbold, &w->d_sidx, &w->d_sprev, &w->d_rounded, &w->d_recL, &w->d_recpy, &w->d_tilebuf, &w->d_xyz, &w->d_w,
                       &w->d_vox_slot, &w->d_sp_pool, &w->d_sp_list, &w->d_sp_ctr, &w->d_sp_halton, &w->d_order, &w->d_sort_bins, &w->d_heads, &w->d_keys_cl, &w->d_keys_sh, &w->d_morder, &w->d_mkeys, &w->d_mbins})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : w->events) (void)hipEventDestroy(e);
@@ -1103,14 +1102,9 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     static const bool split_traversal = std::getenv("PBRT_HIP_SPLIT_TRAVERSAL") != nullptr;  // measurement aid: one launch per ray kind
     uint64_t regular = 0, shadow = 0;
     std::vector<ph::IterCounters> hctr((size_t)n_iter_cap + 2);
-    // general materials with per-hit textures keep PH_HIT_LOBES LobeRec slots per thread of the grid: a smaller grid (each block loops more) bounds that buffer
-    const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, (s->textured_materials && s->general_materials) ? 256 * 4 : 256 * 16);
-    wp.hit_lobes = nullptr; wp.tex_out = nullptr;
+    const uint32_t shade_blocks = (uint32_t)std::min<size_t>((B + 255) / 256, 256 * 16);
+    wp.tex_out = nullptr;
     if (s->textured_materials) wp.tex_out = (TexOut*)w.d_tex_out.p;
-    if (s->textured_materials && s->general_materials) {
-        if ((rc = ensure_buf(s, w.d_hit_lobes, (size_t)shade_blocks * PH_SHADE_BLOCK * PH_HIT_LOBES * sizeof(LobeRec)))) return rc;
-        wp.hit_lobes = (LobeRec*)w.d_hit_lobes.p;
-    }
 
     for (uint32_t s0 = 0; s0 < spp; s0 += chunk_spp) {
         const uint32_t cs = std::min(chunk_spp, spp - s0);
