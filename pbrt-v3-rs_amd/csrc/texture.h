@@ -145,8 +145,23 @@ static __device__ const uint8_t kNoisePerm[512] = {
     108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107,
     49, 192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66,
     215, 61, 156, 180};
+// The table is read three levels deep per lattice corner, eight corners per noise value, up to eighteen values per bump-mapped hit (three evaluations of an fbm displacement):
+// a chain of ~50 dependent byte loads.  Kernels that evaluate procedural textures copy it to LDS once per block (noise_lds_fill) and the chain runs at LDS latency, off the
+// texture-addresser (round 4: the bump phase was 35 % of configs[4]'s texture pass, profiles/r04_phase_clock_shade_texture_config4_*).
+#if defined(__HIP_DEVICE_COMPILE__)
+static __shared__ uint8_t g_noise_perm_lds[512];
+#define PH_NOISE_PERM(i) g_noise_perm_lds[i]
+// every kernel from which the general evaluator (tex_eval<false, *>) can be reached calls this first, all threads of the block
+PH_DEV void noise_lds_fill() {
+    for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) g_noise_perm_lds[i] = kNoisePerm[i];
+    __syncthreads();
+}
+#else
+#define PH_NOISE_PERM(i) kNoisePerm[i]
+PH_DEV void noise_lds_fill() {}   // (the host pass of the compiler only parses the kernels)
+#endif
 PH_DEV float noise_grad(long long x, long long y, long long z, float dx, float dy, float dz) {
-    const int h = kNoisePerm[kNoisePerm[kNoisePerm[x] + y] + z] & 15;
+    const int h = PH_NOISE_PERM(PH_NOISE_PERM(PH_NOISE_PERM(x) + y) + z) & 15;
     const float u = (h < 8 || h == 12 || h == 13) ? dx : dy;
     const float v = (h < 4 || h == 12 || h == 13) ? dy : dz;
     return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
@@ -719,6 +734,7 @@ static __device__ __forceinline__ bool alpha_accept_lean(const DeviceScene& sc, 
     return true;
 }
 
+static __device__ __forceinline__ void alpha_general_prepare() { noise_lds_fill(); }
 // The alpha-mask test of Triangle::intersect / intersect_p (triangle.rs:587-607, 868-898), declared in traverse.h: isect_local carries the hit point
 // (in the triangle's own space), the interpolated uv and no differentials.
 static __device__ __noinline__ bool alpha_accept(const DeviceScene* dsc, uint32_t tri_index, float b0, float b1, float b2, uint32_t any_hit) {

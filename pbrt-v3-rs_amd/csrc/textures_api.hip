@@ -441,6 +441,7 @@ int pbrt_hip_add_material_matte_tex(PbrtHipScene* s, uint32_t kd_tex, float sigm
 // ---- texture probes (test aids: the device's texture evaluation on explicit inputs, and the pyramid the host built) ----------------
 namespace ph {
 __global__ void texture_eval_kernel(DeviceScene sc, uint32_t tex, uint32_t n, const float* in, float* out, uint32_t nodiff) {
+    noise_lds_fill();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* q = in + 15 * (size_t)i;

@@ -348,6 +348,7 @@ PH_DEV void tri_bary(const RayState& r, f3 p0, f3 p1, f3 p2, float& b0_out, floa
 //   ALPHA = 2: any texture class: an out-of-line call of the general evaluator (alpha_accept).  The callee's register appetite becomes the kernel's (336 VGPRs, one wave
 //              per SIMD: measured 30 x slower on a foliage scene than ALPHA = 1) — correct, and kept for the procedural masks only.
 static __device__ __noinline__ bool alpha_accept(const DeviceScene* dsc, uint32_t tri_index, float b0, float b1, float b2, uint32_t any_hit);
+static __device__ __forceinline__ void alpha_general_prepare();
 static __device__ __forceinline__ bool alpha_accept_lean(const DeviceScene& sc, uint32_t prim, uint32_t mesh, float b0, float b1, float b2, bool any_hit);
 // ALPHA_MIN > 0 (round 4) makes the alpha-mask test a PHASE of its own.  The test is a chain of dependent fetches (mesh record -> vertex indices -> uv -> texture program -> MIPMap
 //   record -> four texels): on configs[4] it ran in 85 % of the leaf steps for 3.2 lanes on average and took a third of the waves' cycles (scripts/phase_clock.py,
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
     __syncthreads();
 #endif
     PHC_BEGIN(7);
+    if (ALPHA == 2) alpha_general_prepare();   // (the general evaluator's Perlin table, into LDS: texture.h)
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * PH_TRAV_BLOCK + tid;
     const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));

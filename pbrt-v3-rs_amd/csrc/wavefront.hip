@@ -201,6 +201,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     const uint32_t n_work = w.m_order ? w.m_bins[sc.ms_tex_keys] : w.ctr[it].n_live;
     const uint32_t* live_in = w.live[it & 1];
     const RayIn* rays_in = w.rays_cl[it & 1];
+    if (!SIMPLE) noise_lds_fill();   // the procedural classes' Perlin table, into LDS (texture.h)
+#if PH_PHASE_CLOCK && defined(__HIP_DEVICE_COMPILE__)
+    __shared__ unsigned long long phc_lds[3 * PHC_N];
+    if (threadIdx.x < 3 * PHC_N) phc_lds[threadIdx.x] = 0ull;
+    __syncthreads();
+#endif
+    PHC_BEGIN(3);
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_work; j += gridDim.x * blockDim.x) {
         const uint32_t i = w.m_order ? w.m_order[j] : j;   // the path's position in the round's list
         const uint4 idx4 = w.s_idx[it & 1][i];
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
         const float4 h0 = hp[0];
         if (__float_as_uint(h0.y) == 0xFFFFFFFFu) continue;
         const float4 h1 = hp[1];
+        PHC_BEGIN(0);
         const RayIn ray = load_ray(rays_in + idx4.x);
         const f3 rd = mk3(ray.dx, ray.dy, ray.dz);
         MeshRec m;
@@ -227,19 +235,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
         }
         const TexCtx ctx = hit_tex_ctx(sc.self, w.cam_dev, w.sp.spp, __float_as_uint(h1.y), __float_as_uint(h1.z), mk3(h0.z, h0.w, h1.x), si.p, si.n,
                                        mk3(ray.ox, ray.oy, ray.oz), rd, p_film, lens, camera_ray);
+        PHC_END(0);
         TexOut out;
         out.bumped = 0u; out.lambert = 0u;
         out.ns[0] = si.ns.x; out.ns[1] = si.ns.y; out.ns[2] = si.ns.z; out.dpdu_s[0] = si.dpdu_s.x; out.dpdu_s[1] = si.dpdu_s.y; out.dpdu_s[2] = si.dpdu_s.z;
         if (mr.bump_tex1) {
+            PHC_BEGIN(1);
             BumpIn bi; bi.tex = mr.bump_tex1 - 1u; bi.tri_index = __float_as_uint(h1.y); bi.inst = __float_as_uint(h1.z); bi.bary = mk3(h0.z, h0.w, h1.x);
             bi.p = si.p; bi.n = si.n; bi.ns = si.ns; bi.dpdu_s = si.dpdu_s; bi.c = ctx;
             BumpOut bo;
             hit_bump<SIMPLE, !CAMERA>(sc.self, &bi, &bo);
             out.ns[0] = bo.ns.x; out.ns[1] = bo.ns.y; out.ns[2] = bo.ns.z; out.dpdu_s[0] = bo.dpdu_s.x; out.dpdu_s[1] = bo.dpdu_s.y; out.dpdu_s[2] = bo.dpdu_s.z;
             out.bumped = 1u;
+            PHC_END(1);
         }
         for (int k = 0; k < PH_HIT_COLS; k++) out.col[k][0] = out.col[k][1] = out.col[k][2] = out.col[k][3] = 0.0f;
-        if (mr.textured) eval_lobe_colours<SIMPLE, !CAMERA>(sc.self, mr, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out);
+        if (mr.textured) { PHC_BEGIN(2); eval_lobe_colours<SIMPLE, !CAMERA>(sc.self, mr, sc.lobes + mr.lobe_base, mr.n_lobes, ctx, out); PHC_END(2); }
 
         // only what the shade pass reads for this material: the two header quads if it needs them, then the colour slots in use (a matte with an image map: 16 of the 128 bytes)
         float4* dst = reinterpret_cast<float4*>(w.tex_out + j);   // by position in the round's (sorted) walk: the shade pass's thread j reads it from there
@@ -247,6 +258,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
         if (mr.tex_hdr) { dst[0] = src[0]; dst[1] = src[1]; }
         for (uint32_t k = 0; k < mr.tex_cols; k++) dst[2 + k] = src[2 + k];
     }
+    PHC_END(3);
+#if PH_PHASE_CLOCK && defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+    if (threadIdx.x < 3 * PHC_N && w.phase) atomicAdd(w.phase + 3 * PHC_N + threadIdx.x, phc_lds[threadIdx.x]);   // (behind the shade kernel's tallies)
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -293,7 +309,11 @@ template <> struct BsdfOps<true> {
 // Waves per SIMD the shade kernels are compiled for.  40 KB of LDS per block allow 4 blocks per CU; the one-lobe kernel fits 128 VGPRs with
 // 51 spilled registers and gains 6 % from the fourth wave, the general-BSDF kernel would spill 181 and loses, so it stays at 3; so do the
 // texture variants, whose out-of-line calls keep many values live (textured matte: 279 spilled registers at 4 waves, 45 at 3; 19.5 -> 15.9 ms).
-#define PH_SHADE_ATTR __attribute__((amdgpu_waves_per_eu((GEN || TEX) ? 3 : 4, (GEN || TEX) ? 3 : 4)))
+#ifndef PH_SHADE_GEN_TEX_WAVES
+#define PH_SHADE_GEN_TEX_WAVES 3
+#endif
+#define PH_SHADE_WAVES(GEN, TEX) ((GEN) && (TEX) ? PH_SHADE_GEN_TEX_WAVES : (((GEN) || (TEX)) ? 3 : 4))
+#define PH_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PH_SHADE_WAVES(GEN, TEX), PH_SHADE_WAVES(GEN, TEX))))
 template <bool GEN, bool TEX = false>
 __global__ __launch_bounds__(PH_SHADE_BLOCK) PH_SHADE_ATTR void shade_kernel(DeviceScene sc, WfParams w, int it) {
     using BO = BsdfOps<GEN>;
@@ -978,7 +998,7 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     static const bool mq_env = []() { const char* e = std::getenv("PBRT_HIP_MATERIAL_QUEUES"); return !(e && std::atoi(e) == 0); }();
     const bool mat_queues = mq_env && (s->general_materials || s->textured_materials);
     if ((rc = ensure_buf(s, w.d_ctr, (size_t)(n_iter_cap + 2) * sizeof(ph::IterCounters)))) return rc;
-    if ((rc = ensure_buf(s, w.d_stats, 64 + 3 * PHC_N * 8))) return rc;   // DevStats (+ the shade kernel's phase tallies in measurement builds)
+    if ((rc = ensure_buf(s, w.d_stats, 64 + 6 * PHC_N * 8))) return rc;   // DevStats (+ the shade kernel's phase tallies in measurement builds)
     if ((rc = ensure_buf(s, w.d_recL, (size_t)n_px * spp * 16))) return rc;
     if ((rc = ensure_buf(s, w.d_recpy, (size_t)n_px * spp * 4))) return rc;
     if ((rc = ensure_buf(s, w.d_rounded, (size_t)n_px))) return rc;
@@ -1078,7 +1098,7 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
     wp.m_order = mat_queues ? (const uint32_t*)w.d_morder.p : nullptr; wp.m_bins = mat_queues ? (const uint32_t*)w.d_mbins.p : nullptr;
 
     if (spatial) { if ((rc = setup_spatial(s, wp.spatial))) return rc; }
-    PH_CHECK(s, hipMemsetAsync(w.d_stats.p, 0, 64 + 3 * PHC_N * 8, s->stream));
+    PH_CHECK(s, hipMemsetAsync(w.d_stats.p, 0, 64 + 6 * PHC_N * 8, s->stream));
     wp.phase = PH_PHASE_CLOCK ? (unsigned long long*)((char*)w.d_stats.p + 64) : nullptr;
     bool identity = true;  // does pixel_bounds cover every pixel of this rank's tiles?
     for (const ph::TileInfo& t : w.tiles)
@@ -1223,6 +1243,12 @@ int render_tiles(PbrtHipScene* s, int max_depth, float rr_threshold, int light_s
         for (int k = 0; k < 11; k++)
             std::fprintf(stderr, "SHADE_PHASE %-17s cycles %14llu (%5.1f %% of the kernel)  executions %12llu  mean active lanes %5.1f\n", names[k], ph_[k], ph_[10] ? 100.0 * (double)ph_[k] / (double)ph_[10] : 0.0,
                          ph_[PHC_N + k], ph_[PHC_N + k] ? (double)ph_[2 * PHC_N + k] / (double)ph_[PHC_N + k] : 0.0);
+        unsigned long long pt_[3 * PHC_N];
+        PH_CHECK(s, hipMemcpy(pt_, (const char*)w.d_stats.p + 64 + 3 * PHC_N * 8, sizeof pt_, hipMemcpyDeviceToHost));
+        static const char* tnames[4] = {"hit+context", "bump", "lobe_colours", "whole_kernel"};
+        for (int k = 0; k < 4; k++)
+            std::fprintf(stderr, "TEXTURE_PHASE %-13s cycles %14llu (%5.1f %% of the kernel)  executions %12llu  mean active lanes %5.1f\n", tnames[k], pt_[k], pt_[3] ? 100.0 * (double)pt_[k] / (double)pt_[3] : 0.0,
+                         pt_[PHC_N + k], pt_[PHC_N + k] ? (double)pt_[2 * PHC_N + k] / (double)pt_[PHC_N + k] : 0.0);
     }
 #endif
     if (out_stats) {
