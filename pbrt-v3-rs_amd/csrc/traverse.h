@@ -591,7 +591,8 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
                 if (fire_leaf || fire_alpha) {
 #pragma unroll
                     for (int ls = 0; ls < PH_LEAF_STEPS; ls++)
-                    if ((at_leaf && fire_leaf && cur < PH_NEED_POP && (cur & PH_LEAF_BIT)) || (waiting && fire_alpha)) {
+                    // (the lane's state as it is NOW: with more than one triangle per step a lane may have left its leaf, or begun to wait, in the step before; the waiting lanes join the first only)
+                    if ((has_ray && cur < PH_NEED_POP && (cur & PH_LEAF_BIT) && !(ALPHA && ALPHA_MIN > 0 && alpha_wait) && (ls == 0 ? at_leaf : true) && fire_leaf) || (ls == 0 && waiting && fire_alpha)) {
                         PHC_BEGIN(9);
                         const uint32_t ti = INST ? (cur & ~(PH_LEAF_BIT | PH_LEAF_INST_HINT)) : (cur & ~PH_LEAF_BIT);
                         const float4* tp = reinterpret_cast<const float4*>(sc.tris + ti);
