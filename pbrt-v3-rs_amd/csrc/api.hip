@@ -281,9 +281,11 @@ int upload_light_distribution(PbrtHipScene* s, int light_strategy) {
 // The traversal kernel's shape: {LEAF_MIN, REFILL_MIN, LDS_DEPTH, NODE_STEPS, waves per SIMD the kernel is compiled for (0 = the compiler's choice)}.  Slot 0 is what ships: 6 waves per
 // SIMD with 12 stack entries in LDS (the kernel needs 59 VGPRs since the round-3 register diet and would fit 8 — but a seventh wave buys nothing and costs the stack an entry: same-box,
 // configs[2] / configs[3] 689.5 / 717.0 ms of traversal per frame at 6 waves x 12 entries against 705.5 / 735.5 at 7 x 11; at 6 waves the depth is worth 12 -> 10 -> 8 -> 6 entries:
-// 687 -> 692 -> 708 -> 759 ms, a 13th nothing), lanes wait for 16 companions at leaves and for 20 idle lanes before a refill, 6 node steps per pass (27 shapes swept at 7 waves, 6 more at 6;
-// gpurun r03s - r03x, r03aw, r03ax).  Slot 1 is the shape rounds 2 shipped (24 / 12 / 5), kept for A/B runs (PBRT_HIP_TRAV_VARIANT=1): - 2.3 % traversal time from it to slot 0.
-#define PH_VARIANTS(X) X(0, 16, 20, 12, 6, 6, false) X(1, 24, 12, 12, 5, 6, false)
+// 687 -> 692 -> 708 -> 759 ms, a 13th nothing), lanes wait for 16 companions at leaves, 6 node steps per pass (27 shapes swept at 7 waves, 6 more at 6; gpurun r03s - r03x, r03aw, r03ax).
+// Round 4: since finished rays are written out at the wave's refill (traverse.h), the refill threshold is worth more — HALF the wave idle before a refill: configs[2] 711.9 / 689.8 /
+// 671.2 / 657.6 / 652.0 / 670.9 / 703.1 / 844.8 ms at 12 / 16 / 20 / 28 / 32 / 36 / 40 / 48 idle lanes (leaf threshold 12 / 16 / 20 and 5 / 6 / 8 node steps per pass within 3 ms of
+// each other at 32; configs[3] 704.2 -> 679.2, configs[1] 29.8 -> 29.4; gpurun r04ac - r04ae).  Slot 1 is the round-3 shape (refill at 20), kept for A/B runs (PBRT_HIP_TRAV_VARIANT=1).
+#define PH_VARIANTS(X) X(0, 16, 32, 12, 6, 6, false) X(1, 16, 20, 12, 6, 6, false)
 #define PH_N_VARIANTS 2
 #define PH_DEFAULT_INST_VARIANT 2   // the 5-wave instancing kernel (launch_traverse_kernel); 1 = the 4-wave form, kept as the A/B slot
 #define PH_DEFAULT_VARIANT 0
@@ -378,7 +380,7 @@ void launch_traverse_kernel(PbrtHipScene* s, int mode, uint32_t blocks, const ph
                             // instances: 1 181 ms of traversal per frame against 1 293 for the 4-wave form of round 2 (slot 1; 108 VGPRs, 12 + 13 words of LDS), gpurun r03ad; 1 115 with the deferred pops (traverse.h).  Seven more
                             // loop shapes around 24 / 12 / 5 (16-24 / 12-20 / 4-8) measured 1 308 - 1 387 ms against 1 295 at 4 waves (gpurun r03z), four at 5 waves 1 114 - 1 135 against 1 117 (r03aq).
                 case 1: PH_LAUNCH3(false, 24, 12, PH_LDS_DEPTH, 5, true, 0, false); break;
-                default: PH_LAUNCH3(false, 24, 12, 11, 5, true, 5, false); break;
+                default: PH_LAUNCH3(false, 24, 12, 11, 5, true, 5, false); break;   // (round 4, with finished rays written out at the refill: refill at 20 / 28: 1 044 / 1 101 ms against 1 030; leaf 16: 1 041; gpurun r04af)
             }
         }
         return;
