@@ -479,7 +479,8 @@ def main():
                                            if k.get("sq") and k["sq"].get("valu_issue_of_simd_quads") is not None else None),
                                  "valu": ({"issue_frac": k["sq"]["valu_issue_of_simd_quads"], "lane_util": k["sq"]["valu_lane_utilisation"],
                                            "effective": round(k["sq"]["valu_issue_of_simd_quads"] * k["sq"]["valu_lane_utilisation"], 4),
-                                           "note": "share of the SIMDs' issue quads spent on VALU instructions x share of the 64 lanes those instructions use; round 3 showed that this pipe does not bind the kernel (see limiter)"}
+                                           "note": "share of the SIMDs' issue quads spent on VALU instructions x share of the 64 lanes those instructions use; round 3 removed a sixth of these instructions without effect, round 4 "
+                                                   "halved the dependent chain without effect and gained from every cut in idle-lane time (bound_evidence): issue slots at this lane utilisation are where the waves' time goes"}
                                           if k.get("sq") and k["sq"].get("valu_issue_of_simd_quads") is not None else None),
                                  "traffic_note": "bytes per launch leaving the L2s (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE over " + str(k["dispatches"]) + " traversal launches of one frame, " +
                                                  e.get("source", "profiles/") + "; " + e.get("calibration", "") + ")"})
