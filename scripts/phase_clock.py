@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the traversal kernel's wave cycles go, per phase of its loop (a measurement build: make -C pbrt-v3-rs_amd/csrc EXTRA=-DPH_PHASE_CLOCK=1, traverse.h).
+"""Where the traversal kernel's wave cycles go, per phase of its loop (a measurement build: make -B -C pbrt-v3-rs_amd/csrc EXTRA=-DPH_PHASE_CLOCK=1 — traverse.h, wavefront.hip, phase_clock.h; the shade and texture kernels' phases are printed too).
 Renders one frame of a BASELINE configuration at reduced spp with the SHIPPING kernel shapes and prints the waves' phase clocks (stderr of the library).
 usage (on the GPU box, after the measurement build): scripts/phase_clock.py [config] [spp]"""
 import os

@@ -19,7 +19,7 @@ scene.set_traversal_counting(True)
 scene.render_path(max_depth=cfg["max_depth"])
 c = scene.traversal_counts()
 rays = c["closest"]["rays"] + c["any_hit"]["rays"]
-print(json.dumps({"form": "two-level" if os.environ.get("PBRT_HIP_TRAV_QUAD") else "binary", "rays": rays,
+print(json.dumps({"rays": rays,
                   "node_steps_per_ray": round((c["closest"]["nodes_passed"] + c["any_hit"]["nodes_passed"]) / rays, 2),
                   "tri_tests_per_ray": round((c["closest"]["tri_tests"] + c["any_hit"]["tri_tests"]) / rays, 2),
                   "entries_dropped_at_pop_per_ray": round(c["culled_pops"] / rays, 2)}))
