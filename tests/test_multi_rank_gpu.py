@@ -79,6 +79,14 @@ def test_bench_launches_its_own_ranks():
     a, b = _last_json(one.stdout), json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["scaling"] == "strong"
     assert a["film_sha256"] == b["film_sha256"] and a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+    # what a first real N-GPU line needs to be diagnosable (round-3 review): where the step's time went, every rank's share, what the collective library saw
+    assert b["rccl"]["world_size"] == 2 and b["rccl"]["backend"] == "gloo"
+    rk = b["ranks"]
+    assert len(rk["render_ms"]["per_rank"]) == 2 and rk["render_ms"]["min"] <= rk["render_ms"]["mean"] <= rk["render_ms"]["max"]
+    assert 1.0 <= rk["imbalance"] < 2.0 and sum(rk["rays_per_rank"]) == b["config"]["rays_per_frame"]
+    assert b["stage_ms"]["render"] > 0.0 and b["stage_ms"]["gather_merge"] > 0.0
+    assert b["stage_ms"]["render"] + b["stage_ms"]["gather_merge"] <= b["ms_per_step"] * 1.05
+    assert "ranks" not in a and a["stage_ms"]["gather_merge"] >= 0.0
 
 
 def test_bench_multi_handle_two_contexts():
