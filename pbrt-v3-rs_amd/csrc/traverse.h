@@ -321,9 +321,6 @@ PH_DEV void tri_bary(const RayState& r, f3 p0, f3 p1, f3 p2, float& b0_out, floa
 // utilisation on incoherent rays at wave64 (profiles/r01_v1_*); this shape keeps the node code at >80 % and only runs the leaf
 // code when a quarter of the wave needs it.  Finished lanes are refilled from a wave-local batch of PH_BATCH consecutive rays
 // (one global atomic per batch, not per refill).
-#ifndef PH_SPLIT_NODE_LOADS
-#define PH_SPLIT_NODE_LOADS 0
-#endif
 #ifndef PH_LEAF_MIN
 #define PH_LEAF_MIN 20
 #endif
@@ -532,31 +529,12 @@ __global__ __launch_bounds__(PH_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(W
         // ---- NODE_STEPS interior-node steps for every lane that is at an interior node ---------------------------------------------------
 #pragma unroll
         for (int step = 0; step < NODE_STEPS; step++) {
-#if PH_SPLIT_NODE_LOADS
-        // The node of a lane that is already at an interior node is requested BEFORE the lanes that owe a pop read their stack entry: the pop waits on LDS only, so those requests
-        // stay in flight meanwhile; the popped lanes' nodes are requested after it.  Same loads, same order of tests.
-        float4 q0, q1, q2; uint4 q3;
-        if (has_ray && !(cur & PH_LEAF_BIT)) {   // (PH_INVALID_REF and PH_NEED_POP have the leaf bit set)
-            const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
-            q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = reinterpret_cast<const uint4*>(np)[3];
-        }
-        if (has_ray && cur == PH_NEED_POP) {
-            PHC_BEGIN(8); pop_once(); PHC_END(8);
-            if (!(cur & PH_LEAF_BIT)) {
-                const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
-                q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = reinterpret_cast<const uint4*>(np)[3];
-            }
-        }
-        if (has_ray && !(cur & PH_LEAF_BIT)) {
-            PHC_BEGIN(1);
-#else
         if (has_ray && cur == PH_NEED_POP) { PHC_BEGIN(8); pop_once(); PHC_END(8); }
         if (has_ray && !(cur & PH_LEAF_BIT)) {   // (PH_INVALID_REF and PH_NEED_POP have the leaf bit set)
             PHC_BEGIN(1);
             const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
             const float4 q0 = np[0], q1 = np[1], q2 = np[2];
             const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
-#endif
             if (COUNT) c_nodes[(MIXED && ah) ? 1 : 0]++;
             // q0 = x0[0],x0[1],y0[0],y0[1]; q1 = z0[0],z0[1],x1[0],x1[1]; q2 = y1[0],y1[1],z1[0],z1[1]
             float t0, t1;
