@@ -119,11 +119,12 @@ def test_split_traversal_env_gives_the_same_film():
 
 
 def test_ab_slots_and_binning_modes_give_the_same_film():
-    """The kernels kept as A/B slots (PBRT_HIP_TRAV_VARIANT=1: the 6-wave loop shape of round 2; PBRT_HIP_INST_VARIANT=1: the 4-wave instancing kernel) and every ray-binning mode
-    (PBRT_HIP_SORT_RAYS 0 / 2 / 3) trace the frame the shipping configuration traces: the order in which a round's rays are traced, the loop thresholds and the occupancy are free
+    """The kernels kept as A/B slots (PBRT_HIP_TRAV_VARIANT=1: the round-3 loop shape; PBRT_HIP_INST_VARIANT=1: the 4-wave instancing kernel), every ray-binning mode
+    (PBRT_HIP_SORT_RAYS 0 / 2 / 3), the walk without the shade-side work queues (PBRT_HIP_MATERIAL_QUEUES=0) and the alpha-mask thresholds (PBRT_HIP_ALPHA_MIN 0 / 20) trace the
+    frame the shipping configuration traces: the order in which a round's rays are traced, the loop thresholds and the occupancy are free
     choices, the film is not."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("PBRT_HIP_TRAV_VARIANT", "PBRT_HIP_INST_VARIANT", "PBRT_HIP_SORT_RAYS"):
+    for k in ("PBRT_HIP_TRAV_VARIANT", "PBRT_HIP_INST_VARIANT", "PBRT_HIP_SORT_RAYS", "PBRT_HIP_MATERIAL_QUEUES", "PBRT_HIP_ALPHA_MIN"):
         env.pop(k, None)
 
     def run(extra_args, extra_env):
@@ -140,6 +141,22 @@ def test_ab_slots_and_binning_modes_give_the_same_film():
     inst = ["--n-tris", "500", "--instances", "40"]
     base_i = run(inst, {})
     assert run(inst, {"PBRT_HIP_INST_VARIANT": "1"}) == base_i
+    # round 4: the shade-side work queues (who shades which path when) and the company an alpha-mask verdict waits for are free choices too
+    mixed = ["--n-tris", "8000", "--material", "mixed"]
+    base_m = run(mixed, {})
+    assert run(mixed, {"PBRT_HIP_MATERIAL_QUEUES": "0"}) == base_m
+    textured = ["--n-tris", "8000", "--material", "textured"]
+    assert run(textured, {"PBRT_HIP_MATERIAL_QUEUES": "0"}) == run(textured, {})
+    c4 = ["--config", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-count", "--spp", "2", "--sm-scale", "0.05"]
+
+    def run4(extra_env):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + c4, capture_output=True, text=True, env=dict(env, **extra_env), timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = _last_json(r.stdout)
+        return d["film_sha256"], d["config"]["rays_per_frame"]
+    base_4 = run4({})   # the San-Miguel-shaped scene at a twentieth of its tessellation: instances + alpha masks + every material class
+    for e in ({"PBRT_HIP_ALPHA_MIN": "0"}, {"PBRT_HIP_ALPHA_MIN": "20"}, {"PBRT_HIP_MATERIAL_QUEUES": "0"}):
+        assert run4(e) == base_4, e
 
 
 def test_bench_nccl_code_path_with_one_rank():
