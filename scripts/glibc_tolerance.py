@@ -38,17 +38,23 @@ def report(prod, g, o):
             "max_abs_diff_over_mean": float(d.max() / mean), "rays_device": gr, "rays_oracle": orr, "ray_count_rel_diff": abs(gr - orr) / max(orr, 1)}
 
 
-def spec_case(host, cfg, crop, material="matte"):
+def spec_case(host, cfg, crop, material="matte", libm_mode=0):
     spec = pbrt_hip.SceneSpec(**cfg, crop_window=crop, material=material)
     prod = pbrt_hip.Scene()
     geom = pbrt_hip.capture_spec(spec, prod, host, device_build=True)
     g = prod.render_path(max_depth=cfg["max_depth"])
     orc = OracleScene()
     pbrt_hip.capture_spec(spec, orc, host, geometry=geom)
-    set_libm_mode(0)
+    set_libm_mode(libm_mode)   # 0 = glibc's f32 routines (what a Rust build links); 1 = f64 rounded once (what the device computes: the film must then be bit-identical)
     t0 = time.time()
-    o = orc.render_path_ex(max_depth=cfg["max_depth"], threads=16)
+    try:
+        o = orc.render_path_ex(max_depth=cfg["max_depth"], threads=16)
+    finally:
+        set_libm_mode(0)
     r = report(prod, g, o)
+    r["oracle_libm_mode"] = libm_mode
+    r["differing_pixels"] = int((g[0].view(np.uint32) != o[0].view(np.uint32)).any(axis=2).sum())
+    r["counters_equal"] = (g[2].regular_rays, g[2].shadow_rays, g[2].paths_total, g[2].paths_zero_radiance) == (o[2].regular_rays, o[2].shadow_rays, o[2].paths_total, o[2].paths_zero_radiance)
     r["oracle_seconds"] = round(time.time() - t0, 1)
     prod.close(); orc.close()
     return r
@@ -93,6 +99,9 @@ def main():
     cases = args.cases.split(",")
     if "c2full" in cases:   # the WHOLE headline frame: configs[2], 4.3 M triangles, 1024^2 @ 256 spp, depth 8 — 1.9 G rays, ~3 minutes of the oracle on 16 threads (a one-off record, not a test)
         out["configs[2] FULL FRAME 1024x1024 @ 256 spp"] = spec_case(host, dict(n_tris=4_300_000, seed=1, xres=1024, yres=1024, spp=256, max_depth=8), (0.0, 1.0, 0.0, 1.0))
+        print(json.dumps(out), flush=True)
+    if "c2full_exact" in cases:   # the same whole frame against the oracle's f64-libm mode: bit for bit
+        out["configs[2] FULL FRAME 1024x1024 @ 256 spp, f64-libm oracle"] = spec_case(host, dict(n_tris=4_300_000, seed=1, xres=1024, yres=1024, spp=256, max_depth=8), (0.0, 1.0, 0.0, 1.0), libm_mode=1)
         print(json.dumps(out), flush=True)
     if "c3" in cases:   # configs[3]: 10 M triangles, 2048^2 @ 64 spp: a 98 x 98 crop
         out["configs[3] crop 98x98 @ 64 spp"] = spec_case(host, dict(n_tris=10_000_000, seed=1, xres=2048, yres=2048, spp=64, max_depth=5), (0.47, 0.518, 0.40, 0.448))
