@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--find-c4-window", action="store_true")
     ap.add_argument("--c4-crop", default="0.30,0.35,0.50,0.589")
     ap.add_argument("--c4-spp", type=int, default=512)
+    ap.add_argument("--c4-parts", default="", help="case c4full_exact: 'a:b' = tile parts a .. b-1 of 8 of the WHOLE configs[4] frame against the f64-libm oracle, part by part (one part is ~2.5 minutes of the oracle)")
     args = ap.parse_args()
     host = pbrt_hip.Host()
     out = {}
@@ -103,6 +104,11 @@ def main():
     if "c2full_exact" in cases:   # the same whole frame against the oracle's f64-libm mode: bit for bit
         out["configs[2] FULL FRAME 1024x1024 @ 256 spp, f64-libm oracle"] = spec_case(host, dict(n_tris=4_300_000, seed=1, xres=1024, yres=1024, spp=256, max_depth=8), (0.0, 1.0, 0.0, 1.0), libm_mode=1)
         print(json.dumps(out), flush=True)
+    for name, cfg in (("c1full_exact", dict(n_tris=100_000, seed=1, xres=512, yres=512, spp=64, max_depth=5)), ("1Mfull_exact", dict(n_tris=1_000_000, seed=1, xres=512, yres=512, spp=64, max_depth=5)),
+                      ("c3full_exact", dict(n_tris=10_000_000, seed=1, xres=2048, yres=2048, spp=64, max_depth=5))):
+        if name in cases:   # whole frames of the other flat workloads against the f64-libm oracle (one-off records)
+            out[f"{name}: {cfg['n_tris']} triangles, {cfg['xres']}x{cfg['yres']} @ {cfg['spp']} spp, f64-libm oracle"] = spec_case(host, cfg, (0.0, 1.0, 0.0, 1.0), libm_mode=1)
+            print(json.dumps(out), flush=True)
     if "c3" in cases:   # configs[3]: 10 M triangles, 2048^2 @ 64 spp: a 98 x 98 crop
         out["configs[3] crop 98x98 @ 64 spp"] = spec_case(host, dict(n_tris=10_000_000, seed=1, xres=2048, yres=2048, spp=64, max_depth=5), (0.47, 0.518, 0.40, 0.448))
         print(json.dumps(out), flush=True)
@@ -113,7 +119,7 @@ def main():
         for m in ("plastic", "glass", "metal", "uber", "mixed", "textured"):
             out[f"material {m} 256x256 @ 64 spp"] = spec_case(host, dict(n_tris=100_000, seed=1, xres=256, yres=256, spp=64, max_depth=5), (0.0, 1.0, 0.0, 1.0), material=m)
             print(json.dumps({m: out[f"material {m} 256x256 @ 64 spp"]}), flush=True)
-    if "c4" in cases or args.find_c4_window:
+    if "c4" in cases or "c4full_exact" in cases or args.find_c4_window:
         from pbrt_hip.sanmiguel import SanMiguelScene
         sm = SanMiguelScene(host, scale=1.0)
         if args.find_c4_window:
@@ -136,6 +142,26 @@ def main():
             print(json.dumps({"window_px": [x0, y0, x0 + 96, y0 + 96], "crop": [x0 / 1920, (x0 + 96) / 1920, y0 / 1080, (y0 + 96) / 1080], "fractions": fr,
                               "materials": {names.get(int(i), "miss" if i < 0 else str(i)): int(c) for i, c in zip(ids, cnt)}}), flush=True)
             args.c4_crop = ",".join(repr(v) for v in (x0 / 1920, (x0 + 96) / 1920, y0 / 1080, (y0 + 96) / 1080))
+        if "c4full_exact" in cases:   # the whole 1920 x 1080 @ 512 spp frame, 7.0 G rays, as the 8 tile parts of the multi-GPU partition: each part's film and counters bit for bit
+            a, b = (int(v) for v in args.c4_parts.split(":"))
+            prod = pbrt_hip.Scene(); sm.capture(prod, 1920, 1080, args.c4_spp, device_build=True)
+            orc = OracleScene(); sm.capture(orc, 1920, 1080, args.c4_spp)
+            for part in range(a, b):
+                g = prod.render_path(max_depth=5, tile_part=part, tile_parts=8)
+                set_libm_mode(1)
+                t0 = time.time()
+                try:
+                    o = orc.render_path_ex(max_depth=5, threads=16, tile_part=part, tile_parts=8)
+                finally:
+                    set_libm_mode(0)
+                r = report(prod, g, o)
+                r["oracle_seconds"] = round(time.time() - t0, 1); r["oracle_libm_mode"] = 1
+                r["differing_pixels"] = int((g[0].view(np.uint32) != o[0].view(np.uint32)).any(axis=2).sum())
+                r["counters_equal"] = (g[2].regular_rays, g[2].shadow_rays, g[2].paths_total, g[2].paths_zero_radiance, g[2].light_distributions_created) == \
+                                      (o[2].regular_rays, o[2].shadow_rays, o[2].paths_total, o[2].paths_zero_radiance, o[2].light_distributions_created)
+                out[f"configs[4] tile part {part} of 8, 1920x1080 @ {args.c4_spp} spp, f64-libm oracle"] = r
+                print(json.dumps({f"part {part}": r}), flush=True)
+            prod.close(); orc.close()
         if "c4" in cases:
             crop = tuple(float(v) for v in args.c4_crop.split(","))
             prod = pbrt_hip.Scene(); sm.capture(prod, 1920, 1080, args.c4_spp, crop=crop, device_build=True)
