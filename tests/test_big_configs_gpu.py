@@ -260,3 +260,16 @@ def test_config1_full_size_meets_the_stated_tolerance_in_glibc_mode(host):
     # draw) changes a ray count
     assert abs(int(gst.regular_rays + gst.shadow_rays) - int(ost.regular_rays + ost.shadow_rays)) <= 2e-5 * (ost.regular_rays + ost.shadow_rays)
     prod.close(); orc.close()
+
+
+@pytest.mark.parametrize("n_tris", [100_000, 1_000_000])
+def test_whole_frame_bit_exact_config1_and_1M(host, n_tris):
+    """Not a crop: the WHOLE 512 x 512 @ 64 spp frame of configs[1] and of the north-star's 1 M-triangle scene against the oracle's f64-libm mode — every pixel's bits, ray and path
+    counters (100.7 M / 114.2 M rays; 7 / 10 s of the oracle on 16 threads).  The larger configurations' whole frames were compared once the same way (configs[2], configs[3], and
+    configs[4] as its eight tile parts: profiles/r04_bit_exact_*.json, scripts/glibc_tolerance.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import glibc_tolerance as gt
+    r = gt.spec_case(host, dict(n_tris=n_tris, seed=1, xres=512, yres=512, spp=64, max_depth=5), (0.0, 1.0, 0.0, 1.0), libm_mode=1)
+    assert r["pixels"] == 512 * 512 and r["differing_pixels"] == 0 and r["counters_equal"] and r["rays_device"] == r["rays_oracle"] > 100_000_000, r
