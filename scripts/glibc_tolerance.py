@@ -38,13 +38,13 @@ def report(prod, g, o):
             "max_abs_diff_over_mean": float(d.max() / mean), "rays_device": gr, "rays_oracle": orr, "ray_count_rel_diff": abs(gr - orr) / max(orr, 1)}
 
 
-def spec_case(host, cfg, crop, material="matte", libm_mode=0):
+def spec_case(host, cfg, crop, material="matte", libm_mode=0, instances=0):
     spec = pbrt_hip.SceneSpec(**cfg, crop_window=crop, material=material)
     prod = pbrt_hip.Scene()
-    geom = pbrt_hip.capture_spec(spec, prod, host, device_build=True)
+    geom = pbrt_hip.capture_spec(spec, prod, host, device_build=True, instances=instances)
     g = prod.render_path(max_depth=cfg["max_depth"])
     orc = OracleScene()
-    pbrt_hip.capture_spec(spec, orc, host, geometry=geom)
+    pbrt_hip.capture_spec(spec, orc, host, geometry=geom, instances=instances)
     set_libm_mode(libm_mode)   # 0 = glibc's f32 routines (what a Rust build links); 1 = f64 rounded once (what the device computes: the film must then be bit-identical)
     t0 = time.time()
     try:
@@ -109,6 +109,9 @@ def main():
         if name in cases:   # whole frames of the other flat workloads against the f64-libm oracle (one-off records)
             out[f"{name}: {cfg['n_tris']} triangles, {cfg['xres']}x{cfg['yres']} @ {cfg['spp']} spp, f64-libm oracle"] = spec_case(host, cfg, (0.0, 1.0, 0.0, 1.0), libm_mode=1)
             print(json.dumps(out), flush=True)
+    if "instfull_exact" in cases:   # the instanced bench workload: ONE 10 k-triangle object placed 1 000 times, 2048^2 @ 64 spp, whole frame against the f64-libm oracle
+        out["1000 x 10k instances, 2048x2048 @ 64 spp, f64-libm oracle"] = spec_case(host, dict(n_tris=10_000, seed=1, xres=2048, yres=2048, spp=64, max_depth=5), (0.0, 1.0, 0.0, 1.0), libm_mode=1, instances=1000)
+        print(json.dumps(out), flush=True)
     if "c3" in cases:   # configs[3]: 10 M triangles, 2048^2 @ 64 spp: a 98 x 98 crop
         out["configs[3] crop 98x98 @ 64 spp"] = spec_case(host, dict(n_tris=10_000_000, seed=1, xres=2048, yres=2048, spp=64, max_depth=5), (0.47, 0.518, 0.40, 0.448))
         print(json.dumps(out), flush=True)
